@@ -101,6 +101,8 @@ class FakeClient:
 
     def createVisualShape(self, *a, **k):
         self.n_shapes += 1
+        if 'fileName' in k:
+            k = dict(k, fileName='<envs>/' + '/'.join(k['fileName'].split('/')[-2:]))
         return self._rec('createVisualShape', a, k, self.n_shapes - 1)
 
     def createMultiBody(self, *a, **k):
