@@ -1,0 +1,279 @@
+"""ctypes wrapper over the CPU oracle (oracle/librp_oracle*.so).  TEST INFRASTRUCTURE ONLY.
+
+Allowed importers: tests/, __graft_entry__.smoke(), bench.py's cpu_baseline leg.  The product package
+(roboticsplayroompybullet_amd) never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+KINDS = {'U': 0, 'R': 1, 'P': 2, 'UR5PlayAbsRPY1Obj-v0': 0, 'UR5Reach-v0': 1, 'pandaPick-v0': 2}
+
+
+class RpoObs(C.Structure):
+    _fields_ = [('obs_quat', C.c_double * 19), ('achieved_goal', C.c_double * 11), ('desired_goal', C.c_double * 11),
+                ('controllable_achieved_goal', C.c_double * 4), ('full_positional_state', C.c_double * 19),
+                ('joints', C.c_double * 8), ('velocity', C.c_double * 6), ('observation', C.c_double * 18),
+                ('gripper_proprioception', C.c_int), ('n_obs', C.c_int), ('n_ag', C.c_int), ('n_fps', C.c_int),
+                ('n_observation', C.c_int)]
+
+    def to_dict(self, n_goal):
+        return {
+            'obs_quat': np.array(self.obs_quat[:self.n_obs]),
+            'achieved_goal': np.array(self.achieved_goal[:self.n_ag]),
+            'desired_goal': np.array(self.desired_goal[:n_goal]),
+            'controllable_achieved_goal': np.array(self.controllable_achieved_goal[:4]),
+            'full_positional_state': np.array(self.full_positional_state[:self.n_fps]),
+            'joints': list(self.joints[:8]),
+            'velocity': np.array(self.velocity[:6]),
+            'img': None,
+            'observation': np.array(self.observation[:self.n_observation]),
+            'gripper_proprioception': int(self.gripper_proprioception),
+        }
+
+
+class RpoReadings(C.Structure):
+    _fields_ = [('ee_pos', C.c_double * 3), ('ee_orn', C.c_double * 4), ('ee_lin', C.c_double * 3), ('ee_ang', C.c_double * 3),
+                ('grip_q', C.c_double), ('joints', C.c_double * 8), ('proprio', C.c_int),
+                ('block_pos', C.c_double * 3), ('block_orn', C.c_double * 4), ('block_vel', C.c_double * 3),
+                ('drawer_y', C.c_double), ('door_q', C.c_double), ('button_q', C.c_double), ('dial_q', C.c_double)]
+
+
+_LIBS = {}
+
+
+def build():
+    subprocess.run(['make', '-C', HERE, '-s'], check=True)
+
+
+def load(f32=False):
+    name = 'librp_oracle_f32.so' if f32 else 'librp_oracle.so'
+    if name in _LIBS:
+        return _LIBS[name]
+    path = os.path.join(HERE, name)
+    if not os.path.exists(path):
+        build()
+    lib = C.CDLL(path)
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+    vp = C.c_void_p
+    lib.rpo_create.restype = vp
+    lib.rpo_create.argtypes = [C.c_int, C.c_ulonglong, C.c_int]
+    lib.rpo_destroy.argtypes = [vp]
+    lib.rpo_nv.argtypes = [vp]
+    lib.rpo_n_arm.argtypes = [vp]
+    lib.rpo_reset.argtypes = [vp, dp, C.c_int, C.POINTER(RpoObs)]
+    lib.rpo_reset.restype = C.c_int
+    lib.rpo_reset_goal.argtypes = [vp, dp, dp, C.c_int]
+    lib.rpo_reset_samples.argtypes = [vp, dp, dp, dp]
+    lib.rpo_step.argtypes = [vp, dp, C.POINTER(RpoObs), dp, ip, dp]
+    lib.rpo_calc_state.argtypes = [vp, C.POINTER(RpoObs)]
+    lib.rpo_compute_reward.argtypes = [vp, dp, dp]
+    lib.rpo_compute_reward.restype = C.c_double
+    lib.rpo_read_world.argtypes = [vp, C.POINTER(RpoReadings)]
+    lib.rpo_assemble_obs.argtypes = [vp, C.POINTER(RpoReadings), C.POINTER(RpoObs)]
+    lib.rpo_quat_from_euler.argtypes = [dp, dp]
+    lib.rpo_euler_from_quat.argtypes = [dp, dp]
+    lib.rpo_dial_to_0_1_range.argtypes = [C.c_double]
+    lib.rpo_dial_to_0_1_range.restype = C.c_double
+    lib.rpo_perform_action.argtypes = [vp, dp, dp]
+    lib.rpo_goto_joint_poses.argtypes = [vp, dp, C.c_int, C.c_double, dp]
+    lib.rpo_ik.argtypes = [vp, dp, dp, dp, C.c_int, dp]
+    lib.rpo_calc_angles.argtypes = [vp, dp, dp, dp, dp]
+    lib.rpo_substep.argtypes = [vp]
+    lib.rpo_run_simulation.argtypes = [vp]
+    lib.rpo_state_size.argtypes = [vp]
+    lib.rpo_get_state.argtypes = [vp, dp]
+    lib.rpo_set_state.argtypes = [vp, dp]
+    lib.rpo_get_motor.argtypes = [vp, ip, dp, dp]
+    lib.rpo_set_goal.argtypes = [vp, dp]
+    lib.rpo_clear_quat_memory.argtypes = [vp]
+    lib.rpo_site_pose.argtypes = [vp, C.c_int, dp, dp, dp, dp]
+    lib.rpo_mass_matrix_inv.argtypes = [vp, dp]
+    lib.rpo_forward_dynamics.argtypes = [vp, dp]
+    lib.rpo_contacts.argtypes = [vp, dp, C.c_int]
+    lib.rpo_last_num_rows.argtypes = [vp]
+    lib.rpo_box_box.argtypes = [dp, dp, dp, dp, dp, dp, C.c_double, dp]
+    lib.rpo_rng_uniform.argtypes = [C.c_ulonglong, C.c_uint, C.c_uint]
+    lib.rpo_rng_uniform.restype = C.c_double
+    _LIBS[name] = lib
+    return lib
+
+
+def _d(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class OracleEnv:
+    """One reference env (instance + playEnv) on the CPU oracle."""
+
+    def __init__(self, kind, seed=0, env_index=0, f32=False):
+        self.lib = load(f32)
+        self.kind = KINDS[kind]
+        self.h = self.lib.rpo_create(self.kind, seed, env_index)
+        self.n_arm = self.lib.rpo_n_arm(self.h)
+        self.nv = self.lib.rpo_nv(self.h)
+        self.n_goal = 11 if self.kind == 0 else 3
+        self.n_target = 7 if self.kind == 2 else 6
+
+    def __del__(self):
+        if getattr(self, 'h', None):
+            self.lib.rpo_destroy(self.h)
+            self.h = None
+
+    def reset(self, u=None):
+        o = RpoObs()
+        if u is None:
+            used = self.lib.rpo_reset(self.h, None, 0, C.byref(o))
+        else:
+            ua, up = _d(u)
+            used = self.lib.rpo_reset(self.h, up, len(ua), C.byref(o))
+        self.last_used = used
+        return o.to_dict(self.n_goal)
+
+    def reset_samples(self, u):
+        b, t = np.zeros(6), np.zeros(3)
+        dp = C.POINTER(C.c_double)
+        self.lib.rpo_reset_samples(self.h, _d(u)[1], b.ctypes.data_as(dp), t.ctypes.data_as(dp))
+        return b, t
+
+    def reset_goal_pos(self, goal=None, u=None):
+        gp = _d(goal)[1] if goal is not None else None
+        if u is None:
+            self.lib.rpo_reset_goal(self.h, gp, None, 0)
+        else:
+            ua, up = _d(u)
+            self.lib.rpo_reset_goal(self.h, gp, up, len(ua))
+
+    def step(self, action):
+        a, ap = _d(action)
+        o = RpoObs()
+        r = C.c_double()
+        s = C.c_int()
+        tp = np.zeros(7)
+        self.lib.rpo_step(self.h, ap, C.byref(o), C.byref(r), C.byref(s), tp.ctypes.data_as(C.POINTER(C.c_double)))
+        return o.to_dict(self.n_goal), r.value, False, {'is_success': s.value, 'target_poses': tp[:self.n_target].copy()}
+
+    def calc_state(self):
+        o = RpoObs()
+        self.lib.rpo_calc_state(self.h, C.byref(o))
+        return o.to_dict(self.n_goal)
+
+    def assemble_obs(self, **kw):
+        rd = RpoReadings()
+        for k, v in kw.items():
+            if isinstance(v, (list, tuple, np.ndarray)):
+                for i, x in enumerate(v):
+                    getattr(rd, k)[i] = float(x)
+            else:
+                setattr(rd, k, v)
+        o = RpoObs()
+        self.lib.rpo_assemble_obs(self.h, C.byref(rd), C.byref(o))
+        return o.to_dict(self.n_goal)
+
+    def compute_reward(self, ag, dg):
+        return self.lib.rpo_compute_reward(self.h, _d(ag)[1], _d(dg)[1])
+
+    def perform_action(self, action):
+        tp = np.zeros(7)
+        self.lib.rpo_perform_action(self.h, _d(action)[1], tp.ctypes.data_as(C.POINTER(C.c_double)))
+        return tp[:self.n_target].copy()
+
+    def goto_joint_poses(self, poses, gripper=None):
+        tp = np.zeros(7)
+        self.lib.rpo_goto_joint_poses(self.h, _d(poses)[1], int(gripper is not None), float(gripper or 0.0),
+                                      tp.ctypes.data_as(C.POINTER(C.c_double)))
+        return tp[:self.n_target].copy()
+
+    def ik(self, pos, quat, q_seed, max_iter=20):
+        out = np.zeros(self.n_arm)
+        self.lib.rpo_ik(self.h, _d(pos)[1], _d(quat)[1], _d(q_seed)[1], max_iter, out.ctypes.data_as(C.POINTER(C.c_double)))
+        return out
+
+    def calc_angles(self, pos, quat, current):
+        out = np.zeros(6)
+        self.lib.rpo_calc_angles(self.h, _d(pos)[1], _d(quat)[1], _d(current)[1], out.ctypes.data_as(C.POINTER(C.c_double)))
+        return out
+
+    def substep(self, n=1):
+        for _ in range(n):
+            self.lib.rpo_substep(self.h)
+
+    def run_simulation(self):
+        self.lib.rpo_run_simulation(self.h)
+
+    def get_state(self):
+        s = np.zeros(self.lib.rpo_state_size(self.h))
+        self.lib.rpo_get_state(self.h, s.ctypes.data_as(C.POINTER(C.c_double)))
+        return s
+
+    def set_state(self, s):
+        self.lib.rpo_set_state(self.h, _d(s)[1])
+
+    def get_motor(self):
+        mode = np.zeros(self.n_arm, dtype=np.int32)
+        tgt = np.zeros(self.n_arm)
+        mx = np.zeros(self.n_arm)
+        self.lib.rpo_get_motor(self.h, mode.ctypes.data_as(C.POINTER(C.c_int)), tgt.ctypes.data_as(C.POINTER(C.c_double)),
+                               mx.ctypes.data_as(C.POINTER(C.c_double)))
+        return mode, tgt, mx
+
+    def set_goal(self, goal):
+        self.lib.rpo_set_goal(self.h, _d(goal)[1])
+
+    def clear_quat_memory(self):
+        self.lib.rpo_clear_quat_memory(self.h)
+
+    def site_pose(self, site=0):
+        p, q, l, a = np.zeros(3), np.zeros(4), np.zeros(3), np.zeros(3)
+        dp = C.POINTER(C.c_double)
+        self.lib.rpo_site_pose(self.h, site, p.ctypes.data_as(dp), q.ctypes.data_as(dp), l.ctypes.data_as(dp), a.ctypes.data_as(dp))
+        return p, q, l, a
+
+    def mass_matrix_inv(self):
+        M = np.zeros((self.n_arm, self.n_arm))
+        self.lib.rpo_mass_matrix_inv(self.h, M.ctypes.data_as(C.POINTER(C.c_double)))
+        return M
+
+    def forward_dynamics(self):
+        a = np.zeros(self.n_arm)
+        self.lib.rpo_forward_dynamics(self.h, a.ctypes.data_as(C.POINTER(C.c_double)))
+        return a
+
+    def contacts(self, max_n=96):
+        out = np.zeros((max_n, 9))
+        n = self.lib.rpo_contacts(self.h, out.ctypes.data_as(C.POINTER(C.c_double)), max_n)
+        return out[:min(n, max_n)]
+
+    def num_rows(self):
+        return self.lib.rpo_last_num_rows(self.h)
+
+
+def box_box(ca, Ra, ha, cb, Rb, hb, margin=0.02, f32=False):
+    out = np.zeros((4, 7))
+    n = load(f32).rpo_box_box(_d(ca)[1], _d(np.asarray(Ra).reshape(-1))[1], _d(ha)[1], _d(cb)[1],
+                              _d(np.asarray(Rb).reshape(-1))[1], _d(hb)[1], margin, out.ctypes.data_as(C.POINTER(C.c_double)))
+    return out[:n]
+
+
+def rng_uniform(seed, env, counter):
+    return load().rpo_rng_uniform(seed, env, counter)
+
+
+def quat_from_euler(rpy, f32=False):
+    q = np.zeros(4)
+    load(f32).rpo_quat_from_euler(_d(rpy)[1], q.ctypes.data_as(C.POINTER(C.c_double)))
+    return q
+
+
+def euler_from_quat(q, f32=False):
+    e = np.zeros(3)
+    load(f32).rpo_euler_from_quat(_d(q)[1], e.ctypes.data_as(C.POINTER(C.c_double)))
+    return e
+
+
+def dial_to_0_1_range(x):
+    return load().rpo_dial_to_0_1_range(float(x))

@@ -1,0 +1,1480 @@
+/* oracle/rp_oracle.c — CPU restatement of the reference hot path (TEST INFRASTRUCTURE ONLY; see rp_oracle.h).
+ *
+ * "PARITY UNPINNED" for physics (PyBullet absent).  What each block follows:
+ *   harness   environments.py:206-214 (step), 469-603 (toggles, runSimulation, resets), 720-894 (calc_state,
+ *             quaternion_safe_the_obs), 915-1073 (perform_action .. close_gripper); inverseKinematics.py:44-50;
+ *             playRewardFunc.py:16-77; scenes.py:342-343 (dial)
+ *   physics   Bullet's btMultiBodyDynamicsWorld step as recalled in SURVEY.md App. E: collide -> ABA ->
+ *             velocity += qdd*dt -> sequential-impulse PGS (motors, limits, gear, contacts, friction; 50 sweeps,
+ *             no early exit, environments.py:326) -> semi-implicit Euler.
+ * Scalar, single env, one thread, written for clarity: dense Jacobian rows over the whole velocity vector and
+ * Featherstone ABA in world-origin Pluecker coordinates with O(n) unit-impulse responses (Bullet's
+ * calcAccelerationDeltasMultiDof).  The HIP library uses a different formulation; tests compare the two. */
+#include "rp_oracle.h"
+
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "rp_math.h"
+#include "../roboticsplayroompybullet_amd/csrc/generated/rp_models_gen.h"
+
+/* ------------------------------------------------------------------ solver constants (hypotheses) */
+#define DT ((real)(1.0 / 300.0))        /* environments.py:68-69,233 */
+#define GRAVITY ((real)-9.8)            /* environments.py:234 */
+#define N_SUBSTEPS 12                   /* environments.py:489 */
+#define N_SETTLE 100                    /* environments.py:534 */
+#define N_ITER 50                       /* PyBullet numSolverIterations default; never early-exits (environments.py:326) */
+#define ERP_CONTACT ((real)0.08)        /* PhysicsServerCommandProcessor erp2 (recalled) */
+#define LINEAR_SLOP ((real)1e-5)
+#define CONTACT_MARGIN ((real)0.005)    /* speculative contact distance (Bullet keeps points out to its 0.02 breaking threshold) */
+#define MOTOR_KP ((real)0.1)
+#define MOTOR_KD ((real)1.0)
+#define DEFAULT_MOTOR_MAXIMP ((real)1.0) /* createJointMotors: velocity motor, target 0, max impulse 1 */
+#define LIMIT_MAXIMP ((real)100.0)
+#define LIMIT_ACTIVATION ((real)0.1)
+#define FREE_LIN_DAMP ((real)0.04)
+#define FREE_ANG_DAMP ((real)0.04)
+#define J1_ANG_DAMP ((real)0.04)        /* changeDynamics(linearDamping=0) leaves angular at the 0.04 default */
+#define IK_DAMP ((real)0.1)
+#define IK_RESIDUAL ((real)1e-4)
+#define IK_MAX_STEP ((real)(45.0 * 3.14159265358979323846 / 180.0))
+#define MAX_CONTACTS 96
+#define MAX_ROWS (RP_MAX_ARM * 3 + RP_MAX_J1 + 2 + 3 * MAX_CONTACTS)
+#define NB_MAX (1 + RP_MAX_ARM + RP_MAX_FREE + RP_MAX_J1)
+
+typedef struct { real R[9], p[3]; } xform;
+
+typedef struct {
+  int ca, cb;          /* collider indices; normal points from b toward a */
+  real p[3], n[3], dist, mu;
+} contact;
+
+typedef struct {
+  real J[RP_MAX_NV], B[RP_MAX_NV];
+  real rhs, lo, hi, dinv, lambda;
+  int fric_parent;     /* >=0: friction row, limits = -+mu*lambda[parent] */
+  real mu;
+} row;
+
+struct rpo_env {
+  rp_model m;
+  int nv, nbody;
+  uint64_t seed; uint32_t env_index, rng_counter;
+  /* state */
+  real q[RP_MAX_ARM], qd[RP_MAX_ARM];
+  real fpos[RP_MAX_FREE][3], fquat[RP_MAX_FREE][4], fvel[RP_MAX_FREE][3], fom[RP_MAX_FREE][3];
+  real jq[RP_MAX_J1], jqd[RP_MAX_J1];
+  int mmode[RP_MAX_ARM]; real mtarget[RP_MAX_ARM], mmaximp[RP_MAX_ARM];
+  real goal[11]; int n_goal;
+  real last_obs[19], last_ag[11]; int have_last;
+  /* config flags (envList.py) */
+  int play, use_orientation, return_velocity, num_objects;
+  real goal_lo[3], goal_hi[3], obj_lo[3], obj_hi[3], env_hi[3];
+  /* work */
+  xform xb[NB_MAX];                 /* world transform of every body frame */
+  real S[RP_MAX_ARM][6];            /* joint motion subspace, world-origin Pluecker [ang; lin] */
+  real vsp[RP_MAX_ARM][6];          /* spatial velocity of arm bodies */
+  real IA[RP_MAX_ARM][36], U[RP_MAX_ARM][6], D[RP_MAX_ARM];
+  real finv[RP_MAX_FREE][9];        /* world inverse inertia of free bodies */
+  xform xc[RP_MAX_COL]; real aabb_lo[RP_MAX_COL][3], aabb_hi[RP_MAX_COL][3];
+  contact con[MAX_CONTACTS]; int ncon;
+  row rows[MAX_ROWS]; int nrows;
+};
+
+/* ------------------------------------------------------------------ counter RNG (shared definition with the HIP library) */
+static inline uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ULL;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+  return x ^ (x >> 31);
+}
+double rpo_rng_uniform(unsigned long long seed, unsigned env_index, unsigned counter) {
+  uint64_t h = splitmix64(seed ^ splitmix64(((uint64_t)env_index << 32) | counter));
+  return (double)(h >> 40) * (1.0 / 16777216.0);
+}
+typedef struct { rpo_env* e; const double* u; int n, used; } ustream;
+static real next_u(ustream* s) {
+  if (s->u) { double v = s->used < s->n ? s->u[s->used] : 0.5; s->used++; return (real)v; }
+  s->used++;
+  return (real)rpo_rng_uniform(s->e->seed, s->e->env_index, s->e->rng_counter++);
+}
+
+/* ------------------------------------------------------------------ body bookkeeping */
+static inline int body_is_arm(const rpo_env* e, int b) { return b >= 1 && b <= e->m.n_arm; }
+static inline int body_free_index(const rpo_env* e, int b) { int k = b - 1 - e->m.n_arm; return (k >= 0 && k < e->m.n_free) ? k : -1; }
+static inline int body_j1_index(const rpo_env* e, int b) { int k = b - 1 - e->m.n_arm - e->m.n_free; return (k >= 0 && k < e->m.n_joint1) ? k : -1; }
+static inline int dof_free(const rpo_env* e, int k) { return e->m.n_arm + 6 * k; }
+static inline int dof_j1(const rpo_env* e, int k) { return e->m.n_arm + 6 * e->m.n_free + k; }
+static int dof_of_bullet_joint(const rpo_env* e, int j) {
+  for (int i = 0; i < e->m.n_arm; i++) if (e->m.arm_bullet_index[i] == j) return i;
+  return -1;
+}
+
+/* ------------------------------------------------------------------ forward kinematics */
+static void arm_fk(const rpo_env* e, const real* q, xform* xb /* index 1..n_arm, [0] = base */) {
+  const rp_model* m = &e->m;
+  for (int k = 0; k < 9; k++) xb[0].R[k] = (real)m->base_rot[k];
+  for (int k = 0; k < 3; k++) xb[0].p[k] = (real)m->base_pos[k];
+  for (int i = 0; i < m->n_arm; i++) {
+    const xform* P = &xb[1 + m->arm_parent[i]];       /* parent -1 -> xb[0] */
+    real jr[9], jp[3], ax[3], Rq[9], t[3], Rj[9];
+    for (int k = 0; k < 9; k++) jr[k] = (real)m->arm_jrot[i][k];
+    for (int k = 0; k < 3; k++) { jp[k] = (real)m->arm_jpos[i][k]; ax[k] = (real)m->arm_axis[i][k]; }
+    m3mul(Rj, P->R, jr);
+    m3mulv(t, P->R, jp);
+    v3add(xb[1 + i].p, P->p, t);
+    if (m->arm_jtype[i] == 0) {
+      m3axis_angle(Rq, ax, q[i]);
+      m3mul(xb[1 + i].R, Rj, Rq);
+    } else {
+      memcpy(xb[1 + i].R, Rj, sizeof(Rj));
+      m3mulv(t, Rj, ax);
+      v3axpy(xb[1 + i].p, q[i], t);
+    }
+  }
+}
+
+static void update_transforms(rpo_env* e) {
+  const rp_model* m = &e->m;
+  m3ident(e->xb[0].R); v3set(e->xb[0].p, 0, 0, 0);
+  xform tmp[1 + RP_MAX_ARM];
+  arm_fk(e, e->q, tmp);
+  for (int i = 0; i < m->n_arm; i++) e->xb[1 + i] = tmp[1 + i];
+  /* joint subspaces, world-origin Pluecker coordinates */
+  for (int i = 0; i < m->n_arm; i++) {
+    real ax[3], a[3];
+    for (int k = 0; k < 3; k++) ax[k] = (real)m->arm_axis[i][k];
+    m3mulv(a, e->xb[1 + i].R, ax);
+    if (m->arm_jtype[i] == 0) {
+      real oxa[3];
+      v3cross(oxa, e->xb[1 + i].p, a);
+      v3cpy(e->S[i], a); v3cpy(e->S[i] + 3, oxa);
+    } else {
+      v3set(e->S[i], 0, 0, 0); v3cpy(e->S[i] + 3, a);
+    }
+  }
+  for (int k = 0; k < m->n_free; k++) {
+    xform* x = &e->xb[1 + m->n_arm + k];
+    quat_to_m3(x->R, e->fquat[k]);
+    v3cpy(x->p, e->fpos[k]);
+  }
+  for (int k = 0; k < m->n_joint1; k++) {
+    xform* x = &e->xb[1 + m->n_arm + m->n_free + k];
+    real R0[9], ax[3], t[3];
+    for (int i = 0; i < 9; i++) R0[i] = (real)m->j1_rot[k][i];
+    for (int i = 0; i < 3; i++) { ax[i] = (real)m->j1_axis[k][i]; x->p[i] = (real)m->j1_pos[k][i]; }
+    if (m->j1_type[k] == 0) {
+      real Rq[9];
+      m3axis_angle(Rq, ax, e->jq[k]);
+      m3mul(x->R, R0, Rq);
+    } else {
+      memcpy(x->R, R0, sizeof(R0));
+      m3mulv(t, R0, ax);
+      v3axpy(x->p, e->jq[k], t);
+    }
+  }
+  /* colliders */
+  for (int c = 0; c < m->n_col; c++) {
+    const xform* xb = &e->xb[m->col_body[c]];
+    real Rc[9], pc[3], t[3];
+    for (int i = 0; i < 9; i++) Rc[i] = (real)m->col_rot[c][i];
+    for (int i = 0; i < 3; i++) pc[i] = (real)m->col_pos[c][i];
+    m3mul(e->xc[c].R, xb->R, Rc);
+    m3mulv(t, xb->R, pc);
+    v3add(e->xc[c].p, xb->p, t);
+    for (int i = 0; i < 3; i++) {
+      real ext;
+      if (m->col_type[c] == 0)
+        ext = R_FABS(e->xc[c].R[3 * i]) * (real)m->col_he[c][0] + R_FABS(e->xc[c].R[3 * i + 1]) * (real)m->col_he[c][1] +
+              R_FABS(e->xc[c].R[3 * i + 2]) * (real)m->col_he[c][2];
+      else
+        ext = (real)m->col_he[c][0];
+      e->aabb_lo[c][i] = e->xc[c].p[i] - ext;
+      e->aabb_hi[c][i] = e->xc[c].p[i] + ext;
+    }
+  }
+}
+
+/* ------------------------------------------------------------------ narrowphase */
+typedef struct { real p[3], n[3], dist; } cpoint;
+
+static inline void col_axis(real* o, const real* R, int i) { o[0] = R[i]; o[1] = R[3 + i]; o[2] = R[6 + i]; }
+
+static int clip_poly(const real (*in)[3], int n, const real* c, const real* u, real h, real sign, real (*out)[3]) {
+  /* keep points with sign*((p-c).u) <= h */
+  int m = 0;
+  for (int i = 0; i < n; i++) {
+    const real* a = in[i];
+    const real* b = in[(i + 1) % n];
+    real da = sign * ((a[0] - c[0]) * u[0] + (a[1] - c[1]) * u[1] + (a[2] - c[2]) * u[2]) - h;
+    real db = sign * ((b[0] - c[0]) * u[0] + (b[1] - c[1]) * u[1] + (b[2] - c[2]) * u[2]) - h;
+    if (da <= 0) { v3cpy(out[m], a); m++; }
+    if ((da < 0 && db > 0) || (da > 0 && db < 0)) {
+      real t = da / (da - db);
+      for (int k = 0; k < 3; k++) out[m][k] = a[k] + t * (b[k] - a[k]);
+      m++;
+    }
+  }
+  return m;
+}
+
+/* Box-box contact generation: 15-axis SAT with a 2 cm speculative margin, face clipping (Sutherland-Hodgman)
+ * or edge-edge closest points, at most 4 points.  Normal from B toward A; dist < 0 = penetration. */
+static int box_box(const real* ca, const real* Ra, const real* ha, const real* cb, const real* Rb, const real* hb, real margin,
+                   cpoint* out) {
+  real A[3][3], Bx[3][3], t[3];
+  for (int i = 0; i < 3; i++) { col_axis(A[i], Ra, i); col_axis(Bx[i], Rb, i); }
+  v3sub(t, ca, cb);
+  real best_s = (real)-1e30; int best_kind = -1, best_i = 0, best_j = 0; real best_L[3] = {0, 0, 0};
+  for (int f = 0; f < 6; f++) {
+    const real* L = f < 3 ? A[f] : Bx[f - 3];
+    real ra = 0, rb = 0;
+    for (int k = 0; k < 3; k++) { ra += ha[k] * R_FABS(v3dot(L, A[k])); rb += hb[k] * R_FABS(v3dot(L, Bx[k])); }
+    real s = R_FABS(v3dot(t, L)) - ra - rb;
+    if (s > margin) return 0;
+    if (s > best_s) { best_s = s; best_kind = f < 3 ? 0 : 1; best_i = f % 3; v3cpy(best_L, L); }
+  }
+  real edge_s = (real)-1e30; int ei = 0, ej = 0; real eL[3] = {0, 0, 0};
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      real L[3];
+      v3cross(L, A[i], Bx[j]);
+      real l = v3norm(L);
+      if (l < (real)1e-6) continue;
+      v3scale(L, L, 1 / l);
+      real ra = 0, rb = 0;
+      for (int k = 0; k < 3; k++) { ra += ha[k] * R_FABS(v3dot(L, A[k])); rb += hb[k] * R_FABS(v3dot(L, Bx[k])); }
+      real s = R_FABS(v3dot(t, L)) - ra - rb;
+      if (s > margin) return 0;
+      if (s > edge_s) { edge_s = s; ei = i; ej = j; v3cpy(eL, L); }
+    }
+  if (edge_s > best_s + (real)0.05 * R_FABS(best_s) + (real)1e-6) {
+    /* edge-edge */
+    real n[3]; v3cpy(n, eL);
+    if (v3dot(n, t) < 0) v3scale(n, n, -1);
+    real pa[3], pb[3];
+    v3cpy(pa, ca); v3cpy(pb, cb);
+    for (int k = 0; k < 3; k++) {
+      if (k != ei) v3axpy(pa, (v3dot(n, A[k]) > 0 ? -ha[k] : ha[k]), A[k]);
+      if (k != ej) v3axpy(pb, (v3dot(n, Bx[k]) > 0 ? hb[k] : -hb[k]), Bx[k]);
+    }
+    /* closest points of lines pa + s*A[ei], pb + u*B[ej] */
+    real d[3]; v3sub(d, pb, pa);
+    real ab = v3dot(A[ei], Bx[ej]), q1 = v3dot(A[ei], d), q2 = -v3dot(Bx[ej], d);
+    real den = 1 - ab * ab;
+    real sa = 0, sb = 0;
+    if (den > (real)1e-9) { sa = (q1 + ab * q2) / den; sb = (ab * q1 + q2) / den; }
+    real xa[3], xbp[3];
+    v3cpy(xa, pa); v3axpy(xa, sa, A[ei]);
+    v3cpy(xbp, pb); v3axpy(xbp, sb, Bx[ej]);
+    real dd[3]; v3sub(dd, xa, xbp);
+    out[0].dist = v3dot(dd, n);
+    for (int k = 0; k < 3; k++) { out[0].p[k] = (real)0.5 * (xa[k] + xbp[k]); out[0].n[k] = n[k]; }
+    (void)best_j;
+    return out[0].dist <= margin ? 1 : 0;
+  }
+  /* face contact: reference box X owns axis best_i */
+  const real *cX, *hX, *cY, *hY; real(*X)[3]; real(*Y)[3];
+  if (best_kind == 0) { cX = ca; hX = ha; X = A; cY = cb; hY = hb; Y = Bx; }
+  else { cX = cb; hX = hb; X = Bx; cY = ca; hY = ha; Y = A; }
+  real nref[3], d[3];
+  v3sub(d, cY, cX);
+  v3cpy(nref, best_L);
+  if (v3dot(nref, d) < 0) v3scale(nref, nref, -1);
+  /* incident face of Y: most anti-parallel to nref */
+  int j = 0; real bj = -1;
+  for (int k = 0; k < 3; k++) { real v = R_FABS(v3dot(nref, Y[k])); if (v > bj) { bj = v; j = k; } }
+  real sj = v3dot(nref, Y[j]) > 0 ? (real)-1 : (real)1;
+  int k1 = (j + 1) % 3, k2 = (j + 2) % 3;
+  real fc[3]; v3cpy(fc, cY); v3axpy(fc, sj * hY[j], Y[j]);
+  real poly[2][16][3];
+  static const real sg[4][2] = {{1, 1}, {-1, 1}, {-1, -1}, {1, -1}};
+  for (int v = 0; v < 4; v++) {
+    v3cpy(poly[0][v], fc);
+    v3axpy(poly[0][v], sg[v][0] * hY[k1], Y[k1]);
+    v3axpy(poly[0][v], sg[v][1] * hY[k2], Y[k2]);
+  }
+  int u1 = (best_i + 1) % 3, u2 = (best_i + 2) % 3, n = 4;
+  n = clip_poly(poly[0], n, cX, X[u1], hX[u1], 1, poly[1]);
+  n = clip_poly(poly[1], n, cX, X[u1], hX[u1], -1, poly[0]);
+  n = clip_poly(poly[0], n, cX, X[u2], hX[u2], 1, poly[1]);
+  n = clip_poly(poly[1], n, cX, X[u2], hX[u2], -1, poly[0]);
+  cpoint tmp[16]; int cnt = 0, deepest = 0;
+  for (int v = 0; v < n; v++) {
+    real r[3]; v3sub(r, poly[0][v], cX);
+    real dist = v3dot(r, nref) - hX[best_i];
+    if (dist > margin) continue;
+    for (int k = 0; k < 3; k++) {
+      tmp[cnt].p[k] = poly[0][v][k] - (real)0.5 * dist * nref[k];
+      tmp[cnt].n[k] = best_kind == 1 ? nref[k] : -nref[k];     /* from B toward A */
+    }
+    tmp[cnt].dist = dist;
+    if (dist < tmp[deepest].dist) deepest = cnt;
+    cnt++;
+  }
+  if (cnt <= 4) { for (int v = 0; v < cnt; v++) out[v] = tmp[v]; return cnt; }
+  for (int v = 0; v < 4; v++) out[v] = tmp[(deepest + (v * cnt) / 4) % cnt];
+  return 4;
+}
+
+/* sphere (center cs, radius r) vs box; normal from the sphere toward the box when sphere_is_b */
+static int sphere_box(const real* cs, real r, const real* cb, const real* Rb, const real* hb, real margin, int sphere_is_b, cpoint* out) {
+  real d[3], l[3], cl[3];
+  v3sub(d, cs, cb);
+  m3tmulv(l, Rb, d);
+  int inside = 1;
+  for (int k = 0; k < 3; k++) {
+    cl[k] = l[k];
+    if (cl[k] > hb[k]) { cl[k] = hb[k]; inside = 0; }
+    if (cl[k] < -hb[k]) { cl[k] = -hb[k]; inside = 0; }
+  }
+  real nl[3], dist;
+  if (!inside) {
+    real df[3]; v3sub(df, cl, l);
+    real len = v3norm(df);
+    dist = len - r;
+    if (dist > margin) return 0;
+    v3scale(nl, df, 1 / len);            /* from sphere centre toward the box surface point */
+  } else {
+    int k0 = 0; real best = (real)1e30;
+    for (int k = 0; k < 3; k++) { real pen = hb[k] - R_FABS(l[k]); if (pen < best) { best = pen; k0 = k; } }
+    v3set(nl, 0, 0, 0);
+    nl[k0] = l[k0] > 0 ? (real)-1 : (real)1;
+    cl[k0] = l[k0] > 0 ? hb[k0] : -hb[k0];
+    dist = -best - r;
+  }
+  real nw[3], pw[3];
+  m3mulv(nw, Rb, nl);
+  m3mulv(pw, Rb, cl);
+  v3add(pw, pw, cb);
+  for (int k = 0; k < 3; k++) {
+    out[0].p[k] = pw[k] - (real)0.5 * dist * nw[k];
+    out[0].n[k] = sphere_is_b ? nw[k] : -nw[k];
+  }
+  out[0].dist = dist;
+  return 1;
+}
+
+/* btPersistentManifold::sortCachedPoints: which of the 4 cached points a 5th one replaces (keep the deepest,
+ * maximise the area spanned by the rest).  Positions compared in world space (Bullet uses local-A). */
+static int manifold_replace_index(const contact* c4, const contact* pt) {
+  int deepest = -1; real maxpen = pt->dist;
+  for (int i = 0; i < 4; i++) if (c4[i].dist < maxpen) { deepest = i; maxpen = c4[i].dist; }
+  real res[4] = {0, 0, 0, 0}, a[3], b[3], cr[3];
+  if (deepest != 0) { v3sub(a, pt->p, c4[1].p); v3sub(b, c4[3].p, c4[2].p); v3cross(cr, a, b); res[0] = v3dot(cr, cr); }
+  if (deepest != 1) { v3sub(a, pt->p, c4[0].p); v3sub(b, c4[3].p, c4[2].p); v3cross(cr, a, b); res[1] = v3dot(cr, cr); }
+  if (deepest != 2) { v3sub(a, pt->p, c4[0].p); v3sub(b, c4[3].p, c4[1].p); v3cross(cr, a, b); res[2] = v3dot(cr, cr); }
+  if (deepest != 3) { v3sub(a, pt->p, c4[0].p); v3sub(b, c4[2].p, c4[1].p); v3cross(cr, a, b); res[3] = v3dot(cr, cr); }
+  int best = 0;
+  for (int i = 1; i < 4; i++) if (res[i] > res[best]) best = i;
+  return best;
+}
+
+/* Candidate pairs are sorted so the collider pairs of one object pair are contiguous: one manifold of <= 4 points
+ * per object pair, as Bullet keeps per collision-object pair.  A rotation-locked free body (the drawer, H5) against
+ * the static world keeps only its deepest point: all its points share one Jacobian. */
+static void collide(rpo_env* e) {
+  const rp_model* m = &e->m;
+  e->ncon = 0;
+  int man_start = 0, man_oa = -1, man_ob = -1;
+  for (int pi = 0; pi < m->n_pair; pi++) {
+    int a = m->pair[pi][0], b = m->pair[pi][1];
+    if (m->col_obj[a] != man_oa || m->col_obj[b] != man_ob) { man_start = e->ncon; man_oa = m->col_obj[a]; man_ob = m->col_obj[b]; }
+    int sep = 0;
+    for (int k = 0; k < 3; k++)
+      if (e->aabb_lo[a][k] > e->aabb_hi[b][k] + CONTACT_MARGIN || e->aabb_lo[b][k] > e->aabb_hi[a][k] + CONTACT_MARGIN) sep = 1;
+    if (sep) continue;
+    cpoint pts[4]; int np = 0;
+    real ha[3], hb[3];
+    for (int k = 0; k < 3; k++) { ha[k] = (real)m->col_he[a][k]; hb[k] = (real)m->col_he[b][k]; }
+    if (m->col_type[a] == 0 && m->col_type[b] == 0)
+      np = box_box(e->xc[a].p, e->xc[a].R, ha, e->xc[b].p, e->xc[b].R, hb, CONTACT_MARGIN, pts);
+    else if (m->col_type[a] == 0 && m->col_type[b] == 1)
+      np = sphere_box(e->xc[b].p, hb[0], e->xc[a].p, e->xc[a].R, ha, CONTACT_MARGIN, 1, pts);
+    else if (m->col_type[a] == 1 && m->col_type[b] == 0)
+      np = sphere_box(e->xc[a].p, ha[0], e->xc[b].p, e->xc[b].R, hb, CONTACT_MARGIN, 0, pts);
+    int kf = body_free_index(e, m->col_body[a]);
+    int single = (kf >= 0 && m->free_rot_locked[kf] && m->col_body[b] == 0);
+    for (int i = 0; i < np; i++) {
+      contact c;
+      c.ca = a; c.cb = b;
+      v3cpy(c.p, pts[i].p); v3cpy(c.n, pts[i].n);
+      c.dist = pts[i].dist;
+      c.mu = (real)(m->col_friction[a] * m->col_friction[b]);
+      int have = e->ncon - man_start;
+      if (single) {
+        if (have == 0) e->con[e->ncon++] = c;
+        else if (c.dist < e->con[man_start].dist) e->con[man_start] = c;
+      } else if (have < 4) {
+        if (e->ncon < MAX_CONTACTS) e->con[e->ncon++] = c;
+      } else {
+        e->con[man_start + manifold_replace_index(&e->con[man_start], &c)] = c;
+      }
+    }
+  }
+}
+
+/* ------------------------------------------------------------------ spatial algebra (world-origin Pluecker, [ang; lin]) */
+static void crm(real* o, const real* v, const real* m_) {   /* v x m */
+  real a[3], b[3], c[3];
+  v3cross(a, v, m_);
+  v3cross(b, v, m_ + 3);
+  v3cross(c, v + 3, m_);
+  v3cpy(o, a); v3add(o + 3, b, c);
+}
+static void crf(real* o, const real* v, const real* f) {   /* v x* f */
+  real a[3], b[3], c[3];
+  v3cross(a, v, f);
+  v3cross(b, v + 3, f + 3);
+  v3cross(c, v, f + 3);
+  v3add(o, a, b); v3cpy(o + 3, c);
+}
+static void m6mulv(real* o, const real* M, const real* v) {
+  real t[6];
+  for (int i = 0; i < 6; i++) { real s = 0; for (int j = 0; j < 6; j++) s += M[6 * i + j] * v[j]; t[i] = s; }
+  for (int i = 0; i < 6; i++) o[i] = t[i];
+}
+static real dot6(const real* a, const real* b) { real s = 0; for (int i = 0; i < 6; i++) s += a[i] * b[i]; return s; }
+
+static void spatial_inertia(real* I6, real mass, const real* c /*world COM*/, const real* Ic /*world, about COM*/) {
+  real cx[9] = {0, -c[2], c[1], c[2], 0, -c[0], -c[1], c[0], 0};
+  real cxcx[9];
+  m3mul(cxcx, cx, cx);
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      I6[6 * i + j] = Ic[3 * i + j] - mass * cxcx[3 * i + j];
+      I6[6 * i + 3 + j] = mass * cx[3 * i + j];
+      I6[6 * (3 + i) + j] = -mass * cx[3 * i + j];
+      I6[6 * (3 + i) + 3 + j] = (i == j) ? mass : 0;
+    }
+}
+
+/* ABA passes 1+2: articulated inertias IA, U, D (cached) and, if qdd != NULL, the accelerations with gravity + bias. */
+static void arm_aba(rpo_env* e, real* qdd) {
+  const rp_model* m = &e->m;
+  int n = m->n_arm;
+  real c[RP_MAX_ARM][6], pA[RP_MAX_ARM][6];
+  for (int i = 0; i < n; i++) {
+    int p = m->arm_parent[i];
+    real vj[6];
+    for (int k = 0; k < 6; k++) vj[k] = e->S[i][k] * e->qd[i];
+    for (int k = 0; k < 6; k++) e->vsp[i][k] = (p >= 0 ? e->vsp[p][k] : 0) + vj[k];
+    crm(c[i], e->vsp[i], vj);
+    /* spatial inertia in world coordinates */
+    const xform* x = &e->xb[1 + i];
+    real com[3], cl[3], Il[9], Iw[9], tmp[9], Rt[9];
+    for (int k = 0; k < 3; k++) cl[k] = (real)m->arm_com[i][k];
+    for (int k = 0; k < 9; k++) Il[k] = (real)m->arm_inertia[i][k];
+    m3mulv(com, x->R, cl); v3add(com, com, x->p);
+    m3mul(tmp, x->R, Il);
+    for (int r = 0; r < 3; r++) for (int s = 0; s < 3; s++) Rt[3 * r + s] = x->R[3 * s + r];
+    m3mul(Iw, tmp, Rt);
+    spatial_inertia(e->IA[i], (real)m->arm_mass[i], com, Iw);
+    real Iv[6];
+    m6mulv(Iv, e->IA[i], e->vsp[i]);
+    crf(pA[i], e->vsp[i], Iv);
+  }
+  real u[RP_MAX_ARM];
+  for (int i = n - 1; i >= 0; i--) {
+    m6mulv(e->U[i], e->IA[i], e->S[i]);
+    e->D[i] = dot6(e->S[i], e->U[i]);
+    u[i] = -dot6(e->S[i], pA[i]);
+    int p = m->arm_parent[i];
+    if (p >= 0) {
+      real Ia[36], t6[6];
+      for (int r = 0; r < 6; r++) for (int s = 0; s < 6; s++) Ia[6 * r + s] = e->IA[i][6 * r + s] - e->U[i][r] * e->U[i][s] / e->D[i];
+      m6mulv(t6, Ia, c[i]);
+      for (int k = 0; k < 36; k++) e->IA[p][k] += Ia[k];
+      for (int k = 0; k < 6; k++) pA[p][k] += pA[i][k] + t6[k] + e->U[i][k] * u[i] / e->D[i];
+    }
+  }
+  if (!qdd) return;
+  real a[RP_MAX_ARM][6];
+  for (int i = 0; i < n; i++) {
+    int p = m->arm_parent[i];
+    real ap[6];
+    for (int k = 0; k < 6; k++) ap[k] = (p >= 0 ? a[p][k] : 0) + c[i][k];
+    if (p < 0) ap[5] += -GRAVITY;      /* fictitious base acceleration = -g */
+    qdd[i] = (u[i] - dot6(e->U[i], ap)) / e->D[i];
+    for (int k = 0; k < 6; k++) a[i][k] = ap[k] + e->S[i][k] * qdd[i];
+  }
+}
+
+/* Bullet calcAccelerationDeltasMultiDof: response of the arm's joint velocities to a spatial impulse f on body
+ * `body` (0-based arm index, -1 = none) plus joint-space impulses tau (may be NULL). */
+static void arm_impulse_response(const rpo_env* e, int body, const real* f, const real* tau, real* dqd) {
+  const rp_model* m = &e->m;
+  int n = m->n_arm;
+  real pA[RP_MAX_ARM][6], u[RP_MAX_ARM];
+  memset(pA, 0, sizeof(pA));
+  if (body >= 0) for (int k = 0; k < 6; k++) pA[body][k] = -f[k];
+  for (int i = n - 1; i >= 0; i--) {
+    u[i] = (tau ? tau[i] : 0) - dot6(e->S[i], pA[i]);
+    int p = m->arm_parent[i];
+    if (p >= 0) for (int k = 0; k < 6; k++) pA[p][k] += pA[i][k] + e->U[i][k] * u[i] / e->D[i];
+  }
+  real a[RP_MAX_ARM][6];
+  for (int i = 0; i < n; i++) {
+    int p = m->arm_parent[i];
+    real ap[6];
+    for (int k = 0; k < 6; k++) ap[k] = p >= 0 ? a[p][k] : 0;
+    dqd[i] = (u[i] - dot6(e->U[i], ap)) / e->D[i];
+    for (int k = 0; k < 6; k++) a[i][k] = ap[k] + e->S[i][k] * dqd[i];
+  }
+}
+
+/* ------------------------------------------------------------------ constraint rows */
+static void body_jacobian(const rpo_env* e, int body, const real* p, const real* n, real sign, real* J) {
+  /* adds sign * d(n . v_point)/dv for a point p fixed to `body` */
+  const rp_model* m = &e->m;
+  if (body == 0) return;
+  if (body_is_arm(e, body)) {
+    real f[6];
+    v3cross(f, p, n); v3cpy(f + 3, n);
+    for (int i = body - 1; i >= 0; i = m->arm_parent[i]) J[i] += sign * dot6(e->S[i], f);
+    return;
+  }
+  int k = body_free_index(e, body);
+  if (k >= 0) {
+    real r[3], rxn[3];
+    v3sub(r, p, e->fpos[k]);
+    v3cross(rxn, r, n);
+    int d = dof_free(e, k);
+    for (int i = 0; i < 3; i++) { J[d + i] += sign * n[i]; J[d + 3 + i] += sign * rxn[i]; }
+    return;
+  }
+  k = body_j1_index(e, body);
+  if (k >= 0) {
+    const xform* x = &e->xb[body];
+    real ax[3], a[3];
+    for (int i = 0; i < 3; i++) ax[i] = (real)m->j1_axis[k][i];
+    m3mulv(a, x->R, ax);
+    if (m->j1_type[k] == 1) J[dof_j1(e, k)] += sign * v3dot(n, a);
+    else {
+      real o[3], r[3], rxn[3];
+      for (int i = 0; i < 3; i++) o[i] = (real)m->j1_pos[k][i];
+      v3sub(r, p, o); v3cross(rxn, r, n);
+      J[dof_j1(e, k)] += sign * v3dot(a, rxn);
+    }
+  }
+}
+
+/* B = M^-1 J^T for a contact-like row acting at point p along n on bodyA (+) and bodyB (-) */
+static void contact_response(const rpo_env* e, int bodyA, int bodyB, const real* p, const real* n, const real* J, real* B) {
+  const rp_model* m = &e->m;
+  memset(B, 0, sizeof(real) * RP_MAX_NV);
+  for (int side = 0; side < 2; side++) {
+    int body = side == 0 ? bodyA : bodyB;
+    real sign = side == 0 ? (real)1 : (real)-1;
+    if (body == 0) continue;
+    if (body_is_arm(e, body)) {
+      real f[6], dqd[RP_MAX_ARM];
+      real sn[3]; v3scale(sn, n, sign);
+      v3cross(f, p, sn); v3cpy(f + 3, sn);
+      arm_impulse_response(e, body - 1, f, 0, dqd);
+      for (int i = 0; i < m->n_arm; i++) B[i] += dqd[i];
+      continue;
+    }
+    int k = body_free_index(e, body);
+    if (k >= 0) {
+      int d = dof_free(e, k);
+      real im = 1 / (real)m->free_mass[k], w[3];
+      for (int i = 0; i < 3; i++) B[d + i] = J[d + i] * im;
+      m3mulv(w, e->finv[k], J + d + 3);
+      for (int i = 0; i < 3; i++) B[d + 3 + i] = w[i];
+      continue;
+    }
+    k = body_j1_index(e, body);
+    if (k >= 0) {
+      int d = dof_j1(e, k);
+      real minv = m->j1_type[k] == 1 ? 1 / (real)m->j1_mass[k] : 1 / (real)m->j1_inertia_axis[k];
+      B[d] = J[d] * minv;
+    }
+  }
+}
+
+static real dotn(const real* a, const real* b, int n) { real s = 0; for (int i = 0; i < n; i++) s += a[i] * b[i]; return s; }
+/* Bullet fillMultiBodyConstraint: jacDiagABInv = d > eps ? 1/d : 0 (a row that cannot move anything is inert) */
+static real safe_inv(real d) { return d > (real)1e-9 ? 1 / d : 0; }
+
+static row* new_row(rpo_env* e) {
+  row* r = &e->rows[e->nrows++];
+  memset(r, 0, sizeof(*r));
+  r->fric_parent = -1;
+  return r;
+}
+
+static void plane_space(const real* n, real* p, real* q) {   /* btPlaneSpace1 */
+  if (R_FABS(n[2]) > (real)0.7071067811865475244008443621048490) {
+    real a = n[1] * n[1] + n[2] * n[2], k = 1 / R_SQRT(a);
+    p[0] = 0; p[1] = -n[2] * k; p[2] = n[1] * k;
+    q[0] = a * k; q[1] = -n[0] * p[2]; q[2] = n[0] * p[1];
+  } else {
+    real a = n[0] * n[0] + n[1] * n[1], k = 1 / R_SQRT(a);
+    p[0] = -n[1] * k; p[1] = n[0] * k; p[2] = 0;
+    q[0] = -n[2] * p[1]; q[1] = n[2] * p[0]; q[2] = a * k;
+  }
+}
+
+static void build_rows(rpo_env* e, const real* vstar) {
+  const rp_model* m = &e->m;
+  int nv = e->nv;
+  e->nrows = 0;
+  /* 1. arm joint motors (btMultiBodyJointMotor): velocity-level servo, impulse clamp */
+  for (int i = 0; i < m->n_arm; i++) {
+    row* r = new_row(e);
+    real tau[RP_MAX_ARM] = {0};
+    tau[i] = 1;
+    r->J[i] = 1;
+    arm_impulse_response(e, -1, 0, tau, r->B);
+    r->dinv = 1 / r->B[i];
+    real des = e->mmode[i] ? MOTOR_KP * (e->mtarget[i] - e->q[i]) / DT : 0;   /* kp*err/dt + qd + kd*(0-qd), kd = 1 */
+    r->rhs = (des - vstar[i]) * r->dinv;
+    r->lo = -e->mmaximp[i]; r->hi = e->mmaximp[i];
+  }
+  /* 2. scene joint motors: button position motor (scenes.py:238), default velocity motors on door and dial */
+  for (int k = 0; k < m->n_joint1; k++) {
+    row* r = new_row(e);
+    int d = dof_j1(e, k);
+    real minv = m->j1_type[k] == 1 ? 1 / (real)m->j1_mass[k] : 1 / (real)m->j1_inertia_axis[k];
+    r->J[d] = 1; r->B[d] = minv; r->dinv = 1 / minv;
+    real des = 0, maximp = DEFAULT_MOTOR_MAXIMP;
+    if (m->j1_has_pos_motor[k]) {
+      des = MOTOR_KP * ((real)m->j1_motor_target[k] - e->jq[k]) / DT;
+      maximp = (real)m->j1_motor_force[k] * DT;
+    }
+    r->rhs = (des - vstar[d]) * r->dinv;
+    r->lo = -maximp; r->hi = maximp;
+  }
+  /* 3. joint limits (btMultiBodyJointLimitConstraint): contact-like rows */
+  for (int i = 0; i < m->n_arm; i++) {
+    if (!(m->arm_lower[i] < m->arm_upper[i])) continue;
+    for (int side = 0; side < 2; side++) {
+      real pen = side == 0 ? e->q[i] - (real)m->arm_lower[i] : (real)m->arm_upper[i] - e->q[i];
+      if (pen > LIMIT_ACTIVATION) continue;
+      real sgn = side == 0 ? (real)1 : (real)-1;
+      row* r = new_row(e);
+      real tau[RP_MAX_ARM] = {0};
+      tau[i] = sgn;
+      r->J[i] = sgn;
+      arm_impulse_response(e, -1, 0, tau, r->B);
+      r->dinv = 1 / (sgn * r->B[i]);
+      real relv = sgn * vstar[i], pos_err = 0, vel_err = -relv;
+      if (pen > 0) vel_err -= pen / DT; else pos_err = -pen * ERP_CONTACT / DT;
+      r->rhs = (pos_err + vel_err) * r->dinv;
+      r->lo = 0; r->hi = LIMIT_MAXIMP;
+    }
+  }
+  /* 4. Panda finger gear (btMultiBodyGearConstraint, environments.py:400-405): qd9 + ratio*qd10 -> 0, erp 0.1, maxForce 50 */
+  if (m->kind == RP_KIND_P) {
+    int a = dof_of_bullet_joint(e, 9), b = dof_of_bullet_joint(e, 10);
+    row* r = new_row(e);
+    real tau[RP_MAX_ARM] = {0};
+    real ratio = (real)-1;
+    tau[a] = 1; tau[b] = ratio;             /* Bullet: jacobianA = 1 on joint A, jacobianB = gearRatio on joint B */
+    r->J[a] = 1; r->J[b] = ratio;
+    arm_impulse_response(e, -1, 0, tau, r->B);
+    r->dinv = safe_inv(dotn(r->J, r->B, nv));
+    real relv = dotn(r->J, vstar, nv);
+    real pos_err = -(e->q[a] + ratio * e->q[b]) * (real)0.1 / DT;   /* erp 0.1, relative position target 0 */
+    r->rhs = (pos_err - relv) * r->dinv;
+    r->lo = -(real)50 * DT; r->hi = (real)50 * DT;
+  }
+  /* 5. contact normals, then 6. friction (two directions per point, btPlaneSpace1) */
+  int first_normal = e->nrows;
+  for (int ci = 0; ci < e->ncon; ci++) {
+    contact* c = &e->con[ci];
+    int ba = m->col_body[c->ca], bb = m->col_body[c->cb];
+    row* r = new_row(e);
+    body_jacobian(e, ba, c->p, c->n, 1, r->J);
+    body_jacobian(e, bb, c->p, c->n, -1, r->J);
+    contact_response(e, ba, bb, c->p, c->n, r->J, r->B);
+    r->dinv = safe_inv(dotn(r->J, r->B, nv));
+    real relv = dotn(r->J, vstar, nv);
+    real pen = c->dist + LINEAR_SLOP, pos_err = 0, vel_err = -relv;
+    if (pen > 0) vel_err -= pen / DT; else pos_err = -pen * ERP_CONTACT / DT;
+    r->rhs = (pos_err + vel_err) * r->dinv;
+    r->lo = 0; r->hi = (real)1e10;
+  }
+  for (int ci = 0; ci < e->ncon; ci++) {
+    contact* c = &e->con[ci];
+    int ba = m->col_body[c->ca], bb = m->col_body[c->cb];
+    real t[2][3];
+    plane_space(c->n, t[0], t[1]);
+    for (int d = 0; d < 2; d++) {
+      row* r = new_row(e);
+      body_jacobian(e, ba, c->p, t[d], 1, r->J);
+      body_jacobian(e, bb, c->p, t[d], -1, r->J);
+      contact_response(e, ba, bb, c->p, t[d], r->J, r->B);
+      r->dinv = safe_inv(dotn(r->J, r->B, nv));
+      r->rhs = -dotn(r->J, vstar, nv) * r->dinv;
+      r->fric_parent = first_normal + ci;
+      r->mu = c->mu;
+    }
+  }
+}
+
+static void solve_rows(rpo_env* e, real* dv) {
+  int nv = e->nv;
+  for (int it = 0; it < N_ITER; it++)
+    for (int ri = 0; ri < e->nrows; ri++) {
+      row* r = &e->rows[ri];
+      real lo = r->lo, hi = r->hi;
+      if (r->fric_parent >= 0) { real lim = r->mu * e->rows[r->fric_parent].lambda; lo = -lim; hi = lim; }
+      real d = r->rhs - dotn(r->J, dv, nv) * r->dinv;
+      real sum = r->lambda + d;
+      if (sum < lo) { d = lo - r->lambda; sum = lo; }
+      else if (sum > hi) { d = hi - r->lambda; sum = hi; }
+      r->lambda = sum;
+      for (int i = 0; i < nv; i++) dv[i] += r->B[i] * d;
+    }
+}
+
+/* ------------------------------------------------------------------ one stepSimulation() */
+void rpo_substep(rpo_env* e) {
+  const rp_model* m = &e->m;
+  int nv = e->nv;
+  update_transforms(e);
+  collide(e);
+  real vstar[RP_MAX_NV] = {0}, qdd[RP_MAX_ARM];
+  arm_aba(e, qdd);
+  for (int i = 0; i < m->n_arm; i++) vstar[i] = e->qd[i] + DT * qdd[i];
+  for (int k = 0; k < m->n_free; k++) {
+    int d = dof_free(e, k);
+    const xform* x = &e->xb[1 + m->n_arm + k];
+    real vn = v3norm(e->fvel[k]);
+    for (int i = 0; i < 3; i++) vstar[d + i] = e->fvel[k][i] + DT * (-(FREE_LIN_DAMP + FREE_LIN_DAMP * vn) * e->fvel[k][i]);
+    vstar[d + 2] += DT * GRAVITY;
+    memset(e->finv[k], 0, sizeof(e->finv[k]));
+    if (!m->free_rot_locked[k]) {
+      /* local frame: alpha = I^-1 ( -(w x I w) - I w (k1 + k2 |w|) ) */
+      real wl[3], Iw[3], g[3], al[3], aw[3];
+      m3tmulv(wl, x->R, e->fom[k]);
+      for (int i = 0; i < 3; i++) Iw[i] = (real)m->free_inertia[k][i] * wl[i];
+      v3cross(g, wl, Iw);
+      real wn = v3norm(wl);
+      for (int i = 0; i < 3; i++) al[i] = (-g[i] - Iw[i] * (FREE_ANG_DAMP + FREE_ANG_DAMP * wn)) / (real)m->free_inertia[k][i];
+      m3mulv(aw, x->R, al);
+      for (int i = 0; i < 3; i++) vstar[d + 3 + i] = e->fom[k][i] + DT * aw[i];
+      for (int r = 0; r < 3; r++) for (int s = 0; s < 3; s++) {
+        real v = 0;
+        for (int t = 0; t < 3; t++) v += x->R[3 * r + t] * x->R[3 * s + t] / (real)m->free_inertia[k][t];
+        e->finv[k][3 * r + s] = v;
+      }
+    }
+  }
+  for (int k = 0; k < m->n_joint1; k++) {
+    int d = dof_j1(e, k);
+    if (m->j1_type[k] == 1) {
+      real ax[3], a[3];
+      for (int i = 0; i < 3; i++) ax[i] = (real)m->j1_axis[k][i];
+      m3mulv(a, e->xb[1 + m->n_arm + m->n_free + k].R, ax);
+      vstar[d] = e->jqd[k] + DT * GRAVITY * a[2];
+    } else {
+      real w = e->jqd[k];
+      vstar[d] = w + DT * (-(J1_ANG_DAMP + J1_ANG_DAMP * R_FABS(w)) * w);
+    }
+  }
+  build_rows(e, vstar);
+  real dv[RP_MAX_NV] = {0};
+  solve_rows(e, dv);
+  /* apply and integrate (semi-implicit Euler; free-body orientation by the exponential map) */
+  for (int i = 0; i < m->n_arm; i++) { e->qd[i] = vstar[i] + dv[i]; e->q[i] += DT * e->qd[i]; }
+  for (int k = 0; k < m->n_free; k++) {
+    int d = dof_free(e, k);
+    for (int i = 0; i < 3; i++) {
+      e->fvel[k][i] = vstar[d + i] + dv[d + i];
+      e->fom[k][i] = vstar[d + 3 + i] + dv[d + 3 + i];
+      e->fpos[k][i] += DT * e->fvel[k][i];
+    }
+    real w = v3norm(e->fom[k]);
+    if (w > (real)0.7853981633974483 / DT) w = (real)0.7853981633974483 / DT;   /* ANGULAR_MOTION_THRESHOLD */
+    real ax[3], dq[4], qn[4];
+    if (w < (real)0.001) v3scale(ax, e->fom[k], (real)0.5 * DT - DT * DT * DT * (real)0.020833333333 * w * w);
+    else v3scale(ax, e->fom[k], R_SIN((real)0.5 * w * DT) / w);
+    dq[0] = ax[0]; dq[1] = ax[1]; dq[2] = ax[2]; dq[3] = R_COS((real)0.5 * w * DT);
+    quat_mul(qn, dq, e->fquat[k]);
+    real nrm = R_SQRT(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
+    for (int i = 0; i < 4; i++) e->fquat[k][i] = qn[i] / nrm;
+  }
+  for (int k = 0; k < m->n_joint1; k++) {
+    int d = dof_j1(e, k);
+    e->jqd[k] = vstar[d] + dv[d];
+    e->jq[k] += DT * e->jqd[k];
+  }
+  (void)nv;
+}
+
+void rpo_run_simulation(rpo_env* e) { for (int i = 0; i < N_SUBSTEPS; i++) rpo_substep(e); }
+
+/* ------------------------------------------------------------------ inverse kinematics (damped least squares) */
+static void site_world(const rpo_env* e, const xform* xb, int site, real* pos, real* R) {
+  const rp_model* m = &e->m;
+  const xform* x = &xb[m->site_body[site]];
+  real sp[3], sr[9], t[3];
+  for (int i = 0; i < 3; i++) sp[i] = (real)m->site_pos[site][i];
+  for (int i = 0; i < 9; i++) sr[i] = (real)m->site_rot[site][i];
+  m3mulv(t, x->R, sp); v3add(pos, x->p, t);
+  m3mul(R, x->R, sr);
+}
+
+static void solve_spd(real* A, real* b, int n) {   /* Gaussian elimination with partial pivoting, in place; b <- x */
+  for (int c = 0; c < n; c++) {
+    int piv = c;
+    for (int r = c + 1; r < n; r++) if (R_FABS(A[r * n + c]) > R_FABS(A[piv * n + c])) piv = r;
+    if (piv != c) {
+      for (int k = 0; k < n; k++) { real t = A[c * n + k]; A[c * n + k] = A[piv * n + k]; A[piv * n + k] = t; }
+      real t = b[c]; b[c] = b[piv]; b[piv] = t;
+    }
+    for (int r = c + 1; r < n; r++) {
+      real f = A[r * n + c] / A[c * n + c];
+      for (int k = c; k < n; k++) A[r * n + k] -= f * A[c * n + k];
+      b[r] -= f * b[c];
+    }
+  }
+  for (int r = n - 1; r >= 0; r--) {
+    real s = b[r];
+    for (int k = r + 1; k < n; k++) s -= A[r * n + k] * b[k];
+    b[r] = s / A[r * n + r];
+  }
+}
+
+/* calculateInverseKinematics(body, ee, pos, orn) with IK2_VEL_DLS_WITH_ORIENTATION, as recalled in SURVEY.md App. E:
+ * iterate { FK; e = [dpos; axis*angle(q_t * q_cur^-1)]; dq = (J^T J + damp I)^-1 J^T e; clamp max|dq| to 45 deg }
+ * until |dpos| < 1e-4 or max_iter.  All movable dofs take part; non-ancestor columns are zero. */
+static void ik_solve(const rpo_env* e, const real* pos, const real* quat, const real* q_seed, int max_iter, real* q) {
+  const rp_model* m = &e->m;
+  int n = m->n_arm;
+  for (int i = 0; i < n; i++) q[i] = q_seed[i];
+  for (int it = 0; it < max_iter; it++) {
+    xform xb[1 + RP_MAX_ARM];
+    arm_fk(e, q, xb);
+    real p[3], R[9], qc[4];
+    site_world(e, xb, RP_SITE_EE, p, R);
+    m3_to_quat(qc, R);
+    real err[6];
+    v3sub(err, pos, p);
+    if (it > 0 && v3norm(err) < IK_RESIDUAL) break;
+    real qinv[4] = {-qc[0], -qc[1], -qc[2], qc[3]}, dq[4];
+    quat_mul(dq, quat, qinv);
+    real nq = R_SQRT(dq[0] * dq[0] + dq[1] * dq[1] + dq[2] * dq[2] + dq[3] * dq[3]);
+    real w = dq[3] / nq;
+    if (w > 1) w = 1;
+    if (w < -1) w = -1;
+    real angle = 2 * R_ACOS(w);                       /* btQuaternion::getAngle */
+    real s2 = 1 - w * w, axis[3] = {1, 0, 0};         /* btQuaternion::getAxis */
+    if (s2 >= (real)1e-14) { real s = 1 / R_SQRT(s2); for (int k = 0; k < 3; k++) axis[k] = dq[k] / nq * s; }
+    if (angle > RP_PI) angle -= 2 * RP_PI;
+    for (int k = 0; k < 3; k++) err[3 + k] = angle * axis[k];
+    /* Jacobian columns of the chain to the site */
+    real J[6][RP_MAX_ARM];
+    memset(J, 0, sizeof(J));
+    for (int i = m->site_body[RP_SITE_EE] - 1; i >= 0; i = m->arm_parent[i]) {
+      real ax[3], a[3];
+      for (int k = 0; k < 3; k++) ax[k] = (real)m->arm_axis[i][k];
+      m3mulv(a, xb[1 + i].R, ax);
+      if (m->arm_jtype[i] == 0) {
+        real r[3], c[3];
+        v3sub(r, p, xb[1 + i].p); v3cross(c, a, r);
+        for (int k = 0; k < 3; k++) { J[k][i] = c[k]; J[3 + k][i] = a[k]; }
+      } else {
+        for (int k = 0; k < 3; k++) J[k][i] = a[k];
+      }
+    }
+    real A[RP_MAX_ARM * RP_MAX_ARM], b[RP_MAX_ARM];
+    for (int r = 0; r < n; r++) {
+      for (int c = 0; c < n; c++) {
+        real s = 0;
+        for (int k = 0; k < 6; k++) s += J[k][r] * J[k][c];
+        A[r * n + c] = s + (r == c ? IK_DAMP : 0);
+      }
+      real s = 0;
+      for (int k = 0; k < 6; k++) s += J[k][r] * err[k];
+      b[r] = s;
+    }
+    solve_spd(A, b, n);
+    real mx = 0;
+    for (int i = 0; i < n; i++) if (R_FABS(b[i]) > mx) mx = R_FABS(b[i]);
+    real sc = mx > IK_MAX_STEP ? IK_MAX_STEP / mx : 1;
+    for (int i = 0; i < n; i++) q[i] += sc * b[i];
+  }
+}
+
+void rpo_ik(const rpo_env* e, const double* pos, const double* quat, const double* q_seed, int max_iter, double* q_out) {
+  real p[3], qt[4], qs[RP_MAX_ARM], q[RP_MAX_ARM];
+  for (int i = 0; i < 3; i++) p[i] = (real)pos[i];
+  for (int i = 0; i < 4; i++) qt[i] = (real)quat[i];
+  for (int i = 0; i < e->m.n_arm; i++) qs[i] = (real)q_seed[i];
+  ik_solve(e, p, qt, qs, max_iter, q);
+  for (int i = 0; i < e->m.n_arm; i++) q_out[i] = q[i];
+}
+
+/* InverseKinematicsSolver.calc_angles (inverseKinematics.py:44-50): the shadow arm is set to the current 6 arm
+ * joints (its gripper joints stay 0), then 3 x (IK; set joints) and a 4th IK whose first 6 values are returned. */
+static void calc_angles(const rpo_env* e, const real* pos, const real* quat, const real* current6, real* out6) {
+  real q[RP_MAX_ARM] = {0}, sol[RP_MAX_ARM];
+  for (int i = 0; i < 6; i++) q[i] = current6[i];
+  for (int rep = 0; rep < 4; rep++) {
+    ik_solve(e, pos, quat, q, 20, sol);
+    for (int i = 0; i < 6; i++) q[i] = sol[i];
+  }
+  for (int i = 0; i < 6; i++) out6[i] = sol[i];
+}
+
+void rpo_calc_angles(const rpo_env* e, const double* pos, const double* quat, const double* current, double* q_out) {
+  real p[3], qt[4], c[6], o[6];
+  for (int i = 0; i < 3; i++) p[i] = (real)pos[i];
+  for (int i = 0; i < 4; i++) qt[i] = (real)quat[i];
+  for (int i = 0; i < 6; i++) c[i] = (real)current[i];
+  calc_angles(e, p, qt, c, o);
+  for (int i = 0; i < 6; i++) q_out[i] = o[i];
+}
+
+/* ------------------------------------------------------------------ harness: actions */
+static inline real clampr(real v, real lo, real hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+static void set_pos_motor(rpo_env* e, int bullet_joint, real target, real force) {
+  int d = dof_of_bullet_joint(e, bullet_joint);
+  e->mmode[d] = 1; e->mtarget[d] = target; e->mmaximp[d] = force * DT;
+}
+
+/* close_gripper (environments.py:1037-1073) */
+static void close_gripper(rpo_env* e, real amount) {
+  if (e->m.kind == RP_KIND_P) {
+    amount = (real)0.04 - amount / 25;
+    set_pos_motor(e, 9, amount, 100);
+    set_pos_motor(e, 10, amount, 100);
+  } else {
+    amount -= (real)0.2;
+    real driver = amount * (real)0.055;
+    set_pos_motor(e, 18, driver, 100);
+    real left = e->q[dof_of_bullet_joint(e, 18)];
+    set_pos_motor(e, 20, left, 1000);
+    real spring = amount * (real)0.5;
+    set_pos_motor(e, 12, spring, 100);
+    set_pos_motor(e, 15, spring, 100);
+    real mimic = amount * (real)0.8;
+    set_pos_motor(e, 10, mimic, 100);
+    set_pos_motor(e, 13, mimic, 100);
+  }
+}
+
+/* goto_joint_poses (environments.py:1010-1034) */
+static void goto_joint_poses(rpo_env* e, const real* joint_poses, int has_gripper, real gripper, real* target_poses) {
+  static const double P_LL[7] = {-0.6, -2.2, -3.0, -3.04878596, -3.14159265358979323846, -3.14159265358979323846, -3.14159265358979323846};
+  static const double P_UL[7] = {3, 1.8, 0.5, -0.5002492, 3., 3.45266257, 2.40072908};
+  static const double P_INC[7] = {0.1, 0.1, 0.2, 0.2, 0.2, 0.2, 0.2};
+  static const double U_UL[6] = {-0.7, 2 * 3.14159265358979323846, -0.5, 2 * 3.14159265358979323846, 2 * 3.14159265358979323846,
+                                 2 * 3.14159265358979323846};
+  static const double U_INC[6] = {0.1, 0.1, 0.2, 0.2, 0.2, 0.2};
+  int nd = e->m.kind == RP_KIND_P ? 7 : 6;
+  for (int i = 0; i < nd; i++) {
+    real ll = e->m.kind == RP_KIND_P ? (real)P_LL[i] : (real)(-2 * 3.14159265358979323846);
+    real ul = e->m.kind == RP_KIND_P ? (real)P_UL[i] : (real)U_UL[i];
+    real inc = e->m.kind == RP_KIND_P ? (real)P_INC[i] : (real)U_INC[i];
+    real t = clampr(joint_poses[i], ll, ul);          /* np.clip: min(max(x, lo), hi) */
+    real cur = e->q[i];
+    t = clampr(t, cur - inc, cur + inc);
+    target_poses[i] = t;
+    e->mmode[i] = 1; e->mtarget[i] = t; e->mmaximp[i] = (real)240 * DT;
+  }
+  if (has_gripper) close_gripper(e, gripper);
+}
+
+void rpo_goto_joint_poses(rpo_env* e, const double* joint_poses, int has_gripper, double gripper, double* target_poses) {
+  real jp[7], tp[7];
+  int nd = e->m.kind == RP_KIND_P ? 7 : 6;
+  for (int i = 0; i < nd; i++) jp[i] = (real)joint_poses[i];
+  goto_joint_poses(e, jp, has_gripper, (real)gripper, tp);
+  for (int i = 0; i < nd; i++) target_poses[i] = tp[i];
+}
+
+/* perform_action('absolute_rpy') -> absolute_rpy_step -> goto (environments.py:915-934, 955-961, 984-1007) */
+static void perform_action(rpo_env* e, const real* a, real* target_poses) {
+  real quat[4], jp[RP_MAX_ARM];
+  quat_from_euler(quat, a + 3);
+  if (e->m.kind == RP_KIND_P) {
+    real sol[RP_MAX_ARM];
+    ik_solve(e, a, quat, e->q, 200, sol);        /* maxNumIterations=200 on the live arm (environments.py:995-997) */
+    for (int i = 0; i < 7; i++) jp[i] = sol[i];
+  } else {
+    calc_angles(e, a, quat, e->q, jp);
+  }
+  goto_joint_poses(e, jp, 1, a[6], target_poses);
+}
+
+void rpo_perform_action(rpo_env* e, const double* action, double* target_poses) {
+  real a[7], tp[7];
+  for (int i = 0; i < 7; i++) a[i] = (real)action[i];
+  perform_action(e, a, tp);
+  int nd = e->m.kind == RP_KIND_P ? 7 : 6;
+  for (int i = 0; i < nd; i++) target_poses[i] = tp[i];
+}
+
+/* ------------------------------------------------------------------ harness: observation */
+static real dial_to_0_1_range(real x) {            /* scenes.py:342-343: (x % 2*pi)/(2.2*pi) == (x mod 2)/2.2 (python modulo) */
+  real mod = x - 2 * R_FLOOR(x / 2);
+  return (mod * RP_PI) / ((real)2.2 * RP_PI);
+}
+
+static void body_point_velocity(const rpo_env* e, int body, const real* p, real* lin, real* ang) {
+  if (body_is_arm(e, body)) {
+    const real* v = e->vsp[body - 1];
+    real c[3];
+    v3cross(c, v, p);
+    v3add(lin, v + 3, c);
+    v3cpy(ang, v);
+  } else { v3set(lin, 0, 0, 0); v3set(ang, 0, 0, 0); }
+}
+
+static int ray_box(const real* o, const real* d, const xform* x, const real* he, real* tmin_out) {
+  real ol[3], dl[3], t[3];
+  v3sub(t, o, x->p);
+  m3tmulv(ol, x->R, t);
+  m3tmulv(dl, x->R, d);
+  int inside = 1;
+  for (int k = 0; k < 3; k++) if (R_FABS(ol[k]) > he[k]) inside = 0;
+  if (inside) return 0;                              /* rays that start inside a convex shape report no hit on it */
+  real tmin = 0, tmax = 1;
+  for (int k = 0; k < 3; k++) {
+    if (R_FABS(dl[k]) < (real)1e-12) { if (R_FABS(ol[k]) > he[k]) return 0; continue; }
+    real t1 = (-he[k] - ol[k]) / dl[k], t2 = (he[k] - ol[k]) / dl[k];
+    if (t1 > t2) { real s = t1; t1 = t2; t2 = s; }
+    if (t1 > tmin) tmin = t1;
+    if (t2 < tmax) tmax = t2;
+    if (tmin > tmax) return 0;
+  }
+  *tmin_out = tmin;
+  return 1;
+}
+
+static int ray_sphere(const real* o, const real* d, const real* c, real r, real* t_out) {
+  real oc[3]; v3sub(oc, o, c);
+  real a = v3dot(d, d), b = 2 * v3dot(oc, d), cc = v3dot(oc, oc) - r * r;
+  if (cc < 0) return 0;
+  real disc = b * b - 4 * a * cc;
+  if (disc < 0) return 0;
+  real t = (-b - R_SQRT(disc)) / (2 * a);
+  if (t < 0 || t > 1) return 0;
+  *t_out = t;
+  return 1;
+}
+
+/* gripper_proprioception (environments.py:720-743) */
+static int gripper_proprioception(rpo_env* e) {
+  const rp_model* m = &e->m;
+  if (m->kind == RP_KIND_P) return -1;
+  real g1[3], g2[3], ee[3], wr[3], R[9];
+  site_world(e, e->xb, RP_SITE_PADL, g1, R);
+  site_world(e, e->xb, RP_SITE_PADR, g2, R);
+  site_world(e, e->xb, RP_SITE_EE, ee, R);
+  site_world(e, e->xb, RP_SITE_WRIST, wr, R);
+  real p1[3], p2[3], d[3];
+  for (int k = 0; k < 3; k++) {
+    p1[k] = ee[k] - (ee[k] - wr[k]) * (real)0.5;
+    p2[k] = (g1[k] + g2[k]) / 2 + (ee[k] - wr[k]) * (real)0.2;
+    d[k] = p2[k] - p1[k];
+  }
+  real best = 2; int best_link = -1, hit = 0;
+  for (int c = 0; c < m->n_col; c++) {
+    real t, he[3];
+    for (int k = 0; k < 3; k++) he[k] = (real)m->col_he[c][k];
+    int h = m->col_type[c] == 0 ? ray_box(p1, d, &e->xc[c], he, &t) : ray_sphere(p1, d, e->xc[c].p, he[0], &t);
+    if (h && t < best) { best = t; best_link = m->col_link[c]; hit = 1; }
+  }
+  if (!hit || best >= 1 || best_link == 18 || best_link == 20) return 0;
+  return 1;
+}
+
+static void flip_quats(real* v, const real* last, int a) {
+  int all = 1;
+  for (int i = a; i < a + 4; i++) {
+    int s = (v[i] > 0) - (v[i] < 0), l = (last[i] > 0) - (last[i] < 0);
+    if (s != -l) all = 0;
+  }
+  if (all) for (int i = a; i < a + 4; i++) v[i] = -v[i];
+}
+
+/* world read-back = the PyBullet getters of calc_actor_state / calc_environment_state (environments.py:746-793) */
+static void read_world(rpo_env* e, rpo_readings* rd) {
+  const rp_model* m = &e->m;
+  memset(rd, 0, sizeof(*rd));
+  update_transforms(e);
+  for (int i = 0; i < m->n_arm; i++) {
+    int p = m->arm_parent[i];
+    for (int k = 0; k < 6; k++) e->vsp[i][k] = (p >= 0 ? e->vsp[p][k] : 0) + e->S[i][k] * e->qd[i];
+  }
+  real pos[3], R[9], orn[4], lin[3], ang[3];
+  site_world(e, e->xb, RP_SITE_EE, pos, R);
+  m3_to_quat(orn, R);
+  body_point_velocity(e, m->site_body[RP_SITE_EE], pos, lin, ang);
+  for (int k = 0; k < 3; k++) { rd->ee_pos[k] = pos[k]; rd->ee_lin[k] = lin[k]; rd->ee_ang[k] = ang[k]; }
+  for (int k = 0; k < 4; k++) rd->ee_orn[k] = orn[k];
+  rd->grip_q = m->kind == RP_KIND_P ? e->q[dof_of_bullet_joint(e, 9)] : e->q[dof_of_bullet_joint(e, 18)];
+  for (int j = 0; j < 8; j++) { int d = dof_of_bullet_joint(e, j); rd->joints[j] = d >= 0 ? e->q[d] : 0; }
+  rd->proprio = gripper_proprioception(e);
+  if (e->num_objects > 0) {
+    for (int k = 0; k < 3; k++) { rd->block_pos[k] = e->fpos[0][k]; rd->block_vel[k] = e->fvel[0][k]; }
+    for (int k = 0; k < 4; k++) rd->block_orn[k] = e->fquat[0][k];
+  }
+  if (e->play) { rd->drawer_y = e->fpos[1][1]; rd->door_q = e->jq[0]; rd->button_q = e->jq[1]; rd->dial_q = e->jq[2]; }
+}
+
+/* calc_state's assembly (environments.py:799-864) from the raw readings */
+static void assemble_obs(rpo_env* e, const rpo_readings* rd, rpo_obs* o) {
+  const rp_model* m = &e->m;
+  real pos[3], orn[4], lin[3], ang[3];
+  for (int k = 0; k < 3; k++) { pos[k] = (real)rd->ee_pos[k]; lin[k] = (real)rd->ee_lin[k]; ang[k] = (real)rd->ee_ang[k]; }
+  for (int k = 0; k < 4; k++) orn[k] = (real)rd->ee_orn[k];
+  real grip = m->kind == RP_KIND_P ? (real)rd->grip_q : (real)rd->grip_q * 23;
+  for (int j = 0; j < 8; j++) o->joints[j] = rd->joints[j];
+  o->gripper_proprioception = rd->proprio;
+  real st[19], ag[11], fps[19];
+  int ns = 0, nag = 0, nf = 0;
+  for (int k = 0; k < 3; k++) st[ns++] = pos[k];
+  if (e->return_velocity) for (int k = 0; k < 3; k++) st[ns++] = lin[k];
+  if (e->use_orientation) for (int k = 0; k < 4; k++) st[ns++] = orn[k];
+  st[ns++] = grip;
+  if (e->num_objects > 0) {
+    /* calc_environment_state: block pose (+vel), then drawer y, door, button, dial (environments.py:767-793) */
+    for (int k = 0; k < 3; k++) st[ns++] = (real)rd->block_pos[k];
+    if (e->use_orientation) for (int k = 0; k < 4; k++) st[ns++] = (real)rd->block_orn[k];
+    if (e->return_velocity) for (int k = 0; k < 3; k++) st[ns++] = (real)rd->block_vel[k];
+    for (int k = 0; k < 3; k++) ag[nag++] = (real)rd->block_pos[k];
+    if (e->use_orientation) for (int k = 0; k < 4; k++) ag[nag++] = (real)rd->block_orn[k];
+    if (e->play) {
+      real extra[4] = {(real)rd->drawer_y, (real)rd->door_q, (real)rd->button_q, dial_to_0_1_range((real)rd->dial_q)};
+      for (int k = 0; k < 4; k++) { st[ns++] = extra[k]; ag[nag++] = extra[k]; }
+    }
+    for (int k = 0; k < 3; k++) fps[nf++] = pos[k];
+    if (e->use_orientation) for (int k = 0; k < 4; k++) fps[nf++] = orn[k];
+    fps[nf++] = grip;
+    for (int k = 0; k < nag; k++) fps[nf++] = ag[k];
+  } else {
+    for (int k = 0; k < 3; k++) ag[nag++] = pos[k];
+    for (int k = 0; k < 3; k++) fps[nf++] = pos[k];
+    fps[nf++] = grip;
+  }
+  if (e->play) {        /* quaternion_safe_the_obs (environments.py:868-894) */
+    if (e->have_last) {
+      flip_quats(st, e->last_obs, 3);
+      flip_quats(st, e->last_obs, 11);
+      flip_quats(ag, e->last_ag, 3);
+    }
+    memcpy(e->last_obs, st, sizeof(real) * 19);
+    memcpy(e->last_ag, ag, sizeof(real) * 11);
+    e->have_last = 1;
+  }
+  o->n_obs = ns; o->n_ag = nag; o->n_fps = nf;
+  for (int k = 0; k < ns; k++) o->obs_quat[k] = st[k];
+  for (int k = 0; k < nag; k++) o->achieved_goal[k] = ag[k];
+  for (int k = 0; k < e->n_goal; k++) o->desired_goal[k] = e->goal[k];
+  for (int k = 0; k < nf; k++) o->full_positional_state[k] = fps[k];
+  for (int k = 0; k < 3; k++) { o->controllable_achieved_goal[k] = pos[k]; o->velocity[k] = lin[k]; o->velocity[3 + k] = ang[k]; }
+  o->controllable_achieved_goal[3] = grip;
+  real eul[3];
+  euler_from_quat(eul, st + 3);                      /* applied to state[3:7] whatever it holds (quirk F2) */
+  int no = 0;
+  for (int k = 0; k < 3; k++) o->observation[no++] = st[k];
+  for (int k = 0; k < 3; k++) o->observation[no++] = eul[k];
+  for (int k = 7; k < ns; k++) o->observation[no++] = st[k];
+  o->n_observation = no;
+}
+
+static void calc_state(rpo_env* e, rpo_obs* o) {
+  rpo_readings rd;
+  read_world(e, &rd);
+  assemble_obs(e, &rd, o);
+}
+
+void rpo_assemble_obs(rpo_env* e, const rpo_readings* rd, rpo_obs* out) { assemble_obs(e, rd, out); }
+void rpo_read_world(rpo_env* e, rpo_readings* rd) { read_world(e, rd); }
+void rpo_quat_from_euler(const double* rpy, double* q) {
+  real r[3] = {(real)rpy[0], (real)rpy[1], (real)rpy[2]}, o[4];
+  quat_from_euler(o, r);
+  for (int k = 0; k < 4; k++) q[k] = o[k];
+}
+void rpo_euler_from_quat(const double* q, double* rpy) {
+  real r[4] = {(real)q[0], (real)q[1], (real)q[2], (real)q[3]}, o[3];
+  euler_from_quat(o, r);
+  for (int k = 0; k < 3; k++) rpy[k] = o[k];
+}
+double rpo_dial_to_0_1_range(double x) { return dial_to_0_1_range((real)x); }
+void rpo_calc_state(rpo_env* e, rpo_obs* out) { calc_state(e, out); }
+
+/* ------------------------------------------------------------------ harness: rewards */
+static real success_func(const real* ag, const real* g) {       /* playRewardFunc.py:66-77 */
+  for (int k = 0; k < 3; k++) if (R_FABS(g[k] - ag[k]) > (real)0.05) return -1;
+  real eg[3], ea[3];
+  euler_from_quat(eg, g + 3); euler_from_quat(ea, ag + 3);
+  for (int k = 0; k < 3; k++) if (R_FABS(eg[k] - ea[k]) > RP_PI / 4) return -1;
+  if (R_FABS(g[7] - ag[7]) > (real)0.025) return -1;
+  if (R_FABS(g[8] - ag[8]) > (real)0.04) return -1;             /* limit argument ignored (quirk F6) */
+  if (R_FABS(g[9] - ag[9]) > (real)0.01) return -1;
+  if (R_FABS(g[10] - ag[10]) > (real)0.3) return -1;
+  return 0;
+}
+
+static real compute_reward(const rpo_env* e, const real* ag, const real* dg) {    /* environments.py:278-304 */
+  if (e->play) return success_func(ag, dg);
+  real d[3]; v3sub(d, ag, dg);
+  real dist = v3norm(d);
+  return dist > (real)0.05 ? (real)-1 : -dist;
+}
+
+double rpo_compute_reward(const rpo_env* e, const double* ag, const double* dg) {
+  real a[11], g[11];
+  int n = e->play ? 11 : 3;
+  for (int i = 0; i < n; i++) { a[i] = (real)ag[i]; g[i] = (real)dg[i]; }
+  return compute_reward(e, a, g);
+}
+
+/* ------------------------------------------------------------------ harness: step / reset */
+void rpo_step(rpo_env* e, const double* action, rpo_obs* out, double* reward, int* is_success, double* target_poses) {
+  static const real high[7] = {6, 6, 6, 6, 6, 6, 1};      /* environments.py:108-109 */
+  real a[7], tp[7];
+  for (int i = 0; i < 7; i++) a[i] = clampr((real)action[i], -high[i], high[i]);
+  perform_action(e, a, tp);
+  rpo_run_simulation(e);
+  calc_state(e, out);
+  real ag[11], dg[11];
+  for (int i = 0; i < out->n_ag; i++) ag[i] = (real)(float)out->achieved_goal[i];     /* reward sees the float32 casts */
+  for (int i = 0; i < e->n_goal; i++) dg[i] = (real)(float)out->desired_goal[i];
+  real r = compute_reward(e, ag, dg);
+  *reward = r;
+  *is_success = r < 0 ? 0 : 1;
+  int nd = e->m.kind == RP_KIND_P ? 7 : 6;
+  for (int i = 0; i < nd; i++) target_poses[i] = tp[i];
+}
+
+static void reset_goal_pos(rpo_env* e, const real* goal, ustream* us) {   /* environments.py:492-516 */
+  if (!goal) {
+    for (int k = 0; k < 3; k++) e->goal[k] = e->goal_lo[k] + (e->goal_hi[k] - e->goal_lo[k]) * next_u(us);
+    e->n_goal = 3;
+  } else {
+    for (int k = 0; k < e->n_goal; k++) e->goal[k] = goal[k];
+  }
+  if (e->play) {
+    rpo_obs o;
+    calc_state(e, &o);
+    int n = o.n_ag;
+    int idx = (int)(next_u(us) * n);
+    if (idx >= n) idx = n - 1;
+    real bump = next_u(us);
+    for (int k = 0; k < n; k++) e->goal[k] = (real)(float)o.achieved_goal[k];   /* c is the float32 achieved_goal */
+    e->goal[idx] = (real)(float)((float)e->goal[idx] + (float)bump);
+    e->n_goal = n;
+  }
+}
+
+void rpo_reset_goal(rpo_env* e, const double* goal, const double* u, int n_u) {
+  ustream us = {e, u, n_u, 0};
+  real g[11];
+  if (goal) for (int k = 0; k < e->n_goal; k++) g[k] = (real)goal[k];
+  reset_goal_pos(e, goal ? g : 0, &us);
+}
+
+static void reset_object_pos(rpo_env* e, ustream* us, int depth) {     /* environments.py:519-556, obs=None branch */
+  const rp_model* m = &e->m;
+  if (e->play) {
+    for (int k = 0; k < 3; k++) e->fpos[1][k] = (real)m->free_pos0[1][k];
+    real R0[9]; for (int k = 0; k < 9; k++) R0[k] = (real)m->free_rot0[1][k];
+    m3_to_quat(e->fquat[1], R0);
+    v3set(e->fvel[1], 0, 0, 0); v3set(e->fom[1], 0, 0, 0);
+    for (int k = 0; k < m->n_joint1; k++) { e->jq[k] = 0; e->jqd[k] = 0; }
+  }
+  real height = (real)0.03;
+  for (int b = 0; b < e->num_objects; b++) {
+    for (int k = 0; k < 3; k++) e->fpos[b][k] = e->obj_lo[k] + (e->obj_hi[k] - e->obj_lo[k]) * next_u(us);
+    e->fpos[b][2] += height;
+    e->fquat[b][0] = 0; e->fquat[b][1] = 0; e->fquat[b][2] = (real)0.7071; e->fquat[b][3] = (real)0.7071;
+    v3set(e->fvel[b], 0, 0, 0); v3set(e->fom[b], 0, 0, 0);
+    height += (real)0.03;
+  }
+  for (int i = 0; i < N_SETTLE; i++) rpo_substep(e);
+  for (int b = 0; b < e->num_objects; b++) {
+    int out = 0;
+    for (int k = 0; k < 3; k++) if (e->fpos[b][k] > e->env_hi[k]) out = 1;
+    if (out && depth < 8) reset_object_pos(e, us, depth + 1);
+  }
+}
+
+static void reset_arm(rpo_env* e, ustream* us) {                        /* environments.py:575-596, o=None */
+  const rp_model* m = &e->m;
+  real pos[3], orn[4] = {0, 0, 0, 1};
+  for (int k = 0; k < 3; k++) pos[k] = e->goal_lo[k] + (e->goal_hi[k] - e->goal_lo[k]) * next_u(us);
+  if (m->kind != RP_KIND_P) pos[2] += (real)0.2;
+  /* reset_arm_joints(rest): UR5 joints 0..5; Panda joints 0..6 and finger joint 9 (<- rest[7]) */
+  int nrest = m->kind == RP_KIND_P ? 8 : 6;
+  for (int i = 0; i < nrest; i++) { e->q[i] = (real)m->rest[i]; e->qd[i] = 0; }
+  real sol[RP_MAX_ARM];
+  ik_solve(e, pos, orn, e->q, 20, sol);
+  for (int i = 0; i < 6; i++) { e->q[i] = sol[i]; e->qd[i] = 0; }   /* [0:6] only (quirk F5) */
+}
+
+/* the pure sampling arithmetic of one reset attempt, for the golden test (block spawn, arm IK target) */
+void rpo_reset_samples(const rpo_env* e, const double* u, double* block_pos, double* arm_target) {
+  int n = 0;
+  for (int b = 0; b < e->num_objects; b++) {
+    for (int k = 0; k < 3; k++) block_pos[3 * b + k] = (double)(e->obj_lo[k] + (e->obj_hi[k] - e->obj_lo[k]) * (real)u[n++]);
+    block_pos[3 * b + 2] = (double)((real)block_pos[3 * b + 2] + (real)0.03 * (b + 1));
+  }
+  for (int k = 0; k < 3; k++) arm_target[k] = (double)(e->goal_lo[k] + (e->goal_hi[k] - e->goal_lo[k]) * (real)u[n++]);
+  if (e->m.kind != RP_KIND_P) arm_target[2] = (double)((real)arm_target[2] + (real)0.2);
+}
+
+int rpo_reset(rpo_env* e, const double* u, int n_u, rpo_obs* out) {
+  ustream us = {e, u, n_u, 0};
+  real r = 0;
+  int guard = 0;
+  while (r > -1 && guard++ < 64) {
+    reset_object_pos(e, &us, 0);
+    reset_arm(e, &us);
+    reset_goal_pos(e, 0, &us);
+    calc_state(e, out);
+    real ag[11], dg[11];
+    for (int i = 0; i < out->n_ag; i++) ag[i] = (real)(float)out->achieved_goal[i];
+    for (int i = 0; i < e->n_goal; i++) dg[i] = (real)(float)out->desired_goal[i];
+    r = compute_reward(e, ag, dg);
+  }
+  return us.used;
+}
+
+/* ------------------------------------------------------------------ create / state access / probes */
+rpo_env* rpo_create(int kind, unsigned long long seed, int env_index) {
+  rpo_env* e = (rpo_env*)calloc(1, sizeof(rpo_env));
+  if (kind == RP_KIND_U) rp_fill_model_U(&e->m);
+  else if (kind == RP_KIND_R) rp_fill_model_R(&e->m);
+  else rp_fill_model_P(&e->m);
+  const rp_model* m = &e->m;
+  e->nv = m->n_arm + 6 * m->n_free + m->n_joint1;
+  e->nbody = 1 + m->n_arm + m->n_free + m->n_joint1;
+  e->seed = seed; e->env_index = (uint32_t)env_index;
+  /* envList.py:18-22, 89-99 */
+  if (kind == RP_KIND_U) {
+    e->play = 1; e->use_orientation = 1; e->return_velocity = 0; e->num_objects = 1;
+    real gl[3] = {-0.18, 0, 0.05}, gh[3] = {0.18, 0.3, 0.1}, eh[3] = {1, 1, 1};
+    for (int k = 0; k < 3; k++) { e->goal_lo[k] = e->obj_lo[k] = gl[k]; e->goal_hi[k] = e->obj_hi[k] = gh[k]; e->env_hi[k] = eh[k]; }
+    e->n_goal = 11;
+  } else if (kind == RP_KIND_R) {
+    e->play = 0; e->use_orientation = 0; e->return_velocity = 1; e->num_objects = 0;
+    real gl[3] = {-0.18, -0.18, -0.05}, gh[3] = {0.18, 0.18, 0.05}, eh[3] = {0.18, 0.18, 0.15};
+    for (int k = 0; k < 3; k++) { e->goal_lo[k] = gl[k]; e->goal_hi[k] = gh[k]; e->env_hi[k] = eh[k]; }
+    e->n_goal = 3;
+  } else {
+    e->play = 0; e->use_orientation = 0; e->return_velocity = 1; e->num_objects = 1;
+    real gl[3] = {-0.18, -0.18, 0.0}, gh[3] = {0.18, 0.18, 0.1}, eh[3] = {0.18, 0.18, 0.2};
+    for (int k = 0; k < 3; k++) { e->goal_lo[k] = e->obj_lo[k] = gl[k]; e->goal_hi[k] = e->obj_hi[k] = gh[k]; e->env_hi[k] = eh[k]; }
+    e->n_goal = 3;
+  }
+  /* initial state = as loaded: arm at q = 0, bodies at their creation poses, default velocity motors everywhere */
+  for (int i = 0; i < m->n_arm; i++) { e->mmode[i] = 0; e->mmaximp[i] = DEFAULT_MOTOR_MAXIMP; }
+  for (int k = 0; k < m->n_free; k++) {
+    real R0[9];
+    for (int i = 0; i < 3; i++) e->fpos[k][i] = (real)m->free_pos0[k][i];
+    for (int i = 0; i < 9; i++) R0[i] = (real)m->free_rot0[k][i];
+    m3_to_quat(e->fquat[k], R0);
+  }
+  update_transforms(e);
+  return e;
+}
+void rpo_destroy(rpo_env* e) { free(e); }
+int rpo_nv(const rpo_env* e) { return e->nv; }
+int rpo_n_arm(const rpo_env* e) { return e->m.n_arm; }
+int rpo_state_size(const rpo_env* e) { return 2 * e->m.n_arm + 13 * e->m.n_free + 2 * e->m.n_joint1; }
+void rpo_get_state(const rpo_env* e, double* s) {
+  int n = 0;
+  for (int i = 0; i < e->m.n_arm; i++) s[n++] = e->q[i];
+  for (int i = 0; i < e->m.n_arm; i++) s[n++] = e->qd[i];
+  for (int k = 0; k < e->m.n_free; k++) {
+    for (int i = 0; i < 3; i++) s[n++] = e->fpos[k][i];
+    for (int i = 0; i < 4; i++) s[n++] = e->fquat[k][i];
+    for (int i = 0; i < 3; i++) s[n++] = e->fvel[k][i];
+    for (int i = 0; i < 3; i++) s[n++] = e->fom[k][i];
+  }
+  for (int k = 0; k < e->m.n_joint1; k++) s[n++] = e->jq[k];
+  for (int k = 0; k < e->m.n_joint1; k++) s[n++] = e->jqd[k];
+}
+void rpo_set_state(rpo_env* e, const double* s) {
+  int n = 0;
+  for (int i = 0; i < e->m.n_arm; i++) e->q[i] = (real)s[n++];
+  for (int i = 0; i < e->m.n_arm; i++) e->qd[i] = (real)s[n++];
+  for (int k = 0; k < e->m.n_free; k++) {
+    for (int i = 0; i < 3; i++) e->fpos[k][i] = (real)s[n++];
+    for (int i = 0; i < 4; i++) e->fquat[k][i] = (real)s[n++];
+    for (int i = 0; i < 3; i++) e->fvel[k][i] = (real)s[n++];
+    for (int i = 0; i < 3; i++) e->fom[k][i] = (real)s[n++];
+  }
+  for (int k = 0; k < e->m.n_joint1; k++) e->jq[k] = (real)s[n++];
+  for (int k = 0; k < e->m.n_joint1; k++) e->jqd[k] = (real)s[n++];
+  update_transforms(e);
+}
+void rpo_get_motor(const rpo_env* e, int* mode, double* target, double* maximp) {
+  for (int i = 0; i < e->m.n_arm; i++) { mode[i] = e->mmode[i]; target[i] = e->mtarget[i]; maximp[i] = e->mmaximp[i]; }
+}
+void rpo_set_goal(rpo_env* e, const double* goal) { for (int k = 0; k < e->n_goal; k++) e->goal[k] = (real)goal[k]; }
+void rpo_clear_quat_memory(rpo_env* e) { e->have_last = 0; }
+
+void rpo_site_pose(const rpo_env* e0, int site, double* pos, double* quat, double* linvel, double* angvel) {
+  rpo_env* e = (rpo_env*)e0;
+  update_transforms(e);
+  for (int i = 0; i < e->m.n_arm; i++) {
+    int p = e->m.arm_parent[i];
+    for (int k = 0; k < 6; k++) e->vsp[i][k] = (p >= 0 ? e->vsp[p][k] : 0) + e->S[i][k] * e->qd[i];
+  }
+  real p[3], R[9], q[4], l[3], a[3];
+  site_world(e, e->xb, site, p, R);
+  m3_to_quat(q, R);
+  body_point_velocity(e, e->m.site_body[site], p, l, a);
+  for (int k = 0; k < 3; k++) { pos[k] = p[k]; linvel[k] = l[k]; angvel[k] = a[k]; }
+  for (int k = 0; k < 4; k++) quat[k] = q[k];
+}
+
+void rpo_mass_matrix_inv(rpo_env* e, double* Minv) {
+  int n = e->m.n_arm;
+  update_transforms(e);
+  arm_aba(e, 0);
+  for (int j = 0; j < n; j++) {
+    real tau[RP_MAX_ARM] = {0}, d[RP_MAX_ARM];
+    tau[j] = 1;
+    arm_impulse_response(e, -1, 0, tau, d);
+    for (int i = 0; i < n; i++) Minv[i * n + j] = d[i];
+  }
+}
+
+void rpo_forward_dynamics(rpo_env* e, double* qdd) {
+  real a[RP_MAX_ARM];
+  update_transforms(e);
+  arm_aba(e, a);
+  for (int i = 0; i < e->m.n_arm; i++) qdd[i] = a[i];
+}
+
+int rpo_contacts(rpo_env* e, double* out, int max) {
+  update_transforms(e);
+  collide(e);
+  int n = e->ncon < max ? e->ncon : max;
+  for (int i = 0; i < n; i++) {
+    const contact* c = &e->con[i];
+    double* o = out + 9 * i;
+    o[0] = c->ca; o[1] = c->cb;
+    for (int k = 0; k < 3; k++) { o[2 + k] = c->p[k]; o[5 + k] = c->n[k]; }
+    o[8] = c->dist;
+  }
+  return e->ncon;
+}
+int rpo_last_num_rows(const rpo_env* e) { return e->nrows; }
+
+int rpo_box_box(const double* ca, const double* Ra, const double* ha, const double* cb, const double* Rb, const double* hb,
+                double margin, double* out) {
+  real a[3], A[9], h1[3], b[3], Bm[9], h2[3];
+  for (int i = 0; i < 3; i++) { a[i] = (real)ca[i]; h1[i] = (real)ha[i]; b[i] = (real)cb[i]; h2[i] = (real)hb[i]; }
+  for (int i = 0; i < 9; i++) { A[i] = (real)Ra[i]; Bm[i] = (real)Rb[i]; }
+  cpoint pts[4];
+  int n = box_box(a, A, h1, b, Bm, h2, (real)margin, pts);
+  for (int i = 0; i < n; i++) {
+    for (int k = 0; k < 3; k++) { out[7 * i + k] = pts[i].p[k]; out[7 * i + 3 + k] = pts[i].n[k]; }
+    out[7 * i + 6] = pts[i].dist;
+  }
+  return n;
+}

@@ -1,0 +1,84 @@
+/* oracle/rp_oracle.h — CPU restatement of the reference hot path.  TEST INFRASTRUCTURE ONLY:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ *
+ * PARITY UNPINNED for physics: the reference's physics lives in PyBullet (unpinned third-party dependency,
+ * absent from /root/reference and from this image).  The harness arithmetic (action
+ * mapping, observation assembly, rewards, reset sampling) IS pinned against tests/golden JSON fixtures, which were
+ * produced by executing the reference's own Python (tests/golden/make_goldens.py).
+ *
+ * One rpo_env = one reference `instance` + `playEnv` (environments.py:58-1073) without Python.
+ * All I/O is double regardless of the internal `real` (build with -DRP_FLOAT for an fp32 oracle). */
+#ifndef RP_ORACLE_H
+#define RP_ORACLE_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rpo_env rpo_env;
+
+/* observation bundle of one env, reference calc_state() (environments.py:799-864); sizes are maxima */
+typedef struct rpo_obs {
+  double obs_quat[19], achieved_goal[11], desired_goal[11], controllable_achieved_goal[4];
+  double full_positional_state[19], joints[8], velocity[6], observation[18];
+  int gripper_proprioception;
+  int n_obs, n_ag, n_fps, n_observation;
+} rpo_obs;
+
+/* raw world read-back feeding calc_state (what the reference pulls from PyBullet getters) */
+typedef struct rpo_readings {
+  double ee_pos[3], ee_orn[4], ee_lin[3], ee_ang[3], grip_q, joints[8];
+  int proprio;
+  double block_pos[3], block_orn[4], block_vel[3], drawer_y, door_q, button_q, dial_q;
+} rpo_readings;
+
+rpo_env* rpo_create(int kind /*0 U, 1 R, 2 P*/, unsigned long long seed, int env_index);
+void rpo_destroy(rpo_env*);
+int rpo_nv(const rpo_env*);
+int rpo_n_arm(const rpo_env*);
+
+/* playEnv.reset(o=None) (environments.py:173-187).  If `u` is non-NULL the uniforms are taken from it in the
+ * order np.random would be consumed (returns how many were used), else from the counter RNG. */
+int rpo_reset(rpo_env*, const double* u, int n_u, rpo_obs* out);
+void rpo_reset_samples(const rpo_env*, const double* u, double* block_pos, double* arm_target);
+/* instance.reset_goal_pos(goal) (environments.py:492-516). goal may be NULL. */
+void rpo_reset_goal(rpo_env*, const double* goal, const double* u, int n_u);
+/* playEnv.step (environments.py:206-214) */
+void rpo_step(rpo_env*, const double* action, rpo_obs* out, double* reward, int* is_success, double* target_poses);
+void rpo_calc_state(rpo_env*, rpo_obs* out);
+double rpo_compute_reward(const rpo_env*, const double* ag, const double* dg);
+void rpo_read_world(rpo_env*, rpo_readings*);
+void rpo_assemble_obs(rpo_env*, const rpo_readings*, rpo_obs* out);   /* stateful in play mode (quaternion memory) */
+void rpo_quat_from_euler(const double* rpy, double* q);
+void rpo_euler_from_quat(const double* q, double* rpy);
+double rpo_dial_to_0_1_range(double x);
+
+/* pieces, exposed for unit tests and goldens */
+void rpo_perform_action(rpo_env*, const double* action_clipped, double* target_poses);   /* environments.py:915-1073 */
+void rpo_goto_joint_poses(rpo_env*, const double* joint_poses, int has_gripper, double gripper, double* target_poses);
+void rpo_ik(const rpo_env*, const double* pos, const double* quat, const double* q_seed, int max_iter, double* q_out);
+void rpo_calc_angles(const rpo_env*, const double* pos, const double* quat, const double* current, double* q_out); /* inverseKinematics.py:44-50 */
+void rpo_substep(rpo_env*);                                /* one stepSimulation() */
+void rpo_run_simulation(rpo_env*);                         /* environments.py:485-490 */
+
+/* raw state access: q[n_arm] qd[n_arm] | per free body pos3 quat4 vel3 omega3 | joint1 q, qd */
+int rpo_state_size(const rpo_env*);
+void rpo_get_state(const rpo_env*, double* s);
+void rpo_set_state(rpo_env*, const double* s);
+void rpo_get_motor(const rpo_env*, int* mode, double* target, double* maximp);
+void rpo_set_goal(rpo_env*, const double* goal);
+void rpo_clear_quat_memory(rpo_env*);
+
+/* kinematics/dynamics probes */
+void rpo_site_pose(const rpo_env*, int site, double* pos, double* quat, double* linvel, double* angvel);
+void rpo_mass_matrix_inv(rpo_env*, double* Minv /* nv*nv, arm block via unit impulse responses */);
+void rpo_forward_dynamics(rpo_env*, double* qdd /* n_arm */);
+int rpo_contacts(rpo_env*, double* out /* per contact: colA colB px py pz nx ny nz dist */, int max);
+int rpo_last_num_rows(const rpo_env*);
+int rpo_box_box(const double* ca, const double* Ra, const double* ha, const double* cb, const double* Rb, const double* hb,
+                double margin, double* out /* per point: p3 n3 dist */);
+double rpo_rng_uniform(unsigned long long seed, unsigned env_index, unsigned counter);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

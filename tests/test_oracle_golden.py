@@ -1,0 +1,190 @@
+"""CPU oracle vs the reference's own harness arithmetic (tests/golden/*.json, made by executing the reference's
+Python against a recording fake client — tests/golden/make_goldens.py).  No GPU."""
+import numpy as np
+import pytest
+
+from oracle import OracleEnv, quat_from_euler, euler_from_quat, dial_to_0_1_range
+
+DT = 1.0 / 300.0
+F32_KEYS = ('obs_quat', 'achieved_goal', 'desired_goal', 'controllable_achieved_goal', 'full_positional_state')
+EE = {'U': 7, 'R': 7, 'P': 11}
+GRIP_JOINT = {'U': '18', 'R': '18', 'P': '9'}
+
+
+def readings_from_world(kind, w):
+    ee = w['link'][str(EE[kind])]
+    kw = dict(ee_pos=ee['pos'], ee_orn=ee['orn'], ee_lin=ee['lin'], ee_ang=ee['ang'], grip_q=w['joint'][GRIP_JOINT[kind]],
+              joints=[w['joint'][str(j)] for j in range(8)])
+    ray = w['ray']
+    if kind == 'P':
+        kw['proprio'] = -1
+    else:   # environments.py:736: nothing in hand if the ray misses or hits a pad
+        kw['proprio'] = 0 if (ray['fraction'] == 1.0 or ray['link'] in (18, 20)) else 1
+    if 'block0' in w['base']:
+        b = w['base']['block0']
+        kw.update(block_pos=b['pos'], block_orn=b['orn'], block_vel=b['lin'])
+    if kind == 'U':
+        kw.update(drawer_y=w['base']['drawer']['pos'][1], door_q=w['joint']['door'], button_q=w['joint']['button'],
+                  dial_q=w['joint']['dial'])
+    return kw
+
+
+def check_obs(got, want, tol=0.0):
+    for k, spec in want.items():
+        if spec is None:
+            assert got[k] is None
+            continue
+        v = spec['v']
+        if k in F32_KEYS:
+            assert spec['dtype'] == 'float32'
+            np.testing.assert_array_equal(np.asarray(got[k], dtype=np.float32), np.asarray(v, dtype=np.float32), err_msg=k)
+        elif k == 'gripper_proprioception':
+            assert int(got[k]) == int(v)
+        else:
+            g = np.asarray(got[k], dtype=np.float64)
+            np.testing.assert_allclose(g, np.asarray(v, dtype=np.float64), rtol=0, atol=tol, err_msg=k)
+            assert g.shape == np.asarray(v).shape
+
+
+def test_joint_index_table_matches_reference_notebook(golden):
+    t = golden('ur5_joint_index_table.json')
+    lines = [l for l in t['notebook_stdout'].strip().splitlines() if l.strip()]
+    names = [l.split("b'")[1].rstrip("'") for l in lines]
+    assert names == t['dfs_names']
+    assert len(names) == 22
+    assert [i for i, ty in enumerate(t['dfs_types']) if ty != 4] == [0, 1, 2, 3, 4, 5, 10, 12, 13, 15, 18, 20]
+    assert [i for i, ty in enumerate(t['panda_dfs_types']) if ty != 4] == [0, 1, 2, 3, 4, 5, 6, 9, 10]
+
+
+@pytest.mark.parametrize('kind', ['U', 'R', 'P'])
+def test_calc_state_assembly(golden, kind):
+    """obs layout, dtypes, quaternion sign memory, dial mapping, reward (environments.py:799-894)."""
+    for seq in golden('calc_state.json')[kind]:
+        env = OracleEnv(kind)
+        env.set_goal(seq['goal'])
+        for step in seq['steps']:
+            got = env.assemble_obs(**readings_from_world(kind, step['world']))
+            # 'observation' passes through atan2/asin: allow 1 ulp-class differences between libm and python math
+            check_obs(got, step['obs'], tol=1e-12)
+            r = env.compute_reward(np.float32(got['achieved_goal']), np.float32(got['desired_goal']))
+            assert r == pytest.approx(step['reward'], abs=1e-7)
+
+
+@pytest.mark.parametrize('kind', ['U', 'R', 'P'])
+def test_action_to_motor_targets(golden, kind):
+    """clip -> rpy->quat -> IK call args -> joint clamps -> motor commands (environments.py:206-208, 955-1073)."""
+    high = np.array([6, 6, 6, 6, 6, 6, 1.0])
+    n_arm_j = 7 if kind == 'P' else 6
+    for case in golden('step.json')[kind]:
+        env = OracleEnv(kind)
+        a = np.clip(np.array(case['action']), -high, high)
+        w = case['world']
+        s = env.get_state()
+        bullet_dofs = [0, 1, 2, 3, 4, 5, 10, 12, 13, 15, 18, 20] if kind != 'P' else [0, 1, 2, 3, 4, 5, 6, 9, 10]
+        for d, j in enumerate(bullet_dofs):
+            s[d] = w['joint'][str(j)]
+        env.set_state(s)
+        ik_log = case['shadow_log'] if kind != 'P' else case['main_log']
+        ik_calls = [e for e in ik_log if e['fn'] == 'calculateInverseKinematics']
+        assert len(ik_calls) == (4 if kind != 'P' else 1)
+        for c in ik_calls:
+            np.testing.assert_allclose(c['args'][2], a[:3], atol=0)
+            np.testing.assert_allclose(c['args'][3], quat_from_euler(a[3:6]), atol=1e-15)
+        if kind != 'P':      # calc_angles seeds the shadow arm with the measured joints (inverseKinematics.py:46)
+            first = [e for e in case['shadow_log'] if e['fn'] == 'resetJointState'][:6]
+            np.testing.assert_array_equal([e['args'][2] for e in first], s[:6])
+        else:
+            assert ik_calls[0]['kwargs'] == {'maxNumIterations': 200}
+        tp = env.goto_joint_poses(np.array(case['ik_returns'][-1])[:n_arm_j], gripper=a[6])
+        np.testing.assert_allclose(tp, case['target_poses'], rtol=0, atol=1e-15)
+        arr = [e for e in case['main_log'] if e['fn'] == 'setJointMotorControlArray'][0]
+        np.testing.assert_allclose(tp, arr['kwargs']['targetPositions'], rtol=0, atol=1e-15)
+        mode, tgt, maximp = env.get_motor()
+        for d in range(n_arm_j):
+            assert mode[d] == 1 and maximp[d] == pytest.approx(240.0 * DT, rel=1e-15)
+        singles = [e for e in case['main_log'] if e['fn'] == 'setJointMotorControl2']
+        assert len(singles) == (2 if kind == 'P' else 6)
+        for e in singles:
+            d = bullet_dofs.index(e['args'][1])
+            assert mode[d] == 1
+            assert tgt[d] == pytest.approx(e['args'][3], abs=1e-15)
+            assert maximp[d] == pytest.approx(e['kwargs']['force'] * DT, rel=1e-15)
+        assert sum(1 for e in case['main_log'] if e['fn'] == 'stepSimulation') == 12
+        assert case['done'] is False
+        assert case['is_success'] == (0 if case['reward'] < 0 else 1)
+
+
+def test_rewards_and_dial(golden):
+    g = golden('rewards.json')
+    env = OracleEnv('U')
+    for row in g['success_func']:
+        assert env.compute_reward(row['ag'], row['g']) == row['r']
+    assert {r['r'] for r in g['success_func']} == {0, -1}
+    for kind in ('R', 'P'):
+        env = OracleEnv(kind)
+        for row in g['sparse'][kind]['single']:
+            assert env.compute_reward(row['ag'], row['dg']) == pytest.approx(row['r'], abs=1e-15)
+        b = g['sparse'][kind]['batch']
+        got = [env.compute_reward(a, d) for a, d in zip(b['ag'], b['dg'])]
+        np.testing.assert_allclose(got, b['r'], atol=1e-15)
+    for row in g['dial']:
+        assert dial_to_0_1_range(row['x']) == pytest.approx(row['y'], abs=1e-15)
+    assert dial_to_0_1_range(1.0) == pytest.approx(dial_to_0_1_range(3.0))     # (x mod 2)/2.2 quirk
+
+
+@pytest.mark.parametrize('kind', ['U', 'R', 'P'])
+def test_reset_sampling(golden, kind):
+    """which uniforms reset() draws, in which order, and where they land (environments.py:492-603)."""
+    for case in golden('reset.json')[kind]:
+        draws = case['draws']
+        per_loop = {'U': ['uniform', 'uniform', 'uniform', 'choice', 'random'], 'R': ['uniform', 'uniform'],
+                    'P': ['uniform', 'uniform', 'uniform']}[kind]
+        assert [d['fn'] for d in draws][:len(per_loop)] == per_loop
+        u = []
+        for d in draws[:len(per_loop)]:
+            u += d['u'] if isinstance(d['u'], list) else [d['u']]
+        env = OracleEnv(kind)
+        block, target = env.reset_samples(u)
+        log = case['log']
+        if kind != 'R':
+            spawn = [e for e in log if e['fn'] == 'resetBasePositionAndOrientation' and e['args'][2] == [0.0, 0.0, 0.7071, 0.7071]][0]
+            np.testing.assert_allclose(block[:3], spawn['args'][1], rtol=0, atol=1e-15)
+        ik = [e for e in log if e['fn'] == 'calculateInverseKinematics'][0]
+        np.testing.assert_allclose(target, ik['args'][2], rtol=0, atol=1e-15)
+        assert ik['args'][3] == [0.0, 0.0, 0.0, 1.0]
+        assert [e['n'] for e in log if e['fn'] == 'stepSimulation_x'][0] == 100
+        # the whole reset on the oracle consumes draws in whole attempts
+        env.reset(u=np.tile(u, 16))
+        assert env.last_used % len(u) == 0 and env.last_used >= len(u)
+        if kind == 'U':
+            # play goal = float32 achieved_goal with one index bumped (environments.py:511-516)
+            ag = np.array(case['obs']['achieved_goal']['v'], dtype=np.float32)
+            assert len(draws) % 5 == 0                       # whole attempts; the goal comes from the last one
+            idx = int(draws[-2]['u'] * 11)
+            want = ag.copy()
+            want[idx] = np.float32(want[idx] + np.float32(draws[-1]['u']))
+            np.testing.assert_array_equal(np.array(case['goal'], dtype=np.float32), want)
+            env2 = OracleEnv('U')
+            env2.reset_goal_pos(None, u=[0.1, 0.2, 0.3, draws[-2]['u'], draws[-1]['u']])
+            o = env2.calc_state()
+            want2 = np.float32(o['achieved_goal']).copy()
+            want2[idx] = np.float32(want2[idx] + np.float32(draws[-1]['u']))
+            np.testing.assert_array_equal(np.float32(o['desired_goal']), want2)
+
+
+def test_euler_quaternion_identities():
+    """getQuaternionFromEuler / getEulerFromQuaternion pinned analytically, not by the stub."""
+    from urdf_tree import rpy_to_mat
+    rng = np.random.default_rng(3)
+    for _ in range(50):
+        rpy = rng.uniform([-3.1, -1.5, -3.1], [3.1, 1.5, 3.1])
+        q = quat_from_euler(rpy)
+        assert abs(np.linalg.norm(q) - 1) < 1e-14
+        x, y, z, w = q
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                      [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        np.testing.assert_allclose(R, rpy_to_mat(rpy), atol=1e-14)       # fixed-axis XYZ = Rz Ry Rx
+        np.testing.assert_allclose(euler_from_quat(q), rpy, atol=1e-12)
+    np.testing.assert_allclose(quat_from_euler([0, 0, np.pi / 2]), [0, 0, np.sqrt(0.5), np.sqrt(0.5)], atol=1e-15)
+    np.testing.assert_allclose(euler_from_quat([0, np.sqrt(0.5), 0, np.sqrt(0.5)]), [0, np.pi / 2, 0], atol=1e-12)   # gimbal branch
