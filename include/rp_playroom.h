@@ -1,0 +1,108 @@
+/* rp_playroom.h — C ABI of the MI355X-native batched playroom simulator (librp_playroom_hip.so).
+ *
+ * This is the drop-in boundary of SURVEY.md §8b.  The reference has no FFI of its own: its hot path calls the
+ * PyBullet client (third-party, CPU) from Python.  Each entry point below REPLACES a group of those calls for N
+ * environments at once; the reference interface it stands in for is cited per function
+ * (ENV = roboticsPlayroomPybullet/envs/environments.py, IKS = inverseKinematics.py, RWD = playRewardFunc.py).
+ *
+ * Conventions
+ *   - plain C, no C++ types, no exceptions; every function returns 0 on success or a negative rp_status.
+ *   - all array arguments are DEVICE pointers to caller-owned, contiguous, row-major [N, dim] buffers
+ *     (float32 unless noted), valid until `stream` reaches the call; the library owns only its internal state.
+ *   - a handle is bound to one device, is not thread-safe, and enqueues on the caller's stream
+ *     (pass torch.cuda.current_stream().cuda_stream); `stream` is a hipStream_t passed as void*.
+ *   - no host<->device copies and no synchronisation inside rp_step / rp_reset / rp_compute_reward.
+ *   - per-env numerical blow-ups are not errors: they set status[env] != 0 in rp_out.
+ */
+#ifndef RP_PLAYROOM_H
+#define RP_PLAYROOM_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rp_sim* rp_handle;
+
+enum rp_status { RP_OK = 0, RP_ERR_ARG = -1, RP_ERR_HIP = -2, RP_ERR_UNSUPPORTED = -3, RP_ERR_STATE_SIZE = -4 };
+
+/* registered ids in scope (roboticsPlayroomPybullet/__init__.py:92,66,24) */
+enum rp_env_kind { RP_ENV_UR5_PLAY_ABS_RPY_1OBJ = 0, RP_ENV_UR5_REACH = 1, RP_ENV_PANDA_PICK = 2 };
+
+typedef struct rp_config {
+  int32_t env_kind;      /* rp_env_kind */
+  int32_t num_envs;      /* N */
+  int32_t device;        /* HIP device ordinal */
+  int32_t env_offset;    /* global index of env 0 of this handle (multi-GPU shards: rank * N); keys the per-env RNG */
+  uint64_t seed;         /* counter RNG: u = f(seed, env_offset + env, draw#) — shard-invariant */
+} rp_config;
+
+/* per-kind output widths */
+typedef struct rp_dims {
+  int32_t obs_quat, achieved_goal, desired_goal, controllable_achieved_goal, full_positional_state, joints, velocity,
+      observation, target_poses, action;
+} rp_dims;
+
+/* outputs of one step / reset: the reference's obs dict (ENV:849-861) + reward/info (ENV:211-214). NULL = skip. */
+typedef struct rp_out {
+  float* obs_quat;                   /* [N, dims.obs_quat] */
+  float* achieved_goal;              /* [N, dims.achieved_goal] */
+  float* desired_goal;               /* [N, dims.desired_goal] */
+  float* controllable_achieved_goal; /* [N, 4] */
+  float* full_positional_state;      /* [N, dims.full_positional_state] */
+  float* joints;                     /* [N, 8] */
+  float* velocity;                   /* [N, 6] */
+  float* observation;                /* [N, dims.observation] */
+  int32_t* gripper_proprioception;   /* [N] */
+  float* reward;                     /* [N] */
+  int32_t* is_success;               /* [N] */
+  float* target_poses;               /* [N, dims.target_poses]; written by rp_step only */
+  int32_t* status;                   /* [N] 0 ok, 1 non-finite state detected */
+} rp_out;
+
+typedef struct rp_timers {
+  float last_step_ms;    /* device time of the most recent rp_step kernel (hipEvent pair on the call's stream) */
+  float last_reset_ms;
+  uint64_t steps;        /* rp_step calls so far */
+} rp_timers;
+
+/* gym.make(id) + playEnv.__init__ + activate_physics_client (ENV:64-170, 218-249): builds N identical worlds. */
+int rp_create(const rp_config* cfg, rp_handle* out);
+int rp_destroy(rp_handle h);
+int rp_get_dims(rp_handle h, rp_dims* dims);
+
+/* playEnv.reset(o=None) (ENV:173-187) for every env whose mask byte is non-zero (mask NULL = all):
+ * resample block / arm / goal, 100 settle substeps, repeat while the goal is already satisfied. */
+int rp_reset(rp_handle h, const uint8_t* mask, const rp_out* out, void* stream);
+
+/* playEnv.reset_goal_pos(goal) (ENV:190-191, 492-516). goal [N, dims.desired_goal] or NULL (random goal).
+ * Play envs then overwrite the goal with a random perturbation of the achieved goal, as the reference does. */
+int rp_reset_goal(rp_handle h, const float* goal, const uint8_t* mask, void* stream);
+
+/* playEnv.step(action) (ENV:206-214): clip -> absolute_rpy IK (IKS:44-50 / ENV:995-997) -> motor targets
+ * (ENV:1010-1073) -> 12 x stepSimulation at 300 Hz (ENV:485-490) -> calc_state (ENV:799-864) -> reward.
+ * action [N, 7] = x y z roll pitch yaw gripper. */
+int rp_step(rp_handle h, const float* action, const rp_out* out, void* stream);
+
+/* instance.calc_state() without stepping (ENV:799-864); updates the quaternion sign memory like the reference. */
+int rp_calc_state(rp_handle h, const rp_out* out, void* stream);
+
+/* playEnv.compute_reward(achieved_goal, desired_goal) (ENV:278-304, RWD:66-77) for M rows. */
+int rp_compute_reward(rp_handle h, const float* achieved_goal, const float* desired_goal, float* reward, int32_t m, void* stream);
+
+/* full simulator state (positions, velocities, motor targets, goal, quaternion memory, RNG counters): the
+ * explicit save/restore the reference lacks.  src_env_count == 1 broadcasts one env to all N. */
+size_t rp_state_bytes(rp_handle h);           /* bytes per env */
+int rp_get_state(rp_handle h, void* dst, void* stream);
+int rp_set_state(rp_handle h, const void* src, int32_t src_env_count, void* stream);
+
+int rp_get_timers(rp_handle h, rp_timers* t);
+int rp_enable_timers(rp_handle h, int32_t on);
+const char* rp_last_error(rp_handle h);
+const char* rp_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

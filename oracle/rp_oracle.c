@@ -39,7 +39,8 @@
 #define IK_DAMP ((real)0.1)
 #define IK_RESIDUAL ((real)1e-4)
 #define IK_MAX_STEP ((real)(45.0 * 3.14159265358979323846 / 180.0))
-#define MAX_CONTACTS 96
+#define MAX_CONTACTS 32
+#define MAX_ACTIVE_PAIRS 64
 #define MAX_ROWS (RP_MAX_ARM * 3 + RP_MAX_J1 + 2 + 3 * MAX_CONTACTS)
 #define NB_MAX (1 + RP_MAX_ARM + RP_MAX_FREE + RP_MAX_J1)
 
@@ -373,18 +374,29 @@ static int manifold_replace_index(const contact* c4, const contact* pt) {
 
 /* Candidate pairs are sorted so the collider pairs of one object pair are contiguous: one manifold of <= 4 points
  * per object pair, as Bullet keeps per collision-object pair.  A rotation-locked free body (the drawer, H5) against
- * the static world keeps only its deepest point: all its points share one Jacobian. */
+ * the static world keeps only its deepest point: all its points share one Jacobian.  Caps (shared with the HIP
+ * library): the first 64 AABB-overlapping pairs are examined, the first 32 contact points are kept. */
 static void collide(rpo_env* e) {
   const rp_model* m = &e->m;
   e->ncon = 0;
-  int man_start = 0, man_oa = -1, man_ob = -1;
-  for (int pi = 0; pi < m->n_pair; pi++) {
-    int a = m->pair[pi][0], b = m->pair[pi][1];
-    if (m->col_obj[a] != man_oa || m->col_obj[b] != man_ob) { man_start = e->ncon; man_oa = m->col_obj[a]; man_ob = m->col_obj[b]; }
+  contact man[4]; int nman = 0, man_oa = -1, man_ob = -1, nactive = 0;
+  for (int pi = 0; pi <= m->n_pair; pi++) {
+    int a = 0, b = 0, flush = (pi == m->n_pair);
+    if (!flush) {
+      a = m->pair[pi][0]; b = m->pair[pi][1];
+      if (m->col_obj[a] != man_oa || m->col_obj[b] != man_ob) flush = 1;
+    }
+    if (flush) {
+      for (int i = 0; i < nman && e->ncon < MAX_CONTACTS; i++) e->con[e->ncon++] = man[i];
+      nman = 0;
+      if (pi == m->n_pair) break;
+      man_oa = m->col_obj[a]; man_ob = m->col_obj[b];
+    }
     int sep = 0;
     for (int k = 0; k < 3; k++)
       if (e->aabb_lo[a][k] > e->aabb_hi[b][k] + CONTACT_MARGIN || e->aabb_lo[b][k] > e->aabb_hi[a][k] + CONTACT_MARGIN) sep = 1;
     if (sep) continue;
+    if (nactive++ >= MAX_ACTIVE_PAIRS) continue;
     cpoint pts[4]; int np = 0;
     real ha[3], hb[3];
     for (int k = 0; k < 3; k++) { ha[k] = (real)m->col_he[a][k]; hb[k] = (real)m->col_he[b][k]; }
@@ -402,14 +414,13 @@ static void collide(rpo_env* e) {
       v3cpy(c.p, pts[i].p); v3cpy(c.n, pts[i].n);
       c.dist = pts[i].dist;
       c.mu = (real)(m->col_friction[a] * m->col_friction[b]);
-      int have = e->ncon - man_start;
       if (single) {
-        if (have == 0) e->con[e->ncon++] = c;
-        else if (c.dist < e->con[man_start].dist) e->con[man_start] = c;
-      } else if (have < 4) {
-        if (e->ncon < MAX_CONTACTS) e->con[e->ncon++] = c;
+        if (nman == 0) man[nman++] = c;
+        else if (c.dist < man[0].dist) man[0] = c;
+      } else if (nman < 4) {
+        man[nman++] = c;
       } else {
-        e->con[man_start + manifold_replace_index(&e->con[man_start], &c)] = c;
+        man[manifold_replace_index(man, &c)] = c;
       }
     }
   }

@@ -1,0 +1,85 @@
+"""ctypes binding of the C ABI in include/rp_playroom.h (librp_playroom_hip.so, built in-tree for gfx950).
+
+There is no CPU fallback: if the HIP library is missing or fails to load, every entry point raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB_PATH = os.path.join(CSRC, 'librp_playroom_hip.so')
+
+ENV_KINDS = {'UR5PlayAbsRPY1Obj-v0': 0, 'UR5Reach-v0': 1, 'pandaPick-v0': 2}
+
+
+class RpConfig(C.Structure):
+    _fields_ = [('env_kind', C.c_int32), ('num_envs', C.c_int32), ('device', C.c_int32), ('env_offset', C.c_int32),
+                ('seed', C.c_uint64)]
+
+
+class RpDims(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ('obs_quat', 'achieved_goal', 'desired_goal', 'controllable_achieved_goal',
+                                         'full_positional_state', 'joints', 'velocity', 'observation', 'target_poses', 'action')]
+
+
+class RpOut(C.Structure):
+    _fields_ = [('obs_quat', C.c_void_p), ('achieved_goal', C.c_void_p), ('desired_goal', C.c_void_p),
+                ('controllable_achieved_goal', C.c_void_p), ('full_positional_state', C.c_void_p), ('joints', C.c_void_p),
+                ('velocity', C.c_void_p), ('observation', C.c_void_p), ('gripper_proprioception', C.c_void_p),
+                ('reward', C.c_void_p), ('is_success', C.c_void_p), ('target_poses', C.c_void_p), ('status', C.c_void_p)]
+
+
+class RpTimers(C.Structure):
+    _fields_ = [('last_step_ms', C.c_float), ('last_reset_ms', C.c_float), ('steps', C.c_uint64)]
+
+
+EXPORTS = ['rp_create', 'rp_destroy', 'rp_get_dims', 'rp_reset', 'rp_reset_goal', 'rp_step', 'rp_calc_state',
+           'rp_compute_reward', 'rp_state_bytes', 'rp_get_state', 'rp_set_state', 'rp_get_timers', 'rp_enable_timers',
+           'rp_last_error', 'rp_version']
+
+_lib = None
+
+
+def build(force=False):
+    """Compile the HIP library in-tree (hipcc --offload-arch=gfx950); cross-compiles without a GPU."""
+    if force or not os.path.exists(LIB_PATH):
+        subprocess.run(['make', '-C', CSRC, '-s'], check=True)
+    return LIB_PATH
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError('librp_playroom_hip.so is not built (%s). Run `python -c "import __graft_entry__ as g; g.build()"` '
+                           'or `make -C roboticsplayroompybullet_amd/csrc`. There is no CPU fallback.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    lib.rp_create.argtypes = [C.POINTER(RpConfig), C.POINTER(vp)]
+    lib.rp_destroy.argtypes = [vp]
+    lib.rp_get_dims.argtypes = [vp, C.POINTER(RpDims)]
+    lib.rp_reset.argtypes = [vp, vp, C.POINTER(RpOut), vp]
+    lib.rp_reset_goal.argtypes = [vp, vp, vp, vp]
+    lib.rp_step.argtypes = [vp, vp, C.POINTER(RpOut), vp]
+    lib.rp_calc_state.argtypes = [vp, C.POINTER(RpOut), vp]
+    lib.rp_compute_reward.argtypes = [vp, vp, vp, vp, C.c_int32, vp]
+    lib.rp_state_bytes.argtypes = [vp]
+    lib.rp_state_bytes.restype = C.c_size_t
+    lib.rp_get_state.argtypes = [vp, vp, vp]
+    lib.rp_set_state.argtypes = [vp, vp, C.c_int32, vp]
+    lib.rp_get_timers.argtypes = [vp, C.POINTER(RpTimers)]
+    lib.rp_enable_timers.argtypes = [vp, C.c_int32]
+    lib.rp_last_error.argtypes = [vp]
+    lib.rp_last_error.restype = C.c_char_p
+    lib.rp_version.restype = C.c_char_p
+    lib.rp_debug_substep.argtypes = [vp, C.c_int32, C.POINTER(C.c_float)]
+    _lib = lib
+    return lib
+
+
+def check(lib, handle, code, what):
+    if code != 0:
+        msg = lib.rp_last_error(handle)
+        raise RuntimeError('%s failed (%d): %s' % (what, code, msg.decode() if msg else ''))

@@ -1,0 +1,1389 @@
+/* rp_kernels.cuh — the batched playroom env-step for gfx950 (MI355X), hand-written HIP.
+ *
+ * Mapping: ONE ENVIRONMENT PER WAVEFRONT (64 lanes, one 64-thread workgroup).  At N = 4096 that is 4096 waves over
+ * 256 CUs; every per-env decision (contact count, row count, IK convergence) is wave-uniform, so there is no
+ * divergence between environments and all per-env scalars live in SGPRs.  Inside a wave the lanes take turns owning
+ *   bodies (FK) -> colliders (AABBs) -> candidate pairs (broadphase, 64 per sweep) -> active pairs (narrowphase)
+ *   -> manifolds -> arm links (CRBA / RNEA about a per-substep reference point) -> constraint rows (Jacobians,
+ *   M^-1 J^T) -> velocity components (PGS: lane l owns dv[l], row dot products by DPP wave reductions).
+ * All per-env working data (state record, transforms, 12x12 mass matrix + inverse, Jacobian rows) is staged in LDS;
+ * HBM traffic per env-step is one 512 B state record in, one out, plus action and outputs.
+ * The whole env step (IK, motor targets, 12 substeps, observation, reward) is ONE kernel launch.
+ *
+ * What the pieces restate (reference file:line via the CPU oracle, oracle/rp_oracle.c, which tests compare against):
+ *   perform_action/goto/close_gripper  environments.py:915-1073, inverseKinematics.py:44-50
+ *   substep (stepSimulation)           SURVEY.md App. E recollection of Bullet's multibody step (parity unpinned)
+ *   calc_state / rewards               environments.py:746-894, 278-304; playRewardFunc.py:16-77
+ */
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rp_device_model.h"
+#include "rp_math.cuh"
+
+#define NB_MAX (1 + RP_MAX_ARM + RP_MAX_FREE + RP_MAX_J1)
+#define NVP 28               /* padded row stride (nv <= 27) */
+#define MAXC 32              /* contact points kept per env per substep (shared cap with the oracle) */
+#define MAXACT 64            /* AABB-overlapping pairs examined per substep (shared cap with the oracle) */
+#define MAXROWC (3 * MAXC)
+#define MAXSMALL 44          /* arm motors 12 + scene-joint motors 3 + limits 24 + gear 1 (+ pad) */
+
+#define K_DT (1.0f / 300.0f)
+#define K_GRAVITY (-9.8f)
+#define K_NSUB 12
+#define K_NSETTLE 100
+#define K_NITER 50
+#define K_ERP 0.08f
+#define K_SLOP 1e-5f
+#define K_MARGIN 0.005f
+#define K_KP 0.1f
+#define K_DEFMOTOR 1.0f
+#define K_LIMIT_MAXIMP 100.0f
+#define K_LIMIT_ACT 0.1f
+#define K_LIN_DAMP 0.04f
+#define K_ANG_DAMP 0.04f
+#define K_IK_DAMP 0.1f
+#define K_IK_RES 1e-4f
+#define K_IK_MAXSTEP (45.0f * RP_PI_F / 180.0f)
+
+struct __align__(16) EnvLds {
+  float st[RP_REC_FLOATS];
+  float xR[NB_MAX * 9], xp[NB_MAX * 3];
+  float O[4];
+  float S[RP_MAX_ARM * 6];
+  float inert[RP_MAX_ARM * 10], compI[RP_MAX_ARM * 10];
+  float vsp[RP_MAX_ARM * 6], csp[RP_MAX_ARM * 6], fsp[RP_MAX_ARM * 6], Fv[RP_MAX_ARM * 6];
+  float M[144], Minv[144], tau[RP_MAX_ARM];
+  float finv[RP_MAX_FREE * 9];
+  float vstar[32];
+  float aabb[RP_MAX_COL * 6];
+  int act[MAXACT], candn[MAXACT], key[MAXACT], cnt[MAXACT];
+  float conp[MAXC * 3], conn[MAXC * 3], cond[MAXC], conmu[MAXC];
+  int cona[MAXC], conb[MAXC];
+  float srow[MAXSMALL * 8];      /* type, dofA, sign/ratio, rhs, dinv, lo, hi, dofB */
+  float rowS[MAXROWC * 4];       /* rhs, dinv, mu, parent */
+  float lam[MAXSMALL + MAXROWC];
+  union {
+    struct { float cand[MAXACT * 4 * 8]; float man[MAXACT * 4 * 8]; } c;   /* narrowphase scratch */
+    struct { float J[MAXROWC * NVP]; float B[MAXROWC * NVP]; } r;            /* contact rows */
+  } u;
+  float out[128];
+  int ray_link; float ray_t;
+};
+
+/* ------------------------------------------------------------------ small helpers */
+__device__ __forceinline__ int dof_free(const DevModel* m, int k) { return m->n_arm + 6 * k; }
+__device__ __forceinline__ int dof_j1(const DevModel* m, int k) { return m->n_arm + 6 * m->n_free + k; }
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+__device__ __forceinline__ float safe_inv(float d) { return d > 1e-9f ? 1.0f / d : 0.0f; }
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float unif(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ float lane_read(float v, int src_lane_uniform) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane_uniform));
+}
+
+/* sum over lanes 0..31 (lanes 32..63 must hold 0); result in every lane.  DPP butterflies inside rows of 16. */
+__device__ __forceinline__ float wave_sum32(float v) {
+  int x = __float_as_int(v);
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true));            /* quad_perm [1,0,3,2] */
+  x = __float_as_int(v);
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true));            /* quad_perm [2,3,0,1] */
+  x = __float_as_int(v);
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true));           /* row_half_mirror */
+  x = __float_as_int(v);
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, true));           /* row_mirror */
+  return lane_read(v, 0) + lane_read(v, 16);
+}
+
+/* counter RNG shared with the oracle (oracle/rp_oracle.c rpo_rng_uniform) */
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ULL;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+  return x ^ (x >> 31);
+}
+__device__ __forceinline__ float rng_uniform(uint64_t seed, uint32_t env, uint32_t counter) {
+  uint64_t h = splitmix64(seed ^ splitmix64(((uint64_t)env << 32) | counter));
+  return (float)(h >> 40) * (1.0f / 16777216.0f);
+}
+
+/* ------------------------------------------------------------------ kinematics */
+struct Xf { M3 R; V3 p; };
+
+__device__ __forceinline__ Xf joint_compose(const DevModel* m, const Xf& P, int j, float q) {
+  Xf r;
+  M3 Rj = mul(P.R, ldm3(m->arm_jrot[j]));
+  r.p = P.p + mulv(P.R, ld3(m->arm_jpos[j]));
+  V3 ax = ld3(m->arm_axis[j]);
+  if (m->arm_jtype[j] == 0) {
+    r.R = mul(Rj, axis_angle(ax, q));
+  } else {
+    r.R = Rj;
+    r.p = r.p + mulv(Rj, ax) * q;
+  }
+  return r;
+}
+
+/* lane b < nbody computes the world transform of body b from the state record (redundant chain walk, no barriers) */
+__device__ void fk_bodies(const DevModel* m, EnvLds& L, int lane) {
+  if (lane < m->nbody) {
+    Xf x;
+    x.R = ident3(); x.p = mk3(0, 0, 0);
+    int b = lane;
+    if (b >= 1 && b <= m->n_arm) {
+      uint32_t anc = m->arm_anc[b - 1];
+      x.R = ldm3(m->base_rot); x.p = ld3(m->base_pos);
+      for (int j = 0; j < m->n_arm; j++)
+        if ((anc >> j) & 1u) x = joint_compose(m, x, j, L.st[ST_Q + j]);
+    } else if (b > m->n_arm && b <= m->n_arm + m->n_free) {
+      int k = b - 1 - m->n_arm;
+      const float* f = &L.st[ST_FREE + 13 * k];
+      Q4 q = {f[3], f[4], f[5], f[6]};
+      x.R = quat_to_m3(q); x.p = ld3(f);
+    } else if (b > m->n_arm + m->n_free) {
+      int k = b - 1 - m->n_arm - m->n_free;
+      M3 R0 = ldm3(m->j1_rot[k]);
+      V3 ax = ld3(m->j1_axis[k]);
+      x.p = ld3(m->j1_pos[k]);
+      float q = L.st[ST_JQ + k];
+      if (m->j1_type[k] == 0) x.R = mul(R0, axis_angle(ax, q));
+      else { x.R = R0; x.p = x.p + mulv(R0, ax) * q; }
+    }
+    stm3(&L.xR[9 * b], x.R); st3(&L.xp[3 * b], x.p);
+  }
+}
+
+/* joint motion subspaces about the reference point O (the EE body's origin), world axes */
+__device__ void joint_subspaces(const DevModel* m, EnvLds& L, int lane) {
+  if (lane == 0) st3(L.O, ld3(&L.xp[3 * m->site_body[RP_SITE_EE]]));
+  __syncthreads();
+  if (lane < m->n_arm) {
+    V3 O = ld3(L.O);
+    M3 R = ldm3(&L.xR[9 * (1 + lane)]);
+    V3 a = mulv(R, ld3(m->arm_axis[lane]));
+    V6 S;
+    if (m->arm_jtype[lane] == 0) { S.a = a; S.l = cross(ld3(&L.xp[3 * (1 + lane)]) - O, a); }
+    else { S.a = mk3(0, 0, 0); S.l = a; }
+    st6(&L.S[6 * lane], S);
+  }
+}
+
+__device__ __forceinline__ Xf collider_xf(const DevModel* m, const EnvLds& L, int c) {
+  int b = m->col_body[c];
+  M3 Rb = ldm3(&L.xR[9 * b]);
+  Xf x;
+  x.R = mul(Rb, ldm3(m->col_rot[c]));
+  x.p = ld3(&L.xp[3 * b]) + mulv(Rb, ld3(m->col_pos[c]));
+  return x;
+}
+
+__device__ void collider_aabbs(const DevModel* m, EnvLds& L, int lane) {
+  if (lane < m->n_col) {
+    Xf x = collider_xf(m, L, lane);
+    V3 he = ld3(m->col_he[lane]);
+    float e[3];
+    for (int i = 0; i < 3; i++)
+      e[i] = m->col_type[lane] == 0 ? fabsf(x.R.m[3 * i]) * he.x + fabsf(x.R.m[3 * i + 1]) * he.y + fabsf(x.R.m[3 * i + 2]) * he.z : he.x;
+    float* a = &L.aabb[6 * lane];
+    a[0] = x.p.x - e[0]; a[1] = x.p.y - e[1]; a[2] = x.p.z - e[2];
+    a[3] = x.p.x + e[0]; a[4] = x.p.y + e[1]; a[5] = x.p.z + e[2];
+  }
+}
+
+/* ------------------------------------------------------------------ narrowphase (same decisions as oracle box_box) */
+struct CPt { V3 p, n; float dist; };
+
+__device__ int clip_poly(const float (*in)[3], int n, V3 c, V3 u, float h, float sign, float (*out)[3]) {
+  int m_ = 0;
+  for (int i = 0; i < n; i++) {
+    V3 a = ld3(in[i]);
+    V3 b = ld3(in[(i + 1 == n) ? 0 : i + 1]);
+    float da = sign * dot(a - c, u) - h;
+    float db = sign * dot(b - c, u) - h;
+    if (da <= 0.f) { st3(out[m_], a); m_++; }
+    if ((da < 0.f && db > 0.f) || (da > 0.f && db < 0.f)) {
+      float t = da / (da - db);
+      st3(out[m_], a + (b - a) * t);
+      m_++;
+    }
+  }
+  return m_;
+}
+
+__device__ int box_box(V3 ca, const M3& Ra, V3 ha, V3 cb, const M3& Rb, V3 hb, float margin, CPt* out) {
+  V3 A[3] = {col(Ra, 0), col(Ra, 1), col(Ra, 2)}, B[3] = {col(Rb, 0), col(Rb, 1), col(Rb, 2)};
+  float hA[3] = {ha.x, ha.y, ha.z}, hB[3] = {hb.x, hb.y, hb.z};
+  V3 t = ca - cb;
+  float best_s = -1e30f; int best_kind = -1, best_i = 0; V3 best_L = mk3(0, 0, 0);
+  for (int f = 0; f < 6; f++) {
+    V3 Lx = f < 3 ? A[f] : B[f - 3];
+    float ra = 0.f, rb = 0.f;
+    for (int k = 0; k < 3; k++) { ra += hA[k] * fabsf(dot(Lx, A[k])); rb += hB[k] * fabsf(dot(Lx, B[k])); }
+    float s = fabsf(dot(t, Lx)) - ra - rb;
+    if (s > margin) return 0;
+    if (s > best_s) { best_s = s; best_kind = f < 3 ? 0 : 1; best_i = f % 3; best_L = Lx; }
+  }
+  float edge_s = -1e30f; int ei = 0, ej = 0; V3 eL = mk3(0, 0, 0);
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      V3 Lx = cross(A[i], B[j]);
+      float l = norm(Lx);
+      if (l < 1e-6f) continue;
+      Lx = Lx * (1.f / l);
+      float ra = 0.f, rb = 0.f;
+      for (int k = 0; k < 3; k++) { ra += hA[k] * fabsf(dot(Lx, A[k])); rb += hB[k] * fabsf(dot(Lx, B[k])); }
+      float s = fabsf(dot(t, Lx)) - ra - rb;
+      if (s > margin) return 0;
+      if (s > edge_s) { edge_s = s; ei = i; ej = j; eL = Lx; }
+    }
+  if (edge_s > best_s + 0.05f * fabsf(best_s) + 1e-6f) {
+    V3 n = eL;
+    if (dot(n, t) < 0.f) n = -n;
+    V3 pa = ca, pb = cb;
+    for (int k = 0; k < 3; k++) {
+      if (k != ei) pa = pa + A[k] * (dot(n, A[k]) > 0.f ? -hA[k] : hA[k]);
+      if (k != ej) pb = pb + B[k] * (dot(n, B[k]) > 0.f ? hB[k] : -hB[k]);
+    }
+    V3 d = pb - pa;
+    float ab = dot(A[ei], B[ej]), q1 = dot(A[ei], d), q2 = -dot(B[ej], d);
+    float den = 1.f - ab * ab, sa = 0.f, sb = 0.f;
+    if (den > 1e-9f) { sa = (q1 + ab * q2) / den; sb = (ab * q1 + q2) / den; }
+    V3 xa = pa + A[ei] * sa, xb = pb + B[ej] * sb;
+    out[0].dist = dot(xa - xb, n);
+    out[0].p = (xa + xb) * 0.5f;
+    out[0].n = n;
+    return out[0].dist <= margin ? 1 : 0;
+  }
+  V3 cX, cY; const V3 *X, *Y; const float *hX, *hY;
+  if (best_kind == 0) { cX = ca; hX = hA; X = A; cY = cb; hY = hB; Y = B; }
+  else { cX = cb; hX = hB; X = B; cY = ca; hY = hA; Y = A; }
+  V3 nref = best_L;
+  if (dot(nref, cY - cX) < 0.f) nref = -nref;
+  int j = 0; float bj = -1.f;
+  for (int k = 0; k < 3; k++) { float v = fabsf(dot(nref, Y[k])); if (v > bj) { bj = v; j = k; } }
+  float sj = dot(nref, Y[j]) > 0.f ? -1.f : 1.f;
+  int k1 = (j + 1) % 3, k2 = (j + 2) % 3;
+  V3 fc = cY + Y[j] * (sj * hY[j]);
+  float poly[2][16][3];
+  const float sg[4][2] = {{1, 1}, {-1, 1}, {-1, -1}, {1, -1}};
+  for (int v = 0; v < 4; v++) st3(poly[0][v], fc + Y[k1] * (sg[v][0] * hY[k1]) + Y[k2] * (sg[v][1] * hY[k2]));
+  int u1 = (best_i + 1) % 3, u2 = (best_i + 2) % 3, n = 4;
+  n = clip_poly(poly[0], n, cX, X[u1], hX[u1], 1.f, poly[1]);
+  n = clip_poly(poly[1], n, cX, X[u1], hX[u1], -1.f, poly[0]);
+  n = clip_poly(poly[0], n, cX, X[u2], hX[u2], 1.f, poly[1]);
+  n = clip_poly(poly[1], n, cX, X[u2], hX[u2], -1.f, poly[0]);
+  /* reuse poly[1] as the kept list: [v][0..2] point, dist in a side array */
+  float dists[16]; int cnt = 0, deepest = 0;
+  for (int v = 0; v < n; v++) {
+    V3 pv = ld3(poly[0][v]);
+    float dist = dot(pv - cX, nref) - hX[best_i];
+    if (dist > margin) continue;
+    st3(poly[1][cnt], pv - nref * (0.5f * dist));
+    dists[cnt] = dist;
+    if (dist < dists[deepest]) deepest = cnt;
+    cnt++;
+  }
+  V3 nn = best_kind == 1 ? nref : -nref;
+  int outn = cnt <= 4 ? cnt : 4;
+  for (int v = 0; v < outn; v++) {
+    int src = cnt <= 4 ? v : (deepest + (v * cnt) / 4) % cnt;
+    out[v].p = ld3(poly[1][src]); out[v].n = nn; out[v].dist = dists[src];
+  }
+  return outn;
+}
+
+__device__ int sphere_box(V3 cs, float r, V3 cb, const M3& Rb, V3 hb, float margin, int sphere_is_b, CPt* out) {
+  V3 l = tmulv(Rb, cs - cb);
+  float ll[3] = {l.x, l.y, l.z}, cl[3], h[3] = {hb.x, hb.y, hb.z};
+  int inside = 1;
+  for (int k = 0; k < 3; k++) {
+    cl[k] = ll[k];
+    if (cl[k] > h[k]) { cl[k] = h[k]; inside = 0; }
+    if (cl[k] < -h[k]) { cl[k] = -h[k]; inside = 0; }
+  }
+  V3 nl; float dist;
+  if (!inside) {
+    V3 df = mk3(cl[0] - ll[0], cl[1] - ll[1], cl[2] - ll[2]);
+    float len = norm(df);
+    dist = len - r;
+    if (dist > margin) return 0;
+    nl = df * (1.f / len);
+  } else {
+    int k0 = 0; float best = 1e30f;
+    for (int k = 0; k < 3; k++) { float pen = h[k] - fabsf(ll[k]); if (pen < best) { best = pen; k0 = k; } }
+    float n3[3] = {0, 0, 0};
+    n3[k0] = ll[k0] > 0.f ? -1.f : 1.f;
+    cl[k0] = ll[k0] > 0.f ? h[k0] : -h[k0];
+    nl = mk3(n3[0], n3[1], n3[2]);
+    dist = -best - r;
+  }
+  V3 nw = mulv(Rb, nl), pw = mulv(Rb, mk3(cl[0], cl[1], cl[2])) + cb;
+  out[0].p = pw - nw * (0.5f * dist);
+  out[0].n = sphere_is_b ? nw : -nw;
+  out[0].dist = dist;
+  return 1;
+}
+
+/* btPersistentManifold::sortCachedPoints on points stored as 8-float records (p3 n3 dist pad) */
+__device__ int manifold_replace_index(const float* c4, const float* pt) {
+  int deepest = -1; float maxpen = pt[6];
+  for (int i = 0; i < 4; i++) if (c4[8 * i + 6] < maxpen) { deepest = i; maxpen = c4[8 * i + 6]; }
+  float res[4] = {0, 0, 0, 0};
+  V3 P = ld3(pt), p0 = ld3(c4), p1 = ld3(c4 + 8), p2 = ld3(c4 + 16), p3 = ld3(c4 + 24), cr;
+  if (deepest != 0) { cr = cross(P - p1, p3 - p2); res[0] = dot(cr, cr); }
+  if (deepest != 1) { cr = cross(P - p0, p3 - p2); res[1] = dot(cr, cr); }
+  if (deepest != 2) { cr = cross(P - p0, p3 - p1); res[2] = dot(cr, cr); }
+  if (deepest != 3) { cr = cross(P - p0, p2 - p1); res[3] = dot(cr, cr); }
+  int best = 0;
+  for (int i = 1; i < 4; i++) if (res[i] > res[best]) best = i;
+  return best;
+}
+
+/* broadphase + narrowphase + manifolds -> L.con*, returns ncon (wave-uniform) */
+__device__ int collide(const DevModel* m, EnvLds& L, int lane) {
+  /* 1. AABB sweep over the baked candidate pairs, 64 per pass; keep the first MAXACT overlapping, in order */
+  int nact = 0;
+  for (int base = 0; base < m->n_pair; base += 64) {
+    int pi = base + lane;
+    bool ov = false;
+    if (pi < m->n_pair) {
+      int a = m->pair[pi][0], b = m->pair[pi][1];
+      const float* A = &L.aabb[6 * a];
+      const float* Bb = &L.aabb[6 * b];
+      ov = !(A[0] > Bb[3] + K_MARGIN || Bb[0] > A[3] + K_MARGIN || A[1] > Bb[4] + K_MARGIN || Bb[1] > A[4] + K_MARGIN ||
+             A[2] > Bb[5] + K_MARGIN || Bb[2] > A[5] + K_MARGIN);
+    }
+    unsigned long long mask = __ballot(ov);
+    int before = __popcll(mask & ((1ull << lane) - 1ull));
+    if (ov && nact + before < MAXACT) L.act[nact + before] = pi;
+    nact += __popcll(mask);
+    if (nact >= MAXACT) { nact = MAXACT; break; }
+  }
+  __syncthreads();
+  /* 2. narrowphase: one lane per active pair */
+  if (lane < nact) {
+    int pi = L.act[lane];
+    int a = m->pair[pi][0], b = m->pair[pi][1];
+    Xf xa = collider_xf(m, L, a), xb = collider_xf(m, L, b);
+    V3 ha = ld3(m->col_he[a]), hb = ld3(m->col_he[b]);
+    CPt pts[4]; int np = 0;
+    int ta = m->col_type[a], tb = m->col_type[b];
+    if (ta == 0 && tb == 0) np = box_box(xa.p, xa.R, ha, xb.p, xb.R, hb, K_MARGIN, pts);
+    else if (ta == 0 && tb == 1) np = sphere_box(xb.p, hb.x, xa.p, xa.R, ha, K_MARGIN, 1, pts);
+    else if (ta == 1 && tb == 0) np = sphere_box(xa.p, ha.x, xb.p, xb.R, hb, K_MARGIN, 0, pts);
+    for (int i = 0; i < np; i++) {
+      float* c = &L.u.c.cand[(lane * 4 + i) * 8];
+      st3(c, pts[i].p); st3(c + 3, pts[i].n); c[6] = pts[i].dist; c[7] = __int_as_float(pi);
+    }
+    L.candn[lane] = np;
+    L.key[lane] = m->col_obj[a] * 256 + m->col_obj[b];
+  }
+  __syncthreads();
+  /* 3. manifolds: the first lane of each run of equal object pairs merges the run sequentially (<= 4 points) */
+  int mycnt = 0;
+  if (lane < nact) {
+    bool head = lane == 0 || L.key[lane - 1] != L.key[lane];
+    if (head) {
+      float* man = &L.u.c.man[lane * 32];
+      int pi0 = L.act[lane];
+      int a0 = m->pair[pi0][0], b0 = m->pair[pi0][1];
+      int kf = m->col_body[a0] - 1 - m->n_arm;
+      bool single = kf >= 0 && kf < m->n_free && m->free_rot_locked[kf] && m->col_body[b0] == 0;
+      for (int j = lane; j < nact && L.key[j] == L.key[lane]; j++) {
+        for (int i = 0; i < L.candn[j]; i++) {
+          const float* c = &L.u.c.cand[(j * 4 + i) * 8];
+          int dst;
+          if (single) {
+            if (mycnt == 0) dst = mycnt++;
+            else dst = c[6] < man[6] ? 0 : -1;
+          } else if (mycnt < 4) dst = mycnt++;
+          else dst = manifold_replace_index(man, c);
+          if (dst >= 0) for (int k = 0; k < 8; k++) man[8 * dst + k] = c[k];
+        }
+      }
+    }
+    L.cnt[lane] = mycnt;
+  }
+  __syncthreads();
+  int total = 0;
+  if (lane < nact) {
+    int off = 0;
+    for (int j = 0; j < lane; j++) off += L.cnt[j];
+    for (int i = 0; i < mycnt && off + i < MAXC; i++) {
+      const float* c = &L.u.c.man[lane * 32 + 8 * i];
+      int o = off + i;
+      st3(&L.conp[3 * o], ld3(c)); st3(&L.conn[3 * o], ld3(c + 3));
+      L.cond[o] = c[6];
+      int pi = __float_as_int(c[7]);
+      int a = m->pair[pi][0], b = m->pair[pi][1];
+      L.cona[o] = a; L.conb[o] = b;
+      L.conmu[o] = m->col_friction[a] * m->col_friction[b];
+    }
+  }
+  for (int j = 0; j < nact; j++) total += L.cnt[j];     /* nact uniform; LDS broadcast reads */
+  __syncthreads();
+  return total < MAXC ? total : MAXC;
+}
+
+/* ------------------------------------------------------------------ arm dynamics: CRBA mass matrix, RNEA bias, inverse */
+__device__ void arm_dynamics(const DevModel* m, EnvLds& L, int lane) {
+  int n = m->n_arm;
+  V3 O = ld3(L.O);
+  if (lane < n) {      /* own spatial inertia about O: (m, h = m c, Ibar = R Ic R^T - m [c]x^2) */
+    M3 R = ldm3(&L.xR[9 * (1 + lane)]);
+    V3 c = ld3(&L.xp[3 * (1 + lane)]) + mulv(R, ld3(m->arm_com[lane])) - O;
+    float mass = m->arm_mass[lane];
+    M3 Ic = ldm3(m->arm_inertia[lane]);
+    M3 Rt; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Rt.m[3 * i + j] = R.m[3 * j + i];
+    M3 Iw = mul(mul(R, Ic), Rt);
+    float cc = dot(c, c);
+    float* I = &L.inert[10 * lane];
+    I[0] = mass; st3(I + 1, c * mass);
+    I[4] = Iw.m[0] + mass * (cc - c.x * c.x); I[5] = Iw.m[4] + mass * (cc - c.y * c.y); I[6] = Iw.m[8] + mass * (cc - c.z * c.z);
+    I[7] = Iw.m[1] - mass * c.x * c.y; I[8] = Iw.m[2] - mass * c.x * c.z; I[9] = Iw.m[5] - mass * c.y * c.z;
+  }
+  __syncthreads();
+  if (lane < n) {      /* composite inertia of the subtree; spatial velocity from the ancestors */
+    uint32_t sub = m->arm_sub[lane], anc = m->arm_anc[lane];
+    float acc[10];
+    for (int k = 0; k < 10; k++) acc[k] = 0.f;
+    V6 v = zero6();
+    for (int j = 0; j < n; j++) {
+      if ((sub >> j) & 1u) for (int k = 0; k < 10; k++) acc[k] += L.inert[10 * j + k];
+      if ((anc >> j) & 1u) v = v + ld6(&L.S[6 * j]) * L.st[ST_QD + j];
+    }
+    for (int k = 0; k < 10; k++) L.compI[10 * lane + k] = acc[k];
+    st6(&L.vsp[6 * lane], v);
+    V6 Si = ld6(&L.S[6 * lane]);
+    st6(&L.csp[6 * lane], crm(v, Si * L.st[ST_QD + lane]));
+    st6(&L.Fv[6 * lane], inertia_mul(acc, Si));
+  }
+  __syncthreads();
+  for (int e = lane; e < n * n; e += 64) {   /* M_ij = S_i . (Ic_j S_j) for i an ancestor-or-self of j */
+    int i = e / n, j = e % n;
+    if (i <= j) {
+      float val = ((m->arm_anc[j] >> i) & 1u) ? dot6(ld6(&L.S[6 * i]), ld6(&L.Fv[6 * j])) : 0.f;
+      L.M[i * 12 + j] = val; L.M[j * 12 + i] = val;
+    }
+  }
+  if (lane < n) {      /* bias force of each body: f = I a_bias + v x* (I v), a_bias = -g + sum of ancestors' c */
+    uint32_t anc = m->arm_anc[lane];
+    V6 a = zero6();
+    a.l.z = -K_GRAVITY;
+    for (int j = 0; j < n; j++) if ((anc >> j) & 1u) a = a + ld6(&L.csp[6 * j]);
+    V6 v = ld6(&L.vsp[6 * lane]);
+    const float* I = &L.inert[10 * lane];
+    st6(&L.fsp[6 * lane], inertia_mul(I, a) + crf(v, inertia_mul(I, v)));
+  }
+  __syncthreads();
+  if (lane < n) {
+    uint32_t sub = m->arm_sub[lane];
+    V6 f = zero6();
+    for (int j = 0; j < n; j++) if ((sub >> j) & 1u) f = f + ld6(&L.fsp[6 * j]);
+    L.tau[lane] = dot6(ld6(&L.S[6 * lane]), f);
+  }
+  /* Cholesky M = L L^T in place (lower), lane i owns row i */
+  for (int k = 0; k < n; k++) {
+    __syncthreads();
+    float piv = sqrtf(L.M[k * 12 + k]);
+    float lik = 0.f;
+    if (lane > k && lane < n) lik = L.M[lane * 12 + k] / piv;
+    __syncthreads();
+    if (lane == k) L.M[k * 12 + k] = piv;
+    if (lane > k && lane < n) L.M[lane * 12 + k] = lik;
+    __syncthreads();
+    if (lane > k && lane < n)
+      for (int j = k + 1; j <= lane; j++) L.M[lane * 12 + j] -= lik * L.M[j * 12 + k];
+  }
+  __syncthreads();
+  if (lane < n) {      /* column `lane` of M^-1: L y = e_c, L^T x = y */
+    float y[RP_MAX_ARM];
+#pragma unroll
+    for (int i = 0; i < RP_MAX_ARM; i++) {
+      if (i < n) {
+        float s = (i == lane) ? 1.f : 0.f;
+#pragma unroll
+        for (int k = 0; k < i; k++) s -= L.M[i * 12 + k] * y[k];
+        y[i] = s / L.M[i * 12 + i];
+      } else y[i] = 0.f;
+    }
+#pragma unroll
+    for (int i = RP_MAX_ARM - 1; i >= 0; i--) {
+      if (i < n) {
+        float s = y[i];
+#pragma unroll
+        for (int k = i + 1; k < RP_MAX_ARM; k++) if (k < n) s -= L.M[k * 12 + i] * y[k];
+        y[i] = s / L.M[i * 12 + i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < RP_MAX_ARM; i++) if (i < n) L.Minv[i * 12 + lane] = y[i];
+  }
+  __syncthreads();
+}
+
+/* unconstrained velocities v* = v + dt * a for every dof (lane = dof) */
+__device__ void unconstrained_velocities(const DevModel* m, EnvLds& L, int lane) {
+  int n = m->n_arm;
+  float vs = 0.f;
+  if (lane < n) {
+    float qdd = 0.f;
+    for (int k = 0; k < n; k++) qdd -= L.Minv[lane * 12 + k] * L.tau[k];
+    vs = L.st[ST_QD + lane] + K_DT * qdd;
+  } else if (lane < n + 6 * m->n_free) {
+    int k = (lane - n) / 6, c = (lane - n) % 6;
+    const float* f = &L.st[ST_FREE + 13 * k];
+    if (c < 3) {
+      V3 v = ld3(f + 7);
+      float vn = norm(v);
+      vs = comp(v, c) + K_DT * (-(K_LIN_DAMP + K_LIN_DAMP * vn) * comp(v, c)) + (c == 2 ? K_DT * K_GRAVITY : 0.f);
+    } else if (!m->free_rot_locked[k]) {
+      M3 R = ldm3(&L.xR[9 * (1 + n + k)]);
+      V3 w = ld3(f + 10);
+      V3 wl = tmulv(R, w);
+      V3 I = ld3(m->free_inertia[k]);
+      V3 Iw = mk3(I.x * wl.x, I.y * wl.y, I.z * wl.z);
+      V3 g = cross(wl, Iw);
+      float wn = norm(wl), kd = K_ANG_DAMP + K_ANG_DAMP * wn;
+      V3 al = mk3((-g.x - Iw.x * kd) / I.x, (-g.y - Iw.y * kd) / I.y, (-g.z - Iw.z * kd) / I.z);
+      V3 aw = mulv(R, al);
+      vs = comp(w, c - 3) + K_DT * comp(aw, c - 3);
+    }
+  } else if (lane < m->nv) {
+    int k = lane - n - 6 * m->n_free;
+    float qd = L.st[ST_JQD + k];
+    if (m->j1_type[k] == 1) {
+      M3 R = ldm3(&L.xR[9 * (1 + n + m->n_free + k)]);
+      V3 a = mulv(R, ld3(m->j1_axis[k]));
+      vs = qd + K_DT * K_GRAVITY * a.z;
+    } else {
+      vs = qd + K_DT * (-(K_ANG_DAMP + K_ANG_DAMP * fabsf(qd)) * qd);
+    }
+  }
+  if (lane < 32) L.vstar[lane] = lane < m->nv ? vs : 0.f;
+  if (lane < m->n_free) {     /* world inverse inertia of free body `lane` */
+    float* o = &L.finv[9 * lane];
+    if (m->free_rot_locked[lane]) for (int i = 0; i < 9; i++) o[i] = 0.f;
+    else {
+      M3 R = ldm3(&L.xR[9 * (1 + n + lane)]);
+      V3 I = ld3(m->free_inertia[lane]);
+      float ii[3] = {1.f / I.x, 1.f / I.y, 1.f / I.z};
+      for (int r = 0; r < 3; r++) for (int s = 0; s < 3; s++) {
+        float v = 0.f;
+        for (int t = 0; t < 3; t++) v += R.m[3 * r + t] * R.m[3 * s + t] * ii[t];
+        o[3 * r + s] = v;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+/* ------------------------------------------------------------------ constraint rows */
+#define SR_UNIT 0   /* J = sign * e_dofA on an arm dof                 (motors, limits) */
+#define SR_J1 1     /* J = e_dofA on a scene joint                      (door / button / dial motors) */
+#define SR_GEAR 2   /* J = e_dofA + ratio * e_dofB on arm dofs          (Panda finger gear) */
+
+__device__ __forceinline__ void put_srow(EnvLds& L, int r, int type, int dofA, float sign, float rhs, float dinv, float lo, float hi, int dofB) {
+  float* s = &L.srow[8 * r];
+  s[0] = __int_as_float(type); s[1] = __int_as_float(dofA); s[2] = sign; s[3] = rhs; s[4] = dinv; s[5] = lo; s[6] = hi;
+  s[7] = __int_as_float(dofB);
+}
+
+/* returns the number of small rows (wave-uniform) */
+__device__ int build_small_rows(const DevModel* m, EnvLds& L, int lane) {
+  int n = m->n_arm, nr = 0;
+  if (lane < n) {        /* arm motors (btMultiBodyJointMotor) */
+    float dinv = 1.f / L.Minv[lane * 12 + lane];
+    float mode = L.st[ST_MMODE + lane];
+    float des = mode != 0.f ? K_KP * (L.st[ST_MTARGET + lane] - L.st[ST_Q + lane]) / K_DT : 0.f;
+    float mx = L.st[ST_MMAXIMP + lane];
+    put_srow(L, lane, SR_UNIT, lane, 1.f, (des - L.vstar[lane]) * dinv, dinv, -mx, mx, 0);
+  }
+  nr = n;
+  if (lane < m->n_j1) {  /* scene joint motors */
+    int d = dof_j1(m, lane);
+    float minv = m->j1_minv[lane], dinv = 1.f / minv;
+    float des = m->j1_has_pos_motor[lane] ? K_KP * (m->j1_motor_target[lane] - L.st[ST_JQ + lane]) / K_DT : 0.f;
+    float mx = m->j1_motor_maximp[lane];
+    put_srow(L, nr + lane, SR_J1, d, minv, (des - L.vstar[d]) * dinv, dinv, -mx, mx, 0);
+  }
+  nr += m->n_j1;
+  {                      /* joint limits, dof-major, lower before upper */
+    int i = lane >> 1, side = lane & 1;
+    bool on = false; float pen = 0.f;
+    if (lane < 2 * n && m->arm_limited[i]) {
+      float q = L.st[ST_Q + i];
+      pen = side == 0 ? q - m->arm_lower[i] : m->arm_upper[i] - q;
+      on = pen <= K_LIMIT_ACT;
+    }
+    unsigned long long mask = __ballot(on);
+    if (on) {
+      int r = nr + __popcll(mask & ((1ull << lane) - 1ull));
+      float sgn = side == 0 ? 1.f : -1.f;
+      float dinv = 1.f / L.Minv[i * 12 + i];
+      float relv = sgn * L.vstar[i], pos_err = 0.f, vel_err = -relv;
+      if (pen > 0.f) vel_err -= pen / K_DT; else pos_err = -pen * K_ERP / K_DT;
+      put_srow(L, r, SR_UNIT, i, sgn, (pos_err + vel_err) * dinv, dinv, 0.f, K_LIMIT_MAXIMP, 0);
+    }
+    nr += __popcll(mask);
+  }
+  if (m->kind == RP_KIND_P) {   /* finger gear: qd_a + ratio qd_b -> 0 (environments.py:400-405) */
+    if (lane == 0) {
+      int a = m->d9p, b = m->d10p;
+      float ratio = -1.f;
+      float diag = L.Minv[a * 12 + a] + 2.f * ratio * L.Minv[a * 12 + b] + ratio * ratio * L.Minv[b * 12 + b];
+      float dinv = safe_inv(diag);
+      float relv = L.vstar[a] + ratio * L.vstar[b];
+      float pos_err = -(L.st[ST_Q + a] + ratio * L.st[ST_Q + b]) * 0.1f / K_DT;
+      put_srow(L, nr, SR_GEAR, a, ratio, (pos_err - relv) * dinv, dinv, -50.f * K_DT, 50.f * K_DT, b);
+    }
+    nr += 1;
+  }
+  return nr;
+}
+
+/* d(n . v_point)/dv entries for a point p (relative to O) on `body`, accumulated into Jarm[12] / written to the row */
+__device__ void contact_rows(const DevModel* m, EnvLds& L, int lane, int ncon) {
+  int n = m->n_arm, nv = m->nv;
+  V3 O = ld3(L.O);
+  for (int r = lane; r < 3 * ncon; r += 64) {
+    int ci, dir;
+    if (r < ncon) { ci = r; dir = 0; } else { ci = (r - ncon) >> 1; dir = 1 + ((r - ncon) & 1); }
+    V3 nrm = ld3(&L.conn[3 * ci]);
+    V3 p = ld3(&L.conp[3 * ci]);
+    V3 d = nrm;
+    if (dir > 0) {            /* btPlaneSpace1 */
+      V3 t1, t2;
+      if (fabsf(nrm.z) > 0.7071067811865475244f) {
+        float a = nrm.y * nrm.y + nrm.z * nrm.z, k = 1.f / sqrtf(a);
+        t1 = mk3(0.f, -nrm.z * k, nrm.y * k);
+        t2 = mk3(a * k, -nrm.x * t1.z, nrm.x * t1.y);
+      } else {
+        float a = nrm.x * nrm.x + nrm.y * nrm.y, k = 1.f / sqrtf(a);
+        t1 = mk3(-nrm.y * k, nrm.x * k, 0.f);
+        t2 = mk3(-nrm.z * t1.y, nrm.z * t1.x, a * k);
+      }
+      d = dir == 1 ? t1 : t2;
+    }
+    float* J = &L.u.r.J[r * NVP];
+    float* B = &L.u.r.B[r * NVP];
+    for (int k = 0; k < NVP; k++) { J[k] = 0.f; B[k] = 0.f; }
+    float Jarm[RP_MAX_ARM];
+#pragma unroll
+    for (int k = 0; k < RP_MAX_ARM; k++) Jarm[k] = 0.f;
+    bool has_arm = false;
+    float diag = 0.f, relv = 0.f;
+    for (int side = 0; side < 2; side++) {
+      int body = m->col_body[side == 0 ? L.cona[ci] : L.conb[ci]];
+      float sign = side == 0 ? 1.f : -1.f;
+      if (body == 0) continue;
+      if (body <= n) {
+        V6 f; f.a = cross(p - O, d); f.l = d;
+        uint32_t anc = m->arm_anc[body - 1];
+#pragma unroll
+        for (int k = 0; k < RP_MAX_ARM; k++)
+          if (k < n && ((anc >> k) & 1u)) Jarm[k] += sign * dot6(ld6(&L.S[6 * k]), f);
+        has_arm = true;
+      } else if (body <= n + m->n_free) {
+        int k = body - 1 - n, dd = dof_free(m, k);
+        V3 rr = p - ld3(&L.st[ST_FREE + 13 * k]);
+        V3 rxn = cross(rr, d);
+        float im = 1.f / m->free_mass[k];
+        M3 Ii = ldm3(&L.finv[9 * k]);
+        V3 w = mulv(Ii, rxn);
+        float jl[3] = {sign * d.x, sign * d.y, sign * d.z}, ja[3] = {sign * rxn.x, sign * rxn.y, sign * rxn.z};
+        float ba[3] = {sign * w.x, sign * w.y, sign * w.z};
+        for (int i = 0; i < 3; i++) {
+          J[dd + i] = jl[i]; B[dd + i] = jl[i] * im; J[dd + 3 + i] = ja[i]; B[dd + 3 + i] = ba[i];
+          diag += jl[i] * jl[i] * im + ja[i] * ba[i];
+          relv += jl[i] * L.vstar[dd + i] + ja[i] * L.vstar[dd + 3 + i];
+        }
+      } else {
+        int k = body - 1 - n - m->n_free, dd = dof_j1(m, k);
+        M3 R = ldm3(&L.xR[9 * body]);
+        V3 a = mulv(R, ld3(m->j1_axis[k]));
+        float j = m->j1_type[k] == 1 ? sign * dot(d, a) : sign * dot(a, cross(p - ld3(m->j1_pos[k]), d));
+        float minv = m->j1_minv[k];
+        J[dd] = j; B[dd] = j * minv;
+        diag += j * j * minv; relv += j * L.vstar[dd];
+      }
+    }
+    if (has_arm) {
+#pragma unroll
+      for (int i = 0; i < RP_MAX_ARM; i++) {
+        if (i < n) {
+          float b = 0.f;
+#pragma unroll
+          for (int k = 0; k < RP_MAX_ARM; k++) if (k < n) b += L.Minv[i * 12 + k] * Jarm[k];
+          J[i] = Jarm[i]; B[i] = b;
+          diag += Jarm[i] * b; relv += Jarm[i] * L.vstar[i];
+        }
+      }
+    }
+    float dinv = safe_inv(diag), rhs;
+    if (dir == 0) {
+      float pen = L.cond[ci] + K_SLOP, pos_err = 0.f, vel_err = -relv;
+      if (pen > 0.f) vel_err -= pen / K_DT; else pos_err = -pen * K_ERP / K_DT;
+      rhs = (pos_err + vel_err) * dinv;
+    } else rhs = -relv * dinv;
+    float* s = &L.rowS[4 * r];
+    s[0] = rhs; s[1] = dinv; s[2] = L.conmu[ci]; s[3] = __int_as_float(dir == 0 ? -1 : ci);
+  }
+  (void)nv;
+}
+
+/* 50 sweeps of sequential impulses; lane l owns dv[l]; returns dv of this lane */
+__device__ float solve_rows(const DevModel* m, EnvLds& L, int lane, int nsmall, int ncon) {
+  int n = m->n_arm;
+  float dv = 0.f;
+  int nrc = 3 * ncon;
+  for (int r = lane; r < nsmall + nrc; r += 64) L.lam[r] = 0.f;
+  __syncthreads();
+  for (int it = 0; it < K_NITER; it++) {
+    for (int r = 0; r < nsmall; r++) {
+      const float* s = &L.srow[8 * r];
+      int type = uni(__float_as_int(s[0])), dA = uni(__float_as_int(s[1]));
+      float sg = s[2], rhs = s[3], dinv = s[4], lo = s[5], hi = s[6];
+      float lam = L.lam[r];
+      float jdv, bl = 0.f;
+      if (type == SR_UNIT) {
+        jdv = sg * lane_read(dv, dA);
+        if (lane < n) bl = sg * L.Minv[lane * 12 + dA];
+      } else if (type == SR_J1) {
+        jdv = lane_read(dv, dA);
+        if (lane == dA) bl = sg;              /* sg holds 1/m for scene joints */
+      } else {
+        int dB = uni(__float_as_int(s[7]));
+        jdv = lane_read(dv, dA) + sg * lane_read(dv, dB);
+        if (lane < n) bl = L.Minv[lane * 12 + dA] + sg * L.Minv[lane * 12 + dB];
+      }
+      float d = rhs - jdv * dinv;
+      float sum = lam + d;
+      if (sum < lo) { d = lo - lam; sum = lo; } else if (sum > hi) { d = hi - lam; sum = hi; }
+      if (lane == 0) L.lam[r] = sum;
+      dv += bl * d;
+    }
+    for (int r = 0; r < nrc; r++) {
+      float jl = 0.f, bl = 0.f;
+      if (lane < NVP) { jl = L.u.r.J[r * NVP + lane]; bl = L.u.r.B[r * NVP + lane]; }
+      const float* s = &L.rowS[4 * r];
+      float rhs = s[0], dinv = s[1], mu = s[2];
+      int parent = uni(__float_as_int(s[3]));
+      float lam = L.lam[nsmall + r];
+      float lo = 0.f, hi = 1e10f;
+      if (parent >= 0) { float lim = mu * L.lam[nsmall + parent]; lo = -lim; hi = lim; }
+      float jdv = wave_sum32(jl * dv);
+      float d = rhs - jdv * dinv;
+      float sum = lam + d;
+      if (sum < lo) { d = lo - lam; sum = lo; } else if (sum > hi) { d = hi - lam; sum = hi; }
+      if (lane == 0) L.lam[nsmall + r] = sum;
+      dv += bl * d;
+    }
+  }
+  return dv;
+}
+
+/* ------------------------------------------------------------------ one stepSimulation() */
+__device__ void substep(const DevModel* m, EnvLds& L, int lane) {
+  int n = m->n_arm;
+  fk_bodies(m, L, lane);
+  __syncthreads();
+  joint_subspaces(m, L, lane);
+  collider_aabbs(m, L, lane);
+  __syncthreads();
+  int ncon = collide(m, L, lane);
+  arm_dynamics(m, L, lane);
+  unconstrained_velocities(m, L, lane);
+  int nsmall = build_small_rows(m, L, lane);
+  contact_rows(m, L, lane, ncon);
+  __syncthreads();
+  float dv = solve_rows(m, L, lane, nsmall, ncon);
+  __syncthreads();
+  /* apply and integrate (semi-implicit Euler) */
+  float vnew = (lane < 32 ? L.vstar[lane] : 0.f) + dv;
+  if (lane < n) {
+    L.st[ST_QD + lane] = vnew;
+    L.st[ST_Q + lane] += K_DT * vnew;
+  } else if (lane < n + 6 * m->n_free) {
+    int k = (lane - n) / 6, c = (lane - n) % 6;
+    L.st[ST_FREE + 13 * k + 7 + c] = vnew;
+  } else if (lane < m->nv) {
+    int k = lane - n - 6 * m->n_free;
+    L.st[ST_JQD + k] = vnew;
+    L.st[ST_JQ + k] += K_DT * vnew;
+  }
+  __syncthreads();
+  if (lane < m->n_free) {
+    float* f = &L.st[ST_FREE + 13 * lane];
+    V3 v = ld3(f + 7), w = ld3(f + 10);
+    st3(f, ld3(f) + v * K_DT);
+    float wn = norm(w);
+    if (wn > 0.7853981633974483f / K_DT) wn = 0.7853981633974483f / K_DT;
+    V3 ax;
+    if (wn < 0.001f) ax = w * (0.5f * K_DT - K_DT * K_DT * K_DT * 0.020833333333f * wn * wn);
+    else ax = w * (sinf(0.5f * wn * K_DT) / wn);
+    Q4 dq = {ax.x, ax.y, ax.z, cosf(0.5f * wn * K_DT)};
+    Q4 q0 = {f[3], f[4], f[5], f[6]};
+    Q4 qn = qmul(dq, q0);
+    float nr = 1.f / sqrtf(qn.x * qn.x + qn.y * qn.y + qn.z * qn.z + qn.w * qn.w);
+    f[3] = qn.x * nr; f[4] = qn.y * nr; f[5] = qn.z * nr; f[6] = qn.w * nr;
+  }
+  __syncthreads();
+}
+
+/* ------------------------------------------------------------------ inverse kinematics (wave-uniform, registers only) */
+struct ChainQ { float q[7]; };
+
+/* FK of the serial chain base -> EE body with joint values cq; returns EE site pose and fills joint origins/axes */
+__device__ void chain_fk(const DevModel* m, const ChainQ& cq, int nc, V3* org, V3* axw, V3& pos, M3& Rs) {
+  Xf x; x.R = ldm3(m->base_rot); x.p = ld3(m->base_pos);
+#pragma unroll
+  for (int j = 0; j < 7; j++) {
+    if (j < nc) {
+      x = joint_compose(m, x, j, cq.q[j]);
+      org[j] = x.p;
+      axw[j] = mulv(x.R, ld3(m->arm_axis[j]));
+    }
+  }
+  pos = x.p + mulv(x.R, ld3(m->site_pos[RP_SITE_EE]));
+  Rs = mul(x.R, ldm3(m->site_rot[RP_SITE_EE]));
+}
+
+/* damped-least-squares IK, the oracle's ik_solve restricted to the EE chain (the other dofs decouple exactly) */
+__device__ ChainQ ik_solve(const DevModel* m, V3 tpos, Q4 tq, ChainQ q, int max_iter) {
+  int nc = m->ee_chain;
+  for (int it = 0; it < max_iter; it++) {
+    V3 org[7], axw[7], pos; M3 Rs;
+    chain_fk(m, q, nc, org, axw, pos, Rs);
+    V3 ep = tpos - pos;
+    if (it > 0 && norm(ep) < K_IK_RES) break;
+    Q4 qc = m3_to_quat(Rs);
+    Q4 qi = {-qc.x, -qc.y, -qc.z, qc.w};
+    Q4 dq = qmul(tq, qi);
+    float nq = sqrtf(dq.x * dq.x + dq.y * dq.y + dq.z * dq.z + dq.w * dq.w);
+    float w = clampf(dq.w / nq, -1.f, 1.f);
+    float angle = 2.f * acosf(w);
+    float s2 = 1.f - w * w;
+    V3 axis = mk3(1, 0, 0);
+    if (s2 >= 1e-14f) { float s = 1.f / (sqrtf(s2) * nq); axis = mk3(dq.x * s, dq.y * s, dq.z * s); }
+    if (angle > RP_PI_F) angle -= 2.f * RP_PI_F;
+    float err[6] = {ep.x, ep.y, ep.z, angle * axis.x, angle * axis.y, angle * axis.z};
+    float J[6][7];
+#pragma unroll
+    for (int j = 0; j < 7; j++) {
+      V3 lin = mk3(0, 0, 0), ang = mk3(0, 0, 0);
+      if (j < nc) {
+        if (m->arm_jtype[j] == 0) { lin = cross(axw[j], pos - org[j]); ang = axw[j]; }
+        else lin = axw[j];
+      }
+      J[0][j] = lin.x; J[1][j] = lin.y; J[2][j] = lin.z; J[3][j] = ang.x; J[4][j] = ang.y; J[5][j] = ang.z;
+    }
+    float A[7][7], b[7];
+#pragma unroll
+    for (int r = 0; r < 7; r++) {
+#pragma unroll
+      for (int c = 0; c < 7; c++) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 6; k++) s += J[k][r] * J[k][c];
+        A[r][c] = s + (r == c ? K_IK_DAMP : 0.f);
+      }
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 6; k++) s += J[k][r] * err[k];
+      b[r] = s;
+    }
+    /* SPD solve without pivoting (rows/cols >= nc are 0.1 I / 0 and stay decoupled) */
+#pragma unroll
+    for (int c = 0; c < 7; c++) {
+      float inv = 1.f / A[c][c];
+#pragma unroll
+      for (int r = c + 1; r < 7; r++) {
+        float f = A[r][c] * inv;
+#pragma unroll
+        for (int k = c; k < 7; k++) A[r][k] -= f * A[c][k];
+        b[r] -= f * b[c];
+      }
+    }
+#pragma unroll
+    for (int r = 6; r >= 0; r--) {
+      float s = b[r];
+#pragma unroll
+      for (int k = r + 1; k < 7; k++) s -= A[r][k] * b[k];
+      b[r] = s / A[r][r];
+    }
+    float mx = 0.f;
+#pragma unroll
+    for (int j = 0; j < 7; j++) mx = fmaxf(mx, fabsf(b[j]));
+    float sc = mx > K_IK_MAXSTEP ? K_IK_MAXSTEP / mx : 1.f;
+#pragma unroll
+    for (int j = 0; j < 7; j++) q.q[j] += sc * b[j];
+  }
+  return q;
+}
+
+/* perform_action('absolute_rpy') .. close_gripper (environments.py:915-1073); every lane computes the same values,
+ * lane 0 writes the motor commands into the state record.  Returns the target poses. */
+__device__ ChainQ perform_action(const DevModel* m, EnvLds& L, int lane, const float* a7) {
+  V3 tpos = mk3(a7[0], a7[1], a7[2]);
+  Q4 tq = quat_from_euler(a7[3], a7[4], a7[5]);
+  int nd = m->n_target;
+  ChainQ cur;
+#pragma unroll
+  for (int j = 0; j < 7; j++) cur.q[j] = j < m->ee_chain ? L.st[ST_Q + j] : 0.f;
+  ChainQ sol;
+  if (m->kind == RP_KIND_P) sol = ik_solve(m, tpos, tq, cur, 200);
+  else {   /* InverseKinematicsSolver.calc_angles: 4 chained default IK solves from the measured joints */
+    sol = cur;
+    for (int rep = 0; rep < 4; rep++) sol = ik_solve(m, tpos, tq, sol, 20);
+  }
+  ChainQ tp;
+#pragma unroll
+  for (int j = 0; j < 7; j++) {
+    tp.q[j] = 0.f;
+    if (j < nd) {
+      float t = clampf(sol.q[j], m->ll[j], m->ul[j]);
+      float c = L.st[ST_Q + j];
+      tp.q[j] = clampf(t, c - m->inc[j], c + m->inc[j]);
+    }
+  }
+  __syncthreads();
+  if (lane == 0) {
+    for (int j = 0; j < nd; j++) { L.st[ST_MMODE + j] = 1.f; L.st[ST_MTARGET + j] = tp.q[j]; L.st[ST_MMAXIMP + j] = 240.f * K_DT; }
+    float g = a7[6];
+    if (m->kind == RP_KIND_P) {
+      float amt = 0.04f - g / 25.f;
+      int ds[2] = {m->d9p, m->d10p};
+      for (int i = 0; i < 2; i++) { L.st[ST_MMODE + ds[i]] = 1.f; L.st[ST_MTARGET + ds[i]] = amt; L.st[ST_MMAXIMP + ds[i]] = 100.f * K_DT; }
+    } else {
+      float amt = g - 0.2f;
+      float left = L.st[ST_Q + m->d18];
+      int ds[6] = {m->d18, m->d20, m->d12, m->d15, m->d10, m->d13};
+      float tg[6] = {amt * 0.055f, left, amt * 0.5f, amt * 0.5f, amt * 0.8f, amt * 0.8f};
+      float fo[6] = {100.f, 1000.f, 100.f, 100.f, 100.f, 100.f};
+      for (int i = 0; i < 6; i++) { L.st[ST_MMODE + ds[i]] = 1.f; L.st[ST_MTARGET + ds[i]] = tg[i]; L.st[ST_MMAXIMP + ds[i]] = fo[i] * K_DT; }
+    }
+  }
+  __syncthreads();
+  return tp;
+}
+
+/* ------------------------------------------------------------------ observation / reward */
+__device__ __forceinline__ float dial01(float x) { float mod = x - 2.f * floorf(x * 0.5f); return (mod * RP_PI_F) / (2.2f * RP_PI_F); }
+
+__device__ __forceinline__ V3 site_pos_world(const DevModel* m, const EnvLds& L, int s) {
+  int b = m->site_body[s];
+  return ld3(&L.xp[3 * b]) + mulv(ldm3(&L.xR[9 * b]), ld3(m->site_pos[s]));
+}
+
+__device__ float success_func(const float* ag, const float* g) {
+  for (int k = 0; k < 3; k++) if (fabsf(g[k] - ag[k]) > 0.05f) return -1.f;
+  V3 eg = euler_from_quat(g[3], g[4], g[5], g[6]), ea = euler_from_quat(ag[3], ag[4], ag[5], ag[6]);
+  if (fabsf(eg.x - ea.x) > RP_PI_F / 4 || fabsf(eg.y - ea.y) > RP_PI_F / 4 || fabsf(eg.z - ea.z) > RP_PI_F / 4) return -1.f;
+  if (fabsf(g[7] - ag[7]) > 0.025f) return -1.f;
+  if (fabsf(g[8] - ag[8]) > 0.04f) return -1.f;
+  if (fabsf(g[9] - ag[9]) > 0.01f) return -1.f;
+  if (fabsf(g[10] - ag[10]) > 0.3f) return -1.f;
+  return 0.f;
+}
+
+__device__ float compute_reward(int play, const float* ag, const float* dg) {
+  if (play) return success_func(ag, dg);
+  float dx = ag[0] - dg[0], dy = ag[1] - dg[1], dz = ag[2] - dg[2];
+  float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+  return dist > 0.05f ? -1.f : -dist;
+}
+
+__device__ __forceinline__ void flip_quat(float* v, const float* last) {
+  bool all = true;
+  for (int i = 0; i < 4; i++) {
+    int s = (v[i] > 0.f) - (v[i] < 0.f), l = (last[i] > 0.f) - (last[i] < 0.f);
+    if (s != -l) all = false;
+  }
+  if (all) for (int i = 0; i < 4; i++) v[i] = -v[i];
+}
+
+/* out layout in L.out: obs_quat @0 (19) | ag @19 (11) | dg @30 (11) | cag @41 (4) | fps @45 (19) | joints @64 (8) |
+ * velocity @72 (6) | observation @78 (18) | proprio @96 | reward @97 | is_success @98 | status @99 */
+#define O_OBS 0
+#define O_AG 19
+#define O_DG 30
+#define O_CAG 41
+#define O_FPS 45
+#define O_JOINTS 64
+#define O_VEL 72
+#define O_OBSV 78
+#define O_PROP 96
+#define O_REW 97
+#define O_SUCC 98
+#define O_STATUS 99
+
+/* calc_state (environments.py:799-864): transforms must be current (fk_bodies). Stateful in play mode. */
+__device__ void calc_state(const DevModel* m, EnvLds& L, int lane) {
+  fk_bodies(m, L, lane);
+  __syncthreads();
+  joint_subspaces(m, L, lane);
+  collider_aabbs(m, L, lane);
+  __syncthreads();
+  /* gripper_proprioception ray (environments.py:720-743): lane c tests collider c */
+  int prop = -1;
+  if (m->kind != RP_KIND_P) {
+    V3 g1 = site_pos_world(m, L, RP_SITE_PADL), g2 = site_pos_world(m, L, RP_SITE_PADR);
+    V3 ee = site_pos_world(m, L, RP_SITE_EE), wr = site_pos_world(m, L, RP_SITE_WRIST);
+    V3 p1 = ee - (ee - wr) * 0.5f, p2 = (g1 + g2) * 0.5f + (ee - wr) * 0.2f, d = p2 - p1;
+    float t = 2.f; int link = -1;
+    if (lane < m->n_col) {
+      Xf x = collider_xf(m, L, lane);
+      V3 he = ld3(m->col_he[lane]);
+      if (m->col_type[lane] == 0) {
+        V3 ol = tmulv(x.R, p1 - x.p), dl = tmulv(x.R, d);
+        float o3[3] = {ol.x, ol.y, ol.z}, d3[3] = {dl.x, dl.y, dl.z}, h3[3] = {he.x, he.y, he.z};
+        bool inside = fabsf(o3[0]) <= h3[0] && fabsf(o3[1]) <= h3[1] && fabsf(o3[2]) <= h3[2];
+        bool hit = !inside;
+        float tmin = 0.f, tmax = 1.f;
+        for (int k = 0; k < 3 && hit; k++) {
+          if (fabsf(d3[k]) < 1e-12f) { if (fabsf(o3[k]) > h3[k]) hit = false; continue; }
+          float t1 = (-h3[k] - o3[k]) / d3[k], t2 = (h3[k] - o3[k]) / d3[k];
+          if (t1 > t2) { float s = t1; t1 = t2; t2 = s; }
+          tmin = fmaxf(tmin, t1); tmax = fminf(tmax, t2);
+          if (tmin > tmax) hit = false;
+        }
+        if (hit) { t = tmin; link = m->col_link[lane]; }
+      } else {
+        V3 oc = p1 - x.p;
+        float a = dot(d, d), b = 2.f * dot(oc, d), cc = dot(oc, oc) - he.x * he.x;
+        float disc = b * b - 4.f * a * cc;
+        if (cc >= 0.f && disc >= 0.f) {
+          float tt = (-b - sqrtf(disc)) / (2.f * a);
+          if (tt >= 0.f && tt <= 1.f) { t = tt; link = m->col_link[lane]; }
+        }
+      }
+    }
+    /* min over lanes, lowest collider index wins ties (the oracle scans colliders in order with <) */
+    float best = t; int bl = link, bi = lane;
+    for (int off = 32; off > 0; off >>= 1) {
+      float ot = __shfl_xor(best, off); int ol = __shfl_xor(bl, off); int oi = __shfl_xor(bi, off);
+      if (ot < best || (ot == best && oi < bi)) { best = ot; bl = ol; bi = oi; }
+    }
+    prop = (best >= 1.f || bl == 18 || bl == 20) ? 0 : 1;
+  }
+  if (lane == 0) {
+    int n = m->n_arm;
+    int eb = m->site_body[RP_SITE_EE];
+    M3 Rb = ldm3(&L.xR[9 * eb]);
+    V3 pos = ld3(&L.xp[3 * eb]) + mulv(Rb, ld3(m->site_pos[RP_SITE_EE]));
+    Q4 orn = m3_to_quat(mul(Rb, ldm3(m->site_rot[RP_SITE_EE])));
+    V6 v = zero6();
+    uint32_t anc = m->arm_anc[eb - 1];
+    for (int j = 0; j < n; j++) if ((anc >> j) & 1u) v = v + ld6(&L.S[6 * j]) * L.st[ST_QD + j];
+    V3 lin = v.l + cross(v.a, pos - ld3(L.O)), ang = v.a;
+    float grip = L.st[ST_Q + m->d_grip_obs] * (m->kind == RP_KIND_P ? 1.f : 23.f);
+    float* o = L.out;
+    float st[19], ag[11];
+    int ns = 0, nag = 0, nf = 0;
+    st[ns++] = pos.x; st[ns++] = pos.y; st[ns++] = pos.z;
+    if (m->return_velocity) { st[ns++] = lin.x; st[ns++] = lin.y; st[ns++] = lin.z; }
+    if (m->use_orientation) { st[ns++] = orn.x; st[ns++] = orn.y; st[ns++] = orn.z; st[ns++] = orn.w; }
+    st[ns++] = grip;
+    if (m->num_objects > 0) {
+      const float* f = &L.st[ST_FREE];
+      for (int k = 0; k < 3; k++) { st[ns++] = f[k]; ag[nag++] = f[k]; }
+      if (m->use_orientation) for (int k = 0; k < 4; k++) { st[ns++] = f[3 + k]; ag[nag++] = f[3 + k]; }
+      if (m->return_velocity) for (int k = 0; k < 3; k++) st[ns++] = f[7 + k];
+      if (m->play) {
+        float ex[4] = {L.st[ST_FREE + 13 + 1], L.st[ST_JQ + 0], L.st[ST_JQ + 1], dial01(L.st[ST_JQ + 2])};
+        for (int k = 0; k < 4; k++) { st[ns++] = ex[k]; ag[nag++] = ex[k]; }
+      }
+    } else {
+      ag[nag++] = pos.x; ag[nag++] = pos.y; ag[nag++] = pos.z;
+    }
+    if (m->play) {
+      if (L.st[ST_HAVE_LAST] != 0.f) {
+        flip_quat(&st[3], &L.st[ST_LAST_EE_Q]);
+        flip_quat(&st[11], &L.st[ST_LAST_BLK_Q]);
+        flip_quat(&ag[3], &L.st[ST_LAST_AG_Q]);
+      }
+      for (int k = 0; k < 4; k++) { L.st[ST_LAST_EE_Q + k] = st[3 + k]; L.st[ST_LAST_BLK_Q + k] = st[11 + k]; L.st[ST_LAST_AG_Q + k] = ag[3 + k]; }
+      L.st[ST_HAVE_LAST] = 1.f;
+    }
+    for (int k = 0; k < ns; k++) o[O_OBS + k] = st[k];
+    for (int k = 0; k < nag; k++) o[O_AG + k] = ag[k];
+    int ng = __float_as_int(L.st[ST_NGOAL]);
+    for (int k = 0; k < ng; k++) o[O_DG + k] = L.st[ST_GOAL + k];
+    o[O_CAG] = pos.x; o[O_CAG + 1] = pos.y; o[O_CAG + 2] = pos.z; o[O_CAG + 3] = grip;
+    o[O_FPS + nf++] = pos.x; o[O_FPS + nf++] = pos.y; o[O_FPS + nf++] = pos.z;
+    if (m->num_objects > 0 && m->use_orientation) { o[O_FPS + nf++] = orn.x; o[O_FPS + nf++] = orn.y; o[O_FPS + nf++] = orn.z; o[O_FPS + nf++] = orn.w; }
+    o[O_FPS + nf++] = grip;
+    if (m->num_objects > 0) for (int k = 0; k < nag; k++) o[O_FPS + nf++] = ag[k];
+    for (int j = 0; j < 8; j++) o[O_JOINTS + j] = m->joints_dof[j] >= 0 ? L.st[ST_Q + m->joints_dof[j]] : 0.f;
+    o[O_VEL] = lin.x; o[O_VEL + 1] = lin.y; o[O_VEL + 2] = lin.z; o[O_VEL + 3] = ang.x; o[O_VEL + 4] = ang.y; o[O_VEL + 5] = ang.z;
+    V3 eul = euler_from_quat(st[3], st[4], st[5], st[6]);
+    int no = 0;
+    o[O_OBSV + no++] = st[0]; o[O_OBSV + no++] = st[1]; o[O_OBSV + no++] = st[2];
+    o[O_OBSV + no++] = eul.x; o[O_OBSV + no++] = eul.y; o[O_OBSV + no++] = eul.z;
+    for (int k = 7; k < ns; k++) o[O_OBSV + no++] = st[k];
+    o[O_PROP] = __int_as_float(prop);
+    float r = compute_reward(m->play, &o[O_AG], &o[O_DG]);
+    o[O_REW] = r;
+    o[O_SUCC] = __int_as_float(r < 0.f ? 0 : 1);
+    bool bad = false;
+    for (int k = 0; k < ST_MMODE; k++) if (!isfinite(L.st[k])) bad = true;
+    o[O_STATUS] = __int_as_float(bad ? 1 : 0);
+  }
+  __syncthreads();
+}
+
+struct OutPtrs {
+  float *obs_quat, *achieved_goal, *desired_goal, *cag, *fps, *joints, *velocity, *observation;
+  int *proprio; float* reward; int *is_success; float* target_poses; int* status;
+};
+
+__device__ void write_outputs(const DevModel* m, const EnvLds& L, int lane, int env, const OutPtrs& o) {
+  const float* s = L.out;
+  if (o.obs_quat && lane < m->n_obs) o.obs_quat[(size_t)env * m->n_obs + lane] = s[O_OBS + lane];
+  if (o.achieved_goal && lane < m->n_ag) o.achieved_goal[(size_t)env * m->n_ag + lane] = s[O_AG + lane];
+  if (o.desired_goal && lane < m->n_ag) o.desired_goal[(size_t)env * m->n_ag + lane] = s[O_DG + lane];
+  if (o.cag && lane < 4) o.cag[(size_t)env * 4 + lane] = s[O_CAG + lane];
+  if (o.fps && lane < m->n_fps) o.fps[(size_t)env * m->n_fps + lane] = s[O_FPS + lane];
+  if (o.joints && lane < 8) o.joints[(size_t)env * 8 + lane] = s[O_JOINTS + lane];
+  if (o.velocity && lane < 6) o.velocity[(size_t)env * 6 + lane] = s[O_VEL + lane];
+  if (o.observation && lane < m->n_observation) o.observation[(size_t)env * m->n_observation + lane] = s[O_OBSV + lane];
+  if (lane == 0) {
+    if (o.proprio) o.proprio[env] = __float_as_int(s[O_PROP]);
+    if (o.reward) o.reward[env] = s[O_REW];
+    if (o.is_success) o.is_success[env] = __float_as_int(s[O_SUCC]);
+    if (o.status) o.status[env] = __float_as_int(s[O_STATUS]);
+  }
+}
+
+__device__ __forceinline__ void load_state(EnvLds& L, const float* state, int env, int lane) {
+  const float* r = state + (size_t)env * RP_REC_FLOATS;
+  L.st[lane] = r[lane];
+  L.st[lane + 64] = r[lane + 64];
+  __syncthreads();
+}
+__device__ __forceinline__ void store_state(const EnvLds& L, float* state, int env, int lane) {
+  __syncthreads();
+  float* r = state + (size_t)env * RP_REC_FLOATS;
+  r[lane] = L.st[lane];
+  r[lane + 64] = L.st[lane + 64];
+}
+
+/* ------------------------------------------------------------------ kernels */
+/* playEnv.step for env = blockIdx.x */
+__global__ void __launch_bounds__(64) k_step(const DevModel* __restrict__ m, float* __restrict__ state, const float* __restrict__ action,
+                                            OutPtrs out, int N) {
+  __shared__ EnvLds L;
+  int env = blockIdx.x, lane = threadIdx.x;
+  if (env >= N) return;
+  load_state(L, state, env, lane);
+  float a7[7];
+  const float high[7] = {6.f, 6.f, 6.f, 6.f, 6.f, 6.f, 1.f};       /* environments.py:108-109, 207 */
+#pragma unroll
+  for (int k = 0; k < 7; k++) a7[k] = clampf(action[(size_t)env * 7 + k], -high[k], high[k]);
+  ChainQ tp = perform_action(m, L, lane, a7);
+  for (int s = 0; s < K_NSUB; s++) substep(m, L, lane);
+  calc_state(m, L, lane);
+  write_outputs(m, L, lane, env, out);
+  if (out.target_poses && lane == 0)
+    for (int j = 0; j < m->n_target; j++) out.target_poses[(size_t)env * m->n_target + j] = tp.q[j];
+  store_state(L, state, env, lane);
+}
+
+__global__ void __launch_bounds__(64) k_calc_state(const DevModel* __restrict__ m, float* __restrict__ state, OutPtrs out, int N) {
+  __shared__ EnvLds L;
+  int env = blockIdx.x, lane = threadIdx.x;
+  if (env >= N) return;
+  load_state(L, state, env, lane);
+  calc_state(m, L, lane);
+  write_outputs(m, L, lane, env, out);
+  store_state(L, state, env, lane);
+}
+
+/* uniform draw for this env from the counter RNG; counter lives in the state record */
+__device__ __forceinline__ float next_u(EnvLds& L, uint64_t seed, uint32_t genv) {
+  uint32_t c = (uint32_t)__float_as_int(L.st[ST_RNG]);
+  float u = rng_uniform(seed, genv, c);
+  L.st[ST_RNG] = __int_as_float((int)(c + 1));
+  return u;
+}
+
+/* reset_goal_pos (environments.py:492-516); goal == nullptr draws a random goal; all lanes call, lane 0 mutates */
+__device__ void reset_goal_pos(const DevModel* m, EnvLds& L, int lane, const float* goal, uint64_t seed, uint32_t genv) {
+  if (lane == 0) {
+    if (!goal) {
+      for (int k = 0; k < 3; k++) L.st[ST_GOAL + k] = m->goal_lo[k] + (m->goal_hi[k] - m->goal_lo[k]) * next_u(L, seed, genv);
+      L.st[ST_NGOAL] = __int_as_float(3);
+    } else {
+      int ng = __float_as_int(L.st[ST_NGOAL]);
+      for (int k = 0; k < ng; k++) L.st[ST_GOAL + k] = goal[k];
+    }
+  }
+  __syncthreads();
+  if (m->play) {
+    calc_state(m, L, lane);
+    if (lane == 0) {
+      int n = m->n_ag;
+      int idx = (int)(next_u(L, seed, genv) * n);
+      if (idx >= n) idx = n - 1;
+      float bump = next_u(L, seed, genv);
+      for (int k = 0; k < n; k++) L.st[ST_GOAL + k] = L.out[O_AG + k];
+      L.st[ST_GOAL + idx] = L.st[ST_GOAL + idx] + bump;
+      L.st[ST_NGOAL] = __int_as_float(n);
+    }
+    __syncthreads();
+  }
+}
+
+/* playEnv.reset(o=None) (environments.py:173-187, 519-603) */
+__global__ void __launch_bounds__(64) k_reset(const DevModel* __restrict__ m, float* __restrict__ state, const uint8_t* __restrict__ mask,
+                                             OutPtrs out, int N, uint64_t seed, uint32_t env_offset) {
+  __shared__ EnvLds L;
+  int env = blockIdx.x, lane = threadIdx.x;
+  if (env >= N) return;
+  if (mask && !mask[env]) return;
+  uint32_t genv = env_offset + (uint32_t)env;
+  load_state(L, state, env, lane);
+  float r = 0.f;
+  for (int attempt = 0; attempt < 64 && r > -1.f; attempt++) {
+    /* reset_object_pos */
+    for (int depth = 0; depth < 9; depth++) {
+      if (lane == 0) {
+        if (m->play) {
+          float* d = &L.st[ST_FREE + 13];
+          for (int k = 0; k < 3; k++) d[k] = m->free_pos0[1][k];
+          for (int k = 0; k < 4; k++) d[3 + k] = m->free_quat0[1][k];
+          for (int k = 7; k < 13; k++) d[k] = 0.f;
+          for (int k = 0; k < m->n_j1; k++) { L.st[ST_JQ + k] = 0.f; L.st[ST_JQD + k] = 0.f; }
+        }
+        float height = 0.03f;
+        for (int b = 0; b < m->num_objects; b++) {
+          float* f = &L.st[ST_FREE + 13 * b];
+          for (int k = 0; k < 3; k++) f[k] = m->obj_lo[k] + (m->obj_hi[k] - m->obj_lo[k]) * next_u(L, seed, genv);
+          f[2] += height;
+          f[3] = 0.f; f[4] = 0.f; f[5] = 0.7071f; f[6] = 0.7071f;
+          for (int k = 7; k < 13; k++) f[k] = 0.f;
+          height += 0.03f;
+        }
+      }
+      __syncthreads();
+      for (int i = 0; i < K_NSETTLE; i++) substep(m, L, lane);
+      bool outb = false;
+      for (int b = 0; b < m->num_objects; b++)
+        for (int k = 0; k < 3; k++) if (L.st[ST_FREE + 13 * b + k] > m->env_hi[k]) outb = true;
+      if (!outb) break;
+    }
+    /* reset_arm: rest pose, one IK on the live arm, first 6 joints only (quirk F5) */
+    float tx[3];
+    {
+      float u0 = 0.f, u1 = 0.f, u2 = 0.f;
+      if (lane == 0) { u0 = next_u(L, seed, genv); u1 = next_u(L, seed, genv); u2 = next_u(L, seed, genv); }
+      u0 = unif(u0); u1 = unif(u1); u2 = unif(u2);
+      tx[0] = m->goal_lo[0] + (m->goal_hi[0] - m->goal_lo[0]) * u0;
+      tx[1] = m->goal_lo[1] + (m->goal_hi[1] - m->goal_lo[1]) * u1;
+      tx[2] = m->goal_lo[2] + (m->goal_hi[2] - m->goal_lo[2]) * u2;
+      if (m->kind != RP_KIND_P) tx[2] += 0.2f;
+    }
+    __syncthreads();
+    if (lane == 0) {
+      int nrest = m->kind == RP_KIND_P ? 8 : 6;
+      for (int i = 0; i < nrest; i++) { L.st[ST_Q + i] = m->rest[i]; L.st[ST_QD + i] = 0.f; }
+    }
+    __syncthreads();
+    ChainQ cur;
+#pragma unroll
+    for (int j = 0; j < 7; j++) cur.q[j] = j < m->ee_chain ? L.st[ST_Q + j] : 0.f;
+    Q4 ident = {0.f, 0.f, 0.f, 1.f};
+    ChainQ sol = ik_solve(m, mk3(tx[0], tx[1], tx[2]), ident, cur, 20);
+    __syncthreads();
+    if (lane == 0) for (int i = 0; i < 6; i++) { L.st[ST_Q + i] = sol.q[i]; L.st[ST_QD + i] = 0.f; }
+    __syncthreads();
+    reset_goal_pos(m, L, lane, nullptr, seed, genv);
+    calc_state(m, L, lane);
+    r = L.out[O_REW];
+    __syncthreads();
+  }
+  write_outputs(m, L, lane, env, out);
+  store_state(L, state, env, lane);
+}
+
+__global__ void __launch_bounds__(64) k_reset_goal(const DevModel* __restrict__ m, float* __restrict__ state, const float* __restrict__ goal,
+                                                  const uint8_t* __restrict__ mask, int N, uint64_t seed, uint32_t env_offset) {
+  __shared__ EnvLds L;
+  int env = blockIdx.x, lane = threadIdx.x;
+  if (env >= N) return;
+  if (mask && !mask[env]) return;
+  load_state(L, state, env, lane);
+  reset_goal_pos(m, L, lane, goal ? goal + (size_t)env * m->n_ag : nullptr, seed, env_offset + (uint32_t)env);
+  store_state(L, state, env, lane);
+}
+
+/* initial records: everything as loaded (arm at q = 0, bodies at creation poses, default velocity motors) */
+__global__ void k_init(const DevModel* __restrict__ m, float* __restrict__ state, int N) {
+  int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= N) return;
+  float* r = state + (size_t)env * RP_REC_FLOATS;
+  for (int k = 0; k < RP_REC_FLOATS; k++) r[k] = 0.f;
+  for (int f = 0; f < m->n_free; f++) {
+    for (int k = 0; k < 3; k++) r[ST_FREE + 13 * f + k] = m->free_pos0[f][k];
+    for (int k = 0; k < 4; k++) r[ST_FREE + 13 * f + 3 + k] = m->free_quat0[f][k];
+  }
+  for (int f = m->n_free; f < RP_MAX_FREE; f++) r[ST_FREE + 13 * f + 6] = 1.f;
+  for (int i = 0; i < RP_MAX_ARM; i++) r[ST_MMAXIMP + i] = K_DEFMOTOR;
+  r[ST_NGOAL] = __int_as_float(m->n_goal_init);
+}
+
+__global__ void k_reward(const DevModel* __restrict__ m, const float* __restrict__ ag, const float* __restrict__ dg, float* __restrict__ r, int M) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M) return;
+  r[i] = compute_reward(m->play, ag + (size_t)i * m->n_ag, dg + (size_t)i * m->n_ag);
+}
+
+/* state record copies (rp_get_state / rp_set_state with broadcast) */
+__global__ void k_copy_state(float* __restrict__ dst, const float* __restrict__ src, int N, int src_count) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)N * RP_REC_FLOATS) return;
+  size_t env = i / RP_REC_FLOATS, k = i % RP_REC_FLOATS;
+  dst[i] = src[(src_count == 1 ? 0 : env) * RP_REC_FLOATS + k];
+}
+
+/* debug: one substep for every env, dumping intermediates of env `dbg_env` (tests only) */
+__global__ void __launch_bounds__(64) k_debug_substep(const DevModel* __restrict__ m, float* __restrict__ state, float* __restrict__ dbg, int N, int dbg_env) {
+  __shared__ EnvLds L;
+  int env = blockIdx.x, lane = threadIdx.x;
+  if (env >= N) return;
+  load_state(L, state, env, lane);
+  int n = m->n_arm;
+  fk_bodies(m, L, lane);
+  __syncthreads();
+  joint_subspaces(m, L, lane);
+  collider_aabbs(m, L, lane);
+  __syncthreads();
+  int ncon = collide(m, L, lane);
+  if (env == dbg_env && lane == 0) {
+    dbg[0] = (float)ncon;
+    for (int c = 0; c < ncon; c++) {
+      float* o = dbg + 16 + 9 * c;
+      o[0] = (float)L.cona[c]; o[1] = (float)L.conb[c];
+      for (int k = 0; k < 3; k++) { o[2 + k] = L.conp[3 * c + k]; o[5 + k] = L.conn[3 * c + k]; }
+      o[8] = L.cond[c];
+    }
+  }
+  arm_dynamics(m, L, lane);
+  unconstrained_velocities(m, L, lane);
+  if (env == dbg_env && lane == 0) {
+    for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) dbg[320 + i * 12 + j] = L.Minv[i * 12 + j];
+    for (int i = 0; i < 32; i++) dbg[480 + i] = L.vstar[i];
+    for (int i = 0; i < n; i++) dbg[512 + i] = L.tau[i];
+  }
+  int nsmall = build_small_rows(m, L, lane);
+  contact_rows(m, L, lane, ncon);
+  __syncthreads();
+  float dv = solve_rows(m, L, lane, nsmall, ncon);
+  if (env == dbg_env) {
+    if (lane == 0) { dbg[1] = (float)nsmall; }
+    if (lane < 32) dbg[544 + lane] = dv;
+  }
+  __syncthreads();
+}

@@ -1,0 +1,179 @@
+/* rp_playroom.hip — C ABI (include/rp_playroom.h) over the gfx950 kernels in rp_kernels.cuh. */
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/rp_playroom.h"
+#include "generated/rp_models_gen.h"
+#include "rp_device_model.h"
+#include "rp_kernels.cuh"
+
+struct rp_sim {
+  rp_config cfg;
+  DevModel host_model;
+  DevModel* dev_model;
+  float* state;            /* [N][RP_REC_FLOATS] */
+  float* dbg;
+  hipEvent_t ev0, ev1;
+  int timers_on;
+  rp_timers timers;
+  char err[256];
+};
+
+static char g_err[256] = "";
+
+#define HIPCHK(h, call)                                                                             \
+  do {                                                                                              \
+    hipError_t e_ = (call);                                                                         \
+    if (e_ != hipSuccess) {                                                                         \
+      snprintf((h) ? (h)->err : g_err, 256, "%s failed: %s", #call, hipGetErrorString(e_));         \
+      return RP_ERR_HIP;                                                                            \
+    }                                                                                               \
+  } while (0)
+
+static OutPtrs to_ptrs(const rp_out* o) {
+  OutPtrs p;
+  memset(&p, 0, sizeof(p));
+  if (!o) return p;
+  p.obs_quat = o->obs_quat; p.achieved_goal = o->achieved_goal; p.desired_goal = o->desired_goal;
+  p.cag = o->controllable_achieved_goal; p.fps = o->full_positional_state; p.joints = o->joints; p.velocity = o->velocity;
+  p.observation = o->observation; p.proprio = o->gripper_proprioception; p.reward = o->reward; p.is_success = o->is_success;
+  p.target_poses = o->target_poses; p.status = o->status;
+  return p;
+}
+
+extern "C" {
+
+const char* rp_version(void) { return "rp_playroom 0.1 (gfx950, wave-per-env)"; }
+
+int rp_create(const rp_config* cfg, rp_handle* out) {
+  if (!cfg || !out || cfg->num_envs <= 0) { snprintf(g_err, 256, "rp_create: bad argument"); return RP_ERR_ARG; }
+  if (cfg->env_kind < 0 || cfg->env_kind > 2) { snprintf(g_err, 256, "rp_create: unsupported env kind %d", cfg->env_kind); return RP_ERR_UNSUPPORTED; }
+  rp_sim* h = (rp_sim*)calloc(1, sizeof(rp_sim));
+  h->cfg = *cfg;
+  rp_model* m = (rp_model*)malloc(sizeof(rp_model));
+  if (cfg->env_kind == RP_ENV_UR5_PLAY_ABS_RPY_1OBJ) rp_fill_model_U(m);
+  else if (cfg->env_kind == RP_ENV_UR5_REACH) rp_fill_model_R(m);
+  else rp_fill_model_P(m);
+  rp_build_dev_model(m, &h->host_model);
+  free(m);
+  hipError_t e = hipSetDevice(cfg->device);
+  if (e != hipSuccess) { snprintf(g_err, 256, "hipSetDevice(%d): %s", cfg->device, hipGetErrorString(e)); free(h); return RP_ERR_HIP; }
+  if (hipMalloc((void**)&h->dev_model, sizeof(DevModel)) != hipSuccess ||
+      hipMalloc((void**)&h->state, (size_t)cfg->num_envs * RP_REC_FLOATS * sizeof(float)) != hipSuccess ||
+      hipMalloc((void**)&h->dbg, 4096 * sizeof(float)) != hipSuccess) {
+    snprintf(g_err, 256, "rp_create: hipMalloc failed"); free(h); return RP_ERR_HIP;
+  }
+  if (hipMemcpy(h->dev_model, &h->host_model, sizeof(DevModel), hipMemcpyHostToDevice) != hipSuccess) {
+    snprintf(g_err, 256, "rp_create: model upload failed"); free(h); return RP_ERR_HIP;
+  }
+  hipEventCreate(&h->ev0); hipEventCreate(&h->ev1);
+  int N = cfg->num_envs;
+  hipLaunchKernelGGL(k_init, dim3((N + 255) / 256), dim3(256), 0, 0, h->dev_model, h->state, N);
+  e = hipDeviceSynchronize();
+  if (e != hipSuccess) { snprintf(g_err, 256, "rp_create: init kernel: %s", hipGetErrorString(e)); free(h); return RP_ERR_HIP; }
+  *out = h;
+  return RP_OK;
+}
+
+int rp_destroy(rp_handle h) {
+  if (!h) return RP_ERR_ARG;
+  hipSetDevice(h->cfg.device);
+  hipFree(h->dev_model); hipFree(h->state); hipFree(h->dbg);
+  hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
+  free(h);
+  return RP_OK;
+}
+
+int rp_get_dims(rp_handle h, rp_dims* d) {
+  if (!h || !d) return RP_ERR_ARG;
+  const DevModel* m = &h->host_model;
+  d->obs_quat = m->n_obs; d->achieved_goal = m->n_ag; d->desired_goal = m->n_ag; d->controllable_achieved_goal = 4;
+  d->full_positional_state = m->n_fps; d->joints = 8; d->velocity = 6; d->observation = m->n_observation;
+  d->target_poses = m->n_target; d->action = 7;
+  return RP_OK;
+}
+
+int rp_reset(rp_handle h, const uint8_t* mask, const rp_out* out, void* stream) {
+  if (!h) return RP_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  int N = h->cfg.num_envs;
+  if (h->timers_on) hipEventRecord(h->ev0, s);
+  hipLaunchKernelGGL(k_reset, dim3(N), dim3(64), 0, s, h->dev_model, h->state, mask, to_ptrs(out), N, h->cfg.seed, (uint32_t)h->cfg.env_offset);
+  HIPCHK(h, hipGetLastError());
+  if (h->timers_on) { hipEventRecord(h->ev1, s); hipEventSynchronize(h->ev1); hipEventElapsedTime(&h->timers.last_reset_ms, h->ev0, h->ev1); }
+  return RP_OK;
+}
+
+int rp_reset_goal(rp_handle h, const float* goal, const uint8_t* mask, void* stream) {
+  if (!h) return RP_ERR_ARG;
+  int N = h->cfg.num_envs;
+  hipLaunchKernelGGL(k_reset_goal, dim3(N), dim3(64), 0, (hipStream_t)stream, h->dev_model, h->state, goal, mask, N, h->cfg.seed,
+                     (uint32_t)h->cfg.env_offset);
+  HIPCHK(h, hipGetLastError());
+  return RP_OK;
+}
+
+int rp_step(rp_handle h, const float* action, const rp_out* out, void* stream) {
+  if (!h || !action) { if (h) snprintf(h->err, 256, "rp_step: action is NULL"); return RP_ERR_ARG; }
+  hipStream_t s = (hipStream_t)stream;
+  int N = h->cfg.num_envs;
+  if (h->timers_on) hipEventRecord(h->ev0, s);
+  hipLaunchKernelGGL(k_step, dim3(N), dim3(64), 0, s, h->dev_model, h->state, action, to_ptrs(out), N);
+  HIPCHK(h, hipGetLastError());
+  if (h->timers_on) { hipEventRecord(h->ev1, s); hipEventSynchronize(h->ev1); hipEventElapsedTime(&h->timers.last_step_ms, h->ev0, h->ev1); }
+  h->timers.steps++;
+  return RP_OK;
+}
+
+int rp_calc_state(rp_handle h, const rp_out* out, void* stream) {
+  if (!h) return RP_ERR_ARG;
+  int N = h->cfg.num_envs;
+  hipLaunchKernelGGL(k_calc_state, dim3(N), dim3(64), 0, (hipStream_t)stream, h->dev_model, h->state, to_ptrs(out), N);
+  HIPCHK(h, hipGetLastError());
+  return RP_OK;
+}
+
+int rp_compute_reward(rp_handle h, const float* ag, const float* dg, float* r, int32_t m, void* stream) {
+  if (!h || !ag || !dg || !r || m < 0) return RP_ERR_ARG;
+  if (m == 0) return RP_OK;
+  hipLaunchKernelGGL(k_reward, dim3((m + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->dev_model, ag, dg, r, m);
+  HIPCHK(h, hipGetLastError());
+  return RP_OK;
+}
+
+size_t rp_state_bytes(rp_handle h) { (void)h; return RP_REC_FLOATS * sizeof(float); }
+
+int rp_get_state(rp_handle h, void* dst, void* stream) {
+  if (!h || !dst) return RP_ERR_ARG;
+  HIPCHK(h, hipMemcpyAsync(dst, h->state, (size_t)h->cfg.num_envs * RP_REC_FLOATS * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return RP_OK;
+}
+
+int rp_set_state(rp_handle h, const void* src, int32_t src_env_count, void* stream) {
+  if (!h || !src) return RP_ERR_ARG;
+  int N = h->cfg.num_envs;
+  if (src_env_count != 1 && src_env_count != N) { snprintf(h->err, 256, "rp_set_state: src_env_count %d is neither 1 nor %d", src_env_count, N); return RP_ERR_STATE_SIZE; }
+  size_t total = (size_t)N * RP_REC_FLOATS;
+  hipLaunchKernelGGL(k_copy_state, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h->state, (const float*)src, N, src_env_count);
+  HIPCHK(h, hipGetLastError());
+  return RP_OK;
+}
+
+int rp_get_timers(rp_handle h, rp_timers* t) { if (!h || !t) return RP_ERR_ARG; *t = h->timers; return RP_OK; }
+int rp_enable_timers(rp_handle h, int32_t on) { if (!h) return RP_ERR_ARG; h->timers_on = on; return RP_OK; }
+const char* rp_last_error(rp_handle h) { return h ? h->err : g_err; }
+
+/* test hook (not part of the public header): one substep on every env, intermediates of env `env` into host buf[4096] */
+int rp_debug_substep(rp_handle h, int32_t env, float* host_buf) {
+  if (!h || !host_buf) return RP_ERR_ARG;
+  int N = h->cfg.num_envs;
+  HIPCHK(h, hipMemset(h->dbg, 0, 4096 * sizeof(float)));
+  hipLaunchKernelGGL(k_debug_substep, dim3(N), dim3(64), 0, 0, h->dev_model, h->state, h->dbg, N, env);
+  HIPCHK(h, hipDeviceSynchronize());
+  HIPCHK(h, hipMemcpy(host_buf, h->dbg, 4096 * sizeof(float), hipMemcpyDeviceToHost));
+  return RP_OK;
+}
+
+}  /* extern "C" */

@@ -1,0 +1,142 @@
+"""VecPlayEnv — N reference environments stepped at once on one MI355X through the C ABI.
+
+Method names, argument meaning and dict keys mirror the reference's playEnv (environments.py:58-314); every value
+is a [N, ...] torch tensor on the env's device.  State lives inside the HIP library; the tensors returned by
+step()/reset() are owned by this object and overwritten by the next call (clone to keep).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+OBS_KEYS = ('obs_quat', 'achieved_goal', 'desired_goal', 'controllable_achieved_goal', 'full_positional_state', 'joints',
+            'velocity', 'observation')
+
+# record layout of rp_get_state / rp_set_state (csrc/rp_device_model.h ST_*), floats per env = 128
+STATE_LAYOUT = {'q': (0, 12), 'qd': (12, 24), 'free0': (24, 37), 'free1': (37, 50), 'jq': (50, 53), 'jqd': (53, 56),
+                'motor_mode': (56, 68), 'motor_target': (68, 80), 'motor_maximp': (80, 92), 'goal': (92, 103),
+                'last_ee_quat': (103, 107), 'last_block_quat': (107, 111), 'last_ag_quat': (111, 115), 'have_last': (115, 116)}
+
+
+class VecPlayEnv:
+    def __init__(self, env_id, num_envs, device=0, seed=0, env_offset=0):
+        if env_id not in _lib.ENV_KINDS:
+            raise NotImplementedError('env id %r is outside the hot-path scope (SURVEY.md §8)' % (env_id,))
+        if not torch.cuda.is_available():
+            raise RuntimeError('VecPlayEnv needs a ROCm GPU: the hot path is HIP-only, there is no CPU fallback')
+        self.lib = _lib.load()
+        self.env_id = env_id
+        self.num_envs = int(num_envs)
+        idx = device if isinstance(device, int) else (torch.device(device).index or 0)
+        self.device = torch.device('cuda', idx)
+        cfg = _lib.RpConfig(_lib.ENV_KINDS[env_id], self.num_envs, self.device.index, int(env_offset), int(seed))
+        self.h = C.c_void_p()
+        _lib.check(self.lib, None, self.lib.rp_create(C.byref(cfg), C.byref(self.h)), 'rp_create')
+        d = _lib.RpDims()
+        self.lib.rp_get_dims(self.h, C.byref(d))
+        self.dims = {n: getattr(d, n) for n, _ in _lib.RpDims._fields_}
+        N, dev = self.num_envs, self.device
+
+        def f(w):
+            return torch.zeros((N, w), dtype=torch.float32, device=dev)
+
+        self.buf = {k: f(self.dims[k]) for k in OBS_KEYS}
+        self.buf['gripper_proprioception'] = torch.zeros(N, dtype=torch.int32, device=dev)
+        self.buf['reward'] = torch.zeros(N, dtype=torch.float32, device=dev)
+        self.buf['is_success'] = torch.zeros(N, dtype=torch.int32, device=dev)
+        self.buf['target_poses'] = f(self.dims['target_poses'])
+        self.buf['status'] = torch.zeros(N, dtype=torch.int32, device=dev)
+        self.out = _lib.RpOut(**{k: self.buf[k].data_ptr() for k, _ in _lib.RpOut._fields_})
+        self.action_high = torch.tensor([6, 6, 6, 6, 6, 6, 1], dtype=torch.float32, device=dev)   # environments.py:108-109
+        self._max_episode_steps = None if env_id == 'UR5PlayAbsRPY1Obj-v0' else 250
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _obs(self):
+        o = {k: self.buf[k] for k in OBS_KEYS}
+        o['img'] = None
+        o['gripper_proprioception'] = self.buf['gripper_proprioception']
+        return o
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.lib.rp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self, mask=None):
+        """playEnv.reset(o=None) for all envs (or those where mask != 0)."""
+        mp = None
+        if mask is not None:
+            mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+            mp = C.c_void_p(mask.data_ptr())
+        _lib.check(self.lib, self.h, self.lib.rp_reset(self.h, mp, C.byref(self.out), self._stream()), 'rp_reset')
+        return self._obs()
+
+    def step(self, action):
+        a = action.to(device=self.device, dtype=torch.float32).contiguous()
+        assert a.shape == (self.num_envs, 7), a.shape
+        _lib.check(self.lib, self.h, self.lib.rp_step(self.h, C.c_void_p(a.data_ptr()), C.byref(self.out), self._stream()), 'rp_step')
+        info = {'is_success': self.buf['is_success'], 'target_poses': self.buf['target_poses'], 'status': self.buf['status']}
+        done = torch.zeros(self.num_envs, dtype=torch.bool, device=self.device)      # environments.py:212: always False
+        return self._obs(), self.buf['reward'], done, info
+
+    def calc_state(self):
+        _lib.check(self.lib, self.h, self.lib.rp_calc_state(self.h, C.byref(self.out), self._stream()), 'rp_calc_state')
+        return self._obs()
+
+    def reset_goal_pos(self, goal=None, mask=None):
+        gp = mp = None
+        if goal is not None:
+            goal = goal.to(device=self.device, dtype=torch.float32).contiguous()
+            assert goal.shape == (self.num_envs, self.dims['desired_goal'])
+            gp = C.c_void_p(goal.data_ptr())
+        if mask is not None:
+            mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+            mp = C.c_void_p(mask.data_ptr())
+        _lib.check(self.lib, self.h, self.lib.rp_reset_goal(self.h, gp, mp, self._stream()), 'rp_reset_goal')
+
+    def compute_reward(self, achieved_goal, desired_goal, info=None):
+        ag = achieved_goal.to(device=self.device, dtype=torch.float32).contiguous()
+        dg = desired_goal.to(device=self.device, dtype=torch.float32).contiguous()
+        w = self.dims['achieved_goal']
+        ag2, dg2 = ag.reshape(-1, w), dg.reshape(-1, w)
+        r = torch.empty(ag2.shape[0], dtype=torch.float32, device=self.device)
+        _lib.check(self.lib, self.h, self.lib.rp_compute_reward(self.h, C.c_void_p(ag2.data_ptr()), C.c_void_p(dg2.data_ptr()),
+                                                                  C.c_void_p(r.data_ptr()), ag2.shape[0], self._stream()), 'rp_compute_reward')
+        return r.reshape(ag.shape[:-1])
+
+    def render(self, mode='human'):
+        return None       # rendering is out of scope; kept for call compatibility
+
+    def get_state(self):
+        n = self.lib.rp_state_bytes(self.h) // 4
+        s = torch.empty((self.num_envs, n), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib, self.h, self.lib.rp_get_state(self.h, C.c_void_p(s.data_ptr()), self._stream()), 'rp_get_state')
+        return s
+
+    def set_state(self, s):
+        s = s.to(device=self.device, dtype=torch.float32).contiguous()
+        if s.dim() == 1:
+            s = s[None]
+        _lib.check(self.lib, self.h, self.lib.rp_set_state(self.h, C.c_void_p(s.data_ptr()), s.shape[0], self._stream()), 'rp_set_state')
+
+    def enable_timers(self, on=True):
+        self.lib.rp_enable_timers(self.h, int(on))
+
+    def timers(self):
+        t = _lib.RpTimers()
+        self.lib.rp_get_timers(self.h, C.byref(t))
+        return {'last_step_ms': t.last_step_ms, 'last_reset_ms': t.last_reset_ms, 'steps': t.steps}
+
+    def debug_substep(self, env=0):
+        buf = (C.c_float * 4096)()
+        _lib.check(self.lib, self.h, self.lib.rp_debug_substep(self.h, env, buf), 'rp_debug_substep')
+        return torch.tensor(list(buf))
