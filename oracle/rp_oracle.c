@@ -39,6 +39,7 @@
 #define IK_DAMP ((real)0.1)
 #define IK_RESIDUAL ((real)1e-4)
 #define IK_MAX_STEP ((real)(45.0 * 3.14159265358979323846 / 180.0))
+#define TIE_EPS ((real)1e-6)            /* discrete narrowphase choices need a margin that fp32 and fp64 agree on */
 #define MAX_CONTACTS 32
 #define MAX_ACTIVE_PAIRS 64
 #define MAX_ROWS (RP_MAX_ARM * 3 + RP_MAX_J1 + 2 + 3 * MAX_CONTACTS)
@@ -234,7 +235,7 @@ static int box_box(const real* ca, const real* Ra, const real* ha, const real* c
     for (int k = 0; k < 3; k++) { ra += ha[k] * R_FABS(v3dot(L, A[k])); rb += hb[k] * R_FABS(v3dot(L, Bx[k])); }
     real s = R_FABS(v3dot(t, L)) - ra - rb;
     if (s > margin) return 0;
-    if (s > best_s) { best_s = s; best_kind = f < 3 ? 0 : 1; best_i = f % 3; v3cpy(best_L, L); }
+    if (s > best_s + (f == 0 ? 0 : TIE_EPS)) { best_s = s; best_kind = f < 3 ? 0 : 1; best_i = f % 3; v3cpy(best_L, L); }
   }
   real edge_s = (real)-1e30; int ei = 0, ej = 0; real eL[3] = {0, 0, 0};
   for (int i = 0; i < 3; i++)
@@ -248,7 +249,7 @@ static int box_box(const real* ca, const real* Ra, const real* ha, const real* c
       for (int k = 0; k < 3; k++) { ra += ha[k] * R_FABS(v3dot(L, A[k])); rb += hb[k] * R_FABS(v3dot(L, Bx[k])); }
       real s = R_FABS(v3dot(t, L)) - ra - rb;
       if (s > margin) return 0;
-      if (s > edge_s) { edge_s = s; ei = i; ej = j; v3cpy(eL, L); }
+      if (s > edge_s + TIE_EPS) { edge_s = s; ei = i; ej = j; v3cpy(eL, L); }
     }
   if (edge_s > best_s + (real)0.05 * R_FABS(best_s) + (real)1e-6) {
     /* edge-edge */
@@ -311,7 +312,7 @@ static int box_box(const real* ca, const real* Ra, const real* ha, const real* c
       tmp[cnt].n[k] = best_kind == 1 ? nref[k] : -nref[k];     /* from B toward A */
     }
     tmp[cnt].dist = dist;
-    if (dist < tmp[deepest].dist) deepest = cnt;
+    if (dist < tmp[deepest].dist - TIE_EPS) deepest = cnt;
     cnt++;
   }
   if (cnt <= 4) { for (int v = 0; v < cnt; v++) out[v] = tmp[v]; return cnt; }
@@ -361,14 +362,14 @@ static int sphere_box(const real* cs, real r, const real* cb, const real* Rb, co
  * maximise the area spanned by the rest).  Positions compared in world space (Bullet uses local-A). */
 static int manifold_replace_index(const contact* c4, const contact* pt) {
   int deepest = -1; real maxpen = pt->dist;
-  for (int i = 0; i < 4; i++) if (c4[i].dist < maxpen) { deepest = i; maxpen = c4[i].dist; }
+  for (int i = 0; i < 4; i++) if (c4[i].dist < maxpen - TIE_EPS) { deepest = i; maxpen = c4[i].dist; }
   real res[4] = {0, 0, 0, 0}, a[3], b[3], cr[3];
   if (deepest != 0) { v3sub(a, pt->p, c4[1].p); v3sub(b, c4[3].p, c4[2].p); v3cross(cr, a, b); res[0] = v3dot(cr, cr); }
   if (deepest != 1) { v3sub(a, pt->p, c4[0].p); v3sub(b, c4[3].p, c4[2].p); v3cross(cr, a, b); res[1] = v3dot(cr, cr); }
   if (deepest != 2) { v3sub(a, pt->p, c4[0].p); v3sub(b, c4[3].p, c4[1].p); v3cross(cr, a, b); res[2] = v3dot(cr, cr); }
   if (deepest != 3) { v3sub(a, pt->p, c4[0].p); v3sub(b, c4[2].p, c4[1].p); v3cross(cr, a, b); res[3] = v3dot(cr, cr); }
   int best = 0;
-  for (int i = 1; i < 4; i++) if (res[i] > res[best]) best = i;
+  for (int i = 1; i < 4; i++) if (res[i] > res[best] * (1 + (real)1e-4)) best = i;
   return best;
 }
 
@@ -416,7 +417,7 @@ static void collide(rpo_env* e) {
       c.mu = (real)(m->col_friction[a] * m->col_friction[b]);
       if (single) {
         if (nman == 0) man[nman++] = c;
-        else if (c.dist < man[0].dist) man[0] = c;
+        else if (c.dist < man[0].dist - TIE_EPS) man[0] = c;
       } else if (nman < 4) {
         man[nman++] = c;
       } else {
@@ -869,13 +870,12 @@ static void ik_solve(const rpo_env* e, const real* pos, const real* quat, const 
     if (it > 0 && v3norm(err) < IK_RESIDUAL) break;
     real qinv[4] = {-qc[0], -qc[1], -qc[2], qc[3]}, dq[4];
     quat_mul(dq, quat, qinv);
-    real nq = R_SQRT(dq[0] * dq[0] + dq[1] * dq[1] + dq[2] * dq[2] + dq[3] * dq[3]);
-    real w = dq[3] / nq;
-    if (w > 1) w = 1;
-    if (w < -1) w = -1;
-    real angle = 2 * R_ACOS(w);                       /* btQuaternion::getAngle */
-    real s2 = 1 - w * w, axis[3] = {1, 0, 0};         /* btQuaternion::getAxis */
-    if (s2 >= (real)1e-14) { real s = 1 / R_SQRT(s2); for (int k = 0; k < 3; k++) axis[k] = dq[k] / nq * s; }
+    /* btQuaternion::getAngle()/getAxis() = 2 acos(w), v / sqrt(1 - w^2), written in the equivalent
+     * atan2 / |v| form, which stays accurate in fp32 for small rotations (the HIP path computes in fp32) */
+    real vn = R_SQRT(dq[0] * dq[0] + dq[1] * dq[1] + dq[2] * dq[2]);
+    real angle = 2 * R_ATAN2(vn, dq[3]);
+    real axis[3] = {1, 0, 0};
+    if (vn >= (real)1e-12) for (int k = 0; k < 3; k++) axis[k] = dq[k] / vn;
     if (angle > RP_PI) angle -= 2 * RP_PI;
     for (int k = 0; k < 3; k++) err[3 + k] = angle * axis[k];
     /* Jacobian columns of the chain to the site */

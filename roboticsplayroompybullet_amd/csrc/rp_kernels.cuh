@@ -37,6 +37,7 @@
 #define K_ERP 0.08f
 #define K_SLOP 1e-5f
 #define K_MARGIN 0.005f
+#define K_TIE_EPS 1e-6f
 #define K_KP 0.1f
 #define K_DEFMOTOR 1.0f
 #define K_LIMIT_MAXIMP 100.0f
@@ -222,7 +223,7 @@ __device__ int box_box(V3 ca, const M3& Ra, V3 ha, V3 cb, const M3& Rb, V3 hb, f
     for (int k = 0; k < 3; k++) { ra += hA[k] * fabsf(dot(Lx, A[k])); rb += hB[k] * fabsf(dot(Lx, B[k])); }
     float s = fabsf(dot(t, Lx)) - ra - rb;
     if (s > margin) return 0;
-    if (s > best_s) { best_s = s; best_kind = f < 3 ? 0 : 1; best_i = f % 3; best_L = Lx; }
+    if (s > best_s + (f == 0 ? 0.f : K_TIE_EPS)) { best_s = s; best_kind = f < 3 ? 0 : 1; best_i = f % 3; best_L = Lx; }
   }
   float edge_s = -1e30f; int ei = 0, ej = 0; V3 eL = mk3(0, 0, 0);
   for (int i = 0; i < 3; i++)
@@ -235,7 +236,7 @@ __device__ int box_box(V3 ca, const M3& Ra, V3 ha, V3 cb, const M3& Rb, V3 hb, f
       for (int k = 0; k < 3; k++) { ra += hA[k] * fabsf(dot(Lx, A[k])); rb += hB[k] * fabsf(dot(Lx, B[k])); }
       float s = fabsf(dot(t, Lx)) - ra - rb;
       if (s > margin) return 0;
-      if (s > edge_s) { edge_s = s; ei = i; ej = j; eL = Lx; }
+      if (s > edge_s + K_TIE_EPS) { edge_s = s; ei = i; ej = j; eL = Lx; }
     }
   if (edge_s > best_s + 0.05f * fabsf(best_s) + 1e-6f) {
     V3 n = eL;
@@ -261,7 +262,7 @@ __device__ int box_box(V3 ca, const M3& Ra, V3 ha, V3 cb, const M3& Rb, V3 hb, f
   V3 nref = best_L;
   if (dot(nref, cY - cX) < 0.f) nref = -nref;
   int j = 0; float bj = -1.f;
-  for (int k = 0; k < 3; k++) { float v = fabsf(dot(nref, Y[k])); if (v > bj) { bj = v; j = k; } }
+  for (int k = 0; k < 3; k++) { float v = fabsf(dot(nref, Y[k])); if (v > bj + K_TIE_EPS) { bj = v; j = k; } }
   float sj = dot(nref, Y[j]) > 0.f ? -1.f : 1.f;
   int k1 = (j + 1) % 3, k2 = (j + 2) % 3;
   V3 fc = cY + Y[j] * (sj * hY[j]);
@@ -281,7 +282,7 @@ __device__ int box_box(V3 ca, const M3& Ra, V3 ha, V3 cb, const M3& Rb, V3 hb, f
     if (dist > margin) continue;
     st3(poly[1][cnt], pv - nref * (0.5f * dist));
     dists[cnt] = dist;
-    if (dist < dists[deepest]) deepest = cnt;
+    if (dist < dists[deepest] - K_TIE_EPS) deepest = cnt;
     cnt++;
   }
   V3 nn = best_kind == 1 ? nref : -nref;
@@ -328,7 +329,7 @@ __device__ int sphere_box(V3 cs, float r, V3 cb, const M3& Rb, V3 hb, float marg
 /* btPersistentManifold::sortCachedPoints on points stored as 8-float records (p3 n3 dist pad) */
 __device__ int manifold_replace_index(const float* c4, const float* pt) {
   int deepest = -1; float maxpen = pt[6];
-  for (int i = 0; i < 4; i++) if (c4[8 * i + 6] < maxpen) { deepest = i; maxpen = c4[8 * i + 6]; }
+  for (int i = 0; i < 4; i++) if (c4[8 * i + 6] < maxpen - K_TIE_EPS) { deepest = i; maxpen = c4[8 * i + 6]; }
   float res[4] = {0, 0, 0, 0};
   V3 P = ld3(pt), p0 = ld3(c4), p1 = ld3(c4 + 8), p2 = ld3(c4 + 16), p3 = ld3(c4 + 24), cr;
   if (deepest != 0) { cr = cross(P - p1, p3 - p2); res[0] = dot(cr, cr); }
@@ -336,7 +337,7 @@ __device__ int manifold_replace_index(const float* c4, const float* pt) {
   if (deepest != 2) { cr = cross(P - p0, p3 - p1); res[2] = dot(cr, cr); }
   if (deepest != 3) { cr = cross(P - p0, p2 - p1); res[3] = dot(cr, cr); }
   int best = 0;
-  for (int i = 1; i < 4; i++) if (res[i] > res[best]) best = i;
+  for (int i = 1; i < 4; i++) if (res[i] > res[best] * (1.f + 1e-4f)) best = i;
   return best;
 }
 
@@ -396,7 +397,7 @@ __device__ int collide(const DevModel* m, EnvLds& L, int lane) {
           int dst;
           if (single) {
             if (mycnt == 0) dst = mycnt++;
-            else dst = c[6] < man[6] ? 0 : -1;
+            else dst = c[6] < man[6] - K_TIE_EPS ? 0 : -1;
           } else if (mycnt < 4) dst = mycnt++;
           else dst = manifold_replace_index(man, c);
           if (dst >= 0) for (int k = 0; k < 8; k++) man[8 * dst + k] = c[k];
@@ -861,12 +862,10 @@ __device__ ChainQ ik_solve(const DevModel* m, V3 tpos, Q4 tq, ChainQ q, int max_
     Q4 qc = m3_to_quat(Rs);
     Q4 qi = {-qc.x, -qc.y, -qc.z, qc.w};
     Q4 dq = qmul(tq, qi);
-    float nq = sqrtf(dq.x * dq.x + dq.y * dq.y + dq.z * dq.z + dq.w * dq.w);
-    float w = clampf(dq.w / nq, -1.f, 1.f);
-    float angle = 2.f * acosf(w);
-    float s2 = 1.f - w * w;
+    float vn = sqrtf(dq.x * dq.x + dq.y * dq.y + dq.z * dq.z);     /* 2 acos(w) in its fp32-safe atan2 form */
+    float angle = 2.f * atan2f(vn, dq.w);
     V3 axis = mk3(1, 0, 0);
-    if (s2 >= 1e-14f) { float s = 1.f / (sqrtf(s2) * nq); axis = mk3(dq.x * s, dq.y * s, dq.z * s); }
+    if (vn >= 1e-12f) { float s = 1.f / vn; axis = mk3(dq.x * s, dq.y * s, dq.z * s); }
     if (angle > RP_PI_F) angle -= 2.f * RP_PI_F;
     float err[6] = {ep.x, ep.y, ep.z, angle * axis.x, angle * axis.y, angle * axis.z};
     float J[6][7];

@@ -1,0 +1,157 @@
+"""HIP path (through the C ABI) vs the CPU oracle on identical seeded inputs.  Run with -m gpu on the MI355X box.
+
+Tolerances (fp32 device arithmetic vs the fp64 oracle):
+  * reset (IK + 100 settle substeps) and short rollouts vs the fp32 oracle:     1e-4 absolute on observations
+  * 200-step random-action rollouts vs the fp64 oracle, arm joint state:        1e-3 relative (north_star's bound),
+    measured as max |q_hip - q_oracle| / max(1, |q_oracle|) over the rollout
+  * integer outputs (is_success, proprioception flag, status): exact
+"""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+
+IDS = {'U': 'UR5PlayAbsRPY1Obj-v0', 'R': 'UR5Reach-v0', 'P': 'pandaPick-v0'}
+LO = np.array([-0.18, 0.0, 0.05, -0.5, -0.5, -0.5, -1.0])
+HI = np.array([0.18, 0.3, 0.3, 0.5, 0.5, 0.5, 1.0])
+
+pytestmark = pytest.mark.gpu
+
+
+def actions(kind, steps, n, seed):
+    rng = np.random.default_rng(seed)
+    a = LO + (HI - LO) * rng.random((steps, n, 7))
+    if kind != 'U':
+        a[..., 0:3] = np.array([-0.18, -0.18, 0.0]) + np.array([0.36, 0.36, 0.2]) * rng.random((steps, n, 3))
+    return a
+
+
+def arm_q(env, kind):
+    n_arm = 9 if kind == 'P' else 12
+    return env.get_state()[:, :n_arm].cpu().numpy()
+
+
+@pytest.mark.parametrize('kind', ['U', 'R', 'P'])
+def test_reset_parity(kind):
+    from oracle import OracleEnv
+    from roboticsplayroompybullet_amd import VecPlayEnv
+    env = VecPlayEnv(IDS[kind], 8, seed=42)
+    obs = env.reset()
+    torch.cuda.synchronize()
+    for e in (0, 3, 7):
+        o = OracleEnv(kind, seed=42, env_index=e, f32=True).reset()
+        for k in ('obs_quat', 'achieved_goal', 'desired_goal', 'controllable_achieved_goal', 'full_positional_state',
+                  'velocity', 'observation'):
+            np.testing.assert_allclose(obs[k][e].cpu().numpy(), o[k], atol=1e-4, rtol=0, err_msg='%s env %d' % (k, e))
+        np.testing.assert_allclose(obs['joints'][e].cpu().numpy(), o['joints'], atol=1e-4)
+        assert int(obs['gripper_proprioception'][e]) == o['gripper_proprioception']
+
+
+@pytest.mark.parametrize('kind', ['U', 'R', 'P'])
+def test_rollout_200_steps_vs_fp64_oracle(kind):
+    """north_star: <= 1e-3 relative joint-state divergence over 200 steps on identical initial states and actions."""
+    from oracle import OracleEnv
+    from roboticsplayroompybullet_amd import VecPlayEnv
+    n, steps = 4, 200
+    env = VecPlayEnv(IDS[kind], n, seed=9)
+    env.reset()
+    oracles = [OracleEnv(kind, seed=9, env_index=e) for e in range(n)]
+    for o in oracles:
+        o.reset()
+    # start both from the oracle's post-reset state so fp32/fp64 reset differences do not enter
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    from gpu_debug import record_from_oracle
+    env.set_state(torch.tensor(np.stack([record_from_oracle(o) for o in oracles])))
+    acts = actions(kind, steps, n, 5)
+    worst = 0.0
+    n_arm = oracles[0].n_arm
+    for t in range(steps):
+        obs, r, done, info = env.step(torch.tensor(acts[t], dtype=torch.float32))
+        q = arm_q(env, kind)
+        for e, o in enumerate(oracles):
+            oo, ro, _, io = o.step(acts[t, e].astype(np.float32).astype(np.float64))
+            qo = o.get_state()[:n_arm]
+            worst = max(worst, float(np.max(np.abs(q[e] - qo) / np.maximum(1.0, np.abs(qo)))))
+        assert int(info['status'].sum()) == 0
+    print('max relative joint divergence over %d steps (%s): %.3e' % (steps, kind, worst))
+    assert worst <= 1e-3
+
+
+def test_shard_equivalence_bitwise():
+    """envs [0,8) in one handle == two handles of 4 with env_offset 0 / 4 (what multi-GPU sharding relies on)."""
+    from roboticsplayroompybullet_amd import VecPlayEnv
+    full = VecPlayEnv(IDS['U'], 8, seed=3)
+    a = VecPlayEnv(IDS['U'], 4, seed=3, env_offset=0)
+    b = VecPlayEnv(IDS['U'], 4, seed=3, env_offset=4)
+    of, oa, ob = full.reset(), a.reset(), b.reset()
+    acts = torch.tensor(actions('U', 5, 8, 1), dtype=torch.float32)
+    for t in range(5):
+        of, rf, _, _ = full.step(acts[t])
+        oa, ra, _, _ = a.step(acts[t, :4])
+        ob, rb, _, _ = b.step(acts[t, 4:])
+    torch.cuda.synchronize()
+    assert torch.equal(of['obs_quat'], torch.cat([oa['obs_quat'], ob['obs_quat']]))
+    assert torch.equal(full.get_state(), torch.cat([a.get_state(), b.get_state()]))
+    assert torch.equal(rf, torch.cat([ra, rb]))
+
+
+def test_determinism_and_state_roundtrip():
+    from roboticsplayroompybullet_amd import VecPlayEnv
+    env = VecPlayEnv(IDS['U'], 16, seed=1)
+    env.reset()
+    s0 = env.get_state().clone()
+    acts = torch.tensor(actions('U', 4, 16, 2), dtype=torch.float32)
+    for t in range(4):
+        env.step(acts[t])
+    s1 = env.get_state().clone()
+    env.set_state(s0)
+    for t in range(4):
+        env.step(acts[t])
+    assert torch.equal(env.get_state(), s1)
+    # broadcast one env's state to all (CEM-MPC style) and roll the same actions: all envs stay identical
+    env.set_state(s0[5])
+    a = acts[0, :1].repeat(16, 1)
+    obs, _, _, _ = env.step(a)
+    assert torch.equal(obs['obs_quat'], obs['obs_quat'][:1].repeat(16, 1))
+
+
+def test_compute_reward_matches_reference_goldens(golden):
+    from roboticsplayroompybullet_amd import VecPlayEnv
+    g = golden('rewards.json')
+    env = VecPlayEnv(IDS['U'], 1)
+    ag = torch.tensor([r['ag'] for r in g['success_func']], dtype=torch.float32)
+    dg = torch.tensor([r['g'] for r in g['success_func']], dtype=torch.float32)
+    want = torch.tensor([float(r['r']) for r in g['success_func']])
+    assert torch.equal(env.compute_reward(ag, dg).cpu(), want)
+    for kind in ('R', 'P'):
+        env = VecPlayEnv(IDS[kind], 1)
+        b = g['sparse'][kind]['batch']
+        got = env.compute_reward(torch.tensor(b['ag'], dtype=torch.float32), torch.tensor(b['dg'], dtype=torch.float32)).cpu().numpy()
+        np.testing.assert_allclose(got, b['r'], atol=1e-6)
+
+
+def test_full_size_properties():
+    """N = 4096 (BASELINE.json size): size-independent invariants after 25 random steps."""
+    from roboticsplayroompybullet_amd import VecPlayEnv
+    n = 4096
+    env = VecPlayEnv(IDS['U'], n, seed=77)
+    obs = env.reset()
+    assert int(env.buf['status'].sum()) == 0
+    acts = torch.tensor(actions('U', 25, n, 4), dtype=torch.float32)
+    for t in range(25):
+        obs, r, done, info = env.step(acts[t])
+    torch.cuda.synchronize()
+    assert int(info['status'].sum()) == 0
+    o = obs['obs_quat']
+    assert torch.isfinite(o).all()
+    assert torch.allclose(o[:, 3:7].norm(dim=1), torch.ones(n, device=o.device), atol=1e-4)      # ee quaternion
+    assert torch.allclose(o[:, 11:15].norm(dim=1), torch.ones(n, device=o.device), atol=1e-4)    # block quaternion
+    assert (o[:, 10] > -0.03).all()                               # block never falls through the table (top at z = -0.025)
+    assert ((r == 0) | (r == -1)).all() and not done.any()
+    assert torch.equal(info['is_success'], (r >= 0).int())
+    assert torch.equal(obs['achieved_goal'], o[:, 8:19])          # App. B layout identities
+    assert torch.equal(obs['full_positional_state'][:, :8], o[:, :8])
+    # per-step joint clamp of goto_joint_poses (environments.py:1021-1026)
+    tp = info['target_poses']
+    assert (tp[:, 0] <= -0.7 + 1e-6).all() and (tp[:, 2] <= -0.5 + 1e-6).all()
