@@ -8,7 +8,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-LIB_PATH = os.path.join(CSRC, 'librp_playroom_hip.so')
+LIB_PATH = os.environ.get('RP_PLAYROOM_LIB', os.path.join(CSRC, 'librp_playroom_hip.so'))   # env override: profiling builds
 
 ENV_KINDS = {'UR5PlayAbsRPY1Obj-v0': 0, 'UR5Reach-v0': 1, 'pandaPick-v0': 2}
 

@@ -33,7 +33,11 @@
 #define K_GRAVITY (-9.8f)
 #define K_NSUB 12
 #define K_NSETTLE 100
+#ifdef K_NITER_OVERRIDE   /* timing ablations only */
+#define K_NITER K_NITER_OVERRIDE
+#else
 #define K_NITER 50
+#endif
 #define K_ERP 0.08f
 #define K_SLOP 1e-5f
 #define K_MARGIN 0.005f
@@ -55,7 +59,8 @@ struct __align__(16) EnvLds {
   float S[RP_MAX_ARM * 6];
   float inert[RP_MAX_ARM * 10], compI[RP_MAX_ARM * 10];
   float vsp[RP_MAX_ARM * 6], csp[RP_MAX_ARM * 6], fsp[RP_MAX_ARM * 6], Fv[RP_MAX_ARM * 6];
-  float M[144], Minv[144], tau[RP_MAX_ARM];
+  double Md[144];                /* mass matrix and its Cholesky factor, fp64 (12x12: cheap, removes the fp32 inverse error) */
+  float Minv[144], tau[RP_MAX_ARM];
   float finv[RP_MAX_FREE * 9];
   float vstar[32];
   float aabb[RP_MAX_COL * 6];
@@ -64,7 +69,6 @@ struct __align__(16) EnvLds {
   int cona[MAXC], conb[MAXC];
   float srow[MAXSMALL * 8];      /* type, dofA, sign/ratio, rhs, dinv, lo, hi, dofB */
   float rowS[MAXROWC * 4];       /* rhs, dinv, mu, parent */
-  float lam[MAXSMALL + MAXROWC];
   union {
     struct { float cand[MAXACT * 4 * 8]; float man[MAXACT * 4 * 8]; } c;   /* narrowphase scratch */
     struct { float J[MAXROWC * NVP]; float B[MAXROWC * NVP]; } r;            /* contact rows */
@@ -461,11 +465,16 @@ __device__ void arm_dynamics(const DevModel* m, EnvLds& L, int lane) {
     st6(&L.Fv[6 * lane], inertia_mul(acc, Si));
   }
   __syncthreads();
-  for (int e = lane; e < n * n; e += 64) {   /* M_ij = S_i . (Ic_j S_j) for i an ancestor-or-self of j */
+  for (int e = lane; e < n * n; e += 64) {   /* M_ij = S_i . (Ic_j S_j) for i an ancestor-or-self of j, accumulated in fp64 */
     int i = e / n, j = e % n;
     if (i <= j) {
-      float val = ((m->arm_anc[j] >> i) & 1u) ? dot6(ld6(&L.S[6 * i]), ld6(&L.Fv[6 * j])) : 0.f;
-      L.M[i * 12 + j] = val; L.M[j * 12 + i] = val;
+      double val = 0.0;
+      if ((m->arm_anc[j] >> i) & 1u) {
+        const float* a = &L.S[6 * i];
+        const float* b = &L.Fv[6 * j];
+        for (int k = 0; k < 6; k++) val += (double)a[k] * (double)b[k];
+      }
+      L.Md[i * 12 + j] = val; L.Md[j * 12 + i] = val;
     }
   }
   if (lane < n) {      /* bias force of each body: f = I a_bias + v x* (I v), a_bias = -g + sum of ancestors' c */
@@ -484,42 +493,42 @@ __device__ void arm_dynamics(const DevModel* m, EnvLds& L, int lane) {
     for (int j = 0; j < n; j++) if ((sub >> j) & 1u) f = f + ld6(&L.fsp[6 * j]);
     L.tau[lane] = dot6(ld6(&L.S[6 * lane]), f);
   }
-  /* Cholesky M = L L^T in place (lower), lane i owns row i */
+  /* Cholesky M = L L^T in place (lower), lane i owns row i; fp64 */
   for (int k = 0; k < n; k++) {
     __syncthreads();
-    float piv = sqrtf(L.M[k * 12 + k]);
-    float lik = 0.f;
-    if (lane > k && lane < n) lik = L.M[lane * 12 + k] / piv;
+    double piv = sqrt(L.Md[k * 12 + k]);
+    double lik = 0.0;
+    if (lane > k && lane < n) lik = L.Md[lane * 12 + k] / piv;
     __syncthreads();
-    if (lane == k) L.M[k * 12 + k] = piv;
-    if (lane > k && lane < n) L.M[lane * 12 + k] = lik;
+    if (lane == k) L.Md[k * 12 + k] = piv;
+    if (lane > k && lane < n) L.Md[lane * 12 + k] = lik;
     __syncthreads();
     if (lane > k && lane < n)
-      for (int j = k + 1; j <= lane; j++) L.M[lane * 12 + j] -= lik * L.M[j * 12 + k];
+      for (int j = k + 1; j <= lane; j++) L.Md[lane * 12 + j] -= lik * L.Md[j * 12 + k];
   }
   __syncthreads();
   if (lane < n) {      /* column `lane` of M^-1: L y = e_c, L^T x = y */
-    float y[RP_MAX_ARM];
+    double y[RP_MAX_ARM];
 #pragma unroll
     for (int i = 0; i < RP_MAX_ARM; i++) {
       if (i < n) {
-        float s = (i == lane) ? 1.f : 0.f;
+        double s = (i == lane) ? 1.0 : 0.0;
 #pragma unroll
-        for (int k = 0; k < i; k++) s -= L.M[i * 12 + k] * y[k];
-        y[i] = s / L.M[i * 12 + i];
-      } else y[i] = 0.f;
+        for (int k = 0; k < i; k++) s -= L.Md[i * 12 + k] * y[k];
+        y[i] = s / L.Md[i * 12 + i];
+      } else y[i] = 0.0;
     }
 #pragma unroll
     for (int i = RP_MAX_ARM - 1; i >= 0; i--) {
       if (i < n) {
-        float s = y[i];
+        double s = y[i];
 #pragma unroll
-        for (int k = i + 1; k < RP_MAX_ARM; k++) if (k < n) s -= L.M[k * 12 + i] * y[k];
-        y[i] = s / L.M[i * 12 + i];
+        for (int k = i + 1; k < RP_MAX_ARM; k++) if (k < n) s -= L.Md[k * 12 + i] * y[k];
+        y[i] = s / L.Md[i * 12 + i];
       }
     }
 #pragma unroll
-    for (int i = 0; i < RP_MAX_ARM; i++) if (i < n) L.Minv[i * 12 + lane] = y[i];
+    for (int i = 0; i < RP_MAX_ARM; i++) if (i < n) L.Minv[i * 12 + lane] = (float)y[i];
   }
   __syncthreads();
 }
@@ -734,19 +743,21 @@ __device__ void contact_rows(const DevModel* m, EnvLds& L, int lane, int ncon) {
   (void)nv;
 }
 
-/* 50 sweeps of sequential impulses; lane l owns dv[l]; returns dv of this lane */
+/* 50 sweeps of sequential impulses; lane l owns dv[l]; returns dv of this lane.
+ * Accumulated impulses live in registers, one row per lane (lamS: small rows, lamC0/lamC1: contact rows 0..63 /
+ * 64..95), read with v_readlane, written with a lane-select; row data for row r+1 is fetched from LDS while row r's
+ * dependent chain (multiply -> DPP reduction -> clamp -> axpy) runs. */
 __device__ float solve_rows(const DevModel* m, EnvLds& L, int lane, int nsmall, int ncon) {
   int n = m->n_arm;
   float dv = 0.f;
   int nrc = 3 * ncon;
-  for (int r = lane; r < nsmall + nrc; r += 64) L.lam[r] = 0.f;
-  __syncthreads();
+  float lamS = 0.f, lamC0 = 0.f, lamC1 = 0.f;
   for (int it = 0; it < K_NITER; it++) {
     for (int r = 0; r < nsmall; r++) {
       const float* s = &L.srow[8 * r];
       int type = uni(__float_as_int(s[0])), dA = uni(__float_as_int(s[1]));
       float sg = s[2], rhs = s[3], dinv = s[4], lo = s[5], hi = s[6];
-      float lam = L.lam[r];
+      float lam = lane_read(lamS, r);
       float jdv, bl = 0.f;
       if (type == SR_UNIT) {
         jdv = sg * lane_read(dv, dA);
@@ -762,24 +773,32 @@ __device__ float solve_rows(const DevModel* m, EnvLds& L, int lane, int nsmall, 
       float d = rhs - jdv * dinv;
       float sum = lam + d;
       if (sum < lo) { d = lo - lam; sum = lo; } else if (sum > hi) { d = hi - lam; sum = hi; }
-      if (lane == 0) L.lam[r] = sum;
+      lamS = lane == r ? sum : lamS;
       dv += bl * d;
     }
-    for (int r = 0; r < nrc; r++) {
-      float jl = 0.f, bl = 0.f;
-      if (lane < NVP) { jl = L.u.r.J[r * NVP + lane]; bl = L.u.r.B[r * NVP + lane]; }
-      const float* s = &L.rowS[4 * r];
-      float rhs = s[0], dinv = s[1], mu = s[2];
-      int parent = uni(__float_as_int(s[3]));
-      float lam = L.lam[nsmall + r];
-      float lo = 0.f, hi = 1e10f;
-      if (parent >= 0) { float lim = mu * L.lam[nsmall + parent]; lo = -lim; hi = lim; }
-      float jdv = wave_sum32(jl * dv);
-      float d = rhs - jdv * dinv;
-      float sum = lam + d;
-      if (sum < lo) { d = lo - lam; sum = lo; } else if (sum > hi) { d = hi - lam; sum = hi; }
-      if (lane == 0) L.lam[nsmall + r] = sum;
-      dv += bl * d;
+    if (nrc > 0) {
+      float jn = 0.f, bn = 0.f;
+      if (lane < NVP) { jn = L.u.r.J[lane]; bn = L.u.r.B[lane]; }
+      float4 sn = *(const float4*)&L.rowS[0];
+      for (int r = 0; r < nrc; r++) {
+        float jl = jn, bl = bn;
+        float rhs = sn.x, dinv = sn.y, mu = sn.z;
+        int parent = uni(__float_as_int(sn.w));
+        if (r + 1 < nrc) {
+          if (lane < NVP) { jn = L.u.r.J[(r + 1) * NVP + lane]; bn = L.u.r.B[(r + 1) * NVP + lane]; }
+          sn = *(const float4*)&L.rowS[4 * (r + 1)];
+        }
+        float lam = r < 64 ? lane_read(lamC0, r) : lane_read(lamC1, r - 64);
+        float lo = 0.f, hi = 1e10f;
+        if (parent >= 0) { float lim = mu * lane_read(lamC0, parent); lo = -lim; hi = lim; }   /* parent < ncon <= 32 */
+        float jdv = wave_sum32(jl * dv);
+        float d = rhs - jdv * dinv;
+        float sum = lam + d;
+        if (sum < lo) { d = lo - lam; sum = lo; } else if (sum > hi) { d = hi - lam; sum = hi; }
+        if (r < 64) lamC0 = lane == r ? sum : lamC0;
+        else lamC1 = lane == r - 64 ? sum : lamC1;
+        dv += bl * d;
+      }
     }
   }
   return dv;

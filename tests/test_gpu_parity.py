@@ -64,7 +64,7 @@ def test_rollout_200_steps_vs_fp64_oracle(kind):
     from gpu_debug import record_from_oracle
     env.set_state(torch.tensor(np.stack([record_from_oracle(o) for o in oracles])))
     acts = actions(kind, steps, n, 5)
-    worst = 0.0
+    worst, per_dof = 0.0, None
     n_arm = oracles[0].n_arm
     for t in range(steps):
         obs, r, done, info = env.step(torch.tensor(acts[t], dtype=torch.float32))
@@ -72,9 +72,11 @@ def test_rollout_200_steps_vs_fp64_oracle(kind):
         for e, o in enumerate(oracles):
             oo, ro, _, io = o.step(acts[t, e].astype(np.float32).astype(np.float64))
             qo = o.get_state()[:n_arm]
-            worst = max(worst, float(np.max(np.abs(q[e] - qo) / np.maximum(1.0, np.abs(qo)))))
+            rel = np.abs(q[e] - qo) / np.maximum(1.0, np.abs(qo))
+            worst = max(worst, float(rel.max()))
+            per_dof = np.maximum(per_dof, rel) if per_dof is not None else rel
         assert int(info['status'].sum()) == 0
-    print('max relative joint divergence over %d steps (%s): %.3e' % (steps, kind, worst))
+    print('max relative joint divergence over %d steps (%s): %.3e per dof %s' % (steps, kind, worst, np.array2string(per_dof, precision=1)))
     assert worst <= 1e-3
 
 
