@@ -69,6 +69,7 @@ struct __align__(16) EnvLds {
   int cona[MAXC], conb[MAXC];
   float srow[MAXSMALL * 8];      /* type, dofA, sign/ratio, rhs, dinv, lo, hi, dofB */
   float rowS[MAXROWC * 4];       /* rhs, dinv, mu, parent */
+  float rowT[MAXROWC * 2];       /* lo_c, hi_c */
   union {
     struct { float cand[MAXACT * 4 * 8]; float man[MAXACT * 4 * 8]; } c;   /* narrowphase scratch */
     struct { float J[MAXROWC * NVP]; float B[MAXROWC * NVP]; } r;            /* contact rows */
@@ -738,65 +739,85 @@ __device__ void contact_rows(const DevModel* m, EnvLds& L, int lane, int ncon) {
       rhs = (pos_err + vel_err) * dinv;
     } else rhs = -relv * dinv;
     float* s = &L.rowS[4 * r];
-    s[0] = rhs; s[1] = dinv; s[2] = L.conmu[ci]; s[3] = __int_as_float(dir == 0 ? -1 : ci);
+    s[0] = rhs; s[1] = dinv; s[2] = dir == 0 ? 0.f : L.conmu[ci]; s[3] = __int_as_float(dir == 0 ? 0 : ci);
+    L.rowT[2 * r] = 0.f; L.rowT[2 * r + 1] = dir == 0 ? 1e10f : 0.f;
   }
   (void)nv;
 }
 
 /* 50 sweeps of sequential impulses; lane l owns dv[l]; returns dv of this lane.
- * Accumulated impulses live in registers, one row per lane (lamS: small rows, lamC0/lamC1: contact rows 0..63 /
- * 64..95), read with v_readlane, written with a lane-select; row data for row r+1 is fetched from LDS while row r's
- * dependent chain (multiply -> DPP reduction -> clamp -> axpy) runs. */
-__device__ float solve_rows(const DevModel* m, EnvLds& L, int lane, int nsmall, int ncon) {
-  int n = m->n_arm;
+ * Everything per-row is wave-uniform: loop bounds and indices are forced into SGPRs, the clamp is branch-free
+ * (selects, so the unclamped delta is passed through bit-exactly as in the oracle), accumulated impulses live in
+ * registers one row per lane (v_readlane to fetch, lane-select to store), and the LDS data of row r+1 is fetched
+ * while row r's dependent chain (multiply -> DPP reduction -> clamp -> axpy) runs.
+ * Friction limits are lo = lo_c - mu*lambda[parent], hi = hi_c + mu*lambda[parent]; normal rows carry mu = 0,
+ * lo_c = 0, hi_c = 1e10 and a dummy parent, which reproduces [0, 1e10] exactly without a branch. */
+__device__ __forceinline__ float pgs_update(float rhs, float jdv, float dinv, float lam, float lo, float hi, float& lam_out) {
+  float d = rhs - jdv * dinv;
+  float sum = lam + d;
+  bool below = sum < lo, above = sum > hi;
+  d = below ? lo - lam : (above ? hi - lam : d);
+  lam_out = below ? lo : (above ? hi : sum);
+  return d;
+}
+
+__device__ float solve_rows(const DevModel* m, EnvLds& L, int lane, int nsmall_, int ncon_) {
+  const int n = m->n_arm;
+  const int nsmall = uni(nsmall_), nrc = uni(3 * ncon_);
   float dv = 0.f;
-  int nrc = 3 * ncon;
   float lamS = 0.f, lamC0 = 0.f, lamC1 = 0.f;
   for (int it = 0; it < K_NITER; it++) {
-    for (int r = 0; r < nsmall; r++) {
-      const float* s = &L.srow[8 * r];
-      int type = uni(__float_as_int(s[0])), dA = uni(__float_as_int(s[1]));
-      float sg = s[2], rhs = s[3], dinv = s[4], lo = s[5], hi = s[6];
-      float lam = lane_read(lamS, r);
-      float jdv, bl = 0.f;
-      if (type == SR_UNIT) {
-        jdv = sg * lane_read(dv, dA);
-        if (lane < n) bl = sg * L.Minv[lane * 12 + dA];
-      } else if (type == SR_J1) {
-        jdv = lane_read(dv, dA);
-        if (lane == dA) bl = sg;              /* sg holds 1/m for scene joints */
-      } else {
-        int dB = uni(__float_as_int(s[7]));
-        jdv = lane_read(dv, dA) + sg * lane_read(dv, dB);
-        if (lane < n) bl = L.Minv[lane * 12 + dA] + sg * L.Minv[lane * 12 + dB];
+    {   /* motors, limits, gear: J has one or two unit entries, B is a (combination of) column(s) of M^-1 */
+      float4 s0 = *(const float4*)&L.srow[0], s1 = *(const float4*)&L.srow[4];
+      float bn = 0.f;
+      {
+        int type = uni(__float_as_int(s0.x)), dA = uni(__float_as_int(s0.y)), dB = uni(__float_as_int(s1.w));
+        float sg = s0.z;
+        if (type == SR_J1) bn = lane == dA ? sg : 0.f;
+        else if (lane < n) bn = type == SR_UNIT ? sg * L.Minv[lane * 12 + dA] : L.Minv[lane * 12 + dA] + sg * L.Minv[lane * 12 + dB];
       }
-      float d = rhs - jdv * dinv;
-      float sum = lam + d;
-      if (sum < lo) { d = lo - lam; sum = lo; } else if (sum > hi) { d = hi - lam; sum = hi; }
-      lamS = lane == r ? sum : lamS;
-      dv += bl * d;
+      for (int r = 0; r < nsmall; r++) {
+        float4 c0 = s0, c1 = s1;
+        float bl = bn;
+        int type = uni(__float_as_int(c0.x)), dA = uni(__float_as_int(c0.y)), dB = uni(__float_as_int(c1.w));
+        if (r + 1 < nsmall) {
+          s0 = *(const float4*)&L.srow[8 * (r + 1)]; s1 = *(const float4*)&L.srow[8 * (r + 1) + 4];
+          int t2 = uni(__float_as_int(s0.x)), a2 = uni(__float_as_int(s0.y)), b2 = uni(__float_as_int(s1.w));
+          float g2 = s0.z;
+          bn = 0.f;
+          if (t2 == SR_J1) bn = lane == a2 ? g2 : 0.f;
+          else if (lane < n) bn = t2 == SR_UNIT ? g2 * L.Minv[lane * 12 + a2] : L.Minv[lane * 12 + a2] + g2 * L.Minv[lane * 12 + b2];
+        }
+        float sg = c0.z;
+        float jdv = type == SR_UNIT ? sg * lane_read(dv, dA) : (type == SR_J1 ? lane_read(dv, dA) : lane_read(dv, dA) + sg * lane_read(dv, dB));
+        float lam = lane_read(lamS, r), lnew;
+        float d = pgs_update(c0.w, jdv, c1.x, lam, c1.y, c1.z, lnew);
+        lamS = lane == r ? lnew : lamS;
+        dv += bl * d;
+      }
     }
-    if (nrc > 0) {
+    if (nrc > 0) {   /* contact normals then frictions: dense rows over the velocity vector */
       float jn = 0.f, bn = 0.f;
       if (lane < NVP) { jn = L.u.r.J[lane]; bn = L.u.r.B[lane]; }
       float4 sn = *(const float4*)&L.rowS[0];
+      float2 tn = *(const float2*)&L.rowT[0];
       for (int r = 0; r < nrc; r++) {
         float jl = jn, bl = bn;
-        float rhs = sn.x, dinv = sn.y, mu = sn.z;
+        float rhs = sn.x, dinv = sn.y, mu = sn.z, lo_c = tn.x, hi_c = tn.y;
         int parent = uni(__float_as_int(sn.w));
         if (r + 1 < nrc) {
           if (lane < NVP) { jn = L.u.r.J[(r + 1) * NVP + lane]; bn = L.u.r.B[(r + 1) * NVP + lane]; }
           sn = *(const float4*)&L.rowS[4 * (r + 1)];
+          tn = *(const float2*)&L.rowT[2 * (r + 1)];
         }
-        float lam = r < 64 ? lane_read(lamC0, r) : lane_read(lamC1, r - 64);
-        float lo = 0.f, hi = 1e10f;
-        if (parent >= 0) { float lim = mu * lane_read(lamC0, parent); lo = -lim; hi = lim; }   /* parent < ncon <= 32 */
-        float jdv = wave_sum32(jl * dv);
-        float d = rhs - jdv * dinv;
-        float sum = lam + d;
-        if (sum < lo) { d = lo - lam; sum = lo; } else if (sum > hi) { d = hi - lam; sum = hi; }
-        if (r < 64) lamC0 = lane == r ? sum : lamC0;
-        else lamC1 = lane == r - 64 ? sum : lamC1;
+        float lamv = r < 64 ? lamC0 : lamC1;
+        float lam = lane_read(lamv, r & 63);
+        float lim = mu * lane_read(lamC0, parent);            /* parent < ncon <= 32 */
+        float jdv = wave_sum32(jl * dv), lnew;
+        float d = pgs_update(rhs, jdv, dinv, lam, lo_c - lim, hi_c + lim, lnew);
+        float sel = lane == (r & 63) ? lnew : lamv;
+        lamC0 = r < 64 ? sel : lamC0;
+        lamC1 = r < 64 ? lamC1 : sel;
         dv += bl * d;
       }
     }
