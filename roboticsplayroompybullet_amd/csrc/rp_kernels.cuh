@@ -24,10 +24,14 @@
 
 #define NB_MAX (1 + RP_MAX_ARM + RP_MAX_FREE + RP_MAX_J1)
 #define NVP 28               /* padded row stride (nv <= 27) */
-#define MAXC 32              /* contact points kept per env per substep (shared cap with the oracle) */
+#define MAXC 24              /* contact points kept per env per substep (shared cap with the oracle) */
 #define MAXACT 64            /* AABB-overlapping pairs examined per substep (shared cap with the oracle) */
 #define MAXROWC (3 * MAXC)
 #define MAXSMALL 44          /* arm motors 12 + scene-joint motors 3 + limits 24 + gear 1 (+ pad) */
+
+#ifndef RP_WAVES_PER_EU
+#define RP_WAVES_PER_EU 2      /* register budget: 512 / RP_WAVES_PER_EU VGPR+AGPR per lane */
+#endif
 
 #define K_DT (1.0f / 300.0f)
 #define K_GRAVITY (-9.8f)
@@ -52,30 +56,37 @@
 #define K_IK_RES 1e-4f
 #define K_IK_MAXSTEP (45.0f * RP_PI_F / 180.0f)
 
+#define ROWW 18              /* compact Jacobian row: slot0 = 12 entries at dof offset off0, slot1 = 6 entries at off1 */
+
+/* Per-env LDS block.  Phase-local scratch (collision, dynamics, Jacobian rows) shares one union: the phases of a
+ * substep run strictly one after another, separated by barriers. */
 struct __align__(16) EnvLds {
   float st[RP_REC_FLOATS];
   float xR[NB_MAX * 9], xp[NB_MAX * 3];
   float O[4];
   float S[RP_MAX_ARM * 6];
-  float inert[RP_MAX_ARM * 10], compI[RP_MAX_ARM * 10];
-  float vsp[RP_MAX_ARM * 6], csp[RP_MAX_ARM * 6], fsp[RP_MAX_ARM * 6], Fv[RP_MAX_ARM * 6];
-  double Md[144];                /* mass matrix and its Cholesky factor, fp64 (12x12: cheap, removes the fp32 inverse error) */
   float Minv[144], tau[RP_MAX_ARM];
   float finv[RP_MAX_FREE * 9];
   float vstar[32];
-  float aabb[RP_MAX_COL * 6];
-  int act[MAXACT], candn[MAXACT], key[MAXACT], cnt[MAXACT];
   float conp[MAXC * 3], conn[MAXC * 3], cond[MAXC], conmu[MAXC];
   int cona[MAXC], conb[MAXC];
-  float srow[MAXSMALL * 8];      /* type, dofA, sign/ratio, rhs, dinv, lo, hi, dofB */
+  float srow[MAXSMALL * 8];      /* type, dofA, sign/ratio, rhs | dinv, lo, hi, dofB */
   float rowS[MAXROWC * 4];       /* rhs, dinv, mu, parent */
-  float rowT[MAXROWC * 2];       /* lo_c, hi_c */
+  float rowT[MAXROWC * 4];       /* lo_c, hi_c, off0, off1 */
   union {
-    struct { float cand[MAXACT * 4 * 8]; float man[MAXACT * 4 * 8]; } c;   /* narrowphase scratch */
-    struct { float J[MAXROWC * NVP]; float B[MAXROWC * NVP]; } r;            /* contact rows */
+    struct {                                   /* collide() */
+      float aabb[RP_MAX_COL * 6];
+      int act[MAXACT], candn[MAXACT], key[MAXACT], cnt[MAXACT];
+      float cand[MAXACT * 4 * 8];              /* candidate points; manifolds are merged in place */
+    } c;
+    struct {                                   /* arm_dynamics() */
+      float inert[RP_MAX_ARM * 10], compI[RP_MAX_ARM * 10];
+      float vsp[RP_MAX_ARM * 6], csp[RP_MAX_ARM * 6], fsp[RP_MAX_ARM * 6], Fv[RP_MAX_ARM * 6];
+      double Md[144];                          /* mass matrix / Cholesky factor in fp64 */
+    } d;
+    struct { float J[MAXROWC * ROWW]; float B[MAXROWC * ROWW]; } r;   /* contact rows */
   } u;
   float out[128];
-  int ray_link; float ray_t;
 };
 
 /* ------------------------------------------------------------------ small helpers */
@@ -191,7 +202,7 @@ __device__ void collider_aabbs(const DevModel* m, EnvLds& L, int lane) {
     float e[3];
     for (int i = 0; i < 3; i++)
       e[i] = m->col_type[lane] == 0 ? fabsf(x.R.m[3 * i]) * he.x + fabsf(x.R.m[3 * i + 1]) * he.y + fabsf(x.R.m[3 * i + 2]) * he.z : he.x;
-    float* a = &L.aabb[6 * lane];
+    float* a = &L.u.c.aabb[6 * lane];
     a[0] = x.p.x - e[0]; a[1] = x.p.y - e[1]; a[2] = x.p.z - e[2];
     a[3] = x.p.x + e[0]; a[4] = x.p.y + e[1]; a[5] = x.p.z + e[2];
   }
@@ -355,21 +366,21 @@ __device__ int collide(const DevModel* m, EnvLds& L, int lane) {
     bool ov = false;
     if (pi < m->n_pair) {
       int a = m->pair[pi][0], b = m->pair[pi][1];
-      const float* A = &L.aabb[6 * a];
-      const float* Bb = &L.aabb[6 * b];
+      const float* A = &L.u.c.aabb[6 * a];
+      const float* Bb = &L.u.c.aabb[6 * b];
       ov = !(A[0] > Bb[3] + K_MARGIN || Bb[0] > A[3] + K_MARGIN || A[1] > Bb[4] + K_MARGIN || Bb[1] > A[4] + K_MARGIN ||
              A[2] > Bb[5] + K_MARGIN || Bb[2] > A[5] + K_MARGIN);
     }
     unsigned long long mask = __ballot(ov);
     int before = __popcll(mask & ((1ull << lane) - 1ull));
-    if (ov && nact + before < MAXACT) L.act[nact + before] = pi;
+    if (ov && nact + before < MAXACT) L.u.c.act[nact + before] = pi;
     nact += __popcll(mask);
     if (nact >= MAXACT) { nact = MAXACT; break; }
   }
   __syncthreads();
   /* 2. narrowphase: one lane per active pair */
   if (lane < nact) {
-    int pi = L.act[lane];
+    int pi = L.u.c.act[lane];
     int a = m->pair[pi][0], b = m->pair[pi][1];
     Xf xa = collider_xf(m, L, a), xb = collider_xf(m, L, b);
     V3 ha = ld3(m->col_he[a]), hb = ld3(m->col_he[b]);
@@ -382,22 +393,22 @@ __device__ int collide(const DevModel* m, EnvLds& L, int lane) {
       float* c = &L.u.c.cand[(lane * 4 + i) * 8];
       st3(c, pts[i].p); st3(c + 3, pts[i].n); c[6] = pts[i].dist; c[7] = __int_as_float(pi);
     }
-    L.candn[lane] = np;
-    L.key[lane] = m->col_obj[a] * 256 + m->col_obj[b];
+    L.u.c.candn[lane] = np;
+    L.u.c.key[lane] = m->col_obj[a] * 256 + m->col_obj[b];
   }
   __syncthreads();
   /* 3. manifolds: the first lane of each run of equal object pairs merges the run sequentially (<= 4 points) */
   int mycnt = 0;
   if (lane < nact) {
-    bool head = lane == 0 || L.key[lane - 1] != L.key[lane];
+    bool head = lane == 0 || L.u.c.key[lane - 1] != L.u.c.key[lane];
     if (head) {
-      float* man = &L.u.c.man[lane * 32];
-      int pi0 = L.act[lane];
+      float* man = &L.u.c.cand[lane * 32];          /* in place: a head lane's own points are inserted first */
+      int pi0 = L.u.c.act[lane];
       int a0 = m->pair[pi0][0], b0 = m->pair[pi0][1];
       int kf = m->col_body[a0] - 1 - m->n_arm;
       bool single = kf >= 0 && kf < m->n_free && m->free_rot_locked[kf] && m->col_body[b0] == 0;
-      for (int j = lane; j < nact && L.key[j] == L.key[lane]; j++) {
-        for (int i = 0; i < L.candn[j]; i++) {
+      for (int j = lane; j < nact && L.u.c.key[j] == L.u.c.key[lane]; j++) {
+        for (int i = 0; i < L.u.c.candn[j]; i++) {
           const float* c = &L.u.c.cand[(j * 4 + i) * 8];
           int dst;
           if (single) {
@@ -409,15 +420,15 @@ __device__ int collide(const DevModel* m, EnvLds& L, int lane) {
         }
       }
     }
-    L.cnt[lane] = mycnt;
+    L.u.c.cnt[lane] = mycnt;
   }
   __syncthreads();
   int total = 0;
   if (lane < nact) {
     int off = 0;
-    for (int j = 0; j < lane; j++) off += L.cnt[j];
+    for (int j = 0; j < lane; j++) off += L.u.c.cnt[j];
     for (int i = 0; i < mycnt && off + i < MAXC; i++) {
-      const float* c = &L.u.c.man[lane * 32 + 8 * i];
+      const float* c = &L.u.c.cand[lane * 32 + 8 * i];
       int o = off + i;
       st3(&L.conp[3 * o], ld3(c)); st3(&L.conn[3 * o], ld3(c + 3));
       L.cond[o] = c[6];
@@ -427,7 +438,7 @@ __device__ int collide(const DevModel* m, EnvLds& L, int lane) {
       L.conmu[o] = m->col_friction[a] * m->col_friction[b];
     }
   }
-  for (int j = 0; j < nact; j++) total += L.cnt[j];     /* nact uniform; LDS broadcast reads */
+  for (int j = 0; j < nact; j++) total += L.u.c.cnt[j];     /* nact uniform; LDS broadcast reads */
   __syncthreads();
   return total < MAXC ? total : MAXC;
 }
@@ -444,7 +455,7 @@ __device__ void arm_dynamics(const DevModel* m, EnvLds& L, int lane) {
     M3 Rt; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Rt.m[3 * i + j] = R.m[3 * j + i];
     M3 Iw = mul(mul(R, Ic), Rt);
     float cc = dot(c, c);
-    float* I = &L.inert[10 * lane];
+    float* I = &L.u.d.inert[10 * lane];
     I[0] = mass; st3(I + 1, c * mass);
     I[4] = Iw.m[0] + mass * (cc - c.x * c.x); I[5] = Iw.m[4] + mass * (cc - c.y * c.y); I[6] = Iw.m[8] + mass * (cc - c.z * c.z);
     I[7] = Iw.m[1] - mass * c.x * c.y; I[8] = Iw.m[2] - mass * c.x * c.z; I[9] = Iw.m[5] - mass * c.y * c.z;
@@ -456,14 +467,14 @@ __device__ void arm_dynamics(const DevModel* m, EnvLds& L, int lane) {
     for (int k = 0; k < 10; k++) acc[k] = 0.f;
     V6 v = zero6();
     for (int j = 0; j < n; j++) {
-      if ((sub >> j) & 1u) for (int k = 0; k < 10; k++) acc[k] += L.inert[10 * j + k];
+      if ((sub >> j) & 1u) for (int k = 0; k < 10; k++) acc[k] += L.u.d.inert[10 * j + k];
       if ((anc >> j) & 1u) v = v + ld6(&L.S[6 * j]) * L.st[ST_QD + j];
     }
-    for (int k = 0; k < 10; k++) L.compI[10 * lane + k] = acc[k];
-    st6(&L.vsp[6 * lane], v);
+    for (int k = 0; k < 10; k++) L.u.d.compI[10 * lane + k] = acc[k];
+    st6(&L.u.d.vsp[6 * lane], v);
     V6 Si = ld6(&L.S[6 * lane]);
-    st6(&L.csp[6 * lane], crm(v, Si * L.st[ST_QD + lane]));
-    st6(&L.Fv[6 * lane], inertia_mul(acc, Si));
+    st6(&L.u.d.csp[6 * lane], crm(v, Si * L.st[ST_QD + lane]));
+    st6(&L.u.d.Fv[6 * lane], inertia_mul(acc, Si));
   }
   __syncthreads();
   for (int e = lane; e < n * n; e += 64) {   /* M_ij = S_i . (Ic_j S_j) for i an ancestor-or-self of j, accumulated in fp64 */
@@ -472,40 +483,40 @@ __device__ void arm_dynamics(const DevModel* m, EnvLds& L, int lane) {
       double val = 0.0;
       if ((m->arm_anc[j] >> i) & 1u) {
         const float* a = &L.S[6 * i];
-        const float* b = &L.Fv[6 * j];
+        const float* b = &L.u.d.Fv[6 * j];
         for (int k = 0; k < 6; k++) val += (double)a[k] * (double)b[k];
       }
-      L.Md[i * 12 + j] = val; L.Md[j * 12 + i] = val;
+      L.u.d.Md[i * 12 + j] = val; L.u.d.Md[j * 12 + i] = val;
     }
   }
   if (lane < n) {      /* bias force of each body: f = I a_bias + v x* (I v), a_bias = -g + sum of ancestors' c */
     uint32_t anc = m->arm_anc[lane];
     V6 a = zero6();
     a.l.z = -K_GRAVITY;
-    for (int j = 0; j < n; j++) if ((anc >> j) & 1u) a = a + ld6(&L.csp[6 * j]);
-    V6 v = ld6(&L.vsp[6 * lane]);
-    const float* I = &L.inert[10 * lane];
-    st6(&L.fsp[6 * lane], inertia_mul(I, a) + crf(v, inertia_mul(I, v)));
+    for (int j = 0; j < n; j++) if ((anc >> j) & 1u) a = a + ld6(&L.u.d.csp[6 * j]);
+    V6 v = ld6(&L.u.d.vsp[6 * lane]);
+    const float* I = &L.u.d.inert[10 * lane];
+    st6(&L.u.d.fsp[6 * lane], inertia_mul(I, a) + crf(v, inertia_mul(I, v)));
   }
   __syncthreads();
   if (lane < n) {
     uint32_t sub = m->arm_sub[lane];
     V6 f = zero6();
-    for (int j = 0; j < n; j++) if ((sub >> j) & 1u) f = f + ld6(&L.fsp[6 * j]);
+    for (int j = 0; j < n; j++) if ((sub >> j) & 1u) f = f + ld6(&L.u.d.fsp[6 * j]);
     L.tau[lane] = dot6(ld6(&L.S[6 * lane]), f);
   }
   /* Cholesky M = L L^T in place (lower), lane i owns row i; fp64 */
   for (int k = 0; k < n; k++) {
     __syncthreads();
-    double piv = sqrt(L.Md[k * 12 + k]);
+    double piv = sqrt(L.u.d.Md[k * 12 + k]);
     double lik = 0.0;
-    if (lane > k && lane < n) lik = L.Md[lane * 12 + k] / piv;
+    if (lane > k && lane < n) lik = L.u.d.Md[lane * 12 + k] / piv;
     __syncthreads();
-    if (lane == k) L.Md[k * 12 + k] = piv;
-    if (lane > k && lane < n) L.Md[lane * 12 + k] = lik;
+    if (lane == k) L.u.d.Md[k * 12 + k] = piv;
+    if (lane > k && lane < n) L.u.d.Md[lane * 12 + k] = lik;
     __syncthreads();
     if (lane > k && lane < n)
-      for (int j = k + 1; j <= lane; j++) L.Md[lane * 12 + j] -= lik * L.Md[j * 12 + k];
+      for (int j = k + 1; j <= lane; j++) L.u.d.Md[lane * 12 + j] -= lik * L.u.d.Md[j * 12 + k];
   }
   __syncthreads();
   if (lane < n) {      /* column `lane` of M^-1: L y = e_c, L^T x = y */
@@ -515,8 +526,8 @@ __device__ void arm_dynamics(const DevModel* m, EnvLds& L, int lane) {
       if (i < n) {
         double s = (i == lane) ? 1.0 : 0.0;
 #pragma unroll
-        for (int k = 0; k < i; k++) s -= L.Md[i * 12 + k] * y[k];
-        y[i] = s / L.Md[i * 12 + i];
+        for (int k = 0; k < i; k++) s -= L.u.d.Md[i * 12 + k] * y[k];
+        y[i] = s / L.u.d.Md[i * 12 + i];
       } else y[i] = 0.0;
     }
 #pragma unroll
@@ -524,8 +535,8 @@ __device__ void arm_dynamics(const DevModel* m, EnvLds& L, int lane) {
       if (i < n) {
         double s = y[i];
 #pragma unroll
-        for (int k = i + 1; k < RP_MAX_ARM; k++) if (k < n) s -= L.Md[k * 12 + i] * y[k];
-        y[i] = s / L.Md[i * 12 + i];
+        for (int k = i + 1; k < RP_MAX_ARM; k++) if (k < n) s -= L.u.d.Md[k * 12 + i] * y[k];
+        y[i] = s / L.u.d.Md[i * 12 + i];
       }
     }
 #pragma unroll
@@ -654,9 +665,11 @@ __device__ int build_small_rows(const DevModel* m, EnvLds& L, int lane) {
   return nr;
 }
 
-/* d(n . v_point)/dv entries for a point p (relative to O) on `body`, accumulated into Jarm[12] / written to the row */
+/* Contact rows, one lane per row (normals first, then two friction rows per point, btPlaneSpace1 directions).
+ * A row touches at most two bodies, so it is stored compactly: slot0 = 12 entries starting at dof off0, slot1 = 6
+ * entries starting at dof off1 (an empty slot has off = 64).  If the arm is involved it takes slot0 (off0 = 0). */
 __device__ void contact_rows(const DevModel* m, EnvLds& L, int lane, int ncon) {
-  int n = m->n_arm, nv = m->nv;
+  int n = m->n_arm;
   V3 O = ld3(L.O);
   for (int r = lane; r < 3 * ncon; r += 64) {
     int ci, dir;
@@ -677,16 +690,20 @@ __device__ void contact_rows(const DevModel* m, EnvLds& L, int lane, int ncon) {
       }
       d = dir == 1 ? t1 : t2;
     }
-    float* J = &L.u.r.J[r * NVP];
-    float* B = &L.u.r.B[r * NVP];
-    for (int k = 0; k < NVP; k++) { J[k] = 0.f; B[k] = 0.f; }
+    float* J = &L.u.r.J[r * ROWW];
+    float* B = &L.u.r.B[r * ROWW];
+    for (int k = 0; k < ROWW; k++) { J[k] = 0.f; B[k] = 0.f; }
     float Jarm[RP_MAX_ARM];
 #pragma unroll
     for (int k = 0; k < RP_MAX_ARM; k++) Jarm[k] = 0.f;
     bool has_arm = false;
     float diag = 0.f, relv = 0.f;
+    int off0 = 64, off1 = 64;
+    int bodyA = m->col_body[L.cona[ci]], bodyB = m->col_body[L.conb[ci]];
+    bool any_arm = (bodyA >= 1 && bodyA <= n) || (bodyB >= 1 && bodyB <= n);
+    int nother = 0;
     for (int side = 0; side < 2; side++) {
-      int body = m->col_body[side == 0 ? L.cona[ci] : L.conb[ci]];
+      int body = side == 0 ? bodyA : bodyB;
       float sign = side == 0 ? 1.f : -1.f;
       if (body == 0) continue;
       if (body <= n) {
@@ -696,7 +713,12 @@ __device__ void contact_rows(const DevModel* m, EnvLds& L, int lane, int ncon) {
         for (int k = 0; k < RP_MAX_ARM; k++)
           if (k < n && ((anc >> k) & 1u)) Jarm[k] += sign * dot6(ld6(&L.S[6 * k]), f);
         has_arm = true;
-      } else if (body <= n + m->n_free) {
+        continue;
+      }
+      /* non-arm body: goes to slot1 if the arm holds slot0 or if it is the second such body, else to slot0 */
+      int base = (any_arm || nother == 1) ? 12 : 0;
+      nother++;
+      if (body <= n + m->n_free) {
         int k = body - 1 - n, dd = dof_free(m, k);
         V3 rr = p - ld3(&L.st[ST_FREE + 13 * k]);
         V3 rxn = cross(rr, d);
@@ -706,21 +728,24 @@ __device__ void contact_rows(const DevModel* m, EnvLds& L, int lane, int ncon) {
         float jl[3] = {sign * d.x, sign * d.y, sign * d.z}, ja[3] = {sign * rxn.x, sign * rxn.y, sign * rxn.z};
         float ba[3] = {sign * w.x, sign * w.y, sign * w.z};
         for (int i = 0; i < 3; i++) {
-          J[dd + i] = jl[i]; B[dd + i] = jl[i] * im; J[dd + 3 + i] = ja[i]; B[dd + 3 + i] = ba[i];
+          J[base + i] = jl[i]; B[base + i] = jl[i] * im; J[base + 3 + i] = ja[i]; B[base + 3 + i] = ba[i];
           diag += jl[i] * jl[i] * im + ja[i] * ba[i];
           relv += jl[i] * L.vstar[dd + i] + ja[i] * L.vstar[dd + 3 + i];
         }
+        if (base == 0) off0 = dd; else off1 = dd;
       } else {
         int k = body - 1 - n - m->n_free, dd = dof_j1(m, k);
         M3 R = ldm3(&L.xR[9 * body]);
         V3 a = mulv(R, ld3(m->j1_axis[k]));
         float j = m->j1_type[k] == 1 ? sign * dot(d, a) : sign * dot(a, cross(p - ld3(m->j1_pos[k]), d));
         float minv = m->j1_minv[k];
-        J[dd] = j; B[dd] = j * minv;
+        J[base] = j; B[base] = j * minv;
         diag += j * j * minv; relv += j * L.vstar[dd];
+        if (base == 0) off0 = dd; else off1 = dd;
       }
     }
     if (has_arm) {
+      off0 = 0;
 #pragma unroll
       for (int i = 0; i < RP_MAX_ARM; i++) {
         if (i < n) {
@@ -740,9 +765,9 @@ __device__ void contact_rows(const DevModel* m, EnvLds& L, int lane, int ncon) {
     } else rhs = -relv * dinv;
     float* s = &L.rowS[4 * r];
     s[0] = rhs; s[1] = dinv; s[2] = dir == 0 ? 0.f : L.conmu[ci]; s[3] = __int_as_float(dir == 0 ? 0 : ci);
-    L.rowT[2 * r] = 0.f; L.rowT[2 * r + 1] = dir == 0 ? 1e10f : 0.f;
+    float* t = &L.rowT[4 * r];
+    t[0] = 0.f; t[1] = dir == 0 ? 1e10f : 0.f; t[2] = __int_as_float(off0); t[3] = __int_as_float(off1);
   }
-  (void)nv;
 }
 
 /* 50 sweeps of sequential impulses; lane l owns dv[l]; returns dv of this lane.
@@ -796,23 +821,31 @@ __device__ float solve_rows(const DevModel* m, EnvLds& L, int lane, int nsmall_,
         dv += bl * d;
       }
     }
-    if (nrc > 0) {   /* contact normals then frictions: dense rows over the velocity vector */
+    if (nrc > 0) {   /* contact normals then frictions: compact rows, scalars two rows ahead, J/B one row ahead */
+      float4 sn = *(const float4*)&L.rowS[0], tn = *(const float4*)&L.rowT[0];
+      float4 s2 = sn, t2 = tn;
+      if (nrc > 1) { s2 = *(const float4*)&L.rowS[4]; t2 = *(const float4*)&L.rowT[4]; }
       float jn = 0.f, bn = 0.f;
-      if (lane < NVP) { jn = L.u.r.J[lane]; bn = L.u.r.B[lane]; }
-      float4 sn = *(const float4*)&L.rowS[0];
-      float2 tn = *(const float2*)&L.rowT[0];
+      {
+        int i1 = lane - __float_as_int(tn.w), i0 = lane - __float_as_int(tn.z);
+        int idx = (unsigned)i1 < 6u ? 12 + i1 : ((unsigned)i0 < 12u ? i0 : -1);
+        if (idx >= 0 && lane < 32) { jn = L.u.r.J[idx]; bn = L.u.r.B[idx]; }
+      }
       for (int r = 0; r < nrc; r++) {
         float jl = jn, bl = bn;
         float rhs = sn.x, dinv = sn.y, mu = sn.z, lo_c = tn.x, hi_c = tn.y;
         int parent = uni(__float_as_int(sn.w));
+        sn = s2; tn = t2;
         if (r + 1 < nrc) {
-          if (lane < NVP) { jn = L.u.r.J[(r + 1) * NVP + lane]; bn = L.u.r.B[(r + 1) * NVP + lane]; }
-          sn = *(const float4*)&L.rowS[4 * (r + 1)];
-          tn = *(const float2*)&L.rowT[2 * (r + 1)];
+          int i1 = lane - __float_as_int(tn.w), i0 = lane - __float_as_int(tn.z);
+          int idx = (unsigned)i1 < 6u ? 12 + i1 : ((unsigned)i0 < 12u ? i0 : -1);
+          jn = 0.f; bn = 0.f;
+          if (idx >= 0 && lane < 32) { jn = L.u.r.J[(r + 1) * ROWW + idx]; bn = L.u.r.B[(r + 1) * ROWW + idx]; }
+          if (r + 2 < nrc) { s2 = *(const float4*)&L.rowS[4 * (r + 2)]; t2 = *(const float4*)&L.rowT[4 * (r + 2)]; }
         }
         float lamv = r < 64 ? lamC0 : lamC1;
         float lam = lane_read(lamv, r & 63);
-        float lim = mu * lane_read(lamC0, parent);            /* parent < ncon <= 32 */
+        float lim = mu * lane_read(lamC0, parent);            /* parent < ncon <= MAXC */
         float jdv = wave_sum32(jl * dv), lnew;
         float d = pgs_update(rhs, jdv, dinv, lam, lo_c - lim, hi_c + lim, lnew);
         float sel = lane == (r & 63) ? lnew : lamv;
@@ -1063,7 +1096,6 @@ __device__ void calc_state(const DevModel* m, EnvLds& L, int lane) {
   fk_bodies(m, L, lane);
   __syncthreads();
   joint_subspaces(m, L, lane);
-  collider_aabbs(m, L, lane);
   __syncthreads();
   /* gripper_proprioception ray (environments.py:720-743): lane c tests collider c */
   int prop = -1;
@@ -1211,7 +1243,7 @@ __device__ __forceinline__ void store_state(const EnvLds& L, float* state, int e
 
 /* ------------------------------------------------------------------ kernels */
 /* playEnv.step for env = blockIdx.x */
-__global__ void __launch_bounds__(64) k_step(const DevModel* __restrict__ m, float* __restrict__ state, const float* __restrict__ action,
+__global__ void __launch_bounds__(64, RP_WAVES_PER_EU) k_step(const DevModel* __restrict__ m, float* __restrict__ state, const float* __restrict__ action,
                                             OutPtrs out, int N) {
   __shared__ EnvLds L;
   int env = blockIdx.x, lane = threadIdx.x;
@@ -1276,7 +1308,7 @@ __device__ void reset_goal_pos(const DevModel* m, EnvLds& L, int lane, const flo
 }
 
 /* playEnv.reset(o=None) (environments.py:173-187, 519-603) */
-__global__ void __launch_bounds__(64) k_reset(const DevModel* __restrict__ m, float* __restrict__ state, const uint8_t* __restrict__ mask,
+__global__ void __launch_bounds__(64, RP_WAVES_PER_EU) k_reset(const DevModel* __restrict__ m, float* __restrict__ state, const uint8_t* __restrict__ mask,
                                              OutPtrs out, int N, uint64_t seed, uint32_t env_offset) {
   __shared__ EnvLds L;
   int env = blockIdx.x, lane = threadIdx.x;
