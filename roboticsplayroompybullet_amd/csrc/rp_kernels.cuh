@@ -30,7 +30,7 @@
 #define MAXSMALL 44          /* arm motors 12 + scene-joint motors 3 + limits 24 + gear 1 (+ pad) */
 
 #ifndef RP_WAVES_PER_EU
-#define RP_WAVES_PER_EU 2      /* register budget: 512 / RP_WAVES_PER_EU VGPR+AGPR per lane */
+#define RP_WAVES_PER_EU 1      /* register budget: 512 / RP_WAVES_PER_EU VGPR+AGPR per lane */
 #endif
 
 #define K_DT (1.0f / 300.0f)
@@ -786,7 +786,8 @@ __device__ __forceinline__ float pgs_update(float rhs, float jdv, float dinv, fl
   return d;
 }
 
-__device__ float solve_rows(const DevModel* m, EnvLds& L, int lane, int nsmall_, int ncon_) {
+template <class LDS>
+__device__ float solve_rows(const DevModel* m, LDS& L, int lane, int nsmall_, int ncon_) {
   const int n = m->n_arm;
   const int nsmall = uni(nsmall_), nrc = uni(3 * ncon_);
   float dv = 0.f;
@@ -872,7 +873,7 @@ __device__ void substep(const DevModel* m, EnvLds& L, int lane) {
   int nsmall = build_small_rows(m, L, lane);
   contact_rows(m, L, lane, ncon);
   __syncthreads();
-  float dv = solve_rows(m, L, lane, nsmall, ncon);
+  float dv = solve_rows<EnvLds>(m, L, lane, nsmall, ncon);
   __syncthreads();
   /* apply and integrate (semi-implicit Euler) */
   float vnew = (lane < 32 ? L.vstar[lane] : 0.f) + dv;
@@ -1417,6 +1418,169 @@ __global__ void k_copy_state(float* __restrict__ dst, const float* __restrict__ 
   if (i >= (size_t)N * RP_REC_FLOATS) return;
   size_t env = i / RP_REC_FLOATS, k = i % RP_REC_FLOATS;
   dst[i] = src[(src_count == 1 ? 0 : env) * RP_REC_FLOATS + k];
+}
+
+/* ------------------------------------------------------------------ split pipeline for rp_step
+ * The fused substep() above needs > 256 VGPRs in its cold phases (IK, narrowphase, row build) although the hot PGS
+ * loop needs ~60, so rp_step runs right-sized kernels instead:
+ *   k_action  (thread per env)  clip + absolute-RPY IK + motor targets            -> state records
+ *   12 x { k_prep (wave per env: FK, collision, dynamics, constraint rows -> per-env workspace, L2/HBM resident)
+ *          k_solve (wave per env, lean: PGS sweeps + integration, state record in/out) }
+ *   k_obs     (wave per env)    calc_state + reward + outputs
+ * Workspace record per env (floats): header 16 | Minv 144 | vstar 32 | srow 8*MAXSMALL | rowS 4*MAXROWC |
+ * rowT 4*MAXROWC | J ROWW*MAXROWC | B ROWW*MAXROWC. */
+#define WS_HDR 0
+#define WS_MINV 16
+#define WS_VSTAR (WS_MINV + 144)
+#define WS_SROW (WS_VSTAR + 32)
+#define WS_ROWS (WS_SROW + 8 * MAXSMALL)
+#define WS_ROWT (WS_ROWS + 4 * MAXROWC)
+#define WS_J (WS_ROWT + 4 * MAXROWC)
+#define WS_B (WS_J + ROWW * MAXROWC)
+#define WS_FLOATS (WS_B + ROWW * MAXROWC)
+
+struct __align__(16) SolveLds {
+  float st[RP_REC_FLOATS];
+  float Minv[144];
+  float vstar[32];
+  float srow[MAXSMALL * 8];
+  float rowS[MAXROWC * 4];
+  float rowT[MAXROWC * 4];
+  struct { struct { float J[MAXROWC * ROWW]; float B[MAXROWC * ROWW]; } r; } u;
+};
+
+/* thread per env: perform_action (environments.py:915-1073) with the IK in private registers */
+__global__ void __launch_bounds__(64) k_action(const DevModel* __restrict__ m, float* __restrict__ state, const float* __restrict__ action,
+                                              float* __restrict__ target_poses, int N) {
+  int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= N) return;
+  float* st = state + (size_t)env * RP_REC_FLOATS;
+  const float high[7] = {6.f, 6.f, 6.f, 6.f, 6.f, 6.f, 1.f};       /* environments.py:108-109, 207 */
+  float a7[7];
+#pragma unroll
+  for (int k = 0; k < 7; k++) a7[k] = clampf(action[(size_t)env * 7 + k], -high[k], high[k]);
+  V3 tpos = mk3(a7[0], a7[1], a7[2]);
+  Q4 tq = quat_from_euler(a7[3], a7[4], a7[5]);
+  int nd = m->n_target;
+  ChainQ cur;
+#pragma unroll
+  for (int j = 0; j < 7; j++) cur.q[j] = j < m->ee_chain ? st[ST_Q + j] : 0.f;
+  ChainQ sol;
+  if (m->kind == RP_KIND_P) sol = ik_solve(m, tpos, tq, cur, 200);
+  else {
+    sol = cur;
+    for (int rep = 0; rep < 4; rep++) sol = ik_solve(m, tpos, tq, sol, 20);
+  }
+#pragma unroll
+  for (int j = 0; j < 7; j++) {
+    if (j < nd) {
+      float t = clampf(sol.q[j], m->ll[j], m->ul[j]);
+      float c = st[ST_Q + j];
+      t = clampf(t, c - m->inc[j], c + m->inc[j]);
+      st[ST_MMODE + j] = 1.f; st[ST_MTARGET + j] = t; st[ST_MMAXIMP + j] = 240.f * K_DT;
+      if (target_poses) target_poses[(size_t)env * nd + j] = t;
+    }
+  }
+  float g = a7[6];
+  if (m->kind == RP_KIND_P) {
+    float amt = 0.04f - g / 25.f;
+    int ds[2] = {m->d9p, m->d10p};
+    for (int i = 0; i < 2; i++) { st[ST_MMODE + ds[i]] = 1.f; st[ST_MTARGET + ds[i]] = amt; st[ST_MMAXIMP + ds[i]] = 100.f * K_DT; }
+  } else {
+    float amt = g - 0.2f;
+    float left = st[ST_Q + m->d18];
+    int ds[6] = {m->d18, m->d20, m->d12, m->d15, m->d10, m->d13};
+    float tg[6] = {amt * 0.055f, left, amt * 0.5f, amt * 0.5f, amt * 0.8f, amt * 0.8f};
+    float fo[6] = {100.f, 1000.f, 100.f, 100.f, 100.f, 100.f};
+    for (int i = 0; i < 6; i++) { st[ST_MMODE + ds[i]] = 1.f; st[ST_MTARGET + ds[i]] = tg[i]; st[ST_MMAXIMP + ds[i]] = fo[i] * K_DT; }
+  }
+}
+
+__device__ __forceinline__ void copy_out(float* __restrict__ dst, const float* src, int nfloat, int lane) {
+  for (int i = lane * 4; i < nfloat; i += 256) *(float4*)(dst + i) = *(const float4*)(src + i);
+}
+
+/* wave per env: everything of a substep up to the constraint rows; the state record is only read */
+__global__ void __launch_bounds__(64) k_prep(const DevModel* __restrict__ m, const float* __restrict__ state, float* __restrict__ ws, int N) {
+  __shared__ EnvLds L;
+  int env = blockIdx.x, lane = threadIdx.x;
+  if (env >= N) return;
+  load_state(L, state, env, lane);
+  fk_bodies(m, L, lane);
+  __syncthreads();
+  joint_subspaces(m, L, lane);
+  collider_aabbs(m, L, lane);
+  __syncthreads();
+  int ncon = collide(m, L, lane);
+  arm_dynamics(m, L, lane);
+  unconstrained_velocities(m, L, lane);
+  int nsmall = build_small_rows(m, L, lane);
+  contact_rows(m, L, lane, ncon);
+  __syncthreads();
+  float* w = ws + (size_t)env * WS_FLOATS;
+  if (lane == 0) { w[WS_HDR] = __int_as_float(nsmall); w[WS_HDR + 1] = __int_as_float(ncon); }
+  copy_out(w + WS_MINV, L.Minv, 144, lane);
+  copy_out(w + WS_VSTAR, L.vstar, 32, lane);
+  copy_out(w + WS_SROW, L.srow, 8 * nsmall, lane);
+  copy_out(w + WS_ROWS, L.rowS, 4 * 3 * ncon, lane);
+  copy_out(w + WS_ROWT, L.rowT, 4 * 3 * ncon, lane);
+  copy_out(w + WS_J, L.u.r.J, (ROWW * 3 * ncon + 3) & ~3, lane);
+  copy_out(w + WS_B, L.u.r.B, (ROWW * 3 * ncon + 3) & ~3, lane);
+}
+
+/* wave per env, lean: 50 PGS sweeps + semi-implicit Euler integration */
+__global__ void __launch_bounds__(64, 4) k_solve(const DevModel* __restrict__ m, float* __restrict__ state, const float* __restrict__ ws, int N) {
+  __shared__ SolveLds L;
+  int env = blockIdx.x, lane = threadIdx.x;
+  if (env >= N) return;
+  const float* w = ws + (size_t)env * WS_FLOATS;
+  int nsmall = uni(__float_as_int(w[WS_HDR])), ncon = uni(__float_as_int(w[WS_HDR + 1]));
+  {
+    const float* r = state + (size_t)env * RP_REC_FLOATS;
+    L.st[lane] = r[lane]; L.st[lane + 64] = r[lane + 64];
+  }
+  copy_out(L.Minv, w + WS_MINV, 144, lane);
+  copy_out(L.vstar, w + WS_VSTAR, 32, lane);
+  copy_out(L.srow, w + WS_SROW, 8 * nsmall, lane);
+  copy_out(L.rowS, w + WS_ROWS, 4 * 3 * ncon, lane);
+  copy_out(L.rowT, w + WS_ROWT, 4 * 3 * ncon, lane);
+  copy_out(L.u.r.J, w + WS_J, (ROWW * 3 * ncon + 3) & ~3, lane);
+  copy_out(L.u.r.B, w + WS_B, (ROWW * 3 * ncon + 3) & ~3, lane);
+  __syncthreads();
+  float dv = solve_rows(m, L, lane, nsmall, ncon);
+  int n = m->n_arm;
+  float vnew = (lane < 32 ? L.vstar[lane] : 0.f) + dv;
+  __syncthreads();
+  if (lane < n) {
+    L.st[ST_QD + lane] = vnew;
+    L.st[ST_Q + lane] += K_DT * vnew;
+  } else if (lane < n + 6 * m->n_free) {
+    int k = (lane - n) / 6, c = (lane - n) % 6;
+    L.st[ST_FREE + 13 * k + 7 + c] = vnew;
+  } else if (lane < m->nv) {
+    int k = lane - n - 6 * m->n_free;
+    L.st[ST_JQD + k] = vnew;
+    L.st[ST_JQ + k] += K_DT * vnew;
+  }
+  __syncthreads();
+  if (lane < m->n_free) {
+    float* f = &L.st[ST_FREE + 13 * lane];
+    V3 v = ld3(f + 7), wv = ld3(f + 10);
+    st3(f, ld3(f) + v * K_DT);
+    float wn = norm(wv);
+    if (wn > 0.7853981633974483f / K_DT) wn = 0.7853981633974483f / K_DT;
+    V3 ax;
+    if (wn < 0.001f) ax = wv * (0.5f * K_DT - K_DT * K_DT * K_DT * 0.020833333333f * wn * wn);
+    else ax = wv * (sinf(0.5f * wn * K_DT) / wn);
+    Q4 dq = {ax.x, ax.y, ax.z, cosf(0.5f * wn * K_DT)};
+    Q4 q0 = {f[3], f[4], f[5], f[6]};
+    Q4 qn = qmul(dq, q0);
+    float nr = 1.f / sqrtf(qn.x * qn.x + qn.y * qn.y + qn.z * qn.z + qn.w * qn.w);
+    f[3] = qn.x * nr; f[4] = qn.y * nr; f[5] = qn.z * nr; f[6] = qn.w * nr;
+  }
+  __syncthreads();
+  float* r = state + (size_t)env * RP_REC_FLOATS;
+  r[lane] = L.st[lane]; r[lane + 64] = L.st[lane + 64];
 }
 
 /* debug: one substep for every env, dumping intermediates of env `dbg_env` (tests only) */

@@ -14,9 +14,11 @@ struct rp_sim {
   DevModel host_model;
   DevModel* dev_model;
   float* state;            /* [N][RP_REC_FLOATS] */
+  float* ws;               /* [N][WS_FLOATS] constraint-row workspace of the split step pipeline */
   float* dbg;
   hipEvent_t ev0, ev1;
   int timers_on;
+  int fused;               /* 1: single fused k_step kernel (reference path), 0: split pipeline (default) */
   rp_timers timers;
   char err[256];
 };
@@ -62,6 +64,7 @@ int rp_create(const rp_config* cfg, rp_handle* out) {
   if (e != hipSuccess) { snprintf(g_err, 256, "hipSetDevice(%d): %s", cfg->device, hipGetErrorString(e)); free(h); return RP_ERR_HIP; }
   if (hipMalloc((void**)&h->dev_model, sizeof(DevModel)) != hipSuccess ||
       hipMalloc((void**)&h->state, (size_t)cfg->num_envs * RP_REC_FLOATS * sizeof(float)) != hipSuccess ||
+      hipMalloc((void**)&h->ws, (size_t)cfg->num_envs * WS_FLOATS * sizeof(float)) != hipSuccess ||
       hipMalloc((void**)&h->dbg, 4096 * sizeof(float)) != hipSuccess) {
     snprintf(g_err, 256, "rp_create: hipMalloc failed"); free(h); return RP_ERR_HIP;
   }
@@ -80,7 +83,7 @@ int rp_create(const rp_config* cfg, rp_handle* out) {
 int rp_destroy(rp_handle h) {
   if (!h) return RP_ERR_ARG;
   hipSetDevice(h->cfg.device);
-  hipFree(h->dev_model); hipFree(h->state); hipFree(h->dbg);
+  hipFree(h->dev_model); hipFree(h->state); hipFree(h->ws); hipFree(h->dbg);
   hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
   free(h);
   return RP_OK;
@@ -120,7 +123,17 @@ int rp_step(rp_handle h, const float* action, const rp_out* out, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   int N = h->cfg.num_envs;
   if (h->timers_on) hipEventRecord(h->ev0, s);
-  hipLaunchKernelGGL(k_step, dim3(N), dim3(64), 0, s, h->dev_model, h->state, action, to_ptrs(out), N);
+  if (h->fused) {
+    hipLaunchKernelGGL(k_step, dim3(N), dim3(64), 0, s, h->dev_model, h->state, action, to_ptrs(out), N);
+  } else {
+    OutPtrs op = to_ptrs(out);
+    hipLaunchKernelGGL(k_action, dim3((N + 63) / 64), dim3(64), 0, s, h->dev_model, h->state, action, op.target_poses, N);
+    for (int sub = 0; sub < K_NSUB; sub++) {
+      hipLaunchKernelGGL(k_prep, dim3(N), dim3(64), 0, s, h->dev_model, h->state, h->ws, N);
+      hipLaunchKernelGGL(k_solve, dim3(N), dim3(64), 0, s, h->dev_model, h->state, h->ws, N);
+    }
+    hipLaunchKernelGGL(k_calc_state, dim3(N), dim3(64), 0, s, h->dev_model, h->state, op, N);
+  }
   HIPCHK(h, hipGetLastError());
   if (h->timers_on) { hipEventRecord(h->ev1, s); hipEventSynchronize(h->ev1); hipEventElapsedTime(&h->timers.last_step_ms, h->ev0, h->ev1); }
   h->timers.steps++;
@@ -161,6 +174,7 @@ int rp_set_state(rp_handle h, const void* src, int32_t src_env_count, void* stre
   return RP_OK;
 }
 
+int rp_set_fused(rp_handle h, int32_t fused) { if (!h) return RP_ERR_ARG; h->fused = fused; return RP_OK; }
 int rp_get_timers(rp_handle h, rp_timers* t) { if (!h || !t) return RP_ERR_ARG; *t = h->timers; return RP_OK; }
 int rp_enable_timers(rp_handle h, int32_t on) { if (!h) return RP_ERR_ARG; h->timers_on = on; return RP_OK; }
 const char* rp_last_error(rp_handle h) { return h ? h->err : g_err; }

@@ -128,6 +128,10 @@ class VecPlayEnv:
             s = s[None]
         _lib.check(self.lib, self.h, self.lib.rp_set_state(self.h, C.c_void_p(s.data_ptr()), s.shape[0], self._stream()), 'rp_set_state')
 
+    def set_fused(self, fused=True):
+        """Use the single fused step kernel (reference path of the library) instead of the split pipeline."""
+        self.lib.rp_set_fused(self.h, int(fused))
+
     def enable_timers(self, on=True):
         self.lib.rp_enable_timers(self.h, int(on))
 

@@ -98,6 +98,25 @@ def test_shard_equivalence_bitwise():
     assert torch.equal(rf, torch.cat([ra, rb]))
 
 
+def test_split_pipeline_equals_fused_kernel_bitwise():
+    """rp_step's split kernels (k_action / k_prep / k_solve / k_calc_state) == the fused k_step kernel, bit for bit."""
+    from roboticsplayroompybullet_amd import VecPlayEnv
+    for kind in ('U', 'P'):
+        a = VecPlayEnv(IDS[kind], 32, seed=5)
+        b = VecPlayEnv(IDS[kind], 32, seed=5)
+        b.set_fused(True)
+        a.reset(); b.reset()
+        acts = torch.tensor(actions(kind, 6, 32, 8), dtype=torch.float32)
+        for t in range(6):
+            oa, ra, _, ia = a.step(acts[t])
+            ob, rb, _, ib = b.step(acts[t])
+        torch.cuda.synchronize()
+        assert torch.equal(a.get_state(), b.get_state())
+        for k in ('obs_quat', 'achieved_goal', 'observation', 'velocity'):
+            assert torch.equal(oa[k], ob[k]), k
+        assert torch.equal(ia['target_poses'], ib['target_poses'])
+
+
 def test_determinism_and_state_roundtrip():
     from roboticsplayroompybullet_amd import VecPlayEnv
     env = VecPlayEnv(IDS['U'], 16, seed=1)
