@@ -5,8 +5,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus 8 --steps 200 --warmup 20
 
-One "step" = one playEnv.step() for every env of the batch: clip -> AbsRPY IK -> motor targets -> 12 physics
-substeps at 300 Hz -> observation + reward, all inside ONE HIP kernel launch (rp_step).  Actions are synthetic
+One "step" = one playEnv.step() for every env of the batch (one rp_step call): clip -> AbsRPY IK -> motor targets
+(k_action) -> 12 physics substeps at 300 Hz (k_prep + k_solve each) -> observation + reward (k_calc_state).
+Per-launch durations are measured with hipEvents recorded on the launch stream inside rp_step over the whole timed
+region (rp_enable_timers / rp_get_timers); the roofline object is for the dominant kernel, k_solve.  Actions are synthetic
 (distribution B of SURVEY.md §8d: workspace-uniform, resampled every step), pre-generated on the device so the timed
 region holds only the hot path (and, for N > 1 GPUs, the RCCL all-gather of observations).  Envs shard across ranks
 with no data-path collective (weak scaling: 4096 envs per GPU).  Rank 0 prints one JSON line.
@@ -25,6 +27,7 @@ sys.path.insert(0, REPO)
 ENV_ID = 'UR5PlayAbsRPY1Obj-v0'
 ENVS_PER_GPU = 4096
 ALG_BYTES_PER_ENV_STEP = 1036          # SURVEY.md §8d / BASELINE.md §4: action 28 + goal 44 + state 272 r + 272 w + outputs 420
+ALG_BYTES_PER_ENV_SUBSTEP = 544        # k_solve, one launch = one substep of every env: state S = 272 B read + 272 B written
 HBM_PEAK_GBS = 8000.0                  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
@@ -63,6 +66,11 @@ def cpu_baseline(seed, budget_s=12.0):
             'host_cpus': os.cpu_count()}
 
 
+def sharding_offset(rank, world, n):
+    from roboticsplayroompybullet_amd import sharding
+    return sharding.shard_range(rank, world, n)[0]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -85,23 +93,25 @@ def main():
 
     from roboticsplayroompybullet_amd import VecPlayEnv
     n = args.envs_per_gpu
-    env = VecPlayEnv(ENV_ID, n, device=local_rank, seed=1234, env_offset=rank * n)
+    env = VecPlayEnv(ENV_ID, n, device=local_rank, seed=1234, env_offset=sharding_offset(rank, world, n))
     env.reset()
     actions = make_actions(n, args.steps + args.warmup, device, 1234 + rank)
     pack_w = env.dims['obs_quat'] + env.dims['achieved_goal'] + 2
     gathered = torch.empty((world * n, pack_w), dtype=torch.float32, device=device) if world > 1 else None
 
+    from roboticsplayroompybullet_amd import sharding
+
     def one_step(k):
         obs, r, done, info = env.step(actions[k])
         if world > 1:   # the only collective on the path: gather observations for a single consumer
-            pack = torch.cat([obs['obs_quat'], obs['achieved_goal'], r[:, None], info['is_success'].float()[:, None]], dim=1)
-            dist.all_gather_into_tensor(gathered, pack)
+            sharding.gather_observations(sharding.pack_observations(obs, r, info['is_success']), out=gathered)
         return info
 
     for k in range(args.warmup):
         one_step(k)
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    env.enable_timers(args.steps)        # per-launch hipEvent pairs on the launch stream; read back after the region
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -111,8 +121,7 @@ def main():
         obs, r, done, info = env.step(actions[args.warmup + k])
         ev1[k].record()
         if world > 1:
-            pack = torch.cat([obs['obs_quat'], obs['achieved_goal'], r[:, None], info['is_success'].float()[:, None]], dim=1)
-            dist.all_gather_into_tensor(gathered, pack)
+            sharding.gather_observations(sharding.pack_observations(obs, r, info['is_success']), out=gathered)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -121,13 +130,16 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kern_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / args.steps
+    step_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / args.steps
+    tm = env.timers()
     bad = int(info['status'].sum().item())
     success = float(info['is_success'].float().mean().item())
 
     if rank == 0:
         value = world * n * args.steps / elapsed
-        achieved = ALG_BYTES_PER_ENV_STEP * n / (kern_ms * 1e-3) / 1e9
+        solve_ms = tm['avg_solve_ms']
+        achieved = ALG_BYTES_PER_ENV_SUBSTEP * n / (solve_ms * 1e-3) / 1e9
+        step_achieved = ALG_BYTES_PER_ENV_STEP * n / (step_ms * 1e-3) / 1e9
         line = {
             'metric': 'env-steps/sec at N=4096 parallel UR5PlayAbsRPY1Obj-v0 envs per MI355X',
             'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -138,10 +150,14 @@ def main():
                        'envs_per_gpu': n, 'global_envs': world * n, 'parallelism': 'env-shard x%d' % world,
                        'collective': 'all_gather(obs_quat+achieved_goal+reward+is_success) per step' if world > 1 else 'none'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': None, 'kernel': 'k_step', 'kernel_ms': kern_ms,
-                         'algorithmic_bytes_per_launch': ALG_BYTES_PER_ENV_STEP * n,
-                         'note': 'latency/VALU-bound path (serial PGS chains); advisory FLOP model 9e6 FLOP/env-step => '
-                                 '%.3g of the 157.3 TFLOP/s fp32 vector peak' % (9e6 * n / (kern_ms * 1e-3) / 157.3e12)},
+                         'traffic': None, 'kernel': 'k_solve', 'kernel_ms': solve_ms, 'launches_per_step': 12,
+                         'algorithmic_bytes_per_launch': ALG_BYTES_PER_ENV_SUBSTEP * n,
+                         'whole_step': {'achieved': step_achieved, 'frac': step_achieved / HBM_PEAK_GBS, 'ms': step_ms,
+                                        'algorithmic_bytes': ALG_BYTES_PER_ENV_STEP * n},
+                         'per_launch_ms': {'k_action': tm['avg_action_ms'], 'k_prep': tm['avg_prep_ms'], 'k_solve': solve_ms,
+                                           'k_calc_state': tm['avg_obs_ms'], 'steps_timed': tm['steps_timed']},
+                         'note': 'latency/VALU-issue-bound path (serial PGS chains), not bandwidth-bound; advisory FLOP model '
+                                 '9e6 FLOP/env-step => %.3g of the 157.3 TFLOP/s fp32 vector peak' % (9e6 * n / (step_ms * 1e-3) / 157.3e12)},
             'non_finite_envs': bad, 'success_rate_last_step': success,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -62,9 +62,17 @@ typedef struct rp_out {
 } rp_out;
 
 typedef struct rp_timers {
-  float last_step_ms;    /* device time of the most recent rp_step kernel (hipEvent pair on the call's stream) */
+  float last_step_ms;    /* device time of the most recent rp_step (hipEvent pair on the call's stream) */
   float last_reset_ms;
   uint64_t steps;        /* rp_step calls so far */
+  /* averages over the steps recorded since rp_enable_timers (per-launch hipEvent pairs on the call's stream;
+   * nothing synchronises inside rp_step, rp_get_timers does) */
+  uint32_t steps_timed;
+  float avg_step_ms;     /* k_action .. k_calc_state, one rp_step */
+  float avg_action_ms;   /* k_action, one launch */
+  float avg_prep_ms;     /* k_prep, one launch (12 per step) */
+  float avg_solve_ms;    /* k_solve, one launch (12 per step) */
+  float avg_obs_ms;      /* k_calc_state, one launch */
 } rp_timers;
 
 /* gym.make(id) + playEnv.__init__ + activate_physics_client (ENV:64-170, 218-249): builds N identical worlds. */
@@ -98,6 +106,7 @@ int rp_get_state(rp_handle h, void* dst, void* stream);
 int rp_set_state(rp_handle h, const void* src, int32_t src_env_count, void* stream);
 
 int rp_get_timers(rp_handle h, rp_timers* t);
+/* on = number of rp_step calls to keep per-launch timings for (a ring); 0 disables */
 int rp_enable_timers(rp_handle h, int32_t on);
 const char* rp_last_error(rp_handle h);
 const char* rp_version(void);

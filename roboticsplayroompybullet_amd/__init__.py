@@ -1,4 +1,36 @@
-"""MI355X-native batched playroom simulator behind the reference's gym surface (hot path only)."""
+"""MI355X-native batched playroom simulator behind the reference's gym surface (hot path only).
+
+    import roboticsplayroompybullet_amd as rp
+    env = rp.make('UR5PlayAbsRPY1Obj-v0')            # single env, reference surface (numpy in / out)
+    vec = rp.VecPlayEnv('UR5PlayAbsRPY1Obj-v0', 4096) # batched, torch tensors on the GPU
+"""
+import importlib
+
 from .vec_env import VecPlayEnv  # noqa: F401
 
-__all__ = ['VecPlayEnv']
+# roboticsPlayroomPybullet/__init__.py:24,66,92 — the ids in scope, same entry-point style
+_REGISTRY = {}
+
+
+def register(id, entry_point, **kwargs):
+    _REGISTRY[id] = (entry_point, kwargs)
+    try:  # mirror into gym / gymnasium when they exist (they do not in the build image)
+        from gym.envs.registration import register as gym_register  # type: ignore
+        gym_register(id=id, entry_point=entry_point, **kwargs)
+    except Exception:  # noqa: BLE001
+        pass
+
+
+def make(id, **kwargs):
+    if id not in _REGISTRY:
+        raise KeyError('%r is not registered (in scope: %s)' % (id, sorted(_REGISTRY)))
+    entry_point, kw = _REGISTRY[id]
+    mod, cls = entry_point.split(':')
+    return getattr(importlib.import_module(mod), cls)(**dict(kw, **kwargs))
+
+
+register(id='pandaPick-v0', entry_point='roboticsplayroompybullet_amd.envs:pandaPick')
+register(id='UR5Reach-v0', entry_point='roboticsplayroompybullet_amd.envs:UR5Reach')
+register(id='UR5PlayAbsRPY1Obj-v0', entry_point='roboticsplayroompybullet_amd.envs:UR5PlayAbsRPY1Obj')
+
+__all__ = ['VecPlayEnv', 'make', 'register']

@@ -31,7 +31,9 @@ class RpOut(C.Structure):
 
 
 class RpTimers(C.Structure):
-    _fields_ = [('last_step_ms', C.c_float), ('last_reset_ms', C.c_float), ('steps', C.c_uint64)]
+    _fields_ = [('last_step_ms', C.c_float), ('last_reset_ms', C.c_float), ('steps', C.c_uint64), ('steps_timed', C.c_uint32),
+                ('avg_step_ms', C.c_float), ('avg_action_ms', C.c_float), ('avg_prep_ms', C.c_float), ('avg_solve_ms', C.c_float),
+                ('avg_obs_ms', C.c_float)]
 
 
 EXPORTS = ['rp_create', 'rp_destroy', 'rp_get_dims', 'rp_reset', 'rp_reset_goal', 'rp_step', 'rp_calc_state',

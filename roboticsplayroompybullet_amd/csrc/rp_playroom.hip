@@ -17,12 +17,15 @@ struct rp_sim {
   float* ws;               /* [N][WS_FLOATS] constraint-row workspace of the split step pipeline */
   float* dbg;
   hipEvent_t ev0, ev1;
+  hipEvent_t* pool;        /* per-launch timing ring: EV_PER_STEP events per recorded step */
+  int pool_steps, pool_next, pool_count;
   int timers_on;
   int fused;               /* 1: single fused k_step kernel (reference path), 0: split pipeline (default) */
   rp_timers timers;
   char err[256];
 };
 
+#define EV_PER_STEP (2 + 2 * (2 * K_NSUB + 2))   /* step pair + a pair per launch (action, 12 prep, 12 solve, obs) */
 static char g_err[256] = "";
 
 #define HIPCHK(h, call)                                                                             \
@@ -85,6 +88,7 @@ int rp_destroy(rp_handle h) {
   hipSetDevice(h->cfg.device);
   hipFree(h->dev_model); hipFree(h->state); hipFree(h->ws); hipFree(h->dbg);
   hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
+  if (h->pool) { for (int i = 0; i < h->pool_steps * EV_PER_STEP; i++) hipEventDestroy(h->pool[i]); free(h->pool); }
   free(h);
   return RP_OK;
 }
@@ -122,20 +126,30 @@ int rp_step(rp_handle h, const float* action, const rp_out* out, void* stream) {
   if (!h || !action) { if (h) snprintf(h->err, 256, "rp_step: action is NULL"); return RP_ERR_ARG; }
   hipStream_t s = (hipStream_t)stream;
   int N = h->cfg.num_envs;
-  if (h->timers_on) hipEventRecord(h->ev0, s);
+  if (h->timers_on && h->fused) hipEventRecord(h->ev0, s);
   if (h->fused) {
     hipLaunchKernelGGL(k_step, dim3(N), dim3(64), 0, s, h->dev_model, h->state, action, to_ptrs(out), N);
   } else {
     OutPtrs op = to_ptrs(out);
-    hipLaunchKernelGGL(k_action, dim3((N + 63) / 64), dim3(64), 0, s, h->dev_model, h->state, action, op.target_poses, N);
+    hipEvent_t* ev = h->pool ? h->pool + (size_t)h->pool_next * EV_PER_STEP : nullptr;
+    int e = 2;
+#define TIMED(launch) do { if (ev) hipEventRecord(ev[e++], s); launch; if (ev) hipEventRecord(ev[e++], s); } while (0)
+    if (ev) hipEventRecord(ev[0], s);
+    TIMED(hipLaunchKernelGGL(k_action, dim3((N + 63) / 64), dim3(64), 0, s, h->dev_model, h->state, action, op.target_poses, N));
     for (int sub = 0; sub < K_NSUB; sub++) {
-      hipLaunchKernelGGL(k_prep, dim3(N), dim3(64), 0, s, h->dev_model, h->state, h->ws, N);
-      hipLaunchKernelGGL(k_solve, dim3(N), dim3(64), 0, s, h->dev_model, h->state, h->ws, N);
+      TIMED(hipLaunchKernelGGL(k_prep, dim3(N), dim3(64), 0, s, h->dev_model, h->state, h->ws, N));
+      TIMED(hipLaunchKernelGGL(k_solve, dim3(N), dim3(64), 0, s, h->dev_model, h->state, h->ws, N));
     }
-    hipLaunchKernelGGL(k_calc_state, dim3(N), dim3(64), 0, s, h->dev_model, h->state, op, N);
+    TIMED(hipLaunchKernelGGL(k_calc_state, dim3(N), dim3(64), 0, s, h->dev_model, h->state, op, N));
+    if (ev) {
+      hipEventRecord(ev[1], s);
+      h->pool_next = (h->pool_next + 1) % h->pool_steps;
+      if (h->pool_count < h->pool_steps) h->pool_count++;
+    }
+#undef TIMED
   }
   HIPCHK(h, hipGetLastError());
-  if (h->timers_on) { hipEventRecord(h->ev1, s); hipEventSynchronize(h->ev1); hipEventElapsedTime(&h->timers.last_step_ms, h->ev0, h->ev1); }
+  if (h->timers_on && h->fused) { hipEventRecord(h->ev1, s); hipEventSynchronize(h->ev1); hipEventElapsedTime(&h->timers.last_step_ms, h->ev0, h->ev1); }
   h->timers.steps++;
   return RP_OK;
 }
@@ -175,8 +189,43 @@ int rp_set_state(rp_handle h, const void* src, int32_t src_env_count, void* stre
 }
 
 int rp_set_fused(rp_handle h, int32_t fused) { if (!h) return RP_ERR_ARG; h->fused = fused; return RP_OK; }
-int rp_get_timers(rp_handle h, rp_timers* t) { if (!h || !t) return RP_ERR_ARG; *t = h->timers; return RP_OK; }
-int rp_enable_timers(rp_handle h, int32_t on) { if (!h) return RP_ERR_ARG; h->timers_on = on; return RP_OK; }
+int rp_get_timers(rp_handle h, rp_timers* t) {
+  if (!h || !t) return RP_ERR_ARG;
+  rp_timers r = h->timers;
+  r.steps_timed = 0; r.avg_step_ms = r.avg_action_ms = r.avg_prep_ms = r.avg_solve_ms = r.avg_obs_ms = 0.f;
+  if (h->pool && h->pool_count > 0) {
+    double step = 0, act = 0, prep = 0, solve = 0, obs = 0;
+    for (int k = 0; k < h->pool_count; k++) {
+      hipEvent_t* ev = h->pool + (size_t)k * EV_PER_STEP;
+      HIPCHK(h, hipEventSynchronize(ev[1]));
+      float ms;
+      hipEventElapsedTime(&ms, ev[0], ev[1]); step += ms;
+      hipEventElapsedTime(&ms, ev[2], ev[3]); act += ms;
+      for (int sub = 0; sub < K_NSUB; sub++) {
+        hipEventElapsedTime(&ms, ev[4 + 4 * sub], ev[5 + 4 * sub]); prep += ms;
+        hipEventElapsedTime(&ms, ev[6 + 4 * sub], ev[7 + 4 * sub]); solve += ms;
+      }
+      hipEventElapsedTime(&ms, ev[4 + 4 * K_NSUB], ev[5 + 4 * K_NSUB]); obs += ms;
+    }
+    int c = h->pool_count;
+    r.steps_timed = (uint32_t)c;
+    r.avg_step_ms = (float)(step / c); r.avg_action_ms = (float)(act / c); r.avg_prep_ms = (float)(prep / (c * K_NSUB));
+    r.avg_solve_ms = (float)(solve / (c * K_NSUB)); r.avg_obs_ms = (float)(obs / c);
+    r.last_step_ms = r.avg_step_ms;
+  }
+  *t = r;
+  return RP_OK;
+}
+int rp_enable_timers(rp_handle h, int32_t on) {
+  if (!h || on < 0) return RP_ERR_ARG;
+  if (h->pool) { for (int i = 0; i < h->pool_steps * EV_PER_STEP; i++) hipEventDestroy(h->pool[i]); free(h->pool); h->pool = nullptr; }
+  h->timers_on = on; h->pool_steps = on; h->pool_next = 0; h->pool_count = 0;
+  if (on > 0) {
+    h->pool = (hipEvent_t*)calloc((size_t)on * EV_PER_STEP, sizeof(hipEvent_t));
+    for (int i = 0; i < on * EV_PER_STEP; i++) HIPCHK(h, hipEventCreate(&h->pool[i]));
+  }
+  return RP_OK;
+}
 const char* rp_last_error(rp_handle h) { return h ? h->err : g_err; }
 
 /* test hook (not part of the public header): one substep on every env, intermediates of env `env` into host buf[4096] */

@@ -1,0 +1,195 @@
+"""Single-env adapters with the reference's gym surface (environments.py:58-314, envList.py:18-22, 89-99).
+
+`playEnv` keeps the reference's method names, argument meaning, observation-dict keys, shapes and dtypes; underneath
+it is a VecPlayEnv of one environment on the GPU.  Like the reference, nothing touches the simulator until the first
+reset() ("activate_physics_client", environments.py:175-177).  Out of scope and raising NotImplementedError:
+reset(o=<observation>) (state restore through IK), GUI / VR / rendering.
+"""
+import numpy as np
+
+from .. import spaces
+
+F32_KEYS = ('obs_quat', 'achieved_goal', 'desired_goal', 'controllable_achieved_goal', 'full_positional_state')
+
+
+class _InstanceShim:
+    """The attributes in-tree callers reach through env.instance (interactive.py:8,19,46,53; environments.py:184,210)."""
+
+    def __init__(self, env):
+        self._env = env
+        self.arm_type = env.arm_type
+        self.default_arm_orn_RPY = [0, 0, 0]                                   # environments.py:357,365
+        self.restJointPositions = ([-0.6, 0.437, 0.217, -2.09, 1.1, 1.4, 1.3, 0.0, 0.0, 0.0] if env.arm_type == 'Panda' else
+                                   [-1.50189075, -1.6291067, -1.87020409, -1.21324173, 1.57003561, 0.06970189])
+        self.endEffectorIndex = 11 if env.arm_type == 'Panda' else 7
+        self.record_images = False
+
+    def calc_state(self):
+        return self._env._to_reference_obs(self._env._vec.calc_state())
+
+    def calc_actor_state(self):
+        o = self._env._vec.calc_state()
+        g = lambda k: o[k][0].cpu().numpy().astype(np.float64)   # noqa: E731
+        q = g('obs_quat')
+        ee_orn = q[3:7] if self._env.use_orientation else None
+        return {'pos': g('controllable_achieved_goal')[:3], 'orn': ee_orn, 'pos_vel': g('velocity')[:3], 'orn_vel': g('velocity')[3:],
+                'gripper': [g('controllable_achieved_goal')[3]], 'joints': list(g('joints')),
+                'proprioception': int(o['gripper_proprioception'][0])}
+
+
+class playEnv:
+    metadata = {'render.modes': ['human', 'rgb_array'], 'video.frames_per_second': 60}
+    ENV_ID = None
+
+    def __init__(self, num_objects=0, env_range_low=(-0.18, -0.18, -0.05), env_range_high=(0.18, 0.18, 0.15),
+                 goal_range_low=(-0.18, -0.18, -0.05), goal_range_high=(0.18, 0.18, 0.05), obj_lower_bound=(-0.18, -0.18, -0.05),
+                 obj_upper_bound=(-0.18, -0.18, -0.05), sparse=True, use_orientation=False, sparse_rew_thresh=0.05,
+                 fixed_gripper=False, return_velocity=True, max_episode_steps=250, play=False, action_type='absolute_rpy',
+                 show_goal=True, arm_type='Panda', device=0, seed=0):
+        if action_type != 'absolute_rpy':
+            raise NotImplementedError('action_type %r is outside the hot-path scope (SURVEY.md §8f rank 1)' % action_type)
+        self.timeStep = 1.0 / 300
+        self.render_scene = False
+        self.physics_client_active = 0
+        self.num_objects, self.use_orientation, self.return_velocity = num_objects, use_orientation, return_velocity
+        self.fixed_gripper, self.sparse_reward_threshold, self.sparse_rew_thresh = fixed_gripper, sparse_rew_thresh, sparse_rew_thresh
+        self.num_goals = max(num_objects, 1)
+        self.play, self.action_type, self.show_goal, self.arm_type = play, action_type, show_goal, arm_type
+        self._max_episode_steps = max_episode_steps
+        self._device, self._seed = device, seed
+        high = np.array([6, 6, 6, 6, 6, 6, 1])                                  # environments.py:108-109
+        self.action_space = spaces.Box(-high, high)
+        # declared spaces, reproduced as-is including the arm_lower_obs_lim typo (environments.py:120-166, quirk F11)
+        eu, el = np.array(env_range_high, dtype=float), np.array(env_range_low, dtype=float)
+        self.env_upper_bound, self.env_lower_bound = eu, el
+        self.goal_upper_bound, self.goal_lower_bound = np.array(goal_range_high, dtype=float), np.array(goal_range_low, dtype=float)
+        self.obj_lower_bound, self.obj_upper_bound = list(obj_lower_bound), list(obj_upper_bound)
+        if use_orientation:
+            self.arm_upper_lim = np.concatenate([eu, np.array([1, 1, 1, 1, 0.04])])
+            self.arm_lower_lim = np.concatenate([el, -np.array([1, 1, 1, 1, 0.0])])
+            arm_upper_obs_lim = np.concatenate([eu, np.array([1, 1, 1, 1, 1, 1, 1, 0.04])])
+            arm_lower_obs_lim = np.concatenate([eu, -np.array([1, 1, 1, 1, 1, 1, 1, 0.0])])
+            obj_upper_lim = np.concatenate([self.obj_upper_bound, np.ones(7)])
+            obj_lower_lim = np.concatenate([self.obj_lower_bound, -np.ones(7)])
+            obj_upper_positional_lim = np.concatenate([eu, np.ones(4)])
+            obj_lower_positional_lim = np.concatenate([el, -np.ones(4)])
+        else:
+            self.arm_upper_lim = np.concatenate([eu, np.array([0.04])])
+            self.arm_lower_lim = np.concatenate([el, -np.array([0.0])])
+            arm_upper_obs_lim = np.concatenate([eu, np.array([1, 1, 1, 0.04])])
+            arm_lower_obs_lim = np.concatenate([eu, -np.array([1, 1, 1, 0.0])])
+            obj_upper_lim = np.concatenate([self.obj_upper_bound, np.ones(3)])
+            obj_lower_lim = np.concatenate([self.obj_lower_bound, -np.ones(3)])
+            obj_upper_positional_lim, obj_lower_positional_lim = eu, el
+        cat = np.concatenate
+        self.observation_space = spaces.Dict(dict(
+            desired_goal=spaces.Box(cat([el] * self.num_goals), cat([eu] * self.num_goals)),
+            achieved_goal=spaces.Box(cat([el] * self.num_goals), cat([eu] * self.num_goals)),
+            observation=spaces.Box(cat([arm_lower_obs_lim] + [obj_lower_lim] * num_objects), cat([arm_upper_obs_lim] + [obj_upper_lim] * num_objects)),
+            controllable_achieved_goal=spaces.Box(self.arm_lower_lim, self.arm_upper_lim),
+            full_positional_state=spaces.Box(cat([self.arm_lower_lim] + [obj_lower_positional_lim] * num_objects),
+                                             cat([self.arm_upper_lim] + [obj_upper_positional_lim] * num_objects))))
+        self._vec = None
+        self.instance = None
+        if not sparse:
+            raise NotImplementedError('dense reward variant is not registered by the reference ids in scope')
+
+    # -- reference surface ------------------------------------------------------------------------------------------
+    def activate_physics_client(self, vr=None):
+        if vr is not None or self.render_scene:
+            raise NotImplementedError('GUI / VR clients are out of scope (SURVEY.md §2.1)')
+        from ..vec_env import VecPlayEnv
+        self._vec = VecPlayEnv(self.ENV_ID, 1, device=self._device, seed=self._seed)
+        self.instance = _InstanceShim(self)
+
+    def reset(self, o=None, vr=None):
+        if o is not None:
+            raise NotImplementedError('reset(o=...) (state restore from an observation) is a SURVEY.md §8f "next" row')
+        if not self.physics_client_active:
+            self.activate_physics_client(vr)
+            self.physics_client_active = True
+        return self._to_reference_obs(self._vec.reset())      # the "reset until not already solved" loop runs on device
+
+    def reset_goal_pos(self, goal):
+        import torch
+        g = None if goal is None else torch.as_tensor(np.asarray(goal, dtype=np.float32))[None]
+        self._vec.reset_goal_pos(g)
+
+    def render(self, mode):
+        if mode == 'human':
+            self.render_scene = True
+            return np.array([])
+        return None       # 'rgb_array' / 'playback' only set a flag in the reference; img stays None here
+
+    def step(self, action):
+        import torch
+        a = np.clip(action, self.action_space.low, self.action_space.high)        # environments.py:207 (again on device)
+        obs, r, done, info = self._vec.step(torch.as_tensor(np.asarray(a, dtype=np.float32))[None])
+        o = self._to_reference_obs(obs)
+        reward = float(r[0])
+        if not self.play:
+            reward = float(np.float64(reward))
+        return o, reward, False, {'is_success': int(info['is_success'][0]), 'target_poses': info['target_poses'][0].cpu().numpy().astype(np.float64)}
+
+    def compute_reward(self, achieved_goal, desired_goal, info=None):
+        import torch
+        ag = torch.as_tensor(np.asarray(achieved_goal, dtype=np.float32))
+        dg = torch.as_tensor(np.asarray(desired_goal, dtype=np.float32))
+        r = self._vec.compute_reward(ag, dg).cpu().numpy().astype(np.float64)
+        return float(r) if r.ndim == 0 else r
+
+    compute_reward_sparse = compute_reward
+
+    def calc_target_distance(self, achieved_goal, desired_goal):
+        return float(np.linalg.norm(np.asarray(achieved_goal) - np.asarray(desired_goal)))
+
+    def visualise_sub_goal(self, sub_goal, sub_goal_state='full_positional_state'):
+        raise NotImplementedError('sub-goal visualisation is GUI-only (SURVEY.md §2.1, out of scope)')
+
+    def delete_sub_goal(self):
+        pass
+
+    def close(self):
+        if self._vec is not None:
+            self._vec.close()
+
+    # -- helpers ----------------------------------------------------------------------------------------------------
+    def _to_reference_obs(self, o):
+        """dtypes of environments.py:849-861: float32 for five keys, float64 observation/velocity, list joints, int flag."""
+        out = {}
+        for k in F32_KEYS:
+            out[k] = o[k][0].cpu().numpy().astype(np.float32)
+        out['joints'] = [float(v) for v in o['joints'][0].cpu().numpy()]
+        out['velocity'] = o['velocity'][0].cpu().numpy().astype(np.float64)
+        out['img'] = None
+        out['observation'] = o['observation'][0].cpu().numpy().astype(np.float64)
+        out['gripper_proprioception'] = int(o['gripper_proprioception'][0])
+        return out
+
+
+class pandaPick(playEnv):                     # envList.py:18-22
+    ENV_ID = 'pandaPick-v0'
+
+    def __init__(self, num_objects=1, env_range_low=(-0.18, -0.18, -0.055), env_range_high=(0.18, 0.18, 0.2), goal_range_low=(-0.18, -0.18, 0.0),
+                 goal_range_high=(0.18, 0.18, 0.1), use_orientation=False, **kw):
+        super().__init__(num_objects=num_objects, env_range_low=env_range_low, env_range_high=env_range_high, goal_range_low=goal_range_low,
+                         goal_range_high=goal_range_high, use_orientation=use_orientation, obj_lower_bound=goal_range_low,
+                         obj_upper_bound=goal_range_high, **kw)
+
+
+class UR5Reach(playEnv):                      # envList.py:89-91
+    ENV_ID = 'UR5Reach-v0'
+
+    def __init__(self, num_objects=0, **kw):
+        super().__init__(num_objects=num_objects, use_orientation=False, arm_type='UR5', **kw)
+
+
+class UR5PlayAbsRPY1Obj(playEnv):             # envList.py:93-99
+    ENV_ID = 'UR5PlayAbsRPY1Obj-v0'
+
+    def __init__(self, num_objects=1, env_range_low=(-1.0, -1.0, -0.2), env_range_high=(1.0, 1.0, 1.0), goal_range_low=(-0.18, 0, 0.05),
+                 goal_range_high=(0.18, 0.3, 0.1), use_orientation=True, **kw):
+        super().__init__(num_objects=num_objects, env_range_low=env_range_low, env_range_high=env_range_high, goal_range_low=goal_range_low,
+                         goal_range_high=goal_range_high, use_orientation=use_orientation, obj_lower_bound=[-0.18, 0, 0.05],
+                         obj_upper_bound=[0.18, 0.3, 0.1], return_velocity=False, max_episode_steps=None, play=True,
+                         action_type='absolute_rpy', show_goal=False, arm_type='UR5', **kw)

@@ -132,13 +132,14 @@ class VecPlayEnv:
         """Use the single fused step kernel (reference path of the library) instead of the split pipeline."""
         self.lib.rp_set_fused(self.h, int(fused))
 
-    def enable_timers(self, on=True):
-        self.lib.rp_enable_timers(self.h, int(on))
+    def enable_timers(self, steps=64):
+        """keep per-launch hipEvent timings for the next `steps` rp_step calls (0 disables)"""
+        _lib.check(self.lib, self.h, self.lib.rp_enable_timers(self.h, int(steps)), 'rp_enable_timers')
 
     def timers(self):
         t = _lib.RpTimers()
-        self.lib.rp_get_timers(self.h, C.byref(t))
-        return {'last_step_ms': t.last_step_ms, 'last_reset_ms': t.last_reset_ms, 'steps': t.steps}
+        _lib.check(self.lib, self.h, self.lib.rp_get_timers(self.h, C.byref(t)), 'rp_get_timers')
+        return {n: getattr(t, n) for n, _ in _lib.RpTimers._fields_}
 
     def debug_substep(self, env=0):
         buf = (C.c_float * 4096)()

@@ -1,0 +1,60 @@
+"""N > 1 host path on CPU: two gloo ranks shard the env range, pack and all-gather observations in rank order, and the
+per-env RNG keyed by the global env index makes shards equal to the single-device run (checked on the CPU oracle)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from roboticsplayroompybullet_amd import sharding
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, d_obs, d_ag, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    lo, hi = sharding.shard_range(rank, world, n)
+    g = torch.arange(lo, hi, dtype=torch.float32)
+    obs = {'obs_quat': g[:, None] + torch.arange(d_obs)[None] * 0.01, 'achieved_goal': g[:, None] * 2 + torch.arange(d_ag)[None]}
+    pack = sharding.pack_observations(obs, -g, (g.to(torch.int32) % 2))
+    full = sharding.gather_observations(pack)
+    dist.barrier()
+    if rank == 0:
+        ret['full'] = full.numpy().copy()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gather_is_rank_ordered_concatenation():
+    world, n, d_obs, d_ag = 2, 5, 19, 11
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), n, d_obs, d_ag, ret), nprocs=world, join=True)
+    full = torch.tensor(ret['full'])
+    assert full.shape == (world * n, d_obs + d_ag + 2)
+    u = sharding.unpack_observations(full, d_obs, d_ag)
+    g = torch.arange(world * n, dtype=torch.float32)
+    assert torch.equal(u['obs_quat'][:, 0], g)                    # global env order preserved
+    assert torch.equal(u['achieved_goal'][:, 0], 2 * g)
+    assert torch.equal(u['reward'], -g)
+    assert torch.equal(u['is_success'], (g.to(torch.int32) % 2))
+
+
+def test_global_env_index_keys_the_rng_so_shards_equal_one_run():
+    """oracle-side statement of the shard-equivalence property (the GPU version is tests/test_gpu_parity.py)."""
+    from oracle import OracleEnv
+    single = [OracleEnv('R', seed=5, env_index=e).reset()['obs_quat'] for e in range(4)]
+    for rank in range(2):
+        lo, hi = sharding.shard_range(rank, 2, 2)
+        shard = [OracleEnv('R', seed=5, env_index=e).reset()['obs_quat'] for e in range(lo, hi)]
+        np.testing.assert_array_equal(np.stack(shard), np.stack(single[lo:hi]))
+    assert not np.array_equal(single[0], single[1])               # different envs draw different numbers

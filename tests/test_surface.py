@@ -1,0 +1,44 @@
+"""The gym surface (ids, classes, declared spaces, attributes) equals the reference's, checked against goldens that
+were captured by constructing the reference classes (tests/golden/spaces.json, registry.json).  No GPU."""
+import numpy as np
+import pytest
+
+import roboticsplayroompybullet_amd as rp
+from roboticsplayroompybullet_amd import envs
+
+KIND_CLASS = {'U': envs.UR5PlayAbsRPY1Obj, 'R': envs.UR5Reach, 'P': envs.pandaPick}
+
+
+def test_registered_ids_match_reference_registry(golden):
+    reg = golden('registry.json')
+    ref = {e['id']: e['entry_point'].split(':')[1] for e in reg['registry']}
+    for kind, env_id in reg['ids_in_scope'].items():
+        assert env_id in rp._REGISTRY
+        assert rp._REGISTRY[env_id][0].split(':')[1] == ref[env_id] == KIND_CLASS[kind].__name__
+    with pytest.raises(KeyError):
+        rp.make('pointMass3D-v0')          # dead id in the reference (quirk F13); never registered here
+
+
+@pytest.mark.parametrize('kind', ['U', 'R', 'P'])
+def test_declared_spaces_and_attributes(golden, kind):
+    g = golden('spaces.json')[kind]
+    env = KIND_CLASS[kind]()               # constructing does not touch the GPU (lazy activation, environments.py:175)
+    np.testing.assert_array_equal(env.action_space.low, np.float32(g['action_low']))
+    np.testing.assert_array_equal(env.action_space.high, np.float32(g['action_high']))
+    for k, b in g['observation_space'].items():
+        np.testing.assert_array_equal(env.observation_space.spaces[k].low, np.float32(b['low']), err_msg=k)
+        np.testing.assert_array_equal(env.observation_space.spaces[k].high, np.float32(b['high']), err_msg=k)
+    for attr in ('num_objects', 'num_goals', 'play', 'use_orientation', 'return_velocity', 'action_type', 'arm_type', 'sparse_rew_thresh'):
+        assert getattr(env, attr) == g[attr], attr
+    assert env._max_episode_steps == g['max_episode_steps']
+    np.testing.assert_allclose(env.goal_lower_bound, g['goal_lower_bound'])
+    np.testing.assert_allclose(env.goal_upper_bound, g['goal_upper_bound'])
+    assert env.physics_client_active == 0 and env.instance is None
+
+
+def test_out_of_scope_surface_fails_loudly():
+    with pytest.raises(NotImplementedError):
+        envs.playEnv(action_type='relative_quat')
+    env = envs.UR5Reach()
+    with pytest.raises(NotImplementedError):
+        env.visualise_sub_goal(None)

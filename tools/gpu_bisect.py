@@ -8,7 +8,7 @@ from oracle import OracleEnv
 from roboticsplayroompybullet_amd import VecPlayEnv
 from gpu_debug import record_from_oracle, oracle_state_from_record
 from test_gpu_parity import actions, IDS
-np.set_printoptions(precision=6, suppress=True, linewidth=220)
+np.set_printoptions(precision=8, suppress=True, linewidth=220)
 kind, T, E = 'U', int(sys.argv[1]), int(sys.argv[2])
 n, steps = 4, 200
 o = OracleEnv(kind, seed=9, env_index=E); o.reset()
@@ -36,8 +36,9 @@ for t in range(T, T + 3):
         dvel = np.abs(vg - vo)
         same = (ncon == len(oc)) and np.allclose(gc[:, :2], oc[:, :2]) and np.allclose(gc[:, 2:], oc[:, 2:], atol=1e-4)
         print('t', t, 'sub', sub, 'ncon', ncon, len(oc), 'contacts_same', same, 'max dvel', dvel.max(), 'argmax', dvel.argmax(), 'rows', o.num_rows(), 'nsmall', int(dbg[1]))
-        if not same or dvel.max() > 1e-3:
+        if not same or dvel.max() > 3e-4:
             print(' gpu contacts\n', gc)
             print(' cpu contacts\n', oc)
-            print(' v gpu', vg); print(' v cpu', vo)
+            print(' diff contacts\n', gc - oc if gc.shape == oc.shape else None)
+            print(' v gpu', vg); print(' v cpu', vo); print(' dv diff', vg - vo)
             sys.exit(0)
