@@ -40,7 +40,7 @@
 #define IK_RESIDUAL ((real)1e-4)
 #define IK_MAX_STEP ((real)(45.0 * 3.14159265358979323846 / 180.0))
 #define TIE_EPS ((real)1e-6)            /* discrete narrowphase choices need a margin that fp32 and fp64 agree on */
-#define MAX_CONTACTS 24
+#define MAX_CONTACTS 21
 #define MAX_ACTIVE_PAIRS 64
 #define MAX_ROWS (RP_MAX_ARM * 3 + RP_MAX_J1 + 2 + 3 * MAX_CONTACTS)
 #define NB_MAX (1 + RP_MAX_ARM + RP_MAX_FREE + RP_MAX_J1)
@@ -376,7 +376,7 @@ static int manifold_replace_index(const contact* c4, const contact* pt) {
 /* Candidate pairs are sorted so the collider pairs of one object pair are contiguous: one manifold of <= 4 points
  * per object pair, as Bullet keeps per collision-object pair.  A rotation-locked free body (the drawer, H5) against
  * the static world keeps only its deepest point: all its points share one Jacobian.  Caps (shared with the HIP
- * library): the first 64 AABB-overlapping pairs are examined, the first 24 contact points are kept. */
+ * library): the first 64 AABB-overlapping pairs are examined, the first 21 contact points are kept. */
 static void collide(rpo_env* e) {
   const rp_model* m = &e->m;
   e->ncon = 0;

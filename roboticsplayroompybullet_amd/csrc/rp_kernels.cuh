@@ -24,7 +24,7 @@
 
 #define NB_MAX (1 + RP_MAX_ARM + RP_MAX_FREE + RP_MAX_J1)
 #define NVP 28               /* padded row stride (nv <= 27) */
-#define MAXC 24              /* contact points kept per env per substep (shared cap with the oracle) */
+#define MAXC 21              /* contact points kept per env per substep (shared cap with the oracle): 63 contact rows */
 #define MAXACT 64            /* AABB-overlapping pairs examined per substep (shared cap with the oracle) */
 #define MAXROWC (3 * MAXC)
 #define MAXSMALL 44          /* arm motors 12 + scene-joint motors 3 + limits 24 + gear 1 (+ pad) */
@@ -1581,6 +1581,188 @@ __global__ void __launch_bounds__(64, 4) k_solve(const DevModel* __restrict__ m,
   __syncthreads();
   float* r = state + (size_t)env * RP_REC_FLOATS;
   r[lane] = L.st[lane]; r[lane + 64] = L.st[lane + 64];
+}
+
+/* ------------------------------------------------------------------ split pipeline v2: register-resident rows, 2 envs/wave
+ * k_prep2 writes every constraint row of the substep in ONE generic lane-dense form: J[32], B = M^-1 J^T [32] and
+ * 8 scalars (rhs, dinv, mu, lo_c | hi_c, parent, -, -).  Motor/limit/gear rows become ordinary rows (mu = 0, so
+ * lo = lo_c, hi = hi_c); slots [0, NRS) hold them, slots [NRS, NRS + 3*MAXC) the contact rows, unused slots are null
+ * rows (all zero => exact no-ops).  k_solve2 keeps J and B of all NR slots in registers (lane l of a 32-lane half owns
+ * dof l of that half's env), so the 50 sweeps touch LDS only for row scalars and impulses; one wave solves TWO envs:
+ * the DPP butterflies reduce inside 16-lane rows and v_permlane16_swap folds the two rows of each half. */
+#define NRS 24
+#define NR (NRS + MAXROWC)
+#define W2_HDR 0
+#define W2_VSTAR 16
+#define W2_SC (W2_VSTAR + 32)
+#define W2_J (W2_SC + 8 * NR)
+#define W2_B (W2_J + 32 * NR)
+#define W2_FLOATS (W2_B + 32 * NR)
+
+__global__ void __launch_bounds__(64) k_prep2(const DevModel* __restrict__ m, const float* __restrict__ state, float* __restrict__ ws, int N) {
+  __shared__ EnvLds L;
+  int env = blockIdx.x, lane = threadIdx.x;
+  if (env >= N) return;
+  load_state(L, state, env, lane);
+  fk_bodies(m, L, lane);
+  __syncthreads();
+  joint_subspaces(m, L, lane);
+  collider_aabbs(m, L, lane);
+  __syncthreads();
+  int ncon = collide(m, L, lane);
+  arm_dynamics(m, L, lane);
+  unconstrained_velocities(m, L, lane);
+  int nsmall = build_small_rows(m, L, lane);
+  contact_rows(m, L, lane, ncon);
+  __syncthreads();
+  nsmall = uni(nsmall < NRS ? nsmall : NRS);
+  ncon = uni(ncon);
+  const int n = m->n_arm;
+  float* w = ws + (size_t)env * W2_FLOATS;
+  if (lane == 0) { w[W2_HDR] = __int_as_float(nsmall); w[W2_HDR + 1] = __int_as_float(3 * ncon); }
+  if (lane < 32) w[W2_VSTAR + lane] = L.vstar[lane];
+  /* scalars: lane = row */
+  for (int r = lane; r < nsmall; r += 64) {
+    const float* s = &L.srow[8 * r];
+    float4 a = {s[3], s[4], 0.f, s[5]}, b = {s[6], __int_as_float(0), 0.f, 0.f};
+    *(float4*)&w[W2_SC + 8 * r] = a; *(float4*)&w[W2_SC + 8 * r + 4] = b;
+  }
+  for (int r = lane; r < 3 * ncon; r += 64) {
+    const float* s = &L.rowS[4 * r];
+    const float* t = &L.rowT[4 * r];
+    float4 a = {s[0], s[1], s[2], t[0]}, b = {t[1], s[3], 0.f, 0.f};
+    *(float4*)&w[W2_SC + 8 * (NRS + r)] = a; *(float4*)&w[W2_SC + 8 * (NRS + r) + 4] = b;
+  }
+  /* dense J / B: lane = dof, one coalesced 128-B store per row and array */
+  if (lane < 32) {
+    for (int r = 0; r < nsmall; r++) {
+      const float* s = &L.srow[8 * r];
+      int type = __float_as_int(s[0]), dA = __float_as_int(s[1]), dB = __float_as_int(s[7]);
+      float sg = s[2], j = 0.f, b = 0.f;
+      if (type == SR_UNIT) { j = lane == dA ? sg : 0.f; if (lane < n) b = sg * L.Minv[lane * 12 + dA]; }
+      else if (type == SR_J1) { j = lane == dA ? 1.f : 0.f; b = lane == dA ? sg : 0.f; }
+      else { j = lane == dA ? 1.f : (lane == dB ? sg : 0.f); if (lane < n) b = L.Minv[lane * 12 + dA] + sg * L.Minv[lane * 12 + dB]; }
+      w[W2_J + 32 * r + lane] = j; w[W2_B + 32 * r + lane] = b;
+    }
+    for (int r = 0; r < 3 * ncon; r++) {
+      const float* t = &L.rowT[4 * r];
+      int i1 = lane - __float_as_int(t[3]), i0 = lane - __float_as_int(t[2]);
+      int idx = (unsigned)i1 < 6u ? 12 + i1 : ((unsigned)i0 < 12u ? i0 : -1);
+      float j = 0.f, b = 0.f;
+      if (idx >= 0) { j = L.u.r.J[r * ROWW + idx]; b = L.u.r.B[r * ROWW + idx]; }
+      w[W2_J + 32 * (NRS + r) + lane] = j; w[W2_B + 32 * (NRS + r) + lane] = b;
+    }
+  }
+}
+
+struct __align__(16) Solve2Lds {
+  float st[2][RP_REC_FLOATS];
+  float sc[2][NR * 8];
+  float lam[2][NR + 1];
+  float vstar[2][32];
+};
+
+/* total of v over the 32 lanes of each half, delivered to every lane of that half */
+__device__ __forceinline__ float half_sum32(float v) {
+  int x = __float_as_int(v);
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true));
+  x = __float_as_int(v);
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true));
+  x = __float_as_int(v);
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true));
+  x = __float_as_int(v);
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, true));
+  unsigned u = __float_as_uint(v);
+  auto sw = __builtin_amdgcn_permlane16_swap(u, u, false, false);     /* [r0 r0 r2 r2], [r1 r1 r3 r3] */
+  return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+}
+
+__global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m, float* __restrict__ state, const float* __restrict__ ws, int N) {
+  __shared__ Solve2Lds L;
+  const int lane = threadIdx.x, half = lane >> 5, l = lane & 31;
+  const int env = blockIdx.x * 2 + half;
+  const bool valid = env < N;
+  const float* w = ws + (size_t)(valid ? env : 0) * W2_FLOATS;
+  int my_ns = valid ? __float_as_int(w[W2_HDR]) : 0, my_nrc = valid ? __float_as_int(w[W2_HDR + 1]) : 0;
+  const int ns_max = max(__builtin_amdgcn_readlane(my_ns, 0), __builtin_amdgcn_readlane(my_ns, 32));
+  const int nrc_max = max(__builtin_amdgcn_readlane(my_nrc, 0), __builtin_amdgcn_readlane(my_nrc, 32));
+  {
+    const float* r = state + (size_t)(valid ? env : 0) * RP_REC_FLOATS;
+    for (int k = l; k < RP_REC_FLOATS; k += 32) L.st[half][k] = r[k];
+    L.vstar[half][l] = valid ? w[W2_VSTAR + l] : 0.f;
+    for (int k = l; k < NR + 1; k += 32) L.lam[half][k] = 0.f;
+    for (int k = l * 4; k < NR * 8; k += 128) {
+      int r8 = k >> 3;
+      bool used = r8 < NRS ? r8 < my_ns : (r8 - NRS) < my_nrc;
+      float4 z = {0.f, 0.f, 0.f, 0.f};
+      *(float4*)&L.sc[half][k] = used ? *(const float4*)&w[W2_SC + k] : z;
+    }
+  }
+  float J[NR], B[NR];
+#pragma unroll
+  for (int r = 0; r < NR; r++) {
+    bool used = r < NRS ? r < my_ns : (r - NRS) < my_nrc;
+    J[r] = used ? w[W2_J + 32 * r + l] : 0.f;
+    B[r] = used ? w[W2_B + 32 * r + l] : 0.f;
+  }
+  __syncthreads();
+  float dv = 0.f;
+  const float* sc = L.sc[half];
+  float* lam = L.lam[half];
+#pragma unroll 1
+  for (int it = 0; it < K_NITER; it++) {
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+      if (r < NRS ? r < ns_max : (r - NRS) < nrc_max) {
+        float4 s0 = *(const float4*)&sc[8 * r];
+        float2 s1 = *(const float2*)&sc[8 * r + 4];
+        float lamr = lam[r];
+        float lamp = lam[NRS + __float_as_int(s1.y)];
+        float jdv = half_sum32(J[r] * dv), lnew;
+        float lim = s0.z * lamp;
+        float d = pgs_update(s0.x, jdv, s0.y, lamr, s0.w - lim, s1.x + lim, lnew);
+        lam[r] = lnew;
+        dv += B[r] * d;
+      }
+    }
+  }
+  /* integrate, lane l = dof l of this half's env */
+  const int n = m->n_arm;
+  float* st = L.st[half];
+  float vnew = L.vstar[half][l] + dv;
+  __syncthreads();
+  if (l < n) {
+    st[ST_QD + l] = vnew;
+    st[ST_Q + l] += K_DT * vnew;
+  } else if (l < n + 6 * m->n_free) {
+    int k = (l - n) / 6, c = (l - n) % 6;
+    st[ST_FREE + 13 * k + 7 + c] = vnew;
+  } else if (l < m->nv) {
+    int k = l - n - 6 * m->n_free;
+    st[ST_JQD + k] = vnew;
+    st[ST_JQ + k] += K_DT * vnew;
+  }
+  __syncthreads();
+  if (l < m->n_free) {
+    float* f = &st[ST_FREE + 13 * l];
+    V3 v = ld3(f + 7), wv = ld3(f + 10);
+    st3(f, ld3(f) + v * K_DT);
+    float wn = norm(wv);
+    if (wn > 0.7853981633974483f / K_DT) wn = 0.7853981633974483f / K_DT;
+    V3 ax;
+    if (wn < 0.001f) ax = wv * (0.5f * K_DT - K_DT * K_DT * K_DT * 0.020833333333f * wn * wn);
+    else ax = wv * (sinf(0.5f * wn * K_DT) / wn);
+    Q4 dq = {ax.x, ax.y, ax.z, cosf(0.5f * wn * K_DT)};
+    Q4 q0 = {f[3], f[4], f[5], f[6]};
+    Q4 qn = qmul(dq, q0);
+    float nr = 1.f / sqrtf(qn.x * qn.x + qn.y * qn.y + qn.z * qn.z + qn.w * qn.w);
+    f[3] = qn.x * nr; f[4] = qn.y * nr; f[5] = qn.z * nr; f[6] = qn.w * nr;
+  }
+  __syncthreads();
+  if (valid) {
+    float* r = state + (size_t)env * RP_REC_FLOATS;
+    for (int k = l; k < RP_REC_FLOATS; k += 32) r[k] = st[k];
+  }
 }
 
 /* debug: one substep for every env, dumping intermediates of env `dbg_env` (tests only) */

@@ -20,7 +20,7 @@ struct rp_sim {
   hipEvent_t* pool;        /* per-launch timing ring: EV_PER_STEP events per recorded step */
   int pool_steps, pool_next, pool_count;
   int timers_on;
-  int fused;               /* 1: single fused k_step kernel (reference path), 0: split pipeline (default) */
+  int fused;               /* 0: split pipeline v2 (default), 1: single fused k_step kernel (reference path), 2: split pipeline v1 */
   rp_timers timers;
   char err[256];
 };
@@ -67,7 +67,7 @@ int rp_create(const rp_config* cfg, rp_handle* out) {
   if (e != hipSuccess) { snprintf(g_err, 256, "hipSetDevice(%d): %s", cfg->device, hipGetErrorString(e)); free(h); return RP_ERR_HIP; }
   if (hipMalloc((void**)&h->dev_model, sizeof(DevModel)) != hipSuccess ||
       hipMalloc((void**)&h->state, (size_t)cfg->num_envs * RP_REC_FLOATS * sizeof(float)) != hipSuccess ||
-      hipMalloc((void**)&h->ws, (size_t)cfg->num_envs * WS_FLOATS * sizeof(float)) != hipSuccess ||
+      hipMalloc((void**)&h->ws, (size_t)cfg->num_envs * (W2_FLOATS > WS_FLOATS ? W2_FLOATS : WS_FLOATS) * sizeof(float)) != hipSuccess ||
       hipMalloc((void**)&h->dbg, 4096 * sizeof(float)) != hipSuccess) {
     snprintf(g_err, 256, "rp_create: hipMalloc failed"); free(h); return RP_ERR_HIP;
   }
@@ -126,8 +126,8 @@ int rp_step(rp_handle h, const float* action, const rp_out* out, void* stream) {
   if (!h || !action) { if (h) snprintf(h->err, 256, "rp_step: action is NULL"); return RP_ERR_ARG; }
   hipStream_t s = (hipStream_t)stream;
   int N = h->cfg.num_envs;
-  if (h->timers_on && h->fused) hipEventRecord(h->ev0, s);
-  if (h->fused) {
+  if (h->timers_on && h->fused == 1) hipEventRecord(h->ev0, s);
+  if (h->fused == 1) {
     hipLaunchKernelGGL(k_step, dim3(N), dim3(64), 0, s, h->dev_model, h->state, action, to_ptrs(out), N);
   } else {
     OutPtrs op = to_ptrs(out);
@@ -137,8 +137,13 @@ int rp_step(rp_handle h, const float* action, const rp_out* out, void* stream) {
     if (ev) hipEventRecord(ev[0], s);
     TIMED(hipLaunchKernelGGL(k_action, dim3((N + 63) / 64), dim3(64), 0, s, h->dev_model, h->state, action, op.target_poses, N));
     for (int sub = 0; sub < K_NSUB; sub++) {
-      TIMED(hipLaunchKernelGGL(k_prep, dim3(N), dim3(64), 0, s, h->dev_model, h->state, h->ws, N));
-      TIMED(hipLaunchKernelGGL(k_solve, dim3(N), dim3(64), 0, s, h->dev_model, h->state, h->ws, N));
+      if (h->fused == 2) {       /* split pipeline v1: LDS-resident compact rows, one env per wave */
+        TIMED(hipLaunchKernelGGL(k_prep, dim3(N), dim3(64), 0, s, h->dev_model, h->state, h->ws, N));
+        TIMED(hipLaunchKernelGGL(k_solve, dim3(N), dim3(64), 0, s, h->dev_model, h->state, h->ws, N));
+      } else {                    /* default: register-resident dense rows, two envs per wave */
+        TIMED(hipLaunchKernelGGL(k_prep2, dim3(N), dim3(64), 0, s, h->dev_model, h->state, h->ws, N));
+        TIMED(hipLaunchKernelGGL(k_solve2, dim3((N + 1) / 2), dim3(64), 0, s, h->dev_model, h->state, h->ws, N));
+      }
     }
     TIMED(hipLaunchKernelGGL(k_calc_state, dim3(N), dim3(64), 0, s, h->dev_model, h->state, op, N));
     if (ev) {
@@ -149,7 +154,7 @@ int rp_step(rp_handle h, const float* action, const rp_out* out, void* stream) {
 #undef TIMED
   }
   HIPCHK(h, hipGetLastError());
-  if (h->timers_on && h->fused) { hipEventRecord(h->ev1, s); hipEventSynchronize(h->ev1); hipEventElapsedTime(&h->timers.last_step_ms, h->ev0, h->ev1); }
+  if (h->timers_on && h->fused == 1) { hipEventRecord(h->ev1, s); hipEventSynchronize(h->ev1); hipEventElapsedTime(&h->timers.last_step_ms, h->ev0, h->ev1); }
   h->timers.steps++;
   return RP_OK;
 }

@@ -128,9 +128,10 @@ class VecPlayEnv:
             s = s[None]
         _lib.check(self.lib, self.h, self.lib.rp_set_state(self.h, C.c_void_p(s.data_ptr()), s.shape[0], self._stream()), 'rp_set_state')
 
-    def set_fused(self, fused=True):
-        """Use the single fused step kernel (reference path of the library) instead of the split pipeline."""
-        self.lib.rp_set_fused(self.h, int(fused))
+    def set_fused(self, mode=1):
+        """step pipeline: 0 = default (k_action, k_prep2, k_solve2, k_calc_state), 1 = one fused kernel (the library's
+        reference path), 2 = split v1 (k_prep / k_solve, one env per wave).  All three are bit-identical."""
+        self.lib.rp_set_fused(self.h, int(mode))
 
     def enable_timers(self, steps=64):
         """keep per-launch hipEvent timings for the next `steps` rp_step calls (0 disables)"""

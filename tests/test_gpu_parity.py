@@ -113,19 +113,23 @@ def test_shard_equivalence_bitwise():
 def test_split_pipeline_equals_fused_kernel_bitwise():
     """rp_step's split kernels (k_action / k_prep / k_solve / k_calc_state) == the fused k_step kernel, bit for bit."""
     from roboticsplayroompybullet_amd import VecPlayEnv
-    for kind in ('U', 'P'):
-        a = VecPlayEnv(IDS[kind], 32, seed=5)
-        b = VecPlayEnv(IDS[kind], 32, seed=5)
-        b.set_fused(True)
-        a.reset(); b.reset()
-        acts = torch.tensor(actions(kind, 6, 32, 8), dtype=torch.float32)
+    for kind in ('U', 'P', 'R'):
+        n = 33                                  # odd: the two-envs-per-wave solver has a half-empty last wave
+        a = VecPlayEnv(IDS[kind], n, seed=5)    # default: k_action / k_prep2 / k_solve2 (2 envs per wave, rows in registers)
+        b = VecPlayEnv(IDS[kind], n, seed=5)
+        b.set_fused(1)                          # one fused kernel per env step
+        c = VecPlayEnv(IDS[kind], n, seed=5)
+        c.set_fused(2)                          # k_prep / k_solve (1 env per wave, rows in LDS)
+        a.reset(); b.reset(); c.reset()
+        acts = torch.tensor(actions(kind, 6, n, 8), dtype=torch.float32)
         for t in range(6):
             oa, ra, _, ia = a.step(acts[t])
             ob, rb, _, ib = b.step(acts[t])
+            oc, rc, _, ic = c.step(acts[t])
         torch.cuda.synchronize()
-        assert torch.equal(a.get_state(), b.get_state())
+        assert torch.equal(a.get_state(), b.get_state()) and torch.equal(c.get_state(), b.get_state())
         for k in ('obs_quat', 'achieved_goal', 'observation', 'velocity'):
-            assert torch.equal(oa[k], ob[k]), k
+            assert torch.equal(oa[k], ob[k]) and torch.equal(oc[k], ob[k]), k
         assert torch.equal(ia['target_poses'], ib['target_poses'])
 
 

@@ -445,7 +445,8 @@ def make_model(kind, arm, scene_log, arm_base_pos, arm_base_rot, ee_index, rest)
             # order so that the first collider belongs to the higher body id (dynamic one first)
             M['pair'].append((j, i) if b['body'] > a['body'] else (i, j))
     # pairs of one manifold (object pair) contiguous, in a canonical order
-    M['pair'].sort(key=lambda p: (col[p[0]]['obj'], col[p[1]]['obj'], p[0], p[1]))
+    # dynamic objects with the highest ids first (block, drawer, scene joints, then arm links): they survive the contact cap
+    M['pair'].sort(key=lambda p: (-col[p[0]]['obj'], col[p[1]]['obj'], p[0], p[1]))
     return M
 
 
