@@ -29,6 +29,9 @@
 #define MAXROWC (3 * MAXC)
 #define MAXSMALL 44          /* arm motors 12 + scene-joint motors 3 + limits 24 + gear 1 (+ pad) */
 
+#ifndef RP_PREP_WAVES
+#define RP_PREP_WAVES 1
+#endif
 #ifndef RP_WAVES_PER_EU
 #define RP_WAVES_PER_EU 1      /* register budget: 512 / RP_WAVES_PER_EU VGPR+AGPR per lane */
 #endif
@@ -228,7 +231,7 @@ __device__ int clip_poly(const float (*in)[3], int n, V3 c, V3 u, float h, float
   return m_;
 }
 
-__device__ int box_box(V3 ca, const M3& Ra, V3 ha, V3 cb, const M3& Rb, V3 hb, float margin, CPt* out) {
+__device__ __attribute__((noinline)) int box_box(V3 ca, const M3& Ra, V3 ha, V3 cb, const M3& Rb, V3 hb, float margin, CPt* out) {
   V3 A[3] = {col(Ra, 0), col(Ra, 1), col(Ra, 2)}, B[3] = {col(Rb, 0), col(Rb, 1), col(Rb, 2)};
   float hA[3] = {ha.x, ha.y, ha.z}, hB[3] = {hb.x, hb.y, hb.z};
   V3 t = ca - cb;
@@ -310,7 +313,7 @@ __device__ int box_box(V3 ca, const M3& Ra, V3 ha, V3 cb, const M3& Rb, V3 hb, f
   return outn;
 }
 
-__device__ int sphere_box(V3 cs, float r, V3 cb, const M3& Rb, V3 hb, float margin, int sphere_is_b, CPt* out) {
+__device__ __attribute__((noinline)) int sphere_box(V3 cs, float r, V3 cb, const M3& Rb, V3 hb, float margin, int sphere_is_b, CPt* out) {
   V3 l = tmulv(Rb, cs - cb);
   float ll[3] = {l.x, l.y, l.z}, cl[3], h[3] = {hb.x, hb.y, hb.z};
   int inside = 1;
@@ -665,13 +668,16 @@ __device__ int build_small_rows(const DevModel* m, EnvLds& L, int lane) {
   return nr;
 }
 
-/* Contact rows, one lane per row (normals first, then two friction rows per point, btPlaneSpace1 directions).
+/* Contact rows (normals first, then two friction rows per point, btPlaneSpace1 directions).
  * A row touches at most two bodies, so it is stored compactly: slot0 = 12 entries starting at dof off0, slot1 = 6
- * entries starting at dof off1 (an empty slot has off = 64).  If the arm is involved it takes slot0 (off0 = 0). */
+ * entries starting at dof off1 (an empty slot has off = 64).  If the arm is involved it takes slot0 (off0 = 0).
+ * Three register-light passes: (A) lane = row: Jacobian entries, the non-arm part of M^-1 J^T, partial diagonal;
+ * (B) lane = (row, i): arm part B_i = sum_k Minv[i][k] J_k; (C) lane = row: diagonal, relative velocity, rhs. */
 __device__ void contact_rows(const DevModel* m, EnvLds& L, int lane, int ncon) {
-  int n = m->n_arm;
+  const int n = m->n_arm;
+  const int nrows = 3 * ncon;
   V3 O = ld3(L.O);
-  for (int r = lane; r < 3 * ncon; r += 64) {
+  for (int r = lane; r < nrows; r += 64) {      /* pass A */
     int ci, dir;
     if (r < ncon) { ci = r; dir = 0; } else { ci = (r - ncon) >> 1; dir = 1 + ((r - ncon) & 1); }
     V3 nrm = ld3(&L.conn[3 * ci]);
@@ -693,9 +699,6 @@ __device__ void contact_rows(const DevModel* m, EnvLds& L, int lane, int ncon) {
     float* J = &L.u.r.J[r * ROWW];
     float* B = &L.u.r.B[r * ROWW];
     for (int k = 0; k < ROWW; k++) { J[k] = 0.f; B[k] = 0.f; }
-    float Jarm[RP_MAX_ARM];
-#pragma unroll
-    for (int k = 0; k < RP_MAX_ARM; k++) Jarm[k] = 0.f;
     bool has_arm = false;
     float diag = 0.f, relv = 0.f;
     int off0 = 64, off1 = 64;
@@ -709,9 +712,9 @@ __device__ void contact_rows(const DevModel* m, EnvLds& L, int lane, int ncon) {
       if (body <= n) {
         V6 f; f.a = cross(p - O, d); f.l = d;
         uint32_t anc = m->arm_anc[body - 1];
-#pragma unroll
-        for (int k = 0; k < RP_MAX_ARM; k++)
-          if (k < n && ((anc >> k) & 1u)) Jarm[k] += sign * dot6(ld6(&L.S[6 * k]), f);
+#pragma unroll 1
+        for (int k = 0; k < n; k++)
+          if ((anc >> k) & 1u) J[k] += sign * dot6(ld6(&L.S[6 * k]), f);
         has_arm = true;
         continue;
       }
@@ -744,29 +747,41 @@ __device__ void contact_rows(const DevModel* m, EnvLds& L, int lane, int ncon) {
         if (base == 0) off0 = dd; else off1 = dd;
       }
     }
-    if (has_arm) {
-      off0 = 0;
-#pragma unroll
-      for (int i = 0; i < RP_MAX_ARM; i++) {
-        if (i < n) {
-          float b = 0.f;
-#pragma unroll
-          for (int k = 0; k < RP_MAX_ARM; k++) if (k < n) b += L.Minv[i * 12 + k] * Jarm[k];
-          J[i] = Jarm[i]; B[i] = b;
-          diag += Jarm[i] * b; relv += Jarm[i] * L.vstar[i];
-        }
-      }
+    if (has_arm) off0 = 0;
+    float* s = &L.rowS[4 * r];
+    s[0] = diag; s[1] = relv; s[2] = dir == 0 ? 0.f : L.conmu[ci]; s[3] = __int_as_float(dir == 0 ? 0 : ci);
+    float* t = &L.rowT[4 * r];
+    t[0] = __int_as_float(has_arm ? 1 : 0); t[1] = dir == 0 ? 1e10f : 0.f; t[2] = __int_as_float(off0); t[3] = __int_as_float(off1);
+  }
+  __syncthreads();
+  for (int e = lane; e < nrows * n; e += 64) {  /* pass B */
+    int r = e / n, i = e - r * n;
+    if (__float_as_int(L.rowT[4 * r]) != 0) {
+      const float* J = &L.u.r.J[r * ROWW];
+      const float* Mi = &L.Minv[i * 12];
+      float b = 0.f;
+      for (int k = 0; k < n; k++) b += Mi[k] * J[k];
+      L.u.r.B[r * ROWW + i] = b;
+    }
+  }
+  __syncthreads();
+  for (int r = lane; r < nrows; r += 64) {      /* pass C */
+    float* s = &L.rowS[4 * r];
+    float* t = &L.rowT[4 * r];
+    float diag = s[0], relv = s[1];
+    if (__float_as_int(t[0]) != 0) {
+      const float* J = &L.u.r.J[r * ROWW];
+      const float* B = &L.u.r.B[r * ROWW];
+      for (int i = 0; i < n; i++) { diag += J[i] * B[i]; relv += J[i] * L.vstar[i]; }
     }
     float dinv = safe_inv(diag), rhs;
-    if (dir == 0) {
-      float pen = L.cond[ci] + K_SLOP, pos_err = 0.f, vel_err = -relv;
+    if (r < ncon) {
+      float pen = L.cond[r] + K_SLOP, pos_err = 0.f, vel_err = -relv;
       if (pen > 0.f) vel_err -= pen / K_DT; else pos_err = -pen * K_ERP / K_DT;
       rhs = (pos_err + vel_err) * dinv;
     } else rhs = -relv * dinv;
-    float* s = &L.rowS[4 * r];
-    s[0] = rhs; s[1] = dinv; s[2] = dir == 0 ? 0.f : L.conmu[ci]; s[3] = __int_as_float(dir == 0 ? 0 : ci);
-    float* t = &L.rowT[4 * r];
-    t[0] = 0.f; t[1] = dir == 0 ? 1e10f : 0.f; t[2] = __int_as_float(off0); t[3] = __int_as_float(off1);
+    s[0] = rhs; s[1] = dinv;
+    t[0] = 0.f;
   }
 }
 
@@ -1599,22 +1614,32 @@ __global__ void __launch_bounds__(64, 4) k_solve(const DevModel* __restrict__ m,
 #define W2_B (W2_J + 32 * NR)
 #define W2_FLOATS (W2_B + 32 * NR)
 
-__global__ void __launch_bounds__(64) k_prep2(const DevModel* __restrict__ m, const float* __restrict__ state, float* __restrict__ ws, int N) {
+__global__ void __launch_bounds__(64, RP_PREP_WAVES) k_prep2(const DevModel* __restrict__ m, const float* __restrict__ state, float* __restrict__ ws, int N) {
   __shared__ EnvLds L;
   int env = blockIdx.x, lane = threadIdx.x;
   if (env >= N) return;
   load_state(L, state, env, lane);
+#ifdef RP_PREP_STOP   /* timing ablations only: leave after phase RP_PREP_STOP */
+#define PREP_STOP(k) if (RP_PREP_STOP == (k)) { if (lane == 0) ws[(size_t)env * W2_FLOATS] = L.st[0]; return; }
+#else
+#define PREP_STOP(k)
+#endif
+  PREP_STOP(0)
   fk_bodies(m, L, lane);
   __syncthreads();
   joint_subspaces(m, L, lane);
   collider_aabbs(m, L, lane);
   __syncthreads();
+  PREP_STOP(1)
   int ncon = collide(m, L, lane);
+  PREP_STOP(2)
   arm_dynamics(m, L, lane);
   unconstrained_velocities(m, L, lane);
+  PREP_STOP(3)
   int nsmall = build_small_rows(m, L, lane);
   contact_rows(m, L, lane, ncon);
   __syncthreads();
+  PREP_STOP(4)
   nsmall = uni(nsmall < NRS ? nsmall : NRS);
   ncon = uni(ncon);
   const int n = m->n_arm;
