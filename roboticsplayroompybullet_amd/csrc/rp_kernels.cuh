@@ -1607,10 +1607,13 @@ __global__ void __launch_bounds__(64, 4) k_solve(const DevModel* __restrict__ m,
  * the DPP butterflies reduce inside 16-lane rows and v_permlane16_swap folds the two rows of each half. */
 #define NRS 24
 #define NR (NRS + MAXROWC)
+#define SLOT_N NRS                   /* normal row of contact c      -> slot SLOT_N + c            */
+#define SLOT_F (NRS + MAXC)          /* friction row d of contact c  -> slot SLOT_F + 2 c + d      */
 #define W2_HDR 0
 #define W2_VSTAR 16
-#define W2_SC (W2_VSTAR + 32)
-#define W2_J (W2_SC + 8 * NR)
+#define W2_MU (W2_VSTAR + 32)        /* friction coefficient per contact (MAXC, padded to 32) */
+#define W2_SC (W2_MU + 32)           /* per slot: rhs, dinv, lo_c, hi_c */
+#define W2_J (W2_SC + 4 * NR)
 #define W2_B (W2_J + 32 * NR)
 #define W2_FLOATS (W2_B + 32 * NR)
 
@@ -1644,19 +1647,20 @@ __global__ void __launch_bounds__(64, RP_PREP_WAVES) k_prep2(const DevModel* __r
   ncon = uni(ncon);
   const int n = m->n_arm;
   float* w = ws + (size_t)env * W2_FLOATS;
-  if (lane == 0) { w[W2_HDR] = __int_as_float(nsmall); w[W2_HDR + 1] = __int_as_float(3 * ncon); }
-  if (lane < 32) w[W2_VSTAR + lane] = L.vstar[lane];
+  if (lane == 0) { w[W2_HDR] = __int_as_float(nsmall); w[W2_HDR + 1] = __int_as_float(ncon); }
+  if (lane < 32) { w[W2_VSTAR + lane] = L.vstar[lane]; w[W2_MU + lane] = lane < ncon ? L.conmu[lane] : 0.f; }
   /* scalars: lane = row */
   for (int r = lane; r < nsmall; r += 64) {
     const float* s = &L.srow[8 * r];
-    float4 a = {s[3], s[4], 0.f, s[5]}, b = {s[6], __int_as_float(0), 0.f, 0.f};
-    *(float4*)&w[W2_SC + 8 * r] = a; *(float4*)&w[W2_SC + 8 * r + 4] = b;
+    float4 a = {s[3], s[4], s[5], s[6]};
+    *(float4*)&w[W2_SC + 4 * r] = a;
   }
   for (int r = lane; r < 3 * ncon; r += 64) {
     const float* s = &L.rowS[4 * r];
     const float* t = &L.rowT[4 * r];
-    float4 a = {s[0], s[1], s[2], t[0]}, b = {t[1], s[3], 0.f, 0.f};
-    *(float4*)&w[W2_SC + 8 * (NRS + r)] = a; *(float4*)&w[W2_SC + 8 * (NRS + r) + 4] = b;
+    int slot = r < ncon ? SLOT_N + r : SLOT_F + (r - ncon);
+    float4 a = {s[0], s[1], 0.f, t[1]};
+    *(float4*)&w[W2_SC + 4 * slot] = a;
   }
   /* dense J / B: lane = dof, one coalesced 128-B store per row and array */
   if (lane < 32) {
@@ -1675,15 +1679,17 @@ __global__ void __launch_bounds__(64, RP_PREP_WAVES) k_prep2(const DevModel* __r
       int idx = (unsigned)i1 < 6u ? 12 + i1 : ((unsigned)i0 < 12u ? i0 : -1);
       float j = 0.f, b = 0.f;
       if (idx >= 0) { j = L.u.r.J[r * ROWW + idx]; b = L.u.r.B[r * ROWW + idx]; }
-      w[W2_J + 32 * (NRS + r) + lane] = j; w[W2_B + 32 * (NRS + r) + lane] = b;
+      int slot = r < ncon ? SLOT_N + r : SLOT_F + (r - ncon);
+      w[W2_J + 32 * slot + lane] = j; w[W2_B + 32 * slot + lane] = b;
     }
   }
 }
 
 struct __align__(16) Solve2Lds {
   float st[2][RP_REC_FLOATS];
-  float sc[2][NR * 8];
-  float lam[2][NR + 1];
+  float sc[2][NR * 4];
+  float lam[2][NR];
+  float mu[2][32];
   float vstar[2][32];
 };
 
@@ -1702,31 +1708,43 @@ __device__ __forceinline__ float half_sum32(float v) {
   return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
 }
 
+/* one sequential-impulse row update on register-resident J/B; same arithmetic as pgs_update, clamp by v_med3 */
+__device__ __forceinline__ void row_update(float Jr, float Br, float& dv, float4 sc, float lo, float hi, float* lam_slot) {
+  float lam = *lam_slot;
+  float jdv = half_sum32(Jr * dv);
+  float d = sc.x - jdv * sc.y;
+  float sum = lam + d;
+  float lnew = __builtin_amdgcn_fmed3f(sum, lo, hi);      /* lo <= hi always */
+  d = lnew == sum ? d : lnew - lam;                       /* unclamped: pass d through bit-exactly */
+  *lam_slot = lnew;
+  dv += Br * d;
+}
+
 __global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m, float* __restrict__ state, const float* __restrict__ ws, int N) {
   __shared__ Solve2Lds L;
   const int lane = threadIdx.x, half = lane >> 5, l = lane & 31;
   const int env = blockIdx.x * 2 + half;
   const bool valid = env < N;
   const float* w = ws + (size_t)(valid ? env : 0) * W2_FLOATS;
-  int my_ns = valid ? __float_as_int(w[W2_HDR]) : 0, my_nrc = valid ? __float_as_int(w[W2_HDR + 1]) : 0;
+  int my_ns = valid ? __float_as_int(w[W2_HDR]) : 0, my_nc = valid ? __float_as_int(w[W2_HDR + 1]) : 0;
   const int ns_max = max(__builtin_amdgcn_readlane(my_ns, 0), __builtin_amdgcn_readlane(my_ns, 32));
-  const int nrc_max = max(__builtin_amdgcn_readlane(my_nrc, 0), __builtin_amdgcn_readlane(my_nrc, 32));
+  const int nc_max = max(__builtin_amdgcn_readlane(my_nc, 0), __builtin_amdgcn_readlane(my_nc, 32));
+#define SLOT_USED(r) ((r) < NRS ? (r) < my_ns : ((r) < SLOT_F ? (r) - SLOT_N < my_nc : (r) - SLOT_F < 2 * my_nc))
   {
     const float* r = state + (size_t)(valid ? env : 0) * RP_REC_FLOATS;
     for (int k = l; k < RP_REC_FLOATS; k += 32) L.st[half][k] = r[k];
     L.vstar[half][l] = valid ? w[W2_VSTAR + l] : 0.f;
-    for (int k = l; k < NR + 1; k += 32) L.lam[half][k] = 0.f;
-    for (int k = l * 4; k < NR * 8; k += 128) {
-      int r8 = k >> 3;
-      bool used = r8 < NRS ? r8 < my_ns : (r8 - NRS) < my_nrc;
+    L.mu[half][l] = valid ? w[W2_MU + l] : 0.f;
+    for (int k = l; k < NR; k += 32) {
+      L.lam[half][k] = 0.f;
       float4 z = {0.f, 0.f, 0.f, 0.f};
-      *(float4*)&L.sc[half][k] = used ? *(const float4*)&w[W2_SC + k] : z;
+      *(float4*)&L.sc[half][4 * k] = SLOT_USED(k) ? *(const float4*)&w[W2_SC + 4 * k] : z;
     }
   }
   float J[NR], B[NR];
 #pragma unroll
   for (int r = 0; r < NR; r++) {
-    bool used = r < NRS ? r < my_ns : (r - NRS) < my_nrc;
+    bool used = SLOT_USED(r);
     J[r] = used ? w[W2_J + 32 * r + l] : 0.f;
     B[r] = used ? w[W2_B + 32 * r + l] : 0.f;
   }
@@ -1734,23 +1752,30 @@ __global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m
   float dv = 0.f;
   const float* sc = L.sc[half];
   float* lam = L.lam[half];
+  const float* mu = L.mu[half];
 #pragma unroll 1
   for (int it = 0; it < K_NITER; it++) {
 #pragma unroll
-    for (int r = 0; r < NR; r++) {
-      if (r < NRS ? r < ns_max : (r - NRS) < nrc_max) {
-        float4 s0 = *(const float4*)&sc[8 * r];
-        float2 s1 = *(const float2*)&sc[8 * r + 4];
-        float lamr = lam[r];
-        float lamp = lam[NRS + __float_as_int(s1.y)];
-        float jdv = half_sum32(J[r] * dv), lnew;
-        float lim = s0.z * lamp;
-        float d = pgs_update(s0.x, jdv, s0.y, lamr, s0.w - lim, s1.x + lim, lnew);
-        lam[r] = lnew;
-        dv += B[r] * d;
+    for (int r = 0; r < NRS; r++)                       /* motors, limits, gear */
+      if (r < ns_max) {
+        float4 s = *(const float4*)&sc[4 * r];
+        row_update(J[r], B[r], dv, s, s.z, s.w, &lam[r]);
       }
-    }
+#pragma unroll
+    for (int c = 0; c < MAXC; c++)                      /* contact normals */
+      if (c < nc_max) {
+        float4 s = *(const float4*)&sc[4 * (SLOT_N + c)];
+        row_update(J[SLOT_N + c], B[SLOT_N + c], dv, s, s.z, s.w, &lam[SLOT_N + c]);
+      }
+#pragma unroll
+    for (int j = 0; j < 2 * MAXC; j++)                  /* friction: limits follow the normal impulse of the same contact */
+      if (j < 2 * nc_max) {
+        float4 s = *(const float4*)&sc[4 * (SLOT_F + j)];
+        float lim = mu[j >> 1] * lam[SLOT_N + (j >> 1)];
+        row_update(J[SLOT_F + j], B[SLOT_F + j], dv, s, s.z - lim, s.w + lim, &lam[SLOT_F + j]);
+      }
   }
+#undef SLOT_USED
   /* integrate, lane l = dof l of this half's env */
   const int n = m->n_arm;
   float* st = L.st[half];
