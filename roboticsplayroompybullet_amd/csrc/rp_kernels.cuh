@@ -1727,8 +1727,8 @@ __global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m
   const bool valid = env < N;
   const float* w = ws + (size_t)(valid ? env : 0) * W2_FLOATS;
   int my_ns = valid ? __float_as_int(w[W2_HDR]) : 0, my_nc = valid ? __float_as_int(w[W2_HDR + 1]) : 0;
-  const int ns_max = max(__builtin_amdgcn_readlane(my_ns, 0), __builtin_amdgcn_readlane(my_ns, 32));
-  const int nc_max = max(__builtin_amdgcn_readlane(my_nc, 0), __builtin_amdgcn_readlane(my_nc, 32));
+  int ns_max = max(__builtin_amdgcn_readlane(my_ns, 0), __builtin_amdgcn_readlane(my_ns, 32));
+  int nc_max = max(__builtin_amdgcn_readlane(my_nc, 0), __builtin_amdgcn_readlane(my_nc, 32));
 #define SLOT_USED(r) ((r) < NRS ? (r) < my_ns : ((r) < SLOT_F ? (r) - SLOT_N < my_nc : (r) - SLOT_F < 2 * my_nc))
   {
     const float* r = state + (size_t)(valid ? env : 0) * RP_REC_FLOATS;
@@ -1748,6 +1748,7 @@ __global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m
     J[r] = used ? w[W2_J + 32 * r + l] : 0.f;
     B[r] = used ? w[W2_B + 32 * r + l] : 0.f;
   }
+  __builtin_amdgcn_s_waitcnt(0x0F70);    /* vmcnt(0): all row registers have landed before the sweep loop */
   __syncthreads();
   float dv = 0.f;
   const float* sc = L.sc[half];
@@ -1755,21 +1756,26 @@ __global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m
   const float* mu = L.mu[half];
 #pragma unroll 1
   for (int it = 0; it < K_NITER; it++) {
+    /* keep the per-row guards as in-loop s_cmp + s_cbranch: an opaque (volatile asm) copy stops the compiler from
+     * hoisting 87 predicates out of the sweep loop and spilling them; readfirstlane re-asserts uniformity */
+    int ns_it = ns_max, nc_it = nc_max;
+    asm volatile("" : "+s"(ns_it), "+s"(nc_it));
+    ns_it = __builtin_amdgcn_readfirstlane(ns_it); nc_it = __builtin_amdgcn_readfirstlane(nc_it);
 #pragma unroll
     for (int r = 0; r < NRS; r++)                       /* motors, limits, gear */
-      if (r < ns_max) {
+      if (r < ns_it) {
         float4 s = *(const float4*)&sc[4 * r];
         row_update(J[r], B[r], dv, s, s.z, s.w, &lam[r]);
       }
 #pragma unroll
     for (int c = 0; c < MAXC; c++)                      /* contact normals */
-      if (c < nc_max) {
+      if (c < nc_it) {
         float4 s = *(const float4*)&sc[4 * (SLOT_N + c)];
         row_update(J[SLOT_N + c], B[SLOT_N + c], dv, s, s.z, s.w, &lam[SLOT_N + c]);
       }
 #pragma unroll
     for (int j = 0; j < 2 * MAXC; j++)                  /* friction: limits follow the normal impulse of the same contact */
-      if (j < 2 * nc_max) {
+      if (j < 2 * nc_it) {
         float4 s = *(const float4*)&sc[4 * (SLOT_F + j)];
         float lim = mu[j >> 1] * lam[SLOT_N + (j >> 1)];
         row_update(J[SLOT_F + j], B[SLOT_F + j], dv, s, s.z - lim, s.w + lim, &lam[SLOT_F + j]);
