@@ -940,12 +940,13 @@ __device__ void chain_fk(const DevModel* m, const ChainQ& cq, int nc, V3* org, V
   Rs = mul(x.R, ldm3(m->site_rot[RP_SITE_EE]));
 }
 
-/* damped-least-squares IK, the oracle's ik_solve restricted to the EE chain (the other dofs decouple exactly) */
-__device__ ChainQ ik_solve(const DevModel* m, V3 tpos, Q4 tq, ChainQ q, int max_iter) {
-  int nc = m->ee_chain;
+/* damped-least-squares IK, the oracle's ik_solve restricted to the EE chain (the other dofs decouple exactly).
+ * NC = chain length (6 UR5, 7 Panda) is a compile-time constant so the 6x6 / 7x7 system lives in registers. */
+template <int NC>
+__device__ ChainQ ik_solve_n(const DevModel* m, V3 tpos, Q4 tq, ChainQ q, int max_iter) {
   for (int it = 0; it < max_iter; it++) {
     V3 org[7], axw[7], pos; M3 Rs;
-    chain_fk(m, q, nc, org, axw, pos, Rs);
+    chain_fk(m, q, NC, org, axw, pos, Rs);
     V3 ep = tpos - pos;
     if (it > 0 && norm(ep) < K_IK_RES) break;
     Q4 qc = m3_to_quat(Rs);
@@ -957,58 +958,61 @@ __device__ ChainQ ik_solve(const DevModel* m, V3 tpos, Q4 tq, ChainQ q, int max_
     if (vn >= 1e-12f) { float s = 1.f / vn; axis = mk3(dq.x * s, dq.y * s, dq.z * s); }
     if (angle > RP_PI_F) angle -= 2.f * RP_PI_F;
     float err[6] = {ep.x, ep.y, ep.z, angle * axis.x, angle * axis.y, angle * axis.z};
-    float J[6][7];
+    float J[6][NC];
 #pragma unroll
-    for (int j = 0; j < 7; j++) {
-      V3 lin = mk3(0, 0, 0), ang = mk3(0, 0, 0);
-      if (j < nc) {
-        if (m->arm_jtype[j] == 0) { lin = cross(axw[j], pos - org[j]); ang = axw[j]; }
-        else lin = axw[j];
-      }
+    for (int j = 0; j < NC; j++) {
+      V3 lin, ang = mk3(0, 0, 0);
+      if (m->arm_jtype[j] == 0) { lin = cross(axw[j], pos - org[j]); ang = axw[j]; }
+      else lin = axw[j];
       J[0][j] = lin.x; J[1][j] = lin.y; J[2][j] = lin.z; J[3][j] = ang.x; J[4][j] = ang.y; J[5][j] = ang.z;
     }
-    float A[7][7], b[7];
+    float A[NC][NC], b[NC];
 #pragma unroll
-    for (int r = 0; r < 7; r++) {
+    for (int r = 0; r < NC; r++) {
 #pragma unroll
-      for (int c = 0; c < 7; c++) {
+      for (int c = r; c < NC; c++) {
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < 6; k++) s += J[k][r] * J[k][c];
         A[r][c] = s + (r == c ? K_IK_DAMP : 0.f);
+        A[c][r] = A[r][c];
       }
       float s = 0.f;
 #pragma unroll
       for (int k = 0; k < 6; k++) s += J[k][r] * err[k];
       b[r] = s;
     }
-    /* SPD solve without pivoting (rows/cols >= nc are 0.1 I / 0 and stay decoupled) */
+    /* SPD solve without pivoting */
 #pragma unroll
-    for (int c = 0; c < 7; c++) {
+    for (int c = 0; c < NC; c++) {
       float inv = 1.f / A[c][c];
 #pragma unroll
-      for (int r = c + 1; r < 7; r++) {
+      for (int r = c + 1; r < NC; r++) {
         float f = A[r][c] * inv;
 #pragma unroll
-        for (int k = c; k < 7; k++) A[r][k] -= f * A[c][k];
+        for (int k = c; k < NC; k++) A[r][k] -= f * A[c][k];
         b[r] -= f * b[c];
       }
     }
 #pragma unroll
-    for (int r = 6; r >= 0; r--) {
+    for (int r = NC - 1; r >= 0; r--) {
       float s = b[r];
 #pragma unroll
-      for (int k = r + 1; k < 7; k++) s -= A[r][k] * b[k];
+      for (int k = r + 1; k < NC; k++) s -= A[r][k] * b[k];
       b[r] = s / A[r][r];
     }
     float mx = 0.f;
 #pragma unroll
-    for (int j = 0; j < 7; j++) mx = fmaxf(mx, fabsf(b[j]));
+    for (int j = 0; j < NC; j++) mx = fmaxf(mx, fabsf(b[j]));
     float sc = mx > K_IK_MAXSTEP ? K_IK_MAXSTEP / mx : 1.f;
 #pragma unroll
-    for (int j = 0; j < 7; j++) q.q[j] += sc * b[j];
+    for (int j = 0; j < NC; j++) q.q[j] += sc * b[j];
   }
   return q;
+}
+
+__device__ __forceinline__ ChainQ ik_solve(const DevModel* m, V3 tpos, Q4 tq, ChainQ q, int max_iter) {
+  return m->ee_chain == 6 ? ik_solve_n<6>(m, tpos, tq, q, max_iter) : ik_solve_n<7>(m, tpos, tq, q, max_iter);
 }
 
 /* perform_action('absolute_rpy') .. close_gripper (environments.py:915-1073); every lane computes the same values,

@@ -244,4 +244,14 @@ int rp_debug_substep(rp_handle h, int32_t env, float* host_buf) {
   return RP_OK;
 }
 
+/* test hook: per-env (nsmall, ncon) of the most recent k_prep2 into host_buf[2*N] */
+int rp_debug_row_counts(rp_handle h, int32_t* host_buf) {
+  if (!h || !host_buf) return RP_ERR_ARG;
+  HIPCHK(h, hipDeviceSynchronize());
+  int N = h->cfg.num_envs;
+  for (int e = 0; e < N; e++)
+    HIPCHK(h, hipMemcpy(host_buf + 2 * e, h->ws + (size_t)e * W2_FLOATS, 2 * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return RP_OK;
+}
+
 }  /* extern "C" */

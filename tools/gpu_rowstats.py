@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Histogram of motor/limit rows and contact points per env-substep in the bench workload (GPU box)."""
+import ctypes as C, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from roboticsplayroompybullet_amd import VecPlayEnv
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import make_actions
+n = 4096
+env = VecPlayEnv('UR5PlayAbsRPY1Obj-v0', n, seed=1234); env.reset()
+acts = make_actions(n, 40, env.device, 1234)
+env.lib.rp_debug_row_counts.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+buf = (C.c_int32 * (2 * n))()
+allc = []
+for t in range(40):
+    env.step(acts[t])
+    if t >= 10 and t % 5 == 0:
+        env.lib.rp_debug_row_counts(env.h, buf)
+        a = np.frombuffer(buf, dtype=np.int32).reshape(n, 2).copy()
+        allc.append(a)
+a = np.concatenate(allc)
+print('nsmall: mean %.1f max %d' % (a[:, 0].mean(), a[:, 0].max()), np.bincount(a[:, 0])[12:])
+print('ncon: mean %.2f max %d' % (a[:, 1].mean(), a[:, 1].max()))
+print('ncon hist', np.bincount(a[:, 1], minlength=22))
+print('cum frac <=k', np.round(np.cumsum(np.bincount(a[:, 1], minlength=22)) / len(a), 3))
+pair = np.maximum(a[0::2, 1], a[1::2, 1])
+print('pair-max ncon cum', np.round(np.cumsum(np.bincount(pair, minlength=22)) / len(pair), 3))
