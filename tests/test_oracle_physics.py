@@ -1,0 +1,92 @@
+"""Known-answer and property tests of the CPU oracle's physics pieces (no GPU).  These do not pin parity with PyBullet
+(unpinned); they pin the oracle against analytic answers so that it is a trustworthy checker."""
+import numpy as np
+import pytest
+
+from oracle import OracleEnv, box_box, rng_uniform
+
+REST = [-1.50189075, -1.6291067, -1.87020409, -1.21324173, 1.57003561, 0.06970189]
+
+
+def test_ur5_rest_pose_fk_matches_independent_computation():
+    """SURVEY.md App. H (independent throw-away FK of ur5e2.urdf): grasptarget at (0.0014, -0.0199, 0.120), yaw ~ pi/2."""
+    e = OracleEnv('R')
+    s = e.get_state()
+    s[:6] = REST
+    e.set_state(s)
+    p, q, _, _ = e.site_pose(0)
+    np.testing.assert_allclose(p, [0.0014, -0.0199, 0.120], atol=6e-4)
+    yaw = 2 * np.arctan2(q[2], q[3])
+    assert abs(yaw - np.pi / 2) < 2e-3
+
+
+def test_mass_matrix_inverse_is_symmetric_positive_definite_and_consistent():
+    e = OracleEnv('U')
+    rng = np.random.default_rng(0)
+    for _ in range(5):
+        s = e.get_state()
+        s[:12] = np.concatenate([REST + rng.uniform(-0.4, 0.4, 6), rng.uniform(0, 0.6, 4), rng.uniform(0, 0.04, 2)])
+        s[12:24] = 0
+        e.set_state(s)
+        Mi = e.mass_matrix_inv()
+        assert np.abs(Mi - Mi.T).max() < 1e-9 * np.abs(Mi).max()
+        assert np.linalg.eigvalsh(0.5 * (Mi + Mi.T)).min() > 0
+        # zero velocity: qdd = -M^-1 g(q); the gravity torque M qdd must not depend on which link masses are where only
+        # through M: check M^-1-consistency by finite differences of potential energy along qdd being negative
+        qdd = e.forward_dynamics()
+        tau_g = np.linalg.solve(Mi, qdd)             # = -g(q)
+        assert qdd @ tau_g > 0                       # power of gravity along the induced acceleration is positive
+
+
+def test_box_box_face_contact_four_points_known_depth():
+    R = np.eye(3)
+    pts = box_box([0, 0, -0.001], R, [0.05, 0.025, 0.025], [0, 0, -0.03], R, [0.35, 0.28, 0.005], margin=0.005)
+    assert len(pts) == 4
+    np.testing.assert_allclose(pts[:, 3:6], np.tile([0, 0, 1], (4, 1)), atol=1e-12)        # normal from B (table) to A (block)
+    np.testing.assert_allclose(pts[:, 6], -0.001, atol=1e-12)                               # block sunk 1 mm into the table top
+    assert set(map(tuple, np.round(np.abs(pts[:, :2]), 6))) == {(0.05, 0.025)}              # the block's four bottom corners
+    assert len(box_box([0, 0, 0.0061], R, [0.05, 0.025, 0.025], [0, 0, -0.03], R, [0.35, 0.28, 0.005], margin=0.005)) == 0
+
+
+def test_box_box_edge_edge_single_point():
+    c, s = np.cos(np.pi / 4), np.sin(np.pi / 4)
+    Rx = np.array([[1, 0, 0], [0, c, -s], [0, s, c]])
+    Ry = np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])
+    h = np.array([0.1, 0.1, 0.1])
+    d = 2 * 0.1 * np.sqrt(2) - 0.002
+    pts = box_box([0, 0, d], Rx, h, [0, 0, 0], Ry, h, margin=0.005)
+    assert len(pts) == 1
+    np.testing.assert_allclose(np.abs(pts[0, 3:6]), [0, 0, 1], atol=1e-9)
+    assert pts[0, 6] == pytest.approx(-0.002, abs=1e-9)
+
+
+def test_block_settles_on_table_and_button_rises():
+    e = OracleEnv('U', seed=1)
+    o = e.reset()
+    q = o['obs_quat']
+    assert abs(q[10] - 0.0) < 2e-3            # block centre 25 mm above the table top at z = -0.025
+    np.testing.assert_allclose(q[11:15], [0, 0, 0.70710678, 0.70710678], atol=1e-3)
+    assert 0.005 < q[17] < 0.031              # button pushed up by its spring motor towards 0.03
+    s = e.get_state()
+    assert np.abs(s[24 + 7:24 + 13]).max() < 1e-2     # block at rest
+
+
+def test_ik_reaches_reachable_target_and_grasp_lifts_block():
+    e = OracleEnv('U', seed=2)
+    e.reset()
+    blk = e.calc_state()['obs_quat'][8:11]
+    for a in ([blk[0], blk[1], 0.12, 0, 0, 0, -1.0],) * 12 + ([blk[0], blk[1], -0.005, 0, 0, 0, -1.0],) * 12 + \
+             ([blk[0], blk[1], -0.005, 0, 0, 0, 1.0],) * 10 + ([blk[0], blk[1], 0.15, 0, 0, 0, 1.0],) * 20:
+        o, r, d, info = e.step(np.array(a, dtype=float))
+    q = o['obs_quat']
+    assert np.abs(q[0:2] - blk[0:2]).max() < 5e-3 and abs(q[2] - 0.15) < 5e-3      # EE tracks the commanded pose
+    assert q[10] > 0.1                                                              # the block came up with the gripper
+
+
+def test_counter_rng_regression_and_range():
+    vals = [rng_uniform(1234, e, c) for e in range(3) for c in range(3)]
+    assert all(0.0 <= v < 1.0 for v in vals) and len(set(vals)) == 9
+    assert rng_uniform(1234, 0, 0) == rng_uniform(1234, 0, 0)
+    assert all(float(np.float32(v)) == v for v in vals)        # 24-bit mantissa: exactly representable in fp32
+    u = np.array([rng_uniform(7, e, 0) for e in range(4000)])
+    assert abs(u.mean() - 0.5) < 0.02 and abs(u.std() - 0.2887) < 0.01
