@@ -6,9 +6,9 @@
         bench.py --gpus 8 --steps 200 --warmup 20
 
 One "step" = one playEnv.step() for every env of the batch (one rp_step call): clip -> AbsRPY IK -> motor targets
-(k_action) -> 12 physics substeps at 300 Hz (k_prep + k_solve each) -> observation + reward (k_calc_state).
+(k_action) -> 12 physics substeps at 300 Hz (k_prep2 + k_solve2 each) -> observation + reward (k_calc_state).
 Per-launch durations are measured with hipEvents recorded on the launch stream inside rp_step over the whole timed
-region (rp_enable_timers / rp_get_timers); the roofline object is for the dominant kernel, k_solve.  Actions are synthetic
+region (rp_enable_timers / rp_get_timers); the roofline object is for the dominant kernel, k_solve2.  Actions are synthetic
 (distribution B of SURVEY.md §8d: workspace-uniform, resampled every step), pre-generated on the device so the timed
 region holds only the hot path (and, for N > 1 GPUs, the RCCL all-gather of observations).  Envs shard across ranks
 with no data-path collective (weak scaling: 4096 envs per GPU).  Rank 0 prints one JSON line.
@@ -64,6 +64,20 @@ def cpu_baseline(seed, budget_s=12.0):
             'sample': '%d envs x %d steps of %s (distribution B) on the fp64 CPU oracle, 1 thread, reset excluded; '
                       'PyBullet is not installed on this box' % (n_env, n_steps, ENV_ID),
             'host_cpus': os.cpu_count()}
+
+
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r01_pmc_summary.json:
+    separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same bench; KB units; reads doubled per the gfx950 FETCH_SIZE
+    correction in MI355X_MICROARCH.md).  PMC counters cannot be read from inside this process, so this is the profile's
+    number, not a live one; None if the file is absent."""
+    path = os.path.join(REPO, 'profiles', 'r01_pmc_summary.json')
+    if not os.path.exists(path):
+        return None
+    k = json.load(open(path)).get(kernel)
+    if not k:
+        return None
+    return (2.0 * k['FETCH_SIZE_KB_avg'] + k['WRITE_SIZE_KB_avg']) * 1024.0
 
 
 def sharding_offset(rank, world, n):
@@ -150,11 +164,14 @@ def main():
                        'envs_per_gpu': n, 'global_envs': world * n, 'parallelism': 'env-shard x%d' % world,
                        'collective': 'all_gather(obs_quat+achieved_goal+reward+is_success) per step' if world > 1 else 'none'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': None, 'kernel': 'k_solve', 'kernel_ms': solve_ms, 'launches_per_step': 12,
+                         'traffic': pmc_traffic('k_solve2') if n == ENVS_PER_GPU else None, 'kernel': 'k_solve2', 'kernel_ms': solve_ms, 'launches_per_step': 12,
+                         'traffic_note': 'bytes per k_solve2 launch from profiles/r01_pmc_summary.json (2*FETCH_SIZE + WRITE_SIZE); '
+                                         'it is ~28x the algorithmic bytes because the constraint rows (~14 KB per env-substep) are '
+                                         'handed from k_prep2 to k_solve2 through an Infinity-Cache-resident workspace',
                          'algorithmic_bytes_per_launch': ALG_BYTES_PER_ENV_SUBSTEP * n,
                          'whole_step': {'achieved': step_achieved, 'frac': step_achieved / HBM_PEAK_GBS, 'ms': step_ms,
                                         'algorithmic_bytes': ALG_BYTES_PER_ENV_STEP * n},
-                         'per_launch_ms': {'k_action': tm['avg_action_ms'], 'k_prep': tm['avg_prep_ms'], 'k_solve': solve_ms,
+                         'per_launch_ms': {'k_action': tm['avg_action_ms'], 'k_prep2': tm['avg_prep_ms'], 'k_solve2': solve_ms,
                                            'k_calc_state': tm['avg_obs_ms'], 'steps_timed': tm['steps_timed']},
                          'note': 'latency/VALU-issue-bound path (serial PGS chains), not bandwidth-bound; advisory FLOP model '
                                  '9e6 FLOP/env-step => %.3g of the 157.3 TFLOP/s fp32 vector peak' % (9e6 * n / (step_ms * 1e-3) / 157.3e12)},
