@@ -1691,8 +1691,8 @@ __global__ void __launch_bounds__(64, RP_PREP_WAVES) k_prep2(const DevModel* __r
 
 struct __align__(16) Solve2Lds {
   float st[2][RP_REC_FLOATS];
-  float sc[2][(NR + 1) * 4];
-  float lam[2][NR + 1];
+  float sc[2][NR * 4];
+  float lam[2][NR];
   float mu[2][32];
   float vstar[2][32];
 };
@@ -1712,16 +1712,16 @@ __device__ __forceinline__ float half_sum32(float v) {
   return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
 }
 
-/* one sequential-impulse row update on register-resident J/B; same arithmetic as pgs_update, clamp by v_med3.
- * The row's scalars and its accumulated impulse arrive in registers (fetched from LDS one row earlier). */
-__device__ __forceinline__ float row_update(float Jr, float Br, float& dv, float4 sc, float lo, float hi, float lam) {
+/* one sequential-impulse row update on register-resident J/B; same arithmetic as pgs_update, clamp by v_med3 */
+__device__ __forceinline__ void row_update(float Jr, float Br, float& dv, float4 sc, float lo, float hi, float* lam_slot) {
+  float lam = *lam_slot;
   float jdv = half_sum32(Jr * dv);
   float d = sc.x - jdv * sc.y;
   float sum = lam + d;
   float lnew = __builtin_amdgcn_fmed3f(sum, lo, hi);      /* lo <= hi always */
   d = lnew == sum ? d : lnew - lam;                       /* unclamped: pass d through bit-exactly */
+  *lam_slot = lnew;
   dv += Br * d;
-  return lnew;
 }
 
 __global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m, float* __restrict__ state, const float* __restrict__ ws, int N) {
@@ -1739,10 +1739,10 @@ __global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m
     for (int k = l; k < RP_REC_FLOATS; k += 32) L.st[half][k] = r[k];
     L.vstar[half][l] = valid ? w[W2_VSTAR + l] : 0.f;
     L.mu[half][l] = valid ? w[W2_MU + l] : 0.f;
-    for (int k = l; k < NR + 1; k += 32) {
+    for (int k = l; k < NR; k += 32) {
       L.lam[half][k] = 0.f;
       float4 z = {0.f, 0.f, 0.f, 0.f};
-      *(float4*)&L.sc[half][4 * k] = (k < NR && SLOT_USED(k)) ? *(const float4*)&w[W2_SC + 4 * k] : z;
+      *(float4*)&L.sc[half][4 * k] = SLOT_USED(k) ? *(const float4*)&w[W2_SC + 4 * k] : z;
     }
   }
   float J[NR], B[NR];
@@ -1765,35 +1765,24 @@ __global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m
     int ns_it = ns_max, nc_it = nc_max;
     asm volatile("" : "+s"(ns_it), "+s"(nc_it));
     ns_it = __builtin_amdgcn_readfirstlane(ns_it); nc_it = __builtin_amdgcn_readfirstlane(nc_it);
-    /* software pipeline: scalars / impulse of slot r+1 are fetched from LDS before row r's reduction chain starts */
-    float4 s_nx = *(const float4*)&sc[0];
-    float lam_nx = lam[0];
 #pragma unroll
     for (int r = 0; r < NRS; r++)                       /* motors, limits, gear */
       if (r < ns_it) {
-        float4 s = s_nx; float lm = lam_nx;
-        s_nx = *(const float4*)&sc[4 * (r + 1)]; lam_nx = lam[r + 1];
-        lam[r] = row_update(J[r], B[r], dv, s, s.z, s.w, lm);
+        float4 s = *(const float4*)&sc[4 * r];
+        row_update(J[r], B[r], dv, s, s.z, s.w, &lam[r]);
       }
-    s_nx = *(const float4*)&sc[4 * SLOT_N]; lam_nx = lam[SLOT_N];
 #pragma unroll
     for (int c = 0; c < MAXC; c++)                      /* contact normals */
       if (c < nc_it) {
-        float4 s = s_nx; float lm = lam_nx;
-        s_nx = *(const float4*)&sc[4 * (SLOT_N + c + 1)]; lam_nx = lam[SLOT_N + c + 1];
-        lam[SLOT_N + c] = row_update(J[SLOT_N + c], B[SLOT_N + c], dv, s, s.z, s.w, lm);
+        float4 s = *(const float4*)&sc[4 * (SLOT_N + c)];
+        row_update(J[SLOT_N + c], B[SLOT_N + c], dv, s, s.z, s.w, &lam[SLOT_N + c]);
       }
-    s_nx = *(const float4*)&sc[4 * SLOT_F]; lam_nx = lam[SLOT_F];
-    float lim_nx = mu[0] * lam[SLOT_N];
 #pragma unroll
     for (int j = 0; j < 2 * MAXC; j++)                  /* friction: limits follow the normal impulse of the same contact */
       if (j < 2 * nc_it) {
-        float4 s = s_nx; float lm = lam_nx, lim = lim_nx;
-        if (j + 1 < 2 * MAXC) {
-          s_nx = *(const float4*)&sc[4 * (SLOT_F + j + 1)]; lam_nx = lam[SLOT_F + j + 1];
-          lim_nx = mu[(j + 1) >> 1] * lam[SLOT_N + ((j + 1) >> 1)];      /* normal impulses are final in this sweep */
-        }
-        lam[SLOT_F + j] = row_update(J[SLOT_F + j], B[SLOT_F + j], dv, s, s.z - lim, s.w + lim, lm);
+        float4 s = *(const float4*)&sc[4 * (SLOT_F + j)];
+        float lim = mu[j >> 1] * lam[SLOT_N + (j >> 1)];
+        row_update(J[SLOT_F + j], B[SLOT_F + j], dv, s, s.z - lim, s.w + lim, &lam[SLOT_F + j]);
       }
   }
 #undef SLOT_USED
