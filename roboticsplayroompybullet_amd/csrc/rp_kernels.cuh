@@ -95,6 +95,15 @@ struct __align__(16) EnvLds {
 /* ------------------------------------------------------------------ small helpers */
 __device__ __forceinline__ int dof_free(const DevModel* m, int k) { return m->n_arm + 6 * k; }
 __device__ __forceinline__ int dof_j1(const DevModel* m, int k) { return m->n_arm + 6 * m->n_free + k; }
+/* lane layout of the velocity vector inside a 32-lane group: arm dofs at lanes 0..11 (DPP row 0), every other dof
+ * at lanes 16.. (DPP row 1), so that arm-only and non-arm rows reduce in different DPP rows */
+__device__ __forceinline__ int lane_pos(const DevModel* m, int d) { return d < m->n_arm ? d : 16 + (d - m->n_arm); }
+__device__ __forceinline__ int lane_dof(const DevModel* m, int l) {       /* inverse of lane_pos; -1 = no dof at this lane */
+  if (l < 16) return l < m->n_arm ? l : -1;
+  if (l >= 32) return -1;
+  int d = m->n_arm + (l - 16);
+  return d < m->nv ? d : -1;
+}
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
 __device__ __forceinline__ float safe_inv(float d) { return d > 1e-9f ? 1.0f / d : 0.0f; }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -814,7 +823,7 @@ __device__ float solve_rows(const DevModel* m, LDS& L, int lane, int nsmall_, in
       {
         int type = uni(__float_as_int(s0.x)), dA = uni(__float_as_int(s0.y)), dB = uni(__float_as_int(s1.w));
         float sg = s0.z;
-        if (type == SR_J1) bn = lane == dA ? sg : 0.f;
+        if (type == SR_J1) bn = lane == lane_pos(m, dA) ? sg : 0.f;
         else if (lane < n) bn = type == SR_UNIT ? sg * L.Minv[lane * 12 + dA] : L.Minv[lane * 12 + dA] + sg * L.Minv[lane * 12 + dB];
       }
       for (int r = 0; r < nsmall; r++) {
@@ -826,11 +835,11 @@ __device__ float solve_rows(const DevModel* m, LDS& L, int lane, int nsmall_, in
           int t2 = uni(__float_as_int(s0.x)), a2 = uni(__float_as_int(s0.y)), b2 = uni(__float_as_int(s1.w));
           float g2 = s0.z;
           bn = 0.f;
-          if (t2 == SR_J1) bn = lane == a2 ? g2 : 0.f;
+          if (t2 == SR_J1) bn = lane == lane_pos(m, a2) ? g2 : 0.f;
           else if (lane < n) bn = t2 == SR_UNIT ? g2 * L.Minv[lane * 12 + a2] : L.Minv[lane * 12 + a2] + g2 * L.Minv[lane * 12 + b2];
         }
         float sg = c0.z;
-        float jdv = type == SR_UNIT ? sg * lane_read(dv, dA) : (type == SR_J1 ? lane_read(dv, dA) : lane_read(dv, dA) + sg * lane_read(dv, dB));
+        float jdv = type == SR_UNIT ? sg * lane_read(dv, dA) : (type == SR_J1 ? lane_read(dv, uni(lane_pos(m, dA))) : lane_read(dv, dA) + sg * lane_read(dv, dB));
         float lam = lane_read(lamS, r), lnew;
         float d = pgs_update(c0.w, jdv, c1.x, lam, c1.y, c1.z, lnew);
         lamS = lane == r ? lnew : lamS;
@@ -842,10 +851,11 @@ __device__ float solve_rows(const DevModel* m, LDS& L, int lane, int nsmall_, in
       float4 s2 = sn, t2 = tn;
       if (nrc > 1) { s2 = *(const float4*)&L.rowS[4]; t2 = *(const float4*)&L.rowT[4]; }
       float jn = 0.f, bn = 0.f;
+      const int mydof = lane_dof(m, lane);
       {
-        int i1 = lane - __float_as_int(tn.w), i0 = lane - __float_as_int(tn.z);
+        int i1 = mydof - __float_as_int(tn.w), i0 = mydof - __float_as_int(tn.z);
         int idx = (unsigned)i1 < 6u ? 12 + i1 : ((unsigned)i0 < 12u ? i0 : -1);
-        if (idx >= 0 && lane < 32) { jn = L.u.r.J[idx]; bn = L.u.r.B[idx]; }
+        if (idx >= 0 && mydof >= 0) { jn = L.u.r.J[idx]; bn = L.u.r.B[idx]; }
       }
       for (int r = 0; r < nrc; r++) {
         float jl = jn, bl = bn;
@@ -853,10 +863,10 @@ __device__ float solve_rows(const DevModel* m, LDS& L, int lane, int nsmall_, in
         int parent = uni(__float_as_int(sn.w));
         sn = s2; tn = t2;
         if (r + 1 < nrc) {
-          int i1 = lane - __float_as_int(tn.w), i0 = lane - __float_as_int(tn.z);
+          int i1 = mydof - __float_as_int(tn.w), i0 = mydof - __float_as_int(tn.z);
           int idx = (unsigned)i1 < 6u ? 12 + i1 : ((unsigned)i0 < 12u ? i0 : -1);
           jn = 0.f; bn = 0.f;
-          if (idx >= 0 && lane < 32) { jn = L.u.r.J[(r + 1) * ROWW + idx]; bn = L.u.r.B[(r + 1) * ROWW + idx]; }
+          if (idx >= 0 && mydof >= 0) { jn = L.u.r.J[(r + 1) * ROWW + idx]; bn = L.u.r.B[(r + 1) * ROWW + idx]; }
           if (r + 2 < nrc) { s2 = *(const float4*)&L.rowS[4 * (r + 2)]; t2 = *(const float4*)&L.rowT[4 * (r + 2)]; }
         }
         float lamv = r < 64 ? lamC0 : lamC1;
@@ -891,15 +901,16 @@ __device__ void substep(const DevModel* m, EnvLds& L, int lane) {
   float dv = solve_rows<EnvLds>(m, L, lane, nsmall, ncon);
   __syncthreads();
   /* apply and integrate (semi-implicit Euler) */
-  float vnew = (lane < 32 ? L.vstar[lane] : 0.f) + dv;
-  if (lane < n) {
-    L.st[ST_QD + lane] = vnew;
-    L.st[ST_Q + lane] += K_DT * vnew;
-  } else if (lane < n + 6 * m->n_free) {
-    int k = (lane - n) / 6, c = (lane - n) % 6;
+  const int dd = lane_dof(m, lane);
+  float vnew = (dd >= 0 ? L.vstar[dd] : 0.f) + dv;
+  if (dd >= 0 && dd < n) {
+    L.st[ST_QD + dd] = vnew;
+    L.st[ST_Q + dd] += K_DT * vnew;
+  } else if (dd >= 0 && dd < n + 6 * m->n_free) {
+    int k = (dd - n) / 6, c = (dd - n) % 6;
     L.st[ST_FREE + 13 * k + 7 + c] = vnew;
-  } else if (lane < m->nv) {
-    int k = lane - n - 6 * m->n_free;
+  } else if (dd >= 0) {
+    int k = dd - n - 6 * m->n_free;
     L.st[ST_JQD + k] = vnew;
     L.st[ST_JQ + k] += K_DT * vnew;
   }
@@ -1568,16 +1579,17 @@ __global__ void __launch_bounds__(64, 4) k_solve(const DevModel* __restrict__ m,
   __syncthreads();
   float dv = solve_rows(m, L, lane, nsmall, ncon);
   int n = m->n_arm;
-  float vnew = (lane < 32 ? L.vstar[lane] : 0.f) + dv;
+  const int dd = lane_dof(m, lane);
+  float vnew = (dd >= 0 ? L.vstar[dd] : 0.f) + dv;
   __syncthreads();
-  if (lane < n) {
-    L.st[ST_QD + lane] = vnew;
-    L.st[ST_Q + lane] += K_DT * vnew;
-  } else if (lane < n + 6 * m->n_free) {
-    int k = (lane - n) / 6, c = (lane - n) % 6;
+  if (dd >= 0 && dd < n) {
+    L.st[ST_QD + dd] = vnew;
+    L.st[ST_Q + dd] += K_DT * vnew;
+  } else if (dd >= 0 && dd < n + 6 * m->n_free) {
+    int k = (dd - n) / 6, c = (dd - n) % 6;
     L.st[ST_FREE + 13 * k + 7 + c] = vnew;
-  } else if (lane < m->nv) {
-    int k = lane - n - 6 * m->n_free;
+  } else if (dd >= 0) {
+    int k = dd - n - 6 * m->n_free;
     L.st[ST_JQD + k] = vnew;
     L.st[ST_JQ + k] += K_DT * vnew;
   }
@@ -1602,24 +1614,38 @@ __global__ void __launch_bounds__(64, 4) k_solve(const DevModel* __restrict__ m,
   r[lane] = L.st[lane]; r[lane + 64] = L.st[lane + 64];
 }
 
-/* ------------------------------------------------------------------ split pipeline v2: register-resident rows, 2 envs/wave
- * k_prep2 writes every constraint row of the substep in ONE generic lane-dense form: J[32], B = M^-1 J^T [32] and
- * 8 scalars (rhs, dinv, mu, lo_c | hi_c, parent, -, -).  Motor/limit/gear rows become ordinary rows (mu = 0, so
- * lo = lo_c, hi = hi_c); slots [0, NRS) hold them, slots [NRS, NRS + 3*MAXC) the contact rows, unused slots are null
- * rows (all zero => exact no-ops).  k_solve2 keeps J and B of all NR slots in registers (lane l of a 32-lane half owns
- * dof l of that half's env), so the 50 sweeps touch LDS only for row scalars and impulses; one wave solves TWO envs:
- * the DPP butterflies reduce inside 16-lane rows and v_permlane16_swap folds the two rows of each half. */
-#define NRS 24
-#define NR (NRS + MAXROWC)
-#define SLOT_N NRS                   /* normal row of contact c      -> slot SLOT_N + c            */
-#define SLOT_F (NRS + MAXC)          /* friction row d of contact c  -> slot SLOT_F + 2 c + d      */
-#define W2_HDR 0
+/* ------------------------------------------------------------------ split pipeline v2: register-resident rows, 2 envs/wave,
+ * two concurrent row streams per env.
+ *
+ * k_prep2 writes every constraint row of the substep in one generic lane-dense form (J, B = M^-1 J^T, and the four
+ * scalars rhs, dinv, lo_c, hi_c; motor/limit/gear rows are ordinary rows with mu = 0).  Velocity component d sits at
+ * lane position pos(d) of its env's 32-lane half: arm dofs at lanes 0..11 (DPP row 0), every other dof at lanes
+ * 16.. (DPP row 1).  Rows are split into two streams:
+ *   A  rows that touch only arm dofs (arm motors, joint limits, gear)                    slots [0, NA)
+ *   B  everything else: scene-joint motors [0, 3), contact normals [3, 3 + MAXC), frictions [24, 24 + 2 MAXC)
+ * A rows and B rows without an arm part act on disjoint velocity components, so they COMMUTE exactly: the canonical
+ * sweep order (motors, scene-joint motors, limits, gear, normals, frictions) equals "all A rows, then all B rows"
+ * and, when no contact involves the arm in this substep (flag `coupled` = 0), also equals running stream A in DPP row
+ * 0 and stream B in DPP row 1 AT THE SAME TIME: one instruction stream updates A row t and B row t together, the
+ * 4-step DPP butterfly yields both 16-lane dot products, no cross-row fold is needed, and a sweep takes
+ * max(nA, nB) instead of nA + nB dependent row updates.  Waves whose two envs are both uncoupled take that path
+ * (PAR); the others run the streams one after the other with the 32-lane fold (SEQ).  Results are bit-identical.
+ * k_solve2 keeps J and B of all slots in registers, so the 50 sweeps touch LDS only for row scalars and impulses. */
+#define NA 24
+#define NBJ 3                         /* B slots [0, NBJ): scene-joint motor rows */
+#define SLOT_N NBJ                    /* normal row of contact c      -> B slot SLOT_N + c           */
+#define SLOT_F (NBJ + MAXC)           /* friction row d of contact c  -> B slot SLOT_F + 2 c + d     */
+#define NB (NBJ + 3 * MAXC)
+#define W2_HDR 0                      /* nA, nj1, ncon, coupled */
 #define W2_VSTAR 16
-#define W2_MU (W2_VSTAR + 32)        /* friction coefficient per contact (MAXC, padded to 32) */
-#define W2_SC (W2_MU + 32)           /* per slot: rhs, dinv, lo_c, hi_c */
-#define W2_J (W2_SC + 4 * NR)
-#define W2_B (W2_J + 32 * NR)
-#define W2_FLOATS (W2_B + 32 * NR)
+#define W2_MU (W2_VSTAR + 32)
+#define W2_SCA (W2_MU + 32)
+#define W2_SCB (W2_SCA + 4 * NA)
+#define W2_JA (W2_SCB + 4 * NB)
+#define W2_BA (W2_JA + 16 * NA)
+#define W2_JB (W2_BA + 16 * NA)
+#define W2_BB (W2_JB + 32 * NB)
+#define W2_FLOATS (W2_BB + 32 * NB)
 
 __global__ void __launch_bounds__(64, RP_PREP_WAVES) k_prep2(const DevModel* __restrict__ m, const float* __restrict__ state, float* __restrict__ ws, int N) {
   __shared__ EnvLds L;
@@ -1647,58 +1673,88 @@ __global__ void __launch_bounds__(64, RP_PREP_WAVES) k_prep2(const DevModel* __r
   contact_rows(m, L, lane, ncon);
   __syncthreads();
   PREP_STOP(4)
-  nsmall = uni(nsmall < NRS ? nsmall : NRS);
+  nsmall = uni(nsmall);
   ncon = uni(ncon);
   const int n = m->n_arm;
   float* w = ws + (size_t)env * W2_FLOATS;
-  if (lane == 0) { w[W2_HDR] = __int_as_float(nsmall); w[W2_HDR + 1] = __int_as_float(ncon); }
-  if (lane < 32) { w[W2_VSTAR + lane] = L.vstar[lane]; w[W2_MU + lane] = lane < ncon ? L.conmu[lane] : 0.f; }
+  /* stream assignment of the motor/limit/gear rows, in order: lane r decides for small row r */
+  bool isj1 = false, isa = false;
+  if (lane < nsmall) { isj1 = __float_as_int(L.srow[8 * lane]) == SR_J1; isa = !isj1; }
+  unsigned long long mA = __ballot(isa), mJ = __ballot(isj1);
+  int nA = __popcll(mA), nJ = __popcll(mJ);
+  nA = nA < NA ? nA : NA; nJ = nJ < NBJ ? nJ : NBJ;
+  bool coupled = false;
+  for (int c = 0; c < ncon; c++) {
+    int ba = m->col_body[L.cona[c]], bb = m->col_body[L.conb[c]];
+    if ((ba >= 1 && ba <= n) || (bb >= 1 && bb <= n)) coupled = true;
+  }
+  if (lane == 0) {
+    w[W2_HDR] = __int_as_float(nA); w[W2_HDR + 1] = __int_as_float(nJ); w[W2_HDR + 2] = __int_as_float(ncon);
+    w[W2_HDR + 3] = __int_as_float(coupled ? 1 : 0);
+  }
+  int dl = lane_dof(m, lane & 31);
+  if (lane < 32) { w[W2_VSTAR + lane] = dl >= 0 ? L.vstar[dl] : 0.f; w[W2_MU + lane] = lane < ncon ? L.conmu[lane] : 0.f; }
   /* scalars: lane = row */
-  for (int r = lane; r < nsmall; r += 64) {
-    const float* s = &L.srow[8 * r];
+  if (lane < nsmall) {
+    const float* s = &L.srow[8 * lane];
     float4 a = {s[3], s[4], s[5], s[6]};
-    *(float4*)&w[W2_SC + 4 * r] = a;
+    int slot = isa ? __popcll(mA & ((1ull << lane) - 1ull)) : __popcll(mJ & ((1ull << lane) - 1ull));
+    if (isa && slot < NA) *(float4*)&w[W2_SCA + 4 * slot] = a;
+    if (isj1 && slot < NBJ) *(float4*)&w[W2_SCB + 4 * slot] = a;
   }
   for (int r = lane; r < 3 * ncon; r += 64) {
     const float* s = &L.rowS[4 * r];
     const float* t = &L.rowT[4 * r];
     int slot = r < ncon ? SLOT_N + r : SLOT_F + (r - ncon);
     float4 a = {s[0], s[1], 0.f, t[1]};
-    *(float4*)&w[W2_SC + 4 * slot] = a;
+    *(float4*)&w[W2_SCB + 4 * slot] = a;
   }
-  /* dense J / B: lane = dof, one coalesced 128-B store per row and array */
+  /* dense J / B at lane positions: one coalesced store per row and array */
   if (lane < 32) {
+    int ia = 0, ij = 0;
     for (int r = 0; r < nsmall; r++) {
       const float* s = &L.srow[8 * r];
       int type = __float_as_int(s[0]), dA = __float_as_int(s[1]), dB = __float_as_int(s[7]);
       float sg = s[2], j = 0.f, b = 0.f;
-      if (type == SR_UNIT) { j = lane == dA ? sg : 0.f; if (lane < n) b = sg * L.Minv[lane * 12 + dA]; }
-      else if (type == SR_J1) { j = lane == dA ? 1.f : 0.f; b = lane == dA ? sg : 0.f; }
-      else { j = lane == dA ? 1.f : (lane == dB ? sg : 0.f); if (lane < n) b = L.Minv[lane * 12 + dA] + sg * L.Minv[lane * 12 + dB]; }
-      w[W2_J + 32 * r + lane] = j; w[W2_B + 32 * r + lane] = b;
+      if (type == SR_J1) {
+        if (ij < NBJ) {
+          j = dl == dA ? 1.f : 0.f; b = dl == dA ? sg : 0.f;
+          w[W2_JB + 32 * ij + lane] = j; w[W2_BB + 32 * ij + lane] = b;
+        }
+        ij++;
+      } else {
+        if (ia < NA && lane < 16) {
+          if (type == SR_UNIT) { j = lane == dA ? sg : 0.f; if (lane < n) b = sg * L.Minv[lane * 12 + dA]; }
+          else { j = lane == dA ? 1.f : (lane == dB ? sg : 0.f); if (lane < n) b = L.Minv[lane * 12 + dA] + sg * L.Minv[lane * 12 + dB]; }
+          w[W2_JA + 16 * ia + lane] = j; w[W2_BA + 16 * ia + lane] = b;
+        }
+        ia++;
+      }
     }
     for (int r = 0; r < 3 * ncon; r++) {
       const float* t = &L.rowT[4 * r];
-      int i1 = lane - __float_as_int(t[3]), i0 = lane - __float_as_int(t[2]);
-      int idx = (unsigned)i1 < 6u ? 12 + i1 : ((unsigned)i0 < 12u ? i0 : -1);
       float j = 0.f, b = 0.f;
-      if (idx >= 0) { j = L.u.r.J[r * ROWW + idx]; b = L.u.r.B[r * ROWW + idx]; }
+      if (dl >= 0) {
+        int i1 = dl - __float_as_int(t[3]), i0 = dl - __float_as_int(t[2]);
+        int idx = (unsigned)i1 < 6u ? 12 + i1 : ((unsigned)i0 < 12u ? i0 : -1);
+        if (idx >= 0) { j = L.u.r.J[r * ROWW + idx]; b = L.u.r.B[r * ROWW + idx]; }
+      }
       int slot = r < ncon ? SLOT_N + r : SLOT_F + (r - ncon);
-      w[W2_J + 32 * slot + lane] = j; w[W2_B + 32 * slot + lane] = b;
+      w[W2_JB + 32 * slot + lane] = j; w[W2_BB + 32 * slot + lane] = b;
     }
   }
 }
 
 struct __align__(16) Solve2Lds {
   float st[2][RP_REC_FLOATS];
-  float sc[2][NR * 4];
-  float lam[2][NR];
-  float mu[2][32];
+  float sc[2][2][(NB + 1) * 4];        /* [half][stream][slot] rhs, dinv, lo_c, hi_c */
+  float lam[2][2][NB + 1];
+  float mu[2][2][32];                  /* stream A: zeros */
   float vstar[2][32];
 };
 
-/* total of v over the 32 lanes of each half, delivered to every lane of that half */
-__device__ __forceinline__ float half_sum32(float v) {
+/* DPP butterfly inside each 16-lane row: every lane ends with the sum over its row */
+__device__ __forceinline__ float row16_sum(float v) {
   int x = __float_as_int(v);
   v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true));
   x = __float_as_int(v);
@@ -1707,15 +1763,21 @@ __device__ __forceinline__ float half_sum32(float v) {
   v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true));
   x = __float_as_int(v);
   v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, true));
+  return v;
+}
+/* total over the 32 lanes of each half, delivered to every lane of that half */
+__device__ __forceinline__ float half_sum32(float v) {
+  v = row16_sum(v);
   unsigned u = __float_as_uint(v);
   auto sw = __builtin_amdgcn_permlane16_swap(u, u, false, false);     /* [r0 r0 r2 r2], [r1 r1 r3 r3] */
   return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
 }
 
 /* one sequential-impulse row update on register-resident J/B; same arithmetic as pgs_update, clamp by v_med3 */
+template <bool FULL>
 __device__ __forceinline__ void row_update(float Jr, float Br, float& dv, float4 sc, float lo, float hi, float* lam_slot) {
   float lam = *lam_slot;
-  float jdv = half_sum32(Jr * dv);
+  float jdv = FULL ? half_sum32(Jr * dv) : row16_sum(Jr * dv);
   float d = sc.x - jdv * sc.y;
   float sum = lam + d;
   float lnew = __builtin_amdgcn_fmed3f(sum, lo, hi);      /* lo <= hi always */
@@ -1726,81 +1788,126 @@ __device__ __forceinline__ void row_update(float Jr, float Br, float& dv, float4
 
 __global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m, float* __restrict__ state, const float* __restrict__ ws, int N) {
   __shared__ Solve2Lds L;
-  const int lane = threadIdx.x, half = lane >> 5, l = lane & 31;
+  const int lane = threadIdx.x, half = lane >> 5, l = lane & 31, grp = l >> 4;
   const int env = blockIdx.x * 2 + half;
   const bool valid = env < N;
   const float* w = ws + (size_t)(valid ? env : 0) * W2_FLOATS;
-  int my_ns = valid ? __float_as_int(w[W2_HDR]) : 0, my_nc = valid ? __float_as_int(w[W2_HDR + 1]) : 0;
-  int ns_max = max(__builtin_amdgcn_readlane(my_ns, 0), __builtin_amdgcn_readlane(my_ns, 32));
+  int my_na = valid ? __float_as_int(w[W2_HDR]) : 0, my_nj = valid ? __float_as_int(w[W2_HDR + 1]) : 0;
+  int my_nc = valid ? __float_as_int(w[W2_HDR + 2]) : 0, my_cp = valid ? __float_as_int(w[W2_HDR + 3]) : 0;
+  int na_max = max(__builtin_amdgcn_readlane(my_na, 0), __builtin_amdgcn_readlane(my_na, 32));
+  int nj_max = max(__builtin_amdgcn_readlane(my_nj, 0), __builtin_amdgcn_readlane(my_nj, 32));
   int nc_max = max(__builtin_amdgcn_readlane(my_nc, 0), __builtin_amdgcn_readlane(my_nc, 32));
-#define SLOT_USED(r) ((r) < NRS ? (r) < my_ns : ((r) < SLOT_F ? (r) - SLOT_N < my_nc : (r) - SLOT_F < 2 * my_nc))
+  const bool par = (__builtin_amdgcn_readlane(my_cp, 0) | __builtin_amdgcn_readlane(my_cp, 32)) == 0;
+#define B_USED(t) ((t) < NBJ ? (t) < my_nj : ((t) < SLOT_F ? (t) - SLOT_N < my_nc : (t) - SLOT_F < 2 * my_nc))
   {
     const float* r = state + (size_t)(valid ? env : 0) * RP_REC_FLOATS;
     for (int k = l; k < RP_REC_FLOATS; k += 32) L.st[half][k] = r[k];
     L.vstar[half][l] = valid ? w[W2_VSTAR + l] : 0.f;
-    L.mu[half][l] = valid ? w[W2_MU + l] : 0.f;
-    for (int k = l; k < NR; k += 32) {
-      L.lam[half][k] = 0.f;
-      float4 z = {0.f, 0.f, 0.f, 0.f};
-      *(float4*)&L.sc[half][4 * k] = SLOT_USED(k) ? *(const float4*)&w[W2_SC + 4 * k] : z;
+    L.mu[half][0][l] = 0.f;
+    L.mu[half][1][l] = valid ? w[W2_MU + l] : 0.f;
+    float4 z = {0.f, 0.f, 0.f, 0.f};
+    for (int k = l; k < NB + 1; k += 32) {
+      L.lam[half][0][k] = 0.f; L.lam[half][1][k] = 0.f;
+      *(float4*)&L.sc[half][0][4 * k] = k < my_na ? *(const float4*)&w[W2_SCA + 4 * k] : z;
+      *(float4*)&L.sc[half][1][4 * k] = (k < NB && B_USED(k)) ? *(const float4*)&w[W2_SCB + 4 * k] : z;
     }
   }
-  float J[NR], B[NR];
+  float JA[NA], BA[NA], JB[NB], BB[NB];
 #pragma unroll
-  for (int r = 0; r < NR; r++) {
-    bool used = SLOT_USED(r);
-    J[r] = used ? w[W2_J + 32 * r + l] : 0.f;
-    B[r] = used ? w[W2_B + 32 * r + l] : 0.f;
+  for (int t = 0; t < NA; t++) {
+    bool used = t < my_na && l < 16;
+    JA[t] = used ? w[W2_JA + 16 * t + l] : 0.f;
+    BA[t] = used ? w[W2_BA + 16 * t + l] : 0.f;
   }
+#pragma unroll
+  for (int t = 0; t < NB; t++) {
+    bool used = B_USED(t);
+    JB[t] = used ? w[W2_JB + 32 * t + l] : 0.f;
+    BB[t] = used ? w[W2_BB + 32 * t + l] : 0.f;
+  }
+#undef B_USED
   __builtin_amdgcn_s_waitcnt(0x0F70);    /* vmcnt(0): all row registers have landed before the sweep loop */
   __syncthreads();
   float dv = 0.f;
-  const float* sc = L.sc[half];
-  float* lam = L.lam[half];
-  const float* mu = L.mu[half];
+  if (par) {
+    /* both envs uncoupled: stream A in DPP row 0 and stream B in DPP row 1 of each half, one slot of each per step */
+#pragma unroll
+    for (int t = 0; t < NA; t++) { JB[t] += JA[t]; BB[t] += BA[t]; }     /* disjoint lanes: exact merge */
+    const float* sc = L.sc[half][grp];
+    float* lam = L.lam[half][grp];
+    const float* mu = L.mu[half][grp];
 #pragma unroll 1
-  for (int it = 0; it < K_NITER; it++) {
-    /* keep the per-row guards as in-loop s_cmp + s_cbranch: an opaque (volatile asm) copy stops the compiler from
-     * hoisting 87 predicates out of the sweep loop and spilling them; readfirstlane re-asserts uniformity */
-    int ns_it = ns_max, nc_it = nc_max;
-    asm volatile("" : "+s"(ns_it), "+s"(nc_it));
-    ns_it = __builtin_amdgcn_readfirstlane(ns_it); nc_it = __builtin_amdgcn_readfirstlane(nc_it);
+    for (int it = 0; it < K_NITER; it++) {
+      int na_it = na_max, nj_it = nj_max, nc_it = nc_max;
+      asm volatile("" : "+s"(na_it), "+s"(nj_it), "+s"(nc_it));        /* keep the guards as in-loop s_cmp + s_cbranch */
+      na_it = __builtin_amdgcn_readfirstlane(na_it); nj_it = __builtin_amdgcn_readfirstlane(nj_it);
+      nc_it = __builtin_amdgcn_readfirstlane(nc_it);
 #pragma unroll
-    for (int r = 0; r < NRS; r++)                       /* motors, limits, gear */
-      if (r < ns_it) {
-        float4 s = *(const float4*)&sc[4 * r];
-        row_update(J[r], B[r], dv, s, s.z, s.w, &lam[r]);
-      }
+      for (int t = 0; t < SLOT_F; t++)                    /* A rows | scene-joint motors, contact normals */
+        if (t < na_it || (t < NBJ ? t < nj_it : t - SLOT_N < nc_it)) {
+          float4 s = *(const float4*)&sc[4 * t];
+          row_update<false>(JB[t], BB[t], dv, s, s.z, s.w, &lam[t]);
+        }
 #pragma unroll
-    for (int c = 0; c < MAXC; c++)                      /* contact normals */
-      if (c < nc_it) {
-        float4 s = *(const float4*)&sc[4 * (SLOT_N + c)];
-        row_update(J[SLOT_N + c], B[SLOT_N + c], dv, s, s.z, s.w, &lam[SLOT_N + c]);
-      }
+      for (int j = 0; j < 2 * MAXC; j++)                  /* frictions (stream B only; stream A has mu = 0 and null rows) */
+        if (j < 2 * nc_it) {
+          float4 s = *(const float4*)&sc[4 * (SLOT_F + j)];
+          float lim = mu[j >> 1] * lam[SLOT_N + (j >> 1)];
+          row_update<false>(JB[SLOT_F + j], BB[SLOT_F + j], dv, s, s.z - lim, s.w + lim, &lam[SLOT_F + j]);
+        }
+    }
+  } else {
+    /* a contact involves the arm: all A rows, then all B rows, 32-lane dot products */
+    const float* scA = L.sc[half][0];
+    const float* scB = L.sc[half][1];
+    float* lamA = L.lam[half][0];
+    float* lamB = L.lam[half][1];
+    const float* mu = L.mu[half][1];
+#pragma unroll 1
+    for (int it = 0; it < K_NITER; it++) {
+      int na_it = na_max, nj_it = nj_max, nc_it = nc_max;
+      asm volatile("" : "+s"(na_it), "+s"(nj_it), "+s"(nc_it));
+      na_it = __builtin_amdgcn_readfirstlane(na_it); nj_it = __builtin_amdgcn_readfirstlane(nj_it);
+      nc_it = __builtin_amdgcn_readfirstlane(nc_it);
 #pragma unroll
-    for (int j = 0; j < 2 * MAXC; j++)                  /* friction: limits follow the normal impulse of the same contact */
-      if (j < 2 * nc_it) {
-        float4 s = *(const float4*)&sc[4 * (SLOT_F + j)];
-        float lim = mu[j >> 1] * lam[SLOT_N + (j >> 1)];
-        row_update(J[SLOT_F + j], B[SLOT_F + j], dv, s, s.z - lim, s.w + lim, &lam[SLOT_F + j]);
-      }
+      for (int t = 0; t < NA; t++)
+        if (t < na_it) {
+          float4 s = *(const float4*)&scA[4 * t];
+          row_update<true>(JA[t], BA[t], dv, s, s.z, s.w, &lamA[t]);
+        }
+#pragma unroll
+      for (int t = 0; t < SLOT_F; t++)
+        if (t < NBJ ? t < nj_it : t - SLOT_N < nc_it) {
+          float4 s = *(const float4*)&scB[4 * t];
+          row_update<true>(JB[t], BB[t], dv, s, s.z, s.w, &lamB[t]);
+        }
+#pragma unroll
+      for (int j = 0; j < 2 * MAXC; j++)
+        if (j < 2 * nc_it) {
+          float4 s = *(const float4*)&scB[4 * (SLOT_F + j)];
+          float lim = mu[j >> 1] * lamB[SLOT_N + (j >> 1)];
+          row_update<true>(JB[SLOT_F + j], BB[SLOT_F + j], dv, s, s.z - lim, s.w + lim, &lamB[SLOT_F + j]);
+        }
+    }
   }
-#undef SLOT_USED
-  /* integrate, lane l = dof l of this half's env */
+  /* integrate: lane l holds velocity component lane_dof(l) of this half's env */
   const int n = m->n_arm;
+  const int dd = lane_dof(m, l);
   float* st = L.st[half];
   float vnew = L.vstar[half][l] + dv;
   __syncthreads();
-  if (l < n) {
-    st[ST_QD + l] = vnew;
-    st[ST_Q + l] += K_DT * vnew;
-  } else if (l < n + 6 * m->n_free) {
-    int k = (l - n) / 6, c = (l - n) % 6;
-    st[ST_FREE + 13 * k + 7 + c] = vnew;
-  } else if (l < m->nv) {
-    int k = l - n - 6 * m->n_free;
-    st[ST_JQD + k] = vnew;
-    st[ST_JQ + k] += K_DT * vnew;
+  if (dd >= 0) {
+    if (dd < n) {
+      st[ST_QD + dd] = vnew;
+      st[ST_Q + dd] += K_DT * vnew;
+    } else if (dd < n + 6 * m->n_free) {
+      int k = (dd - n) / 6, c = (dd - n) % 6;
+      st[ST_FREE + 13 * k + 7 + c] = vnew;
+    } else {
+      int k = dd - n - 6 * m->n_free;
+      st[ST_JQD + k] = vnew;
+      st[ST_JQ + k] += K_DT * vnew;
+    }
   }
   __syncthreads();
   if (l < m->n_free) {
@@ -1860,7 +1967,8 @@ __global__ void __launch_bounds__(64) k_debug_substep(const DevModel* __restrict
   float dv = solve_rows(m, L, lane, nsmall, ncon);
   if (env == dbg_env) {
     if (lane == 0) { dbg[1] = (float)nsmall; }
-    if (lane < 32) dbg[544 + lane] = dv;
+    int dd = lane_dof(m, lane);
+    if (dd >= 0) dbg[544 + dd] = dv;
   }
   __syncthreads();
 }

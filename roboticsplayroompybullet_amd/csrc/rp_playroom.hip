@@ -249,8 +249,11 @@ int rp_debug_row_counts(rp_handle h, int32_t* host_buf) {
   if (!h || !host_buf) return RP_ERR_ARG;
   HIPCHK(h, hipDeviceSynchronize());
   int N = h->cfg.num_envs;
-  for (int e = 0; e < N; e++)
-    HIPCHK(h, hipMemcpy(host_buf + 2 * e, h->ws + (size_t)e * W2_FLOATS, 2 * sizeof(int32_t), hipMemcpyDeviceToHost));
+  for (int e = 0; e < N; e++) {   /* header: nA, nj1, ncon, coupled -> (nA + nj1, ncon + 1000 * coupled) */
+    int32_t hdr[4];
+    HIPCHK(h, hipMemcpy(hdr, h->ws + (size_t)e * W2_FLOATS, 4 * sizeof(int32_t), hipMemcpyDeviceToHost));
+    host_buf[2 * e] = hdr[0] + hdr[1]; host_buf[2 * e + 1] = hdr[2] + 1000 * hdr[3];
+  }
   return RP_OK;
 }
 
