@@ -1777,12 +1777,18 @@ __device__ __forceinline__ float half_sum32(float v) {
 template <bool FULL>
 __device__ __forceinline__ void row_update(float Jr, float Br, float& dv, float4 sc, float lo, float hi, float* lam_slot) {
   float lam = *lam_slot;
+#if defined(RP_ABL) && RP_ABL == 1      /* timing ablation: no cross-lane reduction */
+  float jdv = Jr * dv;
+#else
   float jdv = FULL ? half_sum32(Jr * dv) : row16_sum(Jr * dv);
+#endif
   float d = sc.x - jdv * sc.y;
   float sum = lam + d;
   float lnew = __builtin_amdgcn_fmed3f(sum, lo, hi);      /* lo <= hi always */
   d = lnew == sum ? d : lnew - lam;                       /* unclamped: pass d through bit-exactly */
+#if !(defined(RP_ABL) && RP_ABL == 2)   /* timing ablation 2: no impulse store */
   *lam_slot = lnew;
+#endif
   dv += Br * d;
 }
 
@@ -1834,8 +1840,12 @@ __global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m
 #pragma unroll
     for (int t = 0; t < NA; t++) { JB[t] += JA[t]; BB[t] += BA[t]; }     /* disjoint lanes: exact merge */
     const float* sc = L.sc[half][grp];
-    float* lam = L.lam[half][grp];
     const float* mu = L.mu[half][grp];
+    /* accumulated impulses stay in registers here (the stream-A registers are dead after the merge): the sweep loop
+     * has no LDS stores, so the read-only scalar loads can be scheduled freely ahead of the dependent chain */
+    float lam[NB];
+#pragma unroll
+    for (int t = 0; t < NB; t++) lam[t] = 0.f;
 #pragma unroll 1
     for (int it = 0; it < K_NITER; it++) {
       int na_it = na_max, nj_it = nj_max, nc_it = nc_max;

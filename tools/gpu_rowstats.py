@@ -20,6 +20,8 @@ for t in range(40):
         allc.append(a)
 a = np.concatenate(allc)
 print('nsmall: mean %.1f max %d' % (a[:, 0].mean(), a[:, 0].max()), np.bincount(a[:, 0])[12:])
+cp = a[:, 1] >= 1000; a[:, 1] = a[:, 1] % 1000
+print('coupled fraction (env-substeps with an arm contact): %.3f; pairs with any coupled: %.3f' % (cp.mean(), (cp[0::2] | cp[1::2]).mean()))
 print('ncon: mean %.2f max %d' % (a[:, 1].mean(), a[:, 1].max()))
 print('ncon hist', np.bincount(a[:, 1], minlength=22))
 print('cum frac <=k', np.round(np.cumsum(np.bincount(a[:, 1], minlength=22)) / len(a), 3))
