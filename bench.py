@@ -92,6 +92,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--envs-per-gpu', type=int, default=ENVS_PER_GPU)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--groups', type=int, default=0, help='env groups per rp_step (0 = library default)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -108,6 +109,8 @@ def main():
     from roboticsplayroompybullet_amd import VecPlayEnv
     n = args.envs_per_gpu
     env = VecPlayEnv(ENV_ID, n, device=local_rank, seed=1234, env_offset=sharding_offset(rank, world, n))
+    if args.groups:
+        env.set_groups(args.groups)
     env.reset()
     actions = make_actions(n, args.steps + args.warmup, device, 1234 + rank)
     pack_w = env.dims['obs_quat'] + env.dims['achieved_goal'] + 2
@@ -125,7 +128,6 @@ def main():
         one_step(k)
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    env.enable_timers(args.steps)        # per-launch hipEvent pairs on the launch stream; read back after the region
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -145,7 +147,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     step_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / args.steps
+    # per-launch kernel durations: hipEvent pairs recorded on the launch stream inside rp_step; bracketing single kernels
+    # needs the env groups (concurrent streams) switched off, so this is a second region over the same actions
+    n_kt = min(args.steps, 50)
+    env.enable_timers(n_kt)
+    for k in range(n_kt):
+        env.step(actions[args.warmup + k])
+    torch.cuda.synchronize()
     tm = env.timers()
+    env.enable_timers(0)
     bad = int(info['status'].sum().item())
     success = float(info['is_success'].float().mean().item())
 
@@ -172,7 +182,9 @@ def main():
                          'whole_step': {'achieved': step_achieved, 'frac': step_achieved / HBM_PEAK_GBS, 'ms': step_ms,
                                         'algorithmic_bytes': ALG_BYTES_PER_ENV_STEP * n},
                          'per_launch_ms': {'k_action': tm['avg_action_ms'], 'k_prep2': tm['avg_prep_ms'], 'k_solve2': solve_ms,
-                                           'k_calc_state': tm['avg_obs_ms'], 'steps_timed': tm['steps_timed']},
+                                           'k_calc_state': tm['avg_obs_ms'], 'steps_timed': tm['steps_timed'],
+                                           'how': 'hipEvent pair around every launch on the launch stream (rp_enable_timers), separate '
+                                                  'region right after the timed one with the env-group streams switched off'},
                          'note': 'latency/VALU-issue-bound path (serial PGS chains), not bandwidth-bound; advisory FLOP model '
                                  '9e6 FLOP/env-step => %.3g of the 157.3 TFLOP/s fp32 vector peak' % (9e6 * n / (step_ms * 1e-3) / 157.3e12)},
             'non_finite_envs': bad, 'success_rate_last_step': success,

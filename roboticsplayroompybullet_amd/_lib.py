@@ -78,6 +78,7 @@ def load():
     lib.rp_version.restype = C.c_char_p
     lib.rp_debug_substep.argtypes = [vp, C.c_int32, C.POINTER(C.c_float)]
     lib.rp_set_fused.argtypes = [vp, C.c_int32]
+    lib.rp_set_groups.argtypes = [vp, C.c_int32]
     _lib = lib
     return lib
 

@@ -1293,9 +1293,9 @@ __global__ void __launch_bounds__(64, RP_WAVES_PER_EU) k_step(const DevModel* __
   store_state(L, state, env, lane);
 }
 
-__global__ void __launch_bounds__(64) k_calc_state(const DevModel* __restrict__ m, float* __restrict__ state, OutPtrs out, int N) {
+__global__ void __launch_bounds__(64) k_calc_state(const DevModel* __restrict__ m, float* __restrict__ state, OutPtrs out, int env0, int N) {
   __shared__ EnvLds L;
-  int env = blockIdx.x, lane = threadIdx.x;
+  int env = env0 + blockIdx.x, lane = threadIdx.x;
   if (env >= N) return;
   load_state(L, state, env, lane);
   calc_state(m, L, lane);
@@ -1481,8 +1481,8 @@ struct __align__(16) SolveLds {
 
 /* thread per env: perform_action (environments.py:915-1073) with the IK in private registers */
 __global__ void __launch_bounds__(64) k_action(const DevModel* __restrict__ m, float* __restrict__ state, const float* __restrict__ action,
-                                              float* __restrict__ target_poses, int N) {
-  int env = blockIdx.x * blockDim.x + threadIdx.x;
+                                              float* __restrict__ target_poses, int env0, int N) {
+  int env = env0 + blockIdx.x * blockDim.x + threadIdx.x;      /* this launch covers envs [env0, N) */
   if (env >= N) return;
   float* st = state + (size_t)env * RP_REC_FLOATS;
   const float high[7] = {6.f, 6.f, 6.f, 6.f, 6.f, 6.f, 1.f};       /* environments.py:108-109, 207 */
@@ -1647,9 +1647,9 @@ __global__ void __launch_bounds__(64, 4) k_solve(const DevModel* __restrict__ m,
 #define W2_BB (W2_JB + 32 * NB)
 #define W2_FLOATS (W2_BB + 32 * NB)
 
-__global__ void __launch_bounds__(64, RP_PREP_WAVES) k_prep2(const DevModel* __restrict__ m, const float* __restrict__ state, float* __restrict__ ws, int N) {
+__global__ void __launch_bounds__(64, RP_PREP_WAVES) k_prep2(const DevModel* __restrict__ m, const float* __restrict__ state, float* __restrict__ ws, int env0, int N) {
   __shared__ EnvLds L;
-  int env = blockIdx.x, lane = threadIdx.x;
+  int env = env0 + blockIdx.x, lane = threadIdx.x;
   if (env >= N) return;
   load_state(L, state, env, lane);
 #ifdef RP_PREP_STOP   /* timing ablations only: leave after phase RP_PREP_STOP */
@@ -1675,6 +1675,9 @@ __global__ void __launch_bounds__(64, RP_PREP_WAVES) k_prep2(const DevModel* __r
   PREP_STOP(4)
   nsmall = uni(nsmall);
   ncon = uni(ncon);
+#ifdef RP_ABL_MAXCON    /* timing ablation: drop contacts beyond RP_ABL_MAXCON to expose the tail effect in k_solve2 */
+  if (ncon > RP_ABL_MAXCON) ncon = RP_ABL_MAXCON;
+#endif
   const int n = m->n_arm;
   float* w = ws + (size_t)env * W2_FLOATS;
   /* stream assignment of the motor/limit/gear rows, in order: lane r decides for small row r */
@@ -1751,6 +1754,9 @@ struct __align__(16) Solve2Lds {
   float lam[2][2][NB + 1];
   float mu[2][2][32];                  /* stream A: zeros */
   float vstar[2][32];
+#ifdef RP_SOLVE_PAD_KB      /* occupancy experiments: pad LDS so that fewer waves are resident than work units */
+  float pad[RP_SOLVE_PAD_KB * 256];
+#endif
 };
 
 /* DPP butterfly inside each 16-lane row: every lane ends with the sum over its row */
@@ -1792,10 +1798,13 @@ __device__ __forceinline__ void row_update(float Jr, float Br, float& dv, float4
   dv += Br * d;
 }
 
-__global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m, float* __restrict__ state, const float* __restrict__ ws, int N) {
+__global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m, float* __restrict__ state, const float* __restrict__ ws, int env0, int N) {
   __shared__ Solve2Lds L;
   const int lane = threadIdx.x, half = lane >> 5, l = lane & 31, grp = l >> 4;
-  const int env = blockIdx.x * 2 + half;
+#ifdef RP_SOLVE_PAD_KB
+  if (N < 0) L.pad[lane] = 0.f;
+#endif
+  const int env = env0 + blockIdx.x * 2 + half;
   const bool valid = env < N;
   const float* w = ws + (size_t)(valid ? env : 0) * W2_FLOATS;
   int my_na = valid ? __float_as_int(w[W2_HDR]) : 0, my_nj = valid ? __float_as_int(w[W2_HDR + 1]) : 0;
@@ -1852,18 +1861,26 @@ __global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m
       asm volatile("" : "+s"(na_it), "+s"(nj_it), "+s"(nc_it));        /* keep the guards as in-loop s_cmp + s_cbranch */
       na_it = __builtin_amdgcn_readfirstlane(na_it); nj_it = __builtin_amdgcn_readfirstlane(nj_it);
       nc_it = __builtin_amdgcn_readfirstlane(nc_it);
+      /* guards per chunk of 4 slots (null slots are exact no-ops): inside a chunk the scalar loads of all four rows
+       * are issued together, ahead of the dependent chain, instead of one exposed LDS round trip per row */
 #pragma unroll
-      for (int t = 0; t < SLOT_F; t++)                    /* A rows | scene-joint motors, contact normals */
-        if (t < na_it || (t < NBJ ? t < nj_it : t - SLOT_N < nc_it)) {
-          float4 s = *(const float4*)&sc[4 * t];
-          row_update<false>(JB[t], BB[t], dv, s, s.z, s.w, &lam[t]);
+      for (int t0 = 0; t0 < SLOT_F; t0 += 4)              /* A rows | scene-joint motors, contact normals */
+        if (t0 < na_it || (t0 < NBJ ? t0 < nj_it : false) || (t0 + 3 >= SLOT_N && t0 - SLOT_N < nc_it)) {
+#pragma unroll
+          for (int t = t0; t < t0 + 4 && t < SLOT_F; t++) {
+            float4 s = *(const float4*)&sc[4 * t];
+            row_update<false>(JB[t], BB[t], dv, s, s.z, s.w, &lam[t]);
+          }
         }
 #pragma unroll
-      for (int j = 0; j < 2 * MAXC; j++)                  /* frictions (stream B only; stream A has mu = 0 and null rows) */
-        if (j < 2 * nc_it) {
-          float4 s = *(const float4*)&sc[4 * (SLOT_F + j)];
-          float lim = mu[j >> 1] * lam[SLOT_N + (j >> 1)];
-          row_update<false>(JB[SLOT_F + j], BB[SLOT_F + j], dv, s, s.z - lim, s.w + lim, &lam[SLOT_F + j]);
+      for (int j0 = 0; j0 < 2 * MAXC; j0 += 4)            /* frictions (stream B only; stream A has mu = 0 and null rows) */
+        if (j0 < 2 * nc_it) {
+#pragma unroll
+          for (int j = j0; j < j0 + 4 && j < 2 * MAXC; j++) {
+            float4 s = *(const float4*)&sc[4 * (SLOT_F + j)];
+            float lim = mu[j >> 1] * lam[SLOT_N + (j >> 1)];
+            row_update<false>(JB[SLOT_F + j], BB[SLOT_F + j], dv, s, s.z - lim, s.w + lim, &lam[SLOT_F + j]);
+          }
         }
     }
   } else {

@@ -9,6 +9,8 @@
 #include "rp_device_model.h"
 #include "rp_kernels.cuh"
 
+#define RP_MAX_GROUPS 16
+
 struct rp_sim {
   rp_config cfg;
   DevModel host_model;
@@ -20,6 +22,9 @@ struct rp_sim {
   hipEvent_t* pool;        /* per-launch timing ring: EV_PER_STEP events per recorded step */
   int pool_steps, pool_next, pool_count;
   int timers_on;
+  int groups;              /* env groups of the default pipeline, each on its own stream (tail overlap) */
+  hipStream_t gstream[RP_MAX_GROUPS];
+  hipEvent_t gfork, gjoin[RP_MAX_GROUPS];
   int fused;               /* 0: split pipeline v2 (default), 1: single fused k_step kernel (reference path), 2: split pipeline v1 */
   rp_timers timers;
   char err[256];
@@ -75,6 +80,14 @@ int rp_create(const rp_config* cfg, rp_handle* out) {
     snprintf(g_err, 256, "rp_create: model upload failed"); free(h); return RP_ERR_HIP;
   }
   hipEventCreate(&h->ev0); hipEventCreate(&h->ev1);
+  {
+    const char* g = getenv("RP_STEP_GROUPS");
+    h->groups = g ? atoi(g) : 4;
+    if (h->groups < 1) h->groups = 1;
+    if (h->groups > RP_MAX_GROUPS) h->groups = RP_MAX_GROUPS;
+    hipEventCreateWithFlags(&h->gfork, hipEventDisableTiming);
+    for (int i = 0; i < RP_MAX_GROUPS; i++) { hipStreamCreateWithFlags(&h->gstream[i], hipStreamNonBlocking); hipEventCreateWithFlags(&h->gjoin[i], hipEventDisableTiming); }
+  }
   int N = cfg->num_envs;
   hipLaunchKernelGGL(k_init, dim3((N + 255) / 256), dim3(256), 0, 0, h->dev_model, h->state, N);
   e = hipDeviceSynchronize();
@@ -87,7 +100,8 @@ int rp_destroy(rp_handle h) {
   if (!h) return RP_ERR_ARG;
   hipSetDevice(h->cfg.device);
   hipFree(h->dev_model); hipFree(h->state); hipFree(h->ws); hipFree(h->dbg);
-  hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
+  hipEventDestroy(h->ev0); hipEventDestroy(h->ev1); hipEventDestroy(h->gfork);
+  for (int i = 0; i < RP_MAX_GROUPS; i++) { hipStreamDestroy(h->gstream[i]); hipEventDestroy(h->gjoin[i]); }
   if (h->pool) { for (int i = 0; i < h->pool_steps * EV_PER_STEP; i++) hipEventDestroy(h->pool[i]); free(h->pool); }
   free(h);
   return RP_OK;
@@ -132,22 +146,35 @@ int rp_step(rp_handle h, const float* action, const rp_out* out, void* stream) {
   } else {
     OutPtrs op = to_ptrs(out);
     hipEvent_t* ev = h->pool ? h->pool + (size_t)h->pool_next * EV_PER_STEP : nullptr;
+    /* Env groups: substeps of different envs are independent, so the envs are cut into `groups` contiguous ranges and
+     * each range runs its own 26-kernel chain on its own stream; the tail of one group's k_solve2 (its heaviest wave)
+     * overlaps with the other groups' kernels.  Per-launch timing (rp_enable_timers) uses one group so that the event
+     * pairs bracket exactly one kernel each. */
+    int G = (ev || h->fused == 2) ? 1 : h->groups;
+    if (G > (N + 63) / 64) G = (N + 63) / 64;
     int e = 2;
-#define TIMED(launch) do { if (ev) hipEventRecord(ev[e++], s); launch; if (ev) hipEventRecord(ev[e++], s); } while (0)
-    if (ev) hipEventRecord(ev[0], s);
-    TIMED(hipLaunchKernelGGL(k_action, dim3((N + 63) / 64), dim3(64), 0, s, h->dev_model, h->state, action, op.target_poses, N));
-    for (int sub = 0; sub < K_NSUB; sub++) {
-      if (h->fused == 2) {       /* split pipeline v1: LDS-resident compact rows, one env per wave */
-        TIMED(hipLaunchKernelGGL(k_prep, dim3(N), dim3(64), 0, s, h->dev_model, h->state, h->ws, N));
-        TIMED(hipLaunchKernelGGL(k_solve, dim3(N), dim3(64), 0, s, h->dev_model, h->state, h->ws, N));
-      } else {                    /* default: register-resident dense rows, two envs per wave */
-        TIMED(hipLaunchKernelGGL(k_prep2, dim3(N), dim3(64), 0, s, h->dev_model, h->state, h->ws, N));
-        TIMED(hipLaunchKernelGGL(k_solve2, dim3((N + 1) / 2), dim3(64), 0, s, h->dev_model, h->state, h->ws, N));
+#define TIMED(launch) do { if (ev) hipEventRecord(ev[e++], gs); launch; if (ev) hipEventRecord(ev[e++], gs); } while (0)
+    if (G > 1) hipEventRecord(h->gfork, s);
+    for (int g = 0; g < G; g++) {
+      hipStream_t gs = G > 1 ? h->gstream[g] : s;
+      int e0 = (int)((long long)N * g / G), e1 = (int)((long long)N * (g + 1) / G), ng = e1 - e0;
+      if (G > 1) hipStreamWaitEvent(gs, h->gfork, 0);
+      if (ev) hipEventRecord(ev[0], gs);
+      TIMED(hipLaunchKernelGGL(k_action, dim3((ng + 63) / 64), dim3(64), 0, gs, h->dev_model, h->state, action, op.target_poses, e0, e1));
+      for (int sub = 0; sub < K_NSUB; sub++) {
+        if (h->fused == 2) {       /* split pipeline v1: LDS-resident compact rows, one env per wave */
+          TIMED(hipLaunchKernelGGL(k_prep, dim3(N), dim3(64), 0, gs, h->dev_model, h->state, h->ws, N));
+          TIMED(hipLaunchKernelGGL(k_solve, dim3(N), dim3(64), 0, gs, h->dev_model, h->state, h->ws, N));
+        } else {                    /* default: register-resident dense rows, two envs per wave */
+          TIMED(hipLaunchKernelGGL(k_prep2, dim3(ng), dim3(64), 0, gs, h->dev_model, h->state, h->ws, e0, e1));
+          TIMED(hipLaunchKernelGGL(k_solve2, dim3((ng + 1) / 2), dim3(64), 0, gs, h->dev_model, h->state, h->ws, e0, e1));
+        }
       }
+      TIMED(hipLaunchKernelGGL(k_calc_state, dim3(ng), dim3(64), 0, gs, h->dev_model, h->state, op, e0, e1));
+      if (ev) hipEventRecord(ev[1], gs);
+      if (G > 1) { hipEventRecord(h->gjoin[g], gs); hipStreamWaitEvent(s, h->gjoin[g], 0); }
     }
-    TIMED(hipLaunchKernelGGL(k_calc_state, dim3(N), dim3(64), 0, s, h->dev_model, h->state, op, N));
     if (ev) {
-      hipEventRecord(ev[1], s);
       h->pool_next = (h->pool_next + 1) % h->pool_steps;
       if (h->pool_count < h->pool_steps) h->pool_count++;
     }
@@ -162,7 +189,7 @@ int rp_step(rp_handle h, const float* action, const rp_out* out, void* stream) {
 int rp_calc_state(rp_handle h, const rp_out* out, void* stream) {
   if (!h) return RP_ERR_ARG;
   int N = h->cfg.num_envs;
-  hipLaunchKernelGGL(k_calc_state, dim3(N), dim3(64), 0, (hipStream_t)stream, h->dev_model, h->state, to_ptrs(out), N);
+  hipLaunchKernelGGL(k_calc_state, dim3(N), dim3(64), 0, (hipStream_t)stream, h->dev_model, h->state, to_ptrs(out), 0, N);
   HIPCHK(h, hipGetLastError());
   return RP_OK;
 }
@@ -193,6 +220,7 @@ int rp_set_state(rp_handle h, const void* src, int32_t src_env_count, void* stre
   return RP_OK;
 }
 
+int rp_set_groups(rp_handle h, int32_t groups) { if (!h || groups < 1 || groups > RP_MAX_GROUPS) return RP_ERR_ARG; h->groups = groups; return RP_OK; }
 int rp_set_fused(rp_handle h, int32_t fused) { if (!h) return RP_ERR_ARG; h->fused = fused; return RP_OK; }
 int rp_get_timers(rp_handle h, rp_timers* t) {
   if (!h || !t) return RP_ERR_ARG;

@@ -133,6 +133,10 @@ class VecPlayEnv:
         reference path), 2 = split v1 (k_prep / k_solve, one env per wave).  All three are bit-identical."""
         self.lib.rp_set_fused(self.h, int(mode))
 
+    def set_groups(self, groups):
+        """number of env groups (each with its own stream and kernel chain) rp_step uses; results do not depend on it"""
+        _lib.check(self.lib, self.h, self.lib.rp_set_groups(self.h, int(groups)), 'rp_set_groups')
+
     def enable_timers(self, steps=64):
         """keep per-launch hipEvent timings for the next `steps` rp_step calls (0 disables)"""
         _lib.check(self.lib, self.h, self.lib.rp_enable_timers(self.h, int(steps)), 'rp_enable_timers')

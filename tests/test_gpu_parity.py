@@ -120,6 +120,7 @@ def test_split_pipeline_equals_fused_kernel_bitwise():
         b.set_fused(1)                          # one fused kernel per env step
         c = VecPlayEnv(IDS[kind], n, seed=5)
         c.set_fused(2)                          # k_prep / k_solve (1 env per wave, rows in LDS)
+        a.set_groups(3)                         # env groups on separate streams must not change any result
         a.reset(); b.reset(); c.reset()
         acts = torch.tensor(actions(kind, 6, n, 8), dtype=torch.float32)
         for t in range(6):
