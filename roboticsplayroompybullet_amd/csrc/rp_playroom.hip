@@ -82,7 +82,7 @@ int rp_create(const rp_config* cfg, rp_handle* out) {
   hipEventCreate(&h->ev0); hipEventCreate(&h->ev1);
   {
     const char* g = getenv("RP_STEP_GROUPS");
-    h->groups = g ? atoi(g) : 4;
+    h->groups = g ? atoi(g) : 3;      /* 3 group streams + nothing else stays within the 4 hardware queues ROCm multiplexes onto */
     if (h->groups < 1) h->groups = 1;
     if (h->groups > RP_MAX_GROUPS) h->groups = RP_MAX_GROUPS;
     hipEventCreateWithFlags(&h->gfork, hipEventDisableTiming);
@@ -156,9 +156,9 @@ int rp_step(rp_handle h, const float* action, const rp_out* out, void* stream) {
 #define TIMED(launch) do { if (ev) hipEventRecord(ev[e++], gs); launch; if (ev) hipEventRecord(ev[e++], gs); } while (0)
     if (G > 1) hipEventRecord(h->gfork, s);
     for (int g = 0; g < G; g++) {
-      hipStream_t gs = G > 1 ? h->gstream[g] : s;
+      hipStream_t gs = g == 0 ? s : h->gstream[g];      /* group 0 stays on the caller's stream: G hardware queues in use */
       int e0 = (int)((long long)N * g / G), e1 = (int)((long long)N * (g + 1) / G), ng = e1 - e0;
-      if (G > 1) hipStreamWaitEvent(gs, h->gfork, 0);
+      if (g > 0) hipStreamWaitEvent(gs, h->gfork, 0);
       if (ev) hipEventRecord(ev[0], gs);
       TIMED(hipLaunchKernelGGL(k_action, dim3((ng + 63) / 64), dim3(64), 0, gs, h->dev_model, h->state, action, op.target_poses, e0, e1));
       for (int sub = 0; sub < K_NSUB; sub++) {
@@ -172,8 +172,9 @@ int rp_step(rp_handle h, const float* action, const rp_out* out, void* stream) {
       }
       TIMED(hipLaunchKernelGGL(k_calc_state, dim3(ng), dim3(64), 0, gs, h->dev_model, h->state, op, e0, e1));
       if (ev) hipEventRecord(ev[1], gs);
-      if (G > 1) { hipEventRecord(h->gjoin[g], gs); hipStreamWaitEvent(s, h->gjoin[g], 0); }
+      if (g > 0) hipEventRecord(h->gjoin[g], gs);
     }
+    for (int g = 1; g < G; g++) hipStreamWaitEvent(s, h->gjoin[g], 0);
     if (ev) {
       h->pool_next = (h->pool_next + 1) % h->pool_steps;
       if (h->pool_count < h->pool_steps) h->pool_count++;
