@@ -1637,15 +1637,16 @@ __global__ void __launch_bounds__(64, 4) k_solve(const DevModel* __restrict__ m,
 #define SLOT_F (NBJ + MAXC)           /* friction row d of contact c  -> B slot SLOT_F + 2 c + d     */
 #define NB (NBJ + 3 * MAXC)
 #define W2_HDR 0                      /* nA, nj1, ncon, coupled */
-#define W2_VSTAR 16
+#define W2_AROW 4                     /* small-row index of A slot t (NA ints) and of scene-joint slot t (NBJ ints) */
+#define W2_VSTAR 32                   /* dof-indexed */
 #define W2_MU (W2_VSTAR + 32)
-#define W2_SCA (W2_MU + 32)
-#define W2_SCB (W2_SCA + 4 * NA)
-#define W2_JA (W2_SCB + 4 * NB)
-#define W2_BA (W2_JA + 16 * NA)
-#define W2_JB (W2_BA + 16 * NA)
-#define W2_BB (W2_JB + 32 * NB)
-#define W2_FLOATS (W2_BB + 32 * NB)
+#define W2_MINV (W2_MU + 32)
+#define W2_SROW (W2_MINV + 144)       /* motor / limit / gear rows as built (8 floats each) */
+#define W2_ROWS (W2_SROW + 8 * MAXSMALL)
+#define W2_ROWT (W2_ROWS + 4 * MAXROWC)
+#define W2_J (W2_ROWT + 4 * MAXROWC)  /* compact contact rows, ROWW floats each */
+#define W2_B (W2_J + ROWW * MAXROWC)
+#define W2_FLOATS (W2_B + ROWW * MAXROWC)
 
 __global__ void __launch_bounds__(64, RP_PREP_WAVES) k_prep2(const DevModel* __restrict__ m, const float* __restrict__ state, float* __restrict__ ws, int env0, int N) {
   __shared__ EnvLds L;
@@ -1695,57 +1696,19 @@ __global__ void __launch_bounds__(64, RP_PREP_WAVES) k_prep2(const DevModel* __r
     w[W2_HDR] = __int_as_float(nA); w[W2_HDR + 1] = __int_as_float(nJ); w[W2_HDR + 2] = __int_as_float(ncon);
     w[W2_HDR + 3] = __int_as_float(coupled ? 1 : 0);
   }
-  int dl = lane_dof(m, lane & 31);
-  if (lane < 32) { w[W2_VSTAR + lane] = dl >= 0 ? L.vstar[dl] : 0.f; w[W2_MU + lane] = lane < ncon ? L.conmu[lane] : 0.f; }
-  /* scalars: lane = row */
-  if (lane < nsmall) {
-    const float* s = &L.srow[8 * lane];
-    float4 a = {s[3], s[4], s[5], s[6]};
+  if (lane < nsmall) {       /* slot tables: which small row sits in A slot / scene-joint slot t */
     int slot = isa ? __popcll(mA & ((1ull << lane) - 1ull)) : __popcll(mJ & ((1ull << lane) - 1ull));
-    if (isa && slot < NA) *(float4*)&w[W2_SCA + 4 * slot] = a;
-    if (isj1 && slot < NBJ) *(float4*)&w[W2_SCB + 4 * slot] = a;
+    if (isa && slot < NA) w[W2_AROW + slot] = __int_as_float(lane);
+    if (isj1 && slot < NBJ) w[W2_AROW + NA + slot] = __int_as_float(lane);
   }
-  for (int r = lane; r < 3 * ncon; r += 64) {
-    const float* s = &L.rowS[4 * r];
-    const float* t = &L.rowT[4 * r];
-    int slot = r < ncon ? SLOT_N + r : SLOT_F + (r - ncon);
-    float4 a = {s[0], s[1], 0.f, t[1]};
-    *(float4*)&w[W2_SCB + 4 * slot] = a;
-  }
-  /* dense J / B at lane positions: one coalesced store per row and array */
-  if (lane < 32) {
-    int ia = 0, ij = 0;
-    for (int r = 0; r < nsmall; r++) {
-      const float* s = &L.srow[8 * r];
-      int type = __float_as_int(s[0]), dA = __float_as_int(s[1]), dB = __float_as_int(s[7]);
-      float sg = s[2], j = 0.f, b = 0.f;
-      if (type == SR_J1) {
-        if (ij < NBJ) {
-          j = dl == dA ? 1.f : 0.f; b = dl == dA ? sg : 0.f;
-          w[W2_JB + 32 * ij + lane] = j; w[W2_BB + 32 * ij + lane] = b;
-        }
-        ij++;
-      } else {
-        if (ia < NA && lane < 16) {
-          if (type == SR_UNIT) { j = lane == dA ? sg : 0.f; if (lane < n) b = sg * L.Minv[lane * 12 + dA]; }
-          else { j = lane == dA ? 1.f : (lane == dB ? sg : 0.f); if (lane < n) b = L.Minv[lane * 12 + dA] + sg * L.Minv[lane * 12 + dB]; }
-          w[W2_JA + 16 * ia + lane] = j; w[W2_BA + 16 * ia + lane] = b;
-        }
-        ia++;
-      }
-    }
-    for (int r = 0; r < 3 * ncon; r++) {
-      const float* t = &L.rowT[4 * r];
-      float j = 0.f, b = 0.f;
-      if (dl >= 0) {
-        int i1 = dl - __float_as_int(t[3]), i0 = dl - __float_as_int(t[2]);
-        int idx = (unsigned)i1 < 6u ? 12 + i1 : ((unsigned)i0 < 12u ? i0 : -1);
-        if (idx >= 0) { j = L.u.r.J[r * ROWW + idx]; b = L.u.r.B[r * ROWW + idx]; }
-      }
-      int slot = r < ncon ? SLOT_N + r : SLOT_F + (r - ncon);
-      w[W2_JB + 32 * slot + lane] = j; w[W2_BB + 32 * slot + lane] = b;
-    }
-  }
+  if (lane < 32) { w[W2_VSTAR + lane] = L.vstar[lane]; w[W2_MU + lane] = lane < ncon ? L.conmu[lane] : 0.f; }
+  /* the rows leave in the compact form they were built in: coalesced 16-byte copies; k_solve2 expands them */
+  copy_out(w + W2_MINV, L.Minv, 144, lane);
+  copy_out(w + W2_SROW, L.srow, 8 * nsmall, lane);
+  copy_out(w + W2_ROWS, L.rowS, 4 * 3 * ncon, lane);
+  copy_out(w + W2_ROWT, L.rowT, 4 * 3 * ncon, lane);
+  copy_out(w + W2_J, L.u.r.J, (ROWW * 3 * ncon + 3) & ~3, lane);
+  copy_out(w + W2_B, L.u.r.B, (ROWW * 3 * ncon + 3) & ~3, lane);
 }
 
 struct __align__(16) Solve2Lds {
@@ -1814,33 +1777,62 @@ __global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m
   int nc_max = max(__builtin_amdgcn_readlane(my_nc, 0), __builtin_amdgcn_readlane(my_nc, 32));
   const bool par = (__builtin_amdgcn_readlane(my_cp, 0) | __builtin_amdgcn_readlane(my_cp, 32)) == 0;
 #define B_USED(t) ((t) < NBJ ? (t) < my_nj : ((t) < SLOT_F ? (t) - SLOT_N < my_nc : (t) - SLOT_F < 2 * my_nc))
+  /* compact contact row of B slot t (normals first, then frictions), as k_prep2 numbers them */
+#define B_ROW(t) ((t) < SLOT_F ? (t) - SLOT_N : my_nc + ((t) - SLOT_F))
+  const int n = m->n_arm;
+  const int dd = lane_dof(m, l);            /* velocity component owned by this lane, -1 if none */
   {
     const float* r = state + (size_t)(valid ? env : 0) * RP_REC_FLOATS;
     for (int k = l; k < RP_REC_FLOATS; k += 32) L.st[half][k] = r[k];
-    L.vstar[half][l] = valid ? w[W2_VSTAR + l] : 0.f;
+    L.vstar[half][l] = (valid && dd >= 0) ? w[W2_VSTAR + dd] : 0.f;
     L.mu[half][0][l] = 0.f;
     L.mu[half][1][l] = valid ? w[W2_MU + l] : 0.f;
     float4 z = {0.f, 0.f, 0.f, 0.f};
     for (int k = l; k < NB + 1; k += 32) {
       L.lam[half][0][k] = 0.f; L.lam[half][1][k] = 0.f;
-      *(float4*)&L.sc[half][0][4 * k] = k < my_na ? *(const float4*)&w[W2_SCA + 4 * k] : z;
-      *(float4*)&L.sc[half][1][4 * k] = (k < NB && B_USED(k)) ? *(const float4*)&w[W2_SCB + 4 * k] : z;
+      float4 a = z, b = z;
+      if (k < my_na) { const float* s = &w[W2_SROW + 8 * __float_as_int(w[W2_AROW + k])]; a = make_float4(s[3], s[4], s[5], s[6]); }
+      if (k < NB && B_USED(k)) {
+        if (k < NBJ) { const float* s = &w[W2_SROW + 8 * __float_as_int(w[W2_AROW + NA + k])]; b = make_float4(s[3], s[4], s[5], s[6]); }
+        else { int r2 = B_ROW(k); b = make_float4(w[W2_ROWS + 4 * r2], w[W2_ROWS + 4 * r2 + 1], 0.f, w[W2_ROWT + 4 * r2 + 1]); }
+      }
+      *(float4*)&L.sc[half][0][4 * k] = a;
+      *(float4*)&L.sc[half][1][4 * k] = b;
     }
   }
+  /* expand the rows into lane-dense registers: lane l holds entry lane_dof(l) of every row */
   float JA[NA], BA[NA], JB[NB], BB[NB];
 #pragma unroll
   for (int t = 0; t < NA; t++) {
-    bool used = t < my_na && l < 16;
-    JA[t] = used ? w[W2_JA + 16 * t + l] : 0.f;
-    BA[t] = used ? w[W2_BA + 16 * t + l] : 0.f;
+    float j = 0.f, b = 0.f;
+    if (t < my_na && l < n) {                 /* arm-only rows: unit rows sg*e_dA, or the gear row e_dA + sg*e_dB */
+      const float* s = &w[W2_SROW + 8 * __float_as_int(w[W2_AROW + t])];
+      int type = __float_as_int(s[0]), dA = __float_as_int(s[1]), dB = __float_as_int(s[7]);
+      float sg = s[2];
+      if (type == SR_UNIT) { j = l == dA ? sg : 0.f; b = sg * w[W2_MINV + l * 12 + dA]; }
+      else { j = l == dA ? 1.f : (l == dB ? sg : 0.f); b = w[W2_MINV + l * 12 + dA] + sg * w[W2_MINV + l * 12 + dB]; }
+    }
+    JA[t] = j; BA[t] = b;
   }
 #pragma unroll
   for (int t = 0; t < NB; t++) {
-    bool used = B_USED(t);
-    JB[t] = used ? w[W2_JB + 32 * t + l] : 0.f;
-    BB[t] = used ? w[W2_BB + 32 * t + l] : 0.f;
+    float j = 0.f, b = 0.f;
+    if (B_USED(t) && dd >= 0) {
+      if (t < NBJ) {                          /* scene-joint motor: e_dA, B = 1/m at the same entry */
+        const float* s = &w[W2_SROW + 8 * __float_as_int(w[W2_AROW + NA + t])];
+        int dA = __float_as_int(s[1]);
+        j = dd == dA ? 1.f : 0.f; b = dd == dA ? s[2] : 0.f;
+      } else {                                /* contact row: two compact slots -> dense */
+        int r2 = B_ROW(t);
+        int i1 = dd - __float_as_int(w[W2_ROWT + 4 * r2 + 3]), i0 = dd - __float_as_int(w[W2_ROWT + 4 * r2 + 2]);
+        int idx = (unsigned)i1 < 6u ? 12 + i1 : ((unsigned)i0 < 12u ? i0 : -1);
+        if (idx >= 0) { j = w[W2_J + ROWW * r2 + idx]; b = w[W2_B + ROWW * r2 + idx]; }
+      }
+    }
+    JB[t] = j; BB[t] = b;
   }
 #undef B_USED
+#undef B_ROW
   __builtin_amdgcn_s_waitcnt(0x0F70);    /* vmcnt(0): all row registers have landed before the sweep loop */
   __syncthreads();
   float dv = 0.f;
@@ -1918,8 +1910,6 @@ __global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m
     }
   }
   /* integrate: lane l holds velocity component lane_dof(l) of this half's env */
-  const int n = m->n_arm;
-  const int dd = lane_dof(m, l);
   float* st = L.st[half];
   float vnew = L.vstar[half][l] + dv;
   __syncthreads();
