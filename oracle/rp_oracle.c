@@ -727,18 +727,25 @@ static void build_rows(rpo_env* e, const real* vstar) {
   }
 }
 
+/* Sequential impulses (btMultiBodyConstraintSolver::resolveSingleConstraintRowGeneric), in the floating-point
+ * evaluation order shared with the HIP library: with Jd = J * dinv folded at row build time,
+ *     sum = (lambda + rhs) - Jd . dv ;  lambda' = clamp(sum, lo, hi) ;  d = lambda' - lambda ;  dv += B d
+ * which is algebraically Bullet's  d = rhs - (J.dv) dinv, clamp(lambda + d)  with a shorter dependent chain. */
 static void solve_rows(rpo_env* e, real* dv) {
   int nv = e->nv;
+  for (int ri = 0; ri < e->nrows; ri++) {
+    row* r = &e->rows[ri];
+    for (int i = 0; i < nv; i++) r->J[i] *= r->dinv;
+  }
   for (int it = 0; it < N_ITER; it++)
     for (int ri = 0; ri < e->nrows; ri++) {
       row* r = &e->rows[ri];
       real lo = r->lo, hi = r->hi;
       if (r->fric_parent >= 0) { real lim = r->mu * e->rows[r->fric_parent].lambda; lo = -lim; hi = lim; }
-      real d = r->rhs - dotn(r->J, dv, nv) * r->dinv;
-      real sum = r->lambda + d;
-      if (sum < lo) { d = lo - r->lambda; sum = lo; }
-      else if (sum > hi) { d = hi - r->lambda; sum = hi; }
-      r->lambda = sum;
+      real sum = (r->lambda + r->rhs) - dotn(r->J, dv, nv);
+      real lnew = sum < lo ? lo : (sum > hi ? hi : sum);
+      real d = lnew - r->lambda;
+      r->lambda = lnew;
       for (int i = 0; i < nv; i++) dv[i] += r->B[i] * d;
     }
 }

@@ -791,23 +791,24 @@ __device__ void contact_rows(const DevModel* m, EnvLds& L, int lane, int ncon) {
     } else rhs = -relv * dinv;
     s[0] = rhs; s[1] = dinv;
     t[0] = 0.f;
+    float* Jw = &L.u.r.J[r * ROWW];          /* fold dinv into the stored row: the sweeps use Jd = J * dinv */
+    for (int k = 0; k < ROWW; k++) Jw[k] *= dinv;
   }
 }
 
 /* 50 sweeps of sequential impulses; lane l owns dv[l]; returns dv of this lane.
- * Everything per-row is wave-uniform: loop bounds and indices are forced into SGPRs, the clamp is branch-free
- * (selects, so the unclamped delta is passed through bit-exactly as in the oracle), accumulated impulses live in
+ * Everything per-row is wave-uniform: loop bounds and indices are forced into SGPRs, the clamp is one v_med3,
+ * accumulated impulses live in
  * registers one row per lane (v_readlane to fetch, lane-select to store), and the LDS data of row r+1 is fetched
  * while row r's dependent chain (multiply -> DPP reduction -> clamp -> axpy) runs.
  * Friction limits are lo = lo_c - mu*lambda[parent], hi = hi_c + mu*lambda[parent]; normal rows carry mu = 0,
  * lo_c = 0, hi_c = 1e10 and a dummy parent, which reproduces [0, 1e10] exactly without a branch. */
-__device__ __forceinline__ float pgs_update(float rhs, float jdv, float dinv, float lam, float lo, float hi, float& lam_out) {
-  float d = rhs - jdv * dinv;
-  float sum = lam + d;
-  bool below = sum < lo, above = sum > hi;
-  d = below ? lo - lam : (above ? hi - lam : d);
-  lam_out = below ? lo : (above ? hi : sum);
-  return d;
+__device__ __forceinline__ float pgs_update(float rhs, float jdvd, float lam, float lo, float hi, float& lam_out) {
+  /* jdvd = (J * dinv) . dv (dinv folded into the stored row);  sum = (lam + rhs) - jdvd;  d = clamp(sum) - lam */
+  float sum = (lam + rhs) - jdvd;
+  float lnew = __builtin_amdgcn_fmed3f(sum, lo, hi);
+  lam_out = lnew;
+  return lnew - lam;
 }
 
 template <class LDS>
@@ -838,10 +839,11 @@ __device__ float solve_rows(const DevModel* m, LDS& L, int lane, int nsmall_, in
           if (t2 == SR_J1) bn = lane == lane_pos(m, a2) ? g2 : 0.f;
           else if (lane < n) bn = t2 == SR_UNIT ? g2 * L.Minv[lane * 12 + a2] : L.Minv[lane * 12 + a2] + g2 * L.Minv[lane * 12 + b2];
         }
-        float sg = c0.z;
-        float jdv = type == SR_UNIT ? sg * lane_read(dv, dA) : (type == SR_J1 ? lane_read(dv, uni(lane_pos(m, dA))) : lane_read(dv, dA) + sg * lane_read(dv, dB));
+        float sg = c0.z, jA = c1.x;      /* c1.x = dinv = the folded J entry at dofA */
+        float jdv = type == SR_UNIT ? (sg * jA) * lane_read(dv, dA)
+                                    : (type == SR_J1 ? jA * lane_read(dv, uni(lane_pos(m, dA))) : jA * lane_read(dv, dA) + (sg * jA) * lane_read(dv, dB));
         float lam = lane_read(lamS, r), lnew;
-        float d = pgs_update(c0.w, jdv, c1.x, lam, c1.y, c1.z, lnew);
+        float d = pgs_update(c0.w, jdv, lam, c1.y, c1.z, lnew);
         lamS = lane == r ? lnew : lamS;
         dv += bl * d;
       }
@@ -859,7 +861,7 @@ __device__ float solve_rows(const DevModel* m, LDS& L, int lane, int nsmall_, in
       }
       for (int r = 0; r < nrc; r++) {
         float jl = jn, bl = bn;
-        float rhs = sn.x, dinv = sn.y, mu = sn.z, lo_c = tn.x, hi_c = tn.y;
+        float rhs = sn.x, mu = sn.z, lo_c = tn.x, hi_c = tn.y;
         int parent = uni(__float_as_int(sn.w));
         sn = s2; tn = t2;
         if (r + 1 < nrc) {
@@ -873,7 +875,7 @@ __device__ float solve_rows(const DevModel* m, LDS& L, int lane, int nsmall_, in
         float lam = lane_read(lamv, r & 63);
         float lim = mu * lane_read(lamC0, parent);            /* parent < ncon <= MAXC */
         float jdv = wave_sum32(jl * dv), lnew;
-        float d = pgs_update(rhs, jdv, dinv, lam, lo_c - lim, hi_c + lim, lnew);
+        float d = pgs_update(rhs, jdv, lam, lo_c - lim, hi_c + lim, lnew);
         float sel = lane == (r & 63) ? lnew : lamv;
         lamC0 = r < 64 ? sel : lamC0;
         lamC1 = r < 64 ? lamC1 : sel;
@@ -1742,23 +1744,21 @@ __device__ __forceinline__ float half_sum32(float v) {
   return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
 }
 
-/* one sequential-impulse row update on register-resident J/B; same arithmetic as pgs_update, clamp by v_med3 */
+/* one sequential-impulse row update on register-resident Jd = J*dinv and B; same arithmetic as pgs_update */
 template <bool FULL>
 __device__ __forceinline__ void row_update(float Jr, float Br, float& dv, float4 sc, float lo, float hi, float* lam_slot) {
   float lam = *lam_slot;
+  float t = lam + sc.x;                                   /* off the dependent chain */
 #if defined(RP_ABL) && RP_ABL == 1      /* timing ablation: no cross-lane reduction */
   float jdv = Jr * dv;
 #else
   float jdv = FULL ? half_sum32(Jr * dv) : row16_sum(Jr * dv);
 #endif
-  float d = sc.x - jdv * sc.y;
-  float sum = lam + d;
-  float lnew = __builtin_amdgcn_fmed3f(sum, lo, hi);      /* lo <= hi always */
-  d = lnew == sum ? d : lnew - lam;                       /* unclamped: pass d through bit-exactly */
+  float lnew = __builtin_amdgcn_fmed3f(t - jdv, lo, hi);  /* lo <= hi always */
 #if !(defined(RP_ABL) && RP_ABL == 2)   /* timing ablation 2: no impulse store */
   *lam_slot = lnew;
 #endif
-  dv += Br * d;
+  dv += Br * (lnew - lam);
 }
 
 __global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m, float* __restrict__ state, const float* __restrict__ ws, int env0, int N) {
@@ -1809,8 +1809,9 @@ __global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m
       const float* s = &w[W2_SROW + 8 * __float_as_int(w[W2_AROW + t])];
       int type = __float_as_int(s[0]), dA = __float_as_int(s[1]), dB = __float_as_int(s[7]);
       float sg = s[2];
-      if (type == SR_UNIT) { j = l == dA ? sg : 0.f; b = sg * w[W2_MINV + l * 12 + dA]; }
-      else { j = l == dA ? 1.f : (l == dB ? sg : 0.f); b = w[W2_MINV + l * 12 + dA] + sg * w[W2_MINV + l * 12 + dB]; }
+      float jA = s[4];                          /* dinv, folded into the row */
+      if (type == SR_UNIT) { j = l == dA ? sg * jA : 0.f; b = sg * w[W2_MINV + l * 12 + dA]; }
+      else { j = l == dA ? jA : (l == dB ? sg * jA : 0.f); b = w[W2_MINV + l * 12 + dA] + sg * w[W2_MINV + l * 12 + dB]; }
     }
     JA[t] = j; BA[t] = b;
   }
@@ -1821,7 +1822,7 @@ __global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m
       if (t < NBJ) {                          /* scene-joint motor: e_dA, B = 1/m at the same entry */
         const float* s = &w[W2_SROW + 8 * __float_as_int(w[W2_AROW + NA + t])];
         int dA = __float_as_int(s[1]);
-        j = dd == dA ? 1.f : 0.f; b = dd == dA ? s[2] : 0.f;
+        j = dd == dA ? s[4] : 0.f; b = dd == dA ? s[2] : 0.f;
       } else {                                /* contact row: two compact slots -> dense */
         int r2 = B_ROW(t);
         int i1 = dd - __float_as_int(w[W2_ROWT + 4 * r2 + 3]), i0 = dd - __float_as_int(w[W2_ROWT + 4 * r2 + 2]);
