@@ -60,6 +60,7 @@
 #define K_IK_MAXSTEP (45.0f * RP_PI_F / 180.0f)
 
 #define ROWW 18              /* compact Jacobian row: slot0 = 12 entries at dof offset off0, slot1 = 6 entries at off1 */
+#define ROWREG ((ROWW * MAXROWC + 3) & ~3)   /* floats reserved for all compact rows: 16-byte copies must not overrun */
 
 /* Per-env LDS block.  Phase-local scratch (collision, dynamics, Jacobian rows) shares one union: the phases of a
  * substep run strictly one after another, separated by barriers. */
@@ -87,7 +88,7 @@ struct __align__(16) EnvLds {
       float vsp[RP_MAX_ARM * 6], csp[RP_MAX_ARM * 6], fsp[RP_MAX_ARM * 6], Fv[RP_MAX_ARM * 6];
       double Md[144];                          /* mass matrix / Cholesky factor in fp64 */
     } d;
-    struct { float J[MAXROWC * ROWW]; float B[MAXROWC * ROWW]; } r;   /* contact rows */
+    struct { float J[ROWREG]; float B[ROWREG]; } r;                   /* contact rows */
   } u;
   float out[128];
 };
@@ -1468,8 +1469,8 @@ __global__ void k_copy_state(float* __restrict__ dst, const float* __restrict__ 
 #define WS_ROWS (WS_SROW + 8 * MAXSMALL)
 #define WS_ROWT (WS_ROWS + 4 * MAXROWC)
 #define WS_J (WS_ROWT + 4 * MAXROWC)
-#define WS_B (WS_J + ROWW * MAXROWC)
-#define WS_FLOATS (WS_B + ROWW * MAXROWC)
+#define WS_B (WS_J + ROWREG)
+#define WS_FLOATS (WS_B + ROWREG)
 
 struct __align__(16) SolveLds {
   float st[RP_REC_FLOATS];
@@ -1478,7 +1479,7 @@ struct __align__(16) SolveLds {
   float srow[MAXSMALL * 8];
   float rowS[MAXROWC * 4];
   float rowT[MAXROWC * 4];
-  struct { struct { float J[MAXROWC * ROWW]; float B[MAXROWC * ROWW]; } r; } u;
+  struct { struct { float J[ROWREG]; float B[ROWREG]; } r; } u;
 };
 
 /* thread per env: perform_action (environments.py:915-1073) with the IK in private registers */
@@ -1647,8 +1648,8 @@ __global__ void __launch_bounds__(64, 4) k_solve(const DevModel* __restrict__ m,
 #define W2_ROWS (W2_SROW + 8 * MAXSMALL)
 #define W2_ROWT (W2_ROWS + 4 * MAXROWC)
 #define W2_J (W2_ROWT + 4 * MAXROWC)  /* compact contact rows, ROWW floats each */
-#define W2_B (W2_J + ROWW * MAXROWC)
-#define W2_FLOATS (W2_B + ROWW * MAXROWC)
+#define W2_B (W2_J + ROWREG)
+#define W2_FLOATS (W2_B + ROWREG)
 
 __global__ void __launch_bounds__(64, RP_PREP_WAVES) k_prep2(const DevModel* __restrict__ m, const float* __restrict__ state, float* __restrict__ ws, int env0, int N) {
   __shared__ EnvLds L;
@@ -1775,7 +1776,11 @@ __global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m
   int na_max = max(__builtin_amdgcn_readlane(my_na, 0), __builtin_amdgcn_readlane(my_na, 32));
   int nj_max = max(__builtin_amdgcn_readlane(my_nj, 0), __builtin_amdgcn_readlane(my_nj, 32));
   int nc_max = max(__builtin_amdgcn_readlane(my_nc, 0), __builtin_amdgcn_readlane(my_nc, 32));
+#if defined(RP_FORCE_PATH)    /* timing ablations: 0 = every wave takes the SEQ path, 1 = every wave takes the PAR path (wrong results) */
+  const bool par = RP_FORCE_PATH == 1;
+#else
   const bool par = (__builtin_amdgcn_readlane(my_cp, 0) | __builtin_amdgcn_readlane(my_cp, 32)) == 0;
+#endif
 #define B_USED(t) ((t) < NBJ ? (t) < my_nj : ((t) < SLOT_F ? (t) - SLOT_N < my_nc : (t) - SLOT_F < 2 * my_nc))
   /* compact contact row of B slot t (normals first, then frictions), as k_prep2 numbers them */
 #define B_ROW(t) ((t) < SLOT_F ? (t) - SLOT_N : my_nc + ((t) - SLOT_F))
