@@ -1717,7 +1717,6 @@ __global__ void __launch_bounds__(64, RP_PREP_WAVES) k_prep2(const DevModel* __r
 struct __align__(16) Solve2Lds {
   float st[2][RP_REC_FLOATS];
   float sc[2][2][(NB + 1) * 4];        /* [half][stream][slot] rhs, dinv, lo_c, hi_c */
-  float lam[2][2][NB + 1];
   float mu[2][2][32];                  /* stream A: zeros */
   float vstar[2][32];
 #ifdef RP_SOLVE_PAD_KB      /* occupancy experiments: pad LDS so that fewer waves are resident than work units */
@@ -1745,26 +1744,45 @@ __device__ __forceinline__ float half_sum32(float v) {
   return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
 }
 
-/* one sequential-impulse row update on register-resident Jd = J*dinv and B; same arithmetic as pgs_update */
-template <bool FULL>
-__device__ __forceinline__ void row_update(float Jr, float Br, float& dv, float4 sc, float lo, float hi, float* lam_slot) {
-  float lam = *lam_slot;
-  float t = lam + sc.x;                                   /* off the dependent chain */
-#if defined(RP_ABL) && RP_ABL == 1      /* timing ablation: no cross-lane reduction */
-  float jdv = Jr * dv;
-#else
+/* value of lane K (0..15) of each 16-lane DPP row, delivered to the whole row: one v_mov_b32_dpp row_newbcast.
+ * The DPP control is an immediate, so slot indices are template constants (static_for below, not #pragma unroll). */
+template <int K>
+__device__ __forceinline__ float bcast16(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + (K & 15), 0xF, 0xF, true));
+}
+template <int T> struct IdxC { static constexpr int v = T; };
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) { f(IdxC<I>{}); static_for<I + 1, N>(f); }
+}
+
+/* one sequential-impulse row update on register-resident Jd = J*dinv and B; same arithmetic as pgs_update.
+ * The accumulated impulse of slot T lives in lane (T & 15) of every DPP row of `lamreg` (one register per 16 slots,
+ * not one per slot): read with a row broadcast, written back with a lane select - both off the dependent chain. */
+template <bool FULL, int T>
+__device__ __forceinline__ void row_update(float Jr, float Br, float& dv, float rhs, float lo, float hi, float& lamreg, int l16) {
+  float lam = bcast16<T>(lamreg);
+  float s = lam + rhs;                                    /* off the dependent chain */
   float jdv = FULL ? half_sum32(Jr * dv) : row16_sum(Jr * dv);
-#endif
-  float lnew = __builtin_amdgcn_fmed3f(t - jdv, lo, hi);  /* lo <= hi always */
-#if !(defined(RP_ABL) && RP_ABL == 2)   /* timing ablation 2: no impulse store */
-  *lam_slot = lnew;
-#endif
+  float lnew = __builtin_amdgcn_fmed3f(s - jdv, lo, hi);  /* lo <= hi always */
+  lamreg = l16 == (T & 15) ? lnew : lamreg;
   dv += Br * (lnew - lam);
 }
 
+#ifdef RP_CLOCKS      /* profiling build only: per-wave phase timestamps of the last k_solve2 launch */
+__device__ unsigned long long g_clk[8 * 4096];
+#define CLK_MARK(i) if (lane == 0) { g_clk[8 * blockIdx.x + (i)] = __builtin_readcyclecounter(); }
+#else
+#define CLK_MARK(i)
+#endif
+
 __global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m, float* __restrict__ state, const float* __restrict__ ws, int env0, int N) {
   __shared__ Solve2Lds L;
-  const int lane = threadIdx.x, half = lane >> 5, l = lane & 31, grp = l >> 4;
+  const int lane = threadIdx.x, half = lane >> 5, l = lane & 31, grp = l >> 4, l16 = lane & 15;
+#ifdef RP_CLOCKS
+  if (lane == 0) g_clk[8 * blockIdx.x + 4] = wall_clock64();
+#endif
+  CLK_MARK(0)
 #ifdef RP_SOLVE_PAD_KB
   if (N < 0) L.pad[lane] = 0.f;
 #endif
@@ -1794,7 +1812,6 @@ __global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m
     L.mu[half][1][l] = valid ? w[W2_MU + l] : 0.f;
     float4 z = {0.f, 0.f, 0.f, 0.f};
     for (int k = l; k < NB + 1; k += 32) {
-      L.lam[half][0][k] = 0.f; L.lam[half][1][k] = 0.f;
       float4 a = z, b = z;
       if (k < my_na) { const float* s = &w[W2_SROW + 8 * __float_as_int(w[W2_AROW + k])]; a = make_float4(s[3], s[4], s[5], s[6]); }
       if (k < NB && B_USED(k)) {
@@ -1841,84 +1858,104 @@ __global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m
 #undef B_ROW
   __builtin_amdgcn_s_waitcnt(0x0F70);    /* vmcnt(0): all row registers have landed before the sweep loop */
   __syncthreads();
+  CLK_MARK(1)
   float dv = 0.f;
+  /* row scalars, lane-distributed like the impulses: lane k of a DPP row holds the value of slot 16 r + k in register r
+   * (read back with one row broadcast); the sweep loops below touch neither LDS nor memory.
+   * X arrays: PAR path = this DPP row's own stream (A in row 0, B in row 1); SEQ path = stream B in both rows. */
+  float rhsX[(NB + 15) / 16], loX[(SLOT_F + 15) / 16], hiX[(SLOT_F + 15) / 16], muX[(SLOT_F + 15) / 16];
+  {
+    const float* scx = L.sc[half][par ? grp : 1];
+    const float* mux = L.mu[half][par ? grp : 1];
+#pragma unroll
+    for (int r = 0; r < (NB + 15) / 16; r++) { int k = 16 * r + l16; rhsX[r] = k < NB ? scx[4 * k] : 0.f; }
+#pragma unroll
+    for (int r = 0; r < (SLOT_F + 15) / 16; r++) {
+      int k = 16 * r + l16;
+      loX[r] = k < SLOT_F ? scx[4 * k + 2] : 0.f; hiX[r] = k < SLOT_F ? scx[4 * k + 3] : 0.f;
+      muX[r] = (k >= SLOT_N && k < SLOT_F) ? mux[k - SLOT_N] : 0.f;     /* friction coefficient, aligned with the normal's slot */
+    }
+  }
+  float lamX[(NB + 15) / 16];       /* accumulated impulses of the X rows */
+#pragma unroll
+  for (int r = 0; r < (NB + 15) / 16; r++) lamX[r] = 0.f;
+  constexpr int NCH = SLOT_F / 4, NFCH = (2 * MAXC + 3) / 4;
+  static_assert(SLOT_F % 4 == 0, "chunking");
   if (par) {
     /* both envs uncoupled: stream A in DPP row 0 and stream B in DPP row 1 of each half, one slot of each per step */
 #pragma unroll
     for (int t = 0; t < NA; t++) { JB[t] += JA[t]; BB[t] += BA[t]; }     /* disjoint lanes: exact merge */
-    const float* sc = L.sc[half][grp];
-    const float* mu = L.mu[half][grp];
-    /* accumulated impulses stay in registers here (the stream-A registers are dead after the merge): the sweep loop
-     * has no LDS stores, so the read-only scalar loads can be scheduled freely ahead of the dependent chain */
-    float lam[NB];
-#pragma unroll
-    for (int t = 0; t < NB; t++) lam[t] = 0.f;
 #pragma unroll 1
     for (int it = 0; it < K_NITER; it++) {
       int na_it = na_max, nj_it = nj_max, nc_it = nc_max;
       asm volatile("" : "+s"(na_it), "+s"(nj_it), "+s"(nc_it));        /* keep the guards as in-loop s_cmp + s_cbranch */
       na_it = __builtin_amdgcn_readfirstlane(na_it); nj_it = __builtin_amdgcn_readfirstlane(nj_it);
       nc_it = __builtin_amdgcn_readfirstlane(nc_it);
-      /* guards per chunk of 4 slots (null slots are exact no-ops): inside a chunk the scalar loads of all four rows
-       * are issued together, ahead of the dependent chain, instead of one exposed LDS round trip per row */
+      /* guards per chunk of 4 slots (null slots are exact no-ops): A rows | scene-joint motors, contact normals */
+      static_for<0, NCH>([&](auto ch) {
+        constexpr int t0 = 4 * decltype(ch)::v;
+        if (t0 < na_it || (t0 < NBJ ? t0 < nj_it : false) || (t0 + 3 >= SLOT_N && t0 - SLOT_N < nc_it))
+          static_for<t0, t0 + 4>([&](auto tc) {
+            constexpr int t = decltype(tc)::v;
+            row_update<false, t>(JB[t], BB[t], dv, bcast16<t>(rhsX[t >> 4]), bcast16<t>(loX[t >> 4]), bcast16<t>(hiX[t >> 4]), lamX[t >> 4], l16);
+          });
+      });
+      float limX[(SLOT_F + 15) / 16];                      /* friction limits mu * (normal impulse), still lane-distributed */
 #pragma unroll
-      for (int t0 = 0; t0 < SLOT_F; t0 += 4)              /* A rows | scene-joint motors, contact normals */
-        if (t0 < na_it || (t0 < NBJ ? t0 < nj_it : false) || (t0 + 3 >= SLOT_N && t0 - SLOT_N < nc_it)) {
-#pragma unroll
-          for (int t = t0; t < t0 + 4 && t < SLOT_F; t++) {
-            float4 s = *(const float4*)&sc[4 * t];
-            row_update<false>(JB[t], BB[t], dv, s, s.z, s.w, &lam[t]);
-          }
-        }
-#pragma unroll
-      for (int j0 = 0; j0 < 2 * MAXC; j0 += 4)            /* frictions (stream B only; stream A has mu = 0 and null rows) */
-        if (j0 < 2 * nc_it) {
-#pragma unroll
-          for (int j = j0; j < j0 + 4 && j < 2 * MAXC; j++) {
-            float4 s = *(const float4*)&sc[4 * (SLOT_F + j)];
-            float lim = mu[j >> 1] * lam[SLOT_N + (j >> 1)];
-            row_update<false>(JB[SLOT_F + j], BB[SLOT_F + j], dv, s, s.z - lim, s.w + lim, &lam[SLOT_F + j]);
-          }
-        }
+      for (int r = 0; r < (SLOT_F + 15) / 16; r++) limX[r] = muX[r] * lamX[r];
+      static_for<0, NFCH>([&](auto ch) {                   /* frictions (stream B only; stream A has mu = 0 and null rows) */
+        constexpr int j0 = 4 * decltype(ch)::v;
+        if (j0 < 2 * nc_it)
+          static_for<j0, (j0 + 4 < 2 * MAXC ? j0 + 4 : 2 * MAXC)>([&](auto jc) {
+            constexpr int j = decltype(jc)::v, tn = SLOT_N + (j >> 1), t = SLOT_F + j;
+            float lim = bcast16<tn>(limX[tn >> 4]);
+            row_update<false, t>(JB[t], BB[t], dv, bcast16<t>(rhsX[t >> 4]), 0.f - lim, 0.f + lim, lamX[t >> 4], l16);
+          });
+      });
     }
   } else {
-    /* a contact involves the arm: all A rows, then all B rows, 32-lane dot products */
-    const float* scA = L.sc[half][0];
-    const float* scB = L.sc[half][1];
-    float* lamA = L.lam[half][0];
-    float* lamB = L.lam[half][1];
-    const float* mu = L.mu[half][1];
+    /* a contact involves the arm: all A rows, then all B rows, 32-lane dot products; both DPP rows hold the same copies */
+    float rhsA[(NA + 15) / 16], loA[(NA + 15) / 16], hiA[(NA + 15) / 16], lamA[(NA + 15) / 16];
+#pragma unroll
+    for (int r = 0; r < (NA + 15) / 16; r++) {
+      int k = 16 * r + l16;
+      const float* sca = L.sc[half][0];
+      rhsA[r] = k < NA ? sca[4 * k] : 0.f; loA[r] = k < NA ? sca[4 * k + 2] : 0.f; hiA[r] = k < NA ? sca[4 * k + 3] : 0.f;
+      lamA[r] = 0.f;
+    }
 #pragma unroll 1
     for (int it = 0; it < K_NITER; it++) {
       int na_it = na_max, nj_it = nj_max, nc_it = nc_max;
       asm volatile("" : "+s"(na_it), "+s"(nj_it), "+s"(nc_it));
       na_it = __builtin_amdgcn_readfirstlane(na_it); nj_it = __builtin_amdgcn_readfirstlane(nj_it);
       nc_it = __builtin_amdgcn_readfirstlane(nc_it);
+      static_for<0, NA>([&](auto tc) {
+        constexpr int t = decltype(tc)::v;
+        if (t < na_it)
+          row_update<true, t>(JA[t], BA[t], dv, bcast16<t>(rhsA[t >> 4]), bcast16<t>(loA[t >> 4]), bcast16<t>(hiA[t >> 4]), lamA[t >> 4], l16);
+      });
+      static_for<0, SLOT_F>([&](auto tc) {
+        constexpr int t = decltype(tc)::v;
+        if (t < NBJ ? t < nj_it : t - SLOT_N < nc_it)
+          row_update<true, t>(JB[t], BB[t], dv, bcast16<t>(rhsX[t >> 4]), bcast16<t>(loX[t >> 4]), bcast16<t>(hiX[t >> 4]), lamX[t >> 4], l16);
+      });
+      float limX[(SLOT_F + 15) / 16];
 #pragma unroll
-      for (int t = 0; t < NA; t++)
-        if (t < na_it) {
-          float4 s = *(const float4*)&scA[4 * t];
-          row_update<true>(JA[t], BA[t], dv, s, s.z, s.w, &lamA[t]);
-        }
-#pragma unroll
-      for (int t = 0; t < SLOT_F; t++)
-        if (t < NBJ ? t < nj_it : t - SLOT_N < nc_it) {
-          float4 s = *(const float4*)&scB[4 * t];
-          row_update<true>(JB[t], BB[t], dv, s, s.z, s.w, &lamB[t]);
-        }
-#pragma unroll
-      for (int j = 0; j < 2 * MAXC; j++)
+      for (int r = 0; r < (SLOT_F + 15) / 16; r++) limX[r] = muX[r] * lamX[r];
+      static_for<0, 2 * MAXC>([&](auto jc) {
+        constexpr int j = decltype(jc)::v, tn = SLOT_N + (j >> 1), t = SLOT_F + j;
         if (j < 2 * nc_it) {
-          float4 s = *(const float4*)&scB[4 * (SLOT_F + j)];
-          float lim = mu[j >> 1] * lamB[SLOT_N + (j >> 1)];
-          row_update<true>(JB[SLOT_F + j], BB[SLOT_F + j], dv, s, s.z - lim, s.w + lim, &lamB[SLOT_F + j]);
+          float lim = bcast16<tn>(limX[tn >> 4]);
+          row_update<true, t>(JB[t], BB[t], dv, bcast16<t>(rhsX[t >> 4]), 0.f - lim, 0.f + lim, lamX[t >> 4], l16);
         }
+      });
     }
   }
   /* integrate: lane l holds velocity component lane_dof(l) of this half's env */
   float* st = L.st[half];
   float vnew = L.vstar[half][l] + dv;
   __syncthreads();
+  CLK_MARK(2)
   if (dd >= 0) {
     if (dd < n) {
       st[ST_QD + dd] = vnew;
@@ -1953,6 +1990,16 @@ __global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m
     float* r = state + (size_t)env * RP_REC_FLOATS;
     for (int k = l; k < RP_REC_FLOATS; k += 32) r[k] = st[k];
   }
+#ifdef RP_CLOCKS
+  CLK_MARK(3)
+  if (lane == 0) {
+    g_clk[8 * blockIdx.x + 5] = wall_clock64();
+    g_clk[8 * blockIdx.x + 6] = (unsigned long long)na_max | ((unsigned long long)nj_max << 8) | ((unsigned long long)nc_max << 16) | ((unsigned long long)(par ? 1 : 0) << 24);
+    unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    g_clk[8 * blockIdx.x + 7] = ((unsigned long long)xcc << 32) | hw;
+  }
+#endif
 }
 
 /* debug: one substep for every env, dumping intermediates of env `dbg_env` (tests only) */
