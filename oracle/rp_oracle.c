@@ -742,10 +742,12 @@ static void solve_rows(rpo_env* e, real* dv) {
       row* r = &e->rows[ri];
       real lo = r->lo, hi = r->hi;
       if (r->fric_parent >= 0) { real lim = r->mu * e->rows[r->fric_parent].lambda; lo = -lim; hi = lim; }
-      real sum = (r->lambda + r->rhs) - dotn(r->J, dv, nv);
-      real lnew = sum < lo ? lo : (sum > hi ? hi : sum);
-      real d = lnew - r->lambda;
-      r->lambda = lnew;
+      /* btSolveSingleRowSequentialImpulse in delta form: the unclamped step is rhs - (J dinv).dv and the clamp acts on
+       * the step (lower - applied <= step <= upper - applied), exactly as Bullet sets deltaImpulse = limit - applied */
+      real delta = r->rhs - dotn(r->J, dv, nv);
+      real lo2 = lo - r->lambda, hi2 = hi - r->lambda;
+      real d = delta < lo2 ? lo2 : (delta > hi2 ? hi2 : delta);
+      r->lambda += d;
       for (int i = 0; i < nv; i++) dv[i] += r->B[i] * d;
     }
 }

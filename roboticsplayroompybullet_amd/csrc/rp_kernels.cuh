@@ -91,19 +91,29 @@ struct __align__(16) EnvLds {
     struct { float J[ROWREG]; float B[ROWREG]; } r;                   /* contact rows */
   } u;
   float out[128];
+  float aout[192];                /* k_prep2: unit rows in the solver's dof-indexed form */
+  unsigned amask[4];
+  int roff[64];                   /* k_prep2: slot offsets of the compact contact rows */
 };
 
 /* ------------------------------------------------------------------ small helpers */
 __device__ __forceinline__ int dof_free(const DevModel* m, int k) { return m->n_arm + 6 * k; }
 __device__ __forceinline__ int dof_j1(const DevModel* m, int k) { return m->n_arm + 6 * m->n_free + k; }
-/* lane layout of the velocity vector inside a 32-lane group: arm dofs at lanes 0..11 (DPP row 0), every other dof
- * at lanes 16.. (DPP row 1), so that arm-only and non-arm rows reduce in different DPP rows */
-__device__ __forceinline__ int lane_pos(const DevModel* m, int d) { return d < m->n_arm ? d : 16 + (d - m->n_arm); }
+/* lane layout of the velocity vector inside a 32-lane group: arm dof i at lane i (DPP row 0); in DPP row 1 scene
+ * joint k at lane 16 + k (k < 3) and component c of free body f at lane 19 + 6 f + c, so that arm-only and non-arm
+ * rows reduce in different DPP rows and every unit row (motor, limit) sits at a compile-time lane of its DPP row */
+#define LANE_J1 16
+#define LANE_FREE 19
+__device__ __forceinline__ int lane_pos(const DevModel* m, int d) {
+  if (d < m->n_arm) return d;
+  int f6 = 6 * m->n_free;
+  return d - m->n_arm < f6 ? LANE_FREE + (d - m->n_arm) : LANE_J1 + (d - m->n_arm - f6);
+}
 __device__ __forceinline__ int lane_dof(const DevModel* m, int l) {       /* inverse of lane_pos; -1 = no dof at this lane */
   if (l < 16) return l < m->n_arm ? l : -1;
   if (l >= 32) return -1;
-  int d = m->n_arm + (l - 16);
-  return d < m->nv ? d : -1;
+  if (l < LANE_FREE) return l - LANE_J1 < m->n_j1 ? m->n_arm + 6 * m->n_free + (l - LANE_J1) : -1;
+  return l - LANE_FREE < 6 * m->n_free ? m->n_arm + (l - LANE_FREE) : -1;
 }
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
 __device__ __forceinline__ float safe_inv(float d) { return d > 1e-9f ? 1.0f / d : 0.0f; }
@@ -791,7 +801,7 @@ __device__ void contact_rows(const DevModel* m, EnvLds& L, int lane, int ncon) {
       rhs = (pos_err + vel_err) * dinv;
     } else rhs = -relv * dinv;
     s[0] = rhs; s[1] = dinv;
-    t[0] = 0.f;
+    t[0] = __int_as_float((__float_as_int(t[0]) != 0 && __float_as_int(t[3]) != 64) ? 1 : 0);   /* row spans arm and non-arm dofs */
     float* Jw = &L.u.r.J[r * ROWW];          /* fold dinv into the stored row: the sweeps use Jd = J * dinv */
     for (int k = 0; k < ROWW; k++) Jw[k] *= dinv;
   }
@@ -805,11 +815,11 @@ __device__ void contact_rows(const DevModel* m, EnvLds& L, int lane, int ncon) {
  * Friction limits are lo = lo_c - mu*lambda[parent], hi = hi_c + mu*lambda[parent]; normal rows carry mu = 0,
  * lo_c = 0, hi_c = 1e10 and a dummy parent, which reproduces [0, 1e10] exactly without a branch. */
 __device__ __forceinline__ float pgs_update(float rhs, float jdvd, float lam, float lo, float hi, float& lam_out) {
-  /* jdvd = (J * dinv) . dv (dinv folded into the stored row);  sum = (lam + rhs) - jdvd;  d = clamp(sum) - lam */
-  float sum = (lam + rhs) - jdvd;
-  float lnew = __builtin_amdgcn_fmed3f(sum, lo, hi);
-  lam_out = lnew;
-  return lnew - lam;
+  /* jdvd = (J * dinv) . dv (dinv folded into the stored row).  Delta form, as Bullet's row solver: the unclamped step
+   * rhs - jdvd is clamped to [lo - lam, hi - lam], then lam += d */
+  float d = __builtin_amdgcn_fmed3f(rhs - jdvd, lo - lam, hi - lam);
+  lam_out = lam + d;
+  return d;
 }
 
 template <class LDS>
@@ -1457,31 +1467,9 @@ __global__ void k_copy_state(float* __restrict__ dst, const float* __restrict__ 
  * The fused substep() above needs > 256 VGPRs in its cold phases (IK, narrowphase, row build) although the hot PGS
  * loop needs ~60, so rp_step runs right-sized kernels instead:
  *   k_action  (thread per env)  clip + absolute-RPY IK + motor targets            -> state records
- *   12 x { k_prep (wave per env: FK, collision, dynamics, constraint rows -> per-env workspace, L2/HBM resident)
- *          k_solve (wave per env, lean: PGS sweeps + integration, state record in/out) }
- *   k_obs     (wave per env)    calc_state + reward + outputs
- * Workspace record per env (floats): header 16 | Minv 144 | vstar 32 | srow 8*MAXSMALL | rowS 4*MAXROWC |
- * rowT 4*MAXROWC | J ROWW*MAXROWC | B ROWW*MAXROWC. */
-#define WS_HDR 0
-#define WS_MINV 16
-#define WS_VSTAR (WS_MINV + 144)
-#define WS_SROW (WS_VSTAR + 32)
-#define WS_ROWS (WS_SROW + 8 * MAXSMALL)
-#define WS_ROWT (WS_ROWS + 4 * MAXROWC)
-#define WS_J (WS_ROWT + 4 * MAXROWC)
-#define WS_B (WS_J + ROWREG)
-#define WS_FLOATS (WS_B + ROWREG)
-
-struct __align__(16) SolveLds {
-  float st[RP_REC_FLOATS];
-  float Minv[144];
-  float vstar[32];
-  float srow[MAXSMALL * 8];
-  float rowS[MAXROWC * 4];
-  float rowT[MAXROWC * 4];
-  struct { struct { float J[ROWREG]; float B[ROWREG]; } r; } u;
-};
-
+ *   12 x { k_prep2 (wave per env: FK, collision, dynamics, constraint rows -> per-env workspace, L2/MALL resident)
+ *          k_solve2 (two envs per wave: PGS sweeps on register-resident rows + integration, state record in/out) }
+ *   k_calc_state (wave per env) calc_state + reward + outputs */
 /* thread per env: perform_action (environments.py:915-1073) with the IK in private registers */
 __global__ void __launch_bounds__(64) k_action(const DevModel* __restrict__ m, float* __restrict__ state, const float* __restrict__ action,
                                               float* __restrict__ target_poses, int env0, int N) {
@@ -1533,123 +1521,59 @@ __device__ __forceinline__ void copy_out(float* __restrict__ dst, const float* s
   for (int i = lane * 4; i < nfloat; i += 256) *(float4*)(dst + i) = *(const float4*)(src + i);
 }
 
-/* wave per env: everything of a substep up to the constraint rows; the state record is only read */
-__global__ void __launch_bounds__(64) k_prep(const DevModel* __restrict__ m, const float* __restrict__ state, float* __restrict__ ws, int N) {
-  __shared__ EnvLds L;
-  int env = blockIdx.x, lane = threadIdx.x;
-  if (env >= N) return;
-  load_state(L, state, env, lane);
-  fk_bodies(m, L, lane);
-  __syncthreads();
-  joint_subspaces(m, L, lane);
-  collider_aabbs(m, L, lane);
-  __syncthreads();
-  int ncon = collide(m, L, lane);
-  arm_dynamics(m, L, lane);
-  unconstrained_velocities(m, L, lane);
-  int nsmall = build_small_rows(m, L, lane);
-  contact_rows(m, L, lane, ncon);
-  __syncthreads();
-  float* w = ws + (size_t)env * WS_FLOATS;
-  if (lane == 0) { w[WS_HDR] = __int_as_float(nsmall); w[WS_HDR + 1] = __int_as_float(ncon); }
-  copy_out(w + WS_MINV, L.Minv, 144, lane);
-  copy_out(w + WS_VSTAR, L.vstar, 32, lane);
-  copy_out(w + WS_SROW, L.srow, 8 * nsmall, lane);
-  copy_out(w + WS_ROWS, L.rowS, 4 * 3 * ncon, lane);
-  copy_out(w + WS_ROWT, L.rowT, 4 * 3 * ncon, lane);
-  copy_out(w + WS_J, L.u.r.J, (ROWW * 3 * ncon + 3) & ~3, lane);
-  copy_out(w + WS_B, L.u.r.B, (ROWW * 3 * ncon + 3) & ~3, lane);
-}
-
-/* wave per env, lean: 50 PGS sweeps + semi-implicit Euler integration */
-__global__ void __launch_bounds__(64, 4) k_solve(const DevModel* __restrict__ m, float* __restrict__ state, const float* __restrict__ ws, int N) {
-  __shared__ SolveLds L;
-  int env = blockIdx.x, lane = threadIdx.x;
-  if (env >= N) return;
-  const float* w = ws + (size_t)env * WS_FLOATS;
-  int nsmall = uni(__float_as_int(w[WS_HDR])), ncon = uni(__float_as_int(w[WS_HDR + 1]));
-  {
-    const float* r = state + (size_t)env * RP_REC_FLOATS;
-    L.st[lane] = r[lane]; L.st[lane + 64] = r[lane + 64];
-  }
-  copy_out(L.Minv, w + WS_MINV, 144, lane);
-  copy_out(L.vstar, w + WS_VSTAR, 32, lane);
-  copy_out(L.srow, w + WS_SROW, 8 * nsmall, lane);
-  copy_out(L.rowS, w + WS_ROWS, 4 * 3 * ncon, lane);
-  copy_out(L.rowT, w + WS_ROWT, 4 * 3 * ncon, lane);
-  copy_out(L.u.r.J, w + WS_J, (ROWW * 3 * ncon + 3) & ~3, lane);
-  copy_out(L.u.r.B, w + WS_B, (ROWW * 3 * ncon + 3) & ~3, lane);
-  __syncthreads();
-  float dv = solve_rows(m, L, lane, nsmall, ncon);
-  int n = m->n_arm;
-  const int dd = lane_dof(m, lane);
-  float vnew = (dd >= 0 ? L.vstar[dd] : 0.f) + dv;
-  __syncthreads();
-  if (dd >= 0 && dd < n) {
-    L.st[ST_QD + dd] = vnew;
-    L.st[ST_Q + dd] += K_DT * vnew;
-  } else if (dd >= 0 && dd < n + 6 * m->n_free) {
-    int k = (dd - n) / 6, c = (dd - n) % 6;
-    L.st[ST_FREE + 13 * k + 7 + c] = vnew;
-  } else if (dd >= 0) {
-    int k = dd - n - 6 * m->n_free;
-    L.st[ST_JQD + k] = vnew;
-    L.st[ST_JQ + k] += K_DT * vnew;
-  }
-  __syncthreads();
-  if (lane < m->n_free) {
-    float* f = &L.st[ST_FREE + 13 * lane];
-    V3 v = ld3(f + 7), wv = ld3(f + 10);
-    st3(f, ld3(f) + v * K_DT);
-    float wn = norm(wv);
-    if (wn > 0.7853981633974483f / K_DT) wn = 0.7853981633974483f / K_DT;
-    V3 ax;
-    if (wn < 0.001f) ax = wv * (0.5f * K_DT - K_DT * K_DT * K_DT * 0.020833333333f * wn * wn);
-    else ax = wv * (sinf(0.5f * wn * K_DT) / wn);
-    Q4 dq = {ax.x, ax.y, ax.z, cosf(0.5f * wn * K_DT)};
-    Q4 q0 = {f[3], f[4], f[5], f[6]};
-    Q4 qn = qmul(dq, q0);
-    float nr = 1.f / sqrtf(qn.x * qn.x + qn.y * qn.y + qn.z * qn.z + qn.w * qn.w);
-    f[3] = qn.x * nr; f[4] = qn.y * nr; f[5] = qn.z * nr; f[6] = qn.w * nr;
-  }
-  __syncthreads();
-  float* r = state + (size_t)env * RP_REC_FLOATS;
-  r[lane] = L.st[lane]; r[lane + 64] = L.st[lane + 64];
-}
-
-/* ------------------------------------------------------------------ split pipeline v2: register-resident rows, 2 envs/wave,
+/* ------------------------------------------------------------------ split pipeline: register-resident rows, 2 envs/wave,
  * two concurrent row streams per env.
  *
- * k_prep2 writes every constraint row of the substep in one generic lane-dense form (J, B = M^-1 J^T, and the four
- * scalars rhs, dinv, lo_c, hi_c; motor/limit/gear rows are ordinary rows with mu = 0).  Velocity component d sits at
- * lane position pos(d) of its env's 32-lane half: arm dofs at lanes 0..11 (DPP row 0), every other dof at lanes
- * 16.. (DPP row 1).  Rows are split into two streams:
- *   A  rows that touch only arm dofs (arm motors, joint limits, gear)                    slots [0, NA)
- *   B  everything else: scene-joint motors [0, 3), contact normals [3, 3 + MAXC), frictions [24, 24 + 2 MAXC)
+ * Velocity component d sits at lane position lane_pos(d) of its env's 32-lane half: arm dof i at lane i (DPP row 0),
+ * scene joints and free bodies in DPP row 1.  The rows of a substep fall into two streams:
+ *   A  rows on arm dofs only: motor i, lower/upper limit of dof i (unit rows J = +-e_i, B = +-M^-1[:, i]; the sign is
+ *      folded into rhs and the bounds, which is exact), and the Panda finger gear (two entries)
+ *   B  scene-joint motors (unit rows on their own dof), contact normals, contact frictions
  * A rows and B rows without an arm part act on disjoint velocity components, so they COMMUTE exactly: the canonical
  * sweep order (motors, scene-joint motors, limits, gear, normals, frictions) equals "all A rows, then all B rows"
  * and, when no contact involves the arm in this substep (flag `coupled` = 0), also equals running stream A in DPP row
- * 0 and stream B in DPP row 1 AT THE SAME TIME: one instruction stream updates A row t and B row t together, the
- * 4-step DPP butterfly yields both 16-lane dot products, no cross-row fold is needed, and a sweep takes
- * max(nA, nB) instead of nA + nB dependent row updates.  Waves whose two envs are both uncoupled take that path
- * (PAR); the others run the streams one after the other with the 32-lane fold (SEQ).  Results are bit-identical.
- * k_solve2 keeps J and B of all slots in registers, so the 50 sweeps touch LDS only for row scalars and impulses. */
-#define NA 24
-#define NBJ 3                         /* B slots [0, NBJ): scene-joint motor rows */
-#define SLOT_N NBJ                    /* normal row of contact c      -> B slot SLOT_N + c           */
-#define SLOT_F (NBJ + MAXC)           /* friction row d of contact c  -> B slot SLOT_F + 2 c + d     */
-#define NB (NBJ + 3 * MAXC)
-#define W2_HDR 0                      /* nA, nj1, ncon, coupled */
-#define W2_AROW 4                     /* small-row index of A slot t (NA ints) and of scene-joint slot t (NBJ ints) */
-#define W2_VSTAR 32                   /* dof-indexed */
-#define W2_MU (W2_VSTAR + 32)
-#define W2_MINV (W2_MU + 32)
-#define W2_SROW (W2_MINV + 144)       /* motor / limit / gear rows as built (8 floats each) */
-#define W2_ROWS (W2_SROW + 8 * MAXSMALL)
-#define W2_ROWT (W2_ROWS + 4 * MAXROWC)
-#define W2_J (W2_ROWT + 4 * MAXROWC)  /* compact contact rows, ROWW floats each */
-#define W2_B (W2_J + ROWREG)
-#define W2_FLOATS (W2_B + ROWREG)
+ * 0 and stream B in DPP row 1 AT THE SAME TIME.  Waves whose two envs are both uncoupled take that path (PAR); the
+ * others run the streams one after the other (SEQ) and fold the two DPP rows only for rows that span arm and
+ * non-arm dofs.  Results are bit-identical to the sequential order.
+ *
+ * Instruction budget (measured, tools/ubench): a dependent VALU op costs ~4.7 cycles, a DPP op that reads the
+ * previous result 12, and with two waves per SIMD every 8-byte instruction costs ~7 issue cycles - so the sweep
+ * loops hold nothing but the dependent chain and three broadcasts per row:
+ *   - J, B of every contact row live in registers (lane = dof), expanded once in the prologue;
+ *   - per-row scalars live LANE-DISTRIBUTED in "planes" (lane k of a plane register = the value of the row labelled
+ *     k in that plane): rhs, lo, hi, accumulated impulse lam.  Once per sweep and plane, vector ops form the bounds
+ *     of the step lo - lam, hi - lam (delta form of the row update, see pgs_update) and fold the sweep's steps into
+ *     lam; a row reads its three scalars with one row broadcast each (v_mov_b32_dpp row_newbcast);
+ *   - a unit row needs no dot product at all: lane i forms the step from its own dv and its own plane entries, one
+ *     broadcast spreads it, dv += M^-1[:, i] * step.
+ * Planes and labels (label & 15 = lane, label >> 4 = register):
+ *   M / L / U  motor, lower limit, upper limit of arm dof i at lane i        (DPP row 0; U lane 12 = gear row)
+ *   B0, B1     label t: scene joint t (t < 3), normal of contact t - 3 (3 <= t < 24)
+ *   F0x, F1x   friction direction 0 / 1 of contact c at the lane of its normal, so that mu * lam_normal is one
+ *              vector multiply per sweep.
+ * In the PAR path plane M shares registers with B0 (DPP row 0 = M, row 1 = B0) and step t handles motor t and label
+ * t together. */
+#define NBJ 3                         /* scene-joint motor rows: labels [0, NBJ) of plane B0 */
+#define LBL_N NBJ                     /* normal row of contact c -> label LBL_N + c */
+#define NLBL (LBL_N + MAXC)           /* 24 */
+#define GEAR_LANE 12
+#define W3_HDR 0                      /* ints: maskL, maskU, nj, ncon, coupled, foldmask, gear, nA */
+#define W3_VSTAR 8                    /* 32, dof-indexed */
+#define W3_MU 40                      /* 32, contact-indexed */
+#define W3_MINV 72                    /* 144 */
+#define W3_A 216                      /* 10 arrays of 16, dof-indexed: dinv | M rhs lo hi | L rhs lo hi | U rhs lo hi */
+#define W3_GEAR (W3_A + 160)          /* dofA, dofB, ratio, dinv, rhs, lo, hi, - */
+#define W3_ZERO (W3_GEAR + 7)         /* always 0.0f: the address unconditional loads fall back to */
+#define W3_BJ (W3_GEAR + 8)           /* 5 arrays of 4, scene joint k: J*dinv, rhs, lo, hi, 1/m */
+#define W3_ROWS (W3_BJ + 20)          /* contact rows as built: rhs, dinv, mu, parent */
+#define W3_ROWT (W3_ROWS + 4 * MAXROWC)   /* fold flag, hi_c, off0, off1 */
+#define W3_ROFF (W3_ROWT + 4 * MAXROWC)   /* 64 ints: off0 | off1 << 8 of compact row r; entry 63 = 0.0f */
+#define W3_J (W3_ROFF + 64)           /* compact contact rows, ROWW floats each */
+#define W3_B (W3_J + ROWREG)
+#define W3_FLOATS (W3_B + ROWREG)
+#define STAGE_FLOATS (64 + 2 * ROWREG)    /* ROFF | J | B: contiguous, staged through LDS by k_solve2 */
+#define AOUT_FLOATS (160 + 8 + 20)
+static_assert(W3_A % 4 == 0 && W3_ROWS % 4 == 0 && W3_ROFF % 4 == 0 && AOUT_FLOATS % 4 == 0, "16-byte copies");
 
 __global__ void __launch_bounds__(64, RP_PREP_WAVES) k_prep2(const DevModel* __restrict__ m, const float* __restrict__ state, float* __restrict__ ws, int env0, int N) {
   __shared__ EnvLds L;
@@ -1657,7 +1581,7 @@ __global__ void __launch_bounds__(64, RP_PREP_WAVES) k_prep2(const DevModel* __r
   if (env >= N) return;
   load_state(L, state, env, lane);
 #ifdef RP_PREP_STOP   /* timing ablations only: leave after phase RP_PREP_STOP */
-#define PREP_STOP(k) if (RP_PREP_STOP == (k)) { if (lane == 0) ws[(size_t)env * W2_FLOATS] = L.st[0]; return; }
+#define PREP_STOP(k) if (RP_PREP_STOP == (k)) { if (lane == 0) ws[(size_t)env * W3_FLOATS] = L.st[0]; return; }
 #else
 #define PREP_STOP(k)
 #endif
@@ -1675,7 +1599,10 @@ __global__ void __launch_bounds__(64, RP_PREP_WAVES) k_prep2(const DevModel* __r
   PREP_STOP(3)
   int nsmall = build_small_rows(m, L, lane);
   contact_rows(m, L, lane, ncon);
+  for (int i = lane; i < AOUT_FLOATS; i += 64) L.aout[i] = 0.f;
+  if (lane < 2) L.amask[lane] = 0u;
   __syncthreads();
+  L.roff[lane] = lane < 3 * ncon ? (__float_as_int(L.rowT[4 * lane + 2]) | (__float_as_int(L.rowT[4 * lane + 3]) << 8)) : 0;
   PREP_STOP(4)
   nsmall = uni(nsmall);
   ncon = uni(ncon);
@@ -1683,42 +1610,61 @@ __global__ void __launch_bounds__(64, RP_PREP_WAVES) k_prep2(const DevModel* __r
   if (ncon > RP_ABL_MAXCON) ncon = RP_ABL_MAXCON;
 #endif
   const int n = m->n_arm;
-  float* w = ws + (size_t)env * W2_FLOATS;
-  /* stream assignment of the motor/limit/gear rows, in order: lane r decides for small row r */
-  bool isj1 = false, isa = false;
-  if (lane < nsmall) { isj1 = __float_as_int(L.srow[8 * lane]) == SR_J1; isa = !isj1; }
-  unsigned long long mA = __ballot(isa), mJ = __ballot(isj1);
-  int nA = __popcll(mA), nJ = __popcll(mJ);
-  nA = nA < NA ? nA : NA; nJ = nJ < NBJ ? nJ : NBJ;
+  float* w = ws + (size_t)env * W3_FLOATS;
+  /* motor / limit / gear / scene-joint rows in the solver's dof-indexed form (signs folded: exact) */
+  bool gear = false;
+  if (lane < nsmall) {
+    const float* s = &L.srow[8 * lane];
+    int type = __float_as_int(s[0]), dA = __float_as_int(s[1]);
+    float sg = s[2], rhs = s[3], dinv = s[4], lo = s[5], hi = s[6];
+    if (type == SR_UNIT) {
+      if (lane < n) { L.aout[dA] = dinv; L.aout[16 + dA] = rhs; L.aout[32 + dA] = lo; L.aout[48 + dA] = hi; }
+      else {
+        int pl = sg > 0.f ? 64 : 112;
+        L.aout[pl + dA] = sg * rhs; L.aout[pl + 16 + dA] = sg * lo; L.aout[pl + 32 + dA] = sg * hi;
+        atomicOr(&L.amask[sg > 0.f ? 0 : 1], 1u << dA);
+      }
+    } else if (type == SR_J1) {
+      int k = lane - n;
+      if (k < NBJ) { float* b = &L.aout[168]; b[k] = dinv; b[4 + k] = rhs; b[8 + k] = lo; b[12 + k] = hi; b[16 + k] = sg; }
+    } else {
+      float* g = &L.aout[160];
+      g[0] = s[1]; g[1] = s[7]; g[2] = sg; g[3] = dinv; g[4] = rhs; g[5] = lo; g[6] = hi;
+      gear = true;
+    }
+  }
   bool coupled = false;
   for (int c = 0; c < ncon; c++) {
     int ba = m->col_body[L.cona[c]], bb = m->col_body[L.conb[c]];
     if ((ba >= 1 && ba <= n) || (bb >= 1 && bb <= n)) coupled = true;
   }
+  unsigned long long foldm = __ballot(lane < ncon && __float_as_int(L.rowT[4 * lane]) != 0);
+  bool anygear = __ballot(gear) != 0ull;
+  __syncthreads();
   if (lane == 0) {
-    w[W2_HDR] = __int_as_float(nA); w[W2_HDR + 1] = __int_as_float(nJ); w[W2_HDR + 2] = __int_as_float(ncon);
-    w[W2_HDR + 3] = __int_as_float(coupled ? 1 : 0);
+    int nj = m->n_j1 < NBJ ? m->n_j1 : NBJ;
+    w[W3_HDR] = __int_as_float((int)L.amask[0]); w[W3_HDR + 1] = __int_as_float((int)L.amask[1]);
+    w[W3_HDR + 2] = __int_as_float(nj); w[W3_HDR + 3] = __int_as_float(ncon);
+    w[W3_HDR + 4] = __int_as_float(coupled ? 1 : 0); w[W3_HDR + 5] = __int_as_float((int)(unsigned)foldm);
+    w[W3_HDR + 6] = __int_as_float(anygear ? 1 : 0);
+    w[W3_HDR + 7] = __int_as_float(n + __popc(L.amask[0]) + __popc(L.amask[1]) + (anygear ? 1 : 0));
   }
-  if (lane < nsmall) {       /* slot tables: which small row sits in A slot / scene-joint slot t */
-    int slot = isa ? __popcll(mA & ((1ull << lane) - 1ull)) : __popcll(mJ & ((1ull << lane) - 1ull));
-    if (isa && slot < NA) w[W2_AROW + slot] = __int_as_float(lane);
-    if (isj1 && slot < NBJ) w[W2_AROW + NA + slot] = __int_as_float(lane);
-  }
-  if (lane < 32) { w[W2_VSTAR + lane] = L.vstar[lane]; w[W2_MU + lane] = lane < ncon ? L.conmu[lane] : 0.f; }
-  /* the rows leave in the compact form they were built in: coalesced 16-byte copies; k_solve2 expands them */
-  copy_out(w + W2_MINV, L.Minv, 144, lane);
-  copy_out(w + W2_SROW, L.srow, 8 * nsmall, lane);
-  copy_out(w + W2_ROWS, L.rowS, 4 * 3 * ncon, lane);
-  copy_out(w + W2_ROWT, L.rowT, 4 * 3 * ncon, lane);
-  copy_out(w + W2_J, L.u.r.J, (ROWW * 3 * ncon + 3) & ~3, lane);
-  copy_out(w + W2_B, L.u.r.B, (ROWW * 3 * ncon + 3) & ~3, lane);
+  if (lane < 32) { w[W3_VSTAR + lane] = L.vstar[lane]; w[W3_MU + lane] = lane < ncon ? L.conmu[lane] : 0.f; }
+  /* the contact rows leave in the compact form they were built in: coalesced 16-byte copies; k_solve2 expands them */
+  copy_out(w + W3_MINV, L.Minv, 144, lane);
+  copy_out(w + W3_A, L.aout, AOUT_FLOATS, lane);
+  copy_out(w + W3_ROWS, L.rowS, 4 * 3 * ncon, lane);
+  copy_out(w + W3_ROWT, L.rowT, 4 * 3 * ncon, lane);
+  copy_out(w + W3_ROFF, (const float*)L.roff, 64, lane);
+  copy_out(w + W3_J, L.u.r.J, (ROWW * 3 * ncon + 3) & ~3, lane);
+  copy_out(w + W3_B, L.u.r.B, (ROWW * 3 * ncon + 3) & ~3, lane);
 }
 
 struct __align__(16) Solve2Lds {
-  float st[2][RP_REC_FLOATS];
-  float sc[2][2][(NB + 1) * 4];        /* [half][stream][slot] rhs, dinv, lo_c, hi_c */
-  float mu[2][2][32];                  /* stream A: zeros */
-  float vstar[2][32];
+  union {
+    float st[2][RP_REC_FLOATS];            /* state records (after the prologue) */
+    float stage[2][STAGE_FLOATS];          /* prologue: ROFF | J | B of both envs, copied in with 16-byte loads */
+  };
 #ifdef RP_SOLVE_PAD_KB      /* occupancy experiments: pad LDS so that fewer waves are resident than work units */
   float pad[RP_SOLVE_PAD_KB * 256];
 #endif
@@ -1736,16 +1682,14 @@ __device__ __forceinline__ float row16_sum(float v) {
   v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, true));
   return v;
 }
-/* total over the 32 lanes of each half, delivered to every lane of that half */
-__device__ __forceinline__ float half_sum32(float v) {
-  v = row16_sum(v);
+/* sum of the two DPP rows of each half, delivered to every lane of that half */
+__device__ __forceinline__ float fold_rows(float v) {
   unsigned u = __float_as_uint(v);
   auto sw = __builtin_amdgcn_permlane16_swap(u, u, false, false);     /* [r0 r0 r2 r2], [r1 r1 r3 r3] */
   return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
 }
-
 /* value of lane K (0..15) of each 16-lane DPP row, delivered to the whole row: one v_mov_b32_dpp row_newbcast.
- * The DPP control is an immediate, so slot indices are template constants (static_for below, not #pragma unroll). */
+ * The DPP control is an immediate, so labels are template constants (static_for below, not #pragma unroll). */
 template <int K>
 __device__ __forceinline__ float bcast16(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + (K & 15), 0xF, 0xF, true));
@@ -1756,17 +1700,91 @@ __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (I < N) { f(IdxC<I>{}); static_for<I + 1, N>(f); }
 }
 
-/* one sequential-impulse row update on register-resident Jd = J*dinv and B; same arithmetic as pgs_update.
- * The accumulated impulse of slot T lives in lane (T & 15) of every DPP row of `lamreg` (one register per 16 slots,
- * not one per slot): read with a row broadcast, written back with a lane select - both off the dependent chain. */
-template <bool FULL, int T>
-__device__ __forceinline__ void row_update(float Jr, float Br, float& dv, float rhs, float lo, float hi, float& lamreg, int l16) {
-  float lam = bcast16<T>(lamreg);
-  float s = lam + rhs;                                    /* off the dependent chain */
-  float jdv = FULL ? half_sum32(Jr * dv) : row16_sum(Jr * dv);
-  float lnew = __builtin_amdgcn_fmed3f(s - jdv, lo, hi);  /* lo <= hi always */
-  lamreg = l16 == (T & 15) ? lnew : lamreg;
-  dv += Br * (lnew - lam);
+/* one plane register set: lane k holds the scalars of the row labelled k */
+struct Plane { float rhs, lo, hi, lam, dacc, loP, hiP; };
+/* the row bodies below are inline asm (the compiler inserts no hazard nops inside): a DPP read needs two wait states
+ * after the VALU write of its source, so the bounds written here are fenced once per sweep instead */
+#define PLANE_FENCE4(a, b, c, d) asm volatile("s_nop 1" : "+v"((a).loP), "+v"((a).hiP), "+v"((b).loP), "+v"((b).hiP), "+v"((c).loP), "+v"((c).hiP), "+v"((d).loP), "+v"((d).hiP))
+__device__ __forceinline__ void plane_begin(Plane& p) { p.loP = p.lo - p.lam; p.hiP = p.hi - p.lam; p.dacc = 0.f; }
+__device__ __forceinline__ void plane_end(Plane& p) { p.lam += p.dacc; }
+/* friction plane: bounds -+ mu * (normal impulse) from the normals' plane of the same lanes */
+__device__ __forceinline__ void fplane_begin(Plane& p, float lim) { p.loP = (0.f - lim) - p.lam; p.hiP = (0.f + lim) - p.lam; p.dacc = 0.f; }
+
+#define DPP_ALL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+
+/* unit row of the dof at lane I of its DPP row: the step forms in that lane from its own plane entries (delta form:
+ * d = clamp(rhs - Jd dv, lo - lam, hi - lam)), one broadcast spreads it, col = B column of the row.
+ * 7 instructions; dependent chain mul, sub, med3, (2 wait states), broadcast-multiply, add */
+template <int I>
+__device__ __forceinline__ void unit_row(float jd, float col, float& dv, Plane& p, int l16) {
+  float t;
+  asm volatile(
+      "v_mul_f32 %[t], %[jd], %[dv]\n"
+      "v_sub_f32 %[t], %[rhs], %[t]\n"
+      "v_med3_f32 %[t], %[t], %[lo], %[hi]\n"
+      "v_cmp_eq_u32_e32 vcc, %[k], %[l16]\n"            /* the two wait states between med3 and the DPP read */
+      "v_cndmask_b32_e32 %[dacc], %[dacc], %[t], vcc\n"
+      "v_mul_f32_dpp %[t], %[t], %[col] row_newbcast:%[k]" DPP_ALL
+      "v_add_f32 %[dv], %[dv], %[t]\n"
+      : [dv] "+v"(dv), [dacc] "+v"(p.dacc), [t] "=&v"(t)
+      : [jd] "v"(jd), [col] "v"(col), [rhs] "v"(p.rhs), [lo] "v"(p.loP), [hi] "v"(p.hiP), [l16] "v"(l16), [k] "n"(I & 15)
+      : "vcc");
+}
+/* general row labelled K in plane p: 16-lane dot product (DPP butterfly); the three scalars arrive by row broadcast
+ * in the butterfly's hazard slots.  16 instructions.  FOLD rows (SEQ path) add the other DPP row's sum, which is what
+ * a row that spans arm and non-arm dofs needs and an exact no-op (+0) for the others: 4 more instructions, cheaper
+ * than a scalar branch around them (a not-taken s_cbranch costs ~13 cycles in this chain, a taken one ~27) */
+template <int K, bool FOLDABLE, int C>
+__device__ __forceinline__ void generic_row(float Jr, float Br, float& dv, Plane& p, int fm, int l16) {
+  float t, r, lo, hi, u;
+  if (!FOLDABLE)
+    asm volatile(
+        "v_mul_f32 %[t], %[J], %[dv]\n"
+        "v_mov_b32_dpp %[r], %[rhs] row_newbcast:%[k]" DPP_ALL
+        "v_mov_b32_dpp %[lo], %[lop] row_newbcast:%[k]" DPP_ALL
+        "v_add_f32_dpp %[t], %[t], %[t] quad_perm:[1,0,3,2]" DPP_ALL
+        "v_mov_b32_dpp %[hi], %[hip] row_newbcast:%[k]" DPP_ALL
+        "s_nop 0\n"
+        "v_add_f32_dpp %[t], %[t], %[t] quad_perm:[2,3,0,1]" DPP_ALL
+        "v_cmp_eq_u32_e32 vcc, %[k], %[l16]\n"
+        "s_nop 0\n"
+        "v_add_f32_dpp %[t], %[t], %[t] row_half_mirror" DPP_ALL
+        "s_nop 1\n"
+        "v_add_f32_dpp %[t], %[t], %[t] row_mirror" DPP_ALL
+        "v_sub_f32 %[t], %[r], %[t]\n"
+        "v_med3_f32 %[t], %[t], %[lo], %[hi]\n"
+        "v_cndmask_b32_e32 %[dacc], %[dacc], %[t], vcc\n"
+        "v_mul_f32 %[r], %[B], %[t]\n"
+        "v_add_f32 %[dv], %[dv], %[r]\n"
+        : [dv] "+v"(dv), [dacc] "+v"(p.dacc), [t] "=&v"(t), [r] "=&v"(r), [lo] "=&v"(lo), [hi] "=&v"(hi)
+        : [J] "v"(Jr), [B] "v"(Br), [rhs] "v"(p.rhs), [lop] "v"(p.loP), [hip] "v"(p.hiP), [l16] "v"(l16), [k] "n"(K & 15)
+        : "vcc");
+  else
+    asm volatile(
+        "v_mul_f32 %[t], %[J], %[dv]\n"
+        "v_mov_b32_dpp %[r], %[rhs] row_newbcast:%[k]" DPP_ALL
+        "v_mov_b32_dpp %[lo], %[lop] row_newbcast:%[k]" DPP_ALL
+        "v_add_f32_dpp %[t], %[t], %[t] quad_perm:[1,0,3,2]" DPP_ALL
+        "v_mov_b32_dpp %[hi], %[hip] row_newbcast:%[k]" DPP_ALL
+        "s_nop 0\n"
+        "v_add_f32_dpp %[t], %[t], %[t] quad_perm:[2,3,0,1]" DPP_ALL
+        "v_cmp_eq_u32_e32 vcc, %[k], %[l16]\n"
+        "s_nop 0\n"
+        "v_add_f32_dpp %[t], %[t], %[t] row_half_mirror" DPP_ALL
+        "s_nop 1\n"
+        "v_add_f32_dpp %[t], %[t], %[t] row_mirror" DPP_ALL
+        "v_mov_b32 %[u], %[t]\n"
+        "s_nop 1\n"
+        "v_permlane16_swap_b32 %[t], %[u]\n"
+        "v_add_f32 %[t], %[t], %[u]\n"
+        "v_sub_f32 %[t], %[r], %[t]\n"
+        "v_med3_f32 %[t], %[t], %[lo], %[hi]\n"
+        "v_cndmask_b32_e32 %[dacc], %[dacc], %[t], vcc\n"
+        "v_mul_f32 %[r], %[B], %[t]\n"
+        "v_add_f32 %[dv], %[dv], %[r]\n"
+        : [dv] "+v"(dv), [dacc] "+v"(p.dacc), [t] "=&v"(t), [r] "=&v"(r), [lo] "=&v"(lo), [hi] "=&v"(hi), [u] "=&v"(u)
+        : [J] "v"(Jr), [B] "v"(Br), [rhs] "v"(p.rhs), [lop] "v"(p.loP), [hip] "v"(p.hiP), [l16] "v"(l16), [k] "n"(K & 15)
+        : "vcc");
 }
 
 #ifdef RP_CLOCKS      /* profiling build only: per-wave phase timestamps of the last k_solve2 launch */
@@ -1788,172 +1806,240 @@ __global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m
 #endif
   const int env = env0 + blockIdx.x * 2 + half;
   const bool valid = env < N;
-  const float* w = ws + (size_t)(valid ? env : 0) * W2_FLOATS;
-  int my_na = valid ? __float_as_int(w[W2_HDR]) : 0, my_nj = valid ? __float_as_int(w[W2_HDR + 1]) : 0;
-  int my_nc = valid ? __float_as_int(w[W2_HDR + 2]) : 0, my_cp = valid ? __float_as_int(w[W2_HDR + 3]) : 0;
-  int na_max = max(__builtin_amdgcn_readlane(my_na, 0), __builtin_amdgcn_readlane(my_na, 32));
-  int nj_max = max(__builtin_amdgcn_readlane(my_nj, 0), __builtin_amdgcn_readlane(my_nj, 32));
-  int nc_max = max(__builtin_amdgcn_readlane(my_nc, 0), __builtin_amdgcn_readlane(my_nc, 32));
+  const float* w = ws + (size_t)(valid ? env : 0) * W3_FLOATS;
+  const int n = m->n_arm;
+  /* header: per half, then wave-uniform unions for the guards */
+  const float4 h0 = *(const float4*)&w[W3_HDR], h1 = *(const float4*)&w[W3_HDR + 4];
+  const int my_mL = valid ? __float_as_int(h0.x) : 0, my_mU = valid ? __float_as_int(h0.y) : 0;
+  const int my_nj = valid ? __float_as_int(h0.z) : 0, my_nc = valid ? __float_as_int(h0.w) : 0;
+  const int my_cp = valid ? __float_as_int(h1.x) : 0, my_fm = valid ? __float_as_int(h1.y) : 0;
+  const int my_gr = valid ? __float_as_int(h1.z) : 0;
+#define WAVE_OR(x) (__builtin_amdgcn_readlane(x, 0) | __builtin_amdgcn_readlane(x, 32))
+  const int maskL = WAVE_OR(my_mL), maskU = WAVE_OR(my_mU), foldm = WAVE_OR(my_fm), gear = WAVE_OR(my_gr);
+  const int nj_max = max(__builtin_amdgcn_readlane(my_nj, 0), __builtin_amdgcn_readlane(my_nj, 32));
+  const int nc_max = max(__builtin_amdgcn_readlane(my_nc, 0), __builtin_amdgcn_readlane(my_nc, 32));
 #if defined(RP_FORCE_PATH)    /* timing ablations: 0 = every wave takes the SEQ path, 1 = every wave takes the PAR path (wrong results) */
   const bool par = RP_FORCE_PATH == 1;
 #else
-  const bool par = (__builtin_amdgcn_readlane(my_cp, 0) | __builtin_amdgcn_readlane(my_cp, 32)) == 0;
+  const bool par = WAVE_OR(my_cp) == 0;
 #endif
-#define B_USED(t) ((t) < NBJ ? (t) < my_nj : ((t) < SLOT_F ? (t) - SLOT_N < my_nc : (t) - SLOT_F < 2 * my_nc))
-  /* compact contact row of B slot t (normals first, then frictions), as k_prep2 numbers them */
-#define B_ROW(t) ((t) < SLOT_F ? (t) - SLOT_N : my_nc + ((t) - SLOT_F))
-  const int n = m->n_arm;
   const int dd = lane_dof(m, l);            /* velocity component owned by this lane, -1 if none */
+  /* contact rows first: 16-byte coalesced copies of the compact rows into LDS (a per-lane gather straight from memory
+   * costs one 16-cycle vector-memory instruction per row and array: 250 of them per wave were 60% of the prologue) */
+  {
+    float* S = L.stage[half];
+    const float* src = w + W3_ROFF;
+    const int nf = valid ? (ROWW * 3 * my_nc + 3) & ~3 : 0;
+    if (l < 16) *(float4*)&S[4 * l] = *(const float4*)&src[4 * l];
+    for (int i = 4 * l; i < nf; i += 128) {
+      *(float4*)&S[64 + i] = *(const float4*)&src[64 + i];
+      *(float4*)&S[64 + ROWREG + i] = *(const float4*)&src[64 + ROWREG + i];
+    }
+  }
+  /* all prologue loads are unconditional from clamped addresses (then selected), so that they are all in flight at once */
+  const float* wzero = w + W3_ZERO;
+  auto ldz = [&](const float* q, bool c) { return *(c ? q : wzero); };
+  const float vstar = ldz(&w[W3_VSTAR + (dd >= 0 ? dd : 0)], valid && dd >= 0);
+  const bool row0 = grp == 0, arm_lane = valid && row0 && l16 < n;
+  /* stream A: dof-indexed planes in DPP row 0 (zeros in row 1, where a unit row then is an exact no-op) */
+  const float* wa = w + W3_A;
+  const int ia = arm_lane ? l16 : 0;
+  const float dinvA = ldz(&wa[ia], arm_lane);
+  Plane PM, PL, PU;
+  PM.rhs = ldz(&wa[16 + ia], arm_lane); PM.lo = ldz(&wa[32 + ia], arm_lane); PM.hi = ldz(&wa[48 + ia], arm_lane);
+  PL.rhs = ldz(&wa[64 + ia], arm_lane); PL.lo = ldz(&wa[80 + ia], arm_lane); PL.hi = ldz(&wa[96 + ia], arm_lane);
+  PU.rhs = ldz(&wa[112 + ia], arm_lane); PU.lo = ldz(&wa[128 + ia], arm_lane); PU.hi = ldz(&wa[144 + ia], arm_lane);
+  float Jg = 0.f, Bg = 0.f;                 /* Panda finger gear: J = e_a + ratio e_b, scalars at lane GEAR_LANE of plane U */
+  {
+    const float* g = w + W3_GEAR;
+    float g0 = g[0], g1 = g[1], ratio = g[2], gd = g[3], g4 = g[4], g5 = g[5], g6 = g[6];
+    int a = __float_as_int(g0) & 15, b = __float_as_int(g1) & 15;
+    float ma = w[W3_MINV + ia * 12 + (a < 12 ? a : 0)], mb = w[W3_MINV + ia * 12 + (b < 12 ? b : 0)];
+    bool on = arm_lane && my_gr != 0;
+    Jg = on ? (l16 == a ? gd : (l16 == b ? ratio * gd : 0.f)) : 0.f;
+    Bg = on ? ma + ratio * mb : 0.f;
+    bool gl = valid && row0 && l16 == GEAR_LANE && my_gr != 0;
+    PU.rhs = gl ? g4 : PU.rhs; PU.lo = gl ? g5 : PU.lo; PU.hi = gl ? g6 : PU.hi;
+  }
+  float Mcol[12];                           /* B column of every arm unit row: M^-1[:, i] on the arm lanes */
+#pragma unroll
+  for (int t = 0; t < 12; t++) Mcol[t] = ldz(&w[W3_MINV + ia * 12 + t], arm_lane && t < n);
+  /* stream B planes: both DPP rows hold the same copy.  label = 16 r + lane */
+  Plane PB[2], PF[2][2];                    /* PF[direction][register] */
+  float muB[2];
+  float jdJ, colJ;                          /* scene joints: J*dinv and 1/m at their own lanes (DPP row 1) */
+  {
+    const float* bj = w + W3_BJ;
+    bool jl = valid && l16 < my_nj;
+    int kj = jl ? l16 : 0;
+    jdJ = ldz(&bj[kj], jl && !row0); colJ = ldz(&bj[16 + kj], jl && !row0);
+    float jr = bj[4 + kj], jlo = bj[8 + kj], jhi = bj[12 + kj];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      int c = 16 * r + l16 - LBL_N;
+      bool on = valid && c >= 0 && c < my_nc;
+      int cc = on ? c : 0;
+      PB[r].rhs = ldz(&w[W3_ROWS + 4 * cc], on); PB[r].lo = 0.f; PB[r].hi = ldz(&w[W3_ROWT + 4 * cc + 1], on);
+      muB[r] = ldz(&w[W3_MU + cc], on);
+#pragma unroll
+      for (int d = 0; d < 2; d++) { PF[d][r].rhs = ldz(&w[W3_ROWS + 4 * ((on ? my_nc : 0) + 2 * cc + d)], on); PF[d][r].lo = 0.f; PF[d][r].hi = 0.f; }
+    }
+    PB[0].rhs = jl ? jr : PB[0].rhs; PB[0].lo = jl ? jlo : PB[0].lo; PB[0].hi = jl ? jhi : PB[0].hi;
+  }
+  /* contact rows: compact (two body slots) -> lane-dense registers; unconditional loads from clamped addresses so
+   * that all of them are in flight together */
+  float JN[MAXC], BN[MAXC], JF[2][MAXC], BF[2][MAXC];
+  {
+    __syncthreads();
+    const float* S = L.stage[half];
+    auto expand = [&](int rr, bool used, float& j, float& b) {
+      int r2 = used ? rr : 63;                           /* entry 63: offsets 0, value 0.0f */
+      int off = __float_as_int(S[r2]);
+      int i1 = dd - (off >> 8), i0 = dd - (off & 255);
+      int idx = (unsigned)i1 < 6u ? 12 + i1 : ((unsigned)i0 < 12u ? i0 : -1);
+      bool ok = used && dd >= 0 && idx >= 0;
+      j = S[ok ? 64 + ROWW * r2 + idx : 63];             /* no select after the read: absent entries read a stored 0 */
+      b = S[ok ? 64 + ROWREG + ROWW * r2 + idx : 63];
+    };
+#pragma unroll
+    for (int c = 0; c < MAXC; c++) {
+      bool used = valid && c < my_nc;
+      expand(c, used, JN[c], BN[c]);
+      expand(my_nc + 2 * c, used, JF[0][c], BF[0][c]);
+      expand(my_nc + 2 * c + 1, used, JF[1][c], BF[1][c]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 2; r++) { PB[r].lam = 0.f; PF[0][r].lam = 0.f; PF[1][r].lam = 0.f; }
+  PM.lam = 0.f; PL.lam = 0.f; PU.lam = 0.f;
+  __syncthreads();                          /* rows are in registers: the staging area becomes the state records */
   {
     const float* r = state + (size_t)(valid ? env : 0) * RP_REC_FLOATS;
-    for (int k = l; k < RP_REC_FLOATS; k += 32) L.st[half][k] = r[k];
-    L.vstar[half][l] = (valid && dd >= 0) ? w[W2_VSTAR + dd] : 0.f;
-    L.mu[half][0][l] = 0.f;
-    L.mu[half][1][l] = valid ? w[W2_MU + l] : 0.f;
-    float4 z = {0.f, 0.f, 0.f, 0.f};
-    for (int k = l; k < NB + 1; k += 32) {
-      float4 a = z, b = z;
-      if (k < my_na) { const float* s = &w[W2_SROW + 8 * __float_as_int(w[W2_AROW + k])]; a = make_float4(s[3], s[4], s[5], s[6]); }
-      if (k < NB && B_USED(k)) {
-        if (k < NBJ) { const float* s = &w[W2_SROW + 8 * __float_as_int(w[W2_AROW + NA + k])]; b = make_float4(s[3], s[4], s[5], s[6]); }
-        else { int r2 = B_ROW(k); b = make_float4(w[W2_ROWS + 4 * r2], w[W2_ROWS + 4 * r2 + 1], 0.f, w[W2_ROWT + 4 * r2 + 1]); }
-      }
-      *(float4*)&L.sc[half][0][4 * k] = a;
-      *(float4*)&L.sc[half][1][4 * k] = b;
-    }
+    float v0 = r[l], v1 = r[l + 32], v2 = r[l + 64], v3 = r[l + 96];
+    float* st = L.st[half];
+    st[l] = v0; st[l + 32] = v1; st[l + 64] = v2; st[l + 96] = v3;
   }
-  /* expand the rows into lane-dense registers: lane l holds entry lane_dof(l) of every row */
-  float JA[NA], BA[NA], JB[NB], BB[NB];
-#pragma unroll
-  for (int t = 0; t < NA; t++) {
-    float j = 0.f, b = 0.f;
-    if (t < my_na && l < n) {                 /* arm-only rows: unit rows sg*e_dA, or the gear row e_dA + sg*e_dB */
-      const float* s = &w[W2_SROW + 8 * __float_as_int(w[W2_AROW + t])];
-      int type = __float_as_int(s[0]), dA = __float_as_int(s[1]), dB = __float_as_int(s[7]);
-      float sg = s[2];
-      float jA = s[4];                          /* dinv, folded into the row */
-      if (type == SR_UNIT) { j = l == dA ? sg * jA : 0.f; b = sg * w[W2_MINV + l * 12 + dA]; }
-      else { j = l == dA ? jA : (l == dB ? sg * jA : 0.f); b = w[W2_MINV + l * 12 + dA] + sg * w[W2_MINV + l * 12 + dB]; }
-    }
-    JA[t] = j; BA[t] = b;
-  }
-#pragma unroll
-  for (int t = 0; t < NB; t++) {
-    float j = 0.f, b = 0.f;
-    if (B_USED(t) && dd >= 0) {
-      if (t < NBJ) {                          /* scene-joint motor: e_dA, B = 1/m at the same entry */
-        const float* s = &w[W2_SROW + 8 * __float_as_int(w[W2_AROW + NA + t])];
-        int dA = __float_as_int(s[1]);
-        j = dd == dA ? s[4] : 0.f; b = dd == dA ? s[2] : 0.f;
-      } else {                                /* contact row: two compact slots -> dense */
-        int r2 = B_ROW(t);
-        int i1 = dd - __float_as_int(w[W2_ROWT + 4 * r2 + 3]), i0 = dd - __float_as_int(w[W2_ROWT + 4 * r2 + 2]);
-        int idx = (unsigned)i1 < 6u ? 12 + i1 : ((unsigned)i0 < 12u ? i0 : -1);
-        if (idx >= 0) { j = w[W2_J + ROWW * r2 + idx]; b = w[W2_B + ROWW * r2 + idx]; }
-      }
-    }
-    JB[t] = j; BB[t] = b;
-  }
-#undef B_USED
-#undef B_ROW
   __builtin_amdgcn_s_waitcnt(0x0F70);    /* vmcnt(0): all row registers have landed before the sweep loop */
   __syncthreads();
   CLK_MARK(1)
   float dv = 0.f;
-  /* row scalars, lane-distributed like the impulses: lane k of a DPP row holds the value of slot 16 r + k in register r
-   * (read back with one row broadcast); the sweep loops below touch neither LDS nor memory.
-   * X arrays: PAR path = this DPP row's own stream (A in row 0, B in row 1); SEQ path = stream B in both rows. */
-  float rhsX[(NB + 15) / 16], loX[(SLOT_F + 15) / 16], hiX[(SLOT_F + 15) / 16], muX[(SLOT_F + 15) / 16];
-  {
-    const float* scx = L.sc[half][par ? grp : 1];
-    const float* mux = L.mu[half][par ? grp : 1];
-#pragma unroll
-    for (int r = 0; r < (NB + 15) / 16; r++) { int k = 16 * r + l16; rhsX[r] = k < NB ? scx[4 * k] : 0.f; }
-#pragma unroll
-    for (int r = 0; r < (SLOT_F + 15) / 16; r++) {
-      int k = 16 * r + l16;
-      loX[r] = k < SLOT_F ? scx[4 * k + 2] : 0.f; hiX[r] = k < SLOT_F ? scx[4 * k + 3] : 0.f;
-      muX[r] = (k >= SLOT_N && k < SLOT_F) ? mux[k - SLOT_N] : 0.f;     /* friction coefficient, aligned with the normal's slot */
-    }
-  }
-  float lamX[(NB + 15) / 16];       /* accumulated impulses of the X rows */
-#pragma unroll
-  for (int r = 0; r < (NB + 15) / 16; r++) lamX[r] = 0.f;
-  constexpr int NCH = SLOT_F / 4, NFCH = (2 * MAXC + 3) / 4;
-  static_assert(SLOT_F % 4 == 0, "chunking");
+  /* in-loop copies of the guards: kept in SGPRs and re-read every sweep so that they stay s_cmp + s_cbranch */
+#define SWEEP_GUARDS                                                                                     \
+  int nj_it = nj_max, nc_it = nc_max, mL_it = maskL, mU_it = maskU, fm_it = foldm, gr_it = gear;        \
+  asm volatile("" : "+s"(nj_it), "+s"(nc_it), "+s"(mL_it), "+s"(mU_it), "+s"(fm_it), "+s"(gr_it));      \
+  nj_it = __builtin_amdgcn_readfirstlane(nj_it); nc_it = __builtin_amdgcn_readfirstlane(nc_it);         \
+  mL_it = __builtin_amdgcn_readfirstlane(mL_it); mU_it = __builtin_amdgcn_readfirstlane(mU_it);         \
+  fm_it = __builtin_amdgcn_readfirstlane(fm_it); gr_it = __builtin_amdgcn_readfirstlane(gr_it);
+  /* Guards: a sweep visits only the rows that exist.  Contacts are a prefix (c < nc), so their rows use early exits
+   * (one s_cmp + s_cbranch per executed row, none for skipped ones); limits test their mask bit. */
+#define REP9(M, b) M(b) M(b + 1) M(b + 2) M(b + 3) M(b + 4) M(b + 5) M(b + 6) M(b + 7) M(b + 8)
+#define REP12(M, b) REP9(M, b) M(b + 9) M(b + 10) M(b + 11)
+#define REP21(M, b) REP12(M, b) REP9(M, b + 12)
   if (par) {
-    /* both envs uncoupled: stream A in DPP row 0 and stream B in DPP row 1 of each half, one slot of each per step */
+    /* both envs uncoupled: stream A in DPP row 0 and stream B in DPP row 1 of each half.  Plane M and plane B0 share
+     * registers (row 0 = M, row 1 = B0) and step t < 12 handles motor t and label t together */
+    Plane X0;
+    X0.rhs = row0 ? PM.rhs : PB[0].rhs; X0.lo = row0 ? PM.lo : PB[0].lo; X0.hi = row0 ? PM.hi : PB[0].hi; X0.lam = 0.f;
+    const float dinvX = row0 ? dinvA : jdJ;
+    float Jm[12], Bm[12];                  /* merged rows (disjoint lanes: exact) */
 #pragma unroll
-    for (int t = 0; t < NA; t++) { JB[t] += JA[t]; BB[t] += BA[t]; }     /* disjoint lanes: exact merge */
+    for (int t = 0; t < 12; t++) {
+      float jd = (row0 && l16 == t) ? dinvA : 0.f;
+      if (t < LBL_N) { Jm[t] = jd; Bm[t] = Mcol[t] + ((!row0 && l16 == t) ? colJ : 0.f); }
+      else { Jm[t] = JN[t - LBL_N] + jd; Bm[t] = BN[t - LBL_N] + Mcol[t]; }
+    }
 #pragma unroll 1
     for (int it = 0; it < K_NITER; it++) {
-      int na_it = na_max, nj_it = nj_max, nc_it = nc_max;
-      asm volatile("" : "+s"(na_it), "+s"(nj_it), "+s"(nc_it));        /* keep the guards as in-loop s_cmp + s_cbranch */
-      na_it = __builtin_amdgcn_readfirstlane(na_it); nj_it = __builtin_amdgcn_readfirstlane(nj_it);
-      nc_it = __builtin_amdgcn_readfirstlane(nc_it);
-      /* guards per chunk of 4 slots (null slots are exact no-ops): A rows | scene-joint motors, contact normals */
-      static_for<0, NCH>([&](auto ch) {
-        constexpr int t0 = 4 * decltype(ch)::v;
-        if (t0 < na_it || (t0 < NBJ ? t0 < nj_it : false) || (t0 + 3 >= SLOT_N && t0 - SLOT_N < nc_it))
-          static_for<t0, t0 + 4>([&](auto tc) {
-            constexpr int t = decltype(tc)::v;
-            row_update<false, t>(JB[t], BB[t], dv, bcast16<t>(rhsX[t >> 4]), bcast16<t>(loX[t >> 4]), bcast16<t>(hiX[t >> 4]), lamX[t >> 4], l16);
-          });
-      });
-      float limX[(SLOT_F + 15) / 16];                      /* friction limits mu * (normal impulse), still lane-distributed */
-#pragma unroll
-      for (int r = 0; r < (SLOT_F + 15) / 16; r++) limX[r] = muX[r] * lamX[r];
-      static_for<0, NFCH>([&](auto ch) {                   /* frictions (stream B only; stream A has mu = 0 and null rows) */
-        constexpr int j0 = 4 * decltype(ch)::v;
-        if (j0 < 2 * nc_it)
-          static_for<j0, (j0 + 4 < 2 * MAXC ? j0 + 4 : 2 * MAXC)>([&](auto jc) {
-            constexpr int j = decltype(jc)::v, tn = SLOT_N + (j >> 1), t = SLOT_F + j;
-            float lim = bcast16<tn>(limX[tn >> 4]);
-            row_update<false, t>(JB[t], BB[t], dv, bcast16<t>(rhsX[t >> 4]), 0.f - lim, 0.f + lim, lamX[t >> 4], l16);
-          });
-      });
+      SWEEP_GUARDS
+      (void)fm_it; (void)nj_it;
+      plane_begin(X0); plane_begin(PL); plane_begin(PU); plane_begin(PB[1]);
+      PLANE_FENCE4(X0, PL, PU, PB[1]);
+      /* motor t | scene joint t: both unit rows at lane t */
+      unit_row<0>(dinvX, Bm[0], dv, X0, l16); unit_row<1>(dinvX, Bm[1], dv, X0, l16); unit_row<2>(dinvX, Bm[2], dv, X0, l16);
+      /* motor t | normal of contact t - 3 while contacts last, then the remaining motors alone */
+#define PAR_G(t) if (nc_it <= (t) - LBL_N) goto par_u##t; generic_row<(t), false, 0>(Jm[t], Bm[t], dv, X0, 0, l16);
+      PAR_G(3) PAR_G(4) PAR_G(5) PAR_G(6) PAR_G(7) PAR_G(8) PAR_G(9) PAR_G(10) PAR_G(11)
+#undef PAR_G
+#define PAR_H(t) if (nc_it <= (t) - LBL_N) goto par_ndone; generic_row<(t), false, 0>(JN[(t) - LBL_N], BN[(t) - LBL_N], dv, (t) < 16 ? X0 : PB[1], 0, l16);
+      REP12(PAR_H, 12)
+#undef PAR_H
+      goto par_ndone;
+#define PAR_U(t) par_u##t: unit_row<(t)>(dinvX, Bm[t], dv, X0, l16);      /* t >= n_arm: all-zero row, exact no-op */
+      PAR_U(3) PAR_U(4) PAR_U(5) PAR_U(6) PAR_U(7) PAR_U(8) PAR_U(9) PAR_U(10) PAR_U(11)
+#undef PAR_U
+    par_ndone:
+      plane_end(X0); plane_end(PB[1]);
+      /* limits, dof-major, lower before upper (in DPP row 1 these are exact no-ops).  One guard per group of six dofs:
+       * an absent limit row is all zeros and an exact no-op that costs about as much as the branch that would skip it */
+#define PAR_L(i) unit_row<(i)>(dinvX, Bm[i], dv, PL, l16); unit_row<(i)>(dinvX, Bm[i], dv, PU, l16);
+      if ((mL_it | mU_it) & 0x03F) { PAR_L(0) PAR_L(1) PAR_L(2) PAR_L(3) PAR_L(4) PAR_L(5) }
+      if ((mL_it | mU_it) & 0xFC0) { PAR_L(6) PAR_L(7) PAR_L(8) PAR_L(9) PAR_L(10) PAR_L(11) }
+#undef PAR_L
+      if (gr_it) generic_row<GEAR_LANE, false, 0>(Jg, Bg, dv, PU, 0, l16);
+      plane_end(PL); plane_end(PU);
+      if (nc_it > 0) {                                         /* frictions, contact by contact */
+        fplane_begin(PF[0][0], muB[0] * X0.lam); fplane_begin(PF[1][0], muB[0] * X0.lam);
+        fplane_begin(PF[0][1], muB[1] * PB[1].lam); fplane_begin(PF[1][1], muB[1] * PB[1].lam);
+        PLANE_FENCE4(PF[0][0], PF[1][0], PF[0][1], PF[1][1]);
+#define PAR_F(c) generic_row<LBL_N + (c), false, 0>(JF[0][c], BF[0][c], dv, PF[0][(LBL_N + (c)) >> 4], 0, l16); \
+                 generic_row<LBL_N + (c), false, 0>(JF[1][c], BF[1][c], dv, PF[1][(LBL_N + (c)) >> 4], 0, l16); \
+                 if (nc_it <= (c) + 1) goto par_fdone;
+        REP21(PAR_F, 0)
+#undef PAR_F
+      par_fdone:
+        plane_end(PF[0][0]); plane_end(PF[1][0]); plane_end(PF[0][1]); plane_end(PF[1][1]);
+      }
     }
   } else {
-    /* a contact involves the arm: all A rows, then all B rows, 32-lane dot products; both DPP rows hold the same copies */
-    float rhsA[(NA + 15) / 16], loA[(NA + 15) / 16], hiA[(NA + 15) / 16], lamA[(NA + 15) / 16];
-#pragma unroll
-    for (int r = 0; r < (NA + 15) / 16; r++) {
-      int k = 16 * r + l16;
-      const float* sca = L.sc[half][0];
-      rhsA[r] = k < NA ? sca[4 * k] : 0.f; loA[r] = k < NA ? sca[4 * k + 2] : 0.f; hiA[r] = k < NA ? sca[4 * k + 3] : 0.f;
-      lamA[r] = 0.f;
-    }
+    /* a contact involves the arm: all A rows, then all B rows; B rows that span arm and non-arm dofs fold the two DPP
+     * rows, the others need only their own row's sum (the other DPP row then computes a step that multiplies B = 0) */
 #pragma unroll 1
     for (int it = 0; it < K_NITER; it++) {
-      int na_it = na_max, nj_it = nj_max, nc_it = nc_max;
-      asm volatile("" : "+s"(na_it), "+s"(nj_it), "+s"(nc_it));
-      na_it = __builtin_amdgcn_readfirstlane(na_it); nj_it = __builtin_amdgcn_readfirstlane(nj_it);
-      nc_it = __builtin_amdgcn_readfirstlane(nc_it);
-      static_for<0, NA>([&](auto tc) {
-        constexpr int t = decltype(tc)::v;
-        if (t < na_it)
-          row_update<true, t>(JA[t], BA[t], dv, bcast16<t>(rhsA[t >> 4]), bcast16<t>(loA[t >> 4]), bcast16<t>(hiA[t >> 4]), lamA[t >> 4], l16);
-      });
-      static_for<0, SLOT_F>([&](auto tc) {
-        constexpr int t = decltype(tc)::v;
-        if (t < NBJ ? t < nj_it : t - SLOT_N < nc_it)
-          row_update<true, t>(JB[t], BB[t], dv, bcast16<t>(rhsX[t >> 4]), bcast16<t>(loX[t >> 4]), bcast16<t>(hiX[t >> 4]), lamX[t >> 4], l16);
-      });
-      float limX[(SLOT_F + 15) / 16];
-#pragma unroll
-      for (int r = 0; r < (SLOT_F + 15) / 16; r++) limX[r] = muX[r] * lamX[r];
-      static_for<0, 2 * MAXC>([&](auto jc) {
-        constexpr int j = decltype(jc)::v, tn = SLOT_N + (j >> 1), t = SLOT_F + j;
-        if (j < 2 * nc_it) {
-          float lim = bcast16<tn>(limX[tn >> 4]);
-          row_update<true, t>(JB[t], BB[t], dv, bcast16<t>(rhsX[t >> 4]), 0.f - lim, 0.f + lim, lamX[t >> 4], l16);
-        }
-      });
+      SWEEP_GUARDS
+      plane_begin(PM); plane_begin(PL); plane_begin(PU); plane_begin(PB[0]);     /* B0's bounds do not depend on A rows */
+      PLANE_FENCE4(PM, PL, PU, PB[0]);
+#define SEQ_M(t) unit_row<(t)>(dinvA, Mcol[t], dv, PM, l16);               /* t >= n_arm: all-zero row, exact no-op */
+      REP12(SEQ_M, 0)
+#undef SEQ_M
+#define SEQ_L(i) unit_row<(i)>(dinvA, Mcol[i], dv, PL, l16); unit_row<(i)>(dinvA, Mcol[i], dv, PU, l16);
+      if ((mL_it | mU_it) & 0x03F) { SEQ_L(0) SEQ_L(1) SEQ_L(2) SEQ_L(3) SEQ_L(4) SEQ_L(5) }
+      if ((mL_it | mU_it) & 0xFC0) { SEQ_L(6) SEQ_L(7) SEQ_L(8) SEQ_L(9) SEQ_L(10) SEQ_L(11) }
+#undef SEQ_L
+      if (gr_it) generic_row<GEAR_LANE, false, 0>(Jg, Bg, dv, PU, 0, l16);
+      plane_end(PM); plane_end(PL); plane_end(PU);
+      plane_begin(PB[1]);                                      /* first read 13 rows later: no fence needed */
+      {                                                        /* scene-joint motors: lane-local, all at once (no-op without joints) */
+        float d = __builtin_amdgcn_fmed3f(PB[0].rhs - jdJ * dv, PB[0].loP, PB[0].hiP);
+        PB[0].dacc = (!row0 && l16 < LBL_N) ? d : PB[0].dacc;
+        dv += colJ * d;
+      }
+#define SEQ_N(c) if (nc_it <= (c)) goto seq_ndone; generic_row<LBL_N + (c), true, (c)>(JN[c], BN[c], dv, PB[(LBL_N + (c)) >> 4], fm_it, l16);
+      REP21(SEQ_N, 0)
+#undef SEQ_N
+    seq_ndone:
+      plane_end(PB[0]); plane_end(PB[1]);
+      if (nc_it > 0) {
+        fplane_begin(PF[0][0], muB[0] * PB[0].lam); fplane_begin(PF[1][0], muB[0] * PB[0].lam);
+        fplane_begin(PF[0][1], muB[1] * PB[1].lam); fplane_begin(PF[1][1], muB[1] * PB[1].lam);
+        PLANE_FENCE4(PF[0][0], PF[1][0], PF[0][1], PF[1][1]);
+#define SEQ_F(c) generic_row<LBL_N + (c), true, (c)>(JF[0][c], BF[0][c], dv, PF[0][(LBL_N + (c)) >> 4], fm_it, l16); \
+                 generic_row<LBL_N + (c), true, (c)>(JF[1][c], BF[1][c], dv, PF[1][(LBL_N + (c)) >> 4], fm_it, l16); \
+                 if (nc_it <= (c) + 1) goto seq_fdone;
+        REP21(SEQ_F, 0)
+#undef SEQ_F
+      seq_fdone:
+        plane_end(PF[0][0]); plane_end(PF[1][0]); plane_end(PF[0][1]); plane_end(PF[1][1]);
+      }
     }
   }
+#undef REP9
+#undef REP12
+#undef REP21
+#undef SWEEP_GUARDS
+#undef WAVE_OR
   /* integrate: lane l holds velocity component lane_dof(l) of this half's env */
   float* st = L.st[half];
-  float vnew = L.vstar[half][l] + dv;
+  float vnew = vstar + dv;
   __syncthreads();
   CLK_MARK(2)
   if (dd >= 0) {
@@ -1994,7 +2080,8 @@ __global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m
   CLK_MARK(3)
   if (lane == 0) {
     g_clk[8 * blockIdx.x + 5] = wall_clock64();
-    g_clk[8 * blockIdx.x + 6] = (unsigned long long)na_max | ((unsigned long long)nj_max << 8) | ((unsigned long long)nc_max << 16) | ((unsigned long long)(par ? 1 : 0) << 24);
+    int na = n + __popc(maskL) + __popc(maskU);
+    g_clk[8 * blockIdx.x + 6] = (unsigned long long)na | ((unsigned long long)nj_max << 8) | ((unsigned long long)nc_max << 16) | ((unsigned long long)(par ? 1 : 0) << 24);
     unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
     g_clk[8 * blockIdx.x + 7] = ((unsigned long long)xcc << 32) | hw;

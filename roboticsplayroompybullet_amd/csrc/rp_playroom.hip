@@ -16,7 +16,7 @@ struct rp_sim {
   DevModel host_model;
   DevModel* dev_model;
   float* state;            /* [N][RP_REC_FLOATS] */
-  float* ws;               /* [N][WS_FLOATS] constraint-row workspace of the split step pipeline */
+  float* ws;               /* [N][W3_FLOATS] constraint-row workspace of the split step pipeline */
   float* dbg;
   hipEvent_t ev0, ev1;
   hipEvent_t* pool;        /* per-launch timing ring: EV_PER_STEP events per recorded step */
@@ -25,7 +25,7 @@ struct rp_sim {
   int groups;              /* env groups of the default pipeline, each on its own stream (tail overlap) */
   hipStream_t gstream[RP_MAX_GROUPS];
   hipEvent_t gfork, gjoin[RP_MAX_GROUPS];
-  int fused;               /* 0: split pipeline v2 (default), 1: single fused k_step kernel (reference path), 2: split pipeline v1 */
+  int fused;               /* 0: split pipeline (default), 1: single fused k_step kernel (in-library reference path) */
   rp_timers timers;
   char err[256];
 };
@@ -72,7 +72,7 @@ int rp_create(const rp_config* cfg, rp_handle* out) {
   if (e != hipSuccess) { snprintf(g_err, 256, "hipSetDevice(%d): %s", cfg->device, hipGetErrorString(e)); free(h); return RP_ERR_HIP; }
   if (hipMalloc((void**)&h->dev_model, sizeof(DevModel)) != hipSuccess ||
       hipMalloc((void**)&h->state, (size_t)cfg->num_envs * RP_REC_FLOATS * sizeof(float)) != hipSuccess ||
-      hipMalloc((void**)&h->ws, (size_t)cfg->num_envs * (W2_FLOATS > WS_FLOATS ? W2_FLOATS : WS_FLOATS) * sizeof(float)) != hipSuccess ||
+      hipMalloc((void**)&h->ws, (size_t)cfg->num_envs * W3_FLOATS * sizeof(float)) != hipSuccess ||
       hipMalloc((void**)&h->dbg, 4096 * sizeof(float)) != hipSuccess) {
     snprintf(g_err, 256, "rp_create: hipMalloc failed"); free(h); return RP_ERR_HIP;
   }
@@ -150,7 +150,7 @@ int rp_step(rp_handle h, const float* action, const rp_out* out, void* stream) {
      * each range runs its own 26-kernel chain on its own stream; the tail of one group's k_solve2 (its heaviest wave)
      * overlaps with the other groups' kernels.  Per-launch timing (rp_enable_timers) uses one group so that the event
      * pairs bracket exactly one kernel each. */
-    int G = (ev || h->fused == 2) ? 1 : h->groups;
+    int G = ev ? 1 : h->groups;
     if (G > (N + 63) / 64) G = (N + 63) / 64;
     int e = 2;
 #define TIMED(launch) do { if (ev) hipEventRecord(ev[e++], gs); launch; if (ev) hipEventRecord(ev[e++], gs); } while (0)
@@ -162,13 +162,8 @@ int rp_step(rp_handle h, const float* action, const rp_out* out, void* stream) {
       if (ev) hipEventRecord(ev[0], gs);
       TIMED(hipLaunchKernelGGL(k_action, dim3((ng + 63) / 64), dim3(64), 0, gs, h->dev_model, h->state, action, op.target_poses, e0, e1));
       for (int sub = 0; sub < K_NSUB; sub++) {
-        if (h->fused == 2) {       /* split pipeline v1: LDS-resident compact rows, one env per wave */
-          TIMED(hipLaunchKernelGGL(k_prep, dim3(N), dim3(64), 0, gs, h->dev_model, h->state, h->ws, N));
-          TIMED(hipLaunchKernelGGL(k_solve, dim3(N), dim3(64), 0, gs, h->dev_model, h->state, h->ws, N));
-        } else {                    /* default: register-resident dense rows, two envs per wave */
-          TIMED(hipLaunchKernelGGL(k_prep2, dim3(ng), dim3(64), 0, gs, h->dev_model, h->state, h->ws, e0, e1));
-          TIMED(hipLaunchKernelGGL(k_solve2, dim3((ng + 1) / 2), dim3(64), 0, gs, h->dev_model, h->state, h->ws, e0, e1));
-        }
+        TIMED(hipLaunchKernelGGL(k_prep2, dim3(ng), dim3(64), 0, gs, h->dev_model, h->state, h->ws, e0, e1));
+        TIMED(hipLaunchKernelGGL(k_solve2, dim3((ng + 1) / 2), dim3(64), 0, gs, h->dev_model, h->state, h->ws, e0, e1));
       }
       TIMED(hipLaunchKernelGGL(k_calc_state, dim3(ng), dim3(64), 0, gs, h->dev_model, h->state, op, e0, e1));
       if (ev) hipEventRecord(ev[1], gs);
@@ -222,7 +217,7 @@ int rp_set_state(rp_handle h, const void* src, int32_t src_env_count, void* stre
 }
 
 int rp_set_groups(rp_handle h, int32_t groups) { if (!h || groups < 1 || groups > RP_MAX_GROUPS) return RP_ERR_ARG; h->groups = groups; return RP_OK; }
-int rp_set_fused(rp_handle h, int32_t fused) { if (!h) return RP_ERR_ARG; h->fused = fused; return RP_OK; }
+int rp_set_fused(rp_handle h, int32_t fused) { if (!h || (fused != 0 && fused != 1)) return RP_ERR_ARG; h->fused = fused; return RP_OK; }
 int rp_get_timers(rp_handle h, rp_timers* t) {
   if (!h || !t) return RP_ERR_ARG;
   rp_timers r = h->timers;
@@ -278,10 +273,10 @@ int rp_debug_row_counts(rp_handle h, int32_t* host_buf) {
   if (!h || !host_buf) return RP_ERR_ARG;
   HIPCHK(h, hipDeviceSynchronize());
   int N = h->cfg.num_envs;
-  for (int e = 0; e < N; e++) {   /* header: nA, nj1, ncon, coupled -> (nA + nj1, ncon + 1000 * coupled) */
-    int32_t hdr[4];
-    HIPCHK(h, hipMemcpy(hdr, h->ws + (size_t)e * W2_FLOATS, 4 * sizeof(int32_t), hipMemcpyDeviceToHost));
-    host_buf[2 * e] = hdr[0] + hdr[1]; host_buf[2 * e + 1] = hdr[2] + 1000 * hdr[3];
+  for (int e = 0; e < N; e++) {   /* header: maskL, maskU, nj, ncon, coupled, foldmask, gear, nA -> (nA + nj, ncon + 1000 * coupled) */
+    int32_t hdr[8];
+    HIPCHK(h, hipMemcpy(hdr, h->ws + (size_t)e * W3_FLOATS, 8 * sizeof(int32_t), hipMemcpyDeviceToHost));
+    host_buf[2 * e] = hdr[7] + hdr[2]; host_buf[2 * e + 1] = hdr[3] + 1000 * hdr[4];
   }
   return RP_OK;
 }

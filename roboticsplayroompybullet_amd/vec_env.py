@@ -129,9 +129,9 @@ class VecPlayEnv:
         _lib.check(self.lib, self.h, self.lib.rp_set_state(self.h, C.c_void_p(s.data_ptr()), s.shape[0], self._stream()), 'rp_set_state')
 
     def set_fused(self, mode=1):
-        """step pipeline: 0 = default (k_action, k_prep2, k_solve2, k_calc_state), 1 = one fused kernel (the library's
-        reference path), 2 = split v1 (k_prep / k_solve, one env per wave).  All three are bit-identical."""
-        self.lib.rp_set_fused(self.h, int(mode))
+        """step pipeline: 0 = default (k_action, k_prep2, k_solve2, k_calc_state), 1 = one fused kernel per step (the
+        library's in-GPU cross-check path).  Both are bit-identical."""
+        _lib.check(self.lib, self.h, self.lib.rp_set_fused(self.h, int(mode)), 'rp_set_fused')
 
     def set_groups(self, groups):
         """number of env groups (each with its own stream and kernel chain) rp_step uses; results do not depend on it"""

@@ -111,26 +111,25 @@ def test_shard_equivalence_bitwise():
 
 
 def test_split_pipeline_equals_fused_kernel_bitwise():
-    """rp_step's split kernels (k_action / k_prep / k_solve / k_calc_state) == the fused k_step kernel, bit for bit."""
+    """rp_step's split kernels (k_action / k_prep2 / k_solve2 / k_calc_state: two envs per wave, rows in registers, two
+    concurrent row streams, unit rows without dot products) == the fused one-kernel-per-step k_step (one env per wave,
+    every row through the generic 32-lane reduction), bit for bit."""
     from roboticsplayroompybullet_amd import VecPlayEnv
     for kind in ('U', 'P', 'R'):
         n = 33                                  # odd: the two-envs-per-wave solver has a half-empty last wave
-        a = VecPlayEnv(IDS[kind], n, seed=5)    # default: k_action / k_prep2 / k_solve2 (2 envs per wave, rows in registers)
+        a = VecPlayEnv(IDS[kind], n, seed=5)
         b = VecPlayEnv(IDS[kind], n, seed=5)
         b.set_fused(1)                          # one fused kernel per env step
-        c = VecPlayEnv(IDS[kind], n, seed=5)
-        c.set_fused(2)                          # k_prep / k_solve (1 env per wave, rows in LDS)
         a.set_groups(3)                         # env groups on separate streams must not change any result
-        a.reset(); b.reset(); c.reset()
+        a.reset(); b.reset()
         acts = torch.tensor(actions(kind, 6, n, 8), dtype=torch.float32)
         for t in range(6):
             oa, ra, _, ia = a.step(acts[t])
             ob, rb, _, ib = b.step(acts[t])
-            oc, rc, _, ic = c.step(acts[t])
         torch.cuda.synchronize()
-        assert torch.equal(a.get_state(), b.get_state()) and torch.equal(c.get_state(), b.get_state())
+        assert torch.equal(a.get_state(), b.get_state())
         for k in ('obs_quat', 'achieved_goal', 'observation', 'velocity'):
-            assert torch.equal(oa[k], ob[k]) and torch.equal(oc[k], ob[k]), k
+            assert torch.equal(oa[k], ob[k]), k
         assert torch.equal(ia['target_poses'], ib['target_poses'])
 
 

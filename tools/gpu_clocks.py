@@ -54,6 +54,13 @@ for name, sel in (('PAR', par == 1), ('SEQ', par == 0)):
     cps = t_sweep[sel] / (50.0 * np.maximum(stp[sel], 1))
     print('%s waves %d: rows/sweep p50 %d max %d; cycles per row-step p50 %.1f p10 %.1f p90 %.1f' % (
         name, sel.sum(), np.median(stp[sel]), stp[sel].max(), np.median(cps), np.percentile(cps, 10), np.percentile(cps, 90)))
+for name, sel in (('PAR', par == 1), ('SEQ', par == 0)):
+    if sel.sum() < 8:
+        continue
+    A = np.stack([np.ones(sel.sum()), (na[sel] - 12).astype(float), nc[sel].astype(float)], 1)
+    y = t_sweep[sel] / 50.0
+    coef, res, _, _ = np.linalg.lstsq(A, y, rcond=None)
+    print('%s sweep cycles ~ %.0f + %.0f * n_limit_rows + %.0f * n_contacts   (rms resid %.0f)' % (name, coef[0], coef[1], coef[2], np.sqrt(np.mean((A @ coef - y) ** 2))))
 order = np.argsort(-w1)[:12]
 print('last finishers: blk start_us end_us load sweep tail na nj nc par xcc hw')
 for b in order:
