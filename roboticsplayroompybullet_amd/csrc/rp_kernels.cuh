@@ -96,6 +96,22 @@ struct __align__(16) EnvLds {
   int roff[64];                   /* k_prep2: slot offsets of the compact contact rows */
 };
 
+#ifdef RP_CLOCKS      /* profiling build only: per-wave phase timestamps of the last k_solve2 (1) / k_prep2 (2) launch */
+__device__ unsigned long long g_clk[16 * 4096];
+#define CLK_MARK(i) if (lane == 0) { g_clk[8 * blockIdx.x + (i)] = __builtin_readcyclecounter(); }
+#if RP_CLOCKS == 2
+#define PCLK(i) if (lane == 0) { g_clk[16 * blockIdx.x + (i)] = (i) >= 6 && (i) < 8 ? wall_clock64() : __builtin_readcyclecounter(); }
+#define CLK_MARK2(i)
+#else
+#define PCLK(i)
+#define CLK_MARK2(i) CLK_MARK(i)
+#endif
+#else
+#define CLK_MARK(i)
+#define CLK_MARK2(i)
+#define PCLK(i)
+#endif
+
 /* ------------------------------------------------------------------ small helpers */
 __device__ __forceinline__ int dof_free(const DevModel* m, int k) { return m->n_arm + 6 * k; }
 __device__ __forceinline__ int dof_j1(const DevModel* m, int k) { return m->n_arm + 6 * m->n_free + k; }
@@ -234,105 +250,6 @@ __device__ void collider_aabbs(const DevModel* m, EnvLds& L, int lane) {
 /* ------------------------------------------------------------------ narrowphase (same decisions as oracle box_box) */
 struct CPt { V3 p, n; float dist; };
 
-__device__ int clip_poly(const float (*in)[3], int n, V3 c, V3 u, float h, float sign, float (*out)[3]) {
-  int m_ = 0;
-  for (int i = 0; i < n; i++) {
-    V3 a = ld3(in[i]);
-    V3 b = ld3(in[(i + 1 == n) ? 0 : i + 1]);
-    float da = sign * dot(a - c, u) - h;
-    float db = sign * dot(b - c, u) - h;
-    if (da <= 0.f) { st3(out[m_], a); m_++; }
-    if ((da < 0.f && db > 0.f) || (da > 0.f && db < 0.f)) {
-      float t = da / (da - db);
-      st3(out[m_], a + (b - a) * t);
-      m_++;
-    }
-  }
-  return m_;
-}
-
-__device__ __attribute__((noinline)) int box_box(V3 ca, const M3& Ra, V3 ha, V3 cb, const M3& Rb, V3 hb, float margin, CPt* out) {
-  V3 A[3] = {col(Ra, 0), col(Ra, 1), col(Ra, 2)}, B[3] = {col(Rb, 0), col(Rb, 1), col(Rb, 2)};
-  float hA[3] = {ha.x, ha.y, ha.z}, hB[3] = {hb.x, hb.y, hb.z};
-  V3 t = ca - cb;
-  float best_s = -1e30f; int best_kind = -1, best_i = 0; V3 best_L = mk3(0, 0, 0);
-  for (int f = 0; f < 6; f++) {
-    V3 Lx = f < 3 ? A[f] : B[f - 3];
-    float ra = 0.f, rb = 0.f;
-    for (int k = 0; k < 3; k++) { ra += hA[k] * fabsf(dot(Lx, A[k])); rb += hB[k] * fabsf(dot(Lx, B[k])); }
-    float s = fabsf(dot(t, Lx)) - ra - rb;
-    if (s > margin) return 0;
-    if (s > best_s + (f == 0 ? 0.f : K_TIE_EPS)) { best_s = s; best_kind = f < 3 ? 0 : 1; best_i = f % 3; best_L = Lx; }
-  }
-  float edge_s = -1e30f; int ei = 0, ej = 0; V3 eL = mk3(0, 0, 0);
-  for (int i = 0; i < 3; i++)
-    for (int j = 0; j < 3; j++) {
-      V3 Lx = cross(A[i], B[j]);
-      float l = norm(Lx);
-      if (l < 1e-6f) continue;
-      Lx = Lx * (1.f / l);
-      float ra = 0.f, rb = 0.f;
-      for (int k = 0; k < 3; k++) { ra += hA[k] * fabsf(dot(Lx, A[k])); rb += hB[k] * fabsf(dot(Lx, B[k])); }
-      float s = fabsf(dot(t, Lx)) - ra - rb;
-      if (s > margin) return 0;
-      if (s > edge_s + K_TIE_EPS) { edge_s = s; ei = i; ej = j; eL = Lx; }
-    }
-  if (edge_s > best_s + 0.05f * fabsf(best_s) + 1e-6f) {
-    V3 n = eL;
-    if (dot(n, t) < 0.f) n = -n;
-    V3 pa = ca, pb = cb;
-    for (int k = 0; k < 3; k++) {
-      if (k != ei) pa = pa + A[k] * (dot(n, A[k]) > 0.f ? -hA[k] : hA[k]);
-      if (k != ej) pb = pb + B[k] * (dot(n, B[k]) > 0.f ? hB[k] : -hB[k]);
-    }
-    V3 d = pb - pa;
-    float ab = dot(A[ei], B[ej]), q1 = dot(A[ei], d), q2 = -dot(B[ej], d);
-    float den = 1.f - ab * ab, sa = 0.f, sb = 0.f;
-    if (den > 1e-9f) { sa = (q1 + ab * q2) / den; sb = (ab * q1 + q2) / den; }
-    V3 xa = pa + A[ei] * sa, xb = pb + B[ej] * sb;
-    out[0].dist = dot(xa - xb, n);
-    out[0].p = (xa + xb) * 0.5f;
-    out[0].n = n;
-    return out[0].dist <= margin ? 1 : 0;
-  }
-  V3 cX, cY; const V3 *X, *Y; const float *hX, *hY;
-  if (best_kind == 0) { cX = ca; hX = hA; X = A; cY = cb; hY = hB; Y = B; }
-  else { cX = cb; hX = hB; X = B; cY = ca; hY = hA; Y = A; }
-  V3 nref = best_L;
-  if (dot(nref, cY - cX) < 0.f) nref = -nref;
-  int j = 0; float bj = -1.f;
-  for (int k = 0; k < 3; k++) { float v = fabsf(dot(nref, Y[k])); if (v > bj + K_TIE_EPS) { bj = v; j = k; } }
-  float sj = dot(nref, Y[j]) > 0.f ? -1.f : 1.f;
-  int k1 = (j + 1) % 3, k2 = (j + 2) % 3;
-  V3 fc = cY + Y[j] * (sj * hY[j]);
-  float poly[2][16][3];
-  const float sg[4][2] = {{1, 1}, {-1, 1}, {-1, -1}, {1, -1}};
-  for (int v = 0; v < 4; v++) st3(poly[0][v], fc + Y[k1] * (sg[v][0] * hY[k1]) + Y[k2] * (sg[v][1] * hY[k2]));
-  int u1 = (best_i + 1) % 3, u2 = (best_i + 2) % 3, n = 4;
-  n = clip_poly(poly[0], n, cX, X[u1], hX[u1], 1.f, poly[1]);
-  n = clip_poly(poly[1], n, cX, X[u1], hX[u1], -1.f, poly[0]);
-  n = clip_poly(poly[0], n, cX, X[u2], hX[u2], 1.f, poly[1]);
-  n = clip_poly(poly[1], n, cX, X[u2], hX[u2], -1.f, poly[0]);
-  /* reuse poly[1] as the kept list: [v][0..2] point, dist in a side array */
-  float dists[16]; int cnt = 0, deepest = 0;
-  for (int v = 0; v < n; v++) {
-    V3 pv = ld3(poly[0][v]);
-    float dist = dot(pv - cX, nref) - hX[best_i];
-    if (dist > margin) continue;
-    st3(poly[1][cnt], pv - nref * (0.5f * dist));
-    dists[cnt] = dist;
-    if (dist < dists[deepest] - K_TIE_EPS) deepest = cnt;
-    cnt++;
-  }
-  V3 nn = best_kind == 1 ? nref : -nref;
-  int outn = cnt <= 4 ? cnt : 4;
-  for (int v = 0; v < outn; v++) {
-    int src = cnt <= 4 ? v : (deepest + (v * cnt) / 4) % cnt;
-    out[v].p = ld3(poly[1][src]); out[v].n = nn; out[v].dist = dists[src];
-  }
-  return outn;
-}
-
 __device__ __attribute__((noinline)) int sphere_box(V3 cs, float r, V3 cb, const M3& Rb, V3 hb, float margin, int sphere_is_b, CPt* out) {
   V3 l = tmulv(Rb, cs - cb);
   float ll[3] = {l.x, l.y, l.z}, cl[3], h[3] = {hb.x, hb.y, hb.z};
@@ -365,6 +282,198 @@ __device__ __attribute__((noinline)) int sphere_box(V3 cs, float r, V3 cb, const
   return 1;
 }
 
+/* ------------------------------------------------------------------ cooperative narrowphase: 8 lanes per active pair.
+ * Same decisions and the same arithmetic per value as the oracle's sequential box_box (oracle/rp_oracle.c): SAT over
+ * 15 axes with first-wins tie tolerance, edge-edge closest points or reference-face clipping (Sutherland-Hodgman, a
+ * polygon never exceeds 8 vertices), at most 4 points kept around the deepest.  Here the 15 axis tests run one per
+ * lane, the clip handles one polygon edge per lane (ballot + popcount give every output vertex its place, in the
+ * sequential order), and all intermediate data sits in registers or in a 96-float LDS scratch per pair - no private
+ * (scratch) memory. */
+#define NPG 8
+#define NPG_SCRATCH 96         /* sv[16] | poly[2][8][3] | kept[8][4] */
+__device__ __forceinline__ V3 pick3(int i, V3 a, V3 b, V3 c) { return i == 0 ? a : (i == 1 ? b : c); }
+__device__ __forceinline__ float pick1(int i, float a, float b, float c) { return i == 0 ? a : (i == 1 ? b : c); }
+
+__device__ void narrowphase_coop(const DevModel* m, EnvLds& L, int lane, int nact) {
+  const int g = lane >> 3, s = lane & 7;
+  float* scr = &L.srow[NPG_SCRATCH * g];
+  float* sv = scr;
+  float (*poly)[8][3] = (float (*)[8][3])(scr + 16);
+  float (*kept)[4] = (float (*)[4])(scr + 64);
+  const unsigned below = (1u << s) - 1u;
+  const float margin = K_MARGIN;
+  for (int base = 0; base < nact; base += 64 / NPG) {      /* wave-uniform trip count; every lane reaches every barrier */
+    const int ai = base + g;
+    const bool act = ai < nact;
+    const int pi = act ? L.u.c.act[ai] : 0;
+    const int a = m->pair[pi][0], b = m->pair[pi][1];
+    const int ta = m->col_type[a], tb = m->col_type[b];
+    const bool bb = act && ta == 0 && tb == 0;
+    const Xf xa = collider_xf(m, L, a), xb = collider_xf(m, L, b);
+    const V3 ha = ld3(m->col_he[a]), hb = ld3(m->col_he[b]);
+    int np = 0;
+    if (act && !bb && s == 0) {                              /* sphere against box: one lane, closed form */
+      CPt pts[1];
+      if (ta == 0 && tb == 1) np = sphere_box(xb.p, hb.x, xa.p, xa.R, ha, margin, 1, pts);
+      else if (ta == 1 && tb == 0) np = sphere_box(xa.p, ha.x, xb.p, xb.R, hb, margin, 0, pts);
+      if (np > 0) {
+        float* c = &L.u.c.cand[(ai * 4) * 8];
+        st3(c, pts[0].p); st3(c + 3, pts[0].n); c[6] = pts[0].dist; c[7] = __int_as_float(pi);
+      }
+    }
+    /* ---- box against box */
+    const V3 ca = xa.p, cb = xb.p;
+    const V3 A0 = col(xa.R, 0), A1 = col(xa.R, 1), A2 = col(xa.R, 2), B0 = col(xb.R, 0), B1 = col(xb.R, 1), B2 = col(xb.R, 2);
+    const V3 t = ca - cb;
+    auto axis = [&](int ax, bool& valid) {                   /* separating-axis candidate number ax: 0-2 A faces, 3-5 B faces, 6-14 edges */
+      valid = true;
+      if (ax < 3) return pick3(ax, A0, A1, A2);
+      if (ax < 6) return pick3(ax - 3, B0, B1, B2);
+      int e = ax - 6, i = e / 3, j = e - 3 * i;
+      V3 c = cross(pick3(i, A0, A1, A2), pick3(j, B0, B1, B2));
+      float l = norm(c);
+      valid = !(l < 1e-6f);
+      return c * (1.f / l);
+    };
+#pragma unroll
+    for (int round = 0; round < 2; round++) {
+      int ax = 8 * round + s;
+      if (bb && ax < 15) {
+        bool valid;
+        V3 Lx = axis(ax, valid);
+        float ra = 0.f, rb = 0.f;
+        ra += ha.x * fabsf(dot(Lx, A0)); rb += hb.x * fabsf(dot(Lx, B0));
+        ra += ha.y * fabsf(dot(Lx, A1)); rb += hb.y * fabsf(dot(Lx, B1));
+        ra += ha.z * fabsf(dot(Lx, A2)); rb += hb.z * fabsf(dot(Lx, B2));
+        float sval = fabsf(dot(t, Lx)) - ra - rb;
+        sv[ax] = valid ? sval : -1e30f;
+      }
+    }
+    __syncthreads();
+    /* decisions, by every lane of the group alike: reject, best face (first-wins with tolerance), best edge */
+    bool reject = !bb;
+    float best_s = -1e30f, edge_s = -1e30f; int best_f = 0, ee = 0;
+    if (bb) {
+#pragma unroll
+      for (int f = 0; f < 6; f++) {
+        float sf = sv[f];
+        reject |= sf > margin;
+        if (sf > best_s + (f == 0 ? 0.f : K_TIE_EPS)) { best_s = sf; best_f = f; }
+      }
+#pragma unroll
+      for (int e = 0; e < 9; e++) {
+        float se = sv[6 + e];
+        reject |= se > margin;
+        if (se > edge_s + K_TIE_EPS) { edge_s = se; ee = e; }
+      }
+    }
+    const bool live = bb && !reject;
+    const bool edge_case = live && edge_s > best_s + 0.05f * fabsf(best_s) + 1e-6f;
+    const bool face_case = live && !edge_case;
+    const int best_kind = best_f < 3 ? 0 : 1, best_i = best_f < 3 ? best_f : best_f - 3;
+    if (edge_case && s == 0) {
+      bool valid;
+      V3 n = axis(6 + ee, valid);
+      int ei = ee / 3, ej = ee - 3 * ei;
+      if (dot(n, t) < 0.f) n = -n;
+      V3 pa = ca, pb = cb;
+      if (ei != 0) pa = pa + A0 * (dot(n, A0) > 0.f ? -ha.x : ha.x);
+      if (ej != 0) pb = pb + B0 * (dot(n, B0) > 0.f ? hb.x : -hb.x);
+      if (ei != 1) pa = pa + A1 * (dot(n, A1) > 0.f ? -ha.y : ha.y);
+      if (ej != 1) pb = pb + B1 * (dot(n, B1) > 0.f ? hb.y : -hb.y);
+      if (ei != 2) pa = pa + A2 * (dot(n, A2) > 0.f ? -ha.z : ha.z);
+      if (ej != 2) pb = pb + B2 * (dot(n, B2) > 0.f ? hb.z : -hb.z);
+      V3 Ae = pick3(ei, A0, A1, A2), Be = pick3(ej, B0, B1, B2);
+      V3 d = pb - pa;
+      float ab = dot(Ae, Be), q1 = dot(Ae, d), q2 = -dot(Be, d);
+      float den = 1.f - ab * ab, sa = 0.f, sb = 0.f;
+      if (den > 1e-9f) { sa = (q1 + ab * q2) / den; sb = (ab * q1 + q2) / den; }
+      V3 xA = pa + Ae * sa, xB = pb + Be * sb;
+      float dist = dot(xA - xB, n);
+      if (dist <= margin) {
+        float* c = &L.u.c.cand[(ai * 4) * 8];
+        st3(c, (xA + xB) * 0.5f); st3(c + 3, n); c[6] = dist; c[7] = __int_as_float(pi);
+        np = 1;
+      }
+    }
+    /* face contact: reference box X (the one owning the best face), incident box Y */
+    const bool kx = best_kind == 0;
+    const V3 cX = kx ? ca : cb, cY = kx ? cb : ca;
+    const V3 X0 = kx ? A0 : B0, X1 = kx ? A1 : B1, X2 = kx ? A2 : B2, Y0 = kx ? B0 : A0, Y1 = kx ? B1 : A1, Y2 = kx ? B2 : A2;
+    const V3 hX = kx ? ha : hb, hY = kx ? hb : ha;
+    V3 nref = pick3(best_i, X0, X1, X2);                     /* == best_L */
+    if (dot(nref, cY - cX) < 0.f) nref = -nref;
+    int j = 0; float bj = -1.f;
+    { float v0 = fabsf(dot(nref, Y0)), v1 = fabsf(dot(nref, Y1)), v2 = fabsf(dot(nref, Y2));
+      if (v0 > bj + K_TIE_EPS) { bj = v0; j = 0; }
+      if (v1 > bj + K_TIE_EPS) { bj = v1; j = 1; }
+      if (v2 > bj + K_TIE_EPS) { bj = v2; j = 2; } }
+    const V3 Yj = pick3(j, Y0, Y1, Y2);
+    const float sj = dot(nref, Yj) > 0.f ? -1.f : 1.f;
+    const int k1 = j == 2 ? 0 : j + 1, k2 = j == 0 ? 2 : j - 1;             /* (j + 1) % 3, (j + 2) % 3 */
+    const V3 Yk1 = pick3(k1, Y0, Y1, Y2), Yk2 = pick3(k2, Y0, Y1, Y2);
+    const float hYj = pick1(j, hY.x, hY.y, hY.z), hYk1 = pick1(k1, hY.x, hY.y, hY.z), hYk2 = pick1(k2, hY.x, hY.y, hY.z);
+    const V3 fc = cY + Yj * (sj * hYj);
+    if (face_case && s < 4) {
+      float sg0 = (s == 0 || s == 3) ? 1.f : -1.f, sg1 = s < 2 ? 1.f : -1.f;
+      st3(poly[0][s], fc + Yk1 * (sg0 * hYk1) + Yk2 * (sg1 * hYk2));
+    }
+    const int u1 = best_i == 2 ? 0 : best_i + 1, u2 = best_i == 0 ? 2 : best_i - 1;
+    const V3 Xu1 = pick3(u1, X0, X1, X2), Xu2 = pick3(u2, X0, X1, X2);
+    const float hXu1 = pick1(u1, hX.x, hX.y, hX.z), hXu2 = pick1(u2, hX.x, hX.y, hX.z), hXi = pick1(best_i, hX.x, hX.y, hX.z);
+    int n = 4, cur = 0;
+#pragma unroll
+    for (int pass = 0; pass < 4; pass++) {
+      __syncthreads();
+      const V3 u = pass < 2 ? Xu1 : Xu2;
+      const float h = pass < 2 ? hXu1 : hXu2, sign = (pass & 1) ? -1.f : 1.f;
+      bool k0 = false, kc = false; V3 va = mk3(0, 0, 0), vb = va; float da = 0.f, db = 0.f;
+      if (face_case && s < n) {
+        va = ld3(poly[cur][s]);
+        vb = ld3(poly[cur][(s + 1 == n) ? 0 : s + 1]);
+        da = sign * dot(va - cX, u) - h;
+        db = sign * dot(vb - cX, u) - h;
+        k0 = da <= 0.f;
+        kc = (da < 0.f && db > 0.f) || (da > 0.f && db < 0.f);
+      }
+      unsigned m0 = (unsigned)(__ballot(k0) >> (8 * g)) & 0xFFu, m1 = (unsigned)(__ballot(kc) >> (8 * g)) & 0xFFu;
+      int off = __popc(m0 & below) + __popc(m1 & below);
+      if (k0) st3(poly[cur ^ 1][off], va);
+      if (kc) { float tt = da / (da - db); st3(poly[cur ^ 1][off + (k0 ? 1 : 0)], va + (vb - va) * tt); }
+      n = __popc(m0) + __popc(m1);
+      cur ^= 1;
+    }
+    __syncthreads();
+    bool keep = false; V3 pv = mk3(0, 0, 0); float dist = 0.f;
+    if (face_case && s < n) {
+      pv = ld3(poly[cur][s]);
+      dist = dot(pv - cX, nref) - hXi;
+      keep = !(dist > margin);
+    }
+    unsigned mk = (unsigned)(__ballot(keep) >> (8 * g)) & 0xFFu;
+    const int cnt = __popc(mk);
+    if (keep) { float* kp = kept[__popc(mk & below)]; st3(kp, pv - nref * (0.5f * dist)); kp[3] = dist; }
+    __syncthreads();
+    if (face_case) {
+      int deepest = 0;
+      for (int c = 1; c < cnt; c++) if (kept[c][3] < kept[deepest][3] - K_TIE_EPS) deepest = c;
+      const V3 nn = best_kind == 1 ? nref : -nref;
+      const int outn = cnt <= 4 ? cnt : 4;
+      if (s < outn) {
+        int src = cnt <= 4 ? s : (deepest + (s * cnt) / 4) % cnt;
+        float* c = &L.u.c.cand[(ai * 4 + s) * 8];
+        st3(c, ld3(kept[src])); st3(c + 3, nn); c[6] = kept[src][3]; c[7] = __int_as_float(pi);
+      }
+      np = outn;
+    }
+    if (act && s == 0) {
+      L.u.c.candn[ai] = np;
+      L.u.c.key[ai] = m->col_obj[a] * 256 + m->col_obj[b];
+    }
+    __syncthreads();       /* the scratch is reused by the next pass */
+  }
+}
+
 /* btPersistentManifold::sortCachedPoints on points stored as 8-float records (p3 n3 dist pad) */
 __device__ int manifold_replace_index(const float* c4, const float* pt) {
   int deepest = -1; float maxpen = pt[6];
@@ -384,11 +493,19 @@ __device__ int manifold_replace_index(const float* c4, const float* pt) {
 __device__ int collide(const DevModel* m, EnvLds& L, int lane) {
   /* 1. AABB sweep over the baked candidate pairs, 64 per pass; keep the first MAXACT overlapping, in order */
   int nact = 0;
-  for (int base = 0; base < m->n_pair; base += 64) {
+  const int npair = m->n_pair;
+  const unsigned short* pp = (const unsigned short*)m->pair;      /* two collider indices per entry, low byte first */
+  unsigned short pv[RP_MAX_PAIR / 64];
+#pragma unroll
+  for (int k = 0; k < RP_MAX_PAIR / 64; k++) { int pi = 64 * k + lane; pv[k] = pp[pi < npair ? pi : 0]; }   /* all loads in flight at once */
+#pragma unroll
+  for (int k = 0; k < RP_MAX_PAIR / 64; k++) {
+    int base = 64 * k;
+    if (base >= npair) break;
     int pi = base + lane;
     bool ov = false;
-    if (pi < m->n_pair) {
-      int a = m->pair[pi][0], b = m->pair[pi][1];
+    if (pi < npair) {
+      int a = pv[k] & 255, b = pv[k] >> 8;
       const float* A = &L.u.c.aabb[6 * a];
       const float* Bb = &L.u.c.aabb[6 * b];
       ov = !(A[0] > Bb[3] + K_MARGIN || Bb[0] > A[3] + K_MARGIN || A[1] > Bb[4] + K_MARGIN || Bb[1] > A[4] + K_MARGIN ||
@@ -401,25 +518,17 @@ __device__ int collide(const DevModel* m, EnvLds& L, int lane) {
     if (nact >= MAXACT) { nact = MAXACT; break; }
   }
   __syncthreads();
-  /* 2. narrowphase: one lane per active pair */
-  if (lane < nact) {
-    int pi = L.u.c.act[lane];
-    int a = m->pair[pi][0], b = m->pair[pi][1];
-    Xf xa = collider_xf(m, L, a), xb = collider_xf(m, L, b);
-    V3 ha = ld3(m->col_he[a]), hb = ld3(m->col_he[b]);
-    CPt pts[4]; int np = 0;
-    int ta = m->col_type[a], tb = m->col_type[b];
-    if (ta == 0 && tb == 0) np = box_box(xa.p, xa.R, ha, xb.p, xb.R, hb, K_MARGIN, pts);
-    else if (ta == 0 && tb == 1) np = sphere_box(xb.p, hb.x, xa.p, xa.R, ha, K_MARGIN, 1, pts);
-    else if (ta == 1 && tb == 0) np = sphere_box(xa.p, ha.x, xb.p, xb.R, hb, K_MARGIN, 0, pts);
-    for (int i = 0; i < np; i++) {
-      float* c = &L.u.c.cand[(lane * 4 + i) * 8];
-      st3(c, pts[i].p); st3(c + 3, pts[i].n); c[6] = pts[i].dist; c[7] = __int_as_float(pi);
-    }
-    L.u.c.candn[lane] = np;
-    L.u.c.key[lane] = m->col_obj[a] * 256 + m->col_obj[b];
-  }
+  PCLK(8)
+#if defined(RP_CLOCKS) && RP_CLOCKS == 2
+  if (lane == 0) g_clk[16 * blockIdx.x + 12] = nact;
+#endif
+  /* 2. narrowphase: eight lanes per active pair (scratch in srow | rowS | rowT, dead until the rows are built) */
+  static_assert(offsetof(EnvLds, rowS) == offsetof(EnvLds, srow) + sizeof(float) * MAXSMALL * 8 &&
+                offsetof(EnvLds, rowT) == offsetof(EnvLds, rowS) + sizeof(float) * MAXROWC * 4 &&
+                NPG_SCRATCH * (64 / NPG) <= MAXSMALL * 8 + MAXROWC * 8, "scratch aliasing needs srow|rowS|rowT contiguous");
+  narrowphase_coop(m, L, lane, nact);
   __syncthreads();
+  PCLK(9)
   /* 3. manifolds: the first lane of each run of equal object pairs merges the run sequentially (<= 4 points) */
   int mycnt = 0;
   if (lane < nact) {
@@ -463,6 +572,7 @@ __device__ int collide(const DevModel* m, EnvLds& L, int lane) {
   }
   for (int j = 0; j < nact; j++) total += L.u.c.cnt[j];     /* nact uniform; LDS broadcast reads */
   __syncthreads();
+  PCLK(10)
   return total < MAXC ? total : MAXC;
 }
 
@@ -1579,6 +1689,7 @@ __global__ void __launch_bounds__(64, RP_PREP_WAVES) k_prep2(const DevModel* __r
   __shared__ EnvLds L;
   int env = env0 + blockIdx.x, lane = threadIdx.x;
   if (env >= N) return;
+  PCLK(6) PCLK(0)
   load_state(L, state, env, lane);
 #ifdef RP_PREP_STOP   /* timing ablations only: leave after phase RP_PREP_STOP */
 #define PREP_STOP(k) if (RP_PREP_STOP == (k)) { if (lane == 0) ws[(size_t)env * W3_FLOATS] = L.st[0]; return; }
@@ -1592,16 +1703,20 @@ __global__ void __launch_bounds__(64, RP_PREP_WAVES) k_prep2(const DevModel* __r
   collider_aabbs(m, L, lane);
   __syncthreads();
   PREP_STOP(1)
+  PCLK(1)
   int ncon = collide(m, L, lane);
   PREP_STOP(2)
+  PCLK(2)
   arm_dynamics(m, L, lane);
   unconstrained_velocities(m, L, lane);
   PREP_STOP(3)
+  PCLK(3)
   int nsmall = build_small_rows(m, L, lane);
   contact_rows(m, L, lane, ncon);
   for (int i = lane; i < AOUT_FLOATS; i += 64) L.aout[i] = 0.f;
   if (lane < 2) L.amask[lane] = 0u;
   __syncthreads();
+  PCLK(4)
   L.roff[lane] = lane < 3 * ncon ? (__float_as_int(L.rowT[4 * lane + 2]) | (__float_as_int(L.rowT[4 * lane + 3]) << 8)) : 0;
   PREP_STOP(4)
   nsmall = uni(nsmall);
@@ -1658,6 +1773,7 @@ __global__ void __launch_bounds__(64, RP_PREP_WAVES) k_prep2(const DevModel* __r
   copy_out(w + W3_ROFF, (const float*)L.roff, 64, lane);
   copy_out(w + W3_J, L.u.r.J, (ROWW * 3 * ncon + 3) & ~3, lane);
   copy_out(w + W3_B, L.u.r.B, (ROWW * 3 * ncon + 3) & ~3, lane);
+  PCLK(5) PCLK(7)
 }
 
 struct __align__(16) Solve2Lds {
@@ -1787,20 +1903,13 @@ __device__ __forceinline__ void generic_row(float Jr, float Br, float& dv, Plane
         : "vcc");
 }
 
-#ifdef RP_CLOCKS      /* profiling build only: per-wave phase timestamps of the last k_solve2 launch */
-__device__ unsigned long long g_clk[8 * 4096];
-#define CLK_MARK(i) if (lane == 0) { g_clk[8 * blockIdx.x + (i)] = __builtin_readcyclecounter(); }
-#else
-#define CLK_MARK(i)
-#endif
-
 __global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m, float* __restrict__ state, const float* __restrict__ ws, int env0, int N) {
   __shared__ Solve2Lds L;
   const int lane = threadIdx.x, half = lane >> 5, l = lane & 31, grp = l >> 4, l16 = lane & 15;
-#ifdef RP_CLOCKS
+#if defined(RP_CLOCKS) && RP_CLOCKS != 2
   if (lane == 0) g_clk[8 * blockIdx.x + 4] = wall_clock64();
 #endif
-  CLK_MARK(0)
+  CLK_MARK2(0)
 #ifdef RP_SOLVE_PAD_KB
   if (N < 0) L.pad[lane] = 0.f;
 #endif
@@ -1921,7 +2030,7 @@ __global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);    /* vmcnt(0): all row registers have landed before the sweep loop */
   __syncthreads();
-  CLK_MARK(1)
+  CLK_MARK2(1)
   float dv = 0.f;
   /* in-loop copies of the guards: kept in SGPRs and re-read every sweep so that they stay s_cmp + s_cbranch */
 #define SWEEP_GUARDS                                                                                     \
@@ -2041,7 +2150,7 @@ __global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m
   float* st = L.st[half];
   float vnew = vstar + dv;
   __syncthreads();
-  CLK_MARK(2)
+  CLK_MARK2(2)
   if (dd >= 0) {
     if (dd < n) {
       st[ST_QD + dd] = vnew;
@@ -2076,7 +2185,7 @@ __global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m
     float* r = state + (size_t)env * RP_REC_FLOATS;
     for (int k = l; k < RP_REC_FLOATS; k += 32) r[k] = st[k];
   }
-#ifdef RP_CLOCKS
+#if defined(RP_CLOCKS) && RP_CLOCKS != 2
   CLK_MARK(3)
   if (lane == 0) {
     g_clk[8 * blockIdx.x + 5] = wall_clock64();

@@ -282,10 +282,15 @@ int rp_debug_row_counts(rp_handle h, int32_t* host_buf) {
 }
 
 #ifdef RP_CLOCKS
+#if RP_CLOCKS == 2
+#define RP_CLK_STRIDE 16
+#else
+#define RP_CLK_STRIDE 8
+#endif
 int rp_debug_clocks(rp_handle h, uint64_t* host_buf, int32_t nblocks) {
   if (!h || !host_buf || nblocks > 4096) return RP_ERR_ARG;
   HIPCHK(h, hipDeviceSynchronize());
-  HIPCHK(h, hipMemcpyFromSymbol(host_buf, HIP_SYMBOL(g_clk), (size_t)nblocks * 8 * sizeof(uint64_t)));
+  HIPCHK(h, hipMemcpyFromSymbol(host_buf, HIP_SYMBOL(g_clk), (size_t)nblocks * RP_CLK_STRIDE * sizeof(uint64_t)));
   return RP_OK;
 }
 #endif

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Per-wave phase timestamps of the last k_prep2 launch (profiling build: hipcc -DRP_CLOCKS=2, RP_PLAYROOM_LIB=clocks2.so).
+columns: 0 start, 1 after FK/AABB, 2 after collide, 3 after dynamics, 4 after rows, 5 end (shader clock); 6/7 start/end wall clock (100 MHz)"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from roboticsplayroompybullet_amd import VecPlayEnv  # noqa: E402
+import bench  # noqa: E402
+
+n = int(os.environ.get('N_ENVS', '4096'))
+steps = int(os.environ.get('STEPS', '30'))
+env = VecPlayEnv(bench.ENV_ID, n, seed=1234)
+env.set_groups(1)
+env.reset()
+acts = bench.make_actions(n, steps, env.device, 1234)
+for k in range(steps):
+    env.step(acts[k])
+torch.cuda.synchronize()
+buf = (C.c_uint64 * (16 * n))()
+env.lib.rp_debug_clocks.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+assert env.lib.rp_debug_clocks(env.h, buf, n) == 0
+a = np.frombuffer(buf, dtype=np.uint64).reshape(n, 16).astype(np.int64)
+w0, w1 = a[:, 6] - a[:, 6].min(), a[:, 7] - a[:, 6].min()
+print('waves', n, 'kernel span %.1f us' % (w1.max() / 100.0))
+print('start offsets us: p10 %.1f p50 %.1f p90 %.1f max %.1f' % tuple(np.percentile(w0, [10, 50, 90, 100]) / 100.0))
+print('end offsets us:   p10 %.1f p50 %.1f p90 %.1f max %.1f' % tuple(np.percentile(w1, [10, 50, 90, 100]) / 100.0))
+names = ['load+FK+AABB', 'collide', 'dynamics', 'rows', 'output']
+for i, nm in enumerate(names):
+    d = a[:, i + 1] - a[:, i]
+    print('%-14s cycles: p10 %d p50 %d p90 %d max %d' % ((nm,) + tuple(np.percentile(d, [10, 50, 90, 100]))))
+tot = a[:, 5] - a[:, 0]
+print('%-14s cycles: p10 %d p50 %d p90 %d max %d' % (('total',) + tuple(np.percentile(tot, [10, 50, 90, 100]))))
+for nm, i0, i1 in (('  broadphase', 1, 8), ('  narrowphase', 8, 9), ('  manifolds', 9, 10), ('  collide tail', 10, 2)):
+    d = a[:, i1] - a[:, i0]
+    print('%-14s cycles: p10 %d p50 %d p90 %d max %d' % ((nm,) + tuple(np.percentile(d, [10, 50, 90, 100]))))
+na = a[:, 12]
+print('active pairs: p10 %d p50 %d p90 %d max %d' % tuple(np.percentile(na, [10, 50, 90, 100])))
+npd = (a[:, 9] - a[:, 8]).astype(float)
+print('narrowphase cycles vs active pairs: corr %.2f' % np.corrcoef(na, npd)[0, 1])
+late = w0 > np.percentile(w0, 50)
+print('first-round waves: total p50 %d; second-round waves: total p50 %d' % (np.median(tot[~late]), np.median(tot[late])))
