@@ -139,6 +139,11 @@ __device__ __forceinline__ float lane_read(float v, int src_lane_uniform) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane_uniform));
 }
 
+__device__ __forceinline__ double readlane_d(double v, int src_lane_uniform) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane_uniform), hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane_uniform);
+  return __hiloint2double(hi, lo);
+}
+
 /* sum over lanes 0..31 (lanes 32..63 must hold 0); result in every lane.  DPP butterflies inside rows of 16. */
 __device__ __forceinline__ float wave_sum32(float v) {
   int x = __float_as_int(v);
@@ -610,6 +615,7 @@ __device__ void arm_dynamics(const DevModel* m, EnvLds& L, int lane) {
     st6(&L.u.d.Fv[6 * lane], inertia_mul(acc, Si));
   }
   __syncthreads();
+  PCLK(11)
   for (int e = lane; e < n * n; e += 64) {   /* M_ij = S_i . (Ic_j S_j) for i an ancestor-or-self of j, accumulated in fp64 */
     int i = e / n, j = e % n;
     if (i <= j) {
@@ -638,44 +644,49 @@ __device__ void arm_dynamics(const DevModel* m, EnvLds& L, int lane) {
     for (int j = 0; j < n; j++) if ((sub >> j) & 1u) f = f + ld6(&L.u.d.fsp[6 * j]);
     L.tau[lane] = dot6(ld6(&L.S[6 * lane]), f);
   }
-  /* Cholesky M = L L^T in place (lower), lane i owns row i; fp64 */
-  for (int k = 0; k < n; k++) {
-    __syncthreads();
-    double piv = sqrt(L.u.d.Md[k * 12 + k]);
-    double lik = 0.0;
-    if (lane > k && lane < n) lik = L.u.d.Md[lane * 12 + k] / piv;
-    __syncthreads();
-    if (lane == k) L.u.d.Md[k * 12 + k] = piv;
-    if (lane > k && lane < n) L.u.d.Md[lane * 12 + k] = lik;
-    __syncthreads();
-    if (lane > k && lane < n)
-      for (int j = k + 1; j <= lane; j++) L.u.d.Md[lane * 12 + j] -= lik * L.u.d.Md[j * 12 + k];
-  }
+  PCLK(13)
+  /* Cholesky M = L L^T and M^-1 = L^-T L^-1 in fp64, entirely in registers: lane i holds row i of M (then of L), the
+   * entries of other rows arrive by v_readlane (k, j are compile-time, so every register index is static) - no LDS
+   * traffic and no barriers inside the 12-step elimination.  Pivots enter as reciprocals (1/sqrt once per column). */
   __syncthreads();
-  if (lane < n) {      /* column `lane` of M^-1: L y = e_c, L^T x = y */
+  {
+    const int li = lane < RP_MAX_ARM ? lane : 0;
+    double row[RP_MAX_ARM], invd[RP_MAX_ARM];
+#pragma unroll
+    for (int j = 0; j < RP_MAX_ARM; j++) row[j] = (lane < n && j < n) ? L.u.d.Md[li * 12 + j] : (j == lane ? 1.0 : 0.0);   /* identity padding beyond n */
+#pragma unroll
+    for (int k = 0; k < RP_MAX_ARM; k++) {
+      double mkk = readlane_d(row[k], k);
+      double rp = rsqrt(mkk);
+      invd[k] = rp;
+      double lik = row[k] * rp;                 /* lane k: sqrt(m_kk); lanes > k: L_ik; lanes < k: unused upper part */
+      row[k] = lik;
+#pragma unroll
+      for (int j = k + 1; j < RP_MAX_ARM; j++) row[j] -= lik * readlane_d(lik, j);
+    }
+    /* column `lane` of M^-1: L y = e_lane, L^T x = y */
     double y[RP_MAX_ARM];
 #pragma unroll
     for (int i = 0; i < RP_MAX_ARM; i++) {
-      if (i < n) {
-        double s = (i == lane) ? 1.0 : 0.0;
+      double sacc = (i == lane) ? 1.0 : 0.0;
 #pragma unroll
-        for (int k = 0; k < i; k++) s -= L.u.d.Md[i * 12 + k] * y[k];
-        y[i] = s / L.u.d.Md[i * 12 + i];
-      } else y[i] = 0.0;
+      for (int k = 0; k < i; k++) sacc -= readlane_d(row[k], i) * y[k];
+      y[i] = sacc * invd[i];
     }
 #pragma unroll
     for (int i = RP_MAX_ARM - 1; i >= 0; i--) {
-      if (i < n) {
-        double s = y[i];
+      double sacc = y[i];
 #pragma unroll
-        for (int k = i + 1; k < RP_MAX_ARM; k++) if (k < n) s -= L.u.d.Md[k * 12 + i] * y[k];
-        y[i] = s / L.u.d.Md[i * 12 + i];
-      }
+      for (int k = i + 1; k < RP_MAX_ARM; k++) sacc -= readlane_d(row[i], k) * y[k];
+      y[i] = sacc * invd[i];
     }
+    if (lane < n) {
 #pragma unroll
-    for (int i = 0; i < RP_MAX_ARM; i++) if (i < n) L.Minv[i * 12 + lane] = (float)y[i];
+      for (int i = 0; i < RP_MAX_ARM; i++) if (i < n) L.Minv[i * 12 + lane] = (float)y[i];
+    }
   }
   __syncthreads();
+  PCLK(14)
 }
 
 /* unconstrained velocities v* = v + dt * a for every dof (lane = dof) */
@@ -924,10 +935,12 @@ __device__ void contact_rows(const DevModel* m, EnvLds& L, int lane, int ncon) {
  * while row r's dependent chain (multiply -> DPP reduction -> clamp -> axpy) runs.
  * Friction limits are lo = lo_c - mu*lambda[parent], hi = hi_c + mu*lambda[parent]; normal rows carry mu = 0,
  * lo_c = 0, hi_c = 1e10 and a dummy parent, which reproduces [0, 1e10] exactly without a branch. */
-__device__ __forceinline__ float pgs_update(float rhs, float jdvd, float lam, float lo, float hi, float& lam_out) {
-  /* jdvd = (J * dinv) . dv (dinv folded into the stored row).  Delta form, as Bullet's row solver: the unclamped step
-   * rhs - jdvd is clamped to [lo - lam, hi - lam], then lam += d */
-  float d = __builtin_amdgcn_fmed3f(rhs - jdvd, lo - lam, hi - lam);
+__device__ __forceinline__ float pgs_update(float delta, float lam, float lo, float hi, float& lam_out) {
+  /* delta = rhs - (J * dinv) . dv (dinv folded into the stored row): the unclamped step.  Delta form, as Bullet's row
+   * solver: the step is clamped to [lo - lam, hi - lam], then lam += d.  Rounding contract shared with k_solve2: the
+   * products J_i dv_i are rounded on their own and summed (DPP butterfly; a unit row has one product), and every row
+   * ends with the fused dv = fma(B, d, dv). */
+  float d = __builtin_amdgcn_fmed3f(delta, lo - lam, hi - lam);
   lam_out = lam + d;
   return d;
 }
@@ -961,12 +974,16 @@ __device__ float solve_rows(const DevModel* m, LDS& L, int lane, int nsmall_, in
           else if (lane < n) bn = t2 == SR_UNIT ? g2 * L.Minv[lane * 12 + a2] : L.Minv[lane * 12 + a2] + g2 * L.Minv[lane * 12 + b2];
         }
         float sg = c0.z, jA = c1.x;      /* c1.x = dinv = the folded J entry at dofA */
-        float jdv = type == SR_UNIT ? (sg * jA) * lane_read(dv, dA)
-                                    : (type == SR_J1 ? jA * lane_read(dv, uni(lane_pos(m, dA))) : jA * lane_read(dv, dA) + (sg * jA) * lane_read(dv, dB));
+        float delta;
+        float jdv;           /* products rounded on their own (no contraction across statements), as in k_solve2 */
+        if (type == SR_UNIT) jdv = (sg * jA) * lane_read(dv, dA);
+        else if (type == SR_J1) jdv = jA * lane_read(dv, uni(lane_pos(m, dA)));
+        else { float pa = jA * lane_read(dv, dA); float pb = (sg * jA) * lane_read(dv, dB); jdv = pa + pb; }
+        delta = c0.w - jdv;
         float lam = lane_read(lamS, r), lnew;
-        float d = pgs_update(c0.w, jdv, lam, c1.y, c1.z, lnew);
+        float d = pgs_update(delta, lam, c1.y, c1.z, lnew);
         lamS = lane == r ? lnew : lamS;
-        dv += bl * d;
+        dv = fmaf(bl, d, dv);
       }
     }
     if (nrc > 0) {   /* contact normals then frictions: compact rows, scalars two rows ahead, J/B one row ahead */
@@ -982,7 +999,7 @@ __device__ float solve_rows(const DevModel* m, LDS& L, int lane, int nsmall_, in
       }
       for (int r = 0; r < nrc; r++) {
         float jl = jn, bl = bn;
-        float rhs = sn.x, mu = sn.z, lo_c = tn.x, hi_c = tn.y;
+        float rhs = sn.x, mu = sn.z, lo_c = 0.f, hi_c = tn.y;      /* contact rows: lower bound 0 (tn.x carries a flag) */
         int parent = uni(__float_as_int(sn.w));
         sn = s2; tn = t2;
         if (r + 1 < nrc) {
@@ -995,12 +1012,13 @@ __device__ float solve_rows(const DevModel* m, LDS& L, int lane, int nsmall_, in
         float lamv = r < 64 ? lamC0 : lamC1;
         float lam = lane_read(lamv, r & 63);
         float lim = mu * lane_read(lamC0, parent);            /* parent < ncon <= MAXC */
-        float jdv = wave_sum32(jl * dv), lnew;
-        float d = pgs_update(rhs, jdv, lam, lo_c - lim, hi_c + lim, lnew);
+        float prod = jl * dv;
+        float jdv = wave_sum32(prod), lnew;
+        float d = pgs_update(rhs - jdv, lam, lo_c - lim, hi_c + lim, lnew);
         float sel = lane == (r & 63) ? lnew : lamv;
         lamC0 = r < 64 ? sel : lamC0;
         lamC1 = r < 64 ? lamC1 : sel;
-        dv += bl * d;
+        dv = fmaf(bl, d, dv);
       }
     }
   }
@@ -1830,18 +1848,17 @@ __device__ __forceinline__ void fplane_begin(Plane& p, float lim) { p.loP = (0.f
 
 /* unit row of the dof at lane I of its DPP row: the step forms in that lane from its own plane entries (delta form:
  * d = clamp(rhs - Jd dv, lo - lam, hi - lam)), one broadcast spreads it, col = B column of the row.
- * 7 instructions; dependent chain mul, sub, med3, (2 wait states), broadcast-multiply, add */
+ * 6 instructions; dependent chain mul, sub, med3, (2 wait states), broadcast-fmac */
 template <int I>
 __device__ __forceinline__ void unit_row(float jd, float col, float& dv, Plane& p, int l16) {
   float t;
   asm volatile(
-      "v_mul_f32 %[t], %[jd], %[dv]\n"
+      "v_mul_f32 %[t], %[jd], %[dv]\n"                 /* two roundings, like the general row this row may be merged into */
       "v_sub_f32 %[t], %[rhs], %[t]\n"
       "v_med3_f32 %[t], %[t], %[lo], %[hi]\n"
       "v_cmp_eq_u32_e32 vcc, %[k], %[l16]\n"            /* the two wait states between med3 and the DPP read */
       "v_cndmask_b32_e32 %[dacc], %[dacc], %[t], vcc\n"
-      "v_mul_f32_dpp %[t], %[t], %[col] row_newbcast:%[k]" DPP_ALL
-      "v_add_f32 %[dv], %[dv], %[t]\n"
+      "v_fmac_f32_dpp %[dv], %[t], %[col] row_newbcast:%[k]" DPP_ALL
       : [dv] "+v"(dv), [dacc] "+v"(p.dacc), [t] "=&v"(t)
       : [jd] "v"(jd), [col] "v"(col), [rhs] "v"(p.rhs), [lo] "v"(p.loP), [hi] "v"(p.hiP), [l16] "v"(l16), [k] "n"(I & 15)
       : "vcc");
@@ -1870,8 +1887,7 @@ __device__ __forceinline__ void generic_row(float Jr, float Br, float& dv, Plane
         "v_sub_f32 %[t], %[r], %[t]\n"
         "v_med3_f32 %[t], %[t], %[lo], %[hi]\n"
         "v_cndmask_b32_e32 %[dacc], %[dacc], %[t], vcc\n"
-        "v_mul_f32 %[r], %[B], %[t]\n"
-        "v_add_f32 %[dv], %[dv], %[r]\n"
+        "v_fmac_f32 %[dv], %[B], %[t]\n"
         : [dv] "+v"(dv), [dacc] "+v"(p.dacc), [t] "=&v"(t), [r] "=&v"(r), [lo] "=&v"(lo), [hi] "=&v"(hi)
         : [J] "v"(Jr), [B] "v"(Br), [rhs] "v"(p.rhs), [lop] "v"(p.loP), [hip] "v"(p.hiP), [l16] "v"(l16), [k] "n"(K & 15)
         : "vcc");
@@ -1896,8 +1912,7 @@ __device__ __forceinline__ void generic_row(float Jr, float Br, float& dv, Plane
         "v_sub_f32 %[t], %[r], %[t]\n"
         "v_med3_f32 %[t], %[t], %[lo], %[hi]\n"
         "v_cndmask_b32_e32 %[dacc], %[dacc], %[t], vcc\n"
-        "v_mul_f32 %[r], %[B], %[t]\n"
-        "v_add_f32 %[dv], %[dv], %[r]\n"
+        "v_fmac_f32 %[dv], %[B], %[t]\n"
         : [dv] "+v"(dv), [dacc] "+v"(p.dacc), [t] "=&v"(t), [r] "=&v"(r), [lo] "=&v"(lo), [hi] "=&v"(hi), [u] "=&v"(u)
         : [J] "v"(Jr), [B] "v"(Br), [rhs] "v"(p.rhs), [lop] "v"(p.loP), [hip] "v"(p.hiP), [l16] "v"(l16), [k] "n"(K & 15)
         : "vcc");
@@ -2118,9 +2133,10 @@ __global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m
       plane_end(PM); plane_end(PL); plane_end(PU);
       plane_begin(PB[1]);                                      /* first read 13 rows later: no fence needed */
       {                                                        /* scene-joint motors: lane-local, all at once (no-op without joints) */
-        float d = __builtin_amdgcn_fmed3f(PB[0].rhs - jdJ * dv, PB[0].loP, PB[0].hiP);
+        float pj = jdJ * dv;
+        float d = __builtin_amdgcn_fmed3f(PB[0].rhs - pj, PB[0].loP, PB[0].hiP);
         PB[0].dacc = (!row0 && l16 < LBL_N) ? d : PB[0].dacc;
-        dv += colJ * d;
+        dv = fmaf(colJ, d, dv);
       }
 #define SEQ_N(c) if (nc_it <= (c)) goto seq_ndone; generic_row<LBL_N + (c), true, (c)>(JN[c], BN[c], dv, PB[(LBL_N + (c)) >> 4], fm_it, l16);
       REP21(SEQ_N, 0)

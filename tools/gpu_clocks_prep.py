@@ -38,6 +38,9 @@ print('%-14s cycles: p10 %d p50 %d p90 %d max %d' % (('total',) + tuple(np.perce
 for nm, i0, i1 in (('  broadphase', 1, 8), ('  narrowphase', 8, 9), ('  manifolds', 9, 10), ('  collide tail', 10, 2)):
     d = a[:, i1] - a[:, i0]
     print('%-14s cycles: p10 %d p50 %d p90 %d max %d' % ((nm,) + tuple(np.percentile(d, [10, 50, 90, 100]))))
+for nm, i0, i1 in (('  inertia+comp', 2, 11), ('  M, bias, tau', 11, 13), ('  chol+inverse', 13, 14), ('  vstar etc', 14, 3)):
+    d = a[:, i1] - a[:, i0]
+    print('%-14s cycles: p10 %d p50 %d p90 %d max %d' % ((nm,) + tuple(np.percentile(d, [10, 50, 90, 100]))))
 na = a[:, 12]
 print('active pairs: p10 %d p50 %d p90 %d max %d' % tuple(np.percentile(na, [10, 50, 90, 100])))
 npd = (a[:, 9] - a[:, 8]).astype(float)
