@@ -176,7 +176,7 @@ def main():
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': pmc_traffic('k_solve2') if n == ENVS_PER_GPU else None, 'kernel': 'k_solve2', 'kernel_ms': solve_ms, 'launches_per_step': 12,
                          'traffic_note': 'bytes per k_solve2 launch from profiles/r01_pmc_summary.json (2*FETCH_SIZE + WRITE_SIZE); '
-                                         'it is ~28x the algorithmic bytes because the constraint rows (~14 KB per env-substep) are '
+                                         'it is ~13x the algorithmic bytes because the constraint rows (~5 KB per env-substep) are '
                                          'handed from k_prep2 to k_solve2 through an Infinity-Cache-resident workspace',
                          'algorithmic_bytes_per_launch': ALG_BYTES_PER_ENV_SUBSTEP * n,
                          'whole_step': {'achieved': step_achieved, 'frac': step_achieved / HBM_PEAK_GBS, 'ms': step_ms,
@@ -185,7 +185,8 @@ def main():
                                            'k_calc_state': tm['avg_obs_ms'], 'steps_timed': tm['steps_timed'],
                                            'how': 'hipEvent pair around every launch on the launch stream (rp_enable_timers), separate '
                                                   'region right after the timed one with the env-group streams switched off'},
-                         'note': 'latency/VALU-issue-bound path (serial PGS chains), not bandwidth-bound; advisory FLOP model '
+                         'note': 'latency-bound path (50 sweeps of dependent PGS row updates per launch; the launch lasts as long as its '
+                                 'heaviest wave), not bandwidth-bound; advisory FLOP model '
                                  '9e6 FLOP/env-step => %.3g of the 157.3 TFLOP/s fp32 vector peak' % (9e6 * n / (step_ms * 1e-3) / 157.3e12)},
             'non_finite_envs': bad, 'success_rate_last_step': success,
         }
