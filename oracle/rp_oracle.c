@@ -425,6 +425,20 @@ static void collide(rpo_env* e) {
       }
     }
   }
+  /* solver order: contacts that span arm and non-arm dofs (arm link against a free body or a scene joint) go last,
+   * everything else keeps its order (stable partition).  Rows on disjoint dof sets commute, so among the first group
+   * the arm-only and the non-arm contacts may be (and, on the GPU, are) solved side by side. */
+  {
+    contact tmp[MAX_CONTACTS]; int k = 0;
+    for (int pass = 0; pass < 2; pass++)
+      for (int i = 0; i < e->ncon; i++) {
+        int ba = m->col_body[e->con[i].ca], bb = m->col_body[e->con[i].cb];
+        int arm = (ba >= 1 && ba <= m->n_arm) || (bb >= 1 && bb <= m->n_arm);
+        int dyn = ba > m->n_arm || bb > m->n_arm;
+        if ((arm && dyn) == pass) tmp[k++] = e->con[i];
+      }
+    for (int i = 0; i < e->ncon; i++) e->con[i] = tmp[i];
+  }
 }
 
 /* ------------------------------------------------------------------ spatial algebra (world-origin Pluecker, [ang; lin]) */

@@ -73,7 +73,7 @@ struct __align__(16) EnvLds {
   float finv[RP_MAX_FREE * 9];
   float vstar[32];
   float conp[MAXC * 3], conn[MAXC * 3], cond[MAXC], conmu[MAXC];
-  int cona[MAXC], conb[MAXC];
+  int cona[MAXC], conb[MAXC], conk[MAXC];     /* colliders of the contact; class: 0 no arm dof, 1 arm only, 2 spanning */
   float srow[MAXSMALL * 8];      /* type, dofA, sign/ratio, rhs | dinv, lo, hi, dofB */
   float rowS[MAXROWC * 4];       /* rhs, dinv, mu, parent */
   float rowT[MAXROWC * 4];       /* lo_c, hi_c, off0, off1 */
@@ -94,6 +94,7 @@ struct __align__(16) EnvLds {
   float aout[192];                /* k_prep2: unit rows in the solver's dof-indexed form */
   unsigned amask[4];
   int roff[64];                   /* k_prep2: slot offsets of the compact contact rows */
+  int slot[64];                   /* k_prep2: contact index by class rank: [0,21) non-arm, [21,42) arm-only, [42,63) spanning */
 };
 
 #ifdef RP_CLOCKS      /* profiling build only: per-wave phase timestamps of the last k_solve2 (1) / k_prep2 (2) launch */
@@ -577,8 +578,34 @@ __device__ int collide(const DevModel* m, EnvLds& L, int lane) {
   }
   for (int j = 0; j < nact; j++) total += L.u.c.cnt[j];     /* nact uniform; LDS broadcast reads */
   __syncthreads();
+  total = total < MAXC ? total : MAXC;
+  /* solver order: contacts that span arm and non-arm dofs (class 2) go last, the others keep their order (stable
+   * partition; same rule in the oracle).  conk[c] = class: 0 no arm dof, 1 arm dofs only, 2 spanning. */
+  {
+    const int n = m->n_arm;
+    int cls = 0; float rec[8]; int ia = 0, ib = 0;
+    if (lane < total) {
+      ia = L.cona[lane]; ib = L.conb[lane];
+      int ba = m->col_body[ia], bb = m->col_body[ib];
+      bool arm = (ba >= 1 && ba <= n) || (bb >= 1 && bb <= n), dyn = ba > n || bb > n;
+      cls = arm ? (dyn ? 2 : 1) : 0;
+      rec[0] = L.conp[3 * lane]; rec[1] = L.conp[3 * lane + 1]; rec[2] = L.conp[3 * lane + 2];
+      rec[3] = L.conn[3 * lane]; rec[4] = L.conn[3 * lane + 1]; rec[5] = L.conn[3 * lane + 2];
+      rec[6] = L.cond[lane]; rec[7] = L.conmu[lane];
+    }
+    unsigned long long mC = __ballot(lane < total && cls == 2), mN = __ballot(lane < total && cls != 2);
+    unsigned long long lower = (1ull << lane) - 1ull;
+    int dst = cls == 2 ? __popcll(mN) + __popcll(mC & lower) : __popcll(mN & lower);
+    __syncthreads();
+    if (lane < total) {
+      L.conp[3 * dst] = rec[0]; L.conp[3 * dst + 1] = rec[1]; L.conp[3 * dst + 2] = rec[2];
+      L.conn[3 * dst] = rec[3]; L.conn[3 * dst + 1] = rec[4]; L.conn[3 * dst + 2] = rec[5];
+      L.cond[dst] = rec[6]; L.conmu[dst] = rec[7]; L.cona[dst] = ia; L.conb[dst] = ib; L.conk[dst] = cls;
+    }
+    __syncthreads();
+  }
   PCLK(10)
-  return total < MAXC ? total : MAXC;
+  return total;
 }
 
 /* ------------------------------------------------------------------ arm dynamics: CRBA mass matrix, RNEA bias, inverse */
@@ -1685,7 +1712,7 @@ __device__ __forceinline__ void copy_out(float* __restrict__ dst, const float* s
 #define LBL_N NBJ                     /* normal row of contact c -> label LBL_N + c */
 #define NLBL (LBL_N + MAXC)           /* 24 */
 #define GEAR_LANE 12
-#define W3_HDR 0                      /* ints: maskL, maskU, nj, ncon, coupled, foldmask, gear, nA */
+#define W3_HDR 0                      /* ints: maskL, maskU, nj, ncon, n arm-only contacts, n non-arm contacts, gear, n spanning contacts */
 #define W3_VSTAR 8                    /* 32, dof-indexed */
 #define W3_MU 40                      /* 32, contact-indexed */
 #define W3_MINV 72                    /* 144 */
@@ -1696,10 +1723,11 @@ __device__ __forceinline__ void copy_out(float* __restrict__ dst, const float* s
 #define W3_ROWS (W3_BJ + 20)          /* contact rows as built: rhs, dinv, mu, parent */
 #define W3_ROWT (W3_ROWS + 4 * MAXROWC)   /* fold flag, hi_c, off0, off1 */
 #define W3_ROFF (W3_ROWT + 4 * MAXROWC)   /* 64 ints: off0 | off1 << 8 of compact row r; entry 63 = 0.0f */
-#define W3_J (W3_ROFF + 64)           /* compact contact rows, ROWW floats each */
+#define W3_SLOT (W3_ROFF + 64)        /* 64 ints: contact index of the s-th non-arm | arm-only | spanning contact (21 each), -1 = none */
+#define W3_J (W3_SLOT + 64)           /* compact contact rows, ROWW floats each */
 #define W3_B (W3_J + ROWREG)
 #define W3_FLOATS (W3_B + ROWREG)
-#define STAGE_FLOATS (64 + 2 * ROWREG)    /* ROFF | J | B: contiguous, staged through LDS by k_solve2 */
+#define STAGE_FLOATS (128 + 2 * ROWREG)   /* ROFF | SLOT | J | B: contiguous, staged through LDS by k_solve2 */
 #define AOUT_FLOATS (160 + 8 + 20)
 static_assert(W3_A % 4 == 0 && W3_ROWS % 4 == 0 && W3_ROFF % 4 == 0 && AOUT_FLOATS % 4 == 0, "16-byte copies");
 
@@ -1766,21 +1794,23 @@ __global__ void __launch_bounds__(64, RP_PREP_WAVES) k_prep2(const DevModel* __r
       gear = true;
     }
   }
-  bool coupled = false;
-  for (int c = 0; c < ncon; c++) {
-    int ba = m->col_body[L.cona[c]], bb = m->col_body[L.conb[c]];
-    if ((ba >= 1 && ba <= n) || (bb >= 1 && bb <= n)) coupled = true;
-  }
-  unsigned long long foldm = __ballot(lane < ncon && __float_as_int(L.rowT[4 * lane]) != 0);
+  /* contact classes (collide() ordered them: non-spanning first): rank inside the class -> slot tables for k_solve2 */
+  const int cls = lane < ncon ? L.conk[lane] : 3;
+  const unsigned long long mB = __ballot(cls == 0), mA = __ballot(cls == 1), mC = __ballot(cls == 2);
+  const unsigned long long lower = (1ull << lane) - 1ull;
+  L.slot[lane] = -1;
   bool anygear = __ballot(gear) != 0ull;
+  __syncthreads();
+  if (cls == 0) L.slot[__popcll(mB & lower)] = lane;             /* s-th non-arm contact  */
+  else if (cls == 1) L.slot[21 + __popcll(mA & lower)] = lane;   /* s-th arm-only contact */
+  else if (cls == 2) L.slot[42 + __popcll(mC & lower)] = lane;   /* j-th spanning contact */
   __syncthreads();
   if (lane == 0) {
     int nj = m->n_j1 < NBJ ? m->n_j1 : NBJ;
     w[W3_HDR] = __int_as_float((int)L.amask[0]); w[W3_HDR + 1] = __int_as_float((int)L.amask[1]);
     w[W3_HDR + 2] = __int_as_float(nj); w[W3_HDR + 3] = __int_as_float(ncon);
-    w[W3_HDR + 4] = __int_as_float(coupled ? 1 : 0); w[W3_HDR + 5] = __int_as_float((int)(unsigned)foldm);
-    w[W3_HDR + 6] = __int_as_float(anygear ? 1 : 0);
-    w[W3_HDR + 7] = __int_as_float(n + __popc(L.amask[0]) + __popc(L.amask[1]) + (anygear ? 1 : 0));
+    w[W3_HDR + 4] = __int_as_float(__popcll(mA)); w[W3_HDR + 5] = __int_as_float(__popcll(mB));
+    w[W3_HDR + 6] = __int_as_float(anygear ? 1 : 0); w[W3_HDR + 7] = __int_as_float(__popcll(mC));
   }
   if (lane < 32) { w[W3_VSTAR + lane] = L.vstar[lane]; w[W3_MU + lane] = lane < ncon ? L.conmu[lane] : 0.f; }
   /* the contact rows leave in the compact form they were built in: coalesced 16-byte copies; k_solve2 expands them */
@@ -1789,6 +1819,7 @@ __global__ void __launch_bounds__(64, RP_PREP_WAVES) k_prep2(const DevModel* __r
   copy_out(w + W3_ROWS, L.rowS, 4 * 3 * ncon, lane);
   copy_out(w + W3_ROWT, L.rowT, 4 * 3 * ncon, lane);
   copy_out(w + W3_ROFF, (const float*)L.roff, 64, lane);
+  copy_out(w + W3_SLOT, (const float*)L.slot, 64, lane);
   copy_out(w + W3_J, L.u.r.J, (ROWW * 3 * ncon + 3) & ~3, lane);
   copy_out(w + W3_B, L.u.r.B, (ROWW * 3 * ncon + 3) & ~3, lane);
   PCLK(5) PCLK(7)
@@ -1867,8 +1898,8 @@ __device__ __forceinline__ void unit_row(float jd, float col, float& dv, Plane& 
  * in the butterfly's hazard slots.  16 instructions.  FOLD rows (SEQ path) add the other DPP row's sum, which is what
  * a row that spans arm and non-arm dofs needs and an exact no-op (+0) for the others: 4 more instructions, cheaper
  * than a scalar branch around them (a not-taken s_cbranch costs ~13 cycles in this chain, a taken one ~27) */
-template <int K, bool FOLDABLE, int C>
-__device__ __forceinline__ void generic_row(float Jr, float Br, float& dv, Plane& p, int fm, int l16) {
+template <int K, bool FOLDABLE>
+__device__ __forceinline__ void generic_row(float Jr, float Br, float& dv, Plane& p, int l16) {
   float t, r, lo, hi, u;
   if (!FOLDABLE)
     asm volatile(
@@ -1936,41 +1967,51 @@ __global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m
   const float4 h0 = *(const float4*)&w[W3_HDR], h1 = *(const float4*)&w[W3_HDR + 4];
   const int my_mL = valid ? __float_as_int(h0.x) : 0, my_mU = valid ? __float_as_int(h0.y) : 0;
   const int my_nj = valid ? __float_as_int(h0.z) : 0, my_nc = valid ? __float_as_int(h0.w) : 0;
-  const int my_cp = valid ? __float_as_int(h1.x) : 0, my_fm = valid ? __float_as_int(h1.y) : 0;
-  const int my_gr = valid ? __float_as_int(h1.z) : 0;
+  const int my_nA = valid ? __float_as_int(h1.x) : 0, my_nB = valid ? __float_as_int(h1.y) : 0;
+  const int my_gr = valid ? __float_as_int(h1.z) : 0, my_nC = valid ? __float_as_int(h1.w) : 0;
 #define WAVE_OR(x) (__builtin_amdgcn_readlane(x, 0) | __builtin_amdgcn_readlane(x, 32))
-  const int maskL = WAVE_OR(my_mL), maskU = WAVE_OR(my_mU), foldm = WAVE_OR(my_fm), gear = WAVE_OR(my_gr);
-  const int nj_max = max(__builtin_amdgcn_readlane(my_nj, 0), __builtin_amdgcn_readlane(my_nj, 32));
-  const int nc_max = max(__builtin_amdgcn_readlane(my_nc, 0), __builtin_amdgcn_readlane(my_nc, 32));
-#if defined(RP_FORCE_PATH)    /* timing ablations: 0 = every wave takes the SEQ path, 1 = every wave takes the PAR path (wrong results) */
-  const bool par = RP_FORCE_PATH == 1;
+#define WAVE_MAX(x) max(__builtin_amdgcn_readlane(x, 0), __builtin_amdgcn_readlane(x, 32))
+  const int maskL = WAVE_OR(my_mL), maskU = WAVE_OR(my_mU), gear = WAVE_OR(my_gr);
+  const int my_nS = max(my_nA, my_nB);
+  const int nS_w = WAVE_MAX(my_nS), nC_w = WAVE_MAX(my_nC), nc_w = WAVE_MAX(my_nc);
+  /* side-by-side slots for both envs of the wave fit the 21 row registers (practically always); otherwise every contact
+   * takes its own slot and folds (nS = 0): same code, same results */
+#if defined(RP_FORCE_PATH)    /* timing ablation: 0 = never side by side */
+  const bool par = RP_FORCE_PATH == 1 && nS_w + nC_w <= MAXC;
 #else
-  const bool par = WAVE_OR(my_cp) == 0;
+  const bool par = nS_w + nC_w <= MAXC;
 #endif
+  const int nS = par ? nS_w : 0, nC = par ? nC_w : nc_w;
   const int dd = lane_dof(m, l);            /* velocity component owned by this lane, -1 if none */
-  /* contact rows first: 16-byte coalesced copies of the compact rows into LDS (a per-lane gather straight from memory
-   * costs one 16-cycle vector-memory instruction per row and array: 250 of them per wave were 60% of the prologue) */
+  /* contact rows first: 16-byte coalesced copies of the slot tables and the compact rows into LDS (a per-lane gather
+   * straight from memory costs one 16-cycle vector-memory instruction per row and array) */
   {
     float* S = L.stage[half];
     const float* src = w + W3_ROFF;
     const int nf = valid ? (ROWW * 3 * my_nc + 3) & ~3 : 0;
-    if (l < 16) *(float4*)&S[4 * l] = *(const float4*)&src[4 * l];
+    *(float4*)&S[4 * l] = *(const float4*)&src[4 * l];                       /* ROFF | SLOT: 128 words */
     for (int i = 4 * l; i < nf; i += 128) {
-      *(float4*)&S[64 + i] = *(const float4*)&src[64 + i];
-      *(float4*)&S[64 + ROWREG + i] = *(const float4*)&src[64 + ROWREG + i];
+      *(float4*)&S[128 + i] = *(const float4*)&src[128 + i];
+      *(float4*)&S[128 + ROWREG + i] = *(const float4*)&src[128 + ROWREG + i];
     }
   }
-  /* all prologue loads are unconditional from clamped addresses (then selected), so that they are all in flight at once */
+  /* all other prologue loads are unconditional from clamped addresses (absent entries read a stored 0) */
   const float* wzero = w + W3_ZERO;
   auto ldz = [&](const float* q, bool c) { return *(c ? q : wzero); };
   const float vstar = ldz(&w[W3_VSTAR + (dd >= 0 ? dd : 0)], valid && dd >= 0);
   const bool row0 = grp == 0, arm_lane = valid && row0 && l16 < n;
-  /* stream A: dof-indexed planes in DPP row 0 (zeros in row 1, where a unit row then is an exact no-op) */
+  /* unit rows: dof-indexed planes.  DPP row 0: motor / lower / upper limit of arm dof i at lane i; DPP row 1: scene joint
+   * k at lane k of the motor plane (zeros elsewhere, where a unit row then is an exact no-op) */
   const float* wa = w + W3_A;
+  const float* bj = w + W3_BJ;
   const int ia = arm_lane ? l16 : 0;
-  const float dinvA = ldz(&wa[ia], arm_lane);
-  Plane PM, PL, PU;
-  PM.rhs = ldz(&wa[16 + ia], arm_lane); PM.lo = ldz(&wa[32 + ia], arm_lane); PM.hi = ldz(&wa[48 + ia], arm_lane);
+  const bool jl = valid && !row0 && l16 < my_nj;
+  const int kj = jl ? l16 : 0;
+  const float dinvX = row0 ? ldz(&wa[ia], arm_lane) : ldz(&bj[kj], jl);
+  Plane X0, PL, PU;
+  X0.rhs = row0 ? ldz(&wa[16 + ia], arm_lane) : ldz(&bj[4 + kj], jl);
+  X0.lo = row0 ? ldz(&wa[32 + ia], arm_lane) : ldz(&bj[8 + kj], jl);
+  X0.hi = row0 ? ldz(&wa[48 + ia], arm_lane) : ldz(&bj[12 + kj], jl);
   PL.rhs = ldz(&wa[64 + ia], arm_lane); PL.lo = ldz(&wa[80 + ia], arm_lane); PL.hi = ldz(&wa[96 + ia], arm_lane);
   PU.rhs = ldz(&wa[112 + ia], arm_lane); PU.lo = ldz(&wa[128 + ia], arm_lane); PU.hi = ldz(&wa[144 + ia], arm_lane);
   float Jg = 0.f, Bg = 0.f;                 /* Panda finger gear: J = e_a + ratio e_b, scalars at lane GEAR_LANE of plane U */
@@ -1985,57 +2026,67 @@ __global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m
     bool gl = valid && row0 && l16 == GEAR_LANE && my_gr != 0;
     PU.rhs = gl ? g4 : PU.rhs; PU.lo = gl ? g5 : PU.lo; PU.hi = gl ? g6 : PU.hi;
   }
-  float Mcol[12];                           /* B column of every arm unit row: M^-1[:, i] on the arm lanes */
-#pragma unroll
-  for (int t = 0; t < 12; t++) Mcol[t] = ldz(&w[W3_MINV + ia * 12 + t], arm_lane && t < n);
-  /* stream B planes: both DPP rows hold the same copy.  label = 16 r + lane */
-  Plane PB[2], PF[2][2];                    /* PF[direction][register] */
-  float muB[2];
-  float jdJ, colJ;                          /* scene joints: J*dinv and 1/m at their own lanes (DPP row 1) */
+  float Bm[12];                             /* B column of unit row t: M^-1[:, t] on the arm lanes, 1/m of scene joint t at its lane */
   {
-    const float* bj = w + W3_BJ;
-    bool jl = valid && l16 < my_nj;
-    int kj = jl ? l16 : 0;
-    jdJ = ldz(&bj[kj], jl && !row0); colJ = ldz(&bj[16 + kj], jl && !row0);
-    float jr = bj[4 + kj], jlo = bj[8 + kj], jhi = bj[12 + kj];
+    const float colJ = ldz(&bj[16 + kj], jl);
 #pragma unroll
-    for (int r = 0; r < 2; r++) {
-      int c = 16 * r + l16 - LBL_N;
-      bool on = valid && c >= 0 && c < my_nc;
-      int cc = on ? c : 0;
-      PB[r].rhs = ldz(&w[W3_ROWS + 4 * cc], on); PB[r].lo = 0.f; PB[r].hi = ldz(&w[W3_ROWT + 4 * cc + 1], on);
-      muB[r] = ldz(&w[W3_MU + cc], on);
-#pragma unroll
-      for (int d = 0; d < 2; d++) { PF[d][r].rhs = ldz(&w[W3_ROWS + 4 * ((on ? my_nc : 0) + 2 * cc + d)], on); PF[d][r].lo = 0.f; PF[d][r].hi = 0.f; }
-    }
-    PB[0].rhs = jl ? jr : PB[0].rhs; PB[0].lo = jl ? jlo : PB[0].lo; PB[0].hi = jl ? jhi : PB[0].hi;
+    for (int t = 0; t < 12; t++) Bm[t] = row0 ? ldz(&w[W3_MINV + ia * 12 + t], arm_lane && t < n) : ((t < LBL_N && l16 == t) ? colJ : 0.f);
   }
-  /* contact rows: compact (two body slots) -> lane-dense registers; unconditional loads from clamped addresses so
-   * that all of them are in flight together */
+  /* contact slots.  Slot s < nS holds, in DPP row 0, this env's s-th arm-only contact and, in DPP row 1, its s-th
+   * non-arm contact (they commute: solved side by side, no fold); slot 20 - j holds its j-th spanning contact in
+   * both rows (folded).  Two fixed ends keep the sweep's control flow two plain early-exit chains (a jump into the
+   * middle of a chain makes the compiler build a flag-driven state machine).  contact_of(s) is this lane's contact
+   * index in slot s, -1 if none. */
+  __syncthreads();
+  const float* S = L.stage[half];
+  auto contact_of = [&](int s) {
+    int c;
+    if (s < nS) {
+      bool has = row0 ? s < my_nA : s < my_nB;
+      c = has ? __float_as_int(S[64 + (row0 ? 21 : 0) + s]) : -1;
+    } else {
+      int j = MAXC - 1 - s;                  /* folded slots fill from the top end downwards */
+      c = par ? (j < my_nC ? __float_as_int(S[64 + 42 + j]) : -1) : (j < my_nc ? j : -1);
+    }
+    return valid ? c : -1;
+  };
+  Plane PN[2], PF[2][2];                    /* normals, frictions [direction][register]; slot = 16 r + lane */
+  float muN[2];
+#pragma unroll
+  for (int r = 0; r < 2; r++) {
+    int s = 16 * r + l16;
+    int c = s < MAXC ? contact_of(s) : -1;
+    bool on = c >= 0;
+    int cc = on ? c : 0;
+    PN[r].rhs = ldz(&w[W3_ROWS + 4 * cc], on); PN[r].lo = 0.f; PN[r].hi = ldz(&w[W3_ROWT + 4 * cc + 1], on);
+    muN[r] = ldz(&w[W3_MU + cc], on);
+#pragma unroll
+    for (int d = 0; d < 2; d++) { PF[d][r].rhs = ldz(&w[W3_ROWS + 4 * ((on ? my_nc : 0) + 2 * cc + d)], on); PF[d][r].lo = 0.f; PF[d][r].hi = 0.f; }
+  }
+  /* contact rows: compact (two body slots) -> lane-dense registers, from the LDS copy */
   float JN[MAXC], BN[MAXC], JF[2][MAXC], BF[2][MAXC];
   {
-    __syncthreads();
-    const float* S = L.stage[half];
     auto expand = [&](int rr, bool used, float& j, float& b) {
       int r2 = used ? rr : 63;                           /* entry 63: offsets 0, value 0.0f */
       int off = __float_as_int(S[r2]);
       int i1 = dd - (off >> 8), i0 = dd - (off & 255);
       int idx = (unsigned)i1 < 6u ? 12 + i1 : ((unsigned)i0 < 12u ? i0 : -1);
       bool ok = used && dd >= 0 && idx >= 0;
-      j = S[ok ? 64 + ROWW * r2 + idx : 63];             /* no select after the read: absent entries read a stored 0 */
-      b = S[ok ? 64 + ROWREG + ROWW * r2 + idx : 63];
+      j = S[ok ? 128 + ROWW * r2 + idx : 63];            /* no select after the read: absent entries read a stored 0 */
+      b = S[ok ? 128 + ROWREG + ROWW * r2 + idx : 63];
     };
 #pragma unroll
-    for (int c = 0; c < MAXC; c++) {
-      bool used = valid && c < my_nc;
-      expand(c, used, JN[c], BN[c]);
-      expand(my_nc + 2 * c, used, JF[0][c], BF[0][c]);
-      expand(my_nc + 2 * c + 1, used, JF[1][c], BF[1][c]);
+    for (int s = 0; s < MAXC; s++) {
+      int c = contact_of(s);
+      bool used = c >= 0;
+      expand(c, used, JN[s], BN[s]);
+      expand(my_nc + 2 * c, used, JF[0][s], BF[0][s]);
+      expand(my_nc + 2 * c + 1, used, JF[1][s], BF[1][s]);
     }
   }
 #pragma unroll
-  for (int r = 0; r < 2; r++) { PB[r].lam = 0.f; PF[0][r].lam = 0.f; PF[1][r].lam = 0.f; }
-  PM.lam = 0.f; PL.lam = 0.f; PU.lam = 0.f;
+  for (int r = 0; r < 2; r++) { PN[r].lam = 0.f; PF[0][r].lam = 0.f; PF[1][r].lam = 0.f; }
+  X0.lam = 0.f; PL.lam = 0.f; PU.lam = 0.f;
   __syncthreads();                          /* rows are in registers: the staging area becomes the state records */
   {
     const float* r = state + (size_t)(valid ? env : 0) * RP_REC_FLOATS;
@@ -2047,121 +2098,63 @@ __global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m
   __syncthreads();
   CLK_MARK2(1)
   float dv = 0.f;
-  /* in-loop copies of the guards: kept in SGPRs and re-read every sweep so that they stay s_cmp + s_cbranch */
-#define SWEEP_GUARDS                                                                                     \
-  int nj_it = nj_max, nc_it = nc_max, mL_it = maskL, mU_it = maskU, fm_it = foldm, gr_it = gear;        \
-  asm volatile("" : "+s"(nj_it), "+s"(nc_it), "+s"(mL_it), "+s"(mU_it), "+s"(fm_it), "+s"(gr_it));      \
-  nj_it = __builtin_amdgcn_readfirstlane(nj_it); nc_it = __builtin_amdgcn_readfirstlane(nc_it);         \
-  mL_it = __builtin_amdgcn_readfirstlane(mL_it); mU_it = __builtin_amdgcn_readfirstlane(mU_it);         \
-  fm_it = __builtin_amdgcn_readfirstlane(fm_it); gr_it = __builtin_amdgcn_readfirstlane(gr_it);
-  /* Guards: a sweep visits only the rows that exist.  Contacts are a prefix (c < nc), so their rows use early exits
-   * (one s_cmp + s_cbranch per executed row, none for skipped ones); limits test their mask bit. */
-#define REP9(M, b) M(b) M(b + 1) M(b + 2) M(b + 3) M(b + 4) M(b + 5) M(b + 6) M(b + 7) M(b + 8)
-#define REP12(M, b) REP9(M, b) M(b + 9) M(b + 10) M(b + 11)
-#define REP21(M, b) REP12(M, b) REP9(M, b + 12)
-  if (par) {
-    /* both envs uncoupled: stream A in DPP row 0 and stream B in DPP row 1 of each half.  Plane M and plane B0 share
-     * registers (row 0 = M, row 1 = B0) and step t < 12 handles motor t and label t together */
-    Plane X0;
-    X0.rhs = row0 ? PM.rhs : PB[0].rhs; X0.lo = row0 ? PM.lo : PB[0].lo; X0.hi = row0 ? PM.hi : PB[0].hi; X0.lam = 0.f;
-    const float dinvX = row0 ? dinvA : jdJ;
-    float Jm[12], Bm[12];                  /* merged rows (disjoint lanes: exact) */
-#pragma unroll
-    for (int t = 0; t < 12; t++) {
-      float jd = (row0 && l16 == t) ? dinvA : 0.f;
-      if (t < LBL_N) { Jm[t] = jd; Bm[t] = Mcol[t] + ((!row0 && l16 == t) ? colJ : 0.f); }
-      else { Jm[t] = JN[t - LBL_N] + jd; Bm[t] = BN[t - LBL_N] + Mcol[t]; }
-    }
+#define REP12(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11)
+#define REP21(M) REP12(M) M(12) M(13) M(14) M(15) M(16) M(17) M(18) M(19) M(20)      /* literal indices: they name labels */
+  static_assert(MAXC == 21, "slot macros");
 #pragma unroll 1
-    for (int it = 0; it < K_NITER; it++) {
-      SWEEP_GUARDS
-      (void)fm_it; (void)nj_it;
-      plane_begin(X0); plane_begin(PL); plane_begin(PU); plane_begin(PB[1]);
-      PLANE_FENCE4(X0, PL, PU, PB[1]);
-      /* motor t | scene joint t: both unit rows at lane t */
-      unit_row<0>(dinvX, Bm[0], dv, X0, l16); unit_row<1>(dinvX, Bm[1], dv, X0, l16); unit_row<2>(dinvX, Bm[2], dv, X0, l16);
-      /* motor t | normal of contact t - 3 while contacts last, then the remaining motors alone */
-#define PAR_G(t) if (nc_it <= (t) - LBL_N) goto par_u##t; generic_row<(t), false, 0>(Jm[t], Bm[t], dv, X0, 0, l16);
-      PAR_G(3) PAR_G(4) PAR_G(5) PAR_G(6) PAR_G(7) PAR_G(8) PAR_G(9) PAR_G(10) PAR_G(11)
-#undef PAR_G
-#define PAR_H(t) if (nc_it <= (t) - LBL_N) goto par_ndone; generic_row<(t), false, 0>(JN[(t) - LBL_N], BN[(t) - LBL_N], dv, (t) < 16 ? X0 : PB[1], 0, l16);
-      REP12(PAR_H, 12)
-#undef PAR_H
-      goto par_ndone;
-#define PAR_U(t) par_u##t: unit_row<(t)>(dinvX, Bm[t], dv, X0, l16);      /* t >= n_arm: all-zero row, exact no-op */
-      PAR_U(3) PAR_U(4) PAR_U(5) PAR_U(6) PAR_U(7) PAR_U(8) PAR_U(9) PAR_U(10) PAR_U(11)
-#undef PAR_U
-    par_ndone:
-      plane_end(X0); plane_end(PB[1]);
-      /* limits, dof-major, lower before upper (in DPP row 1 these are exact no-ops).  One guard per group of six dofs:
-       * an absent limit row is all zeros and an exact no-op that costs about as much as the branch that would skip it */
-#define PAR_L(i) unit_row<(i)>(dinvX, Bm[i], dv, PL, l16); unit_row<(i)>(dinvX, Bm[i], dv, PU, l16);
-      if ((mL_it | mU_it) & 0x03F) { PAR_L(0) PAR_L(1) PAR_L(2) PAR_L(3) PAR_L(4) PAR_L(5) }
-      if ((mL_it | mU_it) & 0xFC0) { PAR_L(6) PAR_L(7) PAR_L(8) PAR_L(9) PAR_L(10) PAR_L(11) }
-#undef PAR_L
-      if (gr_it) generic_row<GEAR_LANE, false, 0>(Jg, Bg, dv, PU, 0, l16);
-      plane_end(PL); plane_end(PU);
-      if (nc_it > 0) {                                         /* frictions, contact by contact */
-        fplane_begin(PF[0][0], muB[0] * X0.lam); fplane_begin(PF[1][0], muB[0] * X0.lam);
-        fplane_begin(PF[0][1], muB[1] * PB[1].lam); fplane_begin(PF[1][1], muB[1] * PB[1].lam);
-        PLANE_FENCE4(PF[0][0], PF[1][0], PF[0][1], PF[1][1]);
-#define PAR_F(c) generic_row<LBL_N + (c), false, 0>(JF[0][c], BF[0][c], dv, PF[0][(LBL_N + (c)) >> 4], 0, l16); \
-                 generic_row<LBL_N + (c), false, 0>(JF[1][c], BF[1][c], dv, PF[1][(LBL_N + (c)) >> 4], 0, l16); \
-                 if (nc_it <= (c) + 1) goto par_fdone;
-        REP21(PAR_F, 0)
-#undef PAR_F
-      par_fdone:
-        plane_end(PF[0][0]); plane_end(PF[1][0]); plane_end(PF[0][1]); plane_end(PF[1][1]);
-      }
-    }
-  } else {
-    /* a contact involves the arm: all A rows, then all B rows; B rows that span arm and non-arm dofs fold the two DPP
-     * rows, the others need only their own row's sum (the other DPP row then computes a step that multiplies B = 0) */
-#pragma unroll 1
-    for (int it = 0; it < K_NITER; it++) {
-      SWEEP_GUARDS
-      plane_begin(PM); plane_begin(PL); plane_begin(PU); plane_begin(PB[0]);     /* B0's bounds do not depend on A rows */
-      PLANE_FENCE4(PM, PL, PU, PB[0]);
-#define SEQ_M(t) unit_row<(t)>(dinvA, Mcol[t], dv, PM, l16);               /* t >= n_arm: all-zero row, exact no-op */
-      REP12(SEQ_M, 0)
-#undef SEQ_M
-#define SEQ_L(i) unit_row<(i)>(dinvA, Mcol[i], dv, PL, l16); unit_row<(i)>(dinvA, Mcol[i], dv, PU, l16);
-      if ((mL_it | mU_it) & 0x03F) { SEQ_L(0) SEQ_L(1) SEQ_L(2) SEQ_L(3) SEQ_L(4) SEQ_L(5) }
-      if ((mL_it | mU_it) & 0xFC0) { SEQ_L(6) SEQ_L(7) SEQ_L(8) SEQ_L(9) SEQ_L(10) SEQ_L(11) }
-#undef SEQ_L
-      if (gr_it) generic_row<GEAR_LANE, false, 0>(Jg, Bg, dv, PU, 0, l16);
-      plane_end(PM); plane_end(PL); plane_end(PU);
-      plane_begin(PB[1]);                                      /* first read 13 rows later: no fence needed */
-      {                                                        /* scene-joint motors: lane-local, all at once (no-op without joints) */
-        float pj = jdJ * dv;
-        float d = __builtin_amdgcn_fmed3f(PB[0].rhs - pj, PB[0].loP, PB[0].hiP);
-        PB[0].dacc = (!row0 && l16 < LBL_N) ? d : PB[0].dacc;
-        dv = fmaf(colJ, d, dv);
-      }
-#define SEQ_N(c) if (nc_it <= (c)) goto seq_ndone; generic_row<LBL_N + (c), true, (c)>(JN[c], BN[c], dv, PB[(LBL_N + (c)) >> 4], fm_it, l16);
-      REP21(SEQ_N, 0)
-#undef SEQ_N
-    seq_ndone:
-      plane_end(PB[0]); plane_end(PB[1]);
-      if (nc_it > 0) {
-        fplane_begin(PF[0][0], muB[0] * PB[0].lam); fplane_begin(PF[1][0], muB[0] * PB[0].lam);
-        fplane_begin(PF[0][1], muB[1] * PB[1].lam); fplane_begin(PF[1][1], muB[1] * PB[1].lam);
-        PLANE_FENCE4(PF[0][0], PF[1][0], PF[0][1], PF[1][1]);
-#define SEQ_F(c) generic_row<LBL_N + (c), true, (c)>(JF[0][c], BF[0][c], dv, PF[0][(LBL_N + (c)) >> 4], fm_it, l16); \
-                 generic_row<LBL_N + (c), true, (c)>(JF[1][c], BF[1][c], dv, PF[1][(LBL_N + (c)) >> 4], fm_it, l16); \
-                 if (nc_it <= (c) + 1) goto seq_fdone;
-        REP21(SEQ_F, 0)
-#undef SEQ_F
-      seq_fdone:
-        plane_end(PF[0][0]); plane_end(PF[1][0]); plane_end(PF[0][1]); plane_end(PF[1][1]);
-      }
+  for (int it = 0; it < K_NITER; it++) {
+    /* in-loop copies of the guards: kept in SGPRs and re-read every sweep so that they stay s_cmp + s_cbranch */
+    int nS_it = nS, nC_it = nC, mL_it = maskL, mU_it = maskU, gr_it = gear;
+    asm volatile("" : "+s"(nS_it), "+s"(nC_it), "+s"(mL_it), "+s"(mU_it), "+s"(gr_it));
+    nS_it = __builtin_amdgcn_readfirstlane(nS_it); nC_it = __builtin_amdgcn_readfirstlane(nC_it);
+    mL_it = __builtin_amdgcn_readfirstlane(mL_it); mU_it = __builtin_amdgcn_readfirstlane(mU_it);
+    gr_it = __builtin_amdgcn_readfirstlane(gr_it);
+    plane_begin(X0); plane_begin(PL); plane_begin(PU); plane_begin(PN[0]); plane_begin(PN[1]);
+    PLANE_FENCE4(X0, PL, PN[0], PN[1]);                      /* PU is written before the fence and read much later */
+    /* unit rows: motor t in DPP row 0 beside scene joint t in DPP row 1 (t >= n_arm / absent joint: exact no-op) */
+#define UNIT_M(t) unit_row<(t)>(dinvX, Bm[t], dv, X0, l16);
+    REP12(UNIT_M)
+#undef UNIT_M
+    /* limits, dof-major, lower before upper.  One guard per group of six dofs: an absent limit row is all zeros and an
+     * exact no-op that costs about as much as the branch that would skip it */
+#define UNIT_L(i) unit_row<(i)>(dinvX, Bm[i], dv, PL, l16); unit_row<(i)>(dinvX, Bm[i], dv, PU, l16);
+    if ((mL_it | mU_it) & 0x03F) { UNIT_L(0) UNIT_L(1) UNIT_L(2) UNIT_L(3) UNIT_L(4) UNIT_L(5) }
+    if ((mL_it | mU_it) & 0xFC0) { UNIT_L(6) UNIT_L(7) UNIT_L(8) UNIT_L(9) UNIT_L(10) UNIT_L(11) }
+#undef UNIT_L
+    if (gr_it) generic_row<GEAR_LANE, false>(Jg, Bg, dv, PU, l16);
+    plane_end(X0); plane_end(PL); plane_end(PU);
+    /* contact normals: side-by-side slots while they last, then the folded slots.  Contacts are prefixes of both
+     * ranges, so the guards are early exits: nothing is spent on absent slots */
+#define NRM_P(s) if (nS_it <= (s)) goto nrm_pdone; generic_row<(s), false>(JN[s], BN[s], dv, PN[(s) >> 4], l16);
+    REP21(NRM_P)
+#undef NRM_P
+  nrm_pdone:
+#define NRM_C(j) if (nC_it <= (j)) goto nrm_done; generic_row<MAXC - 1 - (j), true>(JN[MAXC - 1 - (j)], BN[MAXC - 1 - (j)], dv, PN[(MAXC - 1 - (j)) >> 4], l16);
+    REP21(NRM_C)
+#undef NRM_C
+  nrm_done:
+    plane_end(PN[0]); plane_end(PN[1]);
+    if (nS_it + nC_it > 0) {                                   /* frictions, slot by slot: bounds -+ mu * (normal impulse) */
+      fplane_begin(PF[0][0], muN[0] * PN[0].lam); fplane_begin(PF[1][0], muN[0] * PN[0].lam);
+      fplane_begin(PF[0][1], muN[1] * PN[1].lam); fplane_begin(PF[1][1], muN[1] * PN[1].lam);
+      PLANE_FENCE4(PF[0][0], PF[1][0], PF[0][1], PF[1][1]);
+#define FRC_P(s) if (nS_it <= (s)) goto frc_pdone; generic_row<(s), false>(JF[0][s], BF[0][s], dv, PF[0][(s) >> 4], l16); \
+                 generic_row<(s), false>(JF[1][s], BF[1][s], dv, PF[1][(s) >> 4], l16);
+      REP21(FRC_P)
+#undef FRC_P
+    frc_pdone:
+#define FRC_C(j) if (nC_it <= (j)) goto frc_done; generic_row<MAXC - 1 - (j), true>(JF[0][MAXC - 1 - (j)], BF[0][MAXC - 1 - (j)], dv, PF[0][(MAXC - 1 - (j)) >> 4], l16); \
+                 generic_row<MAXC - 1 - (j), true>(JF[1][MAXC - 1 - (j)], BF[1][MAXC - 1 - (j)], dv, PF[1][(MAXC - 1 - (j)) >> 4], l16);
+      REP21(FRC_C)
+#undef FRC_C
+    frc_done:
+      plane_end(PF[0][0]); plane_end(PF[1][0]); plane_end(PF[0][1]); plane_end(PF[1][1]);
     }
   }
-#undef REP9
 #undef REP12
 #undef REP21
-#undef SWEEP_GUARDS
 #undef WAVE_OR
+#undef WAVE_MAX
   /* integrate: lane l holds velocity component lane_dof(l) of this half's env */
   float* st = L.st[half];
   float vnew = vstar + dv;
@@ -2206,7 +2199,7 @@ __global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m
   if (lane == 0) {
     g_clk[8 * blockIdx.x + 5] = wall_clock64();
     int na = n + __popc(maskL) + __popc(maskU);
-    g_clk[8 * blockIdx.x + 6] = (unsigned long long)na | ((unsigned long long)nj_max << 8) | ((unsigned long long)nc_max << 16) | ((unsigned long long)(par ? 1 : 0) << 24);
+    g_clk[8 * blockIdx.x + 6] = (unsigned long long)na | ((unsigned long long)nS << 8) | ((unsigned long long)nC << 16) | ((unsigned long long)(par ? 1 : 0) << 24);
     unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
     g_clk[8 * blockIdx.x + 7] = ((unsigned long long)xcc << 32) | hw;

@@ -273,10 +273,11 @@ int rp_debug_row_counts(rp_handle h, int32_t* host_buf) {
   if (!h || !host_buf) return RP_ERR_ARG;
   HIPCHK(h, hipDeviceSynchronize());
   int N = h->cfg.num_envs;
-  for (int e = 0; e < N; e++) {   /* header: maskL, maskU, nj, ncon, coupled, foldmask, gear, nA -> (nA + nj, ncon + 1000 * coupled) */
+  for (int e = 0; e < N; e++) {   /* header: maskL, maskU, nj, ncon, nA, nB, gear, nC -> (unit rows, ncon + 1000 * (arm contact) + 1e5 * spanning contacts) */
     int32_t hdr[8];
     HIPCHK(h, hipMemcpy(hdr, h->ws + (size_t)e * W3_FLOATS, 8 * sizeof(int32_t), hipMemcpyDeviceToHost));
-    host_buf[2 * e] = hdr[7] + hdr[2]; host_buf[2 * e + 1] = hdr[3] + 1000 * hdr[4];
+    host_buf[2 * e] = 12 + __builtin_popcount((unsigned)hdr[0]) + __builtin_popcount((unsigned)hdr[1]) + hdr[2];
+    host_buf[2 * e + 1] = hdr[3] + 1000 * ((hdr[4] + hdr[7]) > 0) + 100000 * hdr[7];
   }
   return RP_OK;
 }

@@ -20,7 +20,11 @@ for t in range(40):
         allc.append(a)
 a = np.concatenate(allc)
 print('nsmall: mean %.1f max %d' % (a[:, 0].mean(), a[:, 0].max()), np.bincount(a[:, 0])[12:])
+span = a[:, 1] // 100000; a[:, 1] = a[:, 1] % 100000
 cp = a[:, 1] >= 1000; a[:, 1] = a[:, 1] % 1000
+print('coupled envs: %d; of them with spanning contacts (arm + other body in one row): %.3f; spanning contacts per coupled env: mean %.2f; contacts per coupled env: mean %.2f' % (cp.sum(), (span[cp] > 0).mean(), span[cp].mean(), a[cp, 1].mean()))
+hv = cp & (a[:, 1] >= 12)
+print('heavy coupled envs (>=12 contacts): %d; spanning contacts mean %.2f of %.2f; with none spanning: %.3f' % (hv.sum(), span[hv].mean(), a[hv, 1].mean(), (span[hv] == 0).mean()))
 print('coupled fraction (env-substeps with an arm contact): %.3f; pairs with any coupled: %.3f' % (cp.mean(), (cp[0::2] | cp[1::2]).mean()))
 print('ncon: mean %.2f max %d' % (a[:, 1].mean(), a[:, 1].max()))
 print('ncon hist', np.bincount(a[:, 1], minlength=22))
