@@ -27,6 +27,9 @@
 #define MAXC 21              /* contact points kept per env per substep (shared cap with the oracle): 63 contact rows */
 #define MAXACT 64            /* AABB-overlapping pairs examined per substep (shared cap with the oracle) */
 #define MAXROWC (3 * MAXC)
+#define SORT_KEYS 64          /* load classes for pairing envs in k_solve2: 8 * min(spanning, 7) + clamp(side-by-side slots - 6, 0, 7) */
+#define SORT_REPS 8           /* histogram replicas (env & 7): one hot word would serialise ~4096 atomics at ~90 per us */
+#define SORT_BINS (SORT_KEYS * SORT_REPS)
 #define MAXSMALL 44          /* arm motors 12 + scene-joint motors 3 + limits 24 + gear 1 (+ pad) */
 
 #ifndef RP_PREP_WAVES
@@ -1731,10 +1734,13 @@ __device__ __forceinline__ void copy_out(float* __restrict__ dst, const float* s
 #define AOUT_FLOATS (160 + 8 + 20)
 static_assert(W3_A % 4 == 0 && W3_ROWS % 4 == 0 && W3_ROFF % 4 == 0 && AOUT_FLOATS % 4 == 0, "16-byte copies");
 
-__global__ void __launch_bounds__(64, RP_PREP_WAVES) k_prep2(const DevModel* __restrict__ m, const float* __restrict__ state, float* __restrict__ ws, int env0, int N) {
+__global__ void __launch_bounds__(64, RP_PREP_WAVES) k_prep2(const DevModel* __restrict__ m, const float* __restrict__ state, float* __restrict__ ws, int env0, int N,
+                                                             int* __restrict__ sort_cnt_next) {
   __shared__ EnvLds L;
   int env = env0 + blockIdx.x, lane = threadIdx.x;
   if (env >= N) return;
+  if (blockIdx.x == 0)               /* the histogram that the k_solve2 after this launch fills (for the substep after it) starts at zero */
+    for (int i = lane; i < SORT_BINS; i += 64) sort_cnt_next[i] = 0;
   PCLK(6) PCLK(0)
   load_state(L, state, env, lane);
 #ifdef RP_PREP_STOP   /* timing ablations only: leave after phase RP_PREP_STOP */
@@ -1949,7 +1955,8 @@ __device__ __forceinline__ void generic_row(float Jr, float Br, float& dv, Plane
         : "vcc");
 }
 
-__global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m, float* __restrict__ state, const float* __restrict__ ws, int env0, int N) {
+__global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m, float* __restrict__ state, const float* __restrict__ ws, int env0, int N,
+                                                  const int* __restrict__ sort_cnt, const int* __restrict__ sort_env, int* __restrict__ sort_cnt_next, int* __restrict__ sort_env_next, int sort_cap) {
   __shared__ Solve2Lds L;
   const int lane = threadIdx.x, half = lane >> 5, l = lane & 31, grp = l >> 4, l16 = lane & 15;
 #if defined(RP_CLOCKS) && RP_CLOCKS != 2
@@ -1959,8 +1966,34 @@ __global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m
 #ifdef RP_SOLVE_PAD_KB
   if (N < 0) L.pad[lane] = 0.f;
 #endif
-  const int env = env0 + blockIdx.x * 2 + half;
-  const bool valid = env < N;
+  /* this wave's two envs: positions 2b and 2b + 1 of the envs sorted by load class, heaviest first (k_prep2's
+   * histogram with 8 replicas per class; lane i scans 8 bins from the top) */
+  int env = -1;
+  {
+    const int ng = N - env0;
+    int c[8], st[8], tot = 0;                                /* lane i owns bins 511 - 8 i ... 504 - 8 i, in that (descending) order */
+    const int top = SORT_BINS - 1 - 8 * lane;
+#pragma unroll
+    for (int t = 0; t < 8; t++) { c[t] = sort_cnt[top - t]; st[t] = tot; tot += c[t]; }
+    int incl = tot;                                          /* inclusive scan over lanes */
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+    const int base = incl - tot;
+#pragma unroll
+    for (int hsel = 0; hsel < 2; hsel++) {
+      const int pp = blockIdx.x * 2 + hsel;
+      int cand = -1;
+#pragma unroll
+      for (int t = 0; t < 8; t++) {
+        int o = pp - base - st[t];
+        if (o >= 0 && o < c[t]) cand = sort_env[(size_t)(top - t) * sort_cap + o];
+      }
+      unsigned long long mk = __ballot(cand >= 0);
+      int e = __shfl(cand, mk ? __ffsll((long long)mk) - 1 : 0);
+      if (half == hsel && pp < ng) env = e;
+    }
+  }
+  const bool valid = env >= 0;
   const float* w = ws + (size_t)(valid ? env : 0) * W3_FLOATS;
   const int n = m->n_arm;
   /* header: per half, then wave-uniform unions for the guards */
@@ -2097,6 +2130,16 @@ __global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m
   __builtin_amdgcn_s_waitcnt(0x0F70);    /* vmcnt(0): all row registers have landed before the sweep loop */
   __syncthreads();
   CLK_MARK2(1)
+  /* counting sort by load class for the NEXT substep's pairing (the classes of this substep stand in for the next one's:
+   * which two envs share a wave never changes any result - absent rows are exact no-ops - it only decides how long the
+   * heaviest wave runs).  The atomic is issued here, after the last wait on a load (vmcnt is in order), and its result is used in
+   * the last lines of the kernel: its round trip under contention, several microseconds, hides behind the sweeps. */
+  int sort_pos = 0, sort_bin = 0;
+  if (l == 0 && valid) {
+    int key = 8 * (my_nC < 7 ? my_nC : 7) + (my_nS < 6 ? 0 : (my_nS > 13 ? 7 : my_nS - 6));
+    sort_bin = key * SORT_REPS + ((blockIdx.x * 2 + half) & (SORT_REPS - 1));
+    sort_pos = atomicAdd(&sort_cnt_next[sort_bin], 1);
+  }
   float dv = 0.f;
 #define REP12(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11)
 #define REP21(M) REP12(M) M(12) M(13) M(14) M(15) M(16) M(17) M(18) M(19) M(20)      /* literal indices: they name labels */
@@ -2193,6 +2236,11 @@ __global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m
   if (valid) {
     float* r = state + (size_t)env * RP_REC_FLOATS;
     for (int k = l; k < RP_REC_FLOATS; k += 32) r[k] = st[k];
+    if (l == 0) {
+      int sp = sort_pos;
+      asm volatile("" : "+v"(sp));           /* first use of the atomic's result: keeps its s_waitcnt down here */
+      sort_env_next[(unsigned)(sort_bin * sort_cap + sp)] = env;
+    }
   }
 #if defined(RP_CLOCKS) && RP_CLOCKS != 2
   CLK_MARK(3)
@@ -2205,6 +2253,13 @@ __global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m
     g_clk[8 * blockIdx.x + 7] = ((unsigned long long)xcc << 32) | hw;
   }
 #endif
+}
+
+/* first pairing of a group's envs (before any load class is known): everything in the lightest class, in index order */
+__global__ void k_sort_init(int* __restrict__ cnt, int* __restrict__ tab, int env0, int ng, int cap) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < SORT_BINS) cnt[i] = i < SORT_REPS ? (ng - i + SORT_REPS - 1) / SORT_REPS : 0;
+  if (i < ng) tab[(size_t)(i & (SORT_REPS - 1)) * cap + (i >> 3)] = env0 + i;
 }
 
 /* debug: one substep for every env, dumping intermediates of env `dbg_env` (tests only) */

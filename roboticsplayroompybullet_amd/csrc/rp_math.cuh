@@ -55,23 +55,30 @@ __device__ __forceinline__ M3 quat_to_m3(Q4 q) { /* btMatrix3x3::setRotation (to
   M3 r = {{1.f - (yy + zz), xy - wz, xz + wy, xy + wz, 1.f - (xx + zz), yz - wx, xz - wy, yz + wx, 1.f - (xx + yy)}};
   return r;
 }
-__device__ __forceinline__ Q4 m3_to_quat(const M3& M) { /* btMatrix3x3::getRotation */
+__device__ __forceinline__ Q4 m3_to_quat(const M3& M) { /* btMatrix3x3::getRotation; the three pivot cases written out so
+                                                            that every index is static (a dynamically indexed t[] lives in scratch) */
   float tr = M.m[0] + M.m[4] + M.m[8];
-  float t[4];
+  Q4 q;
   if (tr > 0.f) {
     float s = sqrtf(tr + 1.f);
-    t[3] = s * 0.5f; s = 0.5f / s;
-    t[0] = (M.m[7] - M.m[5]) * s; t[1] = (M.m[2] - M.m[6]) * s; t[2] = (M.m[3] - M.m[1]) * s;
+    q.w = s * 0.5f; s = 0.5f / s;
+    q.x = (M.m[7] - M.m[5]) * s; q.y = (M.m[2] - M.m[6]) * s; q.z = (M.m[3] - M.m[1]) * s;
   } else {
     int i = M.m[0] < M.m[4] ? (M.m[4] < M.m[8] ? 2 : 1) : (M.m[0] < M.m[8] ? 2 : 0);
-    int j = (i + 1) % 3, k = (i + 2) % 3;
-    float s = sqrtf(M.m[4 * i] - M.m[4 * j] - M.m[4 * k] + 1.f);
-    t[i] = s * 0.5f; s = 0.5f / s;
-    t[3] = (M.m[3 * k + j] - M.m[3 * j + k]) * s;
-    t[j] = (M.m[3 * j + i] + M.m[3 * i + j]) * s;
-    t[k] = (M.m[3 * k + i] + M.m[3 * i + k]) * s;
+    if (i == 0) {          /* j = 1, k = 2 */
+      float s = sqrtf(M.m[0] - M.m[4] - M.m[8] + 1.f);
+      q.x = s * 0.5f; s = 0.5f / s;
+      q.w = (M.m[7] - M.m[5]) * s; q.y = (M.m[3] + M.m[1]) * s; q.z = (M.m[6] + M.m[2]) * s;
+    } else if (i == 1) {   /* j = 2, k = 0 */
+      float s = sqrtf(M.m[4] - M.m[8] - M.m[0] + 1.f);
+      q.y = s * 0.5f; s = 0.5f / s;
+      q.w = (M.m[2] - M.m[6]) * s; q.z = (M.m[7] + M.m[5]) * s; q.x = (M.m[1] + M.m[3]) * s;
+    } else {               /* j = 0, k = 1 */
+      float s = sqrtf(M.m[8] - M.m[0] - M.m[4] + 1.f);
+      q.z = s * 0.5f; s = 0.5f / s;
+      q.w = (M.m[3] - M.m[1]) * s; q.x = (M.m[2] + M.m[6]) * s; q.y = (M.m[5] + M.m[7]) * s;
+    }
   }
-  Q4 q = {t[0], t[1], t[2], t[3]};
   return q;
 }
 __device__ __forceinline__ Q4 qmul(Q4 a, Q4 b) {
