@@ -101,10 +101,10 @@ struct __align__(16) EnvLds {
 };
 
 #ifdef RP_CLOCKS      /* profiling build only: per-wave phase timestamps of the last k_solve2 (1) / k_prep2 (2) launch */
-__device__ unsigned long long g_clk[16 * 4096];
+__device__ unsigned long long g_clk[32 * 4096];
 #define CLK_MARK(i) if (lane == 0) { g_clk[8 * blockIdx.x + (i)] = __builtin_readcyclecounter(); }
 #if RP_CLOCKS == 2
-#define PCLK(i) if (lane == 0) { g_clk[16 * blockIdx.x + (i)] = (i) >= 6 && (i) < 8 ? wall_clock64() : __builtin_readcyclecounter(); }
+#define PCLK(i) if (lane == 0) { g_clk[32 * blockIdx.x + (i)] = (i) >= 6 && (i) < 8 ? wall_clock64() : __builtin_readcyclecounter(); }
 #define CLK_MARK2(i)
 #else
 #define PCLK(i)
@@ -190,32 +190,57 @@ __device__ __forceinline__ Xf joint_compose(const DevModel* m, const Xf& P, int 
   return r;
 }
 
-/* lane b < nbody computes the world transform of body b from the state record (redundant chain walk, no barriers) */
+/* World transform of every body from the state record.  Arm links by pointer jumping over the kinematic tree: lane j
+ * starts with link j's transform relative to its parent link (joint frame times joint motion; root links composed with
+ * the base), then every round composes it with its current ancestor's transform and jumps to that ancestor's ancestor -
+ * ceil(log2(depth)) rounds of one 3x4 composition instead of a walk of up to 12 joints per link. */
 __device__ void fk_bodies(const DevModel* m, EnvLds& L, int lane) {
-  if (lane < m->nbody) {
-    Xf x;
-    x.R = ident3(); x.p = mk3(0, 0, 0);
+  float* T = L.u.c.cand;                     /* two buffers of 12 links x (R row-major, p), then 2 x 12 ancestor indices; dead space until collide() */
+  int* P = (int*)(T + 2 * 12 * RP_MAX_ARM);
+  const int n = m->n_arm;
+  Xf x; x.R = ident3(); x.p = mk3(0, 0, 0);
+  int par = -1;
+  if (lane < n) {
+    M3 R0 = ldm3(m->arm_jrot[lane]);
+    V3 p0 = ld3(m->arm_jpos[lane]), ax = ld3(m->arm_axis[lane]);
+    float q = L.st[ST_Q + lane];
+    x.R = R0; x.p = p0;
+    if (m->arm_jtype[lane] == 0) x.R = mul(R0, axis_angle(ax, q));
+    else x.p = p0 + mulv(R0, ax) * q;
+    par = m->arm_parent[lane];
+    if (par < 0) { M3 Rb = ldm3(m->base_rot); V3 pb = ld3(m->base_pos); x.p = pb + mulv(Rb, x.p); x.R = mul(Rb, x.R); }
+  }
+  for (int it = 0; __ballot(par >= 0) != 0ull; it++) {      /* wave-uniform trip count */
+    float* Tb = T + (it & 1) * 12 * RP_MAX_ARM;
+    int* Pb = P + (it & 1) * RP_MAX_ARM;
+    if (lane < n) { stm3(&Tb[12 * lane], x.R); st3(&Tb[12 * lane + 9], x.p); Pb[lane] = par; }
+    __syncthreads();
+    if (par >= 0) {
+      M3 Ra = ldm3(&Tb[12 * par]); V3 pa = ld3(&Tb[12 * par + 9]);
+      x.p = pa + mulv(Ra, x.p); x.R = mul(Ra, x.R);
+      par = Pb[par];
+    }
+  }
+  /* link j (lane j) is body j + 1; the other bodies (world, free bodies, scene joints) are stored by the lane of their index */
+  if (lane < n) { stm3(&L.xR[9 * (lane + 1)], x.R); st3(&L.xp[3 * (lane + 1)], x.p); }
+  if (lane < m->nbody && !(lane >= 1 && lane <= n)) {
     int b = lane;
-    if (b >= 1 && b <= m->n_arm) {
-      uint32_t anc = m->arm_anc[b - 1];
-      x.R = ldm3(m->base_rot); x.p = ld3(m->base_pos);
-      for (int j = 0; j < m->n_arm; j++)
-        if ((anc >> j) & 1u) x = joint_compose(m, x, j, L.st[ST_Q + j]);
-    } else if (b > m->n_arm && b <= m->n_arm + m->n_free) {
-      int k = b - 1 - m->n_arm;
+    Xf y; y.R = ident3(); y.p = mk3(0, 0, 0);
+    if (b > n && b <= n + m->n_free) {
+      int k = b - 1 - n;
       const float* f = &L.st[ST_FREE + 13 * k];
       Q4 q = {f[3], f[4], f[5], f[6]};
-      x.R = quat_to_m3(q); x.p = ld3(f);
-    } else if (b > m->n_arm + m->n_free) {
-      int k = b - 1 - m->n_arm - m->n_free;
+      y.R = quat_to_m3(q); y.p = ld3(f);
+    } else if (b > n + m->n_free) {
+      int k = b - 1 - n - m->n_free;
       M3 R0 = ldm3(m->j1_rot[k]);
       V3 ax = ld3(m->j1_axis[k]);
-      x.p = ld3(m->j1_pos[k]);
+      y.p = ld3(m->j1_pos[k]);
       float q = L.st[ST_JQ + k];
-      if (m->j1_type[k] == 0) x.R = mul(R0, axis_angle(ax, q));
-      else { x.R = R0; x.p = x.p + mulv(R0, ax) * q; }
+      if (m->j1_type[k] == 0) y.R = mul(R0, axis_angle(ax, q));
+      else { y.R = R0; y.p = y.p + mulv(R0, ax) * q; }
     }
-    stm3(&L.xR[9 * b], x.R); st3(&L.xp[3 * b], x.p);
+    stm3(&L.xR[9 * b], y.R); st3(&L.xp[3 * b], y.p);
   }
 }
 
@@ -529,7 +554,7 @@ __device__ int collide(const DevModel* m, EnvLds& L, int lane) {
   __syncthreads();
   PCLK(8)
 #if defined(RP_CLOCKS) && RP_CLOCKS == 2
-  if (lane == 0) g_clk[16 * blockIdx.x + 12] = nact;
+  if (lane == 0) g_clk[32 * blockIdx.x + 12] = nact;
 #endif
   /* 2. narrowphase: eight lanes per active pair (scratch in srow | rowS | rowT, dead until the rows are built) */
   static_assert(offsetof(EnvLds, rowS) == offsetof(EnvLds, srow) + sizeof(float) * MAXSMALL * 8 &&
@@ -1743,6 +1768,7 @@ __global__ void __launch_bounds__(64, RP_PREP_WAVES) k_prep2(const DevModel* __r
     for (int i = lane; i < SORT_BINS; i += 64) sort_cnt_next[i] = 0;
   PCLK(6) PCLK(0)
   load_state(L, state, env, lane);
+  PCLK(16)
 #ifdef RP_PREP_STOP   /* timing ablations only: leave after phase RP_PREP_STOP */
 #define PREP_STOP(k) if (RP_PREP_STOP == (k)) { if (lane == 0) ws[(size_t)env * W3_FLOATS] = L.st[0]; return; }
 #else
@@ -1751,7 +1777,9 @@ __global__ void __launch_bounds__(64, RP_PREP_WAVES) k_prep2(const DevModel* __r
   PREP_STOP(0)
   fk_bodies(m, L, lane);
   __syncthreads();
+  PCLK(17)
   joint_subspaces(m, L, lane);
+  PCLK(18)
   collider_aabbs(m, L, lane);
   __syncthreads();
   PREP_STOP(1)

@@ -298,7 +298,7 @@ int rp_debug_row_counts(rp_handle h, int32_t* host_buf) {
 
 #ifdef RP_CLOCKS
 #if RP_CLOCKS == 2
-#define RP_CLK_STRIDE 16
+#define RP_CLK_STRIDE 32
 #else
 #define RP_CLK_STRIDE 8
 #endif

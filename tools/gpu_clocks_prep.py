@@ -21,10 +21,10 @@ acts = bench.make_actions(n, steps, env.device, 1234)
 for k in range(steps):
     env.step(acts[k])
 torch.cuda.synchronize()
-buf = (C.c_uint64 * (16 * n))()
+buf = (C.c_uint64 * (32 * n))()
 env.lib.rp_debug_clocks.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
 assert env.lib.rp_debug_clocks(env.h, buf, n) == 0
-a = np.frombuffer(buf, dtype=np.uint64).reshape(n, 16).astype(np.int64)
+a = np.frombuffer(buf, dtype=np.uint64).reshape(n, 32).astype(np.int64)
 w0, w1 = a[:, 6] - a[:, 6].min(), a[:, 7] - a[:, 6].min()
 print('waves', n, 'kernel span %.1f us' % (w1.max() / 100.0))
 print('start offsets us: p10 %.1f p50 %.1f p90 %.1f max %.1f' % tuple(np.percentile(w0, [10, 50, 90, 100]) / 100.0))
@@ -35,7 +35,7 @@ for i, nm in enumerate(names):
     print('%-14s cycles: p10 %d p50 %d p90 %d max %d' % ((nm,) + tuple(np.percentile(d, [10, 50, 90, 100]))))
 tot = a[:, 5] - a[:, 0]
 print('%-14s cycles: p10 %d p50 %d p90 %d max %d' % (('total',) + tuple(np.percentile(tot, [10, 50, 90, 100]))))
-for nm, i0, i1 in (('  broadphase', 1, 8), ('  narrowphase', 8, 9), ('  manifolds', 9, 10), ('  collide tail', 10, 2)):
+for nm, i0, i1 in (('  load state', 0, 16), ('  FK', 16, 17), ('   FK local', 16, 19), ('   FK chain', 19, 20), ('   FK rest', 20, 17), ('  subspaces', 17, 18), ('  AABBs', 18, 1), ('  broadphase', 1, 8), ('  narrowphase', 8, 9), ('  manifolds', 9, 10), ('  collide tail', 10, 2)):
     d = a[:, i1] - a[:, i0]
     print('%-14s cycles: p10 %d p50 %d p90 %d max %d' % ((nm,) + tuple(np.percentile(d, [10, 50, 90, 100]))))
 for nm, i0, i1 in (('  inertia+comp', 2, 11), ('  M, bias, tau', 11, 13), ('  chol+inverse', 13, 14), ('  vstar etc', 14, 3)):
