@@ -502,7 +502,11 @@ __device__ void narrowphase_coop(const DevModel* m, EnvLds& L, int lane, int nac
     }
     if (act && s == 0) {
       L.u.c.candn[ai] = np;
-      L.u.c.key[ai] = m->col_obj[a] * 256 + m->col_obj[b];
+      /* manifold key = object pair; bit 16 marks "rotation-locked free body against the static world" (drawer): that
+       * manifold keeps only its deepest point (a property of the two bodies, so it is the same for the whole run) */
+      int kf = m->col_body[a] - 1 - m->n_arm;
+      bool single = kf >= 0 && kf < m->n_free && m->free_rot_locked[kf] && m->col_body[b] == 0;
+      L.u.c.key[ai] = m->col_obj[a] * 256 + m->col_obj[b] + (single ? 65536 : 0);
     }
     __syncthreads();       /* the scratch is reused by the next pass */
   }
@@ -532,22 +536,28 @@ __device__ int collide(const DevModel* m, EnvLds& L, int lane) {
   unsigned short pv[RP_MAX_PAIR / 64];
 #pragma unroll
   for (int k = 0; k < RP_MAX_PAIR / 64; k++) { int pi = 64 * k + lane; pv[k] = pp[pi < npair ? pi : 0]; }   /* all loads in flight at once */
+  unsigned ovbits = 0u;                  /* bit k: pair 64 k + lane overlaps.  All tests first (independent LDS reads pipeline) */
 #pragma unroll
   for (int k = 0; k < RP_MAX_PAIR / 64; k++) {
-    int base = 64 * k;
-    if (base >= npair) break;
-    int pi = base + lane;
-    bool ov = false;
-    if (pi < npair) {
+    int pi = 64 * k + lane;
+    if (64 * k < npair && pi < npair) {
       int a = pv[k] & 255, b = pv[k] >> 8;
       const float* A = &L.u.c.aabb[6 * a];
       const float* Bb = &L.u.c.aabb[6 * b];
-      ov = !(A[0] > Bb[3] + K_MARGIN || Bb[0] > A[3] + K_MARGIN || A[1] > Bb[4] + K_MARGIN || Bb[1] > A[4] + K_MARGIN ||
-             A[2] > Bb[5] + K_MARGIN || Bb[2] > A[5] + K_MARGIN);
+      /* all twelve reads unconditionally, combined without short-circuit: `||` would make every read wait for the
+       * comparison before it (98 exec-mask branches, one LDS round trip each) */
+      float a0 = A[0], a1 = A[1], a2 = A[2], a3 = A[3], a4 = A[4], a5 = A[5], b0 = Bb[0], b1 = Bb[1], b2 = Bb[2], b3 = Bb[3], b4 = Bb[4], b5 = Bb[5];
+      bool sep = (a0 > b3 + K_MARGIN) | (b0 > a3 + K_MARGIN) | (a1 > b4 + K_MARGIN) | (b1 > a4 + K_MARGIN) | (a2 > b5 + K_MARGIN) | (b2 > a5 + K_MARGIN);
+      ovbits |= sep ? 0u : (1u << k);
     }
+  }
+#pragma unroll
+  for (int k = 0; k < RP_MAX_PAIR / 64; k++) {      /* then the ordered compaction: ballots and popcounts only */
+    if (64 * k >= npair) break;
+    bool ov = (ovbits >> k) & 1u;
     unsigned long long mask = __ballot(ov);
     int before = __popcll(mask & ((1ull << lane) - 1ull));
-    if (ov && nact + before < MAXACT) L.u.c.act[nact + before] = pi;
+    if (ov && nact + before < MAXACT) L.u.c.act[nact + before] = 64 * k + lane;
     nact += __popcll(mask);
     if (nact >= MAXACT) { nact = MAXACT; break; }
   }
@@ -569,11 +579,9 @@ __device__ int collide(const DevModel* m, EnvLds& L, int lane) {
     bool head = lane == 0 || L.u.c.key[lane - 1] != L.u.c.key[lane];
     if (head) {
       float* man = &L.u.c.cand[lane * 32];          /* in place: a head lane's own points are inserted first */
-      int pi0 = L.u.c.act[lane];
-      int a0 = m->pair[pi0][0], b0 = m->pair[pi0][1];
-      int kf = m->col_body[a0] - 1 - m->n_arm;
-      bool single = kf >= 0 && kf < m->n_free && m->free_rot_locked[kf] && m->col_body[b0] == 0;
-      for (int j = lane; j < nact && L.u.c.key[j] == L.u.c.key[lane]; j++) {
+      const int mykey = L.u.c.key[lane];
+      const bool single = (mykey & 65536) != 0;
+      for (int j = lane; j < nact && L.u.c.key[j] == mykey; j++) {
         for (int i = 0; i < L.u.c.candn[j]; i++) {
           const float* c = &L.u.c.cand[(j * 4 + i) * 8];
           int dst;
@@ -582,56 +590,49 @@ __device__ int collide(const DevModel* m, EnvLds& L, int lane) {
             else dst = c[6] < man[6] - K_TIE_EPS ? 0 : -1;
           } else if (mycnt < 4) dst = mycnt++;
           else dst = manifold_replace_index(man, c);
-          if (dst >= 0) for (int k = 0; k < 8; k++) man[8 * dst + k] = c[k];
+          if (dst >= 0 && c != man + 8 * dst) for (int k = 0; k < 8; k++) man[8 * dst + k] = c[k];   /* a head's own first points are already in place */
         }
       }
     }
-    L.u.c.cnt[lane] = mycnt;
   }
   __syncthreads();
-  int total = 0;
-  if (lane < nact) {
-    int off = 0;
-    for (int j = 0; j < lane; j++) off += L.u.c.cnt[j];
-    for (int i = 0; i < mycnt && off + i < MAXC; i++) {
-      const float* c = &L.u.c.cand[lane * 32 + 8 * i];
-      int o = off + i;
-      st3(&L.conp[3 * o], ld3(c)); st3(&L.conn[3 * o], ld3(c + 3));
-      L.cond[o] = c[6];
-      int pi = __float_as_int(c[7]);
-      int a = m->pair[pi][0], b = m->pair[pi][1];
-      L.cona[o] = a; L.conb[o] = b;
-      L.conmu[o] = m->col_friction[a] * m->col_friction[b];
-    }
-  }
-  for (int j = 0; j < nact; j++) total += L.u.c.cnt[j];     /* nact uniform; LDS broadcast reads */
-  __syncthreads();
-  total = total < MAXC ? total : MAXC;
-  /* solver order: contacts that span arm and non-arm dofs (class 2) go last, the others keep their order (stable
-   * partition; same rule in the oracle).  conk[c] = class: 0 no arm dof, 1 arm dofs only, 2 spanning. */
-  {
+  /* Contacts leave in solver order: those that span arm and non-arm dofs (class 2) last, the others first, each group
+   * in manifold order (stable partition; same rule in the oracle), capped at MAXC in manifold order.  A lane's points
+   * all belong to one object pair, hence to one class; exclusive prefixes of the per-lane counts (0..4) come from
+   * three ballots each, so every point gets its final slot without an intermediate pass through LDS. */
+  const unsigned long long lower = (1ull << lane) - 1ull;
+  int off = 0;
+#pragma unroll
+  for (int bit = 0; bit < 3; bit++) off += __popcll(__ballot((mycnt >> bit) & 1) & lower) << bit;
+  const int kept = min(mycnt, max(0, MAXC - off));
+  int cls = 0, ia = 0, ib = 0; float mu = 0.f;
+  if (kept > 0) {
     const int n = m->n_arm;
-    int cls = 0; float rec[8]; int ia = 0, ib = 0;
-    if (lane < total) {
-      ia = L.cona[lane]; ib = L.conb[lane];
-      int ba = m->col_body[ia], bb = m->col_body[ib];
-      bool arm = (ba >= 1 && ba <= n) || (bb >= 1 && bb <= n), dyn = ba > n || bb > n;
-      cls = arm ? (dyn ? 2 : 1) : 0;
-      rec[0] = L.conp[3 * lane]; rec[1] = L.conp[3 * lane + 1]; rec[2] = L.conp[3 * lane + 2];
-      rec[3] = L.conn[3 * lane]; rec[4] = L.conn[3 * lane + 1]; rec[5] = L.conn[3 * lane + 2];
-      rec[6] = L.cond[lane]; rec[7] = L.conmu[lane];
-    }
-    unsigned long long mC = __ballot(lane < total && cls == 2), mN = __ballot(lane < total && cls != 2);
-    unsigned long long lower = (1ull << lane) - 1ull;
-    int dst = cls == 2 ? __popcll(mN) + __popcll(mC & lower) : __popcll(mN & lower);
-    __syncthreads();
-    if (lane < total) {
-      L.conp[3 * dst] = rec[0]; L.conp[3 * dst + 1] = rec[1]; L.conp[3 * dst + 2] = rec[2];
-      L.conn[3 * dst] = rec[3]; L.conn[3 * dst + 1] = rec[4]; L.conn[3 * dst + 2] = rec[5];
-      L.cond[dst] = rec[6]; L.conmu[dst] = rec[7]; L.cona[dst] = ia; L.conb[dst] = ib; L.conk[dst] = cls;
-    }
-    __syncthreads();
+    int pi = __float_as_int(L.u.c.cand[lane * 32 + 7]);
+    ia = m->pair[pi][0]; ib = m->pair[pi][1];
+    int ba = m->col_body[ia], bb = m->col_body[ib];
+    bool arm = (ba >= 1 && ba <= n) || (bb >= 1 && bb <= n), dyn = ba > n || bb > n;
+    cls = arm ? (dyn ? 2 : 1) : 0;
   }
+  int nN_before = 0, nC_before = 0, nN_total = 0, total = 0;
+#pragma unroll
+  for (int bit = 0; bit < 3; bit++) {
+    unsigned long long mb = __ballot((kept >> bit) & 1), mc = __ballot(((kept >> bit) & 1) && cls == 2);
+    nN_before += __popcll(mb & ~mc & lower) << bit; nC_before += __popcll(mc & lower) << bit;
+    nN_total += __popcll(mb & ~mc) << bit; total += __popcll(mb) << bit;
+  }
+  for (int i = 0; i < kept; i++) {
+    const float* c = &L.u.c.cand[lane * 32 + 8 * i];
+    int pi = __float_as_int(c[7]);                    /* the colliders may differ from point to point inside a manifold */
+    int a = m->pair[pi][0], b = m->pair[pi][1];
+    int o = cls == 2 ? nN_total + nC_before + i : nN_before + i;
+    st3(&L.conp[3 * o], ld3(c)); st3(&L.conn[3 * o], ld3(c + 3));
+    L.cond[o] = c[6];
+    L.cona[o] = a; L.conb[o] = b; L.conk[o] = cls;
+    L.conmu[o] = m->col_friction[a] * m->col_friction[b];
+  }
+  (void)ia; (void)ib; (void)mu;
+  __syncthreads();
   PCLK(10)
   return total;
 }
@@ -659,9 +660,11 @@ __device__ void arm_dynamics(const DevModel* m, EnvLds& L, int lane) {
     float acc[10];
     for (int k = 0; k < 10; k++) acc[k] = 0.f;
     V6 v = zero6();
-    for (int j = 0; j < n; j++) {
-      if ((sub >> j) & 1u) for (int k = 0; k < 10; k++) acc[k] += L.u.d.inert[10 * j + k];
-      if ((anc >> j) & 1u) v = v + ld6(&L.S[6 * j]) * L.st[ST_QD + j];
+    for (int j = 0; j < n; j++) {           /* wave-uniform j: LDS broadcasts, read unconditionally and selected (x + 0 is exact) */
+      const bool ins = (sub >> j) & 1u, isanc = (anc >> j) & 1u;
+      for (int k = 0; k < 10; k++) { float t = L.u.d.inert[10 * j + k]; acc[k] += ins ? t : 0.f; }
+      V6 sj = ld6(&L.S[6 * j]) * L.st[ST_QD + j];
+      v.a = v.a + (isanc ? sj.a : mk3(0, 0, 0)); v.l = v.l + (isanc ? sj.l : mk3(0, 0, 0));
     }
     for (int k = 0; k < 10; k++) L.u.d.compI[10 * lane + k] = acc[k];
     st6(&L.u.d.vsp[6 * lane], v);
@@ -687,7 +690,7 @@ __device__ void arm_dynamics(const DevModel* m, EnvLds& L, int lane) {
     uint32_t anc = m->arm_anc[lane];
     V6 a = zero6();
     a.l.z = -K_GRAVITY;
-    for (int j = 0; j < n; j++) if ((anc >> j) & 1u) a = a + ld6(&L.u.d.csp[6 * j]);
+    for (int j = 0; j < n; j++) { V6 cj = ld6(&L.u.d.csp[6 * j]); bool on = (anc >> j) & 1u; a.a = a.a + (on ? cj.a : mk3(0, 0, 0)); a.l = a.l + (on ? cj.l : mk3(0, 0, 0)); }
     V6 v = ld6(&L.u.d.vsp[6 * lane]);
     const float* I = &L.u.d.inert[10 * lane];
     st6(&L.u.d.fsp[6 * lane], inertia_mul(I, a) + crf(v, inertia_mul(I, v)));
@@ -696,7 +699,7 @@ __device__ void arm_dynamics(const DevModel* m, EnvLds& L, int lane) {
   if (lane < n) {
     uint32_t sub = m->arm_sub[lane];
     V6 f = zero6();
-    for (int j = 0; j < n; j++) if ((sub >> j) & 1u) f = f + ld6(&L.u.d.fsp[6 * j]);
+    for (int j = 0; j < n; j++) { V6 fj = ld6(&L.u.d.fsp[6 * j]); bool on = (sub >> j) & 1u; f.a = f.a + (on ? fj.a : mk3(0, 0, 0)); f.l = f.l + (on ? fj.l : mk3(0, 0, 0)); }
     L.tau[lane] = dot6(ld6(&L.S[6 * lane]), f);
   }
   PCLK(13)
