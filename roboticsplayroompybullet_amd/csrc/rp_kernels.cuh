@@ -1763,12 +1763,19 @@ __device__ __forceinline__ void copy_out(float* __restrict__ dst, const float* s
 static_assert(W3_A % 4 == 0 && W3_ROWS % 4 == 0 && W3_ROFF % 4 == 0 && AOUT_FLOATS % 4 == 0, "16-byte copies");
 
 __global__ void __launch_bounds__(64, RP_PREP_WAVES) k_prep2(const DevModel* __restrict__ m, const float* __restrict__ state, float* __restrict__ ws, int env0, int N,
-                                                             int* __restrict__ sort_cnt_next) {
+                                                             const int* __restrict__ sort_cnt, int* __restrict__ sort_cnt_next, const int* __restrict__ sort_slot, int* __restrict__ pair_env) {
   __shared__ EnvLds L;
   int env = env0 + blockIdx.x, lane = threadIdx.x;
   if (env >= N) return;
   if (blockIdx.x == 0)               /* the histogram that the k_solve2 after this launch fills (for the substep after it) starts at zero */
     for (int i = lane; i < SORT_BINS; i += 64) sort_cnt_next[i] = 0;
+  /* pairing table for the k_solve2 after this launch: this env's place among the envs of its group sorted by load class,
+   * heaviest first = envs in heavier (class, replica) bins + its rank inside its bin (both from the previous k_solve2).
+   * The loads are issued here; the sum and the store sit at the end of the kernel */
+  const int my_slot = sort_slot[env];
+  int cnt8[8];
+#pragma unroll
+  for (int t = 0; t < 8; t++) cnt8[t] = sort_cnt[8 * lane + t];
   PCLK(6) PCLK(0)
   load_state(L, state, env, lane);
   PCLK(16)
@@ -1859,6 +1866,15 @@ __global__ void __launch_bounds__(64, RP_PREP_WAVES) k_prep2(const DevModel* __r
   copy_out(w + W3_SLOT, (const float*)L.slot, 64, lane);
   copy_out(w + W3_J, L.u.r.J, (ROWW * 3 * ncon + 3) & ~3, lane);
   copy_out(w + W3_B, L.u.r.B, (ROWW * 3 * ncon + 3) & ~3, lane);
+  {
+    const int mybin = my_slot >> 16;
+    int above = 0;
+#pragma unroll
+    for (int t = 0; t < 8; t++) above += (8 * lane + t > mybin) ? cnt8[t] : 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) above += __shfl_xor(above, d);
+    if (lane == 0) pair_env[env0 + above + (my_slot & 0xFFFF)] = env;
+  }
   PCLK(5) PCLK(7)
 }
 
@@ -1987,7 +2003,7 @@ __device__ __forceinline__ void generic_row(float Jr, float Br, float& dv, Plane
 }
 
 __global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m, float* __restrict__ state, const float* __restrict__ ws, int env0, int N,
-                                                  const int* __restrict__ sort_cnt, const int* __restrict__ sort_env, int* __restrict__ sort_cnt_next, int* __restrict__ sort_env_next, int sort_cap) {
+                                                  const int* __restrict__ pair_env, int* __restrict__ sort_cnt_next, int* __restrict__ sort_slot) {
   __shared__ Solve2Lds L;
   const int lane = threadIdx.x, half = lane >> 5, l = lane & 31, grp = l >> 4, l16 = lane & 15;
 #if defined(RP_CLOCKS) && RP_CLOCKS != 2
@@ -1997,33 +2013,10 @@ __global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m
 #ifdef RP_SOLVE_PAD_KB
   if (N < 0) L.pad[lane] = 0.f;
 #endif
-  /* this wave's two envs: positions 2b and 2b + 1 of the envs sorted by load class, heaviest first (k_prep2's
-   * histogram with 8 replicas per class; lane i scans 8 bins from the top) */
-  int env = -1;
-  {
-    const int ng = N - env0;
-    int c[8], st[8], tot = 0;                                /* lane i owns bins 511 - 8 i ... 504 - 8 i, in that (descending) order */
-    const int top = SORT_BINS - 1 - 8 * lane;
-#pragma unroll
-    for (int t = 0; t < 8; t++) { c[t] = sort_cnt[top - t]; st[t] = tot; tot += c[t]; }
-    int incl = tot;                                          /* inclusive scan over lanes */
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
-    const int base = incl - tot;
-#pragma unroll
-    for (int hsel = 0; hsel < 2; hsel++) {
-      const int pp = blockIdx.x * 2 + hsel;
-      int cand = -1;
-#pragma unroll
-      for (int t = 0; t < 8; t++) {
-        int o = pp - base - st[t];
-        if (o >= 0 && o < c[t]) cand = sort_env[(size_t)(top - t) * sort_cap + o];
-      }
-      unsigned long long mk = __ballot(cand >= 0);
-      int e = __shfl(cand, mk ? __ffsll((long long)mk) - 1 : 0);
-      if (half == hsel && pp < ng) env = e;
-    }
-  }
+  /* this wave's two envs: places 2b and 2b + 1 among the group's envs sorted by load class, heaviest first (table built
+   * by the k_prep2 before this launch) */
+  const int place = blockIdx.x * 2 + half;
+  const int env = place < N - env0 ? pair_env[env0 + place] : -1;
   const bool valid = env >= 0;
   const float* w = ws + (size_t)(valid ? env : 0) * W3_FLOATS;
   const int n = m->n_arm;
@@ -2130,22 +2123,22 @@ __global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m
   /* contact rows: compact (two body slots) -> lane-dense registers, from the LDS copy */
   float JN[MAXC], BN[MAXC], JF[2][MAXC], BF[2][MAXC];
   {
-    auto expand = [&](int rr, bool used, float& j, float& b) {
-      int r2 = used ? rr : 63;                           /* entry 63: offsets 0, value 0.0f */
-      int off = __float_as_int(S[r2]);
-      int i1 = dd - (off >> 8), i0 = dd - (off & 255);
-      int idx = (unsigned)i1 < 6u ? 12 + i1 : ((unsigned)i0 < 12u ? i0 : -1);
-      bool ok = used && dd >= 0 && idx >= 0;
-      j = S[ok ? 128 + ROWW * r2 + idx : 63];            /* no select after the read: absent entries read a stored 0 */
-      b = S[ok ? 128 + ROWREG + ROWW * r2 + idx : 63];
-    };
 #pragma unroll
     for (int s = 0; s < MAXC; s++) {
-      int c = contact_of(s);
-      bool used = c >= 0;
-      expand(c, used, JN[s], BN[s]);
-      expand(my_nc + 2 * c, used, JF[0][s], BF[0][s]);
-      expand(my_nc + 2 * c + 1, used, JF[1][s], BF[1][s]);
+      const int c = contact_of(s);
+      const bool used = c >= 0;
+      /* this lane's entry in the contact's compact rows: the normal and both friction rows share the two body slots */
+      const int off = __float_as_int(S[used ? c : 63]);                 /* entry 63: offsets 0, value 0.0f */
+      const int i1 = dd - (off >> 8), i0 = dd - (off & 255);
+      const int idx = (unsigned)i1 < 6u ? 12 + i1 : ((unsigned)i0 < 12u ? i0 : -1);
+      const bool ok = used && dd >= 0 && idx >= 0;
+      const int rn = ROWW * c + idx, rf = ROWW * (my_nc + 2 * c) + idx;
+      JN[s] = S[ok ? 128 + rn : 63];                                    /* no select after the read: absent entries read a stored 0 */
+      BN[s] = S[ok ? 128 + ROWREG + rn : 63];
+      JF[0][s] = S[ok ? 128 + rf : 63];
+      BF[0][s] = S[ok ? 128 + ROWREG + rf : 63];
+      JF[1][s] = S[ok ? 128 + rf + ROWW : 63];
+      BF[1][s] = S[ok ? 128 + ROWREG + rf + ROWW : 63];
     }
   }
 #pragma unroll
@@ -2270,7 +2263,7 @@ __global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m
     if (l == 0) {
       int sp = sort_pos;
       asm volatile("" : "+v"(sp));           /* first use of the atomic's result: keeps its s_waitcnt down here */
-      sort_env_next[(unsigned)(sort_bin * sort_cap + sp)] = env;
+      sort_slot[env] = (sort_bin << 16) | sp;
     }
   }
 #if defined(RP_CLOCKS) && RP_CLOCKS != 2
@@ -2287,10 +2280,10 @@ __global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m
 }
 
 /* first pairing of a group's envs (before any load class is known): everything in the lightest class, in index order */
-__global__ void k_sort_init(int* __restrict__ cnt, int* __restrict__ tab, int env0, int ng, int cap) {
+__global__ void k_sort_init(int* __restrict__ cnt, int* __restrict__ slot, int env0, int ng) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < SORT_BINS) cnt[i] = i < SORT_REPS ? (ng - i + SORT_REPS - 1) / SORT_REPS : 0;
-  if (i < ng) tab[(size_t)(i & (SORT_REPS - 1)) * cap + (i >> 3)] = env0 + i;
+  if (i < SORT_BINS) cnt[i] = i < SORT_REPS ? (ng + i) / SORT_REPS : 0;              /* envs with (e & 7) == 7 - i */
+  if (i < ng) slot[env0 + i] = ((SORT_REPS - 1 - (i & (SORT_REPS - 1))) << 16) | (i >> 3);      /* bins 7..0 <-> i & 7 = 0..7: keeps index order */
 }
 
 /* debug: one substep for every env, dumping intermediates of env `dbg_env` (tests only) */

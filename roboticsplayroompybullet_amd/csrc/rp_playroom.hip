@@ -19,7 +19,8 @@ struct rp_sim {
   float* ws;               /* [N][W3_FLOATS] constraint-row workspace of the split step pipeline */
   float* dbg;
   int* sort_cnt;           /* [2][RP_MAX_GROUPS][SORT_BINS] load-class histograms for pairing envs in k_solve2 (double-buffered) */
-  int* sort_env;           /* [2] x per group [SORT_BINS][cap] env ids per load class and replica, cap = envs of the group / SORT_REPS + 1 */
+  int* sort_slot;          /* [N] per env: (bin << 16) | rank inside the bin, from the latest k_solve2 */
+  int* pair_env;           /* [N] per group range: env ids sorted by load class, heaviest first (k_solve2 pairs neighbours) */
   int sort_G, sort_par;    /* group count the tables were built for (0 = none yet); buffer that the next k_solve2 reads */
   hipEvent_t ev0, ev1;
   hipEvent_t* pool;        /* per-launch timing ring: EV_PER_STEP events per recorded step */
@@ -78,7 +79,8 @@ int rp_create(const rp_config* cfg, rp_handle* out) {
       hipMalloc((void**)&h->ws, (size_t)cfg->num_envs * W3_FLOATS * sizeof(float)) != hipSuccess ||
       hipMalloc((void**)&h->dbg, 4096 * sizeof(float)) != hipSuccess ||
       hipMalloc((void**)&h->sort_cnt, (size_t)2 * RP_MAX_GROUPS * SORT_BINS * sizeof(int)) != hipSuccess ||
-      hipMalloc((void**)&h->sort_env, (size_t)2 * SORT_KEYS * (cfg->num_envs + 2 * SORT_REPS * RP_MAX_GROUPS) * sizeof(int)) != hipSuccess) {
+      hipMalloc((void**)&h->sort_slot, (size_t)cfg->num_envs * sizeof(int)) != hipSuccess ||
+      hipMalloc((void**)&h->pair_env, (size_t)cfg->num_envs * sizeof(int)) != hipSuccess) {
     snprintf(g_err, 256, "rp_create: hipMalloc failed"); free(h); return RP_ERR_HIP;
   }
   if (hipMemcpy(h->dev_model, &h->host_model, sizeof(DevModel), hipMemcpyHostToDevice) != hipSuccess) {
@@ -104,7 +106,7 @@ int rp_create(const rp_config* cfg, rp_handle* out) {
 int rp_destroy(rp_handle h) {
   if (!h) return RP_ERR_ARG;
   hipSetDevice(h->cfg.device);
-  hipFree(h->dev_model); hipFree(h->state); hipFree(h->ws); hipFree(h->dbg); hipFree(h->sort_cnt); hipFree(h->sort_env);
+  hipFree(h->dev_model); hipFree(h->state); hipFree(h->ws); hipFree(h->dbg); hipFree(h->sort_cnt); hipFree(h->sort_slot); hipFree(h->pair_env);
   hipEventDestroy(h->ev0); hipEventDestroy(h->ev1); hipEventDestroy(h->gfork);
   for (int i = 0; i < RP_MAX_GROUPS; i++) { hipStreamDestroy(h->gstream[i]); hipEventDestroy(h->gjoin[i]); }
   if (h->pool) { for (int i = 0; i < h->pool_steps * EV_PER_STEP; i++) hipEventDestroy(h->pool[i]); free(h->pool); }
@@ -165,17 +167,15 @@ int rp_step(rp_handle h, const float* action, const rp_out* out, void* stream) {
       int e0 = (int)((long long)N * g / G), e1 = (int)((long long)N * (g + 1) / G), ng = e1 - e0;
       if (g > 0) hipStreamWaitEvent(gs, h->gfork, 0);
       if (ev) hipEventRecord(ev[0], gs);
-      /* env pairing tables of this group (double-buffered: k_solve2 reads one and fills the other for the next substep) */
-      int scap = (ng + SORT_REPS - 1) / SORT_REPS + 1;
-      size_t tabsz = (size_t)SORT_KEYS * (N + 2 * SORT_REPS * RP_MAX_GROUPS);
+      /* env pairing of this group: k_solve2 ranks its envs by load class (histogram, double-buffered), the next k_prep2
+       * turns the ranks into the table the next k_solve2 reads */
       int* gcnt[2] = {h->sort_cnt + (size_t)g * SORT_BINS, h->sort_cnt + (size_t)(RP_MAX_GROUPS + g) * SORT_BINS};
-      int* genv[2] = {h->sort_env + (size_t)SORT_KEYS * (e0 + 2 * SORT_REPS * g), h->sort_env + tabsz + (size_t)SORT_KEYS * (e0 + 2 * SORT_REPS * g)};
       int par = h->sort_par;
-      if (h->sort_G != G) hipLaunchKernelGGL(k_sort_init, dim3((max(ng, SORT_BINS) + 255) / 256), dim3(256), 0, gs, gcnt[par], genv[par], e0, ng, scap);
+      if (h->sort_G != G) hipLaunchKernelGGL(k_sort_init, dim3((max(ng, SORT_BINS) + 255) / 256), dim3(256), 0, gs, gcnt[par], h->sort_slot, e0, ng);
       TIMED(hipLaunchKernelGGL(k_action, dim3((ng + 63) / 64), dim3(64), 0, gs, h->dev_model, h->state, action, op.target_poses, e0, e1));
       for (int sub = 0; sub < K_NSUB; sub++) {
-        TIMED(hipLaunchKernelGGL(k_prep2, dim3(ng), dim3(64), 0, gs, h->dev_model, h->state, h->ws, e0, e1, gcnt[par ^ 1]));
-        TIMED(hipLaunchKernelGGL(k_solve2, dim3((ng + 1) / 2), dim3(64), 0, gs, h->dev_model, h->state, h->ws, e0, e1, gcnt[par], genv[par], gcnt[par ^ 1], genv[par ^ 1], scap));
+        TIMED(hipLaunchKernelGGL(k_prep2, dim3(ng), dim3(64), 0, gs, h->dev_model, h->state, h->ws, e0, e1, gcnt[par], gcnt[par ^ 1], h->sort_slot, h->pair_env));
+        TIMED(hipLaunchKernelGGL(k_solve2, dim3((ng + 1) / 2), dim3(64), 0, gs, h->dev_model, h->state, h->ws, e0, e1, h->pair_env, gcnt[par ^ 1], h->sort_slot));
         par ^= 1;
       }
       if (g == G - 1) { h->sort_par = par; h->sort_G = G; }
