@@ -1873,7 +1873,7 @@ __global__ void __launch_bounds__(64, RP_PREP_WAVES) k_prep2(const DevModel* __r
     for (int t = 0; t < 8; t++) above += (8 * lane + t > mybin) ? cnt8[t] : 0;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) above += __shfl_xor(above, d);
-    if (lane == 0) pair_env[env0 + above + (my_slot & 0xFFFF)] = env;
+    if (lane == 0) pair_env[env0 + above + (my_slot & 0xFFFF)] = env | (ncon << 24);     /* + its contact count: k_solve2 sizes its row copy without waiting for the header */
   }
   PCLK(5) PCLK(7)
 }
@@ -2016,7 +2016,8 @@ __global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m
   /* this wave's two envs: places 2b and 2b + 1 among the group's envs sorted by load class, heaviest first (table built
    * by the k_prep2 before this launch) */
   const int place = blockIdx.x * 2 + half;
-  const int env = place < N - env0 ? pair_env[env0 + place] : -1;
+  const int pe = place < N - env0 ? pair_env[env0 + place] : -1;
+  const int env = pe < 0 ? -1 : (pe & 0xFFFFFF), pe_nc = pe < 0 ? 0 : (pe >> 24);
   const bool valid = env >= 0;
   const float* w = ws + (size_t)(valid ? env : 0) * W3_FLOATS;
   const int n = m->n_arm;
@@ -2045,12 +2046,18 @@ __global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m
   {
     float* S = L.stage[half];
     const float* src = w + W3_ROFF;
-    const int nf = valid ? (ROWW * 3 * my_nc + 3) & ~3 : 0;
+    const int nf = valid ? (ROWW * 3 * pe_nc + 3) & ~3 : 0;
     *(float4*)&S[4 * l] = *(const float4*)&src[4 * l];                       /* ROFF | SLOT: 128 words */
     for (int i = 4 * l; i < nf; i += 128) {
       *(float4*)&S[128 + i] = *(const float4*)&src[128 + i];
       *(float4*)&S[128 + ROWREG + i] = *(const float4*)&src[128 + ROWREG + i];
     }
+  }
+  /* the state record: loaded now, parked in registers until the staging area is free */
+  float st_v0, st_v1, st_v2, st_v3;
+  {
+    const float* r = state + (size_t)(valid ? env : 0) * RP_REC_FLOATS;
+    st_v0 = r[l]; st_v1 = r[l + 32]; st_v2 = r[l + 64]; st_v3 = r[l + 96];
   }
   /* all other prologue loads are unconditional from clamped addresses (absent entries read a stored 0) */
   const float* wzero = w + W3_ZERO;
@@ -2146,10 +2153,8 @@ __global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m
   X0.lam = 0.f; PL.lam = 0.f; PU.lam = 0.f;
   __syncthreads();                          /* rows are in registers: the staging area becomes the state records */
   {
-    const float* r = state + (size_t)(valid ? env : 0) * RP_REC_FLOATS;
-    float v0 = r[l], v1 = r[l + 32], v2 = r[l + 64], v3 = r[l + 96];
     float* st = L.st[half];
-    st[l] = v0; st[l + 32] = v1; st[l + 64] = v2; st[l + 96] = v3;
+    st[l] = st_v0; st[l + 32] = st_v1; st[l + 64] = st_v2; st[l + 96] = st_v3;
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);    /* vmcnt(0): all row registers have landed before the sweep loop */
   __syncthreads();
