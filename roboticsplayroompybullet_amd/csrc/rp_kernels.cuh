@@ -148,6 +148,24 @@ __device__ __forceinline__ double readlane_d(double v, int src_lane_uniform) {
   return __hiloint2double(hi, lo);
 }
 
+/* value of lane K (0..15) of each 16-lane DPP row, delivered to the whole row: one v_mov_b32_dpp row_newbcast.
+ * The DPP control is an immediate, so labels are template constants (static_for below, not #pragma unroll). */
+template <int K>
+__device__ __forceinline__ float bcast16(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + (K & 15), 0xF, 0xF, true));
+}
+template <int T> struct IdxC { static constexpr int v = T; };
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) { f(IdxC<I>{}); static_for<I + 1, N>(f); }
+}
+
+/* value of lane (l16 - D) of the same 16-lane DPP row; lanes with l16 < D keep their own value */
+template <int D>
+__device__ __forceinline__ float shr16(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x110 + D, 0xF, 0xF, false));
+}
+
 /* sum over lanes 0..31 (lanes 32..63 must hold 0); result in every lane.  DPP butterflies inside rows of 16. */
 __device__ __forceinline__ float wave_sum32(float v) {
   int x = __float_as_int(v);
@@ -1135,94 +1153,127 @@ __device__ void substep(const DevModel* m, EnvLds& L, int lane) {
 /* ------------------------------------------------------------------ inverse kinematics (wave-uniform, registers only) */
 struct ChainQ { float q[7]; };
 
-/* FK of the serial chain base -> EE body with joint values cq; returns EE site pose and fills joint origins/axes */
-__device__ void chain_fk(const DevModel* m, const ChainQ& cq, int nc, V3* org, V3* axw, V3& pos, M3& Rs) {
-  Xf x; x.R = ldm3(m->base_rot); x.p = ld3(m->base_pos);
+/* damped-least-squares IK, the oracle's ik_solve restricted to the EE chain (the other dofs decouple exactly), solved
+ * COOPERATIVELY BY THE 16 LANES OF A DPP ROW: lane j < NC owns chain joint j.  Per iteration: every lane forms its
+ * joint's local transform (one sincos per lane), a 3-round shifted scan composes the chain (row_shr 1, 2, 4), lane j
+ * builds Jacobian column j, lane r builds and eliminates row r of J^T J + damp I (columns / pivot rows arrive by row
+ * broadcast), the back-substitution walks the pivots once.  ~700 instructions per iteration instead of ~2 700 for one
+ * lane per env, and four times as many waves.  NC = chain length (6 UR5, 7 Panda).  All lanes of a row must call it
+ * with the same target; qj = this lane's joint value; returns the new one.  `live` = this row has an env at all. */
+__device__ __forceinline__ Xf xf_compose(const Xf& a, const Xf& b) { Xf r; r.R = mul(a.R, b.R); r.p = a.p + mulv(a.R, b.p); return r; }
+template <int D>
+__device__ __forceinline__ Xf xf_shr(const Xf& x) {
+  Xf r;
 #pragma unroll
-  for (int j = 0; j < 7; j++) {
-    if (j < nc) {
-      x = joint_compose(m, x, j, cq.q[j]);
-      org[j] = x.p;
-      axw[j] = mulv(x.R, ld3(m->arm_axis[j]));
-    }
-  }
-  pos = x.p + mulv(x.R, ld3(m->site_pos[RP_SITE_EE]));
-  Rs = mul(x.R, ldm3(m->site_rot[RP_SITE_EE]));
+  for (int k = 0; k < 9; k++) r.R.m[k] = shr16<D>(x.R.m[k]);
+  r.p = mk3(shr16<D>(x.p.x), shr16<D>(x.p.y), shr16<D>(x.p.z));
+  return r;
 }
 
-/* damped-least-squares IK, the oracle's ik_solve restricted to the EE chain (the other dofs decouple exactly).
- * NC = chain length (6 UR5, 7 Panda) is a compile-time constant so the 6x6 / 7x7 system lives in registers. */
 template <int NC>
-__device__ ChainQ ik_solve_n(const DevModel* m, V3 tpos, Q4 tq, ChainQ q, int max_iter) {
+__device__ float ik_coop(const DevModel* m, V3 tpos, Q4 tq, float qj, int max_iter, int l16, bool live) {
+  const bool isj = l16 < NC;
+  const int jj = isj ? l16 : 0;
+  const M3 R0 = ldm3(m->arm_jrot[jj]);
+  const V3 p0 = ld3(m->arm_jpos[jj]), ax = ld3(m->arm_axis[jj]);
+  const bool rev = m->arm_jtype[jj] == 0;
+  Xf base; base.R = ldm3(m->base_rot); base.p = ld3(m->base_pos);
+  const V3 sp = ld3(m->site_pos[RP_SITE_EE]);
+  const M3 sr = ldm3(m->site_rot[RP_SITE_EE]);
+  bool done = !live;
   for (int it = 0; it < max_iter; it++) {
-    V3 org[7], axw[7], pos; M3 Rs;
-    chain_fk(m, q, NC, org, axw, pos, Rs);
-    V3 ep = tpos - pos;
-    if (it > 0 && norm(ep) < K_IK_RES) break;
+    /* chain FK: local transforms, then an inclusive scan of compositions over lanes 0..NC-1 */
+    Xf x; x.R = ident3(); x.p = mk3(0, 0, 0);
+    if (isj) {
+      x.R = R0; x.p = p0;
+      if (rev) x.R = mul(R0, axis_angle(ax, qj)); else x.p = p0 + mulv(R0, ax) * qj;
+    }
+    if (l16 == 0) x = xf_compose(base, x);
+    { Xf y = xf_shr<1>(x); Xf z = xf_compose(y, x); if (l16 >= 1) x = z; }
+    { Xf y = xf_shr<2>(x); Xf z = xf_compose(y, x); if (l16 >= 2) x = z; }
+    { Xf y = xf_shr<4>(x); Xf z = xf_compose(y, x); if (l16 >= 4) x = z; }
+    const V3 org = x.p, axw = mulv(x.R, ax);
+    const V3 posl = x.p + mulv(x.R, sp);
+    const M3 Rsl = mul(x.R, sr);
+    const V3 pos = mk3(bcast16<NC - 1>(posl.x), bcast16<NC - 1>(posl.y), bcast16<NC - 1>(posl.z));
+    M3 Rs;
+#pragma unroll
+    for (int k = 0; k < 9; k++) Rs.m[k] = bcast16<NC - 1>(Rsl.m[k]);
+    const V3 ep = tpos - pos;
+    done = done || (it > 0 && norm(ep) < K_IK_RES);
+    if (__ballot(!done) == 0ull) break;                        /* every env of the wave has converged */
+    /* pose error, by every lane alike */
     Q4 qc = m3_to_quat(Rs);
     Q4 qi = {-qc.x, -qc.y, -qc.z, qc.w};
     Q4 dq = qmul(tq, qi);
     float vn = sqrtf(dq.x * dq.x + dq.y * dq.y + dq.z * dq.z);     /* 2 acos(w) in its fp32-safe atan2 form */
     float angle = 2.f * atan2f(vn, dq.w);
     V3 axis = mk3(1, 0, 0);
-    if (vn >= 1e-12f) { float s = 1.f / vn; axis = mk3(dq.x * s, dq.y * s, dq.z * s); }
+    if (vn >= 1e-12f) { float sc = 1.f / vn; axis = mk3(dq.x * sc, dq.y * sc, dq.z * sc); }
     if (angle > RP_PI_F) angle -= 2.f * RP_PI_F;
-    float err[6] = {ep.x, ep.y, ep.z, angle * axis.x, angle * axis.y, angle * axis.z};
-    float J[6][NC];
-#pragma unroll
-    for (int j = 0; j < NC; j++) {
+    const float err[6] = {ep.x, ep.y, ep.z, angle * axis.x, angle * axis.y, angle * axis.z};
+    /* Jacobian column of this lane's joint */
+    float Jc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (isj) {
       V3 lin, ang = mk3(0, 0, 0);
-      if (m->arm_jtype[j] == 0) { lin = cross(axw[j], pos - org[j]); ang = axw[j]; }
-      else lin = axw[j];
-      J[0][j] = lin.x; J[1][j] = lin.y; J[2][j] = lin.z; J[3][j] = ang.x; J[4][j] = ang.y; J[5][j] = ang.z;
+      if (rev) { lin = cross(axw, pos - org); ang = axw; } else lin = axw;
+      Jc[0] = lin.x; Jc[1] = lin.y; Jc[2] = lin.z; Jc[3] = ang.x; Jc[4] = ang.y; Jc[5] = ang.z;
     }
-    float A[NC][NC], b[NC];
+    /* row l16 of A = J^T J + damp I and of b = J^T err */
+    float A[NC], b = 0.f;
 #pragma unroll
-    for (int r = 0; r < NC; r++) {
+    for (int k = 0; k < 6; k++) b += Jc[k] * err[k];
+    static_for<0, NC>([&](auto cc) {
+      constexpr int c = decltype(cc)::v;
+      float sacc = 0.f;
 #pragma unroll
-      for (int c = r; c < NC; c++) {
-        float s = 0.f;
+      for (int k = 0; k < 6; k++) sacc += Jc[k] * bcast16<c>(Jc[k]);
+      A[c] = sacc + (l16 == c ? K_IK_DAMP : 0.f);
+    });
+    /* SPD solve without pivoting: lane r eliminates its row against the broadcast pivot row; the pivots' reciprocals
+     * serve the back-substitution too */
+    float ipiv[NC];
+    static_for<0, NC>([&](auto cc) {
+      constexpr int c = decltype(cc)::v;
+      float pc[NC];
 #pragma unroll
-        for (int k = 0; k < 6; k++) s += J[k][r] * J[k][c];
-        A[r][c] = s + (r == c ? K_IK_DAMP : 0.f);
-        A[c][r] = A[r][c];
+      for (int k = c; k < NC; k++) pc[k] = bcast16<c>(A[k]);
+      const float pbv = bcast16<c>(b);
+      const float inv = 1.f / pc[c];
+      ipiv[c] = inv;
+      if (l16 > c) {
+        float f = A[c] * inv;
+#pragma unroll
+        for (int k = c; k < NC; k++) A[k] -= f * pc[k];
+        b -= f * pbv;
       }
-      float s = 0.f;
+    });
+    float xs[NC];
+    static_for<0, NC>([&](auto rr) {
+      constexpr int r = NC - 1 - decltype(rr)::v;
+      float sacc = b;
 #pragma unroll
-      for (int k = 0; k < 6; k++) s += J[k][r] * err[k];
-      b[r] = s;
-    }
-    /* SPD solve without pivoting */
+      for (int k = r + 1; k < NC; k++) sacc -= A[k] * xs[k];
+      xs[r] = bcast16<r>(sacc * ipiv[r]);
+    });
+    float mx = 0.f, mine = 0.f;
 #pragma unroll
-    for (int c = 0; c < NC; c++) {
-      float inv = 1.f / A[c][c];
-#pragma unroll
-      for (int r = c + 1; r < NC; r++) {
-        float f = A[r][c] * inv;
-#pragma unroll
-        for (int k = c; k < NC; k++) A[r][k] -= f * A[c][k];
-        b[r] -= f * b[c];
-      }
-    }
-#pragma unroll
-    for (int r = NC - 1; r >= 0; r--) {
-      float s = b[r];
-#pragma unroll
-      for (int k = r + 1; k < NC; k++) s -= A[r][k] * b[k];
-      b[r] = s / A[r][r];
-    }
-    float mx = 0.f;
-#pragma unroll
-    for (int j = 0; j < NC; j++) mx = fmaxf(mx, fabsf(b[j]));
-    float sc = mx > K_IK_MAXSTEP ? K_IK_MAXSTEP / mx : 1.f;
-#pragma unroll
-    for (int j = 0; j < NC; j++) q.q[j] += sc * b[j];
+    for (int j = 0; j < NC; j++) { mx = fmaxf(mx, fabsf(xs[j])); mine = l16 == j ? xs[j] : mine; }
+    const float sc = mx > K_IK_MAXSTEP ? K_IK_MAXSTEP / mx : 1.f;
+    if (!done && isj) qj += sc * mine;
   }
-  return q;
+  return qj;
 }
 
-__device__ __forceinline__ ChainQ ik_solve(const DevModel* m, V3 tpos, Q4 tq, ChainQ q, int max_iter) {
-  return m->ee_chain == 6 ? ik_solve_n<6>(m, tpos, tq, q, max_iter) : ik_solve_n<7>(m, tpos, tq, q, max_iter);
+/* replicated-value front end: every lane passes the same start vector and gets the same solution back */
+__device__ __forceinline__ ChainQ ik_solve(const DevModel* m, V3 tpos, Q4 tq, ChainQ q, int max_iter, int l16) {
+  float qj = 0.f;
+#pragma unroll
+  for (int j = 0; j < 7; j++) qj = l16 == j ? q.q[j] : qj;
+  qj = m->ee_chain == 6 ? ik_coop<6>(m, tpos, tq, qj, max_iter, l16, true) : ik_coop<7>(m, tpos, tq, qj, max_iter, l16, true);
+  ChainQ r;
+  static_for<0, 7>([&](auto jc) { constexpr int j = decltype(jc)::v; r.q[j] = bcast16<j>(qj); });
+  return r;
 }
 
 /* perform_action('absolute_rpy') .. close_gripper (environments.py:915-1073); every lane computes the same values,
@@ -1235,10 +1286,10 @@ __device__ ChainQ perform_action(const DevModel* m, EnvLds& L, int lane, const f
 #pragma unroll
   for (int j = 0; j < 7; j++) cur.q[j] = j < m->ee_chain ? L.st[ST_Q + j] : 0.f;
   ChainQ sol;
-  if (m->kind == RP_KIND_P) sol = ik_solve(m, tpos, tq, cur, 200);
+  if (m->kind == RP_KIND_P) sol = ik_solve(m, tpos, tq, cur, 200, lane & 15);
   else {   /* InverseKinematicsSolver.calc_angles: 4 chained default IK solves from the measured joints */
     sol = cur;
-    for (int rep = 0; rep < 4; rep++) sol = ik_solve(m, tpos, tq, sol, 20);
+    for (int rep = 0; rep < 4; rep++) sol = ik_solve(m, tpos, tq, sol, 20, lane & 15);
   }
   ChainQ tp;
 #pragma unroll
@@ -1596,7 +1647,7 @@ __global__ void __launch_bounds__(64, RP_WAVES_PER_EU) k_reset(const DevModel* _
 #pragma unroll
     for (int j = 0; j < 7; j++) cur.q[j] = j < m->ee_chain ? L.st[ST_Q + j] : 0.f;
     Q4 ident = {0.f, 0.f, 0.f, 1.f};
-    ChainQ sol = ik_solve(m, mk3(tx[0], tx[1], tx[2]), ident, cur, 20);
+    ChainQ sol = ik_solve(m, mk3(tx[0], tx[1], tx[2]), ident, cur, 20, lane & 15);
     __syncthreads();
     if (lane == 0) for (int i = 0; i < 6; i++) { L.st[ST_Q + i] = sol.q[i]; L.st[ST_QD + i] = 0.f; }
     __syncthreads();
@@ -1656,11 +1707,13 @@ __global__ void k_copy_state(float* __restrict__ dst, const float* __restrict__ 
  *   12 x { k_prep2 (wave per env: FK, collision, dynamics, constraint rows -> per-env workspace, L2/MALL resident)
  *          k_solve2 (two envs per wave: PGS sweeps on register-resident rows + integration, state record in/out) }
  *   k_calc_state (wave per env) calc_state + reward + outputs */
-/* thread per env: perform_action (environments.py:915-1073) with the IK in private registers */
+/* perform_action (environments.py:915-1073), 16 lanes (one DPP row) per env, four envs per wave: cooperative IK */
 __global__ void __launch_bounds__(64) k_action(const DevModel* __restrict__ m, float* __restrict__ state, const float* __restrict__ action,
                                               float* __restrict__ target_poses, int env0, int N) {
-  int env = env0 + blockIdx.x * blockDim.x + threadIdx.x;      /* this launch covers envs [env0, N) */
-  if (env >= N) return;
+  const int l16 = threadIdx.x & 15;
+  const int env_raw = env0 + blockIdx.x * 4 + (threadIdx.x >> 4);      /* this launch covers envs [env0, N) */
+  const bool live = env_raw < N;
+  const int env = live ? env_raw : env0;
   float* st = state + (size_t)env * RP_REC_FLOATS;
   const float high[7] = {6.f, 6.f, 6.f, 6.f, 6.f, 6.f, 1.f};       /* environments.py:108-109, 207 */
   float a7[7];
@@ -1668,38 +1721,33 @@ __global__ void __launch_bounds__(64) k_action(const DevModel* __restrict__ m, f
   for (int k = 0; k < 7; k++) a7[k] = clampf(action[(size_t)env * 7 + k], -high[k], high[k]);
   V3 tpos = mk3(a7[0], a7[1], a7[2]);
   Q4 tq = quat_from_euler(a7[3], a7[4], a7[5]);
-  int nd = m->n_target;
-  ChainQ cur;
-#pragma unroll
-  for (int j = 0; j < 7; j++) cur.q[j] = j < m->ee_chain ? st[ST_Q + j] : 0.f;
-  ChainQ sol;
-  if (m->kind == RP_KIND_P) sol = ik_solve(m, tpos, tq, cur, 200);
-  else {
-    sol = cur;
-    for (int rep = 0; rep < 4; rep++) sol = ik_solve(m, tpos, tq, sol, 20);
+  const int nd = m->n_target, nc = m->ee_chain;
+  const float q0 = st[ST_Q + (l16 < RP_MAX_ARM ? l16 : 0)];            /* measured joint value of dof l16 */
+  float qj = l16 < nc ? q0 : 0.f;
+  if (m->kind == RP_KIND_P) qj = ik_coop<7>(m, tpos, tq, qj, 200, l16, live);
+  else if (nc == 6) { for (int rep = 0; rep < 4; rep++) qj = ik_coop<6>(m, tpos, tq, qj, 20, l16, live); }
+  else { for (int rep = 0; rep < 4; rep++) qj = ik_coop<7>(m, tpos, tq, qj, 20, l16, live); }
+  if (!live) return;
+  if (l16 < nd) {
+    float t = clampf(qj, m->ll[l16], m->ul[l16]);
+    t = clampf(t, q0 - m->inc[l16], q0 + m->inc[l16]);
+    st[ST_MMODE + l16] = 1.f; st[ST_MTARGET + l16] = t; st[ST_MMAXIMP + l16] = 240.f * K_DT;
+    if (target_poses) target_poses[(size_t)env * nd + l16] = t;
   }
-#pragma unroll
-  for (int j = 0; j < 7; j++) {
-    if (j < nd) {
-      float t = clampf(sol.q[j], m->ll[j], m->ul[j]);
-      float c = st[ST_Q + j];
-      t = clampf(t, c - m->inc[j], c + m->inc[j]);
-      st[ST_MMODE + j] = 1.f; st[ST_MTARGET + j] = t; st[ST_MMAXIMP + j] = 240.f * K_DT;
-      if (target_poses) target_poses[(size_t)env * nd + j] = t;
+  if (l16 == 0) {
+    float g = a7[6];
+    if (m->kind == RP_KIND_P) {
+      float amt = 0.04f - g / 25.f;
+      int ds[2] = {m->d9p, m->d10p};
+      for (int i = 0; i < 2; i++) { st[ST_MMODE + ds[i]] = 1.f; st[ST_MTARGET + ds[i]] = amt; st[ST_MMAXIMP + ds[i]] = 100.f * K_DT; }
+    } else {
+      float amt = g - 0.2f;
+      float left = st[ST_Q + m->d18];
+      int ds[6] = {m->d18, m->d20, m->d12, m->d15, m->d10, m->d13};
+      float tg[6] = {amt * 0.055f, left, amt * 0.5f, amt * 0.5f, amt * 0.8f, amt * 0.8f};
+      float fo[6] = {100.f, 1000.f, 100.f, 100.f, 100.f, 100.f};
+      for (int i = 0; i < 6; i++) { st[ST_MMODE + ds[i]] = 1.f; st[ST_MTARGET + ds[i]] = tg[i]; st[ST_MMAXIMP + ds[i]] = fo[i] * K_DT; }
     }
-  }
-  float g = a7[6];
-  if (m->kind == RP_KIND_P) {
-    float amt = 0.04f - g / 25.f;
-    int ds[2] = {m->d9p, m->d10p};
-    for (int i = 0; i < 2; i++) { st[ST_MMODE + ds[i]] = 1.f; st[ST_MTARGET + ds[i]] = amt; st[ST_MMAXIMP + ds[i]] = 100.f * K_DT; }
-  } else {
-    float amt = g - 0.2f;
-    float left = st[ST_Q + m->d18];
-    int ds[6] = {m->d18, m->d20, m->d12, m->d15, m->d10, m->d13};
-    float tg[6] = {amt * 0.055f, left, amt * 0.5f, amt * 0.5f, amt * 0.8f, amt * 0.8f};
-    float fo[6] = {100.f, 1000.f, 100.f, 100.f, 100.f, 100.f};
-    for (int i = 0; i < 6; i++) { st[ST_MMODE + ds[i]] = 1.f; st[ST_MTARGET + ds[i]] = tg[i]; st[ST_MMAXIMP + ds[i]] = fo[i] * K_DT; }
   }
 }
 
@@ -1906,18 +1954,6 @@ __device__ __forceinline__ float fold_rows(float v) {
   auto sw = __builtin_amdgcn_permlane16_swap(u, u, false, false);     /* [r0 r0 r2 r2], [r1 r1 r3 r3] */
   return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
 }
-/* value of lane K (0..15) of each 16-lane DPP row, delivered to the whole row: one v_mov_b32_dpp row_newbcast.
- * The DPP control is an immediate, so labels are template constants (static_for below, not #pragma unroll). */
-template <int K>
-__device__ __forceinline__ float bcast16(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + (K & 15), 0xF, 0xF, true));
-}
-template <int T> struct IdxC { static constexpr int v = T; };
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I < N) { f(IdxC<I>{}); static_for<I + 1, N>(f); }
-}
-
 /* one plane register set: lane k holds the scalars of the row labelled k */
 struct Plane { float rhs, lo, hi, lam, dacc, loP, hiP; };
 /* the row bodies below are inline asm (the compiler inserts no hazard nops inside): a DPP read needs two wait states

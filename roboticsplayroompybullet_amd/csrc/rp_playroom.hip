@@ -172,7 +172,7 @@ int rp_step(rp_handle h, const float* action, const rp_out* out, void* stream) {
       int* gcnt[2] = {h->sort_cnt + (size_t)g * SORT_BINS, h->sort_cnt + (size_t)(RP_MAX_GROUPS + g) * SORT_BINS};
       int par = h->sort_par;
       if (h->sort_G != G) hipLaunchKernelGGL(k_sort_init, dim3((max(ng, SORT_BINS) + 255) / 256), dim3(256), 0, gs, gcnt[par], h->sort_slot, e0, ng);
-      TIMED(hipLaunchKernelGGL(k_action, dim3((ng + 63) / 64), dim3(64), 0, gs, h->dev_model, h->state, action, op.target_poses, e0, e1));
+      TIMED(hipLaunchKernelGGL(k_action, dim3((ng + 3) / 4), dim3(64), 0, gs, h->dev_model, h->state, action, op.target_poses, e0, e1));
       for (int sub = 0; sub < K_NSUB; sub++) {
         TIMED(hipLaunchKernelGGL(k_prep2, dim3(ng), dim3(64), 0, gs, h->dev_model, h->state, h->ws, e0, e1, gcnt[par], gcnt[par ^ 1], h->sort_slot, h->pair_env));
         TIMED(hipLaunchKernelGGL(k_solve2, dim3((ng + 1) / 2), dim3(64), 0, gs, h->dev_model, h->state, h->ws, e0, e1, h->pair_env, gcnt[par ^ 1], h->sort_slot));
