@@ -79,6 +79,8 @@ def load():
     lib.rp_debug_substep.argtypes = [vp, C.c_int32, C.POINTER(C.c_float)]
     lib.rp_set_fused.argtypes = [vp, C.c_int32]
     lib.rp_set_groups.argtypes = [vp, C.c_int32]
+    lib.rp_set_debug_flags.argtypes = [vp, C.c_int32]
+    lib.rp_debug_row_counts.argtypes = [vp, C.POINTER(C.c_int32)]
     _lib = lib
     return lib
 

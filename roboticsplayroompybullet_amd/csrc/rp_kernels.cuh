@@ -2039,7 +2039,7 @@ __device__ __forceinline__ void generic_row(float Jr, float Br, float& dv, Plane
 }
 
 __global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m, float* __restrict__ state, const float* __restrict__ ws, int env0, int N,
-                                                  const int* __restrict__ pair_env, int* __restrict__ sort_cnt_next, int* __restrict__ sort_slot) {
+                                                  const int* __restrict__ pair_env, int* __restrict__ sort_cnt_next, int* __restrict__ sort_slot, int debug_flags) {
   __shared__ Solve2Lds L;
   const int lane = threadIdx.x, half = lane >> 5, l = lane & 31, grp = l >> 4, l16 = lane & 15;
 #if defined(RP_CLOCKS) && RP_CLOCKS != 2
@@ -2073,7 +2073,7 @@ __global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m
 #if defined(RP_FORCE_PATH)    /* timing ablation: 0 = never side by side */
   const bool par = RP_FORCE_PATH == 1 && nS_w + nC_w <= MAXC;
 #else
-  const bool par = nS_w + nC_w <= MAXC;
+  const bool par = nS_w + nC_w <= MAXC && !(debug_flags & 1);      /* debug flag 1 (tests): always take the fallback */
 #endif
   const int nS = par ? nS_w : 0, nC = par ? nC_w : nc_w;
   const int dd = lane_dof(m, l);            /* velocity component owned by this lane, -1 if none */

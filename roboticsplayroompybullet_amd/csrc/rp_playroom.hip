@@ -21,6 +21,7 @@ struct rp_sim {
   int* sort_cnt;           /* [2][RP_MAX_GROUPS][SORT_BINS] load-class histograms for pairing envs in k_solve2 (double-buffered) */
   int* sort_slot;          /* [N] per env: (bin << 16) | rank inside the bin, from the latest k_solve2 */
   int* pair_env;           /* [N] per group range: env ids sorted by load class, heaviest first (k_solve2 pairs neighbours) */
+  int debug_flags;         /* rp_set_debug_flags: bit 0 = k_solve2 never solves contacts side by side (one folded slot per contact) */
   int sort_G, sort_par;    /* group count the tables were built for (0 = none yet); buffer that the next k_solve2 reads */
   hipEvent_t ev0, ev1;
   hipEvent_t* pool;        /* per-launch timing ring: EV_PER_STEP events per recorded step */
@@ -175,7 +176,7 @@ int rp_step(rp_handle h, const float* action, const rp_out* out, void* stream) {
       TIMED(hipLaunchKernelGGL(k_action, dim3((ng + 3) / 4), dim3(64), 0, gs, h->dev_model, h->state, action, op.target_poses, e0, e1));
       for (int sub = 0; sub < K_NSUB; sub++) {
         TIMED(hipLaunchKernelGGL(k_prep2, dim3(ng), dim3(64), 0, gs, h->dev_model, h->state, h->ws, e0, e1, gcnt[par], gcnt[par ^ 1], h->sort_slot, h->pair_env));
-        TIMED(hipLaunchKernelGGL(k_solve2, dim3((ng + 1) / 2), dim3(64), 0, gs, h->dev_model, h->state, h->ws, e0, e1, h->pair_env, gcnt[par ^ 1], h->sort_slot));
+        TIMED(hipLaunchKernelGGL(k_solve2, dim3((ng + 1) / 2), dim3(64), 0, gs, h->dev_model, h->state, h->ws, e0, e1, h->pair_env, gcnt[par ^ 1], h->sort_slot, h->debug_flags));
         par ^= 1;
       }
       if (g == G - 1) { h->sort_par = par; h->sort_G = G; }
@@ -230,6 +231,7 @@ int rp_set_state(rp_handle h, const void* src, int32_t src_env_count, void* stre
   return RP_OK;
 }
 
+int rp_set_debug_flags(rp_handle h, int32_t flags) { if (!h) return RP_ERR_ARG; h->debug_flags = flags; return RP_OK; }
 int rp_set_groups(rp_handle h, int32_t groups) { if (!h || groups < 1 || groups > RP_MAX_GROUPS) return RP_ERR_ARG; h->groups = groups; return RP_OK; }
 int rp_set_fused(rp_handle h, int32_t fused) { if (!h || (fused != 0 && fused != 1)) return RP_ERR_ARG; h->fused = fused; return RP_OK; }
 int rp_get_timers(rp_handle h, rp_timers* t) {

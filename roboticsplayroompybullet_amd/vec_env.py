@@ -137,6 +137,18 @@ class VecPlayEnv:
         """number of env groups (each with its own stream and kernel chain) rp_step uses; results do not depend on it"""
         _lib.check(self.lib, self.h, self.lib.rp_set_groups(self.h, int(groups)), 'rp_set_groups')
 
+    def set_debug_flags(self, flags):
+        """test hook: bit 0 makes the solver give every contact its own folded slot (its fallback layout) instead of solving
+        arm-only and non-arm contacts side by side; results are bit-identical either way"""
+        _lib.check(self.lib, self.h, self.lib.rp_set_debug_flags(self.h, int(flags)), 'rp_set_debug_flags')
+
+    def debug_row_counts(self):
+        """test hook: per env of the latest substep, [unit rows, contacts, 1 if an arm contact, spanning contacts] (host tensor)"""
+        buf = (C.c_int32 * (2 * self.num_envs))()
+        _lib.check(self.lib, self.h, self.lib.rp_debug_row_counts(self.h, buf), 'rp_debug_row_counts')
+        a = torch.tensor(list(buf), dtype=torch.int64).reshape(self.num_envs, 2)
+        return torch.stack([a[:, 0], a[:, 1] % 1000, (a[:, 1] // 1000) % 100, a[:, 1] // 100000], 1)
+
     def enable_timers(self, steps=64):
         """keep per-launch hipEvent timings for the next `steps` rp_step calls (0 disables)"""
         _lib.check(self.lib, self.h, self.lib.rp_enable_timers(self.h, int(steps)), 'rp_enable_timers')
