@@ -27,8 +27,17 @@ typedef struct rp_sim* rp_handle;
 
 enum rp_status { RP_OK = 0, RP_ERR_ARG = -1, RP_ERR_HIP = -2, RP_ERR_UNSUPPORTED = -3, RP_ERR_STATE_SIZE = -4 };
 
-/* registered ids in scope (roboticsPlayroomPybullet/__init__.py:92,66,24) */
-enum rp_env_kind { RP_ENV_UR5_PLAY_ABS_RPY_1OBJ = 0, RP_ENV_UR5_REACH = 1, RP_ENV_PANDA_PICK = 2 };
+/* registered ids in scope (roboticsPlayroomPybullet/__init__.py:92,66,24) and, from SURVEY.md 8f rank 1, the rest of
+ * the UR5 one-object play family (__init__.py:72,77,82,87,97; envList.py:101-140): same scene and arm as
+ * UR5PlayAbsRPY1Obj-v0, other action types (environments.py:915-981) */
+enum rp_env_kind {
+  RP_ENV_UR5_PLAY_ABS_RPY_1OBJ = 0, RP_ENV_UR5_REACH = 1, RP_ENV_PANDA_PICK = 2,
+  RP_ENV_UR5_PLAY_1OBJ = 3,            /* absolute_quat   [x y z qx qy qz qw grip]  */
+  RP_ENV_UR5_PLAY_REL_1OBJ = 4,        /* relative_quat   (added to the measured EE pose, componentwise) */
+  RP_ENV_UR5_PLAY_REL_JOINTS_1OBJ = 5, /* relative_joints [dq0..dq5 grip], no IK */
+  RP_ENV_UR5_PLAY_ABS_JOINTS_1OBJ = 6, /* absolute_joints [q0..q5 grip], no IK */
+  RP_ENV_UR5_PLAY_REL_RPY_1OBJ = 7     /* relative_rpy    [dx dy dz droll dpitch dyaw grip] */
+};
 
 typedef struct rp_config {
   int32_t env_kind;      /* rp_env_kind */
@@ -90,7 +99,7 @@ int rp_reset_goal(rp_handle h, const float* goal, const uint8_t* mask, void* str
 
 /* playEnv.step(action) (ENV:206-214): clip -> absolute_rpy IK (IKS:44-50 / ENV:995-997) -> motor targets
  * (ENV:1010-1073) -> 12 x stepSimulation at 300 Hz (ENV:485-490) -> calc_state (ENV:799-864) -> reward.
- * action [N, 7] = x y z roll pitch yaw gripper. */
+ * action [N, dims.action]: x y z roll pitch yaw gripper for the absolute_rpy ids; see rp_env_kind for the others. */
 int rp_step(rp_handle h, const float* action, const rp_out* out, void* stream);
 
 /* instance.calc_state() without stepping (ENV:799-864); updates the quaternion sign memory like the reference. */

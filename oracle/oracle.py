@@ -79,6 +79,10 @@ def load(f32=False):
     lib.rpo_dial_to_0_1_range.argtypes = [C.c_double]
     lib.rpo_dial_to_0_1_range.restype = C.c_double
     lib.rpo_perform_action.argtypes = [vp, dp, dp]
+    lib.rpo_action_target.argtypes = [C.c_int, dp, dp, dp, dp, dp]
+    lib.rpo_set_action_type.argtypes = [vp, C.c_int]
+    lib.rpo_action_dim.argtypes = [vp]
+    lib.rpo_action_dim.restype = C.c_int
     lib.rpo_goto_joint_poses.argtypes = [vp, dp, C.c_int, C.c_double, dp]
     lib.rpo_ik.argtypes = [vp, dp, dp, dp, C.c_int, dp]
     lib.rpo_calc_angles.argtypes = [vp, dp, dp, dp, dp]
@@ -107,13 +111,23 @@ def _d(a):
     return a, a.ctypes.data_as(C.POINTER(C.c_double))
 
 
+ACTION_TYPES = {'absolute_rpy': 0, 'relative_rpy': 1, 'absolute_quat': 2, 'relative_quat': 3, 'absolute_joints': 4, 'relative_joints': 5}
+FAMILY = {'UR5PlayAbsRPY1Obj-v0': 'absolute_rpy', 'UR5PlayRelRPY1Obj-v0': 'relative_rpy', 'UR5Play1Obj-v0': 'absolute_quat',
+          'UR5PlayRel1Obj-v0': 'relative_quat', 'UR5PlayAbsJoints1Obj-v0': 'absolute_joints', 'UR5PlayRelJoints1Obj-v0': 'relative_joints'}
+
+
 class OracleEnv:
     """One reference env (instance + playEnv) on the CPU oracle."""
 
-    def __init__(self, kind, seed=0, env_index=0, f32=False):
+    def __init__(self, kind, seed=0, env_index=0, f32=False, action_type=None):
         self.lib = load(f32)
+        if kind in FAMILY:                  # a registered id of the UR5 one-object play family: scene U, other action type
+            kind, action_type = 'U', FAMILY[kind]
         self.kind = KINDS[kind]
         self.h = self.lib.rpo_create(self.kind, seed, env_index)
+        self.action_type = action_type or 'absolute_rpy'
+        self.lib.rpo_set_action_type(self.h, ACTION_TYPES[self.action_type])
+        self.n_action = self.lib.rpo_action_dim(self.h)
         self.n_arm = self.lib.rpo_n_arm(self.h)
         self.nv = self.lib.rpo_nv(self.h)
         self.n_goal = 11 if self.kind == 0 else 3
@@ -156,6 +170,15 @@ class OracleEnv:
         tp = np.zeros(7)
         self.lib.rpo_step(self.h, ap, C.byref(o), C.byref(r), C.byref(s), tp.ctypes.data_as(C.POINTER(C.c_double)))
         return o.to_dict(self.n_goal), r.value, False, {'is_success': s.value, 'target_poses': tp[:self.n_target].copy()}
+
+    def action_target(self, action, ee_pos, ee_orn):
+        """IK target of a pose-type action from the clipped action and a measured EE pose (test hook)"""
+        a = np.zeros(8); a[:len(action)] = action
+        pos, quat = np.zeros(3), np.zeros(4)
+        dp = C.POINTER(C.c_double)
+        at = ACTION_TYPES[self.action_type]
+        self.lib.rpo_action_target(at, _d(a)[1], _d(ee_pos)[1], _d(ee_orn)[1], pos.ctypes.data_as(dp), quat.ctypes.data_as(dp))
+        return pos, quat
 
     def calc_state(self):
         o = RpoObs()

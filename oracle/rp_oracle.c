@@ -72,6 +72,7 @@ struct rpo_env {
   real last_obs[19], last_ag[11]; int have_last;
   /* config flags (envList.py) */
   int play, use_orientation, return_velocity, num_objects;
+  int action_type;                  /* RPO_ACT_*: perform_action's dispatch (environments.py:915-934) */
   real goal_lo[3], goal_hi[3], obj_lo[3], obj_hi[3], env_hi[3];
   /* work */
   xform xb[NB_MAX];                 /* world transform of every body frame */
@@ -1024,23 +1025,86 @@ void rpo_goto_joint_poses(rpo_env* e, const double* joint_poses, int has_gripper
   for (int i = 0; i < nd; i++) target_poses[i] = tp[i];
 }
 
-/* perform_action('absolute_rpy') -> absolute_rpy_step -> goto (environments.py:915-934, 955-961, 984-1007) */
+/* perform_action -> <action type>_step -> goto / goto_joint_poses (environments.py:915-1007).  Action layouts:
+ *   absolute_rpy / relative_rpy   [x y z roll pitch yaw grip]        (7)
+ *   absolute_quat / relative_quat [x y z qx qy qz qw grip]           (8; the quaternion is used as given, not normalised)
+ *   absolute_joints / relative_joints [q0 .. q(nd-1) grip]           (nd + 1; no IK)
+ * The relative types add the action to the measured EE link pose (getLinkState()[0], [1]; orientation componentwise,
+ * for relative_rpy after getEulerFromQuaternion) or to the measured joints. */
+static int action_dim(const rpo_env* e) {
+  int nd = e->m.kind == RP_KIND_P ? 7 : 6;
+  switch (e->action_type) {
+    case RPO_ACT_ABS_QUAT: case RPO_ACT_REL_QUAT: return 8;
+    case RPO_ACT_ABS_JOINTS: case RPO_ACT_REL_JOINTS: return nd + 1;
+    default: return 7;
+  }
+}
+static void action_high(const rpo_env* e, real* high) {   /* environments.py:88-113 */
+  int n = action_dim(e);
+  for (int i = 0; i < n; i++) high[i] = 1;
+  if (e->action_type == RPO_ACT_ABS_RPY) for (int i = 0; i < 6; i++) high[i] = 6;
+  if (e->action_type == RPO_ACT_ABS_JOINTS) for (int i = 0; i < n - 1; i++) high[i] = 6;
+}
+/* IK target of a pose-type action from the (clipped) action and the measured EE pose (environments.py:936-981) */
+static void action_target(int at, const real* a, const real* cp, const real* cq, real* pos, real* quat) {
+  for (int k = 0; k < 3; k++) pos[k] = a[k];
+  if (at == RPO_ACT_ABS_RPY) quat_from_euler(quat, a + 3);
+  else if (at == RPO_ACT_ABS_QUAT) for (int k = 0; k < 4; k++) quat[k] = a[3 + k];
+  else {
+    for (int k = 0; k < 3; k++) pos[k] = a[k] + cp[k];
+    if (at == RPO_ACT_REL_QUAT) for (int k = 0; k < 4; k++) quat[k] = a[3 + k] + cq[k];
+    else {
+      real ce[3], ne[3];
+      euler_from_quat(ce, cq);
+      for (int k = 0; k < 3; k++) ne[k] = a[3 + k] + ce[k];
+      quat_from_euler(quat, ne);
+    }
+  }
+}
+void rpo_action_target(int action_type, const double* action, const double* ee_pos, const double* ee_orn, double* pos, double* quat) {
+  real a[8], cp[3], cq[4], p[3], q[4];
+  for (int i = 0; i < 8; i++) a[i] = (real)action[i];
+  for (int i = 0; i < 3; i++) cp[i] = (real)ee_pos[i];
+  for (int i = 0; i < 4; i++) cq[i] = (real)ee_orn[i];
+  action_target(action_type, a, cp, cq, p, q);
+  for (int i = 0; i < 3; i++) pos[i] = p[i];
+  for (int i = 0; i < 4; i++) quat[i] = q[i];
+}
 static void perform_action(rpo_env* e, const real* a, real* target_poses) {
-  real quat[4], jp[RP_MAX_ARM];
-  quat_from_euler(quat, a + 3);
+  real quat[4], pos[3], jp[RP_MAX_ARM];
+  int nd = e->m.kind == RP_KIND_P ? 7 : 6;
+  int at = e->action_type;
+  if (at == RPO_ACT_ABS_JOINTS || at == RPO_ACT_REL_JOINTS) {
+    for (int i = 0; i < nd; i++) jp[i] = at == RPO_ACT_REL_JOINTS ? a[i] + e->q[i] : a[i];
+    goto_joint_poses(e, jp, 1, a[nd], target_poses);
+    return;
+  }
+  real grip = (at == RPO_ACT_ABS_QUAT || at == RPO_ACT_REL_QUAT) ? a[7] : a[6];
+  real cp[3] = {0, 0, 0}, cq[4] = {0, 0, 0, 1};
+  if (at == RPO_ACT_REL_RPY || at == RPO_ACT_REL_QUAT) {     /* getLinkState(arm, endEffectorIndex)[0], [1] */
+    real R[9];
+    update_transforms(e);
+    site_world(e, e->xb, RP_SITE_EE, cp, R);
+    m3_to_quat(cq, R);
+  }
+  action_target(at, a, cp, cq, pos, quat);
   if (e->m.kind == RP_KIND_P) {
     real sol[RP_MAX_ARM];
-    ik_solve(e, a, quat, e->q, 200, sol);        /* maxNumIterations=200 on the live arm (environments.py:995-997) */
+    ik_solve(e, pos, quat, e->q, 200, sol);        /* maxNumIterations=200 on the live arm (environments.py:995-997) */
     for (int i = 0; i < 7; i++) jp[i] = sol[i];
   } else {
-    calc_angles(e, a, quat, e->q, jp);
+    calc_angles(e, pos, quat, e->q, jp);
   }
-  goto_joint_poses(e, jp, 1, a[6], target_poses);
+  goto_joint_poses(e, jp, 1, grip, target_poses);
 }
 
+void rpo_set_action_type(rpo_env* e, int action_type) { e->action_type = action_type; }
+int rpo_action_dim(const rpo_env* e) { return action_dim(e); }
+
 void rpo_perform_action(rpo_env* e, const double* action, double* target_poses) {
-  real a[7], tp[7];
-  for (int i = 0; i < 7; i++) a[i] = (real)action[i];
+  real a[8], tp[7];
+  int na = action_dim(e);
+  for (int i = 0; i < na; i++) a[i] = (real)action[i];
   perform_action(e, a, tp);
   int nd = e->m.kind == RP_KIND_P ? 7 : 6;
   for (int i = 0; i < nd; i++) target_poses[i] = tp[i];
@@ -1266,9 +1330,10 @@ double rpo_compute_reward(const rpo_env* e, const double* ag, const double* dg) 
 
 /* ------------------------------------------------------------------ harness: step / reset */
 void rpo_step(rpo_env* e, const double* action, rpo_obs* out, double* reward, int* is_success, double* target_poses) {
-  static const real high[7] = {6, 6, 6, 6, 6, 6, 1};      /* environments.py:108-109 */
-  real a[7], tp[7];
-  for (int i = 0; i < 7; i++) a[i] = clampr((real)action[i], -high[i], high[i]);
+  real high[8], a[8], tp[7];
+  action_high(e, high);                                    /* environments.py:88-113, 207 */
+  int na = action_dim(e);
+  for (int i = 0; i < na; i++) a[i] = clampr((real)action[i], -high[i], high[i]);
   perform_action(e, a, tp);
   rpo_run_simulation(e);
   calc_state(e, out);

@@ -32,6 +32,12 @@ typedef struct rpo_readings {
 } rpo_readings;
 
 rpo_env* rpo_create(int kind /*0 U, 1 R, 2 P*/, unsigned long long seed, int env_index);
+/* perform_action's dispatch (environments.py:915-934); default RPO_ACT_ABS_RPY.  Action length: rpo_action_dim. */
+enum { RPO_ACT_ABS_RPY = 0, RPO_ACT_REL_RPY = 1, RPO_ACT_ABS_QUAT = 2, RPO_ACT_REL_QUAT = 3, RPO_ACT_ABS_JOINTS = 4, RPO_ACT_REL_JOINTS = 5 };
+void rpo_set_action_type(rpo_env* e, int action_type);
+int rpo_action_dim(const rpo_env* e);
+/* test hook: IK target (position, quaternion) of a pose-type action given the measured EE link pose */
+void rpo_action_target(int action_type, const double* action8, const double* ee_pos, const double* ee_orn, double* pos, double* quat);
 void rpo_destroy(rpo_env*);
 int rpo_nv(const rpo_env*);
 int rpo_n_arm(const rpo_env*);

@@ -32,5 +32,9 @@ def make(id, **kwargs):
 register(id='pandaPick-v0', entry_point='roboticsplayroompybullet_amd.envs:pandaPick')
 register(id='UR5Reach-v0', entry_point='roboticsplayroompybullet_amd.envs:UR5Reach')
 register(id='UR5PlayAbsRPY1Obj-v0', entry_point='roboticsplayroompybullet_amd.envs:UR5PlayAbsRPY1Obj')
+# roboticsPlayroomPybullet/__init__.py:72,77,82,87,97 - the rest of the UR5 one-object play family
+for _id, _cls in (('UR5Play1Obj-v0', 'UR5Play1Obj'), ('UR5PlayRel1Obj-v0', 'UR5PlayRel1Obj'), ('UR5PlayRelJoints1Obj-v0', 'UR5PlayRelJoints1Obj'),
+                  ('UR5PlayAbsJoints1Obj-v0', 'UR5PlayAbsJoints1Obj'), ('UR5PlayRelRPY1Obj-v0', 'UR5PlayRelRPY1Obj')):
+    register(id=_id, entry_point='roboticsplayroompybullet_amd.envs:' + _cls)
 
 __all__ = ['VecPlayEnv', 'make', 'register']

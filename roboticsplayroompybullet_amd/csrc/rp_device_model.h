@@ -31,6 +31,7 @@ typedef struct DevModel {
   int kind, n_arm, n_free, n_j1, n_col, n_pair, nv, nbody, n_site;
   int play, use_orientation, return_velocity, num_objects, n_goal_init;
   int n_obs, n_ag, n_fps, n_observation, n_target;
+  int action_type, n_action;    /* RP_ACT_* (environments.py:915-934) and the action length: 7, 8 (quaternion types) or n_target + 1 (joint types) */
   int arm_parent[RP_MAX_ARM], arm_jtype[RP_MAX_ARM], arm_limited[RP_MAX_ARM];
   uint32_t arm_anc[RP_MAX_ARM]; /* bit k set: dof k is an ancestor-or-self of body i */
   uint32_t arm_sub[RP_MAX_ARM]; /* bit j set: body j is in the subtree of body i (incl. i) */

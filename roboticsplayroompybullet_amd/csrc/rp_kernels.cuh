@@ -1170,6 +1170,76 @@ __device__ __forceinline__ Xf xf_shr(const Xf& x) {
   return r;
 }
 
+/* chain FK by the 16 lanes of a DPP row: local transforms, then an inclusive scan of compositions over lanes 0..NC-1.
+ * Out: this lane's joint origin and world axis, and (replicated) the EE site position and orientation. */
+template <int NC>
+__device__ __forceinline__ void chain_fk_coop(const M3& R0, V3 p0, V3 ax, bool rev, const Xf& base, V3 sp, const M3& sr, float qj, int l16,
+                                              V3& org, V3& axw, V3& pos, M3& Rs) {
+  const bool isj = l16 < NC;
+  Xf x; x.R = ident3(); x.p = mk3(0, 0, 0);
+  if (isj) {
+    x.R = R0; x.p = p0;
+    if (rev) x.R = mul(R0, axis_angle(ax, qj)); else x.p = p0 + mulv(R0, ax) * qj;
+  }
+  if (l16 == 0) x = xf_compose(base, x);
+  { Xf y = xf_shr<1>(x); Xf z = xf_compose(y, x); if (l16 >= 1) x = z; }
+  { Xf y = xf_shr<2>(x); Xf z = xf_compose(y, x); if (l16 >= 2) x = z; }
+  { Xf y = xf_shr<4>(x); Xf z = xf_compose(y, x); if (l16 >= 4) x = z; }
+  org = x.p; axw = mulv(x.R, ax);
+  const V3 posl = x.p + mulv(x.R, sp);
+  const M3 Rsl = mul(x.R, sr);
+  pos = mk3(bcast16<NC - 1>(posl.x), bcast16<NC - 1>(posl.y), bcast16<NC - 1>(posl.z));
+#pragma unroll
+  for (int k = 0; k < 9; k++) Rs.m[k] = bcast16<NC - 1>(Rsl.m[k]);
+}
+
+/* measured EE link pose (getLinkState(arm, endEffectorIndex)[0], [1]) by the 16 lanes of a DPP row; qj = lane's joint value */
+__device__ __forceinline__ void ee_pose_coop(const DevModel* m, float qj, int l16, V3& pos, Q4& orn) {
+  const int nc = m->ee_chain;
+  const int jj = l16 < nc ? l16 : 0;
+  const M3 R0 = ldm3(m->arm_jrot[jj]);
+  const V3 p0 = ld3(m->arm_jpos[jj]), ax = ld3(m->arm_axis[jj]);
+  const bool rev = m->arm_jtype[jj] == 0;
+  Xf base; base.R = ldm3(m->base_rot); base.p = ld3(m->base_pos);
+  const V3 sp = ld3(m->site_pos[RP_SITE_EE]);
+  const M3 sr = ldm3(m->site_rot[RP_SITE_EE]);
+  V3 org, axw; M3 Rs;
+  if (nc == 6) chain_fk_coop<6>(R0, p0, ax, rev, base, sp, sr, qj, l16, org, axw, pos, Rs);
+  else chain_fk_coop<7>(R0, p0, ax, rev, base, sp, sr, qj, l16, org, axw, pos, Rs);
+  orn = m3_to_quat(Rs);
+}
+
+/* action types (environments.py:88-113, 915-981).  Layouts: rpy types [x y z r p y grip], quat types [x y z qx qy qz qw grip],
+ * joint types [q0..q(nd-1) grip].  The relative pose types add the action to the measured EE pose (orientation
+ * componentwise; relative_rpy after getEulerFromQuaternion), the relative joint type to the measured joints. */
+#define RP_ACT_ABS_RPY 0
+#define RP_ACT_REL_RPY 1
+#define RP_ACT_ABS_QUAT 2
+#define RP_ACT_REL_QUAT 3
+#define RP_ACT_ABS_JOINTS 4
+#define RP_ACT_REL_JOINTS 5
+__device__ __forceinline__ void load_action(const DevModel* m, const float* action, int env, float* a8) {
+  const int at = m->action_type, na = m->n_action, nd = m->n_target;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    float hi = ((at == RP_ACT_ABS_RPY && k < 6) || (at == RP_ACT_ABS_JOINTS && k < nd)) ? 6.f : 1.f;   /* action_space.high, step()'s clip */
+    a8[k] = k < na ? clampf(action[(size_t)env * na + k], -hi, hi) : 0.f;
+  }
+}
+__device__ __forceinline__ void action_target(int at, const float* a8, V3 cp, Q4 cq, V3& tpos, Q4& tq) {
+  tpos = mk3(a8[0], a8[1], a8[2]);
+  if (at == RP_ACT_ABS_RPY) tq = quat_from_euler(a8[3], a8[4], a8[5]);
+  else if (at == RP_ACT_ABS_QUAT) { tq.x = a8[3]; tq.y = a8[4]; tq.z = a8[5]; tq.w = a8[6]; }
+  else {
+    tpos = mk3(a8[0] + cp.x, a8[1] + cp.y, a8[2] + cp.z);
+    if (at == RP_ACT_REL_QUAT) { tq.x = a8[3] + cq.x; tq.y = a8[4] + cq.y; tq.z = a8[5] + cq.z; tq.w = a8[6] + cq.w; }
+    else {
+      V3 ce = euler_from_quat(cq.x, cq.y, cq.z, cq.w);
+      tq = quat_from_euler(a8[3] + ce.x, a8[4] + ce.y, a8[5] + ce.z);
+    }
+  }
+}
+
 template <int NC>
 __device__ float ik_coop(const DevModel* m, V3 tpos, Q4 tq, float qj, int max_iter, int l16, bool live) {
   const bool isj = l16 < NC;
@@ -1182,23 +1252,8 @@ __device__ float ik_coop(const DevModel* m, V3 tpos, Q4 tq, float qj, int max_it
   const M3 sr = ldm3(m->site_rot[RP_SITE_EE]);
   bool done = !live;
   for (int it = 0; it < max_iter; it++) {
-    /* chain FK: local transforms, then an inclusive scan of compositions over lanes 0..NC-1 */
-    Xf x; x.R = ident3(); x.p = mk3(0, 0, 0);
-    if (isj) {
-      x.R = R0; x.p = p0;
-      if (rev) x.R = mul(R0, axis_angle(ax, qj)); else x.p = p0 + mulv(R0, ax) * qj;
-    }
-    if (l16 == 0) x = xf_compose(base, x);
-    { Xf y = xf_shr<1>(x); Xf z = xf_compose(y, x); if (l16 >= 1) x = z; }
-    { Xf y = xf_shr<2>(x); Xf z = xf_compose(y, x); if (l16 >= 2) x = z; }
-    { Xf y = xf_shr<4>(x); Xf z = xf_compose(y, x); if (l16 >= 4) x = z; }
-    const V3 org = x.p, axw = mulv(x.R, ax);
-    const V3 posl = x.p + mulv(x.R, sp);
-    const M3 Rsl = mul(x.R, sr);
-    const V3 pos = mk3(bcast16<NC - 1>(posl.x), bcast16<NC - 1>(posl.y), bcast16<NC - 1>(posl.z));
-    M3 Rs;
-#pragma unroll
-    for (int k = 0; k < 9; k++) Rs.m[k] = bcast16<NC - 1>(Rsl.m[k]);
+    V3 org, axw, pos; M3 Rs;
+    chain_fk_coop<NC>(R0, p0, ax, rev, base, sp, sr, qj, l16, org, axw, pos, Rs);
     const V3 ep = tpos - pos;
     done = done || (it > 0 && norm(ep) < K_IK_RES);
     if (__ballot(!done) == 0ull) break;                        /* every env of the wave has converged */
@@ -1278,18 +1333,30 @@ __device__ __forceinline__ ChainQ ik_solve(const DevModel* m, V3 tpos, Q4 tq, Ch
 
 /* perform_action('absolute_rpy') .. close_gripper (environments.py:915-1073); every lane computes the same values,
  * lane 0 writes the motor commands into the state record.  Returns the target poses. */
-__device__ ChainQ perform_action(const DevModel* m, EnvLds& L, int lane, const float* a7) {
-  V3 tpos = mk3(a7[0], a7[1], a7[2]);
-  Q4 tq = quat_from_euler(a7[3], a7[4], a7[5]);
-  int nd = m->n_target;
+__device__ ChainQ perform_action(const DevModel* m, EnvLds& L, int lane, const float* a8) {
+  const int nd = m->n_target, at = m->action_type, l16 = lane & 15;
   ChainQ cur;
 #pragma unroll
   for (int j = 0; j < 7; j++) cur.q[j] = j < m->ee_chain ? L.st[ST_Q + j] : 0.f;
   ChainQ sol;
-  if (m->kind == RP_KIND_P) sol = ik_solve(m, tpos, tq, cur, 200, lane & 15);
-  else {   /* InverseKinematicsSolver.calc_angles: 4 chained default IK solves from the measured joints */
-    sol = cur;
-    for (int rep = 0; rep < 4; rep++) sol = ik_solve(m, tpos, tq, sol, 20, lane & 15);
+  if (at == RP_ACT_ABS_JOINTS || at == RP_ACT_REL_JOINTS) {
+#pragma unroll
+    for (int j = 0; j < 7; j++) sol.q[j] = j < nd ? (at == RP_ACT_REL_JOINTS ? a8[j] + L.st[ST_Q + j] : a8[j]) : 0.f;
+  } else {
+    V3 cp = mk3(0, 0, 0); Q4 cq = {0.f, 0.f, 0.f, 1.f};
+    if (at == RP_ACT_REL_RPY || at == RP_ACT_REL_QUAT) {
+      float qj = 0.f;
+#pragma unroll
+      for (int j = 0; j < 7; j++) qj = l16 == j ? cur.q[j] : qj;
+      ee_pose_coop(m, qj, l16, cp, cq);
+    }
+    V3 tpos; Q4 tq;
+    action_target(at, a8, cp, cq, tpos, tq);
+    if (m->kind == RP_KIND_P) sol = ik_solve(m, tpos, tq, cur, 200, l16);
+    else {   /* InverseKinematicsSolver.calc_angles: 4 chained default IK solves from the measured joints */
+      sol = cur;
+      for (int rep = 0; rep < 4; rep++) sol = ik_solve(m, tpos, tq, sol, 20, l16);
+    }
   }
   ChainQ tp;
 #pragma unroll
@@ -1304,7 +1371,7 @@ __device__ ChainQ perform_action(const DevModel* m, EnvLds& L, int lane, const f
   __syncthreads();
   if (lane == 0) {
     for (int j = 0; j < nd; j++) { L.st[ST_MMODE + j] = 1.f; L.st[ST_MTARGET + j] = tp.q[j]; L.st[ST_MMAXIMP + j] = 240.f * K_DT; }
-    float g = a7[6];
+    float g = a8[m->n_action - 1];
     if (m->kind == RP_KIND_P) {
       float amt = 0.04f - g / 25.f;
       int ds[2] = {m->d9p, m->d10p};
@@ -1530,11 +1597,9 @@ __global__ void __launch_bounds__(64, RP_WAVES_PER_EU) k_step(const DevModel* __
   int env = blockIdx.x, lane = threadIdx.x;
   if (env >= N) return;
   load_state(L, state, env, lane);
-  float a7[7];
-  const float high[7] = {6.f, 6.f, 6.f, 6.f, 6.f, 6.f, 1.f};       /* environments.py:108-109, 207 */
-#pragma unroll
-  for (int k = 0; k < 7; k++) a7[k] = clampf(action[(size_t)env * 7 + k], -high[k], high[k]);
-  ChainQ tp = perform_action(m, L, lane, a7);
+  float a8[8];
+  load_action(m, action, env, a8);
+  ChainQ tp = perform_action(m, L, lane, a8);
   for (int s = 0; s < K_NSUB; s++) substep(m, L, lane);
   calc_state(m, L, lane);
   write_outputs(m, L, lane, env, out);
@@ -1715,18 +1780,25 @@ __global__ void __launch_bounds__(64) k_action(const DevModel* __restrict__ m, f
   const bool live = env_raw < N;
   const int env = live ? env_raw : env0;
   float* st = state + (size_t)env * RP_REC_FLOATS;
-  const float high[7] = {6.f, 6.f, 6.f, 6.f, 6.f, 6.f, 1.f};       /* environments.py:108-109, 207 */
-  float a7[7];
-#pragma unroll
-  for (int k = 0; k < 7; k++) a7[k] = clampf(action[(size_t)env * 7 + k], -high[k], high[k]);
-  V3 tpos = mk3(a7[0], a7[1], a7[2]);
-  Q4 tq = quat_from_euler(a7[3], a7[4], a7[5]);
-  const int nd = m->n_target, nc = m->ee_chain;
+  float a8[8];
+  load_action(m, action, env, a8);
+  const int nd = m->n_target, nc = m->ee_chain, at = m->action_type;
   const float q0 = st[ST_Q + (l16 < RP_MAX_ARM ? l16 : 0)];            /* measured joint value of dof l16 */
   float qj = l16 < nc ? q0 : 0.f;
-  if (m->kind == RP_KIND_P) qj = ik_coop<7>(m, tpos, tq, qj, 200, l16, live);
-  else if (nc == 6) { for (int rep = 0; rep < 4; rep++) qj = ik_coop<6>(m, tpos, tq, qj, 20, l16, live); }
-  else { for (int rep = 0; rep < 4; rep++) qj = ik_coop<7>(m, tpos, tq, qj, 20, l16, live); }
+  if (at == RP_ACT_ABS_JOINTS || at == RP_ACT_REL_JOINTS) {
+    float aj = 0.f;
+#pragma unroll
+    for (int j = 0; j < 7; j++) aj = l16 == j ? a8[j] : aj;
+    qj = at == RP_ACT_REL_JOINTS ? aj + q0 : aj;
+  } else {
+    V3 cp = mk3(0, 0, 0); Q4 cq = {0.f, 0.f, 0.f, 1.f};
+    if (at == RP_ACT_REL_RPY || at == RP_ACT_REL_QUAT) ee_pose_coop(m, qj, l16, cp, cq);
+    V3 tpos; Q4 tq;
+    action_target(at, a8, cp, cq, tpos, tq);
+    if (m->kind == RP_KIND_P) qj = ik_coop<7>(m, tpos, tq, qj, 200, l16, live);
+    else if (nc == 6) { for (int rep = 0; rep < 4; rep++) qj = ik_coop<6>(m, tpos, tq, qj, 20, l16, live); }
+    else { for (int rep = 0; rep < 4; rep++) qj = ik_coop<7>(m, tpos, tq, qj, 20, l16, live); }
+  }
   if (!live) return;
   if (l16 < nd) {
     float t = clampf(qj, m->ll[l16], m->ul[l16]);
@@ -1735,7 +1807,7 @@ __global__ void __launch_bounds__(64) k_action(const DevModel* __restrict__ m, f
     if (target_poses) target_poses[(size_t)env * nd + l16] = t;
   }
   if (l16 == 0) {
-    float g = a7[6];
+    float g = a8[m->n_action - 1];
     if (m->kind == RP_KIND_P) {
       float amt = 0.04f - g / 25.f;
       int ds[2] = {m->d9p, m->d10p};

@@ -64,14 +64,26 @@ const char* rp_version(void) { return "rp_playroom 0.1 (gfx950, wave-per-env)"; 
 
 int rp_create(const rp_config* cfg, rp_handle* out) {
   if (!cfg || !out || cfg->num_envs <= 0) { snprintf(g_err, 256, "rp_create: bad argument"); return RP_ERR_ARG; }
-  if (cfg->env_kind < 0 || cfg->env_kind > 2) { snprintf(g_err, 256, "rp_create: unsupported env kind %d", cfg->env_kind); return RP_ERR_UNSUPPORTED; }
+  if (cfg->env_kind < 0 || cfg->env_kind > RP_ENV_UR5_PLAY_REL_RPY_1OBJ) { snprintf(g_err, 256, "rp_create: unsupported env kind %d", cfg->env_kind); return RP_ERR_UNSUPPORTED; }
   rp_sim* h = (rp_sim*)calloc(1, sizeof(rp_sim));
   h->cfg = *cfg;
   rp_model* m = (rp_model*)malloc(sizeof(rp_model));
-  if (cfg->env_kind == RP_ENV_UR5_PLAY_ABS_RPY_1OBJ) rp_fill_model_U(m);
-  else if (cfg->env_kind == RP_ENV_UR5_REACH) rp_fill_model_R(m);
-  else rp_fill_model_P(m);
+  /* the UR5 one-object play family shares scene, arm and configuration (envList.py:93-140); only perform_action differs */
+  int action_type = RP_ACT_ABS_RPY;
+  switch (cfg->env_kind) {
+    case RP_ENV_UR5_REACH: rp_fill_model_R(m); break;
+    case RP_ENV_PANDA_PICK: rp_fill_model_P(m); break;
+    case RP_ENV_UR5_PLAY_1OBJ: rp_fill_model_U(m); action_type = RP_ACT_ABS_QUAT; break;
+    case RP_ENV_UR5_PLAY_REL_1OBJ: rp_fill_model_U(m); action_type = RP_ACT_REL_QUAT; break;
+    case RP_ENV_UR5_PLAY_REL_JOINTS_1OBJ: rp_fill_model_U(m); action_type = RP_ACT_REL_JOINTS; break;
+    case RP_ENV_UR5_PLAY_ABS_JOINTS_1OBJ: rp_fill_model_U(m); action_type = RP_ACT_ABS_JOINTS; break;
+    case RP_ENV_UR5_PLAY_REL_RPY_1OBJ: rp_fill_model_U(m); action_type = RP_ACT_REL_RPY; break;
+    default: rp_fill_model_U(m); break;
+  }
   rp_build_dev_model(m, &h->host_model);
+  h->host_model.action_type = action_type;
+  h->host_model.n_action = (action_type == RP_ACT_ABS_QUAT || action_type == RP_ACT_REL_QUAT) ? 8
+                         : ((action_type == RP_ACT_ABS_JOINTS || action_type == RP_ACT_REL_JOINTS) ? h->host_model.n_target + 1 : 7);
   free(m);
   hipError_t e = hipSetDevice(cfg->device);
   if (e != hipSuccess) { snprintf(g_err, 256, "hipSetDevice(%d): %s", cfg->device, hipGetErrorString(e)); free(h); return RP_ERR_HIP; }
@@ -120,7 +132,7 @@ int rp_get_dims(rp_handle h, rp_dims* d) {
   const DevModel* m = &h->host_model;
   d->obs_quat = m->n_obs; d->achieved_goal = m->n_ag; d->desired_goal = m->n_ag; d->controllable_achieved_goal = 4;
   d->full_positional_state = m->n_fps; d->joints = 8; d->velocity = 6; d->observation = m->n_observation;
-  d->target_poses = m->n_target; d->action = 7;
+  d->target_poses = m->n_target; d->action = m->n_action;
   return RP_OK;
 }
 

@@ -46,8 +46,8 @@ class playEnv:
                  obj_upper_bound=(-0.18, -0.18, -0.05), sparse=True, use_orientation=False, sparse_rew_thresh=0.05,
                  fixed_gripper=False, return_velocity=True, max_episode_steps=250, play=False, action_type='absolute_rpy',
                  show_goal=True, arm_type='Panda', device=0, seed=0):
-        if action_type != 'absolute_rpy':
-            raise NotImplementedError('action_type %r is outside the hot-path scope (SURVEY.md §8f rank 1)' % action_type)
+        if action_type != 'absolute_rpy' and not (arm_type == 'UR5' and play and num_objects == 1):
+            raise NotImplementedError('action_type %r is built for the UR5 one-object play ids only (SURVEY.md §8f rank 1)' % action_type)
         self.timeStep = 1.0 / 300
         self.render_scene = False
         self.physics_client_active = 0
@@ -57,7 +57,12 @@ class playEnv:
         self.play, self.action_type, self.show_goal, self.arm_type = play, action_type, show_goal, arm_type
         self._max_episode_steps = max_episode_steps
         self._device, self._seed = device, seed
-        high = np.array([6, 6, 6, 6, 6, 6, 1])                                  # environments.py:108-109
+        ndof = 6 if arm_type == 'UR5' else 7                                    # environments.py:88-113
+        high = {'absolute_rpy': [6] * 6 + [1], 'relative_rpy': [1] * 7, 'absolute_quat': [1] * 8, 'relative_quat': [1] * 8,
+                'absolute_joints': [6] * ndof + [1], 'relative_joints': [1] * (ndof + 1)}.get(action_type)
+        if high is None:
+            raise NotImplementedError(action_type)
+        high = np.array(high)
         self.action_space = spaces.Box(-high, high)
         # declared spaces, reproduced as-is including the arm_lower_obs_lim typo (environments.py:120-166, quirk F11)
         eu, el = np.array(env_range_high, dtype=float), np.array(env_range_low, dtype=float)
@@ -193,3 +198,21 @@ class UR5PlayAbsRPY1Obj(playEnv):             # envList.py:93-99
                          goal_range_high=goal_range_high, use_orientation=use_orientation, obj_lower_bound=[-0.18, 0, 0.05],
                          obj_upper_bound=[0.18, 0.3, 0.1], return_velocity=False, max_episode_steps=None, play=True,
                          action_type='absolute_rpy', show_goal=False, arm_type='UR5', **kw)
+
+
+def _ur5_play_1obj(name, env_id, action_type, anchor):
+    """the other members of the UR5 one-object play family: UR5PlayAbsRPY1Obj with another action type"""
+    def __init__(self, num_objects=1, env_range_low=(-1.0, -1.0, -0.2), env_range_high=(1.0, 1.0, 1.0), goal_range_low=(-0.18, 0, 0.05),
+                 goal_range_high=(0.18, 0.3, 0.1), use_orientation=True, **kw):
+        playEnv.__init__(self, num_objects=num_objects, env_range_low=env_range_low, env_range_high=env_range_high,
+                         goal_range_low=goal_range_low, goal_range_high=goal_range_high, use_orientation=use_orientation,
+                         obj_lower_bound=[-0.18, 0, 0.05], obj_upper_bound=[0.18, 0.3, 0.1], return_velocity=False,
+                         max_episode_steps=None, play=True, action_type=action_type, show_goal=False, arm_type='UR5', **kw)
+    return type(name, (playEnv,), {'ENV_ID': env_id, '__init__': __init__, '__doc__': anchor})
+
+
+UR5PlayRelRPY1Obj = _ur5_play_1obj('UR5PlayRelRPY1Obj', 'UR5PlayRelRPY1Obj-v0', 'relative_rpy', 'envList.py:101-107')
+UR5PlayRelJoints1Obj = _ur5_play_1obj('UR5PlayRelJoints1Obj', 'UR5PlayRelJoints1Obj-v0', 'relative_joints', 'envList.py:109-115')
+UR5PlayAbsJoints1Obj = _ur5_play_1obj('UR5PlayAbsJoints1Obj', 'UR5PlayAbsJoints1Obj-v0', 'absolute_joints', 'envList.py:117-123')
+UR5Play1Obj = _ur5_play_1obj('UR5Play1Obj', 'UR5Play1Obj-v0', 'absolute_quat', 'envList.py:126-132')
+UR5PlayRel1Obj = _ur5_play_1obj('UR5PlayRel1Obj', 'UR5PlayRel1Obj-v0', 'relative_quat', 'envList.py:134-140')

@@ -48,8 +48,11 @@ class VecPlayEnv:
         self.buf['target_poses'] = f(self.dims['target_poses'])
         self.buf['status'] = torch.zeros(N, dtype=torch.int32, device=dev)
         self.out = _lib.RpOut(**{k: self.buf[k].data_ptr() for k, _ in _lib.RpOut._fields_})
-        self.action_high = torch.tensor([6, 6, 6, 6, 6, 6, 1], dtype=torch.float32, device=dev)   # environments.py:108-109
-        self._max_episode_steps = None if env_id == 'UR5PlayAbsRPY1Obj-v0' else 250
+        at = _lib.ACTION_TYPES.get(env_id, 'absolute_rpy')                                          # environments.py:88-113
+        hi = {'absolute_rpy': [6] * 6 + [1], 'absolute_joints': [6] * 6 + [1]}.get(at, [1] * self.dims['action'])
+        self.action_type = at
+        self.action_high = torch.tensor(hi, dtype=torch.float32, device=dev)
+        self._max_episode_steps = None if env_id.startswith('UR5Play') else 250
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -82,7 +85,7 @@ class VecPlayEnv:
 
     def step(self, action):
         a = action.to(device=self.device, dtype=torch.float32).contiguous()
-        assert a.shape == (self.num_envs, 7), a.shape
+        assert a.shape == (self.num_envs, self.dims['action']), a.shape
         _lib.check(self.lib, self.h, self.lib.rp_step(self.h, C.c_void_p(a.data_ptr()), C.byref(self.out), self._stream()), 'rp_step')
         info = {'is_success': self.buf['is_success'], 'target_poses': self.buf['target_poses'], 'status': self.buf['status']}
         done = torch.zeros(self.num_envs, dtype=torch.bool, device=self.device)      # environments.py:212: always False

@@ -38,11 +38,16 @@ sys.path.insert(0, REF)
 with contextlib.redirect_stdout(io.StringIO()):
     import roboticsPlayroomPybullet  # noqa: E402,F401  (fills fb.REGISTRY)
     from roboticsPlayroomPybullet.envs import UR5PlayAbsRPY1Obj, UR5Reach, pandaPick  # noqa: E402
+    from roboticsPlayroomPybullet.envs import (UR5Play1Obj, UR5PlayRel1Obj, UR5PlayRelJoints1Obj, UR5PlayAbsJoints1Obj,  # noqa: E402
+                                               UR5PlayRelRPY1Obj)
     import scenes  # noqa: E402  (the reference puts envs/ on sys.path itself)
     import playRewardFunc  # noqa: E402
 
 KINDS = {'U': UR5PlayAbsRPY1Obj, 'R': UR5Reach, 'P': pandaPick}
 IDS = {'U': 'UR5PlayAbsRPY1Obj-v0', 'R': 'UR5Reach-v0', 'P': 'pandaPick-v0'}
+# the rest of the UR5 one-object play family: the same scene and arm as U, other action types
+FAMILY = {'UR5Play1Obj-v0': UR5Play1Obj, 'UR5PlayRel1Obj-v0': UR5PlayRel1Obj, 'UR5PlayRelJoints1Obj-v0': UR5PlayRelJoints1Obj,
+          'UR5PlayAbsJoints1Obj-v0': UR5PlayAbsJoints1Obj, 'UR5PlayRelRPY1Obj-v0': UR5PlayRelRPY1Obj}
 
 
 def dump(name, obj):
@@ -57,10 +62,10 @@ def quiet(fn, *a, **k):
         return fn(*a, **k)
 
 
-def new_env(kind):
+def new_env(kind, cls=None):
     """Construct the reference env and activate its (fake) physics client."""
     del CLIENTS[:]
-    env = quiet(KINDS[kind])
+    env = quiet(cls or KINDS[kind])
     quiet(env.activate_physics_client)
     env.physics_client_active = True
     main = CLIENTS[0]
@@ -361,7 +366,48 @@ def gen_reset(seed=47):
     dump('reset.json', out)
 
 
+def gen_step_family(seed=61, n_cases=6):
+    """step() of the other UR5 one-object play ids: action-space bounds, the IK call arguments each action type produces
+    from the action and the measured EE pose / joints, joint clamps and motor commands."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    for gid, cls in FAMILY.items():
+        env, c, shadow = new_env('U', cls)
+        info = {'action_type': env.action_type, 'action_low': env.action_space.low, 'action_high': env.action_space.high,
+                'play': env.play, 'use_orientation': env.use_orientation, 'return_velocity': env.return_velocity,
+                'num_objects': env.num_objects, 'max_episode_steps': env._max_episode_steps,
+                'observation_space': {k: {'low': v.low, 'high': v.high} for k, v in env.observation_space.spaces.items()}}
+        na = len(env.action_space.high)
+        cases = []
+        for k in range(n_cases):
+            env, c, shadow = new_env('U', cls)
+            env.instance.goal = rng.uniform(-0.3, 0.3, 11)
+            desc = fill_world('U', env, c, rng)
+            action = rng.uniform(-1.0, 1.0, na) * 0.9
+            if k % 3 == 2:
+                action = rng.uniform(-8, 8, na)      # exercise the action-space clip
+            arm = env.instance.arm
+            cur = np.array([c.world['joint'][(arm, j)] for j in range(6)])
+            iks = []
+            for i in range(4):
+                sol = rng.uniform(-3.5, 3.5, 12)
+                if k % 2 == 0:
+                    sol[:6] = cur + rng.uniform(-0.3, 0.3, 6)
+                iks.append(sol.tolist())
+            shadow.ik_queue = [list(v) for v in iks]
+            c.clear_log()
+            shadow.clear_log()
+            obs, r, done, inf = quiet(env.step, action)
+            cases.append({'goal': env.instance.goal, 'world': desc, 'action': action, 'ik_returns': iks,
+                          'main_log': [e for e in c.log if e['fn'] != 'rayTest'], 'shadow_log': shadow.log,
+                          'obs': obs_to_json(obs), 'reward': float(r), 'done': bool(done),
+                          'is_success': inf['is_success'], 'target_poses': inf['target_poses']})
+        out[gid] = {'info': info, 'cases': cases}
+    dump('step_family.json', out)
+
+
 if __name__ == '__main__':
+    gen_step_family()
     gen_registry_and_spaces()
     gen_scenes()
     gen_calc_state()

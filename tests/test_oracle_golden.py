@@ -114,6 +114,58 @@ def test_action_to_motor_targets(golden, kind):
         assert case['is_success'] == (0 if case['reward'] < 0 else 1)
 
 
+FAMILY_IDS = ['UR5Play1Obj-v0', 'UR5PlayRel1Obj-v0', 'UR5PlayRelJoints1Obj-v0', 'UR5PlayAbsJoints1Obj-v0', 'UR5PlayRelRPY1Obj-v0']
+
+
+@pytest.mark.parametrize('gid', FAMILY_IDS)
+def test_action_types_of_the_ur5_play_family(golden, gid):
+    """The other action types (environments.py:88-113, 915-981): action-space bounds and clip, IK target from the action
+    and the measured EE pose (relative types add componentwise, relative_rpy through getEulerFromQuaternion), joint-space
+    types without IK, then the same clamps and motor commands as absolute_rpy."""
+    from oracle import FAMILY
+    g = golden('step_family.json')[gid]
+    info = g['info']
+    assert info['action_type'] == FAMILY[gid]
+    env0 = OracleEnv(gid)
+    high = np.array(info['action_high'])
+    assert env0.n_action == len(high)
+    np.testing.assert_array_equal(np.array(info['action_low']), -high)
+    for case in g['cases']:
+        env = OracleEnv(gid)
+        a = np.clip(np.array(case['action']), -high, high)
+        w = case['world']
+        s = env.get_state()
+        bullet_dofs = [0, 1, 2, 3, 4, 5, 10, 12, 13, 15, 18, 20]
+        for d, j in enumerate(bullet_dofs):
+            s[d] = w['joint'][str(j)]
+        env.set_state(s)
+        ik_calls = [e for e in case['shadow_log'] if e['fn'] == 'calculateInverseKinematics']
+        if info['action_type'] in ('absolute_joints', 'relative_joints'):
+            assert len(ik_calls) == 0
+            jp = a[:6] + (s[:6] if info['action_type'] == 'relative_joints' else 0.0)
+            tp = env.goto_joint_poses(jp, gripper=a[6])
+        else:
+            assert len(ik_calls) == 4
+            ee = w['link']['7']
+            pos, quat = env.action_target(a, ee['pos'], ee['orn'])
+            for c in ik_calls:
+                np.testing.assert_allclose(c['args'][2], pos, rtol=0, atol=1e-15)
+                np.testing.assert_allclose(c['args'][3], quat, rtol=0, atol=1e-14)
+            tp = env.goto_joint_poses(np.array(case['ik_returns'][-1])[:6], gripper=a[-1])
+        np.testing.assert_allclose(tp, case['target_poses'], rtol=0, atol=1e-15)
+        arr = [e for e in case['main_log'] if e['fn'] == 'setJointMotorControlArray'][0]
+        np.testing.assert_allclose(tp, arr['kwargs']['targetPositions'], rtol=0, atol=1e-15)
+        mode, tgt, maximp = env.get_motor()
+        singles = [e for e in case['main_log'] if e['fn'] == 'setJointMotorControl2']
+        assert len(singles) == 6
+        for e in singles:
+            d = bullet_dofs.index(e['args'][1])
+            assert mode[d] == 1
+            assert tgt[d] == pytest.approx(e['args'][3], abs=1e-15)
+            assert maximp[d] == pytest.approx(e['kwargs']['force'] * DT, rel=1e-15)
+        assert sum(1 for e in case['main_log'] if e['fn'] == 'stepSimulation') == 12
+
+
 def test_rewards_and_dial(golden):
     g = golden('rewards.json')
     env = OracleEnv('U')

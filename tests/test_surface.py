@@ -36,6 +36,28 @@ def test_declared_spaces_and_attributes(golden, kind):
     assert env.physics_client_active == 0 and env.instance is None
 
 
+FAMILY = {'UR5Play1Obj-v0': 'UR5Play1Obj', 'UR5PlayRel1Obj-v0': 'UR5PlayRel1Obj', 'UR5PlayRelJoints1Obj-v0': 'UR5PlayRelJoints1Obj',
+          'UR5PlayAbsJoints1Obj-v0': 'UR5PlayAbsJoints1Obj', 'UR5PlayRelRPY1Obj-v0': 'UR5PlayRelRPY1Obj'}
+
+
+@pytest.mark.parametrize('gid', sorted(FAMILY))
+def test_ur5_play_family_surface(golden, gid):
+    """the other action types of the UR5 one-object play family: registry entry, class name, action and observation spaces"""
+    reg = {e['id']: e['entry_point'].split(':')[1] for e in golden('registry.json')['registry']}
+    assert rp._REGISTRY[gid][0].split(':')[1] == reg[gid] == FAMILY[gid]
+    info = golden('step_family.json')[gid]['info']
+    env = getattr(envs, FAMILY[gid])()
+    assert env.ENV_ID == gid and env.action_type == info['action_type']
+    np.testing.assert_array_equal(env.action_space.low, np.float32(info['action_low']))
+    np.testing.assert_array_equal(env.action_space.high, np.float32(info['action_high']))
+    for k, b in info['observation_space'].items():
+        np.testing.assert_array_equal(env.observation_space.spaces[k].low, np.float32(b['low']), err_msg=k)
+        np.testing.assert_array_equal(env.observation_space.spaces[k].high, np.float32(b['high']), err_msg=k)
+    for attr in ('num_objects', 'play', 'use_orientation', 'return_velocity'):
+        assert getattr(env, attr) == info[attr], attr
+    assert env._max_episode_steps == info['max_episode_steps']
+
+
 def test_out_of_scope_surface_fails_loudly():
     with pytest.raises(NotImplementedError):
         envs.playEnv(action_type='relative_quat')
