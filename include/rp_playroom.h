@@ -93,6 +93,11 @@ int rp_get_dims(rp_handle h, rp_dims* dims);
  * resample block / arm / goal, 100 settle substeps, repeat while the goal is already satisfied. */
 int rp_reset(rp_handle h, const uint8_t* mask, const rp_out* out, void* stream);
 
+/* playEnv.reset(o) (ENV:173-187 with ENV:542-556, 575-590): objects and arm placed from an observation vector o [N, n_o]
+ * instead of being sampled - object pose from o[11:18] (use_orientation ids) or o[7:10], arm IK target o[0:3] with
+ * orientation o[3:7]; no settling; the goal is still drawn.  SURVEY.md 8f rank 2 (state restore). */
+int rp_reset_to(rp_handle h, const float* o, int32_t n_o, const uint8_t* mask, const rp_out* out, void* stream);
+
 /* playEnv.reset_goal_pos(goal) (ENV:190-191, 492-516). goal [N, dims.desired_goal] or NULL (random goal).
  * Play envs then overwrite the goal with a random perturbation of the achieved goal, as the reference does. */
 int rp_reset_goal(rp_handle h, const float* goal, const uint8_t* mask, void* stream);

@@ -65,6 +65,8 @@ def load(f32=False):
     lib.rpo_nv.argtypes = [vp]
     lib.rpo_n_arm.argtypes = [vp]
     lib.rpo_reset.argtypes = [vp, dp, C.c_int, C.POINTER(RpoObs)]
+    lib.rpo_reset_to.argtypes = [vp, dp, C.c_int, dp, C.c_int, C.POINTER(RpoObs)]
+    lib.rpo_reset_to.restype = C.c_int
     lib.rpo_reset.restype = C.c_int
     lib.rpo_reset_goal.argtypes = [vp, dp, dp, C.c_int]
     lib.rpo_reset_samples.argtypes = [vp, dp, dp, dp]
@@ -147,6 +149,18 @@ class OracleEnv:
             used = self.lib.rpo_reset(self.h, up, len(ua), C.byref(o))
         self.last_used = used
         return o.to_dict(self.n_goal)
+
+    def reset_to(self, o, u=None):
+        """playEnv.reset(o): place objects and arm from an observation vector"""
+        ob = RpoObs()
+        oa, op = _d(o)
+        if u is None:
+            used = self.lib.rpo_reset_to(self.h, op, len(oa), None, 0, C.byref(ob))
+        else:
+            ua, up = _d(u)
+            used = self.lib.rpo_reset_to(self.h, op, len(oa), up, len(ua), C.byref(ob))
+        self.last_used = used
+        return ob.to_dict(self.n_goal)
 
     def reset_samples(self, u):
         b, t = np.zeros(6), np.zeros(3)

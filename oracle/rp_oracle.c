@@ -1423,6 +1423,56 @@ void rpo_reset_samples(const rpo_env* e, const double* u, double* block_pos, dou
   if (e->m.kind != RP_KIND_P) arm_target[2] = (double)((real)arm_target[2] + (real)0.2);
 }
 
+/* reset(o): objects and arm placed from an observation vector (environments.py:519-525, 542-556, 575-603 with obs given).
+ * The object block is read from o[11:18] when use_orientation (position, then quaternion) and from o[7:10] otherwise -
+ * as written in the reference, whatever layout o really has; nothing settles and nothing is re-drawn. */
+static void reset_object_pos_obs(rpo_env* e, const real* o) {
+  const rp_model* m = &e->m;
+  if (e->play) {
+    for (int k = 0; k < 3; k++) e->fpos[1][k] = (real)m->free_pos0[1][k];
+    real R0[9]; for (int k = 0; k < 9; k++) R0[k] = (real)m->free_rot0[1][k];
+    m3_to_quat(e->fquat[1], R0);
+    v3set(e->fvel[1], 0, 0, 0); v3set(e->fom[1], 0, 0, 0);
+    for (int k = 0; k < m->n_joint1; k++) { e->jq[k] = 0; e->jqd[k] = 0; }
+  }
+  int index = e->use_orientation ? 11 : 7, inc = e->use_orientation ? 10 : 6;
+  for (int b = 0; b < e->num_objects; b++) {
+    for (int k = 0; k < 3; k++) e->fpos[b][k] = o[index + k];
+    if (e->use_orientation) for (int k = 0; k < 4; k++) e->fquat[b][k] = o[index + 3 + k];
+    else { e->fquat[b][0] = 0; e->fquat[b][1] = 0; e->fquat[b][2] = 0; e->fquat[b][3] = 1; }
+    v3set(e->fvel[b], 0, 0, 0); v3set(e->fom[b], 0, 0, 0);
+    index += inc;
+  }
+}
+static void reset_arm_obs(rpo_env* e, const real* o) {
+  const rp_model* m = &e->m;
+  real pos[3] = {o[0], o[1], o[2]}, orn[4] = {0, 0, 0, 1};
+  if (e->use_orientation) for (int k = 0; k < 4; k++) orn[k] = e->return_velocity ? o[6 + k] : o[3 + k];
+  int nrest = m->kind == RP_KIND_P ? 8 : 6;
+  for (int i = 0; i < nrest; i++) { e->q[i] = (real)m->rest[i]; e->qd[i] = 0; }
+  real sol[RP_MAX_ARM];
+  ik_solve(e, pos, orn, e->q, 20, sol);
+  for (int i = 0; i < 6; i++) { e->q[i] = sol[i]; e->qd[i] = 0; }   /* [0:6] only (quirk F5) */
+}
+int rpo_reset_to(rpo_env* e, const double* o, int n_o, const double* u, int n_u, rpo_obs* out) {
+  ustream us = {e, u, n_u, 0};
+  real ro[32] = {0};
+  for (int i = 0; i < n_o && i < 32; i++) ro[i] = (real)o[i];
+  real r = 0;
+  int guard = 0;
+  while (r > -1 && guard++ < 64) {
+    reset_object_pos_obs(e, ro);
+    reset_arm_obs(e, ro);
+    reset_goal_pos(e, 0, &us);
+    calc_state(e, out);
+    real ag[11], dg[11];
+    for (int i = 0; i < out->n_ag; i++) ag[i] = (real)(float)out->achieved_goal[i];
+    for (int i = 0; i < e->n_goal; i++) dg[i] = (real)(float)out->desired_goal[i];
+    r = compute_reward(e, ag, dg);
+  }
+  return us.used;
+}
+
 int rpo_reset(rpo_env* e, const double* u, int n_u, rpo_obs* out) {
   ustream us = {e, u, n_u, 0};
   real r = 0;

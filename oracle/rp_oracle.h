@@ -45,6 +45,8 @@ int rpo_n_arm(const rpo_env*);
 /* playEnv.reset(o=None) (environments.py:173-187).  If `u` is non-NULL the uniforms are taken from it in the
  * order np.random would be consumed (returns how many were used), else from the counter RNG. */
 int rpo_reset(rpo_env*, const double* u, int n_u, rpo_obs* out);
+/* playEnv.reset(o): objects and arm from an observation vector (environments.py:173-187, 519-603); o needs 18 entries (U), 10 (P), 3 (R) */
+int rpo_reset_to(rpo_env* e, const double* o, int n_o, const double* u, int n_u, rpo_obs* out);
 void rpo_reset_samples(const rpo_env*, const double* u, double* block_pos, double* arm_target);
 /* instance.reset_goal_pos(goal) (environments.py:492-516). goal may be NULL. */
 void rpo_reset_goal(rpo_env*, const double* goal, const double* u, int n_u);

@@ -44,7 +44,7 @@ class RpTimers(C.Structure):
                 ('avg_obs_ms', C.c_float)]
 
 
-EXPORTS = ['rp_create', 'rp_destroy', 'rp_get_dims', 'rp_reset', 'rp_reset_goal', 'rp_step', 'rp_calc_state',
+EXPORTS = ['rp_create', 'rp_destroy', 'rp_get_dims', 'rp_reset', 'rp_reset_to', 'rp_reset_goal', 'rp_step', 'rp_calc_state',
            'rp_compute_reward', 'rp_state_bytes', 'rp_get_state', 'rp_set_state', 'rp_get_timers', 'rp_enable_timers',
            'rp_last_error', 'rp_version']
 
@@ -71,6 +71,7 @@ def load():
     lib.rp_destroy.argtypes = [vp]
     lib.rp_get_dims.argtypes = [vp, C.POINTER(RpDims)]
     lib.rp_reset.argtypes = [vp, vp, C.POINTER(RpOut), vp]
+    lib.rp_reset_to.argtypes = [vp, vp, C.c_int32, vp, C.POINTER(RpOut), vp]
     lib.rp_reset_goal.argtypes = [vp, vp, vp, vp]
     lib.rp_step.argtypes = [vp, vp, C.POINTER(RpOut), vp]
     lib.rp_calc_state.argtypes = [vp, C.POINTER(RpOut), vp]

@@ -1655,7 +1655,7 @@ __device__ void reset_goal_pos(const DevModel* m, EnvLds& L, int lane, const flo
 
 /* playEnv.reset(o=None) (environments.py:173-187, 519-603) */
 __global__ void __launch_bounds__(64, RP_WAVES_PER_EU) k_reset(const DevModel* __restrict__ m, float* __restrict__ state, const uint8_t* __restrict__ mask,
-                                             OutPtrs out, int N, uint64_t seed, uint32_t env_offset) {
+                                             OutPtrs out, int N, uint64_t seed, uint32_t env_offset, const float* __restrict__ obs_o, int n_o) {
   __shared__ EnvLds L;
   int env = blockIdx.x, lane = threadIdx.x;
   if (env >= N) return;
@@ -1664,6 +1664,33 @@ __global__ void __launch_bounds__(64, RP_WAVES_PER_EU) k_reset(const DevModel* _
   load_state(L, state, env, lane);
   float r = 0.f;
   for (int attempt = 0; attempt < 64 && r > -1.f; attempt++) {
+    float tx[3];
+    Q4 torn = {0.f, 0.f, 0.f, 1.f};
+    if (obs_o) {
+      /* reset(o) (environments.py:519-525, 542-556, 575-590): drawer / scene joints to their defaults, the object block read
+       * from o[11:18] (use_orientation) or o[7:10], the arm's IK target from o[0:3] (+ o[3:7] / o[6:10]); no settling */
+      const float* o = obs_o + (size_t)env * n_o;
+      if (lane == 0) {
+        if (m->play) {
+          float* d = &L.st[ST_FREE + 13];
+          for (int k = 0; k < 3; k++) d[k] = m->free_pos0[1][k];
+          for (int k = 0; k < 4; k++) d[3 + k] = m->free_quat0[1][k];
+          for (int k = 7; k < 13; k++) d[k] = 0.f;
+          for (int k = 0; k < m->n_j1; k++) { L.st[ST_JQ + k] = 0.f; L.st[ST_JQD + k] = 0.f; }
+        }
+        int index = m->use_orientation ? 11 : 7, inc = m->use_orientation ? 10 : 6;
+        for (int b = 0; b < m->num_objects; b++) {
+          float* f = &L.st[ST_FREE + 13 * b];
+          for (int k = 0; k < 3; k++) f[k] = o[index + k];
+          if (m->use_orientation) for (int k = 0; k < 4; k++) f[3 + k] = o[index + 3 + k];
+          else { f[3] = 0.f; f[4] = 0.f; f[5] = 0.f; f[6] = 1.f; }
+          for (int k = 7; k < 13; k++) f[k] = 0.f;
+          index += inc;
+        }
+      }
+      tx[0] = o[0]; tx[1] = o[1]; tx[2] = o[2];
+      if (m->use_orientation) { int q0 = m->return_velocity ? 6 : 3; torn.x = o[q0]; torn.y = o[q0 + 1]; torn.z = o[q0 + 2]; torn.w = o[q0 + 3]; }
+    } else {
     /* reset_object_pos */
     for (int depth = 0; depth < 9; depth++) {
       if (lane == 0) {
@@ -1692,7 +1719,6 @@ __global__ void __launch_bounds__(64, RP_WAVES_PER_EU) k_reset(const DevModel* _
       if (!outb) break;
     }
     /* reset_arm: rest pose, one IK on the live arm, first 6 joints only (quirk F5) */
-    float tx[3];
     {
       float u0 = 0.f, u1 = 0.f, u2 = 0.f;
       if (lane == 0) { u0 = next_u(L, seed, genv); u1 = next_u(L, seed, genv); u2 = next_u(L, seed, genv); }
@@ -1701,6 +1727,7 @@ __global__ void __launch_bounds__(64, RP_WAVES_PER_EU) k_reset(const DevModel* _
       tx[1] = m->goal_lo[1] + (m->goal_hi[1] - m->goal_lo[1]) * u1;
       tx[2] = m->goal_lo[2] + (m->goal_hi[2] - m->goal_lo[2]) * u2;
       if (m->kind != RP_KIND_P) tx[2] += 0.2f;
+    }
     }
     __syncthreads();
     if (lane == 0) {
@@ -1711,8 +1738,7 @@ __global__ void __launch_bounds__(64, RP_WAVES_PER_EU) k_reset(const DevModel* _
     ChainQ cur;
 #pragma unroll
     for (int j = 0; j < 7; j++) cur.q[j] = j < m->ee_chain ? L.st[ST_Q + j] : 0.f;
-    Q4 ident = {0.f, 0.f, 0.f, 1.f};
-    ChainQ sol = ik_solve(m, mk3(tx[0], tx[1], tx[2]), ident, cur, 20, lane & 15);
+    ChainQ sol = ik_solve(m, mk3(tx[0], tx[1], tx[2]), torn, cur, 20, lane & 15);
     __syncthreads();
     if (lane == 0) for (int i = 0; i < 6; i++) { L.st[ST_Q + i] = sol.q[i]; L.st[ST_QD + i] = 0.f; }
     __syncthreads();

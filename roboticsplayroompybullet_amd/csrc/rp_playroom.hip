@@ -136,15 +136,27 @@ int rp_get_dims(rp_handle h, rp_dims* d) {
   return RP_OK;
 }
 
-int rp_reset(rp_handle h, const uint8_t* mask, const rp_out* out, void* stream) {
-  if (!h) return RP_ERR_ARG;
+static int reset_impl(rp_handle h, const float* o, int32_t n_o, const uint8_t* mask, const rp_out* out, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   int N = h->cfg.num_envs;
   if (h->timers_on) hipEventRecord(h->ev0, s);
-  hipLaunchKernelGGL(k_reset, dim3(N), dim3(64), 0, s, h->dev_model, h->state, mask, to_ptrs(out), N, h->cfg.seed, (uint32_t)h->cfg.env_offset);
+  hipLaunchKernelGGL(k_reset, dim3(N), dim3(64), 0, s, h->dev_model, h->state, mask, to_ptrs(out), N, h->cfg.seed, (uint32_t)h->cfg.env_offset, o, (int)n_o);
   HIPCHK(h, hipGetLastError());
   if (h->timers_on) { hipEventRecord(h->ev1, s); hipEventSynchronize(h->ev1); hipEventElapsedTime(&h->timers.last_reset_ms, h->ev0, h->ev1); }
   return RP_OK;
+}
+
+int rp_reset(rp_handle h, const uint8_t* mask, const rp_out* out, void* stream) {
+  if (!h) return RP_ERR_ARG;
+  return reset_impl(h, nullptr, 0, mask, out, stream);
+}
+
+int rp_reset_to(rp_handle h, const float* o, int32_t n_o, const uint8_t* mask, const rp_out* out, void* stream) {
+  if (!h || !o) return RP_ERR_ARG;
+  const DevModel* m = &h->host_model;
+  int need = m->num_objects > 0 ? (m->use_orientation ? 18 : 10) : (m->use_orientation ? (m->return_velocity ? 10 : 7) : 3);
+  if (n_o < need) { snprintf(h->err, 256, "rp_reset_to: o has %d entries per env, this env reads %d", n_o, need); return RP_ERR_ARG; }
+  return reset_impl(h, o, n_o, mask, out, stream);
 }
 
 int rp_reset_goal(rp_handle h, const float* goal, const uint8_t* mask, void* stream) {

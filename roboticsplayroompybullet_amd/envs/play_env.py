@@ -108,11 +108,12 @@ class playEnv:
         self.instance = _InstanceShim(self)
 
     def reset(self, o=None, vr=None):
-        if o is not None:
-            raise NotImplementedError('reset(o=...) (state restore from an observation) is a SURVEY.md §8f "next" row')
         if not self.physics_client_active:
             self.activate_physics_client(vr)
             self.physics_client_active = True
+        if o is not None:                                      # environments.py:542-556, 575-590: place objects and arm from o
+            import torch
+            return self._to_reference_obs(self._vec.reset(o=torch.as_tensor(np.asarray(o, dtype=np.float32))[None]))
         return self._to_reference_obs(self._vec.reset())      # the "reset until not already solved" loop runs on device
 
     def reset_goal_pos(self, goal):

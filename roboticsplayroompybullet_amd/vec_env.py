@@ -74,13 +74,20 @@ class VecPlayEnv:
         except Exception:
             pass
 
-    def reset(self, mask=None):
-        """playEnv.reset(o=None) for all envs (or those where mask != 0)."""
+    def reset(self, mask=None, o=None):
+        """playEnv.reset(o=None) for all envs (or those where mask != 0).  With o [N, >= 18 / 10 / 3]: playEnv.reset(o) - objects
+        and arm are placed from the observation vectors instead of being sampled (environments.py:542-556, 575-590)."""
         mp = None
         if mask is not None:
             mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
             mp = C.c_void_p(mask.data_ptr())
-        _lib.check(self.lib, self.h, self.lib.rp_reset(self.h, mp, C.byref(self.out), self._stream()), 'rp_reset')
+        if o is None:
+            _lib.check(self.lib, self.h, self.lib.rp_reset(self.h, mp, C.byref(self.out), self._stream()), 'rp_reset')
+        else:
+            o = o.to(device=self.device, dtype=torch.float32).contiguous()
+            assert o.dim() == 2 and o.shape[0] == self.num_envs, o.shape
+            _lib.check(self.lib, self.h, self.lib.rp_reset_to(self.h, C.c_void_p(o.data_ptr()), o.shape[1], mp, C.byref(self.out), self._stream()),
+                       'rp_reset_to')
         return self._obs()
 
     def step(self, action):

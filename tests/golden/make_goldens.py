@@ -366,6 +366,53 @@ def gen_reset(seed=47):
     dump('reset.json', out)
 
 
+def gen_reset_to(seed=83):
+    """reset(o): objects and arm placed from an observation vector (environments.py:519-603, obs given) - which indices of o
+    are read (the object block starts at index 11 / 7, quirk), the IK target, no settling, and the draws of the goal."""
+    out = {}
+    for kind in KINDS:
+        cases = []
+        for k in range(3):
+            env, c, shadow = new_env(kind)
+            rng = np.random.default_rng(seed + k)
+            fill_world(kind, env, c, rng)
+            ndof_ret = 12 if kind != 'P' else 9
+            c.ik_queue = [rng.uniform(-2, 2, ndof_ret).tolist() for _ in range(8)]
+            o = rng.uniform(-0.4, 0.4, 24)
+            draws = []
+            rs = np.random.RandomState(2000 + k)
+            orig = (np.random.uniform, np.random.choice, np.random.random)
+
+            def uniform(lo, hi):
+                lo, hi = np.asarray(lo, dtype=np.float64), np.asarray(hi, dtype=np.float64)
+                u = rs.random_sample(lo.shape)
+                draws.append({'fn': 'uniform', 'u': u.tolist()})
+                return lo + (hi - lo) * u
+
+            def choice(n):
+                u = rs.random_sample()
+                draws.append({'fn': 'choice', 'n': int(n), 'u': float(u)})
+                return int(u * n)
+
+            def random():
+                u = rs.random_sample()
+                draws.append({'fn': 'random', 'u': float(u)})
+                return u
+
+            np.random.uniform, np.random.choice, np.random.random = uniform, choice, random
+            try:
+                c.clear_log()
+                n_ik_before = len(c.ik_queue)
+                obs = quiet(env.reset, o)
+            finally:
+                np.random.uniform, np.random.choice, np.random.random = orig
+            log = [e for e in c.log if e['fn'] not in ('changeDynamics', 'rayTest')]
+            cases.append({'o': o, 'draws': draws, 'log': log, 'n_resets': n_ik_before - len(c.ik_queue),
+                          'n_objects': len(env.instance.objects), 'goal': env.instance.goal, 'obs': obs_to_json(obs)})
+        out[kind] = cases
+    dump('reset_to.json', out)
+
+
 def gen_step_family(seed=61, n_cases=6):
     """step() of the other UR5 one-object play ids: action-space bounds, the IK call arguments each action type produces
     from the action and the measured EE pose / joints, joint clamps and motor commands."""
@@ -407,6 +454,7 @@ def gen_step_family(seed=61, n_cases=6):
 
 
 if __name__ == '__main__':
+    gen_reset_to()
     gen_step_family()
     gen_registry_and_spaces()
     gen_scenes()

@@ -188,6 +188,36 @@ def test_solver_slot_layouts_bitwise():
         assert torch.equal(obs[0][k], obs[1][k]) and torch.equal(obs[0][k], obs[2][k]), k
 
 
+@pytest.mark.parametrize('kind', ['U', 'R', 'P'])
+def test_reset_to_an_observation(kind):
+    """playEnv.reset(o): objects and arm placed from observation vectors (no settling); device vs the fp32 oracle."""
+    from oracle import OracleEnv
+    from roboticsplayroompybullet_amd import VecPlayEnv
+    n = 6
+    rng = np.random.default_rng(5)
+    o = np.zeros((n, 18))
+    o[:, 0:3] = np.array([-0.1, 0.1, 0.25]) + 0.1 * rng.random((n, 3))        # EE target
+    q = np.array([0, 0, 0, 1.0]) + 0.2 * (rng.random((n, 4)) - 0.5)
+    o[:, 3:7] = q / np.linalg.norm(q, axis=1, keepdims=True)
+    idx = 11 if kind == 'U' else 7
+    o[:, idx:idx + 3] = np.array([-0.1, 0.1, 0.06]) + 0.1 * rng.random((n, 3)) # object position
+    if kind == 'U':
+        o[:, 14:18] = [0, 0, 0.7071, 0.7071]
+    env = VecPlayEnv(IDS[kind], n, seed=77)
+    env.reset()                                                # something else first: reset(o) must overwrite it
+    obs = env.reset(o=torch.tensor(o, dtype=torch.float32))
+    torch.cuda.synchronize()
+    for e in range(n):
+        orc = OracleEnv(kind, seed=77, env_index=e, f32=True)
+        orc.reset()
+        oo = orc.reset_to(np.float32(o[e]))
+        for k in ('obs_quat', 'achieved_goal', 'desired_goal', 'full_positional_state', 'observation'):
+            np.testing.assert_allclose(obs[k][e].cpu().numpy(), oo[k], atol=1e-4, rtol=0, err_msg='%s env %d' % (k, e))
+    if kind != 'R':                                            # the object sits exactly where o says
+        blk = env.get_state()[:, 24:27].cpu().numpy()             # STATE_LAYOUT free0
+        np.testing.assert_array_equal(blk, np.float32(o[:, idx:idx + 3]))
+
+
 FAMILY = ['UR5Play1Obj-v0', 'UR5PlayRel1Obj-v0', 'UR5PlayRelJoints1Obj-v0', 'UR5PlayAbsJoints1Obj-v0', 'UR5PlayRelRPY1Obj-v0']
 
 

@@ -224,6 +224,49 @@ def test_reset_sampling(golden, kind):
             np.testing.assert_array_equal(np.float32(o['desired_goal']), want2)
 
 
+@pytest.mark.parametrize('kind', ['U', 'R', 'P'])
+def test_reset_to_an_observation(golden, kind):
+    """reset(o) (environments.py:519-603 with obs given): which entries of o place the object (index 11 / 7, quirk) and the
+    arm's IK target, drawer / scene joints back to their defaults, rest pose before the single default IK, first six joints
+    written back, no stepSimulation, and the goal draws per attempt."""
+    for case in golden('reset_to.json')[kind]:
+        o = np.array(case['o'])
+        log = case['log']
+        assert not any(e['fn'] == 'stepSimulation' for e in log)
+        per_loop = ['uniform', 'choice', 'random'] if kind == 'U' else ['uniform']
+        draws = case['draws']
+        assert [d['fn'] for d in draws][:len(per_loop)] == per_loop and len(draws) % len(per_loop) == 0
+        ik = [e for e in log if e['fn'] == 'calculateInverseKinematics'][0]
+        np.testing.assert_array_equal(ik['args'][2], o[0:3])
+        np.testing.assert_array_equal(ik['args'][3], o[3:7] if kind == 'U' else [0.0, 0.0, 0.0, 1.0])
+        if kind != 'R':
+            idx = 11 if kind == 'U' else 7
+            spawn = [e for e in log if e['fn'] == 'resetBasePositionAndOrientation'][-1 if kind == 'U' else 0]
+            np.testing.assert_array_equal(spawn['args'][1], o[idx:idx + 3])
+            np.testing.assert_array_equal(spawn['args'][2], o[idx + 3:idx + 7] if kind == 'U' else [0, 0, 0, 1])
+        # the oracle: same placement (the IK itself is the oracle's own), same number of draws per attempt
+        u = []
+        for d in draws:
+            u += d['u'] if isinstance(d['u'], list) else [d['u']]
+        env = OracleEnv(kind)
+        obs = env.reset_to(o, u=np.tile(u, 8))
+        per_attempt = 5 if kind == 'U' else 3
+        assert env.last_used % per_attempt == 0 and env.last_used >= per_attempt
+        s = env.get_state()
+        n_arm = 9 if kind == 'P' else 12
+        if kind != 'R':
+            idx = 11 if kind == 'U' else 7
+            np.testing.assert_allclose(s[2 * n_arm:2 * n_arm + 3], o[idx:idx + 3], atol=1e-15)
+            np.testing.assert_allclose(s[2 * n_arm + 3:2 * n_arm + 7], o[idx + 3:idx + 7] if kind == 'U' else [0, 0, 0, 1], atol=1e-15)
+            np.testing.assert_array_equal(s[2 * n_arm + 7:2 * n_arm + 13], 0.0)
+        assert np.all(s[n_arm:2 * n_arm] == 0.0)           # arm at rest velocity
+        if kind == 'U':                                     # drawer and scene joints at their defaults
+            np.testing.assert_allclose(s[2 * n_arm + 13:2 * n_arm + 16], [-0.1, 0.0, -0.04], atol=1e-12)
+            np.testing.assert_array_equal(s[2 * n_arm + 26:2 * n_arm + 32], 0.0)
+            ag = np.float32(obs['achieved_goal'])
+            np.testing.assert_allclose(ag[0:3], np.float32(o[11:14]), atol=1e-6)
+
+
 def test_euler_quaternion_identities():
     """getQuaternionFromEuler / getEulerFromQuaternion pinned analytically, not by the stub."""
     from urdf_tree import rpy_to_mat
