@@ -36,7 +36,8 @@ enum rp_env_kind {
   RP_ENV_UR5_PLAY_REL_1OBJ = 4,        /* relative_quat   (added to the measured EE pose, componentwise) */
   RP_ENV_UR5_PLAY_REL_JOINTS_1OBJ = 5, /* relative_joints [dq0..dq5 grip], no IK */
   RP_ENV_UR5_PLAY_ABS_JOINTS_1OBJ = 6, /* absolute_joints [q0..q5 grip], no IK */
-  RP_ENV_UR5_PLAY_REL_RPY_1OBJ = 7     /* relative_rpy    [dx dy dz droll dpitch dyaw grip] */
+  RP_ENV_UR5_PLAY_REL_RPY_1OBJ = 7,    /* relative_rpy    [dx dy dz droll dpitch dyaw grip] */
+  RP_ENV_PANDA_PUSH = 8                /* pandaPush-v0 (__init__.py:19, envList.py:12-16): pandaPick's arm and scene, other ranges */
 };
 
 typedef struct rp_config {

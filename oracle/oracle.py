@@ -82,6 +82,7 @@ def load(f32=False):
     lib.rpo_dial_to_0_1_range.restype = C.c_double
     lib.rpo_perform_action.argtypes = [vp, dp, dp]
     lib.rpo_action_target.argtypes = [C.c_int, dp, dp, dp, dp, dp]
+    lib.rpo_set_ranges.argtypes = [vp, dp, dp, dp, dp, dp]
     lib.rpo_set_action_type.argtypes = [vp, C.c_int]
     lib.rpo_action_dim.argtypes = [vp]
     lib.rpo_action_dim.restype = C.c_int
@@ -118,11 +119,18 @@ FAMILY = {'UR5PlayAbsRPY1Obj-v0': 'absolute_rpy', 'UR5PlayRelRPY1Obj-v0': 'relat
           'UR5PlayRel1Obj-v0': 'relative_quat', 'UR5PlayAbsJoints1Obj-v0': 'absolute_joints', 'UR5PlayRelJoints1Obj-v0': 'relative_joints'}
 
 
+# ids that reuse an arm + scene in scope with other ranges: (kind, goal_lo, goal_hi, obj_lo, obj_hi, env_hi)  (envList.py:12-16)
+RANGES = {'pandaPush-v0': ('P', [-0.1, -0.1, -0.06], [0.1, 0.1, -0.05], [-0.1, -0.1, -0.06], [0.1, 0.1, -0.05], [0.18, 0.18, -0.04])}
+
+
 class OracleEnv:
     """One reference env (instance + playEnv) on the CPU oracle."""
 
     def __init__(self, kind, seed=0, env_index=0, f32=False, action_type=None):
         self.lib = load(f32)
+        ranges = None
+        if kind in RANGES:
+            kind, *ranges = RANGES[kind]
         if kind in FAMILY:                  # a registered id of the UR5 one-object play family: scene U, other action type
             kind, action_type = 'U', FAMILY[kind]
         self.kind = KINDS[kind]
@@ -130,6 +138,8 @@ class OracleEnv:
         self.action_type = action_type or 'absolute_rpy'
         self.lib.rpo_set_action_type(self.h, ACTION_TYPES[self.action_type])
         self.n_action = self.lib.rpo_action_dim(self.h)
+        if ranges:
+            self.lib.rpo_set_ranges(self.h, *[_d(r)[1] for r in ranges])
         self.n_arm = self.lib.rpo_n_arm(self.h)
         self.nv = self.lib.rpo_nv(self.h)
         self.n_goal = 11 if self.kind == 0 else 3

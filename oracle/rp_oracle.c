@@ -1099,6 +1099,13 @@ static void perform_action(rpo_env* e, const real* a, real* target_poses) {
 }
 
 void rpo_set_action_type(rpo_env* e, int action_type) { e->action_type = action_type; }
+/* another registered id on the same arm and scene: its goal / object-spawn / env ranges (envList.py kwargs) */
+void rpo_set_ranges(rpo_env* e, const double* goal_lo, const double* goal_hi, const double* obj_lo, const double* obj_hi, const double* env_hi) {
+  for (int k = 0; k < 3; k++) {
+    e->goal_lo[k] = (real)goal_lo[k]; e->goal_hi[k] = (real)goal_hi[k]; e->obj_lo[k] = (real)obj_lo[k]; e->obj_hi[k] = (real)obj_hi[k];
+    e->env_hi[k] = (real)env_hi[k];
+  }
+}
 int rpo_action_dim(const rpo_env* e) { return action_dim(e); }
 
 void rpo_perform_action(rpo_env* e, const double* action, double* target_poses) {

@@ -30,6 +30,7 @@ def make(id, **kwargs):
 
 
 register(id='pandaPick-v0', entry_point='roboticsplayroompybullet_amd.envs:pandaPick')
+register(id='pandaPush-v0', entry_point='roboticsplayroompybullet_amd.envs:pandaPush')     # __init__.py:19
 register(id='UR5Reach-v0', entry_point='roboticsplayroompybullet_amd.envs:UR5Reach')
 register(id='UR5PlayAbsRPY1Obj-v0', entry_point='roboticsplayroompybullet_amd.envs:UR5PlayAbsRPY1Obj')
 # roboticsPlayroomPybullet/__init__.py:72,77,82,87,97 - the rest of the UR5 one-object play family

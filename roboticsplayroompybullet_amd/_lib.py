@@ -13,12 +13,13 @@ LIB_PATH = os.environ.get('RP_PLAYROOM_LIB', os.path.join(CSRC, 'librp_playroom_
 ENV_KINDS = {'UR5PlayAbsRPY1Obj-v0': 0, 'UR5Reach-v0': 1, 'pandaPick-v0': 2,
              # the rest of the UR5 one-object play family (same scene, other action types)
              'UR5Play1Obj-v0': 3, 'UR5PlayRel1Obj-v0': 4, 'UR5PlayRelJoints1Obj-v0': 5, 'UR5PlayAbsJoints1Obj-v0': 6,
-             'UR5PlayRelRPY1Obj-v0': 7}
+             'UR5PlayRelRPY1Obj-v0': 7,
+             'pandaPush-v0': 8}                # pandaPick's arm and scene, other ranges
 
 
 ACTION_TYPES = {'UR5PlayAbsRPY1Obj-v0': 'absolute_rpy', 'UR5Reach-v0': 'absolute_rpy', 'pandaPick-v0': 'absolute_rpy',
                 'UR5Play1Obj-v0': 'absolute_quat', 'UR5PlayRel1Obj-v0': 'relative_quat', 'UR5PlayRelJoints1Obj-v0': 'relative_joints',
-                'UR5PlayAbsJoints1Obj-v0': 'absolute_joints', 'UR5PlayRelRPY1Obj-v0': 'relative_rpy'}
+                'UR5PlayAbsJoints1Obj-v0': 'absolute_joints', 'UR5PlayRelRPY1Obj-v0': 'relative_rpy', 'pandaPush-v0': 'absolute_rpy'}
 
 
 class RpConfig(C.Structure):

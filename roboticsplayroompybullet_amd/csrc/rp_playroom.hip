@@ -64,7 +64,7 @@ const char* rp_version(void) { return "rp_playroom 0.1 (gfx950, wave-per-env)"; 
 
 int rp_create(const rp_config* cfg, rp_handle* out) {
   if (!cfg || !out || cfg->num_envs <= 0) { snprintf(g_err, 256, "rp_create: bad argument"); return RP_ERR_ARG; }
-  if (cfg->env_kind < 0 || cfg->env_kind > RP_ENV_UR5_PLAY_REL_RPY_1OBJ) { snprintf(g_err, 256, "rp_create: unsupported env kind %d", cfg->env_kind); return RP_ERR_UNSUPPORTED; }
+  if (cfg->env_kind < 0 || cfg->env_kind > RP_ENV_PANDA_PUSH) { snprintf(g_err, 256, "rp_create: unsupported env kind %d", cfg->env_kind); return RP_ERR_UNSUPPORTED; }
   rp_sim* h = (rp_sim*)calloc(1, sizeof(rp_sim));
   h->cfg = *cfg;
   rp_model* m = (rp_model*)malloc(sizeof(rp_model));
@@ -72,7 +72,7 @@ int rp_create(const rp_config* cfg, rp_handle* out) {
   int action_type = RP_ACT_ABS_RPY;
   switch (cfg->env_kind) {
     case RP_ENV_UR5_REACH: rp_fill_model_R(m); break;
-    case RP_ENV_PANDA_PICK: rp_fill_model_P(m); break;
+    case RP_ENV_PANDA_PICK: case RP_ENV_PANDA_PUSH: rp_fill_model_P(m); break;
     case RP_ENV_UR5_PLAY_1OBJ: rp_fill_model_U(m); action_type = RP_ACT_ABS_QUAT; break;
     case RP_ENV_UR5_PLAY_REL_1OBJ: rp_fill_model_U(m); action_type = RP_ACT_REL_QUAT; break;
     case RP_ENV_UR5_PLAY_REL_JOINTS_1OBJ: rp_fill_model_U(m); action_type = RP_ACT_REL_JOINTS; break;
@@ -81,6 +81,11 @@ int rp_create(const rp_config* cfg, rp_handle* out) {
     default: rp_fill_model_U(m); break;
   }
   rp_build_dev_model(m, &h->host_model);
+  if (cfg->env_kind == RP_ENV_PANDA_PUSH) {      /* pandaPick's arm and scene with pandaPush's ranges (envList.py:12-16) */
+    const float gl[3] = {-0.1f, -0.1f, -0.06f}, gh[3] = {0.1f, 0.1f, -0.05f}, eh[3] = {0.18f, 0.18f, -0.04f};
+    DevModel* d = &h->host_model;
+    for (int k = 0; k < 3; k++) { d->goal_lo[k] = d->obj_lo[k] = gl[k]; d->goal_hi[k] = d->obj_hi[k] = gh[k]; d->env_hi[k] = eh[k]; }
+  }
   h->host_model.action_type = action_type;
   h->host_model.n_action = (action_type == RP_ACT_ABS_QUAT || action_type == RP_ACT_REL_QUAT) ? 8
                          : ((action_type == RP_ACT_ABS_JOINTS || action_type == RP_ACT_REL_JOINTS) ? h->host_model.n_target + 1 : 7);

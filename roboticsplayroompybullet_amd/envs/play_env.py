@@ -183,6 +183,16 @@ class pandaPick(playEnv):                     # envList.py:18-22
                          obj_upper_bound=goal_range_high, **kw)
 
 
+class pandaPush(playEnv):                     # envList.py:12-16
+    ENV_ID = 'pandaPush-v0'
+
+    def __init__(self, num_objects=1, env_range_low=(-0.18, -0.18, -0.055), env_range_high=(0.18, 0.18, -0.04), goal_range_low=(-0.1, -0.1, -0.06),
+                 goal_range_high=(0.1, 0.1, -0.05), use_orientation=False, **kw):
+        super().__init__(num_objects=num_objects, env_range_low=env_range_low, env_range_high=env_range_high, goal_range_low=goal_range_low,
+                         goal_range_high=goal_range_high, use_orientation=use_orientation, obj_lower_bound=goal_range_low,
+                         obj_upper_bound=goal_range_high, **kw)
+
+
 class UR5Reach(playEnv):                      # envList.py:89-91
     ENV_ID = 'UR5Reach-v0'
 

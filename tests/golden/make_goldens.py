@@ -38,6 +38,7 @@ sys.path.insert(0, REF)
 with contextlib.redirect_stdout(io.StringIO()):
     import roboticsPlayroomPybullet  # noqa: E402,F401  (fills fb.REGISTRY)
     from roboticsPlayroomPybullet.envs import UR5PlayAbsRPY1Obj, UR5Reach, pandaPick  # noqa: E402
+    from roboticsPlayroomPybullet.envs import pandaPush  # noqa: E402
     from roboticsPlayroomPybullet.envs import (UR5Play1Obj, UR5PlayRel1Obj, UR5PlayRelJoints1Obj, UR5PlayAbsJoints1Obj,  # noqa: E402
                                                UR5PlayRelRPY1Obj)
     import scenes  # noqa: E402  (the reference puts envs/ on sys.path itself)
@@ -366,6 +367,23 @@ def gen_reset(seed=47):
     dump('reset.json', out)
 
 
+def gen_spaces_more():
+    """declared spaces and attributes of further ids that reuse a model in scope: pandaPush-v0 = pandaPick's arm and scene
+    with other ranges (envList.py:12-16)"""
+    out = {}
+    for gid, cls in (('pandaPush-v0', pandaPush),):
+        env = quiet(cls)
+        out[gid] = {'action_low': env.action_space.low, 'action_high': env.action_space.high,
+                    'max_episode_steps': env._max_episode_steps, 'num_objects': env.num_objects, 'num_goals': env.num_goals,
+                    'play': env.play, 'use_orientation': env.use_orientation, 'return_velocity': env.return_velocity,
+                    'action_type': env.action_type, 'arm_type': env.arm_type, 'sparse_rew_thresh': env.sparse_rew_thresh,
+                    'env_lower_bound': env.env_lower_bound, 'env_upper_bound': env.env_upper_bound,
+                    'goal_lower_bound': env.goal_lower_bound, 'goal_upper_bound': env.goal_upper_bound,
+                    'obj_lower_bound': env.obj_lower_bound, 'obj_upper_bound': env.obj_upper_bound,
+                    'observation_space': {k: {'low': v.low, 'high': v.high} for k, v in env.observation_space.spaces.items()}}
+    dump('spaces_more.json', out)
+
+
 def gen_reset_to(seed=83):
     """reset(o): objects and arm placed from an observation vector (environments.py:519-603, obs given) - which indices of o
     are read (the object block starts at index 11 / 7, quirk), the IK target, no settling, and the draws of the goal."""
@@ -454,6 +472,7 @@ def gen_step_family(seed=61, n_cases=6):
 
 
 if __name__ == '__main__':
+    gen_spaces_more()
     gen_reset_to()
     gen_step_family()
     gen_registry_and_spaces()

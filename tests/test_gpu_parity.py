@@ -218,6 +218,36 @@ def test_reset_to_an_observation(kind):
         np.testing.assert_array_equal(blk, np.float32(o[:, idx:idx + 3]))
 
 
+def test_panda_push_ranges():
+    """pandaPush-v0 (pandaPick's arm and scene, other goal / spawn / env ranges): reset and a short rollout vs the fp32 oracle"""
+    from oracle import OracleEnv
+    from roboticsplayroompybullet_amd import VecPlayEnv
+    n = 6
+    env = VecPlayEnv('pandaPush-v0', n, seed=31)
+    obs = env.reset()
+    oracles = [OracleEnv('pandaPush-v0', seed=31, env_index=e, f32=True) for e in range(n)]
+    for e, o in enumerate(oracles):
+        oo = o.reset()
+        for k in ('obs_quat', 'achieved_goal', 'desired_goal'):
+            np.testing.assert_allclose(obs[k][e].cpu().numpy(), oo[k], atol=1e-4, rtol=0, err_msg='%s env %d' % (k, e))
+    dg = obs['desired_goal'].cpu().numpy()
+    assert (dg >= np.float32([-0.1, -0.1, -0.06]) - 1e-6).all() and (dg <= np.float32([0.1, 0.1, -0.05]) + 1e-6).all()
+    acts = actions('P', 8, n, 4)
+    acts[..., 2] = -0.03 + 0.05 * acts[..., 2]            # near the table: the pushing workspace
+    for t in range(8):
+        obs, r, d, info = env.step(torch.tensor(acts[t], dtype=torch.float32))
+        for e, o in enumerate(oracles):
+            oo, ro, _, io = o.step(acts[t, e])
+            # obs_quat = [ee pos3, ee vel3, grip, block pos3, block vel3]: positions (incl. the geared finger joint) to 2e-3, velocities to 1e-2: envs whose fingers touch the table or block (tools/push_probe.py: the others agree to 1e-6) are contact-sensitive, and the
+            # velocity-level servo turns a 1e-5 difference between the device's and the oracle's IK iterates into
+            # kp / dt = 30 times that in joint velocity
+            got, want = obs['obs_quat'][e].cpu().numpy(), oo['obs_quat']
+            pos_idx, vel_idx = [0, 1, 2, 6, 7, 8, 9], [3, 4, 5, 10, 11, 12]
+            np.testing.assert_allclose(got[pos_idx], want[pos_idx], atol=2e-3, rtol=0, err_msg='step %d env %d' % (t, e))
+            np.testing.assert_allclose(got[vel_idx], want[vel_idx], atol=1e-2, rtol=2e-2, err_msg='step %d env %d' % (t, e))
+            assert float(r[e]) == pytest.approx(ro, abs=1e-3)
+
+
 FAMILY = ['UR5Play1Obj-v0', 'UR5PlayRel1Obj-v0', 'UR5PlayRelJoints1Obj-v0', 'UR5PlayAbsJoints1Obj-v0', 'UR5PlayRelRPY1Obj-v0']
 
 

@@ -58,6 +58,30 @@ def test_ur5_play_family_surface(golden, gid):
     assert env._max_episode_steps == info['max_episode_steps']
 
 
+def test_panda_push_surface(golden):
+    """pandaPush-v0: pandaPick's arm and scene with other ranges (envList.py:12-16)"""
+    reg = {e['id']: e['entry_point'].split(':')[1] for e in golden('registry.json')['registry']}
+    assert rp._REGISTRY['pandaPush-v0'][0].split(':')[1] == reg['pandaPush-v0'] == 'pandaPush'
+    g = golden('spaces_more.json')['pandaPush-v0']
+    env = envs.pandaPush()
+    np.testing.assert_array_equal(env.action_space.high, np.float32(g['action_high']))
+    for k, b in g['observation_space'].items():
+        np.testing.assert_array_equal(env.observation_space.spaces[k].low, np.float32(b['low']), err_msg=k)
+        np.testing.assert_array_equal(env.observation_space.spaces[k].high, np.float32(b['high']), err_msg=k)
+    for attr in ('num_objects', 'num_goals', 'play', 'use_orientation', 'return_velocity', 'action_type', 'arm_type'):
+        assert getattr(env, attr) == g[attr], attr
+    assert env._max_episode_steps == g['max_episode_steps']
+    for a, b in (('goal_lower_bound', 'goal_lower_bound'), ('goal_upper_bound', 'goal_upper_bound'), ('env_upper_bound', 'env_upper_bound'),
+                 ('obj_lower_bound', 'obj_lower_bound'), ('obj_upper_bound', 'obj_upper_bound')):
+        np.testing.assert_allclose(getattr(env, a), g[b])
+    from oracle import RANGES
+    kind, gl, gh, ol, oh, eh = RANGES['pandaPush-v0']
+    assert kind == 'P'
+    np.testing.assert_allclose(gl, g['goal_lower_bound']); np.testing.assert_allclose(gh, g['goal_upper_bound'])
+    np.testing.assert_allclose(ol, g['obj_lower_bound']); np.testing.assert_allclose(oh, g['obj_upper_bound'])
+    np.testing.assert_allclose(eh, g['env_upper_bound'])
+
+
 def test_out_of_scope_surface_fails_loudly():
     with pytest.raises(NotImplementedError):
         envs.playEnv(action_type='relative_quat')
