@@ -37,7 +37,19 @@ enum rp_env_kind {
   RP_ENV_UR5_PLAY_REL_JOINTS_1OBJ = 5, /* relative_joints [dq0..dq5 grip], no IK */
   RP_ENV_UR5_PLAY_ABS_JOINTS_1OBJ = 6, /* absolute_joints [q0..q5 grip], no IK */
   RP_ENV_UR5_PLAY_REL_RPY_1OBJ = 7,    /* relative_rpy    [dx dy dz droll dpitch dyaw grip] */
-  RP_ENV_PANDA_PUSH = 8                /* pandaPush-v0 (__init__.py:19, envList.py:12-16): pandaPick's arm and scene, other ranges */
+  RP_ENV_PANDA_PUSH = 8,               /* pandaPush-v0 (__init__.py:19, envList.py:12-16): pandaPick's arm and scene, other ranges */
+  /* the Panda in the other two scenes */
+  RP_ENV_PANDA_REACH = 9,              /* pandaReach-v0 (__init__.py:4, envList.py:8-10): Panda + default_scene, no object */
+  RP_ENV_PANDA_REACH_2D = 10,          /* pandaReach2D-v0 (__init__.py:9, envList.py:24-26): same, goals just above the plane */
+  /* the Panda one-object play family (__init__.py:33-64, envList.py:43-88): Panda + complex_scene, one id per action type;
+   * joint-space actions carry 7 joints: [q0..q6 grip] */
+  RP_ENV_PANDA_PLAY_1OBJ = 11,            /* absolute_quat   */
+  RP_ENV_PANDA_PLAY_REL_1OBJ = 12,        /* relative_quat   */
+  RP_ENV_PANDA_PLAY_REL_JOINTS_1OBJ = 13, /* relative_joints */
+  RP_ENV_PANDA_PLAY_ABS_JOINTS_1OBJ = 14, /* absolute_joints */
+  RP_ENV_PANDA_PLAY_ABS_RPY_1OBJ = 15,    /* absolute_rpy    */
+  RP_ENV_PANDA_PLAY_REL_RPY_1OBJ = 16,    /* relative_rpy    */
+  RP_ENV_COUNT = 17
 };
 
 typedef struct rp_config {

@@ -10,7 +10,8 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-KINDS = {'U': 0, 'R': 1, 'P': 2, 'UR5PlayAbsRPY1Obj-v0': 0, 'UR5Reach-v0': 1, 'pandaPick-v0': 2}
+KINDS = {'U': 0, 'R': 1, 'P': 2, 'Q': 3, 'V': 4, 'UR5PlayAbsRPY1Obj-v0': 0, 'UR5Reach-v0': 1, 'pandaPick-v0': 2, 'pandaReach-v0': 3,
+         'pandaPlayAbsRPY1Obj-v0': 4}
 
 
 class RpoObs(C.Structure):
@@ -85,6 +86,7 @@ def load(f32=False):
     lib.rpo_set_ranges.argtypes = [vp, dp, dp, dp, dp, dp]
     lib.rpo_set_action_type.argtypes = [vp, C.c_int]
     lib.rpo_action_dim.argtypes = [vp]
+    lib.rpo_get_config.argtypes = [vp, dp]
     lib.rpo_action_dim.restype = C.c_int
     lib.rpo_goto_joint_poses.argtypes = [vp, dp, C.c_int, C.c_double, dp]
     lib.rpo_ik.argtypes = [vp, dp, dp, dp, C.c_int, dp]
@@ -120,7 +122,13 @@ FAMILY = {'UR5PlayAbsRPY1Obj-v0': 'absolute_rpy', 'UR5PlayRelRPY1Obj-v0': 'relat
 
 
 # ids that reuse an arm + scene in scope with other ranges: (kind, goal_lo, goal_hi, obj_lo, obj_hi, env_hi)  (envList.py:12-16)
-RANGES = {'pandaPush-v0': ('P', [-0.1, -0.1, -0.06], [0.1, 0.1, -0.05], [-0.1, -0.1, -0.06], [0.1, 0.1, -0.05], [0.18, 0.18, -0.04])}
+RANGES = {'pandaPush-v0': ('P', [-0.1, -0.1, -0.06], [0.1, 0.1, -0.05], [-0.1, -0.1, -0.06], [0.1, 0.1, -0.05], [0.18, 0.18, -0.04]),
+          # pandaReach2D-v0 (envList.py:24-26): no objects, so the object range is unused
+          'pandaReach2D-v0': ('Q', [-0.18, -0.18, -0.06], [0.18, 0.18, -0.05], [-0.18, -0.18, -0.05], [-0.18, -0.18, -0.05], [0.18, 0.18, 0.0])}
+# the Panda one-object play family (envList.py:43-88): Panda + complex_scene (model V), one id per action type
+PANDA_FAMILY = {'pandaPlayAbsRPY1Obj-v0': 'absolute_rpy', 'pandaPlayRelRPY1Obj-v0': 'relative_rpy', 'pandaPlay1Obj-v0': 'absolute_quat',
+                'pandaPlayRel1Obj-v0': 'relative_quat', 'pandaPlayAbsJoints1Obj-v0': 'absolute_joints',
+                'pandaPlayRelJoints1Obj-v0': 'relative_joints'}
 
 
 class OracleEnv:
@@ -133,6 +141,8 @@ class OracleEnv:
             kind, *ranges = RANGES[kind]
         if kind in FAMILY:                  # a registered id of the UR5 one-object play family: scene U, other action type
             kind, action_type = 'U', FAMILY[kind]
+        if kind in PANDA_FAMILY:
+            kind, action_type = 'V', PANDA_FAMILY[kind]
         self.kind = KINDS[kind]
         self.h = self.lib.rpo_create(self.kind, seed, env_index)
         self.action_type = action_type or 'absolute_rpy'
@@ -142,8 +152,8 @@ class OracleEnv:
             self.lib.rpo_set_ranges(self.h, *[_d(r)[1] for r in ranges])
         self.n_arm = self.lib.rpo_n_arm(self.h)
         self.nv = self.lib.rpo_nv(self.h)
-        self.n_goal = 11 if self.kind == 0 else 3
-        self.n_target = 7 if self.kind == 2 else 6
+        self.n_goal = 11 if self.kind in (0, 4) else 3
+        self.n_target = 7 if self.kind in (2, 3, 4) else 6
 
     def __del__(self):
         if getattr(self, 'h', None):
@@ -203,6 +213,22 @@ class OracleEnv:
         at = ACTION_TYPES[self.action_type]
         self.lib.rpo_action_target(at, _d(a)[1], _d(ee_pos)[1], _d(ee_orn)[1], pos.ctypes.data_as(dp), quat.ctypes.data_as(dp))
         return pos, quat
+
+    def _config(self):
+        c = np.zeros(27)
+        self.lib.rpo_get_config(self.h, c.ctypes.data_as(C.POINTER(C.c_double)))
+        return c
+
+    def flags(self):
+        c = self._config()
+        return {'play': int(c[0]), 'use_orientation': int(c[1]), 'return_velocity': int(c[2]), 'num_objects': int(c[3])}
+
+    def ranges(self):
+        c = self._config()
+        return {'goal_lo': c[4:7], 'goal_hi': c[7:10], 'obj_lo': c[10:13], 'obj_hi': c[13:16], 'env_hi': c[16:19]}
+
+    def action_high(self):
+        return self._config()[19:19 + self.n_action]
 
     def calc_state(self):
         o = RpoObs()

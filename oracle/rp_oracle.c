@@ -694,7 +694,7 @@ static void build_rows(rpo_env* e, const real* vstar) {
     }
   }
   /* 4. Panda finger gear (btMultiBodyGearConstraint, environments.py:400-405): qd9 + ratio*qd10 -> 0, erp 0.1, maxForce 50 */
-  if (m->kind == RP_KIND_P) {
+  if (m->arm_type == RP_ARM_PANDA) {
     int a = dof_of_bullet_joint(e, 9), b = dof_of_bullet_joint(e, 10);
     row* r = new_row(e);
     real tau[RP_MAX_ARM] = {0};
@@ -976,7 +976,7 @@ static void set_pos_motor(rpo_env* e, int bullet_joint, real target, real force)
 
 /* close_gripper (environments.py:1037-1073) */
 static void close_gripper(rpo_env* e, real amount) {
-  if (e->m.kind == RP_KIND_P) {
+  if (e->m.arm_type == RP_ARM_PANDA) {
     amount = (real)0.04 - amount / 25;
     set_pos_motor(e, 9, amount, 100);
     set_pos_motor(e, 10, amount, 100);
@@ -1003,11 +1003,11 @@ static void goto_joint_poses(rpo_env* e, const real* joint_poses, int has_grippe
   static const double U_UL[6] = {-0.7, 2 * 3.14159265358979323846, -0.5, 2 * 3.14159265358979323846, 2 * 3.14159265358979323846,
                                  2 * 3.14159265358979323846};
   static const double U_INC[6] = {0.1, 0.1, 0.2, 0.2, 0.2, 0.2};
-  int nd = e->m.kind == RP_KIND_P ? 7 : 6;
+  int nd = e->m.arm_type == RP_ARM_PANDA ? 7 : 6;
   for (int i = 0; i < nd; i++) {
-    real ll = e->m.kind == RP_KIND_P ? (real)P_LL[i] : (real)(-2 * 3.14159265358979323846);
-    real ul = e->m.kind == RP_KIND_P ? (real)P_UL[i] : (real)U_UL[i];
-    real inc = e->m.kind == RP_KIND_P ? (real)P_INC[i] : (real)U_INC[i];
+    real ll = e->m.arm_type == RP_ARM_PANDA ? (real)P_LL[i] : (real)(-2 * 3.14159265358979323846);
+    real ul = e->m.arm_type == RP_ARM_PANDA ? (real)P_UL[i] : (real)U_UL[i];
+    real inc = e->m.arm_type == RP_ARM_PANDA ? (real)P_INC[i] : (real)U_INC[i];
     real t = clampr(joint_poses[i], ll, ul);          /* np.clip: min(max(x, lo), hi) */
     real cur = e->q[i];
     t = clampr(t, cur - inc, cur + inc);
@@ -1019,7 +1019,7 @@ static void goto_joint_poses(rpo_env* e, const real* joint_poses, int has_grippe
 
 void rpo_goto_joint_poses(rpo_env* e, const double* joint_poses, int has_gripper, double gripper, double* target_poses) {
   real jp[7], tp[7];
-  int nd = e->m.kind == RP_KIND_P ? 7 : 6;
+  int nd = e->m.arm_type == RP_ARM_PANDA ? 7 : 6;
   for (int i = 0; i < nd; i++) jp[i] = (real)joint_poses[i];
   goto_joint_poses(e, jp, has_gripper, (real)gripper, tp);
   for (int i = 0; i < nd; i++) target_poses[i] = tp[i];
@@ -1032,7 +1032,7 @@ void rpo_goto_joint_poses(rpo_env* e, const double* joint_poses, int has_gripper
  * The relative types add the action to the measured EE link pose (getLinkState()[0], [1]; orientation componentwise,
  * for relative_rpy after getEulerFromQuaternion) or to the measured joints. */
 static int action_dim(const rpo_env* e) {
-  int nd = e->m.kind == RP_KIND_P ? 7 : 6;
+  int nd = e->m.arm_type == RP_ARM_PANDA ? 7 : 6;
   switch (e->action_type) {
     case RPO_ACT_ABS_QUAT: case RPO_ACT_REL_QUAT: return 8;
     case RPO_ACT_ABS_JOINTS: case RPO_ACT_REL_JOINTS: return nd + 1;
@@ -1072,7 +1072,7 @@ void rpo_action_target(int action_type, const double* action, const double* ee_p
 }
 static void perform_action(rpo_env* e, const real* a, real* target_poses) {
   real quat[4], pos[3], jp[RP_MAX_ARM];
-  int nd = e->m.kind == RP_KIND_P ? 7 : 6;
+  int nd = e->m.arm_type == RP_ARM_PANDA ? 7 : 6;
   int at = e->action_type;
   if (at == RPO_ACT_ABS_JOINTS || at == RPO_ACT_REL_JOINTS) {
     for (int i = 0; i < nd; i++) jp[i] = at == RPO_ACT_REL_JOINTS ? a[i] + e->q[i] : a[i];
@@ -1088,7 +1088,7 @@ static void perform_action(rpo_env* e, const real* a, real* target_poses) {
     m3_to_quat(cq, R);
   }
   action_target(at, a, cp, cq, pos, quat);
-  if (e->m.kind == RP_KIND_P) {
+  if (e->m.arm_type == RP_ARM_PANDA) {
     real sol[RP_MAX_ARM];
     ik_solve(e, pos, quat, e->q, 200, sol);        /* maxNumIterations=200 on the live arm (environments.py:995-997) */
     for (int i = 0; i < 7; i++) jp[i] = sol[i];
@@ -1107,13 +1107,23 @@ void rpo_set_ranges(rpo_env* e, const double* goal_lo, const double* goal_hi, co
   }
 }
 int rpo_action_dim(const rpo_env* e) { return action_dim(e); }
+/* test hook: [play, use_orientation, return_velocity, num_objects | goal_lo3 goal_hi3 obj_lo3 obj_hi3 env_hi3 | action_high8] */
+void rpo_get_config(const rpo_env* e, double* out) {
+  out[0] = e->play; out[1] = e->use_orientation; out[2] = e->return_velocity; out[3] = e->num_objects;
+  for (int k = 0; k < 3; k++) {
+    out[4 + k] = e->goal_lo[k]; out[7 + k] = e->goal_hi[k]; out[10 + k] = e->obj_lo[k]; out[13 + k] = e->obj_hi[k]; out[16 + k] = e->env_hi[k];
+  }
+  real high[8] = {0};
+  action_high(e, high);
+  for (int k = 0; k < 8; k++) out[19 + k] = high[k];
+}
 
 void rpo_perform_action(rpo_env* e, const double* action, double* target_poses) {
   real a[8], tp[7];
   int na = action_dim(e);
   for (int i = 0; i < na; i++) a[i] = (real)action[i];
   perform_action(e, a, tp);
-  int nd = e->m.kind == RP_KIND_P ? 7 : 6;
+  int nd = e->m.arm_type == RP_ARM_PANDA ? 7 : 6;
   for (int i = 0; i < nd; i++) target_poses[i] = tp[i];
 }
 
@@ -1169,7 +1179,7 @@ static int ray_sphere(const real* o, const real* d, const real* c, real r, real*
 /* gripper_proprioception (environments.py:720-743) */
 static int gripper_proprioception(rpo_env* e) {
   const rp_model* m = &e->m;
-  if (m->kind == RP_KIND_P) return -1;
+  if (m->arm_type == RP_ARM_PANDA) return -1;
   real g1[3], g2[3], ee[3], wr[3], R[9];
   site_world(e, e->xb, RP_SITE_PADL, g1, R);
   site_world(e, e->xb, RP_SITE_PADR, g2, R);
@@ -1216,7 +1226,7 @@ static void read_world(rpo_env* e, rpo_readings* rd) {
   body_point_velocity(e, m->site_body[RP_SITE_EE], pos, lin, ang);
   for (int k = 0; k < 3; k++) { rd->ee_pos[k] = pos[k]; rd->ee_lin[k] = lin[k]; rd->ee_ang[k] = ang[k]; }
   for (int k = 0; k < 4; k++) rd->ee_orn[k] = orn[k];
-  rd->grip_q = m->kind == RP_KIND_P ? e->q[dof_of_bullet_joint(e, 9)] : e->q[dof_of_bullet_joint(e, 18)];
+  rd->grip_q = m->arm_type == RP_ARM_PANDA ? e->q[dof_of_bullet_joint(e, 9)] : e->q[dof_of_bullet_joint(e, 18)];
   for (int j = 0; j < 8; j++) { int d = dof_of_bullet_joint(e, j); rd->joints[j] = d >= 0 ? e->q[d] : 0; }
   rd->proprio = gripper_proprioception(e);
   if (e->num_objects > 0) {
@@ -1232,7 +1242,7 @@ static void assemble_obs(rpo_env* e, const rpo_readings* rd, rpo_obs* o) {
   real pos[3], orn[4], lin[3], ang[3];
   for (int k = 0; k < 3; k++) { pos[k] = (real)rd->ee_pos[k]; lin[k] = (real)rd->ee_lin[k]; ang[k] = (real)rd->ee_ang[k]; }
   for (int k = 0; k < 4; k++) orn[k] = (real)rd->ee_orn[k];
-  real grip = m->kind == RP_KIND_P ? (real)rd->grip_q : (real)rd->grip_q * 23;
+  real grip = m->arm_type == RP_ARM_PANDA ? (real)rd->grip_q : (real)rd->grip_q * 23;
   for (int j = 0; j < 8; j++) o->joints[j] = rd->joints[j];
   o->gripper_proprioception = rd->proprio;
   real st[19], ag[11], fps[19];
@@ -1350,7 +1360,7 @@ void rpo_step(rpo_env* e, const double* action, rpo_obs* out, double* reward, in
   real r = compute_reward(e, ag, dg);
   *reward = r;
   *is_success = r < 0 ? 0 : 1;
-  int nd = e->m.kind == RP_KIND_P ? 7 : 6;
+  int nd = e->m.arm_type == RP_ARM_PANDA ? 7 : 6;
   for (int i = 0; i < nd; i++) target_poses[i] = tp[i];
 }
 
@@ -1410,9 +1420,9 @@ static void reset_arm(rpo_env* e, ustream* us) {                        /* envir
   const rp_model* m = &e->m;
   real pos[3], orn[4] = {0, 0, 0, 1};
   for (int k = 0; k < 3; k++) pos[k] = e->goal_lo[k] + (e->goal_hi[k] - e->goal_lo[k]) * next_u(us);
-  if (m->kind != RP_KIND_P) pos[2] += (real)0.2;
+  if (m->arm_type != RP_ARM_PANDA) pos[2] += (real)0.2;
   /* reset_arm_joints(rest): UR5 joints 0..5; Panda joints 0..6 and finger joint 9 (<- rest[7]) */
-  int nrest = m->kind == RP_KIND_P ? 8 : 6;
+  int nrest = m->arm_type == RP_ARM_PANDA ? 8 : 6;
   for (int i = 0; i < nrest; i++) { e->q[i] = (real)m->rest[i]; e->qd[i] = 0; }
   real sol[RP_MAX_ARM];
   ik_solve(e, pos, orn, e->q, 20, sol);
@@ -1427,7 +1437,7 @@ void rpo_reset_samples(const rpo_env* e, const double* u, double* block_pos, dou
     block_pos[3 * b + 2] = (double)((real)block_pos[3 * b + 2] + (real)0.03 * (b + 1));
   }
   for (int k = 0; k < 3; k++) arm_target[k] = (double)(e->goal_lo[k] + (e->goal_hi[k] - e->goal_lo[k]) * (real)u[n++]);
-  if (e->m.kind != RP_KIND_P) arm_target[2] = (double)((real)arm_target[2] + (real)0.2);
+  if (e->m.arm_type != RP_ARM_PANDA) arm_target[2] = (double)((real)arm_target[2] + (real)0.2);
 }
 
 /* reset(o): objects and arm placed from an observation vector (environments.py:519-525, 542-556, 575-603 with obs given).
@@ -1455,7 +1465,7 @@ static void reset_arm_obs(rpo_env* e, const real* o) {
   const rp_model* m = &e->m;
   real pos[3] = {o[0], o[1], o[2]}, orn[4] = {0, 0, 0, 1};
   if (e->use_orientation) for (int k = 0; k < 4; k++) orn[k] = e->return_velocity ? o[6 + k] : o[3 + k];
-  int nrest = m->kind == RP_KIND_P ? 8 : 6;
+  int nrest = m->arm_type == RP_ARM_PANDA ? 8 : 6;
   for (int i = 0; i < nrest; i++) { e->q[i] = (real)m->rest[i]; e->qd[i] = 0; }
   real sol[RP_MAX_ARM];
   ik_solve(e, pos, orn, e->q, 20, sol);
@@ -1502,18 +1512,21 @@ rpo_env* rpo_create(int kind, unsigned long long seed, int env_index) {
   rpo_env* e = (rpo_env*)calloc(1, sizeof(rpo_env));
   if (kind == RP_KIND_U) rp_fill_model_U(&e->m);
   else if (kind == RP_KIND_R) rp_fill_model_R(&e->m);
+  else if (kind == RP_KIND_Q) rp_fill_model_Q(&e->m);
+  else if (kind == RP_KIND_V) rp_fill_model_V(&e->m);
   else rp_fill_model_P(&e->m);
   const rp_model* m = &e->m;
   e->nv = m->n_arm + 6 * m->n_free + m->n_joint1;
   e->nbody = 1 + m->n_arm + m->n_free + m->n_joint1;
   e->seed = seed; e->env_index = (uint32_t)env_index;
-  /* envList.py:18-22, 89-99 */
-  if (kind == RP_KIND_U) {
+  /* envList.py:8-10, 18-22, 73-99: the env's flags and ranges go with its scene (play ids: complex_scene; reach ids:
+   * default_scene; pick / push: push_scene); other ids on the same model override the ranges (rpo_set_ranges) */
+  if (m->scene == RP_SCENE_COMPLEX) {
     e->play = 1; e->use_orientation = 1; e->return_velocity = 0; e->num_objects = 1;
     real gl[3] = {-0.18, 0, 0.05}, gh[3] = {0.18, 0.3, 0.1}, eh[3] = {1, 1, 1};
     for (int k = 0; k < 3; k++) { e->goal_lo[k] = e->obj_lo[k] = gl[k]; e->goal_hi[k] = e->obj_hi[k] = gh[k]; e->env_hi[k] = eh[k]; }
     e->n_goal = 11;
-  } else if (kind == RP_KIND_R) {
+  } else if (m->scene == RP_SCENE_DEFAULT) {
     e->play = 0; e->use_orientation = 0; e->return_velocity = 1; e->num_objects = 0;
     real gl[3] = {-0.18, -0.18, -0.05}, gh[3] = {0.18, 0.18, 0.05}, eh[3] = {0.18, 0.18, 0.15};
     for (int k = 0; k < 3; k++) { e->goal_lo[k] = gl[k]; e->goal_hi[k] = gh[k]; e->env_hi[k] = eh[k]; }

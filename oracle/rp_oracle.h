@@ -36,6 +36,7 @@ rpo_env* rpo_create(int kind /*0 U, 1 R, 2 P*/, unsigned long long seed, int env
 enum { RPO_ACT_ABS_RPY = 0, RPO_ACT_REL_RPY = 1, RPO_ACT_ABS_QUAT = 2, RPO_ACT_REL_QUAT = 3, RPO_ACT_ABS_JOINTS = 4, RPO_ACT_REL_JOINTS = 5 };
 void rpo_set_action_type(rpo_env* e, int action_type);
 int rpo_action_dim(const rpo_env* e);
+void rpo_get_config(const rpo_env* e, double* out27);   /* flags, ranges, action-space high (test hook) */
 void rpo_set_ranges(rpo_env* e, const double* goal_lo, const double* goal_hi, const double* obj_lo, const double* obj_hi, const double* env_hi);
 /* test hook: IK target (position, quaternion) of a pose-type action given the measured EE link pose */
 void rpo_action_target(int action_type, const double* action8, const double* ee_pos, const double* ee_orn, double* pos, double* quat);

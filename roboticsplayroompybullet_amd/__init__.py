@@ -37,5 +37,11 @@ register(id='UR5PlayAbsRPY1Obj-v0', entry_point='roboticsplayroompybullet_amd.en
 for _id, _cls in (('UR5Play1Obj-v0', 'UR5Play1Obj'), ('UR5PlayRel1Obj-v0', 'UR5PlayRel1Obj'), ('UR5PlayRelJoints1Obj-v0', 'UR5PlayRelJoints1Obj'),
                   ('UR5PlayAbsJoints1Obj-v0', 'UR5PlayAbsJoints1Obj'), ('UR5PlayRelRPY1Obj-v0', 'UR5PlayRelRPY1Obj')):
     register(id=_id, entry_point='roboticsplayroompybullet_amd.envs:' + _cls)
+# roboticsPlayroomPybullet/__init__.py:4,9,33-64 - the Panda in default_scene and the Panda one-object play family
+for _id, _cls in (('pandaReach-v0', 'pandaReach'), ('pandaReach2D-v0', 'pandaReach2D'), ('pandaPlay1Obj-v0', 'pandaPlay1Obj'),
+                  ('pandaPlayRel1Obj-v0', 'pandaPlayRel1Obj'), ('pandaPlayRelJoints1Obj-v0', 'pandaPlayRelJoints1Obj'),
+                  ('pandaPlayAbsJoints1Obj-v0', 'pandaPlayAbsJoints1Obj'), ('pandaPlayAbsRPY1Obj-v0', 'pandaPlayAbsRPY1Obj'),
+                  ('pandaPlayRelRPY1Obj-v0', 'pandaPlayRelRPY1Obj')):
+    register(id=_id, entry_point='roboticsplayroompybullet_amd.envs:' + _cls)
 
 __all__ = ['VecPlayEnv', 'make', 'register']

@@ -14,12 +14,20 @@ ENV_KINDS = {'UR5PlayAbsRPY1Obj-v0': 0, 'UR5Reach-v0': 1, 'pandaPick-v0': 2,
              # the rest of the UR5 one-object play family (same scene, other action types)
              'UR5Play1Obj-v0': 3, 'UR5PlayRel1Obj-v0': 4, 'UR5PlayRelJoints1Obj-v0': 5, 'UR5PlayAbsJoints1Obj-v0': 6,
              'UR5PlayRelRPY1Obj-v0': 7,
-             'pandaPush-v0': 8}                # pandaPick's arm and scene, other ranges
+             'pandaPush-v0': 8,                # pandaPick's arm and scene, other ranges
+             'pandaReach-v0': 9, 'pandaReach2D-v0': 10,                     # Panda + default_scene
+             # the Panda one-object play family: Panda + complex_scene
+             'pandaPlay1Obj-v0': 11, 'pandaPlayRel1Obj-v0': 12, 'pandaPlayRelJoints1Obj-v0': 13, 'pandaPlayAbsJoints1Obj-v0': 14,
+             'pandaPlayAbsRPY1Obj-v0': 15, 'pandaPlayRelRPY1Obj-v0': 16}
 
 
 ACTION_TYPES = {'UR5PlayAbsRPY1Obj-v0': 'absolute_rpy', 'UR5Reach-v0': 'absolute_rpy', 'pandaPick-v0': 'absolute_rpy',
                 'UR5Play1Obj-v0': 'absolute_quat', 'UR5PlayRel1Obj-v0': 'relative_quat', 'UR5PlayRelJoints1Obj-v0': 'relative_joints',
-                'UR5PlayAbsJoints1Obj-v0': 'absolute_joints', 'UR5PlayRelRPY1Obj-v0': 'relative_rpy', 'pandaPush-v0': 'absolute_rpy'}
+                'UR5PlayAbsJoints1Obj-v0': 'absolute_joints', 'UR5PlayRelRPY1Obj-v0': 'relative_rpy', 'pandaPush-v0': 'absolute_rpy',
+                'pandaReach-v0': 'absolute_rpy', 'pandaReach2D-v0': 'absolute_rpy',
+                'pandaPlay1Obj-v0': 'absolute_quat', 'pandaPlayRel1Obj-v0': 'relative_quat', 'pandaPlayRelJoints1Obj-v0': 'relative_joints',
+                'pandaPlayAbsJoints1Obj-v0': 'absolute_joints', 'pandaPlayAbsRPY1Obj-v0': 'absolute_rpy',
+                'pandaPlayRelRPY1Obj-v0': 'relative_rpy'}
 
 
 class RpConfig(C.Structure):

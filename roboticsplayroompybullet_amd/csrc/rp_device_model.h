@@ -29,6 +29,7 @@
 
 typedef struct DevModel {
   int kind, n_arm, n_free, n_j1, n_col, n_pair, nv, nbody, n_site;
+  int arm_type, scene;
   int play, use_orientation, return_velocity, num_objects, n_goal_init;
   int n_obs, n_ag, n_fps, n_observation, n_target;
   int action_type, n_action;    /* RP_ACT_* (environments.py:915-934) and the action length: 7, 8 (quaternion types) or n_target + 1 (joint types) */
@@ -133,7 +134,8 @@ static inline void rp_build_dev_model(const rp_model* m, DevModel* d) {
     for (int k = 0; k < 9; k++) d->col_rot[c][k] = (float)m->col_rot[c][k];
   }
   memcpy(d->pair, m->pair, sizeof(d->pair));
-  int isP = m->kind == RP_KIND_P;
+  int isP = m->arm_type == RP_ARM_PANDA;
+  d->arm_type = m->arm_type; d->scene = m->scene;
   d->d_grip_obs = rp_dm_dof_of_joint(m, isP ? 9 : 18);
   d->d18 = rp_dm_dof_of_joint(m, 18); d->d20 = rp_dm_dof_of_joint(m, 20); d->d12 = rp_dm_dof_of_joint(m, 12);
   d->d15 = rp_dm_dof_of_joint(m, 15); d->d10 = rp_dm_dof_of_joint(m, 10); d->d13 = rp_dm_dof_of_joint(m, 13);
@@ -141,12 +143,12 @@ static inline void rp_build_dev_model(const rp_model* m, DevModel* d) {
   for (int j = 0; j < 8; j++) d->joints_dof[j] = rp_dm_dof_of_joint(m, j);
   /* envList.py:18-22, 89-99 */
   const float PI = 3.14159265358979323846f;
-  if (m->kind == RP_KIND_U) {
+  if (m->scene == RP_SCENE_COMPLEX) {
     d->play = 1; d->use_orientation = 1; d->return_velocity = 0; d->num_objects = 1; d->n_goal_init = 11;
     float gl[3] = {-0.18f, 0.f, 0.05f}, gh[3] = {0.18f, 0.3f, 0.1f};
     for (int k = 0; k < 3; k++) { d->goal_lo[k] = d->obj_lo[k] = gl[k]; d->goal_hi[k] = d->obj_hi[k] = gh[k]; d->env_hi[k] = 1.f; }
     d->n_obs = 19; d->n_ag = 11; d->n_fps = 19; d->n_observation = 18; d->n_target = 6;
-  } else if (m->kind == RP_KIND_R) {
+  } else if (m->scene == RP_SCENE_DEFAULT) {
     d->play = 0; d->use_orientation = 0; d->return_velocity = 1; d->num_objects = 0; d->n_goal_init = 3;
     float gl[3] = {-0.18f, -0.18f, -0.05f}, gh[3] = {0.18f, 0.18f, 0.05f}, eh[3] = {0.18f, 0.18f, 0.15f};
     for (int k = 0; k < 3; k++) { d->goal_lo[k] = gl[k]; d->goal_hi[k] = gh[k]; d->env_hi[k] = eh[k]; }
@@ -157,6 +159,7 @@ static inline void rp_build_dev_model(const rp_model* m, DevModel* d) {
     for (int k = 0; k < 3; k++) { d->goal_lo[k] = d->obj_lo[k] = gl[k]; d->goal_hi[k] = d->obj_hi[k] = gh[k]; d->env_hi[k] = eh[k]; }
     d->n_obs = 13; d->n_ag = 3; d->n_fps = 7; d->n_observation = 12; d->n_target = 7;
   }
+  d->n_target = isP ? 7 : 6;            /* numDofs (environments.py:361, 371) */
   if (isP) {   /* environments.py:1015-1017 */
     const float ll[7] = {-0.6f, -2.2f, -3.0f, -3.04878596f, -PI, -PI, -PI};
     const float ul[7] = {3.f, 1.8f, 0.5f, -0.5002492f, 3.f, 3.45266257f, 2.40072908f};

@@ -870,7 +870,7 @@ __device__ int build_small_rows(const DevModel* m, EnvLds& L, int lane) {
     }
     nr += __popcll(mask);
   }
-  if (m->kind == RP_KIND_P) {   /* finger gear: qd_a + ratio qd_b -> 0 (environments.py:400-405) */
+  if (m->arm_type == RP_ARM_PANDA) {   /* finger gear: qd_a + ratio qd_b -> 0 (environments.py:400-405) */
     if (lane == 0) {
       int a = m->d9p, b = m->d10p;
       float ratio = -1.f;
@@ -1352,7 +1352,7 @@ __device__ ChainQ perform_action(const DevModel* m, EnvLds& L, int lane, const f
     }
     V3 tpos; Q4 tq;
     action_target(at, a8, cp, cq, tpos, tq);
-    if (m->kind == RP_KIND_P) sol = ik_solve(m, tpos, tq, cur, 200, l16);
+    if (m->arm_type == RP_ARM_PANDA) sol = ik_solve(m, tpos, tq, cur, 200, l16);
     else {   /* InverseKinematicsSolver.calc_angles: 4 chained default IK solves from the measured joints */
       sol = cur;
       for (int rep = 0; rep < 4; rep++) sol = ik_solve(m, tpos, tq, sol, 20, l16);
@@ -1372,7 +1372,7 @@ __device__ ChainQ perform_action(const DevModel* m, EnvLds& L, int lane, const f
   if (lane == 0) {
     for (int j = 0; j < nd; j++) { L.st[ST_MMODE + j] = 1.f; L.st[ST_MTARGET + j] = tp.q[j]; L.st[ST_MMAXIMP + j] = 240.f * K_DT; }
     float g = a8[m->n_action - 1];
-    if (m->kind == RP_KIND_P) {
+    if (m->arm_type == RP_ARM_PANDA) {
       float amt = 0.04f - g / 25.f;
       int ds[2] = {m->d9p, m->d10p};
       for (int i = 0; i < 2; i++) { L.st[ST_MMODE + ds[i]] = 1.f; L.st[ST_MTARGET + ds[i]] = amt; L.st[ST_MMAXIMP + ds[i]] = 100.f * K_DT; }
@@ -1447,7 +1447,7 @@ __device__ void calc_state(const DevModel* m, EnvLds& L, int lane) {
   __syncthreads();
   /* gripper_proprioception ray (environments.py:720-743): lane c tests collider c */
   int prop = -1;
-  if (m->kind != RP_KIND_P) {
+  if (m->arm_type != RP_ARM_PANDA) {
     V3 g1 = site_pos_world(m, L, RP_SITE_PADL), g2 = site_pos_world(m, L, RP_SITE_PADR);
     V3 ee = site_pos_world(m, L, RP_SITE_EE), wr = site_pos_world(m, L, RP_SITE_WRIST);
     V3 p1 = ee - (ee - wr) * 0.5f, p2 = (g1 + g2) * 0.5f + (ee - wr) * 0.2f, d = p2 - p1;
@@ -1497,7 +1497,7 @@ __device__ void calc_state(const DevModel* m, EnvLds& L, int lane) {
     uint32_t anc = m->arm_anc[eb - 1];
     for (int j = 0; j < n; j++) if ((anc >> j) & 1u) v = v + ld6(&L.S[6 * j]) * L.st[ST_QD + j];
     V3 lin = v.l + cross(v.a, pos - ld3(L.O)), ang = v.a;
-    float grip = L.st[ST_Q + m->d_grip_obs] * (m->kind == RP_KIND_P ? 1.f : 23.f);
+    float grip = L.st[ST_Q + m->d_grip_obs] * (m->arm_type == RP_ARM_PANDA ? 1.f : 23.f);
     float* o = L.out;
     float st[19], ag[11];
     int ns = 0, nag = 0, nf = 0;
@@ -1726,12 +1726,12 @@ __global__ void __launch_bounds__(64, RP_WAVES_PER_EU) k_reset(const DevModel* _
       tx[0] = m->goal_lo[0] + (m->goal_hi[0] - m->goal_lo[0]) * u0;
       tx[1] = m->goal_lo[1] + (m->goal_hi[1] - m->goal_lo[1]) * u1;
       tx[2] = m->goal_lo[2] + (m->goal_hi[2] - m->goal_lo[2]) * u2;
-      if (m->kind != RP_KIND_P) tx[2] += 0.2f;
+      if (m->arm_type != RP_ARM_PANDA) tx[2] += 0.2f;
     }
     }
     __syncthreads();
     if (lane == 0) {
-      int nrest = m->kind == RP_KIND_P ? 8 : 6;
+      int nrest = m->arm_type == RP_ARM_PANDA ? 8 : 6;
       for (int i = 0; i < nrest; i++) { L.st[ST_Q + i] = m->rest[i]; L.st[ST_QD + i] = 0.f; }
     }
     __syncthreads();
@@ -1821,7 +1821,7 @@ __global__ void __launch_bounds__(64) k_action(const DevModel* __restrict__ m, f
     if (at == RP_ACT_REL_RPY || at == RP_ACT_REL_QUAT) ee_pose_coop(m, qj, l16, cp, cq);
     V3 tpos; Q4 tq;
     action_target(at, a8, cp, cq, tpos, tq);
-    if (m->kind == RP_KIND_P) qj = ik_coop<7>(m, tpos, tq, qj, 200, l16, live);
+    if (m->arm_type == RP_ARM_PANDA) qj = ik_coop<7>(m, tpos, tq, qj, 200, l16, live);
     else if (nc == 6) { for (int rep = 0; rep < 4; rep++) qj = ik_coop<6>(m, tpos, tq, qj, 20, l16, live); }
     else { for (int rep = 0; rep < 4; rep++) qj = ik_coop<7>(m, tpos, tq, qj, 20, l16, live); }
   }
@@ -1834,7 +1834,7 @@ __global__ void __launch_bounds__(64) k_action(const DevModel* __restrict__ m, f
   }
   if (l16 == 0) {
     float g = a8[m->n_action - 1];
-    if (m->kind == RP_KIND_P) {
+    if (m->arm_type == RP_ARM_PANDA) {
       float amt = 0.04f - g / 25.f;
       int ds[2] = {m->d9p, m->d10p};
       for (int i = 0; i < 2; i++) { st[ST_MMODE + ds[i]] = 1.f; st[ST_MTARGET + ds[i]] = amt; st[ST_MMAXIMP + ds[i]] = 100.f * K_DT; }

@@ -1,5 +1,5 @@
-/* rp_model.h — baked model tables for one env kind (U = UR5PlayAbsRPY1Obj-v0, R = UR5Reach-v0,
- * P = pandaPick-v0).  Plain C, shared as DATA LAYOUT by oracle/rp_oracle.c (CPU restatement) and the
+/* rp_model.h — baked model tables for one env kind = arm + scene (U = UR5PlayAbsRPY1Obj-v0, R = UR5Reach-v0,
+ * P = pandaPick-v0, Q = pandaReach-v0, V = pandaPlayAbsRPY1Obj-v0).  Plain C, shared as DATA LAYOUT by oracle/rp_oracle.c (CPU restatement) and the
  * HIP library; filled by generated/rp_models_gen.h (tools/bake_assets.py).
  *
  * Bodies of one env:   0 = static world (scene statics + the arm's fixed base link)
@@ -15,6 +15,15 @@
 #define RP_KIND_U 0
 #define RP_KIND_R 1
 #define RP_KIND_P 2
+#define RP_KIND_Q 3   /* Panda + default_scene (pandaReach-v0, pandaReach2D-v0) */
+#define RP_KIND_V 4   /* Panda + complex_scene, one block (the pandaPlay*1Obj-v0 ids) */
+#define RP_N_KIND 5
+
+#define RP_ARM_UR5 0
+#define RP_ARM_PANDA 1
+#define RP_SCENE_COMPLEX 0
+#define RP_SCENE_DEFAULT 1
+#define RP_SCENE_PUSH 2
 
 #define RP_MAX_ARM 12
 #define RP_MAX_FREE 2
@@ -31,6 +40,7 @@
 
 typedef struct rp_model {
   int kind, n_arm, n_free, n_joint1, n_col, n_pair, n_site;
+  int arm_type, scene;              /* RP_ARM_*, RP_SCENE_*: what the kind is made of */
   /* arm (tree, parents precede children) */
   int arm_parent[RP_MAX_ARM];       /* movable parent (0-based) or -1 = base */
   int arm_jtype[RP_MAX_ARM];        /* 0 revolute, 1 prismatic */

@@ -64,27 +64,35 @@ const char* rp_version(void) { return "rp_playroom 0.1 (gfx950, wave-per-env)"; 
 
 int rp_create(const rp_config* cfg, rp_handle* out) {
   if (!cfg || !out || cfg->num_envs <= 0) { snprintf(g_err, 256, "rp_create: bad argument"); return RP_ERR_ARG; }
-  if (cfg->env_kind < 0 || cfg->env_kind > RP_ENV_PANDA_PUSH) { snprintf(g_err, 256, "rp_create: unsupported env kind %d", cfg->env_kind); return RP_ERR_UNSUPPORTED; }
+  if (cfg->env_kind < 0 || cfg->env_kind >= RP_ENV_COUNT) { snprintf(g_err, 256, "rp_create: unsupported env kind %d", cfg->env_kind); return RP_ERR_UNSUPPORTED; }
   rp_sim* h = (rp_sim*)calloc(1, sizeof(rp_sim));
   h->cfg = *cfg;
   rp_model* m = (rp_model*)malloc(sizeof(rp_model));
-  /* the UR5 one-object play family shares scene, arm and configuration (envList.py:93-140); only perform_action differs */
-  int action_type = RP_ACT_ABS_RPY;
-  switch (cfg->env_kind) {
-    case RP_ENV_UR5_REACH: rp_fill_model_R(m); break;
-    case RP_ENV_PANDA_PICK: case RP_ENV_PANDA_PUSH: rp_fill_model_P(m); break;
-    case RP_ENV_UR5_PLAY_1OBJ: rp_fill_model_U(m); action_type = RP_ACT_ABS_QUAT; break;
-    case RP_ENV_UR5_PLAY_REL_1OBJ: rp_fill_model_U(m); action_type = RP_ACT_REL_QUAT; break;
-    case RP_ENV_UR5_PLAY_REL_JOINTS_1OBJ: rp_fill_model_U(m); action_type = RP_ACT_REL_JOINTS; break;
-    case RP_ENV_UR5_PLAY_ABS_JOINTS_1OBJ: rp_fill_model_U(m); action_type = RP_ACT_ABS_JOINTS; break;
-    case RP_ENV_UR5_PLAY_REL_RPY_1OBJ: rp_fill_model_U(m); action_type = RP_ACT_REL_RPY; break;
+  /* registered id -> baked model (arm + scene) and action type.  The ids of a play family share scene, arm and configuration
+   * (envList.py:43-140); only perform_action differs. */
+  static const struct { char model; int action_type; } SPEC[RP_ENV_COUNT] = {
+    {'U', RP_ACT_ABS_RPY}, {'R', RP_ACT_ABS_RPY}, {'P', RP_ACT_ABS_RPY},
+    {'U', RP_ACT_ABS_QUAT}, {'U', RP_ACT_REL_QUAT}, {'U', RP_ACT_REL_JOINTS}, {'U', RP_ACT_ABS_JOINTS}, {'U', RP_ACT_REL_RPY},
+    {'P', RP_ACT_ABS_RPY},
+    {'Q', RP_ACT_ABS_RPY}, {'Q', RP_ACT_ABS_RPY},
+    {'V', RP_ACT_ABS_QUAT}, {'V', RP_ACT_REL_QUAT}, {'V', RP_ACT_REL_JOINTS}, {'V', RP_ACT_ABS_JOINTS}, {'V', RP_ACT_ABS_RPY}, {'V', RP_ACT_REL_RPY}};
+  const int action_type = SPEC[cfg->env_kind].action_type;
+  switch (SPEC[cfg->env_kind].model) {
+    case 'R': rp_fill_model_R(m); break;
+    case 'P': rp_fill_model_P(m); break;
+    case 'Q': rp_fill_model_Q(m); break;
+    case 'V': rp_fill_model_V(m); break;
     default: rp_fill_model_U(m); break;
   }
   rp_build_dev_model(m, &h->host_model);
+  DevModel* d = &h->host_model;
   if (cfg->env_kind == RP_ENV_PANDA_PUSH) {      /* pandaPick's arm and scene with pandaPush's ranges (envList.py:12-16) */
     const float gl[3] = {-0.1f, -0.1f, -0.06f}, gh[3] = {0.1f, 0.1f, -0.05f}, eh[3] = {0.18f, 0.18f, -0.04f};
-    DevModel* d = &h->host_model;
     for (int k = 0; k < 3; k++) { d->goal_lo[k] = d->obj_lo[k] = gl[k]; d->goal_hi[k] = d->obj_hi[k] = gh[k]; d->env_hi[k] = eh[k]; }
+  }
+  if (cfg->env_kind == RP_ENV_PANDA_REACH_2D) {  /* envList.py:24-26 */
+    const float gl[3] = {-0.18f, -0.18f, -0.06f}, gh[3] = {0.18f, 0.18f, -0.05f}, eh[3] = {0.18f, 0.18f, 0.0f};
+    for (int k = 0; k < 3; k++) { d->goal_lo[k] = gl[k]; d->goal_hi[k] = gh[k]; d->env_hi[k] = eh[k]; }
   }
   h->host_model.action_type = action_type;
   h->host_model.n_action = (action_type == RP_ACT_ABS_QUAT || action_type == RP_ACT_REL_QUAT) ? 8

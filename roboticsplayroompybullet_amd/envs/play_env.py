@@ -46,8 +46,8 @@ class playEnv:
                  obj_upper_bound=(-0.18, -0.18, -0.05), sparse=True, use_orientation=False, sparse_rew_thresh=0.05,
                  fixed_gripper=False, return_velocity=True, max_episode_steps=250, play=False, action_type='absolute_rpy',
                  show_goal=True, arm_type='Panda', device=0, seed=0):
-        if action_type != 'absolute_rpy' and not (arm_type == 'UR5' and play and num_objects == 1):
-            raise NotImplementedError('action_type %r is built for the UR5 one-object play ids only (SURVEY.md §8f rank 1)' % action_type)
+        if action_type != 'absolute_rpy' and not (play and num_objects == 1):
+            raise NotImplementedError('action_type %r is built for the one-object play ids only (SURVEY.md §8f rank 1)' % action_type)
         self.timeStep = 1.0 / 300
         self.render_scene = False
         self.physics_client_active = 0
@@ -211,19 +211,43 @@ class UR5PlayAbsRPY1Obj(playEnv):             # envList.py:93-99
                          action_type='absolute_rpy', show_goal=False, arm_type='UR5', **kw)
 
 
-def _ur5_play_1obj(name, env_id, action_type, anchor):
-    """the other members of the UR5 one-object play family: UR5PlayAbsRPY1Obj with another action type"""
+class pandaReach(playEnv):                    # envList.py:8-10
+    ENV_ID = 'pandaReach-v0'
+
+    def __init__(self, num_objects=0, **kw):
+        super().__init__(num_objects=num_objects, use_orientation=False, **kw)
+
+
+class pandaReach2D(playEnv):                  # envList.py:24-26
+    ENV_ID = 'pandaReach2D-v0'
+
+    def __init__(self, num_objects=0, env_range_low=(-0.18, -0.18, -0.07), env_range_high=(0.18, 0.18, 0.0), goal_range_low=(-0.18, -0.18, -0.06),
+                 goal_range_high=(0.18, 0.18, -0.05), use_orientation=False, **kw):
+        super().__init__(num_objects=num_objects, env_range_low=env_range_low, env_range_high=env_range_high, goal_range_low=goal_range_low,
+                         goal_range_high=goal_range_high, use_orientation=use_orientation, **kw)
+
+
+def _play_1obj(name, env_id, action_type, anchor, arm_type='UR5'):
+    """a member of a one-object play family: UR5PlayAbsRPY1Obj's configuration with another action type and / or arm"""
     def __init__(self, num_objects=1, env_range_low=(-1.0, -1.0, -0.2), env_range_high=(1.0, 1.0, 1.0), goal_range_low=(-0.18, 0, 0.05),
                  goal_range_high=(0.18, 0.3, 0.1), use_orientation=True, **kw):
         playEnv.__init__(self, num_objects=num_objects, env_range_low=env_range_low, env_range_high=env_range_high,
                          goal_range_low=goal_range_low, goal_range_high=goal_range_high, use_orientation=use_orientation,
                          obj_lower_bound=[-0.18, 0, 0.05], obj_upper_bound=[0.18, 0.3, 0.1], return_velocity=False,
-                         max_episode_steps=None, play=True, action_type=action_type, show_goal=False, arm_type='UR5', **kw)
+                         max_episode_steps=None, play=True, action_type=action_type, show_goal=False, arm_type=arm_type, **kw)
     return type(name, (playEnv,), {'ENV_ID': env_id, '__init__': __init__, '__doc__': anchor})
 
 
-UR5PlayRelRPY1Obj = _ur5_play_1obj('UR5PlayRelRPY1Obj', 'UR5PlayRelRPY1Obj-v0', 'relative_rpy', 'envList.py:101-107')
-UR5PlayRelJoints1Obj = _ur5_play_1obj('UR5PlayRelJoints1Obj', 'UR5PlayRelJoints1Obj-v0', 'relative_joints', 'envList.py:109-115')
-UR5PlayAbsJoints1Obj = _ur5_play_1obj('UR5PlayAbsJoints1Obj', 'UR5PlayAbsJoints1Obj-v0', 'absolute_joints', 'envList.py:117-123')
-UR5Play1Obj = _ur5_play_1obj('UR5Play1Obj', 'UR5Play1Obj-v0', 'absolute_quat', 'envList.py:126-132')
-UR5PlayRel1Obj = _ur5_play_1obj('UR5PlayRel1Obj', 'UR5PlayRel1Obj-v0', 'relative_quat', 'envList.py:134-140')
+UR5PlayRelRPY1Obj = _play_1obj('UR5PlayRelRPY1Obj', 'UR5PlayRelRPY1Obj-v0', 'relative_rpy', 'envList.py:101-107')
+UR5PlayRelJoints1Obj = _play_1obj('UR5PlayRelJoints1Obj', 'UR5PlayRelJoints1Obj-v0', 'relative_joints', 'envList.py:109-115')
+UR5PlayAbsJoints1Obj = _play_1obj('UR5PlayAbsJoints1Obj', 'UR5PlayAbsJoints1Obj-v0', 'absolute_joints', 'envList.py:117-123')
+UR5Play1Obj = _play_1obj('UR5Play1Obj', 'UR5Play1Obj-v0', 'absolute_quat', 'envList.py:126-132')
+UR5PlayRel1Obj = _play_1obj('UR5PlayRel1Obj', 'UR5PlayRel1Obj-v0', 'relative_quat', 'envList.py:134-140')
+
+# the Panda one-object play family (envList.py:43-88): same configuration, arm_type left at its default 'Panda'
+pandaPlayRelJoints1Obj = _play_1obj('pandaPlayRelJoints1Obj', 'pandaPlayRelJoints1Obj-v0', 'relative_joints', 'envList.py:43-48', 'Panda')
+pandaPlayAbsJoints1Obj = _play_1obj('pandaPlayAbsJoints1Obj', 'pandaPlayAbsJoints1Obj-v0', 'absolute_joints', 'envList.py:50-55', 'Panda')
+pandaPlay1Obj = _play_1obj('pandaPlay1Obj', 'pandaPlay1Obj-v0', 'absolute_quat', 'envList.py:58-63', 'Panda')
+pandaPlayRel1Obj = _play_1obj('pandaPlayRel1Obj', 'pandaPlayRel1Obj-v0', 'relative_quat', 'envList.py:65-70', 'Panda')
+pandaPlayAbsRPY1Obj = _play_1obj('pandaPlayAbsRPY1Obj', 'pandaPlayAbsRPY1Obj-v0', 'absolute_rpy', 'envList.py:72-78', 'Panda')
+pandaPlayRelRPY1Obj = _play_1obj('pandaPlayRelRPY1Obj', 'pandaPlayRelRPY1Obj-v0', 'relative_rpy', 'envList.py:80-86', 'Panda')

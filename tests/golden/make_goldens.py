@@ -39,6 +39,8 @@ with contextlib.redirect_stdout(io.StringIO()):
     import roboticsPlayroomPybullet  # noqa: E402,F401  (fills fb.REGISTRY)
     from roboticsPlayroomPybullet.envs import UR5PlayAbsRPY1Obj, UR5Reach, pandaPick  # noqa: E402
     from roboticsPlayroomPybullet.envs import pandaPush  # noqa: E402
+    from roboticsPlayroomPybullet.envs import (pandaReach, pandaReach2D, pandaPlay1Obj, pandaPlayRel1Obj, pandaPlayRelJoints1Obj,  # noqa: E402
+                                               pandaPlayAbsJoints1Obj, pandaPlayAbsRPY1Obj, pandaPlayRelRPY1Obj)
     from roboticsPlayroomPybullet.envs import (UR5Play1Obj, UR5PlayRel1Obj, UR5PlayRelJoints1Obj, UR5PlayAbsJoints1Obj,  # noqa: E402
                                                UR5PlayRelRPY1Obj)
     import scenes  # noqa: E402  (the reference puts envs/ on sys.path itself)
@@ -94,16 +96,17 @@ def fill_world(kind, env, c, rng):
         desc['link'][str(i)] = s
 
     n_j = c.getNumJoints(arm)
+    panda = inst.arm_type == 'Panda'
     for j in range(n_j):
         q = float(rng.uniform(-2.5, 2.5))
-        if kind != 'P' and j in (18, 20):
+        if not panda and j in (18, 20):
             q = float(rng.uniform(0.0, 0.0448))
-        if kind == 'P' and j in (9, 10):
+        if panda and j in (9, 10):
             q = float(rng.uniform(0.0, 0.04))
         w['joint'][(arm, j)] = q
         desc['joint'][str(j)] = q
     link(ee)
-    if kind != 'P':
+    if not panda:
         for i in (ee - 1, 18, 20):
             link(i)
     for k, o in enumerate(inst.objects):
@@ -111,7 +114,7 @@ def fill_world(kind, env, c, rng):
              'lin': rng.uniform(-1, 1, 3).tolist(), 'ang': rng.uniform(-1, 1, 3).tolist()}
         w['base'][o] = s
         desc['base']['block%d' % k] = s
-    if kind == 'U':
+    if inst.play:
         d = inst.drawer['drawer']
         s = {'pos': [-0.1, float(rng.uniform(-0.06, 0.075)), -0.04], 'orn': inst.drawer['defaults']['ori'],
              'lin': [0, 0, 0], 'ang': [0, 0, 0]}
@@ -471,7 +474,62 @@ def gen_step_family(seed=61, n_cases=6):
     dump('step_family.json', out)
 
 
+# the Panda ids beyond pandaPick / pandaPush: Panda + default_scene and Panda + complex_scene
+PANDA_IDS = {'pandaReach-v0': pandaReach, 'pandaReach2D-v0': pandaReach2D, 'pandaPlay1Obj-v0': pandaPlay1Obj,
+             'pandaPlayRel1Obj-v0': pandaPlayRel1Obj, 'pandaPlayRelJoints1Obj-v0': pandaPlayRelJoints1Obj,
+             'pandaPlayAbsJoints1Obj-v0': pandaPlayAbsJoints1Obj, 'pandaPlayAbsRPY1Obj-v0': pandaPlayAbsRPY1Obj,
+             'pandaPlayRelRPY1Obj-v0': pandaPlayRelRPY1Obj}
+
+
+def gen_panda_ids(seed=97, n_cases=5):
+    """Per id: declared spaces / attributes / ranges, the scene and arm it builds (call log), and step() cases: the IK call
+    the action type produces on the live arm (maxNumIterations=200), joint clamps, motor commands, and the observation
+    assembled from the fake world read-back."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    for gid, cls in PANDA_IDS.items():
+        env, c, shadow = new_env(None, cls)
+        assert shadow is None
+        inst = env.instance
+        info = {'action_type': env.action_type, 'action_low': env.action_space.low, 'action_high': env.action_space.high,
+                'play': env.play, 'use_orientation': env.use_orientation, 'return_velocity': env.return_velocity,
+                'num_objects': env.num_objects, 'num_goals': env.num_goals, 'max_episode_steps': env._max_episode_steps,
+                'arm_type': env.arm_type, 'sparse_rew_thresh': env.sparse_rew_thresh,
+                'env_lower_bound': env.env_lower_bound, 'env_upper_bound': env.env_upper_bound,
+                'goal_lower_bound': env.goal_lower_bound, 'goal_upper_bound': env.goal_upper_bound,
+                'obj_lower_bound': env.obj_lower_bound, 'obj_upper_bound': env.obj_upper_bound,
+                'observation_space': {k: {'low': v.low, 'high': v.high} for k, v in env.observation_space.spaces.items()},
+                'base_pos': inst.init_arm_base_pos, 'base_orn': inst.init_arm_base_orn, 'ee_index': inst.endEffectorIndex,
+                'rest': inst.restJointPositions, 'num_dofs': inst.numDofs,
+                'scene_fns': [e['fn'] for e in c.log if e['fn'] in ('loadURDF', 'createMultiBody', 'createConstraint')]}
+        na = len(env.action_space.high)
+        ng = 11 if env.play else 3
+        cases = []
+        for k in range(n_cases):
+            env, c, shadow = new_env(None, cls)
+            env.instance.goal = rng.uniform(-0.3, 0.3, ng)
+            desc = fill_world(None, env, c, rng)
+            action = rng.uniform(-1.0, 1.0, na) * 0.9
+            if k % 3 == 2:
+                action = rng.uniform(-8, 8, na)      # exercise the action-space clip
+            arm = env.instance.arm
+            cur = np.array([c.world['joint'][(arm, j)] for j in range(7)])
+            sol = rng.uniform(-3.5, 3.5, 9)
+            if k % 2 == 0:
+                sol[:7] = cur + rng.uniform(-0.3, 0.3, 7)
+            c.ik_queue = [sol.tolist()]
+            c.clear_log()
+            obs, r, done, inf = quiet(env.step, action)
+            cases.append({'goal': env.instance.goal, 'world': desc, 'action': action, 'ik_returns': [sol.tolist()],
+                          'main_log': [e for e in c.log if e['fn'] != 'rayTest'],
+                          'obs': obs_to_json(obs), 'reward': float(r), 'done': bool(done),
+                          'is_success': inf['is_success'], 'target_poses': inf['target_poses']})
+        out[gid] = {'info': info, 'cases': cases}
+    dump('panda_ids.json', out)
+
+
 if __name__ == '__main__':
+    gen_panda_ids()
     gen_spaces_more()
     gen_reset_to()
     gen_step_family()

@@ -7,8 +7,8 @@ from oracle import OracleEnv, quat_from_euler, euler_from_quat, dial_to_0_1_rang
 
 DT = 1.0 / 300.0
 F32_KEYS = ('obs_quat', 'achieved_goal', 'desired_goal', 'controllable_achieved_goal', 'full_positional_state')
-EE = {'U': 7, 'R': 7, 'P': 11}
-GRIP_JOINT = {'U': '18', 'R': '18', 'P': '9'}
+EE = {'U': 7, 'R': 7, 'P': 11, 'Q': 11, 'V': 11}
+GRIP_JOINT = {'U': '18', 'R': '18', 'P': '9', 'Q': '9', 'V': '9'}
 
 
 def readings_from_world(kind, w):
@@ -16,14 +16,14 @@ def readings_from_world(kind, w):
     kw = dict(ee_pos=ee['pos'], ee_orn=ee['orn'], ee_lin=ee['lin'], ee_ang=ee['ang'], grip_q=w['joint'][GRIP_JOINT[kind]],
               joints=[w['joint'][str(j)] for j in range(8)])
     ray = w['ray']
-    if kind == 'P':
+    if kind in ('P', 'Q', 'V'):
         kw['proprio'] = -1
     else:   # environments.py:736: nothing in hand if the ray misses or hits a pad
         kw['proprio'] = 0 if (ray['fraction'] == 1.0 or ray['link'] in (18, 20)) else 1
     if 'block0' in w['base']:
         b = w['base']['block0']
         kw.update(block_pos=b['pos'], block_orn=b['orn'], block_vel=b['lin'])
-    if kind == 'U':
+    if kind in ('U', 'V'):
         kw.update(drawer_y=w['base']['drawer']['pos'][1], door_q=w['joint']['door'], button_q=w['joint']['button'],
                   dial_q=w['joint']['dial'])
     return kw
@@ -164,6 +164,79 @@ def test_action_types_of_the_ur5_play_family(golden, gid):
             assert tgt[d] == pytest.approx(e['args'][3], abs=1e-15)
             assert maximp[d] == pytest.approx(e['kwargs']['force'] * DT, rel=1e-15)
         assert sum(1 for e in case['main_log'] if e['fn'] == 'stepSimulation') == 12
+
+
+PANDA_IDS = ['pandaReach-v0', 'pandaReach2D-v0', 'pandaPlay1Obj-v0', 'pandaPlayRel1Obj-v0', 'pandaPlayRelJoints1Obj-v0',
+             'pandaPlayAbsJoints1Obj-v0', 'pandaPlayAbsRPY1Obj-v0', 'pandaPlayRelRPY1Obj-v0']
+
+
+@pytest.mark.parametrize('gid', PANDA_IDS)
+def test_panda_reach_and_play_ids(golden, gid):
+    """The Panda ids beyond pick / push (envList.py:8-10, 24-88): the Panda in default_scene (reach) and in complex_scene (one-
+    object play, six action types).  Attributes, ranges, action space; per step() case the IK call on the live arm, joint
+    clamps, motor commands and the observation assembled from the read-back."""
+    g = golden('panda_ids.json')[gid]
+    info = g['info']
+    env0 = OracleEnv(gid)
+    kind = 'V' if info['play'] else 'Q'
+    assert info['arm_type'] == 'Panda' and info['num_dofs'] == 7 and info['ee_index'] == 11
+    initP = golden('scenes.json')['instance_init_P']            # base pose, EE link and rest pose go with the arm type
+    np.testing.assert_array_equal(info['base_pos'], initP['base_pos'])
+    np.testing.assert_array_equal(info['base_orn'], initP['base_orn'])
+    np.testing.assert_array_equal(info['rest'], initP['rest'])
+    assert env0.action_type == info['action_type']
+    high = np.array(info['action_high'])
+    assert env0.n_action == len(high)
+    np.testing.assert_array_equal(env0.action_high(), high)
+    np.testing.assert_array_equal(np.array(info['action_low']), -high)
+    fl = env0.flags()
+    assert (fl['play'], fl['use_orientation'], fl['return_velocity'], fl['num_objects']) == \
+        (int(info['play']), int(info['use_orientation']), int(info['return_velocity']), info['num_objects'])
+    rg = env0.ranges()
+    np.testing.assert_allclose(rg['goal_lo'], info['goal_lower_bound'], atol=0)
+    np.testing.assert_allclose(rg['goal_hi'], info['goal_upper_bound'], atol=0)
+    np.testing.assert_allclose(rg['env_hi'], info['env_upper_bound'], atol=0)
+    if info['num_objects']:
+        np.testing.assert_allclose(rg['obj_lo'], info['obj_lower_bound'], atol=0)
+        np.testing.assert_allclose(rg['obj_hi'], info['obj_upper_bound'], atol=0)
+    bullet_dofs = [0, 1, 2, 3, 4, 5, 6, 9, 10]
+    for case in g['cases']:
+        env = OracleEnv(gid)
+        a = np.clip(np.array(case['action']), -high, high)
+        w = case['world']
+        s = env.get_state()
+        for d, j in enumerate(bullet_dofs):
+            s[d] = w['joint'][str(j)]
+        env.set_state(s)
+        ik_calls = [e for e in case['main_log'] if e['fn'] == 'calculateInverseKinematics']
+        if info['action_type'] in ('absolute_joints', 'relative_joints'):
+            assert len(ik_calls) == 0
+            jp = a[:7] + (s[:7] if info['action_type'] == 'relative_joints' else 0.0)
+            tp = env.goto_joint_poses(jp, gripper=a[7])
+        else:
+            assert len(ik_calls) == 1 and ik_calls[0]['kwargs'] == {'maxNumIterations': 200}
+            ee = w['link']['11']
+            pos, quat = env.action_target(a, ee['pos'], ee['orn'])
+            np.testing.assert_allclose(ik_calls[0]['args'][2], pos, rtol=0, atol=1e-15)
+            np.testing.assert_allclose(ik_calls[0]['args'][3], quat, rtol=0, atol=1e-14)
+            tp = env.goto_joint_poses(np.array(case['ik_returns'][-1])[:7], gripper=a[-1])
+        np.testing.assert_allclose(tp, case['target_poses'], rtol=0, atol=1e-15)
+        arr = [e for e in case['main_log'] if e['fn'] == 'setJointMotorControlArray'][0]
+        np.testing.assert_allclose(tp, arr['kwargs']['targetPositions'], rtol=0, atol=1e-15)
+        mode, tgt, maximp = env.get_motor()
+        singles = [e for e in case['main_log'] if e['fn'] == 'setJointMotorControl2']
+        assert len(singles) == 2
+        for e in singles:
+            d = bullet_dofs.index(e['args'][1])
+            assert mode[d] == 1
+            assert tgt[d] == pytest.approx(e['args'][3], abs=1e-15)
+            assert maximp[d] == pytest.approx(e['kwargs']['force'] * DT, rel=1e-15)
+        assert sum(1 for e in case['main_log'] if e['fn'] == 'stepSimulation') == 12
+        env.set_goal(case['goal'])
+        got = env.assemble_obs(**readings_from_world(kind, w))
+        check_obs(got, case['obs'], tol=1e-12)
+        r = env.compute_reward(np.float32(got['achieved_goal']), np.float32(got['desired_goal']))
+        assert r == pytest.approx(case['reward'], abs=1e-7)
 
 
 def test_rewards_and_dial(golden):

@@ -312,9 +312,9 @@ def shape_boxes(shape):
 WORLD = 0
 
 
-def make_model(kind, arm, scene_log, arm_base_pos, arm_base_rot, ee_index, rest):
+def make_model(kind, arm, scene_log, arm_base_pos, arm_base_rot, ee_index, rest, arm_type='UR5', scene='complex_scene'):
     nb = len(arm['bodies'])
-    M = {'kind': kind, 'n_arm': nb, 'arm': arm['bodies'], 'base_pos': arm_base_pos, 'base_rot': arm_base_rot,
+    M = {'kind': kind, 'arm_type': arm_type, 'scene': scene, 'n_arm': nb, 'arm': arm['bodies'], 'base_pos': arm_base_pos, 'base_rot': arm_base_rot,
          'rest': list(rest), 'free': [], 'joint1': [], 'col': [], 'pair': []}
     col = M['col']
 
@@ -415,7 +415,7 @@ def make_model(kind, arm, scene_log, arm_base_pos, arm_base_rot, ee_index, rest)
     # sites
     sb, sp, sr = arm['site'](ee_index)
     M['sites'] = [{'body': 1 + sb, 'pos': sp, 'rot': sr}]
-    if kind != 'P':
+    if arm_type != 'Panda':
         for li in (ee_index - 1, 18, 20):
             sb, sp, sr = arm['site'](li)
             M['sites'].append({'body': 1 + sb, 'pos': sp, 'rot': sr})
@@ -504,7 +504,10 @@ def emit_header(models, path):
         nb = M['n_arm']
         A = M['arm']
         out.append('  m->kind = %d; m->n_arm = %d; m->n_free = %d; m->n_joint1 = %d; m->n_col = %d; m->n_pair = %d; m->n_site = %d;\n'
-                   % ('URP'.index(k), nb, len(M['free']), len(M['joint1']), len(M['col']), len(M['pair']), len(M['sites'])))
+                   % ('URPQV'.index(k), nb, len(M['free']), len(M['joint1']), len(M['col']), len(M['pair']), len(M['sites'])))
+
+        out.append('  m->arm_type = %d; m->scene = %d;\n' % (['UR5', 'Panda'].index(M['arm_type']),
+                                                               ['complex_scene', 'default_scene', 'push_scene'].index(M['scene'])))
 
         def put(field, arr, ctype='double'):
             name = 't_' + field
@@ -565,10 +568,13 @@ def main():
     ur5 = build_arm(os.path.join(ENVS, 'ur_e_description', 'ur5e2.urdf'))
     panda = build_arm(os.path.join(ENVS, 'franka_panda', 'panda.urdf'))
     models = []
-    for kind, arm, scene in (('U', ur5, 'complex_scene'), ('R', ur5, 'default_scene'), ('P', panda, 'push_scene')):
-        init = gold['instance_init_' + kind]
+    # Q, V: the Panda (instance_init_P: base pose, EE index and rest pose are per arm type, environments.py:356-363) in the
+    # other two scenes
+    for kind, arm, scene, ini in (('U', ur5, 'complex_scene', 'U'), ('R', ur5, 'default_scene', 'R'), ('P', panda, 'push_scene', 'P'),
+                                  ('Q', panda, 'default_scene', 'P'), ('V', panda, 'complex_scene', 'P')):
+        init = gold['instance_init_' + ini]
         M = make_model(kind, arm, gold[scene]['log'], np.array(init['base_pos'], float), quat_to_mat(init['base_orn']),
-                       init['ee_index'], init['rest'])
+                       init['ee_index'], init['rest'], 'UR5' if arm is ur5 else 'Panda', scene)
         print(kind, 'arm dofs', M['n_arm'], 'free', len(M['free']), 'joint1', len(M['joint1']), 'colliders', len(M['col']),
               'pairs', len(M['pair']))
         models.append(M)

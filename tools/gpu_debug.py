@@ -24,8 +24,8 @@ def f2i(x):
 def record_from_oracle(o):
     """oracle state -> 128-float HIP state record"""
     s = o.get_state()
-    n, nf = o.n_arm, (2 if o.kind == 0 else (1 if o.kind == 2 else 0))
-    nj = 3 if o.kind == 0 else 0
+    n, nf = o.n_arm, (2 if o.kind in (0, 4) else (1 if o.kind == 2 else 0))
+    nj = 3 if o.kind in (0, 4) else 0
     r = np.zeros(128, dtype=np.float32)
     r[0:n] = s[0:n]
     r[12:12 + n] = s[n:2 * n]
@@ -52,8 +52,8 @@ def record_from_oracle(o):
 
 
 def oracle_state_from_record(o, r):
-    n, nf = o.n_arm, (2 if o.kind == 0 else (1 if o.kind == 2 else 0))
-    nj = 3 if o.kind == 0 else 0
+    n, nf = o.n_arm, (2 if o.kind in (0, 4) else (1 if o.kind == 2 else 0))
+    nj = 3 if o.kind in (0, 4) else 0
     s = list(r[0:n]) + list(r[12:12 + n])
     for k in range(nf):
         s += list(r[24 + 13 * k:24 + 13 * k + 13])
