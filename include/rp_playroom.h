@@ -11,7 +11,8 @@
  *     (float32 unless noted), valid until `stream` reaches the call; the library owns only its internal state.
  *   - a handle is bound to one device, is not thread-safe, and enqueues on the caller's stream
  *     (pass torch.cuda.current_stream().cuda_stream); `stream` is a hipStream_t passed as void*.
- *   - no host<->device copies and no synchronisation inside rp_step / rp_reset / rp_compute_reward.
+ *   - no host<->device copies and no synchronisation inside rp_step / rp_reset_to / rp_compute_reward; rp_reset reads one
+ *     4-byte counter back per round of settle substeps (see rp_reset).
  *   - per-env numerical blow-ups are not errors: they set status[env] != 0 in rp_out.
  */
 #ifndef RP_PLAYROOM_H
@@ -103,7 +104,10 @@ int rp_destroy(rp_handle h);
 int rp_get_dims(rp_handle h, rp_dims* dims);
 
 /* playEnv.reset(o=None) (ENV:173-187) for every env whose mask byte is non-zero (mask NULL = all):
- * resample block / arm / goal, 100 settle substeps, repeat while the goal is already satisfied. */
+ * resample block / arm / goal, 100 settle substeps, repeat while the goal is already satisfied.  The settle substeps run
+ * through the step pipeline's kernels over the envs that still need them, in rounds; the host waits on `stream` once per round
+ * (1-3 rounds for a few envs, more for the unluckiest env of a large batch), so the call returns when the reset is done.
+ * Uses the handle's row workspace: do not overlap with rp_step on another stream. */
 int rp_reset(rp_handle h, const uint8_t* mask, const rp_out* out, void* stream);
 
 /* playEnv.reset(o) (ENV:173-187 with ENV:542-556, 575-590): objects and arm placed from an observation vector o [N, n_o]

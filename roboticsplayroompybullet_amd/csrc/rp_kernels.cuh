@@ -1653,7 +1653,72 @@ __device__ void reset_goal_pos(const DevModel* m, EnvLds& L, int lane, const flo
   }
 }
 
-/* playEnv.reset(o=None) (environments.py:173-187, 519-603) */
+/* reset_object_pos, o = None (environments.py:519-540): drawer and scene joints to their defaults, every object to a uniform
+ * draw from the spawn range (+3 cm per object), yaw 90 deg.  Lane 0 mutates the record; the 100 settle substeps follow. */
+__device__ void reset_sample_objects(const DevModel* m, EnvLds& L, int lane, uint64_t seed, uint32_t genv) {
+  if (lane == 0) {
+    if (m->play) {
+      float* d = &L.st[ST_FREE + 13];
+      for (int k = 0; k < 3; k++) d[k] = m->free_pos0[1][k];
+      for (int k = 0; k < 4; k++) d[3 + k] = m->free_quat0[1][k];
+      for (int k = 7; k < 13; k++) d[k] = 0.f;
+      for (int k = 0; k < m->n_j1; k++) { L.st[ST_JQ + k] = 0.f; L.st[ST_JQD + k] = 0.f; }
+    }
+    float height = 0.03f;
+    for (int b = 0; b < m->num_objects; b++) {
+      float* f = &L.st[ST_FREE + 13 * b];
+      for (int k = 0; k < 3; k++) f[k] = m->obj_lo[k] + (m->obj_hi[k] - m->obj_lo[k]) * next_u(L, seed, genv);
+      f[2] += height;
+      f[3] = 0.f; f[4] = 0.f; f[5] = 0.7071f; f[6] = 0.7071f;
+      for (int k = 7; k < 13; k++) f[k] = 0.f;
+      height += 0.03f;
+    }
+  }
+  __syncthreads();
+}
+/* an object ended above / beyond the env's upper bound after settling (environments.py:537-540): sample again */
+__device__ __forceinline__ bool reset_objects_out_of_bounds(const DevModel* m, const EnvLds& L) {
+  bool outb = false;
+  for (int b = 0; b < m->num_objects; b++)
+    for (int k = 0; k < 3; k++) if (L.st[ST_FREE + 13 * b + k] > m->env_hi[k]) outb = true;
+  return outb;
+}
+/* reset_arm's target when o = None (environments.py:575-581): uniform in the goal range (+0.2 z for the UR5) */
+__device__ __forceinline__ void reset_sample_arm_target(const DevModel* m, EnvLds& L, int lane, uint64_t seed, uint32_t genv, float* tx) {
+  float u0 = 0.f, u1 = 0.f, u2 = 0.f;
+  if (lane == 0) { u0 = next_u(L, seed, genv); u1 = next_u(L, seed, genv); u2 = next_u(L, seed, genv); }
+  u0 = unif(u0); u1 = unif(u1); u2 = unif(u2);
+  tx[0] = m->goal_lo[0] + (m->goal_hi[0] - m->goal_lo[0]) * u0;
+  tx[1] = m->goal_lo[1] + (m->goal_hi[1] - m->goal_lo[1]) * u1;
+  tx[2] = m->goal_lo[2] + (m->goal_hi[2] - m->goal_lo[2]) * u2;
+  if (m->arm_type != RP_ARM_PANDA) tx[2] += 0.2f;
+}
+/* the rest of one reset attempt (environments.py:590-603, 173-187): rest pose, one IK on the live arm, first 6 joints only
+ * (quirk F5), a new goal, the observation; returns the reward of the fresh state (reset repeats while it is > -1) */
+__device__ float reset_arm_goal_obs(const DevModel* m, EnvLds& L, int lane, uint64_t seed, uint32_t genv, const float* tx, Q4 torn) {
+  __syncthreads();
+  if (lane == 0) {
+    int nrest = m->arm_type == RP_ARM_PANDA ? 8 : 6;
+    for (int i = 0; i < nrest; i++) { L.st[ST_Q + i] = m->rest[i]; L.st[ST_QD + i] = 0.f; }
+  }
+  __syncthreads();
+  ChainQ cur;
+#pragma unroll
+  for (int j = 0; j < 7; j++) cur.q[j] = j < m->ee_chain ? L.st[ST_Q + j] : 0.f;
+  ChainQ sol = ik_solve(m, mk3(tx[0], tx[1], tx[2]), torn, cur, 20, lane & 15);
+  __syncthreads();
+  if (lane == 0) for (int i = 0; i < 6; i++) { L.st[ST_Q + i] = sol.q[i]; L.st[ST_QD + i] = 0.f; }
+  __syncthreads();
+  reset_goal_pos(m, L, lane, nullptr, seed, genv);
+  calc_state(m, L, lane);
+  float r = L.out[O_REW];
+  __syncthreads();
+  return r;
+}
+
+/* playEnv.reset(o=None) and reset(o) (environments.py:173-187, 519-603) in one kernel, one wave per env, the settle substeps
+ * through the fused substep().  rp_reset_to uses it (no settling there), and rp_reset when the fused path is selected; the
+ * default rp_reset runs the same sequence through the split pipeline (k_reset_* below). */
 __global__ void __launch_bounds__(64, RP_WAVES_PER_EU) k_reset(const DevModel* __restrict__ m, float* __restrict__ state, const uint8_t* __restrict__ mask,
                                              OutPtrs out, int N, uint64_t seed, uint32_t env_offset, const float* __restrict__ obs_o, int n_o) {
   __shared__ EnvLds L;
@@ -1691,63 +1756,72 @@ __global__ void __launch_bounds__(64, RP_WAVES_PER_EU) k_reset(const DevModel* _
       tx[0] = o[0]; tx[1] = o[1]; tx[2] = o[2];
       if (m->use_orientation) { int q0 = m->return_velocity ? 6 : 3; torn.x = o[q0]; torn.y = o[q0 + 1]; torn.z = o[q0 + 2]; torn.w = o[q0 + 3]; }
     } else {
-    /* reset_object_pos */
-    for (int depth = 0; depth < 9; depth++) {
-      if (lane == 0) {
-        if (m->play) {
-          float* d = &L.st[ST_FREE + 13];
-          for (int k = 0; k < 3; k++) d[k] = m->free_pos0[1][k];
-          for (int k = 0; k < 4; k++) d[3 + k] = m->free_quat0[1][k];
-          for (int k = 7; k < 13; k++) d[k] = 0.f;
-          for (int k = 0; k < m->n_j1; k++) { L.st[ST_JQ + k] = 0.f; L.st[ST_JQD + k] = 0.f; }
-        }
-        float height = 0.03f;
-        for (int b = 0; b < m->num_objects; b++) {
-          float* f = &L.st[ST_FREE + 13 * b];
-          for (int k = 0; k < 3; k++) f[k] = m->obj_lo[k] + (m->obj_hi[k] - m->obj_lo[k]) * next_u(L, seed, genv);
-          f[2] += height;
-          f[3] = 0.f; f[4] = 0.f; f[5] = 0.7071f; f[6] = 0.7071f;
-          for (int k = 7; k < 13; k++) f[k] = 0.f;
-          height += 0.03f;
-        }
+      for (int depth = 0; depth < 9; depth++) {
+        reset_sample_objects(m, L, lane, seed, genv);
+        for (int i = 0; i < K_NSETTLE; i++) substep(m, L, lane);
+        if (!reset_objects_out_of_bounds(m, L)) break;
       }
-      __syncthreads();
-      for (int i = 0; i < K_NSETTLE; i++) substep(m, L, lane);
-      bool outb = false;
-      for (int b = 0; b < m->num_objects; b++)
-        for (int k = 0; k < 3; k++) if (L.st[ST_FREE + 13 * b + k] > m->env_hi[k]) outb = true;
-      if (!outb) break;
+      reset_sample_arm_target(m, L, lane, seed, genv, tx);
     }
-    /* reset_arm: rest pose, one IK on the live arm, first 6 joints only (quirk F5) */
-    {
-      float u0 = 0.f, u1 = 0.f, u2 = 0.f;
-      if (lane == 0) { u0 = next_u(L, seed, genv); u1 = next_u(L, seed, genv); u2 = next_u(L, seed, genv); }
-      u0 = unif(u0); u1 = unif(u1); u2 = unif(u2);
-      tx[0] = m->goal_lo[0] + (m->goal_hi[0] - m->goal_lo[0]) * u0;
-      tx[1] = m->goal_lo[1] + (m->goal_hi[1] - m->goal_lo[1]) * u1;
-      tx[2] = m->goal_lo[2] + (m->goal_hi[2] - m->goal_lo[2]) * u2;
-      if (m->arm_type != RP_ARM_PANDA) tx[2] += 0.2f;
-    }
-    }
-    __syncthreads();
-    if (lane == 0) {
-      int nrest = m->arm_type == RP_ARM_PANDA ? 8 : 6;
-      for (int i = 0; i < nrest; i++) { L.st[ST_Q + i] = m->rest[i]; L.st[ST_QD + i] = 0.f; }
-    }
-    __syncthreads();
-    ChainQ cur;
-#pragma unroll
-    for (int j = 0; j < 7; j++) cur.q[j] = j < m->ee_chain ? L.st[ST_Q + j] : 0.f;
-    ChainQ sol = ik_solve(m, mk3(tx[0], tx[1], tx[2]), torn, cur, 20, lane & 15);
-    __syncthreads();
-    if (lane == 0) for (int i = 0; i < 6; i++) { L.st[ST_Q + i] = sol.q[i]; L.st[ST_QD + i] = 0.f; }
-    __syncthreads();
-    reset_goal_pos(m, L, lane, nullptr, seed, genv);
-    calc_state(m, L, lane);
-    r = L.out[O_REW];
-    __syncthreads();
+    r = reset_arm_goal_obs(m, L, lane, seed, genv, tx, torn);
   }
   write_outputs(m, L, lane, env, out);
+  store_state(L, state, env, lane);
+}
+
+/* ---- rp_reset through the split pipeline.  The host runs rounds; in a round every env that still has a settle phase ahead
+ * ("pending") is gathered into a dense scratch range, gets its objects sampled (k_reset_sample), runs the 100 settle substeps as
+ * 100 x (k_prep2, k_solve2) over that range - the same kernels as rp_step - and then either finishes its reset, samples the
+ * objects again (out of bounds: depth + 1) or starts its next attempt (fresh state already rewarded: attempt + 1); records go
+ * back to the env's slot after every round (k_reset_finish).  Same draws, same order, same arithmetic as k_reset. */
+__global__ void k_reset_mark(const uint8_t* __restrict__ mask, int4* __restrict__ meta, int N) {
+  int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env < N) meta[env] = make_int4((!mask || mask[env]) ? 1 : 0, 0, 0, 0);        /* pending, attempt, depth */
+}
+/* pending envs in index order -> idx[0 .. count) (one wave) */
+__global__ void __launch_bounds__(64) k_reset_list(const int4* __restrict__ meta, int* __restrict__ idx, int* __restrict__ count, int N) {
+  const int lane = threadIdx.x;
+  int total = 0;
+  for (int base = 0; base < N; base += 64) {
+    const int env = base + lane;
+    const bool p = env < N && meta[env].x != 0;
+    const unsigned long long bal = __ballot(p);
+    if (p) idx[total + __popcll(bal & ((1ull << lane) - 1ull))] = env;
+    total += __popcll(bal);
+  }
+  if (lane == 0) *count = total;
+}
+__global__ void __launch_bounds__(64) k_reset_sample(const DevModel* __restrict__ m, const float* __restrict__ state, float* __restrict__ scratch,
+                                                     const int* __restrict__ idx, int M, uint64_t seed, uint32_t env_offset) {
+  __shared__ EnvLds L;
+  const int slot = blockIdx.x, lane = threadIdx.x;
+  if (slot >= M) return;
+  const int env = idx[slot];
+  load_state(L, state, env, lane);
+  reset_sample_objects(m, L, lane, seed, env_offset + (uint32_t)env);
+  store_state(L, scratch, slot, lane);
+}
+__global__ void __launch_bounds__(64, RP_WAVES_PER_EU) k_reset_finish(const DevModel* __restrict__ m, const float* __restrict__ scratch, float* __restrict__ state,
+                                                                       const int* __restrict__ idx, int4* __restrict__ meta, OutPtrs out, int M, uint64_t seed,
+                                                                       uint32_t env_offset) {
+  __shared__ EnvLds L;
+  const int slot = blockIdx.x, lane = threadIdx.x;
+  if (slot >= M) return;
+  const int env = idx[slot];
+  const uint32_t genv = env_offset + (uint32_t)env;
+  int4 mt = meta[env];
+  load_state(L, scratch, slot, lane);
+  if (reset_objects_out_of_bounds(m, L) && mt.z < 8) {
+    mt.z++;                                        /* sample the objects again, settle again */
+  } else {
+    float tx[3];
+    const Q4 torn = {0.f, 0.f, 0.f, 1.f};
+    reset_sample_arm_target(m, L, lane, seed, genv, tx);
+    const float r = reset_arm_goal_obs(m, L, lane, seed, genv, tx, torn);
+    if (r > -1.f && mt.y + 1 < 64) { mt.y++; mt.z = 0; }      /* already solved: the whole reset again */
+    else { mt.x = 0; write_outputs(m, L, lane, env, out); }
+  }
+  if (lane == 0) meta[env] = mt;
   store_state(L, state, env, lane);
 }
 
@@ -1908,7 +1982,7 @@ __device__ __forceinline__ void copy_out(float* __restrict__ dst, const float* s
 #define AOUT_FLOATS (160 + 8 + 20)
 static_assert(W3_A % 4 == 0 && W3_ROWS % 4 == 0 && W3_ROFF % 4 == 0 && AOUT_FLOATS % 4 == 0, "16-byte copies");
 
-__global__ void __launch_bounds__(64, RP_PREP_WAVES) k_prep2(const DevModel* __restrict__ m, const float* __restrict__ state, float* __restrict__ ws, int env0, int N,
+__device__ __forceinline__ void prep2_body(const DevModel* __restrict__ m, const float* __restrict__ state, float* __restrict__ ws, int env0, int N,
                                                              const int* __restrict__ sort_cnt, int* __restrict__ sort_cnt_next, const int* __restrict__ sort_slot, int* __restrict__ pair_env) {
   __shared__ EnvLds L;
   int env = env0 + blockIdx.x, lane = threadIdx.x;
@@ -2023,6 +2097,13 @@ __global__ void __launch_bounds__(64, RP_PREP_WAVES) k_prep2(const DevModel* __r
   }
   PCLK(5) PCLK(7)
 }
+/* two entry points on the same body: rp_step's substeps, and the settle substeps of rp_reset under their own name so that
+ * profiles keep the two apart */
+#define PREP2_ARGS const DevModel* __restrict__ m, const float* __restrict__ state, float* __restrict__ ws, int env0, int N, \
+                   const int* __restrict__ sort_cnt, int* __restrict__ sort_cnt_next, const int* __restrict__ sort_slot, int* __restrict__ pair_env
+__global__ void __launch_bounds__(64, RP_PREP_WAVES) k_prep2(PREP2_ARGS) { prep2_body(m, state, ws, env0, N, sort_cnt, sort_cnt_next, sort_slot, pair_env); }
+__global__ void __launch_bounds__(64, RP_PREP_WAVES) k_settle_prep(PREP2_ARGS) { prep2_body(m, state, ws, env0, N, sort_cnt, sort_cnt_next, sort_slot, pair_env); }
+
 
 struct __align__(16) Solve2Lds {
   union {
@@ -2136,7 +2217,7 @@ __device__ __forceinline__ void generic_row(float Jr, float Br, float& dv, Plane
         : "vcc");
 }
 
-__global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m, float* __restrict__ state, const float* __restrict__ ws, int env0, int N,
+__device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, float* __restrict__ state, const float* __restrict__ ws, int env0, int N,
                                                   const int* __restrict__ pair_env, int* __restrict__ sort_cnt_next, int* __restrict__ sort_slot, int debug_flags) {
   __shared__ Solve2Lds L;
   const int lane = threadIdx.x, half = lane >> 5, l = lane & 31, grp = l >> 4, l16 = lane & 15;
@@ -2417,6 +2498,11 @@ __global__ void __launch_bounds__(64, 2) k_solve2(const DevModel* __restrict__ m
   }
 #endif
 }
+#define SOLVE2_ARGS const DevModel* __restrict__ m, float* __restrict__ state, const float* __restrict__ ws, int env0, int N, \
+                    const int* __restrict__ pair_env, int* __restrict__ sort_cnt_next, int* __restrict__ sort_slot, int debug_flags
+__global__ void __launch_bounds__(64, 2) k_solve2(SOLVE2_ARGS) { solve2_body(m, state, ws, env0, N, pair_env, sort_cnt_next, sort_slot, debug_flags); }
+__global__ void __launch_bounds__(64, 2) k_settle_solve(SOLVE2_ARGS) { solve2_body(m, state, ws, env0, N, pair_env, sort_cnt_next, sort_slot, debug_flags); }
+
 
 /* first pairing of a group's envs (before any load class is known): everything in the lightest class, in index order */
 __global__ void k_sort_init(int* __restrict__ cnt, int* __restrict__ slot, int env0, int ng) {

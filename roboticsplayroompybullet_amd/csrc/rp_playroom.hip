@@ -31,6 +31,10 @@ struct rp_sim {
   hipStream_t gstream[RP_MAX_GROUPS];
   hipEvent_t gfork, gjoin[RP_MAX_GROUPS];
   int fused;               /* 0: split pipeline (default), 1: single fused k_step kernel (in-library reference path) */
+  /* rp_reset through the split pipeline (allocated at the first reset): dense scratch records of the envs that are settling,
+   * their env ids, per-env progress {pending, attempt, depth}, pairing tables of the scratch range */
+  float* rs_state; int* rs_idx; int4* rs_meta; int* rs_count; int* rs_sort_cnt; int* rs_sort_slot; int* rs_pair; int* rs_count_host;
+  int reset_rounds;        /* rounds the latest rp_reset took (rp_debug) */
   rp_timers timers;
   char err[256];
 };
@@ -133,6 +137,10 @@ int rp_destroy(rp_handle h) {
   if (!h) return RP_ERR_ARG;
   hipSetDevice(h->cfg.device);
   hipFree(h->dev_model); hipFree(h->state); hipFree(h->ws); hipFree(h->dbg); hipFree(h->sort_cnt); hipFree(h->sort_slot); hipFree(h->pair_env);
+  if (h->rs_state) {
+    hipFree(h->rs_state); hipFree(h->rs_idx); hipFree(h->rs_meta); hipFree(h->rs_count); hipFree(h->rs_sort_cnt); hipFree(h->rs_sort_slot);
+    hipFree(h->rs_pair); hipHostFree(h->rs_count_host);
+  }
   hipEventDestroy(h->ev0); hipEventDestroy(h->ev1); hipEventDestroy(h->gfork);
   for (int i = 0; i < RP_MAX_GROUPS; i++) { hipStreamDestroy(h->gstream[i]); hipEventDestroy(h->gjoin[i]); }
   if (h->pool) { for (int i = 0; i < h->pool_steps * EV_PER_STEP; i++) hipEventDestroy(h->pool[i]); free(h->pool); }
@@ -149,11 +157,61 @@ int rp_get_dims(rp_handle h, rp_dims* d) {
   return RP_OK;
 }
 
+/* playEnv.reset() for the masked envs through the split pipeline: rounds of { gather the envs that still have a settle phase
+ * ahead, sample their objects, 100 x (k_settle_prep, k_settle_solve: k_prep2 / k_solve2 under other names) over the dense scratch range, finish / re-sample / next attempt }.
+ * One host sync per round (the pending count sizes the launches); a round is ~100 substeps, most resets take 1-3 rounds, the
+ * unluckiest env of a large batch a few more (play ids repeat the reset while the drawn goal is already satisfied). */
+static int reset_split(rp_handle h, const uint8_t* mask, const rp_out* out, hipStream_t s) {
+  const int N = h->cfg.num_envs;
+  if (!h->rs_state) {
+    if (hipMalloc((void**)&h->rs_state, (size_t)N * RP_REC_FLOATS * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&h->rs_idx, (size_t)N * sizeof(int)) != hipSuccess ||
+        hipMalloc((void**)&h->rs_meta, (size_t)N * sizeof(int4)) != hipSuccess ||
+        hipMalloc((void**)&h->rs_count, sizeof(int)) != hipSuccess ||
+        hipMalloc((void**)&h->rs_sort_cnt, (size_t)2 * SORT_BINS * sizeof(int)) != hipSuccess ||
+        hipMalloc((void**)&h->rs_sort_slot, (size_t)N * sizeof(int)) != hipSuccess ||
+        hipMalloc((void**)&h->rs_pair, (size_t)N * sizeof(int)) != hipSuccess ||
+        hipHostMalloc((void**)&h->rs_count_host, sizeof(int)) != hipSuccess) {
+      snprintf(h->err, 256, "rp_reset: scratch allocation failed"); return RP_ERR_HIP;
+    }
+  }
+  const OutPtrs op = to_ptrs(out);
+  const uint64_t seed = h->cfg.seed;
+  const uint32_t off = (uint32_t)h->cfg.env_offset;
+  hipLaunchKernelGGL(k_reset_mark, dim3((N + 255) / 256), dim3(256), 0, s, mask, h->rs_meta, N);
+  int* cnt[2] = {h->rs_sort_cnt, h->rs_sort_cnt + SORT_BINS};
+  h->reset_rounds = 0;
+  for (int round = 0; round < 64 * 9; round++) {
+    hipLaunchKernelGGL(k_reset_list, dim3(1), dim3(64), 0, s, h->rs_meta, h->rs_idx, h->rs_count, N);
+    HIPCHK(h, hipMemcpyAsync(h->rs_count_host, h->rs_count, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    const int M = *h->rs_count_host;
+    if (M <= 0) break;
+    h->reset_rounds++;
+    hipLaunchKernelGGL(k_reset_sample, dim3(M), dim3(64), 0, s, h->dev_model, h->state, h->rs_state, h->rs_idx, M, seed, off);
+    hipLaunchKernelGGL(k_sort_init, dim3((max(M, SORT_BINS) + 255) / 256), dim3(256), 0, s, cnt[0], h->rs_sort_slot, 0, M);
+    int par = 0;
+    for (int i = 0; i < K_NSETTLE; i++) {
+      hipLaunchKernelGGL(k_settle_prep, dim3(M), dim3(64), 0, s, h->dev_model, h->rs_state, h->ws, 0, M, cnt[par], cnt[par ^ 1], h->rs_sort_slot, h->rs_pair);
+      hipLaunchKernelGGL(k_settle_solve, dim3((M + 1) / 2), dim3(64), 0, s, h->dev_model, h->rs_state, h->ws, 0, M, h->rs_pair, cnt[par ^ 1], h->rs_sort_slot, h->debug_flags);
+      par ^= 1;
+    }
+    hipLaunchKernelGGL(k_reset_finish, dim3(M), dim3(64), 0, s, h->dev_model, h->rs_state, h->state, h->rs_idx, h->rs_meta, op, M, seed, off);
+    HIPCHK(h, hipGetLastError());
+  }
+  return RP_OK;
+}
+
 static int reset_impl(rp_handle h, const float* o, int32_t n_o, const uint8_t* mask, const rp_out* out, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   int N = h->cfg.num_envs;
   if (h->timers_on) hipEventRecord(h->ev0, s);
-  hipLaunchKernelGGL(k_reset, dim3(N), dim3(64), 0, s, h->dev_model, h->state, mask, to_ptrs(out), N, h->cfg.seed, (uint32_t)h->cfg.env_offset, o, (int)n_o);
+  if (!o && h->fused != 1) {
+    int rc = reset_split(h, mask, out, s);
+    if (rc != RP_OK) return rc;
+  } else {          /* reset(o) has no settle phase; the fused path keeps everything in one kernel */
+    hipLaunchKernelGGL(k_reset, dim3(N), dim3(64), 0, s, h->dev_model, h->state, mask, to_ptrs(out), N, h->cfg.seed, (uint32_t)h->cfg.env_offset, o, (int)n_o);
+  }
   HIPCHK(h, hipGetLastError());
   if (h->timers_on) { hipEventRecord(h->ev1, s); hipEventSynchronize(h->ev1); hipEventElapsedTime(&h->timers.last_reset_ms, h->ev0, h->ev1); }
   return RP_OK;

@@ -134,6 +134,39 @@ def test_split_pipeline_equals_fused_kernel_bitwise():
         assert torch.equal(ia['target_poses'], ib['target_poses'])
 
 
+def test_reset_through_split_pipeline_equals_fused_reset_bitwise():
+    """rp_reset's default path (rounds of 100 x (k_prep2, k_solve2) over the gathered pending envs, host-driven) == the one-kernel
+    k_reset (fused substeps), bit for bit: full resets, then a masked reset after some steps (other envs untouched)."""
+    from roboticsplayroompybullet_amd import VecPlayEnv
+    for kind in ('U', 'P', 'R', 'V'):
+        n = 37
+        a = VecPlayEnv(IDS[kind], n, seed=21)
+        b = VecPlayEnv(IDS[kind], n, seed=21)
+        b.set_fused(1)
+        oa, ob = a.reset(), b.reset()
+        torch.cuda.synchronize()
+        assert torch.equal(a.get_state(), b.get_state())
+        for k in ('obs_quat', 'achieved_goal', 'desired_goal', 'observation'):
+            assert torch.equal(oa[k], ob[k]), k
+        b.set_fused(0)
+        acts = torch.tensor(actions(kind, 3, n, 2), dtype=torch.float32)
+        for t in range(3):
+            a.step(acts[t]); b.step(acts[t])
+        before = a.get_state().clone()
+        mask = torch.zeros(n, dtype=torch.uint8)
+        mask[[1, 5, 6, 20, 36]] = 1
+        b.set_fused(1)
+        oa, ob = a.reset(mask=mask), b.reset(mask=mask)
+        torch.cuda.synchronize()
+        sa, sb = a.get_state(), b.get_state()
+        assert torch.equal(sa, sb)
+        keep = mask == 0
+        assert torch.equal(sa[keep.to(sa.device)], before[keep.to(sa.device)])
+        assert not torch.equal(sa[1], before[1])
+        for k in ('obs_quat', 'desired_goal'):
+            assert torch.equal(oa[k][mask.bool().to(sa.device)], ob[k][mask.bool().to(sa.device)]), k
+
+
 def grasp_actions(obs, t, n):
     """drive the gripper onto the block, close, lift: arm-block (spanning) and arm-table (arm-only) contacts"""
     a = np.zeros((n, 7))
