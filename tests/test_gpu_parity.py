@@ -460,3 +460,108 @@ def test_full_size_properties():
     # per-step joint clamp of goto_joint_poses (environments.py:1021-1026)
     tp = info['target_poses']
     assert (tp[:, 0] <= -0.7 + 1e-6).all() and (tp[:, 2] <= -0.5 + 1e-6).all()
+
+
+def test_config_ur5_play_1024_envs_1000_steps():
+    """BASELINE.json configs[1]: UR5PlayAbsRPY1Obj-v0, N = 1024, 1000-step random-action rollout.  Size-independent
+    properties: nothing non-finite, unit quaternions, the reward / success identities, and the whole rollout is
+    reproducible bit for bit from the same seed and actions."""
+    from roboticsplayroompybullet_amd import VecPlayEnv
+    n, steps = 1024, 1000
+    g = torch.Generator(device='cuda').manual_seed(5)
+    lo, hi = torch.tensor(LO, dtype=torch.float32, device='cuda'), torch.tensor(HI, dtype=torch.float32, device='cuda')
+    acts = lo + (hi - lo) * torch.rand((steps, n, 7), generator=g, device='cuda')
+    finals = []
+    for rep in range(2):
+        env = VecPlayEnv(IDS['U'], n, seed=8)
+        env.reset()
+        succ = torch.zeros(n, dtype=torch.int64, device='cuda')
+        for t in range(steps):
+            obs, r, done, info = env.step(acts[t])
+            succ += info['is_success']
+        torch.cuda.synchronize()
+        assert int(info['status'].sum()) == 0
+        o = obs['obs_quat']
+        assert torch.isfinite(o).all() and torch.isfinite(env.get_state()).all()
+        assert torch.allclose(o[:, 3:7].norm(dim=1), torch.ones(n, device=o.device), atol=1e-4)
+        assert torch.allclose(o[:, 11:15].norm(dim=1), torch.ones(n, device=o.device), atol=1e-4)
+        assert ((r == 0) | (r == -1)).all() and torch.equal(info['is_success'], (r >= 0).int())
+        finals.append((env.get_state().clone(), succ.clone()))
+        env.close()
+    assert torch.equal(finals[0][0], finals[1][0]) and torch.equal(finals[0][1], finals[1][1])
+
+
+def test_config_panda_pick_4096_envs():
+    """BASELINE.json configs[2]: pandaPick-v0 at N = 4096 (second arm, finger gear, tray contacts): invariants of a 60-step
+    rollout that drives the gripper onto the block and lifts, and the sparse reward identity -1 / -distance."""
+    from roboticsplayroompybullet_amd import VecPlayEnv
+    n = 4096
+    env = VecPlayEnv(IDS['P'], n, seed=12)
+    obs = env.reset()
+    z0 = obs['achieved_goal'][:, 2].clone()
+    for t in range(60):
+        a = torch.zeros((n, 7), device='cuda')
+        a[:, 0:3] = obs['achieved_goal'][:, 0:3]
+        a[:, 2] += 0.0 if t < 30 else 0.15
+        a[:, 6] = -1.0 if t < 15 else 1.0
+        obs, r, done, info = env.step(a)
+    torch.cuda.synchronize()
+    assert int(info['status'].sum()) == 0 and torch.isfinite(env.get_state()).all()
+    d = (obs['achieved_goal'] - obs['desired_goal']).norm(dim=1)
+    want = torch.where(d > 0.05, -torch.ones_like(d), -d)
+    assert torch.allclose(r, want, atol=1e-6)
+    assert torch.equal(info['is_success'], (d <= 0.05).int()) or torch.equal(info['is_success'], (r > -1).int())
+    g = obs['obs_quat'][:, 6]
+    lifted = (obs['achieved_goal'][:, 2] - z0) > 0.05
+    print('pandaPick grasp-and-lift: finger joint in [%.4f, %.4f]; %d of %d envs hold something between the fingers, %d lifted the block > 5 cm'
+          % (float(g.min()), float(g.max()), int((g > 0.01).sum()), n, int(lifted.sum())))
+    assert (g > -5e-3).all() and (g < 0.045).all()                    # finger joint inside its limits (soft: erp-corrected rows)
+
+
+def test_config_cem_mpc_broadcast_rollouts():
+    """BASELINE.json configs[4]: CEM-MPC shape on UR5PlayAbsRPY1Obj-v0 - 32 start states x 512 candidate action sequences
+    = 16384 envs, horizon 50, open loop, reward summed per candidate.  Candidates of one start state begin bit-identical
+    (rp_set_state), identical candidates stay bit-identical, and one (start, candidate) pair is checked against the fp32
+    oracle started from the same record."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    from gpu_debug import oracle_state_from_record
+    from oracle import OracleEnv
+    from roboticsplayroompybullet_amd import VecPlayEnv
+    n_start, n_cand, horizon = 32, 512, 50
+    n = n_start * n_cand
+    src = VecPlayEnv(IDS['U'], n_start, seed=4)
+    src.reset()
+    starts = src.get_state().clone()                                   # [32, 128]
+    env = VecPlayEnv(IDS['U'], n, seed=4)
+    env.set_state(starts.repeat_interleave(n_cand, dim=0))
+    g = torch.Generator(device='cuda').manual_seed(9)
+    lo, hi = torch.tensor(LO, dtype=torch.float32, device='cuda'), torch.tensor(HI, dtype=torch.float32, device='cuda')
+    mean = lo + (hi - lo) * torch.rand((horizon, n_start, 1, 7), generator=g, device='cuda')
+    acts = (mean + 0.05 * torch.randn((horizon, n_start, n_cand, 7), generator=g, device='cuda')).clamp(lo, hi)
+    acts[:, :, 1] = acts[:, :, 0]                                      # candidate 1 repeats candidate 0
+    acts = acts.reshape(horizon, n, 7).contiguous()
+    ret = torch.zeros(n, device='cuda')
+    first = None
+    for t in range(horizon):
+        obs, r, done, info = env.step(acts[t])
+        ret += r
+        if t == 9:
+            first = obs['obs_quat'][0].clone()
+    torch.cuda.synchronize()
+    assert int(info['status'].sum()) == 0
+    s = env.get_state().reshape(n_start, n_cand, -1)
+    assert torch.equal(s[:, 0], s[:, 1])                               # identical candidates: identical trajectories
+    ret = ret.reshape(n_start, n_cand)
+    assert torch.equal(ret[:, 0], ret[:, 1])
+    assert (ret.max(dim=1).values >= ret.mean(dim=1)).all() and (ret <= 0).all() and (ret >= -horizon).all()
+    # start 0, candidate 0 against the fp32 oracle from the same record (10 steps: before contact chaos can matter)
+    orc = OracleEnv('U', seed=4, env_index=0, f32=True)
+    orc.set_state(oracle_state_from_record(orc, starts[0].cpu().numpy()))
+    orc.set_goal(starts[0, 92:103].cpu().numpy())
+    for t in range(10):
+        oo, ro, _, _ = orc.step(acts[t, 0].cpu().numpy())
+    # (every motor target is rewritten by the step's action, so the record's motor block need not be carried over; positions only:
+    # the quaternion sign memory of the fresh oracle env differs from the record's)
+    idx = [0, 1, 2, 7, 8, 9, 10]
+    np.testing.assert_allclose(first.cpu().numpy()[idx], oo['obs_quat'][idx], atol=1e-3, rtol=0)
