@@ -32,6 +32,7 @@
 #define MOTOR_KD ((real)1.0)
 #define DEFAULT_MOTOR_MAXIMP ((real)1.0) /* createJointMotors: velocity motor, target 0, max impulse 1 */
 #define LIMIT_MAXIMP ((real)100.0)
+#define MAX_COORD_VEL ((real)100.0)     /* btMultiBody::m_maxCoordinateVelocity (recalled) */
 #define LIMIT_ACTIVATION ((real)0.1)
 #define FREE_LIN_DAMP ((real)0.04)
 #define FREE_ANG_DAMP ((real)0.04)
@@ -815,13 +816,21 @@ void rpo_substep(rpo_env* e) {
   build_rows(e, vstar);
   real dv[RP_MAX_NV] = {0};
   solve_rows(e, dv);
-  /* apply and integrate (semi-implicit Euler; free-body orientation by the exponential map) */
-  for (int i = 0; i < m->n_arm; i++) { e->qd[i] = vstar[i] + dv[i]; e->q[i] += DT * e->qd[i]; }
+  /* apply and integrate (semi-implicit Euler; free-body orientation by the exponential map).  Every body here is a
+   * btMultiBody, and btMultiBody::applyDeltaVeeMultiDof - through which processDeltaVeeMultiDof2 adds the solver's velocity
+   * change after the solve - clamps each generalized velocity to +-m_maxCoordinateVelocity = 100 (upstream bullet3
+   * btMultiBody.h / .cpp, from memory, unverified like the rest of App. E).  Never active in ordinary motion; it keeps a
+   * squeezed, deeply penetrating contact from running away. */
+  for (int i = 0; i < nv; i++) {          /* dv becomes the new generalized velocity */
+    real v = vstar[i] + dv[i];
+    dv[i] = v < -MAX_COORD_VEL ? -MAX_COORD_VEL : (v > MAX_COORD_VEL ? MAX_COORD_VEL : v);
+  }
+  for (int i = 0; i < m->n_arm; i++) { e->qd[i] = dv[i]; e->q[i] += DT * e->qd[i]; }
   for (int k = 0; k < m->n_free; k++) {
     int d = dof_free(e, k);
     for (int i = 0; i < 3; i++) {
-      e->fvel[k][i] = vstar[d + i] + dv[d + i];
-      e->fom[k][i] = vstar[d + 3 + i] + dv[d + 3 + i];
+      e->fvel[k][i] = dv[d + i];
+      e->fom[k][i] = dv[d + 3 + i];
       e->fpos[k][i] += DT * e->fvel[k][i];
     }
     real w = v3norm(e->fom[k]);
@@ -836,7 +845,7 @@ void rpo_substep(rpo_env* e) {
   }
   for (int k = 0; k < m->n_joint1; k++) {
     int d = dof_j1(e, k);
-    e->jqd[k] = vstar[d] + dv[d];
+    e->jqd[k] = dv[d];
     e->jq[k] += DT * e->jqd[k];
   }
   (void)nv;

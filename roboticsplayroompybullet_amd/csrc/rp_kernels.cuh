@@ -43,6 +43,7 @@
 #define K_GRAVITY (-9.8f)
 #define K_NSUB 12
 #define K_NSETTLE 100
+#define K_MAXVEL 100.0f       /* btMultiBody::m_maxCoordinateVelocity: clamp of every generalized velocity after the solve */
 #ifdef K_NITER_OVERRIDE   /* timing ablations only */
 #define K_NITER K_NITER_OVERRIDE
 #else
@@ -1119,7 +1120,7 @@ __device__ void substep(const DevModel* m, EnvLds& L, int lane) {
   __syncthreads();
   /* apply and integrate (semi-implicit Euler) */
   const int dd = lane_dof(m, lane);
-  float vnew = (dd >= 0 ? L.vstar[dd] : 0.f) + dv;
+  float vnew = clampf((dd >= 0 ? L.vstar[dd] : 0.f) + dv, -K_MAXVEL, K_MAXVEL);      /* btMultiBody::m_maxCoordinateVelocity */
   if (dd >= 0 && dd < n) {
     L.st[ST_QD + dd] = vnew;
     L.st[ST_Q + dd] += K_DT * vnew;
@@ -2444,7 +2445,7 @@ __device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, floa
 #undef WAVE_MAX
   /* integrate: lane l holds velocity component lane_dof(l) of this half's env */
   float* st = L.st[half];
-  float vnew = vstar + dv;
+  float vnew = clampf(vstar + dv, -K_MAXVEL, K_MAXVEL);       /* btMultiBody::applyDeltaVeeMultiDof's clamp (never active in ordinary motion) */
   __syncthreads();
   CLK_MARK2(2)
   if (dd >= 0) {

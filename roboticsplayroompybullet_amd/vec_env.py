@@ -49,7 +49,7 @@ class VecPlayEnv:
         self.buf['status'] = torch.zeros(N, dtype=torch.int32, device=dev)
         self.out = _lib.RpOut(**{k: self.buf[k].data_ptr() for k, _ in _lib.RpOut._fields_})
         at = _lib.ACTION_TYPES.get(env_id, 'absolute_rpy')                                          # environments.py:88-113
-        hi = {'absolute_rpy': [6] * 6 + [1], 'absolute_joints': [6] * 6 + [1]}.get(at, [1] * self.dims['action'])
+        hi = {'absolute_rpy': [6] * 6 + [1], 'absolute_joints': [6] * (self.dims['action'] - 1) + [1]}.get(at, [1] * self.dims['action'])
         self.action_type = at
         self.action_high = torch.tensor(hi, dtype=torch.float32, device=dev)
         self._max_episode_steps = None if env_id.startswith('UR5Play') else 250

@@ -1,0 +1,31 @@
+"""Stress rollouts on the GPU box: distribution A (actions uniform over the whole action space) for every model,
+counting per-env status flags / non-finite records and the largest speeds seen."""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from roboticsplayroompybullet_amd import VecPlayEnv
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+for gid in ['UR5PlayAbsRPY1Obj-v0', 'pandaPlayAbsRPY1Obj-v0', 'pandaPick-v0', 'pandaPush-v0', 'UR5Reach-v0', 'pandaReach2D-v0',
+            'UR5PlayRelJoints1Obj-v0', 'pandaPlayAbsJoints1Obj-v0', 'UR5Play1Obj-v0']:
+    n = 4096
+    env = VecPlayEnv(gid, n, seed=3)
+    env.reset()
+    hi = env.action_high
+    g = torch.Generator(device='cuda').manual_seed(1)
+    bad = torch.zeros(n, dtype=torch.int64, device='cuda')
+    vmax = 0.0
+    t0 = time.perf_counter()
+    for t in range(steps):
+        a = (2 * torch.rand((n, hi.numel()), generator=g, device='cuda') - 1) * hi
+        obs, r, d, info = env.step(a)
+        bad += info['status']
+        if t % 50 == 49:
+            s = env.get_state()
+            vmax = max(vmax, float(s[:, 12:24].abs().max()), float(s[:, 31:37].abs().max()))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    s = env.get_state()
+    print('%-26s %d steps: envs ever flagged %d, non-finite records %d, max |qd| / |block v| seen %.1f, block z min %.3f, %.2f M env-steps/s'
+          % (gid, steps, int((bad > 0).sum()), int((~torch.isfinite(s).all(dim=1)).sum()), vmax, float(s[:, 26].min()), n * steps / dt / 1e6))
+    env.close()
