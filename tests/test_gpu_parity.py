@@ -565,3 +565,38 @@ def test_config_cem_mpc_broadcast_rollouts():
     # the quaternion sign memory of the fresh oracle env differs from the record's)
     idx = [0, 1, 2, 7, 8, 9, 10]
     np.testing.assert_allclose(first.cpu().numpy()[idx], oo['obs_quat'][idx], atol=1e-3, rtol=0)
+
+
+@pytest.mark.parametrize('kind', ['U', 'P', 'V'])
+def test_substep_intermediates_vs_fp32_oracle(kind):
+    """One substep taken apart (rp_debug_substep): the contact list (collider pair, point, normal, distance, in solver order),
+    the arm's inverse mass matrix and the unconstrained velocities v* = v + dt * forward dynamics, device vs the fp32 oracle
+    at the same state - a state reached by pressing the gripper onto the block, so arm, block and table contacts coexist."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    from gpu_debug import record_from_oracle
+    from oracle import OracleEnv
+    from roboticsplayroompybullet_amd import VecPlayEnv
+    o = OracleEnv(kind, seed=7, env_index=0, f32=True)
+    obs = o.reset()
+    blk = obs['achieved_goal'][:3]
+    for t in range(14):
+        o.step(np.array([blk[0], blk[1], blk[2] + (0.02 if kind != 'P' else 0.0), 0, 0, 0, -1.0 if t < 8 else 1.0]))
+    rec = record_from_oracle(o)
+    env = VecPlayEnv(IDS[kind], 2, seed=7)
+    env.set_state(torch.tensor(np.tile(rec, (2, 1))))
+    dbg = env.debug_substep(0).numpy()
+    oc = o.contacts()
+    ncon = int(dbg[0])
+    assert ncon == len(oc) and ncon >= 4
+    gc = dbg[16:16 + 9 * ncon].reshape(ncon, 9)
+    np.testing.assert_array_equal(gc[:, :2], oc[:, :2])                           # same collider pairs in the same order
+    np.testing.assert_allclose(gc[:, 2:8], oc[:, 2:8], atol=2e-5, rtol=0)         # points and normals
+    np.testing.assert_allclose(gc[:, 8], oc[:, 8], atol=2e-5, rtol=0)             # distances
+    n = o.n_arm
+    Mg, Mo = dbg[320:320 + 144].reshape(12, 12)[:n, :n], o.mass_matrix_inv()
+    assert np.abs(Mg - Mo).max() <= 2e-4 * np.abs(Mo).max()
+    s = o.get_state()
+    vstar = s[n:2 * n] + o.forward_dynamics() / 300.0
+    np.testing.assert_allclose(dbg[480:480 + n], vstar, atol=2e-4 * max(1.0, np.abs(vstar).max()), rtol=0)
+    print('%s: %d contacts, |Minv| max %.3g, |v*| max %.3g' % (kind, ncon, np.abs(Mo).max(), np.abs(vstar).max()))
