@@ -946,7 +946,7 @@ static void ik_solve(const rpo_env* e, const real* pos, const real* quat, const 
 }
 
 void rpo_ik(const rpo_env* e, const double* pos, const double* quat, const double* q_seed, int max_iter, double* q_out) {
-  real p[3], qt[4], qs[RP_MAX_ARM], q[RP_MAX_ARM];
+  real p[3], qt[4], qs[RP_MAX_ARM] = {0}, q[RP_MAX_ARM];
   for (int i = 0; i < 3; i++) p[i] = (real)pos[i];
   for (int i = 0; i < 4; i++) qt[i] = (real)quat[i];
   for (int i = 0; i < e->m.n_arm; i++) qs[i] = (real)q_seed[i];
