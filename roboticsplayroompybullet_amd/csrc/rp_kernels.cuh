@@ -27,6 +27,7 @@
 #define MAXC 21              /* contact points kept per env per substep (shared cap with the oracle): 63 contact rows */
 #define MAXACT 64            /* AABB-overlapping pairs examined per substep (shared cap with the oracle) */
 #define MAXROWC (3 * MAXC)
+#define RP_MAX_GROUPS 16      /* env groups (streams) rp_step can cut the envs into */
 #define SORT_KEYS 64          /* load classes for pairing envs in k_solve2: 8 * min(spanning, 7) + clamp(side-by-side slots - 6, 0, 7) */
 #define SORT_REPS 8           /* histogram replicas (env & 7): one hot word would serialise ~4096 atomics at ~90 per us */
 #define SORT_BINS (SORT_KEYS * SORT_REPS)
@@ -1609,10 +1610,12 @@ __global__ void __launch_bounds__(64, RP_WAVES_PER_EU) k_step(const DevModel* __
   store_state(L, state, env, lane);
 }
 
-__global__ void __launch_bounds__(64) k_calc_state(const DevModel* __restrict__ m, float* __restrict__ state, OutPtrs out, int env0, int N) {
+__global__ void __launch_bounds__(64) k_calc_state(const DevModel* __restrict__ m, float* __restrict__ state, OutPtrs out, int env0, int N,
+                                                   const int* __restrict__ member) {
   __shared__ EnvLds L;
   int env = env0 + blockIdx.x, lane = threadIdx.x;
   if (env >= N) return;
+  if (member) env = member[env];          /* place in the group -> env (groups are cut by load, see k_member) */
   load_state(L, state, env, lane);
   calc_state(m, L, lane);
   write_outputs(m, L, lane, env, out);
@@ -1875,11 +1878,12 @@ __global__ void k_copy_state(float* __restrict__ dst, const float* __restrict__ 
  *   k_calc_state (wave per env) calc_state + reward + outputs */
 /* perform_action (environments.py:915-1073), 16 lanes (one DPP row) per env, four envs per wave: cooperative IK */
 __global__ void __launch_bounds__(64) k_action(const DevModel* __restrict__ m, float* __restrict__ state, const float* __restrict__ action,
-                                              float* __restrict__ target_poses, int env0, int N) {
+                                              float* __restrict__ target_poses, int env0, int N, const int* __restrict__ member) {
   const int l16 = threadIdx.x & 15;
-  const int env_raw = env0 + blockIdx.x * 4 + (threadIdx.x >> 4);      /* this launch covers envs [env0, N) */
+  const int env_raw = env0 + blockIdx.x * 4 + (threadIdx.x >> 4);      /* this launch covers places [env0, N) of its group */
   const bool live = env_raw < N;
-  const int env = live ? env_raw : env0;
+  const int place = live ? env_raw : env0;
+  const int env = member ? member[place] : place;
   float* st = state + (size_t)env * RP_REC_FLOATS;
   float a8[8];
   load_action(m, action, env, a8);
@@ -1984,10 +1988,12 @@ __device__ __forceinline__ void copy_out(float* __restrict__ dst, const float* s
 static_assert(W3_A % 4 == 0 && W3_ROWS % 4 == 0 && W3_ROFF % 4 == 0 && AOUT_FLOATS % 4 == 0, "16-byte copies");
 
 __device__ __forceinline__ void prep2_body(const DevModel* __restrict__ m, const float* __restrict__ state, float* __restrict__ ws, int env0, int N,
-                                                             const int* __restrict__ sort_cnt, int* __restrict__ sort_cnt_next, const int* __restrict__ sort_slot, int* __restrict__ pair_env) {
+                                                             const int* __restrict__ sort_cnt, int* __restrict__ sort_cnt_next, const int* __restrict__ sort_slot, int* __restrict__ pair_env,
+                                                  const int* __restrict__ member) {
   __shared__ EnvLds L;
   int env = env0 + blockIdx.x, lane = threadIdx.x;
   if (env >= N) return;
+  if (member) env = member[env];     /* this block's place in its group -> env (groups are cut by load, see k_member) */
   if (blockIdx.x == 0)               /* the histogram that the k_solve2 after this launch fills (for the substep after it) starts at zero */
     for (int i = lane; i < SORT_BINS; i += 64) sort_cnt_next[i] = 0;
   /* pairing table for the k_solve2 after this launch: this env's place among the envs of its group sorted by load class,
@@ -2101,9 +2107,10 @@ __device__ __forceinline__ void prep2_body(const DevModel* __restrict__ m, const
 /* two entry points on the same body: rp_step's substeps, and the settle substeps of rp_reset under their own name so that
  * profiles keep the two apart */
 #define PREP2_ARGS const DevModel* __restrict__ m, const float* __restrict__ state, float* __restrict__ ws, int env0, int N, \
-                   const int* __restrict__ sort_cnt, int* __restrict__ sort_cnt_next, const int* __restrict__ sort_slot, int* __restrict__ pair_env
-__global__ void __launch_bounds__(64, RP_PREP_WAVES) k_prep2(PREP2_ARGS) { prep2_body(m, state, ws, env0, N, sort_cnt, sort_cnt_next, sort_slot, pair_env); }
-__global__ void __launch_bounds__(64, RP_PREP_WAVES) k_settle_prep(PREP2_ARGS) { prep2_body(m, state, ws, env0, N, sort_cnt, sort_cnt_next, sort_slot, pair_env); }
+                   const int* __restrict__ sort_cnt, int* __restrict__ sort_cnt_next, const int* __restrict__ sort_slot, int* __restrict__ pair_env, \
+                   const int* __restrict__ member
+__global__ void __launch_bounds__(64, RP_PREP_WAVES) k_prep2(PREP2_ARGS) { prep2_body(m, state, ws, env0, N, sort_cnt, sort_cnt_next, sort_slot, pair_env, member); }
+__global__ void __launch_bounds__(64, RP_PREP_WAVES) k_settle_prep(PREP2_ARGS) { prep2_body(m, state, ws, env0, N, sort_cnt, sort_cnt_next, sort_slot, pair_env, member); }
 
 
 struct __align__(16) Solve2Lds {
@@ -2510,6 +2517,61 @@ __global__ void k_sort_init(int* __restrict__ cnt, int* __restrict__ slot, int e
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < SORT_BINS) cnt[i] = i < SORT_REPS ? (ng + i) / SORT_REPS : 0;              /* envs with (e & 7) == 7 - i */
   if (i < ng) slot[env0 + i] = ((SORT_REPS - 1 - (i & (SORT_REPS - 1))) << 16) | (i >> 3);      /* bins 7..0 <-> i & 7 = 0..7: keeps index order */
+}
+
+/* Env groups by load.  rp_step cuts the envs into G groups that run their kernel chains on separate streams; a chain lasts as
+ * long as its heaviest env keeps k_solve2 busy, so the groups are cut by load: before a step, all envs are ranked by the load
+ * class the last k_solve2 gave them (the per-group counting sorts, merged: heavier bins first, inside a bin group by group, then
+ * the rank inside the group's bin), place p of the ranking -> member[p], and group g owns places [N g / G, N (g + 1) / G): the
+ * heaviest envs share group 0, whose chain is the critical path, while the lighter groups finish early and leave the machine to
+ * it.  Inside a group the ranking order is kept for the first pairing (k_sort_init's layout).  One block; results never depend
+ * on membership or pairing. */
+struct GroupBounds { int b[RP_MAX_GROUPS + 1]; };     /* group g owns places [b[g], b[g + 1]) */
+__global__ void __launch_bounds__(1024) k_member(const int* __restrict__ member_old, int* __restrict__ member_new, int* __restrict__ cnt,
+                                                 int* __restrict__ sort_slot, int N, int G_old, GroupBounds bo, int G_new, GroupBounds bn) {
+  __shared__ int tot[SORT_BINS], above[SORT_BINS], gpre[RP_MAX_GROUPS * SORT_BINS];
+  const int t = threadIdx.x;
+  for (int b = t; b < SORT_BINS; b += 1024) {
+    int sum = 0;
+    for (int g = 0; g < G_old; g++) { gpre[g * SORT_BINS + b] = sum; sum += cnt[g * SORT_BINS + b]; }
+    tot[b] = sum;
+  }
+  __syncthreads();
+  if (t < 64) {                          /* envs in heavier bins: suffix sums over the 512 bins, 8 bins per lane of one wave */
+    int loc[8], sum = 0;
+#pragma unroll
+    for (int k = 7; k >= 0; k--) { loc[k] = sum; sum += tot[8 * t + k]; }
+    int suf = sum;                        /* inclusive suffix over lanes: sum of lanes >= t */
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { int o = __shfl_down(suf, d); if (t + d < 64) suf += o; }
+#pragma unroll
+    for (int k = 0; k < 8; k++) above[8 * t + k] = loc[k] + suf - sum;
+  }
+  __syncthreads();
+  for (int p = t; p < N; p += 1024) {
+    const int env = member_old[p];
+    int g = 0;
+    while (g + 1 < G_old && p >= bo.b[g + 1]) g++;
+    const int v = sort_slot[env], b = v >> 16;
+    member_new[above[b] + gpre[g * SORT_BINS + b] + (v & 0xFFFF)] = env;
+  }
+  __threadfence_block();
+  __syncthreads();
+  for (int i = t; i < G_new * SORT_BINS; i += 1024) {
+    const int g = i / SORT_BINS, b = i % SORT_BINS;
+    const int ng = bn.b[g + 1] - bn.b[g];
+    cnt[i] = b < SORT_REPS ? (ng + b) / SORT_REPS : 0;
+  }
+  for (int p = t; p < N; p += 1024) {
+    int g = 0;
+    while (g + 1 < G_new && p >= bn.b[g + 1]) g++;
+    const int i = p - bn.b[g];
+    sort_slot[member_new[p]] = ((SORT_REPS - 1 - (i & (SORT_REPS - 1))) << 16) | (i >> 3);
+  }
+}
+__global__ void k_member_identity(int* __restrict__ member, int N) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) member[i] = i;
 }
 
 /* debug: one substep for every env, dumping intermediates of env `dbg_env` (tests only) */

@@ -9,7 +9,6 @@
 #include "rp_device_model.h"
 #include "rp_kernels.cuh"
 
-#define RP_MAX_GROUPS 16
 
 struct rp_sim {
   rp_config cfg;
@@ -21,6 +20,10 @@ struct rp_sim {
   int* sort_cnt;           /* [2][RP_MAX_GROUPS][SORT_BINS] load-class histograms for pairing envs in k_solve2 (double-buffered) */
   int* sort_slot;          /* [N] per env: (bin << 16) | rank inside the bin, from the latest k_solve2 */
   int* pair_env;           /* [N] per group range: env ids sorted by load class, heaviest first (k_solve2 pairs neighbours) */
+  GroupBounds gb;          /* place ranges of the groups the tables were built for */
+  int gsplit[RP_MAX_GROUPS]; /* RP_GROUP_SPLIT: relative sizes of the groups, heaviest first (0 = equal) */
+  int* member[2];          /* [N] place -> env, all envs ranked by load class (k_member); group g owns places [N g / G, N (g + 1) / G) */
+  int member_cur;
   int debug_flags;         /* rp_set_debug_flags: bit 0 = k_solve2 never solves contacts side by side (one folded slot per contact) */
   int sort_G, sort_par;    /* group count the tables were built for (0 = none yet); buffer that the next k_solve2 reads */
   hipEvent_t ev0, ev1;
@@ -110,7 +113,9 @@ int rp_create(const rp_config* cfg, rp_handle* out) {
       hipMalloc((void**)&h->dbg, 4096 * sizeof(float)) != hipSuccess ||
       hipMalloc((void**)&h->sort_cnt, (size_t)2 * RP_MAX_GROUPS * SORT_BINS * sizeof(int)) != hipSuccess ||
       hipMalloc((void**)&h->sort_slot, (size_t)cfg->num_envs * sizeof(int)) != hipSuccess ||
-      hipMalloc((void**)&h->pair_env, (size_t)cfg->num_envs * sizeof(int)) != hipSuccess) {
+      hipMalloc((void**)&h->pair_env, (size_t)cfg->num_envs * sizeof(int)) != hipSuccess ||
+      hipMalloc((void**)&h->member[0], (size_t)cfg->num_envs * sizeof(int)) != hipSuccess ||
+      hipMalloc((void**)&h->member[1], (size_t)cfg->num_envs * sizeof(int)) != hipSuccess) {
     snprintf(g_err, 256, "rp_create: hipMalloc failed"); free(h); return RP_ERR_HIP;
   }
   if (hipMemcpy(h->dev_model, &h->host_model, sizeof(DevModel), hipMemcpyHostToDevice) != hipSuccess) {
@@ -123,6 +128,11 @@ int rp_create(const rp_config* cfg, rp_handle* out) {
     if (h->groups < 1) h->groups = 1;
     if (h->groups > RP_MAX_GROUPS) h->groups = RP_MAX_GROUPS;
     hipEventCreateWithFlags(&h->gfork, hipEventDisableTiming);
+    /* RP_GROUP_SPLIT="25,35,40": relative group sizes, heaviest group first (default: equal).  Stream priorities for the heavy
+     * group were tried and lose (2.69 vs 2.61 ms per step). */
+    const char* sp = getenv("RP_GROUP_SPLIT");
+    for (int i = 0; i < RP_MAX_GROUPS; i++) h->gsplit[i] = 0;
+    if (sp) { int i = 0; while (*sp && i < RP_MAX_GROUPS) { h->gsplit[i++] = atoi(sp); while (*sp && *sp != ',') sp++; if (*sp == ',') sp++; } }
     for (int i = 0; i < RP_MAX_GROUPS; i++) { hipStreamCreateWithFlags(&h->gstream[i], hipStreamNonBlocking); hipEventCreateWithFlags(&h->gjoin[i], hipEventDisableTiming); }
   }
   int N = cfg->num_envs;
@@ -136,7 +146,7 @@ int rp_create(const rp_config* cfg, rp_handle* out) {
 int rp_destroy(rp_handle h) {
   if (!h) return RP_ERR_ARG;
   hipSetDevice(h->cfg.device);
-  hipFree(h->dev_model); hipFree(h->state); hipFree(h->ws); hipFree(h->dbg); hipFree(h->sort_cnt); hipFree(h->sort_slot); hipFree(h->pair_env);
+  hipFree(h->dev_model); hipFree(h->state); hipFree(h->ws); hipFree(h->dbg); hipFree(h->sort_cnt); hipFree(h->sort_slot); hipFree(h->pair_env); hipFree(h->member[0]); hipFree(h->member[1]);
   if (h->rs_state) {
     hipFree(h->rs_state); hipFree(h->rs_idx); hipFree(h->rs_meta); hipFree(h->rs_count); hipFree(h->rs_sort_cnt); hipFree(h->rs_sort_slot);
     hipFree(h->rs_pair); hipHostFree(h->rs_count_host);
@@ -192,7 +202,7 @@ static int reset_split(rp_handle h, const uint8_t* mask, const rp_out* out, hipS
     hipLaunchKernelGGL(k_sort_init, dim3((max(M, SORT_BINS) + 255) / 256), dim3(256), 0, s, cnt[0], h->rs_sort_slot, 0, M);
     int par = 0;
     for (int i = 0; i < K_NSETTLE; i++) {
-      hipLaunchKernelGGL(k_settle_prep, dim3(M), dim3(64), 0, s, h->dev_model, h->rs_state, h->ws, 0, M, cnt[par], cnt[par ^ 1], h->rs_sort_slot, h->rs_pair);
+      hipLaunchKernelGGL(k_settle_prep, dim3(M), dim3(64), 0, s, h->dev_model, h->rs_state, h->ws, 0, M, cnt[par], cnt[par ^ 1], h->rs_sort_slot, h->rs_pair, (const int*)nullptr);
       hipLaunchKernelGGL(k_settle_solve, dim3((M + 1) / 2), dim3(64), 0, s, h->dev_model, h->rs_state, h->ws, 0, M, h->rs_pair, cnt[par ^ 1], h->rs_sort_slot, h->debug_flags);
       par ^= 1;
     }
@@ -257,27 +267,50 @@ int rp_step(rp_handle h, const float* action, const rp_out* out, void* stream) {
     if (G > (N + 63) / 64) G = (N + 63) / 64;
     int e = 2;
 #define TIMED(launch) do { if (ev) hipEventRecord(ev[e++], gs); launch; if (ev) hipEventRecord(ev[e++], gs); } while (0)
+    /* groups by load: rank all envs by the load class of the latest k_solve2 and cut the ranking into the G groups */
+    GroupBounds gb;
+    {
+      long long tot = 0, acc = 0;
+      for (int g = 0; g < G; g++) tot += h->gsplit[g] > 0 ? h->gsplit[g] : 0;
+      bool custom = tot > 0;
+      for (int g = 0; g < G && custom; g++) if (h->gsplit[g] <= 0) custom = false;
+      gb.b[0] = 0;
+      for (int g = 0; g < G; g++) {
+        acc += custom ? h->gsplit[g] : 1;
+        gb.b[g + 1] = (int)((long long)N * acc / (custom ? tot : G));
+      }
+      for (int g = G + 1; g <= RP_MAX_GROUPS; g++) gb.b[g] = N;
+    }
+    const int* member = h->member[h->member_cur];
+    if (h->sort_G == 0) {
+      hipLaunchKernelGGL(k_member_identity, dim3((N + 255) / 256), dim3(256), 0, s, h->member[h->member_cur], N);
+    } else {
+      hipLaunchKernelGGL(k_member, dim3(1), dim3(1024), 0, s, member, h->member[h->member_cur ^ 1], h->sort_cnt + (size_t)h->sort_par * RP_MAX_GROUPS * SORT_BINS,
+                         h->sort_slot, N, h->sort_G, h->gb, G, gb);
+      h->member_cur ^= 1;
+      member = h->member[h->member_cur];
+    }
     if (G > 1) hipEventRecord(h->gfork, s);
     for (int g = 0; g < G; g++) {
       hipStream_t gs = g == 0 ? s : h->gstream[g];      /* group 0 stays on the caller's stream: G hardware queues in use */
-      int e0 = (int)((long long)N * g / G), e1 = (int)((long long)N * (g + 1) / G), ng = e1 - e0;
-      if (g > 0) hipStreamWaitEvent(gs, h->gfork, 0);
+      int e0 = gb.b[g], e1 = gb.b[g + 1], ng = e1 - e0;
+      if (gs != s) hipStreamWaitEvent(gs, h->gfork, 0);
       if (ev) hipEventRecord(ev[0], gs);
       /* env pairing of this group: k_solve2 ranks its envs by load class (histogram, double-buffered), the next k_prep2
        * turns the ranks into the table the next k_solve2 reads */
       int* gcnt[2] = {h->sort_cnt + (size_t)g * SORT_BINS, h->sort_cnt + (size_t)(RP_MAX_GROUPS + g) * SORT_BINS};
       int par = h->sort_par;
-      if (h->sort_G != G) hipLaunchKernelGGL(k_sort_init, dim3((max(ng, SORT_BINS) + 255) / 256), dim3(256), 0, gs, gcnt[par], h->sort_slot, e0, ng);
-      TIMED(hipLaunchKernelGGL(k_action, dim3((ng + 3) / 4), dim3(64), 0, gs, h->dev_model, h->state, action, op.target_poses, e0, e1));
+      if (h->sort_G == 0) hipLaunchKernelGGL(k_sort_init, dim3((max(ng, SORT_BINS) + 255) / 256), dim3(256), 0, gs, gcnt[par], h->sort_slot, e0, ng);
+      TIMED(hipLaunchKernelGGL(k_action, dim3((ng + 3) / 4), dim3(64), 0, gs, h->dev_model, h->state, action, op.target_poses, e0, e1, member));
       for (int sub = 0; sub < K_NSUB; sub++) {
-        TIMED(hipLaunchKernelGGL(k_prep2, dim3(ng), dim3(64), 0, gs, h->dev_model, h->state, h->ws, e0, e1, gcnt[par], gcnt[par ^ 1], h->sort_slot, h->pair_env));
+        TIMED(hipLaunchKernelGGL(k_prep2, dim3(ng), dim3(64), 0, gs, h->dev_model, h->state, h->ws, e0, e1, gcnt[par], gcnt[par ^ 1], h->sort_slot, h->pair_env, member));
         TIMED(hipLaunchKernelGGL(k_solve2, dim3((ng + 1) / 2), dim3(64), 0, gs, h->dev_model, h->state, h->ws, e0, e1, h->pair_env, gcnt[par ^ 1], h->sort_slot, h->debug_flags));
         par ^= 1;
       }
-      if (g == G - 1) { h->sort_par = par; h->sort_G = G; }
-      TIMED(hipLaunchKernelGGL(k_calc_state, dim3(ng), dim3(64), 0, gs, h->dev_model, h->state, op, e0, e1));
+      if (g == G - 1) { h->sort_par = par; h->sort_G = G; h->gb = gb; }
+      TIMED(hipLaunchKernelGGL(k_calc_state, dim3(ng), dim3(64), 0, gs, h->dev_model, h->state, op, e0, e1, member));
       if (ev) hipEventRecord(ev[1], gs);
-      if (g > 0) hipEventRecord(h->gjoin[g], gs);
+      if (gs != s) hipEventRecord(h->gjoin[g], gs);
     }
     for (int g = 1; g < G; g++) hipStreamWaitEvent(s, h->gjoin[g], 0);
     if (ev) {
@@ -295,7 +328,7 @@ int rp_step(rp_handle h, const float* action, const rp_out* out, void* stream) {
 int rp_calc_state(rp_handle h, const rp_out* out, void* stream) {
   if (!h) return RP_ERR_ARG;
   int N = h->cfg.num_envs;
-  hipLaunchKernelGGL(k_calc_state, dim3(N), dim3(64), 0, (hipStream_t)stream, h->dev_model, h->state, to_ptrs(out), 0, N);
+  hipLaunchKernelGGL(k_calc_state, dim3(N), dim3(64), 0, (hipStream_t)stream, h->dev_model, h->state, to_ptrs(out), 0, N, (const int*)nullptr);
   HIPCHK(h, hipGetLastError());
   return RP_OK;
 }
