@@ -10,14 +10,14 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-KINDS = {'U': 0, 'R': 1, 'P': 2, 'Q': 3, 'V': 4, 'UR5PlayAbsRPY1Obj-v0': 0, 'UR5Reach-v0': 1, 'pandaPick-v0': 2, 'pandaReach-v0': 3,
+KINDS = {'U': 0, 'R': 1, 'P': 2, 'Q': 3, 'V': 4, 'W': 5, 'pandaPlay-v0': 5, 'UR5PlayAbsRPY1Obj-v0': 0, 'UR5Reach-v0': 1, 'pandaPick-v0': 2, 'pandaReach-v0': 3,
          'pandaPlayAbsRPY1Obj-v0': 4}
 
 
 class RpoObs(C.Structure):
-    _fields_ = [('obs_quat', C.c_double * 19), ('achieved_goal', C.c_double * 11), ('desired_goal', C.c_double * 11),
-                ('controllable_achieved_goal', C.c_double * 4), ('full_positional_state', C.c_double * 19),
-                ('joints', C.c_double * 8), ('velocity', C.c_double * 6), ('observation', C.c_double * 18),
+    _fields_ = [('obs_quat', C.c_double * 26), ('achieved_goal', C.c_double * 18), ('desired_goal', C.c_double * 18),
+                ('controllable_achieved_goal', C.c_double * 4), ('full_positional_state', C.c_double * 26),
+                ('joints', C.c_double * 8), ('velocity', C.c_double * 6), ('observation', C.c_double * 25),
                 ('gripper_proprioception', C.c_int), ('n_obs', C.c_int), ('n_ag', C.c_int), ('n_fps', C.c_int),
                 ('n_observation', C.c_int)]
 
@@ -40,7 +40,8 @@ class RpoReadings(C.Structure):
     _fields_ = [('ee_pos', C.c_double * 3), ('ee_orn', C.c_double * 4), ('ee_lin', C.c_double * 3), ('ee_ang', C.c_double * 3),
                 ('grip_q', C.c_double), ('joints', C.c_double * 8), ('proprio', C.c_int),
                 ('block_pos', C.c_double * 3), ('block_orn', C.c_double * 4), ('block_vel', C.c_double * 3),
-                ('drawer_y', C.c_double), ('door_q', C.c_double), ('button_q', C.c_double), ('dial_q', C.c_double)]
+                ('drawer_y', C.c_double), ('door_q', C.c_double), ('button_q', C.c_double), ('dial_q', C.c_double),
+                ('block2_pos', C.c_double * 3), ('block2_orn', C.c_double * 4), ('block2_vel', C.c_double * 3)]
 
 
 _LIBS = {}
@@ -131,6 +132,10 @@ PANDA_FAMILY = {'pandaPlayAbsRPY1Obj-v0': 'absolute_rpy', 'pandaPlayRelRPY1Obj-v
                 'pandaPlayRelJoints1Obj-v0': 'relative_joints'}
 
 
+# the two-object play ids (envList.py:28-41): Panda + complex_scene with two blocks (model W)
+TWO_OBJECT = {'pandaPlay-v0': 'absolute_quat', 'pandaPlayJoints-v0': 'relative_joints'}
+
+
 class OracleEnv:
     """One reference env (instance + playEnv) on the CPU oracle."""
 
@@ -143,6 +148,8 @@ class OracleEnv:
             kind, action_type = 'U', FAMILY[kind]
         if kind in PANDA_FAMILY:
             kind, action_type = 'V', PANDA_FAMILY[kind]
+        if kind in TWO_OBJECT:
+            kind, action_type = 'W', TWO_OBJECT[kind]
         self.kind = KINDS[kind]
         self.h = self.lib.rpo_create(self.kind, seed, env_index)
         self.action_type = action_type or 'absolute_rpy'
@@ -152,8 +159,8 @@ class OracleEnv:
             self.lib.rpo_set_ranges(self.h, *[_d(r)[1] for r in ranges])
         self.n_arm = self.lib.rpo_n_arm(self.h)
         self.nv = self.lib.rpo_nv(self.h)
-        self.n_goal = 11 if self.kind in (0, 4) else 3
-        self.n_target = 7 if self.kind in (2, 3, 4) else 6
+        self.n_goal = {0: 11, 4: 11, 5: 18}.get(self.kind, 3)
+        self.n_target = 7 if self.kind in (2, 3, 4, 5) else 6
 
     def __del__(self):
         if getattr(self, 'h', None):

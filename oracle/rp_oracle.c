@@ -69,8 +69,8 @@ struct rpo_env {
   real fpos[RP_MAX_FREE][3], fquat[RP_MAX_FREE][4], fvel[RP_MAX_FREE][3], fom[RP_MAX_FREE][3];
   real jq[RP_MAX_J1], jqd[RP_MAX_J1];
   int mmode[RP_MAX_ARM]; real mtarget[RP_MAX_ARM], mmaximp[RP_MAX_ARM];
-  real goal[11]; int n_goal;
-  real last_obs[19], last_ag[11]; int have_last;
+  real goal[18]; int n_goal;
+  real last_obs[26], last_ag[18]; int have_last;
   /* config flags (envList.py) */
   int play, use_orientation, return_velocity, num_objects;
   int action_type;                  /* RPO_ACT_*: perform_action's dispatch (environments.py:915-934) */
@@ -1242,7 +1242,11 @@ static void read_world(rpo_env* e, rpo_readings* rd) {
     for (int k = 0; k < 3; k++) { rd->block_pos[k] = e->fpos[0][k]; rd->block_vel[k] = e->fvel[0][k]; }
     for (int k = 0; k < 4; k++) rd->block_orn[k] = e->fquat[0][k];
   }
-  if (e->play) { rd->drawer_y = e->fpos[1][1]; rd->door_q = e->jq[0]; rd->button_q = e->jq[1]; rd->dial_q = e->jq[2]; }
+  if (e->num_objects > 1) {
+    for (int k = 0; k < 3; k++) { rd->block2_pos[k] = e->fpos[1][k]; rd->block2_vel[k] = e->fvel[1][k]; }
+    for (int k = 0; k < 4; k++) rd->block2_orn[k] = e->fquat[1][k];
+  }
+  if (e->play) { rd->drawer_y = e->fpos[m->drawer_free][1]; rd->door_q = e->jq[0]; rd->button_q = e->jq[1]; rd->dial_q = e->jq[2]; }
 }
 
 /* calc_state's assembly (environments.py:799-864) from the raw readings */
@@ -1254,7 +1258,7 @@ static void assemble_obs(rpo_env* e, const rpo_readings* rd, rpo_obs* o) {
   real grip = m->arm_type == RP_ARM_PANDA ? (real)rd->grip_q : (real)rd->grip_q * 23;
   for (int j = 0; j < 8; j++) o->joints[j] = rd->joints[j];
   o->gripper_proprioception = rd->proprio;
-  real st[19], ag[11], fps[19];
+  real st[26], ag[18], fps[26];
   int ns = 0, nag = 0, nf = 0;
   for (int k = 0; k < 3; k++) st[ns++] = pos[k];
   if (e->return_velocity) for (int k = 0; k < 3; k++) st[ns++] = lin[k];
@@ -1262,11 +1266,16 @@ static void assemble_obs(rpo_env* e, const rpo_readings* rd, rpo_obs* o) {
   st[ns++] = grip;
   if (e->num_objects > 0) {
     /* calc_environment_state: block pose (+vel), then drawer y, door, button, dial (environments.py:767-793) */
-    for (int k = 0; k < 3; k++) st[ns++] = (real)rd->block_pos[k];
-    if (e->use_orientation) for (int k = 0; k < 4; k++) st[ns++] = (real)rd->block_orn[k];
-    if (e->return_velocity) for (int k = 0; k < 3; k++) st[ns++] = (real)rd->block_vel[k];
-    for (int k = 0; k < 3; k++) ag[nag++] = (real)rd->block_pos[k];
-    if (e->use_orientation) for (int k = 0; k < 4; k++) ag[nag++] = (real)rd->block_orn[k];
+    for (int b = 0; b < e->num_objects; b++) {        /* every object: pos (+orn) (+vel); the goal space leaves the velocity out */
+      const double* bp = b == 0 ? rd->block_pos : rd->block2_pos;
+      const double* bo = b == 0 ? rd->block_orn : rd->block2_orn;
+      const double* bv = b == 0 ? rd->block_vel : rd->block2_vel;
+      for (int k = 0; k < 3; k++) st[ns++] = (real)bp[k];
+      if (e->use_orientation) for (int k = 0; k < 4; k++) st[ns++] = (real)bo[k];
+      if (e->return_velocity) for (int k = 0; k < 3; k++) st[ns++] = (real)bv[k];
+      for (int k = 0; k < 3; k++) ag[nag++] = (real)bp[k];
+      if (e->use_orientation) for (int k = 0; k < 4; k++) ag[nag++] = (real)bo[k];
+    }
     if (e->play) {
       real extra[4] = {(real)rd->drawer_y, (real)rd->door_q, (real)rd->button_q, dial_to_0_1_range((real)rd->dial_q)};
       for (int k = 0; k < 4; k++) { st[ns++] = extra[k]; ag[nag++] = extra[k]; }
@@ -1284,10 +1293,12 @@ static void assemble_obs(rpo_env* e, const rpo_readings* rd, rpo_obs* o) {
     if (e->have_last) {
       flip_quats(st, e->last_obs, 3);
       flip_quats(st, e->last_obs, 11);
+      if (e->num_objects == 2) flip_quats(st, e->last_obs, 19);     /* (19, 23) as written: one past the second quaternion's start */
       flip_quats(ag, e->last_ag, 3);
+      if (e->num_objects == 2) flip_quats(ag, e->last_ag, 10);
     }
-    memcpy(e->last_obs, st, sizeof(real) * 19);
-    memcpy(e->last_ag, ag, sizeof(real) * 11);
+    memcpy(e->last_obs, st, sizeof(real) * 26);
+    memcpy(e->last_ag, ag, sizeof(real) * 18);
     e->have_last = 1;
   }
   o->n_obs = ns; o->n_ag = nag; o->n_fps = nf;
@@ -1348,7 +1359,7 @@ static real compute_reward(const rpo_env* e, const real* ag, const real* dg) {  
 }
 
 double rpo_compute_reward(const rpo_env* e, const double* ag, const double* dg) {
-  real a[11], g[11];
+  real a[18], g[18];
   int n = e->play ? 11 : 3;
   for (int i = 0; i < n; i++) { a[i] = (real)ag[i]; g[i] = (real)dg[i]; }
   return compute_reward(e, a, g);
@@ -1363,7 +1374,7 @@ void rpo_step(rpo_env* e, const double* action, rpo_obs* out, double* reward, in
   perform_action(e, a, tp);
   rpo_run_simulation(e);
   calc_state(e, out);
-  real ag[11], dg[11];
+  real ag[18], dg[18];
   for (int i = 0; i < out->n_ag; i++) ag[i] = (real)(float)out->achieved_goal[i];     /* reward sees the float32 casts */
   for (int i = 0; i < e->n_goal; i++) dg[i] = (real)(float)out->desired_goal[i];
   real r = compute_reward(e, ag, dg);
@@ -1375,8 +1386,10 @@ void rpo_step(rpo_env* e, const double* action, rpo_obs* out, double* reward, in
 
 static void reset_goal_pos(rpo_env* e, const real* goal, ustream* us) {   /* environments.py:492-516 */
   if (!goal) {
-    for (int k = 0; k < 3; k++) e->goal[k] = e->goal_lo[k] + (e->goal_hi[k] - e->goal_lo[k]) * next_u(us);
-    e->n_goal = 3;
+    int ng = e->num_objects > 1 ? e->num_objects : 1;       /* num_goals = max(num_objects, 1) draws of 3 (environments.py:78, 495-498) */
+    for (int g = 0; g < ng; g++)
+      for (int k = 0; k < 3; k++) e->goal[3 * g + k] = e->goal_lo[k] + (e->goal_hi[k] - e->goal_lo[k]) * next_u(us);
+    e->n_goal = 3 * ng;
   } else {
     for (int k = 0; k < e->n_goal; k++) e->goal[k] = goal[k];
   }
@@ -1395,7 +1408,7 @@ static void reset_goal_pos(rpo_env* e, const real* goal, ustream* us) {   /* env
 
 void rpo_reset_goal(rpo_env* e, const double* goal, const double* u, int n_u) {
   ustream us = {e, u, n_u, 0};
-  real g[11];
+  real g[18];
   if (goal) for (int k = 0; k < e->n_goal; k++) g[k] = (real)goal[k];
   reset_goal_pos(e, goal ? g : 0, &us);
 }
@@ -1403,10 +1416,11 @@ void rpo_reset_goal(rpo_env* e, const double* goal, const double* u, int n_u) {
 static void reset_object_pos(rpo_env* e, ustream* us, int depth) {     /* environments.py:519-556, obs=None branch */
   const rp_model* m = &e->m;
   if (e->play) {
-    for (int k = 0; k < 3; k++) e->fpos[1][k] = (real)m->free_pos0[1][k];
-    real R0[9]; for (int k = 0; k < 9; k++) R0[k] = (real)m->free_rot0[1][k];
-    m3_to_quat(e->fquat[1], R0);
-    v3set(e->fvel[1], 0, 0, 0); v3set(e->fom[1], 0, 0, 0);
+    const int dr = m->drawer_free;
+    for (int k = 0; k < 3; k++) e->fpos[dr][k] = (real)m->free_pos0[dr][k];
+    real R0[9]; for (int k = 0; k < 9; k++) R0[k] = (real)m->free_rot0[dr][k];
+    m3_to_quat(e->fquat[dr], R0);
+    v3set(e->fvel[dr], 0, 0, 0); v3set(e->fom[dr], 0, 0, 0);
     for (int k = 0; k < m->n_joint1; k++) { e->jq[k] = 0; e->jqd[k] = 0; }
   }
   real height = (real)0.03;
@@ -1455,10 +1469,11 @@ void rpo_reset_samples(const rpo_env* e, const double* u, double* block_pos, dou
 static void reset_object_pos_obs(rpo_env* e, const real* o) {
   const rp_model* m = &e->m;
   if (e->play) {
-    for (int k = 0; k < 3; k++) e->fpos[1][k] = (real)m->free_pos0[1][k];
-    real R0[9]; for (int k = 0; k < 9; k++) R0[k] = (real)m->free_rot0[1][k];
-    m3_to_quat(e->fquat[1], R0);
-    v3set(e->fvel[1], 0, 0, 0); v3set(e->fom[1], 0, 0, 0);
+    const int dr = m->drawer_free;
+    for (int k = 0; k < 3; k++) e->fpos[dr][k] = (real)m->free_pos0[dr][k];
+    real R0[9]; for (int k = 0; k < 9; k++) R0[k] = (real)m->free_rot0[dr][k];
+    m3_to_quat(e->fquat[dr], R0);
+    v3set(e->fvel[dr], 0, 0, 0); v3set(e->fom[dr], 0, 0, 0);
     for (int k = 0; k < m->n_joint1; k++) { e->jq[k] = 0; e->jqd[k] = 0; }
   }
   int index = e->use_orientation ? 11 : 7, inc = e->use_orientation ? 10 : 6;
@@ -1491,7 +1506,7 @@ int rpo_reset_to(rpo_env* e, const double* o, int n_o, const double* u, int n_u,
     reset_arm_obs(e, ro);
     reset_goal_pos(e, 0, &us);
     calc_state(e, out);
-    real ag[11], dg[11];
+    real ag[18], dg[18];
     for (int i = 0; i < out->n_ag; i++) ag[i] = (real)(float)out->achieved_goal[i];
     for (int i = 0; i < e->n_goal; i++) dg[i] = (real)(float)out->desired_goal[i];
     r = compute_reward(e, ag, dg);
@@ -1508,7 +1523,7 @@ int rpo_reset(rpo_env* e, const double* u, int n_u, rpo_obs* out) {
     reset_arm(e, &us);
     reset_goal_pos(e, 0, &us);
     calc_state(e, out);
-    real ag[11], dg[11];
+    real ag[18], dg[18];
     for (int i = 0; i < out->n_ag; i++) ag[i] = (real)(float)out->achieved_goal[i];
     for (int i = 0; i < e->n_goal; i++) dg[i] = (real)(float)out->desired_goal[i];
     r = compute_reward(e, ag, dg);
@@ -1523,6 +1538,7 @@ rpo_env* rpo_create(int kind, unsigned long long seed, int env_index) {
   else if (kind == RP_KIND_R) rp_fill_model_R(&e->m);
   else if (kind == RP_KIND_Q) rp_fill_model_Q(&e->m);
   else if (kind == RP_KIND_V) rp_fill_model_V(&e->m);
+  else if (kind == RP_KIND_W) rp_fill_model_W(&e->m);
   else rp_fill_model_P(&e->m);
   const rp_model* m = &e->m;
   e->nv = m->n_arm + 6 * m->n_free + m->n_joint1;
@@ -1531,10 +1547,10 @@ rpo_env* rpo_create(int kind, unsigned long long seed, int env_index) {
   /* envList.py:8-10, 18-22, 73-99: the env's flags and ranges go with its scene (play ids: complex_scene; reach ids:
    * default_scene; pick / push: push_scene); other ids on the same model override the ranges (rpo_set_ranges) */
   if (m->scene == RP_SCENE_COMPLEX) {
-    e->play = 1; e->use_orientation = 1; e->return_velocity = 0; e->num_objects = 1;
+    e->play = 1; e->use_orientation = 1; e->return_velocity = 0; e->num_objects = m->n_free - 1;     /* blocks, then the drawer */
     real gl[3] = {-0.18, 0, 0.05}, gh[3] = {0.18, 0.3, 0.1}, eh[3] = {1, 1, 1};
     for (int k = 0; k < 3; k++) { e->goal_lo[k] = e->obj_lo[k] = gl[k]; e->goal_hi[k] = e->obj_hi[k] = gh[k]; e->env_hi[k] = eh[k]; }
-    e->n_goal = 11;
+    e->n_goal = 7 * e->num_objects + 4;
   } else if (m->scene == RP_SCENE_DEFAULT) {
     e->play = 0; e->use_orientation = 0; e->return_velocity = 1; e->num_objects = 0;
     real gl[3] = {-0.18, -0.18, -0.05}, gh[3] = {0.18, 0.18, 0.05}, eh[3] = {0.18, 0.18, 0.15};

@@ -18,8 +18,8 @@ typedef struct rpo_env rpo_env;
 
 /* observation bundle of one env, reference calc_state() (environments.py:799-864); sizes are maxima */
 typedef struct rpo_obs {
-  double obs_quat[19], achieved_goal[11], desired_goal[11], controllable_achieved_goal[4];
-  double full_positional_state[19], joints[8], velocity[6], observation[18];
+  double obs_quat[26], achieved_goal[18], desired_goal[18], controllable_achieved_goal[4];
+  double full_positional_state[26], joints[8], velocity[6], observation[25];
   int gripper_proprioception;
   int n_obs, n_ag, n_fps, n_observation;
 } rpo_obs;
@@ -29,9 +29,10 @@ typedef struct rpo_readings {
   double ee_pos[3], ee_orn[4], ee_lin[3], ee_ang[3], grip_q, joints[8];
   int proprio;
   double block_pos[3], block_orn[4], block_vel[3], drawer_y, door_q, button_q, dial_q;
+  double block2_pos[3], block2_orn[4], block2_vel[3];      /* second object of the two-object play ids */
 } rpo_readings;
 
-rpo_env* rpo_create(int kind /*0 U, 1 R, 2 P*/, unsigned long long seed, int env_index);
+rpo_env* rpo_create(int kind /*0 U, 1 R, 2 P, 3 Q, 4 V, 5 W (rp_model.h)*/, unsigned long long seed, int env_index);
 /* perform_action's dispatch (environments.py:915-934); default RPO_ACT_ABS_RPY.  Action length: rpo_action_dim. */
 enum { RPO_ACT_ABS_RPY = 0, RPO_ACT_REL_RPY = 1, RPO_ACT_ABS_QUAT = 2, RPO_ACT_REL_QUAT = 3, RPO_ACT_ABS_JOINTS = 4, RPO_ACT_REL_JOINTS = 5 };
 void rpo_set_action_type(rpo_env* e, int action_type);

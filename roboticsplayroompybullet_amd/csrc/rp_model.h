@@ -4,7 +4,7 @@
  *
  * Bodies of one env:   0 = static world (scene statics + the arm's fixed base link)
  *                      1 .. n_arm                 movable arm links (fixed URDF links merged in), dof i-1
- *                      n_arm+1 .. n_arm+n_free    free 6-DoF bodies  (U: block, drawer; P: block)
+ *                      n_arm+1 .. n_arm+n_free    free 6-DoF bodies  (U, V: block, drawer; W: block, block, drawer; P: block)
  *                      then n_joint1 single-DoF scene joints on a static base (U: door, button, dial)
  * Generalised velocity: [arm n_arm | free 6 each (lin xyz, ang xyz, world frame) | joint1 1 each].
  * Reference anchors: arm tables <- ur5e2.urdf / panda.urdf; scene <- scenes.py:46-426 as
@@ -17,7 +17,8 @@
 #define RP_KIND_P 2
 #define RP_KIND_Q 3   /* Panda + default_scene (pandaReach-v0, pandaReach2D-v0) */
 #define RP_KIND_V 4   /* Panda + complex_scene, one block (the pandaPlay*1Obj-v0 ids) */
-#define RP_N_KIND 5
+#define RP_KIND_W 5   /* Panda + complex_scene, two blocks (pandaPlay-v0, pandaPlayJoints-v0) */
+#define RP_N_KIND 6
 
 #define RP_ARM_UR5 0
 #define RP_ARM_PANDA 1
@@ -26,7 +27,7 @@
 #define RP_SCENE_PUSH 2
 
 #define RP_MAX_ARM 12
-#define RP_MAX_FREE 2
+#define RP_MAX_FREE 3
 #define RP_MAX_J1 3
 #define RP_MAX_COL 64
 #define RP_MAX_PAIR 1024
@@ -41,6 +42,7 @@
 typedef struct rp_model {
   int kind, n_arm, n_free, n_joint1, n_col, n_pair, n_site;
   int arm_type, scene;              /* RP_ARM_*, RP_SCENE_*: what the kind is made of */
+  int drawer_free;                  /* index of the drawer among the free bodies (the objects come first), -1 = none */
   /* arm (tree, parents precede children) */
   int arm_parent[RP_MAX_ARM];       /* movable parent (0-based) or -1 = base */
   int arm_jtype[RP_MAX_ARM];        /* 0 revolute, 1 prismatic */

@@ -41,6 +41,7 @@ with contextlib.redirect_stdout(io.StringIO()):
     from roboticsPlayroomPybullet.envs import pandaPush  # noqa: E402
     from roboticsPlayroomPybullet.envs import (pandaReach, pandaReach2D, pandaPlay1Obj, pandaPlayRel1Obj, pandaPlayRelJoints1Obj,  # noqa: E402
                                                pandaPlayAbsJoints1Obj, pandaPlayAbsRPY1Obj, pandaPlayRelRPY1Obj)
+    from roboticsPlayroomPybullet.envs import pandaPlay, pandaPlayRelJoints  # noqa: E402
     from roboticsPlayroomPybullet.envs import (UR5Play1Obj, UR5PlayRel1Obj, UR5PlayRelJoints1Obj, UR5PlayAbsJoints1Obj,  # noqa: E402
                                                UR5PlayRelRPY1Obj)
     import scenes  # noqa: E402  (the reference puts envs/ on sys.path itself)
@@ -528,7 +529,137 @@ def gen_panda_ids(seed=97, n_cases=5):
     dump('panda_ids.json', out)
 
 
+# the two-object play ids: Panda + complex_scene with two blocks
+TWO_OBJ_IDS = {'pandaPlay-v0': pandaPlay, 'pandaPlayJoints-v0': pandaPlayRelJoints}
+
+
+def gen_two_object_ids(seed=131, n_cases=5, n_seq=3, seq_len=5):
+    """pandaPlay-v0 / pandaPlayJoints-v0: the scene with two blocks (call log), declared spaces / attributes, step() cases
+    (IK call, clamps, motor commands, observation of both objects), calc_state sequences that exercise the quaternion sign
+    memory (incl. its (19, 23) index pair for the second object), and reset(): the draws and where they land."""
+    rng = np.random.default_rng(seed)
+    c0 = fb.FakeClient()
+    ret = scenes.complex_scene(c0, [0, 0, 0], c0.URDF_ENABLE_CACHED_GRAPHICS_SHAPES, np.array([-1, -1, -0.2]), np.array([1, 1, 1]), 2)
+    out = {'complex_scene_2obj': {'log': c0.log, 'ret': ret}}
+    for gid, cls in TWO_OBJ_IDS.items():
+        env, c, shadow = new_env(None, cls)
+        assert shadow is None
+        inst = env.instance
+        info = {'action_type': env.action_type, 'action_low': env.action_space.low, 'action_high': env.action_space.high,
+                'play': env.play, 'use_orientation': env.use_orientation, 'return_velocity': env.return_velocity,
+                'num_objects': env.num_objects, 'num_goals': env.num_goals, 'max_episode_steps': env._max_episode_steps,
+                'arm_type': env.arm_type, 'sparse_rew_thresh': env.sparse_rew_thresh,
+                'env_lower_bound': env.env_lower_bound, 'env_upper_bound': env.env_upper_bound,
+                'goal_lower_bound': env.goal_lower_bound, 'goal_upper_bound': env.goal_upper_bound,
+                'obj_lower_bound': env.obj_lower_bound, 'obj_upper_bound': env.obj_upper_bound,
+                'observation_space': {k: {'low': v.low, 'high': v.high} for k, v in env.observation_space.spaces.items()},
+                'base_pos': inst.init_arm_base_pos, 'base_orn': inst.init_arm_base_orn, 'ee_index': inst.endEffectorIndex,
+                'rest': inst.restJointPositions, 'num_dofs': inst.numDofs, 'objects': inst.objects, 'arm': inst.arm,
+                'drawer_defaults': inst.drawer['defaults']}
+        na = len(env.action_space.high)
+        cases = []
+        for k in range(n_cases):
+            env, c, shadow = new_env(None, cls)
+            env.instance.goal = rng.uniform(-0.3, 0.3, 18)
+            desc = fill_world(None, env, c, rng)
+            action = rng.uniform(-1.0, 1.0, na) * 0.9
+            if k % 3 == 2:
+                action = rng.uniform(-8, 8, na)
+            arm = env.instance.arm
+            cur = np.array([c.world['joint'][(arm, j)] for j in range(7)])
+            sol = rng.uniform(-3.5, 3.5, 9)
+            if k % 2 == 0:
+                sol[:7] = cur + rng.uniform(-0.3, 0.3, 7)
+            c.ik_queue = [sol.tolist()]
+            c.clear_log()
+            obs, r, done, inf = quiet(env.step, action)
+            cases.append({'goal': env.instance.goal, 'world': desc, 'action': action, 'ik_returns': [sol.tolist()],
+                          'main_log': [e for e in c.log if e['fn'] != 'rayTest'],
+                          'obs': obs_to_json(obs), 'reward': float(r), 'done': bool(done),
+                          'is_success': inf['is_success'], 'target_poses': inf['target_poses']})
+        seqs = []
+        for s_ in range(n_seq):
+            env, c, _ = new_env(None, cls)
+            env.instance.goal = rng.uniform(-0.3, 0.3, 18)
+            steps, prev = [], None
+            for t in range(seq_len):
+                desc = fill_world(None, env, c, rng)
+                if prev is not None and t % 2 == 1:     # same state as last step with some quaternions negated
+                    ee = env.instance.endEffectorIndex
+                    arm = env.instance.arm
+                    if rng.integers(0, 2):
+                        c.world['link'][(arm, ee)]['orn'] = [-v for v in prev['link'][str(ee)]['orn']]
+                    else:
+                        c.world['link'][(arm, ee)]['orn'] = list(prev['link'][str(ee)]['orn'])
+                    desc['link'][str(ee)]['orn'] = c.world['link'][(arm, ee)]['orn']
+                    for b, uid in enumerate(env.instance.objects):
+                        pb = prev['base']['block%d' % b]
+                        sgn = -1.0 if rng.integers(0, 2) else 1.0
+                        c.world['base'][uid]['orn'] = [sgn * v for v in pb['orn']]
+                        c.world['base'][uid]['pos'] = list(pb['pos'])
+                        desc['base']['block%d' % b]['orn'] = c.world['base'][uid]['orn']
+                        desc['base']['block%d' % b]['pos'] = c.world['base'][uid]['pos']
+                    if rng.integers(0, 2):               # the (19, 23) pair also covers the drawer entry: flip it along
+                        d = env.instance.drawer['drawer']
+                        c.world['base'][d]['pos'] = [prev['base']['drawer']['pos'][0], -prev['base']['drawer']['pos'][1], prev['base']['drawer']['pos'][2]]
+                        desc['base']['drawer']['pos'] = c.world['base'][d]['pos']
+                obs = quiet(env.instance.calc_state)
+                r = env.compute_reward(obs['achieved_goal'], obs['desired_goal'])
+                steps.append({'world': desc, 'obs': obs_to_json(obs), 'reward': float(r)})
+                prev = desc
+            seqs.append({'goal': env.instance.goal, 'steps': steps})
+        resets = []
+        for k in range(3):
+            env, c, shadow = new_env(None, cls)
+            rr = np.random.default_rng(seed + 10 + k)
+            fill_world(None, env, c, rr)
+            c.ik_queue = [rr.uniform(-2, 2, 9).tolist() for _ in range(64)]
+            draws = []
+            rs = np.random.RandomState(2000 + k)
+            orig = (np.random.uniform, np.random.choice, np.random.random)
+
+            def uniform(lo, hi):
+                lo, hi = np.asarray(lo, dtype=np.float64), np.asarray(hi, dtype=np.float64)
+                u = rs.random_sample(lo.shape)
+                draws.append({'fn': 'uniform', 'u': u.tolist()})
+                return lo + (hi - lo) * u
+
+            def choice(n):
+                u = rs.random_sample()
+                draws.append({'fn': 'choice', 'n': int(n), 'u': float(u)})
+                return int(u * n)
+
+            def random():
+                u = rs.random_sample()
+                draws.append({'fn': 'random', 'u': float(u)})
+                return u
+
+            np.random.uniform, np.random.choice, np.random.random = uniform, choice, random
+            try:
+                c.clear_log()
+                n_ik_before = len(c.ik_queue)
+                obs = quiet(env.reset)
+            finally:
+                np.random.uniform, np.random.choice, np.random.random = orig
+            log, n_step = [], 0
+            for e in c.log:
+                if e['fn'] == 'stepSimulation':
+                    n_step += 1
+                    continue
+                if e['fn'] in ('changeDynamics', 'rayTest'):
+                    continue
+                if n_step:
+                    log.append({'fn': 'stepSimulation_x', 'n': n_step})
+                    n_step = 0
+                log.append(e)
+            resets.append({'draws': draws, 'log': log, 'n_resets': n_ik_before - len(c.ik_queue),
+                           'goal': env.instance.goal, 'obs': obs_to_json(obs)})
+        out[gid] = {'info': info, 'cases': cases, 'calc_state': seqs, 'resets': resets}
+    dump('two_object_ids.json', out)
+
+
 if __name__ == '__main__':
+    gen_two_object_ids()
     gen_panda_ids()
     gen_spaces_more()
     gen_reset_to()

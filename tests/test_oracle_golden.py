@@ -7,8 +7,8 @@ from oracle import OracleEnv, quat_from_euler, euler_from_quat, dial_to_0_1_rang
 
 DT = 1.0 / 300.0
 F32_KEYS = ('obs_quat', 'achieved_goal', 'desired_goal', 'controllable_achieved_goal', 'full_positional_state')
-EE = {'U': 7, 'R': 7, 'P': 11, 'Q': 11, 'V': 11}
-GRIP_JOINT = {'U': '18', 'R': '18', 'P': '9', 'Q': '9', 'V': '9'}
+EE = {'U': 7, 'R': 7, 'P': 11, 'Q': 11, 'V': 11, 'W': 11}
+GRIP_JOINT = {'U': '18', 'R': '18', 'P': '9', 'Q': '9', 'V': '9', 'W': '9'}
 
 
 def readings_from_world(kind, w):
@@ -16,14 +16,17 @@ def readings_from_world(kind, w):
     kw = dict(ee_pos=ee['pos'], ee_orn=ee['orn'], ee_lin=ee['lin'], ee_ang=ee['ang'], grip_q=w['joint'][GRIP_JOINT[kind]],
               joints=[w['joint'][str(j)] for j in range(8)])
     ray = w['ray']
-    if kind in ('P', 'Q', 'V'):
+    if kind in ('P', 'Q', 'V', 'W'):
         kw['proprio'] = -1
     else:   # environments.py:736: nothing in hand if the ray misses or hits a pad
         kw['proprio'] = 0 if (ray['fraction'] == 1.0 or ray['link'] in (18, 20)) else 1
     if 'block0' in w['base']:
         b = w['base']['block0']
         kw.update(block_pos=b['pos'], block_orn=b['orn'], block_vel=b['lin'])
-    if kind in ('U', 'V'):
+    if 'block1' in w['base']:
+        b = w['base']['block1']
+        kw.update(block2_pos=b['pos'], block2_orn=b['orn'], block2_vel=b['lin'])
+    if kind in ('U', 'V', 'W'):
         kw.update(drawer_y=w['base']['drawer']['pos'][1], door_q=w['joint']['door'], button_q=w['joint']['button'],
                   dial_q=w['joint']['dial'])
     return kw
@@ -237,6 +240,87 @@ def test_panda_reach_and_play_ids(golden, gid):
         check_obs(got, case['obs'], tol=1e-12)
         r = env.compute_reward(np.float32(got['achieved_goal']), np.float32(got['desired_goal']))
         assert r == pytest.approx(case['reward'], abs=1e-7)
+
+
+@pytest.mark.parametrize('gid', ['pandaPlay-v0', 'pandaPlayJoints-v0'])
+def test_two_object_play_ids(golden, gid):
+    """pandaPlay-v0 / pandaPlayJoints-v0 (envList.py:28-41): two blocks.  Attributes and action space; step() cases (IK call,
+    clamps, motor commands, 26 / 18-wide observation); the quaternion sign memory with its (19, 23) pair; reset(): five
+    uniforms + choice + random per attempt, both spawn heights, the arm target, the goal of the last attempt."""
+    g = golden('two_object_ids.json')[gid]
+    info = g['info']
+    env0 = OracleEnv(gid)
+    assert info['arm_type'] == 'Panda' and info['num_objects'] == 2 and info['num_goals'] == 2 and info['play']
+    assert env0.action_type == info['action_type']
+    high = np.array(info['action_high'])
+    np.testing.assert_array_equal(env0.action_high(), high)
+    fl = env0.flags()
+    assert (fl['play'], fl['use_orientation'], fl['return_velocity'], fl['num_objects']) == (1, 1, 0, 2)
+    rg = env0.ranges()
+    np.testing.assert_allclose(rg['goal_lo'], info['goal_lower_bound'], atol=0)
+    np.testing.assert_allclose(rg['goal_hi'], info['goal_upper_bound'], atol=0)
+    np.testing.assert_allclose(rg['obj_lo'], info['obj_lower_bound'], atol=0)
+    np.testing.assert_allclose(rg['obj_hi'], info['obj_upper_bound'], atol=0)
+    np.testing.assert_allclose(rg['env_hi'], info['env_upper_bound'], atol=0)
+    bullet_dofs = [0, 1, 2, 3, 4, 5, 6, 9, 10]
+    for case in g['cases']:
+        env = OracleEnv(gid)
+        a = np.clip(np.array(case['action']), -high, high)
+        w = case['world']
+        s = env.get_state()
+        for d, j in enumerate(bullet_dofs):
+            s[d] = w['joint'][str(j)]
+        env.set_state(s)
+        ik_calls = [e for e in case['main_log'] if e['fn'] == 'calculateInverseKinematics']
+        if info['action_type'] == 'relative_joints':
+            assert len(ik_calls) == 0
+            tp = env.goto_joint_poses(a[:7] + s[:7], gripper=a[7])
+        else:
+            assert len(ik_calls) == 1 and ik_calls[0]['kwargs'] == {'maxNumIterations': 200}
+            ee = w['link']['11']
+            pos, quat = env.action_target(a, ee['pos'], ee['orn'])
+            np.testing.assert_allclose(ik_calls[0]['args'][2], pos, rtol=0, atol=1e-15)
+            np.testing.assert_allclose(ik_calls[0]['args'][3], quat, rtol=0, atol=1e-14)
+            tp = env.goto_joint_poses(np.array(case['ik_returns'][-1])[:7], gripper=a[-1])
+        np.testing.assert_allclose(tp, case['target_poses'], rtol=0, atol=1e-15)
+        assert sum(1 for e in case['main_log'] if e['fn'] == 'stepSimulation') == 12
+        env.set_goal(case['goal'])
+        got = env.assemble_obs(**readings_from_world('W', w))
+        check_obs(got, case['obs'], tol=1e-12)
+        assert len(got['obs_quat']) == 26 and len(got['achieved_goal']) == 18 and len(got['observation']) == 25
+        r = env.compute_reward(np.float32(got['achieved_goal']), np.float32(got['desired_goal']))
+        assert r == pytest.approx(case['reward'], abs=1e-7)
+    for seq in g['calc_state']:
+        env = OracleEnv(gid)
+        env.set_goal(seq['goal'])
+        for step in seq['steps']:
+            got = env.assemble_obs(**readings_from_world('W', step['world']))
+            check_obs(got, step['obs'], tol=1e-12)
+            r = env.compute_reward(np.float32(got['achieved_goal']), np.float32(got['desired_goal']))
+            assert r == pytest.approx(step['reward'], abs=1e-7)
+    for case in g['resets']:
+        draws = case['draws']
+        per = ['uniform', 'uniform', 'uniform', 'uniform', 'uniform', 'choice', 'random']
+        assert len(draws) % 7 == 0 and [d['fn'] for d in draws][:7] == per
+        u = []
+        for d in draws[:7]:
+            u += d['u'] if isinstance(d['u'], list) else [d['u']]
+        assert len(u) == 17
+        env = OracleEnv(gid)
+        blocks, target = env.reset_samples(u)
+        spawns = [e for e in case['log'] if e['fn'] == 'resetBasePositionAndOrientation' and e['args'][2] == [0.0, 0.0, 0.7071, 0.7071]]
+        np.testing.assert_allclose(blocks[0:3], spawns[0]['args'][1], rtol=0, atol=1e-15)       # +0.03
+        np.testing.assert_allclose(blocks[3:6], spawns[1]['args'][1], rtol=0, atol=1e-15)       # +0.06
+        ik = [e for e in case['log'] if e['fn'] == 'calculateInverseKinematics'][0]
+        np.testing.assert_allclose(target, ik['args'][2], rtol=0, atol=1e-15)
+        assert [e['n'] for e in case['log'] if e['fn'] == 'stepSimulation_x'][0] == 100
+        env.reset(u=np.tile(u, 16))
+        assert env.last_used % 17 == 0 and env.last_used >= 17
+        ag = np.array(case['obs']['achieved_goal']['v'], dtype=np.float32)
+        idx = int(draws[-2]['u'] * 18)
+        want = ag.copy()
+        want[idx] = np.float32(want[idx] + np.float32(draws[-1]['u']))
+        np.testing.assert_array_equal(np.array(case['goal'], dtype=np.float32), want)
 
 
 def test_rewards_and_dial(golden):

@@ -504,8 +504,10 @@ def emit_header(models, path):
         nb = M['n_arm']
         A = M['arm']
         out.append('  m->kind = %d; m->n_arm = %d; m->n_free = %d; m->n_joint1 = %d; m->n_col = %d; m->n_pair = %d; m->n_site = %d;\n'
-                   % ('URPQV'.index(k), nb, len(M['free']), len(M['joint1']), len(M['col']), len(M['pair']), len(M['sites'])))
+                   % ('URPQVW'.index(k), nb, len(M['free']), len(M['joint1']), len(M['col']), len(M['pair']), len(M['sites'])))
 
+        drawer = [i for i, f in enumerate(M['free']) if f['rot_locked']]
+        out.append('  m->drawer_free = %d;\n' % (drawer[0] if drawer else -1))
         out.append('  m->arm_type = %d; m->scene = %d;\n' % (['UR5', 'Panda'].index(M['arm_type']),
                                                                ['complex_scene', 'default_scene', 'push_scene'].index(M['scene'])))
 
@@ -570,10 +572,11 @@ def main():
     models = []
     # Q, V: the Panda (instance_init_P: base pose, EE index and rest pose are per arm type, environments.py:356-363) in the
     # other two scenes
+    gold2 = json.load(open(os.path.join(REPO, 'tests', 'golden', 'two_object_ids.json')))
     for kind, arm, scene, ini in (('U', ur5, 'complex_scene', 'U'), ('R', ur5, 'default_scene', 'R'), ('P', panda, 'push_scene', 'P'),
-                                  ('Q', panda, 'default_scene', 'P'), ('V', panda, 'complex_scene', 'P')):
+                                  ('Q', panda, 'default_scene', 'P'), ('V', panda, 'complex_scene', 'P'), ('W', panda, 'complex_scene', 'P')):
         init = gold['instance_init_' + ini]
-        M = make_model(kind, arm, gold[scene]['log'], np.array(init['base_pos'], float), quat_to_mat(init['base_orn']),
+        M = make_model(kind, arm, gold2['complex_scene_2obj']['log'] if kind == 'W' else gold[scene]['log'], np.array(init['base_pos'], float), quat_to_mat(init['base_orn']),
                        init['ee_index'], init['rest'], 'UR5' if arm is ur5 else 'Panda', scene)
         print(kind, 'arm dofs', M['n_arm'], 'free', len(M['free']), 'joint1', len(M['joint1']), 'colliders', len(M['col']),
               'pairs', len(M['pair']))
