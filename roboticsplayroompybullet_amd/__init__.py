@@ -43,5 +43,8 @@ for _id, _cls in (('pandaReach-v0', 'pandaReach'), ('pandaReach2D-v0', 'pandaRea
                   ('pandaPlayAbsJoints1Obj-v0', 'pandaPlayAbsJoints1Obj'), ('pandaPlayAbsRPY1Obj-v0', 'pandaPlayAbsRPY1Obj'),
                   ('pandaPlayRelRPY1Obj-v0', 'pandaPlayRelRPY1Obj')):
     register(id=_id, entry_point='roboticsplayroompybullet_amd.envs:' + _cls)
+# roboticsPlayroomPybullet/__init__.py:29, 41 - the two-object play ids (the RP_WIDE build of the library)
+register(id='pandaPlay-v0', entry_point='roboticsplayroompybullet_amd.envs:pandaPlay')
+register(id='pandaPlayJoints-v0', entry_point='roboticsplayroompybullet_amd.envs:pandaPlayRelJoints')
 
 __all__ = ['VecPlayEnv', 'make', 'register']

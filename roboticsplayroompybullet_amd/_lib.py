@@ -9,6 +9,9 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB_PATH = os.environ.get('RP_PLAYROOM_LIB', os.path.join(CSRC, 'librp_playroom_hip.so'))   # env override: profiling builds
+# the RP_WIDE build of the same sources: the two-object play ids (three free bodies in the record, one-kernel path only)
+WIDE_LIB_PATH = os.path.join(CSRC, 'librp_playroom_hip_wide.so')
+WIDE_IDS = ('pandaPlay-v0', 'pandaPlayJoints-v0')
 
 ENV_KINDS = {'UR5PlayAbsRPY1Obj-v0': 0, 'UR5Reach-v0': 1, 'pandaPick-v0': 2,
              # the rest of the UR5 one-object play family (same scene, other action types)
@@ -18,7 +21,8 @@ ENV_KINDS = {'UR5PlayAbsRPY1Obj-v0': 0, 'UR5Reach-v0': 1, 'pandaPick-v0': 2,
              'pandaReach-v0': 9, 'pandaReach2D-v0': 10,                     # Panda + default_scene
              # the Panda one-object play family: Panda + complex_scene
              'pandaPlay1Obj-v0': 11, 'pandaPlayRel1Obj-v0': 12, 'pandaPlayRelJoints1Obj-v0': 13, 'pandaPlayAbsJoints1Obj-v0': 14,
-             'pandaPlayAbsRPY1Obj-v0': 15, 'pandaPlayRelRPY1Obj-v0': 16}
+             'pandaPlayAbsRPY1Obj-v0': 15, 'pandaPlayRelRPY1Obj-v0': 16,
+             'pandaPlay-v0': 17, 'pandaPlayJoints-v0': 18}      # two blocks: served by the wide build (WIDE_LIB_PATH)
 
 
 ACTION_TYPES = {'UR5PlayAbsRPY1Obj-v0': 'absolute_rpy', 'UR5Reach-v0': 'absolute_rpy', 'pandaPick-v0': 'absolute_rpy',
@@ -27,7 +31,7 @@ ACTION_TYPES = {'UR5PlayAbsRPY1Obj-v0': 'absolute_rpy', 'UR5Reach-v0': 'absolute
                 'pandaReach-v0': 'absolute_rpy', 'pandaReach2D-v0': 'absolute_rpy',
                 'pandaPlay1Obj-v0': 'absolute_quat', 'pandaPlayRel1Obj-v0': 'relative_quat', 'pandaPlayRelJoints1Obj-v0': 'relative_joints',
                 'pandaPlayAbsJoints1Obj-v0': 'absolute_joints', 'pandaPlayAbsRPY1Obj-v0': 'absolute_rpy',
-                'pandaPlayRelRPY1Obj-v0': 'relative_rpy'}
+                'pandaPlayRelRPY1Obj-v0': 'relative_rpy', 'pandaPlay-v0': 'absolute_quat', 'pandaPlayJoints-v0': 'relative_joints'}
 
 
 class RpConfig(C.Structure):
@@ -58,23 +62,26 @@ EXPORTS = ['rp_create', 'rp_destroy', 'rp_get_dims', 'rp_reset', 'rp_reset_to', 
            'rp_last_error', 'rp_version']
 
 _lib = None
+_libs = {}
 
 
 def build(force=False):
     """Compile the HIP library in-tree (hipcc --offload-arch=gfx950); cross-compiles without a GPU."""
-    if force or not os.path.exists(LIB_PATH):
+    if force or not os.path.exists(LIB_PATH) or not os.path.exists(WIDE_LIB_PATH):
         subprocess.run(['make', '-C', CSRC, '-s'], check=True)
     return LIB_PATH
 
 
-def load():
+def load(wide=False):
+    """the HIP library (wide=True: its RP_WIDE build, which serves WIDE_IDS)"""
     global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise RuntimeError('librp_playroom_hip.so is not built (%s). Run `python -c "import __graft_entry__ as g; g.build()"` '
-                           'or `make -C roboticsplayroompybullet_amd/csrc`. There is no CPU fallback.' % LIB_PATH)
-    lib = C.CDLL(LIB_PATH)
+    path = WIDE_LIB_PATH if wide else LIB_PATH
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        raise RuntimeError('%s is not built (%s). Run `python -c "import __graft_entry__ as g; g.build()"` '
+                           'or `make -C roboticsplayroompybullet_amd/csrc`. There is no CPU fallback.' % (os.path.basename(path), path))
+    lib = C.CDLL(path)
     vp = C.c_void_p
     lib.rp_create.argtypes = [C.POINTER(RpConfig), C.POINTER(vp)]
     lib.rp_destroy.argtypes = [vp]
@@ -99,7 +106,9 @@ def load():
     lib.rp_set_groups.argtypes = [vp, C.c_int32]
     lib.rp_set_debug_flags.argtypes = [vp, C.c_int32]
     lib.rp_debug_row_counts.argtypes = [vp, C.POINTER(C.c_int32)]
-    _lib = lib
+    _libs[path] = lib
+    if not wide:
+        _lib = lib
     return lib
 
 

@@ -10,6 +10,9 @@
 #define RP_REC_FLOATS 128 /* per-env state record, 512 B: one coalesced wave load */
 
 /* state record layout (floats) */
+#ifndef RP_WIDE
+#define ST_NARM 12       /* stride of the per-dof arrays */
+#define ST_NFREE 2       /* free-body slots in the record */
 #define ST_Q 0
 #define ST_QD 12
 #define ST_FREE 24       /* per free body 13: pos3 quat4 vel3 om3 */
@@ -26,10 +29,35 @@
 #define ST_RNG 116       /* uint32 draw counter (bit pattern) */
 #define ST_NGOAL 117
 #define ST_STATUS 118
+#else
+/* RP_WIDE build (librp_playroom_hip_wide.so): the two-object play ids - Panda only (9 arm dofs), three free bodies (block,
+ * block, drawer), 18-wide goal.  Same 128-float record, other offsets.  The sign memory keeps obs[3:7], obs[11:15] (= ag[3:7]:
+ * the same quaternion with the same history, so one copy serves both), obs[19:23] and ag[10:14]. */
+#define ST_NARM 9
+#define ST_NFREE 3
+#define ST_Q 0
+#define ST_QD 9
+#define ST_FREE 18
+#define ST_JQ 57
+#define ST_JQD 60
+#define ST_MMODE 63
+#define ST_MTARGET 72
+#define ST_MMAXIMP 81
+#define ST_GOAL 90
+#define ST_LAST_EE_Q 108
+#define ST_LAST_BLK_Q 112
+#define ST_LAST_AG_Q 112
+#define ST_LAST_OBS19 116
+#define ST_LAST_AG10 120
+#define ST_HAVE_LAST 124
+#define ST_RNG 125
+#define ST_NGOAL 126
+#define ST_STATUS 127
+#endif
 
 typedef struct DevModel {
   int kind, n_arm, n_free, n_j1, n_col, n_pair, nv, nbody, n_site;
-  int arm_type, scene;
+  int arm_type, scene, drawer_free;
   int play, use_orientation, return_velocity, num_objects, n_goal_init;
   int n_obs, n_ag, n_fps, n_observation, n_target;
   int action_type, n_action;    /* RP_ACT_* (environments.py:915-934) and the action length: 7, 8 (quaternion types) or n_target + 1 (joint types) */
@@ -135,7 +163,7 @@ static inline void rp_build_dev_model(const rp_model* m, DevModel* d) {
   }
   memcpy(d->pair, m->pair, sizeof(d->pair));
   int isP = m->arm_type == RP_ARM_PANDA;
-  d->arm_type = m->arm_type; d->scene = m->scene;
+  d->arm_type = m->arm_type; d->scene = m->scene; d->drawer_free = m->drawer_free;
   d->d_grip_obs = rp_dm_dof_of_joint(m, isP ? 9 : 18);
   d->d18 = rp_dm_dof_of_joint(m, 18); d->d20 = rp_dm_dof_of_joint(m, 20); d->d12 = rp_dm_dof_of_joint(m, 12);
   d->d15 = rp_dm_dof_of_joint(m, 15); d->d10 = rp_dm_dof_of_joint(m, 10); d->d13 = rp_dm_dof_of_joint(m, 13);
@@ -144,10 +172,11 @@ static inline void rp_build_dev_model(const rp_model* m, DevModel* d) {
   /* envList.py:18-22, 89-99 */
   const float PI = 3.14159265358979323846f;
   if (m->scene == RP_SCENE_COMPLEX) {
-    d->play = 1; d->use_orientation = 1; d->return_velocity = 0; d->num_objects = 1; d->n_goal_init = 11;
+    d->play = 1; d->use_orientation = 1; d->return_velocity = 0; d->num_objects = m->n_free - 1;      /* blocks, then the drawer */
     float gl[3] = {-0.18f, 0.f, 0.05f}, gh[3] = {0.18f, 0.3f, 0.1f};
     for (int k = 0; k < 3; k++) { d->goal_lo[k] = d->obj_lo[k] = gl[k]; d->goal_hi[k] = d->obj_hi[k] = gh[k]; d->env_hi[k] = 1.f; }
-    d->n_obs = 19; d->n_ag = 11; d->n_fps = 19; d->n_observation = 18; d->n_target = 6;
+    d->n_ag = 7 * d->num_objects + 4; d->n_goal_init = d->n_ag;
+    d->n_obs = 8 + d->n_ag; d->n_fps = 8 + d->n_ag; d->n_observation = 7 + d->n_ag; d->n_target = 6;
   } else if (m->scene == RP_SCENE_DEFAULT) {
     d->play = 0; d->use_orientation = 0; d->return_velocity = 1; d->num_objects = 0; d->n_goal_init = 3;
     float gl[3] = {-0.18f, -0.18f, -0.05f}, gh[3] = {0.18f, 0.18f, 0.05f}, eh[3] = {0.18f, 0.18f, 0.15f};

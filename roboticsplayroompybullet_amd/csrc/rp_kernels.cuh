@@ -69,6 +69,11 @@
 
 /* Per-env LDS block.  Phase-local scratch (collision, dynamics, Jacobian rows) shares one union: the phases of a
  * substep run strictly one after another, separated by barriers. */
+#ifdef RP_WIDE
+#define O_FLOATS 160            /* output block of one env (O_* offsets at calc_state) */
+#else
+#define O_FLOATS 128
+#endif
 struct __align__(16) EnvLds {
   float st[RP_REC_FLOATS];
   float xR[NB_MAX * 9], xp[NB_MAX * 3];
@@ -95,7 +100,7 @@ struct __align__(16) EnvLds {
     } d;
     struct { float J[ROWREG]; float B[ROWREG]; } r;                   /* contact rows */
   } u;
-  float out[128];
+  float out[O_FLOATS];
   float aout[192];                /* k_prep2: unit rows in the solver's dof-indexed form */
   unsigned amask[4];
   int roff[64];                   /* k_prep2: slot offsets of the compact contact rows */
@@ -124,6 +129,7 @@ __device__ __forceinline__ int dof_j1(const DevModel* m, int k) { return m->n_ar
 /* lane layout of the velocity vector inside a 32-lane group: arm dof i at lane i (DPP row 0); in DPP row 1 scene
  * joint k at lane 16 + k (k < 3) and component c of free body f at lane 19 + 6 f + c, so that arm-only and non-arm
  * rows reduce in different DPP rows and every unit row (motor, limit) sits at a compile-time lane of its DPP row */
+#ifndef RP_WIDE
 #define LANE_J1 16
 #define LANE_FREE 19
 __device__ __forceinline__ int lane_pos(const DevModel* m, int d) {
@@ -137,6 +143,21 @@ __device__ __forceinline__ int lane_dof(const DevModel* m, int l) {       /* inv
   if (l < LANE_FREE) return l - LANE_J1 < m->n_j1 ? m->n_arm + 6 * m->n_free + (l - LANE_J1) : -1;
   return l - LANE_FREE < 6 * m->n_free ? m->n_arm + (l - LANE_FREE) : -1;
 }
+#else
+/* RP_WIDE (fused path only, no DPP-row structure needed): arm dofs 0..8, scene joints 9..11, three free bodies 12..29 */
+#define LANE_J1 9
+#define LANE_FREE 12
+__device__ __forceinline__ int lane_pos(const DevModel* m, int d) {
+  if (d < m->n_arm) return d;
+  int f6 = 6 * m->n_free;
+  return d - m->n_arm < f6 ? LANE_FREE + (d - m->n_arm) : LANE_J1 + (d - m->n_arm - f6);
+}
+__device__ __forceinline__ int lane_dof(const DevModel* m, int l) {
+  if (l < LANE_J1) return l < m->n_arm ? l : -1;
+  if (l < LANE_FREE) return l - LANE_J1 < m->n_j1 ? m->n_arm + 6 * m->n_free + (l - LANE_J1) : -1;
+  return l - LANE_FREE < 6 * m->n_free ? m->n_arm + (l - LANE_FREE) : -1;
+}
+#endif
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
 __device__ __forceinline__ float safe_inv(float d) { return d > 1e-9f ? 1.0f / d : 0.0f; }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -1428,6 +1449,7 @@ __device__ __forceinline__ void flip_quat(float* v, const float* last) {
 
 /* out layout in L.out: obs_quat @0 (19) | ag @19 (11) | dg @30 (11) | cag @41 (4) | fps @45 (19) | joints @64 (8) |
  * velocity @72 (6) | observation @78 (18) | proprio @96 | reward @97 | is_success @98 | status @99 */
+#ifndef RP_WIDE
 #define O_OBS 0
 #define O_AG 19
 #define O_DG 30
@@ -1440,6 +1462,24 @@ __device__ __forceinline__ void flip_quat(float* v, const float* last) {
 #define O_REW 97
 #define O_SUCC 98
 #define O_STATUS 99
+#define OBS_MAX 19
+#define AG_MAX 11
+#else      /* two objects: obs_quat 26 | ag 18 | dg 18 | cag 4 | fps 26 | joints 8 | velocity 6 | observation 25 | flags */
+#define O_OBS 0
+#define O_AG 26
+#define O_DG 44
+#define O_CAG 62
+#define O_FPS 66
+#define O_JOINTS 92
+#define O_VEL 100
+#define O_OBSV 106
+#define O_PROP 131
+#define O_REW 132
+#define O_SUCC 133
+#define O_STATUS 134
+#define OBS_MAX 26
+#define AG_MAX 18
+#endif
 
 /* calc_state (environments.py:799-864): transforms must be current (fk_bodies). Stateful in play mode. */
 __device__ void calc_state(const DevModel* m, EnvLds& L, int lane) {
@@ -1501,19 +1541,21 @@ __device__ void calc_state(const DevModel* m, EnvLds& L, int lane) {
     V3 lin = v.l + cross(v.a, pos - ld3(L.O)), ang = v.a;
     float grip = L.st[ST_Q + m->d_grip_obs] * (m->arm_type == RP_ARM_PANDA ? 1.f : 23.f);
     float* o = L.out;
-    float st[19], ag[11];
+    float st[OBS_MAX], ag[AG_MAX];
     int ns = 0, nag = 0, nf = 0;
     st[ns++] = pos.x; st[ns++] = pos.y; st[ns++] = pos.z;
     if (m->return_velocity) { st[ns++] = lin.x; st[ns++] = lin.y; st[ns++] = lin.z; }
     if (m->use_orientation) { st[ns++] = orn.x; st[ns++] = orn.y; st[ns++] = orn.z; st[ns++] = orn.w; }
     st[ns++] = grip;
     if (m->num_objects > 0) {
-      const float* f = &L.st[ST_FREE];
-      for (int k = 0; k < 3; k++) { st[ns++] = f[k]; ag[nag++] = f[k]; }
-      if (m->use_orientation) for (int k = 0; k < 4; k++) { st[ns++] = f[3 + k]; ag[nag++] = f[3 + k]; }
-      if (m->return_velocity) for (int k = 0; k < 3; k++) st[ns++] = f[7 + k];
+      for (int b = 0; b < m->num_objects; b++) {
+        const float* f = &L.st[ST_FREE + 13 * b];
+        for (int k = 0; k < 3; k++) { st[ns++] = f[k]; ag[nag++] = f[k]; }
+        if (m->use_orientation) for (int k = 0; k < 4; k++) { st[ns++] = f[3 + k]; ag[nag++] = f[3 + k]; }
+        if (m->return_velocity) for (int k = 0; k < 3; k++) st[ns++] = f[7 + k];
+      }
       if (m->play) {
-        float ex[4] = {L.st[ST_FREE + 13 + 1], L.st[ST_JQ + 0], L.st[ST_JQ + 1], dial01(L.st[ST_JQ + 2])};
+        float ex[4] = {L.st[ST_FREE + 13 * m->drawer_free + 1], L.st[ST_JQ + 0], L.st[ST_JQ + 1], dial01(L.st[ST_JQ + 2])};
         for (int k = 0; k < 4; k++) { st[ns++] = ex[k]; ag[nag++] = ex[k]; }
       }
     } else {
@@ -1523,9 +1565,18 @@ __device__ void calc_state(const DevModel* m, EnvLds& L, int lane) {
       if (L.st[ST_HAVE_LAST] != 0.f) {
         flip_quat(&st[3], &L.st[ST_LAST_EE_Q]);
         flip_quat(&st[11], &L.st[ST_LAST_BLK_Q]);
+#ifdef RP_WIDE
+        flip_quat(&st[19], &L.st[ST_LAST_OBS19]);       /* (19, 23) as written in the reference: one past the second quaternion's start */
+#endif
         flip_quat(&ag[3], &L.st[ST_LAST_AG_Q]);
+#ifdef RP_WIDE
+        flip_quat(&ag[10], &L.st[ST_LAST_AG10]);
+#endif
       }
       for (int k = 0; k < 4; k++) { L.st[ST_LAST_EE_Q + k] = st[3 + k]; L.st[ST_LAST_BLK_Q + k] = st[11 + k]; L.st[ST_LAST_AG_Q + k] = ag[3 + k]; }
+#ifdef RP_WIDE
+      for (int k = 0; k < 4; k++) { L.st[ST_LAST_OBS19 + k] = st[19 + k]; L.st[ST_LAST_AG10 + k] = ag[10 + k]; }
+#endif
       L.st[ST_HAVE_LAST] = 1.f;
     }
     for (int k = 0; k < ns; k++) o[O_OBS + k] = st[k];
@@ -1634,8 +1685,10 @@ __device__ __forceinline__ float next_u(EnvLds& L, uint64_t seed, uint32_t genv)
 __device__ void reset_goal_pos(const DevModel* m, EnvLds& L, int lane, const float* goal, uint64_t seed, uint32_t genv) {
   if (lane == 0) {
     if (!goal) {
-      for (int k = 0; k < 3; k++) L.st[ST_GOAL + k] = m->goal_lo[k] + (m->goal_hi[k] - m->goal_lo[k]) * next_u(L, seed, genv);
-      L.st[ST_NGOAL] = __int_as_float(3);
+      const int ng = m->num_objects > 1 ? m->num_objects : 1;        /* num_goals = max(num_objects, 1) draws of 3 (environments.py:78, 495-498) */
+      for (int g = 0; g < ng; g++)
+        for (int k = 0; k < 3; k++) L.st[ST_GOAL + 3 * g + k] = m->goal_lo[k] + (m->goal_hi[k] - m->goal_lo[k]) * next_u(L, seed, genv);
+      L.st[ST_NGOAL] = __int_as_float(3 * ng);
     } else {
       int ng = __float_as_int(L.st[ST_NGOAL]);
       for (int k = 0; k < ng; k++) L.st[ST_GOAL + k] = goal[k];
@@ -1662,9 +1715,9 @@ __device__ void reset_goal_pos(const DevModel* m, EnvLds& L, int lane, const flo
 __device__ void reset_sample_objects(const DevModel* m, EnvLds& L, int lane, uint64_t seed, uint32_t genv) {
   if (lane == 0) {
     if (m->play) {
-      float* d = &L.st[ST_FREE + 13];
-      for (int k = 0; k < 3; k++) d[k] = m->free_pos0[1][k];
-      for (int k = 0; k < 4; k++) d[3 + k] = m->free_quat0[1][k];
+      float* d = &L.st[ST_FREE + 13 * m->drawer_free];
+      for (int k = 0; k < 3; k++) d[k] = m->free_pos0[m->drawer_free][k];
+      for (int k = 0; k < 4; k++) d[3 + k] = m->free_quat0[m->drawer_free][k];
       for (int k = 7; k < 13; k++) d[k] = 0.f;
       for (int k = 0; k < m->n_j1; k++) { L.st[ST_JQ + k] = 0.f; L.st[ST_JQD + k] = 0.f; }
     }
@@ -1741,9 +1794,9 @@ __global__ void __launch_bounds__(64, RP_WAVES_PER_EU) k_reset(const DevModel* _
       const float* o = obs_o + (size_t)env * n_o;
       if (lane == 0) {
         if (m->play) {
-          float* d = &L.st[ST_FREE + 13];
-          for (int k = 0; k < 3; k++) d[k] = m->free_pos0[1][k];
-          for (int k = 0; k < 4; k++) d[3 + k] = m->free_quat0[1][k];
+          float* d = &L.st[ST_FREE + 13 * m->drawer_free];
+          for (int k = 0; k < 3; k++) d[k] = m->free_pos0[m->drawer_free][k];
+          for (int k = 0; k < 4; k++) d[3 + k] = m->free_quat0[m->drawer_free][k];
           for (int k = 7; k < 13; k++) d[k] = 0.f;
           for (int k = 0; k < m->n_j1; k++) { L.st[ST_JQ + k] = 0.f; L.st[ST_JQD + k] = 0.f; }
         }
@@ -1850,8 +1903,8 @@ __global__ void k_init(const DevModel* __restrict__ m, float* __restrict__ state
     for (int k = 0; k < 3; k++) r[ST_FREE + 13 * f + k] = m->free_pos0[f][k];
     for (int k = 0; k < 4; k++) r[ST_FREE + 13 * f + 3 + k] = m->free_quat0[f][k];
   }
-  for (int f = m->n_free; f < RP_MAX_FREE; f++) r[ST_FREE + 13 * f + 6] = 1.f;
-  for (int i = 0; i < RP_MAX_ARM; i++) r[ST_MMAXIMP + i] = K_DEFMOTOR;
+  for (int f = m->n_free; f < ST_NFREE; f++) r[ST_FREE + 13 * f + 6] = 1.f;
+  for (int i = 0; i < ST_NARM; i++) r[ST_MMAXIMP + i] = K_DEFMOTOR;
   r[ST_NGOAL] = __int_as_float(m->n_goal_init);
 }
 

@@ -67,7 +67,11 @@ static OutPtrs to_ptrs(const rp_out* o) {
 
 extern "C" {
 
+#ifdef RP_WIDE
+const char* rp_version(void) { return "rp_playroom 0.1 (gfx950, wide build: two-object play ids)"; }
+#else
 const char* rp_version(void) { return "rp_playroom 0.1 (gfx950, wave-per-env)"; }
+#endif
 
 int rp_create(const rp_config* cfg, rp_handle* out) {
   if (!cfg || !out || cfg->num_envs <= 0) { snprintf(g_err, 256, "rp_create: bad argument"); return RP_ERR_ARG; }
@@ -82,9 +86,16 @@ int rp_create(const rp_config* cfg, rp_handle* out) {
     {'U', RP_ACT_ABS_QUAT}, {'U', RP_ACT_REL_QUAT}, {'U', RP_ACT_REL_JOINTS}, {'U', RP_ACT_ABS_JOINTS}, {'U', RP_ACT_REL_RPY},
     {'P', RP_ACT_ABS_RPY},
     {'Q', RP_ACT_ABS_RPY}, {'Q', RP_ACT_ABS_RPY},
-    {'V', RP_ACT_ABS_QUAT}, {'V', RP_ACT_REL_QUAT}, {'V', RP_ACT_REL_JOINTS}, {'V', RP_ACT_ABS_JOINTS}, {'V', RP_ACT_ABS_RPY}, {'V', RP_ACT_REL_RPY}};
+    {'V', RP_ACT_ABS_QUAT}, {'V', RP_ACT_REL_QUAT}, {'V', RP_ACT_REL_JOINTS}, {'V', RP_ACT_ABS_JOINTS}, {'V', RP_ACT_ABS_RPY}, {'V', RP_ACT_REL_RPY},
+    {'W', RP_ACT_ABS_QUAT}, {'W', RP_ACT_REL_JOINTS}};
   const int action_type = SPEC[cfg->env_kind].action_type;
+#ifdef RP_WIDE
+  if (SPEC[cfg->env_kind].model != 'W') { snprintf(g_err, 256, "rp_create: env kind %d is served by librp_playroom_hip.so, not by the wide build", cfg->env_kind); free(m); free(h); return RP_ERR_UNSUPPORTED; }
+#else
+  if (SPEC[cfg->env_kind].model == 'W') { snprintf(g_err, 256, "rp_create: the two-object ids (env kind %d) are served by librp_playroom_hip_wide.so", cfg->env_kind); free(m); free(h); return RP_ERR_UNSUPPORTED; }
+#endif
   switch (SPEC[cfg->env_kind].model) {
+    case 'W': rp_fill_model_W(m); break;
     case 'R': rp_fill_model_R(m); break;
     case 'P': rp_fill_model_P(m); break;
     case 'Q': rp_fill_model_Q(m); break;
@@ -101,6 +112,9 @@ int rp_create(const rp_config* cfg, rp_handle* out) {
     const float gl[3] = {-0.18f, -0.18f, -0.06f}, gh[3] = {0.18f, 0.18f, -0.05f}, eh[3] = {0.18f, 0.18f, 0.0f};
     for (int k = 0; k < 3; k++) { d->goal_lo[k] = gl[k]; d->goal_hi[k] = gh[k]; d->env_hi[k] = eh[k]; }
   }
+#ifdef RP_WIDE
+  h->fused = 1;            /* the wide record and lane layout exist for the one-kernel path only */
+#endif
   h->host_model.action_type = action_type;
   h->host_model.n_action = (action_type == RP_ACT_ABS_QUAT || action_type == RP_ACT_REL_QUAT) ? 8
                          : ((action_type == RP_ACT_ABS_JOINTS || action_type == RP_ACT_REL_JOINTS) ? h->host_model.n_target + 1 : 7);
@@ -235,7 +249,9 @@ int rp_reset(rp_handle h, const uint8_t* mask, const rp_out* out, void* stream) 
 int rp_reset_to(rp_handle h, const float* o, int32_t n_o, const uint8_t* mask, const rp_out* out, void* stream) {
   if (!h || !o) return RP_ERR_ARG;
   const DevModel* m = &h->host_model;
-  int need = m->num_objects > 0 ? (m->use_orientation ? 18 : 10) : (m->use_orientation ? (m->return_velocity ? 10 : 7) : 3);
+  /* reset_object_pos(obs) reads object b at o[11 + 10 b : 18 + 10 b] (use_orientation) or o[7 + 6 b : 10 + 6 b] (environments.py:544-556) */
+  int need = m->num_objects > 0 ? (m->use_orientation ? 18 + 10 * (m->num_objects - 1) : 10 + 6 * (m->num_objects - 1))
+                                : (m->use_orientation ? (m->return_velocity ? 10 : 7) : 3);
   if (n_o < need) { snprintf(h->err, 256, "rp_reset_to: o has %d entries per env, this env reads %d", n_o, need); return RP_ERR_ARG; }
   return reset_impl(h, o, n_o, mask, out, stream);
 }
@@ -361,7 +377,14 @@ int rp_set_state(rp_handle h, const void* src, int32_t src_env_count, void* stre
 
 int rp_set_debug_flags(rp_handle h, int32_t flags) { if (!h) return RP_ERR_ARG; h->debug_flags = flags; return RP_OK; }
 int rp_set_groups(rp_handle h, int32_t groups) { if (!h || groups < 1 || groups > RP_MAX_GROUPS) return RP_ERR_ARG; h->groups = groups; return RP_OK; }
-int rp_set_fused(rp_handle h, int32_t fused) { if (!h || (fused != 0 && fused != 1)) return RP_ERR_ARG; h->fused = fused; return RP_OK; }
+int rp_set_fused(rp_handle h, int32_t fused) {
+  if (!h || (fused != 0 && fused != 1)) return RP_ERR_ARG;
+#ifdef RP_WIDE
+  if (fused != 1) { snprintf(h->err, 256, "rp_set_fused: the wide build has the one-kernel path only"); return RP_ERR_UNSUPPORTED; }
+#endif
+  h->fused = fused;
+  return RP_OK;
+}
 int rp_get_timers(rp_handle h, rp_timers* t) {
   if (!h || !t) return RP_ERR_ARG;
   rp_timers r = h->timers;

@@ -4,3 +4,4 @@ from .play_env import UR5Play1Obj, UR5PlayRel1Obj, UR5PlayRelJoints1Obj, UR5Play
 from .play_env import pandaReach, pandaReach2D  # noqa: F401
 from .play_env import (pandaPlay1Obj, pandaPlayRel1Obj, pandaPlayRelJoints1Obj, pandaPlayAbsJoints1Obj, pandaPlayAbsRPY1Obj,  # noqa: F401
                        pandaPlayRelRPY1Obj)
+from .play_env import pandaPlay, pandaPlayRelJoints  # noqa: F401

@@ -46,8 +46,8 @@ class playEnv:
                  obj_upper_bound=(-0.18, -0.18, -0.05), sparse=True, use_orientation=False, sparse_rew_thresh=0.05,
                  fixed_gripper=False, return_velocity=True, max_episode_steps=250, play=False, action_type='absolute_rpy',
                  show_goal=True, arm_type='Panda', device=0, seed=0):
-        if action_type != 'absolute_rpy' and not (play and num_objects == 1):
-            raise NotImplementedError('action_type %r is built for the one-object play ids only (SURVEY.md §8f rank 1)' % action_type)
+        if action_type != 'absolute_rpy' and not play:
+            raise NotImplementedError('action_type %r is built for the play ids only (SURVEY.md §8f rank 1)' % action_type)
         self.timeStep = 1.0 / 300
         self.render_scene = False
         self.physics_client_active = 0
@@ -251,3 +251,25 @@ pandaPlay1Obj = _play_1obj('pandaPlay1Obj', 'pandaPlay1Obj-v0', 'absolute_quat',
 pandaPlayRel1Obj = _play_1obj('pandaPlayRel1Obj', 'pandaPlayRel1Obj-v0', 'relative_quat', 'envList.py:65-70', 'Panda')
 pandaPlayAbsRPY1Obj = _play_1obj('pandaPlayAbsRPY1Obj', 'pandaPlayAbsRPY1Obj-v0', 'absolute_rpy', 'envList.py:72-78', 'Panda')
 pandaPlayRelRPY1Obj = _play_1obj('pandaPlayRelRPY1Obj', 'pandaPlayRelRPY1Obj-v0', 'relative_rpy', 'envList.py:80-86', 'Panda')
+
+
+class pandaPlay(playEnv):                     # envList.py:28-33: two blocks, absolute_quat
+    ENV_ID = 'pandaPlay-v0'
+
+    def __init__(self, num_objects=2, env_range_low=(-1.0, -1.0, -0.4), env_range_high=(1.0, 1.0, 1.0), goal_range_low=(-0.18, 0, 0.05),
+                 goal_range_high=(0.18, 0.3, 0.1), use_orientation=True, **kw):
+        super().__init__(num_objects=num_objects, env_range_low=env_range_low, env_range_high=env_range_high, goal_range_low=goal_range_low,
+                         goal_range_high=goal_range_high, use_orientation=use_orientation, obj_lower_bound=[-0.18, 0, 0.05],
+                         obj_upper_bound=[0.18, 0.3, 0.1], return_velocity=False, max_episode_steps=None, play=True,
+                         action_type='absolute_quat', show_goal=False, **kw)
+
+
+class pandaPlayRelJoints(playEnv):            # envList.py:36-41 (registered as pandaPlayJoints-v0): two blocks, relative_joints
+    ENV_ID = 'pandaPlayJoints-v0'
+
+    def __init__(self, num_objects=2, env_range_low=(-1.0, -1.0, -0.2), env_range_high=(1.0, 1.0, 1.0), goal_range_low=(-0.18, 0, 0.05),
+                 goal_range_high=(0.18, 0.3, 0.1), use_orientation=True, **kw):
+        super().__init__(num_objects=num_objects, env_range_low=env_range_low, env_range_high=env_range_high, goal_range_low=goal_range_low,
+                         goal_range_high=goal_range_high, use_orientation=use_orientation, obj_lower_bound=[-0.18, 0, 0.05],
+                         obj_upper_bound=[0.18, 0.3, 0.1], return_velocity=False, max_episode_steps=None, play=True,
+                         action_type='relative_joints', show_goal=False, **kw)

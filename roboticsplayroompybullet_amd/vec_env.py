@@ -18,6 +18,12 @@ STATE_LAYOUT = {'q': (0, 12), 'qd': (12, 24), 'free0': (24, 37), 'free1': (37, 5
                 'motor_mode': (56, 68), 'motor_target': (68, 80), 'motor_maximp': (80, 92), 'goal': (92, 103),
                 'last_ee_quat': (103, 107), 'last_block_quat': (107, 111), 'last_ag_quat': (111, 115), 'have_last': (115, 116)}
 
+# the same record in the RP_WIDE build (two-object ids: 9 arm dofs, three free bodies, 18-wide goal)
+WIDE_STATE_LAYOUT = {'q': (0, 9), 'qd': (9, 18), 'free0': (18, 31), 'free1': (31, 44), 'free2': (44, 57), 'jq': (57, 60), 'jqd': (60, 63),
+                     'motor_mode': (63, 72), 'motor_target': (72, 81), 'motor_maximp': (81, 90), 'goal': (90, 108),
+                     'last_ee_quat': (108, 112), 'last_block_quat': (112, 116), 'last_obs_19_23': (116, 120), 'last_ag_10_14': (120, 124),
+                     'have_last': (124, 125)}
+
 
 class VecPlayEnv:
     def __init__(self, env_id, num_envs, device=0, seed=0, env_offset=0):
@@ -25,7 +31,9 @@ class VecPlayEnv:
             raise NotImplementedError('env id %r is outside the hot-path scope (SURVEY.md §8)' % (env_id,))
         if not torch.cuda.is_available():
             raise RuntimeError('VecPlayEnv needs a ROCm GPU: the hot path is HIP-only, there is no CPU fallback')
-        self.lib = _lib.load()
+        self.wide = env_id in _lib.WIDE_IDS
+        self.lib = _lib.load(wide=self.wide)
+        self.state_layout = WIDE_STATE_LAYOUT if self.wide else STATE_LAYOUT
         self.env_id = env_id
         self.num_envs = int(num_envs)
         idx = device if isinstance(device, int) else (torch.device(device).index or 0)

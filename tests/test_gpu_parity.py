@@ -600,3 +600,111 @@ def test_substep_intermediates_vs_fp32_oracle(kind):
     vstar = s[n:2 * n] + o.forward_dynamics() / 300.0
     np.testing.assert_allclose(dbg[480:480 + n], vstar, atol=2e-4 * max(1.0, np.abs(vstar).max()), rtol=0)
     print('%s: %d contacts, |Minv| max %.3g, |v*| max %.3g' % (kind, ncon, np.abs(Mo).max(), np.abs(vstar).max()))
+
+
+def wide_record_from_oracle(o):
+    """oracle state -> the 128-float record of the RP_WIDE build (vec_env.WIDE_STATE_LAYOUT)"""
+    from roboticsplayroompybullet_amd.vec_env import WIDE_STATE_LAYOUT as W
+    s = o.get_state()
+    n = o.n_arm
+    assert n == 9
+    r = np.zeros(128, dtype=np.float32)
+    r[W['q'][0]:W['q'][0] + n] = s[0:n]
+    r[W['qd'][0]:W['qd'][0] + n] = s[n:2 * n]
+    p = 2 * n
+    for k in range(3):
+        r[W['free0'][0] + 13 * k:W['free0'][0] + 13 * k + 13] = s[p:p + 13]
+        p += 13
+    r[W['jq'][0]:W['jq'][1]] = s[p:p + 3]
+    r[W['jqd'][0]:W['jqd'][1]] = s[p + 3:p + 6]
+    mode, tgt, mx = o.get_motor()
+    r[W['motor_mode'][0]:W['motor_mode'][0] + n] = mode
+    r[W['motor_target'][0]:W['motor_target'][0] + n] = tgt
+    r[W['motor_maximp'][0]:W['motor_maximp'][0] + n] = mx
+    g = o.calc_state()['desired_goal']
+    o.clear_quat_memory()
+    r[W['goal'][0]:W['goal'][0] + len(g)] = g
+    r[126] = np.frombuffer(np.int32(len(g)).tobytes(), dtype=np.float32)[0]      # ST_NGOAL (bit pattern)
+    return r
+
+
+TWO_OBJECT = ['pandaPlay-v0', 'pandaPlayJoints-v0']
+
+
+@pytest.mark.parametrize('gid', TWO_OBJECT)
+def test_two_object_play_ids_vs_oracle(gid):
+    """pandaPlay-v0 / pandaPlayJoints-v0 (two blocks, the RP_WIDE build: three free bodies in the record, 26 / 18-wide
+    observations, one-kernel path).  reset() vs the fp32 oracle; a short rollout from the oracle's state vs the fp64 oracle
+    (joint state, north_star's 1e-3 relative bound for the contact-free phase); a reset(o); reproducibility bit for bit."""
+    from oracle import OracleEnv
+    from roboticsplayroompybullet_amd import VecPlayEnv
+    n = 4
+    env = VecPlayEnv(gid, n, seed=17)
+    assert env.wide and env.dims['obs_quat'] == 26 and env.dims['achieved_goal'] == 18 and env.dims['observation'] == 25
+    obs = env.reset()
+    torch.cuda.synchronize()
+    oracles = [OracleEnv(gid, seed=17, env_index=e, f32=True) for e in range(n)]
+    for e, o in enumerate(oracles):
+        oo = o.reset()
+        for k in ('obs_quat', 'achieved_goal', 'desired_goal', 'controllable_achieved_goal', 'full_positional_state', 'observation'):
+            np.testing.assert_allclose(obs[k][e].cpu().numpy(), oo[k], atol=1e-4, rtol=0, err_msg='%s env %d' % (k, e))
+        np.testing.assert_allclose(obs['joints'][e].cpu().numpy(), oo['joints'], atol=1e-4)
+    # rollout: same actions on both, device started from the fp64 oracle's post-reset state
+    o64 = [OracleEnv(gid, seed=17, env_index=e) for e in range(n)]
+    for o in o64:
+        o.reset()
+    env.set_state(torch.tensor(np.stack([wide_record_from_oracle(o) for o in o64])))
+    acts = family_actions(gid.replace('pandaPlay-v0', 'pandaPlay1Obj-v0').replace('pandaPlayJoints-v0', 'pandaPlayRelJoints1Obj-v0'), 30, n, 3)
+    worst = 0.0
+    for t in range(30):
+        ob, r, d, info = env.step(torch.tensor(acts[t], dtype=torch.float32))
+        q = env.get_state()[:, 0:9].cpu().numpy()
+        for e, o in enumerate(o64):
+            oo, ro, _, io = o.step(acts[t, e].astype(np.float32).astype(np.float64))
+            qo = o.get_state()[:9]
+            worst = max(worst, float((np.abs(q[e] - qo) / np.maximum(1.0, np.abs(qo))).max()))
+            np.testing.assert_allclose(info['target_poses'][e].cpu().numpy(), io['target_poses'], atol=2e-3, rtol=0)
+        assert int(info['status'].sum()) == 0
+    print('%s: relative joint divergence over 30 steps vs the fp64 oracle: %.2e' % (gid, worst))
+    assert worst <= 1e-3
+    for e, o in enumerate(o64):
+        oo = o.calc_state()
+        got = ob['obs_quat'][e].cpu().numpy()
+        np.testing.assert_allclose(got[[0, 1, 2, 7]], oo['obs_quat'][[0, 1, 2, 7]], atol=2e-3, rtol=0)          # EE position, gripper
+        np.testing.assert_allclose(got[[8, 9, 10, 15, 16, 17]], oo['obs_quat'][[8, 9, 10, 15, 16, 17]], atol=3e-3, rtol=0)   # both blocks
+    # reset(o): both blocks and the arm placed from observation vectors
+    rng = np.random.default_rng(2)
+    o_in = np.zeros((n, 28))
+    o_in[:, 0:3] = np.array([-0.1, 0.1, 0.25]) + 0.1 * rng.random((n, 3))
+    o_in[:, 3:7] = [0, 0, 0, 1]
+    o_in[:, 11:14] = np.array([-0.1, 0.1, 0.06]) + 0.05 * rng.random((n, 3))
+    o_in[:, 14:18] = [0, 0, 0.7071, 0.7071]
+    o_in[:, 21:24] = np.array([0.05, 0.15, 0.06]) + 0.05 * rng.random((n, 3))     # the second object is read 10 entries on (environments.py:544-556)
+    o_in[:, 24:28] = [0, 0, 0.7071, 0.7071]
+    env2 = VecPlayEnv(gid, n, seed=17)           # fresh: the same draw counter as the fresh oracle envs below
+    env2.reset()
+    ob2 = env2.reset(o=torch.tensor(o_in, dtype=torch.float32))
+    torch.cuda.synchronize()
+    for e in range(n):
+        orc = OracleEnv(gid, seed=17, env_index=e, f32=True)
+        orc.reset()
+        oo = orc.reset_to(np.float32(o_in[e]))
+        for k in ('obs_quat', 'achieved_goal', 'desired_goal'):
+            np.testing.assert_allclose(ob2[k][e].cpu().numpy(), oo[k], atol=1e-4, rtol=0, err_msg='%s env %d' % (k, e))
+    # reproducible bit for bit
+    a, b = VecPlayEnv(gid, 8, seed=5), VecPlayEnv(gid, 8, seed=5)
+    a.reset(); b.reset()
+    acts = torch.tensor(family_actions(gid.replace('pandaPlay-v0', 'pandaPlay1Obj-v0').replace('pandaPlayJoints-v0', 'pandaPlayRelJoints1Obj-v0'), 5, 8, 9), dtype=torch.float32)
+    for t in range(5):
+        a.step(acts[t]); b.step(acts[t])
+    assert torch.equal(a.get_state(), b.get_state())
+    # the single-env adapter with the reference surface
+    import roboticsplayroompybullet_amd as rp
+    env1 = rp.make(gid)
+    o1 = env1.reset()
+    assert o1['obs_quat'].shape == (26,) and o1['obs_quat'].dtype == np.float32 and o1['achieved_goal'].shape == (18,)
+    assert o1['observation'].shape == (25,) and o1['observation'].dtype == np.float64 and o1['full_positional_state'].shape == (26,)
+    o1, r1, d1, i1 = env1.step(env1.action_space.sample() * 0.05)
+    assert d1 is False and r1 in (0, -1) and i1['target_poses'].shape == (7,)
+    assert env1.compute_reward(o1['achieved_goal'], o1['desired_goal']) == r1
+    env1.close()

@@ -110,6 +110,28 @@ def test_panda_reach_and_play_surface(golden, gid):
     assert _lib.ACTION_TYPES[gid] == g['action_type'] and gid in _lib.ENV_KINDS
 
 
+@pytest.mark.parametrize('gid,cls', [('pandaPlay-v0', 'pandaPlay'), ('pandaPlayJoints-v0', 'pandaPlayRelJoints')])
+def test_two_object_play_surface(golden, gid, cls):
+    """pandaPlay-v0 / pandaPlayJoints-v0: registry entry, class name, spaces (two objects, two goals), attributes, ranges"""
+    reg = {e['id']: e['entry_point'].split(':')[1] for e in golden('registry.json')['registry']}
+    assert rp._REGISTRY[gid][0].split(':')[1] == reg[gid] == cls
+    g = golden('two_object_ids.json')[gid]['info']
+    env = getattr(envs, cls)()
+    assert env.ENV_ID == gid
+    np.testing.assert_array_equal(env.action_space.low, np.float32(g['action_low']))
+    np.testing.assert_array_equal(env.action_space.high, np.float32(g['action_high']))
+    for k, b in g['observation_space'].items():
+        np.testing.assert_array_equal(env.observation_space.spaces[k].low, np.float32(b['low']), err_msg=k)
+        np.testing.assert_array_equal(env.observation_space.spaces[k].high, np.float32(b['high']), err_msg=k)
+    for attr in ('num_objects', 'num_goals', 'play', 'use_orientation', 'return_velocity', 'action_type', 'arm_type'):
+        assert getattr(env, attr) == g[attr], attr
+    assert env._max_episode_steps == g['max_episode_steps']
+    for a in ('goal_lower_bound', 'goal_upper_bound', 'env_lower_bound', 'env_upper_bound', 'obj_lower_bound', 'obj_upper_bound'):
+        np.testing.assert_allclose(getattr(env, a), g[a])
+    from roboticsplayroompybullet_amd import _lib
+    assert _lib.ACTION_TYPES[gid] == g['action_type'] and gid in _lib.ENV_KINDS and gid in _lib.WIDE_IDS
+
+
 def test_out_of_scope_surface_fails_loudly():
     with pytest.raises(NotImplementedError):
         envs.playEnv(action_type='relative_quat')
