@@ -146,6 +146,25 @@ class VecPlayEnv:
             s = s[None]
         _lib.check(self.lib, self.h, self.lib.rp_set_state(self.h, C.c_void_p(s.data_ptr()), s.shape[0], self._stream()), 'rp_set_state')
 
+    def replay(self, o0, actions, keys=('obs_quat', 'achieved_goal')):
+        """Play recorded trajectories back (the reference's README use: "playing out the teleop data", "reset the environment to
+        specific locations"): every env is placed from its first recorded observation o0[e] with reset(o) - objects and arm from
+        the observation vector, nothing settles - then the recorded actions [T, N, action] are stepped open loop.  Returns
+        {key: [T + 1, N, dim]} (index 0 = after the reset) plus 'reward' and 'is_success' [T, N]."""
+        obs = self.reset(o=o0)
+        out = {k: [obs[k].clone()] for k in keys}
+        rew, suc = [], []
+        for t in range(actions.shape[0]):
+            obs, r, _, info = self.step(actions[t])
+            for k in keys:
+                out[k].append(obs[k].clone())
+            rew.append(r.clone())
+            suc.append(info['is_success'].clone())
+        res = {k: torch.stack(v) for k, v in out.items()}
+        res['reward'] = torch.stack(rew) if rew else torch.zeros((0, self.num_envs), device=self.device)
+        res['is_success'] = torch.stack(suc) if suc else torch.zeros((0, self.num_envs), dtype=torch.int32, device=self.device)
+        return res
+
     def set_fused(self, mode=1):
         """step pipeline: 0 = default (k_action, k_prep2, k_solve2, k_calc_state), 1 = one fused kernel per step (the
         library's in-GPU cross-check path).  Both are bit-identical."""

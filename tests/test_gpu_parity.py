@@ -708,3 +708,36 @@ def test_two_object_play_ids_vs_oracle(gid):
     assert d1 is False and r1 in (0, -1) and i1['target_poses'].shape == (7,)
     assert env1.compute_reward(o1['achieved_goal'], o1['desired_goal']) == r1
     env1.close()
+
+
+def test_replay_of_recorded_trajectories():
+    """VecPlayEnv.replay: trajectories recorded on the fp32 oracle (first observation + actions) played back on the device -
+    reset(o) from the recorded observation, then the actions open loop; the block and EE positions track the recording."""
+    from oracle import OracleEnv
+    from roboticsplayroompybullet_amd import VecPlayEnv
+    n, T = 4, 15
+    rng = np.random.default_rng(8)
+    o0, acts, rec = [], np.zeros((T, n, 7)), []
+    for e in range(n):
+        orc = OracleEnv('U', seed=30, env_index=e, f32=True)
+        orc.reset()
+        o = np.zeros(18)
+        o[0:3] = np.array([-0.1, 0.1, 0.25]) + 0.1 * rng.random(3)
+        o[3:7] = [0, 0, 0, 1]
+        o[11:14] = np.array([-0.1, 0.1, 0.0]) + np.array([0.1, 0.1, 0.0]) * rng.random(3)      # resting on the table top
+        o[14:18] = [0, 0, 0.7071, 0.7071]
+        first = orc.reset_to(np.float32(o))
+        o0.append(np.float32(o))
+        traj = [first['obs_quat']]
+        for t in range(T):
+            a = np.concatenate([o[0:3] + 0.05 * (rng.random(3) - 0.5), 0.2 * (rng.random(3) - 0.5), [rng.uniform(-1, 1)]])
+            acts[t, e] = a
+            traj.append(orc.step(a)[0]['obs_quat'])
+        rec.append(np.stack(traj))
+    env = VecPlayEnv(IDS['U'], n, seed=30)
+    env.reset()
+    out = env.replay(torch.tensor(np.stack(o0)), torch.tensor(acts, dtype=torch.float32))
+    got = out['obs_quat'].cpu().numpy()                    # [T + 1, n, 19]
+    assert got.shape == (T + 1, n, 19) and out['reward'].shape == (T, n)
+    for e in range(n):
+        np.testing.assert_allclose(got[:, e, [0, 1, 2, 7, 8, 9, 10]], rec[e][:, [0, 1, 2, 7, 8, 9, 10]], atol=5e-4, rtol=0, err_msg='env %d' % e)
