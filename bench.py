@@ -6,7 +6,8 @@
         bench.py --gpus 8 --steps 200 --warmup 20
 
 One "step" = one playEnv.step() for every env of the batch (one rp_step call): clip -> AbsRPY IK -> motor targets
-(k_action) -> 12 physics substeps at 300 Hz (k_prep2 + k_solve2 each) -> observation + reward (k_calc_state).
+(k_action; in the default pipeline fused with the first k_prep2 into one launch, k_action_prep) -> 12 physics substeps at 300 Hz
+(k_prep2 + k_solve2 each) -> observation + reward (k_calc_state).
 Per-launch durations are measured with hipEvents recorded on the launch stream inside rp_step over the whole timed
 region (rp_enable_timers / rp_get_timers); the roofline object is for the dominant kernel, k_solve2.  Actions are synthetic
 (distribution B of SURVEY.md §8d: workspace-uniform, resampled every step), pre-generated on the device so the timed

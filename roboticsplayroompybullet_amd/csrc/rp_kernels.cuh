@@ -1930,10 +1930,10 @@ __global__ void k_copy_state(float* __restrict__ dst, const float* __restrict__ 
  *          k_solve2 (two envs per wave: PGS sweeps on register-resident rows + integration, state record in/out) }
  *   k_calc_state (wave per env) calc_state + reward + outputs */
 /* perform_action (environments.py:915-1073), 16 lanes (one DPP row) per env, four envs per wave: cooperative IK */
-__global__ void __launch_bounds__(64) k_action(const DevModel* __restrict__ m, float* __restrict__ state, const float* __restrict__ action,
-                                              float* __restrict__ target_poses, int env0, int N, const int* __restrict__ member) {
+__device__ __forceinline__ void action_body(const DevModel* __restrict__ m, float* __restrict__ state, const float* __restrict__ action,
+                                            float* __restrict__ target_poses, int env0, int N, const int* __restrict__ member, const int bid) {
   const int l16 = threadIdx.x & 15;
-  const int env_raw = env0 + blockIdx.x * 4 + (threadIdx.x >> 4);      /* this launch covers places [env0, N) of its group */
+  const int env_raw = env0 + bid * 4 + (threadIdx.x >> 4);      /* this launch covers places [env0, N) of its group */
   const bool live = env_raw < N;
   const int place = live ? env_raw : env0;
   const int env = member ? member[place] : place;
@@ -1979,6 +1979,11 @@ __global__ void __launch_bounds__(64) k_action(const DevModel* __restrict__ m, f
       for (int i = 0; i < 6; i++) { st[ST_MMODE + ds[i]] = 1.f; st[ST_MTARGET + ds[i]] = tg[i]; st[ST_MMAXIMP + ds[i]] = fo[i] * K_DT; }
     }
   }
+}
+
+__global__ void __launch_bounds__(64) k_action(const DevModel* __restrict__ m, float* __restrict__ state, const float* __restrict__ action,
+                                              float* __restrict__ target_poses, int env0, int N, const int* __restrict__ member) {
+  action_body(m, state, action, target_poses, env0, N, member, blockIdx.x);
 }
 
 __device__ __forceinline__ void copy_out(float* __restrict__ dst, const float* src, int nfloat, int lane) {
@@ -2042,12 +2047,12 @@ static_assert(W3_A % 4 == 0 && W3_ROWS % 4 == 0 && W3_ROFF % 4 == 0 && AOUT_FLOA
 
 __device__ __forceinline__ void prep2_body(const DevModel* __restrict__ m, const float* __restrict__ state, float* __restrict__ ws, int env0, int N,
                                                              const int* __restrict__ sort_cnt, int* __restrict__ sort_cnt_next, const int* __restrict__ sort_slot, int* __restrict__ pair_env,
-                                                  const int* __restrict__ member) {
+                                                  const int* __restrict__ member, const int bid) {
   __shared__ EnvLds L;
-  int env = env0 + blockIdx.x, lane = threadIdx.x;
+  int env = env0 + bid, lane = threadIdx.x;
   if (env >= N) return;
   if (member) env = member[env];     /* this block's place in its group -> env (groups are cut by load, see k_member) */
-  if (blockIdx.x == 0)               /* the histogram that the k_solve2 after this launch fills (for the substep after it) starts at zero */
+  if (bid == 0)               /* the histogram that the k_solve2 after this launch fills (for the substep after it) starts at zero */
     for (int i = lane; i < SORT_BINS; i += 64) sort_cnt_next[i] = 0;
   /* pairing table for the k_solve2 after this launch: this env's place among the envs of its group sorted by load class,
    * heaviest first = envs in heavier (class, replica) bins + its rank inside its bin (both from the previous k_solve2).
@@ -2162,8 +2167,21 @@ __device__ __forceinline__ void prep2_body(const DevModel* __restrict__ m, const
 #define PREP2_ARGS const DevModel* __restrict__ m, const float* __restrict__ state, float* __restrict__ ws, int env0, int N, \
                    const int* __restrict__ sort_cnt, int* __restrict__ sort_cnt_next, const int* __restrict__ sort_slot, int* __restrict__ pair_env, \
                    const int* __restrict__ member
-__global__ void __launch_bounds__(64, RP_PREP_WAVES) k_prep2(PREP2_ARGS) { prep2_body(m, state, ws, env0, N, sort_cnt, sort_cnt_next, sort_slot, pair_env, member); }
-__global__ void __launch_bounds__(64, RP_PREP_WAVES) k_settle_prep(PREP2_ARGS) { prep2_body(m, state, ws, env0, N, sort_cnt, sort_cnt_next, sort_slot, pair_env, member); }
+__global__ void __launch_bounds__(64, RP_PREP_WAVES) k_prep2(PREP2_ARGS) { prep2_body(m, state, ws, env0, N, sort_cnt, sort_cnt_next, sort_slot, pair_env, member, blockIdx.x); }
+__global__ void __launch_bounds__(64, RP_PREP_WAVES) k_settle_prep(PREP2_ARGS) { prep2_body(m, state, ws, env0, N, sort_cnt, sort_cnt_next, sort_slot, pair_env, member, blockIdx.x); }
+/* First substep of a step: the action kernel and the first k_prep2 in ONE launch.  Nothing k_prep2 builds depends on the new motor
+ * targets except the motor rows themselves (v*, M^-1, contacts and limit rows see q and qd only), so the nab action blocks (first in
+ * the grid: they are the long pole, ~80 dependent IK iterations) and the prep blocks of the same envs run side by side instead of
+ * one after the other, and the k_solve2 that follows rebuilds the motor rows from the record (debug/flag bit 1) with the formula
+ * of build_small_rows.  The prep blocks may read motor fields that an action block is writing: those values only reach the rows
+ * that are rebuilt. */
+__global__ void __launch_bounds__(64, RP_PREP_WAVES) k_action_prep(const DevModel* __restrict__ m, float* __restrict__ state, float* __restrict__ ws, int env0, int N,
+                                                                   const int* __restrict__ sort_cnt, int* __restrict__ sort_cnt_next, const int* __restrict__ sort_slot,
+                                                                   int* __restrict__ pair_env, const int* __restrict__ member, const float* __restrict__ action,
+                                                                   float* __restrict__ target_poses, int nab) {
+  if ((int)blockIdx.x < nab) action_body(m, state, action, target_poses, env0, N, member, blockIdx.x);
+  else prep2_body(m, state, ws, env0, N, sort_cnt, sort_cnt_next, sort_slot, pair_env, member, blockIdx.x - nab);
+}
 
 
 struct __align__(16) Solve2Lds {
@@ -2354,6 +2372,13 @@ __device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, floa
   X0.hi = row0 ? ldz(&wa[48 + ia], arm_lane) : ldz(&bj[12 + kj], jl);
   PL.rhs = ldz(&wa[64 + ia], arm_lane); PL.lo = ldz(&wa[80 + ia], arm_lane); PL.hi = ldz(&wa[96 + ia], arm_lane);
   PU.rhs = ldz(&wa[112 + ia], arm_lane); PU.lo = ldz(&wa[128 + ia], arm_lane); PU.hi = ldz(&wa[144 + ia], arm_lane);
+  if (debug_flags & 2) {      /* first substep after k_action_prep: the motor rows from the record's fresh targets (build_small_rows' formula) */
+    const float* r = state + (size_t)(valid ? env : 0) * RP_REC_FLOATS;
+    const float mode = r[ST_MMODE + ia], tgt = r[ST_MTARGET + ia], mx = r[ST_MMAXIMP + ia], qi = r[ST_Q + ia];
+    const float des = mode != 0.f ? K_KP * (tgt - qi) / K_DT : 0.f;
+    const float rhs = (des - vstar) * dinvX;
+    if (arm_lane) { X0.rhs = rhs; X0.lo = -mx; X0.hi = mx; }
+  }
   float Jg = 0.f, Bg = 0.f;                 /* Panda finger gear: J = e_a + ratio e_b, scalars at lane GEAR_LANE of plane U */
   {
     const float* g = w + W3_GEAR;

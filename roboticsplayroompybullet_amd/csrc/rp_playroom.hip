@@ -317,10 +317,19 @@ int rp_step(rp_handle h, const float* action, const rp_out* out, void* stream) {
       int* gcnt[2] = {h->sort_cnt + (size_t)g * SORT_BINS, h->sort_cnt + (size_t)(RP_MAX_GROUPS + g) * SORT_BINS};
       int par = h->sort_par;
       if (h->sort_G == 0) hipLaunchKernelGGL(k_sort_init, dim3((max(ng, SORT_BINS) + 255) / 256), dim3(256), 0, gs, gcnt[par], h->sort_slot, e0, ng);
-      TIMED(hipLaunchKernelGGL(k_action, dim3((ng + 3) / 4), dim3(64), 0, gs, h->dev_model, h->state, action, op.target_poses, e0, e1, member));
+      /* first substep: action kernel and first k_prep2 in one launch (k_action_prep), the motor rows rebuilt by the k_solve2 after
+       * it (flag bit 1); with per-launch timers on, the kernels stay apart so that every event pair brackets one of them */
+      const int nab = (ng + 3) / 4;
+      if (ev) TIMED(hipLaunchKernelGGL(k_action, dim3(nab), dim3(64), 0, gs, h->dev_model, h->state, action, op.target_poses, e0, e1, member));
       for (int sub = 0; sub < K_NSUB; sub++) {
-        TIMED(hipLaunchKernelGGL(k_prep2, dim3(ng), dim3(64), 0, gs, h->dev_model, h->state, h->ws, e0, e1, gcnt[par], gcnt[par ^ 1], h->sort_slot, h->pair_env, member));
-        TIMED(hipLaunchKernelGGL(k_solve2, dim3((ng + 1) / 2), dim3(64), 0, gs, h->dev_model, h->state, h->ws, e0, e1, h->pair_env, gcnt[par ^ 1], h->sort_slot, h->debug_flags));
+        const bool merged = !ev && sub == 0;
+        if (merged)
+          hipLaunchKernelGGL(k_action_prep, dim3(nab + ng), dim3(64), 0, gs, h->dev_model, h->state, h->ws, e0, e1, gcnt[par], gcnt[par ^ 1], h->sort_slot,
+                             h->pair_env, member, action, op.target_poses, nab);
+        else
+          TIMED(hipLaunchKernelGGL(k_prep2, dim3(ng), dim3(64), 0, gs, h->dev_model, h->state, h->ws, e0, e1, gcnt[par], gcnt[par ^ 1], h->sort_slot, h->pair_env, member));
+        TIMED(hipLaunchKernelGGL(k_solve2, dim3((ng + 1) / 2), dim3(64), 0, gs, h->dev_model, h->state, h->ws, e0, e1, h->pair_env, gcnt[par ^ 1], h->sort_slot,
+                                 h->debug_flags | (merged ? 2 : 0)));
         par ^= 1;
       }
       if (g == G - 1) { h->sort_par = par; h->sort_G = G; h->gb = gb; }
@@ -375,7 +384,7 @@ int rp_set_state(rp_handle h, const void* src, int32_t src_env_count, void* stre
   return RP_OK;
 }
 
-int rp_set_debug_flags(rp_handle h, int32_t flags) { if (!h) return RP_ERR_ARG; h->debug_flags = flags; return RP_OK; }
+int rp_set_debug_flags(rp_handle h, int32_t flags) { if (!h) return RP_ERR_ARG; h->debug_flags = flags & 1; return RP_OK; }   /* bit 1 is internal (k_action_prep) */
 int rp_set_groups(rp_handle h, int32_t groups) { if (!h || groups < 1 || groups > RP_MAX_GROUPS) return RP_ERR_ARG; h->groups = groups; return RP_OK; }
 int rp_set_fused(rp_handle h, int32_t fused) {
   if (!h || (fused != 0 && fused != 1)) return RP_ERR_ARG;
