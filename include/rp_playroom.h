@@ -52,8 +52,8 @@ enum rp_env_kind {
   RP_ENV_PANDA_PLAY_REL_RPY_1OBJ = 16,    /* relative_rpy    */
   /* the two-object play ids (__init__.py:29, 41; envList.py:28-41): Panda + complex_scene with two blocks.  Served by the
    * RP_WIDE build of this library (librp_playroom_hip_wide.so: three free bodies in the state record, observations 26 / 18 wide,
-   * every step through the one-kernel path); librp_playroom_hip.so answers RP_ERR_UNSUPPORTED for them, and the wide build
-   * for every other id. */
+   * the drawer in the arm's half of the solver's lane layout); librp_playroom_hip.so answers RP_ERR_UNSUPPORTED for them, and
+   * the wide build for every other id. */
   RP_ENV_PANDA_PLAY = 17,                 /* pandaPlay-v0: absolute_quat */
   RP_ENV_PANDA_PLAY_JOINTS = 18,          /* pandaPlayJoints-v0: relative_joints */
   RP_ENV_COUNT = 19

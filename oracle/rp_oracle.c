@@ -427,17 +427,23 @@ static void collide(rpo_env* e) {
       }
     }
   }
-  /* solver order: contacts that span arm and non-arm dofs (arm link against a free body or a scene joint) go last,
-   * everything else keeps its order (stable partition).  Rows on disjoint dof sets commute, so among the first group
-   * the arm-only and the non-arm contacts may be (and, on the GPU, are) solved side by side. */
+  /* solver order: contacts that span the two halves of the velocity vector go last, everything else keeps its order (stable
+   * partition).  First half: the arm - and, in the two-block model W, the drawer (rp_model.free_row0) -, second half: the other
+   * free bodies and the scene joints; for every other model "spanning" reads "arm link against a free body or a scene joint".
+   * Rows on disjoint dof sets commute, so among the first group the contacts of either half may be (and, on the GPU, are)
+   * solved side by side. */
   {
     contact tmp[MAX_CONTACTS]; int k = 0;
     for (int pass = 0; pass < 2; pass++)
       for (int i = 0; i < e->ncon; i++) {
-        int ba = m->col_body[e->con[i].ca], bb = m->col_body[e->con[i].cb];
-        int arm = (ba >= 1 && ba <= m->n_arm) || (bb >= 1 && bb <= m->n_arm);
-        int dyn = ba > m->n_arm || bb > m->n_arm;
-        if ((arm && dyn) == pass) tmp[k++] = e->con[i];
+        int half0 = 0, half1 = 0;
+        for (int side = 0; side < 2; side++) {
+          int b = m->col_body[side == 0 ? e->con[i].ca : e->con[i].cb];
+          if (b == 0) continue;
+          int f = b - 1 - m->n_arm;
+          if (b <= m->n_arm || (f < m->n_free && ((m->free_row0 >> f) & 1))) half0 = 1; else half1 = 1;
+        }
+        if ((half0 && half1) == pass) tmp[k++] = e->con[i];
       }
     for (int i = 0; i < e->ncon; i++) e->con[i] = tmp[i];
   }

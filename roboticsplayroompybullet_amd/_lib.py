@@ -9,7 +9,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB_PATH = os.environ.get('RP_PLAYROOM_LIB', os.path.join(CSRC, 'librp_playroom_hip.so'))   # env override: profiling builds
-# the RP_WIDE build of the same sources: the two-object play ids (three free bodies in the record, one-kernel path only)
+# the RP_WIDE build of the same sources: the two-object play ids (three free bodies in the record, the drawer in the arm's DPP row)
 WIDE_LIB_PATH = os.path.join(CSRC, 'librp_playroom_hip_wide.so')
 WIDE_IDS = ('pandaPlay-v0', 'pandaPlayJoints-v0')
 

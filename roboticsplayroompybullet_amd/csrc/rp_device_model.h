@@ -31,7 +31,7 @@
 #define ST_STATUS 118
 #else
 /* RP_WIDE build (librp_playroom_hip_wide.so): the two-object play ids - Panda only (9 arm dofs), three free bodies (block,
- * block, drawer), 18-wide goal.  Same 128-float record, other offsets.  The sign memory keeps obs[3:7], obs[11:15] (= ag[3:7]:
+ * block, drawer), 18-wide goal.  Same 128-float record, other offsets; lane layout: rp_kernels.cuh lane_pos.  The sign memory keeps obs[3:7], obs[11:15] (= ag[3:7]:
  * the same quaternion with the same history, so one copy serves both), obs[19:23] and ag[10:14]. */
 #define ST_NARM 9
 #define ST_NFREE 3
@@ -57,7 +57,7 @@
 
 typedef struct DevModel {
   int kind, n_arm, n_free, n_j1, n_col, n_pair, nv, nbody, n_site;
-  int arm_type, scene, drawer_free;
+  int arm_type, scene, drawer_free, free_row0;
   int play, use_orientation, return_velocity, num_objects, n_goal_init;
   int n_obs, n_ag, n_fps, n_observation, n_target;
   int action_type, n_action;    /* RP_ACT_* (environments.py:915-934) and the action length: 7, 8 (quaternion types) or n_target + 1 (joint types) */
@@ -163,7 +163,7 @@ static inline void rp_build_dev_model(const rp_model* m, DevModel* d) {
   }
   memcpy(d->pair, m->pair, sizeof(d->pair));
   int isP = m->arm_type == RP_ARM_PANDA;
-  d->arm_type = m->arm_type; d->scene = m->scene; d->drawer_free = m->drawer_free;
+  d->arm_type = m->arm_type; d->scene = m->scene; d->drawer_free = m->drawer_free; d->free_row0 = m->free_row0;
   d->d_grip_obs = rp_dm_dof_of_joint(m, isP ? 9 : 18);
   d->d18 = rp_dm_dof_of_joint(m, 18); d->d20 = rp_dm_dof_of_joint(m, 20); d->d12 = rp_dm_dof_of_joint(m, 12);
   d->d15 = rp_dm_dof_of_joint(m, 15); d->d10 = rp_dm_dof_of_joint(m, 10); d->d13 = rp_dm_dof_of_joint(m, 13);

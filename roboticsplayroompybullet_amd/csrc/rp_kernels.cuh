@@ -144,18 +144,25 @@ __device__ __forceinline__ int lane_dof(const DevModel* m, int l) {       /* inv
   return l - LANE_FREE < 6 * m->n_free ? m->n_arm + (l - LANE_FREE) : -1;
 }
 #else
-/* RP_WIDE (fused path only, no DPP-row structure needed): arm dofs 0..8, scene joints 9..11, three free bodies 12..29 */
-#define LANE_J1 9
-#define LANE_FREE 12
+/* RP_WIDE (two blocks + drawer, Panda): DPP row 0 = arm dofs 0..8 and the drawer's six components at lanes 9..14 (the arm's row
+ * has room for them, the other row does not); DPP row 1 = scene joints 16..18, the two blocks at 19..30.  Contacts are classed
+ * by the rows they touch (collide()), so a drawer-against-stop contact rides in row 0 next to a block-against-table contact in
+ * row 1, and drawer-against-block folds like arm-against-block. */
+#define LANE_J1 16
+#define LANE_FREE 19
 __device__ __forceinline__ int lane_pos(const DevModel* m, int d) {
   if (d < m->n_arm) return d;
-  int f6 = 6 * m->n_free;
-  return d - m->n_arm < f6 ? LANE_FREE + (d - m->n_arm) : LANE_J1 + (d - m->n_arm - f6);
+  const int e = d - m->n_arm, f6 = 6 * m->n_free;
+  if (e >= f6) return LANE_J1 + (e - f6);
+  const int f = e / 6, c = e - 6 * f;
+  return f == m->drawer_free ? m->n_arm + c : LANE_FREE + 6 * f + c;        /* the blocks are free bodies 0 and 1 */
 }
 __device__ __forceinline__ int lane_dof(const DevModel* m, int l) {
-  if (l < LANE_J1) return l < m->n_arm ? l : -1;
+  if (l < m->n_arm) return l;
+  if (l < 16) return l - m->n_arm < 6 ? m->n_arm + 6 * m->drawer_free + (l - m->n_arm) : -1;
+  if (l >= 32) return -1;
   if (l < LANE_FREE) return l - LANE_J1 < m->n_j1 ? m->n_arm + 6 * m->n_free + (l - LANE_J1) : -1;
-  return l - LANE_FREE < 6 * m->n_free ? m->n_arm + (l - LANE_FREE) : -1;
+  return l - LANE_FREE < 12 ? m->n_arm + (l - LANE_FREE) : -1;
 }
 #endif
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
@@ -652,8 +659,11 @@ __device__ int collide(const DevModel* m, EnvLds& L, int lane) {
     int pi = __float_as_int(L.u.c.cand[lane * 32 + 7]);
     ia = m->pair[pi][0]; ib = m->pair[pi][1];
     int ba = m->col_body[ia], bb = m->col_body[ib];
-    bool arm = (ba >= 1 && ba <= n) || (bb >= 1 && bb <= n), dyn = ba > n || bb > n;
-    cls = arm ? (dyn ? 2 : 1) : 0;
+    /* which halves of the velocity layout the contact touches: DPP row 0 = the arm (and the free bodies of free_row0: W's
+     * drawer), DPP row 1 = the other free bodies and the scene joints */
+    auto half0 = [&](int b) { int f = b - 1 - n; return b >= 1 && (b <= n || (f < m->n_free && ((m->free_row0 >> f) & 1))); };
+    bool r0 = half0(ba) || half0(bb), r1 = (ba >= 1 && !half0(ba)) || (bb >= 1 && !half0(bb));
+    cls = r0 ? (r1 ? 2 : 1) : 0;
   }
   int nN_before = 0, nC_before = 0, nN_total = 0, total = 0;
 #pragma unroll

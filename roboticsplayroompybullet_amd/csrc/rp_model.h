@@ -43,6 +43,8 @@ typedef struct rp_model {
   int kind, n_arm, n_free, n_joint1, n_col, n_pair, n_site;
   int arm_type, scene;              /* RP_ARM_*, RP_SCENE_*: what the kind is made of */
   int drawer_free;                  /* index of the drawer among the free bodies (the objects come first), -1 = none */
+  int free_row0;                    /* bit f: free body f shares the arm's half of the solver's velocity layout (W: the drawer); contacts
+                                     * are ordered by which halves they touch (see collide / rp_oracle.c) */
   /* arm (tree, parents precede children) */
   int arm_parent[RP_MAX_ARM];       /* movable parent (0-based) or -1 = base */
   int arm_jtype[RP_MAX_ARM];        /* 0 revolute, 1 prismatic */

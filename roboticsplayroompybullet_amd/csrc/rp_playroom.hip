@@ -112,9 +112,6 @@ int rp_create(const rp_config* cfg, rp_handle* out) {
     const float gl[3] = {-0.18f, -0.18f, -0.06f}, gh[3] = {0.18f, 0.18f, -0.05f}, eh[3] = {0.18f, 0.18f, 0.0f};
     for (int k = 0; k < 3; k++) { d->goal_lo[k] = gl[k]; d->goal_hi[k] = gh[k]; d->env_hi[k] = eh[k]; }
   }
-#ifdef RP_WIDE
-  h->fused = 1;            /* the wide record and lane layout exist for the one-kernel path only */
-#endif
   h->host_model.action_type = action_type;
   h->host_model.n_action = (action_type == RP_ACT_ABS_QUAT || action_type == RP_ACT_REL_QUAT) ? 8
                          : ((action_type == RP_ACT_ABS_JOINTS || action_type == RP_ACT_REL_JOINTS) ? h->host_model.n_target + 1 : 7);
@@ -391,9 +388,6 @@ int rp_set_debug_flags(rp_handle h, int32_t flags) { if (!h) return RP_ERR_ARG; 
 int rp_set_groups(rp_handle h, int32_t groups) { if (!h || groups < 1 || groups > RP_MAX_GROUPS) return RP_ERR_ARG; h->groups = groups; return RP_OK; }
 int rp_set_fused(rp_handle h, int32_t fused) {
   if (!h || (fused != 0 && fused != 1)) return RP_ERR_ARG;
-#ifdef RP_WIDE
-  if (fused != 1) { snprintf(h->err, 256, "rp_set_fused: the wide build has the one-kernel path only"); return RP_ERR_UNSUPPORTED; }
-#endif
   h->fused = fused;
   return RP_OK;
 }

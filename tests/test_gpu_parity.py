@@ -691,13 +691,34 @@ def test_two_object_play_ids_vs_oracle(gid):
         oo = orc.reset_to(np.float32(o_in[e]))
         for k in ('obs_quat', 'achieved_goal', 'desired_goal'):
             np.testing.assert_allclose(ob2[k][e].cpu().numpy(), oo[k], atol=1e-4, rtol=0, err_msg='%s env %d' % (k, e))
-    # reproducible bit for bit
-    a, b = VecPlayEnv(gid, 8, seed=5), VecPlayEnv(gid, 8, seed=5)
-    a.reset(); b.reset()
-    acts = torch.tensor(family_actions(gid.replace('pandaPlay-v0', 'pandaPlay1Obj-v0').replace('pandaPlayJoints-v0', 'pandaPlayRelJoints1Obj-v0'), 5, 8, 9), dtype=torch.float32)
-    for t in range(5):
-        a.step(acts[t]); b.step(acts[t])
+    # split pipeline (default; the drawer rides in the arm's DPP row) == one-kernel path, bit for bit: reset, then steps that push
+    # the gripper onto a block (arm, block, drawer and table contacts together)
+    nb = 33
+    a, b = VecPlayEnv(gid, nb, seed=5), VecPlayEnv(gid, nb, seed=5)
+    b.set_fused(1)
+    oa, ob = a.reset(), b.reset()
+    torch.cuda.synchronize()
     assert torch.equal(a.get_state(), b.get_state())
+    seen = 0
+    for t in range(16):
+        if gid == 'pandaPlay-v0':
+            at = torch.zeros((nb, 8), device='cuda')
+            at[:, 0:3] = oa['achieved_goal'][:, (0, 1, 2) if t % 2 == 0 else (7, 8, 9)]
+            at[:, 2] += 0.01
+            at[:, 6] = 1.0
+            at[:, 7] = -1.0 if t < 8 else 1.0
+        else:
+            at = torch.tensor(family_actions('pandaPlayRelJoints1Obj-v0', 1, nb, 40 + t)[0], dtype=torch.float32)
+        oa, ra, _, ia = a.step(at)
+        ob, rb, _, ib = b.step(at)
+        rc = a.debug_row_counts()
+        seen = max(seen, int(rc[:, 1].max()))
+    torch.cuda.synchronize()
+    assert torch.equal(a.get_state(), b.get_state())
+    for k in ('obs_quat', 'achieved_goal', 'observation'):
+        assert torch.equal(oa[k], ob[k]), k
+    assert torch.equal(ia['target_poses'], ib['target_poses'])
+    assert seen >= 8                                   # the drawer on its stops and the blocks on the table at the very least
     # the single-env adapter with the reference surface
     import roboticsplayroompybullet_amd as rp
     env1 = rp.make(gid)
@@ -762,6 +783,3 @@ def test_error_codes_of_the_c_abi():
     assert b'18' in env.lib.rp_last_error(env.h)
     with pytest.raises(RuntimeError):
         env.set_fused(2)
-    w = VecPlayEnv('pandaPlay-v0', 2, seed=1)
-    with pytest.raises(RuntimeError):
-        w.set_fused(0)                                     # the wide build has the one-kernel path only
