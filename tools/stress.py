@@ -7,7 +7,7 @@ from roboticsplayroompybullet_amd import VecPlayEnv
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 for gid in ['UR5PlayAbsRPY1Obj-v0', 'pandaPlayAbsRPY1Obj-v0', 'pandaPick-v0', 'pandaPush-v0', 'UR5Reach-v0', 'pandaReach2D-v0',
-            'UR5PlayRelJoints1Obj-v0', 'pandaPlayAbsJoints1Obj-v0', 'UR5Play1Obj-v0']:
+            'UR5PlayRelJoints1Obj-v0', 'pandaPlayAbsJoints1Obj-v0', 'UR5Play1Obj-v0', 'pandaPlay-v0', 'pandaPlayJoints-v0']:
     n = 4096
     env = VecPlayEnv(gid, n, seed=3)
     env.reset()
@@ -22,10 +22,11 @@ for gid in ['UR5PlayAbsRPY1Obj-v0', 'pandaPlayAbsRPY1Obj-v0', 'pandaPick-v0', 'p
         bad += info['status']
         if t % 50 == 49:
             s = env.get_state()
-            vmax = max(vmax, float(s[:, 12:24].abs().max()), float(s[:, 31:37].abs().max()))
+            L = env.state_layout
+            vmax = max(vmax, float(s[:, L['qd'][0]:L['qd'][1]].abs().max()), float(s[:, L['free0'][0] + 7:L['free0'][1]].abs().max()))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     s = env.get_state()
     print('%-26s %d steps: envs ever flagged %d, non-finite records %d, max |qd| / |block v| seen %.1f, block z min %.3f, %.2f M env-steps/s'
-          % (gid, steps, int((bad > 0).sum()), int((~torch.isfinite(s).all(dim=1)).sum()), vmax, float(s[:, 26].min()), n * steps / dt / 1e6))
+          % (gid, steps, int((bad > 0).sum()), int((~torch.isfinite(s).all(dim=1)).sum()), vmax, float(s[:, env.state_layout['free0'][0] + 2].min()), n * steps / dt / 1e6))
     env.close()
