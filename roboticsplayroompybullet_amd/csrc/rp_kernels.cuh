@@ -1935,7 +1935,7 @@ __global__ void k_copy_state(float* __restrict__ dst, const float* __restrict__ 
 /* ------------------------------------------------------------------ split pipeline for rp_step
  * The fused substep() above needs > 256 VGPRs in its cold phases (IK, narrowphase, row build) although the hot PGS
  * loop needs ~60, so rp_step runs right-sized kernels instead:
- *   k_action  (thread per env)  clip + absolute-RPY IK + motor targets            -> state records
+ *   k_action  (16 lanes per env) clip + action type -> IK target + IK + motor targets -> state records (one launch with the first k_prep2: k_action_prep)
  *   12 x { k_prep2 (wave per env: FK, collision, dynamics, constraint rows -> per-env workspace, L2/MALL resident)
  *          k_solve2 (two envs per wave: PGS sweeps on register-resident rows + integration, state record in/out) }
  *   k_calc_state (wave per env) calc_state + reward + outputs */

@@ -273,7 +273,7 @@ int rp_step(rp_handle h, const float* action, const rp_out* out, void* stream) {
     OutPtrs op = to_ptrs(out);
     hipEvent_t* ev = h->pool ? h->pool + (size_t)h->pool_next * EV_PER_STEP : nullptr;
     /* Env groups: substeps of different envs are independent, so the envs are cut into `groups` contiguous ranges and
-     * each range runs its own 26-kernel chain on its own stream; the tail of one group's k_solve2 (its heaviest wave)
+     * each range runs its own 25-kernel chain on its own stream; the tail of one group's k_solve2 (its heaviest wave)
      * overlaps with the other groups' kernels.  Per-launch timing (rp_enable_timers) uses one group so that the event
      * pairs bracket exactly one kernel each. */
     int G = ev ? 1 : h->groups;
