@@ -783,3 +783,23 @@ def test_error_codes_of_the_c_abi():
     assert b'18' in env.lib.rp_last_error(env.h)
     with pytest.raises(RuntimeError):
         env.set_fused(2)
+
+
+def test_create_destroy_does_not_leak():
+    """rp_create / rp_destroy release what they take (device buffers incl. the lazily allocated reset scratch, streams, events)."""
+    from roboticsplayroompybullet_amd import VecPlayEnv
+    def cycle():
+        for gid in ('UR5PlayAbsRPY1Obj-v0', 'pandaPick-v0', 'pandaPlay-v0'):
+            env = VecPlayEnv(gid, 512, seed=2)
+            env.reset()
+            env.step(torch.zeros((512, env.dims['action']), device='cuda'))
+            torch.cuda.synchronize()
+            env.close()
+    cycle()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(8):
+        cycle()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 8 * 1024 * 1024, 'device memory shrank by %d bytes over 24 create/destroy cycles' % (free0 - free1)
