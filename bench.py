@@ -11,7 +11,8 @@ One "step" = one playEnv.step() for every env of the batch (one rp_step call): c
 Per-launch durations are measured with hipEvents recorded on the launch stream inside rp_step over the whole timed
 region (rp_enable_timers / rp_get_timers); the roofline object is for the dominant kernel, k_solve2.  Actions are synthetic
 (distribution B of SURVEY.md §8d: workspace-uniform, resampled every step), pre-generated on the device so the timed
-region holds only the hot path (and, for N > 1 GPUs, the RCCL all-gather of observations).  Envs shard across ranks
+region holds only the hot path (and, for N > 1 GPUs, the RCCL all-gather of observations, enqueued asynchronously so that it
+overlaps the next step's physics; every gather is complete before the region ends).  Envs shard across ranks
 with no data-path collective (weak scaling: 4096 envs per GPU).  Rank 0 prints one JSON line.
 """
 import argparse
@@ -99,17 +100,24 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    # one rank per GPU; RP_BENCH_BACKEND=gloo is a control-flow check of the N > 1 path on a box with fewer GPUs than ranks (ranks
+    # then share devices and the gather goes through the host) - never a measurement
+    backend = os.environ.get('RP_BENCH_BACKEND', 'nccl')
+    dev_index = local_rank if backend == 'nccl' else local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from roboticsplayroompybullet_amd import VecPlayEnv
     n = args.envs_per_gpu
-    env = VecPlayEnv(ENV_ID, n, device=local_rank, seed=1234, env_offset=sharding_offset(rank, world, n))
+    env = VecPlayEnv(ENV_ID, n, device=dev_index, seed=1234, env_offset=sharding_offset(rank, world, n))
     if args.groups:
         env.set_groups(args.groups)
     env.reset()
@@ -133,12 +141,18 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    pending = None
     for k in range(args.steps):
         ev0[k].record()
         obs, r, done, info = env.step(actions[args.warmup + k])
         ev1[k].record()
-        if world > 1:
-            sharding.gather_observations(sharding.pack_observations(obs, r, info['is_success']), out=gathered)
+        if world > 1:      # the gather of step k runs on RCCL's stream while step k + 1's physics runs on ours
+            pack = sharding.pack_observations(obs, r, info['is_success'])
+            if pending is not None:
+                pending.wait()
+            _, pending = sharding.gather_observations(pack, out=gathered, async_op=True)
+    if pending is not None:
+        pending.wait()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

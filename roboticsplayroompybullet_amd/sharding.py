@@ -25,13 +25,15 @@ def unpack_observations(pack, d_obs, d_ag):
             'is_success': pack[:, d_obs + d_ag + 1].to(torch.int32)}
 
 
-def gather_observations(pack, out=None, group=None):
-    """all-gather the ranks' packs in rank order -> [world*n, W].  `out` may be a preallocated buffer."""
+def gather_observations(pack, out=None, group=None, async_op=False):
+    """all-gather the ranks' packs in rank order -> [world*n, W].  `out` may be a preallocated buffer.  With async_op the
+    collective is only enqueued (RCCL runs it on its own stream while the caller's stream goes on with the next step's
+    physics) and (out, work) is returned: work.wait() before `out` is read or handed to the next gather."""
     world = dist.get_world_size(group)
     if out is None:
         out = torch.empty((world * pack.shape[0], pack.shape[1]), dtype=pack.dtype, device=pack.device)
     if dist.get_backend(group) == 'nccl':
-        dist.all_gather_into_tensor(out, pack.contiguous(), group=group)
+        work = dist.all_gather_into_tensor(out, pack.contiguous(), group=group, async_op=async_op)
     else:
-        dist.all_gather(list(out.chunk(world, dim=0)), pack.contiguous(), group=group)
-    return out
+        work = dist.all_gather(list(out.chunk(world, dim=0)), pack.contiguous(), group=group, async_op=async_op)
+    return (out, work) if async_op else out

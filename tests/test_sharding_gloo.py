@@ -28,6 +28,9 @@ def _worker(rank, world, port, n, d_obs, d_ag, ret):
     obs = {'obs_quat': g[:, None] + torch.arange(d_obs)[None] * 0.01, 'achieved_goal': g[:, None] * 2 + torch.arange(d_ag)[None]}
     pack = sharding.pack_observations(obs, -g, (g.to(torch.int32) % 2))
     full = sharding.gather_observations(pack)
+    out2, work = sharding.gather_observations(pack * 2, async_op=True)      # the overlapped form bench.py uses
+    work.wait()
+    assert torch.equal(out2, full * 2)
     dist.barrier()
     if rank == 0:
         ret['full'] = full.numpy().copy()
