@@ -12,7 +12,10 @@
  *   - a handle is bound to one device, is not thread-safe, and enqueues on the caller's stream
  *     (pass torch.cuda.current_stream().cuda_stream); `stream` is a hipStream_t passed as void*.
  *   - no host<->device copies and no synchronisation inside rp_step / rp_reset_to / rp_compute_reward; rp_reset reads one
- *     4-byte counter back per round of settle substeps (see rp_reset).
+ *     4-byte counter back per round of settle substeps (see rp_reset).  (Debug path only: with rp_set_fused(h, 1) AND timers
+ *     enabled, rp_step waits for its own kernel to read the timer - rp_playroom_debug.h.)
+ *   - every entry point makes the handle's device current for the duration of the call and restores the caller's device,
+ *     so handles on different devices (or several on one device, each driven on its own stream) can live in one process.
  *   - per-env numerical blow-ups are not errors: they set status[env] != 0 in rp_out.
  */
 #ifndef RP_PLAYROOM_H
@@ -26,7 +29,8 @@ extern "C" {
 
 typedef struct rp_sim* rp_handle;
 
-enum rp_status { RP_OK = 0, RP_ERR_ARG = -1, RP_ERR_HIP = -2, RP_ERR_UNSUPPORTED = -3, RP_ERR_STATE_SIZE = -4 };
+enum rp_status { RP_OK = 0, RP_ERR_ARG = -1, RP_ERR_HIP = -2, RP_ERR_UNSUPPORTED = -3, RP_ERR_STATE_SIZE = -4,
+                 RP_ERR_INCOMPLETE = -5 /* rp_reset ran out of rounds with envs still pending (their status[] is set to 4) */ };
 
 /* registered ids in scope (roboticsPlayroomPybullet/__init__.py:92,66,24) and, from SURVEY.md 8f rank 1, the rest of
  * the UR5 one-object play family (__init__.py:72,77,82,87,97; envList.py:101-140): same scene and arm as
@@ -59,12 +63,40 @@ enum rp_env_kind {
   RP_ENV_COUNT = 19
 };
 
+/* perform_action's dispatch (ENV:915-934); values of rp_config.action_type */
+enum rp_action_type { RP_ACTION_ABSOLUTE_RPY = 0, RP_ACTION_RELATIVE_RPY = 1, RP_ACTION_ABSOLUTE_QUAT = 2, RP_ACTION_RELATIVE_QUAT = 3,
+                      RP_ACTION_ABSOLUTE_JOINTS = 4, RP_ACTION_RELATIVE_JOINTS = 5 };
+
+/* rp_config.flags: which of the optional fields are valid.  0 = the id exactly as envList.py registers it. */
+enum rp_config_flags {
+  RP_CFG_GOAL_RANGE = 1,    /* goal_range_low / goal_range_high    (ENV:495-498 goal draw, ENV:577-581 arm reset target) */
+  RP_CFG_OBJ_RANGE = 2,     /* obj_lower_bound / obj_upper_bound   (ENV:527-533 object spawn) */
+  RP_CFG_ENV_RANGE = 4,     /* env_range_high                      (ENV:537-540 out-of-bounds re-sample after settling) */
+  RP_CFG_REW_THRESH = 8,    /* sparse_rew_thresh                   (ENV:297; ids that are not play ids) */
+  RP_CFG_DENSE_REWARD = 16, /* sparse=False: compute_reward = -||ag - dg|| over the whole goal vector (ENV:169-170, 273-275) */
+  RP_CFG_ACTION_TYPE = 32,  /* action_type                         (ENV:88-113, 915-981) */
+  RP_CFG_CONTACT_MARGIN = 64 /* contact_margin, see below */
+};
+
 typedef struct rp_config {
   int32_t env_kind;      /* rp_env_kind */
-  int32_t num_envs;      /* N */
+  int32_t num_envs;      /* N, 1 .. 4194304 */
   int32_t device;        /* HIP device ordinal */
   int32_t env_offset;    /* global index of env 0 of this handle (multi-GPU shards: rank * N); keys the per-env RNG */
   uint64_t seed;         /* counter RNG: u = f(seed, env_offset + env, draw#) — shard-invariant */
+  /* the kwargs an env class of envList.py hands to playEnv.__init__ (ENV:64-67) that reach the simulation; each is read only
+   * when its rp_config_flags bit is set.  Kwargs that change the layout of the observation (num_objects, use_orientation,
+   * return_velocity, play, arm_type) belong to the id and cannot be overridden. */
+  uint32_t flags;
+  int32_t action_type;   /* rp_action_type */
+  float goal_range_low[3], goal_range_high[3];
+  float obj_lower_bound[3], obj_upper_bound[3];
+  float env_range_high[3];
+  float sparse_rew_thresh;
+  /* distance out to which the narrowphase creates contact points, metres.  Bullet keeps the points of its persistent
+   * manifolds out to contactBreakingThreshold = 0.02; this library's manifolds are rebuilt every substep, so the margin is
+   * the distance at which a point first appears.  Default (flag clear): 0.02.  See DESIGN.md H7 for what each choice tracks. */
+  float contact_margin;
 } rp_config;
 
 /* per-kind output widths */
@@ -87,7 +119,11 @@ typedef struct rp_out {
   float* reward;                     /* [N] */
   int32_t* is_success;               /* [N] */
   float* target_poses;               /* [N, dims.target_poses]; written by rp_step only */
-  int32_t* status;                   /* [N] 0 ok, 1 non-finite state detected */
+  int32_t* status;                   /* [N] bit flags, 0 = ok: 1 non-finite state, 2 an object fell through the scene's ground plate
+                                      * (tunnelled: it is below the lowest static collider), 4 rp_reset left this env unfinished */
+  float* pack;                       /* [N, dims.obs_quat + dims.achieved_goal + 2]: obs_quat | achieved_goal | reward | is_success
+                                      * in one row, the message of the per-step multi-GPU observation gather,
+                                      * written by the same kernel so the gather needs no packing pass */
 } rp_out;
 
 typedef struct rp_timers {

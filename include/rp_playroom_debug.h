@@ -1,0 +1,34 @@
+/* rp_playroom_debug.h — test / tuning hooks exported by librp_playroom_hip.so next to the C ABI of rp_playroom.h.
+ *
+ * Nothing here stands in for a reference interface: these exist so that the parity tests can compare the library's two step
+ * pipelines with each other and with the oracle at intermediate points, and so that profiling scripts can pin the launch
+ * layout.  None of them changes a result (both pipelines and every group / slot layout are bit-identical; tests/ check it).
+ * tests/test_abi.py checks that every rp_* symbol the library exports is declared in one of the two headers. */
+#ifndef RP_PLAYROOM_DEBUG_H
+#define RP_PLAYROOM_DEBUG_H
+#include "rp_playroom.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* step pipeline: 0 = split kernels (default), 1 = one fused kernel per env step (k_step; the in-library cross-check).
+ * With fused = 1 and timers enabled rp_step synchronises on its own kernel to read the timer. */
+int rp_set_fused(rp_handle h, int32_t fused);
+/* number of env groups (streams) of the split pipeline, 1 .. 16 */
+int rp_set_groups(rp_handle h, int32_t groups);
+/* bit 0: the solver gives every contact its own folded slot (its fallback layout) instead of solving arm-only and non-arm
+ * contacts side by side */
+int rp_set_debug_flags(rp_handle h, int32_t flags);
+/* one fused substep on every env on the NULL stream; intermediates of env `env` into host_buf[4096] (layout: k_debug_substep) */
+int rp_debug_substep(rp_handle h, int32_t env, float* host_buf);
+/* per env of the most recent k_prep2: host_buf[2 e] = unit rows, host_buf[2 e + 1] = contacts + 1000 * (arm contact) + 100000 *
+ * spanning contacts; synchronises the device */
+int rp_debug_row_counts(rp_handle h, int32_t* host_buf);
+/* rounds the most recent rp_reset took */
+int rp_debug_reset_rounds(rp_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

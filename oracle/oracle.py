@@ -86,6 +86,8 @@ def load(f32=False):
     lib.rpo_action_target.argtypes = [C.c_int, dp, dp, dp, dp, dp]
     lib.rpo_set_ranges.argtypes = [vp, dp, dp, dp, dp, dp]
     lib.rpo_set_action_type.argtypes = [vp, C.c_int]
+    lib.rpo_set_margin.argtypes = [vp, C.c_double]
+    lib.rpo_set_reward_cfg.argtypes = [vp, C.c_double, C.c_int]
     lib.rpo_action_dim.argtypes = [vp]
     lib.rpo_get_config.argtypes = [vp, dp]
     lib.rpo_action_dim.restype = C.c_int
@@ -139,8 +141,12 @@ TWO_OBJECT = {'pandaPlay-v0': 'absolute_quat', 'pandaPlayJoints-v0': 'relative_j
 class OracleEnv:
     """One reference env (instance + playEnv) on the CPU oracle."""
 
-    def __init__(self, kind, seed=0, env_index=0, f32=False, action_type=None):
+    def __init__(self, kind, seed=0, env_index=0, f32=False, action_type=None, margin=None, ranges=None, sparse_rew_thresh=None,
+                 dense_reward=False):
+        """ranges = (goal_lo, goal_hi, obj_lo, obj_hi, env_hi): the env class's range kwargs (envList.py); margin: contact margin
+        in metres (default: the library's default, rp_model.h RP_DEFAULT_CONTACT_MARGIN)"""
         self.lib = load(f32)
+        user_ranges = ranges
         ranges = None
         if kind in RANGES:
             kind, *ranges = RANGES[kind]
@@ -155,8 +161,14 @@ class OracleEnv:
         self.action_type = action_type or 'absolute_rpy'
         self.lib.rpo_set_action_type(self.h, ACTION_TYPES[self.action_type])
         self.n_action = self.lib.rpo_action_dim(self.h)
+        if user_ranges is not None:
+            ranges = user_ranges
         if ranges:
             self.lib.rpo_set_ranges(self.h, *[_d(r)[1] for r in ranges])
+        if margin is not None:
+            self.lib.rpo_set_margin(self.h, float(margin))
+        if sparse_rew_thresh is not None or dense_reward:
+            self.lib.rpo_set_reward_cfg(self.h, 0.05 if sparse_rew_thresh is None else float(sparse_rew_thresh), int(bool(dense_reward)))
         self.n_arm = self.lib.rpo_n_arm(self.h)
         self.nv = self.lib.rpo_nv(self.h)
         self.n_goal = {0: 11, 4: 11, 5: 18}.get(self.kind, 3)

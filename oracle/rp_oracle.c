@@ -27,7 +27,7 @@
 #define N_ITER 50                       /* PyBullet numSolverIterations default; never early-exits (environments.py:326) */
 #define ERP_CONTACT ((real)0.08)        /* PhysicsServerCommandProcessor erp2 (recalled) */
 #define LINEAR_SLOP ((real)1e-5)
-#define CONTACT_MARGIN ((real)0.005)    /* speculative contact distance (Bullet keeps points out to its 0.02 breaking threshold) */
+/* contact margin: rp_model.h RP_DEFAULT_CONTACT_MARGIN (the library's rp_config.contact_margin default), rpo_set_margin overrides */
 #define MOTOR_KP ((real)0.1)
 #define MOTOR_KD ((real)1.0)
 #define DEFAULT_MOTOR_MAXIMP ((real)1.0) /* createJointMotors: velocity motor, target 0, max impulse 1 */
@@ -74,6 +74,8 @@ struct rpo_env {
   /* config flags (envList.py) */
   int play, use_orientation, return_velocity, num_objects;
   int action_type;                  /* RPO_ACT_*: perform_action's dispatch (environments.py:915-934) */
+  real margin;                      /* distance out to which contact points are created */
+  real rew_thresh; int dense_reward; /* sparse_rew_thresh, sparse=False (environments.py:66, 169-170) */
   real goal_lo[3], goal_hi[3], obj_lo[3], obj_hi[3], env_hi[3];
   /* work */
   xform xb[NB_MAX];                 /* world transform of every body frame */
@@ -397,18 +399,18 @@ static void collide(rpo_env* e) {
     }
     int sep = 0;
     for (int k = 0; k < 3; k++)
-      if (e->aabb_lo[a][k] > e->aabb_hi[b][k] + CONTACT_MARGIN || e->aabb_lo[b][k] > e->aabb_hi[a][k] + CONTACT_MARGIN) sep = 1;
+      if (e->aabb_lo[a][k] > e->aabb_hi[b][k] + e->margin || e->aabb_lo[b][k] > e->aabb_hi[a][k] + e->margin) sep = 1;
     if (sep) continue;
     if (nactive++ >= MAX_ACTIVE_PAIRS) continue;
     cpoint pts[4]; int np = 0;
     real ha[3], hb[3];
     for (int k = 0; k < 3; k++) { ha[k] = (real)m->col_he[a][k]; hb[k] = (real)m->col_he[b][k]; }
     if (m->col_type[a] == 0 && m->col_type[b] == 0)
-      np = box_box(e->xc[a].p, e->xc[a].R, ha, e->xc[b].p, e->xc[b].R, hb, CONTACT_MARGIN, pts);
+      np = box_box(e->xc[a].p, e->xc[a].R, ha, e->xc[b].p, e->xc[b].R, hb, e->margin, pts);
     else if (m->col_type[a] == 0 && m->col_type[b] == 1)
-      np = sphere_box(e->xc[b].p, hb[0], e->xc[a].p, e->xc[a].R, ha, CONTACT_MARGIN, 1, pts);
+      np = sphere_box(e->xc[b].p, hb[0], e->xc[a].p, e->xc[a].R, ha, e->margin, 1, pts);
     else if (m->col_type[a] == 1 && m->col_type[b] == 0)
-      np = sphere_box(e->xc[a].p, ha[0], e->xc[b].p, e->xc[b].R, hb, CONTACT_MARGIN, 0, pts);
+      np = sphere_box(e->xc[a].p, ha[0], e->xc[b].p, e->xc[b].R, hb, e->margin, 0, pts);
     int kf = body_free_index(e, m->col_body[a]);
     int single = (kf >= 0 && m->free_rot_locked[kf] && m->col_body[b] == 0);
     for (int i = 0; i < np; i++) {
@@ -1114,6 +1116,8 @@ static void perform_action(rpo_env* e, const real* a, real* target_poses) {
 }
 
 void rpo_set_action_type(rpo_env* e, int action_type) { e->action_type = action_type; }
+void rpo_set_margin(rpo_env* e, double margin) { e->margin = (real)margin; }
+void rpo_set_reward_cfg(rpo_env* e, double sparse_rew_thresh, int dense) { e->rew_thresh = (real)sparse_rew_thresh; e->dense_reward = dense; }
 /* another registered id on the same arm and scene: its goal / object-spawn / env ranges (envList.py kwargs) */
 void rpo_set_ranges(rpo_env* e, const double* goal_lo, const double* goal_hi, const double* obj_lo, const double* obj_hi, const double* env_hi) {
   for (int k = 0; k < 3; k++) {
@@ -1358,15 +1362,20 @@ static real success_func(const real* ag, const real* g) {       /* playRewardFun
 }
 
 static real compute_reward(const rpo_env* e, const real* ag, const real* dg) {    /* environments.py:278-304 */
+  if (e->dense_reward) {         /* sparse=False: -calc_target_distance = -||ag - dg|| over the whole vector (environments.py:269-275) */
+    real s = 0;
+    for (int k = 0; k < e->n_goal; k++) s += (ag[k] - dg[k]) * (ag[k] - dg[k]);
+    return -R_SQRT(s);
+  }
   if (e->play) return success_func(ag, dg);
   real d[3]; v3sub(d, ag, dg);
   real dist = v3norm(d);
-  return dist > (real)0.05 ? (real)-1 : -dist;
+  return dist > e->rew_thresh ? (real)-1 : -dist;
 }
 
 double rpo_compute_reward(const rpo_env* e, const double* ag, const double* dg) {
   real a[18], g[18];
-  int n = e->play ? 11 : 3;
+  int n = e->n_goal;
   for (int i = 0; i < n; i++) { a[i] = (real)ag[i]; g[i] = (real)dg[i]; }
   return compute_reward(e, a, g);
 }
@@ -1550,6 +1559,7 @@ rpo_env* rpo_create(int kind, unsigned long long seed, int env_index) {
   e->nv = m->n_arm + 6 * m->n_free + m->n_joint1;
   e->nbody = 1 + m->n_arm + m->n_free + m->n_joint1;
   e->seed = seed; e->env_index = (uint32_t)env_index;
+  e->margin = (real)RP_DEFAULT_CONTACT_MARGIN; e->rew_thresh = (real)0.05; e->dense_reward = 0;
   /* envList.py:8-10, 18-22, 73-99: the env's flags and ranges go with its scene (play ids: complex_scene; reach ids:
    * default_scene; pick / push: push_scene); other ids on the same model override the ranges (rpo_set_ranges) */
   if (m->scene == RP_SCENE_COMPLEX) {

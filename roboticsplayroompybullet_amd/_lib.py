@@ -36,7 +36,15 @@ ACTION_TYPES = {'UR5PlayAbsRPY1Obj-v0': 'absolute_rpy', 'UR5Reach-v0': 'absolute
 
 class RpConfig(C.Structure):
     _fields_ = [('env_kind', C.c_int32), ('num_envs', C.c_int32), ('device', C.c_int32), ('env_offset', C.c_int32),
-                ('seed', C.c_uint64)]
+                ('seed', C.c_uint64), ('flags', C.c_uint32), ('action_type', C.c_int32),
+                ('goal_range_low', C.c_float * 3), ('goal_range_high', C.c_float * 3),
+                ('obj_lower_bound', C.c_float * 3), ('obj_upper_bound', C.c_float * 3), ('env_range_high', C.c_float * 3),
+                ('sparse_rew_thresh', C.c_float), ('contact_margin', C.c_float)]
+
+
+# rp_config_flags / rp_action_type (include/rp_playroom.h)
+CFG_GOAL_RANGE, CFG_OBJ_RANGE, CFG_ENV_RANGE, CFG_REW_THRESH, CFG_DENSE_REWARD, CFG_ACTION_TYPE, CFG_CONTACT_MARGIN = 1, 2, 4, 8, 16, 32, 64
+ACTION_TYPE_CODES = {'absolute_rpy': 0, 'relative_rpy': 1, 'absolute_quat': 2, 'relative_quat': 3, 'absolute_joints': 4, 'relative_joints': 5}
 
 
 class RpDims(C.Structure):
@@ -48,7 +56,8 @@ class RpOut(C.Structure):
     _fields_ = [('obs_quat', C.c_void_p), ('achieved_goal', C.c_void_p), ('desired_goal', C.c_void_p),
                 ('controllable_achieved_goal', C.c_void_p), ('full_positional_state', C.c_void_p), ('joints', C.c_void_p),
                 ('velocity', C.c_void_p), ('observation', C.c_void_p), ('gripper_proprioception', C.c_void_p),
-                ('reward', C.c_void_p), ('is_success', C.c_void_p), ('target_poses', C.c_void_p), ('status', C.c_void_p)]
+                ('reward', C.c_void_p), ('is_success', C.c_void_p), ('target_poses', C.c_void_p), ('status', C.c_void_p),
+                ('pack', C.c_void_p)]
 
 
 class RpTimers(C.Structure):
@@ -60,6 +69,8 @@ class RpTimers(C.Structure):
 EXPORTS = ['rp_create', 'rp_destroy', 'rp_get_dims', 'rp_reset', 'rp_reset_to', 'rp_reset_goal', 'rp_step', 'rp_calc_state',
            'rp_compute_reward', 'rp_state_bytes', 'rp_get_state', 'rp_set_state', 'rp_get_timers', 'rp_enable_timers',
            'rp_last_error', 'rp_version']
+# include/rp_playroom_debug.h: test / tuning hooks
+DEBUG_EXPORTS = ['rp_set_fused', 'rp_set_groups', 'rp_set_debug_flags', 'rp_debug_substep', 'rp_debug_row_counts', 'rp_debug_reset_rounds']
 
 _lib = None
 _libs = {}
@@ -106,6 +117,7 @@ def load(wide=False):
     lib.rp_set_groups.argtypes = [vp, C.c_int32]
     lib.rp_set_debug_flags.argtypes = [vp, C.c_int32]
     lib.rp_debug_row_counts.argtypes = [vp, C.POINTER(C.c_int32)]
+    lib.rp_debug_reset_rounds.argtypes = [vp]
     _libs[path] = lib
     if not wide:
         _lib = lib

@@ -3,6 +3,7 @@
 #ifndef RP_DEVICE_MODEL_H
 #define RP_DEVICE_MODEL_H
 #include <stdint.h>
+#include <math.h>
 #include <string.h>
 
 #include "rp_model.h"
@@ -84,6 +85,10 @@ typedef struct DevModel {
   int d18, d20, d12, d15, d10, d13, d9p, d10p;
   int joints_dof[8];              /* dof of Bullet joints 0..7 or -1 (fixed) */
   float goal_lo[3], goal_hi[3], obj_lo[3], obj_hi[3], env_hi[3];
+  float rew_thresh;               /* sparse_rew_thresh (environments.py:297) */
+  int dense_reward;               /* sparse=False: compute_reward = -distance (environments.py:169-170, 273-275) */
+  float margin;                   /* contact_margin: distance out to which the narrowphase creates points (rp_config) */
+  float floor_z;                  /* bottom of the lowest static collider: an object below it has left the scene (status bit 2) */
   /* joint clamps of goto_joint_poses (environments.py:1015-1021) */
   float ll[7], ul[7], inc[7];
 } DevModel;
@@ -189,6 +194,15 @@ static inline void rp_build_dev_model(const rp_model* m, DevModel* d) {
     d->n_obs = 13; d->n_ag = 3; d->n_fps = 7; d->n_observation = 12; d->n_target = 7;
   }
   d->n_target = isP ? 7 : 6;            /* numDofs (environments.py:361, 371) */
+  d->rew_thresh = 0.05f; d->dense_reward = 0; d->margin = (float)RP_DEFAULT_CONTACT_MARGIN;
+  d->floor_z = 1e30f;
+  for (int c = 0; c < m->n_col; c++) {
+    if (m->col_body[c] != 0) continue;
+    double ext = m->col_type[c] == 0 ? fabs(m->col_rot[c][6]) * m->col_he[c][0] + fabs(m->col_rot[c][7]) * m->col_he[c][1] + fabs(m->col_rot[c][8]) * m->col_he[c][2]
+                                     : m->col_he[c][0];
+    float lo = (float)(m->col_pos[c][2] - ext);
+    if (lo < d->floor_z) d->floor_z = lo;
+  }
   if (isP) {   /* environments.py:1015-1017 */
     const float ll[7] = {-0.6f, -2.2f, -3.0f, -3.04878596f, -PI, -PI, -PI};
     const float ul[7] = {3.f, 1.8f, 0.5f, -0.5002492f, 3.f, 3.45266257f, 2.40072908f};

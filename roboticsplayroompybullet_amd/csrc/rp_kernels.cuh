@@ -1,14 +1,15 @@
 /* rp_kernels.cuh — the batched playroom env-step for gfx950 (MI355X), hand-written HIP.
  *
- * Mapping: ONE ENVIRONMENT PER WAVEFRONT (64 lanes, one 64-thread workgroup).  At N = 4096 that is 4096 waves over
- * 256 CUs; every per-env decision (contact count, row count, IK convergence) is wave-uniform, so there is no
- * divergence between environments and all per-env scalars live in SGPRs.  Inside a wave the lanes take turns owning
+ * rp_step runs right-sized kernels per env group (see "split pipeline" below): k_action_prep (16 lanes per env for the
+ * cooperative IK, fused with the first substep's preparation), 12 x { k_prep2 (one wave per env: FK, collision, dynamics,
+ * constraint rows -> per-env workspace), k_solve2 (two envs per wave: 50 PGS sweeps over register-resident rows +
+ * integration) }, k_calc_state (one wave per env: observation, reward, outputs).  Inside a k_prep2 wave the lanes take turns
+ * owning
  *   bodies (FK) -> colliders (AABBs) -> candidate pairs (broadphase, 64 per sweep) -> active pairs (narrowphase)
  *   -> manifolds -> arm links (CRBA / RNEA about a per-substep reference point) -> constraint rows (Jacobians,
- *   M^-1 J^T) -> velocity components (PGS: lane l owns dv[l], row dot products by DPP wave reductions).
- * All per-env working data (state record, transforms, 12x12 mass matrix + inverse, Jacobian rows) is staged in LDS;
- * HBM traffic per env-step is one 512 B state record in, one out, plus action and outputs.
- * The whole env step (IK, motor targets, 12 substeps, observation, reward) is ONE kernel launch.
+ *   M^-1 J^T); in k_solve2 lane l owns velocity component l of its env and row dot products are DPP reductions.
+ * The first design - the whole env step as ONE kernel, one wave per env, everything staged in LDS - is kept as k_step / k_reset:
+ * the in-library cross-check (bit-identical to the split pipeline, tests/) and the path of rp_reset_to.
  *
  * What the pieces restate (reference file:line via the CPU oracle, oracle/rp_oracle.c, which tests compare against):
  *   perform_action/goto/close_gripper  environments.py:915-1073, inverseKinematics.py:44-50
@@ -31,6 +32,9 @@
 #define SORT_KEYS 64          /* load classes for pairing envs in k_solve2: 8 * min(spanning, 7) + clamp(side-by-side slots - 6, 0, 7) */
 #define SORT_REPS 8           /* histogram replicas (env & 7): one hot word would serialise ~4096 atomics at ~90 per us */
 #define SORT_BINS (SORT_KEYS * SORT_REPS)
+#define SORT_RANK_BITS 22     /* sort_slot = (bin << 22) | rank inside the bin: 512 bins, ranks < 4 M (rp_create bounds num_envs) */
+#define SORT_RANK_MASK ((1 << SORT_RANK_BITS) - 1)
+#define RP_MAX_ENVS (1 << SORT_RANK_BITS)
 #define MAXSMALL 44          /* arm motors 12 + scene-joint motors 3 + limits 24 + gear 1 (+ pad) */
 
 #ifndef RP_PREP_WAVES
@@ -52,7 +56,6 @@
 #endif
 #define K_ERP 0.08f
 #define K_SLOP 1e-5f
-#define K_MARGIN 0.005f
 #define K_TIE_EPS 1e-6f
 #define K_KP 0.1f
 #define K_DEFMOTOR 1.0f
@@ -383,7 +386,7 @@ __device__ void narrowphase_coop(const DevModel* m, EnvLds& L, int lane, int nac
   float (*poly)[8][3] = (float (*)[8][3])(scr + 16);
   float (*kept)[4] = (float (*)[4])(scr + 64);
   const unsigned below = (1u << s) - 1u;
-  const float margin = K_MARGIN;
+  const float margin = m->margin;
   for (int base = 0; base < nact; base += 64 / NPG) {      /* wave-uniform trip count; every lane reaches every barrier */
     const int ai = base + g;
     const bool act = ai < nact;
@@ -584,6 +587,7 @@ __device__ int collide(const DevModel* m, EnvLds& L, int lane) {
   unsigned short pv[RP_MAX_PAIR / 64];
 #pragma unroll
   for (int k = 0; k < RP_MAX_PAIR / 64; k++) { int pi = 64 * k + lane; pv[k] = pp[pi < npair ? pi : 0]; }   /* all loads in flight at once */
+  const float margin = m->margin;
   unsigned ovbits = 0u;                  /* bit k: pair 64 k + lane overlaps.  All tests first (independent LDS reads pipeline) */
 #pragma unroll
   for (int k = 0; k < RP_MAX_PAIR / 64; k++) {
@@ -595,7 +599,7 @@ __device__ int collide(const DevModel* m, EnvLds& L, int lane) {
       /* all twelve reads unconditionally, combined without short-circuit: `||` would make every read wait for the
        * comparison before it (98 exec-mask branches, one LDS round trip each) */
       float a0 = A[0], a1 = A[1], a2 = A[2], a3 = A[3], a4 = A[4], a5 = A[5], b0 = Bb[0], b1 = Bb[1], b2 = Bb[2], b3 = Bb[3], b4 = Bb[4], b5 = Bb[5];
-      bool sep = (a0 > b3 + K_MARGIN) | (b0 > a3 + K_MARGIN) | (a1 > b4 + K_MARGIN) | (b1 > a4 + K_MARGIN) | (a2 > b5 + K_MARGIN) | (b2 > a5 + K_MARGIN);
+      bool sep = (a0 > b3 + margin) | (b0 > a3 + margin) | (a1 > b4 + margin) | (b1 > a4 + margin) | (a2 > b5 + margin) | (b2 > a5 + margin);
       ovbits |= sep ? 0u : (1u << k);
     }
   }
@@ -1441,11 +1445,18 @@ __device__ float success_func(const float* ag, const float* g) {
   return 0.f;
 }
 
-__device__ float compute_reward(int play, const float* ag, const float* dg) {
-  if (play) return success_func(ag, dg);
+/* compute_reward_sparse (environments.py:278-304) or, with sparse=False, the dense compute_reward = -||ag - dg|| over the whole
+ * goal vector (environments.py:169-170, 273-275; calc_target_distance takes the norm of the full difference) */
+__device__ float compute_reward(const DevModel* m, const float* ag, const float* dg) {
+  if (m->dense_reward) {
+    float s = 0.f;
+    for (int k = 0; k < m->n_ag; k++) { float d = ag[k] - dg[k]; s += d * d; }
+    return -sqrtf(s);
+  }
+  if (m->play) return success_func(ag, dg);
   float dx = ag[0] - dg[0], dy = ag[1] - dg[1], dz = ag[2] - dg[2];
   float dist = sqrtf(dx * dx + dy * dy + dz * dz);
-  return dist > 0.05f ? -1.f : -dist;
+  return dist > m->rew_thresh ? -1.f : -dist;
 }
 
 __device__ __forceinline__ void flip_quat(float* v, const float* last) {
@@ -1606,12 +1617,13 @@ __device__ void calc_state(const DevModel* m, EnvLds& L, int lane) {
     o[O_OBSV + no++] = eul.x; o[O_OBSV + no++] = eul.y; o[O_OBSV + no++] = eul.z;
     for (int k = 7; k < ns; k++) o[O_OBSV + no++] = st[k];
     o[O_PROP] = __int_as_float(prop);
-    float r = compute_reward(m->play, &o[O_AG], &o[O_DG]);
+    float r = compute_reward(m, &o[O_AG], &o[O_DG]);
     o[O_REW] = r;
     o[O_SUCC] = __int_as_float(r < 0.f ? 0 : 1);
-    bool bad = false;
+    bool bad = false, fell = false;
     for (int k = 0; k < ST_MMODE; k++) if (!isfinite(L.st[k])) bad = true;
-    o[O_STATUS] = __int_as_float(bad ? 1 : 0);
+    for (int b = 0; b < m->num_objects; b++) if (L.st[ST_FREE + 13 * b + 2] < m->floor_z) fell = true;   /* below the lowest static collider */
+    o[O_STATUS] = __int_as_float((bad ? 1 : 0) | (fell ? 2 : 0));
   }
   __syncthreads();
 }
@@ -1619,6 +1631,7 @@ __device__ void calc_state(const DevModel* m, EnvLds& L, int lane) {
 struct OutPtrs {
   float *obs_quat, *achieved_goal, *desired_goal, *cag, *fps, *joints, *velocity, *observation;
   int *proprio; float* reward; int *is_success; float* target_poses; int* status;
+  float* pack;            /* [N, n_obs + n_ag + 2]: obs_quat | achieved_goal | reward | is_success (rp_out.pack) */
 };
 
 __device__ void write_outputs(const DevModel* m, const EnvLds& L, int lane, int env, const OutPtrs& o) {
@@ -1631,6 +1644,14 @@ __device__ void write_outputs(const DevModel* m, const EnvLds& L, int lane, int 
   if (o.joints && lane < 8) o.joints[(size_t)env * 8 + lane] = s[O_JOINTS + lane];
   if (o.velocity && lane < 6) o.velocity[(size_t)env * 6 + lane] = s[O_VEL + lane];
   if (o.observation && lane < m->n_observation) o.observation[(size_t)env * m->n_observation + lane] = s[O_OBSV + lane];
+  if (o.pack) {
+    const int no = m->n_obs, na = m->n_ag, w = no + na + 2;
+    float* p = o.pack + (size_t)env * w;
+    if (lane < no) p[lane] = s[O_OBS + lane];
+    else if (lane < no + na) p[lane] = s[O_AG + lane - no];
+    else if (lane == no + na) p[lane] = s[O_REW];
+    else if (lane == no + na + 1) p[lane] = (float)__float_as_int(s[O_SUCC]);
+  }
   if (lane == 0) {
     if (o.proprio) o.proprio[env] = __float_as_int(s[O_PROP]);
     if (o.reward) o.reward[env] = s[O_REW];
@@ -1845,6 +1866,10 @@ __global__ void k_reset_mark(const uint8_t* __restrict__ mask, int4* __restrict_
   int env = blockIdx.x * blockDim.x + threadIdx.x;
   if (env < N) meta[env] = make_int4((!mask || mask[env]) ? 1 : 0, 0, 0, 0);        /* pending, attempt, depth */
 }
+__global__ void k_reset_flag_pending(const int4* __restrict__ meta, int* __restrict__ status, int N) {
+  int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env < N && status && meta[env].x != 0) status[env] |= 4;
+}
 /* pending envs in index order -> idx[0 .. count) (one wave) */
 __global__ void __launch_bounds__(64) k_reset_list(const int4* __restrict__ meta, int* __restrict__ idx, int* __restrict__ count, int N) {
   const int lane = threadIdx.x;
@@ -1921,7 +1946,7 @@ __global__ void k_init(const DevModel* __restrict__ m, float* __restrict__ state
 __global__ void k_reward(const DevModel* __restrict__ m, const float* __restrict__ ag, const float* __restrict__ dg, float* __restrict__ r, int M) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= M) return;
-  r[i] = compute_reward(m->play, ag + (size_t)i * m->n_ag, dg + (size_t)i * m->n_ag);
+  r[i] = compute_reward(m, ag + (size_t)i * m->n_ag, dg + (size_t)i * m->n_ag);
 }
 
 /* state record copies (rp_get_state / rp_set_state with broadcast) */
@@ -2162,13 +2187,13 @@ __device__ __forceinline__ void prep2_body(const DevModel* __restrict__ m, const
   copy_out(w + W3_J, L.u.r.J, (ROWW * 3 * ncon + 3) & ~3, lane);
   copy_out(w + W3_B, L.u.r.B, (ROWW * 3 * ncon + 3) & ~3, lane);
   {
-    const int mybin = my_slot >> 16;
+    const int mybin = my_slot >> SORT_RANK_BITS;
     int above = 0;
 #pragma unroll
     for (int t = 0; t < 8; t++) above += (8 * lane + t > mybin) ? cnt8[t] : 0;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) above += __shfl_xor(above, d);
-    if (lane == 0) pair_env[env0 + above + (my_slot & 0xFFFF)] = env | (ncon << 24);     /* + its contact count: k_solve2 sizes its row copy without waiting for the header */
+    if (lane == 0) pair_env[env0 + above + (my_slot & SORT_RANK_MASK)] = env | (ncon << 24);     /* + its contact count: k_solve2 sizes its row copy without waiting for the header */
   }
   PCLK(5) PCLK(7)
 }
@@ -2579,7 +2604,7 @@ __device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, floa
     if (l == 0) {
       int sp = sort_pos;
       asm volatile("" : "+v"(sp));           /* first use of the atomic's result: keeps its s_waitcnt down here */
-      sort_slot[env] = (sort_bin << 16) | sp;
+      sort_slot[env] = (sort_bin << SORT_RANK_BITS) | sp;
     }
   }
 #if defined(RP_CLOCKS) && RP_CLOCKS != 2
@@ -2604,7 +2629,7 @@ __global__ void __launch_bounds__(64, 2) k_settle_solve(SOLVE2_ARGS) { solve2_bo
 __global__ void k_sort_init(int* __restrict__ cnt, int* __restrict__ slot, int env0, int ng) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < SORT_BINS) cnt[i] = i < SORT_REPS ? (ng + i) / SORT_REPS : 0;              /* envs with (e & 7) == 7 - i */
-  if (i < ng) slot[env0 + i] = ((SORT_REPS - 1 - (i & (SORT_REPS - 1))) << 16) | (i >> 3);      /* bins 7..0 <-> i & 7 = 0..7: keeps index order */
+  if (i < ng) slot[env0 + i] = ((SORT_REPS - 1 - (i & (SORT_REPS - 1))) << SORT_RANK_BITS) | (i >> 3);      /* bins 7..0 <-> i & 7 = 0..7: keeps index order */
 }
 
 /* Env groups by load.  rp_step cuts the envs into G groups that run their kernel chains on separate streams; a chain lasts as
@@ -2640,8 +2665,8 @@ __global__ void __launch_bounds__(1024) k_member(const int* __restrict__ member_
     const int env = member_old[p];
     int g = 0;
     while (g + 1 < G_old && p >= bo.b[g + 1]) g++;
-    const int v = sort_slot[env], b = v >> 16;
-    member_new[above[b] + gpre[g * SORT_BINS + b] + (v & 0xFFFF)] = env;
+    const int v = sort_slot[env], b = v >> SORT_RANK_BITS;
+    member_new[above[b] + gpre[g * SORT_BINS + b] + (v & SORT_RANK_MASK)] = env;
   }
   __threadfence_block();
   __syncthreads();
@@ -2654,7 +2679,7 @@ __global__ void __launch_bounds__(1024) k_member(const int* __restrict__ member_
     int g = 0;
     while (g + 1 < G_new && p >= bn.b[g + 1]) g++;
     const int i = p - bn.b[g];
-    sort_slot[member_new[p]] = ((SORT_REPS - 1 - (i & (SORT_REPS - 1))) << 16) | (i >> 3);
+    sort_slot[member_new[p]] = ((SORT_REPS - 1 - (i & (SORT_REPS - 1))) << SORT_RANK_BITS) | (i >> 3);
   }
 }
 __global__ void k_member_identity(int* __restrict__ member, int N) {

@@ -34,6 +34,9 @@
 #define RP_MAX_SITE 4
 #define RP_MAX_NV (RP_MAX_ARM + 6 * RP_MAX_FREE + RP_MAX_J1)
 
+/* rp_config.contact_margin when RP_CFG_CONTACT_MARGIN is clear (include/rp_playroom.h); the oracle's default too */
+#define RP_DEFAULT_CONTACT_MARGIN 0.02
+
 #define RP_SITE_EE 0     /* Bullet endEffectorIndex (UR5 link 7 / Panda link 11), COM frame */
 #define RP_SITE_WRIST 1  /* endEffectorIndex-1 (UR5 only; gripper_proprioception, environments.py:725) */
 #define RP_SITE_PADL 2   /* UR5 link 18 */

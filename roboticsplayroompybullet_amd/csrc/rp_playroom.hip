@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include "../../include/rp_playroom.h"
+#include "../../include/rp_playroom_debug.h"
 #include "generated/rp_models_gen.h"
 #include "rp_device_model.h"
 #include "rp_kernels.cuh"
@@ -54,6 +55,17 @@ static char g_err[256] = "";
     }                                                                                               \
   } while (0)
 
+/* makes the handle's device current for one entry point and restores the caller's on the way out (handles on several devices,
+ * or a torch caller whose current device is another one) */
+struct DevGuard {
+  int prev = -1, cur = -1;
+  explicit DevGuard(int dev) : cur(dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != cur) (void)hipSetDevice(cur);
+  }
+  ~DevGuard() { if (prev >= 0 && prev != cur) (void)hipSetDevice(prev); }
+};
+
 static OutPtrs to_ptrs(const rp_out* o) {
   OutPtrs p;
   memset(&p, 0, sizeof(p));
@@ -61,24 +73,37 @@ static OutPtrs to_ptrs(const rp_out* o) {
   p.obs_quat = o->obs_quat; p.achieved_goal = o->achieved_goal; p.desired_goal = o->desired_goal;
   p.cag = o->controllable_achieved_goal; p.fps = o->full_positional_state; p.joints = o->joints; p.velocity = o->velocity;
   p.observation = o->observation; p.proprio = o->gripper_proprioception; p.reward = o->reward; p.is_success = o->is_success;
-  p.target_poses = o->target_poses; p.status = o->status;
+  p.target_poses = o->target_poses; p.status = o->status; p.pack = o->pack;
   return p;
 }
 
 extern "C" {
 
 #ifdef RP_WIDE
-const char* rp_version(void) { return "rp_playroom 0.1 (gfx950, wide build: two-object play ids)"; }
+const char* rp_version(void) { return "rp_playroom 0.2 (gfx950, wide build: two-object play ids)"; }
 #else
-const char* rp_version(void) { return "rp_playroom 0.1 (gfx950, wave-per-env)"; }
+const char* rp_version(void) { return "rp_playroom 0.2 (gfx950)"; }
 #endif
+
+static void destroy_handle(rp_sim* h) {        /* frees whatever a (possibly partial) handle owns; hipFree(nullptr) etc. are no-ops */
+  if (!h) return;
+  hipFree(h->dev_model); hipFree(h->state); hipFree(h->ws); hipFree(h->dbg); hipFree(h->sort_cnt); hipFree(h->sort_slot); hipFree(h->pair_env); hipFree(h->member[0]); hipFree(h->member[1]);
+  hipFree(h->rs_state); hipFree(h->rs_idx); hipFree(h->rs_meta); hipFree(h->rs_count); hipFree(h->rs_sort_cnt); hipFree(h->rs_sort_slot); hipFree(h->rs_pair);
+  if (h->rs_count_host) hipHostFree(h->rs_count_host);
+  if (h->ev0) hipEventDestroy(h->ev0);
+  if (h->ev1) hipEventDestroy(h->ev1);
+  if (h->gfork) hipEventDestroy(h->gfork);
+  for (int i = 0; i < RP_MAX_GROUPS; i++) { if (h->gstream[i]) hipStreamDestroy(h->gstream[i]); if (h->gjoin[i]) hipEventDestroy(h->gjoin[i]); }
+  if (h->pool) { for (int i = 0; i < h->pool_steps * EV_PER_STEP; i++) if (h->pool[i]) hipEventDestroy(h->pool[i]); free(h->pool); }
+  free(h);
+}
 
 int rp_create(const rp_config* cfg, rp_handle* out) {
   if (!cfg || !out || cfg->num_envs <= 0) { snprintf(g_err, 256, "rp_create: bad argument"); return RP_ERR_ARG; }
+  if (cfg->num_envs > RP_MAX_ENVS) { snprintf(g_err, 256, "rp_create: num_envs %d exceeds %d (rank field of the env pairing tables)", cfg->num_envs, RP_MAX_ENVS); return RP_ERR_ARG; }
   if (cfg->env_kind < 0 || cfg->env_kind >= RP_ENV_COUNT) { snprintf(g_err, 256, "rp_create: unsupported env kind %d", cfg->env_kind); return RP_ERR_UNSUPPORTED; }
-  rp_sim* h = (rp_sim*)calloc(1, sizeof(rp_sim));
-  h->cfg = *cfg;
-  rp_model* m = (rp_model*)malloc(sizeof(rp_model));
+  if ((cfg->flags & RP_CFG_ACTION_TYPE) && (cfg->action_type < 0 || cfg->action_type > RP_ACTION_RELATIVE_JOINTS)) { snprintf(g_err, 256, "rp_create: action_type %d", cfg->action_type); return RP_ERR_ARG; }
+  if ((cfg->flags & RP_CFG_CONTACT_MARGIN) && !(cfg->contact_margin >= 0.f && cfg->contact_margin <= 0.05f)) { snprintf(g_err, 256, "rp_create: contact_margin %g outside [0, 0.05]", (double)cfg->contact_margin); return RP_ERR_ARG; }
   /* registered id -> baked model (arm + scene) and action type.  The ids of a play family share scene, arm and configuration
    * (envList.py:43-140); only perform_action differs. */
   static const struct { char model; int action_type; } SPEC[RP_ENV_COUNT] = {
@@ -88,12 +113,19 @@ int rp_create(const rp_config* cfg, rp_handle* out) {
     {'Q', RP_ACT_ABS_RPY}, {'Q', RP_ACT_ABS_RPY},
     {'V', RP_ACT_ABS_QUAT}, {'V', RP_ACT_REL_QUAT}, {'V', RP_ACT_REL_JOINTS}, {'V', RP_ACT_ABS_JOINTS}, {'V', RP_ACT_ABS_RPY}, {'V', RP_ACT_REL_RPY},
     {'W', RP_ACT_ABS_QUAT}, {'W', RP_ACT_REL_JOINTS}};
-  const int action_type = SPEC[cfg->env_kind].action_type;
+  static_assert(RP_ACT_ABS_RPY == RP_ACTION_ABSOLUTE_RPY && RP_ACT_REL_RPY == RP_ACTION_RELATIVE_RPY && RP_ACT_ABS_QUAT == RP_ACTION_ABSOLUTE_QUAT &&
+                RP_ACT_REL_QUAT == RP_ACTION_RELATIVE_QUAT && RP_ACT_ABS_JOINTS == RP_ACTION_ABSOLUTE_JOINTS && RP_ACT_REL_JOINTS == RP_ACTION_RELATIVE_JOINTS,
+                "public rp_action_type values are the kernels' RP_ACT_*");
+  const int action_type = (cfg->flags & RP_CFG_ACTION_TYPE) ? cfg->action_type : SPEC[cfg->env_kind].action_type;
 #ifdef RP_WIDE
-  if (SPEC[cfg->env_kind].model != 'W') { snprintf(g_err, 256, "rp_create: env kind %d is served by librp_playroom_hip.so, not by the wide build", cfg->env_kind); free(m); free(h); return RP_ERR_UNSUPPORTED; }
+  if (SPEC[cfg->env_kind].model != 'W') { snprintf(g_err, 256, "rp_create: env kind %d is served by librp_playroom_hip.so, not by the wide build", cfg->env_kind); return RP_ERR_UNSUPPORTED; }
 #else
-  if (SPEC[cfg->env_kind].model == 'W') { snprintf(g_err, 256, "rp_create: the two-object ids (env kind %d) are served by librp_playroom_hip_wide.so", cfg->env_kind); free(m); free(h); return RP_ERR_UNSUPPORTED; }
+  if (SPEC[cfg->env_kind].model == 'W') { snprintf(g_err, 256, "rp_create: the two-object ids (env kind %d) are served by librp_playroom_hip_wide.so", cfg->env_kind); return RP_ERR_UNSUPPORTED; }
 #endif
+  rp_sim* h = (rp_sim*)calloc(1, sizeof(rp_sim));
+  rp_model* m = (rp_model*)malloc(sizeof(rp_model));
+  if (!h || !m) { free(h); free(m); snprintf(g_err, 256, "rp_create: out of host memory"); return RP_ERR_ARG; }
+  h->cfg = *cfg;
   switch (SPEC[cfg->env_kind].model) {
     case 'W': rp_fill_model_W(m); break;
     case 'R': rp_fill_model_R(m); break;
@@ -103,6 +135,7 @@ int rp_create(const rp_config* cfg, rp_handle* out) {
     default: rp_fill_model_U(m); break;
   }
   rp_build_dev_model(m, &h->host_model);
+  free(m);
   DevModel* d = &h->host_model;
   if (cfg->env_kind == RP_ENV_PANDA_PUSH) {      /* pandaPick's arm and scene with pandaPush's ranges (envList.py:12-16) */
     const float gl[3] = {-0.1f, -0.1f, -0.06f}, gh[3] = {0.1f, 0.1f, -0.05f}, eh[3] = {0.18f, 0.18f, -0.04f};
@@ -112,60 +145,73 @@ int rp_create(const rp_config* cfg, rp_handle* out) {
     const float gl[3] = {-0.18f, -0.18f, -0.06f}, gh[3] = {0.18f, 0.18f, -0.05f}, eh[3] = {0.18f, 0.18f, 0.0f};
     for (int k = 0; k < 3; k++) { d->goal_lo[k] = gl[k]; d->goal_hi[k] = gh[k]; d->env_hi[k] = eh[k]; }
   }
-  h->host_model.action_type = action_type;
-  h->host_model.n_action = (action_type == RP_ACT_ABS_QUAT || action_type == RP_ACT_REL_QUAT) ? 8
-                         : ((action_type == RP_ACT_ABS_JOINTS || action_type == RP_ACT_REL_JOINTS) ? h->host_model.n_target + 1 : 7);
-  free(m);
-  hipError_t e = hipSetDevice(cfg->device);
-  if (e != hipSuccess) { snprintf(g_err, 256, "hipSetDevice(%d): %s", cfg->device, hipGetErrorString(e)); free(h); return RP_ERR_HIP; }
-  if (hipMalloc((void**)&h->dev_model, sizeof(DevModel)) != hipSuccess ||
-      hipMalloc((void**)&h->state, (size_t)cfg->num_envs * RP_REC_FLOATS * sizeof(float)) != hipSuccess ||
-      hipMalloc((void**)&h->ws, (size_t)cfg->num_envs * W3_FLOATS * sizeof(float)) != hipSuccess ||
-      hipMalloc((void**)&h->dbg, 4096 * sizeof(float)) != hipSuccess ||
-      hipMalloc((void**)&h->sort_cnt, (size_t)2 * RP_MAX_GROUPS * SORT_BINS * sizeof(int)) != hipSuccess ||
-      hipMalloc((void**)&h->sort_slot, (size_t)cfg->num_envs * sizeof(int)) != hipSuccess ||
-      hipMalloc((void**)&h->pair_env, (size_t)cfg->num_envs * sizeof(int)) != hipSuccess ||
-      hipMalloc((void**)&h->member[0], (size_t)cfg->num_envs * sizeof(int)) != hipSuccess ||
-      hipMalloc((void**)&h->member[1], (size_t)cfg->num_envs * sizeof(int)) != hipSuccess) {
-    snprintf(g_err, 256, "rp_create: hipMalloc failed"); free(h); return RP_ERR_HIP;
+  /* the constructor kwargs of the env class (rp_config.flags; environments.py:64-67) */
+  for (int k = 0; k < 3; k++) {
+    if (cfg->flags & RP_CFG_GOAL_RANGE) { d->goal_lo[k] = cfg->goal_range_low[k]; d->goal_hi[k] = cfg->goal_range_high[k]; }
+    if (cfg->flags & RP_CFG_OBJ_RANGE) { d->obj_lo[k] = cfg->obj_lower_bound[k]; d->obj_hi[k] = cfg->obj_upper_bound[k]; }
+    if (cfg->flags & RP_CFG_ENV_RANGE) d->env_hi[k] = cfg->env_range_high[k];
   }
-  if (hipMemcpy(h->dev_model, &h->host_model, sizeof(DevModel), hipMemcpyHostToDevice) != hipSuccess) {
-    snprintf(g_err, 256, "rp_create: model upload failed"); free(h); return RP_ERR_HIP;
+  if (cfg->flags & RP_CFG_REW_THRESH) d->rew_thresh = cfg->sparse_rew_thresh;
+  if (cfg->flags & RP_CFG_DENSE_REWARD) d->dense_reward = 1;
+  if (cfg->flags & RP_CFG_CONTACT_MARGIN) d->margin = cfg->contact_margin;
+  d->action_type = action_type;
+  d->n_action = (action_type == RP_ACT_ABS_QUAT || action_type == RP_ACT_REL_QUAT) ? 8
+              : ((action_type == RP_ACT_ABS_JOINTS || action_type == RP_ACT_REL_JOINTS) ? d->n_target + 1 : 7);
+  DevGuard guard(cfg->device);
+  const int N = cfg->num_envs;
+  int rc = RP_ERR_HIP;
+  hipError_t e = hipSuccess;
+#define CREATE_CHK(call) do { e = (call); if (e != hipSuccess) { snprintf(g_err, 256, "rp_create: %s: %s", #call, hipGetErrorString(e)); goto fail; } } while (0)
+  {
+    int ndev = 0;
+    CREATE_CHK(hipGetDeviceCount(&ndev));
+    if (cfg->device < 0 || cfg->device >= ndev) { snprintf(g_err, 256, "rp_create: device %d of %d", cfg->device, ndev); rc = RP_ERR_ARG; goto fail; }
   }
-  hipEventCreate(&h->ev0); hipEventCreate(&h->ev1);
+  CREATE_CHK(hipSetDevice(cfg->device));
+  CREATE_CHK(hipMalloc((void**)&h->dev_model, sizeof(DevModel)));
+  CREATE_CHK(hipMalloc((void**)&h->state, (size_t)N * RP_REC_FLOATS * sizeof(float)));
+  CREATE_CHK(hipMalloc((void**)&h->ws, (size_t)N * W3_FLOATS * sizeof(float)));
+  CREATE_CHK(hipMalloc((void**)&h->dbg, 4096 * sizeof(float)));
+  CREATE_CHK(hipMalloc((void**)&h->sort_cnt, (size_t)2 * RP_MAX_GROUPS * SORT_BINS * sizeof(int)));
+  CREATE_CHK(hipMalloc((void**)&h->sort_slot, (size_t)N * sizeof(int)));
+  CREATE_CHK(hipMalloc((void**)&h->pair_env, (size_t)N * sizeof(int)));
+  CREATE_CHK(hipMalloc((void**)&h->member[0], (size_t)N * sizeof(int)));
+  CREATE_CHK(hipMalloc((void**)&h->member[1], (size_t)N * sizeof(int)));
+  CREATE_CHK(hipMemcpy(h->dev_model, &h->host_model, sizeof(DevModel), hipMemcpyHostToDevice));
+  CREATE_CHK(hipEventCreate(&h->ev0));
+  CREATE_CHK(hipEventCreate(&h->ev1));
   {
     const char* g = getenv("RP_STEP_GROUPS");
     h->groups = g ? atoi(g) : 3;      /* 3 group streams + nothing else stays within the 4 hardware queues ROCm multiplexes onto */
     if (h->groups < 1) h->groups = 1;
     if (h->groups > RP_MAX_GROUPS) h->groups = RP_MAX_GROUPS;
-    hipEventCreateWithFlags(&h->gfork, hipEventDisableTiming);
+    CREATE_CHK(hipEventCreateWithFlags(&h->gfork, hipEventDisableTiming));
     /* RP_GROUP_SPLIT="30,30,40": relative group sizes, heaviest group first (default: 25,35,40 for 3 groups, equal otherwise).  Stream priorities for the heavy
      * group were tried and lose (2.69 vs 2.61 ms per step). */
     const char* sp = getenv("RP_GROUP_SPLIT");
     for (int i = 0; i < RP_MAX_GROUPS; i++) h->gsplit[i] = 0;
     if (sp) { int i = 0; while (*sp && i < RP_MAX_GROUPS) { h->gsplit[i++] = atoi(sp); while (*sp && *sp != ',') sp++; if (*sp == ',') sp++; } }
-    for (int i = 0; i < RP_MAX_GROUPS; i++) { hipStreamCreateWithFlags(&h->gstream[i], hipStreamNonBlocking); hipEventCreateWithFlags(&h->gjoin[i], hipEventDisableTiming); }
+    for (int i = 0; i < RP_MAX_GROUPS; i++) {
+      CREATE_CHK(hipStreamCreateWithFlags(&h->gstream[i], hipStreamNonBlocking));
+      CREATE_CHK(hipEventCreateWithFlags(&h->gjoin[i], hipEventDisableTiming));
+    }
   }
-  int N = cfg->num_envs;
   hipLaunchKernelGGL(k_init, dim3((N + 255) / 256), dim3(256), 0, 0, h->dev_model, h->state, N);
-  e = hipDeviceSynchronize();
-  if (e != hipSuccess) { snprintf(g_err, 256, "rp_create: init kernel: %s", hipGetErrorString(e)); free(h); return RP_ERR_HIP; }
+  CREATE_CHK(hipGetLastError());
+  CREATE_CHK(hipDeviceSynchronize());
+#undef CREATE_CHK
   *out = h;
   return RP_OK;
+fail:
+  destroy_handle(h);
+  return rc;
 }
 
 int rp_destroy(rp_handle h) {
   if (!h) return RP_ERR_ARG;
-  hipSetDevice(h->cfg.device);
-  hipFree(h->dev_model); hipFree(h->state); hipFree(h->ws); hipFree(h->dbg); hipFree(h->sort_cnt); hipFree(h->sort_slot); hipFree(h->pair_env); hipFree(h->member[0]); hipFree(h->member[1]);
-  if (h->rs_state) {
-    hipFree(h->rs_state); hipFree(h->rs_idx); hipFree(h->rs_meta); hipFree(h->rs_count); hipFree(h->rs_sort_cnt); hipFree(h->rs_sort_slot);
-    hipFree(h->rs_pair); hipHostFree(h->rs_count_host);
-  }
-  hipEventDestroy(h->ev0); hipEventDestroy(h->ev1); hipEventDestroy(h->gfork);
-  for (int i = 0; i < RP_MAX_GROUPS; i++) { hipStreamDestroy(h->gstream[i]); hipEventDestroy(h->gjoin[i]); }
-  if (h->pool) { for (int i = 0; i < h->pool_steps * EV_PER_STEP; i++) hipEventDestroy(h->pool[i]); free(h->pool); }
-  free(h);
+  DevGuard guard(h->cfg.device);
+  hipDeviceSynchronize();
+  destroy_handle(h);
   return RP_OK;
 }
 
@@ -220,10 +266,21 @@ static int reset_split(rp_handle h, const uint8_t* mask, const rp_out* out, hipS
     hipLaunchKernelGGL(k_reset_finish, dim3(M), dim3(64), 0, s, h->dev_model, h->rs_state, h->state, h->rs_idx, h->rs_meta, op, M, seed, off);
     HIPCHK(h, hipGetLastError());
   }
+  /* the round budget is 9 object re-samples x 64 attempts, which k_reset_finish's own caps (depth < 8, attempt < 64) cannot
+   * exceed; if envs are pending all the same, say so instead of handing back half-reset records */
+  hipLaunchKernelGGL(k_reset_list, dim3(1), dim3(64), 0, s, h->rs_meta, h->rs_idx, h->rs_count, N);
+  HIPCHK(h, hipMemcpyAsync(h->rs_count_host, h->rs_count, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipStreamSynchronize(s));
+  if (*h->rs_count_host > 0) {
+    hipLaunchKernelGGL(k_reset_flag_pending, dim3((N + 255) / 256), dim3(256), 0, s, h->rs_meta, op.status, N);
+    snprintf(h->err, 256, "rp_reset: %d envs still pending after %d rounds (status bit 4 set)", *h->rs_count_host, h->reset_rounds);
+    return RP_ERR_INCOMPLETE;
+  }
   return RP_OK;
 }
 
 static int reset_impl(rp_handle h, const float* o, int32_t n_o, const uint8_t* mask, const rp_out* out, void* stream) {
+  DevGuard guard(h->cfg.device);
   hipStream_t s = (hipStream_t)stream;
   int N = h->cfg.num_envs;
   if (h->timers_on) hipEventRecord(h->ev0, s);
@@ -255,6 +312,7 @@ int rp_reset_to(rp_handle h, const float* o, int32_t n_o, const uint8_t* mask, c
 
 int rp_reset_goal(rp_handle h, const float* goal, const uint8_t* mask, void* stream) {
   if (!h) return RP_ERR_ARG;
+  DevGuard guard(h->cfg.device);
   int N = h->cfg.num_envs;
   hipLaunchKernelGGL(k_reset_goal, dim3(N), dim3(64), 0, (hipStream_t)stream, h->dev_model, h->state, goal, mask, N, h->cfg.seed,
                      (uint32_t)h->cfg.env_offset);
@@ -264,6 +322,7 @@ int rp_reset_goal(rp_handle h, const float* goal, const uint8_t* mask, void* str
 
 int rp_step(rp_handle h, const float* action, const rp_out* out, void* stream) {
   if (!h || !action) { if (h) snprintf(h->err, 256, "rp_step: action is NULL"); return RP_ERR_ARG; }
+  DevGuard guard(h->cfg.device);
   hipStream_t s = (hipStream_t)stream;
   int N = h->cfg.num_envs;
   if (h->timers_on && h->fused == 1) hipEventRecord(h->ev0, s);
@@ -352,6 +411,7 @@ int rp_step(rp_handle h, const float* action, const rp_out* out, void* stream) {
 
 int rp_calc_state(rp_handle h, const rp_out* out, void* stream) {
   if (!h) return RP_ERR_ARG;
+  DevGuard guard(h->cfg.device);
   int N = h->cfg.num_envs;
   hipLaunchKernelGGL(k_calc_state, dim3(N), dim3(64), 0, (hipStream_t)stream, h->dev_model, h->state, to_ptrs(out), 0, N, (const int*)nullptr);
   HIPCHK(h, hipGetLastError());
@@ -361,6 +421,7 @@ int rp_calc_state(rp_handle h, const rp_out* out, void* stream) {
 int rp_compute_reward(rp_handle h, const float* ag, const float* dg, float* r, int32_t m, void* stream) {
   if (!h || !ag || !dg || !r || m < 0) return RP_ERR_ARG;
   if (m == 0) return RP_OK;
+  DevGuard guard(h->cfg.device);
   hipLaunchKernelGGL(k_reward, dim3((m + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->dev_model, ag, dg, r, m);
   HIPCHK(h, hipGetLastError());
   return RP_OK;
@@ -370,12 +431,14 @@ size_t rp_state_bytes(rp_handle h) { (void)h; return RP_REC_FLOATS * sizeof(floa
 
 int rp_get_state(rp_handle h, void* dst, void* stream) {
   if (!h || !dst) return RP_ERR_ARG;
+  DevGuard guard(h->cfg.device);
   HIPCHK(h, hipMemcpyAsync(dst, h->state, (size_t)h->cfg.num_envs * RP_REC_FLOATS * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return RP_OK;
 }
 
 int rp_set_state(rp_handle h, const void* src, int32_t src_env_count, void* stream) {
   if (!h || !src) return RP_ERR_ARG;
+  DevGuard guard(h->cfg.device);
   int N = h->cfg.num_envs;
   if (src_env_count != 1 && src_env_count != N) { snprintf(h->err, 256, "rp_set_state: src_env_count %d is neither 1 nor %d", src_env_count, N); return RP_ERR_STATE_SIZE; }
   size_t total = (size_t)N * RP_REC_FLOATS;
@@ -393,6 +456,7 @@ int rp_set_fused(rp_handle h, int32_t fused) {
 }
 int rp_get_timers(rp_handle h, rp_timers* t) {
   if (!h || !t) return RP_ERR_ARG;
+  DevGuard guard(h->cfg.device);
   rp_timers r = h->timers;
   r.steps_timed = 0; r.avg_step_ms = r.avg_action_ms = r.avg_prep_ms = r.avg_solve_ms = r.avg_obs_ms = 0.f;
   if (h->pool && h->pool_count > 0) {
@@ -420,6 +484,7 @@ int rp_get_timers(rp_handle h, rp_timers* t) {
 }
 int rp_enable_timers(rp_handle h, int32_t on) {
   if (!h || on < 0) return RP_ERR_ARG;
+  DevGuard guard(h->cfg.device);
   if (h->pool) { for (int i = 0; i < h->pool_steps * EV_PER_STEP; i++) hipEventDestroy(h->pool[i]); free(h->pool); h->pool = nullptr; }
   h->timers_on = on; h->pool_steps = on; h->pool_next = 0; h->pool_count = 0;
   if (on > 0) {
@@ -430,9 +495,12 @@ int rp_enable_timers(rp_handle h, int32_t on) {
 }
 const char* rp_last_error(rp_handle h) { return h ? h->err : g_err; }
 
-/* test hook (not part of the public header): one substep on every env, intermediates of env `env` into host buf[4096] */
+int rp_debug_reset_rounds(rp_handle h) { return h ? h->reset_rounds : RP_ERR_ARG; }
+
+/* test hooks (include/rp_playroom_debug.h): one substep on every env, intermediates of env `env` into host buf[4096] */
 int rp_debug_substep(rp_handle h, int32_t env, float* host_buf) {
   if (!h || !host_buf) return RP_ERR_ARG;
+  DevGuard guard(h->cfg.device);
   int N = h->cfg.num_envs;
   HIPCHK(h, hipMemset(h->dbg, 0, 4096 * sizeof(float)));
   hipLaunchKernelGGL(k_debug_substep, dim3(N), dim3(64), 0, 0, h->dev_model, h->state, h->dbg, N, env);
@@ -444,6 +512,7 @@ int rp_debug_substep(rp_handle h, int32_t env, float* host_buf) {
 /* test hook: per-env (nsmall, ncon) of the most recent k_prep2 into host_buf[2*N] */
 int rp_debug_row_counts(rp_handle h, int32_t* host_buf) {
   if (!h || !host_buf) return RP_ERR_ARG;
+  DevGuard guard(h->cfg.device);
   HIPCHK(h, hipDeviceSynchronize());
   int N = h->cfg.num_envs;
   for (int e = 0; e < N; e++) {   /* header: maskL, maskU, nj, ncon, nA, nB, gear, nC -> (unit rows, ncon + 1000 * (arm contact) + 1e5 * spanning contacts) */

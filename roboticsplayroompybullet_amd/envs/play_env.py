@@ -2,8 +2,10 @@
 
 `playEnv` keeps the reference's method names, argument meaning, observation-dict keys, shapes and dtypes; underneath
 it is a VecPlayEnv of one environment on the GPU.  Like the reference, nothing touches the simulator until the first
-reset() ("activate_physics_client", environments.py:175-177).  Out of scope and raising NotImplementedError:
-reset(o=<observation>) (state restore through IK), GUI / VR / rendering.
+reset() ("activate_physics_client", environments.py:175-177).  The constructor kwargs that reach the simulation (ranges,
+reward threshold, sparse / dense reward, action type) are handed to the library through rp_config; kwargs that would change
+the observation layout of the registered id (num_objects, use_orientation, return_velocity, play, arm_type) raise when they
+differ from the id's.  Out of scope and raising NotImplementedError: GUI / VR clients.
 """
 import numpy as np
 
@@ -45,9 +47,12 @@ class playEnv:
                  goal_range_low=(-0.18, -0.18, -0.05), goal_range_high=(0.18, 0.18, 0.05), obj_lower_bound=(-0.18, -0.18, -0.05),
                  obj_upper_bound=(-0.18, -0.18, -0.05), sparse=True, use_orientation=False, sparse_rew_thresh=0.05,
                  fixed_gripper=False, return_velocity=True, max_episode_steps=250, play=False, action_type='absolute_rpy',
-                 show_goal=True, arm_type='Panda', device=0, seed=0):
-        if action_type != 'absolute_rpy' and not play:
-            raise NotImplementedError('action_type %r is built for the play ids only (SURVEY.md §8f rank 1)' % action_type)
+                 show_goal=True, arm_type='Panda', device=0, seed=None, contact_margin=None):
+        # seed=None: like the reference, which draws from the global np.random (environments.py:496, 530, 579), every new env gets
+        # its own episode stream and np.random.seed(k) makes it repeatable
+        if seed is None:
+            seed = int(np.random.randint(0, 2 ** 31 - 1))
+        self.sparse, self._contact_margin = bool(sparse), contact_margin
         self.timeStep = 1.0 / 300
         self.render_scene = False
         self.physics_client_active = 0
@@ -96,15 +101,27 @@ class playEnv:
                                              cat([self.arm_upper_lim] + [obj_upper_positional_lim] * num_objects))))
         self._vec = None
         self.instance = None
-        if not sparse:
-            raise NotImplementedError('dense reward variant is not registered by the reference ids in scope')
 
     # -- reference surface ------------------------------------------------------------------------------------------
     def activate_physics_client(self, vr=None):
         if vr is not None or self.render_scene:
             raise NotImplementedError('GUI / VR clients are out of scope (SURVEY.md §2.1)')
         from ..vec_env import VecPlayEnv
-        self._vec = VecPlayEnv(self.ENV_ID, 1, device=self._device, seed=self._seed)
+        self._vec = VecPlayEnv(self.ENV_ID, 1, device=self._device, seed=self._seed, action_type=self.action_type,
+                               goal_range_low=self.goal_lower_bound, goal_range_high=self.goal_upper_bound,
+                               obj_lower_bound=self.obj_lower_bound, obj_upper_bound=self.obj_upper_bound,
+                               env_range_high=self.env_upper_bound, sparse_rew_thresh=self.sparse_rew_thresh, sparse=self.sparse,
+                               contact_margin=self._contact_margin)
+        # kwargs that define the layout belong to the registered id: refuse silently different envs
+        d = self._vec.dims
+        per_obj = 3 + (4 if self.use_orientation else 0) + (3 if self.return_velocity else 0)
+        want_obs = 3 + (3 if self.return_velocity else 0) + (4 if self.use_orientation else 0) + 1 + self.num_objects * per_obj + (4 if self.play and self.num_objects else 0)
+        want_tp = 6 if self.arm_type == 'UR5' else 7
+        if d['obs_quat'] != want_obs or d['target_poses'] != want_tp:
+            self._vec.close()
+            self._vec = None
+            raise NotImplementedError('%s is registered with another num_objects / use_orientation / return_velocity / play / arm_type; '
+                                      'these kwargs cannot be overridden (the id fixes the baked scene and the observation layout)' % self.ENV_ID)
         self.instance = _InstanceShim(self)
 
     def reset(self, o=None, vr=None):
@@ -144,7 +161,10 @@ class playEnv:
         r = self._vec.compute_reward(ag, dg).cpu().numpy().astype(np.float64)
         return float(r) if r.ndim == 0 else r
 
-    compute_reward_sparse = compute_reward
+    def compute_reward_sparse(self, achieved_goal, desired_goal, info=None):
+        if self.sparse:
+            return self.compute_reward(achieved_goal, desired_goal, info)
+        raise NotImplementedError('this env was built with sparse=False: the device holds the dense reward (environments.py:169-170)')
 
     def calc_target_distance(self, achieved_goal, desired_goal):
         return float(np.linalg.norm(np.asarray(achieved_goal) - np.asarray(desired_goal)))

@@ -26,7 +26,11 @@ WIDE_STATE_LAYOUT = {'q': (0, 9), 'qd': (9, 18), 'free0': (18, 31), 'free1': (31
 
 
 class VecPlayEnv:
-    def __init__(self, env_id, num_envs, device=0, seed=0, env_offset=0):
+    def __init__(self, env_id, num_envs, device=0, seed=0, env_offset=0, action_type=None, goal_range_low=None, goal_range_high=None,
+                 obj_lower_bound=None, obj_upper_bound=None, env_range_high=None, sparse_rew_thresh=None, sparse=True,
+                 contact_margin=None):
+        """The keyword arguments after env_offset are the constructor kwargs of the reference's env classes that reach the
+        simulation (envList.py -> environments.py:64-67); None keeps what the id registers.  contact_margin: rp_config."""
         if env_id not in _lib.ENV_KINDS:
             raise NotImplementedError('env id %r is outside the hot-path scope (SURVEY.md §8)' % (env_id,))
         if not torch.cuda.is_available():
@@ -39,6 +43,32 @@ class VecPlayEnv:
         idx = device if isinstance(device, int) else (torch.device(device).index or 0)
         self.device = torch.device('cuda', idx)
         cfg = _lib.RpConfig(_lib.ENV_KINDS[env_id], self.num_envs, self.device.index, int(env_offset), int(seed))
+        flags = 0
+        if (goal_range_low is None) != (goal_range_high is None) or (obj_lower_bound is None) != (obj_upper_bound is None):
+            raise ValueError('range kwargs come in low / high pairs')
+        if goal_range_low is not None:
+            flags |= _lib.CFG_GOAL_RANGE
+            cfg.goal_range_low[:] = [float(v) for v in goal_range_low]
+            cfg.goal_range_high[:] = [float(v) for v in goal_range_high]
+        if obj_lower_bound is not None:
+            flags |= _lib.CFG_OBJ_RANGE
+            cfg.obj_lower_bound[:] = [float(v) for v in obj_lower_bound]
+            cfg.obj_upper_bound[:] = [float(v) for v in obj_upper_bound]
+        if env_range_high is not None:
+            flags |= _lib.CFG_ENV_RANGE
+            cfg.env_range_high[:] = [float(v) for v in env_range_high]
+        if sparse_rew_thresh is not None:
+            flags |= _lib.CFG_REW_THRESH
+            cfg.sparse_rew_thresh = float(sparse_rew_thresh)
+        if not sparse:
+            flags |= _lib.CFG_DENSE_REWARD
+        if action_type is not None:
+            flags |= _lib.CFG_ACTION_TYPE
+            cfg.action_type = _lib.ACTION_TYPE_CODES[action_type]
+        if contact_margin is not None:
+            flags |= _lib.CFG_CONTACT_MARGIN
+            cfg.contact_margin = float(contact_margin)
+        cfg.flags = flags
         self.h = C.c_void_p()
         _lib.check(self.lib, None, self.lib.rp_create(C.byref(cfg), C.byref(self.h)), 'rp_create')
         d = _lib.RpDims()
@@ -55,8 +85,10 @@ class VecPlayEnv:
         self.buf['is_success'] = torch.zeros(N, dtype=torch.int32, device=dev)
         self.buf['target_poses'] = f(self.dims['target_poses'])
         self.buf['status'] = torch.zeros(N, dtype=torch.int32, device=dev)
+        # obs_quat | achieved_goal | reward | is_success in one row per env: the per-step multi-GPU gather's message (sharding.py)
+        self.buf['pack'] = f(self.dims['obs_quat'] + self.dims['achieved_goal'] + 2)
         self.out = _lib.RpOut(**{k: self.buf[k].data_ptr() for k, _ in _lib.RpOut._fields_})
-        at = _lib.ACTION_TYPES.get(env_id, 'absolute_rpy')                                          # environments.py:88-113
+        at = action_type or _lib.ACTION_TYPES.get(env_id, 'absolute_rpy')                           # environments.py:88-113
         hi = {'absolute_rpy': [6] * 6 + [1], 'absolute_joints': [6] * (self.dims['action'] - 1) + [1]}.get(at, [1] * self.dims['action'])
         self.action_type = at
         self.action_high = torch.tensor(hi, dtype=torch.float32, device=dev)
@@ -130,6 +162,12 @@ class VecPlayEnv:
         _lib.check(self.lib, self.h, self.lib.rp_compute_reward(self.h, C.c_void_p(ag2.data_ptr()), C.c_void_p(dg2.data_ptr()),
                                                                   C.c_void_p(r.data_ptr()), ag2.shape[0], self._stream()), 'rp_compute_reward')
         return r.reshape(ag.shape[:-1])
+
+    @property
+    def pack(self):
+        """[N, obs_quat + achieved_goal + 2] written by the latest step / reset / calc_state: obs_quat | achieved_goal | reward |
+        is_success (float)"""
+        return self.buf['pack']
 
     def render(self, mode='human'):
         return None       # rendering is out of scope (SURVEY.md §2.1); kept for call compatibility

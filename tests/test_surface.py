@@ -134,7 +134,7 @@ def test_two_object_play_surface(golden, gid, cls):
 
 def test_out_of_scope_surface_fails_loudly():
     with pytest.raises(NotImplementedError):
-        envs.playEnv(action_type='relative_quat')
+        envs.playEnv(action_type='velocity')          # not one of the six action types of environments.py:88-113
     env = envs.UR5Reach()
     with pytest.raises(NotImplementedError):
         env.visualise_sub_goal(None)
