@@ -42,44 +42,58 @@ def make_actions(n, steps, device, seed):
     return lo + (hi - lo) * u
 
 
-def cpu_baseline(seed, budget_s=12.0):
-    """The CPU oracle (a port of the same semantics, NOT PyBullet) on one host core: bounded sample of the workload."""
+def cpu_baseline(seed, margin=None):
+    """The CPU oracle (a port of the same semantics, NOT PyBullet) on the box's host cores: a bounded sample of the workload on
+    one thread and on all cores (envs over threads, static partition - SURVEY.md 8d)."""
     sys.path.insert(0, os.path.join(REPO, 'oracle'))
     import numpy as np
-    from oracle import OracleEnv
+    import oracle
     rng = np.random.default_rng(seed)
     lo = np.array([-0.18, 0.0, 0.05, -0.5, -0.5, -0.5, -1.0])
     hi = np.array([0.18, 0.3, 0.3, 0.5, 0.5, 0.5, 1.0])
-    n_env, n_steps, done = 0, 100, 0
-    t_total = 0.0
-    while t_total < budget_s and n_env < 256:
-        env = OracleEnv(ENV_ID, seed=seed, env_index=n_env)
-        env.reset()
-        acts = lo + (hi - lo) * rng.random((n_steps, 7))
-        t0 = time.perf_counter()
-        for a in acts:
-            env.step(a)
-        t_total += time.perf_counter() - t0
-        done += n_steps
-        n_env += 1
-    return {'value': done / t_total, 'unit': 'env-steps/s', 'cores': 1, 'kind': 'port',
-            'sample': '%d envs x %d steps of %s (distribution B) on the fp64 CPU oracle, 1 thread, reset excluded; '
-                      'PyBullet is not installed on this box' % (n_env, n_steps, ENV_ID),
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    n_steps = 50
+    # one thread: 40 envs x 50 steps ~ 3-5 s; all cores: 8 envs per thread x 50 steps ~ the same wall time (plus their resets)
+    a1 = lo + (hi - lo) * rng.random((40, n_steps, 7))
+    one = oracle.bench_rollout(ENV_ID, seed, a1, 1, margin=margin)
+    threads = min(cores, 1024)
+    aN = lo + (hi - lo) * rng.random((8 * threads, n_steps, 7))
+    allc = oracle.bench_rollout(ENV_ID, seed, aN, threads, margin=margin)
+    return {'value': allc, 'unit': 'env-steps/s', 'cores': threads, 'kind': 'port',
+            'one_core': {'value': one, 'cores': 1, 'sample': '40 envs x %d steps' % n_steps},
+            'sample': '%d envs x %d steps of %s (distribution B) on the fp64 CPU oracle, %d threads with the envs statically partitioned '
+                      '(8 per thread), resets excluded; the one_core leg runs 40 envs x %d steps on one thread; PyBullet is not installed '
+                      'on this box' % (8 * threads, n_steps, ENV_ID, threads, n_steps),
             'host_cpus': os.cpu_count()}
 
 
-def pmc_traffic(kernel):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r01_pmc_summary.json:
-    separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same bench; KB units; reads doubled per the gfx950 FETCH_SIZE
-    correction in MI355X_MICROARCH.md).  PMC counters cannot be read from inside this process, so this is the profile's
-    number, not a live one; None if the file is absent."""
-    path = os.path.join(REPO, 'profiles', 'r01_pmc_summary.json')
+STEP_KERNELS = ('k_action_prep', 'k_prep2', 'k_solve2', 'k_calc_state')     # what one rp_step launches (default pipeline)
+PMC_SUMMARY = 'r02_pmc_summary.json'
+
+
+def pmc_traffic(kernel=None):
+    """HBM-side bytes per launch of `kernel` (None: per env step, all of STEP_KERNELS weighted by their launches per step) from the
+    committed rocprofv3 PMC passes (profiles/r02_pmc_summary.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same bench;
+    KB units; reads doubled per the gfx950 FETCH_SIZE correction in MI355X_MICROARCH.md).  PMC counters cannot be read from
+    inside this process, so this is the profile's number, not a live one.  None if the file is absent, was taken with another
+    library version, or lacks one of the kernels rp_step launches today (a stale profile is refused, not quoted)."""
+    path = os.path.join(REPO, 'profiles', PMC_SUMMARY)
     if not os.path.exists(path):
         return None
-    k = json.load(open(path)).get(kernel)
-    if not k:
+    prof = json.load(open(path))
+    from roboticsplayroompybullet_amd import _lib
+    if prof.get('library_version') != _lib.load().rp_version().decode():
         return None
-    return (2.0 * k['FETCH_SIZE_KB_avg'] + k['WRITE_SIZE_KB_avg']) * 1024.0
+    if any(k not in prof for k in STEP_KERNELS):
+        return None
+    one = lambda k: (2.0 * prof[k]['FETCH_SIZE_KB_avg'] + prof[k]['WRITE_SIZE_KB_avg']) * 1024.0   # noqa: E731
+    if kernel is not None:
+        return one(kernel)
+    per_step = {'k_action_prep': 1, 'k_prep2': 11, 'k_solve2': 12, 'k_calc_state': 1}
+    return sum(n * one(k) * prof[k].get('launch_fraction_of_envs', 1.0) for k, n in per_step.items())
 
 
 def sharding_offset(rank, world, n):
@@ -95,6 +109,9 @@ def main():
     ap.add_argument('--envs-per-gpu', type=int, default=ENVS_PER_GPU)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--groups', type=int, default=0, help='env groups per rp_step (0 = library default)')
+    ap.add_argument('--contact-margin', type=float, default=None, help='rp_config.contact_margin in metres (default: the library default)')
+    ap.add_argument('--repeats', type=int, default=3, help='timed regions of --steps steps; `value` is the first one, the median is reported beside it')
+    ap.add_argument('--no-extras', action='store_true', help='skip distribution A and the second contact margin')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -117,7 +134,7 @@ def main():
 
     from roboticsplayroompybullet_amd import VecPlayEnv
     n = args.envs_per_gpu
-    env = VecPlayEnv(ENV_ID, n, device=dev_index, seed=1234, env_offset=sharding_offset(rank, world, n))
+    env = VecPlayEnv(ENV_ID, n, device=dev_index, seed=1234, env_offset=sharding_offset(rank, world, n), contact_margin=args.contact_margin)
     if args.groups:
         env.set_groups(args.groups)
     env.reset()
@@ -127,40 +144,46 @@ def main():
 
     from roboticsplayroompybullet_amd import sharding
 
-    def one_step(k):
-        obs, r, done, info = env.step(actions[k])
-        if world > 1:   # the only collective on the path: gather observations for a single consumer
-            sharding.gather_observations(sharding.pack_observations(obs, r, info['is_success']), out=gathered)
-        return info
+    def timed_region(env, acts, first, steps, events=None):
+        """EXACTLY `steps` env steps between barrier + synchronize on both sides; returns the max over ranks of the wall seconds.
+        For N > 1 the only collective on the path - the all-gather of env.pack (obs_quat | achieved_goal | reward | is_success,
+        written in that layout by k_calc_state itself) - is enqueued asynchronously after every step, so the gather of step k runs
+        on RCCL's stream while step k + 1's physics runs on ours; every gather is complete inside the region."""
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pending = None
+        for k in range(steps):
+            if events:
+                events[0][k].record()
+            obs, r, done, info = env.step(acts[first + k])
+            if events:
+                events[1][k].record()
+            if world > 1:
+                if pending is not None:
+                    pending.wait()
+                _, pending = sharding.gather_observations(env.pack, out=gathered, async_op=True)
+        if pending is not None:
+            pending.wait()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, info
 
     for k in range(args.warmup):
-        one_step(k)
+        env.step(actions[k])
+        if world > 1:
+            sharding.gather_observations(env.pack, out=gathered)
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    if world > 1:
-        dist.barrier()
+    elapsed, info = timed_region(env, actions, args.warmup, args.steps, (ev0, ev1))       # the contract's region: `value`
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    pending = None
-    for k in range(args.steps):
-        ev0[k].record()
-        obs, r, done, info = env.step(actions[args.warmup + k])
-        ev1[k].record()
-        if world > 1:      # the gather of step k runs on RCCL's stream while step k + 1's physics runs on ours
-            pack = sharding.pack_observations(obs, r, info['is_success'])
-            if pending is not None:
-                pending.wait()
-            _, pending = sharding.gather_observations(pack, out=gathered, async_op=True)
-    if pending is not None:
-        pending.wait()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
     step_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / args.steps
     # per-launch kernel durations: hipEvent pairs recorded on the launch stream inside rp_step; bracketing single kernels
     # needs the env groups (concurrent streams) switched off, so this is a second region over the same actions
@@ -171,11 +194,40 @@ def main():
     torch.cuda.synchronize()
     tm = env.timers()
     env.enable_timers(0)
-    bad = int(info['status'].sum().item())
+    bad = int((info['status'] & 1).sum().item())
+    fell = int(((info['status'] & 2) != 0).sum().item())
     success = float(info['is_success'].float().mean().item())
+    # repeats of the same region (same actions; the state keeps evolving) for a median, then the extras: distribution A (the literal
+    # random-action distribution of SURVEY.md 8d: U(action_space.low, high)) and the other contact margin
+    rep_values = [world * n * args.steps / elapsed]
+    for _ in range(max(0, args.repeats - 1)):
+        t_rep, _ = timed_region(env, actions, args.warmup, args.steps)
+        rep_values.append(world * n * args.steps / t_rep)
+    extras = {}
+    if not args.no_extras and world == 1:
+        g = torch.Generator(device=device).manual_seed(4321 + rank)
+        hi = env.action_high
+        acts_a = (2 * torch.rand((args.steps + args.warmup, n, 7), generator=g, device=device) - 1) * hi
+        for k in range(args.warmup):
+            env.step(acts_a[k])
+        t_a, info_a = timed_region(env, acts_a, args.warmup, args.steps)
+        extras['distribution_A'] = {'value': n * args.steps / t_a, 'ms_per_step': 1e3 * t_a / args.steps,
+                                    'what': 'a ~ U(action_space.low, action_space.high) = U(-6, 6)^6 x U(-1, 1), resampled every step (the '
+                                            'literal random-action rollout: targets mostly unreachable, the arm slews at the per-step clip)',
+                                    'non_finite_envs': int((info_a['status'] & 1).sum().item())}
+        other = 0.005 if (args.contact_margin is None or args.contact_margin > 0.01) else 0.02
+        env2 = VecPlayEnv(ENV_ID, n, device=dev_index, seed=1234, contact_margin=other)
+        env2.reset()
+        for k in range(args.warmup):
+            env2.step(actions[k])
+        t_m, _ = timed_region(env2, actions, args.warmup, args.steps)
+        extras['contact_margin_%g' % other] = {'value': n * args.steps / t_m, 'ms_per_step': 1e3 * t_m / args.steps,
+                                               'what': 'the same workload with rp_config.contact_margin = %g m' % other}
+        env2.close()
 
     if rank == 0:
         value = world * n * args.steps / elapsed
+        margin_used = args.contact_margin if args.contact_margin is not None else 'library default'
         solve_ms = tm['avg_solve_ms']
         achieved = ALG_BYTES_PER_ENV_SUBSTEP * n / (solve_ms * 1e-3) / 1e9
         step_achieved = ALG_BYTES_PER_ENV_STEP * n / (step_ms * 1e-3) / 1e9
@@ -185,28 +237,36 @@ def main():
             'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': '%s, %d envs per GPU, 12 substeps x 50 PGS sweeps per step, random actions '
-                                   '(distribution B, resampled every step), reset excluded' % (ENV_ID, n),
+                                   '(distribution B, resampled every step), reset excluded, contact margin: %s' % (ENV_ID, n, margin_used),
                        'envs_per_gpu': n, 'global_envs': world * n, 'parallelism': 'env-shard x%d' % world,
                        'collective': 'all_gather(obs_quat+achieved_goal+reward+is_success) per step' if world > 1 else 'none'},
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': pmc_traffic('k_solve2') if n == ENVS_PER_GPU else None, 'kernel': 'k_solve2', 'kernel_ms': solve_ms, 'launches_per_step': 12,
-                         'traffic_note': 'bytes per k_solve2 launch from profiles/r01_pmc_summary.json (2*FETCH_SIZE + WRITE_SIZE); '
-                                         'it is ~13x the algorithmic bytes because the constraint rows (~5 KB per env-substep) are '
-                                         'handed from k_prep2 to k_solve2 through an Infinity-Cache-resident workspace',
-                         'algorithmic_bytes_per_launch': ALG_BYTES_PER_ENV_SUBSTEP * n,
-                         'whole_step': {'achieved': step_achieved, 'frac': step_achieved / HBM_PEAK_GBS, 'ms': step_ms,
-                                        'algorithmic_bytes': ALG_BYTES_PER_ENV_STEP * n},
+            # frac = the strict SURVEY.md 8d figure: algorithmic bytes of a whole env step / measured step time / HBM peak; the dominant
+            # kernel's own per-launch figure sits in `dominant_kernel`
+            'roofline': {'bound': 'hbm', 'achieved': step_achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': step_achieved / HBM_PEAK_GBS,
+                         'traffic': pmc_traffic() if n == ENVS_PER_GPU else None,
+                         'what': 'whole env step: %d B algorithmic per env-step (SURVEY.md 8d) x %d envs / %.3f ms (torch events around rp_step on its stream)'
+                                 % (ALG_BYTES_PER_ENV_STEP, n, step_ms),
+                         'algorithmic_bytes_per_step': ALG_BYTES_PER_ENV_STEP * n,
+                         'limiter': 'latency / issue, not bandwidth: 50 sweeps of dependent PGS row updates per k_solve2 launch (the launch lasts as '
+                                    'long as its heaviest wave) - the HBM fraction is reported because the contract asks for it, not because it '
+                                    'is the ceiling; advisory FLOP model 9e6 FLOP/env-step => %.3g of the 157.3 TFLOP/s fp32 vector peak'
+                                    % (9e6 * n / (step_ms * 1e-3) / 157.3e12),
+                         'dominant_kernel': {'kernel': 'k_solve2', 'kernel_ms': solve_ms, 'launches_per_step': 12, 'achieved': achieved,
+                                             'frac': achieved / HBM_PEAK_GBS, 'algorithmic_bytes_per_launch': ALG_BYTES_PER_ENV_SUBSTEP * n,
+                                             'traffic': pmc_traffic('k_solve2') if n == ENVS_PER_GPU else None},
+                         'traffic_note': 'bytes per env step from profiles/%s (sum over the step\'s launches of 2*FETCH_SIZE + WRITE_SIZE); null when '
+                                         'that profile was taken with another library version' % PMC_SUMMARY,
                          'per_launch_ms': {'k_action': tm['avg_action_ms'], 'k_prep2': tm['avg_prep_ms'], 'k_solve2': solve_ms,
                                            'k_calc_state': tm['avg_obs_ms'], 'steps_timed': tm['steps_timed'],
                                            'how': 'hipEvent pair around every launch on the launch stream (rp_enable_timers), separate '
-                                                  'region right after the timed one with the env-group streams switched off'},
-                         'note': 'latency-bound path (50 sweeps of dependent PGS row updates per launch; the launch lasts as long as its '
-                                 'heaviest wave), not bandwidth-bound; advisory FLOP model '
-                                 '9e6 FLOP/env-step => %.3g of the 157.3 TFLOP/s fp32 vector peak' % (9e6 * n / (step_ms * 1e-3) / 157.3e12)},
-            'non_finite_envs': bad, 'success_rate_last_step': success,
+                                                  'region right after the timed one with the env-group streams switched off'}},
+            'repeats': {'values': rep_values, 'median': sorted(rep_values)[len(rep_values) // 2],
+                        'what': '%d timed regions of %d steps each; `value` is the first' % (len(rep_values), args.steps)},
+            'non_finite_envs': bad, 'fallen_objects': fell, 'success_rate_last_step': success,
         }
+        line.update(extras)
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(1234)
+            line['cpu_baseline'] = cpu_baseline(1234, args.contact_margin)
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

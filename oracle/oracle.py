@@ -108,6 +108,8 @@ def load(f32=False):
     lib.rpo_contacts.argtypes = [vp, dp, C.c_int]
     lib.rpo_last_num_rows.argtypes = [vp]
     lib.rpo_box_box.argtypes = [dp, dp, dp, dp, dp, dp, C.c_double, dp]
+    lib.rpo_bench_rollout.argtypes = [C.c_int, C.c_ulonglong, C.c_int, C.c_int, C.c_int, dp, C.c_int, C.c_double]
+    lib.rpo_bench_rollout.restype = C.c_double
     lib.rpo_rng_uniform.argtypes = [C.c_ulonglong, C.c_uint, C.c_uint]
     lib.rpo_rng_uniform.restype = C.c_double
     _LIBS[name] = lib
@@ -369,3 +371,15 @@ def euler_from_quat(q, f32=False):
 
 def dial_to_0_1_range(x):
     return load().rpo_dial_to_0_1_range(float(x))
+
+
+def bench_rollout(kind, seed, actions, n_threads, margin=None, f32=False):
+    """cpu_baseline leg: actions [n_envs, n_steps, action_dim] stepped on n_threads threads (envs statically partitioned);
+    returns env-steps per second of the stepping phase"""
+    lib = load(f32)
+    a, ap = _d(actions)
+    n_envs, n_steps, na = a.shape
+    t = lib.rpo_bench_rollout(KINDS[kind], seed, n_envs, n_steps, na, ap, int(n_threads), -1.0 if margin is None else float(margin))
+    if t <= 0:
+        raise RuntimeError('rpo_bench_rollout failed')
+    return n_envs * n_steps / t

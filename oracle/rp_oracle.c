@@ -12,9 +12,11 @@
  * calcAccelerationDeltasMultiDof).  The HIP library uses a different formulation; tests compare the two. */
 #include "rp_oracle.h"
 
+#include <pthread.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "rp_math.h"
 #include "../roboticsplayroompybullet_amd/csrc/generated/rp_models_gen.h"
@@ -1687,4 +1689,47 @@ int rpo_box_box(const double* ca, const double* Ra, const double* ha, const doub
     out[7 * i + 6] = pts[i].dist;
   }
   return n;
+}
+
+/* ------------------------------------------------------------------ bench.py's cpu_baseline leg: envs over threads, static partition
+ * ("one env per thread, static partition").  Every thread creates and resets its envs, all threads meet at a barrier,
+ * then step their envs through the given actions [n_envs][n_steps][action_dim]; returns the wall seconds of the stepping phase
+ * (resets excluded), 0 on failure. */
+typedef struct { int kind, tid, nthreads, n_envs, n_steps, na; unsigned long long seed; const double* actions; double margin; pthread_barrier_t* bar; double t0, t1; } bench_arg;
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+static void* bench_worker(void* p) {
+  bench_arg* a = (bench_arg*)p;
+  int lo = (int)((long long)a->n_envs * a->tid / a->nthreads), hi = (int)((long long)a->n_envs * (a->tid + 1) / a->nthreads);
+  int n = hi - lo;
+  rpo_env** envs = (rpo_env**)calloc(n > 0 ? n : 1, sizeof(rpo_env*));
+  rpo_obs o; double r, tp[7]; int ok;
+  for (int i = 0; i < n; i++) {
+    envs[i] = rpo_create(a->kind, a->seed, lo + i);
+    if (a->margin >= 0) rpo_set_margin(envs[i], a->margin);
+    rpo_reset(envs[i], 0, 0, &o);
+  }
+  pthread_barrier_wait(a->bar);
+  a->t0 = now_s();
+  for (int i = 0; i < n; i++)
+    for (int t = 0; t < a->n_steps; t++) rpo_step(envs[i], a->actions + ((size_t)(lo + i) * a->n_steps + t) * a->na, &o, &r, &ok, tp);
+  a->t1 = now_s();
+  pthread_barrier_wait(a->bar);
+  for (int i = 0; i < n; i++) rpo_destroy(envs[i]);
+  free(envs);
+  return 0;
+}
+double rpo_bench_rollout(int kind, unsigned long long seed, int n_envs, int n_steps, int action_dim, const double* actions, int n_threads, double margin) {
+  if (n_threads < 1 || n_envs < 1 || n_threads > 1024) return 0;
+  pthread_t th[1024]; bench_arg args[1024];
+  pthread_barrier_t bar;
+  pthread_barrier_init(&bar, 0, (unsigned)n_threads);
+  for (int t = 0; t < n_threads; t++) {
+    bench_arg a = {kind, t, n_threads, n_envs, n_steps, action_dim, seed, actions, margin, &bar, 0, 0};
+    args[t] = a;
+    if (pthread_create(&th[t], 0, bench_worker, &args[t])) return 0;
+  }
+  double t0 = 1e300, t1 = 0;
+  for (int t = 0; t < n_threads; t++) { pthread_join(th[t], 0); if (args[t].t0 < t0) t0 = args[t].t0; if (args[t].t1 > t1) t1 = args[t].t1; }
+  pthread_barrier_destroy(&bar);
+  return t1 - t0;
 }

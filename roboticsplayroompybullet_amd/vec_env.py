@@ -86,7 +86,10 @@ class VecPlayEnv:
         self.buf['target_poses'] = f(self.dims['target_poses'])
         self.buf['status'] = torch.zeros(N, dtype=torch.int32, device=dev)
         # obs_quat | achieved_goal | reward | is_success in one row per env: the per-step multi-GPU gather's message (sharding.py)
-        self.buf['pack'] = f(self.dims['obs_quat'] + self.dims['achieved_goal'] + 2)
+        # (two buffers, alternating per step: an asynchronous gather of step k's pack may still be reading it while step k + 1 runs)
+        self._packs = [f(self.dims['obs_quat'] + self.dims['achieved_goal'] + 2) for _ in range(2)]
+        self._pack_i = 0
+        self.buf['pack'] = self._packs[0]
         self.out = _lib.RpOut(**{k: self.buf[k].data_ptr() for k, _ in _lib.RpOut._fields_})
         at = action_type or _lib.ACTION_TYPES.get(env_id, 'absolute_rpy')                           # environments.py:88-113
         hi = {'absolute_rpy': [6] * 6 + [1], 'absolute_joints': [6] * (self.dims['action'] - 1) + [1]}.get(at, [1] * self.dims['action'])
@@ -133,6 +136,9 @@ class VecPlayEnv:
     def step(self, action):
         a = action.to(device=self.device, dtype=torch.float32).contiguous()
         assert a.shape == (self.num_envs, self.dims['action']), a.shape
+        self._pack_i ^= 1
+        self.buf['pack'] = self._packs[self._pack_i]
+        self.out.pack = self.buf['pack'].data_ptr()
         _lib.check(self.lib, self.h, self.lib.rp_step(self.h, C.c_void_p(a.data_ptr()), C.byref(self.out), self._stream()), 'rp_step')
         info = {'is_success': self.buf['is_success'], 'target_poses': self.buf['target_poses'], 'status': self.buf['status']}
         done = torch.zeros(self.num_envs, dtype=torch.bool, device=self.device)      # environments.py:212: always False

@@ -6,10 +6,16 @@ import re
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_functions():
-    src = open(os.path.join(REPO, 'include', 'rp_playroom.h')).read()
+def declared_functions(header='rp_playroom.h'):
+    src = open(os.path.join(REPO, 'include', header)).read()
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
-    return sorted(set(re.findall(r'\b(rp_[a-z_]+)\s*\(', src)))
+    return sorted(set(re.findall(r'\b(rp_[a-z_0-9]+)\s*\(', src)))
+
+
+def exported_functions(path):
+    import subprocess
+    out = subprocess.run(['nm', '-D', '--defined-only', path], check=True, capture_output=True, text=True).stdout
+    return sorted({ln.split()[-1] for ln in out.splitlines() if len(ln.split()) == 3 and ln.split()[1] == 'T' and ln.split()[-1].startswith('rp_')})
 
 
 def test_header_symbols_are_exported():
@@ -24,6 +30,36 @@ def test_header_symbols_are_exported():
         lib.rp_version.restype = ctypes.c_char_p
         assert b'gfx950' in lib.rp_version()
     assert set(_lib.EXPORTS) == set(names)
+
+
+def test_every_exported_symbol_is_declared_in_a_header():
+    """the converse: the library exports no rp_* function that neither include/rp_playroom.h nor include/rp_playroom_debug.h declares"""
+    from roboticsplayroompybullet_amd import _lib
+    _lib.build()
+    public, debug = set(declared_functions()), set(declared_functions('rp_playroom_debug.h'))
+    assert set(_lib.DEBUG_EXPORTS) == debug and not (public & debug)
+    for path in (_lib.LIB_PATH, _lib.WIDE_LIB_PATH):
+        exported = set(exported_functions(path))
+        assert exported, path
+        assert exported <= public | debug, 'undeclared exports in %s: %s' % (path, sorted(exported - public - debug))
+        assert public | debug <= exported
+
+
+def test_config_struct_matches_the_header():
+    """the ctypes mirror of rp_config / rp_out has the field order of include/rp_playroom.h"""
+    from roboticsplayroompybullet_amd import _lib
+    src = open(os.path.join(REPO, 'include', 'rp_playroom.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    for name, cls in (('rp_config', _lib.RpConfig), ('rp_out', _lib.RpOut), ('rp_dims', _lib.RpDims)):
+        body = re.search(r'typedef struct %s \{(.*?)\} %s;' % (name, name), src, flags=re.S).group(1)
+        fields = []
+        for decl in body.split(';'):
+            decl = decl.strip()
+            if not decl:
+                continue
+            for part in decl.split(',')[0:1] + decl.split(',')[1:]:
+                fields.append(re.sub(r'\[.*?\]', '', part.replace('*', ' ')).split()[-1])
+        assert fields == [f for f, _ in cls._fields_], (name, fields)
 
 
 def test_no_compute_without_gpu_and_no_cpu_fallback():

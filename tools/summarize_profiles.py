@@ -46,5 +46,9 @@ for sub, counter in (('pmc_fetch', 'FETCH_SIZE'), ('pmc_write', 'WRITE_SIZE')):
         e = pmc.setdefault(k, {})
         e['launches_sampled'] = len(vals)
         e['%s_KB_avg' % counter] = sum(vals) / len(vals)
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+from roboticsplayroompybullet_amd import _lib  # noqa: E402
+pmc['library_version'] = _lib.load().rp_version().decode()      # bench.py refuses to quote a profile of another library version
+pmc['command'] = 'bench.py --steps 5 --warmup 1 --groups 1 --no-cpu-baseline --no-extras (one rocprofv3 --pmc pass per counter)'
 json.dump(pmc, open(os.path.join(dst, '%s_pmc_summary.json' % tag), 'w'), indent=1)
 print(json.dumps({k: v for k, v in pmc.items() if k in ('k_solve2', 'k_prep2')}, indent=1))
