@@ -146,7 +146,7 @@ class OracleEnv:
     def __init__(self, kind, seed=0, env_index=0, f32=False, action_type=None, margin=None, ranges=None, sparse_rew_thresh=None,
                  dense_reward=False):
         """ranges = (goal_lo, goal_hi, obj_lo, obj_hi, env_hi): the env class's range kwargs (envList.py); margin: contact margin
-        in metres (default: the library's default, rp_model.h RP_DEFAULT_CONTACT_MARGIN)"""
+        in metres for every pair (default, like the library: per pair the smaller of the two objects' Bullet breaking thresholds, rp_model.col_thr)"""
         self.lib = load(f32)
         user_ranges = ranges
         ranges = None

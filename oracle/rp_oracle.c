@@ -29,7 +29,7 @@
 #define N_ITER 50                       /* PyBullet numSolverIterations default; never early-exits (environments.py:326) */
 #define ERP_CONTACT ((real)0.08)        /* PhysicsServerCommandProcessor erp2 (recalled) */
 #define LINEAR_SLOP ((real)1e-5)
-/* contact margin: rp_model.h RP_DEFAULT_CONTACT_MARGIN (the library's rp_config.contact_margin default), rpo_set_margin overrides */
+/* contact margin of a pair: the smaller of its two colliders' Bullet breaking thresholds (rp_model.col_thr) unless rpo_set_margin gave one value for all */
 #define MOTOR_KP ((real)0.1)
 #define MOTOR_KD ((real)1.0)
 #define DEFAULT_MOTOR_MAXIMP ((real)1.0) /* createJointMotors: velocity motor, target 0, max impulse 1 */
@@ -76,7 +76,7 @@ struct rpo_env {
   /* config flags (envList.py) */
   int play, use_orientation, return_velocity, num_objects;
   int action_type;                  /* RPO_ACT_*: perform_action's dispatch (environments.py:915-934) */
-  real margin;                      /* distance out to which contact points are created */
+  real margin;                      /* < 0: per pair min(col_thr[a], col_thr[b]) (default); >= 0: this value for every pair */
   real rew_thresh; int dense_reward; /* sparse_rew_thresh, sparse=False (environments.py:66, 169-170) */
   real goal_lo[3], goal_hi[3], obj_lo[3], obj_hi[3], env_hi[3];
   /* work */
@@ -400,19 +400,20 @@ static void collide(rpo_env* e) {
       man_oa = m->col_obj[a]; man_ob = m->col_obj[b];
     }
     int sep = 0;
+    const real margin = e->margin >= 0 ? e->margin : (real)(m->col_thr[a] < m->col_thr[b] ? m->col_thr[a] : m->col_thr[b]);
     for (int k = 0; k < 3; k++)
-      if (e->aabb_lo[a][k] > e->aabb_hi[b][k] + e->margin || e->aabb_lo[b][k] > e->aabb_hi[a][k] + e->margin) sep = 1;
+      if (e->aabb_lo[a][k] > e->aabb_hi[b][k] + margin || e->aabb_lo[b][k] > e->aabb_hi[a][k] + margin) sep = 1;
     if (sep) continue;
     if (nactive++ >= MAX_ACTIVE_PAIRS) continue;
     cpoint pts[4]; int np = 0;
     real ha[3], hb[3];
     for (int k = 0; k < 3; k++) { ha[k] = (real)m->col_he[a][k]; hb[k] = (real)m->col_he[b][k]; }
     if (m->col_type[a] == 0 && m->col_type[b] == 0)
-      np = box_box(e->xc[a].p, e->xc[a].R, ha, e->xc[b].p, e->xc[b].R, hb, e->margin, pts);
+      np = box_box(e->xc[a].p, e->xc[a].R, ha, e->xc[b].p, e->xc[b].R, hb, margin, pts);
     else if (m->col_type[a] == 0 && m->col_type[b] == 1)
-      np = sphere_box(e->xc[b].p, hb[0], e->xc[a].p, e->xc[a].R, ha, e->margin, 1, pts);
+      np = sphere_box(e->xc[b].p, hb[0], e->xc[a].p, e->xc[a].R, ha, margin, 1, pts);
     else if (m->col_type[a] == 1 && m->col_type[b] == 0)
-      np = sphere_box(e->xc[a].p, ha[0], e->xc[b].p, e->xc[b].R, hb, e->margin, 0, pts);
+      np = sphere_box(e->xc[a].p, ha[0], e->xc[b].p, e->xc[b].R, hb, margin, 0, pts);
     int kf = body_free_index(e, m->col_body[a]);
     int single = (kf >= 0 && m->free_rot_locked[kf] && m->col_body[b] == 0);
     for (int i = 0; i < np; i++) {
@@ -1561,7 +1562,7 @@ rpo_env* rpo_create(int kind, unsigned long long seed, int env_index) {
   e->nv = m->n_arm + 6 * m->n_free + m->n_joint1;
   e->nbody = 1 + m->n_arm + m->n_free + m->n_joint1;
   e->seed = seed; e->env_index = (uint32_t)env_index;
-  e->margin = (real)RP_DEFAULT_CONTACT_MARGIN; e->rew_thresh = (real)0.05; e->dense_reward = 0;
+  e->margin = -1; e->rew_thresh = (real)0.05; e->dense_reward = 0;
   /* envList.py:8-10, 18-22, 73-99: the env's flags and ranges go with its scene (play ids: complex_scene; reach ids:
    * default_scene; pick / push: push_scene); other ids on the same model override the ranges (rpo_set_ranges) */
   if (m->scene == RP_SCENE_COMPLEX) {

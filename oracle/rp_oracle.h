@@ -36,7 +36,7 @@ rpo_env* rpo_create(int kind /*0 U, 1 R, 2 P, 3 Q, 4 V, 5 W (rp_model.h)*/, unsi
 /* perform_action's dispatch (environments.py:915-934); default RPO_ACT_ABS_RPY.  Action length: rpo_action_dim. */
 enum { RPO_ACT_ABS_RPY = 0, RPO_ACT_REL_RPY = 1, RPO_ACT_ABS_QUAT = 2, RPO_ACT_REL_QUAT = 3, RPO_ACT_ABS_JOINTS = 4, RPO_ACT_REL_JOINTS = 5 };
 void rpo_set_action_type(rpo_env* e, int action_type);
-void rpo_set_margin(rpo_env* e, double margin);                     /* contact margin, metres (default RP_DEFAULT_CONTACT_MARGIN) */
+void rpo_set_margin(rpo_env* e, double margin);                     /* one contact margin for all pairs, metres (default: per pair, rp_model.col_thr) */
 void rpo_set_reward_cfg(rpo_env* e, double sparse_rew_thresh, int dense);   /* environments.py:66, 169-170 */
 int rpo_action_dim(const rpo_env* e);
 void rpo_get_config(const rpo_env* e, double* out27);   /* flags, ranges, action-space high (test hook) */

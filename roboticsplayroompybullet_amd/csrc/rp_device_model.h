@@ -87,7 +87,9 @@ typedef struct DevModel {
   float goal_lo[3], goal_hi[3], obj_lo[3], obj_hi[3], env_hi[3];
   float rew_thresh;               /* sparse_rew_thresh (environments.py:297) */
   int dense_reward;               /* sparse=False: compute_reward = -distance (environments.py:169-170, 273-275) */
-  float margin;                   /* contact_margin: distance out to which the narrowphase creates points (rp_config) */
+  float col_margin[RP_MAX_COL];   /* distance out to which a collider's contact points exist; a pair's margin is the smaller of the two.
+                                   * Default: Bullet's relative contact breaking threshold of the collider's object (rp_model.col_thr);
+                                   * rp_config.contact_margin replaces it by one value for all */
   float floor_z;                  /* bottom of the lowest static collider: an object below it has left the scene (status bit 2) */
   /* joint clamps of goto_joint_poses (environments.py:1015-1021) */
   float ll[7], ul[7], inc[7];
@@ -194,7 +196,8 @@ static inline void rp_build_dev_model(const rp_model* m, DevModel* d) {
     d->n_obs = 13; d->n_ag = 3; d->n_fps = 7; d->n_observation = 12; d->n_target = 7;
   }
   d->n_target = isP ? 7 : 6;            /* numDofs (environments.py:361, 371) */
-  d->rew_thresh = 0.05f; d->dense_reward = 0; d->margin = (float)RP_DEFAULT_CONTACT_MARGIN;
+  d->rew_thresh = 0.05f; d->dense_reward = 0;
+  for (int c = 0; c < m->n_col; c++) d->col_margin[c] = (float)m->col_thr[c];
   d->floor_z = 1e30f;
   for (int c = 0; c < m->n_col; c++) {
     if (m->col_body[c] != 0) continue;

@@ -93,6 +93,7 @@ struct __align__(16) EnvLds {
   union {
     struct {                                   /* collide() */
       float aabb[RP_MAX_COL * 6];
+      float cmarg[RP_MAX_COL];                 /* per-collider contact margin (DevModel.col_margin); a pair's is the smaller */
       int act[MAXACT], candn[MAXACT], key[MAXACT], cnt[MAXACT];
       float cand[MAXACT * 4 * 8];              /* candidate points; manifolds are merged in place */
     } c;
@@ -329,6 +330,7 @@ __device__ void collider_aabbs(const DevModel* m, EnvLds& L, int lane) {
     float* a = &L.u.c.aabb[6 * lane];
     a[0] = x.p.x - e[0]; a[1] = x.p.y - e[1]; a[2] = x.p.z - e[2];
     a[3] = x.p.x + e[0]; a[4] = x.p.y + e[1]; a[5] = x.p.z + e[2];
+    L.u.c.cmarg[lane] = m->col_margin[lane];
   }
 }
 
@@ -386,13 +388,13 @@ __device__ void narrowphase_coop(const DevModel* m, EnvLds& L, int lane, int nac
   float (*poly)[8][3] = (float (*)[8][3])(scr + 16);
   float (*kept)[4] = (float (*)[4])(scr + 64);
   const unsigned below = (1u << s) - 1u;
-  const float margin = m->margin;
   for (int base = 0; base < nact; base += 64 / NPG) {      /* wave-uniform trip count; every lane reaches every barrier */
     const int ai = base + g;
     const bool act = ai < nact;
     const int pi = act ? L.u.c.act[ai] : 0;
     const int a = m->pair[pi][0], b = m->pair[pi][1];
     const int ta = m->col_type[a], tb = m->col_type[b];
+    const float margin = fminf(m->col_margin[a], m->col_margin[b]);      /* Bullet: a manifold's breaking threshold is the smaller of its two objects' */
     const bool bb = act && ta == 0 && tb == 0;
     const Xf xa = collider_xf(m, L, a), xb = collider_xf(m, L, b);
     const V3 ha = ld3(m->col_he[a]), hb = ld3(m->col_he[b]);
@@ -587,7 +589,6 @@ __device__ int collide(const DevModel* m, EnvLds& L, int lane) {
   unsigned short pv[RP_MAX_PAIR / 64];
 #pragma unroll
   for (int k = 0; k < RP_MAX_PAIR / 64; k++) { int pi = 64 * k + lane; pv[k] = pp[pi < npair ? pi : 0]; }   /* all loads in flight at once */
-  const float margin = m->margin;
   unsigned ovbits = 0u;                  /* bit k: pair 64 k + lane overlaps.  All tests first (independent LDS reads pipeline) */
 #pragma unroll
   for (int k = 0; k < RP_MAX_PAIR / 64; k++) {
@@ -599,6 +600,7 @@ __device__ int collide(const DevModel* m, EnvLds& L, int lane) {
       /* all twelve reads unconditionally, combined without short-circuit: `||` would make every read wait for the
        * comparison before it (98 exec-mask branches, one LDS round trip each) */
       float a0 = A[0], a1 = A[1], a2 = A[2], a3 = A[3], a4 = A[4], a5 = A[5], b0 = Bb[0], b1 = Bb[1], b2 = Bb[2], b3 = Bb[3], b4 = Bb[4], b5 = Bb[5];
+      const float margin = fminf(L.u.c.cmarg[a], L.u.c.cmarg[b]);
       bool sep = (a0 > b3 + margin) | (b0 > a3 + margin) | (a1 > b4 + margin) | (b1 > a4 + margin) | (a2 > b5 + margin) | (b2 > a5 + margin);
       ovbits |= sep ? 0u : (1u << k);
     }

@@ -34,9 +34,6 @@
 #define RP_MAX_SITE 4
 #define RP_MAX_NV (RP_MAX_ARM + 6 * RP_MAX_FREE + RP_MAX_J1)
 
-/* rp_config.contact_margin when RP_CFG_CONTACT_MARGIN is clear (include/rp_playroom.h); the oracle's default too */
-#define RP_DEFAULT_CONTACT_MARGIN 0.02
-
 #define RP_SITE_EE 0     /* Bullet endEffectorIndex (UR5 link 7 / Panda link 11), COM frame */
 #define RP_SITE_WRIST 1  /* endEffectorIndex-1 (UR5 only; gripper_proprioception, environments.py:725) */
 #define RP_SITE_PADL 2   /* UR5 link 18 */
@@ -77,6 +74,10 @@ typedef struct rp_model {
   int col_link[RP_MAX_COL];         /* Bullet link index of an arm collider (-1 otherwise); rayTest link filter */
   int col_obj[RP_MAX_COL];          /* collision object id: one contact manifold (<= 4 points) per object pair */
   double col_he[RP_MAX_COL][3], col_pos[RP_MAX_COL][3], col_rot[RP_MAX_COL][9], col_friction[RP_MAX_COL];
+  /* Bullet's contact breaking threshold of the collision object the collider belongs to: gContactBreakingThreshold (0.02) x
+   * btCollisionShape::getAngularMotionDisc (|AABB centre| + half diagonal of the object's shape in its own frame); a pair's
+   * threshold is the smaller of its two objects' (btCollisionDispatcher::getNewManifold, relative thresholds are its default) */
+  double col_thr[RP_MAX_COL];
   /* candidate collider pairs (first = collider of the higher body id), sorted so that the pairs of one
    * object pair (manifold) are contiguous */
   unsigned char pair[RP_MAX_PAIR][2];

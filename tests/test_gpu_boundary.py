@@ -105,23 +105,27 @@ def test_constructor_kwargs_reach_the_device():
     n = 8
     gl, gh = [-0.05, -0.05, 0.02], [0.05, 0.05, 0.04]
     ol, oh = [-0.02, -0.02, 0.0], [0.02, 0.02, 0.01]
+    gl, gh = [-0.05, -0.05, 0.12], [0.05, 0.05, 0.14]             # goals (and the arm's reset target) well above the block
     env = VecPlayEnv('pandaPick-v0', n, seed=4, goal_range_low=gl, goal_range_high=gh, obj_lower_bound=ol, obj_upper_bound=oh,
-                     env_range_high=[0.18, 0.18, 0.2], sparse_rew_thresh=0.2)
+                     env_range_high=[0.18, 0.18, 0.2])
     obs = env.reset()
     dg = obs['desired_goal'].cpu().numpy()
     assert (dg >= np.float32(gl) - 1e-6).all() and (dg <= np.float32(gh) + 1e-6).all()
     blk = obs['achieved_goal'].cpu().numpy()
-    assert (np.abs(blk[:, :2]) < 0.06).all()                      # spawned in the small object range, settled nearby
+    assert (np.abs(blk[:, :2]) < 0.03).all()                      # spawned in the small object range, settled where it fell
     for e in range(n):
-        o = OracleEnv('P', seed=4, env_index=e, f32=True, ranges=(gl, gh, ol, oh, [0.18, 0.18, 0.2]), sparse_rew_thresh=0.2)
+        o = OracleEnv('P', seed=4, env_index=e, f32=True, ranges=(gl, gh, ol, oh, [0.18, 0.18, 0.2]))
         oo = o.reset()
         for k in ('obs_quat', 'desired_goal'):
             np.testing.assert_allclose(obs[k][e].cpu().numpy(), oo[k], atol=1e-4, rtol=0, err_msg=k)
     # reward threshold 0.2: distances between 0.05 and 0.2 now give -distance
+    env = VecPlayEnv('pandaPick-v0', n, seed=4, sparse_rew_thresh=0.2)
     ag = torch.tensor([[0.0, 0.0, 0.0], [0.0, 0.0, 0.0]])
     g2 = torch.tensor([[0.1, 0.0, 0.0], [0.3, 0.0, 0.0]])
     r = env.compute_reward(ag, g2).cpu().numpy()
     np.testing.assert_allclose(r, [-0.1, -1.0], atol=1e-7)
+    orc = OracleEnv('P', seed=4, env_index=0, sparse_rew_thresh=0.2)
+    assert orc.compute_reward(np.zeros(3), np.array([0.1, 0, 0])) == pytest.approx(-0.1)
     # dense reward (sparse=False): -||ag - dg|| on every id, over the whole goal vector for the play ids (environments.py:269-275)
     dense = VecPlayEnv(U, n, seed=4, sparse=False)
     obs = dense.reset()
