@@ -51,8 +51,12 @@ def build():
     subprocess.run(['make', '-C', HERE, '-s'], check=True)
 
 
-def load(f32=False):
-    name = 'librp_oracle_f32.so' if f32 else 'librp_oracle.so'
+REF_FLAGS = {'hull': 1, 'persist': 2, 'order': 4, 'lever': 8, 'soft': 16, 'anchor': 32, 'spin': 64, 'fricskip': 128, 'warm': 256}
+REF_DEFAULT = 255          # everything but warm starting (rp_bullet_ref.c RPB_DEFAULT)
+
+
+def load(f32=False, bullet_ref=False):
+    name = 'librp_oracle_bullet.so' if bullet_ref else ('librp_oracle_f32.so' if f32 else 'librp_oracle.so')
     if name in _LIBS:
         return _LIBS[name]
     path = os.path.join(HERE, name)
@@ -112,6 +116,12 @@ def load(f32=False):
     lib.rpo_bench_rollout.restype = C.c_double
     lib.rpo_rng_uniform.argtypes = [C.c_ulonglong, C.c_uint, C.c_uint]
     lib.rpo_rng_uniform.restype = C.c_double
+    if bullet_ref:
+        lib.rpo_set_ref_flags.argtypes = [vp, C.c_uint]
+        lib.rpo_get_ref_flags.argtypes = [vp]
+        lib.rpo_get_ref_flags.restype = C.c_uint
+        lib.rpo_ref_num_contacts.argtypes = [vp]
+        lib.rpo_ref_num_manifolds.argtypes = [vp]
     _LIBS[name] = lib
     return lib
 
@@ -144,10 +154,10 @@ class OracleEnv:
     """One reference env (instance + playEnv) on the CPU oracle."""
 
     def __init__(self, kind, seed=0, env_index=0, f32=False, action_type=None, margin=None, ranges=None, sparse_rew_thresh=None,
-                 dense_reward=False):
+                 dense_reward=False, bullet_ref=False, ref_flags=None):
         """ranges = (goal_lo, goal_hi, obj_lo, obj_hi, env_hi): the env class's range kwargs (envList.py); margin: contact margin
         in metres for every pair (default, like the library: per pair the smaller of the two objects' Bullet breaking thresholds, rp_model.col_thr)"""
-        self.lib = load(f32)
+        self.lib = load(f32, bullet_ref)      # bullet_ref: the frozen Bullet-like step (rp_bullet_ref.c) under the same harness
         user_ranges = ranges
         ranges = None
         if kind in RANGES:
@@ -169,6 +179,8 @@ class OracleEnv:
             self.lib.rpo_set_ranges(self.h, *[_d(r)[1] for r in ranges])
         if margin is not None:
             self.lib.rpo_set_margin(self.h, float(margin))
+        if bullet_ref and ref_flags is not None:
+            self.lib.rpo_set_ref_flags(self.h, int(ref_flags))
         if sparse_rew_thresh is not None or dense_reward:
             self.lib.rpo_set_reward_cfg(self.h, 0.05 if sparse_rew_thresh is None else float(sparse_rew_thresh), int(bool(dense_reward)))
         self.n_arm = self.lib.rpo_n_arm(self.h)

@@ -88,6 +88,7 @@ struct rpo_env {
   xform xc[RP_MAX_COL]; real aabb_lo[RP_MAX_COL][3], aabb_hi[RP_MAX_COL][3];
   contact con[MAX_CONTACTS]; int ncon;
   row rows[MAX_ROWS]; int nrows;
+  void* ref;                        /* librp_oracle_bullet.so only: persistent state of the frozen Bullet-like step (rp_bullet_ref.c) */
 };
 
 /* ------------------------------------------------------------------ counter RNG (shared definition with the HIP library) */
@@ -780,12 +781,10 @@ static void solve_rows(rpo_env* e, real* dv) {
 }
 
 /* ------------------------------------------------------------------ one stepSimulation() */
-void rpo_substep(rpo_env* e) {
+/* unconstrained velocities v* = v + dt a: ABA for the arm, damping and gravity for the free bodies and the scene joints */
+static void substep_unconstrained(rpo_env* e, real* vstar) {
   const rp_model* m = &e->m;
-  int nv = e->nv;
-  update_transforms(e);
-  collide(e);
-  real vstar[RP_MAX_NV] = {0}, qdd[RP_MAX_ARM];
+  real qdd[RP_MAX_ARM];
   arm_aba(e, qdd);
   for (int i = 0; i < m->n_arm; i++) vstar[i] = e->qd[i] + DT * qdd[i];
   for (int k = 0; k < m->n_free; k++) {
@@ -824,14 +823,16 @@ void rpo_substep(rpo_env* e) {
       vstar[d] = w + DT * (-(J1_ANG_DAMP + J1_ANG_DAMP * R_FABS(w)) * w);
     }
   }
-  build_rows(e, vstar);
-  real dv[RP_MAX_NV] = {0};
-  solve_rows(e, dv);
-  /* apply and integrate (semi-implicit Euler; free-body orientation by the exponential map).  Every body here is a
-   * btMultiBody, and btMultiBody::applyDeltaVeeMultiDof - through which processDeltaVeeMultiDof2 adds the solver's velocity
-   * change after the solve - clamps each generalized velocity to +-m_maxCoordinateVelocity = 100 (upstream bullet3
-   * btMultiBody.h / .cpp, from memory, unverified like the rest of App. E).  Never active in ordinary motion; it keeps a
-   * squeezed, deeply penetrating contact from running away. */
+}
+
+/* apply the solver's velocity change and integrate (semi-implicit Euler; free-body orientation by the exponential map).  Every body
+ * here is a btMultiBody, and btMultiBody::applyDeltaVeeMultiDof - through which processDeltaVeeMultiDof2 adds the solver's velocity
+ * change after the solve - clamps each generalized velocity to +-m_maxCoordinateVelocity = 100 (upstream bullet3 btMultiBody.h /
+ * .cpp, from memory, unverified like the rest of App. E).  Never active in ordinary motion; it keeps a squeezed, deeply
+ * penetrating contact from running away. */
+static void substep_integrate(rpo_env* e, const real* vstar, real* dv) {
+  const rp_model* m = &e->m;
+  int nv = e->nv;
   for (int i = 0; i < nv; i++) {          /* dv becomes the new generalized velocity */
     real v = vstar[i] + dv[i];
     dv[i] = v < -MAX_COORD_VEL ? -MAX_COORD_VEL : (v > MAX_COORD_VEL ? MAX_COORD_VEL : v);
@@ -859,8 +860,33 @@ void rpo_substep(rpo_env* e) {
     e->jqd[k] = dv[d];
     e->jq[k] += DT * e->jqd[k];
   }
-  (void)nv;
 }
+
+#ifdef RPO_BULLET_REF
+#include "rp_bullet_ref.c"      /* the frozen Bullet-like collision + solve ("mode B"); see its header */
+void rpo_substep(rpo_env* e) {
+  rpb_state* st = rpb_get(e);
+  update_transforms(e);
+  rpb_collide(e, st);
+  real vstar[RP_MAX_NV] = {0};
+  substep_unconstrained(e, vstar);
+  rpb_build_rows(e, st, vstar);
+  real dv[RP_MAX_NV] = {0};
+  rpb_solve(e, st, dv);
+  substep_integrate(e, vstar, dv);
+}
+#else
+void rpo_substep(rpo_env* e) {
+  update_transforms(e);
+  collide(e);
+  real vstar[RP_MAX_NV] = {0};
+  substep_unconstrained(e, vstar);
+  build_rows(e, vstar);
+  real dv[RP_MAX_NV] = {0};
+  solve_rows(e, dv);
+  substep_integrate(e, vstar, dv);
+}
+#endif
 
 void rpo_run_simulation(rpo_env* e) { for (int i = 0; i < N_SUBSTEPS; i++) rpo_substep(e); }
 
@@ -1592,7 +1618,11 @@ rpo_env* rpo_create(int kind, unsigned long long seed, int env_index) {
   update_transforms(e);
   return e;
 }
+#ifdef RPO_BULLET_REF
+void rpo_destroy(rpo_env* e) { rpo_ref_free(e); free(e); }
+#else
 void rpo_destroy(rpo_env* e) { free(e); }
+#endif
 int rpo_nv(const rpo_env* e) { return e->nv; }
 int rpo_n_arm(const rpo_env* e) { return e->m.n_arm; }
 int rpo_state_size(const rpo_env* e) { return 2 * e->m.n_arm + 13 * e->m.n_free + 2 * e->m.n_joint1; }

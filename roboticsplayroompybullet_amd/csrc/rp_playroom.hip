@@ -122,6 +122,12 @@ int rp_create(const rp_config* cfg, rp_handle* out) {
 #else
   if (SPEC[cfg->env_kind].model == 'W') { snprintf(g_err, 256, "rp_create: the two-object ids (env kind %d) are served by librp_playroom_hip_wide.so", cfg->env_kind); return RP_ERR_UNSUPPORTED; }
 #endif
+  {
+    int ndev = 0;
+    hipError_t de = hipGetDeviceCount(&ndev);
+    if (de != hipSuccess) { (void)hipGetLastError(); snprintf(g_err, 256, "rp_create: hipGetDeviceCount: %s", hipGetErrorString(de)); return RP_ERR_HIP; }
+    if (cfg->device < 0 || cfg->device >= ndev) { snprintf(g_err, 256, "rp_create: device %d of %d", cfg->device, ndev); return RP_ERR_ARG; }
+  }
   rp_sim* h = (rp_sim*)calloc(1, sizeof(rp_sim));
   rp_model* m = (rp_model*)malloc(sizeof(rp_model));
   if (!h || !m) { free(h); free(m); snprintf(g_err, 256, "rp_create: out of host memory"); return RP_ERR_ARG; }
@@ -162,11 +168,7 @@ int rp_create(const rp_config* cfg, rp_handle* out) {
   int rc = RP_ERR_HIP;
   hipError_t e = hipSuccess;
 #define CREATE_CHK(call) do { e = (call); if (e != hipSuccess) { snprintf(g_err, 256, "rp_create: %s: %s", #call, hipGetErrorString(e)); goto fail; } } while (0)
-  {
-    int ndev = 0;
-    CREATE_CHK(hipGetDeviceCount(&ndev));
-    if (cfg->device < 0 || cfg->device >= ndev) { snprintf(g_err, 256, "rp_create: device %d of %d", cfg->device, ndev); rc = RP_ERR_ARG; goto fail; }
-  }
+  (void)hipGetLastError();          /* a stale error of an earlier, unrelated call must not fail this one */
   CREATE_CHK(hipSetDevice(cfg->device));
   CREATE_CHK(hipMalloc((void**)&h->dev_model, sizeof(DevModel)));
   CREATE_CHK(hipMalloc((void**)&h->state, (size_t)N * RP_REC_FLOATS * sizeof(float)));
@@ -203,6 +205,7 @@ int rp_create(const rp_config* cfg, rp_handle* out) {
   *out = h;
   return RP_OK;
 fail:
+  (void)hipGetLastError();
   destroy_handle(h);
   return rc;
 }
