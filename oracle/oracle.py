@@ -51,8 +51,8 @@ def build():
     subprocess.run(['make', '-C', HERE, '-s'], check=True)
 
 
-REF_FLAGS = {'hull': 1, 'persist': 2, 'order': 4, 'lever': 8, 'soft': 16, 'anchor': 32, 'spin': 64, 'fricskip': 128, 'warm': 256}
-REF_DEFAULT = 255          # everything but warm starting (rp_bullet_ref.c RPB_DEFAULT)
+REF_FLAGS = {'hull': 1, 'persist': 2, 'order': 4, 'lever': 8, 'soft': 16, 'anchor': 32, 'spin': 64, 'fricskip': 128, 'warm': 256, 'limit': 512}
+REF_DEFAULT = 255 + 512          # everything but warm starting (rp_bullet_ref.c RPB_DEFAULT)
 
 
 def load(f32=False, bullet_ref=False):

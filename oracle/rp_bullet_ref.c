@@ -21,8 +21,10 @@
  *                tangential drift); box-box (btBoxBoxDetector = ODE dBoxBox2) adds points only while the boxes overlap;
  *                a new point within the threshold of a cached one replaces it.  No cap on the number of manifolds.
  *   RPB_ORDER    btMultiBodyConstraintSolver::solveSingleIteration's order: non-contact rows (limits, motors, gear) in creation
- *                order and in ALTERNATING direction from sweep to sweep, then normals, torsional friction, friction;
- *                a joint-limit row exists only while the limit is violated (btMultiBodyJointLimitConstraint, erp 0.2)
+ *                order and in ALTERNATING direction from sweep to sweep, then normals, torsional friction, friction
+ *   RPB_LIMIT    a joint-limit row exists only while the limit is violated, and pushes back with erp 0.2
+ *                (btMultiBodyJointLimitConstraint::createConstraintRows: `if (penetration > 0) continue;`, m_erp); mode A keeps
+ *                a speculative row from 0.1 rad before the limit on, which stops the joint exactly at the limit
  *   RPB_LEVER    a contact acts at positionWorldOnA on body A and positionWorldOnB on body B (mode A: their midpoint on both)
  *   RPB_SOFT     <contact> stiffness / damping of the gripper links (ur5e2.urdf:306-312, panda.urdf:256-262) become the
  *                row's cfm and erp (BT_CONTACT_FLAG_CONTACT_STIFFNESS_DAMPING in setupMultiBodyContactConstraint)
@@ -52,7 +54,8 @@
 #define RPB_SPIN 64
 #define RPB_FRICSKIP 128
 #define RPB_WARM 256
-#define RPB_DEFAULT (RPB_HULL | RPB_PERSIST | RPB_ORDER | RPB_LEVER | RPB_SOFT | RPB_ANCHOR | RPB_SPIN | RPB_FRICSKIP)
+#define RPB_LIMIT 512
+#define RPB_DEFAULT (RPB_HULL | RPB_PERSIST | RPB_ORDER | RPB_LEVER | RPB_SOFT | RPB_ANCHOR | RPB_SPIN | RPB_FRICSKIP | RPB_LIMIT)
 
 #define RPB_SHAPE_MARGIN 0.001          /* gUrdfDefaultCollisionMargin / the physics server's default collision margin */
 #define RPB_BREAKING 0.02               /* gContactBreakingThreshold; a manifold's threshold is relative (rp_model.col_thr) */
@@ -708,7 +711,7 @@ static void rpb_build_rows(rpo_env* e, rpb_state* st, const real* vstar) {
   const rp_model* m = &e->m;
   const int nv = e->nv;
   st->nrows = 0;
-  const int order = (st->flags & RPB_ORDER) != 0;
+  const int order = (st->flags & RPB_ORDER) != 0, blimit = (st->flags & RPB_LIMIT) != 0;
   /* --- non-contact rows.  Creation order in the world: the scene bodies' joint motors (bodies 1, 7, 9 are made before the arm),
    * then the arm - its limit constraints are added while the URDF tree is converted, its motors afterwards - then the gear */
   for (int k = 0; k < m->n_joint1; k++) {
@@ -727,7 +730,7 @@ static void rpb_build_rows(rpo_env* e, rpb_state* st, const real* vstar) {
         if (!(m->arm_lower[i] < m->arm_upper[i])) continue;
         for (int side = 0; side < 2; side++) {
           real pen = side == 0 ? e->q[i] - (real)m->arm_lower[i] : (real)m->arm_upper[i] - e->q[i];
-          if (order ? pen > 0 : pen > LIMIT_ACTIVATION) continue;     /* btMultiBodyJointLimitConstraint: a row only while violated */
+          if (blimit ? pen > 0 : pen > LIMIT_ACTIVATION) continue;     /* btMultiBodyJointLimitConstraint: a row only while violated */
           real sgn = side == 0 ? 1 : -1;
           rpb_row* r = rpb_new_row(st);
           real tau[RP_MAX_ARM] = {0};
@@ -735,7 +738,7 @@ static void rpb_build_rows(rpo_env* e, rpb_state* st, const real* vstar) {
           arm_impulse_response(e, -1, 0, tau, r->B);
           r->dinv = 1 / (sgn * r->B[i]);
           real relv = sgn * vstar[i], pos_err = 0, vel_err = -relv;
-          if (pen > 0) vel_err -= pen / DT; else pos_err = -pen * (order ? (real)RPB_ERP_LIMIT : ERP_CONTACT) / DT;
+          if (pen > 0) vel_err -= pen / DT; else pos_err = -pen * (blimit ? (real)RPB_ERP_LIMIT : ERP_CONTACT) / DT;
           r->rhs = (pos_err + vel_err) * r->dinv; r->lo = 0; r->hi = LIMIT_MAXIMP;
         }
       }
@@ -940,5 +943,17 @@ int rpo_ref_manifolds(rpo_env* e, double* out, int max_points) {
       for (int k = 0; k < 3; k++) { o[4 + k] = p->pA[k]; o[7 + k] = p->pB[k]; o[10 + k] = p->n[k]; }
       o[13] = p->dist; o[14] = p->imp; o[15] = p->life; o[16] = mf->thr;
     }
+  return n;
+}
+/* rows of the latest step touching arm dof `dof`: per row [index, J[dof], B[dof], rhs, dinv, lo, hi, lambda] */
+int rpo_ref_rows_of_dof(rpo_env* e, int dof, double* out, int max_rows) {
+  rpb_state* st = rpb_get(e);
+  int n = 0;
+  for (int i = 0; i < st->n_noncontact && n < max_rows; i++) {
+    const rpb_row* r = &st->rows[i];
+    if (r->J[dof] == 0) continue;
+    double* o = out + 8 * n++;
+    o[0] = i; o[1] = r->J[dof]; o[2] = r->B[dof]; o[3] = r->rhs; o[4] = r->dinv; o[5] = r->lo; o[6] = r->hi; o[7] = r->lambda;
+  }
   return n;
 }

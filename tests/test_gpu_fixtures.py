@@ -1,0 +1,207 @@
+"""The playroom's articulated fixtures driven on the MI355X against the CPU oracle (scenes.py:117-426, environments.py:469-483,
+767-793, 868-894): the drawer pulled and pushed to both stops and the door slid by the arm, the button pressed by a dropped block,
+non-rest door / button / dial / drawer values through calc_state and the reward, the quaternion sign memory.  Run with -m gpu.
+
+Contact-rich rollouts are compared with the fp32 oracle step by step; where the fp32 and the fp64 CPU oracle themselves drift apart
+(a pushed body is sensitive to rounding), the device - a third evaluation order of the same fp32 arithmetic - is held to three
+times their gap."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+
+pytestmark = pytest.mark.gpu
+U = 'UR5PlayAbsRPY1Obj-v0'
+FREE0, JQ = 24, 50                      # VecPlayEnv.STATE_LAYOUT: free0 (block), jq (door, button, dial); free1 = drawer at 37
+
+
+def drive(env, oracles32, oracles64, script, atol=1e-3, check=None):
+    """script: list of (target xyz, grip, steps); every env gets the same commands"""
+    n = env.num_envs
+    worst = 0.0
+    last = None
+    for target, grip, steps in script:
+        a = np.array(list(target) + [0, 0, 0, grip], dtype=np.float64)
+        for _ in range(steps):
+            obs, r, _, info = env.step(torch.tensor(np.tile(a, (n, 1)), dtype=torch.float32))
+            got = obs['obs_quat'].cpu().numpy()
+            for e in range(n):
+                o32 = oracles32[e].step(a)[0]['obs_quat']
+                o64 = oracles64[e].step(a)[0]['obs_quat']
+                tol = np.maximum(atol, 3 * np.abs(o32 - o64))
+                err = np.abs(got[e] - o32)
+                assert (err <= tol).all(), 'env %d: err %s tol %s' % (e, err, tol)
+                worst = max(worst, float((err / tol).max()))
+            assert int((info['status'] & 1).sum()) == 0
+        last = obs
+        if check:
+            check(target, last)
+    return last, worst
+
+
+def make(n, seed):
+    from oracle import OracleEnv
+    from roboticsplayroompybullet_amd import VecPlayEnv
+    env = VecPlayEnv(U, n, seed=seed)
+    obs = env.reset()
+    o32 = [OracleEnv('U', seed=seed, env_index=e, f32=True) for e in range(n)]
+    o64 = [OracleEnv('U', seed=seed, env_index=e) for e in range(n)]
+    for e in range(n):
+        a = o32[e].reset()
+        o64[e].reset()
+        np.testing.assert_allclose(obs['obs_quat'][e].cpu().numpy(), a['obs_quat'], atol=1e-4, rtol=0)
+    return env, o32, o64
+
+
+def test_drawer_pulled_and_pushed_to_both_stops():
+    """the closed gripper goes into the drawer's handle hole, pulls it against the two front stops (-0.06 m), pushes it against the back
+    stop (+0.075 m): obs_quat[15] = drawer base y (environments.py:783), every step against the oracle"""
+    env, o32, o64 = make(3, 5)
+    seen = {}
+
+    def note(target, obs):
+        seen[target] = obs['obs_quat'][:, 15].cpu().numpy().copy()
+    script = [((-0.13, -0.165, 0.10), 1.0, 40), ((-0.13, -0.165, -0.05), 1.0, 40), ((-0.13, -0.30, -0.05), 1.0, 60),
+              ((-0.13, -0.02, -0.05), 1.0, 80)]
+    obs, worst = drive(env, o32, o64, script, check=note)
+    pulled, pushed = seen[(-0.13, -0.30, -0.05)], seen[(-0.13, -0.02, -0.05)]
+    assert (pulled < -0.055).all() and (pulled > -0.08).all(), pulled          # against the front stops
+    assert (pushed > 0.07).all() and (pushed < 0.095).all(), pushed            # against the back stop
+    rc = env.debug_row_counts()
+    assert int(rc[:, 1].max()) >= 4                                             # contacts were there to be solved
+    print('drawer scenario: worst error / tolerance = %.2f' % worst)
+
+
+def test_door_slid_by_the_arm():
+    """a finger beside the door's loop handle pushes it along world x (door joint: prismatic, scenes.py:117-182) by more than the reward's
+    0.04 tolerance, then back: obs_quat[16] = door joint position"""
+    env, o32, o64 = make(3, 6)
+    seen = {}
+
+    def note(target, obs):
+        seen[target] = obs['obs_quat'][:, 16].cpu().numpy().copy()
+    script = [((-0.06, 0.322, 0.15), 1.0, 40), ((-0.06, 0.322, 0.10), 1.0, 30), ((0.15, 0.322, 0.10), 1.0, 80),
+              ((0.15, 0.322, 0.2), 1.0, 20), ((0.28, 0.322, 0.2), 1.0, 20), ((0.28, 0.322, 0.10), 1.0, 30), ((0.05, 0.322, 0.10), 1.0, 70)]
+    obs, worst = drive(env, o32, o64, script, atol=1.5e-3, check=note)
+    out, back = seen[(0.15, 0.322, 0.10)], seen[(0.05, 0.322, 0.10)]
+    assert (out > 0.1).all(), out
+    assert (back < out - 0.05).all(), (out, back)
+    print('door scenario: worst error / tolerance = %.2f' % worst)
+
+
+def test_button_pressed_by_a_dropped_block():
+    """the block (0.3 kg) dropped on the button (spring = position motor, target 0.03, force 1 N: scenes.py:238) presses it below the
+    toggle threshold q < 0.025 (environments.py:474): obs_quat[17] against the oracle through the contact phase"""
+    from oracle import OracleEnv
+    from roboticsplayroompybullet_amd import VecPlayEnv
+    n = 3
+    env = VecPlayEnv(U, n, seed=7)
+    env.reset()
+    o32 = [OracleEnv('U', seed=7, env_index=e, f32=True) for e in range(n)]
+    o64 = [OracleEnv('U', seed=7, env_index=e) for e in range(n)]
+    s = env.get_state()
+    for e in range(n):
+        o32[e].reset()
+        o64[e].reset()
+    s[:, FREE0:FREE0 + 13] = torch.tensor([-0.25, 0.45, 0.09, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0], dtype=torch.float32)
+    env.set_state(s)
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    from gpu_debug import oracle_state_from_record
+    rec = s.cpu().numpy()
+    for e in range(n):
+        for o in (o32[e], o64[e]):
+            o.set_state(oracle_state_from_record(o, rec[e]))
+    park = ((0.1, 0.1, 0.25), 0.0, 40)                       # the arm stays away
+    obs, worst = drive(env, o32, o64, [park], atol=1e-3)
+    q = obs['obs_quat'][:, 17].cpu().numpy()
+    assert (q < 0.025).all() and (q > -0.04).all(), q        # pressed: the toggle condition of updateToggles
+    assert (obs['obs_quat'][:, 10].cpu().numpy() < 0.04).all()      # the block came down with it
+    print('button scenario: worst error / tolerance = %.2f' % worst)
+
+
+def test_fixture_values_through_calc_state_and_reward(golden):
+    """door / button / dial / drawer at non-rest values (set through rp_set_state): calc_state's environment half (environments.py:767-793,
+    dial_to_0_1_range over several turns incl. negative angles) and the reward / success truth table (playRewardFunc.py:16-77) against the
+    oracle, whose arithmetic the reference goldens pin (tests/test_oracle_golden.py)"""
+    from oracle import OracleEnv
+    from roboticsplayroompybullet_amd import VecPlayEnv
+    vals = [(0.0, 0.0, 0.03, 0.0), (0.05, 0.12, 0.01, 1.0), (-0.04, -0.1, 0.02, 3.0), (0.07, 0.03, -0.01, -0.5), (0.0, 0.2, 0.03, 7.3),
+            (-0.06, -0.15, 0.029, 1.99), (0.02, 0.0, 0.0, 2.01), (0.0, 0.05, 0.03, -3.7)]
+    n = len(vals)
+    env = VecPlayEnv(U, n, seed=2)
+    env.reset()
+    s = env.get_state()
+    for e, (dy, door, button, dial) in enumerate(vals):
+        s[e, 37 + 1] = dy
+        s[e, JQ:JQ + 3] = torch.tensor([door, button, dial])
+    env.set_state(s)
+    obs = env.calc_state()
+    torch.cuda.synchronize()
+    o = OracleEnv('U', seed=2, env_index=0, f32=True)
+    o.reset()
+    for e, (dy, door, button, dial) in enumerate(vals):
+        want_dial = o.lib.rpo_dial_to_0_1_range(float(np.float32(dial)))
+        got = obs['obs_quat'][e, 15:19].cpu().numpy()
+        np.testing.assert_allclose(got, [dy, door, button, want_dial], atol=2e-7, rtol=0)
+        np.testing.assert_array_equal(obs['achieved_goal'][e, 7:11].cpu().numpy(), got)
+        assert 0.0 <= got[3] < 0.9091
+    # the dial mapping's golden samples (scenes.py:342-343 = (x mod 2) / 2.2)
+    dial_gold = golden('rewards.json')['dial']
+    fo = OracleEnv('U', seed=2, env_index=0)
+    for d in dial_gold:
+        assert fo.lib.rpo_dial_to_0_1_range(float(d['x'])) == pytest.approx(d['y'], abs=1e-12)
+    # ... and the device at the golden samples themselves
+    m = min(n, len(dial_gold))
+    for e in range(m):
+        s[e, JQ + 2] = float(dial_gold[e * (len(dial_gold) // m)]['x'])
+    env.set_state(s)
+    obs2 = env.calc_state()
+    for e in range(m):
+        assert float(obs2['obs_quat'][e, 18]) == pytest.approx(dial_gold[e * (len(dial_gold) // m)]['y'], abs=2e-7)
+    # reward: goal = achieved with one fixture entry moved just inside / outside its tolerance
+    ag = obs['achieved_goal'].clone()
+    tol = {7: 0.025, 8: 0.04, 9: 0.01, 10: 0.3}
+    for idx, t in tol.items():
+        for f, want in ((0.9, 0.0), (1.1, -1.0)):
+            g = ag.clone()
+            g[:, idx] += f * t
+            r = env.compute_reward(ag, g).cpu().numpy()
+            assert (r == want).all(), (idx, f, r)
+            for e in range(n):
+                assert o.compute_reward(ag[e].cpu().numpy().astype(np.float64), g[e].cpu().numpy().astype(np.float64)) == want
+
+
+def test_quaternion_sign_memory_sequence():
+    """quaternion_safe_the_obs (environments.py:868-894): a quaternion whose four signs are all opposite to the previous observation's is
+    negated, any other is passed through, zeros count as equal signs; the memory follows what was returned.  Block orientation set
+    through rp_set_state, observed through calc_state, against the oracle fed the same sequence."""
+    from oracle import OracleEnv
+    from roboticsplayroompybullet_amd import VecPlayEnv
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    from gpu_debug import oracle_state_from_record
+    q0 = np.array([0.1, -0.2, 0.3, 0.9]); q0 /= np.linalg.norm(q0)
+    seq = [q0, -q0, -q0, q0, np.array([0.1, 0.2, -0.3, -0.9]) / np.linalg.norm(q0), -q0, np.array([0.0, -0.2, 0.3, 0.9]), np.array([0.0, 0.2, -0.3, -0.9]),
+           np.array([1e-9, 0.2, -0.3, -0.9])]
+    env = VecPlayEnv(U, 2, seed=3)
+    env.reset()
+    o = OracleEnv('U', seed=3, env_index=0, f32=True)
+    o.reset()
+    env.calc_state()
+    flips = 0
+    for q in seq:
+        s = env.get_state()
+        s[0, FREE0 + 3:FREE0 + 7] = torch.tensor(q, dtype=torch.float32)
+        env.set_state(s)
+        rec = s[0].cpu().numpy()
+        o.set_state(oracle_state_from_record(o, rec))
+        got = env.calc_state()
+        want = o.calc_state()
+        g = got['obs_quat'][0, 11:15].cpu().numpy()
+        np.testing.assert_allclose(g, want['obs_quat'][11:15], atol=1e-7, rtol=0)
+        np.testing.assert_allclose(got['achieved_goal'][0, 3:7].cpu().numpy(), want['achieved_goal'][3:7], atol=1e-7, rtol=0)
+        if not np.allclose(g, np.float32(q), atol=1e-7):
+            flips += 1
+            np.testing.assert_allclose(g, -np.float32(q), atol=1e-7)
+    assert flips >= 2           # the sequence exercises both branches
