@@ -60,6 +60,7 @@
 #define RPB_SHAPE_MARGIN 0.001          /* gUrdfDefaultCollisionMargin / the physics server's default collision margin */
 #define RPB_BREAKING 0.02               /* gContactBreakingThreshold; a manifold's threshold is relative (rp_model.col_thr) */
 #define RPB_ERP_LIMIT 0.2               /* btContactSolverInfo::m_erp */
+#define LIMIT_ACTIVATION ((real)0.1)     /* RPB_LIMIT off = round 1's fast model: a speculative limit row from 0.1 rad before the limit on */
 #define RPB_FRICTION_ERP 0.2            /* m_frictionERP */
 #define RPB_WARM_FACTOR 0.85            /* m_warmstartingFactor default */
 #define RPB_MAX_MAN 160

@@ -35,7 +35,7 @@
 #define DEFAULT_MOTOR_MAXIMP ((real)1.0) /* createJointMotors: velocity motor, target 0, max impulse 1 */
 #define LIMIT_MAXIMP ((real)100.0)
 #define MAX_COORD_VEL ((real)100.0)     /* btMultiBody::m_maxCoordinateVelocity (recalled) */
-#define LIMIT_ACTIVATION ((real)0.1)
+#define ERP_LIMIT ((real)0.2)          /* btContactSolverInfo::m_erp: joint-limit rows (btMultiBodyJointLimitConstraint) */
 #define FREE_LIN_DAMP ((real)0.04)
 #define FREE_ANG_DAMP ((real)0.04)
 #define J1_ANG_DAMP ((real)0.04)        /* changeDynamics(linearDamping=0) leaves angular at the 0.04 default */
@@ -58,6 +58,7 @@ typedef struct {
 typedef struct {
   real J[RP_MAX_NV], B[RP_MAX_NV];
   real rhs, lo, hi, dinv, lambda;
+  real cfm;            /* contact softness (cfm * dinv): the row's step also subtracts lambda * cfm */
   int fric_parent;     /* >=0: friction row, limits = -+mu*lambda[parent] */
   real mu;
 } row;
@@ -87,7 +88,7 @@ struct rpo_env {
   real finv[RP_MAX_FREE][9];        /* world inverse inertia of free bodies */
   xform xc[RP_MAX_COL]; real aabb_lo[RP_MAX_COL][3], aabb_hi[RP_MAX_COL][3];
   contact con[MAX_CONTACTS]; int ncon;
-  row rows[MAX_ROWS]; int nrows;
+  row rows[MAX_ROWS]; int nrows, n_noncontact;
   void* ref;                        /* librp_oracle_bullet.so only: persistent state of the frozen Bullet-like step (rp_bullet_ref.c) */
 };
 
@@ -661,19 +662,10 @@ static void build_rows(rpo_env* e, const real* vstar) {
   const rp_model* m = &e->m;
   int nv = e->nv;
   e->nrows = 0;
-  /* 1. arm joint motors (btMultiBodyJointMotor): velocity-level servo, impulse clamp */
-  for (int i = 0; i < m->n_arm; i++) {
-    row* r = new_row(e);
-    real tau[RP_MAX_ARM] = {0};
-    tau[i] = 1;
-    r->J[i] = 1;
-    arm_impulse_response(e, -1, 0, tau, r->B);
-    r->dinv = 1 / r->B[i];
-    real des = e->mmode[i] ? MOTOR_KP * (e->mtarget[i] - e->q[i]) / DT : 0;   /* kp*err/dt + qd + kd*(0-qd), kd = 1 */
-    r->rhs = (des - vstar[i]) * r->dinv;
-    r->lo = -e->mmaximp[i]; r->hi = e->mmaximp[i];
-  }
-  /* 2. scene joint motors: button position motor (scenes.py:238), default velocity motors on door and dial */
+  /* Non-contact rows in the order Bullet's world holds its multibody constraints (creation order): the scene bodies' joint motors
+   * (made before the arm is loaded), the arm's joint-limit constraints (added while the URDF tree is converted), the arm's joint
+   * motors (createJointMotors, afterwards), the gear (environments.py:400-405).  solve_rows walks them in alternating direction. */
+  /* 1. scene joint motors: button position motor (scenes.py:238), default velocity motors on door and dial */
   for (int k = 0; k < m->n_joint1; k++) {
     row* r = new_row(e);
     int d = dof_j1(e, k);
@@ -687,12 +679,13 @@ static void build_rows(rpo_env* e, const real* vstar) {
     r->rhs = (des - vstar[d]) * r->dinv;
     r->lo = -maximp; r->hi = maximp;
   }
-  /* 3. joint limits (btMultiBodyJointLimitConstraint): contact-like rows */
+  /* 2. joint limits (btMultiBodyJointLimitConstraint::createConstraintRows): a row exists only while its limit is violated
+   * (`if (penetration > 0) continue;`) and pushes back with erp = m_erp = 0.2 */
   for (int i = 0; i < m->n_arm; i++) {
     if (!(m->arm_lower[i] < m->arm_upper[i])) continue;
     for (int side = 0; side < 2; side++) {
       real pen = side == 0 ? e->q[i] - (real)m->arm_lower[i] : (real)m->arm_upper[i] - e->q[i];
-      if (pen > LIMIT_ACTIVATION) continue;
+      if (pen > 0) continue;
       real sgn = side == 0 ? (real)1 : (real)-1;
       row* r = new_row(e);
       real tau[RP_MAX_ARM] = {0};
@@ -700,11 +693,22 @@ static void build_rows(rpo_env* e, const real* vstar) {
       r->J[i] = sgn;
       arm_impulse_response(e, -1, 0, tau, r->B);
       r->dinv = 1 / (sgn * r->B[i]);
-      real relv = sgn * vstar[i], pos_err = 0, vel_err = -relv;
-      if (pen > 0) vel_err -= pen / DT; else pos_err = -pen * ERP_CONTACT / DT;
+      real relv = sgn * vstar[i], pos_err = -pen * ERP_LIMIT / DT, vel_err = -relv;
       r->rhs = (pos_err + vel_err) * r->dinv;
       r->lo = 0; r->hi = LIMIT_MAXIMP;
     }
+  }
+  /* 3. arm joint motors (btMultiBodyJointMotor): velocity-level servo, impulse clamp */
+  for (int i = 0; i < m->n_arm; i++) {
+    row* r = new_row(e);
+    real tau[RP_MAX_ARM] = {0};
+    tau[i] = 1;
+    r->J[i] = 1;
+    arm_impulse_response(e, -1, 0, tau, r->B);
+    r->dinv = 1 / r->B[i];
+    real des = e->mmode[i] ? MOTOR_KP * (e->mtarget[i] - e->q[i]) / DT : 0;   /* kp*err/dt + qd + kd*(0-qd), kd = 1 */
+    r->rhs = (des - vstar[i]) * r->dinv;
+    r->lo = -e->mmaximp[i]; r->hi = e->mmaximp[i];
   }
   /* 4. Panda finger gear (btMultiBodyGearConstraint, environments.py:400-405): qd9 + ratio*qd10 -> 0, erp 0.1, maxForce 50 */
   if (m->arm_type == RP_ARM_PANDA) {
@@ -721,6 +725,7 @@ static void build_rows(rpo_env* e, const real* vstar) {
     r->rhs = (pos_err - relv) * r->dinv;
     r->lo = -(real)50 * DT; r->hi = (real)50 * DT;
   }
+  e->n_noncontact = e->nrows;
   /* 5. contact normals, then 6. friction (two directions per point, btPlaneSpace1) */
   int first_normal = e->nrows;
   for (int ci = 0; ci < e->ncon; ci++) {
@@ -730,10 +735,27 @@ static void build_rows(rpo_env* e, const real* vstar) {
     body_jacobian(e, ba, c->p, c->n, 1, r->J);
     body_jacobian(e, bb, c->p, c->n, -1, r->J);
     contact_response(e, ba, bb, c->p, c->n, r->J, r->B);
-    r->dinv = safe_inv(dotn(r->J, r->B, nv));
+    /* <contact> stiffness / damping of either link (the gripper links: ur5e2.urdf:306-312, panda.urdf:256-262) make the row soft
+     * (setupMultiBodyContactConstraint, BT_CONTACT_FLAG_CONTACT_STIFFNESS_DAMPING): combined stiffness 1 / (1/s0 + 1/s1) and damping
+     * d0 + d1 (an object without the block counts as stiffness 1e18, damping 0.1) give cfm = 1 / (dt (dt ks + kd)) and
+     * erp = dt ks / (dt kd + ks) */
+    real cfm = 0, erp = ERP_CONTACT;
+    {
+      real s0 = (real)m->col_stiffness[c->ca], s1 = (real)m->col_stiffness[c->cb];
+      if (s0 > 0 || s1 > 0) {
+        real d0 = s0 > 0 ? (real)m->col_damping[c->ca] : (real)0.1, d1 = s1 > 0 ? (real)m->col_damping[c->cb] : (real)0.1;
+        if (!(s0 > 0)) s0 = (real)1e18;
+        if (!(s1 > 0)) s1 = (real)1e18;
+        real ks = 1 / (1 / s0 + 1 / s1), kd = d0 + d1;
+        cfm = 1 / (DT * (DT * ks + kd));
+        erp = (DT * ks) / (DT * kd + ks);
+      }
+    }
+    r->dinv = safe_inv(dotn(r->J, r->B, nv) + cfm);
+    r->cfm = cfm * r->dinv;
     real relv = dotn(r->J, vstar, nv);
     real pen = c->dist + LINEAR_SLOP, pos_err = 0, vel_err = -relv;
-    if (pen > 0) vel_err -= pen / DT; else pos_err = -pen * ERP_CONTACT / DT;
+    if (pen > 0) vel_err -= pen / DT; else pos_err = -pen * erp / DT;
     r->rhs = (pos_err + vel_err) * r->dinv;
     r->lo = 0; r->hi = (real)1e10;
   }
@@ -755,29 +777,41 @@ static void build_rows(rpo_env* e, const real* vstar) {
   }
 }
 
-/* Sequential impulses (btMultiBodyConstraintSolver::resolveSingleConstraintRowGeneric), in the floating-point
- * evaluation order shared with the HIP library: with Jd = J * dinv folded at row build time,
- *     sum = (lambda + rhs) - Jd . dv ;  lambda' = clamp(sum, lo, hi) ;  d = lambda' - lambda ;  dv += B d
- * which is algebraically Bullet's  d = rhs - (J.dv) dinv, clamp(lambda + d)  with a shorter dependent chain. */
-static void solve_rows(rpo_env* e, real* dv) {
+/* Sequential impulses (btMultiBodyConstraintSolver::solveSingleIteration / resolveSingleConstraintRowGeneric), in the floating-point
+ * evaluation order shared with the HIP library.  With Jd = J * dinv folded at row build time a row's step is
+ *     delta = rhs - lambda cfm - Jd . dv, clamped to [lo - lambda, hi - lambda];  lambda += delta;  dv += B delta
+ * (Bullet's deltaImpulse in delta form).  Per sweep: the non-contact rows in ALTERNATING direction (`index = iteration & 1 ? j :
+ * size - 1 - j`: sweep 0 runs them last to first), then the contact normals, then the friction rows; a friction row is skipped while
+ * its normal impulse is not positive (`if (totalImpulse > 0)`), keeping whatever impulse it has. */
+static void solve_one(rpo_env* e, row* r, real lo, real hi, real* dv) {
   int nv = e->nv;
+  real delta = (r->rhs - r->lambda * r->cfm) - dotn(r->J, dv, nv);
+  real lo2 = lo - r->lambda, hi2 = hi - r->lambda;
+  real d = delta < lo2 ? lo2 : (delta > hi2 ? hi2 : delta);
+  r->lambda += d;
+  for (int i = 0; i < nv; i++) dv[i] += r->B[i] * d;
+}
+static void solve_rows(rpo_env* e, real* dv) {
+  int nv = e->nv, nnc = e->n_noncontact;
   for (int ri = 0; ri < e->nrows; ri++) {
     row* r = &e->rows[ri];
     for (int i = 0; i < nv; i++) r->J[i] *= r->dinv;
   }
-  for (int it = 0; it < N_ITER; it++)
-    for (int ri = 0; ri < e->nrows; ri++) {
-      row* r = &e->rows[ri];
-      real lo = r->lo, hi = r->hi;
-      if (r->fric_parent >= 0) { real lim = r->mu * e->rows[r->fric_parent].lambda; lo = -lim; hi = lim; }
-      /* btSolveSingleRowSequentialImpulse in delta form: the unclamped step is rhs - (J dinv).dv and the clamp acts on
-       * the step (lower - applied <= step <= upper - applied), exactly as Bullet sets deltaImpulse = limit - applied */
-      real delta = r->rhs - dotn(r->J, dv, nv);
-      real lo2 = lo - r->lambda, hi2 = hi - r->lambda;
-      real d = delta < lo2 ? lo2 : (delta > hi2 ? hi2 : delta);
-      r->lambda += d;
-      for (int i = 0; i < nv; i++) dv[i] += r->B[i] * d;
+  for (int it = 0; it < N_ITER; it++) {
+    for (int j = 0; j < nnc; j++) {
+      row* r = &e->rows[(it & 1) ? j : nnc - 1 - j];
+      solve_one(e, r, r->lo, r->hi, dv);
     }
+    for (int ri = nnc; ri < e->nrows; ri++) {
+      row* r = &e->rows[ri];
+      if (r->fric_parent >= 0) {
+        real tot = e->rows[r->fric_parent].lambda;
+        if (!(tot > 0)) continue;
+        real lim = r->mu * tot;
+        solve_one(e, r, -lim, lim, dv);
+      } else solve_one(e, r, r->lo, r->hi, dv);
+    }
+  }
 }
 
 /* ------------------------------------------------------------------ one stepSimulation() */

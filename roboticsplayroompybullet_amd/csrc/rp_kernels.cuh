@@ -60,7 +60,7 @@
 #define K_KP 0.1f
 #define K_DEFMOTOR 1.0f
 #define K_LIMIT_MAXIMP 100.0f
-#define K_LIMIT_ACT 0.1f
+#define K_ERP_LIMIT 0.2f     /* btContactSolverInfo::m_erp: joint-limit rows */
 #define K_LIN_DAMP 0.04f
 #define K_ANG_DAMP 0.04f
 #define K_IK_DAMP 0.1f
@@ -88,7 +88,7 @@ struct __align__(16) EnvLds {
   float conp[MAXC * 3], conn[MAXC * 3], cond[MAXC], conmu[MAXC];
   int cona[MAXC], conb[MAXC], conk[MAXC];     /* colliders of the contact; class: 0 no arm dof, 1 arm only, 2 spanning */
   float srow[MAXSMALL * 8];      /* type, dofA, sign/ratio, rhs | dinv, lo, hi, dofB */
-  float rowS[MAXROWC * 4];       /* rhs, dinv, mu, parent */
+  float rowS[MAXROWC * 4];       /* rhs, cfm * dinv (soft normal rows, else 0), mu, parent */
   float rowT[MAXROWC * 4];       /* lo_c, hi_c, off0, off1 */
   union {
     struct {                                   /* collide() */
@@ -896,15 +896,14 @@ __device__ int build_small_rows(const DevModel* m, EnvLds& L, int lane) {
     if (lane < 2 * n && m->arm_limited[i]) {
       float q = L.st[ST_Q + i];
       pen = side == 0 ? q - m->arm_lower[i] : m->arm_upper[i] - q;
-      on = pen <= K_LIMIT_ACT;
+      on = !(pen > 0.f);          /* btMultiBodyJointLimitConstraint: a row only while the limit is violated */
     }
     unsigned long long mask = __ballot(on);
     if (on) {
       int r = nr + __popcll(mask & ((1ull << lane) - 1ull));
       float sgn = side == 0 ? 1.f : -1.f;
       float dinv = 1.f / L.Minv[i * 12 + i];
-      float relv = sgn * L.vstar[i], pos_err = 0.f, vel_err = -relv;
-      if (pen > 0.f) vel_err -= pen / K_DT; else pos_err = -pen * K_ERP / K_DT;
+      float relv = sgn * L.vstar[i], pos_err = -pen * K_ERP_LIMIT / K_DT, vel_err = -relv;
       put_srow(L, r, SR_UNIT, i, sgn, (pos_err + vel_err) * dinv, dinv, 0.f, K_LIMIT_MAXIMP, 0);
     }
     nr += __popcll(mask);
@@ -1030,13 +1029,27 @@ __device__ void contact_rows(const DevModel* m, EnvLds& L, int lane, int ncon) {
       const float* B = &L.u.r.B[r * ROWW];
       for (int i = 0; i < n; i++) { diag += J[i] * B[i]; relv += J[i] * L.vstar[i]; }
     }
-    float dinv = safe_inv(diag), rhs;
+    float dinv, rhs, cfmr = 0.f;
     if (r < ncon) {
+      /* <contact> stiffness / damping of either link (the gripper links) make the normal row soft: cfm and erp as in
+       * setupMultiBodyContactConstraint (BT_CONTACT_FLAG_CONTACT_STIFFNESS_DAMPING); same arithmetic as the oracle's build_rows */
+      float cfm = 0.f, erp = K_ERP;
+      float s0 = m->col_stiff[L.cona[r]], s1 = m->col_stiff[L.conb[r]];
+      if (s0 > 0.f || s1 > 0.f) {
+        float d0 = s0 > 0.f ? m->col_damp[L.cona[r]] : 0.1f, d1 = s1 > 0.f ? m->col_damp[L.conb[r]] : 0.1f;
+        if (!(s0 > 0.f)) s0 = 1e18f;
+        if (!(s1 > 0.f)) s1 = 1e18f;
+        float ks = 1.f / (1.f / s0 + 1.f / s1), kd = d0 + d1;
+        cfm = 1.f / (K_DT * (K_DT * ks + kd));
+        erp = (K_DT * ks) / (K_DT * kd + ks);
+      }
+      dinv = safe_inv(diag + cfm);
+      cfmr = cfm * dinv;
       float pen = L.cond[r] + K_SLOP, pos_err = 0.f, vel_err = -relv;
-      if (pen > 0.f) vel_err -= pen / K_DT; else pos_err = -pen * K_ERP / K_DT;
+      if (pen > 0.f) vel_err -= pen / K_DT; else pos_err = -pen * erp / K_DT;
       rhs = (pos_err + vel_err) * dinv;
-    } else rhs = -relv * dinv;
-    s[0] = rhs; s[1] = dinv;
+    } else { dinv = safe_inv(diag); rhs = -relv * dinv; }
+    s[0] = rhs; s[1] = cfmr;          /* [1]: the row's softness cfm * dinv (dinv itself is folded into J below) */
     t[0] = __int_as_float((__float_as_int(t[0]) != 0 && __float_as_int(t[3]) != 64) ? 1 : 0);   /* row spans arm and non-arm dofs */
     float* Jw = &L.u.r.J[r * ROWW];          /* fold dinv into the stored row: the sweeps use Jd = J * dinv */
     for (int k = 0; k < ROWW; k++) Jw[k] *= dinv;
@@ -1067,36 +1080,27 @@ __device__ float solve_rows(const DevModel* m, LDS& L, int lane, int nsmall_, in
   float dv = 0.f;
   float lamS = 0.f, lamC0 = 0.f, lamC1 = 0.f;
   for (int it = 0; it < K_NITER; it++) {
-    {   /* motors, limits, gear: J has one or two unit entries, B is a (combination of) column(s) of M^-1 */
-      float4 s0 = *(const float4*)&L.srow[0], s1 = *(const float4*)&L.srow[4];
-      float bn = 0.f;
-      {
-        int type = uni(__float_as_int(s0.x)), dA = uni(__float_as_int(s0.y)), dB = uni(__float_as_int(s1.w));
-        float sg = s0.z;
-        if (type == SR_J1) bn = lane == lane_pos(m, dA) ? sg : 0.f;
-        else if (lane < n) bn = type == SR_UNIT ? sg * L.Minv[lane * 12 + dA] : L.Minv[lane * 12 + dA] + sg * L.Minv[lane * 12 + dB];
-      }
-      for (int r = 0; r < nsmall; r++) {
-        float4 c0 = s0, c1 = s1;
-        float bl = bn;
-        int type = uni(__float_as_int(c0.x)), dA = uni(__float_as_int(c0.y)), dB = uni(__float_as_int(c1.w));
-        if (r + 1 < nsmall) {
-          s0 = *(const float4*)&L.srow[8 * (r + 1)]; s1 = *(const float4*)&L.srow[8 * (r + 1) + 4];
-          int t2 = uni(__float_as_int(s0.x)), a2 = uni(__float_as_int(s0.y)), b2 = uni(__float_as_int(s1.w));
-          float g2 = s0.z;
-          bn = 0.f;
-          if (t2 == SR_J1) bn = lane == lane_pos(m, a2) ? g2 : 0.f;
-          else if (lane < n) bn = t2 == SR_UNIT ? g2 * L.Minv[lane * 12 + a2] : L.Minv[lane * 12 + a2] + g2 * L.Minv[lane * 12 + b2];
-        }
-        float sg = c0.z, jA = c1.x;      /* c1.x = dinv = the folded J entry at dofA */
-        float delta;
+    {   /* scene-joint motors, limits, motors, gear - the order Bullet's world holds them in (see the oracle's build_rows) - walked in
+         * ALTERNATING direction: sweep 0 last to first (`index = iteration & 1 ? j : size - 1 - j`).  srow holds them as
+         * [motors n | scene joints nj | limits | gear]; sidx maps a position of Bullet's order to that storage.
+         * J has one or two unit entries, B is a (combination of) column(s) of M^-1 */
+      const int nj = m->n_j1, ngear = m->arm_type == RP_ARM_PANDA ? 1 : 0, nlim = nsmall - n - nj - ngear;
+      auto sidx = [&](int pos) { return pos < nj ? n + pos : (pos < nj + nlim ? n + pos : (pos < nj + nlim + n ? pos - nj - nlim : pos)); };
+      for (int rr = 0; rr < nsmall; rr++) {
+        const int r = uni(sidx((it & 1) ? rr : nsmall - 1 - rr));
+        const float4 c0 = *(const float4*)&L.srow[8 * r], c1 = *(const float4*)&L.srow[8 * r + 4];
+        const int type = uni(__float_as_int(c0.x)), dA = uni(__float_as_int(c0.y)), dB = uni(__float_as_int(c1.w));
+        const float sg = c0.z, jA = c1.x;      /* c1.x = dinv = the folded J entry at dofA */
+        float bl = 0.f;
+        if (type == SR_J1) bl = lane == lane_pos(m, dA) ? sg : 0.f;
+        else if (lane < n) bl = type == SR_UNIT ? sg * L.Minv[lane * 12 + dA] : L.Minv[lane * 12 + dA] + sg * L.Minv[lane * 12 + dB];
         float jdv;           /* products rounded on their own (no contraction across statements), as in k_solve2 */
         if (type == SR_UNIT) jdv = (sg * jA) * lane_read(dv, dA);
         else if (type == SR_J1) jdv = jA * lane_read(dv, uni(lane_pos(m, dA)));
         else { float pa = jA * lane_read(dv, dA); float pb = (sg * jA) * lane_read(dv, dB); jdv = pa + pb; }
-        delta = c0.w - jdv;
+        const float delta = c0.w - jdv;
         float lam = lane_read(lamS, r), lnew;
-        float d = pgs_update(delta, lam, c1.y, c1.z, lnew);
+        const float d = pgs_update(delta, lam, c1.y, c1.z, lnew);
         lamS = lane == r ? lnew : lamS;
         dv = fmaf(bl, d, dv);
       }
@@ -1114,7 +1118,7 @@ __device__ float solve_rows(const DevModel* m, LDS& L, int lane, int nsmall_, in
       }
       for (int r = 0; r < nrc; r++) {
         float jl = jn, bl = bn;
-        float rhs = sn.x, mu = sn.z, lo_c = 0.f, hi_c = tn.y;      /* contact rows: lower bound 0 (tn.x carries a flag) */
+        float rhs = sn.x, cfmr = sn.y, mu = sn.z, lo_c = 0.f, hi_c = tn.y;      /* contact rows: lower bound 0 (tn.x carries a flag) */
         int parent = uni(__float_as_int(sn.w));
         sn = s2; tn = t2;
         if (r + 1 < nrc) {
@@ -1126,10 +1130,12 @@ __device__ float solve_rows(const DevModel* m, LDS& L, int lane, int nsmall_, in
         }
         float lamv = r < 64 ? lamC0 : lamC1;
         float lam = lane_read(lamv, r & 63);
-        float lim = mu * lane_read(lamC0, parent);            /* parent < ncon <= MAXC */
+        const float tot = lane_read(lamC0, parent);             /* parent < ncon <= MAXC */
+        float lim = mu * tot;
         float prod = jl * dv;
         float jdv = wave_sum32(prod), lnew;
-        float d = pgs_update(rhs - jdv, lam, lo_c - lim, hi_c + lim, lnew);
+        float d = pgs_update(__fmaf_rn(-lam, cfmr, rhs) - jdv, lam, lo_c - lim, hi_c + lim, lnew);
+        if (r >= uni(ncon_) && !(tot > 0.f)) { d = 0.f; lnew = lam; }      /* a friction row is skipped while its normal impulse is not positive */
         float sel = lane == (r & 63) ? lnew : lamv;
         lamC0 = r < 64 ? sel : lamC0;
         lamC1 = r < 64 ? lamC1 : sel;
@@ -2251,13 +2257,21 @@ __device__ __forceinline__ float fold_rows(float v) {
 }
 /* one plane register set: lane k holds the scalars of the row labelled k */
 struct Plane { float rhs, lo, hi, lam, dacc, loP, hiP; };
+struct PlaneN : Plane { float cfm, rhsE; };      /* contact normals: softness cfm * dinv of the row, rhsE = rhs - lam cfm per sweep */
 /* the row bodies below are inline asm (the compiler inserts no hazard nops inside): a DPP read needs two wait states
  * after the VALU write of its source, so the bounds written here are fenced once per sweep instead */
 #define PLANE_FENCE4(a, b, c, d) asm volatile("s_nop 1" : "+v"((a).loP), "+v"((a).hiP), "+v"((b).loP), "+v"((b).hiP), "+v"((c).loP), "+v"((c).hiP), "+v"((d).loP), "+v"((d).hiP))
+#define PLANE_FENCE_N(a, b, c) asm volatile("s_nop 1" : "+v"((a).loP), "+v"((a).hiP), "+v"((b).rhsE), "+v"((c).rhsE))
 __device__ __forceinline__ void plane_begin(Plane& p) { p.loP = p.lo - p.lam; p.hiP = p.hi - p.lam; p.dacc = 0.f; }
 __device__ __forceinline__ void plane_end(Plane& p) { p.lam += p.dacc; }
 /* friction plane: bounds -+ mu * (normal impulse) from the normals' plane of the same lanes */
-__device__ __forceinline__ void fplane_begin(Plane& p, float lim) { p.loP = (0.f - lim) - p.lam; p.hiP = (0.f + lim) - p.lam; p.dacc = 0.f; }
+__device__ __forceinline__ void nplane_begin(PlaneN& p) { p.loP = p.lo - p.lam; p.hiP = p.hi - p.lam; p.dacc = 0.f; p.rhsE = __fmaf_rn(-p.lam, p.cfm, p.rhs); }
+/* ... while the normal impulse is not positive the friction rows of that contact are skipped (Bullet's `if (totalImpulse > 0)`): step
+ * bounds [0, 0] */
+__device__ __forceinline__ void fplane_begin(Plane& p, float lim, float tot) {
+  const bool on = tot > 0.f;
+  p.loP = on ? (0.f - lim) - p.lam : 0.f; p.hiP = on ? (0.f + lim) - p.lam : 0.f; p.dacc = 0.f;
+}
 
 #define DPP_ALL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
 
@@ -2283,7 +2297,7 @@ __device__ __forceinline__ void unit_row(float jd, float col, float& dv, Plane& 
  * a row that spans arm and non-arm dofs needs and an exact no-op (+0) for the others: 4 more instructions, cheaper
  * than a scalar branch around them (a not-taken s_cbranch costs ~13 cycles in this chain, a taken one ~27) */
 template <int K, bool FOLDABLE>
-__device__ __forceinline__ void generic_row(float Jr, float Br, float& dv, Plane& p, int l16) {
+__device__ __forceinline__ void generic_row(float Jr, float Br, float& dv, Plane& p, int l16, float prhs) {
   float t, r, lo, hi, u;
   if (!FOLDABLE)
     asm volatile(
@@ -2304,7 +2318,7 @@ __device__ __forceinline__ void generic_row(float Jr, float Br, float& dv, Plane
         "v_cndmask_b32_e32 %[dacc], %[dacc], %[t], vcc\n"
         "v_fmac_f32 %[dv], %[B], %[t]\n"
         : [dv] "+v"(dv), [dacc] "+v"(p.dacc), [t] "=&v"(t), [r] "=&v"(r), [lo] "=&v"(lo), [hi] "=&v"(hi)
-        : [J] "v"(Jr), [B] "v"(Br), [rhs] "v"(p.rhs), [lop] "v"(p.loP), [hip] "v"(p.hiP), [l16] "v"(l16), [k] "n"(K & 15)
+        : [J] "v"(Jr), [B] "v"(Br), [rhs] "v"(prhs), [lop] "v"(p.loP), [hip] "v"(p.hiP), [l16] "v"(l16), [k] "n"(K & 15)
         : "vcc");
   else
     asm volatile(
@@ -2329,7 +2343,7 @@ __device__ __forceinline__ void generic_row(float Jr, float Br, float& dv, Plane
         "v_cndmask_b32_e32 %[dacc], %[dacc], %[t], vcc\n"
         "v_fmac_f32 %[dv], %[B], %[t]\n"
         : [dv] "+v"(dv), [dacc] "+v"(p.dacc), [t] "=&v"(t), [r] "=&v"(r), [lo] "=&v"(lo), [hi] "=&v"(hi), [u] "=&v"(u)
-        : [J] "v"(Jr), [B] "v"(Br), [rhs] "v"(p.rhs), [lop] "v"(p.loP), [hip] "v"(p.hiP), [l16] "v"(l16), [k] "n"(K & 15)
+        : [J] "v"(Jr), [B] "v"(Br), [rhs] "v"(prhs), [lop] "v"(p.loP), [hip] "v"(p.hiP), [l16] "v"(l16), [k] "n"(K & 15)
         : "vcc");
 }
 
@@ -2452,7 +2466,7 @@ __device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, floa
     }
     return valid ? c : -1;
   };
-  Plane PN[2], PF[2][2];                    /* normals, frictions [direction][register]; slot = 16 r + lane */
+  PlaneN PN[2]; Plane PF[2][2];             /* normals, frictions [direction][register]; slot = 16 r + lane */
   float muN[2];
 #pragma unroll
   for (int r = 0; r < 2; r++) {
@@ -2461,6 +2475,7 @@ __device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, floa
     bool on = c >= 0;
     int cc = on ? c : 0;
     PN[r].rhs = ldz(&w[W3_ROWS + 4 * cc], on); PN[r].lo = 0.f; PN[r].hi = ldz(&w[W3_ROWT + 4 * cc + 1], on);
+    PN[r].cfm = ldz(&w[W3_ROWS + 4 * cc + 1], on); PN[r].rhsE = PN[r].rhs;
     muN[r] = ldz(&w[W3_MU + cc], on);
 #pragma unroll
     for (int d = 0; d < 2; d++) { PF[d][r].rhs = ldz(&w[W3_ROWS + 4 * ((on ? my_nc : 0) + 2 * cc + d)], on); PF[d][r].lo = 0.f; PF[d][r].hi = 0.f; }
@@ -2519,42 +2534,54 @@ __device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, floa
     nS_it = __builtin_amdgcn_readfirstlane(nS_it); nC_it = __builtin_amdgcn_readfirstlane(nC_it);
     mL_it = __builtin_amdgcn_readfirstlane(mL_it); mU_it = __builtin_amdgcn_readfirstlane(mU_it);
     gr_it = __builtin_amdgcn_readfirstlane(gr_it);
-    plane_begin(X0); plane_begin(PL); plane_begin(PU); plane_begin(PN[0]); plane_begin(PN[1]);
-    PLANE_FENCE4(X0, PL, PN[0], PN[1]);                      /* PU is written before the fence and read much later */
-    /* unit rows: motor t in DPP row 0 beside scene joint t in DPP row 1 (t >= n_arm / absent joint: exact no-op) */
+    plane_begin(X0); plane_begin(PL); plane_begin(PU); nplane_begin(PN[0]); nplane_begin(PN[1]);
+    PLANE_FENCE4(X0, PL, PU, PN[0]);
+    PLANE_FENCE_N(PN[1], PN[0], PN[1]);
+    /* unit rows in Bullet's order - limits (dof-major, lower before upper), motors, gear - walked in ALTERNATING direction: odd sweeps
+     * first to last, even sweeps (the first one too) last to first.  Motor t in DPP row 0 runs beside scene joint t in DPP row 1
+     * (t >= n_arm / absent joint: exact no-op; the scene joints share no dof with any other unit row, so their place is free).
+     * One guard per group of six limit dofs: an absent limit row is all zeros and an exact no-op that costs about as much as the
+     * branch that would skip it; limit rows exist only while a limit is violated, so the groups are mostly skipped */
 #define UNIT_M(t) unit_row<(t)>(dinvX, Bm[t], dv, X0, l16);
-    REP12(UNIT_M)
-#undef UNIT_M
-    /* limits, dof-major, lower before upper.  One guard per group of six dofs: an absent limit row is all zeros and an
-     * exact no-op that costs about as much as the branch that would skip it */
 #define UNIT_L(i) unit_row<(i)>(dinvX, Bm[i], dv, PL, l16); unit_row<(i)>(dinvX, Bm[i], dv, PU, l16);
-    if ((mL_it | mU_it) & 0x03F) { UNIT_L(0) UNIT_L(1) UNIT_L(2) UNIT_L(3) UNIT_L(4) UNIT_L(5) }
-    if ((mL_it | mU_it) & 0xFC0) { UNIT_L(6) UNIT_L(7) UNIT_L(8) UNIT_L(9) UNIT_L(10) UNIT_L(11) }
+#define UNIT_LR(i) unit_row<(i)>(dinvX, Bm[i], dv, PU, l16); unit_row<(i)>(dinvX, Bm[i], dv, PL, l16);
+    if (it & 1) {
+      if ((mL_it | mU_it) & 0x03F) { UNIT_L(0) UNIT_L(1) UNIT_L(2) UNIT_L(3) UNIT_L(4) UNIT_L(5) }
+      if ((mL_it | mU_it) & 0xFC0) { UNIT_L(6) UNIT_L(7) UNIT_L(8) UNIT_L(9) UNIT_L(10) UNIT_L(11) }
+      REP12(UNIT_M)
+      if (gr_it) generic_row<GEAR_LANE, false>(Jg, Bg, dv, PU, l16, PU.rhs);
+    } else {
+      if (gr_it) generic_row<GEAR_LANE, false>(Jg, Bg, dv, PU, l16, PU.rhs);
+      UNIT_M(11) UNIT_M(10) UNIT_M(9) UNIT_M(8) UNIT_M(7) UNIT_M(6) UNIT_M(5) UNIT_M(4) UNIT_M(3) UNIT_M(2) UNIT_M(1) UNIT_M(0)
+      if ((mL_it | mU_it) & 0xFC0) { UNIT_LR(11) UNIT_LR(10) UNIT_LR(9) UNIT_LR(8) UNIT_LR(7) UNIT_LR(6) }
+      if ((mL_it | mU_it) & 0x03F) { UNIT_LR(5) UNIT_LR(4) UNIT_LR(3) UNIT_LR(2) UNIT_LR(1) UNIT_LR(0) }
+    }
+#undef UNIT_M
 #undef UNIT_L
-    if (gr_it) generic_row<GEAR_LANE, false>(Jg, Bg, dv, PU, l16);
+#undef UNIT_LR
     plane_end(X0); plane_end(PL); plane_end(PU);
     /* contact normals: side-by-side slots while they last, then the folded slots.  Contacts are prefixes of both
      * ranges, so the guards are early exits: nothing is spent on absent slots */
-#define NRM_P(s) if (nS_it <= (s)) goto nrm_pdone; generic_row<(s), false>(JN[s], BN[s], dv, PN[(s) >> 4], l16);
+#define NRM_P(s) if (nS_it <= (s)) goto nrm_pdone; generic_row<(s), false>(JN[s], BN[s], dv, PN[(s) >> 4], l16, PN[(s) >> 4].rhsE);
     REP21(NRM_P)
 #undef NRM_P
   nrm_pdone:
-#define NRM_C(j) if (nC_it <= (j)) goto nrm_done; generic_row<MAXC - 1 - (j), true>(JN[MAXC - 1 - (j)], BN[MAXC - 1 - (j)], dv, PN[(MAXC - 1 - (j)) >> 4], l16);
+#define NRM_C(j) if (nC_it <= (j)) goto nrm_done; generic_row<MAXC - 1 - (j), true>(JN[MAXC - 1 - (j)], BN[MAXC - 1 - (j)], dv, PN[(MAXC - 1 - (j)) >> 4], l16, PN[(MAXC - 1 - (j)) >> 4].rhsE);
     REP21(NRM_C)
 #undef NRM_C
   nrm_done:
     plane_end(PN[0]); plane_end(PN[1]);
     if (nS_it + nC_it > 0) {                                   /* frictions, slot by slot: bounds -+ mu * (normal impulse) */
-      fplane_begin(PF[0][0], muN[0] * PN[0].lam); fplane_begin(PF[1][0], muN[0] * PN[0].lam);
-      fplane_begin(PF[0][1], muN[1] * PN[1].lam); fplane_begin(PF[1][1], muN[1] * PN[1].lam);
+      fplane_begin(PF[0][0], muN[0] * PN[0].lam, PN[0].lam); fplane_begin(PF[1][0], muN[0] * PN[0].lam, PN[0].lam);
+      fplane_begin(PF[0][1], muN[1] * PN[1].lam, PN[1].lam); fplane_begin(PF[1][1], muN[1] * PN[1].lam, PN[1].lam);
       PLANE_FENCE4(PF[0][0], PF[1][0], PF[0][1], PF[1][1]);
-#define FRC_P(s) if (nS_it <= (s)) goto frc_pdone; generic_row<(s), false>(JF[0][s], BF[0][s], dv, PF[0][(s) >> 4], l16); \
-                 generic_row<(s), false>(JF[1][s], BF[1][s], dv, PF[1][(s) >> 4], l16);
+#define FRC_P(s) if (nS_it <= (s)) goto frc_pdone; generic_row<(s), false>(JF[0][s], BF[0][s], dv, PF[0][(s) >> 4], l16, PF[0][(s) >> 4].rhs); \
+                 generic_row<(s), false>(JF[1][s], BF[1][s], dv, PF[1][(s) >> 4], l16, PF[1][(s) >> 4].rhs);
       REP21(FRC_P)
 #undef FRC_P
     frc_pdone:
-#define FRC_C(j) if (nC_it <= (j)) goto frc_done; generic_row<MAXC - 1 - (j), true>(JF[0][MAXC - 1 - (j)], BF[0][MAXC - 1 - (j)], dv, PF[0][(MAXC - 1 - (j)) >> 4], l16); \
-                 generic_row<MAXC - 1 - (j), true>(JF[1][MAXC - 1 - (j)], BF[1][MAXC - 1 - (j)], dv, PF[1][(MAXC - 1 - (j)) >> 4], l16);
+#define FRC_C(j) if (nC_it <= (j)) goto frc_done; generic_row<MAXC - 1 - (j), true>(JF[0][MAXC - 1 - (j)], BF[0][MAXC - 1 - (j)], dv, PF[0][(MAXC - 1 - (j)) >> 4], l16, PF[0][(MAXC - 1 - (j)) >> 4].rhs); \
+                 generic_row<MAXC - 1 - (j), true>(JF[1][MAXC - 1 - (j)], BF[1][MAXC - 1 - (j)], dv, PF[1][(MAXC - 1 - (j)) >> 4], l16, PF[1][(MAXC - 1 - (j)) >> 4].rhs);
       REP21(FRC_C)
 #undef FRC_C
     frc_done:

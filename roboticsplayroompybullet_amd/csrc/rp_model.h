@@ -78,6 +78,9 @@ typedef struct rp_model {
    * btCollisionShape::getAngularMotionDisc (|AABB centre| + half diagonal of the object's shape in its own frame); a pair's
    * threshold is the smaller of its two objects' (btCollisionDispatcher::getNewManifold, relative thresholds are its default) */
   double col_thr[RP_MAX_COL];
+  /* URDF <contact> stiffness / damping of the link the collider belongs to (0 = absent): Bullet turns them into the contact row's
+   * cfm and erp (BT_CONTACT_FLAG_CONTACT_STIFFNESS_DAMPING, btMultiBodyConstraintSolver::setupMultiBodyContactConstraint) */
+  double col_stiffness[RP_MAX_COL], col_damping[RP_MAX_COL];
   /* candidate collider pairs (first = collider of the higher body id), sorted so that the pairs of one
    * object pair (manifold) are contiguous */
   unsigned char pair[RP_MAX_PAIR][2];

@@ -600,6 +600,9 @@ def emit_header(models, path):
         put('col_link', [c['link'] for c in C], 'int')
         put('col_obj', [c['obj'] for c in C], 'int')
         put('col_thr', [0.02 * c['disc'] for c in C])
+        # URDF <contact> stiffness / damping (gripper links; ur5e2.urdf:306-312, panda.urdf:256-262); 0 = none (rigid contact)
+        put('col_stiffness', [float(c.get('contact', {}).get('stiffness', 0.0)) for c in C])
+        put('col_damping', [float(c.get('contact', {}).get('damping', 0.0)) for c in C])
         put('pair', M['pair'], 'unsigned char')
         out.append('}\n\n')
     out.append('#endif\n')
