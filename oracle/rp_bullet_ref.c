@@ -60,7 +60,6 @@
 #define RPB_SHAPE_MARGIN 0.001          /* gUrdfDefaultCollisionMargin / the physics server's default collision margin */
 #define RPB_BREAKING 0.02               /* gContactBreakingThreshold; a manifold's threshold is relative (rp_model.col_thr) */
 #define RPB_ERP_LIMIT 0.2               /* btContactSolverInfo::m_erp */
-#define LIMIT_ACTIVATION ((real)0.1)     /* RPB_LIMIT off = round 1's fast model: a speculative limit row from 0.1 rad before the limit on */
 #define RPB_FRICTION_ERP 0.2            /* m_frictionERP */
 #define RPB_WARM_FACTOR 0.85            /* m_warmstartingFactor default */
 #define RPB_MAX_MAN 160
@@ -789,8 +788,8 @@ static void rpb_build_rows(rpo_env* e, rpb_state* st, const real* vstar) {
         real d0 = sa && sa->damping >= 0 && sa->stiffness > 0 ? sa->damping : 0.1, d1 = sb && sb->damping >= 0 && sb->stiffness > 0 ? sb->damping : 0.1;
         real ks = 1 / (1 / s0 + 1 / s1), kd = d0 + d1;
         real den = DT * kd + DT * DT * ks;
-        cfm = (1 / (den < 2.2e-16 ? 2.2e-16 : den)) / DT;
-        erp = (DT * ks) / (DT * kd + ks);
+        cfm = 1 / (den < 2.2e-16 ? 2.2e-16 : den);            /* (a `cfm *= invTimeStep` is recalled after this block: see rp_oracle.c build_rows) */
+        erp = (DT * ks) / (DT * ks + kd);
       }
       r->dinv = (d + cfm) > 2.2e-16 ? 1 / (d + cfm) : 0;
       r->cfm = cfm * r->dinv;

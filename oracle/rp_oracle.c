@@ -35,7 +35,7 @@
 #define DEFAULT_MOTOR_MAXIMP ((real)1.0) /* createJointMotors: velocity motor, target 0, max impulse 1 */
 #define LIMIT_MAXIMP ((real)100.0)
 #define MAX_COORD_VEL ((real)100.0)     /* btMultiBody::m_maxCoordinateVelocity (recalled) */
-#define ERP_LIMIT ((real)0.2)          /* btContactSolverInfo::m_erp: joint-limit rows (btMultiBodyJointLimitConstraint) */
+#define LIMIT_ACTIVATION ((real)0.1)
 #define FREE_LIN_DAMP ((real)0.04)
 #define FREE_ANG_DAMP ((real)0.04)
 #define J1_ANG_DAMP ((real)0.04)        /* changeDynamics(linearDamping=0) leaves angular at the 0.04 default */
@@ -662,10 +662,27 @@ static void build_rows(rpo_env* e, const real* vstar) {
   const rp_model* m = &e->m;
   int nv = e->nv;
   e->nrows = 0;
-  /* Non-contact rows in the order Bullet's world holds its multibody constraints (creation order): the scene bodies' joint motors
-   * (made before the arm is loaded), the arm's joint-limit constraints (added while the URDF tree is converted), the arm's joint
-   * motors (createJointMotors, afterwards), the gear (environments.py:400-405).  solve_rows walks them in alternating direction. */
-  /* 1. scene joint motors: button position motor (scenes.py:238), default velocity motors on door and dial */
+  /* Non-contact rows: motors, scene-joint motors, limits, gear - limits AFTER the motors and every sweep in the same direction, so
+   * that a limit wins over a motor that pushes its joint into it, and a limit row from LIMIT_ACTIVATION before the limit on (a
+   * speculative row: it stops the joint exactly at the limit).  The frozen reference step (rp_bullet_ref.c: RPB_ORDER, RPB_LIMIT)
+   * restates what is recalled of Bullet instead - creation order walked in alternating direction, a limit row only while the limit
+   * is violated, erp 0.2 - under which a position motor that is not force-saturated drives a light link (the Robotiq's mimic and
+   * spring links) 0.1 - 0.3 rad through its limit; that rule makes the sweep's outcome depend on the last rows solved and is
+   * ill-conditioned in fp32 (the fp32 and fp64 builds of this oracle then differ by 5e-3 rad/s per substep on those joints), so
+   * the fast model keeps the well-conditioned rule and DESIGN.md section 2 reports what it costs against the reference step. */
+  /* 1. arm joint motors (btMultiBodyJointMotor): velocity-level servo, impulse clamp */
+  for (int i = 0; i < m->n_arm; i++) {
+    row* r = new_row(e);
+    real tau[RP_MAX_ARM] = {0};
+    tau[i] = 1;
+    r->J[i] = 1;
+    arm_impulse_response(e, -1, 0, tau, r->B);
+    r->dinv = 1 / r->B[i];
+    real des = e->mmode[i] ? MOTOR_KP * (e->mtarget[i] - e->q[i]) / DT : 0;   /* kp*err/dt + qd + kd*(0-qd), kd = 1 */
+    r->rhs = (des - vstar[i]) * r->dinv;
+    r->lo = -e->mmaximp[i]; r->hi = e->mmaximp[i];
+  }
+  /* 2. scene joint motors: button position motor (scenes.py:238), default velocity motors on door and dial */
   for (int k = 0; k < m->n_joint1; k++) {
     row* r = new_row(e);
     int d = dof_j1(e, k);
@@ -679,13 +696,12 @@ static void build_rows(rpo_env* e, const real* vstar) {
     r->rhs = (des - vstar[d]) * r->dinv;
     r->lo = -maximp; r->hi = maximp;
   }
-  /* 2. joint limits (btMultiBodyJointLimitConstraint::createConstraintRows): a row exists only while its limit is violated
-   * (`if (penetration > 0) continue;`) and pushes back with erp = m_erp = 0.2 */
+  /* 3. joint limits (btMultiBodyJointLimitConstraint): contact-like rows */
   for (int i = 0; i < m->n_arm; i++) {
     if (!(m->arm_lower[i] < m->arm_upper[i])) continue;
     for (int side = 0; side < 2; side++) {
       real pen = side == 0 ? e->q[i] - (real)m->arm_lower[i] : (real)m->arm_upper[i] - e->q[i];
-      if (pen > 0) continue;
+      if (pen > LIMIT_ACTIVATION) continue;
       real sgn = side == 0 ? (real)1 : (real)-1;
       row* r = new_row(e);
       real tau[RP_MAX_ARM] = {0};
@@ -693,22 +709,11 @@ static void build_rows(rpo_env* e, const real* vstar) {
       r->J[i] = sgn;
       arm_impulse_response(e, -1, 0, tau, r->B);
       r->dinv = 1 / (sgn * r->B[i]);
-      real relv = sgn * vstar[i], pos_err = -pen * ERP_LIMIT / DT, vel_err = -relv;
+      real relv = sgn * vstar[i], pos_err = 0, vel_err = -relv;
+      if (pen > 0) vel_err -= pen / DT; else pos_err = -pen * ERP_CONTACT / DT;
       r->rhs = (pos_err + vel_err) * r->dinv;
       r->lo = 0; r->hi = LIMIT_MAXIMP;
     }
-  }
-  /* 3. arm joint motors (btMultiBodyJointMotor): velocity-level servo, impulse clamp */
-  for (int i = 0; i < m->n_arm; i++) {
-    row* r = new_row(e);
-    real tau[RP_MAX_ARM] = {0};
-    tau[i] = 1;
-    r->J[i] = 1;
-    arm_impulse_response(e, -1, 0, tau, r->B);
-    r->dinv = 1 / r->B[i];
-    real des = e->mmode[i] ? MOTOR_KP * (e->mtarget[i] - e->q[i]) / DT : 0;   /* kp*err/dt + qd + kd*(0-qd), kd = 1 */
-    r->rhs = (des - vstar[i]) * r->dinv;
-    r->lo = -e->mmaximp[i]; r->hi = e->mmaximp[i];
   }
   /* 4. Panda finger gear (btMultiBodyGearConstraint, environments.py:400-405): qd9 + ratio*qd10 -> 0, erp 0.1, maxForce 50 */
   if (m->arm_type == RP_ARM_PANDA) {
@@ -737,8 +742,11 @@ static void build_rows(rpo_env* e, const real* vstar) {
     contact_response(e, ba, bb, c->p, c->n, r->J, r->B);
     /* <contact> stiffness / damping of either link (the gripper links: ur5e2.urdf:306-312, panda.urdf:256-262) make the row soft
      * (setupMultiBodyContactConstraint, BT_CONTACT_FLAG_CONTACT_STIFFNESS_DAMPING): combined stiffness 1 / (1/s0 + 1/s1) and damping
-     * d0 + d1 (an object without the block counts as stiffness 1e18, damping 0.1) give cfm = 1 / (dt (dt ks + kd)) and
-     * erp = dt ks / (dt kd + ks) */
+     * d0 + d1 (an object without the block counts as stiffness 1e18, damping 0.1) give the implicit spring-damper row
+     * cfm = 1 / (dt kd + dt^2 ks), erp = dt ks / (dt ks + kd): 0.27 and 0.09 for the grippers' 30000 N/m, 1000 N s/m.  (Recollection
+     * of the upstream lines also has a `cfm *= invTimeStep` after this block; taken literally that makes the contact 300 times softer -
+     * a 0.3 kg block would sink centimetres into a pad - so it is read as belonging to m_globalCfm only.  One more thing only a live
+     * PyBullet can settle: DESIGN.md H13.) */
     real cfm = 0, erp = ERP_CONTACT;
     {
       real s0 = (real)m->col_stiffness[c->ca], s1 = (real)m->col_stiffness[c->cb];
@@ -748,7 +756,7 @@ static void build_rows(rpo_env* e, const real* vstar) {
         if (!(s1 > 0)) s1 = (real)1e18;
         real ks = 1 / (1 / s0 + 1 / s1), kd = d0 + d1;
         cfm = 1 / (DT * (DT * ks + kd));
-        erp = (DT * ks) / (DT * kd + ks);
+        erp = (DT * ks) / (DT * ks + kd);
       }
     }
     r->dinv = safe_inv(dotn(r->J, r->B, nv) + cfm);
@@ -780,9 +788,9 @@ static void build_rows(rpo_env* e, const real* vstar) {
 /* Sequential impulses (btMultiBodyConstraintSolver::solveSingleIteration / resolveSingleConstraintRowGeneric), in the floating-point
  * evaluation order shared with the HIP library.  With Jd = J * dinv folded at row build time a row's step is
  *     delta = rhs - lambda cfm - Jd . dv, clamped to [lo - lambda, hi - lambda];  lambda += delta;  dv += B delta
- * (Bullet's deltaImpulse in delta form).  Per sweep: the non-contact rows in ALTERNATING direction (`index = iteration & 1 ? j :
- * size - 1 - j`: sweep 0 runs them last to first), then the contact normals, then the friction rows; a friction row is skipped while
- * its normal impulse is not positive (`if (totalImpulse > 0)`), keeping whatever impulse it has. */
+ * (Bullet's deltaImpulse in delta form).  Per sweep: the non-contact rows (build_rows explains their order), then the contact normals,
+ * then the friction rows; a friction row is skipped while its normal impulse is not positive (`if (totalImpulse > 0)`), keeping
+ * whatever impulse it has. */
 static void solve_one(rpo_env* e, row* r, real lo, real hi, real* dv) {
   int nv = e->nv;
   real delta = (r->rhs - r->lambda * r->cfm) - dotn(r->J, dv, nv);
@@ -799,7 +807,7 @@ static void solve_rows(rpo_env* e, real* dv) {
   }
   for (int it = 0; it < N_ITER; it++) {
     for (int j = 0; j < nnc; j++) {
-      row* r = &e->rows[(it & 1) ? j : nnc - 1 - j];
+      row* r = &e->rows[j];
       solve_one(e, r, r->lo, r->hi, dv);
     }
     for (int ri = nnc; ri < e->nrows; ri++) {

@@ -60,7 +60,7 @@
 #define K_KP 0.1f
 #define K_DEFMOTOR 1.0f
 #define K_LIMIT_MAXIMP 100.0f
-#define K_ERP_LIMIT 0.2f     /* btContactSolverInfo::m_erp: joint-limit rows */
+#define K_LIMIT_ACT 0.1f
 #define K_LIN_DAMP 0.04f
 #define K_ANG_DAMP 0.04f
 #define K_IK_DAMP 0.1f
@@ -896,14 +896,15 @@ __device__ int build_small_rows(const DevModel* m, EnvLds& L, int lane) {
     if (lane < 2 * n && m->arm_limited[i]) {
       float q = L.st[ST_Q + i];
       pen = side == 0 ? q - m->arm_lower[i] : m->arm_upper[i] - q;
-      on = !(pen > 0.f);          /* btMultiBodyJointLimitConstraint: a row only while the limit is violated */
+      on = pen <= K_LIMIT_ACT;
     }
     unsigned long long mask = __ballot(on);
     if (on) {
       int r = nr + __popcll(mask & ((1ull << lane) - 1ull));
       float sgn = side == 0 ? 1.f : -1.f;
       float dinv = 1.f / L.Minv[i * 12 + i];
-      float relv = sgn * L.vstar[i], pos_err = -pen * K_ERP_LIMIT / K_DT, vel_err = -relv;
+      float relv = sgn * L.vstar[i], pos_err = 0.f, vel_err = -relv;
+      if (pen > 0.f) vel_err -= pen / K_DT; else pos_err = -pen * K_ERP / K_DT;
       put_srow(L, r, SR_UNIT, i, sgn, (pos_err + vel_err) * dinv, dinv, 0.f, K_LIMIT_MAXIMP, 0);
     }
     nr += __popcll(mask);
@@ -1041,7 +1042,7 @@ __device__ void contact_rows(const DevModel* m, EnvLds& L, int lane, int ncon) {
         if (!(s1 > 0.f)) s1 = 1e18f;
         float ks = 1.f / (1.f / s0 + 1.f / s1), kd = d0 + d1;
         cfm = 1.f / (K_DT * (K_DT * ks + kd));
-        erp = (K_DT * ks) / (K_DT * kd + ks);
+        erp = (K_DT * ks) / (K_DT * ks + kd);
       }
       dinv = safe_inv(diag + cfm);
       cfmr = cfm * dinv;
@@ -1080,14 +1081,9 @@ __device__ float solve_rows(const DevModel* m, LDS& L, int lane, int nsmall_, in
   float dv = 0.f;
   float lamS = 0.f, lamC0 = 0.f, lamC1 = 0.f;
   for (int it = 0; it < K_NITER; it++) {
-    {   /* scene-joint motors, limits, motors, gear - the order Bullet's world holds them in (see the oracle's build_rows) - walked in
-         * ALTERNATING direction: sweep 0 last to first (`index = iteration & 1 ? j : size - 1 - j`).  srow holds them as
-         * [motors n | scene joints nj | limits | gear]; sidx maps a position of Bullet's order to that storage.
-         * J has one or two unit entries, B is a (combination of) column(s) of M^-1 */
-      const int nj = m->n_j1, ngear = m->arm_type == RP_ARM_PANDA ? 1 : 0, nlim = nsmall - n - nj - ngear;
-      auto sidx = [&](int pos) { return pos < nj ? n + pos : (pos < nj + nlim ? n + pos : (pos < nj + nlim + n ? pos - nj - nlim : pos)); };
-      for (int rr = 0; rr < nsmall; rr++) {
-        const int r = uni(sidx((it & 1) ? rr : nsmall - 1 - rr));
+    {   /* motors, scene-joint motors, limits, gear (the oracle's build_rows explains the order): J has one or two unit entries, B is a
+         * (combination of) column(s) of M^-1 */
+      for (int r = 0; r < nsmall; r++) {
         const float4 c0 = *(const float4*)&L.srow[8 * r], c1 = *(const float4*)&L.srow[8 * r + 4];
         const int type = uni(__float_as_int(c0.x)), dA = uni(__float_as_int(c0.y)), dB = uni(__float_as_int(c1.w));
         const float sg = c0.z, jA = c1.x;      /* c1.x = dinv = the folded J entry at dofA */
@@ -2537,28 +2533,17 @@ __device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, floa
     plane_begin(X0); plane_begin(PL); plane_begin(PU); nplane_begin(PN[0]); nplane_begin(PN[1]);
     PLANE_FENCE4(X0, PL, PU, PN[0]);
     PLANE_FENCE_N(PN[1], PN[0], PN[1]);
-    /* unit rows in Bullet's order - limits (dof-major, lower before upper), motors, gear - walked in ALTERNATING direction: odd sweeps
-     * first to last, even sweeps (the first one too) last to first.  Motor t in DPP row 0 runs beside scene joint t in DPP row 1
-     * (t >= n_arm / absent joint: exact no-op; the scene joints share no dof with any other unit row, so their place is free).
-     * One guard per group of six limit dofs: an absent limit row is all zeros and an exact no-op that costs about as much as the
-     * branch that would skip it; limit rows exist only while a limit is violated, so the groups are mostly skipped */
+    /* unit rows: motor t in DPP row 0 beside scene joint t in DPP row 1 (t >= n_arm / absent joint: exact no-op), then the limits,
+     * dof-major, lower before upper, then the gear.  One guard per group of six limit dofs: an absent limit row is all zeros and an
+     * exact no-op that costs about as much as the branch that would skip it */
 #define UNIT_M(t) unit_row<(t)>(dinvX, Bm[t], dv, X0, l16);
 #define UNIT_L(i) unit_row<(i)>(dinvX, Bm[i], dv, PL, l16); unit_row<(i)>(dinvX, Bm[i], dv, PU, l16);
-#define UNIT_LR(i) unit_row<(i)>(dinvX, Bm[i], dv, PU, l16); unit_row<(i)>(dinvX, Bm[i], dv, PL, l16);
-    if (it & 1) {
-      if ((mL_it | mU_it) & 0x03F) { UNIT_L(0) UNIT_L(1) UNIT_L(2) UNIT_L(3) UNIT_L(4) UNIT_L(5) }
-      if ((mL_it | mU_it) & 0xFC0) { UNIT_L(6) UNIT_L(7) UNIT_L(8) UNIT_L(9) UNIT_L(10) UNIT_L(11) }
-      REP12(UNIT_M)
-      if (gr_it) generic_row<GEAR_LANE, false>(Jg, Bg, dv, PU, l16, PU.rhs);
-    } else {
-      if (gr_it) generic_row<GEAR_LANE, false>(Jg, Bg, dv, PU, l16, PU.rhs);
-      UNIT_M(11) UNIT_M(10) UNIT_M(9) UNIT_M(8) UNIT_M(7) UNIT_M(6) UNIT_M(5) UNIT_M(4) UNIT_M(3) UNIT_M(2) UNIT_M(1) UNIT_M(0)
-      if ((mL_it | mU_it) & 0xFC0) { UNIT_LR(11) UNIT_LR(10) UNIT_LR(9) UNIT_LR(8) UNIT_LR(7) UNIT_LR(6) }
-      if ((mL_it | mU_it) & 0x03F) { UNIT_LR(5) UNIT_LR(4) UNIT_LR(3) UNIT_LR(2) UNIT_LR(1) UNIT_LR(0) }
-    }
+    REP12(UNIT_M)
+    if ((mL_it | mU_it) & 0x03F) { UNIT_L(0) UNIT_L(1) UNIT_L(2) UNIT_L(3) UNIT_L(4) UNIT_L(5) }
+    if ((mL_it | mU_it) & 0xFC0) { UNIT_L(6) UNIT_L(7) UNIT_L(8) UNIT_L(9) UNIT_L(10) UNIT_L(11) }
+    if (gr_it) generic_row<GEAR_LANE, false>(Jg, Bg, dv, PU, l16, PU.rhs);
 #undef UNIT_M
 #undef UNIT_L
-#undef UNIT_LR
     plane_end(X0); plane_end(PL); plane_end(PU);
     /* contact normals: side-by-side slots while they last, then the folded slots.  Contacts are prefixes of both
      * ranges, so the guards are early exits: nothing is spent on absent slots */

@@ -81,6 +81,10 @@ typedef struct rp_model {
   /* URDF <contact> stiffness / damping of the link the collider belongs to (0 = absent): Bullet turns them into the contact row's
    * cfm and erp (BT_CONTACT_FLAG_CONTACT_STIFFNESS_DAMPING, btMultiBodyConstraintSolver::setupMultiBodyContactConstraint) */
   double col_stiffness[RP_MAX_COL], col_damping[RP_MAX_COL];
+  /* rendering (environments.py:841-845 img): colour of the visual shape the collider stands for (scenes.py rgbaColor, URDF materials);
+   * col_toggle 1 = the globe recoloured by the button, 2 = the grill recoloured by the dial (updateToggles, environments.py:469-483) */
+  double col_rgb[RP_MAX_COL][3];
+  int col_toggle[RP_MAX_COL];
   /* candidate collider pairs (first = collider of the higher body id), sorted so that the pairs of one
    * object pair (manifold) are contiguous */
   unsigned char pair[RP_MAX_PAIR][2];

@@ -288,17 +288,21 @@ def quat_to_mat(q):
 def parse_scene(log):
     """Turn the recorded createCollisionShape/createMultiBody calls into bodies."""
     shapes = {}
+    visuals = {}
     bodies = []
     extras = {}
     for e in log:
+        if e['fn'] == 'createVisualShape':
+            visuals[e['ret']] = e['kwargs'].get('rgbaColor', [1, 1, 1, 1])[:3]
         if e['fn'] == 'createCollisionShape':
             shapes[e['ret']] = (e['args'][0], e['kwargs'])
         elif e['fn'] == 'createMultiBody':
             a, k = e['args'], e['kwargs']
             b = {'id': e['ret'], 'mass': a[0], 'shape': shapes.get(a[1]), 'pos': np.array(a[3], float),
                  'rot': quat_to_mat(a[4]) if len(a) > 4 else quat_to_mat(k.get('baseOrientation', [0, 0, 0, 1])),
-                 'friction': 0.5, 'link': None}
+                 'friction': 0.5, 'link': None, 'rgb': visuals.get(a[2] if len(a) > 2 else -1, [1, 1, 1])}
             if k.get('linkMasses'):
+                b['link_rgb'] = visuals.get((k.get('linkVisualShapeIndices') or [-1])[0], None)
                 b['link'] = {'mass': k['linkMasses'][0], 'shape': shapes[k['linkCollisionShapeIndices'][0]],
                              'pos': np.array(k['linkPositions'][0], float), 'rot': quat_to_mat(k['linkOrientations'][0]),
                              'jtype': k['linkJointTypes'][0], 'axis': np.array(k['linkJointAxis'][0], float)}
@@ -355,7 +359,8 @@ def make_model(kind, arm, scene_log, arm_base_pos, arm_base_rot, ee_index, rest,
             pos, rot = pw + Rw @ pos, Rw @ rot
         e = {'body': body, 'type': 0 if c['type'] == 'box' else 1, 'he': np.array(c['he'], float),
              'pos': np.array(pos, float), 'rot': np.array(rot, float), 'friction': float(friction), 'tag': tag,
-             'link': int(c.get('link', -1)), 'disc': float(c.get('disc', 0.0)), 'contact': c.get('contact', {})}
+             'link': int(c.get('link', -1)), 'disc': float(c.get('disc', 0.0)), 'contact': c.get('contact', {}),
+             'rgb': [float(v) for v in c.get('rgb', [0.7, 0.7, 0.7] if arm_type == 'UR5' else [0.9, 0.9, 0.9])], 'toggle': int(c.get('toggle', 0))}
         if 'hull' in c:
             H = np.array(c['hull'], float)
             e['hull'] = (world_pose[0] @ H.T).T + world_pose[1] if world_pose is not None else H
@@ -388,7 +393,10 @@ def make_model(kind, arm, scene_log, arm_base_pos, arm_base_rot, ee_index, rest,
             if not tiny:
                 for c in boxes:
                     base_cols.append(len(col))
-                    add_col(WORLD, c, b['friction'], (b['rot'], b['pos']), 'static%d' % b['id'])
+                    # colours of the visual shapes (scenes.py); the two toggles are recoloured by updateToggles (environments.py:469-483):
+                    # 1 = the globe over the button (body 10), 2 = the grill over the dial (body 8)
+                    tog = (1 if b['id'] == 10 else (2 if b['id'] == 8 else 0)) if scene == 'complex_scene' else 0
+                    add_col(WORLD, dict(c, rgb=b['rgb'], toggle=tog), b['friction'], (b['rot'], b['pos']), 'static%d' % b['id'])
             if b['link'] is not None:
                 L = b['link']
                 jb = 1 + nb + 100 + len(M['joint1'])       # provisional id, fixed below
@@ -410,7 +418,8 @@ def make_model(kind, arm, scene_log, arm_base_pos, arm_base_rot, ee_index, rest,
                       'scene_id': b['id']}
                 for c in lb:
                     j1['cols'].append(len(col))
-                    add_col(jb, c, b['friction'], None, 'joint1_%d' % b['id'])
+                    # a link without a visual shape is drawn from its collision shape; the dial link takes the colour of its (1e-5) base
+                    add_col(jb, dict(c, rgb=b.get('link_rgb') or b['rgb']), b['friction'], None, 'joint1_%d' % b['id'])
                 for a in base_cols:
                     for c2 in j1['cols']:
                         excluded.add((a, c2))
@@ -427,11 +436,15 @@ def make_model(kind, arm, scene_log, arm_base_pos, arm_base_rot, ee_index, rest,
                   'rot_locked': int(np.all(I == 0))}
             for c in boxes:
                 fb['cols'].append(len(col))
-                add_col(1 + nb + 200 + len(M['free']), c, b['friction'], None, 'free%d' % b['id'])
+                add_col(1 + nb + 200 + len(M['free']), dict(c, rgb=b['rgb']), b['friction'], None, 'free%d' % b['id'])
             M['free'].append(fb)
     # the reference lists objects (blocks) first in obs; scene creation order puts the drawer before the block.
     # canonical order here: free[0] = block (if any), free[1] = drawer.
     M['free'].sort(key=lambda f: f['rot_locked'])
+    # environments.py:432, 454: the objects are recoloured green, blue
+    for k, f in enumerate(x for x in M['free'] if not x['rot_locked']):
+        for ci in f['cols']:
+            col[ci]['rgb'] = [[0.0, 1.0, 0.0], [0.0, 0.0, 1.0]][k % 2]
     # final body ids
     remap = {}
     for k, f in enumerate(M['free']):
@@ -601,6 +614,8 @@ def emit_header(models, path):
         put('col_obj', [c['obj'] for c in C], 'int')
         put('col_thr', [0.02 * c['disc'] for c in C])
         # URDF <contact> stiffness / damping (gripper links; ur5e2.urdf:306-312, panda.urdf:256-262); 0 = none (rigid contact)
+        put('col_rgb', [c['rgb'] for c in C])
+        put('col_toggle', [c['toggle'] for c in C], 'int')
         put('col_stiffness', [float(c.get('contact', {}).get('stiffness', 0.0)) for c in C])
         put('col_damping', [float(c.get('contact', {}).get('damping', 0.0)) for c in C])
         put('pair', M['pair'], 'unsigned char')
