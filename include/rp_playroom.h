@@ -181,6 +181,31 @@ size_t rp_state_bytes(rp_handle h);           /* bytes per env */
 int rp_get_state(rp_handle h, void* dst, void* stream);
 int rp_set_state(rp_handle h, const void* src, int32_t src_env_count, void* stream);
 
+/* ---- images and ray queries ----------------------------------------------------------------------
+ * The reference renders obs['img'] with PyBullet's OpenGL rasteriser and asks Bullet for one ray per step; this library casts rays
+ * against the boxes and spheres of its contact model, coloured like the reference's visual shapes (flat shading, no textures). */
+typedef struct rp_camera {
+  float eye[3], target[3], up[3];   /* computeViewMatrix(eye, target, up) */
+  float fov_deg, aspect;            /* computeProjectionMatrixFOV(fov, aspect, near, far); near / far only clip: rays run 0 .. 10 m */
+  int32_t mode;                     /* 0 = this camera; 1 = gripper camera (ENV:33-49): eye at the EE link, looking along its -z, up = its x */
+} rp_camera;
+/* the reference's fixed camera (ENV:21-30): computeViewMatrixFromYawPitchRoll(target [0, 0.25, 0], distance 1.3, yaw -30, pitch -30, roll 0,
+ * upAxisIndex 2), computeProjectionMatrixFOV(fov 50, aspect 1, near 0.01, far 10) */
+int rp_default_camera(rp_camera* cam);
+/* p.computeViewMatrixFromYawPitchRoll's camera placement (degrees, upAxisIndex 2) */
+int rp_camera_from_yaw_pitch_roll(const float target[3], float distance, float yaw_deg, float pitch_deg, float roll_deg, rp_camera* cam);
+/* instance.calc_state()'s img (ENV:841-845: getCameraImage(width, height, view, projection)[2][:, :, :3]) for envs [first_env, first_env +
+ * num_envs): rgb [num_envs, height, width, 3] uint8, row 0 = top.  cam NULL = rp_default_camera.  sub_goal (may be NULL):
+ * [num_envs, dims.achieved_goal] - visualise_sub_goal(sub_goal, 'achieved_goal') (ENV:606-690): the objects and, for the play ids,
+ * drawer / door / button / dial drawn a second time, half transparent, at the poses the vectors name. */
+int rp_render(rp_handle h, const rp_camera* cam, int32_t width, int32_t height, int32_t first_env, int32_t num_envs, uint8_t* rgb,
+              const float* sub_goal, void* stream);
+/* bullet_client.rayTest(from, to) (ENV:738-741) for k rays per env: from / to [N, k, 3] world coordinates.  Outputs (each may be NULL):
+ * hit_fraction [N, k] (1 on a miss), collider [N, k] (index into the model's collider table, -1 on a miss), link [N, k] (Bullet link
+ * index of an arm collider, -1 otherwise), hit_position [N, k, 3], hit_normal [N, k, 3].  A ray that starts inside a shape does not hit it. */
+int rp_ray_test(rp_handle h, const float* from, const float* to, int32_t k, float* hit_fraction, int32_t* collider, int32_t* link,
+                float* hit_position, float* hit_normal, void* stream);
+
 int rp_get_timers(rp_handle h, rp_timers* t);
 /* on = number of rp_step calls to keep per-launch timings for (a ring); 0 disables */
 int rp_enable_timers(rp_handle h, int32_t on);

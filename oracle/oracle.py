@@ -112,6 +112,8 @@ def load(f32=False, bullet_ref=False):
     lib.rpo_contacts.argtypes = [vp, dp, C.c_int]
     lib.rpo_last_num_rows.argtypes = [vp]
     lib.rpo_box_box.argtypes = [dp, dp, dp, dp, dp, dp, C.c_double, dp]
+    lib.rpo_collider_poses.argtypes = [vp, dp]
+    lib.rpo_collider_table.argtypes = [vp, dp]
     lib.rpo_bench_rollout.argtypes = [C.c_int, C.c_ulonglong, C.c_int, C.c_int, C.c_int, dp, C.c_int, C.c_double]
     lib.rpo_bench_rollout.restype = C.c_double
     lib.rpo_rng_uniform.argtypes = [C.c_ulonglong, C.c_uint, C.c_uint]
@@ -279,6 +281,15 @@ class OracleEnv:
         o = RpoObs()
         self.lib.rpo_assemble_obs(self.h, C.byref(rd), C.byref(o))
         return o.to_dict(self.n_goal)
+
+    def colliders(self):
+        """(R [n, 3, 3], p [n, 3], table [n, 9] = type, he3, rgb3, toggle, link) of the current state"""
+        buf = np.zeros(64 * 12)
+        n = self.lib.rpo_collider_poses(self.h, buf.ctypes.data_as(C.POINTER(C.c_double)))
+        tab = np.zeros(64 * 9)
+        self.lib.rpo_collider_table(self.h, tab.ctypes.data_as(C.POINTER(C.c_double)))
+        b = buf[:12 * n].reshape(n, 12)
+        return b[:, :9].reshape(n, 3, 3), b[:, 9:], tab[:9 * n].reshape(n, 9)
 
     def compute_reward(self, ag, dg):
         return self.lib.rpo_compute_reward(self.h, _d(ag)[1], _d(dg)[1])

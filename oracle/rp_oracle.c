@@ -1749,6 +1749,25 @@ int rpo_contacts(rpo_env* e, double* out, int max) {
   return e->ncon;
 }
 int rpo_last_num_rows(const rpo_env* e) { return e->nrows; }
+/* world pose of every collider in the current state: out[12 c] = R (row-major), p; returns the collider count (render / ray tests) */
+int rpo_collider_poses(rpo_env* e, double* out) {
+  update_transforms(e);
+  for (int c = 0; c < e->m.n_col; c++) {
+    for (int k = 0; k < 9; k++) out[12 * c + k] = e->xc[c].R[k];
+    for (int k = 0; k < 3; k++) out[12 * c + 9 + k] = e->xc[c].p[k];
+  }
+  return e->m.n_col;
+}
+/* static tables a renderer needs: per collider [type, he3, rgb3, toggle, link] (9 doubles) */
+int rpo_collider_table(const rpo_env* e, double* out) {
+  const rp_model* m = &e->m;
+  for (int c = 0; c < m->n_col; c++) {
+    double* o = out + 9 * c;
+    o[0] = m->col_type[c]; for (int k = 0; k < 3; k++) { o[1 + k] = m->col_he[c][k]; o[4 + k] = m->col_rgb[c][k]; }
+    o[7] = m->col_toggle[c]; o[8] = m->col_link[c];
+  }
+  return m->n_col;
+}
 
 int rpo_box_box(const double* ca, const double* Ra, const double* ha, const double* cb, const double* Rb, const double* hb,
                 double margin, double* out) {

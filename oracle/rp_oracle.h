@@ -94,6 +94,9 @@ double rpo_rng_uniform(unsigned long long seed, unsigned env_index, unsigned cou
 #ifdef __cplusplus
 }
 #endif
+int rpo_collider_poses(rpo_env* e, double* out12_per_collider);      /* world R (row-major) and p of every collider, returns the count */
+int rpo_collider_table(const rpo_env* e, double* out9_per_collider); /* type, he3, rgb3, toggle, link */
+
 /* bench.py's cpu_baseline: n_envs envs over n_threads threads (static partition), n_steps steps each of actions [n_envs][n_steps][action_dim];
  * returns wall seconds of the stepping phase (resets excluded).  margin < 0 keeps the default. */
 double rpo_bench_rollout(int kind, unsigned long long seed, int n_envs, int n_steps, int action_dim, const double* actions, int n_threads, double margin);

@@ -60,6 +60,11 @@ class RpOut(C.Structure):
                 ('pack', C.c_void_p)]
 
 
+class RpCamera(C.Structure):
+    _fields_ = [('eye', C.c_float * 3), ('target', C.c_float * 3), ('up', C.c_float * 3), ('fov_deg', C.c_float), ('aspect', C.c_float),
+                ('mode', C.c_int32)]
+
+
 class RpTimers(C.Structure):
     _fields_ = [('last_step_ms', C.c_float), ('last_reset_ms', C.c_float), ('steps', C.c_uint64), ('steps_timed', C.c_uint32),
                 ('avg_step_ms', C.c_float), ('avg_action_ms', C.c_float), ('avg_prep_ms', C.c_float), ('avg_solve_ms', C.c_float),
@@ -68,7 +73,7 @@ class RpTimers(C.Structure):
 
 EXPORTS = ['rp_create', 'rp_destroy', 'rp_get_dims', 'rp_reset', 'rp_reset_to', 'rp_reset_goal', 'rp_step', 'rp_calc_state',
            'rp_compute_reward', 'rp_state_bytes', 'rp_get_state', 'rp_set_state', 'rp_get_timers', 'rp_enable_timers',
-           'rp_last_error', 'rp_version']
+           'rp_last_error', 'rp_version', 'rp_default_camera', 'rp_camera_from_yaw_pitch_roll', 'rp_render', 'rp_ray_test']
 # include/rp_playroom_debug.h: test / tuning hooks
 DEBUG_EXPORTS = ['rp_set_fused', 'rp_set_groups', 'rp_set_debug_flags', 'rp_debug_substep', 'rp_debug_row_counts', 'rp_debug_reset_rounds']
 
@@ -112,6 +117,10 @@ def load(wide=False):
     lib.rp_last_error.argtypes = [vp]
     lib.rp_last_error.restype = C.c_char_p
     lib.rp_version.restype = C.c_char_p
+    lib.rp_default_camera.argtypes = [C.POINTER(RpCamera)]
+    lib.rp_camera_from_yaw_pitch_roll.argtypes = [C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(RpCamera)]
+    lib.rp_render.argtypes = [vp, C.POINTER(RpCamera), C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp]
+    lib.rp_ray_test.argtypes = [vp, vp, vp, C.c_int32, vp, vp, vp, vp, vp, vp]
     lib.rp_debug_substep.argtypes = [vp, C.c_int32, C.POINTER(C.c_float)]
     lib.rp_set_fused.argtypes = [vp, C.c_int32]
     lib.rp_set_groups.argtypes = [vp, C.c_int32]

@@ -9,6 +9,7 @@
 #include "generated/rp_models_gen.h"
 #include "rp_device_model.h"
 #include "rp_kernels.cuh"
+#include "rp_render.cuh"
 
 
 struct rp_sim {
@@ -39,6 +40,7 @@ struct rp_sim {
    * their env ids, per-env progress {pending, attempt, depth}, pairing tables of the scratch range */
   float* rs_state; int* rs_idx; int4* rs_meta; int* rs_count; int* rs_sort_cnt; int* rs_sort_slot; int* rs_pair; int* rs_count_host;
   int reset_rounds;        /* rounds the latest rp_reset took (rp_debug) */
+  float* rc_tab; int* rc_cnt; float* rc_ee; int rc_cap;      /* rp_render / rp_ray_test: collider poses of rc_cap envs (allocated on first use) */
   rp_timers timers;
   char err[256];
 };
@@ -88,6 +90,7 @@ const char* rp_version(void) { return "rp_playroom 0.2 (gfx950)"; }
 static void destroy_handle(rp_sim* h) {        /* frees whatever a (possibly partial) handle owns; hipFree(nullptr) etc. are no-ops */
   if (!h) return;
   hipFree(h->dev_model); hipFree(h->state); hipFree(h->ws); hipFree(h->dbg); hipFree(h->sort_cnt); hipFree(h->sort_slot); hipFree(h->pair_env); hipFree(h->member[0]); hipFree(h->member[1]);
+  hipFree(h->rc_tab); hipFree(h->rc_cnt); hipFree(h->rc_ee);
   hipFree(h->rs_state); hipFree(h->rs_idx); hipFree(h->rs_meta); hipFree(h->rs_count); hipFree(h->rs_sort_cnt); hipFree(h->rs_sort_slot); hipFree(h->rs_pair);
   if (h->rs_count_host) hipHostFree(h->rs_count_host);
   if (h->ev0) hipEventDestroy(h->ev0);
@@ -457,6 +460,81 @@ int rp_set_fused(rp_handle h, int32_t fused) {
   h->fused = fused;
   return RP_OK;
 }
+static int rc_reserve(rp_handle h, int num) {
+  if (num <= h->rc_cap) return RP_OK;
+  hipFree(h->rc_tab); hipFree(h->rc_cnt); hipFree(h->rc_ee);
+  h->rc_tab = nullptr; h->rc_cnt = nullptr; h->rc_ee = nullptr; h->rc_cap = 0;
+  HIPCHK(h, hipMalloc((void**)&h->rc_tab, (size_t)num * RC_MAX * RC_STRIDE * sizeof(float)));
+  HIPCHK(h, hipMalloc((void**)&h->rc_cnt, (size_t)num * sizeof(int)));
+  HIPCHK(h, hipMalloc((void**)&h->rc_ee, (size_t)num * 12 * sizeof(float)));
+  h->rc_cap = num;
+  return RP_OK;
+}
+
+int rp_camera_from_yaw_pitch_roll(const float target[3], float distance, float yaw_deg, float pitch_deg, float roll_deg, rp_camera* cam) {
+  if (!target || !cam) return RP_ERR_ARG;
+  /* b3ComputeViewMatrixFromYawPitchRoll, upAxis 2: eye = target + R (0, -distance, 0), up = R (0, 0, 1), R = Rz(yaw) Ry(roll) Rx(pitch) */
+  const double d2r = 0.01745329251994329547, y = yaw_deg * d2r, p = pitch_deg * d2r, r = roll_deg * d2r;
+  const double cy = cos(y), sy = sin(y), cp = cos(p), sp = sin(p), cr = cos(r), sr = sin(r);
+  const double R[9] = {cy * cr, cy * sr * sp - sy * cp, cy * sr * cp + sy * sp, sy * cr, sy * sr * sp + cy * cp, sy * sr * cp - cy * sp, -sr, cr * sp, cr * cp};
+  memset(cam, 0, sizeof(*cam));
+  for (int k = 0; k < 3; k++) { cam->target[k] = target[k]; cam->eye[k] = target[k] + (float)(R[3 * k + 1] * -distance); cam->up[k] = (float)R[3 * k + 2]; }
+  cam->fov_deg = 50.f; cam->aspect = 1.f; cam->mode = 0;
+  return RP_OK;
+}
+int rp_default_camera(rp_camera* cam) {
+  const float target[3] = {0.f, 0.25f, 0.f};
+  return rp_camera_from_yaw_pitch_roll(target, 1.3f, -30.f, -30.f, 0.f, cam);
+}
+
+static RpCamera device_camera(const rp_camera* c) {
+  RpCamera d; memset(&d, 0, sizeof(d));
+  double f[3], u[3], s[3], n = 0;
+  for (int k = 0; k < 3; k++) { f[k] = c->target[k] - c->eye[k]; n += f[k] * f[k]; }
+  n = sqrt(n > 0 ? n : 1);
+  for (int k = 0; k < 3; k++) f[k] /= n;
+  s[0] = f[1] * c->up[2] - f[2] * c->up[1]; s[1] = f[2] * c->up[0] - f[0] * c->up[2]; s[2] = f[0] * c->up[1] - f[1] * c->up[0];
+  n = sqrt(s[0] * s[0] + s[1] * s[1] + s[2] * s[2]); n = n > 0 ? n : 1;
+  for (int k = 0; k < 3; k++) s[k] /= n;
+  u[0] = s[1] * f[2] - s[2] * f[1]; u[1] = s[2] * f[0] - s[0] * f[2]; u[2] = s[0] * f[1] - s[1] * f[0];
+  for (int k = 0; k < 3; k++) { d.eye[k] = c->eye[k]; d.fwd[k] = (float)f[k]; d.right[k] = (float)s[k]; d.up[k] = (float)u[k]; }
+  d.tan_half_fov = (float)tan(0.5 * c->fov_deg * 0.01745329251994329547); d.aspect = c->aspect; d.mode = c->mode;
+  return d;
+}
+
+int rp_render(rp_handle h, const rp_camera* cam, int32_t width, int32_t height, int32_t first_env, int32_t num_envs, uint8_t* rgb,
+              const float* sub_goal, void* stream) {
+  if (!h || !rgb || width <= 0 || height <= 0 || width > 4096 || height > 4096 || first_env < 0 || num_envs <= 0 || first_env + num_envs > h->cfg.num_envs) {
+    if (h) snprintf(h->err, 256, "rp_render: bad argument"); return RP_ERR_ARG;
+  }
+  DevGuard guard(h->cfg.device);
+  rp_camera def;
+  if (!cam) { rp_default_camera(&def); cam = &def; }
+  if (cam->mode < 0 || cam->mode > 1 || !(cam->fov_deg > 0.f && cam->fov_deg < 180.f) || !(cam->aspect > 0.f)) { snprintf(h->err, 256, "rp_render: bad camera"); return RP_ERR_ARG; }
+  int rc = rc_reserve(h, num_envs);
+  if (rc != RP_OK) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_collider_poses, dim3(num_envs), dim3(64), 0, s, h->dev_model, h->state, first_env, num_envs, h->rc_tab, h->rc_cnt, sub_goal, h->rc_ee);
+  const int tiles = (width * height + 255) / 256;
+  hipLaunchKernelGGL(k_render, dim3((unsigned)num_envs * tiles), dim3(256), 0, s, h->rc_tab, h->rc_cnt, num_envs, device_camera(cam), h->rc_ee, width, height, rgb);
+  HIPCHK(h, hipGetLastError());
+  return RP_OK;
+}
+
+int rp_ray_test(rp_handle h, const float* from, const float* to, int32_t k, float* hit_fraction, int32_t* collider, int32_t* link,
+                float* hit_position, float* hit_normal, void* stream) {
+  if (!h || !from || !to || k <= 0) { if (h) snprintf(h->err, 256, "rp_ray_test: bad argument"); return RP_ERR_ARG; }
+  DevGuard guard(h->cfg.device);
+  const int N = h->cfg.num_envs;
+  int rc = rc_reserve(h, N);
+  if (rc != RP_OK) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_collider_poses, dim3(N), dim3(64), 0, s, h->dev_model, h->state, 0, N, h->rc_tab, h->rc_cnt, (const float*)nullptr, (float*)nullptr);
+  hipLaunchKernelGGL(k_ray_test, dim3(N), dim3(64), 0, s, h->rc_tab, h->rc_cnt, N, k, from, to, hit_fraction, collider, link, hit_position, hit_normal);
+  HIPCHK(h, hipGetLastError());
+  return RP_OK;
+}
+
 int rp_get_timers(rp_handle h, rp_timers* t) {
   if (!h || !t) return RP_ERR_ARG;
   DevGuard guard(h->cfg.device);

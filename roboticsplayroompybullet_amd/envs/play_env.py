@@ -123,6 +123,7 @@ class playEnv:
             raise NotImplementedError('%s is registered with another num_objects / use_orientation / return_velocity / play / arm_type; '
                                       'these kwargs cannot be overridden (the id fixes the baked scene and the observation layout)' % self.ENV_ID)
         self.instance = _InstanceShim(self)
+        self._vec.record_images = self.instance.record_images = getattr(self, '_record_images', False)
 
     def reset(self, o=None, vr=None):
         if not self.physics_client_active:
@@ -142,7 +143,11 @@ class playEnv:
         if mode == 'human':
             self.render_scene = True
             return np.array([])
-        return None       # 'rgb_array' / 'playback' only set a flag in the reference; img stays None here
+        if mode in ('rgb_array', 'playback'):      # environments.py:200-203: from now on calc_state fills obs['img']
+            self._record_images = True
+            if self._vec is not None:
+                self._vec.record_images = True
+                self.instance.record_images = True
 
     def step(self, action):
         import torch
@@ -170,10 +175,27 @@ class playEnv:
         return float(np.linalg.norm(np.asarray(achieved_goal) - np.asarray(desired_goal)))
 
     def visualise_sub_goal(self, sub_goal, sub_goal_state='full_positional_state'):
-        raise NotImplementedError('sub-goal visualisation is GUI-only (SURVEY.md §2.1, out of scope)')
+        """environments.py:606-690: draw a sub-goal into the images as half-transparent ghosts.  'achieved_goal' and the object part of
+        'full_positional_state' (objects, and for the play ids drawer / door / button / dial) are drawn; the ghost ARM of
+        'full_positional_state' / 'controllable_achieved_goal' is not (the reference has one for the Panda only and raises for the UR5)."""
+        import torch
+        if self._vec is None:
+            raise RuntimeError('visualise_sub_goal before the first reset(): the physics client is not active yet')
+        g = np.asarray(sub_goal, dtype=np.float32)
+        if sub_goal_state == 'controllable_achieved_goal':
+            raise NotImplementedError('the ghost arm is not drawn; only the object / fixture part of a sub-goal is visualised')
+        if sub_goal_state == 'full_positional_state':
+            g = g[(8 if self.use_orientation else 4):]
+        elif sub_goal_state != 'achieved_goal':
+            raise ValueError(sub_goal_state)
+        if self.num_objects == 0:
+            raise NotImplementedError('this id has no objects: its sub-goal is the arm itself, which is not drawn')
+        assert g.shape == (self._vec.dims['achieved_goal'],), g.shape
+        self._vec.sub_goal = torch.as_tensor(g)[None]
 
     def delete_sub_goal(self):
-        pass
+        if self._vec is not None:
+            self._vec.sub_goal = None
 
     def close(self):
         if self._vec is not None:
@@ -187,7 +209,7 @@ class playEnv:
             out[k] = o[k][0].cpu().numpy().astype(np.float32)
         out['joints'] = [float(v) for v in o['joints'][0].cpu().numpy()]
         out['velocity'] = o['velocity'][0].cpu().numpy().astype(np.float64)
-        out['img'] = None
+        out['img'] = None if o.get('img') is None else o['img'][0].cpu().numpy()      # [200, 200, 3] uint8 (environments.py:841-845)
         out['observation'] = o['observation'][0].cpu().numpy().astype(np.float64)
         out['gripper_proprioception'] = int(o['gripper_proprioception'][0])
         return out

@@ -96,13 +96,16 @@ class VecPlayEnv:
         self.action_type = at
         self.action_high = torch.tensor(hi, dtype=torch.float32, device=dev)
         self._max_episode_steps = None if env_id.startswith('UR5Play') else 250
+        self.record_images = False          # instance.record_images (environments.py:201, 203)
+        self.sub_goal = None                # [N, dims.achieved_goal] ghosts drawn into img (visualise_sub_goal)
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def _obs(self):
         o = {k: self.buf[k] for k in OBS_KEYS}
-        o['img'] = None
+        # environments.py:841-845: img only while record_images is set (render('rgb_array')); all envs, [N, 200, 200, 3] uint8
+        o['img'] = self.render('rgb_array', sub_goal=self.sub_goal) if self.record_images else None
         o['gripper_proprioception'] = self.buf['gripper_proprioception']
         return o
 
@@ -175,8 +178,50 @@ class VecPlayEnv:
         is_success (float)"""
         return self.buf['pack']
 
-    def render(self, mode='human'):
-        return None       # rendering is out of scope (SURVEY.md §2.1); kept for call compatibility
+    def camera(self, target=(0.0, 0.25, 0.0), distance=1.3, yaw=-30.0, pitch=-30.0, roll=0.0, fov=50.0, aspect=1.0, gripper=False):
+        """an rp_camera: p.computeViewMatrixFromYawPitchRoll + computeProjectionMatrixFOV (the defaults are the reference's fixed camera,
+        environments.py:21-30); gripper=True: the gripper camera of environments.py:33-49"""
+        cam = _lib.RpCamera()
+        _lib.check(self.lib, self.h, self.lib.rp_camera_from_yaw_pitch_roll((C.c_float * 3)(*[float(v) for v in target]), float(distance), float(yaw),
+                                                                             float(pitch), float(roll), C.byref(cam)), 'rp_camera_from_yaw_pitch_roll')
+        cam.fov_deg, cam.aspect, cam.mode = float(fov), float(aspect), 1 if gripper else 0
+        return cam
+
+    def render(self, mode='rgb_array', width=200, height=200, envs=None, camera=None, sub_goal=None):
+        """obs['img'] of the reference (environments.py:841-845: getCameraImage(200, 200, ...)[2][:, :, :3]) for envs [lo, hi) (default: all):
+        uint8 [n, height, width, 3] on the device.  sub_goal [n, dims.achieved_goal]: draw the sub-goal's ghosts
+        (visualise_sub_goal, environments.py:606-690).  mode 'human' (a GUI window) does not exist here and returns None."""
+        if mode == 'human':
+            return None
+        lo, hi = (0, self.num_envs) if envs is None else (int(envs[0]), int(envs[1]))
+        n = hi - lo
+        img = torch.empty((n, int(height), int(width), 3), dtype=torch.uint8, device=self.device)
+        sg = None
+        if sub_goal is not None:
+            sub_goal = sub_goal.to(device=self.device, dtype=torch.float32).contiguous()
+            assert sub_goal.shape == (n, self.dims['achieved_goal']), sub_goal.shape
+            sg = C.c_void_p(sub_goal.data_ptr())
+        _lib.check(self.lib, self.h, self.lib.rp_render(self.h, C.byref(camera) if camera is not None else None, int(width), int(height), lo, n,
+                                                        C.c_void_p(img.data_ptr()), sg, self._stream()), 'rp_render')
+        return img
+
+    def ray_test(self, ray_from, ray_to):
+        """bullet_client.rayTest for k rays per env: ray_from / ray_to [N, k, 3] (world).  Returns dict(hit_fraction [N, k] (1 = miss),
+        collider [N, k] (-1 = miss), link [N, k] (Bullet link index of an arm collider, else -1), hit_position, hit_normal [N, k, 3])"""
+        f = ray_from.to(device=self.device, dtype=torch.float32).contiguous()
+        t = ray_to.to(device=self.device, dtype=torch.float32).contiguous()
+        assert f.shape == t.shape and f.dim() == 3 and f.shape[0] == self.num_envs and f.shape[2] == 3, f.shape
+        k = f.shape[1]
+        out = {'hit_fraction': torch.empty((self.num_envs, k), dtype=torch.float32, device=self.device),
+               'collider': torch.empty((self.num_envs, k), dtype=torch.int32, device=self.device),
+               'link': torch.empty((self.num_envs, k), dtype=torch.int32, device=self.device),
+               'hit_position': torch.empty((self.num_envs, k, 3), dtype=torch.float32, device=self.device),
+               'hit_normal': torch.empty((self.num_envs, k, 3), dtype=torch.float32, device=self.device)}
+        _lib.check(self.lib, self.h, self.lib.rp_ray_test(self.h, C.c_void_p(f.data_ptr()), C.c_void_p(t.data_ptr()), k, C.c_void_p(out['hit_fraction'].data_ptr()),
+                                                          C.c_void_p(out['collider'].data_ptr()), C.c_void_p(out['link'].data_ptr()),
+                                                          C.c_void_p(out['hit_position'].data_ptr()), C.c_void_p(out['hit_normal'].data_ptr()), self._stream()),
+                   'rp_ray_test')
+        return out
 
     def get_state(self):
         n = self.lib.rp_state_bytes(self.h) // 4

@@ -371,7 +371,8 @@ def test_play_family_action_types(gid):
     b.set_fused(1)
     oa = a.reset(); b.reset()
     oracles = [OracleEnv(gid, seed=13, env_index=e, f32=True) for e in range(n)]
-    for o in oracles:
+    oracles64 = [OracleEnv(gid, seed=13, env_index=e) for e in range(n)]
+    for o in oracles + oracles64:
         o.reset()
     acts = family_actions(gid, steps, n, 3)
     assert acts.shape[-1] == a.dims['action'] == oracles[0].n_action
@@ -385,7 +386,10 @@ def test_play_family_action_types(gid):
             # EE pose and gripper to 5e-4; the block (pushed around by the arm in some envs: contact-sensitive) to 3e-3
             got = oa['obs_quat'][e].cpu().numpy()
             np.testing.assert_allclose(got[:8], oo['obs_quat'][:8], atol=5e-4, rtol=0, err_msg='step %d env %d' % (t, e))
-            np.testing.assert_allclose(got[8:], oo['obs_quat'][8:], atol=3e-3, rtol=0, err_msg='step %d env %d' % (t, e))
+            # (where the fp32 and fp64 CPU oracles themselves drift apart - a block knocked off the table and tumbling - three times their gap)
+            o64 = oracles64[e].step(acts[t, e])[0]['obs_quat']
+            tol = np.maximum(3e-3, 3 * np.abs(oo['obs_quat'][8:] - o64[8:]))
+            assert (np.abs(got[8:] - oo['obs_quat'][8:]) <= tol).all(), 'step %d env %d: %s' % (t, e, np.abs(got[8:] - oo['obs_quat'][8:]))
     torch.cuda.synchronize()
     assert torch.equal(a.get_state(), b.get_state())
     assert torch.equal(ia['target_poses'], ib['target_poses'])

@@ -136,5 +136,5 @@ def test_out_of_scope_surface_fails_loudly():
     with pytest.raises(NotImplementedError):
         envs.playEnv(action_type='velocity')          # not one of the six action types of environments.py:88-113
     env = envs.UR5Reach()
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError, match='before the first reset'):
         env.visualise_sub_goal(None)
