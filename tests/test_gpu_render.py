@@ -1,0 +1,230 @@
+"""obs['img'] (environments.py:21-30, 841-845), sub-goal ghosts (environments.py:606-690), the gripper camera (environments.py:33-49) and
+batched rayTest (environments.py:720-743) on the MI355X against a numpy restatement of the same ray casts over the oracle's collider
+poses.  Run with -m gpu."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+
+pytestmark = pytest.mark.gpu
+U = 'UR5PlayAbsRPY1Obj-v0'
+LIGHT = np.array([1.0, -2.0, 3.0]) / np.sqrt(14.0)
+BACKGROUND = np.array([0.82, 0.88, 0.96])
+
+
+def cast(R, p, tab, o, d, tmax):
+    """nearest hit of rays o + t d (t in [0, tmax]) against the colliders: (t [n], collider [n], normal [n, 3]); numpy float64"""
+    n = o.shape[0]
+    best = np.full(n, np.inf)
+    who = np.full(n, -1)
+    nrm = np.zeros((n, 3))
+    for c in range(len(tab)):
+        he = tab[c, 1:4]
+        if tab[c, 0] == 0:
+            ol = (o - p[c]) @ R[c]
+            dl = d @ R[c]
+            inside = (np.abs(ol) <= he).all(axis=1)
+            with np.errstate(divide='ignore', invalid='ignore'):
+                t1 = (-he - ol) / dl
+                t2 = (he - ol) / dl
+            lo, hi = np.minimum(t1, t2), np.maximum(t1, t2)
+            par = np.abs(dl) < 1e-12
+            lo = np.where(par, -np.inf, lo)
+            hi = np.where(par, np.inf, hi)
+            miss_par = (par & (np.abs(ol) > he)).any(axis=1)
+            tmin = np.maximum(lo.max(axis=1), 0.0)
+            tm = np.minimum(hi.min(axis=1), tmax)
+            hit = (~inside) & (~miss_par) & (tmin <= tm)
+            axis = np.where(lo.max(axis=1) > 0, lo.argmax(axis=1), 0)
+            sgn = np.where(np.take_along_axis(t1, axis[:, None], 1)[:, 0] > np.take_along_axis(t2, axis[:, None], 1)[:, 0], 1.0, -1.0)
+            nn = R[c][:, axis].T * sgn[:, None]
+            t = tmin
+        else:
+            oc = o - p[c]
+            a = (d * d).sum(1)
+            b = 2 * (oc * d).sum(1)
+            cc = (oc * oc).sum(1) - he[0] ** 2
+            disc = b * b - 4 * a * cc
+            with np.errstate(invalid='ignore'):
+                t = (-b - np.sqrt(np.maximum(disc, 0))) / (2 * a)
+            hit = (cc >= 0) & (disc >= 0) & (t >= 0) & (t <= tmax)
+            nn = (oc + d * t[:, None]) / he[0]
+        better = hit & (t < best)
+        best = np.where(better, t, best)
+        who = np.where(better, c, who)
+        nrm = np.where(better[:, None], nn, nrm)
+    return best, who, nrm
+
+
+def reference_image(orc, cam_eye, cam_target, cam_up, fov, w, h, button_q, dial01):
+    R, p, tab = orc.colliders()
+    f = cam_target - cam_eye
+    f /= np.linalg.norm(f)
+    s = np.cross(f, cam_up)
+    s /= np.linalg.norm(s)
+    u = np.cross(s, f)
+    th = np.tan(0.5 * np.radians(fov))
+    px, py = np.meshgrid(np.arange(w), np.arange(h))
+    nx = (2 * (px.ravel() + 0.5) / w - 1) * th
+    ny = (1 - 2 * (py.ravel() + 0.5) / h) * th
+    d = f + nx[:, None] * s + ny[:, None] * u
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    o = np.tile(cam_eye, (w * h, 1))
+    t, who, nrm = cast(R, p, tab, o, d, 10.0)
+    rgb = tab[:, 4:7].copy()
+    for c in range(len(tab)):
+        if tab[c, 7] == 1:
+            rgb[c] = [1, 0, 0] if button_q < 0.025 else [1, 1, 1]
+        if tab[c, 7] == 2:
+            rgb[c] = [1, 0, 0] if dial01 < 0.5 else [1, 1, 1]
+    k = 0.45 + 0.55 * np.maximum(0, nrm @ LIGHT)
+    col = np.where((who >= 0)[:, None], rgb[np.maximum(who, 0)] * k[:, None], BACKGROUND)
+    return np.floor(np.clip(col, 0, 1) * 255 + 0.5).astype(np.uint8).reshape(h, w, 3), who.reshape(h, w)
+
+
+def default_camera():
+    y, pt = np.radians(-30.0), np.radians(-30.0)
+    # computeViewMatrixFromYawPitchRoll, upAxis 2: eye = target + Rz(yaw) Rx(pitch) (0, -d, 0), up = Rz(yaw) Rx(pitch) (0, 0, 1)
+    Rz = np.array([[np.cos(y), -np.sin(y), 0], [np.sin(y), np.cos(y), 0], [0, 0, 1]])
+    Rx = np.array([[1, 0, 0], [0, np.cos(pt), -np.sin(pt)], [0, np.sin(pt), np.cos(pt)]])
+    target = np.array([0.0, 0.25, 0.0])
+    return target + Rz @ Rx @ np.array([0, -1.3, 0]), target, Rz @ Rx @ np.array([0, 0, 1.0])
+
+
+def test_default_camera_is_the_references():
+    from roboticsplayroompybullet_amd import VecPlayEnv
+    env = VecPlayEnv(U, 1, seed=0)
+    cam = env.camera()
+    eye, target, up = default_camera()
+    np.testing.assert_allclose(list(cam.eye), eye, atol=1e-6)
+    np.testing.assert_allclose(list(cam.target), target, atol=1e-7)
+    np.testing.assert_allclose(list(cam.up), up, atol=1e-6)
+    assert abs(np.linalg.norm(eye - target) - 1.3) < 1e-12 and eye[2] == pytest.approx(0.65)       # 30 degrees above the target plane
+    assert cam.fov_deg == 50.0 and cam.aspect == 1.0 and cam.mode == 0
+
+
+def test_image_matches_the_numpy_ray_cast_and_toggles_recolour():
+    from oracle import OracleEnv
+    from roboticsplayroompybullet_amd import VecPlayEnv
+    n = 3
+    env = VecPlayEnv(U, n, seed=4)
+    obs = env.reset()
+    img = env.render('rgb_array')
+    torch.cuda.synchronize()
+    assert img.shape == (n, 200, 200, 3) and img.dtype == torch.uint8
+    eye, target, up = default_camera()
+    for e in range(n):
+        o = OracleEnv('U', seed=4, env_index=e, f32=True)
+        oo = o.reset()
+        ref, who = reference_image(o, eye, target, up, 50.0, 200, 200, oo['obs_quat'][17], oo['obs_quat'][18])
+        got = img[e].cpu().numpy()
+        close = (np.abs(got.astype(int) - ref.astype(int)) <= 1).all(axis=2)
+        assert close.mean() > 0.995, close.mean()                  # silhouette pixels may fall on the other side of an edge in fp32
+        assert (who >= 0).mean() > 0.5                             # the scene fills the view
+        assert len(np.unique(who)) > 15                            # table, cabinet, arm links, block, fixtures are all in it
+    # toggles (environments.py:469-483): at reset the button is up (q = 0.03: globe white) and the dial at 0 (dial01 = 0 < 0.5: grill red);
+    # pressing the button turns the globe red, turning the dial past 1.1 rad turns the grill white
+    s = env.get_state()
+    s[0, 50 + 1] = 0.01
+    s[0, 50 + 2] = 1.5
+    env.set_state(s)
+    img2 = env.render('rgb_array', envs=(0, 1))[0].cpu().numpy()
+    o = OracleEnv('U', seed=4, env_index=0, f32=True)
+    o.reset()
+    st = o.get_state()
+    st[2 * 12 + 26 + 1] = 0.01
+    st[2 * 12 + 26 + 2] = 1.5
+    o.set_state(st)
+    ref2, who2 = reference_image(o, eye, target, up, 50.0, 200, 200, 0.01, (1.5 % 2) / 2.2)
+    assert ((np.abs(img2.astype(int) - ref2.astype(int)) <= 1).all(axis=2)).mean() > 0.995
+    globe, grill = who2 == 45, who2 == 42
+    assert globe.sum() > 5 and grill.sum() > 5
+    before = img[0].cpu().numpy()
+    assert (before[globe][:, 1] > 100).all() and (img2[globe][:, 1] < 5).all()        # white -> red: green channel drops to 0
+    assert (before[grill][:, 1] < 5).all() and (img2[grill][:, 1] > 100).all()        # red -> white
+
+
+def test_sub_goal_ghosts_and_other_cameras():
+    from roboticsplayroompybullet_amd import VecPlayEnv
+    env = VecPlayEnv(U, 2, seed=5)
+    obs = env.reset()
+    plain = env.render('rgb_array').cpu().numpy()
+    sg = obs['achieved_goal'].clone()
+    sg[:, 0] += 0.12                 # the ghost block 12 cm to the side
+    sg[:, 7] = -0.05                 # and the ghost drawer pulled out
+    ghost = env.render('rgb_array', sub_goal=sg).cpu().numpy()
+    changed = (plain != ghost).any(axis=3)
+    assert 50 < changed[0].sum() < 8000                           # something was drawn, the picture is not a different one
+    same_goal = env.render('rgb_array', sub_goal=obs['achieved_goal']).cpu().numpy()
+    assert (same_goal != plain).any(axis=3).mean() < 0.2          # ghosts on top of their bodies change the shade of those pixels only
+    # ghosts are not obstacles: rays see the same world with or without them (rp_ray_test never takes a sub-goal)
+    wide = env.render('rgb_array', width=320, height=240, camera=env.camera(distance=2.0, yaw=20.0, pitch=-40.0, fov=60.0, aspect=320 / 240))
+    assert wide.shape == (2, 240, 320, 3)
+    grip = env.render('rgb_array', camera=env.camera(gripper=True)).cpu().numpy()
+    assert grip.shape == (2, 200, 200, 3) and len(np.unique(grip.reshape(-1, 3), axis=0)) > 3     # the gripper camera looks down at the table
+    with pytest.raises(RuntimeError, match='rp_render'):
+        env.render('rgb_array', width=0)
+
+
+def test_batched_ray_test_against_the_numpy_ray_cast():
+    from oracle import OracleEnv
+    from roboticsplayroompybullet_amd import VecPlayEnv
+    n, k = 3, 64
+    env = VecPlayEnv(U, n, seed=6)
+    env.reset()
+    rng = np.random.default_rng(0)
+    frm = np.concatenate([rng.uniform(-0.4, 0.4, (n, k, 2)), rng.uniform(0.3, 0.6, (n, k, 1))], axis=2)
+    to = np.concatenate([rng.uniform(-0.4, 0.5, (n, k, 2)), rng.uniform(-0.3, 0.0, (n, k, 1))], axis=2)
+    out = env.ray_test(torch.tensor(frm, dtype=torch.float32), torch.tensor(to, dtype=torch.float32))
+    torch.cuda.synchronize()
+    hits = 0
+    for e in range(n):
+        o = OracleEnv('U', seed=6, env_index=e, f32=True)
+        o.reset()
+        R, p, tab = o.colliders()
+        f32 = np.float32(frm[e]).astype(np.float64)
+        t32 = np.float32(to[e]).astype(np.float64)
+        t, who, nrm = cast(R, p, tab, f32, t32 - f32, 1.0)
+        got_t = out['hit_fraction'][e].cpu().numpy()
+        got_c = out['collider'][e].cpu().numpy()
+        want_t = np.where(who >= 0, t, 1.0)
+        agree = got_c == who
+        assert agree.mean() > 0.95                                 # a ray grazing an edge may go either way in fp32
+        np.testing.assert_allclose(got_t[agree], want_t[agree], atol=2e-5)
+        hp = out['hit_position'][e].cpu().numpy()
+        np.testing.assert_allclose(hp[agree & (who >= 0)], (f32 + (t32 - f32) * t[:, None])[agree & (who >= 0)], atol=3e-5)
+        np.testing.assert_allclose(out['hit_normal'][e].cpu().numpy()[agree & (who >= 0)], nrm[agree & (who >= 0)], atol=1e-4)
+        link = out['link'][e].cpu().numpy()
+        assert (link[who >= 0] == tab[who[who >= 0], 8].astype(int))[agree[who >= 0]].all()
+        hits += int((who >= 0).sum())
+    assert hits > n * k // 2
+    # a vertical ray onto the block: hit at its top face
+    blk = env.get_state()[:, 24:27].cpu().numpy()
+    f = torch.tensor(blk + [0, 0, 0.3], dtype=torch.float32)[:, None, :]
+    t = torch.tensor(blk - [0, 0, 0.1], dtype=torch.float32)[:, None, :]
+    o2 = env.ray_test(f, t)
+    assert (o2['collider'][:, 0].cpu().numpy() == 51).all()
+    np.testing.assert_allclose(o2['hit_position'][:, 0, 2].cpu().numpy(), blk[:, 2] + 0.025, atol=1e-4)
+    np.testing.assert_allclose(o2['hit_normal'][:, 0].cpu().numpy(), np.tile([0, 0, 1.0], (n, 1)), atol=1e-3)
+
+
+def test_single_env_adapter_records_images():
+    import roboticsplayroompybullet_amd as rp
+    env = rp.make(U, seed=1)
+    o = env.reset()
+    assert o['img'] is None                                      # like the reference: no image until render('rgb_array')
+    assert env.render('rgb_array') is None                       # environments.py:200-201: sets instance.record_images, returns nothing
+    o, r, d, info = env.step(np.array([0.0, 0.2, 0.15, 0, 0, 0, 0.0]))
+    assert o['img'].shape == (200, 200, 3) and o['img'].dtype == np.uint8 and len(np.unique(o['img'].reshape(-1, 3), axis=0)) > 10
+    plain = o['img']
+    sg = o['achieved_goal'].copy()
+    sg[1] -= 0.15
+    env.visualise_sub_goal(sg, sub_goal_state='achieved_goal')
+    o2 = env.instance.calc_state()
+    assert (o2['img'] != plain).any()
+    env.delete_sub_goal()
+    o3 = env.instance.calc_state()
+    assert (o3['img'] == plain).all()
+    with pytest.raises(NotImplementedError):
+        env.visualise_sub_goal(o['controllable_achieved_goal'], sub_goal_state='controllable_achieved_goal')
+    env.close()
