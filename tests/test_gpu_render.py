@@ -122,9 +122,13 @@ def test_image_matches_the_numpy_ray_cast_and_toggles_recolour():
         assert close.mean() > 0.995, close.mean()                  # silhouette pixels may fall on the other side of an edge in fp32
         assert (who >= 0).mean() > 0.5                             # the scene fills the view
         assert len(np.unique(who)) > 15                            # table, cabinet, arm links, block, fixtures are all in it
-    # toggles (environments.py:469-483): at reset the button is up (q = 0.03: globe white) and the dial at 0 (dial01 = 0 < 0.5: grill red);
-    # pressing the button turns the globe red, turning the dial past 1.1 rad turns the grill white
+    # toggles (environments.py:469-483): with the button up (q = 0.03) the globe is white, with the dial at 0 (dial01 = 0 < 0.5) the grill is
+    # red; pressing the button (q < 0.025) turns the globe red, turning the dial past 1.1 rad turns the grill white
     s = env.get_state()
+    s[0, 50 + 1] = 0.03
+    s[0, 50 + 2] = 0.0
+    env.set_state(s)
+    before = env.render('rgb_array', envs=(0, 1))[0].cpu().numpy()
     s[0, 50 + 1] = 0.01
     s[0, 50 + 2] = 1.5
     env.set_state(s)
@@ -139,7 +143,6 @@ def test_image_matches_the_numpy_ray_cast_and_toggles_recolour():
     assert ((np.abs(img2.astype(int) - ref2.astype(int)) <= 1).all(axis=2)).mean() > 0.995
     globe, grill = who2 == 45, who2 == 42
     assert globe.sum() > 5 and grill.sum() > 5
-    before = img[0].cpu().numpy()
     assert (before[globe][:, 1] > 100).all() and (img2[globe][:, 1] < 5).all()        # white -> red: green channel drops to 0
     assert (before[grill][:, 1] < 5).all() and (img2[grill][:, 1] > 100).all()        # red -> white
 

@@ -5,7 +5,8 @@ step (oracle/rp_bullet_ref.c "mode B")?  CPU only, fp64 both.
 For every BASELINE config's env kind and two action scenarios - `random` (bench.py's distribution B) and `grasp` (drive the open gripper
 onto the block, close, lift: the contact-rich case) - N envs are reset once by mode B, both models start from that state, get the same
 200 actions, and the divergence is reported as
-    joints  max over steps and arm joints of |q_A - q_B| / max(1, |q_B|)      (north_star's "relative joint-state divergence")
+    arm     max over steps and the arm's own joints (6 UR5 / 7 Panda) of |q_A - q_B| / max(1, |q_B|)
+    joints  the same over all dofs, the gripper's auxiliary joints included (north_star's "relative joint-state divergence")
     block   max over steps of |block position A - B| in metres
 as median / 90th percentile / max over the envs.  Rows:
     A default      the shipped model: per-pair contact margins = Bullet's relative breaking thresholds
@@ -66,9 +67,10 @@ def rollout(env, kind, scenario, steps, acts, state0):
     return np.array(q), np.array(blk)
 
 
-def divergence(qa, ba, qb, bb):
+def divergence(qa, ba, qb, bb, n_main):
+    """(arm joints proper: 6 UR5 / 7 Panda, all dofs incl. the gripper's, block) - max over the rollout"""
     rel = np.abs(qa - qb) / np.maximum(1.0, np.abs(qb))
-    return float(rel.max()), float(np.linalg.norm(ba - bb, axis=1).max())
+    return float(rel[:, :n_main].max()), float(rel.max()), float(np.linalg.norm(ba - bb, axis=1).max())
 
 
 def main():
@@ -100,8 +102,8 @@ def main():
                     env = OracleEnv(kind, seed=77, env_index=e, **kw)
                     env.lib.rpo_set_goal(env.h, oracle._d(goal)[1]) if hasattr(env.lib, 'rpo_set_goal') else None
                     qa, ba = rollout(env, kind, scenario, args.steps, acts, state0)
-                    rows[name].append(divergence(qa, ba, qb, bb))
-            results['%s/%s' % (kind, scenario)] = {k: {'joints': [r[0] for r in v], 'block': [r[1] for r in v]} for k, v in rows.items()}
+                    rows[name].append(divergence(qa, ba, qb, bb, 6 if kind in ('R', 'U') else 7))
+            results['%s/%s' % (kind, scenario)] = {k: {'arm': [r[0] for r in v], 'joints': [r[1] for r in v], 'block': [r[2] for r in v]} for k, v in rows.items()}
     os.makedirs(os.path.join(REPO, 'profiles'), exist_ok=True)
     out = {'envs': args.envs, 'steps': args.steps, 'reference': 'oracle/rp_bullet_ref.c, default flags %d' % D, 'results': results}
     json.dump(out, open(os.path.join(REPO, 'profiles', '%s_model_divergence.json' % args.tag), 'w'), indent=1)
@@ -110,11 +112,11 @@ def main():
         v = np.array(v)
         return '%.1e / %.1e / %.1e' % (np.median(v), np.percentile(v, 90), v.max())
 
-    print('| config / scenario | model | joints: median / p90 / max | block [m]: median / p90 / max |')
-    print('|---|---|---|---|')
+    print('| config / scenario | model | arm joints: median / p90 / max | all dofs (with the gripper\'s): median / p90 / max | block [m]: median / p90 / max |')
+    print('|---|---|---|---|---|')
     for key, rows in results.items():
         for name, r in rows.items():
-            print('| %s | %s | %s | %s |' % (key, name, stat(r['joints']), stat(r['block'])))
+            print('| %s | %s | %s | %s | %s |' % (key, name, stat(r['arm']), stat(r['joints']), stat(r['block'])))
 
 
 if __name__ == '__main__':

@@ -1,0 +1,10 @@
+#!/bin/bash
+# GPU box: kernel trace of a short bench run, then the timeline of one step (per stream: kernel, start offset, duration, gap to the previous kernel)
+set -u
+REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$REPO/gpurun_out/trace_chain
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/t" -- python3 "$REPO/bench.py" --steps 12 --warmup 4 --no-cpu-baseline --no-extras --repeats 1 > "$OUT/bench.json" 2> "$OUT/log.txt"
+cd "$REPO"
+python3 tools/trace_chain.py "$OUT/t" | tee "$OUT/chain.txt" | tail -120
