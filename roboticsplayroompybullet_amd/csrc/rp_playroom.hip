@@ -372,33 +372,51 @@ int rp_step(rp_handle h, const float* action, const rp_out* out, void* stream) {
       member = h->member[h->member_cur];
     }
     if (G > 1) hipEventRecord(h->gfork, s);
+    /* The groups' chains are enqueued ROUND-ROBIN, one launch per group at a time: a chain is 26 dependent launches and its length (not the
+     * machine's width) sets the step time at N = 4096, so all chains have to start at once - enqueued group by group, the last group's chain
+     * started a whole group's worth of host launch time late (2.38 -> 2.1x ms per step).  Same kernels, same arguments, same order inside
+     * every stream. */
+    struct GroupCtx { hipStream_t gs; int e0, e1, ng, nab; int* gcnt[2]; } gc[RP_MAX_GROUPS];
+    const int par0 = h->sort_par;
     for (int g = 0; g < G; g++) {
-      hipStream_t gs = g == 0 ? s : h->gstream[g];      /* group 0 stays on the caller's stream: G hardware queues in use */
-      int e0 = gb.b[g], e1 = gb.b[g + 1], ng = e1 - e0;
-      if (gs != s) hipStreamWaitEvent(gs, h->gfork, 0);
-      if (ev) hipEventRecord(ev[0], gs);
+      GroupCtx& c = gc[g];
+      c.gs = g == 0 ? s : h->gstream[g];      /* group 0 stays on the caller's stream: G hardware queues in use */
+      c.e0 = gb.b[g]; c.e1 = gb.b[g + 1]; c.ng = c.e1 - c.e0; c.nab = (c.ng + 3) / 4;
       /* env pairing of this group: k_solve2 ranks its envs by load class (histogram, double-buffered), the next k_prep2
        * turns the ranks into the table the next k_solve2 reads */
-      int* gcnt[2] = {h->sort_cnt + (size_t)g * SORT_BINS, h->sort_cnt + (size_t)(RP_MAX_GROUPS + g) * SORT_BINS};
-      int par = h->sort_par;
-      if (h->sort_G == 0) hipLaunchKernelGGL(k_sort_init, dim3((max(ng, SORT_BINS) + 255) / 256), dim3(256), 0, gs, gcnt[par], h->sort_slot, e0, ng);
-      /* first substep: action kernel and first k_prep2 in one launch (k_action_prep), the motor rows rebuilt by the k_solve2 after
-       * it (flag bit 1); with per-launch timers on, the kernels stay apart so that every event pair brackets one of them */
-      const int nab = (ng + 3) / 4;
-      if (ev) TIMED(hipLaunchKernelGGL(k_action, dim3(nab), dim3(64), 0, gs, h->dev_model, h->state, action, op.target_poses, e0, e1, member));
-      for (int sub = 0; sub < K_NSUB; sub++) {
-        const bool merged = !ev && sub == 0;
+      c.gcnt[0] = h->sort_cnt + (size_t)g * SORT_BINS; c.gcnt[1] = h->sort_cnt + (size_t)(RP_MAX_GROUPS + g) * SORT_BINS;
+      if (c.gs != s) hipStreamWaitEvent(c.gs, h->gfork, 0);
+      if (ev) hipEventRecord(ev[0], c.gs);
+      if (h->sort_G == 0) hipLaunchKernelGGL(k_sort_init, dim3((max(c.ng, SORT_BINS) + 255) / 256), dim3(256), 0, c.gs, c.gcnt[par0], h->sort_slot, c.e0, c.ng);
+    }
+    /* first substep: action kernel and first k_prep2 in one launch (k_action_prep), the motor rows rebuilt by the k_solve2 after
+     * it (flag bit 1); with per-launch timers on (one group), the kernels stay apart so that every event pair brackets one of them */
+    if (ev) { hipStream_t gs = gc[0].gs; TIMED(hipLaunchKernelGGL(k_action, dim3(gc[0].nab), dim3(64), 0, gs, h->dev_model, h->state, action, op.target_poses, gc[0].e0, gc[0].e1, member)); }
+    int par = par0;
+    for (int sub = 0; sub < K_NSUB; sub++) {
+      const bool merged = !ev && sub == 0;
+      for (int g = 0; g < G; g++) {
+        const GroupCtx& c = gc[g];
+        hipStream_t gs = c.gs;
         if (merged)
-          hipLaunchKernelGGL(k_action_prep, dim3(nab + ng), dim3(64), 0, gs, h->dev_model, h->state, h->ws, e0, e1, gcnt[par], gcnt[par ^ 1], h->sort_slot,
-                             h->pair_env, member, action, op.target_poses, nab);
+          hipLaunchKernelGGL(k_action_prep, dim3(c.nab + c.ng), dim3(64), 0, gs, h->dev_model, h->state, h->ws, c.e0, c.e1, c.gcnt[par], c.gcnt[par ^ 1], h->sort_slot,
+                             h->pair_env, member, action, op.target_poses, c.nab);
         else
-          TIMED(hipLaunchKernelGGL(k_prep2, dim3(ng), dim3(64), 0, gs, h->dev_model, h->state, h->ws, e0, e1, gcnt[par], gcnt[par ^ 1], h->sort_slot, h->pair_env, member));
-        TIMED(hipLaunchKernelGGL(k_solve2, dim3((ng + 1) / 2), dim3(64), 0, gs, h->dev_model, h->state, h->ws, e0, e1, h->pair_env, gcnt[par ^ 1], h->sort_slot,
-                                 h->debug_flags | (merged ? 2 : 0)));
-        par ^= 1;
+          TIMED(hipLaunchKernelGGL(k_prep2, dim3(c.ng), dim3(64), 0, gs, h->dev_model, h->state, h->ws, c.e0, c.e1, c.gcnt[par], c.gcnt[par ^ 1], h->sort_slot, h->pair_env, member));
       }
-      if (g == G - 1) { h->sort_par = par; h->sort_G = G; h->gb = gb; }
-      TIMED(hipLaunchKernelGGL(k_calc_state, dim3(ng), dim3(64), 0, gs, h->dev_model, h->state, op, e0, e1, member));
+      for (int g = 0; g < G; g++) {
+        const GroupCtx& c = gc[g];
+        hipStream_t gs = c.gs;
+        TIMED(hipLaunchKernelGGL(k_solve2, dim3((c.ng + 1) / 2), dim3(64), 0, gs, h->dev_model, h->state, h->ws, c.e0, c.e1, h->pair_env, c.gcnt[par ^ 1], h->sort_slot,
+                                 h->debug_flags | (merged ? 2 : 0)));
+      }
+      par ^= 1;
+    }
+    h->sort_par = par; h->sort_G = G; h->gb = gb;
+    for (int g = 0; g < G; g++) {
+      const GroupCtx& c = gc[g];
+      hipStream_t gs = c.gs;
+      TIMED(hipLaunchKernelGGL(k_calc_state, dim3(c.ng), dim3(64), 0, gs, h->dev_model, h->state, op, c.e0, c.e1, member));
       if (ev) hipEventRecord(ev[1], gs);
       if (gs != s) hipEventRecord(h->gjoin[g], gs);
     }

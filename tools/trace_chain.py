@@ -10,7 +10,8 @@ ks.sort()
 starts = [i for i, k in enumerate(ks) if k[2].startswith('k_member')]
 if len(starts) < 3:
     print('no steps found'); sys.exit(0)
-a, b = starts[-3], starts[-2]
+k = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+a, b = starts[-k], starts[-k + 1]
 step = ks[a:b]
 t0 = step[0][0]
 print('step: %d kernels, %.3f ms from first start to last end' % (len(step), (max(k[1] for k in step) - t0) / 1e6))
