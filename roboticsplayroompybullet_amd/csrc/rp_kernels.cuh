@@ -115,7 +115,7 @@ struct __align__(16) EnvLds {
 __device__ unsigned long long g_clk[32 * 4096];
 #define CLK_MARK(i) if (lane == 0) { g_clk[8 * blockIdx.x + (i)] = __builtin_readcyclecounter(); }
 #if RP_CLOCKS == 2
-#define PCLK(i) if (lane == 0) { g_clk[32 * blockIdx.x + (i)] = (i) >= 6 && (i) < 8 ? wall_clock64() : __builtin_readcyclecounter(); }
+#define PCLK(i) if (lane == 0) { g_clk[32 * (blockIdx.x & 4095) + (i)] = (i) >= 6 && (i) < 8 ? wall_clock64() : __builtin_readcyclecounter(); }
 #define CLK_MARK2(i)
 #else
 #define PCLK(i)
@@ -246,7 +246,7 @@ __device__ __forceinline__ Xf joint_compose(const DevModel* m, const Xf& P, int 
  * starts with link j's transform relative to its parent link (joint frame times joint motion; root links composed with
  * the base), then every round composes it with its current ancestor's transform and jumps to that ancestor's ancestor -
  * ceil(log2(depth)) rounds of one 3x4 composition instead of a walk of up to 12 joints per link. */
-__device__ void fk_bodies(const DevModel* m, EnvLds& L, int lane) {
+__device__ __forceinline__ void fk_bodies(const DevModel* m, EnvLds& L, int lane) {
   float* T = L.u.c.cand;                     /* two buffers of 12 links x (R row-major, p), then 2 x 12 ancestor indices; dead space until collide() */
   int* P = (int*)(T + 2 * 12 * RP_MAX_ARM);
   const int n = m->n_arm;
@@ -297,7 +297,7 @@ __device__ void fk_bodies(const DevModel* m, EnvLds& L, int lane) {
 }
 
 /* joint motion subspaces about the reference point O (the EE body's origin), world axes */
-__device__ void joint_subspaces(const DevModel* m, EnvLds& L, int lane) {
+__device__ __forceinline__ void joint_subspaces(const DevModel* m, EnvLds& L, int lane) {
   if (lane == 0) st3(L.O, ld3(&L.xp[3 * m->site_body[RP_SITE_EE]]));
   __syncthreads();
   if (lane < m->n_arm) {
@@ -320,7 +320,7 @@ __device__ __forceinline__ Xf collider_xf(const DevModel* m, const EnvLds& L, in
   return x;
 }
 
-__device__ void collider_aabbs(const DevModel* m, EnvLds& L, int lane) {
+__device__ __forceinline__ void collider_aabbs(const DevModel* m, EnvLds& L, int lane) {
   if (lane < m->n_col) {
     Xf x = collider_xf(m, L, lane);
     V3 he = ld3(m->col_he[lane]);
@@ -381,7 +381,7 @@ __device__ __attribute__((noinline)) int sphere_box(V3 cs, float r, V3 cb, const
 __device__ __forceinline__ V3 pick3(int i, V3 a, V3 b, V3 c) { return i == 0 ? a : (i == 1 ? b : c); }
 __device__ __forceinline__ float pick1(int i, float a, float b, float c) { return i == 0 ? a : (i == 1 ? b : c); }
 
-__device__ void narrowphase_coop(const DevModel* m, EnvLds& L, int lane, int nact) {
+__device__ __forceinline__ void narrowphase_coop(const DevModel* m, EnvLds& L, int lane, int nact) {
   const int g = lane >> 3, s = lane & 7;
   float* scr = &L.srow[NPG_SCRATCH * g];
   float* sv = scr;
@@ -566,7 +566,7 @@ __device__ void narrowphase_coop(const DevModel* m, EnvLds& L, int lane, int nac
 }
 
 /* btPersistentManifold::sortCachedPoints on points stored as 8-float records (p3 n3 dist pad) */
-__device__ int manifold_replace_index(const float* c4, const float* pt) {
+__device__ __forceinline__ int manifold_replace_index(const float* c4, const float* pt) {
   int deepest = -1; float maxpen = pt[6];
   for (int i = 0; i < 4; i++) if (c4[8 * i + 6] < maxpen - K_TIE_EPS) { deepest = i; maxpen = c4[8 * i + 6]; }
   float res[4] = {0, 0, 0, 0};
@@ -581,7 +581,7 @@ __device__ int manifold_replace_index(const float* c4, const float* pt) {
 }
 
 /* broadphase + narrowphase + manifolds -> L.con*, returns ncon (wave-uniform) */
-__device__ int collide(const DevModel* m, EnvLds& L, int lane) {
+__device__ __forceinline__ int collide(const DevModel* m, EnvLds& L, int lane) {
   /* 1. AABB sweep over the baked candidate pairs, 64 per pass; keep the first MAXACT overlapping, in order */
   int nact = 0;
   const int npair = m->n_pair;
@@ -618,7 +618,7 @@ __device__ int collide(const DevModel* m, EnvLds& L, int lane) {
   __syncthreads();
   PCLK(8)
 #if defined(RP_CLOCKS) && RP_CLOCKS == 2
-  if (lane == 0) g_clk[32 * blockIdx.x + 12] = nact;
+  if (lane == 0) g_clk[32 * (blockIdx.x & 4095) + 12] = nact;
 #endif
   /* 2. narrowphase: eight lanes per active pair (scratch in srow | rowS | rowT, dead until the rows are built) */
   static_assert(offsetof(EnvLds, rowS) == offsetof(EnvLds, srow) + sizeof(float) * MAXSMALL * 8 &&
@@ -695,7 +695,7 @@ __device__ int collide(const DevModel* m, EnvLds& L, int lane) {
 }
 
 /* ------------------------------------------------------------------ arm dynamics: CRBA mass matrix, RNEA bias, inverse */
-__device__ void arm_dynamics(const DevModel* m, EnvLds& L, int lane) {
+__device__ __forceinline__ void arm_dynamics(const DevModel* m, EnvLds& L, int lane) {
   int n = m->n_arm;
   V3 O = ld3(L.O);
   if (lane < n) {      /* own spatial inertia about O: (m, h = m c, Ibar = R Ic R^T - m [c]x^2) */
@@ -805,7 +805,7 @@ __device__ void arm_dynamics(const DevModel* m, EnvLds& L, int lane) {
 }
 
 /* unconstrained velocities v* = v + dt * a for every dof (lane = dof) */
-__device__ void unconstrained_velocities(const DevModel* m, EnvLds& L, int lane) {
+__device__ __forceinline__ void unconstrained_velocities(const DevModel* m, EnvLds& L, int lane) {
   int n = m->n_arm;
   float vs = 0.f;
   if (lane < n) {
@@ -872,7 +872,7 @@ __device__ __forceinline__ void put_srow(EnvLds& L, int r, int type, int dofA, f
 }
 
 /* returns the number of small rows (wave-uniform) */
-__device__ int build_small_rows(const DevModel* m, EnvLds& L, int lane) {
+__device__ __forceinline__ int build_small_rows(const DevModel* m, EnvLds& L, int lane) {
   int n = m->n_arm, nr = 0;
   if (lane < n) {        /* arm motors (btMultiBodyJointMotor) */
     float dinv = 1.f / L.Minv[lane * 12 + lane];
@@ -929,7 +929,7 @@ __device__ int build_small_rows(const DevModel* m, EnvLds& L, int lane) {
  * entries starting at dof off1 (an empty slot has off = 64).  If the arm is involved it takes slot0 (off0 = 0).
  * Three register-light passes: (A) lane = row: Jacobian entries, the non-arm part of M^-1 J^T, partial diagonal;
  * (B) lane = (row, i): arm part B_i = sum_k Minv[i][k] J_k; (C) lane = row: diagonal, relative velocity, rhs. */
-__device__ void contact_rows(const DevModel* m, EnvLds& L, int lane, int ncon) {
+__device__ __forceinline__ void contact_rows(const DevModel* m, EnvLds& L, int lane, int ncon) {
   const int n = m->n_arm;
   const int nrows = 3 * ncon;
   V3 O = ld3(L.O);
@@ -2525,7 +2525,11 @@ __device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, floa
 #pragma unroll 1
   for (int it = 0; it < K_NITER; it++) {
     /* in-loop copies of the guards: kept in SGPRs and re-read every sweep so that they stay s_cmp + s_cbranch */
+#ifdef RP_ABL_NOCONTACT
+    int nS_it = 0, nC_it = 0, mL_it = maskL, mU_it = maskU, gr_it = gear;
+#else
     int nS_it = nS, nC_it = nC, mL_it = maskL, mU_it = maskU, gr_it = gear;
+#endif
     asm volatile("" : "+s"(nS_it), "+s"(nC_it), "+s"(mL_it), "+s"(mU_it), "+s"(gr_it));
     nS_it = __builtin_amdgcn_readfirstlane(nS_it); nC_it = __builtin_amdgcn_readfirstlane(nC_it);
     mL_it = __builtin_amdgcn_readfirstlane(mL_it); mU_it = __builtin_amdgcn_readfirstlane(mU_it);
@@ -2538,12 +2542,23 @@ __device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, floa
      * exact no-op that costs about as much as the branch that would skip it */
 #define UNIT_M(t) unit_row<(t)>(dinvX, Bm[t], dv, X0, l16);
 #define UNIT_L(i) unit_row<(i)>(dinvX, Bm[i], dv, PL, l16); unit_row<(i)>(dinvX, Bm[i], dv, PU, l16);
+#define UNIT_LO(i) unit_row<(i)>(dinvX, Bm[i], dv, PL, l16);
+#define UNIT_UP(i) unit_row<(i)>(dinvX, Bm[i], dv, PU, l16);
+#ifndef RP_ABL_NOUNIT      /* timing ablations only (tools/): RP_ABL_NOUNIT drops the unit rows, RP_ABL_NOCONTACT the contact rows */
     REP12(UNIT_M)
-    if ((mL_it | mU_it) & 0x03F) { UNIT_L(0) UNIT_L(1) UNIT_L(2) UNIT_L(3) UNIT_L(4) UNIT_L(5) }
-    if ((mL_it | mU_it) & 0xFC0) { UNIT_L(6) UNIT_L(7) UNIT_L(8) UNIT_L(9) UNIT_L(10) UNIT_L(11) }
+    /* limits: per group of six dofs one of {lower and upper interleaved, lower only, upper only, nothing} - an absent row is an exact no-op, so
+     * leaving it out changes nothing but the time (per-wave clocks: the unit rows were 80 % of a typical wave's sweep, two thirds of them
+     * limit rows of which a quarter existed: the gripper's joints sit at their lower limits) */
+    if (mL_it & 0x03F) { if (mU_it & 0x03F) { UNIT_L(0) UNIT_L(1) UNIT_L(2) UNIT_L(3) UNIT_L(4) UNIT_L(5) } else { UNIT_LO(0) UNIT_LO(1) UNIT_LO(2) UNIT_LO(3) UNIT_LO(4) UNIT_LO(5) } }
+    else if (mU_it & 0x03F) { UNIT_UP(0) UNIT_UP(1) UNIT_UP(2) UNIT_UP(3) UNIT_UP(4) UNIT_UP(5) }
+    if (mL_it & 0xFC0) { if (mU_it & 0xFC0) { UNIT_L(6) UNIT_L(7) UNIT_L(8) UNIT_L(9) UNIT_L(10) UNIT_L(11) } else { UNIT_LO(6) UNIT_LO(7) UNIT_LO(8) UNIT_LO(9) UNIT_LO(10) UNIT_LO(11) } }
+    else if (mU_it & 0xFC0) { UNIT_UP(6) UNIT_UP(7) UNIT_UP(8) UNIT_UP(9) UNIT_UP(10) UNIT_UP(11) }
     if (gr_it) generic_row<GEAR_LANE, false>(Jg, Bg, dv, PU, l16, PU.rhs);
+#endif
 #undef UNIT_M
 #undef UNIT_L
+#undef UNIT_LO
+#undef UNIT_UP
     plane_end(X0); plane_end(PL); plane_end(PU);
     /* contact normals: side-by-side slots while they last, then the folded slots.  Contacts are prefixes of both
      * ranges, so the guards are early exits: nothing is spent on absent slots */
