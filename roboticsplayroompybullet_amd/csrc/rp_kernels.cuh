@@ -337,32 +337,39 @@ __device__ __forceinline__ void collider_aabbs(const DevModel* m, EnvLds& L, int
 /* ------------------------------------------------------------------ narrowphase (same decisions as oracle box_box) */
 struct CPt { V3 p, n; float dist; };
 
-__device__ __attribute__((noinline)) int sphere_box(V3 cs, float r, V3 cb, const M3& Rb, V3 hb, float margin, int sphere_is_b, CPt* out) {
-  V3 l = tmulv(Rb, cs - cb);
-  float ll[3] = {l.x, l.y, l.z}, cl[3], h[3] = {hb.x, hb.y, hb.z};
-  int inside = 1;
-  for (int k = 0; k < 3; k++) {
-    cl[k] = ll[k];
-    if (cl[k] > h[k]) { cl[k] = h[k]; inside = 0; }
-    if (cl[k] < -h[k]) { cl[k] = -h[k]; inside = 0; }
-  }
+/* sphere against box (same decisions and arithmetic as the oracle's sphere_box).  Inlined and written without dynamically indexed
+ * arrays: as a called function it took the box's rotation by reference, and the caller spilled both pairs' matrices to scratch on
+ * every narrowphase pass (6 KB per env and launch of write traffic for a path that almost never runs). */
+__device__ __forceinline__ int sphere_box(V3 cs, float r, V3 cb, const M3& Rb, V3 hb, float margin, int sphere_is_b, CPt* out) {
+  const V3 l = tmulv(Rb, cs - cb);
+  V3 cl = l;
+  bool inside = true;
+  if (cl.x > hb.x) { cl.x = hb.x; inside = false; }
+  if (cl.x < -hb.x) { cl.x = -hb.x; inside = false; }
+  if (cl.y > hb.y) { cl.y = hb.y; inside = false; }
+  if (cl.y < -hb.y) { cl.y = -hb.y; inside = false; }
+  if (cl.z > hb.z) { cl.z = hb.z; inside = false; }
+  if (cl.z < -hb.z) { cl.z = -hb.z; inside = false; }
   V3 nl; float dist;
   if (!inside) {
-    V3 df = mk3(cl[0] - ll[0], cl[1] - ll[1], cl[2] - ll[2]);
-    float len = norm(df);
+    const V3 df = cl - l;
+    const float len = norm(df);
     dist = len - r;
     if (dist > margin) return 0;
     nl = df * (1.f / len);
   } else {
-    int k0 = 0; float best = 1e30f;
-    for (int k = 0; k < 3; k++) { float pen = h[k] - fabsf(ll[k]); if (pen < best) { best = pen; k0 = k; } }
-    float n3[3] = {0, 0, 0};
-    n3[k0] = ll[k0] > 0.f ? -1.f : 1.f;
-    cl[k0] = ll[k0] > 0.f ? h[k0] : -h[k0];
-    nl = mk3(n3[0], n3[1], n3[2]);
+    const float px = hb.x - fabsf(l.x), py = hb.y - fabsf(l.y), pz = hb.z - fabsf(l.z);
+    int k0 = 0; float best = 1e30f;          /* first strict minimum, in axis order (the oracle's loop) */
+    if (px < best) { best = px; k0 = 0; }
+    if (py < best) { best = py; k0 = 1; }
+    if (pz < best) { best = pz; k0 = 2; }
+    const float lk = k0 == 0 ? l.x : (k0 == 1 ? l.y : l.z), hk = k0 == 0 ? hb.x : (k0 == 1 ? hb.y : hb.z);
+    const float nk = lk > 0.f ? -1.f : 1.f, ck = lk > 0.f ? hk : -hk;
+    nl = mk3(k0 == 0 ? nk : 0.f, k0 == 1 ? nk : 0.f, k0 == 2 ? nk : 0.f);
+    cl = mk3(k0 == 0 ? ck : cl.x, k0 == 1 ? ck : cl.y, k0 == 2 ? ck : cl.z);
     dist = -best - r;
   }
-  V3 nw = mulv(Rb, nl), pw = mulv(Rb, mk3(cl[0], cl[1], cl[2])) + cb;
+  const V3 nw = mulv(Rb, nl), pw = mulv(Rb, cl) + cb;
   out[0].p = pw - nw * (0.5f * dist);
   out[0].n = sphere_is_b ? nw : -nw;
   out[0].dist = dist;
