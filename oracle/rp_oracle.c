@@ -45,6 +45,7 @@
 #define TIE_EPS ((real)1e-6)            /* discrete narrowphase choices need a margin that fp32 and fp64 agree on */
 #define MAX_CONTACTS 21
 #define MAX_ACTIVE_PAIRS 64
+#define MAX_CANDIDATES 64    /* candidate points that enter the manifolds per substep (CANDMAX of the HIP library) */
 #define MAX_ROWS (RP_MAX_ARM * 3 + RP_MAX_J1 + 2 + 3 * MAX_CONTACTS)
 #define NB_MAX (1 + RP_MAX_ARM + RP_MAX_FREE + RP_MAX_J1)
 
@@ -384,11 +385,12 @@ static int manifold_replace_index(const contact* c4, const contact* pt) {
 /* Candidate pairs are sorted so the collider pairs of one object pair are contiguous: one manifold of <= 4 points
  * per object pair, as Bullet keeps per collision-object pair.  A rotation-locked free body (the drawer, H5) against
  * the static world keeps only its deepest point: all its points share one Jacobian.  Caps (shared with the HIP
- * library): the first 64 AABB-overlapping pairs are examined, the first 21 contact points are kept. */
+ * library): the first 64 AABB-overlapping pairs are examined, their first 64 candidate points enter the manifolds, the first 21
+ * contact points are kept. */
 static void collide(rpo_env* e) {
   const rp_model* m = &e->m;
   e->ncon = 0;
-  contact man[4]; int nman = 0, man_oa = -1, man_ob = -1, nactive = 0;
+  contact man[4]; int nman = 0, man_oa = -1, man_ob = -1, nactive = 0, ncand = 0;
   for (int pi = 0; pi <= m->n_pair; pi++) {
     int a = 0, b = 0, flush = (pi == m->n_pair);
     if (!flush) {
@@ -416,6 +418,8 @@ static void collide(rpo_env* e) {
       np = sphere_box(e->xc[b].p, hb[0], e->xc[a].p, e->xc[a].R, ha, margin, 1, pts);
     else if (m->col_type[a] == 1 && m->col_type[b] == 0)
       np = sphere_box(e->xc[a].p, ha[0], e->xc[b].p, e->xc[b].R, hb, margin, 0, pts);
+    if (ncand + np > MAX_CANDIDATES) np = MAX_CANDIDATES - ncand;      /* the candidate list ends at MAX_CANDIDATES points, pairs in order */
+    ncand += np;
     int kf = body_free_index(e, m->col_body[a]);
     int single = (kf >= 0 && m->free_rot_locked[kf] && m->col_body[b] == 0);
     for (int i = 0; i < np; i++) {

@@ -38,7 +38,7 @@
 #define MAXSMALL 44          /* arm motors 12 + scene-joint motors 3 + limits 24 + gear 1 (+ pad) */
 
 #ifndef RP_PREP_WAVES
-#define RP_PREP_WAVES 1
+#define RP_PREP_WAVES 4      /* k_prep2: at most 128 VGPRs, four waves per SIMD (its LDS block allows 16 blocks per CU) */
 #endif
 #ifndef RP_WAVES_PER_EU
 #define RP_WAVES_PER_EU 1      /* register budget: 512 / RP_WAVES_PER_EU VGPR+AGPR per lane */
@@ -77,6 +77,13 @@
 #else
 #define O_FLOATS 128
 #endif
+#define CANDMAX 64             /* candidate points examined per env per substep, in pair order (shared cap with the oracle) */
+#define MANPTS (MAXC + 3)      /* merged manifold points that can still reach the solver: the manifold that crosses MAXC is merged whole */
+#define NPSCR_FLOATS 768       /* narrowphase scratch: 96 floats for each of the 8 lane groups */
+#define PREP_CH 8              /* k_prep2 builds the contact rows of PREP_CH contacts at a time (PrepLds) */
+
+/* The phases of a substep are templates over the LDS block; both blocks below carry the same member names.
+ * EnvLds: the one-kernel path (k_step, resets, calc_state): everything of a substep at once, the solver sweeps read all rows from LDS. */
 struct __align__(16) EnvLds {
   float st[RP_REC_FLOATS];
   float xR[NB_MAX * 9], xp[NB_MAX * 3];
@@ -94,22 +101,80 @@ struct __align__(16) EnvLds {
     struct {                                   /* collide() */
       float aabb[RP_MAX_COL * 6];
       float cmarg[RP_MAX_COL];                 /* per-collider contact margin (DevModel.col_margin); a pair's is the smaller */
-      int act[MAXACT], candn[MAXACT], key[MAXACT], cnt[MAXACT];
-      float cand[MAXACT * 4 * 8];              /* candidate points; manifolds are merged in place */
-    } c;
+      int act[MAXACT], candn[MAXACT], key[MAXACT];   /* active pair -> baked pair index | number of candidate points + 256 * their offset | manifold key */
+      float cand[CANDMAX * 8];                 /* candidate points, compact, in pair order (fk_bodies' scratch before that) */
+      float man[MANPTS * 8];                   /* merged manifolds, in solver-bound order */
+      float npscr[NPSCR_FLOATS];
+    };
     struct {                                   /* arm_dynamics() */
       float inert[RP_MAX_ARM * 10], compI[RP_MAX_ARM * 10];
       float vsp[RP_MAX_ARM * 6], csp[RP_MAX_ARM * 6], fsp[RP_MAX_ARM * 6], Fv[RP_MAX_ARM * 6];
       double Md[144];                          /* mass matrix / Cholesky factor in fp64 */
-    } d;
-    struct { float J[ROWREG]; float B[ROWREG]; } r;                   /* contact rows */
-  } u;
+    };
+    struct { float J[ROWREG]; float B[ROWREG]; };                    /* contact rows */
+  };
   float out[O_FLOATS];
-  float aout[192];                /* k_prep2: unit rows in the solver's dof-indexed form */
+  float aout[192];
   unsigned amask[4];
-  int roff[64];                   /* k_prep2: slot offsets of the compact contact rows */
-  int slot[64];                   /* k_prep2: contact index by class rank: [0,21) non-arm, [21,42) arm-only, [42,63) spanning */
+  int roff[64];
+  int slot[64];
+#ifdef RP_LDS_PAD                 /* occupancy experiments only */
+  float pad[RP_LDS_PAD];
+#endif
 };
+
+/* PrepLds: k_prep2 / k_settle_prep / the prep blocks of k_action_prep.  The kernel is a chain of latency-bound phases, so what it needs
+ * is resident waves, and LDS is what limits them: under 10 KB per env 16 blocks fit a CU (4 waves per SIMD; EnvLds: 8).  Lifetimes:
+ *   whole kernel      st, body transforms, joint subspaces, the contact list, slot tables
+ *   collide           AABBs (dead after the broadphase: the narrowphase scratch and then the merged manifolds take their place),
+ *                     active-pair tables, candidate points
+ *   after collide     M^-1, tau, v*, free-body inverse inertias; over them first the dynamics scratch, then the small rows and ONE CHUNK of
+ *                     contact rows (PREP_CH contacts: built, copied to the workspace, next chunk), last the unit rows in solver form */
+struct __align__(16) PrepLds {
+  float st[RP_REC_FLOATS];
+  int roff[64];
+  int slot[64];
+  unsigned amask[4];
+  float O[4];
+  float S[RP_MAX_ARM * 6];
+  float xR[NB_MAX * 9], xp[NB_MAX * 3];
+  float conp[MAXC * 3], conn[MAXC * 3], cond[MAXC], conmu[MAXC];
+  int cona[MAXC], conb[MAXC], conk[MAXC];
+  alignas(16) union {
+    struct {                                   /* collide() */
+      union {
+        struct { float aabb[RP_MAX_COL * 6]; float cmarg[RP_MAX_COL]; };
+        float npscr[NPSCR_FLOATS];
+        float man[MANPTS * 8];
+      };
+      int act[MAXACT], candn[MAXACT], key[MAXACT];
+      float cand[CANDMAX * 8];
+    };
+    struct {
+      float Minv[144], tau[RP_MAX_ARM];
+      float finv[RP_MAX_FREE * 9];
+      float vstar[32];
+      union {
+        struct {                               /* arm_dynamics() */
+          float inert[RP_MAX_ARM * 10], compI[RP_MAX_ARM * 10];
+          float vsp[RP_MAX_ARM * 6], csp[RP_MAX_ARM * 6], fsp[RP_MAX_ARM * 6], Fv[RP_MAX_ARM * 6];
+          double Md[144];
+        };
+        struct {
+          float srow[MAXSMALL * 8];
+          float rowS[3 * PREP_CH * 4], rowT[3 * PREP_CH * 4];
+          union {
+            struct { float J[3 * PREP_CH * ROWW], B[3 * PREP_CH * ROWW]; };
+            float aout[192];
+          };
+        };
+      };
+    };
+  };
+};
+static_assert(sizeof(PrepLds) <= 10240, "k_prep2: 16 blocks per CU need at most 10 KB of LDS each");
+static_assert(offsetof(PrepLds, roff) % 16 == 0 && offsetof(PrepLds, slot) % 16 == 0 && offsetof(PrepLds, Minv) % 16 == 0 && offsetof(PrepLds, aout) % 16 == 0 &&
+              offsetof(PrepLds, Md) % 8 == 0 && offsetof(PrepLds, cand) % 16 == 0, "16-byte copies out of LDS");
 
 #ifdef RP_CLOCKS      /* profiling build only: per-wave phase timestamps of the last k_solve2 (1) / k_prep2 (2) launch */
 __device__ unsigned long long g_clk[32 * 4096];
@@ -246,8 +311,10 @@ __device__ __forceinline__ Xf joint_compose(const DevModel* m, const Xf& P, int 
  * starts with link j's transform relative to its parent link (joint frame times joint motion; root links composed with
  * the base), then every round composes it with its current ancestor's transform and jumps to that ancestor's ancestor -
  * ceil(log2(depth)) rounds of one 3x4 composition instead of a walk of up to 12 joints per link. */
-__device__ __forceinline__ void fk_bodies(const DevModel* m, EnvLds& L, int lane) {
-  float* T = L.u.c.cand;                     /* two buffers of 12 links x (R row-major, p), then 2 x 12 ancestor indices; dead space until collide() */
+template <class LDS>
+__device__ __forceinline__ void fk_bodies(const DevModel* m, LDS& L, int lane) {
+  float* T = L.cand;                     /* two buffers of 12 links x (R row-major, p), then 2 x 12 ancestor indices; dead space until collide() */
+  static_assert(2 * 12 * RP_MAX_ARM + 2 * RP_MAX_ARM <= CANDMAX * 8, "fk scratch fits the candidate list");
   int* P = (int*)(T + 2 * 12 * RP_MAX_ARM);
   const int n = m->n_arm;
   Xf x; x.R = ident3(); x.p = mk3(0, 0, 0);
@@ -297,7 +364,8 @@ __device__ __forceinline__ void fk_bodies(const DevModel* m, EnvLds& L, int lane
 }
 
 /* joint motion subspaces about the reference point O (the EE body's origin), world axes */
-__device__ __forceinline__ void joint_subspaces(const DevModel* m, EnvLds& L, int lane) {
+template <class LDS>
+__device__ __forceinline__ void joint_subspaces(const DevModel* m, LDS& L, int lane) {
   if (lane == 0) st3(L.O, ld3(&L.xp[3 * m->site_body[RP_SITE_EE]]));
   __syncthreads();
   if (lane < m->n_arm) {
@@ -311,7 +379,8 @@ __device__ __forceinline__ void joint_subspaces(const DevModel* m, EnvLds& L, in
   }
 }
 
-__device__ __forceinline__ Xf collider_xf(const DevModel* m, const EnvLds& L, int c) {
+template <class LDS>
+__device__ __forceinline__ Xf collider_xf(const DevModel* m, const LDS& L, int c) {
   int b = m->col_body[c];
   M3 Rb = ldm3(&L.xR[9 * b]);
   Xf x;
@@ -320,17 +389,18 @@ __device__ __forceinline__ Xf collider_xf(const DevModel* m, const EnvLds& L, in
   return x;
 }
 
-__device__ __forceinline__ void collider_aabbs(const DevModel* m, EnvLds& L, int lane) {
+template <class LDS>
+__device__ __forceinline__ void collider_aabbs(const DevModel* m, LDS& L, int lane) {
   if (lane < m->n_col) {
     Xf x = collider_xf(m, L, lane);
     V3 he = ld3(m->col_he[lane]);
     float e[3];
     for (int i = 0; i < 3; i++)
       e[i] = m->col_type[lane] == 0 ? fabsf(x.R.m[3 * i]) * he.x + fabsf(x.R.m[3 * i + 1]) * he.y + fabsf(x.R.m[3 * i + 2]) * he.z : he.x;
-    float* a = &L.u.c.aabb[6 * lane];
+    float* a = &L.aabb[6 * lane];
     a[0] = x.p.x - e[0]; a[1] = x.p.y - e[1]; a[2] = x.p.z - e[2];
     a[3] = x.p.x + e[0]; a[4] = x.p.y + e[1]; a[5] = x.p.z + e[2];
-    L.u.c.cmarg[lane] = m->col_margin[lane];
+    L.cmarg[lane] = m->col_margin[lane];
   }
 }
 
@@ -388,17 +458,20 @@ __device__ __forceinline__ int sphere_box(V3 cs, float r, V3 cb, const M3& Rb, V
 __device__ __forceinline__ V3 pick3(int i, V3 a, V3 b, V3 c) { return i == 0 ? a : (i == 1 ? b : c); }
 __device__ __forceinline__ float pick1(int i, float a, float b, float c) { return i == 0 ? a : (i == 1 ? b : c); }
 
-__device__ __forceinline__ void narrowphase_coop(const DevModel* m, EnvLds& L, int lane, int nact) {
+template <class LDS>
+__device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int lane, int nact) {
   const int g = lane >> 3, s = lane & 7;
-  float* scr = &L.srow[NPG_SCRATCH * g];
+  float* scr = &L.npscr[NPG_SCRATCH * g];
   float* sv = scr;
   float (*poly)[8][3] = (float (*)[8][3])(scr + 16);
   float (*kept)[4] = (float (*)[4])(scr + 64);
   const unsigned below = (1u << s) - 1u;
+  const unsigned long long lower_groups = (1ull << (8 * g)) - 1ull;      /* lanes of the groups before this one */
+  int cbase = 0;                                    /* candidate points stored so far (wave-uniform) */
   for (int base = 0; base < nact; base += 64 / NPG) {      /* wave-uniform trip count; every lane reaches every barrier */
     const int ai = base + g;
     const bool act = ai < nact;
-    const int pi = act ? L.u.c.act[ai] : 0;
+    const int pi = act ? L.act[ai] : 0;
     const int a = m->pair[pi][0], b = m->pair[pi][1];
     const int ta = m->col_type[a], tb = m->col_type[b];
     const float margin = fminf(m->col_margin[a], m->col_margin[b]);      /* Bullet: a manifold's breaking threshold is the smaller of its two objects' */
@@ -406,14 +479,10 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, EnvLds& L, i
     const Xf xa = collider_xf(m, L, a), xb = collider_xf(m, L, b);
     const V3 ha = ld3(m->col_he[a]), hb = ld3(m->col_he[b]);
     int np = 0;
+    CPt mine; mine.p = mk3(0, 0, 0); mine.n = mk3(0, 0, 0); mine.dist = 0.f;      /* the point this lane contributes (lane s < np of its group) */
     if (act && !bb && s == 0) {                              /* sphere against box: one lane, closed form */
-      CPt pts[1];
-      if (ta == 0 && tb == 1) np = sphere_box(xb.p, hb.x, xa.p, xa.R, ha, margin, 1, pts);
-      else if (ta == 1 && tb == 0) np = sphere_box(xa.p, ha.x, xb.p, xb.R, hb, margin, 0, pts);
-      if (np > 0) {
-        float* c = &L.u.c.cand[(ai * 4) * 8];
-        st3(c, pts[0].p); st3(c + 3, pts[0].n); c[6] = pts[0].dist; c[7] = __int_as_float(pi);
-      }
+      if (ta == 0 && tb == 1) np = sphere_box(xb.p, hb.x, xa.p, xa.R, ha, margin, 1, &mine);
+      else if (ta == 1 && tb == 0) np = sphere_box(xa.p, ha.x, xb.p, xb.R, hb, margin, 0, &mine);
     }
     /* ---- box against box */
     const V3 ca = xa.p, cb = xb.p;
@@ -484,11 +553,7 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, EnvLds& L, i
       if (den > 1e-9f) { sa = (q1 + ab * q2) / den; sb = (ab * q1 + q2) / den; }
       V3 xA = pa + Ae * sa, xB = pb + Be * sb;
       float dist = dot(xA - xB, n);
-      if (dist <= margin) {
-        float* c = &L.u.c.cand[(ai * 4) * 8];
-        st3(c, (xA + xB) * 0.5f); st3(c + 3, n); c[6] = dist; c[7] = __int_as_float(pi);
-        np = 1;
-      }
+      if (dist <= margin) { mine.p = (xA + xB) * 0.5f; mine.n = n; mine.dist = dist; np = 1; }
     }
     /* face contact: reference box X (the one owning the best face), incident box Y */
     const bool kx = best_kind == 0;
@@ -555,18 +620,32 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, EnvLds& L, i
       const int outn = cnt <= 4 ? cnt : 4;
       if (s < outn) {
         int src = cnt <= 4 ? s : (deepest + (s * cnt) / 4) % cnt;
-        float* c = &L.u.c.cand[(ai * 4 + s) * 8];
-        st3(c, ld3(kept[src])); st3(c + 3, nn); c[6] = kept[src][3]; c[7] = __int_as_float(pi);
+        mine.p = ld3(kept[src]); mine.n = nn; mine.dist = kept[src][3];
       }
       np = outn;
     }
+    /* the pair's points go to the compact candidate list, pairs in order; the list ends at CANDMAX points (the oracle's rule) */
+    const int npl = (act && s == 0) ? np : 0;                /* the group's count, at its first lane */
+    int off = cbase, tot = 0;
+#pragma unroll
+    for (int bit = 0; bit < 3; bit++) {
+      const unsigned long long mb = __ballot((npl >> bit) & 1);
+      off += __popcll(mb & lower_groups) << bit; tot += __popcll(mb) << bit;
+    }
+    cbase += tot;
+    const int npg = __shfl(np, lane & ~7);                   /* edge / sphere pairs: only the first lane knows */
+    const int nst = min(npg, max(0, CANDMAX - off));
+    if (act && s < nst) {
+      float* c = &L.cand[(off + s) * 8];
+      st3(c, mine.p); st3(c + 3, mine.n); c[6] = mine.dist; c[7] = __int_as_float(pi);
+    }
     if (act && s == 0) {
-      L.u.c.candn[ai] = np;
+      L.candn[ai] = nst | (min(off, CANDMAX) << 8);
       /* manifold key = object pair; bit 16 marks "rotation-locked free body against the static world" (drawer): that
        * manifold keeps only its deepest point (a property of the two bodies, so it is the same for the whole run) */
       int kf = m->col_body[a] - 1 - m->n_arm;
       bool single = kf >= 0 && kf < m->n_free && m->free_rot_locked[kf] && m->col_body[b] == 0;
-      L.u.c.key[ai] = m->col_obj[a] * 256 + m->col_obj[b] + (single ? 65536 : 0);
+      L.key[ai] = m->col_obj[a] * 256 + m->col_obj[b] + (single ? 65536 : 0);
     }
     __syncthreads();       /* the scratch is reused by the next pass */
   }
@@ -588,7 +667,8 @@ __device__ __forceinline__ int manifold_replace_index(const float* c4, const flo
 }
 
 /* broadphase + narrowphase + manifolds -> L.con*, returns ncon (wave-uniform) */
-__device__ __forceinline__ int collide(const DevModel* m, EnvLds& L, int lane) {
+template <class LDS>
+__device__ __forceinline__ int collide(const DevModel* m, LDS& L, int lane) {
   /* 1. AABB sweep over the baked candidate pairs, 64 per pass; keep the first MAXACT overlapping, in order */
   int nact = 0;
   const int npair = m->n_pair;
@@ -602,12 +682,12 @@ __device__ __forceinline__ int collide(const DevModel* m, EnvLds& L, int lane) {
     int pi = 64 * k + lane;
     if (64 * k < npair && pi < npair) {
       int a = pv[k] & 255, b = pv[k] >> 8;
-      const float* A = &L.u.c.aabb[6 * a];
-      const float* Bb = &L.u.c.aabb[6 * b];
+      const float* A = &L.aabb[6 * a];
+      const float* Bb = &L.aabb[6 * b];
       /* all twelve reads unconditionally, combined without short-circuit: `||` would make every read wait for the
        * comparison before it (98 exec-mask branches, one LDS round trip each) */
       float a0 = A[0], a1 = A[1], a2 = A[2], a3 = A[3], a4 = A[4], a5 = A[5], b0 = Bb[0], b1 = Bb[1], b2 = Bb[2], b3 = Bb[3], b4 = Bb[4], b5 = Bb[5];
-      const float margin = fminf(L.u.c.cmarg[a], L.u.c.cmarg[b]);
+      const float margin = fminf(L.cmarg[a], L.cmarg[b]);
       bool sep = (a0 > b3 + margin) | (b0 > a3 + margin) | (a1 > b4 + margin) | (b1 > a4 + margin) | (a2 > b5 + margin) | (b2 > a5 + margin);
       ovbits |= sep ? 0u : (1u << k);
     }
@@ -618,7 +698,7 @@ __device__ __forceinline__ int collide(const DevModel* m, EnvLds& L, int lane) {
     bool ov = (ovbits >> k) & 1u;
     unsigned long long mask = __ballot(ov);
     int before = __popcll(mask & ((1ull << lane) - 1ull));
-    if (ov && nact + before < MAXACT) L.u.c.act[nact + before] = 64 * k + lane;
+    if (ov && nact + before < MAXACT) L.act[nact + before] = 64 * k + lane;
     nact += __popcll(mask);
     if (nact >= MAXACT) { nact = MAXACT; break; }
   }
@@ -627,49 +707,56 @@ __device__ __forceinline__ int collide(const DevModel* m, EnvLds& L, int lane) {
 #if defined(RP_CLOCKS) && RP_CLOCKS == 2
   if (lane == 0) g_clk[32 * (blockIdx.x & 4095) + 12] = nact;
 #endif
-  /* 2. narrowphase: eight lanes per active pair (scratch in srow | rowS | rowT, dead until the rows are built) */
-  static_assert(offsetof(EnvLds, rowS) == offsetof(EnvLds, srow) + sizeof(float) * MAXSMALL * 8 &&
-                offsetof(EnvLds, rowT) == offsetof(EnvLds, rowS) + sizeof(float) * MAXROWC * 4 &&
-                NPG_SCRATCH * (64 / NPG) <= MAXSMALL * 8 + MAXROWC * 8, "scratch aliasing needs srow|rowS|rowT contiguous");
+  /* 2. narrowphase: eight lanes per active pair */
   narrowphase_coop(m, L, lane, nact);
   __syncthreads();
   PCLK(9)
-  /* 3. manifolds: the first lane of each run of equal object pairs merges the run sequentially (<= 4 points) */
-  int mycnt = 0;
+  /* 3. manifolds: one per run of equal object pairs, <= 4 points (1 for a rotation-locked body against the world).  A manifold's size
+   * follows from its candidate counts alone, so every manifold knows its place in the contact list before anything is merged; the
+   * first lane of a run merges it (sequentially, in candidate order) into L.man at that place - and only if the list still has room
+   * for at least one of its points (cap MAXC, in manifold order). */
+  int mycnt = 0, run_end = lane;
+  bool single = false;
   if (lane < nact) {
-    bool head = lane == 0 || L.u.c.key[lane - 1] != L.u.c.key[lane];
+    const int mykey = L.key[lane];
+    const bool head = lane == 0 || L.key[lane - 1] != mykey;
     if (head) {
-      float* man = &L.u.c.cand[lane * 32];          /* in place: a head lane's own points are inserted first */
-      const int mykey = L.u.c.key[lane];
-      const bool single = (mykey & 65536) != 0;
-      for (int j = lane; j < nact && L.u.c.key[j] == mykey; j++) {
-        for (int i = 0; i < L.u.c.candn[j]; i++) {
-          const float* c = &L.u.c.cand[(j * 4 + i) * 8];
-          int dst;
-          if (single) {
-            if (mycnt == 0) dst = mycnt++;
-            else dst = c[6] < man[6] - K_TIE_EPS ? 0 : -1;
-          } else if (mycnt < 4) dst = mycnt++;
-          else dst = manifold_replace_index(man, c);
-          if (dst >= 0 && c != man + 8 * dst) for (int k = 0; k < 8; k++) man[8 * dst + k] = c[k];   /* a head's own first points are already in place */
-        }
+      int sum = 0;
+      for (run_end = lane; run_end < nact && L.key[run_end] == mykey; run_end++) sum += L.candn[run_end] & 255;
+      single = (mykey & 65536) != 0;
+      mycnt = min(sum, single ? 1 : 4);
+    }
+  }
+  const unsigned long long lower = (1ull << lane) - 1ull;
+  int off = 0;
+#pragma unroll
+  for (int bit = 0; bit < 3; bit++) off += __popcll(__ballot((mycnt >> bit) & 1) & lower) << bit;
+  const int kept = min(mycnt, max(0, MAXC - off));      /* (the AABBs / narrowphase scratch that L.man may lie over are dead since the last barrier) */
+  float* man = &L.man[8 * (off < MANPTS ? off : 0)];
+  if (kept > 0) {
+    int cnt = 0;
+    for (int j = lane; j < run_end; j++) {
+      const int cn = L.candn[j];
+      for (int i = 0; i < (cn & 255); i++) {
+        const float* c = &L.cand[((cn >> 8) + i) * 8];
+        int dst;
+        if (single) {
+          if (cnt == 0) dst = cnt++;
+          else dst = c[6] < man[6] - K_TIE_EPS ? 0 : -1;
+        } else if (cnt < 4) dst = cnt++;
+        else dst = manifold_replace_index(man, c);
+        if (dst >= 0) for (int k = 0; k < 8; k++) man[8 * dst + k] = c[k];
       }
     }
   }
   __syncthreads();
   /* Contacts leave in solver order: those that span arm and non-arm dofs (class 2) last, the others first, each group
-   * in manifold order (stable partition; same rule in the oracle), capped at MAXC in manifold order.  A lane's points
-   * all belong to one object pair, hence to one class; exclusive prefixes of the per-lane counts (0..4) come from
-   * three ballots each, so every point gets its final slot without an intermediate pass through LDS. */
-  const unsigned long long lower = (1ull << lane) - 1ull;
-  int off = 0;
-#pragma unroll
-  for (int bit = 0; bit < 3; bit++) off += __popcll(__ballot((mycnt >> bit) & 1) & lower) << bit;
-  const int kept = min(mycnt, max(0, MAXC - off));
+   * in manifold order (stable partition; same rule in the oracle).  A lane's points all belong to one object pair, hence to one
+   * class; exclusive prefixes of the per-lane counts (0..4) come from three ballots each. */
   int cls = 0, ia = 0, ib = 0; float mu = 0.f;
   if (kept > 0) {
     const int n = m->n_arm;
-    int pi = __float_as_int(L.u.c.cand[lane * 32 + 7]);
+    int pi = __float_as_int(man[7]);
     ia = m->pair[pi][0]; ib = m->pair[pi][1];
     int ba = m->col_body[ia], bb = m->col_body[ib];
     /* which halves of the velocity layout the contact touches: DPP row 0 = the arm (and the free bodies of free_row0: W's
@@ -686,7 +773,7 @@ __device__ __forceinline__ int collide(const DevModel* m, EnvLds& L, int lane) {
     nN_total += __popcll(mb & ~mc) << bit; total += __popcll(mb) << bit;
   }
   for (int i = 0; i < kept; i++) {
-    const float* c = &L.u.c.cand[lane * 32 + 8 * i];
+    const float* c = &man[8 * i];
     int pi = __float_as_int(c[7]);                    /* the colliders may differ from point to point inside a manifold */
     int a = m->pair[pi][0], b = m->pair[pi][1];
     int o = cls == 2 ? nN_total + nC_before + i : nN_before + i;
@@ -702,7 +789,8 @@ __device__ __forceinline__ int collide(const DevModel* m, EnvLds& L, int lane) {
 }
 
 /* ------------------------------------------------------------------ arm dynamics: CRBA mass matrix, RNEA bias, inverse */
-__device__ __forceinline__ void arm_dynamics(const DevModel* m, EnvLds& L, int lane) {
+template <class LDS>
+__device__ __forceinline__ void arm_dynamics(const DevModel* m, LDS& L, int lane) {
   int n = m->n_arm;
   V3 O = ld3(L.O);
   if (lane < n) {      /* own spatial inertia about O: (m, h = m c, Ibar = R Ic R^T - m [c]x^2) */
@@ -713,7 +801,7 @@ __device__ __forceinline__ void arm_dynamics(const DevModel* m, EnvLds& L, int l
     M3 Rt; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Rt.m[3 * i + j] = R.m[3 * j + i];
     M3 Iw = mul(mul(R, Ic), Rt);
     float cc = dot(c, c);
-    float* I = &L.u.d.inert[10 * lane];
+    float* I = &L.inert[10 * lane];
     I[0] = mass; st3(I + 1, c * mass);
     I[4] = Iw.m[0] + mass * (cc - c.x * c.x); I[5] = Iw.m[4] + mass * (cc - c.y * c.y); I[6] = Iw.m[8] + mass * (cc - c.z * c.z);
     I[7] = Iw.m[1] - mass * c.x * c.y; I[8] = Iw.m[2] - mass * c.x * c.z; I[9] = Iw.m[5] - mass * c.y * c.z;
@@ -726,15 +814,15 @@ __device__ __forceinline__ void arm_dynamics(const DevModel* m, EnvLds& L, int l
     V6 v = zero6();
     for (int j = 0; j < n; j++) {           /* wave-uniform j: LDS broadcasts, read unconditionally and selected (x + 0 is exact) */
       const bool ins = (sub >> j) & 1u, isanc = (anc >> j) & 1u;
-      for (int k = 0; k < 10; k++) { float t = L.u.d.inert[10 * j + k]; acc[k] += ins ? t : 0.f; }
+      for (int k = 0; k < 10; k++) { float t = L.inert[10 * j + k]; acc[k] += ins ? t : 0.f; }
       V6 sj = ld6(&L.S[6 * j]) * L.st[ST_QD + j];
       v.a = v.a + (isanc ? sj.a : mk3(0, 0, 0)); v.l = v.l + (isanc ? sj.l : mk3(0, 0, 0));
     }
-    for (int k = 0; k < 10; k++) L.u.d.compI[10 * lane + k] = acc[k];
-    st6(&L.u.d.vsp[6 * lane], v);
+    for (int k = 0; k < 10; k++) L.compI[10 * lane + k] = acc[k];
+    st6(&L.vsp[6 * lane], v);
     V6 Si = ld6(&L.S[6 * lane]);
-    st6(&L.u.d.csp[6 * lane], crm(v, Si * L.st[ST_QD + lane]));
-    st6(&L.u.d.Fv[6 * lane], inertia_mul(acc, Si));
+    st6(&L.csp[6 * lane], crm(v, Si * L.st[ST_QD + lane]));
+    st6(&L.Fv[6 * lane], inertia_mul(acc, Si));
   }
   __syncthreads();
   PCLK(11)
@@ -744,26 +832,26 @@ __device__ __forceinline__ void arm_dynamics(const DevModel* m, EnvLds& L, int l
       double val = 0.0;
       if ((m->arm_anc[j] >> i) & 1u) {
         const float* a = &L.S[6 * i];
-        const float* b = &L.u.d.Fv[6 * j];
+        const float* b = &L.Fv[6 * j];
         for (int k = 0; k < 6; k++) val += (double)a[k] * (double)b[k];
       }
-      L.u.d.Md[i * 12 + j] = val; L.u.d.Md[j * 12 + i] = val;
+      L.Md[i * 12 + j] = val; L.Md[j * 12 + i] = val;
     }
   }
   if (lane < n) {      /* bias force of each body: f = I a_bias + v x* (I v), a_bias = -g + sum of ancestors' c */
     uint32_t anc = m->arm_anc[lane];
     V6 a = zero6();
     a.l.z = -K_GRAVITY;
-    for (int j = 0; j < n; j++) { V6 cj = ld6(&L.u.d.csp[6 * j]); bool on = (anc >> j) & 1u; a.a = a.a + (on ? cj.a : mk3(0, 0, 0)); a.l = a.l + (on ? cj.l : mk3(0, 0, 0)); }
-    V6 v = ld6(&L.u.d.vsp[6 * lane]);
-    const float* I = &L.u.d.inert[10 * lane];
-    st6(&L.u.d.fsp[6 * lane], inertia_mul(I, a) + crf(v, inertia_mul(I, v)));
+    for (int j = 0; j < n; j++) { V6 cj = ld6(&L.csp[6 * j]); bool on = (anc >> j) & 1u; a.a = a.a + (on ? cj.a : mk3(0, 0, 0)); a.l = a.l + (on ? cj.l : mk3(0, 0, 0)); }
+    V6 v = ld6(&L.vsp[6 * lane]);
+    const float* I = &L.inert[10 * lane];
+    st6(&L.fsp[6 * lane], inertia_mul(I, a) + crf(v, inertia_mul(I, v)));
   }
   __syncthreads();
   if (lane < n) {
     uint32_t sub = m->arm_sub[lane];
     V6 f = zero6();
-    for (int j = 0; j < n; j++) { V6 fj = ld6(&L.u.d.fsp[6 * j]); bool on = (sub >> j) & 1u; f.a = f.a + (on ? fj.a : mk3(0, 0, 0)); f.l = f.l + (on ? fj.l : mk3(0, 0, 0)); }
+    for (int j = 0; j < n; j++) { V6 fj = ld6(&L.fsp[6 * j]); bool on = (sub >> j) & 1u; f.a = f.a + (on ? fj.a : mk3(0, 0, 0)); f.l = f.l + (on ? fj.l : mk3(0, 0, 0)); }
     L.tau[lane] = dot6(ld6(&L.S[6 * lane]), f);
   }
   PCLK(13)
@@ -775,7 +863,7 @@ __device__ __forceinline__ void arm_dynamics(const DevModel* m, EnvLds& L, int l
     const int li = lane < RP_MAX_ARM ? lane : 0;
     double row[RP_MAX_ARM], invd[RP_MAX_ARM];
 #pragma unroll
-    for (int j = 0; j < RP_MAX_ARM; j++) row[j] = (lane < n && j < n) ? L.u.d.Md[li * 12 + j] : (j == lane ? 1.0 : 0.0);   /* identity padding beyond n */
+    for (int j = 0; j < RP_MAX_ARM; j++) row[j] = (lane < n && j < n) ? L.Md[li * 12 + j] : (j == lane ? 1.0 : 0.0);   /* identity padding beyond n */
 #pragma unroll
     for (int k = 0; k < RP_MAX_ARM; k++) {
       double mkk = readlane_d(row[k], k);
@@ -812,7 +900,8 @@ __device__ __forceinline__ void arm_dynamics(const DevModel* m, EnvLds& L, int l
 }
 
 /* unconstrained velocities v* = v + dt * a for every dof (lane = dof) */
-__device__ __forceinline__ void unconstrained_velocities(const DevModel* m, EnvLds& L, int lane) {
+template <class LDS>
+__device__ __forceinline__ void unconstrained_velocities(const DevModel* m, LDS& L, int lane) {
   int n = m->n_arm;
   float vs = 0.f;
   if (lane < n) {
@@ -872,14 +961,16 @@ __device__ __forceinline__ void unconstrained_velocities(const DevModel* m, EnvL
 #define SR_J1 1     /* J = e_dofA on a scene joint                      (door / button / dial motors) */
 #define SR_GEAR 2   /* J = e_dofA + ratio * e_dofB on arm dofs          (Panda finger gear) */
 
-__device__ __forceinline__ void put_srow(EnvLds& L, int r, int type, int dofA, float sign, float rhs, float dinv, float lo, float hi, int dofB) {
+template <class LDS>
+__device__ __forceinline__ void put_srow(LDS& L, int r, int type, int dofA, float sign, float rhs, float dinv, float lo, float hi, int dofB) {
   float* s = &L.srow[8 * r];
   s[0] = __int_as_float(type); s[1] = __int_as_float(dofA); s[2] = sign; s[3] = rhs; s[4] = dinv; s[5] = lo; s[6] = hi;
   s[7] = __int_as_float(dofB);
 }
 
 /* returns the number of small rows (wave-uniform) */
-__device__ __forceinline__ int build_small_rows(const DevModel* m, EnvLds& L, int lane) {
+template <class LDS>
+__device__ __forceinline__ int build_small_rows(const DevModel* m, LDS& L, int lane) {
   int n = m->n_arm, nr = 0;
   if (lane < n) {        /* arm motors (btMultiBodyJointMotor) */
     float dinv = 1.f / L.Minv[lane * 12 + lane];
@@ -936,13 +1027,17 @@ __device__ __forceinline__ int build_small_rows(const DevModel* m, EnvLds& L, in
  * entries starting at dof off1 (an empty slot has off = 64).  If the arm is involved it takes slot0 (off0 = 0).
  * Three register-light passes: (A) lane = row: Jacobian entries, the non-arm part of M^-1 J^T, partial diagonal;
  * (B) lane = (row, i): arm part B_i = sum_k Minv[i][k] J_k; (C) lane = row: diagonal, relative velocity, rhs. */
-__device__ __forceinline__ void contact_rows(const DevModel* m, EnvLds& L, int lane, int ncon) {
+/* The rows of contacts [c0, c0 + nc) are built at local indices [0, 3 nc): normals first, then the friction pairs.  The one-kernel path
+ * builds all contacts at once (c0 = 0, nc = ncon: local index = row number); k_prep2 builds PREP_CH contacts at a time and copies each
+ * chunk to its rows of the workspace. */
+template <class LDS>
+__device__ __forceinline__ void contact_rows(const DevModel* m, LDS& L, int lane, int c0, int nc) {
   const int n = m->n_arm;
-  const int nrows = 3 * ncon;
+  const int nrows = 3 * nc;
   V3 O = ld3(L.O);
   for (int r = lane; r < nrows; r += 64) {      /* pass A */
     int ci, dir;
-    if (r < ncon) { ci = r; dir = 0; } else { ci = (r - ncon) >> 1; dir = 1 + ((r - ncon) & 1); }
+    if (r < nc) { ci = c0 + r; dir = 0; } else { ci = c0 + ((r - nc) >> 1); dir = 1 + ((r - nc) & 1); }
     V3 nrm = ld3(&L.conn[3 * ci]);
     V3 p = ld3(&L.conp[3 * ci]);
     V3 d = nrm;
@@ -959,8 +1054,8 @@ __device__ __forceinline__ void contact_rows(const DevModel* m, EnvLds& L, int l
       }
       d = dir == 1 ? t1 : t2;
     }
-    float* J = &L.u.r.J[r * ROWW];
-    float* B = &L.u.r.B[r * ROWW];
+    float* J = &L.J[r * ROWW];
+    float* B = &L.B[r * ROWW];
     for (int k = 0; k < ROWW; k++) { J[k] = 0.f; B[k] = 0.f; }
     bool has_arm = false;
     float diag = 0.f, relv = 0.f;
@@ -1020,11 +1115,11 @@ __device__ __forceinline__ void contact_rows(const DevModel* m, EnvLds& L, int l
   for (int e = lane; e < nrows * n; e += 64) {  /* pass B */
     int r = e / n, i = e - r * n;
     if (__float_as_int(L.rowT[4 * r]) != 0) {
-      const float* J = &L.u.r.J[r * ROWW];
+      const float* J = &L.J[r * ROWW];
       const float* Mi = &L.Minv[i * 12];
       float b = 0.f;
       for (int k = 0; k < n; k++) b += Mi[k] * J[k];
-      L.u.r.B[r * ROWW + i] = b;
+      L.B[r * ROWW + i] = b;
     }
   }
   __syncthreads();
@@ -1033,18 +1128,19 @@ __device__ __forceinline__ void contact_rows(const DevModel* m, EnvLds& L, int l
     float* t = &L.rowT[4 * r];
     float diag = s[0], relv = s[1];
     if (__float_as_int(t[0]) != 0) {
-      const float* J = &L.u.r.J[r * ROWW];
-      const float* B = &L.u.r.B[r * ROWW];
+      const float* J = &L.J[r * ROWW];
+      const float* B = &L.B[r * ROWW];
       for (int i = 0; i < n; i++) { diag += J[i] * B[i]; relv += J[i] * L.vstar[i]; }
     }
     float dinv, rhs, cfmr = 0.f;
-    if (r < ncon) {
+    if (r < nc) {
+      const int ci = c0 + r;
       /* <contact> stiffness / damping of either link (the gripper links) make the normal row soft: cfm and erp as in
        * setupMultiBodyContactConstraint (BT_CONTACT_FLAG_CONTACT_STIFFNESS_DAMPING); same arithmetic as the oracle's build_rows */
       float cfm = 0.f, erp = K_ERP;
-      float s0 = m->col_stiff[L.cona[r]], s1 = m->col_stiff[L.conb[r]];
+      float s0 = m->col_stiff[L.cona[ci]], s1 = m->col_stiff[L.conb[ci]];
       if (s0 > 0.f || s1 > 0.f) {
-        float d0 = s0 > 0.f ? m->col_damp[L.cona[r]] : 0.1f, d1 = s1 > 0.f ? m->col_damp[L.conb[r]] : 0.1f;
+        float d0 = s0 > 0.f ? m->col_damp[L.cona[ci]] : 0.1f, d1 = s1 > 0.f ? m->col_damp[L.conb[ci]] : 0.1f;
         if (!(s0 > 0.f)) s0 = 1e18f;
         if (!(s1 > 0.f)) s1 = 1e18f;
         float ks = 1.f / (1.f / s0 + 1.f / s1), kd = d0 + d1;
@@ -1053,13 +1149,13 @@ __device__ __forceinline__ void contact_rows(const DevModel* m, EnvLds& L, int l
       }
       dinv = safe_inv(diag + cfm);
       cfmr = cfm * dinv;
-      float pen = L.cond[r] + K_SLOP, pos_err = 0.f, vel_err = -relv;
+      float pen = L.cond[ci] + K_SLOP, pos_err = 0.f, vel_err = -relv;
       if (pen > 0.f) vel_err -= pen / K_DT; else pos_err = -pen * erp / K_DT;
       rhs = (pos_err + vel_err) * dinv;
     } else { dinv = safe_inv(diag); rhs = -relv * dinv; }
     s[0] = rhs; s[1] = cfmr;          /* [1]: the row's softness cfm * dinv (dinv itself is folded into J below) */
     t[0] = __int_as_float((__float_as_int(t[0]) != 0 && __float_as_int(t[3]) != 64) ? 1 : 0);   /* row spans arm and non-arm dofs */
-    float* Jw = &L.u.r.J[r * ROWW];          /* fold dinv into the stored row: the sweeps use Jd = J * dinv */
+    float* Jw = &L.J[r * ROWW];          /* fold dinv into the stored row: the sweeps use Jd = J * dinv */
     for (int k = 0; k < ROWW; k++) Jw[k] *= dinv;
   }
 }
@@ -1117,7 +1213,7 @@ __device__ float solve_rows(const DevModel* m, LDS& L, int lane, int nsmall_, in
       {
         int i1 = mydof - __float_as_int(tn.w), i0 = mydof - __float_as_int(tn.z);
         int idx = (unsigned)i1 < 6u ? 12 + i1 : ((unsigned)i0 < 12u ? i0 : -1);
-        if (idx >= 0 && mydof >= 0) { jn = L.u.r.J[idx]; bn = L.u.r.B[idx]; }
+        if (idx >= 0 && mydof >= 0) { jn = L.J[idx]; bn = L.B[idx]; }
       }
       for (int r = 0; r < nrc; r++) {
         float jl = jn, bl = bn;
@@ -1128,7 +1224,7 @@ __device__ float solve_rows(const DevModel* m, LDS& L, int lane, int nsmall_, in
           int i1 = mydof - __float_as_int(tn.w), i0 = mydof - __float_as_int(tn.z);
           int idx = (unsigned)i1 < 6u ? 12 + i1 : ((unsigned)i0 < 12u ? i0 : -1);
           jn = 0.f; bn = 0.f;
-          if (idx >= 0 && mydof >= 0) { jn = L.u.r.J[(r + 1) * ROWW + idx]; bn = L.u.r.B[(r + 1) * ROWW + idx]; }
+          if (idx >= 0 && mydof >= 0) { jn = L.J[(r + 1) * ROWW + idx]; bn = L.B[(r + 1) * ROWW + idx]; }
           if (r + 2 < nrc) { s2 = *(const float4*)&L.rowS[4 * (r + 2)]; t2 = *(const float4*)&L.rowT[4 * (r + 2)]; }
         }
         float lamv = r < 64 ? lamC0 : lamC1;
@@ -1161,7 +1257,7 @@ __device__ void substep(const DevModel* m, EnvLds& L, int lane) {
   arm_dynamics(m, L, lane);
   unconstrained_velocities(m, L, lane);
   int nsmall = build_small_rows(m, L, lane);
-  contact_rows(m, L, lane, ncon);
+  contact_rows(m, L, lane, 0, ncon);
   __syncthreads();
   float dv = solve_rows<EnvLds>(m, L, lane, nsmall, ncon);
   __syncthreads();
@@ -1671,7 +1767,8 @@ __device__ void write_outputs(const DevModel* m, const EnvLds& L, int lane, int 
   }
 }
 
-__device__ __forceinline__ void load_state(EnvLds& L, const float* state, int env, int lane) {
+template <class LDS>
+__device__ __forceinline__ void load_state(LDS& L, const float* state, int env, int lane) {
   const float* r = state + (size_t)env * RP_REC_FLOATS;
   L.st[lane] = r[lane];
   L.st[lane + 64] = r[lane + 64];
@@ -2094,7 +2191,7 @@ static_assert(W3_A % 4 == 0 && W3_ROWS % 4 == 0 && W3_ROFF % 4 == 0 && AOUT_FLOA
 __device__ __forceinline__ void prep2_body(const DevModel* __restrict__ m, const float* __restrict__ state, float* __restrict__ ws, int env0, int N,
                                                              const int* __restrict__ sort_cnt, int* __restrict__ sort_cnt_next, const int* __restrict__ sort_slot, int* __restrict__ pair_env,
                                                   const int* __restrict__ member, const int bid) {
-  __shared__ EnvLds L;
+  __shared__ PrepLds L;
   int env = env0 + bid, lane = threadIdx.x;
   if (env >= N) return;
   if (member) env = member[env];     /* this block's place in its group -> env (groups are cut by load, see k_member) */
@@ -2133,13 +2230,6 @@ __device__ __forceinline__ void prep2_body(const DevModel* __restrict__ m, const
   PREP_STOP(3)
   PCLK(3)
   int nsmall = build_small_rows(m, L, lane);
-  contact_rows(m, L, lane, ncon);
-  for (int i = lane; i < AOUT_FLOATS; i += 64) L.aout[i] = 0.f;
-  if (lane < 2) L.amask[lane] = 0u;
-  __syncthreads();
-  PCLK(4)
-  L.roff[lane] = lane < 3 * ncon ? (__float_as_int(L.rowT[4 * lane + 2]) | (__float_as_int(L.rowT[4 * lane + 3]) << 8)) : 0;
-  PREP_STOP(4)
   nsmall = uni(nsmall);
   ncon = uni(ncon);
 #ifdef RP_ABL_MAXCON    /* timing ablation: drop contacts beyond RP_ABL_MAXCON to expose the tail effect in k_solve2 */
@@ -2147,6 +2237,34 @@ __device__ __forceinline__ void prep2_body(const DevModel* __restrict__ m, const
 #endif
   const int n = m->n_arm;
   float* w = ws + (size_t)env * W3_FLOATS;
+  /* contact rows, PREP_CH contacts at a time: built in LDS, then copied to their places in the workspace (row number: normals first,
+   * then the friction pairs - the order the one-kernel path builds them in) */
+  L.roff[lane] = 0;
+  for (int c0 = 0; c0 < ncon; c0 += PREP_CH) {
+    const int nc = min(PREP_CH, ncon - c0);
+    contact_rows(m, L, lane, c0, nc);
+    __syncthreads();
+    for (int e = lane; e < 3 * nc * ROWW; e += 64) {
+      const int lr = e / ROWW, k = e - lr * ROWW;
+      const int gr = lr < nc ? c0 + lr : ncon + 2 * c0 + (lr - nc);
+      w[W3_J + gr * ROWW + k] = L.J[e]; w[W3_B + gr * ROWW + k] = L.B[e];
+    }
+    for (int e = lane; e < 3 * nc * 4; e += 64) {
+      const int lr = e >> 2, k = e & 3;
+      const int gr = lr < nc ? c0 + lr : ncon + 2 * c0 + (lr - nc);
+      w[W3_ROWS + gr * 4 + k] = L.rowS[e]; w[W3_ROWT + gr * 4 + k] = L.rowT[e];
+    }
+    if (lane < 3 * nc) {
+      const int gr = lane < nc ? c0 + lane : ncon + 2 * c0 + (lane - nc);
+      L.roff[gr] = __float_as_int(L.rowT[4 * lane + 2]) | (__float_as_int(L.rowT[4 * lane + 3]) << 8);
+    }
+    __syncthreads();
+  }
+  PCLK(4)
+  for (int i = lane; i < AOUT_FLOATS; i += 64) L.aout[i] = 0.f;      /* (over the row chunk, which has left) */
+  if (lane < 2) L.amask[lane] = 0u;
+  __syncthreads();
+  PREP_STOP(4)
   /* motor / limit / gear / scene-joint rows in the solver's dof-indexed form (signs folded: exact) */
   bool gear = false;
   if (lane < nsmall) {
@@ -2191,12 +2309,8 @@ __device__ __forceinline__ void prep2_body(const DevModel* __restrict__ m, const
   /* the contact rows leave in the compact form they were built in: coalesced 16-byte copies; k_solve2 expands them */
   copy_out(w + W3_MINV, L.Minv, 144, lane);
   copy_out(w + W3_A, L.aout, AOUT_FLOATS, lane);
-  copy_out(w + W3_ROWS, L.rowS, 4 * 3 * ncon, lane);
-  copy_out(w + W3_ROWT, L.rowT, 4 * 3 * ncon, lane);
   copy_out(w + W3_ROFF, (const float*)L.roff, 64, lane);
   copy_out(w + W3_SLOT, (const float*)L.slot, 64, lane);
-  copy_out(w + W3_J, L.u.r.J, (ROWW * 3 * ncon + 3) & ~3, lane);
-  copy_out(w + W3_B, L.u.r.B, (ROWW * 3 * ncon + 3) & ~3, lane);
   {
     const int mybin = my_slot >> SORT_RANK_BITS;
     int above = 0;
@@ -2753,7 +2867,7 @@ __global__ void __launch_bounds__(64) k_debug_substep(const DevModel* __restrict
     for (int i = 0; i < n; i++) dbg[512 + i] = L.tau[i];
   }
   int nsmall = build_small_rows(m, L, lane);
-  contact_rows(m, L, lane, ncon);
+  contact_rows(m, L, lane, 0, ncon);
   __syncthreads();
   float dv = solve_rows(m, L, lane, nsmall, ncon);
   if (env == dbg_env) {
