@@ -438,23 +438,29 @@ static void collide(rpo_env* e) {
       }
     }
   }
-  /* solver order: contacts that span the two halves of the velocity vector go last, everything else keeps its order (stable
-   * partition).  First half: the arm - and, in the two-block model W, the drawer (rp_model.free_row0) -, second half: the other
-   * free bodies and the scene joints; for every other model "spanning" reads "arm link against a free body or a scene joint".
-   * Rows on disjoint dof sets commute, so among the first group the contacts of either half may be (and, on the GPU, are)
-   * solved side by side. */
+  /* Solver order (stable partition of the manifold order; shared with the HIP library, whose k_solve2 depends on it).  The velocity
+   * vector has two halves - first: the arm and the free bodies of rp_model.free_row0 (the rotation-locked drawer), second: the other
+   * free bodies and the scene joints - and rows on disjoint dof sets commute, so the GPU solves the contacts of either half side by
+   * side; those that touch BOTH halves come after all of them.  Inside each of the two groups, contacts between an arm link and a
+   * movable body come last (the gripper's grip is the last thing a sweep satisfies - what the model did before the drawer moved
+   * into the arm's half):
+   *   0  one half, not arm-against-movable     block on table, drawer on its rails, arm against the world
+   *   1  one half, arm against movable         arm against the drawer
+   *   2  both halves, not arm-against-movable  block against the drawer
+   *   3  both halves, arm against movable      arm against the block, the door, the button, the dial */
   {
     contact tmp[MAX_CONTACTS]; int k = 0;
-    for (int pass = 0; pass < 2; pass++)
+    for (int pass = 0; pass < 4; pass++)
       for (int i = 0; i < e->ncon; i++) {
-        int half0 = 0, half1 = 0;
+        int half0 = 0, half1 = 0, arm = 0, movable = 0;
         for (int side = 0; side < 2; side++) {
           int b = m->col_body[side == 0 ? e->con[i].ca : e->con[i].cb];
           if (b == 0) continue;
           int f = b - 1 - m->n_arm;
+          if (b <= m->n_arm) arm = 1; else movable = 1;
           if (b <= m->n_arm || (f < m->n_free && ((m->free_row0 >> f) & 1))) half0 = 1; else half1 = 1;
         }
-        if ((half0 && half1) == pass) tmp[k++] = e->con[i];
+        if (2 * (half0 && half1) + (arm && movable) == pass) tmp[k++] = e->con[i];
       }
     for (int i = 0; i < e->ncon; i++) e->con[i] = tmp[i];
   }

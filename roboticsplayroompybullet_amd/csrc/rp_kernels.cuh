@@ -197,20 +197,32 @@ __device__ __forceinline__ int dof_free(const DevModel* m, int k) { return m->n_
 __device__ __forceinline__ int dof_j1(const DevModel* m, int k) { return m->n_arm + 6 * m->n_free + k; }
 /* lane layout of the velocity vector inside a 32-lane group: arm dof i at lane i (DPP row 0); in DPP row 1 scene
  * joint k at lane 16 + k (k < 3) and component c of free body f at lane 19 + 6 f + c, so that arm-only and non-arm
- * rows reduce in different DPP rows and every unit row (motor, limit) sits at a compile-time lane of its DPP row */
+ * rows reduce in different DPP rows and every unit row (motor, limit) sits at a compile-time lane of its DPP row.
+ * A free body of rp_model.free_row0 (the rotation-locked drawer) lives in DPP row 0 instead, its three translation components
+ * at lanes n_arm .. n_arm + 2: its contacts against the world (always there: it rests on its rails) then ride in row 0 side
+ * by side with the block's contacts in row 1, instead of queueing behind them.  Its angular velocity has no lane: it is zero and
+ * stays zero (no inverse inertia), so every product it would enter is an exact zero. */
 #ifndef RP_WIDE
 #define LANE_J1 16
 #define LANE_FREE 19
 __device__ __forceinline__ int lane_pos(const DevModel* m, int d) {
   if (d < m->n_arm) return d;
-  int f6 = 6 * m->n_free;
-  return d - m->n_arm < f6 ? LANE_FREE + (d - m->n_arm) : LANE_J1 + (d - m->n_arm - f6);
+  const int e = d - m->n_arm, f6 = 6 * m->n_free;
+  if (e >= f6) return LANE_J1 + (e - f6);
+  const int f = e / 6, c = e - 6 * f;
+  if ((m->free_row0 >> f) & 1) return c < 3 ? m->n_arm + c : -1;
+  return LANE_FREE + e;
 }
 __device__ __forceinline__ int lane_dof(const DevModel* m, int l) {       /* inverse of lane_pos; -1 = no dof at this lane */
-  if (l < 16) return l < m->n_arm ? l : -1;
+  if (l < 16) {
+    if (l < m->n_arm) return l;
+    const int c = l - m->n_arm;
+    return (m->free_row0 != 0 && c < 3) ? m->n_arm + 6 * (__ffs(m->free_row0) - 1) + c : -1;
+  }
   if (l >= 32) return -1;
   if (l < LANE_FREE) return l - LANE_J1 < m->n_j1 ? m->n_arm + 6 * m->n_free + (l - LANE_J1) : -1;
-  return l - LANE_FREE < 6 * m->n_free ? m->n_arm + (l - LANE_FREE) : -1;
+  const int e = l - LANE_FREE, f = e / 6;
+  return (e < 6 * m->n_free && !((m->free_row0 >> f) & 1)) ? m->n_arm + e : -1;
 }
 #else
 /* RP_WIDE (two blocks + drawer, Panda): DPP row 0 = arm dofs 0..8 and the drawer's six components at lanes 9..14 (the arm's row
@@ -750,39 +762,49 @@ __device__ __forceinline__ int collide(const DevModel* m, LDS& L, int lane) {
     }
   }
   __syncthreads();
-  /* Contacts leave in solver order: those that span arm and non-arm dofs (class 2) last, the others first, each group
-   * in manifold order (stable partition; same rule in the oracle).  A lane's points all belong to one object pair, hence to one
-   * class; exclusive prefixes of the per-lane counts (0..4) come from three ballots each. */
-  int cls = 0, ia = 0, ib = 0; float mu = 0.f;
+  /* Contacts leave in solver order (stable partition of the manifold order, the oracle's collide() explains it): key 2 * (touches both
+   * halves of the velocity layout) + (arm link against a movable body).  A lane's points all belong to one object pair, hence to one
+   * key; exclusive prefixes of the per-lane counts (0..4) per key come from ballots. */
+  int cls = 0, key = 0;
   if (kept > 0) {
     const int n = m->n_arm;
     int pi = __float_as_int(man[7]);
-    ia = m->pair[pi][0]; ib = m->pair[pi][1];
+    int ia = m->pair[pi][0], ib = m->pair[pi][1];
     int ba = m->col_body[ia], bb = m->col_body[ib];
-    /* which halves of the velocity layout the contact touches: DPP row 0 = the arm (and the free bodies of free_row0: W's
-     * drawer), DPP row 1 = the other free bodies and the scene joints */
+    /* which halves of the velocity layout the contact touches: DPP row 0 = the arm and the free bodies of free_row0 (the drawer),
+     * DPP row 1 = the other free bodies and the scene joints */
     auto half0 = [&](int b) { int f = b - 1 - n; return b >= 1 && (b <= n || (f < m->n_free && ((m->free_row0 >> f) & 1))); };
     bool r0 = half0(ba) || half0(bb), r1 = (ba >= 1 && !half0(ba)) || (bb >= 1 && !half0(bb));
     cls = r0 ? (r1 ? 2 : 1) : 0;
+    bool arm = (ba >= 1 && ba <= n) || (bb >= 1 && bb <= n), movable = ba > n || bb > n;
+    key = 2 * (cls == 2 ? 1 : 0) + ((arm && movable) ? 1 : 0);
   }
-  int nN_before = 0, nC_before = 0, nN_total = 0, total = 0;
+  int before = 0, total = 0;          /* points of smaller keys + points of my key in earlier lanes */
+  {
+    unsigned long long mk[4];
 #pragma unroll
-  for (int bit = 0; bit < 3; bit++) {
-    unsigned long long mb = __ballot((kept >> bit) & 1), mc = __ballot(((kept >> bit) & 1) && cls == 2);
-    nN_before += __popcll(mb & ~mc & lower) << bit; nC_before += __popcll(mc & lower) << bit;
-    nN_total += __popcll(mb & ~mc) << bit; total += __popcll(mb) << bit;
+    for (int k = 0; k < 4; k++) mk[k] = __ballot(kept > 0 && key == k);
+#pragma unroll
+    for (int bit = 0; bit < 3; bit++) {
+      const unsigned long long mb = __ballot((kept >> bit) & 1);
+      total += __popcll(mb) << bit;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int all = __popcll(mb & mk[k]) << bit, low = __popcll(mb & mk[k] & lower) << bit;
+        before += k < key ? all : (k == key ? low : 0);
+      }
+    }
   }
   for (int i = 0; i < kept; i++) {
     const float* c = &man[8 * i];
     int pi = __float_as_int(c[7]);                    /* the colliders may differ from point to point inside a manifold */
     int a = m->pair[pi][0], b = m->pair[pi][1];
-    int o = cls == 2 ? nN_total + nC_before + i : nN_before + i;
+    int o = before + i;
     st3(&L.conp[3 * o], ld3(c)); st3(&L.conn[3 * o], ld3(c + 3));
     L.cond[o] = c[6];
     L.cona[o] = a; L.conb[o] = b; L.conk[o] = cls;
     L.conmu[o] = m->col_friction[a] * m->col_friction[b];
   }
-  (void)ia; (void)ib; (void)mu;
   __syncthreads();
   PCLK(10)
   return total;

@@ -560,7 +560,10 @@ def emit_header(models, path):
 
         drawer = [i for i, f in enumerate(M['free']) if f['rot_locked']]
         out.append('  m->drawer_free = %d;\n' % (drawer[0] if drawer else -1))
-        out.append('  m->free_row0 = %d;\n' % ((1 << drawer[0]) if (drawer and len(M['free']) > 2) else 0))
+        # the rotation-locked drawer shares the arm's half of the solver's velocity layout (lanes n_arm .. : three translation lanes in the
+        # default build, six in the wide one), so that its resting contacts are solved beside the objects' instead of after them
+        assert not drawer or nb + 3 <= 16
+        out.append('  m->free_row0 = %d;\n' % ((1 << drawer[0]) if drawer else 0))
         out.append('  m->arm_type = %d; m->scene = %d;\n' % (['UR5', 'Panda'].index(M['arm_type']),
                                                                ['complex_scene', 'default_scene', 'push_scene'].index(M['scene'])))
 
