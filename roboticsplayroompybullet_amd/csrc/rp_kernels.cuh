@@ -94,16 +94,15 @@ struct __align__(16) EnvLds {
   float vstar[32];
   float conp[MAXC * 3], conn[MAXC * 3], cond[MAXC], conmu[MAXC];
   int cona[MAXC], conb[MAXC], conk[MAXC];     /* colliders of the contact; class: 0 no arm dof, 1 arm only, 2 spanning */
-  float srow[MAXSMALL * 8];      /* type, dofA, sign/ratio, rhs | dinv, lo, hi, dofB */
-  float rowS[MAXROWC * 4];       /* rhs, cfm * dinv (soft normal rows, else 0), mu, parent */
-  float rowT[MAXROWC * 4];       /* lo_c, hi_c, off0, off1 */
-  union {
+  alignas(16) float srow[MAXSMALL * 8];      /* type, dofA, sign/ratio, rhs | dinv, lo, hi, dofB */
+  alignas(16) float rowS[MAXROWC * 4];       /* rhs, cfm * dinv (soft normal rows, else 0), mu, parent */
+  alignas(16) float rowT[MAXROWC * 4];       /* lo_c, hi_c, off0, off1 */
+  alignas(16) union {
     struct {                                   /* collide() */
-      float aabb[RP_MAX_COL * 6];
-      float cmarg[RP_MAX_COL];                 /* per-collider contact margin (DevModel.col_margin); a pair's is the smaller */
+      float aabb[RP_MAX_COL * 8];              /* lo.xyz, contact margin of the collider (DevModel.col_margin; a pair's is the smaller) | hi.xyz, - */
       int act[MAXACT], candn[MAXACT], key[MAXACT];   /* active pair -> baked pair index | number of candidate points + 256 * their offset | manifold key */
-      float cand[CANDMAX * 8];                 /* candidate points, compact, in pair order (fk_bodies' scratch before that) */
-      float man[MANPTS * 8];                   /* merged manifolds, in solver-bound order */
+      alignas(16) float cand[CANDMAX * 8];     /* candidate points, compact, in pair order (fk_bodies' scratch before that) */
+      alignas(16) float man[MANPTS * 8];                 /* merged manifolds, in solver-bound order */
       float npscr[NPSCR_FLOATS];
     };
     struct {                                   /* arm_dynamics() */
@@ -113,8 +112,8 @@ struct __align__(16) EnvLds {
     };
     struct { float J[ROWREG]; float B[ROWREG]; };                    /* contact rows */
   };
-  float out[O_FLOATS];
-  float aout[192];
+  alignas(16) float out[O_FLOATS];
+  alignas(16) float aout[192];
   unsigned amask[4];
   int roff[64];
   int slot[64];
@@ -143,7 +142,7 @@ struct __align__(16) PrepLds {
   alignas(16) union {
     struct {                                   /* collide() */
       union {
-        struct { float aabb[RP_MAX_COL * 6]; float cmarg[RP_MAX_COL]; };
+        float aabb[RP_MAX_COL * 8];
         float npscr[NPSCR_FLOATS];
         float man[MANPTS * 8];
       };
@@ -172,9 +171,11 @@ struct __align__(16) PrepLds {
     };
   };
 };
+static_assert(offsetof(EnvLds, aabb) % 16 == 0 && offsetof(PrepLds, aabb) % 16 == 0 && offsetof(EnvLds, cand) % 16 == 0 && offsetof(EnvLds, man) % 16 == 0 && offsetof(EnvLds, srow) % 16 == 0 && offsetof(EnvLds, rowS) % 16 == 0 &&
+              offsetof(EnvLds, rowT) % 16 == 0 && offsetof(EnvLds, J) % 16 == 0 && offsetof(EnvLds, B) % 16 == 0, "16-byte LDS accesses");
 static_assert(sizeof(PrepLds) <= 10240, "k_prep2: 16 blocks per CU need at most 10 KB of LDS each");
 static_assert(offsetof(PrepLds, roff) % 16 == 0 && offsetof(PrepLds, slot) % 16 == 0 && offsetof(PrepLds, Minv) % 16 == 0 && offsetof(PrepLds, aout) % 16 == 0 &&
-              offsetof(PrepLds, Md) % 8 == 0 && offsetof(PrepLds, cand) % 16 == 0, "16-byte copies out of LDS");
+              offsetof(PrepLds, Md) % 8 == 0 && offsetof(PrepLds, cand) % 16 == 0 && offsetof(PrepLds, man) % 16 == 0, "16-byte copies out of LDS");
 
 #ifdef RP_CLOCKS      /* profiling build only: per-wave phase timestamps of the last k_solve2 (1) / k_prep2 (2) launch */
 __device__ unsigned long long g_clk[32 * 4096];
@@ -409,10 +410,8 @@ __device__ __forceinline__ void collider_aabbs(const DevModel* m, LDS& L, int la
     float e[3];
     for (int i = 0; i < 3; i++)
       e[i] = m->col_type[lane] == 0 ? fabsf(x.R.m[3 * i]) * he.x + fabsf(x.R.m[3 * i + 1]) * he.y + fabsf(x.R.m[3 * i + 2]) * he.z : he.x;
-    float* a = &L.aabb[6 * lane];
-    a[0] = x.p.x - e[0]; a[1] = x.p.y - e[1]; a[2] = x.p.z - e[2];
-    a[3] = x.p.x + e[0]; a[4] = x.p.y + e[1]; a[5] = x.p.z + e[2];
-    L.cmarg[lane] = m->col_margin[lane];
+    *(float4*)&L.aabb[8 * lane] = make_float4(x.p.x - e[0], x.p.y - e[1], x.p.z - e[2], m->col_margin[lane]);
+    *(float4*)&L.aabb[8 * lane + 4] = make_float4(x.p.x + e[0], x.p.y + e[1], x.p.z + e[2], 0.f);
   }
 }
 
@@ -649,7 +648,8 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
     const int nst = min(npg, max(0, CANDMAX - off));
     if (act && s < nst) {
       float* c = &L.cand[(off + s) * 8];
-      st3(c, mine.p); st3(c + 3, mine.n); c[6] = mine.dist; c[7] = __int_as_float(pi);
+      *(float4*)c = make_float4(mine.p.x, mine.p.y, mine.p.z, mine.n.x);
+      *(float4*)(c + 4) = make_float4(mine.n.y, mine.n.z, mine.dist, __int_as_float(a | (b << 8)));      /* the record carries its two colliders */
     }
     if (act && s == 0) {
       L.candn[ai] = nst | (min(off, CANDMAX) << 8);
@@ -694,13 +694,12 @@ __device__ __forceinline__ int collide(const DevModel* m, LDS& L, int lane) {
     int pi = 64 * k + lane;
     if (64 * k < npair && pi < npair) {
       int a = pv[k] & 255, b = pv[k] >> 8;
-      const float* A = &L.aabb[6 * a];
-      const float* Bb = &L.aabb[6 * b];
-      /* all twelve reads unconditionally, combined without short-circuit: `||` would make every read wait for the
+      /* four 16-byte reads, unconditionally, combined without short-circuit: `||` would make every read wait for the
        * comparison before it (98 exec-mask branches, one LDS round trip each) */
-      float a0 = A[0], a1 = A[1], a2 = A[2], a3 = A[3], a4 = A[4], a5 = A[5], b0 = Bb[0], b1 = Bb[1], b2 = Bb[2], b3 = Bb[3], b4 = Bb[4], b5 = Bb[5];
-      const float margin = fminf(L.cmarg[a], L.cmarg[b]);
-      bool sep = (a0 > b3 + margin) | (b0 > a3 + margin) | (a1 > b4 + margin) | (b1 > a4 + margin) | (a2 > b5 + margin) | (b2 > a5 + margin);
+      const float4 alo = *(const float4*)&L.aabb[8 * a], ahi = *(const float4*)&L.aabb[8 * a + 4];
+      const float4 blo = *(const float4*)&L.aabb[8 * b], bhi = *(const float4*)&L.aabb[8 * b + 4];
+      const float margin = fminf(alo.w, blo.w);
+      bool sep = (alo.x > bhi.x + margin) | (blo.x > ahi.x + margin) | (alo.y > bhi.y + margin) | (blo.y > ahi.y + margin) | (alo.z > bhi.z + margin) | (blo.z > ahi.z + margin);
       ovbits |= sep ? 0u : (1u << k);
     }
   }
@@ -757,7 +756,7 @@ __device__ __forceinline__ int collide(const DevModel* m, LDS& L, int lane) {
           else dst = c[6] < man[6] - K_TIE_EPS ? 0 : -1;
         } else if (cnt < 4) dst = cnt++;
         else dst = manifold_replace_index(man, c);
-        if (dst >= 0) for (int k = 0; k < 8; k++) man[8 * dst + k] = c[k];
+        if (dst >= 0) { const float4 c0 = *(const float4*)c, c1 = *(const float4*)(c + 4); *(float4*)&man[8 * dst] = c0; *(float4*)&man[8 * dst + 4] = c1; }
       }
     }
   }
@@ -768,9 +767,8 @@ __device__ __forceinline__ int collide(const DevModel* m, LDS& L, int lane) {
   int cls = 0, key = 0;
   if (kept > 0) {
     const int n = m->n_arm;
-    int pi = __float_as_int(man[7]);
-    int ia = m->pair[pi][0], ib = m->pair[pi][1];
-    int ba = m->col_body[ia], bb = m->col_body[ib];
+    const int ab = __float_as_int(man[7]);
+    int ba = m->col_body[ab & 255], bb = m->col_body[ab >> 8];
     /* which halves of the velocity layout the contact touches: DPP row 0 = the arm and the free bodies of free_row0 (the drawer),
      * DPP row 1 = the other free bodies and the scene joints */
     auto half0 = [&](int b) { int f = b - 1 - n; return b >= 1 && (b <= n || (f < m->n_free && ((m->free_row0 >> f) & 1))); };
@@ -796,15 +794,16 @@ __device__ __forceinline__ int collide(const DevModel* m, LDS& L, int lane) {
     }
   }
   for (int i = 0; i < kept; i++) {
-    const float* c = &man[8 * i];
-    int pi = __float_as_int(c[7]);                    /* the colliders may differ from point to point inside a manifold */
-    int a = m->pair[pi][0], b = m->pair[pi][1];
-    int o = before + i;
-    st3(&L.conp[3 * o], ld3(c)); st3(&L.conn[3 * o], ld3(c + 3));
-    L.cond[o] = c[6];
-    L.cona[o] = a; L.conb[o] = b; L.conk[o] = cls;
-    L.conmu[o] = m->col_friction[a] * m->col_friction[b];
+    const float4 c0 = *(const float4*)&man[8 * i], c1 = *(const float4*)&man[8 * i + 4];
+    const int ab = __float_as_int(c1.w);              /* the colliders may differ from point to point inside a manifold */
+    const int o = before + i;
+    L.conp[3 * o] = c0.x; L.conp[3 * o + 1] = c0.y; L.conp[3 * o + 2] = c0.z;
+    L.conn[3 * o] = c0.w; L.conn[3 * o + 1] = c1.x; L.conn[3 * o + 2] = c1.y;
+    L.cond[o] = c1.z;
+    L.cona[o] = ab & 255; L.conb[o] = ab >> 8; L.conk[o] = cls;
   }
+  __syncthreads();
+  if (lane < total) L.conmu[lane] = m->col_friction[L.cona[lane]] * m->col_friction[L.conb[lane]];      /* one round of table loads for all points */
   __syncthreads();
   PCLK(10)
   return total;
@@ -2657,7 +2656,7 @@ __device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, floa
    * the last lines of the kernel: its round trip under contention, several microseconds, hides behind the sweeps. */
   int sort_pos = 0, sort_bin = 0;
   if (l == 0 && valid) {
-    int key = 8 * (my_nC < 7 ? my_nC : 7) + (my_nS < 6 ? 0 : (my_nS > 13 ? 7 : my_nS - 6));
+    int key = 8 * (my_nC < 7 ? my_nC : 7) + (my_nS < 1 ? 0 : (my_nS > 14 ? 7 : (my_nS - 1) >> 1));      /* side-by-side slots in steps of two: a resting scene has 2..6 */
     sort_bin = key * SORT_REPS + ((blockIdx.x * 2 + half) & (SORT_REPS - 1));
     sort_pos = atomicAdd(&sort_cnt_next[sort_bin], 1);
   }
