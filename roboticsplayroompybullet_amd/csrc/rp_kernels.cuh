@@ -101,6 +101,7 @@ struct __align__(16) EnvLds {
     struct {                                   /* collide() */
       float aabb[RP_MAX_COL * 8];              /* lo.xyz, contact margin of the collider (DevModel.col_margin; a pair's is the smaller) | hi.xyz, - */
       int act[MAXACT], candn[MAXACT], key[MAXACT];   /* active pair -> baked pair index | number of candidate points + 256 * their offset | manifold key */
+      float pmu[MAXACT];                       /* ... | friction coefficient of the pair */
       alignas(16) float cand[CANDMAX * 8];     /* candidate points, compact, in pair order (fk_bodies' scratch before that) */
       alignas(16) float man[MANPTS * 8];                 /* merged manifolds, in solver-bound order */
       float npscr[NPSCR_FLOATS];
@@ -147,6 +148,7 @@ struct __align__(16) PrepLds {
         float man[MANPTS * 8];
       };
       int act[MAXACT], candn[MAXACT], key[MAXACT];
+      float pmu[MAXACT];
       float cand[CANDMAX * 8];
     };
     struct {
@@ -487,6 +489,21 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
     const int ta = m->col_type[a], tb = m->col_type[b];
     const float margin = fminf(m->col_margin[a], m->col_margin[b]);      /* Bullet: a manifold's breaking threshold is the smaller of its two objects' */
     const bool bb = act && ta == 0 && tb == 0;
+    if (act && s == 0) {
+      /* what the pair's contacts will need later, looked up here (the table loads hide behind the axis tests): friction, and the manifold key =
+       * object pair, bit 16 "rotation-locked free body against the static world" (the drawer: that manifold keeps only its deepest point),
+       * bits 20-21 which halves of the velocity layout the two bodies touch (0 second only, 1 first only, 2 both: DPP row 0 = the arm and the
+       * free bodies of free_row0, DPP row 1 = the other free bodies and the scene joints), bit 22 arm link against a movable body - all
+       * properties of the two objects, so the same for the whole run of pairs that makes a manifold */
+      const int n = m->n_arm, ba = m->col_body[a], bdy = m->col_body[b];
+      const int kf = ba - 1 - n;
+      const bool single = kf >= 0 && kf < m->n_free && m->free_rot_locked[kf] && bdy == 0;
+      auto half0 = [&](int q) { int f = q - 1 - n; return q >= 1 && (q <= n || (f < m->n_free && ((m->free_row0 >> f) & 1))); };
+      const bool r0 = half0(ba) || half0(bdy), r1 = (ba >= 1 && !half0(ba)) || (bdy >= 1 && !half0(bdy));
+      const bool arm = (ba >= 1 && ba <= n) || (bdy >= 1 && bdy <= n), movable = ba > n || bdy > n;
+      L.key[ai] = m->col_obj[a] * 256 + m->col_obj[b] + (single ? 65536 : 0) + ((r0 ? (r1 ? 2 : 1) : 0) << 20) + ((arm && movable) ? (1 << 22) : 0);
+      L.pmu[ai] = m->col_friction[a] * m->col_friction[b];
+    }
     const Xf xa = collider_xf(m, L, a), xb = collider_xf(m, L, b);
     const V3 ha = ld3(m->col_he[a]), hb = ld3(m->col_he[b]);
     int np = 0;
@@ -649,16 +666,9 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
     if (act && s < nst) {
       float* c = &L.cand[(off + s) * 8];
       *(float4*)c = make_float4(mine.p.x, mine.p.y, mine.p.z, mine.n.x);
-      *(float4*)(c + 4) = make_float4(mine.n.y, mine.n.z, mine.dist, __int_as_float(a | (b << 8)));      /* the record carries its two colliders */
+      *(float4*)(c + 4) = make_float4(mine.n.y, mine.n.z, mine.dist, __int_as_float(a | (b << 8) | (ai << 16)));      /* the record carries its two colliders and its pair */
     }
-    if (act && s == 0) {
-      L.candn[ai] = nst | (min(off, CANDMAX) << 8);
-      /* manifold key = object pair; bit 16 marks "rotation-locked free body against the static world" (drawer): that
-       * manifold keeps only its deepest point (a property of the two bodies, so it is the same for the whole run) */
-      int kf = m->col_body[a] - 1 - m->n_arm;
-      bool single = kf >= 0 && kf < m->n_free && m->free_rot_locked[kf] && m->col_body[b] == 0;
-      L.key[ai] = m->col_obj[a] * 256 + m->col_obj[b] + (single ? 65536 : 0);
-    }
+    if (act && s == 0) L.candn[ai] = nst | (min(off, CANDMAX) << 8);
     __syncthreads();       /* the scratch is reused by the next pass */
   }
 }
@@ -765,18 +775,7 @@ __device__ __forceinline__ int collide(const DevModel* m, LDS& L, int lane) {
    * halves of the velocity layout) + (arm link against a movable body).  A lane's points all belong to one object pair, hence to one
    * key; exclusive prefixes of the per-lane counts (0..4) per key come from ballots. */
   int cls = 0, key = 0;
-  if (kept > 0) {
-    const int n = m->n_arm;
-    const int ab = __float_as_int(man[7]);
-    int ba = m->col_body[ab & 255], bb = m->col_body[ab >> 8];
-    /* which halves of the velocity layout the contact touches: DPP row 0 = the arm and the free bodies of free_row0 (the drawer),
-     * DPP row 1 = the other free bodies and the scene joints */
-    auto half0 = [&](int b) { int f = b - 1 - n; return b >= 1 && (b <= n || (f < m->n_free && ((m->free_row0 >> f) & 1))); };
-    bool r0 = half0(ba) || half0(bb), r1 = (ba >= 1 && !half0(ba)) || (bb >= 1 && !half0(bb));
-    cls = r0 ? (r1 ? 2 : 1) : 0;
-    bool arm = (ba >= 1 && ba <= n) || (bb >= 1 && bb <= n), movable = ba > n || bb > n;
-    key = 2 * (cls == 2 ? 1 : 0) + ((arm && movable) ? 1 : 0);
-  }
+  if (kept > 0) { const int pk = L.key[lane]; cls = (pk >> 20) & 3; key = 2 * (cls == 2 ? 1 : 0) + ((pk >> 22) & 1); }      /* (narrowphase_coop wrote the pair's classes into its key) */
   int before = 0, total = 0;          /* points of smaller keys + points of my key in earlier lanes */
   {
     unsigned long long mk[4];
@@ -800,10 +799,9 @@ __device__ __forceinline__ int collide(const DevModel* m, LDS& L, int lane) {
     L.conp[3 * o] = c0.x; L.conp[3 * o + 1] = c0.y; L.conp[3 * o + 2] = c0.z;
     L.conn[3 * o] = c0.w; L.conn[3 * o + 1] = c1.x; L.conn[3 * o + 2] = c1.y;
     L.cond[o] = c1.z;
-    L.cona[o] = ab & 255; L.conb[o] = ab >> 8; L.conk[o] = cls;
+    L.cona[o] = ab & 255; L.conb[o] = (ab >> 8) & 255; L.conk[o] = cls;
+    L.conmu[o] = L.pmu[ab >> 16];
   }
-  __syncthreads();
-  if (lane < total) L.conmu[lane] = m->col_friction[L.cona[lane]] * m->col_friction[L.conb[lane]];      /* one round of table loads for all points */
   __syncthreads();
   PCLK(10)
   return total;
@@ -2430,45 +2428,44 @@ __device__ __forceinline__ void unit_row(float jd, float col, float& dv, Plane& 
       : [jd] "v"(jd), [col] "v"(col), [rhs] "v"(p.rhs), [lo] "v"(p.loP), [hi] "v"(p.hiP), [l16] "v"(l16), [k] "n"(I & 15)
       : "vcc");
 }
-/* general row labelled K in plane p: 16-lane dot product (DPP butterfly); the three scalars arrive by row broadcast
- * in the butterfly's hazard slots.  16 instructions.  FOLD rows (SEQ path) add the other DPP row's sum, which is what
- * a row that spans arm and non-arm dofs needs and an exact no-op (+0) for the others: 4 more instructions, cheaper
- * than a scalar branch around them (a not-taken s_cbranch costs ~13 cycles in this chain, a taken one ~27) */
+/* general row labelled K in plane p: 16-lane dot product (DPP butterfly), every lane ends with the sum; then - like the unit row - the
+ * step forms in EVERY lane from that lane's own plane entries (lane K's are the row's), and the last instruction takes lane K's step by
+ * row broadcast: no broadcast of rhs / lo / hi (10 VALU instructions instead of 13; with two waves per SIMD the sweeps are issue-bound).
+ * FOLD rows (SEQ path) add the other DPP row's sum, which is what a row that spans arm and non-arm dofs needs and an exact no-op (+0)
+ * for the others: 4 more instructions, cheaper than a scalar branch around them (a not-taken s_cbranch costs ~13 cycles in this chain,
+ * a taken one ~27).  A DPP read needs two wait states after the VALU write of its source: the s_nops. */
 template <int K, bool FOLDABLE>
 __device__ __forceinline__ void generic_row(float Jr, float Br, float& dv, Plane& p, int l16, float prhs) {
-  float t, r, lo, hi, u;
+  float t, u;
   if (!FOLDABLE)
     asm volatile(
         "v_mul_f32 %[t], %[J], %[dv]\n"
-        "v_mov_b32_dpp %[r], %[rhs] row_newbcast:%[k]" DPP_ALL
-        "v_mov_b32_dpp %[lo], %[lop] row_newbcast:%[k]" DPP_ALL
-        "v_add_f32_dpp %[t], %[t], %[t] quad_perm:[1,0,3,2]" DPP_ALL
-        "v_mov_b32_dpp %[hi], %[hip] row_newbcast:%[k]" DPP_ALL
-        "s_nop 0\n"
-        "v_add_f32_dpp %[t], %[t], %[t] quad_perm:[2,3,0,1]" DPP_ALL
         "v_cmp_eq_u32_e32 vcc, %[k], %[l16]\n"
         "s_nop 0\n"
+        "v_add_f32_dpp %[t], %[t], %[t] quad_perm:[1,0,3,2]" DPP_ALL
+        "s_nop 1\n"
+        "v_add_f32_dpp %[t], %[t], %[t] quad_perm:[2,3,0,1]" DPP_ALL
+        "s_nop 1\n"
         "v_add_f32_dpp %[t], %[t], %[t] row_half_mirror" DPP_ALL
         "s_nop 1\n"
         "v_add_f32_dpp %[t], %[t], %[t] row_mirror" DPP_ALL
-        "v_sub_f32 %[t], %[r], %[t]\n"
+        "v_sub_f32 %[t], %[rhs], %[t]\n"
         "v_med3_f32 %[t], %[t], %[lo], %[hi]\n"
         "v_cndmask_b32_e32 %[dacc], %[dacc], %[t], vcc\n"
-        "v_fmac_f32 %[dv], %[B], %[t]\n"
-        : [dv] "+v"(dv), [dacc] "+v"(p.dacc), [t] "=&v"(t), [r] "=&v"(r), [lo] "=&v"(lo), [hi] "=&v"(hi)
-        : [J] "v"(Jr), [B] "v"(Br), [rhs] "v"(prhs), [lop] "v"(p.loP), [hip] "v"(p.hiP), [l16] "v"(l16), [k] "n"(K & 15)
+        "s_nop 0\n"
+        "v_fmac_f32_dpp %[dv], %[t], %[B] row_newbcast:%[k]" DPP_ALL
+        : [dv] "+v"(dv), [dacc] "+v"(p.dacc), [t] "=&v"(t)
+        : [J] "v"(Jr), [B] "v"(Br), [rhs] "v"(prhs), [lo] "v"(p.loP), [hi] "v"(p.hiP), [l16] "v"(l16), [k] "n"(K & 15)
         : "vcc");
   else
     asm volatile(
         "v_mul_f32 %[t], %[J], %[dv]\n"
-        "v_mov_b32_dpp %[r], %[rhs] row_newbcast:%[k]" DPP_ALL
-        "v_mov_b32_dpp %[lo], %[lop] row_newbcast:%[k]" DPP_ALL
-        "v_add_f32_dpp %[t], %[t], %[t] quad_perm:[1,0,3,2]" DPP_ALL
-        "v_mov_b32_dpp %[hi], %[hip] row_newbcast:%[k]" DPP_ALL
-        "s_nop 0\n"
-        "v_add_f32_dpp %[t], %[t], %[t] quad_perm:[2,3,0,1]" DPP_ALL
         "v_cmp_eq_u32_e32 vcc, %[k], %[l16]\n"
         "s_nop 0\n"
+        "v_add_f32_dpp %[t], %[t], %[t] quad_perm:[1,0,3,2]" DPP_ALL
+        "s_nop 1\n"
+        "v_add_f32_dpp %[t], %[t], %[t] quad_perm:[2,3,0,1]" DPP_ALL
+        "s_nop 1\n"
         "v_add_f32_dpp %[t], %[t], %[t] row_half_mirror" DPP_ALL
         "s_nop 1\n"
         "v_add_f32_dpp %[t], %[t], %[t] row_mirror" DPP_ALL
@@ -2476,12 +2473,13 @@ __device__ __forceinline__ void generic_row(float Jr, float Br, float& dv, Plane
         "s_nop 1\n"
         "v_permlane16_swap_b32 %[t], %[u]\n"
         "v_add_f32 %[t], %[t], %[u]\n"
-        "v_sub_f32 %[t], %[r], %[t]\n"
+        "v_sub_f32 %[t], %[rhs], %[t]\n"
         "v_med3_f32 %[t], %[t], %[lo], %[hi]\n"
         "v_cndmask_b32_e32 %[dacc], %[dacc], %[t], vcc\n"
-        "v_fmac_f32 %[dv], %[B], %[t]\n"
-        : [dv] "+v"(dv), [dacc] "+v"(p.dacc), [t] "=&v"(t), [r] "=&v"(r), [lo] "=&v"(lo), [hi] "=&v"(hi), [u] "=&v"(u)
-        : [J] "v"(Jr), [B] "v"(Br), [rhs] "v"(prhs), [lop] "v"(p.loP), [hip] "v"(p.hiP), [l16] "v"(l16), [k] "n"(K & 15)
+        "s_nop 0\n"
+        "v_fmac_f32_dpp %[dv], %[t], %[B] row_newbcast:%[k]" DPP_ALL
+        : [dv] "+v"(dv), [dacc] "+v"(p.dacc), [t] "=&v"(t), [u] "=&v"(u)
+        : [J] "v"(Jr), [B] "v"(Br), [rhs] "v"(prhs), [lo] "v"(p.loP), [hi] "v"(p.hiP), [l16] "v"(l16), [k] "n"(K & 15)
         : "vcc");
 }
 
