@@ -97,7 +97,7 @@ struct __align__(16) EnvLds {
   alignas(16) float srow[MAXSMALL * 8];      /* type, dofA, sign/ratio, rhs | dinv, lo, hi, dofB */
   alignas(16) float rowS[MAXROWC * 4];       /* rhs, cfm * dinv (soft normal rows, else 0), mu, parent */
   alignas(16) float rowT[MAXROWC * 4];       /* lo_c, hi_c, off0, off1 */
-  alignas(16) union {
+  union alignas(16) {
     struct {                                   /* collide() */
       float aabb[RP_MAX_COL * 8];              /* lo.xyz, contact margin of the collider (DevModel.col_margin; a pair's is the smaller) | hi.xyz, - */
       int act[MAXACT], candn[MAXACT], key[MAXACT];   /* active pair -> baked pair index | number of candidate points + 256 * their offset | manifold key */
@@ -123,59 +123,58 @@ struct __align__(16) EnvLds {
 #endif
 };
 
-/* PrepLds: k_prep2 / k_settle_prep / the prep blocks of k_action_prep.  The kernel is a chain of latency-bound phases, so what it needs
- * is resident waves, and LDS is what limits them: under 10 KB per env 16 blocks fit a CU (4 waves per SIMD; EnvLds: 8).  Lifetimes:
- *   whole kernel      st, body transforms, joint subspaces, the contact list, slot tables
- *   collide           AABBs (dead after the broadphase: the narrowphase scratch and then the merged manifolds take their place),
- *                     active-pair tables, candidate points
- *   after collide     M^-1, tau, v*, free-body inverse inertias; over them first the dynamics scratch, then the small rows and ONE CHUNK of
- *                     contact rows (PREP_CH contacts: built, copied to the workspace, next chunk), last the unit rows in solver form */
+/* PrepLds: k_prep2 / k_settle_prep / the prep blocks of k_action_prep: one env per block of TWO waves.  A substep's preparation is a chain
+ * of latency-bound phases; collision detection (AABBs, broadphase, narrowphase, manifolds: 26 k cycles) and the arm's dynamics (joint
+ * subspaces, CRBA, Cholesky, bias forces, v*, the unit rows: 24 k) need nothing from each other, so wave 0 runs the first and wave 1 the
+ * second, and only the contact rows wait for both.  What the kernel needs beyond that is resident waves, and LDS limits them: under 16 KB
+ * per block ten blocks (twenty waves) fit a CU.  Lifetimes:
+ *   whole kernel   st, body transforms, joint subspaces, the contact list, slot tables, M^-1, tau, v*, free-body inverse inertias
+ *   wave 0         AABBs (dead after the broadphase: the narrowphase scratch and then the merged manifolds take their place), active-pair
+ *                  tables, candidate points
+ *   wave 1         the dynamics scratch, then over it the small rows; after the join ONE CHUNK of contact rows (PREP_CH contacts: built,
+ *                  copied to the workspace, next chunk); aout (the unit rows in solver form) has left by then */
 struct __align__(16) PrepLds {
   float st[RP_REC_FLOATS];
   int roff[64];
   int slot[64];
   unsigned amask[4];
+  int hdr[4];                                  /* ncon (wave 0) | gear present (wave 1) */
   float O[4];
   float S[RP_MAX_ARM * 6];
   float xR[NB_MAX * 9], xp[NB_MAX * 3];
   float conp[MAXC * 3], conn[MAXC * 3], cond[MAXC], conmu[MAXC];
   int cona[MAXC], conb[MAXC], conk[MAXC];
-  alignas(16) union {
-    struct {                                   /* collide() */
-      union {
-        float aabb[RP_MAX_COL * 8];
-        float npscr[NPSCR_FLOATS];
-        float man[MANPTS * 8];
-      };
-      int act[MAXACT], candn[MAXACT], key[MAXACT];
-      float pmu[MAXACT];
-      float cand[CANDMAX * 8];
+  union alignas(16) {                          /* wave 0: collide() */
+    float aabb[RP_MAX_COL * 8];
+    float npscr[NPSCR_FLOATS];
+    float man[MANPTS * 8];
+  };
+  int act[MAXACT], candn[MAXACT], key[MAXACT];
+  float pmu[MAXACT];
+  alignas(16) float cand[CANDMAX * 8];
+  alignas(16) float Minv[144];
+  float tau[RP_MAX_ARM];
+  float finv[RP_MAX_FREE * 9];
+  float vstar[32];
+  union alignas(16) {
+    struct {                                   /* wave 1: arm_dynamics() */
+      float inert[RP_MAX_ARM * 10], compI[RP_MAX_ARM * 10];
+      float vsp[RP_MAX_ARM * 6], csp[RP_MAX_ARM * 6], fsp[RP_MAX_ARM * 6], Fv[RP_MAX_ARM * 6];
+      double Md[144];
     };
     struct {
-      float Minv[144], tau[RP_MAX_ARM];
-      float finv[RP_MAX_FREE * 9];
-      float vstar[32];
+      float srow[MAXSMALL * 8];
+      float rowS[3 * PREP_CH * 4], rowT[3 * PREP_CH * 4];
       union {
-        struct {                               /* arm_dynamics() */
-          float inert[RP_MAX_ARM * 10], compI[RP_MAX_ARM * 10];
-          float vsp[RP_MAX_ARM * 6], csp[RP_MAX_ARM * 6], fsp[RP_MAX_ARM * 6], Fv[RP_MAX_ARM * 6];
-          double Md[144];
-        };
-        struct {
-          float srow[MAXSMALL * 8];
-          float rowS[3 * PREP_CH * 4], rowT[3 * PREP_CH * 4];
-          union {
-            struct { float J[3 * PREP_CH * ROWW], B[3 * PREP_CH * ROWW]; };
-            float aout[192];
-          };
-        };
+        struct { float J[3 * PREP_CH * ROWW], B[3 * PREP_CH * ROWW]; };
+        float aout[192];
       };
     };
   };
 };
 static_assert(offsetof(EnvLds, aabb) % 16 == 0 && offsetof(PrepLds, aabb) % 16 == 0 && offsetof(EnvLds, cand) % 16 == 0 && offsetof(EnvLds, man) % 16 == 0 && offsetof(EnvLds, srow) % 16 == 0 && offsetof(EnvLds, rowS) % 16 == 0 &&
               offsetof(EnvLds, rowT) % 16 == 0 && offsetof(EnvLds, J) % 16 == 0 && offsetof(EnvLds, B) % 16 == 0, "16-byte LDS accesses");
-static_assert(sizeof(PrepLds) <= 10240, "k_prep2: 16 blocks per CU need at most 10 KB of LDS each");
+static_assert(sizeof(PrepLds) <= 16384, "k_prep2: ten blocks (twenty waves) per CU");
 static_assert(offsetof(PrepLds, roff) % 16 == 0 && offsetof(PrepLds, slot) % 16 == 0 && offsetof(PrepLds, Minv) % 16 == 0 && offsetof(PrepLds, aout) % 16 == 0 &&
               offsetof(PrepLds, Md) % 8 == 0 && offsetof(PrepLds, cand) % 16 == 0 && offsetof(PrepLds, man) % 16 == 0, "16-byte copies out of LDS");
 
@@ -194,6 +193,10 @@ __device__ unsigned long long g_clk[32 * 4096];
 #define CLK_MARK2(i)
 #define PCLK(i)
 #endif
+
+/* The phases of a substep each run inside ONE wave (k_prep2 runs two of them side by side in the two waves of its block), so what they need
+ * between a lane's LDS write and another lane's read is program order, not a workgroup barrier: LDS operations of a wave execute in order. */
+#define WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
 
 /* ------------------------------------------------------------------ small helpers */
 __device__ __forceinline__ int dof_free(const DevModel* m, int k) { return m->n_arm + 6 * k; }
@@ -348,7 +351,7 @@ __device__ __forceinline__ void fk_bodies(const DevModel* m, LDS& L, int lane) {
     float* Tb = T + (it & 1) * 12 * RP_MAX_ARM;
     int* Pb = P + (it & 1) * RP_MAX_ARM;
     if (lane < n) { stm3(&Tb[12 * lane], x.R); st3(&Tb[12 * lane + 9], x.p); Pb[lane] = par; }
-    __syncthreads();
+    WSYNC();
     if (par >= 0) {
       M3 Ra = ldm3(&Tb[12 * par]); V3 pa = ld3(&Tb[12 * par + 9]);
       x.p = pa + mulv(Ra, x.p); x.R = mul(Ra, x.R);
@@ -382,7 +385,7 @@ __device__ __forceinline__ void fk_bodies(const DevModel* m, LDS& L, int lane) {
 template <class LDS>
 __device__ __forceinline__ void joint_subspaces(const DevModel* m, LDS& L, int lane) {
   if (lane == 0) st3(L.O, ld3(&L.xp[3 * m->site_body[RP_SITE_EE]]));
-  __syncthreads();
+  WSYNC();
   if (lane < m->n_arm) {
     V3 O = ld3(L.O);
     M3 R = ldm3(&L.xR[9 * (1 + lane)]);
@@ -540,7 +543,7 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
         sv[ax] = valid ? sval : -1e30f;
       }
     }
-    __syncthreads();
+    WSYNC();
     /* decisions, by every lane of the group alike: reject, best face (first-wins with tolerance), best edge */
     bool reject = !bb;
     float best_s = -1e30f, edge_s = -1e30f; int best_f = 0, ee = 0;
@@ -611,7 +614,7 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
     int n = 4, cur = 0;
 #pragma unroll
     for (int pass = 0; pass < 4; pass++) {
-      __syncthreads();
+      WSYNC();
       const V3 u = pass < 2 ? Xu1 : Xu2;
       const float h = pass < 2 ? hXu1 : hXu2, sign = (pass & 1) ? -1.f : 1.f;
       bool k0 = false, kc = false; V3 va = mk3(0, 0, 0), vb = va; float da = 0.f, db = 0.f;
@@ -630,7 +633,7 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
       n = __popc(m0) + __popc(m1);
       cur ^= 1;
     }
-    __syncthreads();
+    WSYNC();
     bool keep = false; V3 pv = mk3(0, 0, 0); float dist = 0.f;
     if (face_case && s < n) {
       pv = ld3(poly[cur][s]);
@@ -640,7 +643,7 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
     unsigned mk = (unsigned)(__ballot(keep) >> (8 * g)) & 0xFFu;
     const int cnt = __popc(mk);
     if (keep) { float* kp = kept[__popc(mk & below)]; st3(kp, pv - nref * (0.5f * dist)); kp[3] = dist; }
-    __syncthreads();
+    WSYNC();
     if (face_case) {
       int deepest = 0;
       for (int c = 1; c < cnt; c++) if (kept[c][3] < kept[deepest][3] - K_TIE_EPS) deepest = c;
@@ -669,7 +672,7 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
       *(float4*)(c + 4) = make_float4(mine.n.y, mine.n.z, mine.dist, __int_as_float(a | (b << 8) | (ai << 16)));      /* the record carries its two colliders and its pair */
     }
     if (act && s == 0) L.candn[ai] = nst | (min(off, CANDMAX) << 8);
-    __syncthreads();       /* the scratch is reused by the next pass */
+    WSYNC();       /* the scratch is reused by the next pass */
   }
 }
 
@@ -723,14 +726,14 @@ __device__ __forceinline__ int collide(const DevModel* m, LDS& L, int lane) {
     nact += __popcll(mask);
     if (nact >= MAXACT) { nact = MAXACT; break; }
   }
-  __syncthreads();
+  WSYNC();
   PCLK(8)
 #if defined(RP_CLOCKS) && RP_CLOCKS == 2
   if (lane == 0) g_clk[32 * (blockIdx.x & 4095) + 12] = nact;
 #endif
   /* 2. narrowphase: eight lanes per active pair */
   narrowphase_coop(m, L, lane, nact);
-  __syncthreads();
+  WSYNC();
   PCLK(9)
   /* 3. manifolds: one per run of equal object pairs, <= 4 points (1 for a rotation-locked body against the world).  A manifold's size
    * follows from its candidate counts alone, so every manifold knows its place in the contact list before anything is merged; the
@@ -770,7 +773,7 @@ __device__ __forceinline__ int collide(const DevModel* m, LDS& L, int lane) {
       }
     }
   }
-  __syncthreads();
+  WSYNC();
   /* Contacts leave in solver order (stable partition of the manifold order, the oracle's collide() explains it): key 2 * (touches both
    * halves of the velocity layout) + (arm link against a movable body).  A lane's points all belong to one object pair, hence to one
    * key; exclusive prefixes of the per-lane counts (0..4) per key come from ballots. */
@@ -802,7 +805,7 @@ __device__ __forceinline__ int collide(const DevModel* m, LDS& L, int lane) {
     L.cona[o] = ab & 255; L.conb[o] = (ab >> 8) & 255; L.conk[o] = cls;
     L.conmu[o] = L.pmu[ab >> 16];
   }
-  __syncthreads();
+  WSYNC();
   PCLK(10)
   return total;
 }
@@ -825,7 +828,7 @@ __device__ __forceinline__ void arm_dynamics(const DevModel* m, LDS& L, int lane
     I[4] = Iw.m[0] + mass * (cc - c.x * c.x); I[5] = Iw.m[4] + mass * (cc - c.y * c.y); I[6] = Iw.m[8] + mass * (cc - c.z * c.z);
     I[7] = Iw.m[1] - mass * c.x * c.y; I[8] = Iw.m[2] - mass * c.x * c.z; I[9] = Iw.m[5] - mass * c.y * c.z;
   }
-  __syncthreads();
+  WSYNC();
   if (lane < n) {      /* composite inertia of the subtree; spatial velocity from the ancestors */
     uint32_t sub = m->arm_sub[lane], anc = m->arm_anc[lane];
     float acc[10];
@@ -843,7 +846,7 @@ __device__ __forceinline__ void arm_dynamics(const DevModel* m, LDS& L, int lane
     st6(&L.csp[6 * lane], crm(v, Si * L.st[ST_QD + lane]));
     st6(&L.Fv[6 * lane], inertia_mul(acc, Si));
   }
-  __syncthreads();
+  WSYNC();
   PCLK(11)
   for (int e = lane; e < n * n; e += 64) {   /* M_ij = S_i . (Ic_j S_j) for i an ancestor-or-self of j, accumulated in fp64 */
     int i = e / n, j = e % n;
@@ -866,7 +869,7 @@ __device__ __forceinline__ void arm_dynamics(const DevModel* m, LDS& L, int lane
     const float* I = &L.inert[10 * lane];
     st6(&L.fsp[6 * lane], inertia_mul(I, a) + crf(v, inertia_mul(I, v)));
   }
-  __syncthreads();
+  WSYNC();
   if (lane < n) {
     uint32_t sub = m->arm_sub[lane];
     V6 f = zero6();
@@ -877,7 +880,7 @@ __device__ __forceinline__ void arm_dynamics(const DevModel* m, LDS& L, int lane
   /* Cholesky M = L L^T and M^-1 = L^-T L^-1 in fp64, entirely in registers: lane i holds row i of M (then of L), the
    * entries of other rows arrive by v_readlane (k, j are compile-time, so every register index is static) - no LDS
    * traffic and no barriers inside the 12-step elimination.  Pivots enter as reciprocals (1/sqrt once per column). */
-  __syncthreads();
+  WSYNC();
   {
     const int li = lane < RP_MAX_ARM ? lane : 0;
     double row[RP_MAX_ARM], invd[RP_MAX_ARM];
@@ -914,7 +917,7 @@ __device__ __forceinline__ void arm_dynamics(const DevModel* m, LDS& L, int lane
       for (int i = 0; i < RP_MAX_ARM; i++) if (i < n) L.Minv[i * 12 + lane] = (float)y[i];
     }
   }
-  __syncthreads();
+  WSYNC();
   PCLK(14)
 }
 
@@ -972,7 +975,7 @@ __device__ __forceinline__ void unconstrained_velocities(const DevModel* m, LDS&
       }
     }
   }
-  __syncthreads();
+  WSYNC();
 }
 
 /* ------------------------------------------------------------------ constraint rows */
@@ -1130,7 +1133,7 @@ __device__ __forceinline__ void contact_rows(const DevModel* m, LDS& L, int lane
     float* t = &L.rowT[4 * r];
     t[0] = __int_as_float(has_arm ? 1 : 0); t[1] = dir == 0 ? 1e10f : 0.f; t[2] = __int_as_float(off0); t[3] = __int_as_float(off1);
   }
-  __syncthreads();
+  WSYNC();
   for (int e = lane; e < nrows * n; e += 64) {  /* pass B */
     int r = e / n, i = e - r * n;
     if (__float_as_int(L.rowT[4 * r]) != 0) {
@@ -1141,7 +1144,7 @@ __device__ __forceinline__ void contact_rows(const DevModel* m, LDS& L, int lane
       L.B[r * ROWW + i] = b;
     }
   }
-  __syncthreads();
+  WSYNC();
   for (int r = lane; r < nrows; r += 64) {      /* pass C */
     float* s = &L.rowS[4 * r];
     float* t = &L.rowT[4 * r];
@@ -2095,7 +2098,7 @@ __global__ void k_copy_state(float* __restrict__ dst, const float* __restrict__ 
 __device__ __forceinline__ void action_body(const DevModel* __restrict__ m, float* __restrict__ state, const float* __restrict__ action,
                                             float* __restrict__ target_poses, int env0, int N, const int* __restrict__ member, const int bid) {
   const int l16 = threadIdx.x & 15;
-  const int env_raw = env0 + bid * 4 + (threadIdx.x >> 4);      /* this launch covers places [env0, N) of its group */
+  const int env_raw = env0 + bid * (blockDim.x >> 4) + (threadIdx.x >> 4);      /* this launch covers places [env0, N) of its group; one env per DPP row */
   const bool live = env_raw < N;
   const int place = live ? env_raw : env0;
   const int env = member ? member[place] : place;
@@ -2207,130 +2210,136 @@ __device__ __forceinline__ void copy_out(float* __restrict__ dst, const float* s
 #define AOUT_FLOATS (160 + 8 + 20)
 static_assert(W3_A % 4 == 0 && W3_ROWS % 4 == 0 && W3_ROFF % 4 == 0 && AOUT_FLOATS % 4 == 0, "16-byte copies");
 
+#define PREP_THREADS 128
 __device__ __forceinline__ void prep2_body(const DevModel* __restrict__ m, const float* __restrict__ state, float* __restrict__ ws, int env0, int N,
-                                                             const int* __restrict__ sort_cnt, int* __restrict__ sort_cnt_next, const int* __restrict__ sort_slot, int* __restrict__ pair_env,
-                                                  const int* __restrict__ member, const int bid) {
+                                           const int* __restrict__ sort_cnt, int* __restrict__ sort_cnt_next, const int* __restrict__ sort_slot, int* __restrict__ pair_env,
+                                           const int* __restrict__ member, const int bid) {
   __shared__ PrepLds L;
-  int env = env0 + bid, lane = threadIdx.x;
+  const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+  int env = env0 + bid;
   if (env >= N) return;
   if (member) env = member[env];     /* this block's place in its group -> env (groups are cut by load, see k_member) */
   if (bid == 0)               /* the histogram that the k_solve2 after this launch fills (for the substep after it) starts at zero */
-    for (int i = lane; i < SORT_BINS; i += 64) sort_cnt_next[i] = 0;
+    for (int i = tid; i < SORT_BINS; i += PREP_THREADS) sort_cnt_next[i] = 0;
   /* pairing table for the k_solve2 after this launch: this env's place among the envs of its group sorted by load class,
    * heaviest first = envs in heavier (class, replica) bins + its rank inside its bin (both from the previous k_solve2).
-   * The loads are issued here; the sum and the store sit at the end of the kernel */
-  const int my_slot = sort_slot[env];
-  int cnt8[8];
+   * The loads are issued here (wave 1); the sum and the store sit at the end of the kernel */
+  int my_slot = 0, cnt8[8];
+  if (wid == 1) {
+    my_slot = sort_slot[env];
 #pragma unroll
-  for (int t = 0; t < 8; t++) cnt8[t] = sort_cnt[8 * lane + t];
+    for (int t = 0; t < 8; t++) cnt8[t] = sort_cnt[8 * lane + t];
+  }
   PCLK(6) PCLK(0)
-  load_state(L, state, env, lane);
+  static_assert(RP_REC_FLOATS == PREP_THREADS, "one float of the record per thread");
+  L.st[tid] = state[(size_t)env * RP_REC_FLOATS + tid];
+  __syncthreads();
   PCLK(16)
-#ifdef RP_PREP_STOP   /* timing ablations only: leave after phase RP_PREP_STOP */
-#define PREP_STOP(k) if (RP_PREP_STOP == (k)) { if (lane == 0) ws[(size_t)env * W3_FLOATS] = L.st[0]; return; }
-#else
-#define PREP_STOP(k)
-#endif
-  PREP_STOP(0)
-  fk_bodies(m, L, lane);
+  if (wid == 0) fk_bodies(m, L, lane);
   __syncthreads();
   PCLK(17)
-  joint_subspaces(m, L, lane);
-  PCLK(18)
-  collider_aabbs(m, L, lane);
-  __syncthreads();
-  PREP_STOP(1)
-  PCLK(1)
-  int ncon = collide(m, L, lane);
-  PREP_STOP(2)
-  PCLK(2)
-  arm_dynamics(m, L, lane);
-  unconstrained_velocities(m, L, lane);
-  PREP_STOP(3)
-  PCLK(3)
-  int nsmall = build_small_rows(m, L, lane);
-  nsmall = uni(nsmall);
-  ncon = uni(ncon);
-#ifdef RP_ABL_MAXCON    /* timing ablation: drop contacts beyond RP_ABL_MAXCON to expose the tail effect in k_solve2 */
-  if (ncon > RP_ABL_MAXCON) ncon = RP_ABL_MAXCON;
-#endif
-  const int n = m->n_arm;
   float* w = ws + (size_t)env * W3_FLOATS;
-  /* contact rows, PREP_CH contacts at a time: built in LDS, then copied to their places in the workspace (row number: normals first,
-   * then the friction pairs - the order the one-kernel path builds them in) */
-  L.roff[lane] = 0;
-  for (int c0 = 0; c0 < ncon; c0 += PREP_CH) {
-    const int nc = min(PREP_CH, ncon - c0);
-    contact_rows(m, L, lane, c0, nc);
-    __syncthreads();
-    for (int e = lane; e < 3 * nc * ROWW; e += 64) {
-      const int lr = e / ROWW, k = e - lr * ROWW;
-      const int gr = lr < nc ? c0 + lr : ncon + 2 * c0 + (lr - nc);
-      w[W3_J + gr * ROWW + k] = L.J[e]; w[W3_B + gr * ROWW + k] = L.B[e];
-    }
-    for (int e = lane; e < 3 * nc * 4; e += 64) {
-      const int lr = e >> 2, k = e & 3;
-      const int gr = lr < nc ? c0 + lr : ncon + 2 * c0 + (lr - nc);
-      w[W3_ROWS + gr * 4 + k] = L.rowS[e]; w[W3_ROWT + gr * 4 + k] = L.rowT[e];
-    }
-    if (lane < 3 * nc) {
-      const int gr = lane < nc ? c0 + lane : ncon + 2 * c0 + (lane - nc);
-      L.roff[gr] = __float_as_int(L.rowT[4 * lane + 2]) | (__float_as_int(L.rowT[4 * lane + 3]) << 8);
-    }
-    __syncthreads();
-  }
-  PCLK(4)
-  for (int i = lane; i < AOUT_FLOATS; i += 64) L.aout[i] = 0.f;      /* (over the row chunk, which has left) */
-  if (lane < 2) L.amask[lane] = 0u;
-  __syncthreads();
-  PREP_STOP(4)
-  /* motor / limit / gear / scene-joint rows in the solver's dof-indexed form (signs folded: exact) */
-  bool gear = false;
-  if (lane < nsmall) {
-    const float* s = &L.srow[8 * lane];
-    int type = __float_as_int(s[0]), dA = __float_as_int(s[1]);
-    float sg = s[2], rhs = s[3], dinv = s[4], lo = s[5], hi = s[6];
-    if (type == SR_UNIT) {
-      if (lane < n) { L.aout[dA] = dinv; L.aout[16 + dA] = rhs; L.aout[32 + dA] = lo; L.aout[48 + dA] = hi; }
-      else {
-        int pl = sg > 0.f ? 64 : 112;
-        L.aout[pl + dA] = sg * rhs; L.aout[pl + 16 + dA] = sg * lo; L.aout[pl + 32 + dA] = sg * hi;
-        atomicOr(&L.amask[sg > 0.f ? 0 : 1], 1u << dA);
+  const int n = m->n_arm;
+  if (wid == 0) {
+    /* ---- wave 0: collision detection -> the contact list */
+    collider_aabbs(m, L, lane);
+    WSYNC();
+    PCLK(1)
+    int ncon = collide(m, L, lane);
+    ncon = uni(ncon);
+#ifdef RP_ABL_MAXCON    /* timing ablation: drop contacts beyond RP_ABL_MAXCON to expose the tail effect in k_solve2 */
+    if (ncon > RP_ABL_MAXCON) ncon = RP_ABL_MAXCON;
+#endif
+    if (lane == 0) L.hdr[0] = ncon;
+    PCLK(2)
+  } else {
+    /* ---- wave 1: the arm's dynamics, v*, the unit rows (motors, limits, gear, scene-joint motors) in the solver's dof-indexed form */
+    joint_subspaces(m, L, lane);
+    PCLK(18)
+    arm_dynamics(m, L, lane);
+    unconstrained_velocities(m, L, lane);
+    PCLK(3)
+    int nsmall = build_small_rows(m, L, lane);
+    nsmall = uni(nsmall);
+    for (int i = lane; i < AOUT_FLOATS; i += 64) L.aout[i] = 0.f;
+    if (lane < 2) L.amask[lane] = 0u;
+    WSYNC();
+    bool gear = false;
+    if (lane < nsmall) {      /* signs folded into rhs and bounds: exact */
+      const float* s = &L.srow[8 * lane];
+      int type = __float_as_int(s[0]), dA = __float_as_int(s[1]);
+      float sg = s[2], rhs = s[3], dinv = s[4], lo = s[5], hi = s[6];
+      if (type == SR_UNIT) {
+        if (lane < n) { L.aout[dA] = dinv; L.aout[16 + dA] = rhs; L.aout[32 + dA] = lo; L.aout[48 + dA] = hi; }
+        else {
+          int pl = sg > 0.f ? 64 : 112;
+          L.aout[pl + dA] = sg * rhs; L.aout[pl + 16 + dA] = sg * lo; L.aout[pl + 32 + dA] = sg * hi;
+          atomicOr(&L.amask[sg > 0.f ? 0 : 1], 1u << dA);
+        }
+      } else if (type == SR_J1) {
+        int k = lane - n;
+        if (k < NBJ) { float* bq = &L.aout[168]; bq[k] = dinv; bq[4 + k] = rhs; bq[8 + k] = lo; bq[12 + k] = hi; bq[16 + k] = sg; }
+      } else {
+        float* g = &L.aout[160];
+        g[0] = s[1]; g[1] = s[7]; g[2] = sg; g[3] = dinv; g[4] = rhs; g[5] = lo; g[6] = hi;
+        gear = true;
       }
-    } else if (type == SR_J1) {
-      int k = lane - n;
-      if (k < NBJ) { float* b = &L.aout[168]; b[k] = dinv; b[4 + k] = rhs; b[8 + k] = lo; b[12 + k] = hi; b[16 + k] = sg; }
-    } else {
-      float* g = &L.aout[160];
-      g[0] = s[1]; g[1] = s[7]; g[2] = sg; g[3] = dinv; g[4] = rhs; g[5] = lo; g[6] = hi;
-      gear = true;
     }
+    const bool anygear = __ballot(gear) != 0ull;
+    if (lane == 0) L.hdr[1] = anygear ? 1 : 0;
+    WSYNC();
+    if (lane < 32) w[W3_VSTAR + lane] = L.vstar[lane];
+    copy_out(w + W3_MINV, L.Minv, 144, lane);
+    copy_out(w + W3_A, L.aout, AOUT_FLOATS, lane);
   }
-  /* contact classes (collide() ordered them: non-spanning first): rank inside the class -> slot tables for k_solve2 */
-  const int cls = lane < ncon ? L.conk[lane] : 3;
-  const unsigned long long mB = __ballot(cls == 0), mA = __ballot(cls == 1), mC = __ballot(cls == 2);
-  const unsigned long long lower = (1ull << lane) - 1ull;
-  L.slot[lane] = -1;
-  bool anygear = __ballot(gear) != 0ull;
-  __syncthreads();
-  if (cls == 0) L.slot[__popcll(mB & lower)] = lane;             /* s-th non-arm contact  */
-  else if (cls == 1) L.slot[21 + __popcll(mA & lower)] = lane;   /* s-th arm-only contact */
-  else if (cls == 2) L.slot[42 + __popcll(mC & lower)] = lane;   /* j-th spanning contact */
-  __syncthreads();
-  if (lane == 0) {
-    int nj = m->n_j1 < NBJ ? m->n_j1 : NBJ;
-    w[W3_HDR] = __int_as_float((int)L.amask[0]); w[W3_HDR + 1] = __int_as_float((int)L.amask[1]);
-    w[W3_HDR + 2] = __int_as_float(nj); w[W3_HDR + 3] = __int_as_float(ncon);
-    w[W3_HDR + 4] = __int_as_float(__popcll(mA)); w[W3_HDR + 5] = __int_as_float(__popcll(mB));
-    w[W3_HDR + 6] = __int_as_float(anygear ? 1 : 0); w[W3_HDR + 7] = __int_as_float(__popcll(mC));
-  }
-  if (lane < 32) { w[W3_VSTAR + lane] = L.vstar[lane]; w[W3_MU + lane] = lane < ncon ? L.conmu[lane] : 0.f; }
-  /* the contact rows leave in the compact form they were built in: coalesced 16-byte copies; k_solve2 expands them */
-  copy_out(w + W3_MINV, L.Minv, 144, lane);
-  copy_out(w + W3_A, L.aout, AOUT_FLOATS, lane);
-  copy_out(w + W3_ROFF, (const float*)L.roff, 64, lane);
-  copy_out(w + W3_SLOT, (const float*)L.slot, 64, lane);
-  {
+  __syncthreads();            /* the join: contacts (wave 0) and M^-1, v*, joint subspaces (wave 1) are there; aout and the dynamics scratch are dead */
+  const int ncon = L.hdr[0];
+  if (wid == 0) {
+    /* contact rows, PREP_CH contacts at a time: built in LDS, then copied to their places in the workspace (row number: normals first,
+     * then the friction pairs - the order the one-kernel path builds them in) */
+    L.roff[lane] = 0;
+    for (int c0 = 0; c0 < ncon; c0 += PREP_CH) {
+      const int nc = min(PREP_CH, ncon - c0);
+      contact_rows(m, L, lane, c0, nc);
+      WSYNC();
+      for (int e = lane; e < 3 * nc * ROWW; e += 64) {
+        const int lr = e / ROWW, k = e - lr * ROWW;
+        const int gr = lr < nc ? c0 + lr : ncon + 2 * c0 + (lr - nc);
+        w[W3_J + gr * ROWW + k] = L.J[e]; w[W3_B + gr * ROWW + k] = L.B[e];
+      }
+      for (int e = lane; e < 3 * nc * 4; e += 64) {
+        const int lr = e >> 2, k = e & 3;
+        const int gr = lr < nc ? c0 + lr : ncon + 2 * c0 + (lr - nc);
+        w[W3_ROWS + gr * 4 + k] = L.rowS[e]; w[W3_ROWT + gr * 4 + k] = L.rowT[e];
+      }
+      if (lane < 3 * nc) {
+        const int gr = lane < nc ? c0 + lane : ncon + 2 * c0 + (lane - nc);
+        L.roff[gr] = __float_as_int(L.rowT[4 * lane + 2]) | (__float_as_int(L.rowT[4 * lane + 3]) << 8);
+      }
+      WSYNC();
+    }
+    PCLK(4)
+    /* contact classes (collide() ordered them): rank inside the class -> slot tables for k_solve2 */
+    const int cls = lane < ncon ? L.conk[lane] : 3;
+    const unsigned long long mB = __ballot(cls == 0), mA = __ballot(cls == 1), mC = __ballot(cls == 2);
+    const unsigned long long lower = (1ull << lane) - 1ull;
+    L.slot[lane] = -1;
+    WSYNC();
+    if (cls == 0) L.slot[__popcll(mB & lower)] = lane;             /* s-th contact of the second half (DPP row 1) */
+    else if (cls == 1) L.slot[21 + __popcll(mA & lower)] = lane;   /* s-th contact of the first half (DPP row 0) */
+    else if (cls == 2) L.slot[42 + __popcll(mC & lower)] = lane;   /* j-th contact that touches both */
+    WSYNC();
+    if (lane == 0) {
+      int nj = m->n_j1 < NBJ ? m->n_j1 : NBJ;
+      w[W3_HDR] = __int_as_float((int)L.amask[0]); w[W3_HDR + 1] = __int_as_float((int)L.amask[1]);
+      w[W3_HDR + 2] = __int_as_float(nj); w[W3_HDR + 3] = __int_as_float(ncon);
+      w[W3_HDR + 4] = __int_as_float(__popcll(mA)); w[W3_HDR + 5] = __int_as_float(__popcll(mB));
+      w[W3_HDR + 6] = __int_as_float(L.hdr[1]); w[W3_HDR + 7] = __int_as_float(__popcll(mC));
+    }
+    if (lane < 32) w[W3_MU + lane] = lane < ncon ? L.conmu[lane] : 0.f;
+    copy_out(w + W3_ROFF, (const float*)L.roff, 64, lane);
+    copy_out(w + W3_SLOT, (const float*)L.slot, 64, lane);
+  } else {
     const int mybin = my_slot >> SORT_RANK_BITS;
     int above = 0;
 #pragma unroll
@@ -2346,15 +2355,15 @@ __device__ __forceinline__ void prep2_body(const DevModel* __restrict__ m, const
 #define PREP2_ARGS const DevModel* __restrict__ m, const float* __restrict__ state, float* __restrict__ ws, int env0, int N, \
                    const int* __restrict__ sort_cnt, int* __restrict__ sort_cnt_next, const int* __restrict__ sort_slot, int* __restrict__ pair_env, \
                    const int* __restrict__ member
-__global__ void __launch_bounds__(64, RP_PREP_WAVES) k_prep2(PREP2_ARGS) { prep2_body(m, state, ws, env0, N, sort_cnt, sort_cnt_next, sort_slot, pair_env, member, blockIdx.x); }
-__global__ void __launch_bounds__(64, RP_PREP_WAVES) k_settle_prep(PREP2_ARGS) { prep2_body(m, state, ws, env0, N, sort_cnt, sort_cnt_next, sort_slot, pair_env, member, blockIdx.x); }
+__global__ void __launch_bounds__(PREP_THREADS, RP_PREP_WAVES) k_prep2(PREP2_ARGS) { prep2_body(m, state, ws, env0, N, sort_cnt, sort_cnt_next, sort_slot, pair_env, member, blockIdx.x); }
+__global__ void __launch_bounds__(PREP_THREADS, RP_PREP_WAVES) k_settle_prep(PREP2_ARGS) { prep2_body(m, state, ws, env0, N, sort_cnt, sort_cnt_next, sort_slot, pair_env, member, blockIdx.x); }
 /* First substep of a step: the action kernel and the first k_prep2 in ONE launch.  Nothing k_prep2 builds depends on the new motor
  * targets except the motor rows themselves (v*, M^-1, contacts and limit rows see q and qd only), so the nab action blocks (first in
  * the grid: they are the long pole, ~80 dependent IK iterations) and the prep blocks of the same envs run side by side instead of
  * one after the other, and the k_solve2 that follows rebuilds the motor rows from the record (debug/flag bit 1) with the formula
  * of build_small_rows.  The prep blocks may read motor fields that an action block is writing: those values only reach the rows
  * that are rebuilt. */
-__global__ void __launch_bounds__(64, RP_PREP_WAVES) k_action_prep(const DevModel* __restrict__ m, float* __restrict__ state, float* __restrict__ ws, int env0, int N,
+__global__ void __launch_bounds__(PREP_THREADS, RP_PREP_WAVES) k_action_prep(const DevModel* __restrict__ m, float* __restrict__ state, float* __restrict__ ws, int env0, int N,
                                                                    const int* __restrict__ sort_cnt, int* __restrict__ sort_cnt_next, const int* __restrict__ sort_slot,
                                                                    int* __restrict__ pair_env, const int* __restrict__ member, const float* __restrict__ action,
                                                                    float* __restrict__ target_poses, int nab) {

@@ -265,7 +265,7 @@ static int reset_split(rp_handle h, const uint8_t* mask, const rp_out* out, hipS
     hipLaunchKernelGGL(k_sort_init, dim3((max(M, SORT_BINS) + 255) / 256), dim3(256), 0, s, cnt[0], h->rs_sort_slot, 0, M);
     int par = 0;
     for (int i = 0; i < K_NSETTLE; i++) {
-      hipLaunchKernelGGL(k_settle_prep, dim3(M), dim3(64), 0, s, h->dev_model, h->rs_state, h->ws, 0, M, cnt[par], cnt[par ^ 1], h->rs_sort_slot, h->rs_pair, (const int*)nullptr);
+      hipLaunchKernelGGL(k_settle_prep, dim3(M), dim3(PREP_THREADS), 0, s, h->dev_model, h->rs_state, h->ws, 0, M, cnt[par], cnt[par ^ 1], h->rs_sort_slot, h->rs_pair, (const int*)nullptr);
       hipLaunchKernelGGL(k_settle_solve, dim3((M + 1) / 2), dim3(64), 0, s, h->dev_model, h->rs_state, h->ws, 0, M, h->rs_pair, cnt[par ^ 1], h->rs_sort_slot, h->debug_flags);
       par ^= 1;
     }
@@ -381,7 +381,7 @@ int rp_step(rp_handle h, const float* action, const rp_out* out, void* stream) {
     for (int g = 0; g < G; g++) {
       GroupCtx& c = gc[g];
       c.gs = g == 0 ? s : h->gstream[g];      /* group 0 stays on the caller's stream: G hardware queues in use */
-      c.e0 = gb.b[g]; c.e1 = gb.b[g + 1]; c.ng = c.e1 - c.e0; c.nab = (c.ng + 3) / 4;
+      c.e0 = gb.b[g]; c.e1 = gb.b[g + 1]; c.ng = c.e1 - c.e0; c.nab = (c.ng + 3) / 4;      /* action blocks of 64 threads: one env per 16 lanes (k_action_prep: 128 threads, half as many) */
       /* env pairing of this group: k_solve2 ranks its envs by load class (histogram, double-buffered), the next k_prep2
        * turns the ranks into the table the next k_solve2 reads */
       c.gcnt[0] = h->sort_cnt + (size_t)g * SORT_BINS; c.gcnt[1] = h->sort_cnt + (size_t)(RP_MAX_GROUPS + g) * SORT_BINS;
@@ -399,10 +399,10 @@ int rp_step(rp_handle h, const float* action, const rp_out* out, void* stream) {
         const GroupCtx& c = gc[g];
         hipStream_t gs = c.gs;
         if (merged)
-          hipLaunchKernelGGL(k_action_prep, dim3(c.nab + c.ng), dim3(64), 0, gs, h->dev_model, h->state, h->ws, c.e0, c.e1, c.gcnt[par], c.gcnt[par ^ 1], h->sort_slot,
-                             h->pair_env, member, action, op.target_poses, c.nab);
+          hipLaunchKernelGGL(k_action_prep, dim3((c.ng + 7) / 8 + c.ng), dim3(PREP_THREADS), 0, gs, h->dev_model, h->state, h->ws, c.e0, c.e1, c.gcnt[par], c.gcnt[par ^ 1], h->sort_slot,
+                             h->pair_env, member, action, op.target_poses, (c.ng + 7) / 8);
         else
-          TIMED(hipLaunchKernelGGL(k_prep2, dim3(c.ng), dim3(64), 0, gs, h->dev_model, h->state, h->ws, c.e0, c.e1, c.gcnt[par], c.gcnt[par ^ 1], h->sort_slot, h->pair_env, member));
+          TIMED(hipLaunchKernelGGL(k_prep2, dim3(c.ng), dim3(PREP_THREADS), 0, gs, h->dev_model, h->state, h->ws, c.e0, c.e1, c.gcnt[par], c.gcnt[par ^ 1], h->sort_slot, h->pair_env, member));
       }
       for (int g = 0; g < G; g++) {
         const GroupCtx& c = gc[g];
