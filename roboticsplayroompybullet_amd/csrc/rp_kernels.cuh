@@ -2700,8 +2700,16 @@ __device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, floa
      * limit rows of which a quarter existed: the gripper's joints sit at their lower limits) */
     if (mL_it & 0x03F) { if (mU_it & 0x03F) { UNIT_L(0) UNIT_L(1) UNIT_L(2) UNIT_L(3) UNIT_L(4) UNIT_L(5) } else { UNIT_LO(0) UNIT_LO(1) UNIT_LO(2) UNIT_LO(3) UNIT_LO(4) UNIT_LO(5) } }
     else if (mU_it & 0x03F) { UNIT_UP(0) UNIT_UP(1) UNIT_UP(2) UNIT_UP(3) UNIT_UP(4) UNIT_UP(5) }
-    if (mL_it & 0xFC0) { if (mU_it & 0xFC0) { UNIT_L(6) UNIT_L(7) UNIT_L(8) UNIT_L(9) UNIT_L(10) UNIT_L(11) } else { UNIT_LO(6) UNIT_LO(7) UNIT_LO(8) UNIT_LO(9) UNIT_LO(10) UNIT_LO(11) } }
-    else if (mU_it & 0xFC0) { UNIT_UP(6) UNIT_UP(7) UNIT_UP(8) UNIT_UP(9) UNIT_UP(10) UNIT_UP(11) }
+    /* dofs 6..11 (the UR5's gripper): the two pad joints (10, 11; range 0.0448 < 2 * K_LIMIT_ACT) always carry both rows, the four finger joints
+     * (6..9) their lower rows while the gripper opens and practically never their upper ones (the commanded range ends 0.16 rad below) - so that
+     * case gets its own straight line: 4..8 rows instead of 12 */
+    if (mU_it & 0x3C0) {
+      if (mL_it & 0xFC0) { UNIT_L(6) UNIT_L(7) UNIT_L(8) UNIT_L(9) UNIT_L(10) UNIT_L(11) } else { UNIT_UP(6) UNIT_UP(7) UNIT_UP(8) UNIT_UP(9) UNIT_UP(10) UNIT_UP(11) }
+    } else {
+      if (mL_it & 0x3C0) { UNIT_LO(6) UNIT_LO(7) UNIT_LO(8) UNIT_LO(9) }
+      if (mL_it & 0xC00) { if (mU_it & 0xC00) { UNIT_L(10) UNIT_L(11) } else { UNIT_LO(10) UNIT_LO(11) } }
+      else if (mU_it & 0xC00) { UNIT_UP(10) UNIT_UP(11) }
+    }
     if (gr_it) generic_row<GEAR_LANE, false>(Jg, Bg, dv, PU, l16, PU.rhs);
 #endif
 #undef UNIT_M
