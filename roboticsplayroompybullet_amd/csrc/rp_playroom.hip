@@ -81,10 +81,13 @@ static OutPtrs to_ptrs(const rp_out* o) {
 
 extern "C" {
 
+#ifndef RP_BUILD_ID
+#define RP_BUILD_ID "unversioned"
+#endif
 #ifdef RP_WIDE
-const char* rp_version(void) { return "rp_playroom 0.2 (gfx950, wide build: two-object play ids)"; }
+const char* rp_version(void) { return "rp_playroom 0.2 (gfx950, wide build: two-object play ids) build " RP_BUILD_ID; }
 #else
-const char* rp_version(void) { return "rp_playroom 0.2 (gfx950)"; }
+const char* rp_version(void) { return "rp_playroom 0.2 (gfx950) build " RP_BUILD_ID; }
 #endif
 
 static void destroy_handle(rp_sim* h) {        /* frees whatever a (possibly partial) handle owns; hipFree(nullptr) etc. are no-ops */
