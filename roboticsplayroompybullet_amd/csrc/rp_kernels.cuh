@@ -2426,16 +2426,17 @@ __device__ __forceinline__ void fplane_begin(Plane& p, float lim, float tot) {
 template <int I>
 __device__ __forceinline__ void unit_row(float jd, float col, float& dv, Plane& p, int l16) {
   float t;
+  const unsigned long long own = 0x0001000100010001ull << (I & 15);      /* the lanes that own label I (one per DPP row): an SGPR pair, no v_cmp */
   asm volatile(
       "v_mul_f32 %[t], %[jd], %[dv]\n"                 /* two roundings, like the general row this row may be merged into */
       "v_sub_f32 %[t], %[rhs], %[t]\n"
       "v_med3_f32 %[t], %[t], %[lo], %[hi]\n"
-      "v_cmp_eq_u32_e32 vcc, %[k], %[l16]\n"            /* the two wait states between med3 and the DPP read */
-      "v_cndmask_b32_e32 %[dacc], %[dacc], %[t], vcc\n"
+      "v_cndmask_b32_e64 %[dacc], %[dacc], %[t], %[own]\n"      /* the two wait states between med3 and the DPP read: this and the nop */
+      "s_nop 0\n"
       "v_fmac_f32_dpp %[dv], %[t], %[col] row_newbcast:%[k]" DPP_ALL
       : [dv] "+v"(dv), [dacc] "+v"(p.dacc), [t] "=&v"(t)
-      : [jd] "v"(jd), [col] "v"(col), [rhs] "v"(p.rhs), [lo] "v"(p.loP), [hi] "v"(p.hiP), [l16] "v"(l16), [k] "n"(I & 15)
-      : "vcc");
+      : [jd] "v"(jd), [col] "v"(col), [rhs] "v"(p.rhs), [lo] "v"(p.loP), [hi] "v"(p.hiP), [own] "s"(own), [k] "n"(I & 15));
+  (void)l16;
 }
 /* general row labelled K in plane p: 16-lane dot product (DPP butterfly), every lane ends with the sum; then - like the unit row - the
  * step forms in EVERY lane from that lane's own plane entries (lane K's are the row's), and the last instruction takes lane K's step by
@@ -2446,11 +2447,12 @@ __device__ __forceinline__ void unit_row(float jd, float col, float& dv, Plane& 
 template <int K, bool FOLDABLE>
 __device__ __forceinline__ void generic_row(float Jr, float Br, float& dv, Plane& p, int l16, float prhs) {
   float t, u;
+  const unsigned long long own = 0x0001000100010001ull << (K & 15);
+  (void)l16;
   if (!FOLDABLE)
     asm volatile(
         "v_mul_f32 %[t], %[J], %[dv]\n"
-        "v_cmp_eq_u32_e32 vcc, %[k], %[l16]\n"
-        "s_nop 0\n"
+        "s_nop 1\n"
         "v_add_f32_dpp %[t], %[t], %[t] quad_perm:[1,0,3,2]" DPP_ALL
         "s_nop 1\n"
         "v_add_f32_dpp %[t], %[t], %[t] quad_perm:[2,3,0,1]" DPP_ALL
@@ -2460,17 +2462,15 @@ __device__ __forceinline__ void generic_row(float Jr, float Br, float& dv, Plane
         "v_add_f32_dpp %[t], %[t], %[t] row_mirror" DPP_ALL
         "v_sub_f32 %[t], %[rhs], %[t]\n"
         "v_med3_f32 %[t], %[t], %[lo], %[hi]\n"
-        "v_cndmask_b32_e32 %[dacc], %[dacc], %[t], vcc\n"
+        "v_cndmask_b32_e64 %[dacc], %[dacc], %[t], %[own]\n"
         "s_nop 0\n"
         "v_fmac_f32_dpp %[dv], %[t], %[B] row_newbcast:%[k]" DPP_ALL
         : [dv] "+v"(dv), [dacc] "+v"(p.dacc), [t] "=&v"(t)
-        : [J] "v"(Jr), [B] "v"(Br), [rhs] "v"(prhs), [lo] "v"(p.loP), [hi] "v"(p.hiP), [l16] "v"(l16), [k] "n"(K & 15)
-        : "vcc");
+        : [J] "v"(Jr), [B] "v"(Br), [rhs] "v"(prhs), [lo] "v"(p.loP), [hi] "v"(p.hiP), [own] "s"(own), [k] "n"(K & 15));
   else
     asm volatile(
         "v_mul_f32 %[t], %[J], %[dv]\n"
-        "v_cmp_eq_u32_e32 vcc, %[k], %[l16]\n"
-        "s_nop 0\n"
+        "s_nop 1\n"
         "v_add_f32_dpp %[t], %[t], %[t] quad_perm:[1,0,3,2]" DPP_ALL
         "s_nop 1\n"
         "v_add_f32_dpp %[t], %[t], %[t] quad_perm:[2,3,0,1]" DPP_ALL
@@ -2484,12 +2484,11 @@ __device__ __forceinline__ void generic_row(float Jr, float Br, float& dv, Plane
         "v_add_f32 %[t], %[t], %[u]\n"
         "v_sub_f32 %[t], %[rhs], %[t]\n"
         "v_med3_f32 %[t], %[t], %[lo], %[hi]\n"
-        "v_cndmask_b32_e32 %[dacc], %[dacc], %[t], vcc\n"
+        "v_cndmask_b32_e64 %[dacc], %[dacc], %[t], %[own]\n"
         "s_nop 0\n"
         "v_fmac_f32_dpp %[dv], %[t], %[B] row_newbcast:%[k]" DPP_ALL
         : [dv] "+v"(dv), [dacc] "+v"(p.dacc), [t] "=&v"(t), [u] "=&v"(u)
-        : [J] "v"(Jr), [B] "v"(Br), [rhs] "v"(prhs), [lo] "v"(p.loP), [hi] "v"(p.hiP), [l16] "v"(l16), [k] "n"(K & 15)
-        : "vcc");
+        : [J] "v"(Jr), [B] "v"(Br), [rhs] "v"(prhs), [lo] "v"(p.loP), [hi] "v"(p.hiP), [own] "s"(own), [k] "n"(K & 15));
 }
 
 __device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, float* __restrict__ state, const float* __restrict__ ws, int env0, int N,
