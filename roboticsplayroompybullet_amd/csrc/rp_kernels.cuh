@@ -1215,11 +1215,10 @@ __device__ float solve_rows(const DevModel* m, LDS& L, int lane, int nsmall_, in
         float bl = 0.f;
         if (type == SR_J1) bl = lane == lane_pos(m, dA) ? sg : 0.f;
         else if (lane < n) bl = type == SR_UNIT ? sg * L.Minv[lane * 12 + dA] : L.Minv[lane * 12 + dA] + sg * L.Minv[lane * 12 + dB];
-        float jdv;           /* products rounded on their own (no contraction across statements), as in k_solve2 */
-        if (type == SR_UNIT) jdv = (sg * jA) * lane_read(dv, dA);
-        else if (type == SR_J1) jdv = jA * lane_read(dv, uni(lane_pos(m, dA)));
-        else { float pa = jA * lane_read(dv, dA); float pb = (sg * jA) * lane_read(dv, dB); jdv = pa + pb; }
-        const float delta = c0.w - jdv;
+        float delta;         /* rounding contract shared with k_solve2: a unit row is one fma, the gear row two products rounded on their own, summed, subtracted */
+        if (type == SR_UNIT) delta = __fmaf_rn(-(sg * jA), lane_read(dv, dA), c0.w);
+        else if (type == SR_J1) delta = __fmaf_rn(-jA, lane_read(dv, uni(lane_pos(m, dA))), c0.w);
+        else { float pa = jA * lane_read(dv, dA); float pb = (sg * jA) * lane_read(dv, dB); float jdv = pa + pb; delta = c0.w - jdv; }
         float lam = lane_read(lamS, r), lnew;
         const float d = pgs_update(delta, lam, c1.y, c1.z, lnew);
         lamS = lane == r ? lnew : lamS;
@@ -2422,14 +2421,13 @@ __device__ __forceinline__ void fplane_begin(Plane& p, float lim, float tot) {
 
 /* unit row of the dof at lane I of its DPP row: the step forms in that lane from its own plane entries (delta form:
  * d = clamp(rhs - Jd dv, lo - lam, hi - lam)), one broadcast spreads it, col = B column of the row.
- * 6 instructions; dependent chain mul, sub, med3, (2 wait states), broadcast-fmac */
+ * 4 VALU instructions; dependent chain fma, med3, (2 wait states), broadcast-fmac */
 template <int I>
 __device__ __forceinline__ void unit_row(float jd, float col, float& dv, Plane& p, int l16) {
   float t;
   const unsigned long long own = 0x0001000100010001ull << (I & 15);      /* the lanes that own label I (one per DPP row): an SGPR pair, no v_cmp */
   asm volatile(
-      "v_mul_f32 %[t], %[jd], %[dv]\n"                 /* two roundings, like the general row this row may be merged into */
-      "v_sub_f32 %[t], %[rhs], %[t]\n"
+      "v_fma_f32 %[t], -%[jd], %[dv], %[rhs]\n"        /* rhs - Jd dv, one rounding (the one-kernel path's unit rows: the same fma) */
       "v_med3_f32 %[t], %[t], %[lo], %[hi]\n"
       "v_cndmask_b32_e64 %[dacc], %[dacc], %[t], %[own]\n"      /* the two wait states between med3 and the DPP read: this and the nop */
       "s_nop 0\n"
