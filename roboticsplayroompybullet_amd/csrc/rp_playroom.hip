@@ -383,7 +383,10 @@ int rp_step(rp_handle h, const float* action, const rp_out* out, void* stream) {
     const int par0 = h->sort_par;
     for (int g = 0; g < G; g++) {
       GroupCtx& c = gc[g];
-      c.gs = g == 0 ? s : h->gstream[g];      /* group 0 stays on the caller's stream: G hardware queues in use */
+      /* group 0 stays on the caller's stream; a fourth group takes gstream[0], the stream created first: with the default four hardware queues of a process it is
+       * the one that has a queue to itself (the kernel trace shows queues 1, 3, 4 for three groups and 2 for gstream[0]); gstream[3] shares one, and two chains on
+       * one queue run one after the other (3.6 ms per step).  Four groups are 0.7 % faster than three and leave no queue for anybody else: the default stays 3 */
+      c.gs = g == 0 ? s : h->gstream[g == 3 ? 0 : g];
       c.e0 = gb.b[g]; c.e1 = gb.b[g + 1]; c.ng = c.e1 - c.e0; c.nab = (c.ng + 3) / 4;      /* action blocks of 64 threads: one env per 16 lanes (k_action_prep: 128 threads, half as many) */
       /* env pairing of this group: k_solve2 ranks its envs by load class (histogram, double-buffered), the next k_prep2
        * turns the ranks into the table the next k_solve2 reads */
