@@ -170,7 +170,7 @@ def test_single_env_adapter_honours_kwargs_and_refuses_layout_changes():
     assert not np.array_equal(a, b) and np.array_equal(a, c)
 
 
-@pytest.mark.parametrize('margin', [0.0, 0.005, 0.02])
+@pytest.mark.parametrize('margin', [0.0, 0.005, 0.02, 0.05])      # 0.05: every cap (64 pairs, 64 candidate points, 21 contacts) is hit
 def test_contact_margin_is_a_parameter_shared_with_the_oracle(margin):
     """rp_config.contact_margin: reset (100 settle substeps) and a grasp-like rollout at each margin, device vs the fp32 oracle at
     the same margin"""
