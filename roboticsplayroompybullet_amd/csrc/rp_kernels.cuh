@@ -114,13 +114,6 @@ struct __align__(16) EnvLds {
     struct { float J[ROWREG]; float B[ROWREG]; };                    /* contact rows */
   };
   alignas(16) float out[O_FLOATS];
-  alignas(16) float aout[192];
-  unsigned amask[4];
-  int roff[64];
-  int slot[64];
-#ifdef RP_LDS_PAD                 /* occupancy experiments only */
-  float pad[RP_LDS_PAD];
-#endif
 };
 
 /* PrepLds: k_prep2 / k_settle_prep / the prep blocks of k_action_prep: one env per block of TWO waves.  A substep's preparation is a chain
@@ -171,6 +164,9 @@ struct __align__(16) PrepLds {
       };
     };
   };
+#ifdef RP_LDS_PAD                 /* occupancy experiments only: fewer k_prep2 blocks per CU */
+  float pad[RP_LDS_PAD];
+#endif
 };
 static_assert(offsetof(EnvLds, aabb) % 16 == 0 && offsetof(PrepLds, aabb) % 16 == 0 && offsetof(EnvLds, cand) % 16 == 0 && offsetof(EnvLds, man) % 16 == 0 && offsetof(EnvLds, srow) % 16 == 0 && offsetof(EnvLds, rowS) % 16 == 0 &&
               offsetof(EnvLds, rowT) % 16 == 0 && offsetof(EnvLds, J) % 16 == 0 && offsetof(EnvLds, B) % 16 == 0, "16-byte LDS accesses");
