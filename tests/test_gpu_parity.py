@@ -98,6 +98,50 @@ def test_rollout_200_steps_vs_fp64_oracle(kind):
     assert strict.mean() >= 0.9
 
 
+def test_rollout_sampled_envs_of_4096_vs_fp64_oracle():
+    """the same measure at BASELINE's batch size: 4096 headline envs stepped together (three env groups on three streams, pairs and groups
+    re-sorted by load every substep), 16 of them - spread over the index range - followed by fp64 and fp32 CPU oracles with the same
+    env indices for 100 steps"""
+    from oracle import OracleEnv
+    from roboticsplayroompybullet_amd import VecPlayEnv
+    n, steps = 4096, 100
+    sample = [0, 1, 63, 64, 255, 1000, 1023, 1024, 2047, 2048, 2500, 3071, 3072, 3999, 4094, 4095]
+    env = VecPlayEnv(IDS['U'], n, seed=9)
+    obs = env.reset()
+    o64 = [OracleEnv('U', seed=9, env_index=e) for e in sample]
+    o32 = [OracleEnv('U', seed=9, env_index=e, f32=True) for e in sample]
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    from gpu_debug import oracle_state_from_record
+    rec = env.get_state().cpu().numpy()
+    for k, e in enumerate(sample):                     # every follower starts from the device's own post-reset record of its env
+        for o in (o64[k], o32[k]):
+            a = o.reset()
+            o.set_state(oracle_state_from_record(o, rec[e]))
+        np.testing.assert_allclose(obs['obs_quat'][e].cpu().numpy(), a['obs_quat'], atol=1e-4, rtol=0)
+    g = torch.Generator().manual_seed(77)
+    lo = torch.tensor([-0.18, 0.0, 0.05, -0.5, -0.5, -0.5, -1.0]); hi = torch.tensor([0.18, 0.3, 0.3, 0.5, 0.5, 0.5, 1.0])
+    n_arm = o64[0].n_arm
+    d_hip, d_o32 = np.zeros(len(sample)), np.zeros(len(sample))
+    for t in range(steps):
+        a = lo + (hi - lo) * torch.rand((n, 7), generator=g)
+        obs, r, done, info = env.step(a)
+        q = arm_q(env, 'U')
+        for k, e in enumerate(sample):
+            ae = a[e].numpy().astype(np.float64)
+            o64[k].step(ae)
+            o32[k].step(ae)
+            qo = o64[k].get_state()[:n_arm]
+            d_hip[k] = max(d_hip[k], float((np.abs(q[e] - qo) / np.maximum(1.0, np.abs(qo))).max()))
+            d_o32[k] = max(d_o32[k], float((np.abs(o32[k].get_state()[:n_arm] - qo) / np.maximum(1.0, np.abs(qo))).max()))
+        assert int((info['status'] & 1).sum()) == 0
+    strict = d_hip <= 1e-3
+    print('sampled envs of 4096, %d steps: device max %.3e median %.3e, %d of %d within 1e-3; fp32 CPU oracle max %.3e' % (
+        steps, d_hip.max(), np.median(d_hip), int(strict.sum()), len(sample), d_o32.max()))
+    assert (d_hip <= np.maximum(1e-3, 3 * d_o32)).all(), (d_hip, d_o32)
+    assert strict.mean() >= 0.85
+
+
 def oracle_goal_ptr(o):
     import ctypes as C
     g = np.ascontiguousarray(o.calc_state()['desired_goal'], dtype=np.float64)
