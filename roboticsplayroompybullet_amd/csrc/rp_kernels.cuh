@@ -1,13 +1,12 @@
 /* rp_kernels.cuh — the batched playroom env-step for gfx950 (MI355X), hand-written HIP.
  *
  * rp_step runs right-sized kernels per env group (see "split pipeline" below): k_action_prep (16 lanes per env for the
- * cooperative IK, fused with the first substep's preparation), 12 x { k_prep2 (one wave per env: FK, collision, dynamics,
- * constraint rows -> per-env workspace), k_solve2 (two envs per wave: 50 PGS sweeps over register-resident rows +
- * integration) }, k_calc_state (one wave per env: observation, reward, outputs).  Inside a k_prep2 wave the lanes take turns
- * owning
- *   bodies (FK) -> colliders (AABBs) -> candidate pairs (broadphase, 64 per sweep) -> active pairs (narrowphase)
- *   -> manifolds -> arm links (CRBA / RNEA about a per-substep reference point) -> constraint rows (Jacobians,
- *   M^-1 J^T); in k_solve2 lane l owns velocity component l of its env and row dot products are DPP reductions.
+ * cooperative IK, in one launch with the first substep's preparation), 12 x { k_prep2 (one env per block of two waves, PrepLds:
+ * wave 0 bodies (FK) -> colliders (AABBs) -> candidate pairs (broadphase, 64 per sweep) -> active pairs (cooperative narrowphase,
+ * 8 lanes per pair) -> manifolds -> contact list, beside wave 1 joint subspaces -> arm links (CRBA / RNEA about a per-substep
+ * reference point) -> fp64 Cholesky -> v* -> unit rows; joined for the contact rows (Jacobians, M^-1 J^T) -> per-env workspace),
+ * k_solve2 (two envs per wave: 50 PGS sweeps over register-resident rows + integration; lane l owns velocity component l of its
+ * env, row dot products are DPP reductions) }, k_calc_state (one wave per env: observation, reward, outputs).
  * The first design - the whole env step as ONE kernel, one wave per env, everything staged in LDS - is kept as k_step / k_reset:
  * the in-library cross-check (bit-identical to the split pipeline, tests/) and the path of rp_reset_to.
  *
@@ -29,7 +28,7 @@
 #define MAXACT 64            /* AABB-overlapping pairs examined per substep (shared cap with the oracle) */
 #define MAXROWC (3 * MAXC)
 #define RP_MAX_GROUPS 16      /* env groups (streams) rp_step can cut the envs into */
-#define SORT_KEYS 64          /* load classes for pairing envs in k_solve2: 8 * min(spanning, 7) + clamp(side-by-side slots - 6, 0, 7) */
+#define SORT_KEYS 64          /* load classes for pairing envs in k_solve2: 8 * min(folded slots, 7) + min((side-by-side slots - 1) / 2, 7) */
 #define SORT_REPS 8           /* histogram replicas (env & 7): one hot word would serialise ~4096 atomics at ~90 per us */
 #define SORT_BINS (SORT_KEYS * SORT_REPS)
 #define SORT_RANK_BITS 22     /* sort_slot = (bin << 22) | rank inside the bin: 512 bins, ranks < 4 M (rp_create bounds num_envs) */
@@ -2153,35 +2152,36 @@ __device__ __forceinline__ void copy_out(float* __restrict__ dst, const float* s
 /* ------------------------------------------------------------------ split pipeline: register-resident rows, 2 envs/wave,
  * two concurrent row streams per env.
  *
- * Velocity component d sits at lane position lane_pos(d) of its env's 32-lane half: arm dof i at lane i (DPP row 0),
- * scene joints and free bodies in DPP row 1.  The rows of a substep fall into two streams:
- *   A  rows on arm dofs only: motor i, lower/upper limit of dof i (unit rows J = +-e_i, B = +-M^-1[:, i]; the sign is
- *      folded into rhs and the bounds, which is exact), and the Panda finger gear (two entries)
- *   B  scene-joint motors (unit rows on their own dof), contact normals, contact frictions
- * A rows and B rows without an arm part act on disjoint velocity components, so they COMMUTE exactly: the canonical
- * sweep order (motors, scene-joint motors, limits, gear, normals, frictions) equals "all A rows, then all B rows"
- * and, when no contact involves the arm in this substep (flag `coupled` = 0), also equals running stream A in DPP row
- * 0 and stream B in DPP row 1 AT THE SAME TIME.  Waves whose two envs are both uncoupled take that path (PAR); the
- * others run the streams one after the other (SEQ) and fold the two DPP rows only for rows that span arm and
- * non-arm dofs.  Results are bit-identical to the sequential order.
+ * Velocity component d sits at lane position lane_pos(d) of its env's 32-lane half.  DPP row 0: arm dof i at lane i and the three
+ * translation components of the rotation-locked drawer behind them (rp_model.free_row0); DPP row 1: scene joints and the other free
+ * bodies.  The rows of a substep:
+ *   unit rows    motor i, lower / upper limit of arm dof i (J = +-e_i, B = +-M^-1[:, i]; the sign is folded into rhs and the
+ *                bounds, which is exact) in row 0; the motor of scene joint t in row 1, solved by the same instructions as arm motor t
+ *   gear         the Panda finger gear (two entries, row 0)
+ *   contacts     every contact touches row 0 only (arm against the world, drawer on its rails, arm against the drawer), row 1 only
+ *                (objects and scene-joint bodies against the world) or both (arm or drawer against an object / a scene-joint body)
+ * Rows of different DPP rows act on disjoint velocity components and COMMUTE exactly, so a register SLOT holds the s-th row-0
+ * contact in DPP row 0 and the s-th row-1 contact in DPP row 1 and one instruction sequence solves both; contacts that touch
+ * both rows come after all of them in the solver order (collide(), shared with the oracle), one per slot from the top end, with
+ * the two DPP rows' partial dot products folded.  If the slots of the two envs of a wave do not fit the 21 registers, every
+ * contact takes a folded slot of its own (same code, same results).  Results are bit-identical to the sequential order.
  *
- * Instruction budget (measured, tools/ubench): a dependent VALU op costs ~4.7 cycles, a DPP op that reads the
- * previous result 12, and with two waves per SIMD every 8-byte instruction costs ~7 issue cycles - so the sweep
- * loops hold nothing but the dependent chain and three broadcasts per row:
+ * Instruction budget (measured, tools/ubench): a dependent VALU op costs ~4.7 cycles, a DPP op that reads the previous result
+ * 12, and a DPP read needs two wait states after the VALU write of its source - so the sweep loops hold nothing but the
+ * dependent chain:
  *   - J, B of every contact row live in registers (lane = dof), expanded once in the prologue;
- *   - per-row scalars live LANE-DISTRIBUTED in "planes" (lane k of a plane register = the value of the row labelled
- *     k in that plane): rhs, lo, hi, accumulated impulse lam.  Once per sweep and plane, vector ops form the bounds
- *     of the step lo - lam, hi - lam (delta form of the row update, see pgs_update) and fold the sweep's steps into
- *     lam; a row reads its three scalars with one row broadcast each (v_mov_b32_dpp row_newbcast);
- *   - a unit row needs no dot product at all: lane i forms the step from its own dv and its own plane entries, one
- *     broadcast spreads it, dv += M^-1[:, i] * step.
+ *   - per-row scalars live LANE-DISTRIBUTED in "planes" (lane k of a plane register = the value of the row labelled k in that
+ *     plane): rhs, lo, hi, accumulated impulse lam.  Once per sweep and plane, vector ops form the bounds of the step lo - lam,
+ *     hi - lam (delta form of the row update, see pgs_update) and fold the sweep's steps into lam;
+ *   - a row's step forms in every lane from that lane's own plane entries - lane k's are the row's - and leaves lane k by one
+ *     row broadcast fused into dv += B * step (v_fmac_f32_dpp row_newbcast:k); the owner lanes are an SGPR-pair mask;
+ *   - a unit row needs no dot product at all (one fma, med3, the broadcast-fmac).
  * Planes and labels (label & 15 = lane, label >> 4 = register):
- *   M / L / U  motor, lower limit, upper limit of arm dof i at lane i        (DPP row 0; U lane 12 = gear row)
- *   B0, B1     label t: scene joint t (t < 3), normal of contact t - 3 (3 <= t < 24)
- *   F0x, F1x   friction direction 0 / 1 of contact c at the lane of its normal, so that mu * lam_normal is one
- *              vector multiply per sweep.
- * In the PAR path plane M shares registers with B0 (DPP row 0 = M, row 1 = B0) and step t handles motor t and label
- * t together. */
+ *   M / L / U  motor, lower limit, upper limit of arm dof i at lane i        (DPP row 0; U lane 12 = gear row); plane M's DPP
+ *              row 1 holds the scene-joint motors at lanes 0..2
+ *   N0, N1     normal of the contact in slot s at lane s & 15 of register s >> 4
+ *   F0x, F1x   friction direction 0 / 1 of that contact at the lane of its normal, so that mu * lam_normal is one vector
+ *              multiply per sweep. */
 #define NBJ 3                         /* scene-joint motor rows: labels [0, NBJ) of plane B0 */
 #define LBL_N NBJ                     /* normal row of contact c -> label LBL_N + c */
 #define NLBL (LBL_N + MAXC)           /* 24 */
