@@ -175,7 +175,7 @@ static_assert(offsetof(PrepLds, roff) % 16 == 0 && offsetof(PrepLds, slot) % 16 
 
 #ifdef RP_CLOCKS      /* profiling build only: per-wave phase timestamps of the last k_solve2 (1) / k_prep2 (2) launch */
 __device__ unsigned long long g_clk[32 * 4096];
-#define CLK_MARK(i) if (lane == 0) { g_clk[8 * blockIdx.x + (i)] = __builtin_readcyclecounter(); }
+#define CLK_MARK(i) if (lane == 0) { g_clk[8 * wb + (i)] = __builtin_readcyclecounter(); }      /* (k_solve2: wb = the wave's number in the launch) */
 #if RP_CLOCKS == 2
 #define PCLK(i) if (lane == 0) { g_clk[32 * (blockIdx.x & 4095) + (i)] = (i) >= 6 && (i) < 8 ? wall_clock64() : __builtin_readcyclecounter(); }
 #define CLK_MARK2(i)
@@ -2485,12 +2485,15 @@ __device__ __forceinline__ void generic_row(float Jr, float Br, float& dv, Plane
         : [J] "v"(Jr), [B] "v"(Br), [rhs] "v"(prhs), [lo] "v"(p.loP), [hi] "v"(p.hiP), [own] "s"(own), [k] "n"(K & 15));
 }
 
+#define SOLVE_WAVES 2                 /* k_solve2 waves per block */
 __device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, float* __restrict__ state, const float* __restrict__ ws, int env0, int N,
-                                                  const int* __restrict__ pair_env, int* __restrict__ sort_cnt_next, int* __restrict__ sort_slot, int debug_flags) {
-  __shared__ Solve2Lds L;
-  const int lane = threadIdx.x, half = lane >> 5, l = lane & 31, grp = l >> 4, l16 = lane & 15;
+                                                  const int* __restrict__ pair_env, int* __restrict__ sort_cnt_next, int* __restrict__ sort_slot, int debug_flags, Solve2Lds* Ls) {
+  /* the waves of a block work independently, each on its own pair of envs and its own LDS block Ls[wid] */
+  const int wid = threadIdx.x >> 6, wb = blockIdx.x * SOLVE_WAVES + wid;      /* wb: this wave's number in the launch */
+  Solve2Lds& L = Ls[wid];
+  const int lane = threadIdx.x & 63, half = lane >> 5, l = lane & 31, grp = l >> 4, l16 = lane & 15;
 #if defined(RP_CLOCKS) && RP_CLOCKS != 2
-  if (lane == 0) g_clk[8 * blockIdx.x + 4] = wall_clock64();
+  if (lane == 0) g_clk[8 * wb + 4] = wall_clock64();
 #endif
   CLK_MARK2(0)
 #ifdef RP_SOLVE_PAD_KB
@@ -2498,7 +2501,7 @@ __device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, floa
 #endif
   /* this wave's two envs: places 2b and 2b + 1 among the group's envs sorted by load class, heaviest first (table built
    * by the k_prep2 before this launch) */
-  const int place = blockIdx.x * 2 + half;
+  const int place = wb * 2 + half;
   const int pe = place < N - env0 ? pair_env[env0 + place] : -1;
   const int env = pe < 0 ? -1 : (pe & 0xFFFFFF), pe_nc = pe < 0 ? 0 : (pe >> 24);
   const bool valid = env >= 0;
@@ -2591,7 +2594,7 @@ __device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, floa
    * both rows (folded).  Two fixed ends keep the sweep's control flow two plain early-exit chains (a jump into the
    * middle of a chain makes the compiler build a flag-driven state machine).  contact_of(s) is this lane's contact
    * index in slot s, -1 if none. */
-  __syncthreads();
+  WSYNC();
   const float* S = L.stage[half];
   auto contact_of = [&](int s) {
     int c;
@@ -2642,13 +2645,13 @@ __device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, floa
 #pragma unroll
   for (int r = 0; r < 2; r++) { PN[r].lam = 0.f; PF[0][r].lam = 0.f; PF[1][r].lam = 0.f; }
   X0.lam = 0.f; PL.lam = 0.f; PU.lam = 0.f;
-  __syncthreads();                          /* rows are in registers: the staging area becomes the state records */
+  WSYNC();                          /* rows are in registers: the staging area becomes the state records */
   {
     float* st = L.st[half];
     st[l] = st_v0; st[l + 32] = st_v1; st[l + 64] = st_v2; st[l + 96] = st_v3;
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);    /* vmcnt(0): all row registers have landed before the sweep loop */
-  __syncthreads();
+  WSYNC();
   CLK_MARK2(1)
   /* counting sort by load class for the NEXT substep's pairing (the classes of this substep stand in for the next one's:
    * which two envs share a wave never changes any result - absent rows are exact no-ops - it only decides how long the
@@ -2657,7 +2660,7 @@ __device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, floa
   int sort_pos = 0, sort_bin = 0;
   if (l == 0 && valid) {
     int key = 8 * (my_nC < 7 ? my_nC : 7) + (my_nS < 1 ? 0 : (my_nS > 14 ? 7 : (my_nS - 1) >> 1));      /* side-by-side slots in steps of two: a resting scene has 2..6 */
-    sort_bin = key * SORT_REPS + ((blockIdx.x * 2 + half) & (SORT_REPS - 1));
+    sort_bin = key * SORT_REPS + ((wb * 2 + half) & (SORT_REPS - 1));
     sort_pos = atomicAdd(&sort_cnt_next[sort_bin], 1);
   }
   float dv = 0.f;
@@ -2745,7 +2748,7 @@ __device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, floa
   /* integrate: lane l holds velocity component lane_dof(l) of this half's env */
   float* st = L.st[half];
   float vnew = clampf(vstar + dv, -K_MAXVEL, K_MAXVEL);       /* btMultiBody::applyDeltaVeeMultiDof's clamp (never active in ordinary motion) */
-  __syncthreads();
+  WSYNC();
   CLK_MARK2(2)
   if (dd >= 0) {
     if (dd < n) {
@@ -2760,7 +2763,7 @@ __device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, floa
       st[ST_JQ + k] += K_DT * vnew;
     }
   }
-  __syncthreads();
+  WSYNC();
   if (l < m->n_free) {
     float* f = &st[ST_FREE + 13 * l];
     V3 v = ld3(f + 7), wv = ld3(f + 10);
@@ -2776,7 +2779,7 @@ __device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, floa
     float nr = 1.f / sqrtf(qn.x * qn.x + qn.y * qn.y + qn.z * qn.z + qn.w * qn.w);
     f[3] = qn.x * nr; f[4] = qn.y * nr; f[5] = qn.z * nr; f[6] = qn.w * nr;
   }
-  __syncthreads();
+  WSYNC();
   if (valid) {
     float* r = state + (size_t)env * RP_REC_FLOATS;
     for (int k = l; k < RP_REC_FLOATS; k += 32) r[k] = st[k];
@@ -2789,19 +2792,274 @@ __device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, floa
 #if defined(RP_CLOCKS) && RP_CLOCKS != 2
   CLK_MARK(3)
   if (lane == 0) {
-    g_clk[8 * blockIdx.x + 5] = wall_clock64();
+    g_clk[8 * wb + 5] = wall_clock64();
     int na = n + __popc(maskL) + __popc(maskU);
-    g_clk[8 * blockIdx.x + 6] = (unsigned long long)na | ((unsigned long long)nS << 8) | ((unsigned long long)nC << 16) | ((unsigned long long)(par ? 1 : 0) << 24);
+    g_clk[8 * wb + 6] = (unsigned long long)na | ((unsigned long long)nS << 8) | ((unsigned long long)nC << 16) | ((unsigned long long)(par ? 1 : 0) << 24);
     unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    g_clk[8 * blockIdx.x + 7] = ((unsigned long long)xcc << 32) | hw;
+    g_clk[8 * wb + 7] = ((unsigned long long)xcc << 32) | hw;
   }
 #endif
 }
+/* ------------------------------------------------------------------ k_solve2, uncoupled envs: FOUR envs per pair of waves.
+ * When no contact of an env touches both halves of the velocity layout (the usual case: block on table, drawer on its rails), the rows of
+ * DPP row 0 (arm motors, limits, gear, the drawer's contacts) and those of DPP row 1 (scene-joint motors, the objects' contacts) never
+ * meet: two independent streams.  solve2_body above zips them in one wave (motor t beside scene joint t, slot s of row 0 beside slot s of
+ * row 1) and half of its lanes idle most of the time - the limit rows have no partner, the block has more contacts than the drawer.  Here
+ * a block's two waves take four such envs and one STREAM each: wave 0 solves the row-0 streams of all four (one env per DPP row), wave 1
+ * their row-1 streams.  Same row bodies, same order inside each stream, hence the same bits - with half the instructions per env and a
+ * shorter chain (row-0 stream: ~20 unit rows + the drawer's 6; row-1 stream: 3 unit rows + the block's 12).  A block takes this path if
+ * all its four envs are uncoupled and their contacts fit the slots below; otherwise its waves run solve2_body on two envs each. */
+#define S4_SLOTS0 8      /* row-0 contact slots (wave 0) */
+#define S4_SLOTS1 16     /* row-1 contact slots (wave 1): one plane register */
+template <int T>
+__device__ __forceinline__ void solve4_body(const DevModel* __restrict__ m, float* __restrict__ state, const float* __restrict__ ws, int env0, int N,
+                                            const int* __restrict__ pair_env, int* __restrict__ sort_cnt_next, int* __restrict__ sort_slot, int debug_flags, float* __restrict__ stl) {
+  constexpr int NSL = T == 0 ? S4_SLOTS0 : S4_SLOTS1;
+  const int lane = threadIdx.x & 63, g = lane >> 4, l16 = lane & 15;
+  const int place = blockIdx.x * 4 + g;
+  const int pe = place < N - env0 ? pair_env[env0 + place] : -1;
+  const int env = pe < 0 ? -1 : (pe & 0xFFFFFF);
+  const bool valid = env >= 0;
+  const float* w = ws + (size_t)(valid ? env : 0) * W3_FLOATS;
+  const int n = m->n_arm;
+  const float4 h0 = *(const float4*)&w[W3_HDR], h1 = *(const float4*)&w[W3_HDR + 4];
+  const int my_mL = valid ? __float_as_int(h0.x) : 0, my_mU = valid ? __float_as_int(h0.y) : 0;
+  const int my_nj = valid ? __float_as_int(h0.z) : 0, my_nc = valid ? __float_as_int(h0.w) : 0;
+  const int my_nA = valid ? __float_as_int(h1.x) : 0, my_nB = valid ? __float_as_int(h1.y) : 0;
+  const int my_gr = valid ? __float_as_int(h1.z) : 0;
+#define W4_OR(x) (__builtin_amdgcn_readlane(x, 0) | __builtin_amdgcn_readlane(x, 16) | __builtin_amdgcn_readlane(x, 32) | __builtin_amdgcn_readlane(x, 48))
+#define W4_MAX(x) max(max(__builtin_amdgcn_readlane(x, 0), __builtin_amdgcn_readlane(x, 16)), max(__builtin_amdgcn_readlane(x, 32), __builtin_amdgcn_readlane(x, 48)))
+  const int maskL = T == 0 ? W4_OR(my_mL) : 0, maskU = T == 0 ? W4_OR(my_mU) : 0, gear = T == 0 ? W4_OR(my_gr) : 0;
+  const int my_ns = T == 0 ? my_nA : my_nB;                  /* this stream's contacts */
+  const int nS = W4_MAX(my_ns), nJ = T == 0 ? 0 : W4_MAX(my_nj);
+  const int dd = lane_dof(m, T == 0 ? l16 : 16 + l16);      /* velocity component owned by this lane, -1 if none */
+  /* the four state records: one DPP row each */
+  float* st = stl + RP_REC_FLOATS * g;
+  {
+    const float* r = state + (size_t)(valid ? env : 0) * RP_REC_FLOATS;
+#pragma unroll
+    for (int k = 0; k < RP_REC_FLOATS / 16; k++) st[l16 + 16 * k] = r[l16 + 16 * k];
+  }
+  const float* wzero = w + W3_ZERO;
+  auto ldz = [&](const float* q, bool c) { return *(c ? q : wzero); };
+  const float vstar = ldz(&w[W3_VSTAR + (dd >= 0 ? dd : 0)], valid && dd >= 0);
+  /* unit rows (the planes of solve2_body, one DPP row's worth) */
+  const float* wa = w + W3_A;
+  const float* bj = w + W3_BJ;
+  const bool arm_lane = T == 0 && valid && l16 < n;
+  const int ia = arm_lane ? l16 : 0;
+  const bool jl = T == 1 && valid && l16 < my_nj;
+  const int kj = jl ? l16 : 0;
+  const float dinvX = T == 0 ? ldz(&wa[ia], arm_lane) : ldz(&bj[kj], jl);
+  Plane X0, PL, PU;
+  X0.rhs = T == 0 ? ldz(&wa[16 + ia], arm_lane) : ldz(&bj[4 + kj], jl);
+  X0.lo = T == 0 ? ldz(&wa[32 + ia], arm_lane) : ldz(&bj[8 + kj], jl);
+  X0.hi = T == 0 ? ldz(&wa[48 + ia], arm_lane) : ldz(&bj[12 + kj], jl);
+  PL.rhs = PL.lo = PL.hi = PU.rhs = PU.lo = PU.hi = 0.f;
+  PL.loP = PL.hiP = PL.dacc = PU.loP = PU.hiP = PU.dacc = 0.f;
+  float Jg = 0.f, Bg = 0.f;
+  float Bm[12];
+  if (T == 0) {
+    PL.rhs = ldz(&wa[64 + ia], arm_lane); PL.lo = ldz(&wa[80 + ia], arm_lane); PL.hi = ldz(&wa[96 + ia], arm_lane);
+    PU.rhs = ldz(&wa[112 + ia], arm_lane); PU.lo = ldz(&wa[128 + ia], arm_lane); PU.hi = ldz(&wa[144 + ia], arm_lane);
+    if (debug_flags & 2) {      /* first substep after k_action_prep: the motor rows from the record's fresh targets (build_small_rows' formula) */
+      const float* r = state + (size_t)(valid ? env : 0) * RP_REC_FLOATS;
+      const float mode = r[ST_MMODE + ia], tgt = r[ST_MTARGET + ia], mx = r[ST_MMAXIMP + ia], qi = r[ST_Q + ia];
+      const float des = mode != 0.f ? K_KP * (tgt - qi) / K_DT : 0.f;
+      const float rhs = (des - vstar) * dinvX;
+      if (arm_lane) { X0.rhs = rhs; X0.lo = -mx; X0.hi = mx; }
+    }
+    {
+      const float* gq = w + W3_GEAR;
+      float g0 = gq[0], g1 = gq[1], ratio = gq[2], gd = gq[3], g4 = gq[4], g5 = gq[5], g6 = gq[6];
+      int a = __float_as_int(g0) & 15, b = __float_as_int(g1) & 15;
+      float ma = w[W3_MINV + ia * 12 + (a < 12 ? a : 0)], mb = w[W3_MINV + ia * 12 + (b < 12 ? b : 0)];
+      bool on = arm_lane && my_gr != 0;
+      Jg = on ? (l16 == a ? gd : (l16 == b ? ratio * gd : 0.f)) : 0.f;
+      Bg = on ? ma + ratio * mb : 0.f;
+      bool gl = valid && l16 == GEAR_LANE && my_gr != 0;
+      PU.rhs = gl ? g4 : PU.rhs; PU.lo = gl ? g5 : PU.lo; PU.hi = gl ? g6 : PU.hi;
+    }
+#pragma unroll
+    for (int t = 0; t < 12; t++) Bm[t] = ldz(&w[W3_MINV + ia * 12 + t], arm_lane && t < n);
+  } else {
+    const float colJ = ldz(&bj[16 + kj], jl);
+#pragma unroll
+    for (int t = 0; t < 12; t++) Bm[t] = (t < LBL_N && l16 == t) ? colJ : 0.f;
+  }
+  /* contact slots: slot s = this stream's s-th contact, its scalars at lane s of the planes */
+  const int* slot_tab = (const int*)(w + W3_SLOT) + (T == 0 ? 21 : 0);
+  PlaneN PN; Plane PF[2];
+  float muN;
+  {
+    const bool on = valid && l16 < NSL && l16 < my_ns;
+    const int cc = on ? slot_tab[l16] : 0;
+    PN.rhs = ldz(&w[W3_ROWS + 4 * cc], on); PN.lo = 0.f; PN.hi = ldz(&w[W3_ROWT + 4 * cc + 1], on);
+    PN.cfm = ldz(&w[W3_ROWS + 4 * cc + 1], on); PN.rhsE = PN.rhs;
+    muN = ldz(&w[W3_MU + cc], on);
+#pragma unroll
+    for (int d = 0; d < 2; d++) { PF[d].rhs = ldz(&w[W3_ROWS + 4 * ((on ? my_nc : 0) + 2 * cc + d)], on); PF[d].lo = 0.f; PF[d].hi = 0.f; }
+  }
+  float JN[NSL], BN[NSL], JF[2][NSL], BF[2][NSL];
+#pragma unroll
+  for (int s = 0; s < NSL; s++) {
+    const bool used = valid && s < my_ns;
+    const int c = used ? slot_tab[s] : 0;
+    const int off = used ? __float_as_int(w[W3_ROFF + c]) : 0;
+    const int i1 = dd - (off >> 8), i0 = dd - (off & 255);
+    const int idx = (unsigned)i1 < 6u ? 12 + i1 : ((unsigned)i0 < 12u ? i0 : -1);
+    const bool ok = used && dd >= 0 && idx >= 0;
+    const int rn = ROWW * c + idx, rf = ROWW * (my_nc + 2 * c) + idx;
+    JN[s] = ldz(&w[W3_J + (ok ? rn : 0)], ok); BN[s] = ldz(&w[W3_B + (ok ? rn : 0)], ok);
+    JF[0][s] = ldz(&w[W3_J + (ok ? rf : 0)], ok); BF[0][s] = ldz(&w[W3_B + (ok ? rf : 0)], ok);
+    JF[1][s] = ldz(&w[W3_J + (ok ? rf + ROWW : 0)], ok); BF[1][s] = ldz(&w[W3_B + (ok ? rf + ROWW : 0)], ok);
+  }
+  PN.lam = 0.f; PF[0].lam = 0.f; PF[1].lam = 0.f; X0.lam = 0.f; PL.lam = 0.f; PU.lam = 0.f;
+  __builtin_amdgcn_s_waitcnt(0x0F70);    /* vmcnt(0): all row registers have landed before the sweep loop */
+  /* counting sort by load class for the next substep's pairing: one atomic per env, from the row-1 wave */
+  int sort_pos = 0, sort_bin = 0;
+  if (T == 1 && l16 == 0 && valid) {
+    const int my_nS = max(my_nA, my_nB);
+    const int key = my_nS < 1 ? 0 : (my_nS > 14 ? 7 : (my_nS - 1) >> 1);
+    sort_bin = key * SORT_REPS + (place & (SORT_REPS - 1));
+    sort_pos = atomicAdd(&sort_cnt_next[sort_bin], 1);
+  }
+  float dv = 0.f;
+#define REP3(M) M(0) M(1) M(2)
+#define REP8(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
+#define REP12(M) REP8(M) M(8) M(9) M(10) M(11)
+#define REP16(M) REP12(M) M(12) M(13) M(14) M(15)
+#pragma unroll 1
+  for (int it = 0; it < K_NITER; it++) {
+    /* in-loop copies of the guards, re-read every sweep so that they stay s_cmp + s_cbranch */
+    int nS_it = __builtin_amdgcn_readfirstlane(nS), mL_it = __builtin_amdgcn_readfirstlane(maskL), mU_it = __builtin_amdgcn_readfirstlane(maskU);
+    int gr_it = __builtin_amdgcn_readfirstlane(gear), nJ_it = __builtin_amdgcn_readfirstlane(nJ);
+    asm volatile("" : "+s"(nS_it), "+s"(mL_it), "+s"(mU_it), "+s"(gr_it), "+s"(nJ_it));
+    plane_begin(X0); nplane_begin(PN);
+    if (T == 0) { plane_begin(PL); plane_begin(PU); }
+    asm volatile("s_nop 1" : "+v"(X0.loP), "+v"(X0.hiP), "+v"(PL.loP), "+v"(PL.hiP), "+v"(PU.loP), "+v"(PU.hiP), "+v"(PN.loP), "+v"(PN.hiP), "+v"(PN.rhsE));
+#define UNIT_M(t) unit_row<(t)>(dinvX, Bm[t], dv, X0, l16);
+#define UNIT_L(i) unit_row<(i)>(dinvX, Bm[i], dv, PL, l16); unit_row<(i)>(dinvX, Bm[i], dv, PU, l16);
+#define UNIT_LO(i) unit_row<(i)>(dinvX, Bm[i], dv, PL, l16);
+#define UNIT_UP(i) unit_row<(i)>(dinvX, Bm[i], dv, PU, l16);
+    if (T == 0) {
+      REP12(UNIT_M)
+      /* limits: the guards of solve2_body */
+      if (mL_it & 0x03F) { if (mU_it & 0x03F) { UNIT_L(0) UNIT_L(1) UNIT_L(2) UNIT_L(3) UNIT_L(4) UNIT_L(5) } else { UNIT_LO(0) UNIT_LO(1) UNIT_LO(2) UNIT_LO(3) UNIT_LO(4) UNIT_LO(5) } }
+      else if (mU_it & 0x03F) { UNIT_UP(0) UNIT_UP(1) UNIT_UP(2) UNIT_UP(3) UNIT_UP(4) UNIT_UP(5) }
+      if (mU_it & 0x3C0) {
+        if (mL_it & 0xFC0) { UNIT_L(6) UNIT_L(7) UNIT_L(8) UNIT_L(9) UNIT_L(10) UNIT_L(11) } else { UNIT_UP(6) UNIT_UP(7) UNIT_UP(8) UNIT_UP(9) UNIT_UP(10) UNIT_UP(11) }
+      } else {
+        if (mL_it & 0x3C0) { UNIT_LO(6) UNIT_LO(7) UNIT_LO(8) UNIT_LO(9) }
+        if (mL_it & 0xC00) { if (mU_it & 0xC00) { UNIT_L(10) UNIT_L(11) } else { UNIT_LO(10) UNIT_LO(11) } }
+        else if (mU_it & 0xC00) { UNIT_UP(10) UNIT_UP(11) }
+      }
+      if (gr_it) generic_row<GEAR_LANE, false>(Jg, Bg, dv, PU, l16, PU.rhs);
+      plane_end(X0); plane_end(PL); plane_end(PU);
+    } else {
+      if (nJ_it > 0) { REP3(UNIT_M) }
+      plane_end(X0);
+    }
+#undef UNIT_M
+#undef UNIT_L
+#undef UNIT_LO
+#undef UNIT_UP
+#define NRM4(s) if (nS_it <= (s)) goto nrm_done; generic_row<(s), false>(JN[s], BN[s], dv, PN, l16, PN.rhsE);
+    if (T == 0) { REP8(NRM4) } else { REP16(NRM4) }
+#undef NRM4
+  nrm_done:
+    plane_end(PN);
+    if (nS_it > 0) {
+      fplane_begin(PF[0], muN * PN.lam, PN.lam); fplane_begin(PF[1], muN * PN.lam, PN.lam);
+      asm volatile("s_nop 1" : "+v"(PF[0].loP), "+v"(PF[0].hiP), "+v"(PF[1].loP), "+v"(PF[1].hiP));
+#define FRC4(s) if (nS_it <= (s)) goto frc_done; generic_row<(s), false>(JF[0][s], BF[0][s], dv, PF[0], l16, PF[0].rhs); generic_row<(s), false>(JF[1][s], BF[1][s], dv, PF[1], l16, PF[1].rhs);
+      if (T == 0) { REP8(FRC4) } else { REP16(FRC4) }
+#undef FRC4
+    frc_done:
+      plane_end(PF[0]); plane_end(PF[1]);
+    }
+  }
+#undef REP3
+#undef REP8
+#undef REP12
+#undef REP16
+#undef W4_OR
+#undef W4_MAX
+  /* integrate this stream's components and bodies; write this stream's fields of the records */
+  const float vnew = clampf(vstar + dv, -K_MAXVEL, K_MAXVEL);
+  const int nfree = m->n_free;
+  WSYNC();
+  if (dd >= 0) {
+    if (dd < n) { st[ST_QD + dd] = vnew; st[ST_Q + dd] += K_DT * vnew; }
+    else if (dd < n + 6 * nfree) { int k = (dd - n) / 6, c = (dd - n) % 6; st[ST_FREE + 13 * k + 7 + c] = vnew; }
+    else { int k = dd - n - 6 * nfree; st[ST_JQD + k] = vnew; st[ST_JQ + k] += K_DT * vnew; }
+  }
+  WSYNC();
+  const bool mine = l16 < nfree && (((m->free_row0 >> l16) & 1) != 0) == (T == 0);      /* free body l16 belongs to this stream */
+  if (mine) {
+    float* f = &st[ST_FREE + 13 * l16];
+    V3 v = ld3(f + 7), wv = ld3(f + 10);
+    st3(f, ld3(f) + v * K_DT);
+    float wn = norm(wv);
+    if (wn > 0.7853981633974483f / K_DT) wn = 0.7853981633974483f / K_DT;
+    V3 ax;
+    if (wn < 0.001f) ax = wv * (0.5f * K_DT - K_DT * K_DT * K_DT * 0.020833333333f * wn * wn);
+    else ax = wv * (sinf(0.5f * wn * K_DT) / wn);
+    Q4 dq = {ax.x, ax.y, ax.z, cosf(0.5f * wn * K_DT)};
+    Q4 q0 = {f[3], f[4], f[5], f[6]};
+    Q4 qn = qmul(dq, q0);
+    float nr = 1.f / sqrtf(qn.x * qn.x + qn.y * qn.y + qn.z * qn.z + qn.w * qn.w);
+    f[3] = qn.x * nr; f[4] = qn.y * nr; f[5] = qn.z * nr; f[6] = qn.w * nr;
+  }
+  WSYNC();
+  if (valid) {
+    float* r = state + (size_t)env * RP_REC_FLOATS;
+    if (T == 0) {
+      if (l16 < n) { r[ST_Q + l16] = st[ST_Q + l16]; r[ST_QD + l16] = st[ST_QD + l16]; }
+    } else {
+      if (l16 < m->n_j1) { r[ST_JQ + l16] = st[ST_JQ + l16]; r[ST_JQD + l16] = st[ST_JQD + l16]; }
+      if (l16 == 0) {
+        int sp = sort_pos;
+        asm volatile("" : "+v"(sp));
+        sort_slot[env] = (sort_bin << SORT_RANK_BITS) | sp;
+      }
+    }
+    for (int k = 0; k < nfree; k++)
+      if ((((m->free_row0 >> k) & 1) != 0) == (T == 0) && l16 < 13) r[ST_FREE + 13 * k + l16] = st[ST_FREE + 13 * k + l16];
+  }
+}
+
+/* does this block take the four-env path?  Decided from the same headers by both waves alike. */
+__device__ __forceinline__ bool solve4_eligible(const float* __restrict__ ws, int env0, int N, const int* __restrict__ pair_env, int debug_flags) {
+  const int lane = threadIdx.x & 63, g = lane >> 4;
+  const int place = blockIdx.x * 4 + g;
+  const int pe = place < N - env0 ? pair_env[env0 + place] : -1;
+  /* the entry carries the env's contact count in its top byte.  The mask is inline asm on purpose: written in C, hipcc (ROCm 7.2) drops it here - it turns
+   * (pe & 0xFFFFFF) * W3_FLOATS into a 24-bit multiply and then widens that to v_mad_u64_u32 on the unmasked register: wild address, aperture violation */
+  int envm;
+  asm volatile("v_and_b32 %0, 0xffffff, %1" : "=v"(envm) : "v"(pe));
+  const bool valid = pe >= 0;
+  const float* w = ws + (size_t)(valid ? envm : 0) * W3_FLOATS;
+  const float4 h1 = *(const float4*)&w[W3_HDR + 4];
+  const bool bad = valid && (__float_as_int(h1.w) != 0 || __float_as_int(h1.x) > S4_SLOTS0 || __float_as_int(h1.y) > S4_SLOTS1);
+#ifdef RP_S4_OFF            /* timing ablation: every block takes the two-env path */
+  return false;
+#endif
+  return __ballot(bad) == 0ull && !(debug_flags & 1);
+}
+
 #define SOLVE2_ARGS const DevModel* __restrict__ m, float* __restrict__ state, const float* __restrict__ ws, int env0, int N, \
                     const int* __restrict__ pair_env, int* __restrict__ sort_cnt_next, int* __restrict__ sort_slot, int debug_flags
-__global__ void __launch_bounds__(64, 2) k_solve2(SOLVE2_ARGS) { solve2_body(m, state, ws, env0, N, pair_env, sort_cnt_next, sort_slot, debug_flags); }
-__global__ void __launch_bounds__(64, 2) k_settle_solve(SOLVE2_ARGS) { solve2_body(m, state, ws, env0, N, pair_env, sort_cnt_next, sort_slot, debug_flags); }
+#define SOLVE_DISPATCH \
+  __shared__ Solve2Lds Ls[SOLVE_WAVES]; \
+  static_assert(sizeof(Solve2Lds) >= 4 * RP_REC_FLOATS * sizeof(float), "the four-env path keeps four state records where the two-env path stages its rows"); \
+  if (solve4_eligible(ws, env0, N, pair_env, debug_flags)) { \
+    if ((threadIdx.x >> 6) == 0) solve4_body<0>(m, state, ws, env0, N, pair_env, sort_cnt_next, sort_slot, debug_flags, (float*)&Ls[0]); \
+    else solve4_body<1>(m, state, ws, env0, N, pair_env, sort_cnt_next, sort_slot, debug_flags, (float*)&Ls[1]); \
+  } else solve2_body(m, state, ws, env0, N, pair_env, sort_cnt_next, sort_slot, debug_flags, Ls);
+__global__ void __launch_bounds__(64 * SOLVE_WAVES, 2) k_solve2(SOLVE2_ARGS) { SOLVE_DISPATCH }
+__global__ void __launch_bounds__(64 * SOLVE_WAVES, 2) k_settle_solve(SOLVE2_ARGS) { SOLVE_DISPATCH }
 
 
 /* first pairing of a group's envs (before any load class is known): everything in the lightest class, in index order */

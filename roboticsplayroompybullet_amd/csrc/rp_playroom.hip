@@ -269,7 +269,7 @@ static int reset_split(rp_handle h, const uint8_t* mask, const rp_out* out, hipS
     int par = 0;
     for (int i = 0; i < K_NSETTLE; i++) {
       hipLaunchKernelGGL(k_settle_prep, dim3(M), dim3(PREP_THREADS), 0, s, h->dev_model, h->rs_state, h->ws, 0, M, cnt[par], cnt[par ^ 1], h->rs_sort_slot, h->rs_pair, (const int*)nullptr);
-      hipLaunchKernelGGL(k_settle_solve, dim3((M + 1) / 2), dim3(64), 0, s, h->dev_model, h->rs_state, h->ws, 0, M, h->rs_pair, cnt[par ^ 1], h->rs_sort_slot, h->debug_flags);
+      hipLaunchKernelGGL(k_settle_solve, dim3((M + 2 * SOLVE_WAVES - 1) / (2 * SOLVE_WAVES)), dim3(64 * SOLVE_WAVES), 0, s, h->dev_model, h->rs_state, h->ws, 0, M, h->rs_pair, cnt[par ^ 1], h->rs_sort_slot, h->debug_flags);
       par ^= 1;
     }
     hipLaunchKernelGGL(k_reset_finish, dim3(M), dim3(64), 0, s, h->dev_model, h->rs_state, h->state, h->rs_idx, h->rs_meta, op, M, seed, off);
@@ -347,7 +347,11 @@ int rp_step(rp_handle h, const float* action, const rp_out* out, void* stream) {
     int G = ev ? 1 : h->groups;
     if (G > (N + 63) / 64) G = (N + 63) / 64;
     int e = 2;
+#ifdef RP_SYNC_DEBUG      /* debugging builds: synchronise after every launch of the chain and say which one died */
+#define TIMED(launch) do { fprintf(stderr, "[rp sync] launching %.40s\n", #launch); fflush(stderr); launch; hipError_t e_ = hipDeviceSynchronize(); fprintf(stderr, "[rp sync]   -> %d\n", (int)e_); fflush(stderr); } while (0)
+#else
 #define TIMED(launch) do { if (ev) hipEventRecord(ev[e++], gs); launch; if (ev) hipEventRecord(ev[e++], gs); } while (0)
+#endif
     /* groups by load: rank all envs by the load class of the latest k_solve2 and cut the ranking into the G groups */
     GroupBounds gb;
     {
@@ -404,16 +408,22 @@ int rp_step(rp_handle h, const float* action, const rp_out* out, void* stream) {
       for (int g = 0; g < G; g++) {
         const GroupCtx& c = gc[g];
         hipStream_t gs = c.gs;
-        if (merged)
+        if (merged) {
+#ifdef RP_SYNC_DEBUG
+          fprintf(stderr, "[rp sync] before k_action_prep: %d\n", (int)hipDeviceSynchronize()); fflush(stderr);
+#endif
           hipLaunchKernelGGL(k_action_prep, dim3((c.ng + 7) / 8 + c.ng), dim3(PREP_THREADS), 0, gs, h->dev_model, h->state, h->ws, c.e0, c.e1, c.gcnt[par], c.gcnt[par ^ 1], h->sort_slot,
                              h->pair_env, member, action, op.target_poses, (c.ng + 7) / 8);
-        else
+#ifdef RP_SYNC_DEBUG
+          fprintf(stderr, "[rp sync] after k_action_prep: %d\n", (int)hipDeviceSynchronize()); fflush(stderr);
+#endif
+        } else
           TIMED(hipLaunchKernelGGL(k_prep2, dim3(c.ng), dim3(PREP_THREADS), 0, gs, h->dev_model, h->state, h->ws, c.e0, c.e1, c.gcnt[par], c.gcnt[par ^ 1], h->sort_slot, h->pair_env, member));
       }
       for (int g = 0; g < G; g++) {
         const GroupCtx& c = gc[g];
         hipStream_t gs = c.gs;
-        TIMED(hipLaunchKernelGGL(k_solve2, dim3((c.ng + 1) / 2), dim3(64), 0, gs, h->dev_model, h->state, h->ws, c.e0, c.e1, h->pair_env, c.gcnt[par ^ 1], h->sort_slot,
+        TIMED(hipLaunchKernelGGL(k_solve2, dim3((c.ng + 2 * SOLVE_WAVES - 1) / (2 * SOLVE_WAVES)), dim3(64 * SOLVE_WAVES), 0, gs, h->dev_model, h->state, h->ws, c.e0, c.e1, h->pair_env, c.gcnt[par ^ 1], h->sort_slot,
                                  h->debug_flags | (merged ? 2 : 0)));
       }
       par ^= 1;
