@@ -2904,6 +2904,7 @@ __device__ __forceinline__ void solve4_body(const DevModel* __restrict__ m, floa
   float JN[NSL], BN[NSL], JF[2][NSL], BF[2][NSL];
 #pragma unroll
   for (int s = 0; s < NSL; s++) {
+    if (s >= nS) { JN[s] = BN[s] = JF[0][s] = BF[0][s] = JF[1][s] = BF[1][s] = 0.f; continue; }      /* (wave-uniform) no env of the four has a contact here: no loads */
     const bool used = valid && s < my_ns;
     const int c = used ? slot_tab[s] : 0;
     const int off = used ? __float_as_int(w[W3_ROFF + c]) : 0;
