@@ -31,3 +31,7 @@ print('ncon hist', np.bincount(a[:, 1], minlength=22))
 print('cum frac <=k', np.round(np.cumsum(np.bincount(a[:, 1], minlength=22)) / len(a), 3))
 pair = np.maximum(a[0::2, 1], a[1::2, 1])
 print('pair-max ncon cum', np.round(np.cumsum(np.bincount(pair, minlength=22)) / len(pair), 3))
+print('env-substeps with contacts that touch both halves of the velocity layout (nC > 0: the two-env solve path): %.4f; with more than 16 row-1 or 8 row-0 contacts: n/a' % (span > 0).mean())
+q = (span > 0).reshape(-1, 4).any(axis=1) if len(span) % 4 == 0 else None
+if q is not None:
+    print('quads (4 consecutive envs in index order - the launch pairs by load class, so this is an upper bound) with a coupled env: %.4f' % q.mean())
