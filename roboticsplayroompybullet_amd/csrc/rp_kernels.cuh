@@ -2488,7 +2488,9 @@ __device__ __forceinline__ void generic_row(float Jr, float Br, float& dv, Plane
 #define SOLVE_WAVES 2                 /* k_solve2 waves per block */
 __device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, float* __restrict__ state, const float* __restrict__ ws, int env0, int N,
                                                   const int* __restrict__ pair_env, int* __restrict__ sort_cnt_next, int* __restrict__ sort_slot, int debug_flags, Solve2Lds* Ls) {
-  /* the waves of a block work independently, each on its own pair of envs and its own LDS block Ls[wid] */
+  /* the waves of a block work independently, each on its own pair of envs and its own LDS block Ls[wid].  Few blocks come here (the ones with a coupled env:
+   * 1 - 2 % of the envs) and they last twice as long as the four-env blocks: they are the launch's critical path (raising their wave priority changes nothing:
+   * they already run alone for the second half of the launch) */
   const int wid = threadIdx.x >> 6, wb = blockIdx.x * SOLVE_WAVES + wid;      /* wb: this wave's number in the launch */
   Solve2Lds& L = Ls[wid];
   const int lane = threadIdx.x & 63, half = lane >> 5, l = lane & 31, grp = l >> 4, l16 = lane & 15;
@@ -3052,12 +3054,19 @@ __device__ __forceinline__ bool solve4_eligible(const float* __restrict__ ws, in
 
 #define SOLVE2_ARGS const DevModel* __restrict__ m, float* __restrict__ state, const float* __restrict__ ws, int env0, int N, \
                     const int* __restrict__ pair_env, int* __restrict__ sort_cnt_next, int* __restrict__ sort_slot, int debug_flags
+#if defined(RP_CLOCKS) && RP_CLOCKS != 2      /* profiling build: wall clock at both ends of a four-env wave, bit 30 of word 6 = "took the four-env path" */
+#define S4_CLK(i) if ((threadIdx.x & 63) == 0) { const int wb_ = blockIdx.x * SOLVE_WAVES + (threadIdx.x >> 6); g_clk[8 * wb_ + (i)] = wall_clock64(); g_clk[8 * wb_ + 6] = 1ull << 30; }
+#else
+#define S4_CLK(i)
+#endif
 #define SOLVE_DISPATCH \
   __shared__ Solve2Lds Ls[SOLVE_WAVES]; \
   static_assert(sizeof(Solve2Lds) >= 4 * RP_REC_FLOATS * sizeof(float), "the four-env path keeps four state records where the two-env path stages its rows"); \
   if (solve4_eligible(ws, env0, N, pair_env, debug_flags)) { \
+    S4_CLK(4) \
     if ((threadIdx.x >> 6) == 0) solve4_body<0>(m, state, ws, env0, N, pair_env, sort_cnt_next, sort_slot, debug_flags, (float*)&Ls[0]); \
     else solve4_body<1>(m, state, ws, env0, N, pair_env, sort_cnt_next, sort_slot, debug_flags, (float*)&Ls[1]); \
+    S4_CLK(5) \
   } else solve2_body(m, state, ws, env0, N, pair_env, sort_cnt_next, sort_slot, debug_flags, Ls);
 __global__ void __launch_bounds__(64 * SOLVE_WAVES, 2) k_solve2(SOLVE2_ARGS) { SOLVE_DISPATCH }
 __global__ void __launch_bounds__(64 * SOLVE_WAVES, 2) k_settle_solve(SOLVE2_ARGS) { SOLVE_DISPATCH }

@@ -73,3 +73,12 @@ print('distinct CUs used', len(u), 'waves per CU: min %d p50 %d max %d' % (cnt.m
 key2 = key * 10 + simd
 u2, cnt2 = np.unique(key2, return_counts=True)
 print('distinct SIMDs used', len(u2), 'waves per SIMD: min %d p50 %d max %d' % (cnt2.min(), np.median(cnt2), cnt2.max()))
+four = (a[:, 6] >> 30) & 1
+if four.any():
+    d4 = (a[four == 1, 5] - a[four == 1, 4]) / 100.0
+    d2 = (a[four == 0, 5] - a[four == 0, 4]) / 100.0
+    print('waves on the four-env path: %d of %d; their duration us: p50 %.1f p90 %.1f max %.1f; two-env path waves: %d, duration us p50 %.1f max %.1f' % (
+        int(four.sum()), nb, np.median(d4), np.percentile(d4, 90), d4.max(), int((four == 0).sum()), np.median(d2) if len(d2) else 0, d2.max() if len(d2) else 0))
+    e4 = (a[four == 1, 5] - a[:, 4].min()) / 100.0
+    e2 = (a[four == 0, 5] - a[:, 4].min()) / 100.0
+    print('end offsets us: four-env path max %.1f; two-env path max %.1f' % (e4.max(), e2.max() if len(e2) else 0))
