@@ -2486,6 +2486,14 @@ __device__ __forceinline__ void generic_row(float Jr, float Br, float& dv, Plane
 }
 
 #define SOLVE_WAVES 2                 /* k_solve2 waves per block */
+/* a pair_env entry carries its env's contact count in the top byte.  The mask is inline asm on purpose: written in C, hipcc (ROCm 7.2) can drop it - in
+ * solve4_eligible it turned (pe & 0xFFFFFF) * W3_FLOATS into a 24-bit multiply and then widened that to v_mad_u64_u32 on the unmasked register: wild
+ * address, aperture violation */
+__device__ __forceinline__ int pair_env_id(int pe) {
+  int e;
+  asm volatile("v_and_b32 %0, 0xffffff, %1" : "=v"(e) : "v"(pe));
+  return e;
+}
 __device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, float* __restrict__ state, const float* __restrict__ ws, int env0, int N,
                                                   const int* __restrict__ pair_env, int* __restrict__ sort_cnt_next, int* __restrict__ sort_slot, int debug_flags, Solve2Lds* Ls) {
   /* the waves of a block work independently, each on its own pair of envs and its own LDS block Ls[wid].  Few blocks come here (the ones with a coupled env:
@@ -2505,7 +2513,7 @@ __device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, floa
    * by the k_prep2 before this launch) */
   const int place = wb * 2 + half;
   const int pe = place < N - env0 ? pair_env[env0 + place] : -1;
-  const int env = pe < 0 ? -1 : (pe & 0xFFFFFF), pe_nc = pe < 0 ? 0 : (pe >> 24);
+  const int env = pe < 0 ? -1 : pair_env_id(pe), pe_nc = pe < 0 ? 0 : (pe >> 24);
   const bool valid = env >= 0;
   const float* w = ws + (size_t)(valid ? env : 0) * W3_FLOATS;
   const int n = m->n_arm;
@@ -2821,7 +2829,7 @@ __device__ __forceinline__ void solve4_body(const DevModel* __restrict__ m, floa
   const int lane = threadIdx.x & 63, g = lane >> 4, l16 = lane & 15;
   const int place = blockIdx.x * 4 + g;
   const int pe = place < N - env0 ? pair_env[env0 + place] : -1;
-  const int env = pe < 0 ? -1 : (pe & 0xFFFFFF);
+  const int env = pe < 0 ? -1 : pair_env_id(pe);
   const bool valid = env >= 0;
   const float* w = ws + (size_t)(valid ? env : 0) * W3_FLOATS;
   const int n = m->n_arm;
@@ -3038,10 +3046,7 @@ __device__ __forceinline__ bool solve4_eligible(const float* __restrict__ ws, in
   const int lane = threadIdx.x & 63, g = lane >> 4;
   const int place = blockIdx.x * 4 + g;
   const int pe = place < N - env0 ? pair_env[env0 + place] : -1;
-  /* the entry carries the env's contact count in its top byte.  The mask is inline asm on purpose: written in C, hipcc (ROCm 7.2) drops it here - it turns
-   * (pe & 0xFFFFFF) * W3_FLOATS into a 24-bit multiply and then widens that to v_mad_u64_u32 on the unmasked register: wild address, aperture violation */
-  int envm;
-  asm volatile("v_and_b32 %0, 0xffffff, %1" : "=v"(envm) : "v"(pe));
+  const int envm = pair_env_id(pe);
   const bool valid = pe >= 0;
   const float* w = ws + (size_t)(valid ? envm : 0) * W3_FLOATS;
   const float4 h1 = *(const float4*)&w[W3_HDR + 4];
