@@ -2,7 +2,7 @@
 """timeline of one rp_step from a rocprofv3 --kernel-trace CSV: per queue/stream the kernels with start offset, duration and the gap
 to the previous kernel of the same queue; plus totals.  Usage: trace_chain.py <dir>"""
 import csv, glob, os, sys
-f = sorted(glob.glob(os.path.join(sys.argv[1], '**', '*kernel_trace.csv'), recursive=True))[0]
+f = sorted(glob.glob(os.path.join(sys.argv[1], '**', '*kernel_trace.csv'), recursive=True), key=os.path.getmtime)[-1]      # the newest run
 rows = list(csv.DictReader(open(f)))
 ks = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0], r.get('Queue_Id', r.get('Stream_Id', '0'))) for r in rows]
 ks.sort()

@@ -1,6 +1,8 @@
+"""per-queue summary of one rp_step from the kernel traces tools/trace_chain.sh left under gpurun_out/trace_chain_g<G>/ (which stream ran on which
+hardware queue, how long its chain was busy, average kernel durations).   python3 tools/trace_groups.py 3 4"""
 import csv,glob,os,sys
 for G in sys.argv[1:]:
-    f=sorted(glob.glob('gpurun_out/trace_chain_g%s/t/**/*kernel_trace.csv'%G,recursive=True))[0]
+    f=sorted(glob.glob('gpurun_out/trace_chain_g%s/t/**/*kernel_trace.csv'%G,recursive=True),key=os.path.getmtime)[-1]      # the newest run
     rows=list(csv.DictReader(open(f)))
     ks=[(int(r['Start_Timestamp']),int(r['End_Timestamp']),r['Kernel_Name'].split('(')[0],r.get('Queue_Id','0')) for r in rows]
     ks.sort()
