@@ -91,6 +91,8 @@ def load(f32=False, bullet_ref=False):
     lib.rpo_set_ranges.argtypes = [vp, dp, dp, dp, dp, dp]
     lib.rpo_set_action_type.argtypes = [vp, C.c_int]
     lib.rpo_set_margin.argtypes = [vp, C.c_double]
+    lib.rpo_set_rule.argtypes = [vp, C.c_int]
+    lib.rpo_get_rule.argtypes = [vp]
     lib.rpo_set_reward_cfg.argtypes = [vp, C.c_double, C.c_int]
     lib.rpo_action_dim.argtypes = [vp]
     lib.rpo_get_config.argtypes = [vp, dp]
@@ -111,6 +113,7 @@ def load(f32=False, bullet_ref=False):
     lib.rpo_forward_dynamics.argtypes = [vp, dp]
     lib.rpo_contacts.argtypes = [vp, dp, C.c_int]
     lib.rpo_last_num_rows.argtypes = [vp]
+    lib.rpo_contact_substeps.argtypes = [vp]
     lib.rpo_box_box.argtypes = [dp, dp, dp, dp, dp, dp, C.c_double, dp]
     lib.rpo_collider_poses.argtypes = [vp, dp]
     lib.rpo_collider_table.argtypes = [vp, dp]
@@ -156,7 +159,7 @@ class OracleEnv:
     """One reference env (instance + playEnv) on the CPU oracle."""
 
     def __init__(self, kind, seed=0, env_index=0, f32=False, action_type=None, margin=None, ranges=None, sparse_rew_thresh=None,
-                 dense_reward=False, bullet_ref=False, ref_flags=None):
+                 dense_reward=False, bullet_ref=False, ref_flags=None, rule=None):
         """ranges = (goal_lo, goal_hi, obj_lo, obj_hi, env_hi): the env class's range kwargs (envList.py); margin: contact margin
         in metres for every pair (default, like the library: per pair the smaller of the two objects' Bullet breaking thresholds, rp_model.col_thr)"""
         self.lib = load(f32, bullet_ref)      # bullet_ref: the frozen Bullet-like step (rp_bullet_ref.c) under the same harness
@@ -181,6 +184,8 @@ class OracleEnv:
             self.lib.rpo_set_ranges(self.h, *[_d(r)[1] for r in ranges])
         if margin is not None:
             self.lib.rpo_set_margin(self.h, float(margin))
+        if rule is not None:
+            self.lib.rpo_set_rule(self.h, int(rule))
         if bullet_ref and ref_flags is not None:
             self.lib.rpo_set_ref_flags(self.h, int(ref_flags))
         if sparse_rew_thresh is not None or dense_reward:

@@ -36,6 +36,9 @@
 #define LIMIT_MAXIMP ((real)100.0)
 #define MAX_COORD_VEL ((real)100.0)     /* btMultiBody::m_maxCoordinateVelocity (recalled) */
 #define LIMIT_ACTIVATION ((real)0.1)
+#define ERP_LIMIT ((real)0.2)           /* btContactSolverInfo::m_erp: joint-limit rows under RPO_RULE_LIMIT */
+#define RPO_RULE_ORDER 1
+#define RPO_RULE_LIMIT 2
 #define FREE_LIN_DAMP ((real)0.04)
 #define FREE_ANG_DAMP ((real)0.04)
 #define J1_ANG_DAMP ((real)0.04)        /* changeDynamics(linearDamping=0) leaves angular at the 0.04 default */
@@ -78,6 +81,7 @@ struct rpo_env {
   /* config flags (envList.py) */
   int play, use_orientation, return_velocity, num_objects;
   int action_type;                  /* RPO_ACT_*: perform_action's dispatch (environments.py:915-934) */
+  int rule;                         /* RPO_RULE_*: non-contact row order / limit rule (build_rows) */
   real margin;                      /* < 0: per pair min(col_thr[a], col_thr[b]) (default); >= 0: this value for every pair */
   real rew_thresh; int dense_reward; /* sparse_rew_thresh, sparse=False (environments.py:66, 169-170) */
   real goal_lo[3], goal_hi[3], obj_lo[3], obj_hi[3], env_hi[3];
@@ -90,6 +94,7 @@ struct rpo_env {
   xform xc[RP_MAX_COL]; real aabb_lo[RP_MAX_COL][3], aabb_hi[RP_MAX_COL][3];
   contact con[MAX_CONTACTS]; int ncon;
   row rows[MAX_ROWS]; int nrows, n_noncontact;
+  int contact_substeps;             /* substeps so far whose solve had at least one contact row (tests: where does a rollout stop being free motion) */
   void* ref;                        /* librp_oracle_bullet.so only: persistent state of the frozen Bullet-like step (rp_bullet_ref.c) */
 };
 
@@ -672,73 +677,75 @@ static void build_rows(rpo_env* e, const real* vstar) {
   const rp_model* m = &e->m;
   int nv = e->nv;
   e->nrows = 0;
-  /* Non-contact rows: motors, scene-joint motors, limits, gear - limits AFTER the motors and every sweep in the same direction, so
-   * that a limit wins over a motor that pushes its joint into it, and a limit row from LIMIT_ACTIVATION before the limit on (a
-   * speculative row: it stops the joint exactly at the limit).  The frozen reference step (rp_bullet_ref.c: RPB_ORDER, RPB_LIMIT)
-   * restates what is recalled of Bullet instead - creation order walked in alternating direction, a limit row only while the limit
-   * is violated, erp 0.2 - under which a position motor that is not force-saturated drives a light link (the Robotiq's mimic and
-   * spring links) 0.1 - 0.3 rad through its limit; that rule makes the sweep's outcome depend on the last rows solved and is
-   * ill-conditioned in fp32 (the fp32 and fp64 builds of this oracle then differ by 5e-3 rad/s per substep on those joints), so
-   * the fast model keeps the well-conditioned rule and DESIGN.md section 2 reports what it costs against the reference step. */
-  /* 1. arm joint motors (btMultiBodyJointMotor): velocity-level servo, impulse clamp */
-  for (int i = 0; i < m->n_arm; i++) {
-    row* r = new_row(e);
-    real tau[RP_MAX_ARM] = {0};
-    tau[i] = 1;
-    r->J[i] = 1;
-    arm_impulse_response(e, -1, 0, tau, r->B);
-    r->dinv = 1 / r->B[i];
-    real des = e->mmode[i] ? MOTOR_KP * (e->mtarget[i] - e->q[i]) / DT : 0;   /* kp*err/dt + qd + kd*(0-qd), kd = 1 */
-    r->rhs = (des - vstar[i]) * r->dinv;
-    r->lo = -e->mmaximp[i]; r->hi = e->mmaximp[i];
-  }
-  /* 2. scene joint motors: button position motor (scenes.py:238), default velocity motors on door and dial */
-  for (int k = 0; k < m->n_joint1; k++) {
-    row* r = new_row(e);
-    int d = dof_j1(e, k);
-    real minv = m->j1_type[k] == 1 ? 1 / (real)m->j1_mass[k] : 1 / (real)m->j1_inertia_axis[k];
-    r->J[d] = 1; r->B[d] = minv; r->dinv = 1 / minv;
-    real des = 0, maximp = DEFAULT_MOTOR_MAXIMP;
-    if (m->j1_has_pos_motor[k]) {
-      des = MOTOR_KP * ((real)m->j1_motor_target[k] - e->jq[k]) / DT;
-      maximp = (real)m->j1_motor_force[k] * DT;
-    }
-    r->rhs = (des - vstar[d]) * r->dinv;
-    r->lo = -maximp; r->hi = maximp;
-  }
-  /* 3. joint limits (btMultiBodyJointLimitConstraint): contact-like rows */
-  for (int i = 0; i < m->n_arm; i++) {
-    if (!(m->arm_lower[i] < m->arm_upper[i])) continue;
-    for (int side = 0; side < 2; side++) {
-      real pen = side == 0 ? e->q[i] - (real)m->arm_lower[i] : (real)m->arm_upper[i] - e->q[i];
-      if (pen > LIMIT_ACTIVATION) continue;
-      real sgn = side == 0 ? (real)1 : (real)-1;
+  /* Non-contact rows.  RPO_RULE_ORDER: the order btMultiBodyConstraintSolver walks them in - creation order in the world: the scene
+   * bodies' joint motors (made before the arm), the arm's limit constraints (added while the URDF tree is converted), its motors, the
+   * gear - and solve_rows walks that list in ALTERNATING direction from sweep to sweep.  RPO_RULE_LIMIT: a joint-limit row exists only
+   * while the limit is violated and pushes back with erp 0.2 (btMultiBodyJointLimitConstraint::createConstraintRows).  Both follow the
+   * frozen reference step (rp_bullet_ref.c RPB_ORDER, RPB_LIMIT).  Without the flags: motors, scene-joint motors, limits (speculative
+   * rows from LIMIT_ACTIVATION before the limit on, erp of the contacts), gear, every sweep forward - round 2's rule. */
+  const int order = (e->rule & RPO_RULE_ORDER) != 0, blimit = (e->rule & RPO_RULE_LIMIT) != 0;
+  for (int pass = 0; pass < 4; pass++) {
+    /* order: j1 motors, limits, arm motors, gear;  otherwise: arm motors, j1 motors, limits, gear */
+    const int what = order ? (pass == 0 ? 1 : pass == 1 ? 2 : pass == 2 ? 0 : 3) : pass;
+    if (what == 0) {        /* arm joint motors (btMultiBodyJointMotor): velocity-level servo, impulse clamp */
+      for (int i = 0; i < m->n_arm; i++) {
+        row* r = new_row(e);
+        real tau[RP_MAX_ARM] = {0};
+        tau[i] = 1;
+        r->J[i] = 1;
+        arm_impulse_response(e, -1, 0, tau, r->B);
+        r->dinv = 1 / r->B[i];
+        real des = e->mmode[i] ? MOTOR_KP * (e->mtarget[i] - e->q[i]) / DT : 0;   /* kp*err/dt + qd + kd*(0-qd), kd = 1 */
+        r->rhs = (des - vstar[i]) * r->dinv;
+        r->lo = -e->mmaximp[i]; r->hi = e->mmaximp[i];
+      }
+    } else if (what == 1) { /* scene joint motors: button position motor (scenes.py:238), default velocity motors on door and dial */
+      for (int k = 0; k < m->n_joint1; k++) {
+        row* r = new_row(e);
+        int d = dof_j1(e, k);
+        real minv = m->j1_type[k] == 1 ? 1 / (real)m->j1_mass[k] : 1 / (real)m->j1_inertia_axis[k];
+        r->J[d] = 1; r->B[d] = minv; r->dinv = 1 / minv;
+        real des = 0, maximp = DEFAULT_MOTOR_MAXIMP;
+        if (m->j1_has_pos_motor[k]) {
+          des = MOTOR_KP * ((real)m->j1_motor_target[k] - e->jq[k]) / DT;
+          maximp = (real)m->j1_motor_force[k] * DT;
+        }
+        r->rhs = (des - vstar[d]) * r->dinv;
+        r->lo = -maximp; r->hi = maximp;
+      }
+    } else if (what == 2) { /* joint limits (btMultiBodyJointLimitConstraint): contact-like rows, dof-major, lower before upper */
+      for (int i = 0; i < m->n_arm; i++) {
+        if (!(m->arm_lower[i] < m->arm_upper[i])) continue;
+        for (int side = 0; side < 2; side++) {
+          real pen = side == 0 ? e->q[i] - (real)m->arm_lower[i] : (real)m->arm_upper[i] - e->q[i];
+          if (blimit ? pen > 0 : pen > LIMIT_ACTIVATION) continue;
+          real sgn = side == 0 ? (real)1 : (real)-1;
+          row* r = new_row(e);
+          real tau[RP_MAX_ARM] = {0};
+          tau[i] = sgn;
+          r->J[i] = sgn;
+          arm_impulse_response(e, -1, 0, tau, r->B);
+          r->dinv = 1 / (sgn * r->B[i]);
+          real relv = sgn * vstar[i], pos_err = 0, vel_err = -relv;
+          if (pen > 0) vel_err -= pen / DT; else pos_err = -pen * (blimit ? ERP_LIMIT : ERP_CONTACT) / DT;
+          r->rhs = (pos_err + vel_err) * r->dinv;
+          r->lo = 0; r->hi = LIMIT_MAXIMP;
+        }
+      }
+    } else if (m->arm_type == RP_ARM_PANDA) {   /* finger gear (btMultiBodyGearConstraint, environments.py:400-405): qd9 + ratio*qd10 -> 0, erp 0.1, maxForce 50 */
+      int a = dof_of_bullet_joint(e, 9), b = dof_of_bullet_joint(e, 10);
       row* r = new_row(e);
       real tau[RP_MAX_ARM] = {0};
-      tau[i] = sgn;
-      r->J[i] = sgn;
+      real ratio = (real)-1;
+      tau[a] = 1; tau[b] = ratio;             /* Bullet: jacobianA = 1 on joint A, jacobianB = gearRatio on joint B */
+      r->J[a] = 1; r->J[b] = ratio;
       arm_impulse_response(e, -1, 0, tau, r->B);
-      r->dinv = 1 / (sgn * r->B[i]);
-      real relv = sgn * vstar[i], pos_err = 0, vel_err = -relv;
-      if (pen > 0) vel_err -= pen / DT; else pos_err = -pen * ERP_CONTACT / DT;
-      r->rhs = (pos_err + vel_err) * r->dinv;
-      r->lo = 0; r->hi = LIMIT_MAXIMP;
+      r->dinv = safe_inv(dotn(r->J, r->B, nv));
+      real relv = dotn(r->J, vstar, nv);
+      real pos_err = -(e->q[a] + ratio * e->q[b]) * (real)0.1 / DT;   /* erp 0.1, relative position target 0 */
+      r->rhs = (pos_err - relv) * r->dinv;
+      r->lo = -(real)50 * DT; r->hi = (real)50 * DT;
     }
-  }
-  /* 4. Panda finger gear (btMultiBodyGearConstraint, environments.py:400-405): qd9 + ratio*qd10 -> 0, erp 0.1, maxForce 50 */
-  if (m->arm_type == RP_ARM_PANDA) {
-    int a = dof_of_bullet_joint(e, 9), b = dof_of_bullet_joint(e, 10);
-    row* r = new_row(e);
-    real tau[RP_MAX_ARM] = {0};
-    real ratio = (real)-1;
-    tau[a] = 1; tau[b] = ratio;             /* Bullet: jacobianA = 1 on joint A, jacobianB = gearRatio on joint B */
-    r->J[a] = 1; r->J[b] = ratio;
-    arm_impulse_response(e, -1, 0, tau, r->B);
-    r->dinv = safe_inv(dotn(r->J, r->B, nv));
-    real relv = dotn(r->J, vstar, nv);
-    real pos_err = -(e->q[a] + ratio * e->q[b]) * (real)0.1 / DT;   /* erp 0.1, relative position target 0 */
-    r->rhs = (pos_err - relv) * r->dinv;
-    r->lo = -(real)50 * DT; r->hi = (real)50 * DT;
   }
   e->n_noncontact = e->nrows;
   /* 5. contact normals, then 6. friction (two directions per point, btPlaneSpace1) */
@@ -816,8 +823,8 @@ static void solve_rows(rpo_env* e, real* dv) {
     for (int i = 0; i < nv; i++) r->J[i] *= r->dinv;
   }
   for (int it = 0; it < N_ITER; it++) {
-    for (int j = 0; j < nnc; j++) {
-      row* r = &e->rows[j];
+    for (int j = 0; j < nnc; j++) {      /* RPO_RULE_ORDER: backwards in the even sweeps (the first one), forwards in the odd ones */
+      row* r = &e->rows[((e->rule & RPO_RULE_ORDER) && !(it & 1)) ? nnc - 1 - j : j];
       solve_one(e, r, r->lo, r->hi, dv);
     }
     for (int ri = nnc; ri < e->nrows; ri++) {
@@ -923,6 +930,7 @@ void rpo_substep(rpo_env* e) {
   real vstar[RP_MAX_NV] = {0};
   substep_unconstrained(e, vstar);
   rpb_build_rows(e, st, vstar);
+  if (st->ncon > 0) e->contact_substeps++;
   real dv[RP_MAX_NV] = {0};
   rpb_solve(e, st, dv);
   substep_integrate(e, vstar, dv);
@@ -934,6 +942,7 @@ void rpo_substep(rpo_env* e) {
   real vstar[RP_MAX_NV] = {0};
   substep_unconstrained(e, vstar);
   build_rows(e, vstar);
+  if (e->ncon > 0) e->contact_substeps++;
   real dv[RP_MAX_NV] = {0};
   solve_rows(e, dv);
   substep_integrate(e, vstar, dv);
@@ -1198,6 +1207,8 @@ static void perform_action(rpo_env* e, const real* a, real* target_poses) {
 
 void rpo_set_action_type(rpo_env* e, int action_type) { e->action_type = action_type; }
 void rpo_set_margin(rpo_env* e, double margin) { e->margin = (real)margin; }
+void rpo_set_rule(rpo_env* e, int rule) { e->rule = rule; }
+int rpo_get_rule(const rpo_env* e) { return e->rule; }
 void rpo_set_reward_cfg(rpo_env* e, double sparse_rew_thresh, int dense) { e->rew_thresh = (real)sparse_rew_thresh; e->dense_reward = dense; }
 /* another registered id on the same arm and scene: its goal / object-spawn / env ranges (envList.py kwargs) */
 void rpo_set_ranges(rpo_env* e, const double* goal_lo, const double* goal_hi, const double* obj_lo, const double* obj_hi, const double* env_hi) {
@@ -1640,6 +1651,7 @@ rpo_env* rpo_create(int kind, unsigned long long seed, int env_index) {
   e->nv = m->n_arm + 6 * m->n_free + m->n_joint1;
   e->nbody = 1 + m->n_arm + m->n_free + m->n_joint1;
   e->seed = seed; e->env_index = (uint32_t)env_index;
+  e->rule = RPO_RULE_ORDER | RPO_RULE_LIMIT;       /* the shipped model (the HIP kernels implement exactly this); rpo_set_rule(0) = round 2's rule */
   e->margin = -1; e->rew_thresh = (real)0.05; e->dense_reward = 0;
   /* envList.py:8-10, 18-22, 73-99: the env's flags and ranges go with its scene (play ids: complex_scene; reach ids:
    * default_scene; pick / push: push_scene); other ids on the same model override the ranges (rpo_set_ranges) */
@@ -1759,6 +1771,7 @@ int rpo_contacts(rpo_env* e, double* out, int max) {
   return e->ncon;
 }
 int rpo_last_num_rows(const rpo_env* e) { return e->nrows; }
+int rpo_contact_substeps(const rpo_env* e) { return e->contact_substeps; }
 /* world pose of every collider in the current state: out[12 c] = R (row-major), p; returns the collider count (render / ray tests) */
 int rpo_collider_poses(rpo_env* e, double* out) {
   update_transforms(e);

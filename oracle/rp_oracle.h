@@ -36,6 +36,8 @@ rpo_env* rpo_create(int kind /*0 U, 1 R, 2 P, 3 Q, 4 V, 5 W (rp_model.h)*/, unsi
 /* perform_action's dispatch (environments.py:915-934); default RPO_ACT_ABS_RPY.  Action length: rpo_action_dim. */
 enum { RPO_ACT_ABS_RPY = 0, RPO_ACT_REL_RPY = 1, RPO_ACT_ABS_QUAT = 2, RPO_ACT_REL_QUAT = 3, RPO_ACT_ABS_JOINTS = 4, RPO_ACT_REL_JOINTS = 5 };
 void rpo_set_action_type(rpo_env* e, int action_type);
+void rpo_set_rule(rpo_env* e, int rule);                              /* bit 0: Bullet's non-contact row order (alternating direction), bit 1: joint-limit rows only while violated, erp 0.2 */
+int rpo_get_rule(const rpo_env* e);
 void rpo_set_margin(rpo_env* e, double margin);                     /* one contact margin for all pairs, metres (default: per pair, rp_model.col_thr) */
 void rpo_set_reward_cfg(rpo_env* e, double sparse_rew_thresh, int dense);   /* environments.py:66, 169-170 */
 int rpo_action_dim(const rpo_env* e);
@@ -87,6 +89,7 @@ void rpo_mass_matrix_inv(rpo_env*, double* Minv /* nv*nv, arm block via unit imp
 void rpo_forward_dynamics(rpo_env*, double* qdd /* n_arm */);
 int rpo_contacts(rpo_env*, double* out /* per contact: colA colB px py pz nx ny nz dist */, int max);
 int rpo_last_num_rows(const rpo_env*);
+int rpo_contact_substeps(const rpo_env* e);                           /* substeps since creation whose solve had a contact row */
 int rpo_box_box(const double* ca, const double* Ra, const double* ha, const double* cb, const double* Rb, const double* hb,
                 double margin, double* out /* per point: p3 n3 dist */);
 double rpo_rng_uniform(unsigned long long seed, unsigned env_index, unsigned counter);

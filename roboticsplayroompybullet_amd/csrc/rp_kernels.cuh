@@ -59,7 +59,7 @@
 #define K_KP 0.1f
 #define K_DEFMOTOR 1.0f
 #define K_LIMIT_MAXIMP 100.0f
-#define K_LIMIT_ACT 0.1f
+#define K_ERP_LIMIT 0.2f      /* btContactSolverInfo::m_erp: what a violated joint limit pushes back with */
 #define K_LIN_DAMP 0.04f
 #define K_ANG_DAMP 0.04f
 #define K_IK_DAMP 0.1f
@@ -974,9 +974,10 @@ __device__ __forceinline__ void unconstrained_velocities(const DevModel* m, LDS&
 }
 
 /* ------------------------------------------------------------------ constraint rows */
-#define SR_UNIT 0   /* J = sign * e_dofA on an arm dof                 (motors, limits) */
+#define SR_UNIT 0   /* J = e_dofA on an arm dof                        (motors) */
 #define SR_J1 1     /* J = e_dofA on a scene joint                      (door / button / dial motors) */
 #define SR_GEAR 2   /* J = e_dofA + ratio * e_dofB on arm dofs          (Panda finger gear) */
+#define SR_LIMIT 3  /* J = sign * e_dofA on an arm dof                 (joint limits; solved like SR_UNIT) */
 
 template <class LDS>
 __device__ __forceinline__ void put_srow(LDS& L, int r, int type, int dofA, float sign, float rhs, float dinv, float lo, float hi, int dofB) {
@@ -985,45 +986,48 @@ __device__ __forceinline__ void put_srow(LDS& L, int r, int type, int dofA, floa
   s[7] = __int_as_float(dofB);
 }
 
-/* returns the number of small rows (wave-uniform) */
+/* The non-contact rows in the order btMultiBodyConstraintSolver walks them (creation order in the world: the scene bodies' joint motors - made before
+ * the arm -, the arm's joint-limit constraints - added while the URDF tree is converted -, its motors, the gear; the sweeps walk this list in
+ * ALTERNATING direction, solve_rows / k_solve2).  A joint-limit row exists only while the limit is violated and pushes back with erp 0.2
+ * (btMultiBodyJointLimitConstraint::createConstraintRows).  Same rule as the oracle's build_rows (RPO_RULE_ORDER | RPO_RULE_LIMIT) and the frozen
+ * reference step (rp_bullet_ref.c RPB_ORDER, RPB_LIMIT).  Returns the number of small rows (wave-uniform). */
 template <class LDS>
 __device__ __forceinline__ int build_small_rows(const DevModel* m, LDS& L, int lane) {
   int n = m->n_arm, nr = 0;
-  if (lane < n) {        /* arm motors (btMultiBodyJointMotor) */
-    float dinv = 1.f / L.Minv[lane * 12 + lane];
-    float mode = L.st[ST_MMODE + lane];
-    float des = mode != 0.f ? K_KP * (L.st[ST_MTARGET + lane] - L.st[ST_Q + lane]) / K_DT : 0.f;
-    float mx = L.st[ST_MMAXIMP + lane];
-    put_srow(L, lane, SR_UNIT, lane, 1.f, (des - L.vstar[lane]) * dinv, dinv, -mx, mx, 0);
-  }
-  nr = n;
   if (lane < m->n_j1) {  /* scene joint motors */
     int d = dof_j1(m, lane);
     float minv = m->j1_minv[lane], dinv = 1.f / minv;
     float des = m->j1_has_pos_motor[lane] ? K_KP * (m->j1_motor_target[lane] - L.st[ST_JQ + lane]) / K_DT : 0.f;
     float mx = m->j1_motor_maximp[lane];
-    put_srow(L, nr + lane, SR_J1, d, minv, (des - L.vstar[d]) * dinv, dinv, -mx, mx, 0);
+    put_srow(L, lane, SR_J1, d, minv, (des - L.vstar[d]) * dinv, dinv, -mx, mx, 0);
   }
-  nr += m->n_j1;
+  nr = m->n_j1;
   {                      /* joint limits, dof-major, lower before upper */
     int i = lane >> 1, side = lane & 1;
     bool on = false; float pen = 0.f;
     if (lane < 2 * n && m->arm_limited[i]) {
       float q = L.st[ST_Q + i];
       pen = side == 0 ? q - m->arm_lower[i] : m->arm_upper[i] - q;
-      on = pen <= K_LIMIT_ACT;
+      on = !(pen > 0.f);
     }
     unsigned long long mask = __ballot(on);
     if (on) {
       int r = nr + __popcll(mask & ((1ull << lane) - 1ull));
       float sgn = side == 0 ? 1.f : -1.f;
       float dinv = 1.f / L.Minv[i * 12 + i];
-      float relv = sgn * L.vstar[i], pos_err = 0.f, vel_err = -relv;
-      if (pen > 0.f) vel_err -= pen / K_DT; else pos_err = -pen * K_ERP / K_DT;
-      put_srow(L, r, SR_UNIT, i, sgn, (pos_err + vel_err) * dinv, dinv, 0.f, K_LIMIT_MAXIMP, 0);
+      float relv = sgn * L.vstar[i], pos_err = -pen * K_ERP_LIMIT / K_DT, vel_err = -relv;
+      put_srow(L, r, SR_LIMIT, i, sgn, (pos_err + vel_err) * dinv, dinv, 0.f, K_LIMIT_MAXIMP, 0);
     }
     nr += __popcll(mask);
   }
+  if (lane < n) {        /* arm motors (btMultiBodyJointMotor) */
+    float dinv = 1.f / L.Minv[lane * 12 + lane];
+    float mode = L.st[ST_MMODE + lane];
+    float des = mode != 0.f ? K_KP * (L.st[ST_MTARGET + lane] - L.st[ST_Q + lane]) / K_DT : 0.f;
+    float mx = L.st[ST_MMAXIMP + lane];
+    put_srow(L, nr + lane, SR_UNIT, lane, 1.f, (des - L.vstar[lane]) * dinv, dinv, -mx, mx, 0);
+  }
+  nr += n;
   if (m->arm_type == RP_ARM_PANDA) {   /* finger gear: qd_a + ratio qd_b -> 0 (environments.py:400-405) */
     if (lane == 0) {
       int a = m->d9p, b = m->d10p;
@@ -1201,11 +1205,13 @@ __device__ float solve_rows(const DevModel* m, LDS& L, int lane, int nsmall_, in
   float dv = 0.f;
   float lamS = 0.f, lamC0 = 0.f, lamC1 = 0.f;
   for (int it = 0; it < K_NITER; it++) {
-    {   /* motors, scene-joint motors, limits, gear (the oracle's build_rows explains the order): J has one or two unit entries, B is a
-         * (combination of) column(s) of M^-1 */
-      for (int r = 0; r < nsmall; r++) {
+    {   /* scene-joint motors, limits, motors, gear (build_small_rows explains the order), walked in alternating direction: J has one or two
+         * unit entries, B is a (combination of) column(s) of M^-1 */
+      for (int rr = 0; rr < nsmall; rr++) {
+        const int r = (it & 1) ? rr : nsmall - 1 - rr;      /* backwards in the even sweeps (the first one), forwards in the odd ones */
         const float4 c0 = *(const float4*)&L.srow[8 * r], c1 = *(const float4*)&L.srow[8 * r + 4];
-        const int type = uni(__float_as_int(c0.x)), dA = uni(__float_as_int(c0.y)), dB = uni(__float_as_int(c1.w));
+        const int type_ = uni(__float_as_int(c0.x)), dA = uni(__float_as_int(c0.y)), dB = uni(__float_as_int(c1.w));
+        const int type = type_ == SR_LIMIT ? SR_UNIT : type_;
         const float sg = c0.z, jA = c1.x;      /* c1.x = dinv = the folded J entry at dofA */
         float bl = 0.f;
         if (type == SR_J1) bl = lane == lane_pos(m, dA) ? sg : 0.f;
@@ -2234,7 +2240,6 @@ __device__ __forceinline__ void prep2_body(const DevModel* __restrict__ m, const
   __syncthreads();
   PCLK(17)
   float* w = ws + (size_t)env * W3_FLOATS;
-  const int n = m->n_arm;
   if (wid == 0) {
     /* ---- wave 0: collision detection -> the contact list */
     collider_aabbs(m, L, lane);
@@ -2265,14 +2270,13 @@ __device__ __forceinline__ void prep2_body(const DevModel* __restrict__ m, const
       int type = __float_as_int(s[0]), dA = __float_as_int(s[1]);
       float sg = s[2], rhs = s[3], dinv = s[4], lo = s[5], hi = s[6];
       if (type == SR_UNIT) {
-        if (lane < n) { L.aout[dA] = dinv; L.aout[16 + dA] = rhs; L.aout[32 + dA] = lo; L.aout[48 + dA] = hi; }
-        else {
-          int pl = sg > 0.f ? 64 : 112;
-          L.aout[pl + dA] = sg * rhs; L.aout[pl + 16 + dA] = sg * lo; L.aout[pl + 32 + dA] = sg * hi;
-          atomicOr(&L.amask[sg > 0.f ? 0 : 1], 1u << dA);
-        }
+        L.aout[dA] = dinv; L.aout[16 + dA] = rhs; L.aout[32 + dA] = lo; L.aout[48 + dA] = hi;
+      } else if (type == SR_LIMIT) {
+        int pl = sg > 0.f ? 64 : 112;
+        L.aout[pl + dA] = sg * rhs; L.aout[pl + 16 + dA] = sg * lo; L.aout[pl + 32 + dA] = sg * hi;
+        atomicOr(&L.amask[sg > 0.f ? 0 : 1], 1u << dA);
       } else if (type == SR_J1) {
-        int k = lane - n;
+        int k = lane;
         if (k < NBJ) { float* bq = &L.aout[168]; bq[k] = dinv; bq[4 + k] = rhs; bq[8 + k] = lo; bq[12 + k] = hi; bq[16 + k] = sg; }
       } else {
         float* g = &L.aout[160];
@@ -2675,6 +2679,7 @@ __device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, floa
   }
   float dv = 0.f;
 #define REP12(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11)
+#define REP12R(M) M(11) M(10) M(9) M(8) M(7) M(6) M(5) M(4) M(3) M(2) M(1) M(0)
 #define REP21(M) REP12(M) M(12) M(13) M(14) M(15) M(16) M(17) M(18) M(19) M(20)      /* literal indices: they name labels */
   static_assert(MAXC == 21, "slot macros");
 #pragma unroll 1
@@ -2692,36 +2697,32 @@ __device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, floa
     plane_begin(X0); plane_begin(PL); plane_begin(PU); nplane_begin(PN[0]); nplane_begin(PN[1]);
     PLANE_FENCE4(X0, PL, PU, PN[0]);
     PLANE_FENCE_N(PN[1], PN[0], PN[1]);
-    /* unit rows: motor t in DPP row 0 beside scene joint t in DPP row 1 (t >= n_arm / absent joint: exact no-op), then the limits,
-     * dof-major, lower before upper, then the gear.  One guard per group of six limit dofs: an absent limit row is all zeros and an
-     * exact no-op that costs about as much as the branch that would skip it */
+    /* unit rows in Bullet's order (build_small_rows), walked backwards in the even sweeps and forwards in the odd ones: forwards = the limits
+     * (dof-major, lower before upper), the motors (motor t in DPP row 0 beside scene joint t in DPP row 1; t >= n_arm / absent joint: exact
+     * no-op), the gear.  A limit row exists only while its limit is violated: per group of six dofs the guards pick {nothing, lower rows
+     * only, both interleaved} - an absent row is all zeros and an exact no-op that costs about as much as the branch that would skip it.
+     * (The UR5's opening gripper is the common case with limit rows: its six joints 6..11 commanded below their lower limits.) */
 #define UNIT_M(t) unit_row<(t)>(dinvX, Bm[t], dv, X0, l16);
 #define UNIT_L(i) unit_row<(i)>(dinvX, Bm[i], dv, PL, l16); unit_row<(i)>(dinvX, Bm[i], dv, PU, l16);
+#define UNIT_LR(i) unit_row<(i)>(dinvX, Bm[i], dv, PU, l16); unit_row<(i)>(dinvX, Bm[i], dv, PL, l16);
 #define UNIT_LO(i) unit_row<(i)>(dinvX, Bm[i], dv, PL, l16);
-#define UNIT_UP(i) unit_row<(i)>(dinvX, Bm[i], dv, PU, l16);
 #ifndef RP_ABL_NOUNIT      /* timing ablations only (tools/): RP_ABL_NOUNIT drops the unit rows, RP_ABL_NOCONTACT the contact rows */
-    REP12(UNIT_M)
-    /* limits: per group of six dofs one of {lower and upper interleaved, lower only, upper only, nothing} - an absent row is an exact no-op, so
-     * leaving it out changes nothing but the time (per-wave clocks: the unit rows were 80 % of a typical wave's sweep, two thirds of them
-     * limit rows of which a quarter existed: the gripper's joints sit at their lower limits) */
-    if (mL_it & 0x03F) { if (mU_it & 0x03F) { UNIT_L(0) UNIT_L(1) UNIT_L(2) UNIT_L(3) UNIT_L(4) UNIT_L(5) } else { UNIT_LO(0) UNIT_LO(1) UNIT_LO(2) UNIT_LO(3) UNIT_LO(4) UNIT_LO(5) } }
-    else if (mU_it & 0x03F) { UNIT_UP(0) UNIT_UP(1) UNIT_UP(2) UNIT_UP(3) UNIT_UP(4) UNIT_UP(5) }
-    /* dofs 6..11 (the UR5's gripper): the two pad joints (10, 11; range 0.0448 < 2 * K_LIMIT_ACT) always carry both rows, the four finger joints
-     * (6..9) their lower rows while the gripper opens and practically never their upper ones (the commanded range ends 0.16 rad below) - so that
-     * case gets its own straight line: 4..8 rows instead of 12 */
-    if (mU_it & 0x3C0) {
-      if (mL_it & 0xFC0) { UNIT_L(6) UNIT_L(7) UNIT_L(8) UNIT_L(9) UNIT_L(10) UNIT_L(11) } else { UNIT_UP(6) UNIT_UP(7) UNIT_UP(8) UNIT_UP(9) UNIT_UP(10) UNIT_UP(11) }
+    if (it & 1) {
+      if ((mL_it | mU_it) & 0x03F) { if (mU_it & 0x03F) { UNIT_L(0) UNIT_L(1) UNIT_L(2) UNIT_L(3) UNIT_L(4) UNIT_L(5) } else { UNIT_LO(0) UNIT_LO(1) UNIT_LO(2) UNIT_LO(3) UNIT_LO(4) UNIT_LO(5) } }
+      if ((mL_it | mU_it) & 0xFC0) { if (mU_it & 0xFC0) { UNIT_L(6) UNIT_L(7) UNIT_L(8) UNIT_L(9) UNIT_L(10) UNIT_L(11) } else { UNIT_LO(6) UNIT_LO(7) UNIT_LO(8) UNIT_LO(9) UNIT_LO(10) UNIT_LO(11) } }
+      REP12(UNIT_M)
+      if (gr_it) generic_row<GEAR_LANE, false>(Jg, Bg, dv, PU, l16, PU.rhs);
     } else {
-      if (mL_it & 0x3C0) { UNIT_LO(6) UNIT_LO(7) UNIT_LO(8) UNIT_LO(9) }
-      if (mL_it & 0xC00) { if (mU_it & 0xC00) { UNIT_L(10) UNIT_L(11) } else { UNIT_LO(10) UNIT_LO(11) } }
-      else if (mU_it & 0xC00) { UNIT_UP(10) UNIT_UP(11) }
+      if (gr_it) generic_row<GEAR_LANE, false>(Jg, Bg, dv, PU, l16, PU.rhs);
+      REP12R(UNIT_M)
+      if ((mL_it | mU_it) & 0xFC0) { if (mU_it & 0xFC0) { UNIT_LR(11) UNIT_LR(10) UNIT_LR(9) UNIT_LR(8) UNIT_LR(7) UNIT_LR(6) } else { UNIT_LO(11) UNIT_LO(10) UNIT_LO(9) UNIT_LO(8) UNIT_LO(7) UNIT_LO(6) } }
+      if ((mL_it | mU_it) & 0x03F) { if (mU_it & 0x03F) { UNIT_LR(5) UNIT_LR(4) UNIT_LR(3) UNIT_LR(2) UNIT_LR(1) UNIT_LR(0) } else { UNIT_LO(5) UNIT_LO(4) UNIT_LO(3) UNIT_LO(2) UNIT_LO(1) UNIT_LO(0) } }
     }
-    if (gr_it) generic_row<GEAR_LANE, false>(Jg, Bg, dv, PU, l16, PU.rhs);
 #endif
 #undef UNIT_M
 #undef UNIT_L
+#undef UNIT_LR
 #undef UNIT_LO
-#undef UNIT_UP
     plane_end(X0); plane_end(PL); plane_end(PU);
     /* contact normals: side-by-side slots while they last, then the folded slots.  Contacts are prefixes of both
      * ranges, so the guards are early exits: nothing is spent on absent slots */
@@ -2752,6 +2753,7 @@ __device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, floa
     }
   }
 #undef REP12
+#undef REP12R
 #undef REP21
 #undef WAVE_OR
 #undef WAVE_MAX
@@ -2940,6 +2942,7 @@ __device__ __forceinline__ void solve4_body(const DevModel* __restrict__ m, floa
 #define REP3(M) M(0) M(1) M(2)
 #define REP8(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
 #define REP12(M) REP8(M) M(8) M(9) M(10) M(11)
+#define REP12R(M) M(11) M(10) M(9) M(8) M(7) M(6) M(5) M(4) M(3) M(2) M(1) M(0)
 #define REP16(M) REP12(M) M(12) M(13) M(14) M(15)
 #pragma unroll 1
   for (int it = 0; it < K_NITER; it++) {
@@ -2952,30 +2955,29 @@ __device__ __forceinline__ void solve4_body(const DevModel* __restrict__ m, floa
     asm volatile("s_nop 1" : "+v"(X0.loP), "+v"(X0.hiP), "+v"(PL.loP), "+v"(PL.hiP), "+v"(PU.loP), "+v"(PU.hiP), "+v"(PN.loP), "+v"(PN.hiP), "+v"(PN.rhsE));
 #define UNIT_M(t) unit_row<(t)>(dinvX, Bm[t], dv, X0, l16);
 #define UNIT_L(i) unit_row<(i)>(dinvX, Bm[i], dv, PL, l16); unit_row<(i)>(dinvX, Bm[i], dv, PU, l16);
+#define UNIT_LR(i) unit_row<(i)>(dinvX, Bm[i], dv, PU, l16); unit_row<(i)>(dinvX, Bm[i], dv, PL, l16);
 #define UNIT_LO(i) unit_row<(i)>(dinvX, Bm[i], dv, PL, l16);
-#define UNIT_UP(i) unit_row<(i)>(dinvX, Bm[i], dv, PU, l16);
-    if (T == 0) {
-      REP12(UNIT_M)
-      /* limits: the guards of solve2_body */
-      if (mL_it & 0x03F) { if (mU_it & 0x03F) { UNIT_L(0) UNIT_L(1) UNIT_L(2) UNIT_L(3) UNIT_L(4) UNIT_L(5) } else { UNIT_LO(0) UNIT_LO(1) UNIT_LO(2) UNIT_LO(3) UNIT_LO(4) UNIT_LO(5) } }
-      else if (mU_it & 0x03F) { UNIT_UP(0) UNIT_UP(1) UNIT_UP(2) UNIT_UP(3) UNIT_UP(4) UNIT_UP(5) }
-      if (mU_it & 0x3C0) {
-        if (mL_it & 0xFC0) { UNIT_L(6) UNIT_L(7) UNIT_L(8) UNIT_L(9) UNIT_L(10) UNIT_L(11) } else { UNIT_UP(6) UNIT_UP(7) UNIT_UP(8) UNIT_UP(9) UNIT_UP(10) UNIT_UP(11) }
+    if (T == 0) {      /* the unit rows in Bullet's order, walked in alternating direction: the sequence and the guards of solve2_body */
+      if (it & 1) {
+        if ((mL_it | mU_it) & 0x03F) { if (mU_it & 0x03F) { UNIT_L(0) UNIT_L(1) UNIT_L(2) UNIT_L(3) UNIT_L(4) UNIT_L(5) } else { UNIT_LO(0) UNIT_LO(1) UNIT_LO(2) UNIT_LO(3) UNIT_LO(4) UNIT_LO(5) } }
+        if ((mL_it | mU_it) & 0xFC0) { if (mU_it & 0xFC0) { UNIT_L(6) UNIT_L(7) UNIT_L(8) UNIT_L(9) UNIT_L(10) UNIT_L(11) } else { UNIT_LO(6) UNIT_LO(7) UNIT_LO(8) UNIT_LO(9) UNIT_LO(10) UNIT_LO(11) } }
+        REP12(UNIT_M)
+        if (gr_it) generic_row<GEAR_LANE, false>(Jg, Bg, dv, PU, l16, PU.rhs);
       } else {
-        if (mL_it & 0x3C0) { UNIT_LO(6) UNIT_LO(7) UNIT_LO(8) UNIT_LO(9) }
-        if (mL_it & 0xC00) { if (mU_it & 0xC00) { UNIT_L(10) UNIT_L(11) } else { UNIT_LO(10) UNIT_LO(11) } }
-        else if (mU_it & 0xC00) { UNIT_UP(10) UNIT_UP(11) }
+        if (gr_it) generic_row<GEAR_LANE, false>(Jg, Bg, dv, PU, l16, PU.rhs);
+        REP12R(UNIT_M)
+        if ((mL_it | mU_it) & 0xFC0) { if (mU_it & 0xFC0) { UNIT_LR(11) UNIT_LR(10) UNIT_LR(9) UNIT_LR(8) UNIT_LR(7) UNIT_LR(6) } else { UNIT_LO(11) UNIT_LO(10) UNIT_LO(9) UNIT_LO(8) UNIT_LO(7) UNIT_LO(6) } }
+        if ((mL_it | mU_it) & 0x03F) { if (mU_it & 0x03F) { UNIT_LR(5) UNIT_LR(4) UNIT_LR(3) UNIT_LR(2) UNIT_LR(1) UNIT_LR(0) } else { UNIT_LO(5) UNIT_LO(4) UNIT_LO(3) UNIT_LO(2) UNIT_LO(1) UNIT_LO(0) } }
       }
-      if (gr_it) generic_row<GEAR_LANE, false>(Jg, Bg, dv, PU, l16, PU.rhs);
       plane_end(X0); plane_end(PL); plane_end(PU);
     } else {
-      if (nJ_it > 0) { REP3(UNIT_M) }
+      if (nJ_it > 0) { REP3(UNIT_M) }      /* the scene-joint motors act on different dofs with diagonal responses: they commute exactly, any order gives the same bits */
       plane_end(X0);
     }
 #undef UNIT_M
 #undef UNIT_L
+#undef UNIT_LR
 #undef UNIT_LO
-#undef UNIT_UP
 #define NRM4(s) if (nS_it <= (s)) goto nrm_done; generic_row<(s), false>(JN[s], BN[s], dv, PN, l16, PN.rhsE);
     if (T == 0) { REP8(NRM4) } else { REP16(NRM4) }
 #undef NRM4
@@ -2994,6 +2996,7 @@ __device__ __forceinline__ void solve4_body(const DevModel* __restrict__ m, floa
 #undef REP3
 #undef REP8
 #undef REP12
+#undef REP12R
 #undef REP16
 #undef W4_OR
 #undef W4_MAX

@@ -160,14 +160,14 @@ def test_manifold_life_cycle(lib):
 
 
 def test_with_the_remaining_differences_off_it_is_the_fast_model():
-    """the fast model shares the soft gripper contacts and the friction skip with the reference step; with the differences that remain
-    switched off (no hulls, no persistence, the fast model's row order and limit rule, midpoint lever arms, no anchors, no torsional
-    friction) the reference step against the fast model's oracle at contact margin 0: no contacts at all (UR5Reach) - identical; a block on a plane
+    """the fast model shares the soft gripper contacts, the friction skip and (since round 3) the row order in alternating direction and the
+    violated-only limit rule with the reference step; with the differences that remain switched off (no hulls, no persistence, midpoint lever
+    arms, no anchors, no torsional friction) the reference step against the fast model's oracle at contact margin 0: no contacts at all (UR5Reach) - identical; a block on a plane
     (pandaPick) - the same trajectories up to what is left (GJK instead of closed forms, no cap, the detector's own point culling)"""
     rng = np.random.default_rng(3)
     for kind, tol in (('R', 1e-10), ('P', 2e-4)):
         a = OracleEnv(kind, seed=5, env_index=1, margin=0.0)
-        b = OracleEnv(kind, seed=5, env_index=1, bullet_ref=True, ref_flags=sum(oracle.REF_FLAGS[k] for k in ('soft', 'fricskip')))
+        b = OracleEnv(kind, seed=5, env_index=1, bullet_ref=True, ref_flags=sum(oracle.REF_FLAGS[k] for k in ('soft', 'fricskip', 'order', 'limit')))
         oa, ob = a.reset(), b.reset()
         np.testing.assert_allclose(ob['obs_quat'], oa['obs_quat'], atol=tol, rtol=0)
         for t in range(40):

@@ -1,0 +1,79 @@
+"""HIP path (through the C ABI) vs the FROZEN Bullet-like reference step (oracle/rp_bullet_ref.c, librp_oracle_bullet.so, default flags).
+
+The other GPU parity tests hold the device to the fast model's own oracle - the model the kernels implement.  This file holds it to the
+independent restatement of Bullet's step instead (PARITY UNPINNED like all physics here: PyBullet itself is absent; rp_bullet_ref.c is the only
+independent evidence there is).  Measure: north_star's, max over steps and the ARM'S OWN joints (6 UR5 / 7 Panda) of |q_hip - q_ref| / max(1, |q_ref|)
+per env, 200 steps, identical post-reset states and actions, tolerance 1e-3.
+
+What the shipped model shares with the reference step since round 3: the non-contact row order walked in alternating direction, joint-limit rows
+only while violated (erp 0.2), soft gripper contacts, the friction skip.  What it does not: hull colliders (its arm links are OBBs), per-body lever
+arms, persistent manifolds, torsional friction.  Hence
+  * both ids must meet 1e-3 in every env for as long as the rollout is free motion - until the first substep in which either the reference step
+    or the fast model (an fp64 CPU follower of the same env) has a contact row: the fingers of both grippers reach the ground plate at
+    z = -0.07 in many rollouts, the fast model's OBBs a little earlier than the hulls;
+  * after that the measured figure is reported and bounded by what the missing contact features cost.
+"""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+
+pytestmark = pytest.mark.gpu
+
+IDS = {'R': 'UR5Reach-v0', 'Q': 'pandaReach-v0'}
+TOL = 1e-3
+
+
+def reach_actions(steps, n, seed):
+    rng = np.random.default_rng(seed)
+    a = np.array([-0.18, 0.0, 0.05, -0.5, -0.5, -0.5, -1.0]) + np.array([0.36, 0.3, 0.25, 1.0, 1.0, 1.0, 2.0]) * rng.random((steps, n, 7))
+    a[..., 0:3] = np.array([-0.18, -0.18, 0.0]) + np.array([0.36, 0.36, 0.2]) * rng.random((steps, n, 3))
+    return a
+
+
+@pytest.mark.parametrize('kind', ['R', 'Q'])
+def test_hip_vs_frozen_reference_step(kind):
+    import os
+    import sys
+    from oracle import OracleEnv
+    from roboticsplayroompybullet_amd import VecPlayEnv
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    from gpu_debug import record_from_oracle
+    n, steps = 16, 200
+    n_main = 6 if kind == 'R' else 7
+    env = VecPlayEnv(IDS[kind], n, seed=21)
+    env.reset()
+    refs = [OracleEnv(kind, seed=21, env_index=e, bullet_ref=True) for e in range(n)]
+    fast = [OracleEnv(kind, seed=21, env_index=e) for e in range(n)]
+    for o, f in zip(refs, fast):
+        o.reset()
+        f.reset()
+        f.set_state(o.get_state())
+    c0 = [(o.lib.rpo_contact_substeps(o.h), f.lib.rpo_contact_substeps(f.h)) for o, f in zip(refs, fast)]
+    env.set_state(torch.tensor(np.stack([record_from_oracle(o) for o in refs])))     # both start from the reference step's post-reset state
+    acts = reach_actions(steps, n, 3)
+    d_free, d_all = np.zeros(n), np.zeros(n)
+    touched = np.zeros(n, bool)
+    first = np.full(n, steps)
+    for t in range(steps):
+        obs, r, done, info = env.step(torch.tensor(acts[t], dtype=torch.float32))
+        q = env.get_state()[:, :n_main].cpu().numpy()
+        for e, o in enumerate(refs):
+            a = acts[t, e].astype(np.float32).astype(np.float64)
+            o.step(a)
+            fast[e].step(a)
+            if not touched[e] and (o.lib.rpo_contact_substeps(o.h), fast[e].lib.rpo_contact_substeps(fast[e].h)) != c0[e]:
+                touched[e] = True
+                first[e] = t
+            qo = o.get_state()[:n_main]
+            d = float((np.abs(q[e] - qo) / np.maximum(1.0, np.abs(qo))).max())
+            d_all[e] = max(d_all[e], d)
+            if not touched[e]:
+                d_free[e] = max(d_free[e], d)
+        assert int((info['status'] & 1).sum()) == 0
+    print('%s vs the frozen reference step, %d envs x %d steps, arm joints: contact-free part max %.2e median %.2e; whole rollout max %.2e median %.2e; '
+          '%d envs touched something (first at step %s)' % (kind, n, steps, d_free.max(), np.median(d_free), d_all.max(), np.median(d_all), int(touched.sum()),
+                                                              int(first.min()) if touched.any() else '-'))
+    assert (d_free <= TOL).all(), d_free
+    assert (~touched).sum() >= 2 and (d_all[~touched] <= TOL).all()      # some envs stay free for all 200 steps
+    assert (d_all <= 5e-2).all(), d_all       # OBB fingers against the plate instead of hulls, no torsional friction: DESIGN.md section 2
