@@ -71,12 +71,13 @@ def cpu_baseline(seed, margin=None):
 
 
 STEP_KERNELS = ('k_action_prep', 'k_prep2', 'k_solve2', 'k_calc_state')     # what one rp_step launches (default pipeline)
-PMC_SUMMARY = 'r02_pmc_summary.json'
+PMC_SUMMARY = 'r03_pmc_summary.json'
+WARMUP_FLOOR = 20      # untimed steps before the first timed region whatever --warmup says: clocks, caches and the load-sorted env pairing have settled by then
 
 
 def pmc_traffic(kernel=None):
     """HBM-side bytes per launch of `kernel` (None: per env step, all of STEP_KERNELS weighted by their launches per step) from the
-    committed rocprofv3 PMC passes (profiles/r02_pmc_summary.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same bench;
+    committed rocprofv3 PMC passes (profiles/r03_pmc_summary.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same bench;
     KB units; reads doubled per the gfx950 FETCH_SIZE correction in MI355X_MICROARCH.md).  PMC counters cannot be read from
     inside this process, so this is the profile's number, not a live one.  None if the file is absent, was taken with another
     library version, or lacks one of the kernels rp_step launches today (a stale profile is refused, not quoted)."""
@@ -138,7 +139,9 @@ def main():
     if args.groups:
         env.set_groups(args.groups)
     env.reset()
-    actions = make_actions(n, args.steps + args.warmup, device, 1234 + rank)
+    pre = max(0, WARMUP_FLOOR - args.warmup)          # uncounted steps in front of the --warmup ones
+    actions = make_actions(n, args.steps + args.warmup + pre, device, 1234 + rank)
+    actions, pre_actions = actions[pre:], actions[:pre]
     pack_w = env.dims['obs_quat'] + env.dims['achieved_goal'] + 2
     gathered = torch.empty((world * n, pack_w), dtype=torch.float32, device=device) if world > 1 else None
 
@@ -176,8 +179,8 @@ def main():
             elapsed = float(t.item())
         return elapsed, info
 
-    for k in range(args.warmup):
-        env.step(actions[k])
+    for a in list(pre_actions) + [actions[k] for k in range(args.warmup)]:
+        env.step(a)
         if world > 1:
             sharding.gather_observations(env.pack, out=gathered)
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
@@ -210,6 +213,8 @@ def main():
         acts_a = (2 * torch.rand((args.steps + args.warmup, n, 7), generator=g, device=device) - 1) * hi
         for k in range(args.warmup):
             env.step(acts_a[k])
+        for k in range(pre):                        # the same floor for this distribution (other actions, other contact sets)
+            env.step(acts_a[args.warmup + k])
         t_a, info_a = timed_region(env, acts_a, args.warmup, args.steps)
         extras['distribution_A'] = {'value': n * args.steps / t_a, 'ms_per_step': 1e3 * t_a / args.steps,
                                     'what': 'a ~ U(action_space.low, action_space.high) = U(-6, 6)^6 x U(-1, 1), resampled every step (the '
@@ -221,13 +226,21 @@ def main():
                 continue
             env2 = VecPlayEnv(ENV_ID, n, device=dev_index, seed=1234, contact_margin=other)
             env2.reset()
-            for k in range(args.warmup):
-                env2.step(actions[k])
+            for a in list(pre_actions) + [actions[k] for k in range(args.warmup)]:
+                env2.step(a)
             t_m, _ = timed_region(env2, actions, args.warmup, args.steps)
             extras['contact_margin_%g' % other] = {'value': n * args.steps / t_m, 'ms_per_step': 1e3 * t_m / args.steps,
                                                    'what': 'the same workload with rp_config.contact_margin = %g m for every pair' % other}
             env2.close()
 
+    # who took part: every rank's device as RCCL / torch saw it, gathered so that "did N ranks on N GPUs run" can be read off the line
+    props = torch.cuda.get_device_properties(dev_index)
+    me = {'rank': rank, 'local_rank': local_rank, 'device_index': dev_index, 'name': props.name, 'uuid': str(getattr(props, 'uuid', '')),
+          'envs': [sharding_offset(rank, world, n), sharding_offset(rank, world, n) + n]}
+    ranks = [me]
+    if world > 1:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, me)
     if rank == 0:
         value = world * n * args.steps / elapsed
         margin_used = ('%g m for every pair' % args.contact_margin) if args.contact_margin is not None else "per pair, Bullet's relative breaking thresholds (library default)"
@@ -242,10 +255,13 @@ def main():
             'config': {'workload': '%s, %d envs per GPU, 12 substeps x 50 PGS sweeps per step, random actions '
                                    '(distribution B, resampled every step), reset excluded, contact margin: %s' % (ENV_ID, n, margin_used),
                        'envs_per_gpu': n, 'global_envs': world * n, 'parallelism': 'env-shard x%d' % world,
-                       'collective': 'all_gather(obs_quat+achieved_goal+reward+is_success) per step' if world > 1 else 'none'},
+                       'collective': 'all_gather(obs_quat+achieved_goal+reward+is_success) per step' if world > 1 else 'none',
+                       'collective_backend': (dist.get_backend() + (' (RCCL)' if dist.get_backend() == 'nccl' else '')) if world > 1 else None,
+                       'ranks_seen': dist.get_world_size() if world > 1 else 1, 'ranks': ranks,
+                       'warmup_untimed_steps': pre + args.warmup},
             # frac = the strict SURVEY.md 8d figure: algorithmic bytes of a whole env step / measured step time / HBM peak; the dominant
             # kernel's own per-launch figure sits in `dominant_kernel`
-            'roofline': {'bound': 'hbm', 'achieved': step_achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': step_achieved / HBM_PEAK_GBS,
+            'roofline': {'bound': 'latency/issue', 'nominal_bound': 'hbm', 'hbm_frac': step_achieved / HBM_PEAK_GBS, 'achieved': step_achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': step_achieved / HBM_PEAK_GBS,
                          'traffic': pmc_traffic() if n == ENVS_PER_GPU else None,
                          'what': 'whole env step: %d B algorithmic per env-step (SURVEY.md 8d) x %d envs / %.3f ms (torch events around rp_step on its stream)'
                                  % (ALG_BYTES_PER_ENV_STEP, n, step_ms),

@@ -1617,6 +1617,9 @@ int rpo_reset_to(rpo_env* e, const double* o, int n_o, const double* u, int n_u,
     for (int i = 0; i < out->n_ag; i++) ag[i] = (real)(float)out->achieved_goal[i];
     for (int i = 0; i < e->n_goal; i++) dg[i] = (real)(float)out->desired_goal[i];
     r = compute_reward(e, ag, dg);
+    /* sparse=False: compute_reward is -distance, never <= -1 inside the scene, and the reference's `while r > -1` would not end
+     * (environments.py:176-186 with 169-170): there is no behaviour to match, so a dense env keeps its first draw */
+    if (e->dense_reward) break;
   }
   return us.used;
 }
@@ -1634,6 +1637,9 @@ int rpo_reset(rpo_env* e, const double* u, int n_u, rpo_obs* out) {
     for (int i = 0; i < out->n_ag; i++) ag[i] = (real)(float)out->achieved_goal[i];
     for (int i = 0; i < e->n_goal; i++) dg[i] = (real)(float)out->desired_goal[i];
     r = compute_reward(e, ag, dg);
+    /* sparse=False: compute_reward is -distance, never <= -1 inside the scene, and the reference's `while r > -1` would not end
+     * (environments.py:176-186 with 169-170): there is no behaviour to match, so a dense env keeps its first draw */
+    if (e->dense_reward) break;
   }
   return us.used;
 }

@@ -1407,7 +1407,7 @@ __device__ __forceinline__ void action_target(int at, const float* a8, V3 cp, Q4
 }
 
 template <int NC>
-__device__ float ik_coop(const DevModel* m, V3 tpos, Q4 tq, float qj, int max_iter, int l16, bool live) {
+__device__ float ik_coop(const DevModel* m, V3 tpos, Q4 tq, float qj, int max_iter, int l16, bool live, bool* capped = nullptr) {
   const bool isj = l16 < NC;
   const int jj = isj ? l16 : 0;
   const M3 R0 = ldm3(m->arm_jrot[jj]);
@@ -1483,15 +1483,16 @@ __device__ float ik_coop(const DevModel* m, V3 tpos, Q4 tq, float qj, int max_it
     const float sc = mx > K_IK_MAXSTEP ? K_IK_MAXSTEP / mx : 1.f;
     if (!done && isj) qj += sc * mine;
   }
+  if (capped) *capped = !done;      /* the residual test never passed: this call ran out of iterations (status bit 8 of the step) */
   return qj;
 }
 
 /* replicated-value front end: every lane passes the same start vector and gets the same solution back */
-__device__ __forceinline__ ChainQ ik_solve(const DevModel* m, V3 tpos, Q4 tq, ChainQ q, int max_iter, int l16) {
+__device__ __forceinline__ ChainQ ik_solve(const DevModel* m, V3 tpos, Q4 tq, ChainQ q, int max_iter, int l16, bool* capped = nullptr) {
   float qj = 0.f;
 #pragma unroll
   for (int j = 0; j < 7; j++) qj = l16 == j ? q.q[j] : qj;
-  qj = m->ee_chain == 6 ? ik_coop<6>(m, tpos, tq, qj, max_iter, l16, true) : ik_coop<7>(m, tpos, tq, qj, max_iter, l16, true);
+  qj = m->ee_chain == 6 ? ik_coop<6>(m, tpos, tq, qj, max_iter, l16, true, capped) : ik_coop<7>(m, tpos, tq, qj, max_iter, l16, true, capped);
   ChainQ r;
   static_for<0, 7>([&](auto jc) { constexpr int j = decltype(jc)::v; r.q[j] = bcast16<j>(qj); });
   return r;
@@ -1501,6 +1502,7 @@ __device__ __forceinline__ ChainQ ik_solve(const DevModel* m, V3 tpos, Q4 tq, Ch
  * lane 0 writes the motor commands into the state record.  Returns the target poses. */
 __device__ ChainQ perform_action(const DevModel* m, EnvLds& L, int lane, const float* a8) {
   const int nd = m->n_target, at = m->action_type, l16 = lane & 15;
+  bool ik_capped = false;
   ChainQ cur;
 #pragma unroll
   for (int j = 0; j < 7; j++) cur.q[j] = j < m->ee_chain ? L.st[ST_Q + j] : 0.f;
@@ -1518,10 +1520,10 @@ __device__ ChainQ perform_action(const DevModel* m, EnvLds& L, int lane, const f
     }
     V3 tpos; Q4 tq;
     action_target(at, a8, cp, cq, tpos, tq);
-    if (m->arm_type == RP_ARM_PANDA) sol = ik_solve(m, tpos, tq, cur, 200, l16);
+    if (m->arm_type == RP_ARM_PANDA) sol = ik_solve(m, tpos, tq, cur, 200, l16, &ik_capped);
     else {   /* InverseKinematicsSolver.calc_angles: 4 chained default IK solves from the measured joints */
       sol = cur;
-      for (int rep = 0; rep < 4; rep++) sol = ik_solve(m, tpos, tq, sol, 20, l16);
+      for (int rep = 0; rep < 4; rep++) sol = ik_solve(m, tpos, tq, sol, 20, l16, &ik_capped);
     }
   }
   ChainQ tp;
@@ -1536,6 +1538,7 @@ __device__ ChainQ perform_action(const DevModel* m, EnvLds& L, int lane, const f
   }
   __syncthreads();
   if (lane == 0) {
+    L.st[ST_STATUS] = __int_as_float(ik_capped ? 8 : 0);
     for (int j = 0; j < nd; j++) { L.st[ST_MMODE + j] = 1.f; L.st[ST_MTARGET + j] = tp.q[j]; L.st[ST_MMAXIMP + j] = 240.f * K_DT; }
     float g = a8[m->n_action - 1];
     if (m->arm_type == RP_ARM_PANDA) {
@@ -1752,7 +1755,7 @@ __device__ void calc_state(const DevModel* m, EnvLds& L, int lane) {
     bool bad = false, fell = false;
     for (int k = 0; k < ST_MMODE; k++) if (!isfinite(L.st[k])) bad = true;
     for (int b = 0; b < m->num_objects; b++) if (L.st[ST_FREE + 13 * b + 2] < m->floor_z) fell = true;   /* below the lowest static collider */
-    o[O_STATUS] = __int_as_float((bad ? 1 : 0) | (fell ? 2 : 0));
+    o[O_STATUS] = __int_as_float((bad ? 1 : 0) | (fell ? 2 : 0) | (__float_as_int(L.st[ST_STATUS]) & 8));
   }
   __syncthreads();
 }
@@ -1918,6 +1921,7 @@ __device__ float reset_arm_goal_obs(const DevModel* m, EnvLds& L, int lane, uint
   if (lane == 0) {
     int nrest = m->arm_type == RP_ARM_PANDA ? 8 : 6;
     for (int i = 0; i < nrest; i++) { L.st[ST_Q + i] = m->rest[i]; L.st[ST_QD + i] = 0.f; }
+    L.st[ST_STATUS] = 0.f;               /* (the "IK capped" note of the last step does not outlive a reset) */
   }
   __syncthreads();
   ChainQ cur;
@@ -1929,7 +1933,9 @@ __device__ float reset_arm_goal_obs(const DevModel* m, EnvLds& L, int lane, uint
   __syncthreads();
   reset_goal_pos(m, L, lane, nullptr, seed, genv);
   calc_state(m, L, lane);
-  float r = L.out[O_REW];
+  /* sparse=False: the reward is -distance, never <= -1 inside the scene - the reference's `while r > -1` would not end there (environments.py:176-186
+   * with 169-170), so there is no behaviour to match: a dense env keeps its first draw (the oracle does the same) */
+  float r = m->dense_reward ? -1.f : L.out[O_REW];
   __syncthreads();
   return r;
 }
@@ -2108,6 +2114,7 @@ __device__ __forceinline__ void action_body(const DevModel* __restrict__ m, floa
   const int nd = m->n_target, nc = m->ee_chain, at = m->action_type;
   const float q0 = st[ST_Q + (l16 < RP_MAX_ARM ? l16 : 0)];            /* measured joint value of dof l16 */
   float qj = l16 < nc ? q0 : 0.f;
+  bool ik_capped = false;
   if (at == RP_ACT_ABS_JOINTS || at == RP_ACT_REL_JOINTS) {
     float aj = 0.f;
 #pragma unroll
@@ -2118,9 +2125,9 @@ __device__ __forceinline__ void action_body(const DevModel* __restrict__ m, floa
     if (at == RP_ACT_REL_RPY || at == RP_ACT_REL_QUAT) ee_pose_coop(m, qj, l16, cp, cq);
     V3 tpos; Q4 tq;
     action_target(at, a8, cp, cq, tpos, tq);
-    if (m->arm_type == RP_ARM_PANDA) qj = ik_coop<7>(m, tpos, tq, qj, 200, l16, live);
-    else if (nc == 6) { for (int rep = 0; rep < 4; rep++) qj = ik_coop<6>(m, tpos, tq, qj, 20, l16, live); }
-    else { for (int rep = 0; rep < 4; rep++) qj = ik_coop<7>(m, tpos, tq, qj, 20, l16, live); }
+    if (m->arm_type == RP_ARM_PANDA) qj = ik_coop<7>(m, tpos, tq, qj, 200, l16, live, &ik_capped);
+    else if (nc == 6) { for (int rep = 0; rep < 4; rep++) qj = ik_coop<6>(m, tpos, tq, qj, 20, l16, live, &ik_capped); }
+    else { for (int rep = 0; rep < 4; rep++) qj = ik_coop<7>(m, tpos, tq, qj, 20, l16, live, &ik_capped); }
   }
   if (!live) return;
   if (l16 < nd) {
@@ -2130,6 +2137,7 @@ __device__ __forceinline__ void action_body(const DevModel* __restrict__ m, floa
     if (target_poses) target_poses[(size_t)env * nd + l16] = t;
   }
   if (l16 == 0) {
+    st[ST_STATUS] = __int_as_float(ik_capped ? 8 : 0);      /* the last IK call of this step ran out of iterations: k_calc_state passes it on (status bit 8) */
     float g = a8[m->n_action - 1];
     if (m->arm_type == RP_ARM_PANDA) {
       float amt = 0.04f - g / 25.f;

@@ -46,7 +46,7 @@ struct rp_sim {
 };
 
 #define EV_PER_STEP (2 + 2 * (2 * K_NSUB + 2))   /* step pair + a pair per launch (action, 12 prep, 12 solve, obs) */
-static char g_err[256] = "";
+static thread_local char g_err[256] = "";   /* rp_create / NULL-handle errors: per calling thread (rp_last_error(NULL) reads the caller's own) */
 
 #define HIPCHK(h, call)                                                                             \
   do {                                                                                              \
@@ -257,12 +257,13 @@ static int reset_split(rp_handle h, const uint8_t* mask, const rp_out* out, hipS
   hipLaunchKernelGGL(k_reset_mark, dim3((N + 255) / 256), dim3(256), 0, s, mask, h->rs_meta, N);
   int* cnt[2] = {h->rs_sort_cnt, h->rs_sort_cnt + SORT_BINS};
   h->reset_rounds = 0;
+  bool exhausted = true;            /* the loop ran out of rounds (otherwise it left through M <= 0, which already proved that nothing is pending) */
   for (int round = 0; round < 64 * 9; round++) {
     hipLaunchKernelGGL(k_reset_list, dim3(1), dim3(64), 0, s, h->rs_meta, h->rs_idx, h->rs_count, N);
     HIPCHK(h, hipMemcpyAsync(h->rs_count_host, h->rs_count, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
     const int M = *h->rs_count_host;
-    if (M <= 0) break;
+    if (M <= 0) { exhausted = false; break; }
     h->reset_rounds++;
     hipLaunchKernelGGL(k_reset_sample, dim3(M), dim3(64), 0, s, h->dev_model, h->state, h->rs_state, h->rs_idx, M, seed, off);
     hipLaunchKernelGGL(k_sort_init, dim3((max(M, SORT_BINS) + 255) / 256), dim3(256), 0, s, cnt[0], h->rs_sort_slot, 0, M);
@@ -277,6 +278,7 @@ static int reset_split(rp_handle h, const uint8_t* mask, const rp_out* out, hipS
   }
   /* the round budget is 9 object re-samples x 64 attempts, which k_reset_finish's own caps (depth < 8, attempt < 64) cannot
    * exceed; if envs are pending all the same, say so instead of handing back half-reset records */
+  if (!exhausted) return RP_OK;
   hipLaunchKernelGGL(k_reset_list, dim3(1), dim3(64), 0, s, h->rs_meta, h->rs_idx, h->rs_count, N);
   HIPCHK(h, hipMemcpyAsync(h->rs_count_host, h->rs_count, sizeof(int), hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipStreamSynchronize(s));

@@ -120,6 +120,17 @@ class VecPlayEnv:
         except Exception:
             pass
 
+    def _flip_pack(self, keep_rows=False):
+        """the next writer of the pack gets the other buffer: an asynchronous gather of the previous step's pack (sharding.gather_observations,
+        on RCCL's stream) may still be reading the current one, and nothing orders a write on our stream after that read.  keep_rows: a masked
+        reset rewrites only some rows, so the others are carried over first (a device copy on our stream that only READS the old buffer)."""
+        new = self._packs[self._pack_i ^ 1]
+        if keep_rows:
+            new.copy_(self._packs[self._pack_i])
+        self._pack_i ^= 1
+        self.buf['pack'] = new
+        self.out.pack = new.data_ptr()
+
     def reset(self, mask=None, o=None):
         """playEnv.reset(o=None) for all envs (or those where mask != 0).  With o [N, >= 18 / 10 / 3]: playEnv.reset(o) - objects
         and arm are placed from the observation vectors instead of being sampled (environments.py:542-556, 575-590)."""
@@ -127,6 +138,7 @@ class VecPlayEnv:
         if mask is not None:
             mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
             mp = C.c_void_p(mask.data_ptr())
+        self._flip_pack(keep_rows=mask is not None)
         if o is None:
             _lib.check(self.lib, self.h, self.lib.rp_reset(self.h, mp, C.byref(self.out), self._stream()), 'rp_reset')
         else:
@@ -139,15 +151,14 @@ class VecPlayEnv:
     def step(self, action):
         a = action.to(device=self.device, dtype=torch.float32).contiguous()
         assert a.shape == (self.num_envs, self.dims['action']), a.shape
-        self._pack_i ^= 1
-        self.buf['pack'] = self._packs[self._pack_i]
-        self.out.pack = self.buf['pack'].data_ptr()
+        self._flip_pack()
         _lib.check(self.lib, self.h, self.lib.rp_step(self.h, C.c_void_p(a.data_ptr()), C.byref(self.out), self._stream()), 'rp_step')
         info = {'is_success': self.buf['is_success'], 'target_poses': self.buf['target_poses'], 'status': self.buf['status']}
         done = torch.zeros(self.num_envs, dtype=torch.bool, device=self.device)      # environments.py:212: always False
         return self._obs(), self.buf['reward'], done, info
 
     def calc_state(self):
+        self._flip_pack()
         _lib.check(self.lib, self.h, self.lib.rp_calc_state(self.h, C.byref(self.out), self._stream()), 'rp_calc_state')
         return self._obs()
 

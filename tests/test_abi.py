@@ -81,3 +81,23 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith(('.py', '.hip', '.cuh', '.h')) and 'generated' not in root:
                 text = open(os.path.join(root, f)).read()
                 assert 'import oracle' not in text and 'from oracle' not in text and 'librp_oracle' not in text, f
+
+
+def test_pair_env_entries_are_decoded_through_the_masked_helper_only():
+    """a pair_env entry carries its env's contact count in the top byte; hipcc 7.2 miscompiled the plain-C mask in front of a 64-bit address
+    multiply once (rp_kernels.cuh pair_env_id), so every read of the table must go through pair_env_id() (the env) or `>> 24` (the count),
+    and nothing else may touch the raw word"""
+    import re
+    src = open(os.path.join(REPO, 'roboticsplayroompybullet_amd', 'csrc', 'rp_kernels.cuh')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)                                              # comments
+    src = re.sub(r'__device__ __forceinline__ int pair_env_id\(int pe\) \{.*?\n\}', '', src, flags=re.S)      # the helper itself
+    reads = re.findall(r'const int (\w+) = [^;]*pair_env\[[^;]*;', src)
+    assert len(reads) >= 3, reads
+    for name in set(reads):
+        for line in src.splitlines():
+            if 'pair_env[' in line or not re.search(r'\b%s\b' % name, line):
+                continue
+            rest = line
+            for allowed in (r'pair_env_id\(%s\)', r'\(?%s >> 24\)?', r'%s < 0', r'%s >= 0'):
+                rest = re.sub(allowed % name, '', rest)
+            assert not re.search(r'\b%s\b' % name, rest), 'raw use of a pair_env word: %s' % line.strip()

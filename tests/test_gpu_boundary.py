@@ -40,6 +40,39 @@ def test_pack_output_is_the_gather_message_bitwise():
         assert torch.equal(u['obs_quat'], obs['obs_quat']) and torch.equal(u['is_success'], info['is_success'])
 
 
+def test_every_writer_of_the_pack_takes_the_other_buffer():
+    """step, reset(mask), calc_state all write rp_out.pack; an asynchronous all-gather of the previous pack may still be reading it on RCCL's
+    stream (sharding.gather_observations(async_op=True): the auto-reset loop is step -> async gather -> masked reset), so every writer gets the
+    OTHER of the two buffers and the one handed to the gather stays as it was; a masked reset carries the rows it does not rewrite over."""
+    import torch
+    from roboticsplayroompybullet_amd import VecPlayEnv
+    n = 8
+    env = VecPlayEnv('UR5PlayAbsRPY1Obj-v0', n, seed=3)
+    env.reset()
+    a = torch.zeros((n, 7)); a[:, :3] = torch.tensor([0.0, 0.15, 0.2])
+    obs, r, _, info = env.step(a)
+    sent = env.pack                         # what a gather of this step would be reading
+    want = sent.clone()
+    mask = torch.zeros(n, dtype=torch.uint8); mask[[1, 6]] = 1
+    ob2 = env.reset(mask=mask)
+    torch.cuda.synchronize()
+    assert env.pack.data_ptr() != sent.data_ptr()
+    assert torch.equal(sent, want)          # untouched by the reset
+    keep = (mask == 0).to(sent.device)
+    w = env.dims['obs_quat']
+    assert torch.equal(env.pack[keep], want[keep])                                   # rows of the envs that were not reset: carried over
+    assert torch.equal(env.pack[~keep][:, :w], ob2['obs_quat'][~keep])               # rows of the reset envs: their fresh observation
+    assert not torch.equal(env.pack[~keep], want[~keep])
+    sent2, want2 = env.pack, env.pack.clone()
+    env.calc_state()
+    torch.cuda.synchronize()
+    assert env.pack.data_ptr() != sent2.data_ptr() and torch.equal(sent2, want2)
+    sent3, want3 = env.pack, env.pack.clone()
+    env.reset()                             # unmasked: every row rewritten, still the other buffer
+    torch.cuda.synchronize()
+    assert env.pack.data_ptr() != sent3.data_ptr() and torch.equal(sent3, want3)
+
+
 def test_two_handles_one_process_distinct_streams():
     """two handles driven alternately on their own torch streams (and with another device-current state around the calls) ==
     the same two handles driven one after the other: handles share nothing"""
@@ -129,6 +162,10 @@ def test_constructor_kwargs_reach_the_device():
     # dense reward (sparse=False): -||ag - dg|| on every id, over the whole goal vector for the play ids (environments.py:269-275)
     dense = VecPlayEnv(U, n, seed=4, sparse=False)
     obs = dense.reset()
+    # a dense env keeps the first draw of its reset (the reference's `while r > -1` would not end: INTEGRATION.md): rounds = object re-samples only, not 64 attempts
+    assert dense.lib.rp_debug_reset_rounds(dense.h) <= 9
+    o_d = OracleEnv('U', seed=4, env_index=0, f32=True, dense_reward=True).reset()
+    np.testing.assert_allclose(obs['obs_quat'][0].cpu().numpy()[:7], o_d['obs_quat'][:7], atol=1e-4, rtol=0)
     o2, r2, _, info = dense.step(acts(1, n, 0)[0])
     want = -torch.linalg.vector_norm(o2['achieved_goal'] - o2['desired_goal'], dim=1)
     torch.testing.assert_close(r2, want, atol=1e-6, rtol=1e-6)

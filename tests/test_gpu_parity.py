@@ -95,8 +95,10 @@ def test_rollout_200_steps_vs_fp64_oracle(kind):
     acts = actions(kind, steps, n, 5)
     n_arm, nm = fol[0].o64.n_arm, N_MAIN[kind]
     d_hip, d_o32, g_hip = np.zeros(n), np.zeros(n), np.zeros(n)
+    capped = np.zeros(n, bool)
     for t in range(steps):
         obs, r, done, info = env.step(torch.tensor(acts[t], dtype=torch.float32))
+        capped |= (info['status'].cpu().numpy() & 8) != 0        # the device says so itself: this env's IK ran out of iterations in this step
         q = arm_q(env, kind)
         for e, f in enumerate(fol):
             f.step(acts[t, e].astype(np.float32).astype(np.float64))
@@ -114,6 +116,10 @@ def test_rollout_200_steps_vs_fp64_oracle(kind):
     assert bad.size == 0, 'envs %s: device %s, fp32 CPU oracle %s' % (bad, d_hip[bad], d_o32[bad])
     assert (g_hip <= GRIP_JOINT_TOL).all(), g_hip
     assert strict.mean() >= 0.9
+    # every env that neither had an IK run out of iterations (status bit 8) nor is sensitive by the CPU followers' own account meets the plain bound
+    plain = ~capped & (d_o32 <= 1e-3 / 3)
+    print('    IK ran out of iterations at least once in %d envs; envs neither capped nor sensitive: %d, all of them within 1e-3: %s' % (int(capped.sum()), int(plain.sum()), bool(strict[plain].all())))
+    assert strict[plain].all(), (np.where(plain & ~strict)[0], d_hip[plain & ~strict])
 
 
 def test_rollout_sampled_envs_of_4096_vs_fp64_oracle():
@@ -543,12 +549,12 @@ def test_full_size_properties():
     n = 4096
     env = VecPlayEnv(IDS['U'], n, seed=77)
     obs = env.reset()
-    assert int(env.buf['status'].sum()) == 0
+    assert int((env.buf['status'] & 7).sum()) == 0
     acts = torch.tensor(actions('U', 25, n, 4), dtype=torch.float32)
     for t in range(25):
         obs, r, done, info = env.step(acts[t])
     torch.cuda.synchronize()
-    assert int(info['status'].sum()) == 0
+    assert int((info['status'] & 7).sum()) == 0
     o = obs['obs_quat']
     assert torch.isfinite(o).all()
     assert torch.allclose(o[:, 3:7].norm(dim=1), torch.ones(n, device=o.device), atol=1e-4)      # ee quaternion
@@ -581,7 +587,7 @@ def test_config_ur5_play_1024_envs_1000_steps():
             obs, r, done, info = env.step(acts[t])
             succ += info['is_success']
         torch.cuda.synchronize()
-        assert int(info['status'].sum()) == 0
+        assert int((info['status'] & 7).sum()) == 0
         o = obs['obs_quat']
         assert torch.isfinite(o).all() and torch.isfinite(env.get_state()).all()
         assert torch.allclose(o[:, 3:7].norm(dim=1), torch.ones(n, device=o.device), atol=1e-4)
@@ -654,7 +660,7 @@ def test_config_cem_mpc_broadcast_rollouts():
         if t == 9:
             first = obs['obs_quat'][0].clone()
     torch.cuda.synchronize()
-    assert int(info['status'].sum()) == 0
+    assert int((info['status'] & 7).sum()) == 0
     s = env.get_state().reshape(n_start, n_cand, -1)
     assert torch.equal(s[:, 0], s[:, 1])                               # identical candidates: identical trajectories
     ret = ret.reshape(n_start, n_cand)
@@ -772,7 +778,7 @@ def test_two_object_play_ids_vs_oracle(gid):
             qo = o.get_state()[:9]
             worst = max(worst, float((np.abs(q[e] - qo) / np.maximum(1.0, np.abs(qo))).max()))
             np.testing.assert_allclose(info['target_poses'][e].cpu().numpy(), io['target_poses'], atol=2e-3, rtol=0)
-        assert int(info['status'].sum()) == 0
+        assert int((info['status'] & 7).sum()) == 0
     print('%s: relative joint divergence over 30 steps vs the fp64 oracle: %.2e' % (gid, worst))
     assert worst <= 1e-3
     for e, o in enumerate(o64):

@@ -13,5 +13,5 @@ for gid, n in cfgs:
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for t in range(20, 120): o, r, d, info = env.step(acts[t])
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print('%s N=%d: reset %.0f ms, %.2f ms/step, %.0f env-steps/s, flagged %d' % (gid, n, 1e3 * tr, 1e3 * dt / 100, n * 100 / dt, int(info['status'].sum())))
+    print('%s N=%d: reset %.0f ms, %.2f ms/step, %.0f env-steps/s, flagged %d' % (gid, n, 1e3 * tr, 1e3 * dt / 100, n * 100 / dt, int((info['status'] & 7).sum())))
     env.close()
