@@ -114,6 +114,9 @@ def load(f32=False, bullet_ref=False):
     lib.rpo_contacts.argtypes = [vp, dp, C.c_int]
     lib.rpo_last_num_rows.argtypes = [vp]
     lib.rpo_contact_substeps.argtypes = [vp]
+    lib.rpo_arm_table.argtypes = [vp, dp]
+    lib.rpo_collider_dynamics.argtypes = [vp, dp]
+    lib.rpo_set_arm_q.argtypes = [vp, dp]
     lib.rpo_box_box.argtypes = [dp, dp, dp, dp, dp, dp, C.c_double, dp]
     lib.rpo_collider_poses.argtypes = [vp, dp]
     lib.rpo_collider_table.argtypes = [vp, dp]
@@ -369,6 +372,25 @@ class OracleEnv:
         out = np.zeros((max_n, 9))
         n = self.lib.rpo_contacts(self.h, out.ctypes.data_as(C.POINTER(C.c_double)), max_n)
         return out[:min(n, max_n)]
+
+    def arm_table(self):
+        """[n_arm, 6]: jtype, lower, upper, body mass, Bullet joint index, parent dof"""
+        t = np.zeros((self.n_arm, 6))
+        self.lib.rpo_arm_table(self.h, t.ctypes.data_as(C.POINTER(C.c_double)))
+        return t
+
+    def colliders(self):
+        """every collider at the current state: dict(type, he [3], R [3, 3], p [3], body, friction, mass, stiffness, damping, threshold, link)"""
+        tab, dyn, pose = np.zeros((64, 9)), np.zeros((64, 6)), np.zeros((64, 12))
+        dp = C.POINTER(C.c_double)
+        n = self.lib.rpo_collider_table(self.h, tab.ctypes.data_as(dp))
+        self.lib.rpo_collider_dynamics(self.h, dyn.ctypes.data_as(dp))
+        self.lib.rpo_collider_poses(self.h, pose.ctypes.data_as(dp))
+        return [dict(type=int(tab[c, 0]), he=tab[c, 1:4].copy(), R=pose[c, :9].reshape(3, 3).copy(), p=pose[c, 9:12].copy(), body=int(dyn[c, 0]), friction=dyn[c, 1],
+                     mass=dyn[c, 2], stiffness=dyn[c, 3], damping=dyn[c, 4], threshold=dyn[c, 5], link=int(tab[c, 8])) for c in range(n)]
+
+    def set_arm_q(self, q):
+        self.lib.rpo_set_arm_q(self.h, _d(q)[1])
 
     def num_rows(self):
         return self.lib.rpo_last_num_rows(self.h)

@@ -1798,6 +1798,28 @@ int rpo_collider_table(const rpo_env* e, double* out) {
   return m->n_col;
 }
 
+/* the baked tables as the oracle holds them (tests/test_bake_independent.py walks them against an independent reading of the reference's files) */
+int rpo_arm_table(const rpo_env* e, double* out) {       /* per dof: jtype, lower, upper, body mass, Bullet joint index, parent dof */
+  const rp_model* m = &e->m;
+  for (int i = 0; i < m->n_arm; i++) {
+    double* o = out + 6 * i;
+    o[0] = m->arm_jtype[i]; o[1] = m->arm_lower[i]; o[2] = m->arm_upper[i]; o[3] = m->arm_mass[i]; o[4] = m->arm_bullet_index[i]; o[5] = m->arm_parent[i];
+  }
+  return m->n_arm;
+}
+int rpo_collider_dynamics(const rpo_env* e, double* out) {   /* per collider: body, lateral friction, mass of the body (0 = static), contact stiffness, damping, breaking threshold */
+  const rp_model* m = &e->m;
+  for (int c = 0; c < m->n_col; c++) {
+    double* o = out + 6 * c;
+    int b = m->col_body[c], kf = body_free_index(e, b), kj = body_j1_index(e, b);
+    o[0] = b; o[1] = m->col_friction[c];
+    o[2] = b == 0 ? 0 : (body_is_arm(e, b) ? m->arm_mass[b - 1] : (kf >= 0 ? m->free_mass[kf] : (kj >= 0 ? m->j1_mass[kj] : -1)));
+    o[3] = m->col_stiffness[c]; o[4] = m->col_damping[c]; o[5] = m->col_thr[c];
+  }
+  return m->n_col;
+}
+void rpo_set_arm_q(rpo_env* e, const double* q) { for (int i = 0; i < e->m.n_arm; i++) { e->q[i] = (real)q[i]; e->qd[i] = 0; } }
+
 int rpo_box_box(const double* ca, const double* Ra, const double* ha, const double* cb, const double* Rb, const double* hb,
                 double margin, double* out) {
   real a[3], A[9], h1[3], b[3], Bm[9], h2[3];

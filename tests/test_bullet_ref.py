@@ -181,3 +181,20 @@ def test_default_flags_are_everything_but_warm_starting():
     env = OracleEnv('U', seed=0, env_index=0, bullet_ref=True)
     assert env.lib.rpo_get_ref_flags(env.h) == oracle.REF_DEFAULT == sum(v for k, v in oracle.REF_FLAGS.items() if k != 'warm')
     assert oracle.REF_DEFAULT == 255 + 512
+
+
+FROZEN_SHA256 = {       # recorded in DESIGN.md section 2 ("the freeze"); the file last changed in commit 2bd34cf (round 2, before any of that round's kernel work)
+    'oracle/rp_bullet_ref.c': '35ea2de6f7c903a6ff344558d48a6fc691e433c5366499d361ccf2e274548d0c',
+    'oracle/generated/rp_hulls_gen.h': '1c2e6a61327da163d5c7e7c90b8ce7a1043309625e33e29caf8787881fc01a96',
+}
+
+
+def test_the_reference_step_is_frozen():
+    """kernel work may not touch the frozen reference step: an edit of rp_bullet_ref.c (or of the hull tables it includes) fails here and has to be a
+    visible, justified event - correct a recollection of Bullet, say so in DESIGN.md section 2, record the new hash there and here"""
+    import hashlib
+    import os
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for rel, want in FROZEN_SHA256.items():
+        got = hashlib.sha256(open(os.path.join(repo, rel), 'rb').read()).hexdigest()
+        assert got == want, '%s changed (sha256 %s): the reference step is frozen, see DESIGN.md section 2' % (rel, got)
