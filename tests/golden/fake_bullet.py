@@ -221,6 +221,72 @@ class FakeClient:
         pass
 
 
+class StaticWorldClient(FakeClient):
+    """A FakeClient whose world answers by itself - no physics: joints stay where resetJointState put them, bodies where they were created /
+    reset, links at a fixed pose - plus the read-only calls tools/pybullet_replay.py makes on a real PyBullet (getDynamicsInfo,
+    calculateMassMatrix, getContactPoints, getPhysicsEngineParameters, getAPIVersion, the full getJointInfo / getLinkState tuples).
+    tests/test_pybullet_golden.py runs the replay tool's PyBullet half against it, end to end, so that the half a human with a real PyBullet
+    has to run works on the first try.  Whatever it records is FORMAT, never a pin."""
+
+    def __init__(self, connection_mode=None):
+        super().__init__(connection_mode)
+        self.world = {'joint': {}, 'link': {}, 'base': {}, 'ray': [(-1, -1, 1.0, (0.0, 0.0, 0.0), (0.0, 0.0, 0.0))]}
+
+    def _n_movable(self, body):
+        kind = self.body_kind.get(body)
+        types_ = UR5_JOINT_TYPES if kind == 'ur5' else (PANDA_JOINT_TYPES if kind == 'panda' else [0] * self.body_links.get(body, 0))
+        return sum(1 for t in types_ if t != self.JOINT_FIXED)
+
+    def createMultiBody(self, *a, **k):
+        b = super().createMultiBody(*a, **k)
+        pos = k.get('basePosition', a[3] if len(a) > 3 else [0.0, 0.0, 0.0])
+        orn = k.get('baseOrientation', a[4] if len(a) > 4 else [0.0, 0.0, 0.0, 1.0])
+        self.world['base'][b] = {'pos': [float(v) for v in pos], 'orn': [float(v) for v in orn], 'lin': [0.0] * 3, 'ang': [0.0] * 3}
+        return b
+
+    def loadURDF(self, fileName, *a, **k):
+        b = super().loadURDF(fileName, *a, **k)
+        pos = a[0] if len(a) > 0 else k.get('basePosition', [0.0, 0.0, 0.0])
+        orn = a[1] if len(a) > 1 else k.get('baseOrientation', [0.0, 0.0, 0.0, 1.0])
+        self.world['base'][b] = {'pos': [float(v) for v in pos], 'orn': [float(v) for v in orn], 'lin': [0.0] * 3, 'ang': [0.0] * 3}
+        return b
+
+    def getJointState(self, body, j):
+        return (self.world['joint'].get((body, j), 0.0), 0.0, (0.0,) * 6, 0.0)
+
+    def getJointInfo(self, body, j):
+        kind = self.body_kind[body]
+        types_ = UR5_JOINT_TYPES if kind == 'ur5' else (PANDA_JOINT_TYPES if kind == 'panda' else [self.JOINT_PRISMATIC] * 8)
+        # (index, name, type, qIndex, uIndex, flags, damping, friction, lower, upper, maxForce, maxVelocity, linkName, axis, parentFramePos, parentFrameOrn, parentIndex)
+        return (j, b'joint%d' % j, types_[j], j, j, 0, 0.0, 0.0, -1.0, 1.0, 100.0, 1.0, b'link%d' % j, (0.0, 0.0, 1.0), (0.0, 0.0, 0.0), (0.0, 0.0, 0.0, 1.0), j - 1)
+
+    def getLinkState(self, body, link, computeLinkVelocity=0):
+        s = self.world['link'].get((body, link), {'pos': [0.1, 0.2, 0.3 + 0.01 * link], 'orn': [0.0, 0.0, 0.0, 1.0], 'lin': [0.0] * 3, 'ang': [0.0] * 3})
+        return (tuple(s['pos']), tuple(s['orn']), (0.0, 0.0, 0.0), (0.0, 0.0, 0.0, 1.0), tuple(s['pos']), tuple(s['orn']), tuple(s['lin']), tuple(s['ang']))
+
+    def calculateInverseKinematics(self, body, *a, **k):
+        self._rec('calculateInverseKinematics', (body,) + a, k, None)
+        return tuple([0.0] * self._n_movable(body))
+
+    def getDynamicsInfo(self, body, link):
+        # (mass, lateral friction, local inertia diagonal, local inertial pos, local inertial orn, restitution, rolling friction, spinning friction,
+        #  contact damping, contact stiffness, body type, collision margin)
+        return (1.0, 0.5, (1.0, 1.0, 1.0), (0.0, 0.0, 0.0), (0.0, 0.0, 0.0, 1.0), 0.0, 0.0, 0.0, -1.0, -1.0, 2, 0.001)
+
+    def calculateMassMatrix(self, body, q):
+        n = len(q)
+        return tuple(tuple(1.0 if i == j else 0.0 for j in range(n)) for i in range(n))
+
+    def getContactPoints(self, *a, **k):
+        return ()
+
+    def getPhysicsEngineParameters(self):
+        return {'fixedTimeStep': 1.0 / 300.0, 'numSolverIterations': 50, 'numSubSteps': 0, 'useSplitImpulse': 0, 'contactBreakingThreshold': 0.02}
+
+    def getAPIVersion(self):
+        return 0
+
+
 class _Box:
     def __init__(self, low, high):
         self.low = np.asarray(low, dtype=np.float32)
@@ -237,12 +303,13 @@ class _Dict:
 REGISTRY = []
 
 
-def install_stubs(shared_clients):
+def install_stubs(shared_clients, client_class=None):
     """Put pybullet / pybullet_data / pybullet_utils.bullet_client / gym stubs in sys.modules.
 
-    Every BulletClient() the reference constructs is appended to `shared_clients`.
+    Every BulletClient() the reference constructs is appended to `shared_clients`.  client_class: FakeClient (default) or StaticWorldClient.
     """
-    module_client = FakeClient()
+    client_class = client_class or FakeClient
+    module_client = client_class()
 
     pb = types.ModuleType('pybullet')
     for name in dir(FakeClient):
@@ -260,7 +327,7 @@ def install_stubs(shared_clients):
     bc = types.ModuleType('pybullet_utils.bullet_client')
 
     def BulletClient(connection_mode=None):
-        c = FakeClient(connection_mode)
+        c = client_class(connection_mode)
         shared_clients.append(c)
         return c
 

@@ -119,3 +119,52 @@ def test_fixture_pipeline_with_an_oracle_written_fixture(tmp_path):
         assert rel.max() < 1e-9 and tp.max() < 1e-9 and (len(blk) == 0 or blk.max() < 1e-9)
         relB, _, _ = replay_on_oracle(fx, bullet_ref=True)
         assert np.isfinite(relB).all()
+
+
+FAKE_RUN = r'''
+import json, os, sys, types
+sys.path.insert(0, os.path.join(%(repo)r, 'tests', 'golden')); sys.path.insert(0, os.path.join(%(repo)r, 'tools'))
+import fake_bullet
+gold = json.load(open(os.path.join(%(repo)r, 'tests', 'golden', 'assets_independent.json')))
+def joint_types(model):       # Bullet's joint order: depth-first, children in XML order (pybullet: 0 revolute, 1 prismatic, 4 fixed)
+    out = []
+    def visit(link):
+        for j in model['joints']:
+            if j['parent'] == link:
+                out.append({'revolute': 0, 'continuous': 0, 'prismatic': 1}.get(j['type'], 4)); visit(j['child'])
+    visit(model['root'])
+    return out
+fake_bullet.UR5_JOINT_TYPES, fake_bullet.PANDA_JOINT_TYPES = joint_types(gold['ur5']), joint_types(gold['panda'])
+clients = []
+fake_bullet.install_stubs(clients, fake_bullet.StaticWorldClient)
+import pybullet_replay
+args = types.SimpleNamespace(env=%(env)r, steps=4, seed=0, scenario=%(scenario)r, reference_root='/root/reference', dump=%(out)r, source_label='fake')
+pybullet_replay.dump_from_pybullet(args)
+'''
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference'), reason='needs the reference repo (build container only)')
+@pytest.mark.parametrize('env_id,scenario', [('UR5PlayAbsRPY1Obj-v0', 'random'), ('pandaPick-v0', 'grasp')])
+def test_the_pybullet_half_of_the_replay_tool_runs_end_to_end_on_a_fake_client(env_id, scenario, tmp_path):
+    """tools/pybullet_replay.py --dump has to work on the first try on the one machine with a real PyBullet: here its PyBullet half drives the
+    REFERENCE'S OWN env class against tests/golden/fake_bullet.StaticWorldClient (no physics: format only, `source` = "fake", never a pin) and
+    the fixture it writes has every section the consumers read"""
+    out = str(tmp_path / 'fx.json')
+    r = subprocess.run([sys.executable, '-c', FAKE_RUN % {'repo': REPO, 'env': env_id, 'scenario': scenario, 'out': out}], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    fx = json.load(open(out))
+    assert fx['source'] == 'fake' and fx['format'] == pybullet_replay.FORMAT and fx['env'] == env_id
+    n = 12 if env_id.startswith('UR5') else 9
+    for key in ('joint_info', 'dynamics_info', 'mass_matrix', 'ik_probes', 'link_states_at_reset', 'contact_points_at_reset', 'physics_engine_parameters',
+                'pybullet_api_version', 'initial_state', 'initial_obs', 'trajectory'):
+        assert key in fx, key
+    assert len(fx['trajectory']) == 4 and len(fx['initial_state']['q']) == n and len(fx['mass_matrix']['M']) == n
+    assert len(fx['dynamics_info']) == len(fx['joint_info']) + 1
+    s = fx['trajectory'][-1]
+    assert {'q', 'qd', 'action', 'obs_quat', 'reward', 'target_poses', 'block_pos'} <= set(s)
+    if env_id.startswith('UR5Play'):
+        assert len(s['scene_joints']) == 3 and len(s['drawer_pos']) == 3
+    # the consumers' state hand-over accepts it
+    o = OracleEnv(env_id, seed=0)
+    v = pybullet_replay.state_vector_from_snapshot(o.kind, o.n_arm, fx['initial_state'])
+    assert v.shape == (o.lib.rpo_state_size(o.h),)

@@ -5,6 +5,8 @@
 Two halves, joined by a JSON fixture:
 
   1. ON ANY MACHINE WITH `pip install pybullet gym==0.21` AND THE REFERENCE REPO:
+         python tools/pybullet_replay.py --all --reference-root /path/to/RoboticsPlayroomPybullet        (five ids x {random, grasp})
+     or one at a time:
          python tools/pybullet_replay.py --dump tests/golden/pybullet_UR5PlayAbsRPY1Obj-v0.json \\
                 --env UR5PlayAbsRPY1Obj-v0 --reference-root /path/to/RoboticsPlayroomPybullet [--steps 200 --seed 0 --scenario random|grasp]
      runs the REFERENCE'S OWN env class on PyBullet (nothing is restated), and records
@@ -34,6 +36,7 @@ FORMAT = 1
 CLASSES = {'UR5PlayAbsRPY1Obj-v0': 'UR5PlayAbsRPY1Obj', 'UR5Reach-v0': 'UR5Reach', 'pandaPick-v0': 'pandaPick', 'pandaReach-v0': 'pandaReach',
            'pandaPlayAbsRPY1Obj-v0': 'pandaPlayAbsRPY1Obj', 'pandaPush-v0': 'pandaPush'}
 # Bullet joint indices of the movable arm joints, in this repo's dof order
+ALL_IDS = ['UR5PlayAbsRPY1Obj-v0', 'UR5Reach-v0', 'pandaPick-v0', 'pandaReach-v0', 'pandaPlayAbsRPY1Obj-v0']     # BASELINE.json's ids and their Panda / reach counterparts
 ARM_JOINTS = {'UR5': [0, 1, 2, 3, 4, 5, 10, 12, 13, 15, 18, 20], 'Panda': [0, 1, 2, 3, 4, 5, 6, 9, 10]}
 LO = np.array([-0.18, 0.0, 0.05, -0.5, -0.5, -0.5, -1.0])
 HI = np.array([0.18, 0.3, 0.3, 0.5, 0.5, 0.5, 1.0])
@@ -74,7 +77,7 @@ def dump_from_pybullet(args):
     arm = inst.arm
     arm_type = inst.arm_type
     joints = ARM_JOINTS[arm_type]
-    out = {'format': FORMAT, 'source': 'pybullet', 'env': args.env, 'seed': args.seed, 'scenario': args.scenario, 'arm_type': arm_type,
+    out = {'format': FORMAT, 'source': getattr(args, 'source_label', 'pybullet'), 'env': args.env, 'seed': args.seed, 'scenario': args.scenario, 'arm_type': arm_type,
            'pybullet_api_version': c.getAPIVersion(), 'physics_engine_parameters': {k: v for k, v in c.getPhysicsEngineParameters().items()}}
     # known answers
     n_joints = c.getNumJoints(arm)
@@ -193,10 +196,23 @@ def main():
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--scenario', default='random', choices=['random', 'grasp'])
     ap.add_argument('--reference-root', default='/root/reference')
-    ap.add_argument('--dump', required=True, help='fixture to write, e.g. tests/golden/pybullet_<env id>.json')
+    ap.add_argument('--dump', help='fixture to write, e.g. tests/golden/pybullet_<env id>.json')
+    ap.add_argument('--all', action='store_true', help="every BASELINE id x {random, grasp} into tests/golden/pybullet_<env id>_<scenario>.json (the grasp scenario only for ids with a block)")
     ap.add_argument('--from-oracle', action='store_true', help='write the fixture from the CPU oracle (format check only)')
     args = ap.parse_args()
-    (dump_from_oracle if args.from_oracle else dump_from_pybullet)(args)
+    dump = dump_from_oracle if args.from_oracle else dump_from_pybullet
+    if args.all:
+        for env_id in ALL_IDS:
+            for scenario in ('random', 'grasp'):
+                if scenario == 'grasp' and 'Reach' in env_id:
+                    continue
+                args.env, args.scenario = env_id, scenario
+                args.dump = os.path.join(REPO, 'tests', 'golden', 'pybullet_%s_%s.json' % (env_id, scenario))
+                dump(args)
+        return
+    if not args.dump:
+        ap.error('--dump FILE or --all')
+    dump(args)
 
 
 if __name__ == '__main__':
