@@ -379,7 +379,7 @@ class OracleEnv:
         self.lib.rpo_arm_table(self.h, t.ctypes.data_as(C.POINTER(C.c_double)))
         return t
 
-    def colliders(self):
+    def collider_list(self):
         """every collider at the current state: dict(type, he [3], R [3, 3], p [3], body, friction, mass, stiffness, damping, threshold, link)"""
         tab, dyn, pose = np.zeros((64, 9)), np.zeros((64, 6)), np.zeros((64, 12))
         dp = C.POINTER(C.c_double)

@@ -226,7 +226,7 @@ def test_arm_colliders_sit_on_their_links(kind):
     q[:6] = [-1.5, -1.6, -1.9, -1.2, 1.57, 0.07]
     o.set_arm_q(q)
     link, _ = arm.frames(q)
-    cols = [c for c in o.colliders() if c['link'] >= 0 or (c['body'] == 0 and c['link'] == -1 and False)]
+    cols = [c for c in o.collider_list() if c['link'] >= 0 or (c['body'] == 0 and c['link'] == -1 and False)]
     seen = 0
     for li, (j, par) in enumerate(arm.order):
         ln = arm.m['links'][j['child']]
@@ -287,7 +287,7 @@ def test_scene_colliders_against_the_reference_scene_calls(kind):
     log = SCN[KINDS[kind][2]]['log']
     bodies = scene_bodies(log)
     fric = {c['args'][0]: c['kwargs']['lateralFriction'] for c in log if c['fn'] == 'changeDynamics' and 'lateralFriction' in c['kwargs']}
-    cols = [c for c in o.colliders() if c['link'] < 0]                # everything that is not an arm link (the arm's base link has link -1 too: excluded by place below)
+    cols = [c for c in o.collider_list() if c['link'] < 0]                # everything that is not an arm link (the arm's base link has link -1 too: excluded by place below)
     used = set()
 
     def find(shape, R, p, mass, what):

@@ -90,6 +90,29 @@ def test_door_slid_by_the_arm():
     print('door scenario: worst error / tolerance = %.2f' % worst)
 
 
+def test_dial_turned_by_the_closed_gripper():
+    """the dial (scenes.py:345-426: a 0.1 kg box link on a revolute joint about world -y at the table's front face, held only by Bullet's default
+    velocity motor, max impulse 1 per substep) with the closed gripper pressed down on its rim, 15 mm off its axis: the joint turns by several tenths of
+    a radian (the arm's push outweighs the motor), obs_quat[18] = dial_to_0_1_range(q) follows through the wrap of scenes.py:342-343 - every step of
+    the device against the fp32 oracle inside the fp32 / fp64 envelope, and all three agree on how far it went"""
+    env, o32, o64 = make(3, 8)
+    seen = {}
+
+    def note(target, obs):
+        seen[target] = obs['obs_quat'][:, 18].cpu().numpy().copy()
+    script = [((0.215, -0.055, 0.10), 1.0, 30), ((0.215, -0.055, -0.02), 1.0, 40), ((0.215, -0.055, -0.09), 1.0, 40)]
+    obs, worst = drive(env, o32, o64, script, atol=2e-3, check=note)
+    before, after = seen[(0.215, -0.055, -0.02)], seen[(0.215, -0.055, -0.09)]
+    assert (before == 0).all(), before                                          # nothing touched it on the way down
+    q = env.get_state()[:, JQ + 2].cpu().numpy()
+    q32 = np.array([o.get_state()[2 * o.n_arm + 26 + 2] for o in o32])
+    assert (np.abs(q) > 0.1).all() and (np.abs(q) < 2.0).all(), q                # turned, not spun
+    np.testing.assert_allclose(q, q32, atol=max(2e-2, 3 * float(np.abs(q32 - np.array([o.get_state()[2 * o.n_arm + 26 + 2] for o in o64])).max())))
+    want = (q - 2.0 * np.floor(q / 2.0)) / 2.2                                   # dial_to_0_1_range: (q mod 2) / 2.2 with Python's modulo
+    np.testing.assert_allclose(after, want, atol=1e-5)
+    print('dial scenario: q = %s, worst error / tolerance = %.2f' % (q, worst))
+
+
 def test_button_pressed_by_a_dropped_block():
     """the block (0.3 kg) dropped on the button (spring = position motor, target 0.03, force 1 N: scenes.py:238) presses it below the
     toggle threshold q < 0.025 (environments.py:474): obs_quat[17] against the oracle through the contact phase"""

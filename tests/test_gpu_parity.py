@@ -95,10 +95,10 @@ def test_rollout_200_steps_vs_fp64_oracle(kind):
     acts = actions(kind, steps, n, 5)
     n_arm, nm = fol[0].o64.n_arm, N_MAIN[kind]
     d_hip, d_o32, g_hip = np.zeros(n), np.zeros(n), np.zeros(n)
-    capped = np.zeros(n, bool)
+    capped = np.zeros(n)
     for t in range(steps):
         obs, r, done, info = env.step(torch.tensor(acts[t], dtype=torch.float32))
-        capped |= (info['status'].cpu().numpy() & 8) != 0        # the device says so itself: this env's IK ran out of iterations in this step
+        capped += (info['status'].cpu().numpy() & 8) != 0        # the device says so itself: this env's IK ran out of iterations in this step
         q = arm_q(env, kind)
         for e, f in enumerate(fol):
             f.step(acts[t, e].astype(np.float32).astype(np.float64))
@@ -116,10 +116,11 @@ def test_rollout_200_steps_vs_fp64_oracle(kind):
     assert bad.size == 0, 'envs %s: device %s, fp32 CPU oracle %s' % (bad, d_hip[bad], d_o32[bad])
     assert (g_hip <= GRIP_JOINT_TOL).all(), g_hip
     assert strict.mean() >= 0.9
-    # every env that neither had an IK run out of iterations (status bit 8) nor is sensitive by the CPU followers' own account meets the plain bound
-    plain = ~capped & (d_o32 <= 1e-3 / 3)
-    print('    IK ran out of iterations at least once in %d envs; envs neither capped nor sensitive: %d, all of them within 1e-3: %s' % (int(capped.sum()), int(plain.sum()), bool(strict[plain].all())))
-    assert strict[plain].all(), (np.where(plain & ~strict)[0], d_hip[plain & ~strict])
+    # status bit 8 (the IK ran out of its 4 x 20 / 200 iterations in that step; the joint targets then hang on the measured joints): how common it is, and
+    # whether the envs that leave 1e-3 are the ones where it happens most - reported, not asserted: with a new random target every step it happens in
+    # every env sooner or later, so it cannot single envs out
+    print('    IK out of iterations (status bit 8): %.1f %% of the env-steps, at least once in %d of %d envs; mean count in the envs beyond 1e-3: %.1f, in the others: %.1f'
+          % (100.0 * capped.sum() / (n * steps), int((capped > 0).sum()), n, capped[~strict].mean() if (~strict).any() else 0.0, capped[strict].mean()))
 
 
 def test_rollout_sampled_envs_of_4096_vs_fp64_oracle():
