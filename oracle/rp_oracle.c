@@ -20,6 +20,7 @@
 
 #include "rp_math.h"
 #include "../roboticsplayroompybullet_amd/csrc/generated/rp_models_gen.h"
+#include "../roboticsplayroompybullet_amd/csrc/generated/rp_hullverts_gen.h"
 
 /* ------------------------------------------------------------------ solver constants (hypotheses) */
 #define DT ((real)(1.0 / 300.0))        /* environments.py:68-69,233 */
@@ -39,6 +40,8 @@
 #define ERP_LIMIT ((real)0.2)           /* btContactSolverInfo::m_erp: joint-limit rows under RPO_RULE_LIMIT */
 #define RPO_RULE_ORDER 1
 #define RPO_RULE_LIMIT 2
+#define RPO_RULE_HULLFACE 4         /* arm links touch static boxes with the vertices of their collision meshes' convex hulls (hull_face) instead of their OBBs */
+#define HULL_MARGIN ((real)RP_HULL_MARGIN)
 #define FREE_LIN_DAMP ((real)0.04)
 #define FREE_ANG_DAMP ((real)0.04)
 #define J1_ANG_DAMP ((real)0.04)        /* changeDynamics(linearDamping=0) leaves angular at the 0.04 default */
@@ -392,6 +395,62 @@ static int manifold_replace_index(const contact* c4, const contact* pt) {
  * the static world keeps only its deepest point: all its points share one Jacobian.  Caps (shared with the HIP
  * library): the first 64 AABB-overlapping pairs are examined, their first 64 candidate points enter the manifolds, the first 21
  * contact points are kept. */
+/* Arm link (convex hull of its collision mesh, Bullet margin 0.001 around it) against a static box: separating-axis test over the box's six face
+ * normals on the hull's VERTICES; the contact is the hull vertex deepest along the face of least penetration, if it lies over that face.  This is
+ * what GJK / EPA return for a vertex-on-face contact (the generic case of a link touching the ground plate or the table top); anything else
+ * (vertex beside the face: edges, corners) is left to the OBB path.  Returns 1 and the point, 0 = no contact within margin, -1 = use the OBB path. */
+static int hull_face(const rpo_env* e, int a, int b, real margin, cpoint* out) {
+  const rp_model* m = &e->m;
+  const float (*hv)[4]; const int *hoff, *hcnt;
+  rp_hull_tables(m->kind, &hv, &hoff, &hcnt);
+  const int nvert = hcnt ? hcnt[a] : 0;
+  if (nvert == 0) return -1;
+  hv += hoff[a];
+  const xform* xa = &e->xb[m->col_body[a]];     /* hull vertices live in the body frame */
+  const xform* xb = &e->xc[b];
+  /* the box in the hull's body frame: per box axis k the direction u_k = Ra^T Rb e_k and the offset of the box centre along it, so that a vertex v has
+   * the box coordinate l_k = u_k . v - c_k (one dot product per axis and vertex; same arithmetic as the HIP library) */
+  real u[3][3], c[3];
+  for (int k = 0; k < 3; k++) {
+    real bk[3] = {xb->R[k], xb->R[3 + k], xb->R[6 + k]}, t[3];
+    m3tmulv(u[k], xa->R, bk);
+    v3sub(t, xb->p, xa->p);
+    c[k] = v3dot(bk, t);
+  }
+  real lo[3] = {(real)1e30, (real)1e30, (real)1e30}, hi[3] = {(real)-1e30, (real)-1e30, (real)-1e30}; int ilo[3] = {0, 0, 0}, ihi[3] = {0, 0, 0};
+  for (int i = 0; i < nvert; i++) {
+    const real v[3] = {(real)hv[i][0], (real)hv[i][1], (real)hv[i][2]};
+    for (int k = 0; k < 3; k++) {
+      const real l = (u[k][0] * v[0] + u[k][1] * v[1] + u[k][2] * v[2]) - c[k];
+      if (l < lo[k]) { lo[k] = l; ilo[k] = i; }
+      if (l > hi[k]) { hi[k] = l; ihi[k] = i; }
+    }
+  }
+  real best = -1e30; int bf = 0;
+  for (int f = 0; f < 6; f++) {
+    int k = f >> 1; real h = (real)m->col_he[b][k];
+    real sgap = (f & 1) ? (-hi[k] - h) : (lo[k] - h);      /* face +k: lowest vertex above it; face -k: highest vertex below it */
+    if (sgap > best + (f == 0 ? 0 : TIE_EPS)) { best = sgap; bf = f; }
+  }
+  real d = best - HULL_MARGIN;
+  if (d > margin) return 0;
+  int k = bf >> 1, iv = (bf & 1) ? ihi[k] : ilo[k];
+  const real v[3] = {(real)hv[iv][0], (real)hv[iv][1], (real)hv[iv][2]};
+  real w[3];
+  m3mulv(w, xa->R, v); v3add(w, w, xa->p);
+  for (int j = 0; j < 3; j++) {
+    const real l = (u[j][0] * v[0] + u[j][1] * v[1] + u[j][2] * v[2]) - c[j];
+    if (j != k && R_FABS(l) > (real)m->col_he[b][j]) return -1;      /* beside the face: edges and corners stay with the OBB path */
+  }
+  real nl[3] = {0, 0, 0}; nl[k] = (bf & 1) ? -1 : 1;
+  real n[3]; m3mulv(n, xb->R, nl);
+  /* point on the box face under the vertex, then mode A's single application point: halfway along the gap */
+  real pB[3]; v3cpy(pB, w); v3axpy(pB, -best, n);
+  v3cpy(out->p, pB); v3axpy(out->p, (real)0.5 * d, n);
+  v3cpy(out->n, n); out->dist = d;
+  return 1;
+}
+
 static void collide(rpo_env* e) {
   const rp_model* m = &e->m;
   e->ncon = 0;
@@ -417,7 +476,11 @@ static void collide(rpo_env* e) {
     cpoint pts[4]; int np = 0;
     real ha[3], hb[3];
     for (int k = 0; k < 3; k++) { ha[k] = (real)m->col_he[a][k]; hb[k] = (real)m->col_he[b][k]; }
-    if (m->col_type[a] == 0 && m->col_type[b] == 0)
+    int hf = -1;
+    if ((e->rule & RPO_RULE_HULLFACE) && m->col_type[b] == 0 && m->col_body[b] == 0 && body_is_arm(e, m->col_body[a]))
+      hf = hull_face(e, a, b, margin, pts);
+    if (hf >= 0) np = hf;
+    else if (m->col_type[a] == 0 && m->col_type[b] == 0)
       np = box_box(e->xc[a].p, e->xc[a].R, ha, e->xc[b].p, e->xc[b].R, hb, margin, pts);
     else if (m->col_type[a] == 0 && m->col_type[b] == 1)
       np = sphere_box(e->xc[b].p, hb[0], e->xc[a].p, e->xc[a].R, ha, margin, 1, pts);
@@ -1657,7 +1720,7 @@ rpo_env* rpo_create(int kind, unsigned long long seed, int env_index) {
   e->nv = m->n_arm + 6 * m->n_free + m->n_joint1;
   e->nbody = 1 + m->n_arm + m->n_free + m->n_joint1;
   e->seed = seed; e->env_index = (uint32_t)env_index;
-  e->rule = RPO_RULE_ORDER | RPO_RULE_LIMIT;       /* the shipped model (the HIP kernels implement exactly this); rpo_set_rule(0) = round 2's rule */
+  e->rule = RPO_RULE_ORDER | RPO_RULE_LIMIT | RPO_RULE_HULLFACE;       /* the shipped model (the HIP kernels implement exactly this); rpo_set_rule(0) = round 2's rule */
   e->margin = -1; e->rew_thresh = (real)0.05; e->dense_reward = 0;
   /* envList.py:8-10, 18-22, 73-99: the env's flags and ranges go with its scene (play ids: complex_scene; reach ids:
    * default_scene; pick / push: push_scene); other ids on the same model override the ranges (rpo_set_ranges) */

@@ -96,6 +96,10 @@ typedef struct DevModel {
   float floor_z;                  /* bottom of the lowest static collider: an object below it has left the scene (status bit 2) */
   /* joint clamps of goto_joint_poses (environments.py:1015-1021) */
   float ll[7], ul[7], inc[7];
+  /* convex-hull vertices of the arm links' collision meshes (generated/rp_hullverts_gen.h): device pointer to the arm's table (x, y, z, 0 in the owning
+   * body's frame), per collider the first vertex and the count (0 = no hull).  rp_create uploads the table and sets the pointer. */
+  const float* hullv;
+  int hull_off[RP_MAX_COL], hull_cnt[RP_MAX_COL];
 } DevModel;
 
 static inline int rp_dm_dof_of_joint(const rp_model* m, int j) {

@@ -469,6 +469,10 @@ __device__ __forceinline__ int sphere_box(V3 cs, float r, V3 cb, const M3& Rb, V
 __device__ __forceinline__ V3 pick3(int i, V3 a, V3 b, V3 c) { return i == 0 ? a : (i == 1 ? b : c); }
 __device__ __forceinline__ float pick1(int i, float a, float b, float c) { return i == 0 ? a : (i == 1 ? b : c); }
 
+/* coordinate of hull vertex v along a box axis (u = the axis in the hull's body frame, c = the box centre along it): ONE instruction sequence wherever it is
+ * needed, so that the second scan finds the extreme of the first by equality */
+__device__ __forceinline__ float hull_coord(V3 u, float4 v, float c) { return __fmaf_rn(u.z, v.z, __fmaf_rn(u.y, v.y, u.x * v.x)) - c; }
+
 template <class LDS>
 __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int lane, int nact) {
   const int g = lane >> 3, s = lane & 7;
@@ -486,7 +490,7 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
     const int a = m->pair[pi][0], b = m->pair[pi][1];
     const int ta = m->col_type[a], tb = m->col_type[b];
     const float margin = fminf(m->col_margin[a], m->col_margin[b]);      /* Bullet: a manifold's breaking threshold is the smaller of its two objects' */
-    const bool bb = act && ta == 0 && tb == 0;
+    const bool bbox = act && ta == 0 && tb == 0;
     if (act && s == 0) {
       /* what the pair's contacts will need later, looked up here (the table loads hide behind the axis tests): friction, and the manifold key =
        * object pair, bit 16 "rotation-locked free body against the static world" (the drawer: that manifold keeps only its deepest point),
@@ -502,10 +506,108 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
       L.key[ai] = m->col_obj[a] * 256 + m->col_obj[b] + (single ? 65536 : 0) + ((r0 ? (r1 ? 2 : 1) : 0) << 20) + ((arm && movable) ? (1 << 22) : 0);
       L.pmu[ai] = m->col_friction[a] * m->col_friction[b];
     }
-    const Xf xa = collider_xf(m, L, a), xb = collider_xf(m, L, b);
-    const V3 ha = ld3(m->col_he[a]), hb = ld3(m->col_he[b]);
     int np = 0;
     CPt mine; mine.p = mk3(0, 0, 0); mine.n = mk3(0, 0, 0); mine.dist = 0.f;      /* the point this lane contributes (lane s < np of its group) */
+    /* ---- arm link against a static box: the VERTICES of the convex hull of the link's collision mesh (Bullet: btConvexHullShape, margin 0.001) against the
+     * box's six faces - the same decisions and arithmetic as the oracle's hull_face.  The vertex deepest along the face of least penetration is the contact
+     * if it lies over that face (what GJK / EPA return for a vertex-on-face contact: a link on the ground plate, on the table top); beside the face the
+     * pair stays with the OBB path below.  The eight lanes of the group scan the vertices in strides of eight and reduce (min / max per box axis, lowest
+     * vertex index among equals: the oracle's sequential scan). */
+    int hf = -1;                                             /* 1: hull contact (lane 0 of the group holds it), 0: hull says apart, -1: OBB path */
+    {
+      const int hn = act ? m->hull_cnt[a] : 0;
+      bool hq = hn > 0 && tb == 0 && m->col_body[b] == 0;
+      if (hq) {
+        const Xf xa = collider_xf(m, L, a), xb = collider_xf(m, L, b);
+        const V3 ha = ld3(m->col_he[a]), hb = ld3(m->col_he[b]);
+        /* the link's OBB (it contains the hull) against the same six faces first: if even the OBB stays clear of the box by more than the pair's margin
+         * along one of the box's axes, so does every vertex and the scan would end with "apart" - the common case, a long link whose AABB merely overlaps
+         * the table's (same outcome as the oracle's full scan; the 1e-5 keeps rounding at the threshold on the scanning side) */
+        const V3 tt = xa.p - xb.p;
+        const V3 A0 = col(xa.R, 0), A1 = col(xa.R, 1), A2 = col(xa.R, 2), B0 = col(xb.R, 0), B1 = col(xb.R, 1), B2 = col(xb.R, 2);
+        const float r0 = ha.x * fabsf(dot(B0, A0)) + ha.y * fabsf(dot(B0, A1)) + ha.z * fabsf(dot(B0, A2));
+        const float r1 = ha.x * fabsf(dot(B1, A0)) + ha.y * fabsf(dot(B1, A1)) + ha.z * fabsf(dot(B1, A2));
+        const float r2 = ha.x * fabsf(dot(B2, A0)) + ha.y * fabsf(dot(B2, A1)) + ha.z * fabsf(dot(B2, A2));
+        const float og = fmaxf(fmaxf(fabsf(dot(B0, tt)) - r0 - hb.x, fabsf(dot(B1, tt)) - r1 - hb.y), fabsf(dot(B2, tt)) - r2 - hb.z);
+        if (og > margin + RP_HULL_MARGIN + 1e-5f) { hq = false; hf = 0; }
+      }
+      /* The pairs that are left - rare - are done by the WHOLE WAVE, one at a time (a link of a thousand vertices in sixteen rounds instead of 125: its block
+       * would otherwise end long after the rest of the launch): the pair's two collider indices go to all lanes, everything below is the same in every
+       * lane except the vertices it scans (lane, lane + 64, ...), and the pair's own group keeps the outcome. */
+      asm volatile("" ::: "memory");                         /* (the transforms above are loaded again where they are needed: nothing of them stays in registers across the scan) */
+      for (unsigned long long todo = __ballot(hq && s == 0); todo != 0ull; todo &= todo - 1ull) {
+        const int src = __ffsll((long long)todo) - 1;        /* first lane of the group whose pair is scanned now (wave-uniform) */
+        const int ca = __builtin_amdgcn_readlane(a, src), cb = __builtin_amdgcn_readlane(b, src);
+        const float mg = lane_read(margin, src);
+        const int body = m->col_body[ca];
+        const M3 Rw = ldm3(&L.xR[9 * body]);
+        const V3 pw = ld3(&L.xp[3 * body]);
+        const Xf xc = collider_xf(m, L, cb);
+        const V3 hc = ld3(m->col_he[cb]);
+        const V3 tc = xc.p - pw;
+        const V3 b0 = col(xc.R, 0), b1 = col(xc.R, 1), b2 = col(xc.R, 2);
+        const V3 u0 = tmulv(Rw, b0), u1 = tmulv(Rw, b1), u2 = tmulv(Rw, b2);      /* box axes in the body frame: a vertex v has box coordinate u_k . v - c_k */
+        const float c0 = dot(b0, tc), c1 = dot(b1, tc), c2 = dot(b2, tc);
+        const int nn = m->hull_cnt[ca];
+        const float4* tv = (const float4*)m->hullv + m->hull_off[ca];
+        float lo0 = 1e30f, lo1 = 1e30f, lo2 = 1e30f, hi0 = -1e30f, hi1 = -1e30f, hi2 = -1e30f;
+        for (int i = lane; i < nn; i += 64) {
+          const float4 v = tv[i];
+          const float l0 = hull_coord(u0, v, c0), l1 = hull_coord(u1, v, c1), l2 = hull_coord(u2, v, c2);
+          lo0 = fminf(lo0, l0); hi0 = fmaxf(hi0, l0); lo1 = fminf(lo1, l1); hi1 = fmaxf(hi1, l1); lo2 = fminf(lo2, l2); hi2 = fmaxf(hi2, l2);
+        }
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          lo0 = fminf(lo0, __shfl_xor(lo0, off)); lo1 = fminf(lo1, __shfl_xor(lo1, off)); lo2 = fminf(lo2, __shfl_xor(lo2, off));
+          hi0 = fmaxf(hi0, __shfl_xor(hi0, off)); hi1 = fmaxf(hi1, __shfl_xor(hi1, off)); hi2 = fmaxf(hi2, __shfl_xor(hi2, off));
+        }
+        const float g0 = lo0 - hc.x, g1 = -hi0 - hc.x, g2 = lo1 - hc.y, g3 = -hi1 - hc.y, g4 = lo2 - hc.z, g5 = -hi2 - hc.z;      /* face +k: lowest vertex above it; face -k: highest vertex below it */
+        float best = g0; int bf = 0;
+        if (g1 > best + K_TIE_EPS) { best = g1; bf = 1; }
+        if (g2 > best + K_TIE_EPS) { best = g2; bf = 2; }
+        if (g3 > best + K_TIE_EPS) { best = g3; bf = 3; }
+        if (g4 > best + K_TIE_EPS) { best = g4; bf = 4; }
+        if (g5 > best + K_TIE_EPS) { best = g5; bf = 5; }
+        const float d = best - RP_HULL_MARGIN;
+        int out = 0;                                         /* this pair's hf */
+        CPt pt; pt.p = mk3(0, 0, 0); pt.n = mk3(0, 0, 0); pt.dist = 0.f;
+        if (!(d > mg)) {                                     /* (wave-uniform) */
+          /* the first vertex (lowest index: the oracle's sequential scan keeps the first strict extreme) whose coordinate along that axis IS the extreme -
+           * the same instruction sequence gives the same bits */
+          const int k = bf >> 1;
+          const V3 uk = pick3(k, u0, u1, u2);
+          const float ck = pick1(k, c0, c1, c2);
+          const float ext = (bf & 1) ? pick1(k, hi0, hi1, hi2) : pick1(k, lo0, lo1, lo2);
+          int iv = 0x7fffffff;
+          for (int i = lane; i < nn; i += 64)
+            if (hull_coord(uk, tv[i], ck) == ext) { iv = i; break; }
+#pragma unroll
+          for (int off = 1; off < 64; off <<= 1) iv = min(iv, __shfl_xor(iv, off));
+          out = -1;
+          if (iv != 0x7fffffff) {
+            const float4 v = tv[iv];
+            const float l0 = hull_coord(u0, v, c0), l1 = hull_coord(u1, v, c1), l2 = hull_coord(u2, v, c2);
+            const bool beside = (k != 0 && fabsf(l0) > hc.x) || (k != 1 && fabsf(l1) > hc.y) || (k != 2 && fabsf(l2) > hc.z);
+            if (!beside) {
+              out = 1;
+              const V3 w = mulv(Rw, mk3(v.x, v.y, v.z)) + pw;
+              const V3 nb = pick3(k, b0, b1, b2);
+              const V3 nrm = (bf & 1) ? -nb : nb;
+              const V3 pB = w - nrm * best;                  /* on the box face under the vertex; the model's single application point lies halfway along the gap */
+              pt.p = pB + nrm * (0.5f * d); pt.n = nrm; pt.dist = d;
+            }
+          }
+        }
+        if ((lane >> 3) == (src >> 3)) {
+          hf = out;
+          if (out == 1 && s == 0) { mine = pt; np = 1; }
+        }
+      }
+    }
+    asm volatile("" ::: "memory");
+    const Xf xa = collider_xf(m, L, a), xb = collider_xf(m, L, b);
+    const V3 ha = ld3(m->col_he[a]), hb = ld3(m->col_he[b]);
+    const bool bb = bbox && hf < 0;                          /* box against box through the SAT + clipping path */
     if (act && !bb && s == 0) {                              /* sphere against box: one lane, closed form */
       if (ta == 0 && tb == 1) np = sphere_box(xb.p, hb.x, xa.p, xa.R, ha, margin, 1, &mine);
       else if (ta == 1 && tb == 0) np = sphere_box(xa.p, ha.x, xb.p, xb.R, hb, margin, 0, &mine);

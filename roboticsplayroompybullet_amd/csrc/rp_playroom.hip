@@ -7,6 +7,7 @@
 #include "../../include/rp_playroom.h"
 #include "../../include/rp_playroom_debug.h"
 #include "generated/rp_models_gen.h"
+#include "generated/rp_hullverts_gen.h"
 #include "rp_device_model.h"
 #include "rp_kernels.cuh"
 #include "rp_render.cuh"
@@ -19,6 +20,7 @@ struct rp_sim {
   float* state;            /* [N][RP_REC_FLOATS] */
   float* ws;               /* [N][W3_FLOATS] constraint-row workspace of the split step pipeline */
   float* dbg;
+  float* hullv;            /* convex-hull vertices of the arm's collision meshes (DevModel.hullv points here) */
   int* sort_cnt;           /* [2][RP_MAX_GROUPS][SORT_BINS] load-class histograms for pairing envs in k_solve2 (double-buffered) */
   int* sort_slot;          /* [N] per env: (bin << 16) | rank inside the bin, from the latest k_solve2 */
   int* pair_env;           /* [N] per group range: env ids sorted by load class, heaviest first (k_solve2 pairs neighbours) */
@@ -92,7 +94,7 @@ const char* rp_version(void) { return "rp_playroom 0.2 (gfx950) build " RP_BUILD
 
 static void destroy_handle(rp_sim* h) {        /* frees whatever a (possibly partial) handle owns; hipFree(nullptr) etc. are no-ops */
   if (!h) return;
-  hipFree(h->dev_model); hipFree(h->state); hipFree(h->ws); hipFree(h->dbg); hipFree(h->sort_cnt); hipFree(h->sort_slot); hipFree(h->pair_env); hipFree(h->member[0]); hipFree(h->member[1]);
+  hipFree(h->hullv); hipFree(h->dev_model); hipFree(h->state); hipFree(h->ws); hipFree(h->dbg); hipFree(h->sort_cnt); hipFree(h->sort_slot); hipFree(h->pair_env); hipFree(h->member[0]); hipFree(h->member[1]);
   hipFree(h->rc_tab); hipFree(h->rc_cnt); hipFree(h->rc_ee);
   hipFree(h->rs_state); hipFree(h->rs_idx); hipFree(h->rs_meta); hipFree(h->rs_count); hipFree(h->rs_sort_cnt); hipFree(h->rs_sort_slot); hipFree(h->rs_pair);
   if (h->rs_count_host) hipHostFree(h->rs_count_host);
@@ -185,6 +187,17 @@ int rp_create(const rp_config* cfg, rp_handle* out) {
   CREATE_CHK(hipMalloc((void**)&h->pair_env, (size_t)N * sizeof(int)));
   CREATE_CHK(hipMalloc((void**)&h->member[0], (size_t)N * sizeof(int)));
   CREATE_CHK(hipMalloc((void**)&h->member[1], (size_t)N * sizeof(int)));
+  {
+    const float (*hv)[4]; const int *hoff, *hcnt;
+    const int nhv = rp_hull_tables(d->kind, &hv, &hoff, &hcnt);
+    if (nhv > 0) {
+      CREATE_CHK(hipMalloc((void**)&h->hullv, (size_t)nhv * 4 * sizeof(float)));
+      CREATE_CHK(hipMemcpy(h->hullv, hv, (size_t)nhv * 4 * sizeof(float), hipMemcpyHostToDevice));
+      const bool off = getenv("RP_NO_HULL") != nullptr;      /* timing / model studies only: arm links as their OBBs everywhere (round 2's contacts) */
+      for (int c = 0; c < RP_MAX_COL; c++) { d->hull_off[c] = hoff[c]; d->hull_cnt[c] = off ? 0 : hcnt[c]; }
+    }
+    d->hullv = h->hullv;
+  }
   CREATE_CHK(hipMemcpy(h->dev_model, &h->host_model, sizeof(DevModel), hipMemcpyHostToDevice));
   CREATE_CHK(hipEventCreate(&h->ev0));
   CREATE_CHK(hipEventCreate(&h->ev1));

@@ -658,6 +658,48 @@ def emit_hulls(models, path):
     open(path, 'w').write(''.join(out))
 
 
+def cfloat(x):
+    t = '%.9g' % x
+    return t + ('f' if ('.' in t or 'e' in t or 'n' in t) else '.f')
+
+
+def emit_hull_verts(models, path):
+    """convex-hull vertices of the arm colliders for the PRODUCT (HIP library) and the fast model's oracle: float, owning body's frame, one table per arm
+    (the kinds of one arm share it), per kind the first vertex and the count of every collider (count 0 = no hull: boxes, cylinders, the scene).  Used
+    for the vertex-against-face contacts of arm links with static boxes (rp_kernels.cuh hull_face, rp_oracle.c hull_face)."""
+    out = ['/* GENERATED by tools/bake_assets.py from the reference URDFs and collision meshes.  Do not edit.\n'
+           ' * Convex-hull vertices of the arm links\' collision meshes (body frame; Bullet keeps a 0.001 margin around them), shared by the HIP library and\n'
+           ' * oracle/rp_oracle.c. */\n#ifndef RP_HULLVERTS_GEN_H\n#define RP_HULLVERTS_GEN_H\n\n#define RP_HULL_MARGIN 0.001f\n\n']
+    tables = {}          # arm name -> (table name, flat list of vertices)
+    per_kind = []
+    for M in models:
+        arm = M['arm_type']
+        name = 'rp_hullv_%s' % arm.upper()
+        verts, off, cnt = [], [0] * 64, [0] * 64
+        for ci, c in enumerate(M['col']):
+            if 'hull' in c:
+                H = np.asarray(c['hull'], np.float32)
+                off[ci], cnt[ci] = len(verts), len(H)
+                verts += [tuple(float(x) for x in v) for v in H]
+        if arm in tables:
+            assert tables[arm][1] == verts, 'the kinds of one arm share their hulls'
+        else:
+            tables[arm] = (name, verts)
+        per_kind.append((M['kind'], name, len(verts), off, cnt))
+    for arm, (name, verts) in tables.items():
+        out.append('static const float %s[%d][4] = {\n%s};\n\n' % (name, len(verts), ',\n'.join(
+            ','.join('{%s,%s,%s,0.f}' % tuple(cfloat(x) for x in v) for v in verts[i:i + 4]) for i in range(0, len(verts), 4))))
+    for kind, name, n, off, cnt in per_kind:
+        out.append('static const int rp_hull_off_%s[64] = {%s};\nstatic const int rp_hull_cnt_%s[64] = {%s};\n' % (
+            kind, ','.join(str(v) for v in off), kind, ','.join(str(v) for v in cnt)))
+    out.append('\n/* kind (RP_KIND_*) -> vertex table, number of vertices in it, per-collider first vertex and count */\n'
+               'static inline int rp_hull_tables(int kind, const float (**v)[4], const int** off, const int** cnt) {\n  switch (kind) {\n')
+    for kind, name, n, off, cnt in per_kind:
+        out.append('    case %d: *v = %s; *off = rp_hull_off_%s; *cnt = rp_hull_cnt_%s; return %d;\n' % ('URPQVW'.index(kind), name, kind, kind, n))
+    out.append('  }\n  *v = 0; *off = 0; *cnt = 0; return 0;\n}\n\n#endif\n')
+    open(path, 'w').write(''.join(out))
+
+
 def main():
     gold = json.load(open(os.path.join(REPO, 'tests', 'golden', 'scenes.json')))
     ur5 = build_arm(os.path.join(ENVS, 'ur_e_description', 'ur5e2.urdf'))
@@ -677,6 +719,7 @@ def main():
     os.makedirs(os.path.join(REPO, 'roboticsplayroompybullet_amd', 'csrc', 'generated'), exist_ok=True)
     emit_header(models, os.path.join(REPO, 'roboticsplayroompybullet_amd', 'csrc', 'generated', 'rp_models_gen.h'))
     emit_hulls(models, os.path.join(REPO, 'oracle', 'generated', 'rp_hulls_gen.h'))
+    emit_hull_verts(models, os.path.join(REPO, 'roboticsplayroompybullet_amd', 'csrc', 'generated', 'rp_hullverts_gen.h'))
     slim = []
     for M in models:
         m = {k: v for k, v in M.items()}
