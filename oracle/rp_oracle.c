@@ -40,6 +40,10 @@
 #define ERP_LIMIT ((real)0.2)           /* btContactSolverInfo::m_erp: joint-limit rows under RPO_RULE_LIMIT */
 #define RPO_RULE_ORDER 1
 #define RPO_RULE_LIMIT 2
+#define RPO_RULE_BOXOVERLAP 16      /* an arm link's box against a box: points only while the boxes overlap.  btBoxBoxDetector makes none before that and Bullet's manifold then
+                                    * KEEPS them out to the breaking threshold; a stateless model has to pick one rule per pair: the arm's contacts are impacts (making them early
+                                    * is measurably further from the reference step: UR5Reach arm divergence 2.6e-4 -> 5.6e-5 median), the objects' are resting contacts that
+                                    * live for seconds (they keep the threshold as their margin, which is what the kept points look like) */
 #define RPO_RULE_HULLFACE 4         /* arm links touch static boxes with the vertices of their collision meshes' convex hulls (hull_face) instead of their OBBs */
 #define HULL_MARGIN ((real)RP_HULL_MARGIN)
 #define FREE_LIN_DAMP ((real)0.04)
@@ -428,7 +432,9 @@ static int hull_face(const rpo_env* e, int a, int b, real margin, cpoint* out) {
   }
   real best = -1e30; int bf = 0;
   for (int f = 0; f < 6; f++) {
-    int k = f >> 1; real h = (real)m->col_he[b][k];
+    /* the box as the reference step's GJK sees it: core (half extents less the 0.001 margin, never below 0) plus that margin - a box thinner than
+     * the margin (the 0.1 mm ground plate) comes out 0.001 thick (rp_bullet_ref.c rpb_convex_of) */
+    int k = f >> 1; real h = (real)m->col_he[b][k] > HULL_MARGIN ? (real)m->col_he[b][k] : HULL_MARGIN;
     real sgap = (f & 1) ? (-hi[k] - h) : (lo[k] - h);      /* face +k: lowest vertex above it; face -k: highest vertex below it */
     if (sgap > best + (f == 0 ? 0 : TIE_EPS)) { best = sgap; bf = f; }
   }
@@ -481,7 +487,7 @@ static void collide(rpo_env* e) {
       hf = hull_face(e, a, b, margin, pts);
     if (hf >= 0) np = hf;
     else if (m->col_type[a] == 0 && m->col_type[b] == 0)
-      np = box_box(e->xc[a].p, e->xc[a].R, ha, e->xc[b].p, e->xc[b].R, hb, margin, pts);
+      np = box_box(e->xc[a].p, e->xc[a].R, ha, e->xc[b].p, e->xc[b].R, hb, (e->margin < 0 && (e->rule & RPO_RULE_BOXOVERLAP) && (body_is_arm(e, m->col_body[a]) || body_is_arm(e, m->col_body[b]))) ? (real)0 : margin, pts);
     else if (m->col_type[a] == 0 && m->col_type[b] == 1)
       np = sphere_box(e->xc[b].p, hb[0], e->xc[a].p, e->xc[a].R, ha, margin, 1, pts);
     else if (m->col_type[a] == 1 && m->col_type[b] == 0)
@@ -1720,7 +1726,7 @@ rpo_env* rpo_create(int kind, unsigned long long seed, int env_index) {
   e->nv = m->n_arm + 6 * m->n_free + m->n_joint1;
   e->nbody = 1 + m->n_arm + m->n_free + m->n_joint1;
   e->seed = seed; e->env_index = (uint32_t)env_index;
-  e->rule = RPO_RULE_ORDER | RPO_RULE_LIMIT | RPO_RULE_HULLFACE;       /* the shipped model (the HIP kernels implement exactly this); rpo_set_rule(0) = round 2's rule */
+  e->rule = RPO_RULE_ORDER | RPO_RULE_LIMIT | RPO_RULE_HULLFACE | RPO_RULE_BOXOVERLAP;       /* the shipped model (the HIP kernels implement exactly this); rpo_set_rule(0) = round 2's rule */
   e->margin = -1; e->rew_thresh = (real)0.05; e->dense_reward = 0;
   /* envList.py:8-10, 18-22, 73-99: the env's flags and ranges go with its scene (play ids: complex_scene; reach ids:
    * default_scene; pick / push: push_scene); other ids on the same model override the ranges (rpo_set_ranges) */

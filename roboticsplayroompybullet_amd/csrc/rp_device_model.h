@@ -93,6 +93,8 @@ typedef struct DevModel {
   float col_margin[RP_MAX_COL];   /* distance out to which a collider's contact points exist; a pair's margin is the smaller of the two.
                                    * Default: Bullet's relative contact breaking threshold of the collider's object (rp_model.col_thr);
                                    * rp_config.contact_margin replaces it by one value for all */
+  float boxbox_margin;            /* >= 0: the margin of box-against-box pairs (default 0: points only while the boxes overlap, as btBoxBoxDetector makes them); < 0: the pair's
+                                   * margin like every other pair (rp_config.contact_margin given: one value for all) */
   float floor_z;                  /* bottom of the lowest static collider: an object below it has left the scene (status bit 2) */
   /* joint clamps of goto_joint_poses (environments.py:1015-1021) */
   float ll[7], ul[7], inc[7];
@@ -203,7 +205,7 @@ static inline void rp_build_dev_model(const rp_model* m, DevModel* d) {
     d->n_obs = 13; d->n_ag = 3; d->n_fps = 7; d->n_observation = 12; d->n_target = 7;
   }
   d->n_target = isP ? 7 : 6;            /* numDofs (environments.py:361, 371) */
-  d->rew_thresh = 0.05f; d->dense_reward = 0;
+  d->rew_thresh = 0.05f; d->dense_reward = 0; d->boxbox_margin = 0.f;
   for (int c = 0; c < m->n_col; c++) { d->col_margin[c] = (float)m->col_thr[c]; d->col_stiff[c] = (float)m->col_stiffness[c]; d->col_damp[c] = (float)m->col_damping[c];
     d->col_toggle[c] = m->col_toggle[c]; for (int k = 0; k < 3; k++) d->col_rgb[c][k] = (float)m->col_rgb[c][k]; }
   d->floor_z = 1e30f;

@@ -489,7 +489,7 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
     const int pi = act ? L.act[ai] : 0;
     const int a = m->pair[pi][0], b = m->pair[pi][1];
     const int ta = m->col_type[a], tb = m->col_type[b];
-    const float margin = fminf(m->col_margin[a], m->col_margin[b]);      /* Bullet: a manifold's breaking threshold is the smaller of its two objects' */
+    const float margin0 = fminf(m->col_margin[a], m->col_margin[b]);     /* Bullet: a manifold's breaking threshold is the smaller of its two objects' */
     const bool bbox = act && ta == 0 && tb == 0;
     if (act && s == 0) {
       /* what the pair's contacts will need later, looked up here (the table loads hide behind the axis tests): friction, and the manifold key =
@@ -529,7 +529,7 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
         const float r1 = ha.x * fabsf(dot(B1, A0)) + ha.y * fabsf(dot(B1, A1)) + ha.z * fabsf(dot(B1, A2));
         const float r2 = ha.x * fabsf(dot(B2, A0)) + ha.y * fabsf(dot(B2, A1)) + ha.z * fabsf(dot(B2, A2));
         const float og = fmaxf(fmaxf(fabsf(dot(B0, tt)) - r0 - hb.x, fabsf(dot(B1, tt)) - r1 - hb.y), fabsf(dot(B2, tt)) - r2 - hb.z);
-        if (og > margin + RP_HULL_MARGIN + 1e-5f) { hq = false; hf = 0; }
+        if (og > margin0 + RP_HULL_MARGIN + 1e-5f) { hq = false; hf = 0; }
       }
       /* The pairs that are left - rare - are done by the WHOLE WAVE, one at a time (a link of a thousand vertices in sixteen rounds instead of 125: its block
        * would otherwise end long after the rest of the launch): the pair's two collider indices go to all lanes, everything below is the same in every
@@ -538,12 +538,13 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
       for (unsigned long long todo = __ballot(hq && s == 0); todo != 0ull; todo &= todo - 1ull) {
         const int src = __ffsll((long long)todo) - 1;        /* first lane of the group whose pair is scanned now (wave-uniform) */
         const int ca = __builtin_amdgcn_readlane(a, src), cb = __builtin_amdgcn_readlane(b, src);
-        const float mg = lane_read(margin, src);
+        const float mg = lane_read(margin0, src);
         const int body = m->col_body[ca];
         const M3 Rw = ldm3(&L.xR[9 * body]);
         const V3 pw = ld3(&L.xp[3 * body]);
         const Xf xc = collider_xf(m, L, cb);
-        const V3 hc = ld3(m->col_he[cb]);
+        const V3 hc0 = ld3(m->col_he[cb]);
+        const V3 hc = mk3(fmaxf(hc0.x, RP_HULL_MARGIN), fmaxf(hc0.y, RP_HULL_MARGIN), fmaxf(hc0.z, RP_HULL_MARGIN));      /* the box as the reference step's GJK sees it: core + margin, a box thinner than the margin comes out 0.001 thick (oracle hull_face) */
         const V3 tc = xc.p - pw;
         const V3 b0 = col(xc.R, 0), b1 = col(xc.R, 1), b2 = col(xc.R, 2);
         const V3 u0 = tmulv(Rw, b0), u1 = tmulv(Rw, b1), u2 = tmulv(Rw, b2);      /* box axes in the body frame: a vertex v has box coordinate u_k . v - c_k */
@@ -587,7 +588,7 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
           if (iv != 0x7fffffff) {
             const float4 v = tv[iv];
             const float l0 = hull_coord(u0, v, c0), l1 = hull_coord(u1, v, c1), l2 = hull_coord(u2, v, c2);
-            const bool beside = (k != 0 && fabsf(l0) > hc.x) || (k != 1 && fabsf(l1) > hc.y) || (k != 2 && fabsf(l2) > hc.z);
+            const bool beside = (k != 0 && fabsf(l0) > hc0.x) || (k != 1 && fabsf(l1) > hc0.y) || (k != 2 && fabsf(l2) > hc0.z);
             if (!beside) {
               out = 1;
               const V3 w = mulv(Rw, mk3(v.x, v.y, v.z)) + pw;
@@ -608,6 +609,11 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
     const Xf xa = collider_xf(m, L, a), xb = collider_xf(m, L, b);
     const V3 ha = ld3(m->col_he[a]), hb = ld3(m->col_he[b]);
     const bool bb = bbox && hf < 0;                          /* box against box through the SAT + clipping path */
+    /* ... whose points, when one of the boxes is an arm link, exist only while the boxes overlap (DevModel.boxbox_margin = 0: btBoxBoxDetector makes none before
+     * that; the oracle's RPO_RULE_BOXOVERLAP explains why the arm's pairs and not the resting objects') */
+    const int body_a = m->col_body[a], body_b = m->col_body[b];
+    const bool arm_pair = (body_a >= 1 && body_a <= m->n_arm) || (body_b >= 1 && body_b <= m->n_arm);
+    const float margin = (bb && arm_pair && m->boxbox_margin >= 0.f) ? m->boxbox_margin : margin0;
     if (act && !bb && s == 0) {                              /* sphere against box: one lane, closed form */
       if (ta == 0 && tb == 1) np = sphere_box(xb.p, hb.x, xa.p, xa.R, ha, margin, 1, &mine);
       else if (ta == 1 && tb == 0) np = sphere_box(xa.p, ha.x, xb.p, xb.R, hb, margin, 0, &mine);

@@ -167,7 +167,7 @@ int rp_create(const rp_config* cfg, rp_handle* out) {
   }
   if (cfg->flags & RP_CFG_REW_THRESH) d->rew_thresh = cfg->sparse_rew_thresh;
   if (cfg->flags & RP_CFG_DENSE_REWARD) d->dense_reward = 1;
-  if (cfg->flags & RP_CFG_CONTACT_MARGIN) for (int c = 0; c < RP_MAX_COL; c++) d->col_margin[c] = cfg->contact_margin;
+  if (cfg->flags & RP_CFG_CONTACT_MARGIN) { for (int c = 0; c < RP_MAX_COL; c++) d->col_margin[c] = cfg->contact_margin; d->boxbox_margin = -1.f; }
   d->action_type = action_type;
   d->n_action = (action_type == RP_ACT_ABS_QUAT || action_type == RP_ACT_REL_QUAT) ? 8
               : ((action_type == RP_ACT_ABS_JOINTS || action_type == RP_ACT_REL_JOINTS) ? d->n_target + 1 : 7);

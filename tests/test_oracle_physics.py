@@ -1,5 +1,7 @@
 """Known-answer and property tests of the CPU oracle's physics pieces (no GPU).  These do not pin parity with PyBullet
 (unpinned); they pin the oracle against analytic answers so that it is a trustworthy checker."""
+import os
+
 import numpy as np
 import pytest
 
@@ -90,3 +92,60 @@ def test_counter_rng_regression_and_range():
     assert all(float(np.float32(v)) == v for v in vals)        # 24-bit mantissa: exactly representable in fp32
     u = np.array([rng_uniform(7, e, 0) for e in range(4000)])
     assert abs(u.mean() - 0.5) < 0.02 and abs(u.std() - 0.2887) < 0.01
+
+
+def test_hull_vertex_contacts_against_the_reference_steps_gjk_epa():
+    """the fast model's arm-link-against-static-box contacts (hull_face: the deepest vertex of the link's convex hull over the box face of least
+    penetration) against the frozen reference step's GJK / EPA on the SAME hull and box (rpo_ref_collider_distance), UR5 links lowered onto
+    UR5Reach's ground plate at random orientations: the same distance, normal and point on the plate whenever one vertex is the lowest (the
+    generic case); both signs of the distance are covered (EPA inside, GJK outside)"""
+    import ctypes as C
+    import oracle
+    from oracle import OracleEnv
+    DP = C.POINTER(C.c_double)
+    lib = oracle.load(bullet_ref=True)
+    lib.rpo_ref_collider_distance.argtypes = [C.c_void_p, C.c_int, C.c_int, DP, DP, DP, DP]
+    a = OracleEnv('R', seed=0)
+    b = OracleEnv('R', seed=0, bullet_ref=True)
+    cols = a.collider_list()
+    plate = [i for i, c in enumerate(cols) if c['body'] == 0 and c['link'] < 0 and c['he'][0] > 1.0][0]
+    rng = np.random.default_rng(4)
+    seen = {'apart': 0, 'inside': 0}
+    tab = a.arm_table()
+    rest = np.array([-1.50189075, -1.6291067, -1.87020409, -1.21324173, 1.57003561, 0.06970189])
+    for trial in range(150):
+        # the grasp target a few centimetres above the plate (z = -0.07), tilted: the IK of the harness brings the gripper's links down to it
+        pos = np.array([rng.uniform(-0.15, 0.15), rng.uniform(-0.15, 0.15), rng.uniform(-0.062, -0.02)])
+        rpy = np.array([0.0, np.pi / 2, 0.0]) + rng.uniform(-0.5, 0.5, 3)
+        quat = np.zeros(4)
+        a.lib.rpo_quat_from_euler(rpy.ctypes.data_as(DP), quat.ctypes.data_as(DP))
+        q6 = rest
+        for _ in range(4):
+            q6 = a.calc_angles(pos, quat, q6)
+        q = tab[:, 1] + (tab[:, 2] - tab[:, 1]) * rng.random(a.n_arm)
+        q[:6] = q6[:6]
+        a.set_arm_q(q)
+        b.set_arm_q(q)
+        cons = [c for c in a.contacts() if int(c[1]) == plate]
+        for c in cons:
+            ca = int(c[0])
+            dist, pa, pb, n = np.zeros(1), np.zeros(3), np.zeros(3), np.zeros(3)
+            r = lib.rpo_ref_collider_distance(b.h, ca, plate, dist.ctypes.data_as(DP), pa.ctypes.data_as(DP), pb.ctypes.data_as(DP), n.ctypes.data_as(DP))
+            if r == 0 or cols[ca]['type'] != 0:
+                continue
+            is_hull = oracle_has_hull(ca)
+            if not is_hull:
+                continue
+            # the reference step's point on the plate and the fast model's: p = pB + d/2 n  =>  pB = p - d/2 n
+            pB = c[2:5] - 0.5 * c[8] * c[5:8]
+            if abs(dist[0] - c[8]) < 2e-6 and np.allclose(n, c[5:8], atol=1e-6):
+                np.testing.assert_allclose(pB, pb, atol=5e-5)      # (a face-parallel edge or face has no unique closest point: those poses fail the two tests above and are skipped)
+                seen['inside' if c[8] < 0 else 'apart'] += 1
+    assert seen['apart'] >= 5 and seen['inside'] >= 5, seen
+
+
+def oracle_has_hull(col):
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'roboticsplayroompybullet_amd', 'csrc', 'generated', 'rp_hullverts_gen.h')).read()
+    cnt = [int(x) for x in re.search(r'rp_hull_cnt_R\[64\] = \{([^}]*)\}', src).group(1).split(',')]
+    return cnt[col] > 0
