@@ -9,7 +9,9 @@ onto the block, close, lift: the contact-rich case) - N envs are reset once by m
     joints  the same over all dofs, the gripper's auxiliary joints included (north_star's "relative joint-state divergence")
     block   max over steps of |block position A - B| in metres
 as median / 90th percentile / max over the envs.  Rows:
-    A default      the shipped model: per-pair contact margins = Bullet's relative breaking thresholds
+    A default      the shipped model: Bullet's row order and limit rule, hull vertices against static boxes, arm boxes overlap-only, per-pair contact margins =
+                   Bullet's relative breaking thresholds for everything else
+    A round 2      last round's model (rule 0); A -x: the shipped model with one of its round-3 features off
     A m=...        the same model with one uniform contact margin (0, 5 mm = round 1's choice, 20 mm = gContactBreakingThreshold taken absolute)
     B -flag        mode B with one of its differences switched off (what each Bullet feature is worth, measured inside mode B)
     B +warm        mode B with warm starting on
@@ -77,11 +79,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--envs', type=int, default=12)
     ap.add_argument('--steps', type=int, default=200)
-    ap.add_argument('--tag', default='r02')
-    ap.add_argument('--kinds', default='R,U,P')
+    ap.add_argument('--tag', default='r03')
+    ap.add_argument('--kinds', default='R,Q,U,P')
     args = ap.parse_args()
     D = oracle.REF_DEFAULT
-    variants = [('A default (shipped)', dict()), ('A m=0', dict(margin=0.0)), ('A m=5mm', dict(margin=0.005)), ('A m=20mm', dict(margin=0.02))]
+    # the shipped model's rule bits (rp_oracle.c RPO_RULE_*): 1 Bullet's row order, 2 violated-only limits, 4 hull vertices against static boxes, 16 arm boxes overlap-only
+    variants = [('A default (shipped)', dict()), ('A round 2 (rule 0)', dict(rule=0)), ('A -order -limit', dict(rule=20)), ('A -hull', dict(rule=19)), ('A -boxoverlap', dict(rule=7)),
+                ('A m=0', dict(margin=0.0)), ('A m=5mm', dict(margin=0.005)), ('A m=20mm', dict(margin=0.02))]
     for name, bit in oracle.REF_FLAGS.items():
         if name == 'warm':
             variants.append(('B +warm', dict(bullet_ref=True, ref_flags=D | bit)))
@@ -89,14 +93,14 @@ def main():
             variants.append(('B -%s' % name, dict(bullet_ref=True, ref_flags=D & ~bit)))
     results = {}
     for kind in args.kinds.split(','):
-        for scenario in (('random',) if kind == 'R' else ('random', 'grasp')):
+        for scenario in (('random',) if kind in ('R', 'Q') else ('random', 'grasp')):
             rows = {v[0]: [] for v in variants}
             for e in range(args.envs):
                 ref = OracleEnv(kind, seed=77, env_index=e, bullet_ref=True)
                 ref.reset()
                 state0 = ref.get_state()
                 goal = ref.calc_state()['desired_goal']
-                acts = random_actions(kind, args.steps, np.random.default_rng(1000 + e))
+                acts = random_actions('R' if kind == 'Q' else kind, args.steps, np.random.default_rng(1000 + e))
                 qb, bb = rollout(ref, kind, scenario, args.steps, acts, state0)
                 for name, kw in variants:
                     env = OracleEnv(kind, seed=77, env_index=e, **kw)
