@@ -72,7 +72,7 @@ def cpu_baseline(seed, margin=None):
 
 STEP_KERNELS = ('k_action_prep', 'k_prep2', 'k_solve2', 'k_calc_state')     # what one rp_step launches (default pipeline)
 PMC_SUMMARY = 'r03_pmc_summary.json'
-WARMUP_FLOOR = 20      # untimed steps before the first timed region whatever --warmup says: clocks, caches and the load-sorted env pairing have settled by then
+WARMUP_FLOOR = 200     # untimed steps before the first timed region whatever --warmup says: the rollout has reached its steady contact statistics by then (the first ~100 steps after a reset run ~3 % slower: arms still travelling from the rest pose), and clocks, caches and the load-sorted env pairing have settled
 
 
 def pmc_traffic(kernel=None):
@@ -157,18 +157,18 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         pending = None
+        if events:
+            events[0].record()                 # ONE pair around the whole region (a pair per step puts two marker packets into the queue per step: 2 % of the step)
         for k in range(steps):
-            if events:
-                events[0][k].record()
             obs, r, done, info = env.step(acts[first + k])
-            if events:
-                events[1][k].record()
             if world > 1:
                 if pending is not None:
                     pending.wait()
                 _, pending = sharding.gather_observations(env.pack, out=gathered, async_op=True)
         if pending is not None:
             pending.wait()
+        if events:
+            events[1].record()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -183,11 +183,10 @@ def main():
         env.step(a)
         if world > 1:
             sharding.gather_observations(env.pack, out=gathered)
-    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     elapsed, info = timed_region(env, actions, args.warmup, args.steps, (ev0, ev1))       # the contract's region: `value`
     torch.cuda.synchronize()
-    step_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / args.steps
+    step_ms = ev0.elapsed_time(ev1) / args.steps      # device-side time of the same region (events on rp_step's stream)
     # per-launch kernel durations: hipEvent pairs recorded on the launch stream inside rp_step; bracketing single kernels
     # needs the env groups (concurrent streams) switched off, so this is a second region over the same actions
     n_kt = min(args.steps, 50)
@@ -263,7 +262,7 @@ def main():
             # kernel's own per-launch figure sits in `dominant_kernel`
             'roofline': {'bound': 'latency/issue', 'nominal_bound': 'hbm', 'hbm_frac': step_achieved / HBM_PEAK_GBS, 'achieved': step_achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': step_achieved / HBM_PEAK_GBS,
                          'traffic': pmc_traffic() if n == ENVS_PER_GPU else None,
-                         'what': 'whole env step: %d B algorithmic per env-step (SURVEY.md 8d) x %d envs / %.3f ms (torch events around rp_step on its stream)'
+                         'what': 'whole env step: %d B algorithmic per env-step (SURVEY.md 8d) x %d envs / %.3f ms (torch events on the stream of rp_step around the timed region)'
                                  % (ALG_BYTES_PER_ENV_STEP, n, step_ms),
                          'algorithmic_bytes_per_step': ALG_BYTES_PER_ENV_STEP * n,
                          'limiter': 'latency / issue, not bandwidth: 50 sweeps of dependent PGS row updates per k_solve2 launch (the launch lasts as '
