@@ -621,7 +621,8 @@ def test_config_panda_pick_4096_envs():
         obs, r, done, info = env.step(a)
     torch.cuda.synchronize()
     # status bit 1 = non-finite state: never.  Bit 2 = an object left the scene: this scenario presses the closed fingers onto the block
-    # that lies on the reference's 0.2 mm ground plate (scenes.py:8-21), and a fraction of a percent of the blocks is pushed through it
+    # that lies on the reference's 0.2 mm ground plate (scenes.py:8-21), and a fraction of a percent of the blocks is pushed through it - under the frozen
+    # reference step too (tools/plate_tunnelling.py: 1 of 1024 sampled envs in both models), so the bound stays
     st = info['status']
     assert int((st & 1).sum()) == 0 and torch.isfinite(env.get_state()).all()
     assert int(((st & 2) != 0).sum()) <= n // 100, 'fallen blocks: %d' % int(((st & 2) != 0).sum())
