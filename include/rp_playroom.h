@@ -176,6 +176,9 @@ int rp_calc_state(rp_handle h, const rp_out* out, void* stream);
 
 /* playEnv.compute_reward(achieved_goal, desired_goal) (ENV:278-304, RWD:66-77) for M rows. */
 int rp_compute_reward(rp_handle h, const float* achieved_goal, const float* desired_goal, float* reward, int32_t m, void* stream);
+/* playEnv.compute_reward_sparse (environments.py:278-304): the sparse formula whatever `sparse` the env was built with (the reference rebinds only
+ * compute_reward when sparse=False, environments.py:169-170; compute_reward_sparse stays callable) */
+int rp_compute_reward_sparse(rp_handle h, const float* achieved_goal, const float* desired_goal, float* reward, int32_t m, void* stream);
 
 /* full simulator state (positions, velocities, motor targets, goal, quaternion memory, RNG counters): the
  * explicit save/restore the reference lacks.  src_env_count == 1 broadcasts one env to all N. */

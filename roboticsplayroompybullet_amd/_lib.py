@@ -72,7 +72,7 @@ class RpTimers(C.Structure):
 
 
 EXPORTS = ['rp_create', 'rp_destroy', 'rp_get_dims', 'rp_reset', 'rp_reset_to', 'rp_reset_goal', 'rp_step', 'rp_calc_state',
-           'rp_compute_reward', 'rp_state_bytes', 'rp_get_state', 'rp_set_state', 'rp_get_timers', 'rp_enable_timers',
+           'rp_compute_reward', 'rp_compute_reward_sparse', 'rp_state_bytes', 'rp_get_state', 'rp_set_state', 'rp_get_timers', 'rp_enable_timers',
            'rp_last_error', 'rp_version', 'rp_default_camera', 'rp_camera_from_yaw_pitch_roll', 'rp_render', 'rp_ray_test']
 # include/rp_playroom_debug.h: test / tuning hooks
 DEBUG_EXPORTS = ['rp_set_fused', 'rp_set_groups', 'rp_set_debug_flags', 'rp_debug_substep', 'rp_debug_row_counts', 'rp_debug_reset_rounds']
@@ -108,6 +108,7 @@ def load(wide=False):
     lib.rp_step.argtypes = [vp, vp, C.POINTER(RpOut), vp]
     lib.rp_calc_state.argtypes = [vp, C.POINTER(RpOut), vp]
     lib.rp_compute_reward.argtypes = [vp, vp, vp, vp, C.c_int32, vp]
+    lib.rp_compute_reward_sparse.argtypes = [vp, vp, vp, vp, C.c_int32, vp]
     lib.rp_state_bytes.argtypes = [vp]
     lib.rp_state_bytes.restype = C.c_size_t
     lib.rp_get_state.argtypes = [vp, vp, vp]

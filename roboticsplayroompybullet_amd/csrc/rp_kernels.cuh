@@ -1687,8 +1687,8 @@ __device__ float success_func(const float* ag, const float* g) {
 
 /* compute_reward_sparse (environments.py:278-304) or, with sparse=False, the dense compute_reward = -||ag - dg|| over the whole
  * goal vector (environments.py:169-170, 273-275; calc_target_distance takes the norm of the full difference) */
-__device__ float compute_reward(const DevModel* m, const float* ag, const float* dg) {
-  if (m->dense_reward) {
+__device__ float compute_reward(const DevModel* m, const float* ag, const float* dg, bool force_sparse = false) {
+  if (m->dense_reward && !force_sparse) {
     float s = 0.f;
     for (int k = 0; k < m->n_ag; k++) { float d = ag[k] - dg[k]; s += d * d; }
     return -sqrtf(s);
@@ -2187,10 +2187,10 @@ __global__ void k_init(const DevModel* __restrict__ m, float* __restrict__ state
   r[ST_NGOAL] = __int_as_float(m->n_goal_init);
 }
 
-__global__ void k_reward(const DevModel* __restrict__ m, const float* __restrict__ ag, const float* __restrict__ dg, float* __restrict__ r, int M) {
+__global__ void k_reward(const DevModel* __restrict__ m, const float* __restrict__ ag, const float* __restrict__ dg, float* __restrict__ r, int M, int force_sparse) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= M) return;
-  r[i] = compute_reward(m, ag + (size_t)i * m->n_ag, dg + (size_t)i * m->n_ag);
+  r[i] = compute_reward(m, ag + (size_t)i * m->n_ag, dg + (size_t)i * m->n_ag, force_sparse != 0);
 }
 
 /* state record copies (rp_get_state / rp_set_state with broadcast) */

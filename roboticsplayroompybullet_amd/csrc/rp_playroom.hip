@@ -473,14 +473,16 @@ int rp_calc_state(rp_handle h, const rp_out* out, void* stream) {
   return RP_OK;
 }
 
-int rp_compute_reward(rp_handle h, const float* ag, const float* dg, float* r, int32_t m, void* stream) {
+static int reward_impl(rp_handle h, const float* ag, const float* dg, float* r, int32_t m, void* stream, int force_sparse) {
   if (!h || !ag || !dg || !r || m < 0) return RP_ERR_ARG;
   if (m == 0) return RP_OK;
   DevGuard guard(h->cfg.device);
-  hipLaunchKernelGGL(k_reward, dim3((m + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->dev_model, ag, dg, r, m);
+  hipLaunchKernelGGL(k_reward, dim3((m + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->dev_model, ag, dg, r, m, force_sparse);
   HIPCHK(h, hipGetLastError());
   return RP_OK;
 }
+int rp_compute_reward(rp_handle h, const float* ag, const float* dg, float* r, int32_t m, void* stream) { return reward_impl(h, ag, dg, r, m, stream, 0); }
+int rp_compute_reward_sparse(rp_handle h, const float* ag, const float* dg, float* r, int32_t m, void* stream) { return reward_impl(h, ag, dg, r, m, stream, 1); }
 
 size_t rp_state_bytes(rp_handle h) { (void)h; return RP_REC_FLOATS * sizeof(float); }
 

@@ -67,6 +67,8 @@ class playEnv:
                 'absolute_joints': [6] * ndof + [1], 'relative_joints': [1] * (ndof + 1)}.get(action_type)
         if high is None:
             raise NotImplementedError(action_type)
+        if action_type == 'absolute_quat' and not use_orientation:
+            high = [1, 1, 1, 1]              # the reference declares a 4-wide space here (environments.py:90-95) and then cannot step it: absolute_quat_step asserts 8 (937)
         high = np.array(high)
         self.action_space = spaces.Box(-high, high)
         # declared spaces, reproduced as-is including the arm_lower_obs_lim typo (environments.py:120-166, quirk F11)
@@ -151,6 +153,8 @@ class playEnv:
 
     def step(self, action):
         import torch
+        if self.action_type in ('absolute_quat', 'relative_quat'):
+            assert len(action) == 8          # environments.py:937, 948 (an id without use_orientation declares 4 and fails here, like the reference)
         a = np.clip(action, self.action_space.low, self.action_space.high)        # environments.py:207 (again on device)
         obs, r, done, info = self._vec.step(torch.as_tensor(np.asarray(a, dtype=np.float32))[None])
         o = self._to_reference_obs(obs)
@@ -167,9 +171,12 @@ class playEnv:
         return float(r) if r.ndim == 0 else r
 
     def compute_reward_sparse(self, achieved_goal, desired_goal, info=None):
-        if self.sparse:
-            return self.compute_reward(achieved_goal, desired_goal, info)
-        raise NotImplementedError('this env was built with sparse=False: the device holds the dense reward (environments.py:169-170)')
+        """environments.py:278-304; stays the sparse formula when the env was built with sparse=False (the reference rebinds only compute_reward, 169-170)"""
+        import torch
+        ag = torch.as_tensor(np.asarray(achieved_goal, dtype=np.float32))
+        dg = torch.as_tensor(np.asarray(desired_goal, dtype=np.float32))
+        r = self._vec.compute_reward_sparse(ag, dg).cpu().numpy().astype(np.float64)
+        return float(r) if r.ndim == 0 else r
 
     def calc_target_distance(self, achieved_goal, desired_goal):
         return float(np.linalg.norm(np.asarray(achieved_goal) - np.asarray(desired_goal)))

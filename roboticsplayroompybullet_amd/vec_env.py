@@ -97,6 +97,8 @@ class VecPlayEnv:
         self.action_high = torch.tensor(hi, dtype=torch.float32, device=dev)
         self._max_episode_steps = None if env_id.startswith('UR5Play') else 250
         self.record_images = False          # instance.record_images (environments.py:201, 203)
+        self.image_envs = None              # (lo, hi): the envs whose img is rendered while record_images is set (default: all - 120 KB per env and call)
+        self._img = None                    # reused image buffer: obs['img'] is overwritten by the next step / reset / calc_state (clone() to keep one)
         self.sub_goal = None                # [N, dims.achieved_goal] ghosts drawn into img (visualise_sub_goal)
 
     def _stream(self):
@@ -105,7 +107,13 @@ class VecPlayEnv:
     def _obs(self):
         o = {k: self.buf[k] for k in OBS_KEYS}
         # environments.py:841-845: img only while record_images is set (render('rgb_array')); all envs, [N, 200, 200, 3] uint8
-        o['img'] = self.render('rgb_array', sub_goal=self.sub_goal) if self.record_images else None
+        o['img'] = None
+        if self.record_images:
+            lo, hi = self.image_envs or (0, self.num_envs)
+            if self._img is None or self._img.shape[0] != hi - lo:
+                self._img = torch.empty((hi - lo, 200, 200, 3), dtype=torch.uint8, device=self.device)
+            sg = self.sub_goal[lo:hi] if (self.sub_goal is not None and self.sub_goal.shape[0] == self.num_envs) else self.sub_goal
+            o['img'] = self.render('rgb_array', envs=(lo, hi), sub_goal=sg, out=self._img)
         o['gripper_proprioception'] = self.buf['gripper_proprioception']
         return o
 
@@ -173,14 +181,18 @@ class VecPlayEnv:
             mp = C.c_void_p(mask.data_ptr())
         _lib.check(self.lib, self.h, self.lib.rp_reset_goal(self.h, gp, mp, self._stream()), 'rp_reset_goal')
 
-    def compute_reward(self, achieved_goal, desired_goal, info=None):
+    def compute_reward_sparse(self, achieved_goal, desired_goal, info=None):
+        """the sparse formula (environments.py:278-304) whatever `sparse` the env was built with"""
+        return self.compute_reward(achieved_goal, desired_goal, info, _fn='rp_compute_reward_sparse')
+
+    def compute_reward(self, achieved_goal, desired_goal, info=None, _fn='rp_compute_reward'):
         ag = achieved_goal.to(device=self.device, dtype=torch.float32).contiguous()
         dg = desired_goal.to(device=self.device, dtype=torch.float32).contiguous()
         w = self.dims['achieved_goal']
         ag2, dg2 = ag.reshape(-1, w), dg.reshape(-1, w)
         r = torch.empty(ag2.shape[0], dtype=torch.float32, device=self.device)
-        _lib.check(self.lib, self.h, self.lib.rp_compute_reward(self.h, C.c_void_p(ag2.data_ptr()), C.c_void_p(dg2.data_ptr()),
-                                                                  C.c_void_p(r.data_ptr()), ag2.shape[0], self._stream()), 'rp_compute_reward')
+        _lib.check(self.lib, self.h, getattr(self.lib, _fn)(self.h, C.c_void_p(ag2.data_ptr()), C.c_void_p(dg2.data_ptr()),
+                                                             C.c_void_p(r.data_ptr()), ag2.shape[0], self._stream()), _fn)
         return r.reshape(ag.shape[:-1])
 
     @property
@@ -198,7 +210,7 @@ class VecPlayEnv:
         cam.fov_deg, cam.aspect, cam.mode = float(fov), float(aspect), 1 if gripper else 0
         return cam
 
-    def render(self, mode='rgb_array', width=200, height=200, envs=None, camera=None, sub_goal=None):
+    def render(self, mode='rgb_array', width=200, height=200, envs=None, camera=None, sub_goal=None, out=None):
         """obs['img'] of the reference (environments.py:841-845: getCameraImage(200, 200, ...)[2][:, :, :3]) for envs [lo, hi) (default: all):
         uint8 [n, height, width, 3] on the device.  sub_goal [n, dims.achieved_goal]: draw the sub-goal's ghosts
         (visualise_sub_goal, environments.py:606-690).  mode 'human' (a GUI window) does not exist here and returns None."""
@@ -206,7 +218,8 @@ class VecPlayEnv:
             return None
         lo, hi = (0, self.num_envs) if envs is None else (int(envs[0]), int(envs[1]))
         n = hi - lo
-        img = torch.empty((n, int(height), int(width), 3), dtype=torch.uint8, device=self.device)
+        img = out if out is not None else torch.empty((n, int(height), int(width), 3), dtype=torch.uint8, device=self.device)
+        assert img.shape == (n, int(height), int(width), 3) and img.dtype == torch.uint8 and img.is_contiguous()
         sg = None
         if sub_goal is not None:
             sub_goal = sub_goal.to(device=self.device, dtype=torch.float32).contiguous()

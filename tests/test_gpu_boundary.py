@@ -194,6 +194,10 @@ def test_single_env_adapter_honours_kwargs_and_refuses_layout_changes():
     o = dense.reset()
     o, r, _, info = dense.step(np.array([0.0, 0.0, 0.1, 0, 0, 0, 0]))
     assert r == pytest.approx(-np.linalg.norm(o['achieved_goal'] - o['desired_goal']), abs=1e-6)
+    # compute_reward_sparse stays the sparse formula on a dense env (the reference rebinds only compute_reward, environments.py:169-170)
+    assert dense.compute_reward_sparse(np.zeros(3), np.array([0.2, 0, 0])) == -1.0
+    assert dense.compute_reward_sparse(np.zeros(3), np.array([0.03, 0, 0])) == pytest.approx(-0.03, abs=1e-7)
+    assert dense.compute_reward(np.zeros(3), np.array([0.2, 0, 0])) == pytest.approx(-0.2, abs=1e-7)
     dense.close()
     bad = rp.make('UR5Reach-v0', num_objects=1)
     with pytest.raises(NotImplementedError, match='cannot be overridden'):
