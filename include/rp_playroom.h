@@ -125,7 +125,9 @@ typedef struct rp_out {
   int32_t* status;                   /* [N] bit flags, 0 = ok: 1 non-finite state, 2 an object fell through the scene's ground plate
                                       * (tunnelled: it is below the lowest static collider), 4 rp_reset left this env unfinished,
                                       * 8 (informational, not a fault) the IK of the latest rp_step ran out of its iterations for this env
-                                      * (inverseKinematics.py:44-50: 4 x 20; Panda: 200) - its joint targets then hang on the measured joints */
+                                      * (inverseKinematics.py:44-50: 4 x 20; Panda: 200) - its joint targets then hang on the measured joints,
+                                      * 16 (informational) one of that IK's stopping tests was decided within 0.5 % of the residual threshold: another
+                                      * evaluation order of the same arithmetic may have stopped an iteration apart (~5e-5 rad in the joint targets) */
   float* pack;                       /* [N, dims.obs_quat + dims.achieved_goal + 2]: obs_quat | achieved_goal | reward | is_success
                                       * in one row, the message of the per-step multi-GPU observation gather,
                                       * written by the same kernel so the gather needs no packing pass */

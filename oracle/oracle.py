@@ -130,6 +130,7 @@ def load(f32=False, bullet_ref=False):
         lib.rpo_get_ref_flags.restype = C.c_uint
         lib.rpo_ref_num_contacts.argtypes = [vp]
         lib.rpo_ref_num_manifolds.argtypes = [vp]
+        lib.rpo_ref_contacts.argtypes = [vp, dp, C.c_int]
     _LIBS[name] = lib
     return lib
 
@@ -165,6 +166,7 @@ class OracleEnv:
                  dense_reward=False, bullet_ref=False, ref_flags=None, rule=None):
         """ranges = (goal_lo, goal_hi, obj_lo, obj_hi, env_hi): the env class's range kwargs (envList.py); margin: contact margin
         in metres for every pair (default, like the library: per pair the smaller of the two objects' Bullet breaking thresholds, rp_model.col_thr)"""
+        self.bullet_ref = bullet_ref
         self.lib = load(f32, bullet_ref)      # bullet_ref: the frozen Bullet-like step (rp_bullet_ref.c) under the same harness
         user_ranges = ranges
         ranges = None
@@ -369,8 +371,11 @@ class OracleEnv:
         return a
 
     def contacts(self, max_n=96):
+        """[n, 9]: collider a, collider b, point, normal (from b toward a), distance.  Mode B: the points of its persistent manifolds (this call advances
+        them as a substep's collision phase would)"""
         out = np.zeros((max_n, 9))
-        n = self.lib.rpo_contacts(self.h, out.ctypes.data_as(C.POINTER(C.c_double)), max_n)
+        fn = self.lib.rpo_ref_contacts if self.bullet_ref else self.lib.rpo_contacts
+        n = fn(self.h, out.ctypes.data_as(C.POINTER(C.c_double)), max_n)
         return out[:min(n, max_n)]
 
     def arm_table(self):

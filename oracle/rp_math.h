@@ -9,6 +9,7 @@
 #ifdef RP_FLOAT
 typedef float real;
 #define R_SQRT sqrtf
+#define R_EPS 1.1920929e-7f
 #define R_SIN sinf
 #define R_COS cosf
 #define R_ATAN2 atan2f
@@ -20,6 +21,7 @@ typedef float real;
 #else
 typedef double real;
 #define R_SQRT sqrt
+#define R_EPS 2.220446049250313e-16
 #define R_SIN sin
 #define R_COS cos
 #define R_ATAN2 atan2

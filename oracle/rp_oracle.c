@@ -44,6 +44,9 @@
                                     * KEEPS them out to the breaking threshold; a stateless model has to pick one rule per pair: the arm's contacts are impacts (making them early
                                     * is measurably further from the reference step: UR5Reach arm divergence 2.6e-4 -> 5.6e-5 median), the objects' are resting contacts that
                                     * live for seconds (they keep the threshold as their margin, which is what the kept points look like) */
+#define RPO_RULE_ODEORDER 32        /* box against box: the face clip emits its points in btBoxBoxDetector's order (box_box) */
+#define RPO_RULE_LEVER 64           /* a contact acts at its point on A on body A and at its point on B on body B (otherwise: at their midpoint on both) */
+#define RPO_RULE_SPIN 128           /* spinning_friction of the gripper links: one torsional friction row per collider pair in contact */
 #define RPO_RULE_HULLFACE 4         /* arm links touch static boxes with the vertices of their collision meshes' convex hulls (hull_face) instead of their OBBs */
 #define HULL_MARGIN ((real)RP_HULL_MARGIN)
 #define FREE_LIN_DAMP ((real)0.04)
@@ -54,9 +57,10 @@
 #define IK_MAX_STEP ((real)(45.0 * 3.14159265358979323846 / 180.0))
 #define TIE_EPS ((real)1e-6)            /* discrete narrowphase choices need a margin that fp32 and fp64 agree on */
 #define MAX_CONTACTS 21
+#define MAX_TORS 4                /* torsional friction rows per substep (RPO_RULE_SPIN), shared with the HIP library (MAXT) */
 #define MAX_ACTIVE_PAIRS 64
 #define MAX_CANDIDATES 64    /* candidate points that enter the manifolds per substep (CANDMAX of the HIP library) */
-#define MAX_ROWS (RP_MAX_ARM * 3 + RP_MAX_J1 + 2 + 3 * MAX_CONTACTS)
+#define MAX_ROWS (RP_MAX_ARM * 3 + RP_MAX_J1 + 2 + 3 * MAX_CONTACTS + MAX_TORS)
 #define NB_MAX (1 + RP_MAX_ARM + RP_MAX_FREE + RP_MAX_J1)
 
 typedef struct { real R[9], p[3]; } xform;
@@ -244,7 +248,7 @@ static int clip_poly(const real (*in)[3], int n, const real* c, const real* u, r
 
 /* Box-box contact generation: 15-axis SAT with a 2 cm speculative margin, face clipping (Sutherland-Hodgman)
  * or edge-edge closest points, at most 4 points.  Normal from B toward A; dist < 0 = penetration. */
-static int box_box(const real* ca, const real* Ra, const real* ha, const real* cb, const real* Rb, const real* hb, real margin,
+static int box_box(const real* ca, const real* Ra, const real* ha, const real* cb, const real* Rb, const real* hb, real margin, int ode_order,
                    cpoint* out) {
   real A[3][3], Bx[3][3], t[3];
   for (int i = 0; i < 3; i++) { col_axis(A[i], Ra, i); col_axis(Bx[i], Rb, i); }
@@ -310,19 +314,26 @@ static int box_box(const real* ca, const real* Ra, const real* ha, const real* c
   for (int k = 0; k < 3; k++) { real v = R_FABS(v3dot(nref, Y[k])); if (v > bj) { bj = v; j = k; } }
   real sj = v3dot(nref, Y[j]) > 0 ? (real)-1 : (real)1;
   int k1 = (j + 1) % 3, k2 = (j + 2) % 3;
+  /* RPO_RULE_ODEORDER: the polygon is walked the way btBoxBoxDetector (ODE's dBoxBox2) walks it - the incident face from its (-, -) corner with its two
+   * axes in increasing order, the reference rectangle's sides in the order -u1, +u1, -u2, +u2 with u1 < u2 - because the ORDER of a pair's points is the
+   * order of the solver's rows (same points either way) */
+  if (ode_order && k1 > k2) { int tmp = k1; k1 = k2; k2 = tmp; }
   real fc[3]; v3cpy(fc, cY); v3axpy(fc, sj * hY[j], Y[j]);
   real poly[2][16][3];
-  static const real sg[4][2] = {{1, 1}, {-1, 1}, {-1, -1}, {1, -1}};
+  static const real sg0[4][2] = {{1, 1}, {-1, 1}, {-1, -1}, {1, -1}}, sg1[4][2] = {{-1, -1}, {-1, 1}, {1, 1}, {1, -1}};
+  const real (*sg)[2] = ode_order ? sg1 : sg0;
   for (int v = 0; v < 4; v++) {
     v3cpy(poly[0][v], fc);
     v3axpy(poly[0][v], sg[v][0] * hY[k1], Y[k1]);
     v3axpy(poly[0][v], sg[v][1] * hY[k2], Y[k2]);
   }
   int u1 = (best_i + 1) % 3, u2 = (best_i + 2) % 3, n = 4;
-  n = clip_poly(poly[0], n, cX, X[u1], hX[u1], 1, poly[1]);
-  n = clip_poly(poly[1], n, cX, X[u1], hX[u1], -1, poly[0]);
-  n = clip_poly(poly[0], n, cX, X[u2], hX[u2], 1, poly[1]);
-  n = clip_poly(poly[1], n, cX, X[u2], hX[u2], -1, poly[0]);
+  if (ode_order && u1 > u2) { int tmp = u1; u1 = u2; u2 = tmp; }
+  const real s1 = ode_order ? -1 : 1;
+  n = clip_poly(poly[0], n, cX, X[u1], hX[u1], s1, poly[1]);
+  n = clip_poly(poly[1], n, cX, X[u1], hX[u1], -s1, poly[0]);
+  n = clip_poly(poly[0], n, cX, X[u2], hX[u2], s1, poly[1]);
+  n = clip_poly(poly[1], n, cX, X[u2], hX[u2], -s1, poly[0]);
   cpoint tmp[16]; int cnt = 0, deepest = 0;
   for (int v = 0; v < n; v++) {
     real r[3]; v3sub(r, poly[0][v], cX);
@@ -337,7 +348,36 @@ static int box_box(const real* ca, const real* Ra, const real* ha, const real* c
     cnt++;
   }
   if (cnt <= 4) { for (int v = 0; v < cnt; v++) out[v] = tmp[v]; return cnt; }
-  for (int v = 0; v < 4; v++) out[v] = tmp[(deepest + (v * cnt) / 4) % cnt];
+  if (!ode_order) { for (int v = 0; v < 4; v++) out[v] = tmp[(deepest + (v * cnt) / 4) % cnt]; return 4; }
+  /* more than four: the detector's cullPoints2 - the deepest first, then for each of the three directions a quarter turn further around the polygon's
+   * centroid (in the reference face's plane) the unused point nearest to it in angle */
+  {
+    real q2[16][2], ang[16], area = 0, cx = 0, cy = 0; int avail[16];
+    for (int v = 0; v < cnt; v++) {
+      real r[3]; v3cpy(r, tmp[v].p); v3axpy(r, (real)0.5 * tmp[v].dist, nref); v3sub(r, r, cX);      /* back to the polygon's vertex */
+      q2[v][0] = v3dot(r, X[u1]); q2[v][1] = v3dot(r, X[u2]);
+    }
+    for (int v = 0; v < cnt; v++) {
+      const int w = (v + 1) % cnt;
+      const real q = q2[v][0] * q2[w][1] - q2[w][0] * q2[v][1];
+      area += q; cx += q * (q2[v][0] + q2[w][0]); cy += q * (q2[v][1] + q2[w][1]);
+    }
+    area = R_FABS(area) > (real)1e-30 ? 1 / (3 * area) : (real)1e30;
+    cx *= area; cy *= area;
+    for (int v = 0; v < cnt; v++) { ang[v] = R_ATAN2(q2[v][1] - cy, q2[v][0] - cx); avail[v] = 1; }
+    avail[deepest] = 0; out[0] = tmp[deepest];
+    for (int j = 1; j < 4; j++) {
+      real want = (real)j * (real)(0.5 * RP_PI) + ang[deepest];
+      if (want > (real)RP_PI) want -= (real)(2 * RP_PI);
+      real bestd = (real)1e9; int pick = deepest;
+      for (int v = 0; v < cnt; v++) if (avail[v]) {
+        real diff = R_FABS(ang[v] - want);
+        if (diff > (real)RP_PI) diff = (real)(2 * RP_PI) - diff;
+        if (diff < bestd) { bestd = diff; pick = v; }
+      }
+      avail[pick] = 0; out[j] = tmp[pick];
+    }
+  }
   return 4;
 }
 
@@ -487,7 +527,7 @@ static void collide(rpo_env* e) {
       hf = hull_face(e, a, b, margin, pts);
     if (hf >= 0) np = hf;
     else if (m->col_type[a] == 0 && m->col_type[b] == 0)
-      np = box_box(e->xc[a].p, e->xc[a].R, ha, e->xc[b].p, e->xc[b].R, hb, (e->margin < 0 && (e->rule & RPO_RULE_BOXOVERLAP) && (body_is_arm(e, m->col_body[a]) || body_is_arm(e, m->col_body[b]))) ? (real)0 : margin, pts);
+      np = box_box(e->xc[a].p, e->xc[a].R, ha, e->xc[b].p, e->xc[b].R, hb, (e->margin < 0 && (e->rule & RPO_RULE_BOXOVERLAP) && (body_is_arm(e, m->col_body[a]) || body_is_arm(e, m->col_body[b]))) ? (real)0 : margin, (e->rule & RPO_RULE_ODEORDER) != 0, pts);
     else if (m->col_type[a] == 0 && m->col_type[b] == 1)
       np = sphere_box(e->xc[b].p, hb[0], e->xc[a].p, e->xc[a].R, ha, margin, 1, pts);
     else if (m->col_type[a] == 1 && m->col_type[b] == 0)
@@ -686,17 +726,20 @@ static void body_jacobian(const rpo_env* e, int body, const real* p, const real*
 }
 
 /* B = M^-1 J^T for a contact-like row acting at point p along n on bodyA (+) and bodyB (-) */
-static void contact_response(const rpo_env* e, int bodyA, int bodyB, const real* p, const real* n, const real* J, real* B) {
+/* B = M^-1 J^T of a row that pushes along n at pa on body A (+) and at pb on body B (-); ang: a pure torque about n instead (torsional friction) */
+static void contact_response2(const rpo_env* e, int bodyA, int bodyB, const real* pa, const real* pb, const real* n, int ang, const real* J, real* B) {
   const rp_model* m = &e->m;
   memset(B, 0, sizeof(real) * RP_MAX_NV);
   for (int side = 0; side < 2; side++) {
     int body = side == 0 ? bodyA : bodyB;
+    const real* p = side == 0 ? pa : pb;
     real sign = side == 0 ? (real)1 : (real)-1;
     if (body == 0) continue;
     if (body_is_arm(e, body)) {
       real f[6], dqd[RP_MAX_ARM];
       real sn[3]; v3scale(sn, n, sign);
-      v3cross(f, p, sn); v3cpy(f + 3, sn);
+      if (ang) { v3cpy(f, sn); v3set(f + 3, 0, 0, 0); }
+      else { v3cross(f, p, sn); v3cpy(f + 3, sn); }
       arm_impulse_response(e, body - 1, f, 0, dqd);
       for (int i = 0; i < m->n_arm; i++) B[i] += dqd[i];
       continue;
@@ -719,10 +762,33 @@ static void contact_response(const rpo_env* e, int bodyA, int bodyB, const real*
   }
 }
 
+static void contact_response(const rpo_env* e, int bodyA, int bodyB, const real* p, const real* n, const real* J, real* B) { contact_response2(e, bodyA, bodyB, p, p, n, 0, J, B); }
+/* the angular part of a body's Jacobian along n (torsional friction rows) */
+static void ang_jacobian(const rpo_env* e, int body, const real* n, real sign, real* J) {
+  const rp_model* m = &e->m;
+  if (body == 0) return;
+  if (body_is_arm(e, body)) { for (int i = body - 1; i >= 0; i = m->arm_parent[i]) J[i] += sign * v3dot(e->S[i], n); return; }
+  int k = body_free_index(e, body);
+  if (k >= 0) { int d = dof_free(e, k); for (int i = 0; i < 3; i++) J[d + 3 + i] += sign * n[i]; return; }
+  k = body_j1_index(e, body);
+  if (k >= 0 && m->j1_type[k] == 0) {
+    real ax[3], a[3];
+    for (int i = 0; i < 3; i++) ax[i] = (real)m->j1_axis[k][i];
+    m3mulv(a, e->xb[body].R, ax);
+    J[dof_j1(e, k)] += sign * v3dot(a, n);
+  }
+}
+
 static real dotn(const real* a, const real* b, int n) { real s = 0; for (int i = 0; i < n; i++) s += a[i] * b[i]; return s; }
 /* Bullet fillMultiBodyConstraint: jacDiagABInv = d > eps ? 1/d : 0 (a row that cannot move anything is inert) */
 static real safe_inv(real d) { return d > (real)1e-9 ? 1 / d : 0; }
 
+/* where a contact acts on its two bodies: RPO_RULE_LEVER: at its point on A and at its point on B (c->p is their midpoint, c->dist apart along c->n),
+ * otherwise at the midpoint on both */
+static void contact_points(const rpo_env* e, const contact* c, real* pa, real* pb) {
+  v3cpy(pa, c->p); v3cpy(pb, c->p);
+  if (e->rule & RPO_RULE_LEVER) { v3axpy(pa, (real)0.5 * c->dist, c->n); v3axpy(pb, (real)-0.5 * c->dist, c->n); }
+}
 static row* new_row(rpo_env* e) {
   row* r = &e->rows[e->nrows++];
   memset(r, 0, sizeof(*r));
@@ -823,9 +889,11 @@ static void build_rows(rpo_env* e, const real* vstar) {
     contact* c = &e->con[ci];
     int ba = m->col_body[c->ca], bb = m->col_body[c->cb];
     row* r = new_row(e);
-    body_jacobian(e, ba, c->p, c->n, 1, r->J);
-    body_jacobian(e, bb, c->p, c->n, -1, r->J);
-    contact_response(e, ba, bb, c->p, c->n, r->J, r->B);
+    real pa[3], pb[3];
+    contact_points(e, c, pa, pb);
+    body_jacobian(e, ba, pa, c->n, 1, r->J);
+    body_jacobian(e, bb, pb, c->n, -1, r->J);
+    contact_response2(e, ba, bb, pa, pb, c->n, 0, r->J, r->B);
     /* <contact> stiffness / damping of either link (the gripper links: ur5e2.urdf:306-312, panda.urdf:256-262) make the row soft
      * (setupMultiBodyContactConstraint, BT_CONTACT_FLAG_CONTACT_STIFFNESS_DAMPING): combined stiffness 1 / (1/s0 + 1/s1) and damping
      * d0 + d1 (an object without the block counts as stiffness 1e18, damping 0.1) give the implicit spring-damper row
@@ -853,16 +921,37 @@ static void build_rows(rpo_env* e, const real* vstar) {
     r->rhs = (pos_err + vel_err) * r->dinv;
     r->lo = 0; r->hi = (real)1e10;
   }
+  /* RPO_RULE_SPIN: one torsional friction row per run of contacts of one collider pair whose colliders carry spinning_friction (the gripper links), bounded by
+   * that coefficient times the normal impulse of the run's first point; solved after the normals and before the friction rows.  At most MAX_TORS of them,
+   * in contact order (a cap shared with the HIP library, like MAX_CONTACTS) */
+  if (e->rule & RPO_RULE_SPIN)
+    for (int ci = 0, nt = 0; ci < e->ncon && nt < MAX_TORS; ci++) {
+      contact* c = &e->con[ci];
+      if (ci > 0 && e->con[ci - 1].ca == c->ca && e->con[ci - 1].cb == c->cb) continue;
+      real spin = (real)m->col_spin[c->ca] * (real)m->col_friction[c->cb] + (real)m->col_spin[c->cb] * (real)m->col_friction[c->ca];
+      if (!(spin > 0)) continue;
+      int ba = m->col_body[c->ca], bb = m->col_body[c->cb];
+      row* r = new_row(e);
+      ang_jacobian(e, ba, c->n, 1, r->J);
+      ang_jacobian(e, bb, c->n, -1, r->J);
+      contact_response2(e, ba, bb, c->p, c->p, c->n, 1, r->J, r->B);
+      r->dinv = safe_inv(dotn(r->J, r->B, nv));
+      r->rhs = -dotn(r->J, vstar, nv) * r->dinv;
+      r->fric_parent = first_normal + ci;
+      r->mu = spin;
+      nt++;
+    }
   for (int ci = 0; ci < e->ncon; ci++) {
     contact* c = &e->con[ci];
     int ba = m->col_body[c->ca], bb = m->col_body[c->cb];
-    real t[2][3];
+    real t[2][3], pa[3], pb[3];
+    contact_points(e, c, pa, pb);
     plane_space(c->n, t[0], t[1]);
     for (int d = 0; d < 2; d++) {
       row* r = new_row(e);
-      body_jacobian(e, ba, c->p, t[d], 1, r->J);
-      body_jacobian(e, bb, c->p, t[d], -1, r->J);
-      contact_response(e, ba, bb, c->p, t[d], r->J, r->B);
+      body_jacobian(e, ba, pa, t[d], 1, r->J);
+      body_jacobian(e, bb, pb, t[d], -1, r->J);
+      contact_response2(e, ba, bb, pa, pb, t[d], 0, r->J, r->B);
       r->dinv = safe_inv(dotn(r->J, r->B, nv));
       r->rhs = -dotn(r->J, vstar, nv) * r->dinv;
       r->fric_parent = first_normal + ci;
@@ -1726,7 +1815,7 @@ rpo_env* rpo_create(int kind, unsigned long long seed, int env_index) {
   e->nv = m->n_arm + 6 * m->n_free + m->n_joint1;
   e->nbody = 1 + m->n_arm + m->n_free + m->n_joint1;
   e->seed = seed; e->env_index = (uint32_t)env_index;
-  e->rule = RPO_RULE_ORDER | RPO_RULE_LIMIT | RPO_RULE_HULLFACE | RPO_RULE_BOXOVERLAP;       /* the shipped model (the HIP kernels implement exactly this); rpo_set_rule(0) = round 2's rule */
+  e->rule = RPO_RULE_ORDER | RPO_RULE_LIMIT | RPO_RULE_HULLFACE | RPO_RULE_BOXOVERLAP | RPO_RULE_ODEORDER | RPO_RULE_LEVER | RPO_RULE_SPIN;       /* the shipped model (the HIP kernels implement exactly this); rpo_set_rule(0) = round 2's rule */
   e->margin = -1; e->rew_thresh = (real)0.05; e->dense_reward = 0;
   /* envList.py:8-10, 18-22, 73-99: the env's flags and ranges go with its scene (play ids: complex_scene; reach ids:
    * default_scene; pick / push: push_scene); other ids on the same model override the ranges (rpo_set_ranges) */
@@ -1759,6 +1848,26 @@ rpo_env* rpo_create(int kind, unsigned long long seed, int env_index) {
 }
 #ifdef RPO_BULLET_REF
 void rpo_destroy(rpo_env* e) { rpo_ref_free(e); free(e); }
+/* debugging aid (tools/ab_contacts.py): the contact points of mode B's manifolds at the current state, the format of rpo_contacts; the manifolds
+ * are the persistent ones, so this advances them exactly as one substep's collision phase would - call it on a scratch env */
+int rpo_ref_contacts(rpo_env* e, double* out, int max) {
+  rpb_state* st = rpb_get(e);
+  update_transforms(e);
+  rpb_collide(e, st);
+  int n = 0;
+  for (int i = 0; i < st->nman; i++)
+    for (int j = 0; j < st->man[i].n; j++) {
+      const rpb_point* p = &st->man[i].p[j];
+      if (n < max) {
+        double* o = out + 9 * n;
+        o[0] = st->man[i].ca; o[1] = st->man[i].cb;
+        for (int k = 0; k < 3; k++) { o[2 + k] = p->pB[k]; o[5 + k] = p->n[k]; }
+        o[8] = p->dist;
+      }
+      n++;
+    }
+  return n;
+}
 #else
 void rpo_destroy(rpo_env* e) { free(e); }
 #endif
@@ -1895,7 +2004,7 @@ int rpo_box_box(const double* ca, const double* Ra, const double* ha, const doub
   for (int i = 0; i < 3; i++) { a[i] = (real)ca[i]; h1[i] = (real)ha[i]; b[i] = (real)cb[i]; h2[i] = (real)hb[i]; }
   for (int i = 0; i < 9; i++) { A[i] = (real)Ra[i]; Bm[i] = (real)Rb[i]; }
   cpoint pts[4];
-  int n = box_box(a, A, h1, b, Bm, h2, (real)margin, pts);
+  int n = box_box(a, A, h1, b, Bm, h2, (real)margin, 1 /* the shipped rule: RPO_RULE_ODEORDER */, pts);
   for (int i = 0; i < n; i++) {
     for (int k = 0; k < 3; k++) { out[7 * i + k] = pts[i].p[k]; out[7 * i + 3 + k] = pts[i].n[k]; }
     out[7 * i + 6] = pts[i].dist;

@@ -90,6 +90,7 @@ typedef struct DevModel {
   float col_rgb[RP_MAX_COL][3];   /* rendering: colour of the collider's visual shape; col_toggle 1 globe (button), 2 grill (dial) */
   int col_toggle[RP_MAX_COL];
   float col_stiff[RP_MAX_COL], col_damp[RP_MAX_COL];   /* URDF <contact> stiffness / damping of the collider's link, 0 = none */
+  float col_spin[RP_MAX_COL];     /* URDF <contact> spinning_friction of the collider's link (the gripper links: 0.1), 0 = none: torsional friction rows */
   float col_margin[RP_MAX_COL];   /* distance out to which a collider's contact points exist; a pair's margin is the smaller of the two.
                                    * Default: Bullet's relative contact breaking threshold of the collider's object (rp_model.col_thr);
                                    * rp_config.contact_margin replaces it by one value for all */
@@ -206,7 +207,7 @@ static inline void rp_build_dev_model(const rp_model* m, DevModel* d) {
   }
   d->n_target = isP ? 7 : 6;            /* numDofs (environments.py:361, 371) */
   d->rew_thresh = 0.05f; d->dense_reward = 0; d->boxbox_margin = 0.f;
-  for (int c = 0; c < m->n_col; c++) { d->col_margin[c] = (float)m->col_thr[c]; d->col_stiff[c] = (float)m->col_stiffness[c]; d->col_damp[c] = (float)m->col_damping[c];
+  for (int c = 0; c < m->n_col; c++) { d->col_margin[c] = (float)m->col_thr[c]; d->col_stiff[c] = (float)m->col_stiffness[c]; d->col_damp[c] = (float)m->col_damping[c]; d->col_spin[c] = (float)m->col_spin[c];
     d->col_toggle[c] = m->col_toggle[c]; for (int k = 0; k < 3; k++) d->col_rgb[c][k] = (float)m->col_rgb[c][k]; }
   d->floor_z = 1e30f;
   for (int c = 0; c < m->n_col; c++) {

@@ -26,7 +26,8 @@
 #define NVP 28               /* padded row stride (nv <= 27) */
 #define MAXC 21              /* contact points kept per env per substep (shared cap with the oracle): 63 contact rows */
 #define MAXACT 64            /* AABB-overlapping pairs examined per substep (shared cap with the oracle) */
-#define MAXROWC (3 * MAXC)
+#define MAXT 4               /* torsional friction rows kept per env per substep (shared cap with the oracle): one per collider pair in contact whose links carry spinning_friction */
+#define MAXROWC (3 * MAXC + MAXT)
 #define RP_MAX_GROUPS 16      /* env groups (streams) rp_step can cut the envs into */
 #define SORT_KEYS 64          /* load classes for pairing envs in k_solve2: 8 * min(folded slots, 7) + min((side-by-side slots - 1) / 2, 7) */
 #define SORT_REPS 8           /* histogram replicas (env & 7): one hot word would serialise ~4096 atomics at ~90 per us */
@@ -93,6 +94,7 @@ struct __align__(16) EnvLds {
   float vstar[32];
   float conp[MAXC * 3], conn[MAXC * 3], cond[MAXC], conmu[MAXC];
   int cona[MAXC], conb[MAXC], conk[MAXC];     /* colliders of the contact; class: 0 no arm dof, 1 arm only, 2 spanning */
+  int torc[MAXT]; float tors[MAXT];           /* torsional rows: parent contact, coefficient (tors_list) */
   alignas(16) float srow[MAXSMALL * 8];      /* type, dofA, sign/ratio, rhs | dinv, lo, hi, dofB */
   alignas(16) float rowS[MAXROWC * 4];       /* rhs, cfm * dinv (soft normal rows, else 0), mu, parent */
   alignas(16) float rowT[MAXROWC * 4];       /* lo_c, hi_c, off0, off1 */
@@ -136,6 +138,7 @@ struct __align__(16) PrepLds {
   float xR[NB_MAX * 9], xp[NB_MAX * 3];
   float conp[MAXC * 3], conn[MAXC * 3], cond[MAXC], conmu[MAXC];
   int cona[MAXC], conb[MAXC], conk[MAXC];
+  int torc[MAXT]; float tors[MAXT];
   union alignas(16) {                          /* wave 0: collide() */
     float aabb[RP_MAX_COL * 8];
     float npscr[NPSCR_FLOATS];
@@ -703,15 +706,18 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
       if (v2 > bj + K_TIE_EPS) { bj = v2; j = 2; } }
     const V3 Yj = pick3(j, Y0, Y1, Y2);
     const float sj = dot(nref, Yj) > 0.f ? -1.f : 1.f;
-    const int k1 = j == 2 ? 0 : j + 1, k2 = j == 0 ? 2 : j - 1;             /* (j + 1) % 3, (j + 2) % 3 */
+    /* The polygon is walked the way btBoxBoxDetector (ODE's dBoxBox2) walks it (oracle RPO_RULE_ODEORDER): the incident face from its (-, -) corner with its
+     * two axes in increasing order, the reference rectangle's sides in the order -u1, +u1, -u2, +u2 with u1 < u2 - the order of a pair's points is the order
+     * of the solver's rows */
+    const int k1 = j == 0 ? 1 : 0, k2 = j == 2 ? 1 : 2;
     const V3 Yk1 = pick3(k1, Y0, Y1, Y2), Yk2 = pick3(k2, Y0, Y1, Y2);
     const float hYj = pick1(j, hY.x, hY.y, hY.z), hYk1 = pick1(k1, hY.x, hY.y, hY.z), hYk2 = pick1(k2, hY.x, hY.y, hY.z);
     const V3 fc = cY + Yj * (sj * hYj);
     if (face_case && s < 4) {
-      float sg0 = (s == 0 || s == 3) ? 1.f : -1.f, sg1 = s < 2 ? 1.f : -1.f;
+      float sg0 = s < 2 ? -1.f : 1.f, sg1 = (s == 0 || s == 3) ? -1.f : 1.f;
       st3(poly[0][s], fc + Yk1 * (sg0 * hYk1) + Yk2 * (sg1 * hYk2));
     }
-    const int u1 = best_i == 2 ? 0 : best_i + 1, u2 = best_i == 0 ? 2 : best_i - 1;
+    const int u1 = best_i == 0 ? 1 : 0, u2 = best_i == 2 ? 1 : 2;
     const V3 Xu1 = pick3(u1, X0, X1, X2), Xu2 = pick3(u2, X0, X1, X2);
     const float hXu1 = pick1(u1, hX.x, hX.y, hX.z), hXu2 = pick1(u2, hX.x, hX.y, hX.z), hXi = pick1(best_i, hX.x, hX.y, hX.z);
     int n = 4, cur = 0;
@@ -719,7 +725,7 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
     for (int pass = 0; pass < 4; pass++) {
       WSYNC();
       const V3 u = pass < 2 ? Xu1 : Xu2;
-      const float h = pass < 2 ? hXu1 : hXu2, sign = (pass & 1) ? -1.f : 1.f;
+      const float h = pass < 2 ? hXu1 : hXu2, sign = (pass & 1) ? 1.f : -1.f;
       bool k0 = false, kc = false; V3 va = mk3(0, 0, 0), vb = va; float da = 0.f, db = 0.f;
       if (face_case && s < n) {
         va = ld3(poly[cur][s]);
@@ -752,10 +758,48 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
       for (int c = 1; c < cnt; c++) if (kept[c][3] < kept[deepest][3] - K_TIE_EPS) deepest = c;
       const V3 nn = best_kind == 1 ? nref : -nref;
       const int outn = cnt <= 4 ? cnt : 4;
-      if (s < outn) {
-        int src = cnt <= 4 ? s : (deepest + (s * cnt) / 4) % cnt;
-        mine.p = ld3(kept[src]); mine.n = nn; mine.dist = kept[src][3];
+      int src = s;
+      if (cnt > 4) {
+        /* more than four (rare): the detector's cullPoints2, by every lane of the group alike - the deepest first, then for each of the three directions
+         * a quarter turn further around the polygon's centroid (in the reference face's plane) the unused point nearest to it in angle; lane s takes the
+         * s-th pick (same arithmetic as the oracle's box_box) */
+        /* (few registers on purpose: the polygon's plane coordinates and angles go through the clip scratch, free by now) */
+        float (*q2)[3] = poly[0];
+        if (s < cnt) {
+          const V3 r = ld3(kept[s]) + nref * (0.5f * kept[s][3]) - cX;      /* back to the polygon's vertex */
+          q2[s][0] = dot(r, Xu1); q2[s][1] = dot(r, Xu2);
+        }
+        WSYNC();
+        float area = 0.f, cx = 0.f, cy = 0.f;
+#pragma unroll 1
+        for (int v = 0; v < cnt; v++) {
+          const int w = v + 1 == cnt ? 0 : v + 1;
+          const float q = q2[v][0] * q2[w][1] - q2[w][0] * q2[v][1];
+          area += q; cx += q * (q2[v][0] + q2[w][0]); cy += q * (q2[v][1] + q2[w][1]);
+        }
+        area = fabsf(area) > 1e-30f ? 1.f / (3.f * area) : 1e30f;
+        cx *= area; cy *= area;
+        if (s < cnt) q2[s][2] = atan2f(q2[s][1] - cy, q2[s][0] - cx);
+        WSYNC();
+        const float a0 = q2[deepest][2];
+        unsigned avail = ((1u << cnt) - 1u) & ~(1u << deepest);
+        src = deepest;
+#pragma unroll 1
+        for (int jj = 1; jj < 4; jj++) {
+          float want = (float)jj * 1.57079632679489661923f + a0;
+          if (want > 3.14159265358979323846f) want -= 6.28318530717958647692f;
+          float bestd = 1e9f; int pick = deepest;
+#pragma unroll 1
+          for (int v = 0; v < cnt; v++) {
+            float diff = fabsf(q2[v][2] - want);
+            if (diff > 3.14159265358979323846f) diff = 6.28318530717958647692f - diff;
+            if (((avail >> v) & 1u) && diff < bestd) { bestd = diff; pick = v; }
+          }
+          avail &= ~(1u << pick);
+          src = s == jj ? pick : src;
+        }
       }
+      if (s < outn) { mine.p = ld3(kept[src]); mine.n = nn; mine.dist = kept[src][3]; }
       np = outn;
     }
     /* the pair's points go to the compact candidate list, pairs in order; the list ends at CANDMAX points (the oracle's rule) */
@@ -1151,6 +1195,24 @@ __device__ __forceinline__ int build_small_rows(const DevModel* m, LDS& L, int l
   return nr;
 }
 
+/* Torsional friction (URDF spinning_friction of the gripper links; oracle RPO_RULE_SPIN): one row per run of contacts of one collider pair, bounded by
+ * (spin_a mu_b + spin_b mu_a) times the normal impulse of the run's first contact, at most MAXT of them in contact order.  Fills L.torc / L.tors, returns
+ * their number (wave-uniform).  Contacts of one collider pair are neighbours in the contact list (one manifold, one class). */
+template <class LDS>
+__device__ __forceinline__ int tors_list(const DevModel* m, LDS& L, int lane, int ncon) {
+  bool head = false; float spin = 0.f;
+  if (lane < ncon) {
+    const int a = L.cona[lane], b = L.conb[lane];
+    head = lane == 0 || L.cona[lane - 1] != a || L.conb[lane - 1] != b;
+    spin = m->col_spin[a] * m->col_friction[b] + m->col_spin[b] * m->col_friction[a];
+  }
+  const unsigned long long mk = __ballot(head && spin > 0.f);
+  const int t = __popcll(mk & ((1ull << lane) - 1ull));
+  if (head && spin > 0.f && t < MAXT) { L.torc[t] = lane; L.tors[t] = spin; }
+  const int nt = __popcll(mk);
+  return nt < MAXT ? nt : MAXT;
+}
+
 /* Contact rows (normals first, then two friction rows per point, btPlaneSpace1 directions).
  * A row touches at most two bodies, so it is stored compactly: slot0 = 12 entries starting at dof off0, slot1 = 6
  * entries starting at dof off1 (an empty slot has off = 64).  If the arm is involved it takes slot0 (off0 = 0).
@@ -1159,18 +1221,26 @@ __device__ __forceinline__ int build_small_rows(const DevModel* m, LDS& L, int l
 /* The rows of contacts [c0, c0 + nc) are built at local indices [0, 3 nc): normals first, then the friction pairs.  The one-kernel path
  * builds all contacts at once (c0 = 0, nc = ncon: local index = row number); k_prep2 builds PREP_CH contacts at a time and copies each
  * chunk to its rows of the workspace. */
+/* ... and nt torsional rows (tors_list) between the normals and the friction rows, local indices [nc, nc + nt): pure torques about the parent contact's
+ * normal.  The one-kernel path builds them with the contacts; k_prep2 as a chunk of their own (nc = 0). */
 template <class LDS>
-__device__ __forceinline__ void contact_rows(const DevModel* m, LDS& L, int lane, int c0, int nc) {
+__device__ __forceinline__ void contact_rows(const DevModel* m, LDS& L, int lane, int c0, int nc, int nt) {
   const int n = m->n_arm;
-  const int nrows = 3 * nc;
+  const int nrows = 3 * nc + nt;
   V3 O = ld3(L.O);
   for (int r = lane; r < nrows; r += 64) {      /* pass A */
     int ci, dir;
-    if (r < nc) { ci = c0 + r; dir = 0; } else { ci = c0 + ((r - nc) >> 1); dir = 1 + ((r - nc) & 1); }
+    if (r < nc) { ci = c0 + r; dir = 0; }
+    else if (r < nc + nt) { ci = L.torc[r - nc]; dir = 3; }
+    else { ci = c0 + ((r - nc - nt) >> 1); dir = 1 + ((r - nc - nt) & 1); }
     V3 nrm = ld3(&L.conn[3 * ci]);
-    V3 p = ld3(&L.conp[3 * ci]);
+    const V3 pmid = ld3(&L.conp[3 * ci]);
+    /* a contact acts at its point on A on body A and at its point on B on body B (Bullet's positionWorldOnA / B; oracle RPO_RULE_LEVER): the stored point is
+     * their midpoint, they lie cond apart along the normal */
+    const V3 half = nrm * (0.5f * L.cond[ci]);
     V3 d = nrm;
-    if (dir > 0) {            /* btPlaneSpace1 */
+    const bool tors = dir == 3;
+    if (dir == 1 || dir == 2) {            /* btPlaneSpace1 */
       V3 t1, t2;
       if (fabsf(nrm.z) > 0.7071067811865475244f) {
         float a = nrm.y * nrm.y + nrm.z * nrm.z, k = 1.f / sqrtf(a);
@@ -1196,8 +1266,9 @@ __device__ __forceinline__ void contact_rows(const DevModel* m, LDS& L, int lane
       int body = side == 0 ? bodyA : bodyB;
       float sign = side == 0 ? 1.f : -1.f;
       if (body == 0) continue;
+      const V3 p = side == 0 ? pmid + half : pmid - half;
       if (body <= n) {
-        V6 f; f.a = cross(p - O, d); f.l = d;
+        V6 f; f.a = tors ? d : cross(p - O, d); f.l = tors ? mk3(0, 0, 0) : d;
         uint32_t anc = m->arm_anc[body - 1];
 #pragma unroll 1
         for (int k = 0; k < n; k++)
@@ -1211,11 +1282,12 @@ __device__ __forceinline__ void contact_rows(const DevModel* m, LDS& L, int lane
       if (body <= n + m->n_free) {
         int k = body - 1 - n, dd = dof_free(m, k);
         V3 rr = p - ld3(&L.st[ST_FREE + 13 * k]);
-        V3 rxn = cross(rr, d);
+        V3 rxn = tors ? d : cross(rr, d);
         float im = 1.f / m->free_mass[k];
         M3 Ii = ldm3(&L.finv[9 * k]);
         V3 w = mulv(Ii, rxn);
-        float jl[3] = {sign * d.x, sign * d.y, sign * d.z}, ja[3] = {sign * rxn.x, sign * rxn.y, sign * rxn.z};
+        const V3 dl = tors ? mk3(0, 0, 0) : d;
+        float jl[3] = {sign * dl.x, sign * dl.y, sign * dl.z}, ja[3] = {sign * rxn.x, sign * rxn.y, sign * rxn.z};
         float ba[3] = {sign * w.x, sign * w.y, sign * w.z};
         for (int i = 0; i < 3; i++) {
           J[base + i] = jl[i]; B[base + i] = jl[i] * im; J[base + 3 + i] = ja[i]; B[base + 3 + i] = ba[i];
@@ -1227,7 +1299,7 @@ __device__ __forceinline__ void contact_rows(const DevModel* m, LDS& L, int lane
         int k = body - 1 - n - m->n_free, dd = dof_j1(m, k);
         M3 R = ldm3(&L.xR[9 * body]);
         V3 a = mulv(R, ld3(m->j1_axis[k]));
-        float j = m->j1_type[k] == 1 ? sign * dot(d, a) : sign * dot(a, cross(p - ld3(m->j1_pos[k]), d));
+        float j = tors ? (m->j1_type[k] == 1 ? 0.f : sign * dot(a, d)) : (m->j1_type[k] == 1 ? sign * dot(d, a) : sign * dot(a, cross(p - ld3(m->j1_pos[k]), d)));
         float minv = m->j1_minv[k];
         J[base] = j; B[base] = j * minv;
         diag += j * j * minv; relv += j * L.vstar[dd];
@@ -1236,7 +1308,7 @@ __device__ __forceinline__ void contact_rows(const DevModel* m, LDS& L, int lane
     }
     if (has_arm) off0 = 0;
     float* s = &L.rowS[4 * r];
-    s[0] = diag; s[1] = relv; s[2] = dir == 0 ? 0.f : L.conmu[ci]; s[3] = __int_as_float(dir == 0 ? 0 : ci);
+    s[0] = diag; s[1] = relv; s[2] = dir == 0 ? 0.f : (tors ? L.tors[r - nc] : L.conmu[ci]); s[3] = __int_as_float(dir == 0 ? 0 : ci);
     float* t = &L.rowT[4 * r];
     t[0] = __int_as_float(has_arm ? 1 : 0); t[1] = dir == 0 ? 1e10f : 0.f; t[2] = __int_as_float(off0); t[3] = __int_as_float(off1);
   }
@@ -1307,9 +1379,9 @@ __device__ __forceinline__ float pgs_update(float delta, float lam, float lo, fl
 }
 
 template <class LDS>
-__device__ float solve_rows(const DevModel* m, LDS& L, int lane, int nsmall_, int ncon_) {
+__device__ float solve_rows(const DevModel* m, LDS& L, int lane, int nsmall_, int ncon_, int nt_) {
   const int n = m->n_arm;
-  const int nsmall = uni(nsmall_), nrc = uni(3 * ncon_);
+  const int nsmall = uni(nsmall_), nrc = uni(3 * ncon_ + nt_);      /* contact rows: normals, torsional rows, friction pairs (contact_rows) */
   float dv = 0.f;
   float lamS = 0.f, lamC0 = 0.f, lamC1 = 0.f;
   for (int it = 0; it < K_NITER; it++) {
@@ -1364,7 +1436,7 @@ __device__ float solve_rows(const DevModel* m, LDS& L, int lane, int nsmall_, in
         float prod = jl * dv;
         float jdv = wave_sum32(prod), lnew;
         float d = pgs_update(__fmaf_rn(-lam, cfmr, rhs) - jdv, lam, lo_c - lim, hi_c + lim, lnew);
-        if (r >= uni(ncon_) && !(tot > 0.f)) { d = 0.f; lnew = lam; }      /* a friction row is skipped while its normal impulse is not positive */
+        if (r >= uni(ncon_) && !(tot > 0.f)) { d = 0.f; lnew = lam; }      /* a friction (or torsional) row is skipped while its normal impulse is not positive */
         float sel = lane == (r & 63) ? lnew : lamv;
         lamC0 = r < 64 ? sel : lamC0;
         lamC1 = r < 64 ? lamC1 : sel;
@@ -1387,9 +1459,11 @@ __device__ void substep(const DevModel* m, EnvLds& L, int lane) {
   arm_dynamics(m, L, lane);
   unconstrained_velocities(m, L, lane);
   int nsmall = build_small_rows(m, L, lane);
-  contact_rows(m, L, lane, 0, ncon);
+  const int nt = tors_list(m, L, lane, ncon);
+  WSYNC();
+  contact_rows(m, L, lane, 0, ncon, nt);
   __syncthreads();
-  float dv = solve_rows<EnvLds>(m, L, lane, nsmall, ncon);
+  float dv = solve_rows<EnvLds>(m, L, lane, nsmall, ncon, nt);
   __syncthreads();
   /* apply and integrate (semi-implicit Euler) */
   const int dd = lane_dof(m, lane);
@@ -1515,7 +1589,7 @@ __device__ __forceinline__ void action_target(int at, const float* a8, V3 cp, Q4
 }
 
 template <int NC>
-__device__ float ik_coop(const DevModel* m, V3 tpos, Q4 tq, float qj, int max_iter, int l16, bool live, bool* capped = nullptr) {
+__device__ float ik_coop(const DevModel* m, V3 tpos, Q4 tq, float qj, int max_iter, int l16, bool live, bool* capped = nullptr, bool* marginal = nullptr) {
   const bool isj = l16 < NC;
   const int jj = isj ? l16 : 0;
   const M3 R0 = ldm3(m->arm_jrot[jj]);
@@ -1529,7 +1603,12 @@ __device__ float ik_coop(const DevModel* m, V3 tpos, Q4 tq, float qj, int max_it
     V3 org, axw, pos; M3 Rs;
     chain_fk_coop<NC>(R0, p0, ax, rev, base, sp, sr, qj, l16, org, axw, pos, Rs);
     const V3 ep = tpos - pos;
-    done = done || (it > 0 && norm(ep) < K_IK_RES);
+    const float res = norm(ep);
+    /* a stopping test decided within 0.5 % of the threshold (fp32 rounding of a residual of 1e-4 on positions of order 1: ~0.1 %): another evaluation order
+     * of the same arithmetic (the CPU oracle's) may stop an iteration earlier or later and end ~5e-5 rad elsewhere (status bit 16 of the step; the parity
+     * tests read it) */
+    if (marginal && !done && it > 0 && res > 0.995f * K_IK_RES && res < 1.005f * K_IK_RES) *marginal = true;
+    done = done || (it > 0 && res < K_IK_RES);
     if (__ballot(!done) == 0ull) break;                        /* every env of the wave has converged */
     /* pose error, by every lane alike */
     Q4 qc = m3_to_quat(Rs);
@@ -1596,11 +1675,11 @@ __device__ float ik_coop(const DevModel* m, V3 tpos, Q4 tq, float qj, int max_it
 }
 
 /* replicated-value front end: every lane passes the same start vector and gets the same solution back */
-__device__ __forceinline__ ChainQ ik_solve(const DevModel* m, V3 tpos, Q4 tq, ChainQ q, int max_iter, int l16, bool* capped = nullptr) {
+__device__ __forceinline__ ChainQ ik_solve(const DevModel* m, V3 tpos, Q4 tq, ChainQ q, int max_iter, int l16, bool* capped = nullptr, bool* marginal = nullptr) {
   float qj = 0.f;
 #pragma unroll
   for (int j = 0; j < 7; j++) qj = l16 == j ? q.q[j] : qj;
-  qj = m->ee_chain == 6 ? ik_coop<6>(m, tpos, tq, qj, max_iter, l16, true, capped) : ik_coop<7>(m, tpos, tq, qj, max_iter, l16, true, capped);
+  qj = m->ee_chain == 6 ? ik_coop<6>(m, tpos, tq, qj, max_iter, l16, true, capped, marginal) : ik_coop<7>(m, tpos, tq, qj, max_iter, l16, true, capped, marginal);
   ChainQ r;
   static_for<0, 7>([&](auto jc) { constexpr int j = decltype(jc)::v; r.q[j] = bcast16<j>(qj); });
   return r;
@@ -1610,7 +1689,7 @@ __device__ __forceinline__ ChainQ ik_solve(const DevModel* m, V3 tpos, Q4 tq, Ch
  * lane 0 writes the motor commands into the state record.  Returns the target poses. */
 __device__ ChainQ perform_action(const DevModel* m, EnvLds& L, int lane, const float* a8) {
   const int nd = m->n_target, at = m->action_type, l16 = lane & 15;
-  bool ik_capped = false;
+  bool ik_capped = false, ik_marginal = false;
   ChainQ cur;
 #pragma unroll
   for (int j = 0; j < 7; j++) cur.q[j] = j < m->ee_chain ? L.st[ST_Q + j] : 0.f;
@@ -1628,10 +1707,10 @@ __device__ ChainQ perform_action(const DevModel* m, EnvLds& L, int lane, const f
     }
     V3 tpos; Q4 tq;
     action_target(at, a8, cp, cq, tpos, tq);
-    if (m->arm_type == RP_ARM_PANDA) sol = ik_solve(m, tpos, tq, cur, 200, l16, &ik_capped);
+    if (m->arm_type == RP_ARM_PANDA) sol = ik_solve(m, tpos, tq, cur, 200, l16, &ik_capped, &ik_marginal);
     else {   /* InverseKinematicsSolver.calc_angles: 4 chained default IK solves from the measured joints */
       sol = cur;
-      for (int rep = 0; rep < 4; rep++) sol = ik_solve(m, tpos, tq, sol, 20, l16, &ik_capped);
+      for (int rep = 0; rep < 4; rep++) sol = ik_solve(m, tpos, tq, sol, 20, l16, &ik_capped, &ik_marginal);
     }
   }
   ChainQ tp;
@@ -1646,7 +1725,7 @@ __device__ ChainQ perform_action(const DevModel* m, EnvLds& L, int lane, const f
   }
   __syncthreads();
   if (lane == 0) {
-    L.st[ST_STATUS] = __int_as_float(ik_capped ? 8 : 0);
+    L.st[ST_STATUS] = __int_as_float((ik_capped ? 8 : 0) | (ik_marginal ? 16 : 0));
     for (int j = 0; j < nd; j++) { L.st[ST_MMODE + j] = 1.f; L.st[ST_MTARGET + j] = tp.q[j]; L.st[ST_MMAXIMP + j] = 240.f * K_DT; }
     float g = a8[m->n_action - 1];
     if (m->arm_type == RP_ARM_PANDA) {
@@ -1863,7 +1942,7 @@ __device__ void calc_state(const DevModel* m, EnvLds& L, int lane) {
     bool bad = false, fell = false;
     for (int k = 0; k < ST_MMODE; k++) if (!isfinite(L.st[k])) bad = true;
     for (int b = 0; b < m->num_objects; b++) if (L.st[ST_FREE + 13 * b + 2] < m->floor_z) fell = true;   /* below the lowest static collider */
-    o[O_STATUS] = __int_as_float((bad ? 1 : 0) | (fell ? 2 : 0) | (__float_as_int(L.st[ST_STATUS]) & 8));
+    o[O_STATUS] = __int_as_float((bad ? 1 : 0) | (fell ? 2 : 0) | (__float_as_int(L.st[ST_STATUS]) & 24));
   }
   __syncthreads();
 }
@@ -2222,7 +2301,7 @@ __device__ __forceinline__ void action_body(const DevModel* __restrict__ m, floa
   const int nd = m->n_target, nc = m->ee_chain, at = m->action_type;
   const float q0 = st[ST_Q + (l16 < RP_MAX_ARM ? l16 : 0)];            /* measured joint value of dof l16 */
   float qj = l16 < nc ? q0 : 0.f;
-  bool ik_capped = false;
+  bool ik_capped = false, ik_marginal = false;
   if (at == RP_ACT_ABS_JOINTS || at == RP_ACT_REL_JOINTS) {
     float aj = 0.f;
 #pragma unroll
@@ -2233,9 +2312,9 @@ __device__ __forceinline__ void action_body(const DevModel* __restrict__ m, floa
     if (at == RP_ACT_REL_RPY || at == RP_ACT_REL_QUAT) ee_pose_coop(m, qj, l16, cp, cq);
     V3 tpos; Q4 tq;
     action_target(at, a8, cp, cq, tpos, tq);
-    if (m->arm_type == RP_ARM_PANDA) qj = ik_coop<7>(m, tpos, tq, qj, 200, l16, live, &ik_capped);
-    else if (nc == 6) { for (int rep = 0; rep < 4; rep++) qj = ik_coop<6>(m, tpos, tq, qj, 20, l16, live, &ik_capped); }
-    else { for (int rep = 0; rep < 4; rep++) qj = ik_coop<7>(m, tpos, tq, qj, 20, l16, live, &ik_capped); }
+    if (m->arm_type == RP_ARM_PANDA) qj = ik_coop<7>(m, tpos, tq, qj, 200, l16, live, &ik_capped, &ik_marginal);
+    else if (nc == 6) { for (int rep = 0; rep < 4; rep++) qj = ik_coop<6>(m, tpos, tq, qj, 20, l16, live, &ik_capped, &ik_marginal); }
+    else { for (int rep = 0; rep < 4; rep++) qj = ik_coop<7>(m, tpos, tq, qj, 20, l16, live, &ik_capped, &ik_marginal); }
   }
   if (!live) return;
   if (l16 < nd) {
@@ -2245,7 +2324,7 @@ __device__ __forceinline__ void action_body(const DevModel* __restrict__ m, floa
     if (target_poses) target_poses[(size_t)env * nd + l16] = t;
   }
   if (l16 == 0) {
-    st[ST_STATUS] = __int_as_float(ik_capped ? 8 : 0);      /* the last IK call of this step ran out of iterations: k_calc_state passes it on (status bit 8) */
+    st[ST_STATUS] = __int_as_float((ik_capped ? 8 : 0) | (ik_marginal ? 16 : 0));      /* the last IK call of this step ran out of iterations / a stopping test was marginal: k_calc_state passes them on (status bits 8, 16) */
     float g = a8[m->n_action - 1];
     if (m->arm_type == RP_ARM_PANDA) {
       float amt = 0.04f - g / 25.f;
@@ -2415,7 +2494,7 @@ __device__ __forceinline__ void prep2_body(const DevModel* __restrict__ m, const
     L.roff[lane] = 0;
     for (int c0 = 0; c0 < ncon; c0 += PREP_CH) {
       const int nc = min(PREP_CH, ncon - c0);
-      contact_rows(m, L, lane, c0, nc);
+      contact_rows(m, L, lane, c0, nc, 0);
       WSYNC();
       for (int e = lane; e < 3 * nc * ROWW; e += 64) {
         const int lr = e / ROWW, k = e - lr * ROWW;
@@ -2444,12 +2523,31 @@ __device__ __forceinline__ void prep2_body(const DevModel* __restrict__ m, const
     else if (cls == 1) L.slot[21 + __popcll(mA & lower)] = lane;   /* s-th contact of the first half (DPP row 0) */
     else if (cls == 2) L.slot[42 + __popcll(mC & lower)] = lane;   /* j-th contact that touches both */
     WSYNC();
+    /* torsional rows (tors_list): a chunk of their own, stored behind the contact rows (compact rows 3 ncon + t); k_solve2 finds the parent's normal impulse
+     * through the parent's class and rank inside it (= its slot), packed beside its index */
+    const int nt = tors_list(m, L, lane, ncon);
+    WSYNC();
+    if (nt > 0) {
+      contact_rows(m, L, lane, 0, 0, nt);
+      WSYNC();
+      for (int e = lane; e < nt * ROWW; e += 64) { w[W3_J + 3 * ncon * ROWW + e] = L.J[e]; w[W3_B + 3 * ncon * ROWW + e] = L.B[e]; }
+      if (lane < 4 * nt) {
+        const int t = lane >> 2, k = lane & 3;
+        float v = L.rowS[lane];
+        if (k == 3) {
+          const int c = L.torc[t], kc = L.conk[c];
+          const unsigned long long mk = kc == 1 ? mA : (kc == 2 ? mC : mB);
+          v = __int_as_float(c | (kc << 8) | (__popcll(mk & ((1ull << c) - 1ull)) << 12));
+        }
+        w[W3_ROWS + 4 * (3 * ncon + t) + k] = v; w[W3_ROWT + 4 * (3 * ncon + t) + k] = L.rowT[lane];
+      }
+    }
     if (lane == 0) {
       int nj = m->n_j1 < NBJ ? m->n_j1 : NBJ;
       w[W3_HDR] = __int_as_float((int)L.amask[0]); w[W3_HDR + 1] = __int_as_float((int)L.amask[1]);
       w[W3_HDR + 2] = __int_as_float(nj); w[W3_HDR + 3] = __int_as_float(ncon);
       w[W3_HDR + 4] = __int_as_float(__popcll(mA)); w[W3_HDR + 5] = __int_as_float(__popcll(mB));
-      w[W3_HDR + 6] = __int_as_float(L.hdr[1]); w[W3_HDR + 7] = __int_as_float(__popcll(mC));
+      w[W3_HDR + 6] = __int_as_float(L.hdr[1] | (nt << 8)); w[W3_HDR + 7] = __int_as_float(__popcll(mC));      /* gear present | torsional rows << 8 */
     }
     if (lane < 32) w[W3_MU + lane] = lane < ncon ? L.conmu[lane] : 0.f;
     copy_out(w + W3_ROFF, (const float*)L.roff, 64, lane);
@@ -2642,12 +2740,13 @@ __device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, floa
   const int my_mL = valid ? __float_as_int(h0.x) : 0, my_mU = valid ? __float_as_int(h0.y) : 0;
   const int my_nj = valid ? __float_as_int(h0.z) : 0, my_nc = valid ? __float_as_int(h0.w) : 0;
   const int my_nA = valid ? __float_as_int(h1.x) : 0, my_nB = valid ? __float_as_int(h1.y) : 0;
-  const int my_gr = valid ? __float_as_int(h1.z) : 0, my_nC = valid ? __float_as_int(h1.w) : 0;
+  const int my_gr = valid ? (__float_as_int(h1.z) & 255) : 0, my_nC = valid ? __float_as_int(h1.w) : 0;
+  const int my_nt = valid ? (__float_as_int(h1.z) >> 8) : 0;       /* torsional rows */
 #define WAVE_OR(x) (__builtin_amdgcn_readlane(x, 0) | __builtin_amdgcn_readlane(x, 32))
 #define WAVE_MAX(x) max(__builtin_amdgcn_readlane(x, 0), __builtin_amdgcn_readlane(x, 32))
   const int maskL = WAVE_OR(my_mL), maskU = WAVE_OR(my_mU), gear = WAVE_OR(my_gr);
   const int my_nS = max(my_nA, my_nB);
-  const int nS_w = WAVE_MAX(my_nS), nC_w = WAVE_MAX(my_nC), nc_w = WAVE_MAX(my_nc);
+  const int nS_w = WAVE_MAX(my_nS), nC_w = WAVE_MAX(my_nC), nc_w = WAVE_MAX(my_nc), nT = WAVE_MAX(my_nt);
   /* side-by-side slots for both envs of the wave fit the 21 row registers (practically always); otherwise every contact
    * takes its own slot and folds (nS = 0): same code, same results */
 #if defined(RP_FORCE_PATH)    /* timing ablation: 0 = never side by side */
@@ -2775,6 +2874,32 @@ __device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, floa
 #pragma unroll
   for (int r = 0; r < 2; r++) { PN[r].lam = 0.f; PF[0][r].lam = 0.f; PF[1][r].lam = 0.f; }
   X0.lam = 0.f; PL.lam = 0.f; PU.lam = 0.f;
+  /* torsional rows (rare: a gripper link in contact): row t at label t of plane PT, in BOTH DPP rows (they fold like the spanning contacts; for a row that
+   * touches the arm only the other row's sum is an exact +0), J / B straight from the workspace (compact rows 3 ncon + t).  Its bounds follow the normal
+   * impulse of its parent contact: that contact's slot - from its class and rank, the way contact_of fills the slots - names the lane and the register of
+   * the normals' planes, DPP row 0 of this half */
+  float JT[MAXT], BT[MAXT], spinT = 0.f; Plane PT; int tsrc = lane; bool treg = false;
+  PT.rhs = PT.lo = PT.hi = PT.lam = PT.dacc = PT.loP = PT.hiP = 0.f;
+#pragma unroll
+  for (int t = 0; t < MAXT; t++) { JT[t] = 0.f; BT[t] = 0.f; }
+  if (nT > 0) {
+    const bool on = l16 < my_nt;
+    const int rt = 3 * my_nc + (on ? l16 : 0);
+    PT.rhs = ldz(&w[W3_ROWS + 4 * rt], on);
+    spinT = ldz(&w[W3_ROWS + 4 * rt + 2], on);
+    const int pk = on ? __float_as_int(w[W3_ROWS + 4 * rt + 3]) : 0;
+    const int pslot = par ? (((pk >> 8) & 3) == 1 ? (pk >> 12) : MAXC - 1 - (pk >> 12)) : MAXC - 1 - (pk & 255);
+    tsrc = (lane & 32) + (pslot & 15); treg = pslot >= 16;
+#pragma unroll
+    for (int t = 0; t < MAXT; t++) {
+      const bool used = t < my_nt;
+      const int r = 3 * my_nc + (used ? t : 0);
+      const int i1 = dd - (used ? __float_as_int(w[W3_ROWT + 4 * r + 3]) : 64), i0 = dd - (used ? __float_as_int(w[W3_ROWT + 4 * r + 2]) : 64);
+      const int idx = (unsigned)i1 < 6u ? 12 + i1 : ((unsigned)i0 < 12u ? i0 : -1);
+      const bool ok = used && dd >= 0 && idx >= 0;
+      JT[t] = ldz(&w[W3_J + ROWW * r + (ok ? idx : 0)], ok); BT[t] = ldz(&w[W3_B + ROWW * r + (ok ? idx : 0)], ok);
+    }
+  }
   WSYNC();                          /* rows are in registers: the staging area becomes the state records */
   {
     float* st = L.st[half];
@@ -2806,7 +2931,9 @@ __device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, floa
 #else
     int nS_it = nS, nC_it = nC, mL_it = maskL, mU_it = maskU, gr_it = gear;
 #endif
-    asm volatile("" : "+s"(nS_it), "+s"(nC_it), "+s"(mL_it), "+s"(mU_it), "+s"(gr_it));
+    int nT_it = nT;
+    asm volatile("" : "+s"(nS_it), "+s"(nC_it), "+s"(mL_it), "+s"(mU_it), "+s"(gr_it), "+s"(nT_it));
+    nT_it = __builtin_amdgcn_readfirstlane(nT_it);
     nS_it = __builtin_amdgcn_readfirstlane(nS_it); nC_it = __builtin_amdgcn_readfirstlane(nC_it);
     mL_it = __builtin_amdgcn_readfirstlane(mL_it); mU_it = __builtin_amdgcn_readfirstlane(mU_it);
     gr_it = __builtin_amdgcn_readfirstlane(gr_it);
@@ -2851,6 +2978,17 @@ __device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, floa
 #undef NRM_C
   nrm_done:
     plane_end(PN[0]); plane_end(PN[1]);
+    if (nT_it > 0) {                                           /* torsional rows: after the normals, before the friction rows (Bullet's order) */
+      const float l0 = __shfl(PN[0].lam, tsrc), l1 = __shfl(PN[1].lam, tsrc);
+      const float lp = treg ? l1 : l0;
+      fplane_begin(PT, spinT * lp, lp);
+      asm volatile("s_nop 1" : "+v"(PT.loP), "+v"(PT.hiP));
+      generic_row<0, true>(JT[0], BT[0], dv, PT, l16, PT.rhs);
+      if (nT_it > 1) generic_row<1, true>(JT[1], BT[1], dv, PT, l16, PT.rhs);
+      if (nT_it > 2) generic_row<2, true>(JT[2], BT[2], dv, PT, l16, PT.rhs);
+      if (nT_it > 3) generic_row<3, true>(JT[3], BT[3], dv, PT, l16, PT.rhs);
+      plane_end(PT);
+    }
     if (nS_it + nC_it > 0) {                                   /* frictions, slot by slot: bounds -+ mu * (normal impulse) */
       fplane_begin(PF[0][0], muN[0] * PN[0].lam, PN[0].lam); fplane_begin(PF[1][0], muN[0] * PN[0].lam, PN[0].lam);
       fplane_begin(PF[0][1], muN[1] * PN[1].lam, PN[1].lam); fplane_begin(PF[1][1], muN[1] * PN[1].lam, PN[1].lam);
@@ -2955,12 +3093,13 @@ __device__ __forceinline__ void solve4_body(const DevModel* __restrict__ m, floa
   const int my_mL = valid ? __float_as_int(h0.x) : 0, my_mU = valid ? __float_as_int(h0.y) : 0;
   const int my_nj = valid ? __float_as_int(h0.z) : 0, my_nc = valid ? __float_as_int(h0.w) : 0;
   const int my_nA = valid ? __float_as_int(h1.x) : 0, my_nB = valid ? __float_as_int(h1.y) : 0;
-  const int my_gr = valid ? __float_as_int(h1.z) : 0;
+  const int my_gr = valid ? (__float_as_int(h1.z) & 255) : 0;
+  const int my_nt = (T == 0 && valid) ? (__float_as_int(h1.z) >> 8) : 0;       /* torsional rows: all in the row-0 stream (their parents are the arm's contacts) */
 #define W4_OR(x) (__builtin_amdgcn_readlane(x, 0) | __builtin_amdgcn_readlane(x, 16) | __builtin_amdgcn_readlane(x, 32) | __builtin_amdgcn_readlane(x, 48))
 #define W4_MAX(x) max(max(__builtin_amdgcn_readlane(x, 0), __builtin_amdgcn_readlane(x, 16)), max(__builtin_amdgcn_readlane(x, 32), __builtin_amdgcn_readlane(x, 48)))
   const int maskL = T == 0 ? W4_OR(my_mL) : 0, maskU = T == 0 ? W4_OR(my_mU) : 0, gear = T == 0 ? W4_OR(my_gr) : 0;
   const int my_ns = T == 0 ? my_nA : my_nB;                  /* this stream's contacts */
-  const int nS = W4_MAX(my_ns), nJ = T == 0 ? 0 : W4_MAX(my_nj);
+  const int nS = W4_MAX(my_ns), nJ = T == 0 ? 0 : W4_MAX(my_nj), nT = T == 0 ? W4_MAX(my_nt) : 0;
   const int dd = lane_dof(m, T == 0 ? l16 : 16 + l16);      /* velocity component owned by this lane, -1 if none */
   /* the four state records: one DPP row each */
   float* st = stl + RP_REC_FLOATS * g;
@@ -3045,6 +3184,28 @@ __device__ __forceinline__ void solve4_body(const DevModel* __restrict__ m, floa
     JF[1][s] = ldz(&w[W3_J + (ok ? rf + ROWW : 0)], ok); BF[1][s] = ldz(&w[W3_B + (ok ? rf + ROWW : 0)], ok);
   }
   PN.lam = 0.f; PF[0].lam = 0.f; PF[1].lam = 0.f; X0.lam = 0.f; PL.lam = 0.f; PU.lam = 0.f;
+  /* torsional rows (solve2_body explains them): here the parent is this stream's contact number `rank`, at lane `rank` of the normals' plane */
+  float JT[MAXT], BT[MAXT], spinT = 0.f; Plane PT; int tsrc = lane;
+  PT.rhs = PT.lo = PT.hi = PT.lam = PT.dacc = PT.loP = PT.hiP = 0.f;
+#pragma unroll
+  for (int t = 0; t < MAXT; t++) { JT[t] = 0.f; BT[t] = 0.f; }
+  if (T == 0 && nT > 0) {
+    const bool on = l16 < my_nt;
+    const int rt = 3 * my_nc + (on ? l16 : 0);
+    PT.rhs = ldz(&w[W3_ROWS + 4 * rt], on);
+    spinT = ldz(&w[W3_ROWS + 4 * rt + 2], on);
+    const int pk = on ? __float_as_int(w[W3_ROWS + 4 * rt + 3]) : 0;
+    tsrc = (lane & 48) + ((pk >> 12) & 15);
+#pragma unroll
+    for (int t = 0; t < MAXT; t++) {
+      const bool used = t < my_nt;
+      const int r = 3 * my_nc + (used ? t : 0);
+      const int i1 = dd - (used ? __float_as_int(w[W3_ROWT + 4 * r + 3]) : 64), i0 = dd - (used ? __float_as_int(w[W3_ROWT + 4 * r + 2]) : 64);
+      const int idx = (unsigned)i1 < 6u ? 12 + i1 : ((unsigned)i0 < 12u ? i0 : -1);
+      const bool ok = used && dd >= 0 && idx >= 0;
+      JT[t] = ldz(&w[W3_J + ROWW * r + (ok ? idx : 0)], ok); BT[t] = ldz(&w[W3_B + ROWW * r + (ok ? idx : 0)], ok);
+    }
+  }
   __builtin_amdgcn_s_waitcnt(0x0F70);    /* vmcnt(0): all row registers have landed before the sweep loop */
   /* counting sort by load class for the next substep's pairing: one atomic per env, from the row-1 wave */
   int sort_pos = 0, sort_bin = 0;
@@ -3064,8 +3225,8 @@ __device__ __forceinline__ void solve4_body(const DevModel* __restrict__ m, floa
   for (int it = 0; it < K_NITER; it++) {
     /* in-loop copies of the guards, re-read every sweep so that they stay s_cmp + s_cbranch */
     int nS_it = __builtin_amdgcn_readfirstlane(nS), mL_it = __builtin_amdgcn_readfirstlane(maskL), mU_it = __builtin_amdgcn_readfirstlane(maskU);
-    int gr_it = __builtin_amdgcn_readfirstlane(gear), nJ_it = __builtin_amdgcn_readfirstlane(nJ);
-    asm volatile("" : "+s"(nS_it), "+s"(mL_it), "+s"(mU_it), "+s"(gr_it), "+s"(nJ_it));
+    int gr_it = __builtin_amdgcn_readfirstlane(gear), nJ_it = __builtin_amdgcn_readfirstlane(nJ), nT_it = __builtin_amdgcn_readfirstlane(nT);
+    asm volatile("" : "+s"(nS_it), "+s"(mL_it), "+s"(mU_it), "+s"(gr_it), "+s"(nJ_it), "+s"(nT_it));
     plane_begin(X0); nplane_begin(PN);
     if (T == 0) { plane_begin(PL); plane_begin(PU); }
     asm volatile("s_nop 1" : "+v"(X0.loP), "+v"(X0.hiP), "+v"(PL.loP), "+v"(PL.hiP), "+v"(PU.loP), "+v"(PU.hiP), "+v"(PN.loP), "+v"(PN.hiP), "+v"(PN.rhsE));
@@ -3099,6 +3260,16 @@ __device__ __forceinline__ void solve4_body(const DevModel* __restrict__ m, floa
 #undef NRM4
   nrm_done:
     plane_end(PN);
+    if (T == 0 && nT_it > 0) {
+      const float lp = __shfl(PN.lam, tsrc);
+      fplane_begin(PT, spinT * lp, lp);
+      asm volatile("s_nop 1" : "+v"(PT.loP), "+v"(PT.hiP));
+      generic_row<0, false>(JT[0], BT[0], dv, PT, l16, PT.rhs);
+      if (nT_it > 1) generic_row<1, false>(JT[1], BT[1], dv, PT, l16, PT.rhs);
+      if (nT_it > 2) generic_row<2, false>(JT[2], BT[2], dv, PT, l16, PT.rhs);
+      if (nT_it > 3) generic_row<3, false>(JT[3], BT[3], dv, PT, l16, PT.rhs);
+      plane_end(PT);
+    }
     if (nS_it > 0) {
       fplane_begin(PF[0], muN * PN.lam, PN.lam); fplane_begin(PF[1], muN * PN.lam, PN.lam);
       asm volatile("s_nop 1" : "+v"(PF[0].loP), "+v"(PF[0].hiP), "+v"(PF[1].loP), "+v"(PF[1].hiP));
@@ -3288,9 +3459,11 @@ __global__ void __launch_bounds__(64) k_debug_substep(const DevModel* __restrict
     for (int i = 0; i < n; i++) dbg[512 + i] = L.tau[i];
   }
   int nsmall = build_small_rows(m, L, lane);
-  contact_rows(m, L, lane, 0, ncon);
+  const int nt = tors_list(m, L, lane, ncon);
+  WSYNC();
+  contact_rows(m, L, lane, 0, ncon, nt);
   __syncthreads();
-  float dv = solve_rows(m, L, lane, nsmall, ncon);
+  float dv = solve_rows(m, L, lane, nsmall, ncon, nt);
   if (env == dbg_env) {
     if (lane == 0) { dbg[1] = (float)nsmall; }
     int dd = lane_dof(m, lane);

@@ -81,6 +81,7 @@ typedef struct rp_model {
   /* URDF <contact> stiffness / damping of the link the collider belongs to (0 = absent): Bullet turns them into the contact row's
    * cfm and erp (BT_CONTACT_FLAG_CONTACT_STIFFNESS_DAMPING, btMultiBodyConstraintSolver::setupMultiBodyContactConstraint) */
   double col_stiffness[RP_MAX_COL], col_damping[RP_MAX_COL];
+  double col_spin[RP_MAX_COL];      /* URDF <contact> spinning_friction of the link (0 = absent): torsional friction of its contacts */
   /* rendering (environments.py:841-845 img): colour of the visual shape the collider stands for (scenes.py rgbaColor, URDF materials);
    * col_toggle 1 = the globe recoloured by the button, 2 = the grill recoloured by the dial (updateToggles, environments.py:469-483) */
   double col_rgb[RP_MAX_COL][3];

@@ -80,7 +80,7 @@ def test_box_box_detector_against_the_fast_models_sat(lib):
     normal, same deepest penetration, every point inside both boxes' slabs along the normal"""
     la = oracle.load()
     rng = np.random.default_rng(1)
-    hits = 0
+    hits = ordered = 0
     for _ in range(1500):
         b = random_boxes(rng)
         nrm, out, outA = np.zeros(3), np.zeros(16), np.zeros(28)
@@ -99,7 +99,15 @@ def test_box_box_detector_against_the_fast_models_sat(lib):
             assert abs(d - dA) < 0.06 * max(d, dA) + 1e-5
         else:
             assert nrm @ nA > 0.999
-    assert hits > 200
+            # ... and under RPO_RULE_ODEORDER the fast model emits a face contact's points in the detector's ORDER (the order of the solver's rows):
+            # same count and same depths (so nothing was thinned differently) -> the same points, one by one (the fast model's point is the midpoint,
+            # the detector's lies on B: half a depth apart along the normal)
+            if k == kA and np.allclose(np.sort(out[3::4][:k]), np.sort(-outA[6::7][:kA]), atol=1e-9):
+                for i in range(k):
+                    pB = outA[7 * i:7 * i + 3] - 0.5 * outA[7 * i + 6] * nA
+                    assert np.abs(pB - out[4 * i:4 * i + 3]).max() < 1e-8, (i, k)
+                    ordered += 1
+    assert hits > 200 and ordered > 150
 
 
 def test_hull_and_sphere_colliders_distance(lib):

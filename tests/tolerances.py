@@ -39,7 +39,11 @@ class Followers:
     link of 1e-4 kg m^2 on a 20 kg arm), and two fp32 evaluation orders of ONE substep from the SAME state differ by up to 1e-3 relative in
     those links' velocities (tools/gpu_bisect3.py: device vs fp32 CPU oracle 4e-2 rad/s, device vs fp64 CPU oracle 4e-3 rad/s on 10 rad/s),
     which reaches the arm's own joints at the 1e-5 level within a step.  An fp32 CPU run shares the fp64 oracle's evaluation order and
-    underestimates that; the nudged runs stand in for it."""
+    underestimates that; the nudged runs stand in for it.
+
+    How many: an event's outcome is one draw per run.  The 200-step tests follow every env with `extra` = 6 nudged runs (+-1e-5, +-2e-5, +-3e-5): with two,
+    2 of 64 envs had an event (the gripper striking the block at 4 mm per substep; an IK stopping one iteration apart) that the
+    device drew and none of the three CPU runs did."""
     NUDGE = 1e-5
 
 
@@ -75,6 +79,15 @@ class Followers:
                 o.set_state(s)
                 o.lib.rpo_set_goal(o.h, g.ctypes.data_as(C.POINTER(C.c_double)))
         self.nudge()
+
+    def start_from_state(self, s):
+        """every follower resets on its own and then takes the state vector `s` (OracleEnv.get_state layout); returns (fp32 obs, fp64 obs) of the resets"""
+        res = []
+        for o in self.all():
+            res.append(o.reset())
+            o.set_state(s)
+        self.nudge()
+        return res[1], res[0]
 
     def nudge(self):
         for k, o in enumerate(self.more):

@@ -621,6 +621,7 @@ def emit_header(models, path):
         put('col_toggle', [c['toggle'] for c in C], 'int')
         put('col_stiffness', [float(c.get('contact', {}).get('stiffness', 0.0)) for c in C])
         put('col_damping', [float(c.get('contact', {}).get('damping', 0.0)) for c in C])
+        put('col_spin', [float(c.get('contact', {}).get('spinning_friction', 0.0)) for c in C])
         put('pair', M['pair'], 'unsigned char')
         out.append('}\n\n')
     out.append('#endif\n')
