@@ -213,7 +213,7 @@ def main():
         for k in range(args.warmup):
             env.step(acts_a[k])
         for k in range(pre):                        # the same floor for this distribution (other actions, other contact sets)
-            env.step(acts_a[args.warmup + k])
+            env.step(acts_a[args.warmup + k % args.steps])
         t_a, info_a = timed_region(env, acts_a, args.warmup, args.steps)
         extras['distribution_A'] = {'value': n * args.steps / t_a, 'ms_per_step': 1e3 * t_a / args.steps,
                                     'what': 'a ~ U(action_space.low, action_space.high) = U(-6, 6)^6 x U(-1, 1), resampled every step (the '

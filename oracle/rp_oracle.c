@@ -104,7 +104,7 @@ struct rpo_env {
   real finv[RP_MAX_FREE][9];        /* world inverse inertia of free bodies */
   xform xc[RP_MAX_COL]; real aabb_lo[RP_MAX_COL][3], aabb_hi[RP_MAX_COL][3];
   contact con[MAX_CONTACTS]; int ncon;
-  row rows[MAX_ROWS]; int nrows, n_noncontact;
+  row rows[MAX_ROWS]; int nrows, n_noncontact, n_tors;
   int contact_substeps;             /* substeps so far whose solve had at least one contact row (tests: where does a rollout stop being free motion) */
   void* ref;                        /* librp_oracle_bullet.so only: persistent state of the frozen Bullet-like step (rp_bullet_ref.c) */
 };
@@ -924,6 +924,7 @@ static void build_rows(rpo_env* e, const real* vstar) {
   /* RPO_RULE_SPIN: one torsional friction row per run of contacts of one collider pair whose colliders carry spinning_friction (the gripper links), bounded by
    * that coefficient times the normal impulse of the run's first point; solved after the normals and before the friction rows.  At most MAX_TORS of them,
    * in contact order (a cap shared with the HIP library, like MAX_CONTACTS) */
+  e->n_tors = 0;
   if (e->rule & RPO_RULE_SPIN)
     for (int ci = 0, nt = 0; ci < e->ncon && nt < MAX_TORS; ci++) {
       contact* c = &e->con[ci];
@@ -939,7 +940,7 @@ static void build_rows(rpo_env* e, const real* vstar) {
       r->rhs = -dotn(r->J, vstar, nv) * r->dinv;
       r->fric_parent = first_normal + ci;
       r->mu = spin;
-      nt++;
+      nt++; e->n_tors = nt;
     }
   for (int ci = 0; ci < e->ncon; ci++) {
     contact* c = &e->con[ci];
@@ -1955,6 +1956,7 @@ int rpo_contacts(rpo_env* e, double* out, int max) {
   return e->ncon;
 }
 int rpo_last_num_rows(const rpo_env* e) { return e->nrows; }
+int rpo_last_num_tors(const rpo_env* e) { return e->n_tors; }      /* torsional rows of the latest substep (mode A) */
 int rpo_contact_substeps(const rpo_env* e) { return e->contact_substeps; }
 /* world pose of every collider in the current state: out[12 c] = R (row-major), p; returns the collider count (render / ray tests) */
 int rpo_collider_poses(rpo_env* e, double* out) {

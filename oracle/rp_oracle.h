@@ -36,7 +36,11 @@ rpo_env* rpo_create(int kind /*0 U, 1 R, 2 P, 3 Q, 4 V, 5 W (rp_model.h)*/, unsi
 /* perform_action's dispatch (environments.py:915-934); default RPO_ACT_ABS_RPY.  Action length: rpo_action_dim. */
 enum { RPO_ACT_ABS_RPY = 0, RPO_ACT_REL_RPY = 1, RPO_ACT_ABS_QUAT = 2, RPO_ACT_REL_QUAT = 3, RPO_ACT_ABS_JOINTS = 4, RPO_ACT_REL_JOINTS = 5 };
 void rpo_set_action_type(rpo_env* e, int action_type);
-void rpo_set_rule(rpo_env* e, int rule);                              /* bit 0: Bullet's non-contact row order (alternating direction), bit 1: joint-limit rows only while violated, erp 0.2 */
+/* what the fast model shares with the frozen reference step (rp_oracle.c RPO_RULE_*; default: all of them = 247, rule 0 = round 2's model).  1: Bullet's
+ * non-contact row order, walked in alternating direction; 2: joint-limit rows only while violated, erp 0.2; 4: arm links touch static boxes with their hulls'
+ * vertices; 16: an arm link's box touches a box only on overlap; 32: box-box points in btBoxBoxDetector's order; 64: a contact acts at its point on A / on B;
+ * 128: torsional friction rows of links with spinning_friction */
+void rpo_set_rule(rpo_env* e, int rule);
 int rpo_get_rule(const rpo_env* e);
 void rpo_set_margin(rpo_env* e, double margin);                     /* one contact margin for all pairs, metres (default: per pair, rp_model.col_thr) */
 void rpo_set_reward_cfg(rpo_env* e, double sparse_rew_thresh, int dense);   /* environments.py:66, 169-170 */
@@ -88,6 +92,7 @@ void rpo_site_pose(const rpo_env*, int site, double* pos, double* quat, double* 
 void rpo_mass_matrix_inv(rpo_env*, double* Minv /* nv*nv, arm block via unit impulse responses */);
 void rpo_forward_dynamics(rpo_env*, double* qdd /* n_arm */);
 int rpo_contacts(rpo_env*, double* out /* per contact: colA colB px py pz nx ny nz dist */, int max);
+int rpo_last_num_tors(const rpo_env* e);        /* torsional friction rows of the latest substep */
 int rpo_last_num_rows(const rpo_env*);
 int rpo_arm_table(const rpo_env* e, double* out);                      /* [n_arm][6]: jtype, lower, upper, body mass, Bullet joint index, parent dof */
 int rpo_collider_dynamics(const rpo_env* e, double* out);              /* [n_col][6]: body, friction, body mass, contact stiffness, damping, breaking threshold */

@@ -2489,59 +2489,53 @@ __device__ __forceinline__ void prep2_body(const DevModel* __restrict__ m, const
   __syncthreads();            /* the join: contacts (wave 0) and M^-1, v*, joint subspaces (wave 1) are there; aout and the dynamics scratch are dead */
   const int ncon = L.hdr[0];
   if (wid == 0) {
-    /* contact rows, PREP_CH contacts at a time: built in LDS, then copied to their places in the workspace (row number: normals first,
-     * then the friction pairs - the order the one-kernel path builds them in) */
-    L.roff[lane] = 0;
-    for (int c0 = 0; c0 < ncon; c0 += PREP_CH) {
-      const int nc = min(PREP_CH, ncon - c0);
-      contact_rows(m, L, lane, c0, nc, 0);
-      WSYNC();
-      for (int e = lane; e < 3 * nc * ROWW; e += 64) {
-        const int lr = e / ROWW, k = e - lr * ROWW;
-        const int gr = lr < nc ? c0 + lr : ncon + 2 * c0 + (lr - nc);
-        w[W3_J + gr * ROWW + k] = L.J[e]; w[W3_B + gr * ROWW + k] = L.B[e];
-      }
-      for (int e = lane; e < 3 * nc * 4; e += 64) {
-        const int lr = e >> 2, k = e & 3;
-        const int gr = lr < nc ? c0 + lr : ncon + 2 * c0 + (lr - nc);
-        w[W3_ROWS + gr * 4 + k] = L.rowS[e]; w[W3_ROWT + gr * 4 + k] = L.rowT[e];
-      }
-      if (lane < 3 * nc) {
-        const int gr = lane < nc ? c0 + lane : ncon + 2 * c0 + (lane - nc);
-        L.roff[gr] = __float_as_int(L.rowT[4 * lane + 2]) | (__float_as_int(L.rowT[4 * lane + 3]) << 8);
-      }
-      WSYNC();
-    }
-    PCLK(4)
     /* contact classes (collide() ordered them): rank inside the class -> slot tables for k_solve2 */
     const int cls = lane < ncon ? L.conk[lane] : 3;
     const unsigned long long mB = __ballot(cls == 0), mA = __ballot(cls == 1), mC = __ballot(cls == 2);
     const unsigned long long lower = (1ull << lane) - 1ull;
     L.slot[lane] = -1;
+    L.roff[lane] = 0;
+    const int nt = tors_list(m, L, lane, ncon);               /* torsional rows */
     WSYNC();
     if (cls == 0) L.slot[__popcll(mB & lower)] = lane;             /* s-th contact of the second half (DPP row 1) */
     else if (cls == 1) L.slot[21 + __popcll(mA & lower)] = lane;   /* s-th contact of the first half (DPP row 0) */
     else if (cls == 2) L.slot[42 + __popcll(mC & lower)] = lane;   /* j-th contact that touches both */
-    WSYNC();
-    /* torsional rows (tors_list): a chunk of their own, stored behind the contact rows (compact rows 3 ncon + t); k_solve2 finds the parent's normal impulse
-     * through the parent's class and rank inside it (= its slot), packed beside its index */
-    const int nt = tors_list(m, L, lane, ncon);
-    WSYNC();
-    if (nt > 0) {
-      contact_rows(m, L, lane, 0, 0, nt);
+    /* contact rows, PREP_CH contacts at a time: built in LDS, then copied to their places in the workspace (row number: normals first,
+     * then the friction pairs - the order the one-kernel path builds them in - and behind them, compact rows 3 ncon + t, the torsional rows).
+     * The torsional rows ride in the last chunk when it has room for them (its lanes are idle anyway), else in a chunk of their own; k_solve2
+     * finds a torsional row's parent - the normal impulse that bounds it - through the parent's class and its rank inside it (= its slot),
+     * packed beside the parent's index */
+    bool tors_done = nt == 0;
+    for (int c0 = 0; c0 < ncon || !tors_done; c0 += PREP_CH) {
+      const int nc = max(0, min(PREP_CH, ncon - c0));
+      const int ntl = (!tors_done && c0 + PREP_CH >= ncon && 3 * nc + nt <= 3 * PREP_CH) ? nt : 0;      /* (wave-uniform) */
+      contact_rows(m, L, lane, c0, nc, ntl);
       WSYNC();
-      for (int e = lane; e < nt * ROWW; e += 64) { w[W3_J + 3 * ncon * ROWW + e] = L.J[e]; w[W3_B + 3 * ncon * ROWW + e] = L.B[e]; }
-      if (lane < 4 * nt) {
-        const int t = lane >> 2, k = lane & 3;
-        float v = L.rowS[lane];
-        if (k == 3) {
-          const int c = L.torc[t], kc = L.conk[c];
+      auto global_row = [&](int lr) { return lr < nc ? c0 + lr : (lr < nc + ntl ? 3 * ncon + (lr - nc) : ncon + 2 * c0 + (lr - nc - ntl)); };
+      for (int e = lane; e < (3 * nc + ntl) * ROWW; e += 64) {
+        const int lr = e / ROWW, k = e - lr * ROWW;
+        const int gr = global_row(lr);
+        w[W3_J + gr * ROWW + k] = L.J[e]; w[W3_B + gr * ROWW + k] = L.B[e];
+      }
+      for (int e = lane; e < (3 * nc + ntl) * 4; e += 64) {
+        const int lr = e >> 2, k = e & 3;
+        const int gr = global_row(lr);
+        float v = L.rowS[e];
+        if (k == 3 && lr >= nc && lr < nc + ntl) {
+          const int c = L.torc[lr - nc], kc = L.conk[c];
           const unsigned long long mk = kc == 1 ? mA : (kc == 2 ? mC : mB);
           v = __int_as_float(c | (kc << 8) | (__popcll(mk & ((1ull << c) - 1ull)) << 12));
         }
-        w[W3_ROWS + 4 * (3 * ncon + t) + k] = v; w[W3_ROWT + 4 * (3 * ncon + t) + k] = L.rowT[lane];
+        w[W3_ROWS + gr * 4 + k] = v; w[W3_ROWT + gr * 4 + k] = L.rowT[e];
       }
+      if (lane < 3 * nc + ntl && !(lane >= nc && lane < nc + ntl)) {
+        const int gr = global_row(lane);
+        L.roff[gr] = __float_as_int(L.rowT[4 * lane + 2]) | (__float_as_int(L.rowT[4 * lane + 3]) << 8);
+      }
+      if (ntl > 0) tors_done = true;
+      WSYNC();
     }
+    PCLK(4)
     if (lane == 0) {
       int nj = m->n_j1 < NBJ ? m->n_j1 : NBJ;
       w[W3_HDR] = __int_as_float((int)L.amask[0]); w[W3_HDR + 1] = __int_as_float((int)L.amask[1]);

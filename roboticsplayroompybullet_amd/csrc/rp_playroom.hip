@@ -197,6 +197,8 @@ int rp_create(const rp_config* cfg, rp_handle* out) {
       for (int c = 0; c < RP_MAX_COL; c++) { d->hull_off[c] = hoff[c]; d->hull_cnt[c] = off ? 0 : hcnt[c]; }
     }
     d->hullv = h->hullv;
+    if (getenv("RP_NO_SPIN") != nullptr)                     /* timing / model studies only: no torsional friction rows */
+      for (int c = 0; c < RP_MAX_COL; c++) d->col_spin[c] = 0.f;
   }
   CREATE_CHK(hipMemcpy(h->dev_model, &h->host_model, sizeof(DevModel), hipMemcpyHostToDevice));
   CREATE_CHK(hipEventCreate(&h->ev0));

@@ -185,6 +185,29 @@ def test_with_the_remaining_differences_off_it_is_the_fast_model():
             np.testing.assert_allclose(a.get_state()[:a.n_arm], b.get_state()[:a.n_arm], atol=tol * 5, rtol=0)
 
 
+def test_on_ur5reach_the_fast_model_is_the_reference_step_without_persistence():
+    """what the shipped model took from the reference step in round 3 - row order and limit rule, hull vertices against static boxes, the box-box detector's
+    point order, per-body lever arms, torsional friction - leaves ONE difference on UR5Reach-v0: persistent manifolds.  With persistence switched off the
+    frozen reference step and the fast model walk the same 200-step trajectories to 1e-6, gripper-on-table contacts included (tools/model_divergence.py:
+    row 'B -persist' = row 'A default')"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    import model_divergence as md
+    contact_substeps = 0
+    for e in (0, 4, 7, 9):
+        ref = OracleEnv('R', seed=77, env_index=e, bullet_ref=True, ref_flags=oracle.REF_DEFAULT & ~oracle.REF_FLAGS['persist'])
+        ref.reset()
+        s0 = ref.get_state()
+        acts = md.random_actions('R', 200, np.random.default_rng(1000 + e))
+        qb, _ = md.rollout(ref, 'R', 'random', 200, acts, s0)
+        a = OracleEnv('R', seed=77, env_index=e)
+        qa, _ = md.rollout(a, 'R', 'random', 200, acts, s0)
+        assert np.abs(qa - qb).max() < 1e-6, (e, np.abs(qa - qb).max())
+        contact_substeps += a.lib.rpo_contact_substeps(a.h)
+    assert contact_substeps > 100
+
+
 def test_default_flags_are_everything_but_warm_starting():
     env = OracleEnv('U', seed=0, env_index=0, bullet_ref=True)
     assert env.lib.rpo_get_ref_flags(env.h) == oracle.REF_DEFAULT == sum(v for k, v in oracle.REF_FLAGS.items() if k != 'warm')

@@ -9,8 +9,8 @@ onto the block, close, lift: the contact-rich case) - N envs are reset once by m
     joints  the same over all dofs, the gripper's auxiliary joints included (north_star's "relative joint-state divergence")
     block   max over steps of |block position A - B| in metres
 as median / 90th percentile / max over the envs.  Rows:
-    A default      the shipped model: Bullet's row order and limit rule, hull vertices against static boxes, arm boxes overlap-only, per-pair contact margins =
-                   Bullet's relative breaking thresholds for everything else
+    A default      the shipped model: Bullet's row order and limit rule, hull vertices against static boxes, arm boxes overlap-only, box-box points in the
+                   detector's order, per-body lever arms, torsional friction rows, per-pair contact margins = Bullet's relative breaking thresholds
     A round 2      last round's model (rule 0); A -x: the shipped model with one of its round-3 features off
     A m=...        the same model with one uniform contact margin (0, 5 mm = round 1's choice, 20 mm = gContactBreakingThreshold taken absolute)
     B -flag        mode B with one of its differences switched off (what each Bullet feature is worth, measured inside mode B)
@@ -83,8 +83,10 @@ def main():
     ap.add_argument('--kinds', default='R,Q,U,P')
     args = ap.parse_args()
     D = oracle.REF_DEFAULT
-    # the shipped model's rule bits (rp_oracle.c RPO_RULE_*): 1 Bullet's row order, 2 violated-only limits, 4 hull vertices against static boxes, 16 arm boxes overlap-only
-    variants = [('A default (shipped)', dict()), ('A round 2 (rule 0)', dict(rule=0)), ('A -order -limit', dict(rule=20)), ('A -hull', dict(rule=19)), ('A -boxoverlap', dict(rule=7)),
+    # the shipped model's rule bits (rp_oracle.c RPO_RULE_*): 1 Bullet's row order, 2 violated-only limits, 4 hull vertices against static boxes, 16 arm boxes overlap-only,
+    # 32 box-box points in the detector's order, 64 per-body lever arms, 128 torsional friction rows
+    variants = [('A default (shipped)', dict()), ('A round 2 (rule 0)', dict(rule=0)), ('A -order -limit', dict(rule=247 & ~3)), ('A -hull', dict(rule=247 & ~4)), ('A -boxoverlap', dict(rule=247 & ~16)),
+                ('A -boxorder', dict(rule=247 & ~32)), ('A -lever', dict(rule=247 & ~64)), ('A -spin', dict(rule=247 & ~128)), ('A -boxorder -lever -spin', dict(rule=23)),
                 ('A m=0', dict(margin=0.0)), ('A m=5mm', dict(margin=0.005)), ('A m=20mm', dict(margin=0.02))]
     for name, bit in oracle.REF_FLAGS.items():
         if name == 'warm':
