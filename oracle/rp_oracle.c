@@ -352,7 +352,7 @@ static int box_box(const real* ca, const real* Ra, const real* ha, const real* c
   /* more than four: the detector's cullPoints2 - the deepest first, then for each of the three directions a quarter turn further around the polygon's
    * centroid (in the reference face's plane) the unused point nearest to it in angle */
   {
-    real q2[16][2], ang[16], area = 0, cx = 0, cy = 0; int avail[16];
+    real q2[16][2], area = 0, cx = 0, cy = 0; int avail[16];
     for (int v = 0; v < cnt; v++) {
       real r[3]; v3cpy(r, tmp[v].p); v3axpy(r, (real)0.5 * tmp[v].dist, nref); v3sub(r, r, cX);      /* back to the polygon's vertex */
       q2[v][0] = v3dot(r, X[u1]); q2[v][1] = v3dot(r, X[u2]);
@@ -364,16 +364,22 @@ static int box_box(const real* ca, const real* Ra, const real* ha, const real* c
     }
     area = R_FABS(area) > (real)1e-30 ? 1 / (3 * area) : (real)1e30;
     cx *= area; cy *= area;
-    for (int v = 0; v < cnt; v++) { ang[v] = R_ATAN2(q2[v][1] - cy, q2[v][0] - cx); avail[v] = 1; }
+    /* "nearest in angle" without angles: the largest cosine against the deepest point's direction turned by j quarter turns (a point AT the centroid counts
+     * as direction (1, 0), atan2(0, 0) = 0); the first of equals wins, like the detector's strict comparison */
+    real ux[16], uy[16];
+    for (int v = 0; v < cnt; v++) {
+      real x = q2[v][0] - cx, y = q2[v][1] - cy, l = R_SQRT(x * x + y * y);
+      if (l > 0) { ux[v] = x / l; uy[v] = y / l; } else { ux[v] = 1; uy[v] = 0; }
+      avail[v] = 1;
+    }
     avail[deepest] = 0; out[0] = tmp[deepest];
+    real wx = ux[deepest], wy = uy[deepest];
     for (int j = 1; j < 4; j++) {
-      real want = (real)j * (real)(0.5 * RP_PI) + ang[deepest];
-      if (want > (real)RP_PI) want -= (real)(2 * RP_PI);
-      real bestd = (real)1e9; int pick = deepest;
+      const real t = wx; wx = -wy; wy = t;                  /* a quarter turn further */
+      real bestc = (real)-2; int pick = deepest;
       for (int v = 0; v < cnt; v++) if (avail[v]) {
-        real diff = R_FABS(ang[v] - want);
-        if (diff > (real)RP_PI) diff = (real)(2 * RP_PI) - diff;
-        if (diff < bestd) { bestd = diff; pick = v; }
+        const real c = ux[v] * wx + uy[v] * wy;
+        if (c > bestc) { bestc = c; pick = v; }
       }
       avail[pick] = 0; out[j] = tmp[pick];
     }

@@ -762,7 +762,8 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
       if (cnt > 4) {
         /* more than four (rare): the detector's cullPoints2, by every lane of the group alike - the deepest first, then for each of the three directions
          * a quarter turn further around the polygon's centroid (in the reference face's plane) the unused point nearest to it in angle; lane s takes the
-         * s-th pick (same arithmetic as the oracle's box_box) */
+         * s-th pick (same arithmetic as the oracle's box_box).  NOTE: `cnt` is the same in all eight lanes of the group, so the barriers below are
+         * reached by whole groups */
         /* (few registers on purpose: the polygon's plane coordinates and angles go through the clip scratch, free by now) */
         float (*q2)[3] = poly[0];
         if (s < cnt) {
@@ -779,21 +780,27 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
         }
         area = fabsf(area) > 1e-30f ? 1.f / (3.f * area) : 1e30f;
         cx *= area; cy *= area;
-        if (s < cnt) q2[s][2] = atan2f(q2[s][1] - cy, q2[s][0] - cx);
+        /* "nearest in angle" without angles (oracle box_box): unit directions from the centroid, the largest cosine against the deepest point's direction
+         * turned by jj quarter turns; the first of equals wins */
+        float mx = 1.f, my = 0.f;
+        if (s < cnt) {
+          const float x = q2[s][0] - cx, y = q2[s][1] - cy, l = sqrtf(x * x + y * y);
+          if (l > 0.f) { mx = x / l; my = y / l; }
+        }
+        WSYNC();                                             /* every lane has read the coordinates: the scratch takes the directions */
+        if (s < cnt) { q2[s][0] = mx; q2[s][1] = my; }
         WSYNC();
-        const float a0 = q2[deepest][2];
+        float wx = q2[deepest][0], wy = q2[deepest][1];
         unsigned avail = ((1u << cnt) - 1u) & ~(1u << deepest);
         src = deepest;
 #pragma unroll 1
         for (int jj = 1; jj < 4; jj++) {
-          float want = (float)jj * 1.57079632679489661923f + a0;
-          if (want > 3.14159265358979323846f) want -= 6.28318530717958647692f;
-          float bestd = 1e9f; int pick = deepest;
+          const float tq = wx; wx = -wy; wy = tq;            /* a quarter turn further */
+          float bestc = -2.f; int pick = deepest;
 #pragma unroll 1
           for (int v = 0; v < cnt; v++) {
-            float diff = fabsf(q2[v][2] - want);
-            if (diff > 3.14159265358979323846f) diff = 6.28318530717958647692f - diff;
-            if (((avail >> v) & 1u) && diff < bestd) { bestd = diff; pick = v; }
+            const float c = q2[v][0] * wx + q2[v][1] * wy;
+            if (((avail >> v) & 1u) && c > bestc) { bestc = c; pick = v; }
           }
           avail &= ~(1u << pick);
           src = s == jj ? pick : src;
