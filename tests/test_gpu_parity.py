@@ -317,6 +317,42 @@ def test_solver_slot_layouts_bitwise():
         assert torch.equal(obs[0][k], obs[1][k]) and torch.equal(obs[0][k], obs[2][k]), k
 
 
+def test_torsional_rows_of_uncoupled_envs_bitwise():
+    """the gripper of UR5Reach pressed onto the table, opened and closed: pads and fingers on the static scene = torsional friction rows (spinning_friction of
+    the gripper links) in envs WITHOUT spanning contacts - the four-env path of k_solve2 solves them in its row-0 stream.  Split pipeline == fallback slot
+    layout == fused kernel, bit for bit; a CPU oracle that follows env 0 says the rows were there."""
+    import ctypes as C
+    from oracle import OracleEnv
+    from roboticsplayroompybullet_amd import VecPlayEnv
+    n = 9
+    envs = [VecPlayEnv(IDS['R'], n, seed=31) for _ in range(3)]
+    envs[1].set_debug_flags(1)
+    envs[2].set_fused(1)
+    for e in envs:
+        e.reset()
+    o = OracleEnv('R', seed=31, env_index=0, f32=True)
+    o.reset()
+    rng = np.random.default_rng(2)
+    tors = arm = 0
+    for t in range(60):
+        a = np.zeros((n, 7))
+        a[:, 0:2] = 0.1 * (rng.random((n, 2)) - 0.5)
+        a[:, 2] = -0.12 if t % 30 < 22 else 0.05             # below the table top: the arm presses its gripper onto it
+        a[:, 3:6] = 0.4 * (rng.random((n, 3)) - 0.5)
+        a[:, 6] = 1.0 if (t // 10) % 2 else -1.0
+        at = torch.tensor(a, dtype=torch.float32)
+        for e in envs:
+            e.step(at)
+        arm += int((envs[0].debug_row_counts()[:, 2] > 0).sum())
+        assert int(envs[0].debug_row_counts()[:, 3].sum()) == 0          # no spanning contacts in this scene
+        o.step(a[0].astype(np.float32).astype(np.float64))
+        tors += o.lib.rpo_last_num_tors(o.h)
+    torch.cuda.synchronize()
+    assert arm > 0 and tors > 0, (arm, tors)
+    assert torch.equal(envs[0].get_state(), envs[1].get_state())
+    assert torch.equal(envs[0].get_state(), envs[2].get_state())
+
+
 @pytest.mark.parametrize('kind', ['U', 'R', 'P', 'Q', 'V'])
 def test_reset_to_an_observation(kind):
     """playEnv.reset(o): objects and arm placed from observation vectors (no settling); device vs the fp32 oracle."""
