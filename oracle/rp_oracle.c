@@ -47,6 +47,7 @@
 #define RPO_RULE_ODEORDER 32        /* box against box: the face clip emits its points in btBoxBoxDetector's order (box_box) */
 #define RPO_RULE_LEVER 64           /* a contact acts at its point on A on body A and at its point on B on body B (otherwise: at their midpoint on both) */
 #define RPO_RULE_SPIN 128           /* spinning_friction of the gripper links: one torsional friction row per collider pair in contact */
+#define RPO_RULE_PERSIST 256        /* persistent contact manifolds (collide_persistent); OFF in the shipped model */
 #define RPO_RULE_HULLFACE 4         /* arm links touch static boxes with the vertices of their collision meshes' convex hulls (hull_face) instead of their OBBs */
 #define HULL_MARGIN ((real)RP_HULL_MARGIN)
 #define FREE_LIN_DAMP ((real)0.04)
@@ -56,7 +57,10 @@
 #define IK_RESIDUAL ((real)1e-4)
 #define IK_MAX_STEP ((real)(45.0 * 3.14159265358979323846 / 180.0))
 #define TIE_EPS ((real)1e-6)            /* discrete narrowphase choices need a margin that fp32 and fp64 agree on */
+#ifndef MAX_CONTACTS
 #define MAX_CONTACTS 21
+#endif
+#define PM_MAX 12                 /* cached manifolds per env under RPO_RULE_PERSIST (those with at least one point), shared with the HIP library */
 #define MAX_TORS 4                /* torsional friction rows per substep (RPO_RULE_SPIN), shared with the HIP library (MAXT) */
 #define MAX_ACTIVE_PAIRS 64
 #define MAX_CANDIDATES 64    /* candidate points that enter the manifolds per substep (CANDMAX of the HIP library) */
@@ -106,6 +110,9 @@ struct rpo_env {
   contact con[MAX_CONTACTS]; int ncon;
   row rows[MAX_ROWS]; int nrows, n_noncontact, n_tors;
   int contact_substeps;             /* substeps so far whose solve had at least one contact row (tests: where does a rollout stop being free motion) */
+  /* RPO_RULE_PERSIST: the contact cache - one manifold per object pair in creation order, <= 4 points each, kept in the two bodies' frames */
+  struct { int oa, ob, n; real thr; struct { int ca, cb; real lA[3], lB[3], n[3], pA[3], pB[3], dist; } pt[4]; } pm[PM_MAX];
+  int npm;
   void* ref;                        /* librp_oracle_bullet.so only: persistent state of the frozen Bullet-like step (rp_bullet_ref.c) */
 };
 
@@ -503,9 +510,190 @@ static int hull_face(const rpo_env* e, int a, int b, real margin, cpoint* out) {
   return 1;
 }
 
+/* ------------------------------------------------------------------ RPO_RULE_PERSIST: persistent manifolds (btPersistentManifold's life cycle on the fast
+ * model's own manifolds: one per OBJECT pair, <= 4 points).  Per substep:
+ *   1. candidates as in collide() - same broadphase, caps and narrowphase, but a box pair makes points only while the boxes overlap (the cache keeps them
+ *      afterwards, out to the pair's breaking threshold);
+ *   2. cached manifolds whose object pair has no AABB-overlapping collider pair any more are dropped;
+ *   3. every candidate enters its manifold (created at the end of the list if new and there is room: PM_MAX): its two points go to the frames of the
+ *      two bodies; a cached point within the threshold of it (in A's frame) is REPLACED, else it is appended, else (four already) it takes the place
+ *      btPersistentManifold::sortCachedPoints picks (the deepest stays, the area of the rest is maximised);
+ *   4. every point is refreshed from its two local points (world points, distance along its normal) and dropped when the distance exceeds the threshold
+ *      or the points have drifted apart sideways by more than it (the last point takes the slot); manifolds left without points are dropped;
+ *   5. the contacts of the substep are the cached points in manifold order (a rotation-locked body against the static world: its deepest point alone),
+ *      the first MAX_CONTACTS of them, in the solver's four-tier order. */
+static void pm_to_local(const rpo_env* e, int body, const real* pw, real* pl) { real t[3]; v3sub(t, pw, e->xb[body].p); m3tmulv(pl, e->xb[body].R, t); }
+static void pm_to_world(const rpo_env* e, int body, const real* pl, real* pw) { m3mulv(pw, e->xb[body].R, pl); v3add(pw, pw, e->xb[body].p); }
+static void solver_order(rpo_env* e);
+static void collide_persistent(rpo_env* e) {
+  const rp_model* m = &e->m;
+  contact cand[MAX_CANDIDATES]; int ncand = 0, nactive = 0;
+  int act_oa[MAX_ACTIVE_PAIRS], act_ob[MAX_ACTIVE_PAIRS]; real act_thr[MAX_ACTIVE_PAIRS];
+  for (int pi = 0; pi < m->n_pair; pi++) {
+    const int a = m->pair[pi][0], b = m->pair[pi][1];
+    const real margin = e->margin >= 0 ? e->margin : (real)(m->col_thr[a] < m->col_thr[b] ? m->col_thr[a] : m->col_thr[b]);
+    int sep = 0;
+    for (int k = 0; k < 3; k++)
+      if (e->aabb_lo[a][k] > e->aabb_hi[b][k] + margin || e->aabb_lo[b][k] > e->aabb_hi[a][k] + margin) sep = 1;
+    if (sep) continue;
+    if (nactive >= MAX_ACTIVE_PAIRS) continue;
+    act_oa[nactive] = m->col_obj[a]; act_ob[nactive] = m->col_obj[b]; act_thr[nactive] = (real)(m->col_thr[a] < m->col_thr[b] ? m->col_thr[a] : m->col_thr[b]); nactive++;
+    cpoint pts[4]; int np = 0;
+    real ha[3], hb[3];
+    for (int k = 0; k < 3; k++) { ha[k] = (real)m->col_he[a][k]; hb[k] = (real)m->col_he[b][k]; }
+    int hf = -1;
+    if ((e->rule & RPO_RULE_HULLFACE) && m->col_type[b] == 0 && m->col_body[b] == 0 && body_is_arm(e, m->col_body[a])) hf = hull_face(e, a, b, margin, pts);
+    if (hf >= 0) np = hf;
+    else if (m->col_type[a] == 0 && m->col_type[b] == 0) np = box_box(e->xc[a].p, e->xc[a].R, ha, e->xc[b].p, e->xc[b].R, hb, 0, (e->rule & RPO_RULE_ODEORDER) != 0, pts);
+    else if (m->col_type[a] == 0 && m->col_type[b] == 1) np = sphere_box(e->xc[b].p, hb[0], e->xc[a].p, e->xc[a].R, ha, margin, 1, pts);
+    else if (m->col_type[a] == 1 && m->col_type[b] == 0) np = sphere_box(e->xc[a].p, ha[0], e->xc[b].p, e->xc[b].R, hb, margin, 0, pts);
+    if (ncand + np > MAX_CANDIDATES) np = MAX_CANDIDATES - ncand;
+    for (int i = 0; i < np; i++) {
+      contact* c = &cand[ncand++];
+      c->ca = a; c->cb = b; v3cpy(c->p, pts[i].p); v3cpy(c->n, pts[i].n); c->dist = pts[i].dist; c->mu = 0;
+    }
+  }
+  /* 2. */
+  {
+    int w = 0;
+    for (int i = 0; i < e->npm; i++) {
+      int touched = 0;
+      for (int k = 0; k < nactive; k++) if (act_oa[k] == e->pm[i].oa && act_ob[k] == e->pm[i].ob) touched = 1;
+      if (!touched) continue;
+      if (w != i) e->pm[w] = e->pm[i];
+      w++;
+    }
+    e->npm = w;
+  }
+  /* 2b. a manifold exists from the substep in which its object pair first has an AABB-overlapping collider pair (Bullet creates it in the broadphase
+   * callback, before any point): creation order = row order */
+  for (int k = 0; k < nactive; k++) {
+    int found = 0;
+    for (int i = 0; i < e->npm; i++) if (e->pm[i].oa == act_oa[k] && e->pm[i].ob == act_ob[k]) found = 1;
+    if (found || e->npm >= PM_MAX) continue;
+    e->pm[e->npm].oa = act_oa[k]; e->pm[e->npm].ob = act_ob[k]; e->pm[e->npm].n = 0; e->pm[e->npm].thr = act_thr[k];
+    e->npm++;
+  }
+  /* 3. */
+  for (int ci = 0; ci < ncand; ci++) {
+    const contact* c = &cand[ci];
+    const int oa = m->col_obj[c->ca], ob = m->col_obj[c->cb];
+    int mi = -1;
+    for (int i = 0; i < e->npm; i++) if (e->pm[i].oa == oa && e->pm[i].ob == ob) mi = i;
+    if (mi < 0) continue;                                  /* no room for its manifold (PM_MAX) */
+    const real thr = e->pm[mi].thr;
+    if (c->dist > thr) continue;
+    real pA[3], pB[3], lA[3], lB[3];
+    v3cpy(pA, c->p); v3axpy(pA, (real)0.5 * c->dist, c->n);
+    v3cpy(pB, c->p); v3axpy(pB, (real)-0.5 * c->dist, c->n);
+    pm_to_local(e, m->col_body[c->ca], pA, lA);
+    pm_to_local(e, m->col_body[c->cb], pB, lB);
+    int slot = -1; real shortest = thr * thr;
+    for (int i = 0; i < e->pm[mi].n; i++) {
+      real d[3]; v3sub(d, e->pm[mi].pt[i].lA, lA);
+      const real dd = v3dot(d, d);
+      if (dd < shortest) { shortest = dd; slot = i; }
+    }
+    if (slot < 0) {
+      if (e->pm[mi].n < 4) slot = e->pm[mi].n++;
+      else {                                                 /* sortCachedPoints on the local-A points */
+        int deepest = -1; real maxpen = c->dist;
+        for (int i = 0; i < 4; i++) if (e->pm[mi].pt[i].dist < maxpen) { deepest = i; maxpen = e->pm[mi].pt[i].dist; }
+        real res[4] = {0, 0, 0, 0}, u[3], v[3], cr[3];
+#define PM_LA(i) e->pm[mi].pt[i].lA
+        if (deepest != 0) { v3sub(u, lA, PM_LA(1)); v3sub(v, PM_LA(3), PM_LA(2)); v3cross(cr, u, v); res[0] = v3dot(cr, cr); }
+        if (deepest != 1) { v3sub(u, lA, PM_LA(0)); v3sub(v, PM_LA(3), PM_LA(2)); v3cross(cr, u, v); res[1] = v3dot(cr, cr); }
+        if (deepest != 2) { v3sub(u, lA, PM_LA(0)); v3sub(v, PM_LA(3), PM_LA(1)); v3cross(cr, u, v); res[2] = v3dot(cr, cr); }
+        if (deepest != 3) { v3sub(u, lA, PM_LA(0)); v3sub(v, PM_LA(2), PM_LA(1)); v3cross(cr, u, v); res[3] = v3dot(cr, cr); }
+#undef PM_LA
+        slot = 0;
+        for (int i = 1; i < 4; i++) if (res[i] > res[slot]) slot = i;
+      }
+    }
+    e->pm[mi].pt[slot].ca = c->ca; e->pm[mi].pt[slot].cb = c->cb;
+    v3cpy(e->pm[mi].pt[slot].lA, lA); v3cpy(e->pm[mi].pt[slot].lB, lB); v3cpy(e->pm[mi].pt[slot].n, c->n);
+    e->pm[mi].pt[slot].dist = c->dist;
+  }
+  /* 4. */
+  {
+    int w = 0;
+    for (int mi = 0; mi < e->npm; mi++) {
+      const real thr = e->pm[mi].thr;
+      for (int i = 0; i < e->pm[mi].n; i++) {
+        real d[3];
+        pm_to_world(e, m->col_body[e->pm[mi].pt[i].ca], e->pm[mi].pt[i].lA, e->pm[mi].pt[i].pA);
+        pm_to_world(e, m->col_body[e->pm[mi].pt[i].cb], e->pm[mi].pt[i].lB, e->pm[mi].pt[i].pB);
+        v3sub(d, e->pm[mi].pt[i].pA, e->pm[mi].pt[i].pB);
+        e->pm[mi].pt[i].dist = v3dot(d, e->pm[mi].pt[i].n);
+      }
+      for (int i = e->pm[mi].n - 1; i >= 0; i--) {
+        int drop = 0;
+        if (!(e->pm[mi].pt[i].dist <= thr)) drop = 1;
+        else {
+          real proj[3], diff[3];
+          v3cpy(proj, e->pm[mi].pt[i].pA); v3axpy(proj, -e->pm[mi].pt[i].dist, e->pm[mi].pt[i].n);
+          v3sub(diff, e->pm[mi].pt[i].pB, proj);
+          if (v3dot(diff, diff) > thr * thr) drop = 1;
+        }
+        if (drop) { e->pm[mi].pt[i] = e->pm[mi].pt[e->pm[mi].n - 1]; e->pm[mi].n--; }
+      }
+      if (w != mi) e->pm[w] = e->pm[mi];
+      w++;
+    }
+    e->npm = w;
+  }
+  /* 5. */
+  e->ncon = 0;
+  for (int mi = 0; mi < e->npm; mi++) {
+    int only = -1;
+    if (e->pm[mi].n > 0) {
+      const int kf = body_free_index(e, m->col_body[e->pm[mi].pt[0].ca]);
+      if (kf >= 0 && m->free_rot_locked[kf] && m->col_body[e->pm[mi].pt[0].cb] == 0) {
+        only = 0;
+        for (int i = 1; i < e->pm[mi].n; i++) if (e->pm[mi].pt[i].dist < e->pm[mi].pt[only].dist - TIE_EPS) only = i;
+      }
+    }
+    for (int i = 0; i < e->pm[mi].n && e->ncon < MAX_CONTACTS; i++) {
+      if (only >= 0 && i != only) continue;
+      contact* c = &e->con[e->ncon++];
+      c->ca = e->pm[mi].pt[i].ca; c->cb = e->pm[mi].pt[i].cb;
+      for (int k = 0; k < 3; k++) { c->p[k] = (real)0.5 * (e->pm[mi].pt[i].pA[k] + e->pm[mi].pt[i].pB[k]); c->n[k] = e->pm[mi].pt[i].n[k]; }
+      c->dist = e->pm[mi].pt[i].dist;
+      c->mu = (real)(m->col_friction[c->ca] * m->col_friction[c->cb]);
+    }
+  }
+  solver_order(e);
+}
+
+static void solver_order(rpo_env* e) {
+  const rp_model* m = &e->m;
+  {
+    contact tmp[MAX_CONTACTS]; int k = 0;
+    for (int pass = 0; pass < 4; pass++)
+      for (int i = 0; i < e->ncon; i++) {
+        int half0 = 0, half1 = 0, arm = 0, movable = 0;
+        for (int side = 0; side < 2; side++) {
+          int b = m->col_body[side == 0 ? e->con[i].ca : e->con[i].cb];
+          if (b == 0) continue;
+          int f = b - 1 - m->n_arm;
+          if (b <= m->n_arm) arm = 1; else movable = 1;
+          if (b <= m->n_arm || (f < m->n_free && ((m->free_row0 >> f) & 1))) half0 = 1; else half1 = 1;
+        }
+        if (2 * (half0 && half1) + (arm && movable) == pass) tmp[k++] = e->con[i];
+      }
+    for (int i = 0; i < e->ncon; i++) e->con[i] = tmp[i];
+  }
+}
+#ifdef RPO_ABX
+static int collide_persist(rpo_env* e);
+#endif
 static void collide(rpo_env* e) {
   const rp_model* m = &e->m;
   e->ncon = 0;
+#ifdef RPO_ABX
+  if ((e->rule & 2048) && collide_persist(e)) return;      /* (experiment build: the reference step's own manifold upkeep) */
+#endif
+  if (e->rule & RPO_RULE_PERSIST) { collide_persistent(e); return; }
   contact man[4]; int nman = 0, man_oa = -1, man_ob = -1, nactive = 0, ncand = 0;
   for (int pi = 0; pi <= m->n_pair; pi++) {
     int a = 0, b = 0, flush = (pi == m->n_pair);
@@ -568,22 +756,7 @@ static void collide(rpo_env* e) {
    *   1  one half, arm against movable         arm against the drawer
    *   2  both halves, not arm-against-movable  block against the drawer
    *   3  both halves, arm against movable      arm against the block, the door, the button, the dial */
-  {
-    contact tmp[MAX_CONTACTS]; int k = 0;
-    for (int pass = 0; pass < 4; pass++)
-      for (int i = 0; i < e->ncon; i++) {
-        int half0 = 0, half1 = 0, arm = 0, movable = 0;
-        for (int side = 0; side < 2; side++) {
-          int b = m->col_body[side == 0 ? e->con[i].ca : e->con[i].cb];
-          if (b == 0) continue;
-          int f = b - 1 - m->n_arm;
-          if (b <= m->n_arm) arm = 1; else movable = 1;
-          if (b <= m->n_arm || (f < m->n_free && ((m->free_row0 >> f) & 1))) half0 = 1; else half1 = 1;
-        }
-        if (2 * (half0 && half1) + (arm && movable) == pass) tmp[k++] = e->con[i];
-      }
-    for (int i = 0; i < e->ncon; i++) e->con[i] = tmp[i];
-  }
+  solver_order(e);
 }
 
 /* ------------------------------------------------------------------ spatial algebra (world-origin Pluecker, [ang; lin]) */
@@ -1086,6 +1259,79 @@ static void substep_integrate(rpo_env* e, const real* vstar, real* dv) {
   }
 }
 
+#ifdef RPO_ABX      /* EXPERIMENT build (not shipped, not tested): the fast model's narrowphase feeding the reference step's persistent manifolds (rule bit 256) */
+#define RPO_BULLET_REF
+#include "rp_bullet_ref.c"
+#undef RPO_BULLET_REF
+static int collide_persist(rpo_env* e) {
+  const rp_model* m = &e->m;
+  rpb_state* st = rpb_get(e);
+  for (int i = 0; i < st->nman; i++) st->man[i].touched = 0;
+  for (int pi = 0; pi < m->n_pair; pi++) {
+    int a = m->pair[pi][0], b = m->pair[pi][1];
+    int sep = 0;
+    for (int k = 0; k < 3; k++)
+      if (e->aabb_lo[a][k] > e->aabb_hi[b][k] + 2 * RPB_BREAKING + 2 * RPB_SHAPE_MARGIN || e->aabb_lo[b][k] > e->aabb_hi[a][k] + 2 * RPB_BREAKING + 2 * RPB_SHAPE_MARGIN) sep = 1;
+    if (sep) continue;
+    rpb_manifold* mf = 0;
+    if (e->rule & 1024) {       /* the fast model's manifolds: one per OBJECT pair */
+      const int ka = 2000 + m->col_obj[a], kb = 2000 + m->col_obj[b];
+      for (int i = 0; i < st->nman; i++) if (st->man[i].key_a == ka && st->man[i].key_b == kb) mf = &st->man[i];
+      if (!mf && st->nman < RPB_MAX_MAN) {
+        mf = &st->man[st->nman++];
+        memset(mf, 0, sizeof(*mf));
+        mf->key_a = ka; mf->key_b = kb; mf->ca = a; mf->cb = b;
+        mf->thr = m->col_thr[a] < m->col_thr[b] ? m->col_thr[a] : m->col_thr[b];
+      }
+    } else mf = rpb_find_manifold(e, st, a, b, 1);
+    if (!mf) continue;
+    mf->touched = 1;
+    cpoint pts[4]; int np = 0;
+    real ha[3], hb[3];
+    for (int k = 0; k < 3; k++) { ha[k] = (real)m->col_he[a][k]; hb[k] = (real)m->col_he[b][k]; }
+    const real margin = (real)mf->thr;
+    int hf = -1;
+    if ((e->rule & RPO_RULE_HULLFACE) && m->col_type[b] == 0 && m->col_body[b] == 0 && body_is_arm(e, m->col_body[a])) hf = hull_face(e, a, b, margin, pts);
+    if (hf >= 0) np = hf;
+    else if (m->col_type[a] == 0 && m->col_type[b] == 0) np = box_box(e->xc[a].p, e->xc[a].R, ha, e->xc[b].p, e->xc[b].R, hb, 0, 1, pts);      /* overlap only: the manifold keeps the points */
+    else if (m->col_type[a] == 0 && m->col_type[b] == 1) np = sphere_box(e->xc[b].p, hb[0], e->xc[a].p, e->xc[a].R, ha, margin, 1, pts);
+    else if (m->col_type[a] == 1 && m->col_type[b] == 0) np = sphere_box(e->xc[a].p, ha[0], e->xc[b].p, e->xc[b].R, hb, margin, 0, pts);
+    for (int i = 0; i < np; i++) {
+      real pB[3]; v3cpy(pB, pts[i].p); v3axpy(pB, (real)-0.5 * pts[i].dist, pts[i].n);
+      rpb_add_point(e, mf, pts[i].n, pB, pts[i].dist);
+    }
+  }
+  int w = 0;
+  for (int i = 0; i < st->nman; i++) {
+    if (!st->man[i].touched) continue;
+    rpb_refresh(e, &st->man[i]);
+    if (w != i) st->man[w] = st->man[i];
+    w++;
+  }
+  st->nman = w;
+  e->ncon = 0;
+  for (int i = 0; i < st->nman; i++) {
+    int only = -1;            /* the fast model's rule for a rotation-locked body against the static world: its deepest point alone (all share one Jacobian) */
+    if (e->rule & 1024) {
+      int kf = body_free_index(e, m->col_body[st->man[i].ca]);
+      if (kf >= 0 && m->free_rot_locked[kf] && m->col_body[st->man[i].cb] == 0)
+        for (int j = 0; j < st->man[i].n; j++) if (only < 0 || st->man[i].p[j].dist < st->man[i].p[only].dist) only = j;
+    }
+    for (int j = 0; j < st->man[i].n && e->ncon < MAX_CONTACTS; j++) {
+      if (only >= 0 && j != only) continue;
+      const rpb_point* p = &st->man[i].p[j];
+      contact c;
+      c.ca = st->man[i].ca; c.cb = st->man[i].cb;
+      for (int k = 0; k < 3; k++) { c.p[k] = (real)0.5 * (p->pA[k] + p->pB[k]); c.n[k] = p->n[k]; }
+      c.dist = p->dist;
+      c.mu = (real)(m->col_friction[c.ca] * m->col_friction[c.cb]);
+      e->con[e->ncon++] = c;
+    }
+  }
+  if (!(e->rule & 512)) solver_order(e);      /* bit 512: keep the manifold order (Bullet's) instead of the four-tier partition */
+  return 1;
+}
+#endif
 #ifdef RPO_BULLET_REF
 #include "rp_bullet_ref.c"      /* the frozen Bullet-like collision + solve ("mode B"); see its header */
 void rpo_substep(rpo_env* e) {
@@ -1906,6 +2152,7 @@ void rpo_set_state(rpo_env* e, const double* s) {
   }
   for (int k = 0; k < e->m.n_joint1; k++) e->jq[k] = (real)s[n++];
   for (int k = 0; k < e->m.n_joint1; k++) e->jqd[k] = (real)s[n++];
+  e->npm = 0;                     /* a state set from outside starts with an empty contact cache (RPO_RULE_PERSIST) */
   update_transforms(e);
 }
 void rpo_get_motor(const rpo_env* e, int* mode, double* target, double* maximp) {
@@ -1962,7 +2209,9 @@ int rpo_contacts(rpo_env* e, double* out, int max) {
   return e->ncon;
 }
 int rpo_last_num_rows(const rpo_env* e) { return e->nrows; }
-int rpo_last_num_tors(const rpo_env* e) { return e->n_tors; }      /* torsional rows of the latest substep (mode A) */
+int rpo_last_num_tors(const rpo_env* e) { return e->n_tors; }
+/* RPO_RULE_PERSIST: cached manifolds (empty ones included) and, in *points, their points */
+int rpo_cache_size(const rpo_env* e, int* points) { int n = 0; for (int i = 0; i < e->npm; i++) n += e->pm[i].n; if (points) *points = n; return e->npm; }      /* torsional rows of the latest substep (mode A) */
 int rpo_contact_substeps(const rpo_env* e) { return e->contact_substeps; }
 /* world pose of every collider in the current state: out[12 c] = R (row-major), p; returns the collider count (render / ray tests) */
 int rpo_collider_poses(rpo_env* e, double* out) {
