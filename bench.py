@@ -111,6 +111,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--groups', type=int, default=0, help='env groups per rp_step (0 = library default)')
     ap.add_argument('--contact-margin', type=float, default=None, help='rp_config.contact_margin in metres (default: the library default)')
+    ap.add_argument('--stateless-contacts', action='store_true', help='RP_CFG_STATELESS_CONTACTS: no contact cache (round 3\'s first model)')
     ap.add_argument('--repeats', type=int, default=3, help='timed regions of --steps steps; `value` is the first one, the median is reported beside it')
     ap.add_argument('--no-extras', action='store_true', help='skip distribution A and the second contact margin')
     args = ap.parse_args()
@@ -135,7 +136,8 @@ def main():
 
     from roboticsplayroompybullet_amd import VecPlayEnv
     n = args.envs_per_gpu
-    env = VecPlayEnv(ENV_ID, n, device=dev_index, seed=1234, env_offset=sharding_offset(rank, world, n), contact_margin=args.contact_margin)
+    env = VecPlayEnv(ENV_ID, n, device=dev_index, seed=1234, env_offset=sharding_offset(rank, world, n), contact_margin=args.contact_margin,
+                     persistent_manifolds=not args.stateless_contacts)
     if args.groups:
         env.set_groups(args.groups)
     env.reset()

@@ -75,7 +75,13 @@ enum rp_config_flags {
   RP_CFG_REW_THRESH = 8,    /* sparse_rew_thresh                   (ENV:297; ids that are not play ids) */
   RP_CFG_DENSE_REWARD = 16, /* sparse=False: compute_reward = -||ag - dg|| over the whole goal vector (ENV:169-170, 273-275) */
   RP_CFG_ACTION_TYPE = 32,  /* action_type                         (ENV:88-113, 915-981) */
-  RP_CFG_CONTACT_MARGIN = 64 /* contact_margin, see below */
+  RP_CFG_CONTACT_MARGIN = 64, /* contact_margin, see below */
+  RP_CFG_STATELESS_CONTACTS = 128 /* (no field) rebuild the contact points every substep instead of keeping them across substeps.  Default (flag clear): a
+                                   * per-env contact cache (2.1 KB beside the state record) with btPersistentManifold's life cycle - one manifold per object pair
+                                   * in creation order, <= 4 points in the two bodies' frames, refreshed every substep, dropped beyond the pair's breaking
+                                   * threshold; a box pair makes new points only while the boxes overlap.  The cache is part of the state (rp_get_state /
+                                   * rp_set_state rows carry it behind the record).  With the flag: round 3's first model - points
+                                   * exist out to the pair's margin, nothing is remembered (13 % faster, further from Bullet: DESIGN.md section 2) */
 };
 
 typedef struct rp_config {
@@ -182,9 +188,10 @@ int rp_compute_reward(rp_handle h, const float* achieved_goal, const float* desi
  * compute_reward when sparse=False, environments.py:169-170; compute_reward_sparse stays callable) */
 int rp_compute_reward_sparse(rp_handle h, const float* achieved_goal, const float* desired_goal, float* reward, int32_t m, void* stream);
 
-/* full simulator state (positions, velocities, motor targets, goal, quaternion memory, RNG counters): the
- * explicit save/restore the reference lacks.  src_env_count == 1 broadcasts one env to all N. */
-size_t rp_state_bytes(rp_handle h);           /* bytes per env */
+/* full simulator state (positions, velocities, motor targets, goal, quaternion memory, RNG counters - the first 512 bytes of a row: the state record -
+ * and, unless RP_CFG_STATELESS_CONTACTS, the env's contact cache behind it): the explicit save/restore the reference lacks.
+ * src_env_count == 1 broadcasts one env to all N.  A row whose cache part is all zeros is a state without contact history. */
+size_t rp_state_bytes(rp_handle h);           /* bytes per env (a row of the buffers below) */
 int rp_get_state(rp_handle h, void* dst, void* stream);
 int rp_set_state(rp_handle h, const void* src, int32_t src_env_count, void* stream);
 

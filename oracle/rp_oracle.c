@@ -47,7 +47,7 @@
 #define RPO_RULE_ODEORDER 32        /* box against box: the face clip emits its points in btBoxBoxDetector's order (box_box) */
 #define RPO_RULE_LEVER 64           /* a contact acts at its point on A on body A and at its point on B on body B (otherwise: at their midpoint on both) */
 #define RPO_RULE_SPIN 128           /* spinning_friction of the gripper links: one torsional friction row per collider pair in contact */
-#define RPO_RULE_PERSIST 256        /* persistent contact manifolds (collide_persistent); OFF in the shipped model */
+#define RPO_RULE_PERSIST 256        /* persistent contact manifolds (collide_persistent) */
 #define RPO_RULE_HULLFACE 4         /* arm links touch static boxes with the vertices of their collision meshes' convex hulls (hull_face) instead of their OBBs */
 #define HULL_MARGIN ((real)RP_HULL_MARGIN)
 #define FREE_LIN_DAMP ((real)0.04)
@@ -60,7 +60,7 @@
 #ifndef MAX_CONTACTS
 #define MAX_CONTACTS 21
 #endif
-#define PM_MAX 12                 /* cached manifolds per env under RPO_RULE_PERSIST (those with at least one point), shared with the HIP library */
+#define PM_MAX 11                 /* cached manifolds per env under RPO_RULE_PERSIST (those with at least one point), shared with the HIP library */
 #define MAX_TORS 4                /* torsional friction rows per substep (RPO_RULE_SPIN), shared with the HIP library (MAXT) */
 #define MAX_ACTIVE_PAIRS 64
 #define MAX_CANDIDATES 64    /* candidate points that enter the manifolds per substep (CANDMAX of the HIP library) */
@@ -693,7 +693,7 @@ static void collide(rpo_env* e) {
 #ifdef RPO_ABX
   if ((e->rule & 2048) && collide_persist(e)) return;      /* (experiment build: the reference step's own manifold upkeep) */
 #endif
-  if (e->rule & RPO_RULE_PERSIST) { collide_persistent(e); return; }
+  if ((e->rule & RPO_RULE_PERSIST) && e->margin < 0) { collide_persistent(e); return; }      /* (a uniform contact margin is a study of the stateless model: it keeps the stateless contacts, like the HIP library) */
   contact man[4]; int nman = 0, man_oa = -1, man_ob = -1, nactive = 0, ncand = 0;
   for (int pi = 0; pi <= m->n_pair; pi++) {
     int a = 0, b = 0, flush = (pi == m->n_pair);
@@ -2068,7 +2068,7 @@ rpo_env* rpo_create(int kind, unsigned long long seed, int env_index) {
   e->nv = m->n_arm + 6 * m->n_free + m->n_joint1;
   e->nbody = 1 + m->n_arm + m->n_free + m->n_joint1;
   e->seed = seed; e->env_index = (uint32_t)env_index;
-  e->rule = RPO_RULE_ORDER | RPO_RULE_LIMIT | RPO_RULE_HULLFACE | RPO_RULE_BOXOVERLAP | RPO_RULE_ODEORDER | RPO_RULE_LEVER | RPO_RULE_SPIN;       /* the shipped model (the HIP kernels implement exactly this); rpo_set_rule(0) = round 2's rule */
+  e->rule = RPO_RULE_ORDER | RPO_RULE_LIMIT | RPO_RULE_HULLFACE | RPO_RULE_BOXOVERLAP | RPO_RULE_ODEORDER | RPO_RULE_LEVER | RPO_RULE_SPIN | RPO_RULE_PERSIST;       /* the shipped model (the HIP kernels implement exactly this); rpo_set_rule(0) = round 2's rule */
   e->margin = -1; e->rew_thresh = (real)0.05; e->dense_reward = 0;
   /* envList.py:8-10, 18-22, 73-99: the env's flags and ranges go with its scene (play ids: complex_scene; reach ids:
    * default_scene; pick / push: push_scene); other ids on the same model override the ranges (rpo_set_ranges) */

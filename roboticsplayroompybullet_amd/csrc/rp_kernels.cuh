@@ -28,6 +28,13 @@
 #define MAXACT 64            /* AABB-overlapping pairs examined per substep (shared cap with the oracle) */
 #define MAXT 4               /* torsional friction rows kept per env per substep (shared cap with the oracle): one per collider pair in contact whose links carry spinning_friction */
 #define MAXROWC (3 * MAXC + MAXT)
+/* persistent contact manifolds (DevModel.persist; oracle RPO_RULE_PERSIST, collide_persistent): the per-env contact cache.  Header: number of manifolds, 3 pad.
+ * Manifold (PMC_MAN floats): object-pair key (objA * 256 + objB) | points | breaking threshold | flags of the pair (bits 16.. of LDS.key, rebuilt every substep)
+ * | colliders of points 0, 1 (a | b << 8 | a' << 16 | b' << 24) | of points 2, 3 | 2 pad | 4 points x 10: point in A's body frame, in B's, normal, distance */
+#define PM_MAX 11
+#define PMC_HDR 4
+#define PMC_MAN 48
+#define PMC_FLOATS (PMC_HDR + PM_MAX * PMC_MAN)      /* 532 */
 #define RP_MAX_GROUPS 16      /* env groups (streams) rp_step can cut the envs into */
 #define SORT_KEYS 64          /* load classes for pairing envs in k_solve2: 8 * min(folded slots, 7) + min((side-by-side slots - 1) / 2, 7) */
 #define SORT_REPS 8           /* histogram replicas (env & 7): one hot word would serialise ~4096 atomics at ~90 per us */
@@ -616,7 +623,7 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
      * that; the oracle's RPO_RULE_BOXOVERLAP explains why the arm's pairs and not the resting objects') */
     const int body_a = m->col_body[a], body_b = m->col_body[b];
     const bool arm_pair = (body_a >= 1 && body_a <= m->n_arm) || (body_b >= 1 && body_b <= m->n_arm);
-    const float margin = (bb && arm_pair && m->boxbox_margin >= 0.f) ? m->boxbox_margin : margin0;
+    const float margin = (bb && (arm_pair || m->persist) && m->boxbox_margin >= 0.f) ? m->boxbox_margin : margin0;      /* (with the contact cache every box pair: the cache keeps the points) */
     if (act && !bb && s == 0) {                              /* sphere against box: one lane, closed form */
       if (ta == 0 && tb == 1) np = sphere_box(xb.p, hb.x, xa.p, xa.R, ha, margin, 1, &mine);
       else if (ta == 1 && tb == 0) np = sphere_box(xa.p, ha.x, xb.p, xb.R, hb, margin, 0, &mine);
@@ -847,7 +854,7 @@ __device__ __forceinline__ int manifold_replace_index(const float* c4, const flo
 
 /* broadphase + narrowphase + manifolds -> L.con*, returns ncon (wave-uniform) */
 template <class LDS>
-__device__ __forceinline__ int collide(const DevModel* m, LDS& L, int lane) {
+__device__ __forceinline__ int collide(const DevModel* m, LDS& L, int lane, int env) {
   /* 1. AABB sweep over the baked candidate pairs, 64 per pass; keep the first MAXACT overlapping, in order */
   int nact = 0;
   const int npair = m->n_pair;
@@ -893,6 +900,159 @@ __device__ __forceinline__ int collide(const DevModel* m, LDS& L, int lane) {
    * follows from its candidate counts alone, so every manifold knows its place in the contact list before anything is merged; the
    * first lane of a run merges it (sequentially, in candidate order) into L.man at that place - and only if the list still has room
    * for at least one of its points (cap MAXC, in manifold order). */
+  const unsigned long long lower = (1ull << lane) - 1ull;
+  int kept = 0, pk = 0;
+  float* man = L.man;
+  if (m->persist) {
+    /* 3'. PERSISTENT manifolds (oracle collide_persistent): the env's contact cache - one manifold per object pair in creation order, <= 4 points kept in the
+     * two bodies' frames - is staged behind L.man; lane i owns manifold i.  (a) manifolds whose object pair has no AABB-overlapping collider pair any
+     * more leave, the rest close ranks; (b) every active object pair without a manifold gets one, empty, at the end (creation order = row order);
+     * (c) every candidate enters its manifold: it replaces the cached point within the threshold of it (A's frame), else it is appended, else it takes
+     * the place sortCachedPoints picks; (d) every point is refreshed from its two local points and dropped beyond the threshold (distance or sideways
+     * drift; the last point takes the slot); (e) the surviving points - the deepest alone for a rotation-locked body against the static world - go to
+     * L.man as this substep's records, the cache goes back to memory. */
+    float* C = L.npscr + 8 * MANPTS;
+    static_assert(8 * MANPTS + PMC_FLOATS <= NPSCR_FLOATS, "the staged contact cache lies behind L.man in the narrowphase scratch");
+    float* g = m->pmcache + (size_t)env * PMC_FLOATS;
+    for (int i = lane * 4; i < PMC_FLOATS; i += 256) *(float4*)&C[i] = *(const float4*)&g[i];
+    WSYNC();
+    int npm = uni(__float_as_int(C[0]));
+    {                                                        /* (a) */
+      const int mykey = lane < npm ? __float_as_int(C[PMC_HDR + PMC_MAN * lane]) : -1;
+      bool touched = false; int fl = 0;
+      for (int k = 0; k < nact; k++) { const int kk = L.key[k]; if ((kk & 0xFFFF) == mykey) { touched = true; fl = kk >> 16; } }
+      if (touched) C[PMC_HDR + PMC_MAN * lane + 3] = __int_as_float(fl);
+      const unsigned long long keep = __ballot(touched);
+      WSYNC();
+      int nk = 0;
+      for (int j = 0; j < npm; j++)
+        if ((keep >> j) & 1ull) {
+          if (nk != j && lane < PMC_MAN) C[PMC_HDR + PMC_MAN * nk + lane] = C[PMC_HDR + PMC_MAN * j + lane];
+          nk++;
+        }
+      npm = nk;
+      WSYNC();
+    }
+    {                                                        /* (b) the collider pairs of one object pair are neighbours in the pair list */
+      const int objk = lane < nact ? (L.key[lane] & 0xFFFF) : -1;
+      const bool first = lane < nact && (lane == 0 || (L.key[lane - 1] & 0xFFFF) != objk);
+      bool present = false;
+      for (int j = 0; j < npm; j++) present |= __float_as_int(C[PMC_HDR + PMC_MAN * j]) == objk;
+      const bool isnew = first && !present;
+      const unsigned long long mnew = __ballot(isnew);
+      const int slot = npm + __popcll(mnew & lower);
+      if (isnew && slot < PM_MAX) {
+        const int pi = L.act[lane];
+        float* M = &C[PMC_HDR + PMC_MAN * slot];
+        M[0] = __int_as_float(objk); M[1] = __int_as_float(0);
+        M[2] = fminf(m->col_margin[m->pair[pi][0]], m->col_margin[m->pair[pi][1]]);
+        M[3] = __int_as_float(L.key[lane] >> 16);
+      }
+      npm = min(PM_MAX, npm + (int)__popcll(mnew));
+      WSYNC();
+    }
+    int cnt = 0, only = -1;
+    if (lane < npm) {
+      float* M = &C[PMC_HDR + PMC_MAN * lane];
+      const int key = __float_as_int(M[0]);
+      int n = __float_as_int(M[1]);
+      const float thr = M[2];
+      unsigned cw0 = __float_as_uint(M[4]), cw1 = __float_as_uint(M[5]);      /* colliders of the four points, 16 bits each */
+      auto getc = [&](int q) { return (q < 2 ? (cw0 >> (16 * q)) : (cw1 >> (16 * (q - 2)))) & 0xFFFFu; };
+      auto setc = [&](int q, unsigned v) { if (q < 2) cw0 = (cw0 & ~(0xFFFFu << (16 * q))) | (v << (16 * q)); else cw1 = (cw1 & ~(0xFFFFu << (16 * (q - 2)))) | (v << (16 * (q - 2))); };
+      for (int k = 0; k < nact; k++) {                       /* (c) */
+        if ((L.key[k] & 0xFFFF) != key) continue;
+        const int cn = L.candn[k];
+        for (int i = 0; i < (cn & 255); i++) {
+          const float* c = &L.cand[((cn >> 8) + i) * 8];
+          const V3 p = ld3(c), nr = mk3(c[3], c[4], c[5]);
+          const float dist = c[6];
+          const int ab = __float_as_int(c[7]) & 0xFFFF;
+          if (dist > thr) continue;
+          const int ba = m->col_body[ab & 255], bb = m->col_body[ab >> 8];
+          const V3 lA = tmulv(ldm3(&L.xR[9 * ba]), p + nr * (0.5f * dist) - ld3(&L.xp[3 * ba]));
+          const V3 lB = tmulv(ldm3(&L.xR[9 * bb]), p - nr * (0.5f * dist) - ld3(&L.xp[3 * bb]));
+          int sl = -1; float shortest = thr * thr;
+          for (int q = 0; q < n; q++) { const V3 d = ld3(&M[8 + 10 * q]) - lA; const float dd = dot(d, d); if (dd < shortest) { shortest = dd; sl = q; } }
+          if (sl < 0) {
+            if (n < 4) sl = n++;
+            else {                                           /* btPersistentManifold::sortCachedPoints on the local-A points */
+              int deepest = -1; float maxpen = dist;
+              for (int q = 0; q < 4; q++) if (M[8 + 10 * q + 9] < maxpen) { deepest = q; maxpen = M[8 + 10 * q + 9]; }
+              const V3 q0 = ld3(&M[8]), q1 = ld3(&M[18]), q2 = ld3(&M[28]), q3 = ld3(&M[38]);
+              float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f; V3 cr;
+              if (deepest != 0) { cr = cross(lA - q1, q3 - q2); r0 = dot(cr, cr); }
+              if (deepest != 1) { cr = cross(lA - q0, q3 - q2); r1 = dot(cr, cr); }
+              if (deepest != 2) { cr = cross(lA - q0, q3 - q1); r2 = dot(cr, cr); }
+              if (deepest != 3) { cr = cross(lA - q0, q2 - q1); r3 = dot(cr, cr); }
+              sl = 0; float rb = r0;
+              if (r1 > rb) { rb = r1; sl = 1; }
+              if (r2 > rb) { rb = r2; sl = 2; }
+              if (r3 > rb) { rb = r3; sl = 3; }
+            }
+          }
+          float* P = &M[8 + 10 * sl];
+          st3(P, lA); st3(P + 3, lB); st3(P + 6, nr); P[9] = dist;
+          setc(sl, (unsigned)ab);
+        }
+      }
+      for (int q = 0; q < n; q++) {                          /* (d) */
+        float* P = &M[8 + 10 * q];
+        const unsigned ab = getc(q);
+        const int ba = m->col_body[ab & 255], bb = m->col_body[ab >> 8];
+        const V3 pA = mulv(ldm3(&L.xR[9 * ba]), ld3(P)) + ld3(&L.xp[3 * ba]), pB = mulv(ldm3(&L.xR[9 * bb]), ld3(P + 3)) + ld3(&L.xp[3 * bb]);
+        P[9] = dot(pA - pB, ld3(P + 6));
+      }
+      for (int q = n - 1; q >= 0; q--) {
+        float* P = &M[8 + 10 * q];
+        const unsigned ab = getc(q);
+        const int ba = m->col_body[ab & 255], bb = m->col_body[ab >> 8];
+        const V3 nr = ld3(P + 6);
+        const float dist = P[9];
+        bool drop = !(dist <= thr);
+        if (!drop) {
+          const V3 pA = mulv(ldm3(&L.xR[9 * ba]), ld3(P)) + ld3(&L.xp[3 * ba]), pB = mulv(ldm3(&L.xR[9 * bb]), ld3(P + 3)) + ld3(&L.xp[3 * bb]);
+          const V3 diff = pB - (pA - nr * dist);
+          drop = dot(diff, diff) > thr * thr;
+        }
+        if (drop) {
+          if (q != n - 1) { for (int t = 0; t < 10; t++) P[t] = M[8 + 10 * (n - 1) + t]; setc(q, getc(n - 1)); }
+          n--;
+        }
+      }
+      M[1] = __int_as_float(n); M[4] = __uint_as_float(cw0); M[5] = __uint_as_float(cw1);
+      pk = __float_as_int(M[3]) << 16;
+      cnt = n;
+      if ((pk & 65536) && n > 0) {                           /* the rotation-locked body against the static world: its deepest point alone */
+        only = 0;
+        for (int q = 1; q < n; q++) if (M[8 + 10 * q + 9] < M[8 + 10 * only + 9] - K_TIE_EPS) only = q;
+        cnt = 1;
+      }
+    }
+    int off = 0;
+#pragma unroll
+    for (int bit = 0; bit < 3; bit++) off += __popcll(__ballot((cnt >> bit) & 1) & lower) << bit;
+    kept = min(cnt, max(0, MAXC - off));
+    man = &L.man[8 * (off < MANPTS ? off : 0)];
+    if (kept > 0) {                                          /* (e) */
+      const float* M = &C[PMC_HDR + PMC_MAN * lane];
+      const unsigned cw0 = __float_as_uint(M[4]), cw1 = __float_as_uint(M[5]);
+      for (int i = 0; i < kept; i++) {
+        const int q = only >= 0 ? only : i;
+        const float* P = &M[8 + 10 * q];
+        const unsigned ab = (q < 2 ? (cw0 >> (16 * q)) : (cw1 >> (16 * (q - 2)))) & 0xFFFFu;
+        const int ba = m->col_body[ab & 255], bb = m->col_body[ab >> 8];
+        const V3 pA = mulv(ldm3(&L.xR[9 * ba]), ld3(P)) + ld3(&L.xp[3 * ba]), pB = mulv(ldm3(&L.xR[9 * bb]), ld3(P + 3)) + ld3(&L.xp[3 * bb]);
+        const V3 pm = (pA + pB) * 0.5f;
+        float* r = &man[8 * i];
+        r[0] = pm.x; r[1] = pm.y; r[2] = pm.z; r[3] = P[6]; r[4] = P[7]; r[5] = P[8]; r[6] = P[9]; r[7] = __int_as_float((int)ab);
+      }
+    }
+    WSYNC();
+    if (lane == 0) C[0] = __int_as_float(npm);
+    WSYNC();
+    for (int i = lane * 4; i < PMC_FLOATS; i += 256) *(float4*)&g[i] = *(const float4*)&C[i];
+  } else {
   int mycnt = 0, run_end = lane;
   bool single = false;
   if (lane < nact) {
@@ -905,12 +1065,12 @@ __device__ __forceinline__ int collide(const DevModel* m, LDS& L, int lane) {
       mycnt = min(sum, single ? 1 : 4);
     }
   }
-  const unsigned long long lower = (1ull << lane) - 1ull;
   int off = 0;
 #pragma unroll
   for (int bit = 0; bit < 3; bit++) off += __popcll(__ballot((mycnt >> bit) & 1) & lower) << bit;
-  const int kept = min(mycnt, max(0, MAXC - off));      /* (the AABBs / narrowphase scratch that L.man may lie over are dead since the last barrier) */
-  float* man = &L.man[8 * (off < MANPTS ? off : 0)];
+  kept = min(mycnt, max(0, MAXC - off));      /* (the AABBs / narrowphase scratch that L.man may lie over are dead since the last barrier) */
+  man = &L.man[8 * (off < MANPTS ? off : 0)];
+  pk = lane < nact ? L.key[lane] : 0;
   if (kept > 0) {
     int cnt = 0;
     for (int j = lane; j < run_end; j++) {
@@ -928,11 +1088,12 @@ __device__ __forceinline__ int collide(const DevModel* m, LDS& L, int lane) {
     }
   }
   WSYNC();
+  }
   /* Contacts leave in solver order (stable partition of the manifold order, the oracle's collide() explains it): key 2 * (touches both
    * halves of the velocity layout) + (arm link against a movable body).  A lane's points all belong to one object pair, hence to one
    * key; exclusive prefixes of the per-lane counts (0..4) per key come from ballots. */
   int cls = 0, key = 0;
-  if (kept > 0) { const int pk = L.key[lane]; cls = (pk >> 20) & 3; key = 2 * (cls == 2 ? 1 : 0) + ((pk >> 22) & 1); }      /* (narrowphase_coop wrote the pair's classes into its key) */
+  if (kept > 0) { cls = (pk >> 20) & 3; key = 2 * (cls == 2 ? 1 : 0) + ((pk >> 22) & 1); }      /* (narrowphase_coop wrote the pair's classes into its key) */
   int before = 0, total = 0;          /* points of smaller keys + points of my key in earlier lanes */
   {
     unsigned long long mk[4];
@@ -957,7 +1118,7 @@ __device__ __forceinline__ int collide(const DevModel* m, LDS& L, int lane) {
     L.conn[3 * o] = c0.w; L.conn[3 * o + 1] = c1.x; L.conn[3 * o + 2] = c1.y;
     L.cond[o] = c1.z;
     L.cona[o] = ab & 255; L.conb[o] = (ab >> 8) & 255; L.conk[o] = cls;
-    L.conmu[o] = L.pmu[ab >> 16];
+    L.conmu[o] = m->col_friction[ab & 255] * m->col_friction[(ab >> 8) & 255];      /* (= L.pmu of the point's pair) */
   }
   WSYNC();
   PCLK(10)
@@ -1455,14 +1616,14 @@ __device__ float solve_rows(const DevModel* m, LDS& L, int lane, int nsmall_, in
 }
 
 /* ------------------------------------------------------------------ one stepSimulation() */
-__device__ void substep(const DevModel* m, EnvLds& L, int lane) {
+__device__ void substep(const DevModel* m, EnvLds& L, int lane, int env) {
   int n = m->n_arm;
   fk_bodies(m, L, lane);
   __syncthreads();
   joint_subspaces(m, L, lane);
   collider_aabbs(m, L, lane);
   __syncthreads();
-  int ncon = collide(m, L, lane);
+  int ncon = collide(m, L, lane, env);
   arm_dynamics(m, L, lane);
   unconstrained_velocities(m, L, lane);
   int nsmall = build_small_rows(m, L, lane);
@@ -2011,7 +2172,7 @@ __global__ void __launch_bounds__(64, RP_WAVES_PER_EU) k_step(const DevModel* __
   float a8[8];
   load_action(m, action, env, a8);
   ChainQ tp = perform_action(m, L, lane, a8);
-  for (int s = 0; s < K_NSUB; s++) substep(m, L, lane);
+  for (int s = 0; s < K_NSUB; s++) substep(m, L, lane, env);
   calc_state(m, L, lane);
   write_outputs(m, L, lane, env, out);
   if (out.target_poses && lane == 0)
@@ -2176,7 +2337,7 @@ __global__ void __launch_bounds__(64, RP_WAVES_PER_EU) k_reset(const DevModel* _
     } else {
       for (int depth = 0; depth < 9; depth++) {
         reset_sample_objects(m, L, lane, seed, genv);
-        for (int i = 0; i < K_NSETTLE; i++) substep(m, L, lane);
+        for (int i = 0; i < K_NSETTLE; i++) substep(m, L, lane, env);
         if (!reset_objects_out_of_bounds(m, L)) break;
       }
       reset_sample_arm_target(m, L, lane, seed, genv, tx);
@@ -2279,12 +2440,22 @@ __global__ void k_reward(const DevModel* __restrict__ m, const float* __restrict
   r[i] = compute_reward(m, ag + (size_t)i * m->n_ag, dg + (size_t)i * m->n_ag, force_sparse != 0);
 }
 
-/* state record copies (rp_get_state / rp_set_state with broadcast) */
-__global__ void k_copy_state(float* __restrict__ dst, const float* __restrict__ src, int N, int src_count) {
+/* state copies (rp_get_state / rp_set_state with broadcast): a row of the caller's buffer is the env's record followed by its contact cache (nc floats, 0 under
+ * RP_CFG_STATELESS_CONTACTS) */
+__global__ void k_copy_state(float* __restrict__ rec, float* __restrict__ cache, const float* __restrict__ src, int N, int src_count, int nc) {
+  const size_t W = RP_REC_FLOATS + (size_t)nc;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (size_t)N * RP_REC_FLOATS) return;
-  size_t env = i / RP_REC_FLOATS, k = i % RP_REC_FLOATS;
-  dst[i] = src[(src_count == 1 ? 0 : env) * RP_REC_FLOATS + k];
+  if (i >= (size_t)N * W) return;
+  const size_t env = i / W, k = i % W;
+  const float v = src[(src_count == 1 ? 0 : env) * W + k];
+  if (k < RP_REC_FLOATS) rec[env * RP_REC_FLOATS + k] = v; else cache[env * nc + (k - RP_REC_FLOATS)] = v;
+}
+__global__ void k_read_state(float* __restrict__ dst, const float* __restrict__ rec, const float* __restrict__ cache, int N, int nc) {
+  const size_t W = RP_REC_FLOATS + (size_t)nc;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)N * W) return;
+  const size_t env = i / W, k = i % W;
+  dst[i] = k < RP_REC_FLOATS ? rec[env * RP_REC_FLOATS + k] : cache[env * nc + (k - RP_REC_FLOATS)];
 }
 
 /* ------------------------------------------------------------------ split pipeline for rp_step
@@ -2416,7 +2587,7 @@ static_assert(W3_A % 4 == 0 && W3_ROWS % 4 == 0 && W3_ROFF % 4 == 0 && AOUT_FLOA
 #define PREP_THREADS 128
 __device__ __forceinline__ void prep2_body(const DevModel* __restrict__ m, const float* __restrict__ state, float* __restrict__ ws, int env0, int N,
                                            const int* __restrict__ sort_cnt, int* __restrict__ sort_cnt_next, const int* __restrict__ sort_slot, int* __restrict__ pair_env,
-                                           const int* __restrict__ member, const int bid) {
+                                           const int* __restrict__ member, const int bid, const int* __restrict__ cache_env = nullptr) {
   __shared__ PrepLds L;
   const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
   int env = env0 + bid;
@@ -2447,7 +2618,7 @@ __device__ __forceinline__ void prep2_body(const DevModel* __restrict__ m, const
     collider_aabbs(m, L, lane);
     WSYNC();
     PCLK(1)
-    int ncon = collide(m, L, lane);
+    int ncon = collide(m, L, lane, cache_env ? cache_env[env] : env);      /* (rp_reset settles in a dense scratch range: the contact cache stays the env's own) */
     ncon = uni(ncon);
 #ifdef RP_ABL_MAXCON    /* timing ablation: drop contacts beyond RP_ABL_MAXCON to expose the tail effect in k_solve2 */
     if (ncon > RP_ABL_MAXCON) ncon = RP_ABL_MAXCON;
@@ -2570,7 +2741,7 @@ __device__ __forceinline__ void prep2_body(const DevModel* __restrict__ m, const
                    const int* __restrict__ sort_cnt, int* __restrict__ sort_cnt_next, const int* __restrict__ sort_slot, int* __restrict__ pair_env, \
                    const int* __restrict__ member
 __global__ void __launch_bounds__(PREP_THREADS, RP_PREP_WAVES) k_prep2(PREP2_ARGS) { prep2_body(m, state, ws, env0, N, sort_cnt, sort_cnt_next, sort_slot, pair_env, member, blockIdx.x); }
-__global__ void __launch_bounds__(PREP_THREADS, RP_PREP_WAVES) k_settle_prep(PREP2_ARGS) { prep2_body(m, state, ws, env0, N, sort_cnt, sort_cnt_next, sort_slot, pair_env, member, blockIdx.x); }
+__global__ void __launch_bounds__(PREP_THREADS, RP_PREP_WAVES) k_settle_prep(PREP2_ARGS, const int* __restrict__ cache_env) { prep2_body(m, state, ws, env0, N, sort_cnt, sort_cnt_next, sort_slot, pair_env, member, blockIdx.x, cache_env); }
 /* First substep of a step: the action kernel and the first k_prep2 in ONE launch.  Nothing k_prep2 builds depends on the new motor
  * targets except the motor rows themselves (v*, M^-1, contacts and limit rows see q and qd only), so the nab action blocks (first in
  * the grid: they are the long pole, ~80 dependent IK iterations) and the prep blocks of the same envs run side by side instead of
@@ -3442,7 +3613,7 @@ __global__ void __launch_bounds__(64) k_debug_substep(const DevModel* __restrict
   joint_subspaces(m, L, lane);
   collider_aabbs(m, L, lane);
   __syncthreads();
-  int ncon = collide(m, L, lane);
+  int ncon = collide(m, L, lane, env);
   if (env == dbg_env && lane == 0) {
     dbg[0] = (float)ncon;
     for (int c = 0; c < ncon; c++) {

@@ -21,6 +21,7 @@ struct rp_sim {
   float* ws;               /* [N][W3_FLOATS] constraint-row workspace of the split step pipeline */
   float* dbg;
   float* hullv;            /* convex-hull vertices of the arm's collision meshes (DevModel.hullv points here) */
+  float* pmcache;          /* the contact caches, [N][PMC_FLOATS] (DevModel.pmcache points here); nullptr under RP_CFG_STATELESS_CONTACTS */
   int* sort_cnt;           /* [2][RP_MAX_GROUPS][SORT_BINS] load-class histograms for pairing envs in k_solve2 (double-buffered) */
   int* sort_slot;          /* [N] per env: (bin << 16) | rank inside the bin, from the latest k_solve2 */
   int* pair_env;           /* [N] per group range: env ids sorted by load class, heaviest first (k_solve2 pairs neighbours) */
@@ -94,7 +95,7 @@ const char* rp_version(void) { return "rp_playroom 0.2 (gfx950) build " RP_BUILD
 
 static void destroy_handle(rp_sim* h) {        /* frees whatever a (possibly partial) handle owns; hipFree(nullptr) etc. are no-ops */
   if (!h) return;
-  hipFree(h->hullv); hipFree(h->dev_model); hipFree(h->state); hipFree(h->ws); hipFree(h->dbg); hipFree(h->sort_cnt); hipFree(h->sort_slot); hipFree(h->pair_env); hipFree(h->member[0]); hipFree(h->member[1]);
+  hipFree(h->hullv); hipFree(h->pmcache); hipFree(h->dev_model); hipFree(h->state); hipFree(h->ws); hipFree(h->dbg); hipFree(h->sort_cnt); hipFree(h->sort_slot); hipFree(h->pair_env); hipFree(h->member[0]); hipFree(h->member[1]);
   hipFree(h->rc_tab); hipFree(h->rc_cnt); hipFree(h->rc_ee);
   hipFree(h->rs_state); hipFree(h->rs_idx); hipFree(h->rs_meta); hipFree(h->rs_count); hipFree(h->rs_sort_cnt); hipFree(h->rs_sort_slot); hipFree(h->rs_pair);
   if (h->rs_count_host) hipHostFree(h->rs_count_host);
@@ -197,6 +198,11 @@ int rp_create(const rp_config* cfg, rp_handle* out) {
       for (int c = 0; c < RP_MAX_COL; c++) { d->hull_off[c] = hoff[c]; d->hull_cnt[c] = off ? 0 : hcnt[c]; }
     }
     d->hullv = h->hullv;
+    if (!(cfg->flags & RP_CFG_STATELESS_CONTACTS) && !(cfg->flags & RP_CFG_CONTACT_MARGIN) && getenv("RP_STATELESS") == nullptr) {      /* (a uniform contact margin is a stateless-model study: it keeps the stateless contacts) */
+      CREATE_CHK(hipMalloc((void**)&h->pmcache, (size_t)N * PMC_FLOATS * sizeof(float)));
+      CREATE_CHK(hipMemset(h->pmcache, 0, (size_t)N * PMC_FLOATS * sizeof(float)));
+      d->persist = 1; d->pmcache = h->pmcache;
+    }
     if (getenv("RP_NO_SPIN") != nullptr)                     /* timing / model studies only: no torsional friction rows */
       for (int c = 0; c < RP_MAX_COL; c++) d->col_spin[c] = 0.f;
   }
@@ -284,7 +290,7 @@ static int reset_split(rp_handle h, const uint8_t* mask, const rp_out* out, hipS
     hipLaunchKernelGGL(k_sort_init, dim3((max(M, SORT_BINS) + 255) / 256), dim3(256), 0, s, cnt[0], h->rs_sort_slot, 0, M);
     int par = 0;
     for (int i = 0; i < K_NSETTLE; i++) {
-      hipLaunchKernelGGL(k_settle_prep, dim3(M), dim3(PREP_THREADS), 0, s, h->dev_model, h->rs_state, h->ws, 0, M, cnt[par], cnt[par ^ 1], h->rs_sort_slot, h->rs_pair, (const int*)nullptr);
+      hipLaunchKernelGGL(k_settle_prep, dim3(M), dim3(PREP_THREADS), 0, s, h->dev_model, h->rs_state, h->ws, 0, M, cnt[par], cnt[par ^ 1], h->rs_sort_slot, h->rs_pair, (const int*)nullptr, (const int*)h->rs_idx);
       hipLaunchKernelGGL(k_settle_solve, dim3((M + 2 * SOLVE_WAVES - 1) / (2 * SOLVE_WAVES)), dim3(64 * SOLVE_WAVES), 0, s, h->dev_model, h->rs_state, h->ws, 0, M, h->rs_pair, cnt[par ^ 1], h->rs_sort_slot, h->debug_flags);
       par ^= 1;
     }
@@ -486,12 +492,15 @@ static int reward_impl(rp_handle h, const float* ag, const float* dg, float* r, 
 int rp_compute_reward(rp_handle h, const float* ag, const float* dg, float* r, int32_t m, void* stream) { return reward_impl(h, ag, dg, r, m, stream, 0); }
 int rp_compute_reward_sparse(rp_handle h, const float* ag, const float* dg, float* r, int32_t m, void* stream) { return reward_impl(h, ag, dg, r, m, stream, 1); }
 
-size_t rp_state_bytes(rp_handle h) { (void)h; return RP_REC_FLOATS * sizeof(float); }
+size_t rp_state_bytes(rp_handle h) { return (RP_REC_FLOATS + (h && h->pmcache ? PMC_FLOATS : 0)) * sizeof(float); }
 
 int rp_get_state(rp_handle h, void* dst, void* stream) {
   if (!h || !dst) return RP_ERR_ARG;
   DevGuard guard(h->cfg.device);
-  HIPCHK(h, hipMemcpyAsync(dst, h->state, (size_t)h->cfg.num_envs * RP_REC_FLOATS * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  const int N = h->cfg.num_envs, nc = h->pmcache ? PMC_FLOATS : 0;
+  const size_t total = (size_t)N * (RP_REC_FLOATS + nc);
+  hipLaunchKernelGGL(k_read_state, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (float*)dst, h->state, h->pmcache, N, nc);
+  HIPCHK(h, hipGetLastError());
   return RP_OK;
 }
 
@@ -500,8 +509,9 @@ int rp_set_state(rp_handle h, const void* src, int32_t src_env_count, void* stre
   DevGuard guard(h->cfg.device);
   int N = h->cfg.num_envs;
   if (src_env_count != 1 && src_env_count != N) { snprintf(h->err, 256, "rp_set_state: src_env_count %d is neither 1 nor %d", src_env_count, N); return RP_ERR_STATE_SIZE; }
-  size_t total = (size_t)N * RP_REC_FLOATS;
-  hipLaunchKernelGGL(k_copy_state, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h->state, (const float*)src, N, src_env_count);
+  const int nc = h->pmcache ? PMC_FLOATS : 0;
+  const size_t total = (size_t)N * (RP_REC_FLOATS + nc);
+  hipLaunchKernelGGL(k_copy_state, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h->state, h->pmcache, (const float*)src, N, src_env_count, nc);
   HIPCHK(h, hipGetLastError());
   return RP_OK;
 }

@@ -28,7 +28,7 @@ WIDE_STATE_LAYOUT = {'q': (0, 9), 'qd': (9, 18), 'free0': (18, 31), 'free1': (31
 class VecPlayEnv:
     def __init__(self, env_id, num_envs, device=0, seed=0, env_offset=0, action_type=None, goal_range_low=None, goal_range_high=None,
                  obj_lower_bound=None, obj_upper_bound=None, env_range_high=None, sparse_rew_thresh=None, sparse=True,
-                 contact_margin=None):
+                 contact_margin=None, persistent_manifolds=True):
         """The keyword arguments after env_offset are the constructor kwargs of the reference's env classes that reach the
         simulation (envList.py -> environments.py:64-67); None keeps what the id registers.  contact_margin: rp_config."""
         if env_id not in _lib.ENV_KINDS:
@@ -68,6 +68,8 @@ class VecPlayEnv:
         if contact_margin is not None:
             flags |= _lib.CFG_CONTACT_MARGIN
             cfg.contact_margin = float(contact_margin)
+        if not persistent_manifolds:
+            flags |= _lib.CFG_STATELESS_CONTACTS      # rp_config_flags: no contact cache, points rebuilt every substep (round 3's first model)
         cfg.flags = flags
         self.h = C.c_void_p()
         _lib.check(self.lib, None, self.lib.rp_create(C.byref(cfg), C.byref(self.h)), 'rp_create')
@@ -254,9 +256,15 @@ class VecPlayEnv:
         return s
 
     def set_state(self, s):
-        s = s.to(device=self.device, dtype=torch.float32).contiguous()
+        """s: [N or 1, rp_state_bytes / 4] as get_state returns it - or only the state records ([.., 128], e.g. built from an oracle's state): the envs then
+        start without contact history (an all-zero contact cache)"""
+        s = s.to(device=self.device, dtype=torch.float32)
         if s.dim() == 1:
             s = s[None]
+        n = self.lib.rp_state_bytes(self.h) // 4
+        if s.shape[1] < n:
+            s = torch.cat([s, torch.zeros((s.shape[0], n - s.shape[1]), dtype=torch.float32, device=self.device)], 1)
+        s = s.contiguous()
         _lib.check(self.lib, self.h, self.lib.rp_set_state(self.h, C.c_void_p(s.data_ptr()), s.shape[0], self._stream()), 'rp_set_state')
 
     def replay(self, o0, actions, keys=('obs_quat', 'achieved_goal')):

@@ -185,27 +185,32 @@ def test_with_the_remaining_differences_off_it_is_the_fast_model():
             np.testing.assert_allclose(a.get_state()[:a.n_arm], b.get_state()[:a.n_arm], atol=tol * 5, rtol=0)
 
 
-def test_on_ur5reach_the_fast_model_is_the_reference_step_without_persistence():
+def test_on_ur5reach_the_fast_model_is_the_reference_step():
     """what the shipped model took from the reference step in round 3 - row order and limit rule, hull vertices against static boxes, the box-box detector's
-    point order, per-body lever arms, torsional friction - leaves ONE difference on UR5Reach-v0: persistent manifolds.  With persistence switched off the
-    frozen reference step and the fast model walk the same 200-step trajectories to 1e-6, gripper-on-table contacts included (tools/model_divergence.py:
-    row 'B -persist' = row 'A default')"""
+    point order, per-body lever arms, torsional friction, persistent manifolds - leaves nothing on UR5Reach-v0: the frozen reference step (default flags) and
+    the fast model walk the same 200-step trajectories to 1e-5, gripper-on-table contacts included; and so do the two without their contact caches (reference
+    step with persistence switched off, fast model with RPO_RULE_PERSIST off) to 1e-6: the cache is one difference, switched on both sides alike
+    (tools/model_divergence.py: rows 'A default', 'B -persist' / 'A -persist')"""
     import os
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
     import model_divergence as md
     contact_substeps = 0
     for e in (0, 4, 7, 9):
-        ref = OracleEnv('R', seed=77, env_index=e, bullet_ref=True, ref_flags=oracle.REF_DEFAULT & ~oracle.REF_FLAGS['persist'])
-        ref.reset()
-        s0 = ref.get_state()
         acts = md.random_actions('R', 200, np.random.default_rng(1000 + e))
-        qb, _ = md.rollout(ref, 'R', 'random', 200, acts, s0)
-        a = OracleEnv('R', seed=77, env_index=e)
-        qa, _ = md.rollout(a, 'R', 'random', 200, acts, s0)
-        assert np.abs(qa - qb).max() < 1e-6, (e, np.abs(qa - qb).max())
-        contact_substeps += a.lib.rpo_contact_substeps(a.h)
-    assert contact_substeps > 100
+        s0 = None
+        for flags, rule, tol in ((oracle.REF_DEFAULT, None, 1e-5), (oracle.REF_DEFAULT & ~oracle.REF_FLAGS['persist'], 503 & ~256, 1e-6)):
+            ref = OracleEnv('R', seed=77, env_index=e, bullet_ref=True, ref_flags=flags)
+            if s0 is None:
+                ref.reset()
+                s0 = ref.get_state()
+                ref = OracleEnv('R', seed=77, env_index=e, bullet_ref=True, ref_flags=flags)      # (both sides start without contact history)
+            qb, _ = md.rollout(ref, 'R', 'random', 200, acts, s0)
+            a = OracleEnv('R', seed=77, env_index=e, **({} if rule is None else dict(rule=rule)))
+            qa, _ = md.rollout(a, 'R', 'random', 200, acts, s0)
+            assert np.abs(qa - qb).max() < tol, (e, flags, np.abs(qa - qb).max())
+            contact_substeps += a.lib.rpo_contact_substeps(a.h)
+    assert contact_substeps > 200
 
 
 def test_default_flags_are_everything_but_warm_starting():

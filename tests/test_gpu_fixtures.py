@@ -149,19 +149,20 @@ def test_panda_pick_grasp_and_lift():
     soft <contact> pads, the finger gear, arm-against-block rows in the solver's folded slots).  Approach and closing (60 steps): every step
     of every env against the fp32 oracle inside the running fp32 / fp64 sensitivity envelope.  The lift itself is chaotic (DESIGN.md
     section 2: the fp32 and the fp64 oracle part ways by centimetres too, and which envs end with the block in the air differs between any two
-    runs), so it is judged by its outcome: the device holds the block in the air in as many of the envs as the four CPU followers
-    (tolerances.Followers: fp64, fp32, two nudged fp32 runs) do, give or take one."""
+    runs), so it is judged by its outcome: the device holds the block in the air in as many of the envs as the eight CPU followers
+    (tolerances.Followers: fp64, fp32, six nudged fp32 runs) do, give or take one."""
     from oracle import OracleEnv
     from roboticsplayroompybullet_amd import VecPlayEnv
     n, seed = 6, 3
     env = VecPlayEnv('pandaPick-v0', n, seed=seed)
     obs = env.reset()
-    fol = [Followers('P', seed, e) for e in range(n)]
+    fol = [Followers('P', seed, e, extra=6) for e in range(n)]
     ob32 = [f.reset()[0] for f in fol]
     for e in range(n):
         assert (np.abs(obs['obs_quat'][e].cpu().numpy() - ob32[e]['obs_quat']) <= obs_atol('P', 13, 1e-4, rest=True)).all()
     worst, folded = 0.0, 0
     gap = [np.zeros(13) for _ in range(n)]
+    kicked = np.zeros(n, bool)
     for t in range(110):
         a = np.zeros((n, 7))
         for e in range(n):
@@ -179,6 +180,10 @@ def test_panda_pick_grasp_and_lift():
                 continue
             # trajectories that have separated need not meet again: the envelope is the running maximum of the fp32 followers' distance from the fp64 one
             gap[e] = np.maximum(gap[e], np.max([np.abs(x[0]['obs_quat'] - r64[0]['obs_quat']) for x in allres[1:]], axis=0))
+            if gap[e][10:13].max() > 0.1:                   # a finger landed on the block's edge and the CPU runs themselves disagree about the kick by > 0.1 m/s:
+                kicked[e] = True                            # this env has branched, it is judged by the outcome only
+            if kicked[e]:
+                continue
             tol = np.maximum(1e-3, 3 * gap[e])
             tol[3:6] = np.maximum(tol[3:6], 1e-2)           # the EE's velocity feels the fingers' limit chatter while they are commanded open past their limits (tests/tolerances.py)
             tol[6] = max(tol[6], obs_atol('P', 13, 1e-3)[6])
@@ -194,9 +199,10 @@ def test_panda_pick_grasp_and_lift():
     lifted = (zs > 0.05).sum(axis=0)                      # per follower: in how many envs it holds the block in the air
     n_dev = int((z_dev > 0.05).sum())
     assert folded > 0, 'the scenario must exercise arm-against-block rows'
+    assert kicked.sum() <= n // 3, kicked
     assert lifted.max() >= 1, zs
     assert lifted.min() - 1 <= n_dev <= lifted.max() + 1, (z_dev, zs)
-    print('panda pick scenario: worst arm error / tolerance before the lift = %.2f, lifted %d of %d (the four CPU followers: %s)' % (worst, n_dev, n, lifted))
+    print('panda pick scenario: worst arm error / tolerance before the lift = %.2f, lifted %d of %d (the eight CPU followers: %s)' % (worst, n_dev, n, lifted))
 
 
 def test_fixture_values_through_calc_state_and_reward(golden):

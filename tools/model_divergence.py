@@ -10,7 +10,8 @@ onto the block, close, lift: the contact-rich case) - N envs are reset once by m
     block   max over steps of |block position A - B| in metres
 as median / 90th percentile / max over the envs.  Rows:
     A default      the shipped model: Bullet's row order and limit rule, hull vertices against static boxes, arm boxes overlap-only, box-box points in the
-                   detector's order, per-body lever arms, torsional friction rows, per-pair contact margins = Bullet's relative breaking thresholds
+                   detector's order, per-body lever arms, torsional friction rows, persistent manifolds (a uniform margin `A m=...` switches those off: it is a study
+                   of the stateless contacts)
     A round 2      last round's model (rule 0); A -x: the shipped model with one of its round-3 features off
     A m=...        the same model with one uniform contact margin (0, 5 mm = round 1's choice, 20 mm = gContactBreakingThreshold taken absolute)
     B -flag        mode B with one of its differences switched off (what each Bullet feature is worth, measured inside mode B)
@@ -84,9 +85,11 @@ def main():
     args = ap.parse_args()
     D = oracle.REF_DEFAULT
     # the shipped model's rule bits (rp_oracle.c RPO_RULE_*): 1 Bullet's row order, 2 violated-only limits, 4 hull vertices against static boxes, 16 arm boxes overlap-only,
-    # 32 box-box points in the detector's order, 64 per-body lever arms, 128 torsional friction rows
-    variants = [('A default (shipped)', dict()), ('A round 2 (rule 0)', dict(rule=0)), ('A -order -limit', dict(rule=247 & ~3)), ('A -hull', dict(rule=247 & ~4)), ('A -boxoverlap', dict(rule=247 & ~16)),
-                ('A -boxorder', dict(rule=247 & ~32)), ('A -lever', dict(rule=247 & ~64)), ('A -spin', dict(rule=247 & ~128)), ('A -boxorder -lever -spin', dict(rule=23)),
+    # 32 box-box points in the detector's order, 64 per-body lever arms, 128 torsional friction rows, 256 persistent manifolds
+    ALL = 503
+    variants = [('A default (shipped)', dict()), ('A round 2 (rule 0)', dict(rule=0)), ('A -order -limit', dict(rule=ALL & ~3)), ('A -hull', dict(rule=ALL & ~4)),
+                ('A -boxorder', dict(rule=ALL & ~32)), ('A -lever', dict(rule=ALL & ~64)), ('A -spin', dict(rule=ALL & ~128)), ('A -persist', dict(rule=ALL & ~256)),
+                ('A -persist -boxorder -lever -spin', dict(rule=23)), ('A -persist -boxoverlap', dict(rule=ALL & ~256 & ~16)),
                 ('A m=0', dict(margin=0.0)), ('A m=5mm', dict(margin=0.005)), ('A m=20mm', dict(margin=0.02))]
     for name, bit in oracle.REF_FLAGS.items():
         if name == 'warm':
