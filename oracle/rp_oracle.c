@@ -574,45 +574,66 @@ static void collide_persistent(rpo_env* e) {
     e->pm[e->npm].oa = act_oa[k]; e->pm[e->npm].ob = act_ob[k]; e->pm[e->npm].n = 0; e->pm[e->npm].thr = act_thr[k];
     e->npm++;
   }
-  /* 3. */
-  for (int ci = 0; ci < ncand; ci++) {
-    const contact* c = &cand[ci];
-    const int oa = m->col_obj[c->ca], ob = m->col_obj[c->cb];
-    int mi = -1;
-    for (int i = 0; i < e->npm; i++) if (e->pm[i].oa == oa && e->pm[i].ob == ob) mi = i;
-    if (mi < 0) continue;                                  /* no room for its manifold (PM_MAX) */
-    const real thr = e->pm[mi].thr;
-    if (c->dist > thr) continue;
-    real pA[3], pB[3], lA[3], lB[3];
-    v3cpy(pA, c->p); v3axpy(pA, (real)0.5 * c->dist, c->n);
-    v3cpy(pB, c->p); v3axpy(pB, (real)-0.5 * c->dist, c->n);
-    pm_to_local(e, m->col_body[c->ca], pA, lA);
-    pm_to_local(e, m->col_body[c->cb], pB, lB);
-    int slot = -1; real shortest = thr * thr;
-    for (int i = 0; i < e->pm[mi].n; i++) {
-      real d[3]; v3sub(d, e->pm[mi].pt[i].lA, lA);
-      const real dd = v3dot(d, d);
-      if (dd < shortest) { shortest = dd; slot = i; }
-    }
-    if (slot < 0) {
-      if (e->pm[mi].n < 4) slot = e->pm[mi].n++;
-      else {                                                 /* sortCachedPoints on the local-A points */
-        int deepest = -1; real maxpen = c->dist;
-        for (int i = 0; i < 4; i++) if (e->pm[mi].pt[i].dist < maxpen) { deepest = i; maxpen = e->pm[mi].pt[i].dist; }
-        real res[4] = {0, 0, 0, 0}, u[3], v[3], cr[3];
-#define PM_LA(i) e->pm[mi].pt[i].lA
-        if (deepest != 0) { v3sub(u, lA, PM_LA(1)); v3sub(v, PM_LA(3), PM_LA(2)); v3cross(cr, u, v); res[0] = v3dot(cr, cr); }
-        if (deepest != 1) { v3sub(u, lA, PM_LA(0)); v3sub(v, PM_LA(3), PM_LA(2)); v3cross(cr, u, v); res[1] = v3dot(cr, cr); }
-        if (deepest != 2) { v3sub(u, lA, PM_LA(0)); v3sub(v, PM_LA(3), PM_LA(1)); v3cross(cr, u, v); res[2] = v3dot(cr, cr); }
-        if (deepest != 3) { v3sub(u, lA, PM_LA(0)); v3sub(v, PM_LA(2), PM_LA(1)); v3cross(cr, u, v); res[3] = v3dot(cr, cr); }
-#undef PM_LA
-        slot = 0;
-        for (int i = 1; i < 4; i++) if (res[i] > res[slot]) slot = i;
+  /* 3.  First every candidate is matched against the cached points AS THEY ARE NOW, before any of this substep's candidates goes in (that is what makes the
+   * step parallel on the GPU: one lane per candidate): a candidate whose point on A lies within the threshold of a cached point's REPLACES the nearest
+   * such point - of several candidates on one slot the last in pair order stays.  The candidates that matched nothing (a contact in its first substep)
+   * then go in one after the other, btPersistentManifold::addManifoldPoint's way: replace the nearest point within the threshold (now including this
+   * substep's), else append, else (four already) take the place sortCachedPoints picks. */
+  {
+    int cmi[MAX_CANDIDATES], csl[MAX_CANDIDATES];
+    real clA[MAX_CANDIDATES][3], clB[MAX_CANDIDATES][3];
+    for (int ci = 0; ci < ncand; ci++) {
+      const contact* c = &cand[ci];
+      const int oa = m->col_obj[c->ca], ob = m->col_obj[c->cb];
+      cmi[ci] = -1; csl[ci] = -1;
+      for (int i = 0; i < e->npm; i++) if (e->pm[i].oa == oa && e->pm[i].ob == ob) cmi[ci] = i;
+      if (cmi[ci] < 0) continue;                           /* no room for its manifold (PM_MAX) */
+      const real thr = e->pm[cmi[ci]].thr;
+      if (c->dist > thr) { cmi[ci] = -1; continue; }
+      real pA[3], pB[3];
+      v3cpy(pA, c->p); v3axpy(pA, (real)0.5 * c->dist, c->n);
+      v3cpy(pB, c->p); v3axpy(pB, (real)-0.5 * c->dist, c->n);
+      pm_to_local(e, m->col_body[c->ca], pA, clA[ci]);
+      pm_to_local(e, m->col_body[c->cb], pB, clB[ci]);
+      real shortest = thr * thr;
+      for (int i = 0; i < e->pm[cmi[ci]].n; i++) {
+        real d[3]; v3sub(d, e->pm[cmi[ci]].pt[i].lA, clA[ci]);
+        const real dd = v3dot(d, d);
+        if (dd < shortest) { shortest = dd; csl[ci] = i; }
       }
     }
-    e->pm[mi].pt[slot].ca = c->ca; e->pm[mi].pt[slot].cb = c->cb;
-    v3cpy(e->pm[mi].pt[slot].lA, lA); v3cpy(e->pm[mi].pt[slot].lB, lB); v3cpy(e->pm[mi].pt[slot].n, c->n);
-    e->pm[mi].pt[slot].dist = c->dist;
+#define PM_PUT(mi, slot, ci) do { e->pm[mi].pt[slot].ca = cand[ci].ca; e->pm[mi].pt[slot].cb = cand[ci].cb; v3cpy(e->pm[mi].pt[slot].lA, clA[ci]); v3cpy(e->pm[mi].pt[slot].lB, clB[ci]); \
+                                   v3cpy(e->pm[mi].pt[slot].n, cand[ci].n); e->pm[mi].pt[slot].dist = cand[ci].dist; } while (0)
+    for (int ci = 0; ci < ncand; ci++) if (cmi[ci] >= 0 && csl[ci] >= 0) PM_PUT(cmi[ci], csl[ci], ci);
+    for (int ci = 0; ci < ncand; ci++) {
+      if (cmi[ci] < 0 || csl[ci] >= 0) continue;
+      const int mi = cmi[ci];
+      const real thr = e->pm[mi].thr;
+      int slot = -1; real shortest = thr * thr;
+      for (int i = 0; i < e->pm[mi].n; i++) {
+        real d[3]; v3sub(d, e->pm[mi].pt[i].lA, clA[ci]);
+        const real dd = v3dot(d, d);
+        if (dd < shortest) { shortest = dd; slot = i; }
+      }
+      if (slot < 0) {
+        if (e->pm[mi].n < 4) slot = e->pm[mi].n++;
+        else {                                               /* sortCachedPoints on the local-A points */
+          int deepest = -1; real maxpen = cand[ci].dist;
+          for (int i = 0; i < 4; i++) if (e->pm[mi].pt[i].dist < maxpen) { deepest = i; maxpen = e->pm[mi].pt[i].dist; }
+          real res[4] = {0, 0, 0, 0}, u[3], v[3], cr[3];
+#define PM_LA(i) e->pm[mi].pt[i].lA
+          if (deepest != 0) { v3sub(u, clA[ci], PM_LA(1)); v3sub(v, PM_LA(3), PM_LA(2)); v3cross(cr, u, v); res[0] = v3dot(cr, cr); }
+          if (deepest != 1) { v3sub(u, clA[ci], PM_LA(0)); v3sub(v, PM_LA(3), PM_LA(2)); v3cross(cr, u, v); res[1] = v3dot(cr, cr); }
+          if (deepest != 2) { v3sub(u, clA[ci], PM_LA(0)); v3sub(v, PM_LA(3), PM_LA(1)); v3cross(cr, u, v); res[2] = v3dot(cr, cr); }
+          if (deepest != 3) { v3sub(u, clA[ci], PM_LA(0)); v3sub(v, PM_LA(2), PM_LA(1)); v3cross(cr, u, v); res[3] = v3dot(cr, cr); }
+#undef PM_LA
+          slot = 0;
+          for (int i = 1; i < 4; i++) if (res[i] > res[slot]) slot = i;
+        }
+      }
+      PM_PUT(mi, slot, ci);
+    }
+#undef PM_PUT
   }
   /* 4. */
   {

@@ -28,13 +28,15 @@
 #define MAXACT 64            /* AABB-overlapping pairs examined per substep (shared cap with the oracle) */
 #define MAXT 4               /* torsional friction rows kept per env per substep (shared cap with the oracle): one per collider pair in contact whose links carry spinning_friction */
 #define MAXROWC (3 * MAXC + MAXT)
+static_assert(MAXACT <= 64 && NB_MAX <= 32, "a candidate record packs its pair index in 6 bits and its bodies in 5 bits each");
 /* persistent contact manifolds (DevModel.persist; oracle RPO_RULE_PERSIST, collide_persistent): the per-env contact cache.  Header: number of manifolds, 3 pad.
  * Manifold (PMC_MAN floats): object-pair key (objA * 256 + objB) | points | breaking threshold | flags of the pair (bits 16.. of LDS.key, rebuilt every substep)
- * | colliders of points 0, 1 (a | b << 8 | a' << 16 | b' << 24) | of points 2, 3 | 2 pad | 4 points x 10: point in A's body frame, in B's, normal, distance */
+ * | 4 pad | 4 points x PMC_PT: point in A's body frame, in B's, normal, distance, colliders (a | b << 8) */
 #define PM_MAX 11
 #define PMC_HDR 4
-#define PMC_MAN 48
-#define PMC_FLOATS (PMC_HDR + PM_MAX * PMC_MAN)      /* 532 */
+#define PMC_PT 11
+#define PMC_MAN (8 + 4 * PMC_PT)
+#define PMC_FLOATS (PMC_HDR + PM_MAX * PMC_MAN)      /* 576 */
 #define RP_MAX_GROUPS 16      /* env groups (streams) rp_step can cut the envs into */
 #define SORT_KEYS 64          /* load classes for pairing envs in k_solve2: 8 * min(folded slots, 7) + min((side-by-side slots - 1) / 2, 7) */
 #define SORT_REPS 8           /* histogram replicas (env & 7): one hot word would serialise ~4096 atomics at ~90 per us */
@@ -830,7 +832,7 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
     if (act && s < nst) {
       float* c = &L.cand[(off + s) * 8];
       *(float4*)c = make_float4(mine.p.x, mine.p.y, mine.p.z, mine.n.x);
-      *(float4*)(c + 4) = make_float4(mine.n.y, mine.n.z, mine.dist, __int_as_float(a | (b << 8) | (ai << 16)));      /* the record carries its two colliders and its pair */
+      *(float4*)(c + 4) = make_float4(mine.n.y, mine.n.z, mine.dist, __int_as_float(a | (b << 8) | (ai << 16) | (body_a << 22) | (body_b << 27)));      /* the record carries its two colliders, its pair (6 bits) and the two bodies (5 bits each) */
     }
     if (act && s == 0) L.candn[ai] = nst | (min(off, CANDMAX) << 8);
     WSYNC();       /* the scratch is reused by the next pass */
@@ -916,6 +918,7 @@ __device__ __forceinline__ int collide(const DevModel* m, LDS& L, int lane, int 
     float* g = m->pmcache + (size_t)env * PMC_FLOATS;
     for (int i = lane * 4; i < PMC_FLOATS; i += 256) *(float4*)&C[i] = *(const float4*)&g[i];
     WSYNC();
+    PCLK(21)
     int npm = uni(__float_as_int(C[0]));
     {                                                        /* (a) */
       const int mykey = lane < npm ? __float_as_int(C[PMC_HDR + PMC_MAN * lane]) : -1;
@@ -951,107 +954,173 @@ __device__ __forceinline__ int collide(const DevModel* m, LDS& L, int lane, int 
       npm = min(PM_MAX, npm + (int)__popcll(mnew));
       WSYNC();
     }
-    int cnt = 0, only = -1;
-    if (lane < npm) {
+    PCLK(22)
+    /* (c) one lane per CANDIDATE (at most CANDMAX = 64): its manifold, its two points in the bodies' frames, the nearest cached point within the threshold
+     * - among the points as they are now, before any candidate of this substep goes in (the oracle's rule: that is what makes this parallel).  A matched
+     * candidate replaces that point - of several on one slot the last in pair order (LDS max over the lane numbers) stays; the unmatched ones (a contact
+     * in its first substep: rare) go in afterwards, one after the other, in the lane of their manifold */
+    unsigned long long unmatched;
+    {
+      int ncand = 0;
+      if (lane < nact) { const int cn = L.candn[lane]; ncand = (cn >> 8) + (cn & 255); }
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) ncand = max(ncand, __shfl_xor(ncand, d));
+      const bool isc = lane < ncand;
+      const float* c = &L.cand[8 * (isc ? lane : 0)];
+      const V3 p = ld3(c), nr = mk3(c[3], c[4], c[5]);
+      const float dist = c[6];
+      const int abw = __float_as_int(c[7]);
+      const int objk = L.key[(abw >> 16) & 63] & 0xFFFF;
+      int mi = -1;
+      for (int jm = 0; jm < npm; jm++) if (__float_as_int(C[PMC_HDR + PMC_MAN * jm]) == objk) mi = jm;
+      if (!isc) mi = -1;
+      const float* M = &C[PMC_HDR + PMC_MAN * (mi >= 0 ? mi : 0)];
+      const float thr = M[2];
+      if (dist > thr) mi = -1;
+      const int n = __float_as_int(M[1]);
+      const int ba = (abw >> 22) & 31, bb = (abw >> 27) & 31;
+      const V3 lA = tmulv(ldm3(&L.xR[9 * ba]), p + nr * (0.5f * dist) - ld3(&L.xp[3 * ba]));
+      const V3 lB = tmulv(ldm3(&L.xR[9 * bb]), p - nr * (0.5f * dist) - ld3(&L.xp[3 * bb]));
+      int sl = -1; float shortest = thr * thr;
+      for (int q = 0; q < 4; q++) {
+        const V3 d = ld3(&M[8 + PMC_PT * q]) - lA;
+        const float dd = dot(d, d);
+        if (q < n && dd < shortest) { shortest = dd; sl = q; }
+      }
+      if (lane < 4 * PM_MAX) C[PMC_HDR + PMC_MAN * (lane >> 2) + 4 + (lane & 3)] = 0.f;      /* slot owners (header pad): candidate number + 1, 0 = none (no NaN patterns in a state row) */
+      WSYNC();
+      const bool hit = mi >= 0 && sl >= 0;
+      int* own = (int*)&C[PMC_HDR + PMC_MAN * (hit ? mi : 0) + 4 + (hit ? sl : 0)];
+      if (hit) atomicMax(own, lane + 1);
+      WSYNC();
+      if (hit && *own == lane + 1) {
+        float* P = &C[PMC_HDR + PMC_MAN * mi + 8 + PMC_PT * sl];
+        st3(P, lA); st3(P + 3, lB); st3(P + 6, nr); P[9] = dist; P[10] = __int_as_float(abw & (int)0xFFC0FFFF);      /* colliders and bodies (the pair index is of this substep only) */
+      }
+      unmatched = __ballot(mi >= 0 && sl < 0);
+      WSYNC();
+    }
+    if (unmatched != 0ull && lane < npm) {                   /* (rare) lane i adds the unmatched candidates of manifold i, one after the other */
       float* M = &C[PMC_HDR + PMC_MAN * lane];
       const int key = __float_as_int(M[0]);
       int n = __float_as_int(M[1]);
       const float thr = M[2];
-      unsigned cw0 = __float_as_uint(M[4]), cw1 = __float_as_uint(M[5]);      /* colliders of the four points, 16 bits each */
-      auto getc = [&](int q) { return (q < 2 ? (cw0 >> (16 * q)) : (cw1 >> (16 * (q - 2)))) & 0xFFFFu; };
-      auto setc = [&](int q, unsigned v) { if (q < 2) cw0 = (cw0 & ~(0xFFFFu << (16 * q))) | (v << (16 * q)); else cw1 = (cw1 & ~(0xFFFFu << (16 * (q - 2)))) | (v << (16 * (q - 2))); };
-      for (int k = 0; k < nact; k++) {                       /* (c) */
-        if ((L.key[k] & 0xFFFF) != key) continue;
-        const int cn = L.candn[k];
-        for (int i = 0; i < (cn & 255); i++) {
-          const float* c = &L.cand[((cn >> 8) + i) * 8];
-          const V3 p = ld3(c), nr = mk3(c[3], c[4], c[5]);
-          const float dist = c[6];
-          const int ab = __float_as_int(c[7]) & 0xFFFF;
-          if (dist > thr) continue;
-          const int ba = m->col_body[ab & 255], bb = m->col_body[ab >> 8];
-          const V3 lA = tmulv(ldm3(&L.xR[9 * ba]), p + nr * (0.5f * dist) - ld3(&L.xp[3 * ba]));
-          const V3 lB = tmulv(ldm3(&L.xR[9 * bb]), p - nr * (0.5f * dist) - ld3(&L.xp[3 * bb]));
-          int sl = -1; float shortest = thr * thr;
-          for (int q = 0; q < n; q++) { const V3 d = ld3(&M[8 + 10 * q]) - lA; const float dd = dot(d, d); if (dd < shortest) { shortest = dd; sl = q; } }
-          if (sl < 0) {
-            if (n < 4) sl = n++;
-            else {                                           /* btPersistentManifold::sortCachedPoints on the local-A points */
-              int deepest = -1; float maxpen = dist;
-              for (int q = 0; q < 4; q++) if (M[8 + 10 * q + 9] < maxpen) { deepest = q; maxpen = M[8 + 10 * q + 9]; }
-              const V3 q0 = ld3(&M[8]), q1 = ld3(&M[18]), q2 = ld3(&M[28]), q3 = ld3(&M[38]);
-              float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f; V3 cr;
-              if (deepest != 0) { cr = cross(lA - q1, q3 - q2); r0 = dot(cr, cr); }
-              if (deepest != 1) { cr = cross(lA - q0, q3 - q2); r1 = dot(cr, cr); }
-              if (deepest != 2) { cr = cross(lA - q0, q3 - q1); r2 = dot(cr, cr); }
-              if (deepest != 3) { cr = cross(lA - q0, q2 - q1); r3 = dot(cr, cr); }
-              sl = 0; float rb = r0;
-              if (r1 > rb) { rb = r1; sl = 1; }
-              if (r2 > rb) { rb = r2; sl = 2; }
-              if (r3 > rb) { rb = r3; sl = 3; }
-            }
+      for (unsigned long long todo = unmatched; todo != 0ull; todo &= todo - 1ull) {
+        const int ci = __ffsll((long long)todo) - 1;
+        const float* c = &L.cand[8 * ci];
+        const int abw = __float_as_int(c[7]);
+        if ((L.key[(abw >> 16) & 63] & 0xFFFF) != key) continue;
+        const V3 p = ld3(c), nr = mk3(c[3], c[4], c[5]);
+        const float dist = c[6];
+        const int ba = (abw >> 22) & 31, bb = (abw >> 27) & 31;
+        const V3 lA = tmulv(ldm3(&L.xR[9 * ba]), p + nr * (0.5f * dist) - ld3(&L.xp[3 * ba]));
+        const V3 lB = tmulv(ldm3(&L.xR[9 * bb]), p - nr * (0.5f * dist) - ld3(&L.xp[3 * bb]));
+        int sl = -1; float shortest = thr * thr;
+        for (int q = 0; q < n; q++) { const V3 d = ld3(&M[8 + PMC_PT * q]) - lA; const float dd = dot(d, d); if (dd < shortest) { shortest = dd; sl = q; } }
+        if (sl < 0) {
+          if (n < 4) sl = n++;
+          else {                                             /* btPersistentManifold::sortCachedPoints on the local-A points */
+            int deepest = -1; float maxpen = dist;
+            for (int q = 0; q < 4; q++) if (M[8 + PMC_PT * q + 9] < maxpen) { deepest = q; maxpen = M[8 + PMC_PT * q + 9]; }
+            const V3 q0 = ld3(&M[8]), q1 = ld3(&M[8 + PMC_PT]), q2 = ld3(&M[8 + 2 * PMC_PT]), q3 = ld3(&M[8 + 3 * PMC_PT]);
+            float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f; V3 cr;
+            if (deepest != 0) { cr = cross(lA - q1, q3 - q2); r0 = dot(cr, cr); }
+            if (deepest != 1) { cr = cross(lA - q0, q3 - q2); r1 = dot(cr, cr); }
+            if (deepest != 2) { cr = cross(lA - q0, q3 - q1); r2 = dot(cr, cr); }
+            if (deepest != 3) { cr = cross(lA - q0, q2 - q1); r3 = dot(cr, cr); }
+            sl = 0; float rb = r0;
+            if (r1 > rb) { rb = r1; sl = 1; }
+            if (r2 > rb) { rb = r2; sl = 2; }
+            if (r3 > rb) { rb = r3; sl = 3; }
           }
-          float* P = &M[8 + 10 * sl];
-          st3(P, lA); st3(P + 3, lB); st3(P + 6, nr); P[9] = dist;
-          setc(sl, (unsigned)ab);
         }
+        float* P = &M[8 + PMC_PT * sl];
+        st3(P, lA); st3(P + 3, lB); st3(P + 6, nr); P[9] = dist; P[10] = __int_as_float(abw & (int)0xFFC0FFFF);
       }
-      for (int q = 0; q < n; q++) {                          /* (d) */
-        float* P = &M[8 + 10 * q];
-        const unsigned ab = getc(q);
-        const int ba = m->col_body[ab & 255], bb = m->col_body[ab >> 8];
-        const V3 pA = mulv(ldm3(&L.xR[9 * ba]), ld3(P)) + ld3(&L.xp[3 * ba]), pB = mulv(ldm3(&L.xR[9 * bb]), ld3(P + 3)) + ld3(&L.xp[3 * bb]);
-        P[9] = dot(pA - pB, ld3(P + 6));
-      }
-      for (int q = n - 1; q >= 0; q--) {
-        float* P = &M[8 + 10 * q];
-        const unsigned ab = getc(q);
-        const int ba = m->col_body[ab & 255], bb = m->col_body[ab >> 8];
-        const V3 nr = ld3(P + 6);
-        const float dist = P[9];
-        bool drop = !(dist <= thr);
-        if (!drop) {
-          const V3 pA = mulv(ldm3(&L.xR[9 * ba]), ld3(P)) + ld3(&L.xp[3 * ba]), pB = mulv(ldm3(&L.xR[9 * bb]), ld3(P + 3)) + ld3(&L.xp[3 * bb]);
-          const V3 diff = pB - (pA - nr * dist);
-          drop = dot(diff, diff) > thr * thr;
-        }
-        if (drop) {
-          if (q != n - 1) { for (int t = 0; t < 10; t++) P[t] = M[8 + 10 * (n - 1) + t]; setc(q, getc(n - 1)); }
-          n--;
-        }
-      }
-      M[1] = __int_as_float(n); M[4] = __uint_as_float(cw0); M[5] = __uint_as_float(cw1);
-      pk = __float_as_int(M[3]) << 16;
-      cnt = n;
-      if ((pk & 65536) && n > 0) {                           /* the rotation-locked body against the static world: its deepest point alone */
-        only = 0;
-        for (int q = 1; q < n; q++) if (M[8 + 10 * q + 9] < M[8 + 10 * only + 9] - K_TIE_EPS) only = q;
-        cnt = 1;
-      }
+      M[1] = __int_as_float(n);
     }
-    int off = 0;
+    WSYNC();
+    PCLK(23)
+    /* (d), (e): one lane per cached POINT (lane = 4 * manifold + slot).  The point is refreshed and judged in its lane; the four lanes of a manifold then
+     * replay the sequential removal (slot i dropped: the last point takes it) on the four drop bits - the same arrangement in all of them - and every
+     * survivor goes to its new slot of the cache and, if the contact list has room for it, to its record in L.man straight from its registers */
+    int cnt = 0;
+    {
+      const int mi = lane >> 2, q = lane & 3;
+      const bool mine = mi < npm;
+      const float* M = &C[PMC_HDR + PMC_MAN * (mine ? mi : 0)];
+      const int n = mine ? __float_as_int(M[1]) : 0;
+      const float thr = M[2];
+      const int fl = __float_as_int(M[3]);
+      const bool valid = q < n;
+      float pt[PMC_PT];
 #pragma unroll
-    for (int bit = 0; bit < 3; bit++) off += __popcll(__ballot((cnt >> bit) & 1) & lower) << bit;
-    kept = min(cnt, max(0, MAXC - off));
-    man = &L.man[8 * (off < MANPTS ? off : 0)];
-    if (kept > 0) {                                          /* (e) */
-      const float* M = &C[PMC_HDR + PMC_MAN * lane];
-      const unsigned cw0 = __float_as_uint(M[4]), cw1 = __float_as_uint(M[5]);
-      for (int i = 0; i < kept; i++) {
-        const int q = only >= 0 ? only : i;
-        const float* P = &M[8 + 10 * q];
-        const unsigned ab = (q < 2 ? (cw0 >> (16 * q)) : (cw1 >> (16 * (q - 2)))) & 0xFFFFu;
-        const int ba = m->col_body[ab & 255], bb = m->col_body[ab >> 8];
-        const V3 pA = mulv(ldm3(&L.xR[9 * ba]), ld3(P)) + ld3(&L.xp[3 * ba]), pB = mulv(ldm3(&L.xR[9 * bb]), ld3(P + 3)) + ld3(&L.xp[3 * bb]);
+      for (int t = 0; t < PMC_PT; t++) pt[t] = M[8 + PMC_PT * q + t];
+      const int ab = valid ? __float_as_int(pt[10]) : 0;
+      const int ba = (ab >> 22) & 31, bb = (ab >> 27) & 31;
+      const V3 nr = mk3(pt[6], pt[7], pt[8]);
+      const V3 pA = mulv(ldm3(&L.xR[9 * ba]), mk3(pt[0], pt[1], pt[2])) + ld3(&L.xp[3 * ba]);
+      const V3 pB = mulv(ldm3(&L.xR[9 * bb]), mk3(pt[3], pt[4], pt[5])) + ld3(&L.xp[3 * bb]);
+      const float dist = dot(pA - pB, nr);
+      bool drop = !(dist <= thr);
+      if (!drop) { const V3 diff = pB - (pA - nr * dist); drop = dot(diff, diff) > thr * thr; }
+      const unsigned d4 = (unsigned)(__ballot(valid && drop) >> (4 * (mi & 15))) & 15u;
+      /* the removal loop of the oracle on slot numbers: arr[i] = which original point sits in slot i */
+      int a0 = 0, a1 = 1, a2 = 2, a3 = 3, nn = n;
+      for (int i = n - 1; i >= 0; i--) {
+        const int at = i == 0 ? a0 : (i == 1 ? a1 : (i == 2 ? a2 : a3));
+        if ((d4 >> at) & 1u) {
+          const int last = nn - 1 == 0 ? a0 : (nn - 1 == 1 ? a1 : (nn - 1 == 2 ? a2 : a3));
+          if (i == 0) a0 = last; else if (i == 1) a1 = last; else if (i == 2) a2 = last; else a3 = last;
+          nn--;
+        }
+      }
+      int slot = -1;                                        /* this point's slot after the removals, -1 = dropped */
+      if (valid && !((d4 >> q) & 1u)) slot = (nn > 0 && a0 == q) ? 0 : ((nn > 1 && a1 == q) ? 1 : ((nn > 2 && a2 == q) ? 2 : ((nn > 3 && a3 == q) ? 3 : -1)));
+      /* the rotation-locked body against the static world: its deepest point alone (first of equals within K_TIE_EPS, in slot order) */
+      const bool single = (fl & 1) != 0;
+      bool emit = slot >= 0;
+      if (single && nn > 0) {
+        const int base = lane & ~3;
+        const int s0 = __shfl(slot, base), s1 = __shfl(slot, base + 1), s2 = __shfl(slot, base + 2), s3 = __shfl(slot, base + 3);
+        const float e0 = __shfl(dist, base), e1 = __shfl(dist, base + 1), e2 = __shfl(dist, base + 2), e3 = __shfl(dist, base + 3);
+        float ds[4] = {0.f, 0.f, 0.f, 0.f}; int who[4] = {0, 0, 0, 0};      /* distance and owner lane of the point in slot k */
+        if (s0 >= 0) { ds[s0] = e0; who[s0] = 0; }
+        if (s1 >= 0) { ds[s1] = e1; who[s1] = 1; }
+        if (s2 >= 0) { ds[s2] = e2; who[s2] = 2; }
+        if (s3 >= 0) { ds[s3] = e3; who[s3] = 3; }
+        int only = 0;
+        for (int k = 1; k < nn; k++) if (ds[k] < ds[only] - K_TIE_EPS) only = k;
+        emit = slot >= 0 && who[only] == q;
+      }
+      cnt = (q == 0 && mine) ? (single ? (nn > 0 ? 1 : 0) : nn) : 0;
+      int off = 0;
+#pragma unroll
+      for (int bit = 0; bit < 3; bit++) off += __popcll(__ballot((cnt >> bit) & 1) & lower) << bit;
+      off = __shfl(off, lane & ~3);                          /* the manifold's first record */
+      const int room = max(0, MAXC - off);
+      if (q == 0 && mine) { kept = min(cnt, room); man = &L.man[8 * (off < MANPTS ? off : 0)]; pk = fl << 16; }
+      WSYNC();                                               /* every lane holds its point: the cache slots may be overwritten */
+      if (slot >= 0) {
+        float* P = &C[PMC_HDR + PMC_MAN * mi + 8 + PMC_PT * slot];
+#pragma unroll
+        for (int t = 0; t < 9; t++) P[t] = pt[t];
+        P[9] = dist; P[10] = pt[10];
+      }
+      if (q == 0 && mine) C[PMC_HDR + PMC_MAN * mi + 1] = __int_as_float(nn);
+      const int ri = single ? 0 : slot;
+      if (emit && ri < room) {
         const V3 pm = (pA + pB) * 0.5f;
-        float* r = &man[8 * i];
-        r[0] = pm.x; r[1] = pm.y; r[2] = pm.z; r[3] = P[6]; r[4] = P[7]; r[5] = P[8]; r[6] = P[9]; r[7] = __int_as_float((int)ab);
+        float* r = &L.man[8 * (off + ri)];
+        r[0] = pm.x; r[1] = pm.y; r[2] = pm.z; r[3] = nr.x; r[4] = nr.y; r[5] = nr.z; r[6] = dist; r[7] = __int_as_float(ab);
       }
     }
     WSYNC();
+    PCLK(24)
     if (lane == 0) C[0] = __int_as_float(npm);
     WSYNC();
     for (int i = lane * 4; i < PMC_FLOATS; i += 256) *(float4*)&g[i] = *(const float4*)&C[i];
+    PCLK(25)
   } else {
   int mycnt = 0, run_end = lane;
   bool single = false;
@@ -1118,7 +1187,7 @@ __device__ __forceinline__ int collide(const DevModel* m, LDS& L, int lane, int 
     L.conn[3 * o] = c0.w; L.conn[3 * o + 1] = c1.x; L.conn[3 * o + 2] = c1.y;
     L.cond[o] = c1.z;
     L.cona[o] = ab & 255; L.conb[o] = (ab >> 8) & 255; L.conk[o] = cls;
-    L.conmu[o] = m->col_friction[ab & 255] * m->col_friction[(ab >> 8) & 255];      /* (= L.pmu of the point's pair) */
+    L.conmu[o] = m->persist ? m->col_friction[ab & 255] * m->col_friction[(ab >> 8) & 255] : L.pmu[(ab >> 16) & 63];      /* (a cached point's pair may not be active now: same product from the table) */
   }
   WSYNC();
   PCLK(10)

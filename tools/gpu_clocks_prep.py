@@ -35,7 +35,7 @@ for i, nm in enumerate(names):
     print('%-14s cycles: p10 %d p50 %d p90 %d max %d' % ((nm,) + tuple(np.percentile(d, [10, 50, 90, 100]))))
 tot = a[:, 5] - a[:, 0]
 print('%-14s cycles: p10 %d p50 %d p90 %d max %d' % (('total',) + tuple(np.percentile(tot, [10, 50, 90, 100]))))
-for nm, i0, i1 in (('  load state', 0, 16), ('  FK', 16, 17), ('   FK local', 16, 19), ('   FK chain', 19, 20), ('   FK rest', 20, 17), ('  subspaces', 17, 18), ('  AABBs', 18, 1), ('  broadphase', 1, 8), ('  narrowphase', 8, 9), ('  manifolds', 9, 10), ('  collide tail', 10, 2)):
+for nm, i0, i1 in (('  load state', 0, 16), ('  FK', 16, 17), ('   FK local', 16, 19), ('   FK chain', 19, 20), ('   FK rest', 20, 17), ('  subspaces', 17, 18), ('  AABBs', 18, 1), ('  broadphase', 1, 8), ('  narrowphase', 8, 9), ('  manifolds', 9, 10), ('   cache load', 9, 21), ('   (a) (b)', 21, 22), ('   (c) add', 22, 23), ('   (d) (e)', 23, 24), ('   cache store', 24, 25), ('  collide tail', 10, 2)):
     d = a[:, i1] - a[:, i0]
     print('%-14s cycles: p10 %d p50 %d p90 %d max %d' % ((nm,) + tuple(np.percentile(d, [10, 50, 90, 100]))))
 for nm, i0, i1 in (('  inertia+comp', 2, 11), ('  M, bias, tau', 11, 13), ('  chol+inverse', 13, 14), ('  vstar etc', 14, 3)):
