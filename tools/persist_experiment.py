@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""What would PERSISTENT MANIFOLDS in the fast model be worth?  CPU only, an experiment build of the oracle - nothing of it ships.
+"""What are PERSISTENT MANIFOLDS in the fast model worth?  CPU only.  (This experiment came first; the shipped model has them since: RPO_RULE_PERSIST.)
 
-`oracle/rp_oracle.c -DRPO_ABX` (built here into a scratch directory) adds rule bit 256 to mode A: its own narrowphase (hull vertices, box_box in the
+`oracle/rp_oracle.c -DRPO_ABX` (built here into a scratch directory) adds rule bit 2048 to mode A: its own narrowphase (hull vertices, box_box in the
 detector's order - overlap only for every pair -, sphere_box) feeds the frozen reference step's manifold upkeep (`rpb_find_manifold`, `rpb_add_point`,
 `rpb_refresh`: points in the two bodies' frames, refreshed every substep, dropped beyond the breaking threshold, a new point within the threshold of a
 cached one replaces it).  Bit 1024 on top: manifolds keyed by OBJECT pair and the deepest point alone for a rotation-locked body against the static world -
@@ -41,7 +41,7 @@ def main():
     from oracle import OracleEnv
     import model_divergence as md
     base = 247
-    variants = [('shipped model', base), ('+ persistent manifolds, native (RPO_RULE_PERSIST)', base | 256), ('+ the reference step\'s own manifold upkeep', base | 2048), ('+ the same, the fast model\'s manifold rules', base | 2048 | 1024),
+    variants = [('stateless contacts (RP_CFG_STATELESS_CONTACTS)', base), ('shipped model: persistent manifolds (RPO_RULE_PERSIST)', base | 256), ('+ the reference step\'s own manifold upkeep', base | 2048), ('+ the same, the fast model\'s manifold rules', base | 2048 | 1024),
                 ('+ the same, manifold order', base | 2048 | 512)]
     for kind in args.kinds.split(','):
         res = {v[0]: [] for v in variants}
