@@ -93,6 +93,8 @@ def load(f32=False, bullet_ref=False):
     lib.rpo_set_margin.argtypes = [vp, C.c_double]
     lib.rpo_set_rule.argtypes = [vp, C.c_int]
     lib.rpo_last_num_tors.argtypes = [vp]
+    lib.rpo_cache_size.argtypes = [vp, ip]
+    lib.rpo_shift_free_body.argtypes = [vp, C.c_int, C.c_double, C.c_double, C.c_double]
     lib.rpo_get_rule.argtypes = [vp]
     lib.rpo_set_reward_cfg.argtypes = [vp, C.c_double, C.c_int]
     lib.rpo_action_dim.argtypes = [vp]

@@ -2176,6 +2176,11 @@ void rpo_set_state(rpo_env* e, const double* s) {
   e->npm = 0;                     /* a state set from outside starts with an empty contact cache (RPO_RULE_PERSIST) */
   update_transforms(e);
 }
+/* test hook: shift free body k, keeping its velocity and - unlike rpo_set_state - the contact cache (tests of the cache's life cycle) */
+void rpo_shift_free_body(rpo_env* e, int k, double dx, double dy, double dz) {
+  e->fpos[k][0] += (real)dx; e->fpos[k][1] += (real)dy; e->fpos[k][2] += (real)dz;
+  update_transforms(e);
+}
 void rpo_get_motor(const rpo_env* e, int* mode, double* target, double* maximp) {
   for (int i = 0; i < e->m.n_arm; i++) { mode[i] = e->mmode[i]; target[i] = e->mtarget[i]; maximp[i] = e->mmaximp[i]; }
 }

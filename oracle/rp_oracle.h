@@ -93,6 +93,8 @@ void rpo_mass_matrix_inv(rpo_env*, double* Minv /* nv*nv, arm block via unit imp
 void rpo_forward_dynamics(rpo_env*, double* qdd /* n_arm */);
 int rpo_contacts(rpo_env*, double* out /* per contact: colA colB px py pz nx ny nz dist */, int max);
 int rpo_last_num_tors(const rpo_env* e);        /* torsional friction rows of the latest substep */
+int rpo_cache_size(const rpo_env* e, int* points);     /* RPO_RULE_PERSIST: cached manifolds (empty ones included), their points */
+void rpo_shift_free_body(rpo_env* e, int k, double dx, double dy, double dz);      /* test hook: moves a free body, keeps the contact cache */
 int rpo_last_num_rows(const rpo_env*);
 int rpo_arm_table(const rpo_env* e, double* out);                      /* [n_arm][6]: jtype, lower, upper, body mass, Bullet joint index, parent dof */
 int rpo_collider_dynamics(const rpo_env* e, double* out);              /* [n_col][6]: body, friction, body mass, contact stiffness, damping, breaking threshold */

@@ -7,13 +7,13 @@ per env, 200 steps, identical post-reset states and actions, tolerance 1e-3.
 
 What the shipped model shares with the reference step since round 3: the non-contact row order walked in alternating direction, joint-limit rows
 only while violated (erp 0.2), soft gripper contacts, the friction skip, hull vertices of arm links against static boxes, the box-box detector's point
-order, per-body lever arms, torsional friction.  What it does not: persistent manifolds (on these two ids the only difference left),
-GJK / EPA beyond vertex-on-face.  Hence
+order, per-body lever arms, torsional friction, persistent manifolds.  What it does not: GJK / EPA beyond vertex-on-face, one manifold per collider pair
+ - neither matters on these two ids: the fp64 oracles of the two models agree to 6e-6 on UR5Reach.  Hence
   * both ids must meet 1e-3 in every env for as long as the rollout is free motion - until the first substep in which either the reference step
     or the fast model (an fp64 CPU follower of the same env) has a contact row: the fingers of both grippers reach the ground plate at
     z = -0.07 in many rollouts;
-  * after that the measured figure is reported and bounded: median over the envs 2e-4 (measured: R 3e-5, Q 3e-6; this round's first model 5e-4), every
-    env 1e-2 (measured max: R 4e-3 - persistence plus what fp32 makes of a pad's impact -, Q 1.5e-4).
+  * after that the measured figure is reported and bounded: median over the envs 2e-4 (measured: R 4e-6, Q 3e-6; this round's first model 5e-4), every
+    env 1e-2 (measured max: R 2.4e-3 - what fp32 makes of a pad's impact -, Q 1.5e-4).
 """
 import numpy as np
 import pytest
@@ -78,4 +78,4 @@ def test_hip_vs_frozen_reference_step(kind):
                                                               int(first.min()) if touched.any() else '-'))
     assert (d_free <= TOL).all(), d_free
     assert (~touched).sum() >= 2 and (d_all[~touched] <= TOL).all()      # some envs stay free for all 200 steps
-    assert np.median(d_all) <= 2e-4 and (d_all <= 1e-2).all(), d_all       # no persistent manifolds: DESIGN.md section 2
+    assert np.median(d_all) <= 2e-4 and (d_all <= 1e-2).all(), d_all       # fp32 against fp64 across a pad's impacts: DESIGN.md section 2

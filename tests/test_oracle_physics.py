@@ -149,3 +149,32 @@ def oracle_has_hull(col):
     src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'roboticsplayroompybullet_amd', 'csrc', 'generated', 'rp_hullverts_gen.h')).read()
     cnt = [int(x) for x in re.search(r'rp_hull_cnt_R\[64\] = \{([^}]*)\}', src).group(1).split(',')]
     return cnt[col] > 0
+
+
+def test_contact_cache_life_cycle():
+    """the fast model's persistent manifolds (RPO_RULE_PERSIST, oracle collide_persistent; the HIP library keeps the same cache): a block at rest on the table
+    has its four points in the cache; lifted by less than the pair's breaking threshold (1.22 mm: the block's relative threshold) they STAY, now at a
+    positive distance, although a box pair makes no new points while apart; lifted beyond it they are dropped; a state set from outside starts without
+    history; without the rule (the stateless model) the same lifted block has points only out to its margin, rebuilt every substep"""
+    import ctypes as C
+    env = OracleEnv('U', seed=2, env_index=0)
+    env.reset()
+    for _ in range(5):
+        env.substep()
+    pts = C.c_int(0)
+    nman = env.lib.rpo_cache_size(env.h, C.byref(pts))
+    assert nman >= 3 and pts.value >= 8                       # block on the table, the drawer on its two rails
+    def block_table():
+        c = env.contacts()
+        return c[(c[:, 0] == 51) & ((c[:, 1] == 46) | (c[:, 1] == 42))]
+    blk = block_table()
+    assert len(blk) == 4 and (blk[:, 8] < 1e-4).all()
+    env.lib.rpo_shift_free_body(env.h, 0, 0.0, 0.0, 0.0010)
+    blk = block_table()
+    assert len(blk) == 4 and (blk[:, 8] > 5e-4).all()         # kept, at a positive distance
+    env.lib.rpo_shift_free_body(env.h, 0, 0.0, 0.0, 0.0010)
+    assert len(block_table()) == 0                            # 2 mm: beyond the threshold
+    env.lib.rpo_shift_free_body(env.h, 0, 0.0, 0.0, -0.0020)
+    assert len(block_table()) == 4                            # back on the table: new points (overlap)
+    env.set_state(env.get_state())
+    assert env.lib.rpo_cache_size(env.h, None) == 0           # a state set from outside: no history
