@@ -244,7 +244,9 @@ def main():
         dist.all_gather_object(ranks, me)
     if rank == 0:
         value = world * n * args.steps / elapsed
-        margin_used = ('%g m for every pair' % args.contact_margin) if args.contact_margin is not None else "per pair, Bullet's relative breaking thresholds (library default)"
+        margin_used = ('stateless, margin %g m for every pair' % args.contact_margin) if args.contact_margin is not None else (
+            "stateless (RP_CFG_STATELESS_CONTACTS), per-pair margins = Bullet's relative breaking thresholds" if args.stateless_contacts else
+            "persistent manifolds (per-env contact cache, library default), per-pair breaking thresholds = Bullet's relative ones")
         solve_ms = tm['avg_solve_ms']
         achieved = ALG_BYTES_PER_ENV_SUBSTEP * n / (solve_ms * 1e-3) / 1e9
         step_achieved = ALG_BYTES_PER_ENV_STEP * n / (step_ms * 1e-3) / 1e9
@@ -254,7 +256,7 @@ def main():
             'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': '%s, %d envs per GPU, 12 substeps x 50 PGS sweeps per step, random actions '
-                                   '(distribution B, resampled every step), reset excluded, contact margin: %s' % (ENV_ID, n, margin_used),
+                                   '(distribution B, resampled every step), reset excluded, contacts: %s' % (ENV_ID, n, margin_used),
                        'envs_per_gpu': n, 'global_envs': world * n, 'parallelism': 'env-shard x%d' % world,
                        'collective': 'all_gather(obs_quat+achieved_goal+reward+is_success) per step' if world > 1 else 'none',
                        'collective_backend': (dist.get_backend() + (' (RCCL)' if dist.get_backend() == 'nccl' else '')) if world > 1 else None,
