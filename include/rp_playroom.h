@@ -103,8 +103,9 @@ typedef struct rp_config {
    * Default (flag clear): per pair, Bullet's contact breaking threshold - gContactBreakingThreshold (0.02) x the smaller of
    * the two collision objects' angular-motion discs (btCollisionDispatcher's CD_USE_RELATIVE_CONTACT_BREAKING_THRESHOLD
    * default): 1.2 mm for the block, 0.4 - 6 mm for the arm links, 9 mm for the table.  Bullet keeps the points of its
-   * persistent manifolds out to that distance; this library's manifolds are rebuilt every substep, so the margin is the
-   * distance within which a point exists.  See DESIGN.md H7. */
+   * persistent manifolds out to that distance, and so does this library's contact cache (default).  Setting this field is a
+   * study of the STATELESS contacts (it implies RP_CFG_STATELESS_CONTACTS): points are rebuilt every substep and the margin
+   * is the distance within which a point exists.  See DESIGN.md H7. */
   float contact_margin;
 } rp_config;
 
