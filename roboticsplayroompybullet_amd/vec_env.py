@@ -72,6 +72,7 @@ class VecPlayEnv:
             flags |= _lib.CFG_STATELESS_CONTACTS      # rp_config_flags: no contact cache, points rebuilt every substep (round 3's first model)
         cfg.flags = flags
         self.h = C.c_void_p()
+        self._done = None
         _lib.check(self.lib, None, self.lib.rp_create(C.byref(cfg), C.byref(self.h)), 'rp_create')
         d = _lib.RpDims()
         self.lib.rp_get_dims(self.h, C.byref(d))
@@ -164,8 +165,9 @@ class VecPlayEnv:
         self._flip_pack()
         _lib.check(self.lib, self.h, self.lib.rp_step(self.h, C.c_void_p(a.data_ptr()), C.byref(self.out), self._stream()), 'rp_step')
         info = {'is_success': self.buf['is_success'], 'target_poses': self.buf['target_poses'], 'status': self.buf['status']}
-        done = torch.zeros(self.num_envs, dtype=torch.bool, device=self.device)      # environments.py:212: always False
-        return self._obs(), self.buf['reward'], done, info
+        if self._done is None:      # environments.py:212: always False - one tensor for the handle's life (a fill kernel per step sat at the end of the step's chain: 8 us)
+            self._done = torch.zeros(self.num_envs, dtype=torch.bool, device=self.device)
+        return self._obs(), self.buf['reward'], self._done, info
 
     def calc_state(self):
         self._flip_pack()
