@@ -48,6 +48,7 @@
 #define RPO_RULE_LEVER 64           /* a contact acts at its point on A on body A and at its point on B on body B (otherwise: at their midpoint on both) */
 #define RPO_RULE_SPIN 128           /* spinning_friction of the gripper links: one torsional friction row per collider pair in contact */
 #define RPO_RULE_PERSIST 256        /* persistent contact manifolds (collide_persistent) */
+#define RPO_RULE_HULLMOV 512        /* ... and movable boxes (the block, the drawer, the door: collider a of the pair) with them too */
 #define RPO_RULE_HULLFACE 4         /* arm links touch static boxes with the vertices of their collision meshes' convex hulls (hull_face) instead of their OBBs */
 #define HULL_MARGIN ((real)RP_HULL_MARGIN)
 #define FREE_LIN_DAMP ((real)0.04)
@@ -543,6 +544,10 @@ static void collide_persistent(rpo_env* e) {
     for (int k = 0; k < 3; k++) { ha[k] = (real)m->col_he[a][k]; hb[k] = (real)m->col_he[b][k]; }
     int hf = -1;
     if ((e->rule & RPO_RULE_HULLFACE) && m->col_type[b] == 0 && m->col_body[b] == 0 && body_is_arm(e, m->col_body[a])) hf = hull_face(e, a, b, margin, pts);
+    else if ((e->rule & RPO_RULE_HULLMOV) && (e->rule & RPO_RULE_HULLFACE) && m->col_type[a] == 0 && m->col_type[b] == 0 && body_is_arm(e, m->col_body[b]) && !body_is_arm(e, m->col_body[a]) && m->col_body[a] != 0) {
+      hf = hull_face(e, b, a, margin, pts);      /* a movable box (collider a) against an arm link's hull (collider b): the pair's normal points from b toward a */
+      if (hf == 1) v3scale(pts[0].n, pts[0].n, -1);
+    }
     if (hf >= 0) np = hf;
     else if (m->col_type[a] == 0 && m->col_type[b] == 0) np = box_box(e->xc[a].p, e->xc[a].R, ha, e->xc[b].p, e->xc[b].R, hb, 0, (e->rule & RPO_RULE_ODEORDER) != 0, pts);
     else if (m->col_type[a] == 0 && m->col_type[b] == 1) np = sphere_box(e->xc[b].p, hb[0], e->xc[a].p, e->xc[a].R, ha, margin, 1, pts);
@@ -740,6 +745,10 @@ static void collide(rpo_env* e) {
     int hf = -1;
     if ((e->rule & RPO_RULE_HULLFACE) && m->col_type[b] == 0 && m->col_body[b] == 0 && body_is_arm(e, m->col_body[a]))
       hf = hull_face(e, a, b, margin, pts);
+    else if ((e->rule & RPO_RULE_HULLMOV) && (e->rule & RPO_RULE_HULLFACE) && m->col_type[a] == 0 && m->col_type[b] == 0 && body_is_arm(e, m->col_body[b]) && !body_is_arm(e, m->col_body[a]) && m->col_body[a] != 0) {
+      hf = hull_face(e, b, a, margin, pts);      /* a movable box (collider a) against an arm link's hull (collider b): the pair's normal points from b toward a */
+      if (hf == 1) v3scale(pts[0].n, pts[0].n, -1);
+    }
     if (hf >= 0) np = hf;
     else if (m->col_type[a] == 0 && m->col_type[b] == 0)
       np = box_box(e->xc[a].p, e->xc[a].R, ha, e->xc[b].p, e->xc[b].R, hb, (e->margin < 0 && (e->rule & RPO_RULE_BOXOVERLAP) && (body_is_arm(e, m->col_body[a]) || body_is_arm(e, m->col_body[b]))) ? (real)0 : margin, (e->rule & RPO_RULE_ODEORDER) != 0, pts);
@@ -1349,7 +1358,7 @@ static int collide_persist(rpo_env* e) {
       e->con[e->ncon++] = c;
     }
   }
-  if (!(e->rule & 512)) solver_order(e);      /* bit 512: keep the manifold order (Bullet's) instead of the four-tier partition */
+  if (!(e->rule & 16384)) solver_order(e);      /* bit 16384: keep the manifold order (Bullet's) instead of the four-tier partition */
   return 1;
 }
 #endif
@@ -2089,7 +2098,7 @@ rpo_env* rpo_create(int kind, unsigned long long seed, int env_index) {
   e->nv = m->n_arm + 6 * m->n_free + m->n_joint1;
   e->nbody = 1 + m->n_arm + m->n_free + m->n_joint1;
   e->seed = seed; e->env_index = (uint32_t)env_index;
-  e->rule = RPO_RULE_ORDER | RPO_RULE_LIMIT | RPO_RULE_HULLFACE | RPO_RULE_BOXOVERLAP | RPO_RULE_ODEORDER | RPO_RULE_LEVER | RPO_RULE_SPIN | RPO_RULE_PERSIST;       /* the shipped model (the HIP kernels implement exactly this); rpo_set_rule(0) = round 2's rule */
+  e->rule = RPO_RULE_ORDER | RPO_RULE_LIMIT | RPO_RULE_HULLFACE | RPO_RULE_BOXOVERLAP | RPO_RULE_ODEORDER | RPO_RULE_LEVER | RPO_RULE_SPIN | RPO_RULE_PERSIST | RPO_RULE_HULLMOV;       /* the shipped model (the HIP kernels implement exactly this); rpo_set_rule(0) = round 2's rule */
   e->margin = -1; e->rew_thresh = (real)0.05; e->dense_reward = 0;
   /* envList.py:8-10, 18-22, 73-99: the env's flags and ranges go with its scene (play ids: complex_scene; reach ids:
    * default_scene; pick / push: push_scene); other ids on the same model override the ranges (rpo_set_ranges) */

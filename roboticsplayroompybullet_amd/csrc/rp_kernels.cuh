@@ -527,11 +527,16 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
      * vertex index among equals: the oracle's sequential scan). */
     int hf = -1;                                             /* 1: hull contact (lane 0 of the group holds it), 0: hull says apart, -1: OBB path */
     {
-      const int hn = act ? m->hull_cnt[a] : 0;
-      bool hq = hn > 0 && tb == 0 && m->col_body[b] == 0;
+      /* the hull is collider a against a STATIC box b - or collider b against a MOVABLE box a (pairs list the collider of the higher body first, and the
+       * movable bodies come after the arm's links: the block, the drawer, the door, ... against an arm link; oracle RPO_RULE_HULLMOV): hc / bc = hull / box */
+      const int body_b0 = m->col_body[b], body_a0 = m->col_body[a];
+      const bool hswap = act && m->hull_cnt[b] > 0 && ta == 0 && tb == 0 && body_a0 > m->n_arm;
+      const int hc = hswap ? b : a, bc = hswap ? a : b;
+      const int hn = act ? m->hull_cnt[hc] : 0;
+      bool hq = hn > 0 && (hswap || (tb == 0 && body_b0 == 0));
       if (hq) {
-        const Xf xa = collider_xf(m, L, a), xb = collider_xf(m, L, b);
-        const V3 ha = ld3(m->col_he[a]), hb = ld3(m->col_he[b]);
+        const Xf xa = collider_xf(m, L, hc), xb = collider_xf(m, L, bc);
+        const V3 ha = ld3(m->col_he[hc]), hb = ld3(m->col_he[bc]);
         /* the link's OBB (it contains the hull) against the same six faces first: if even the OBB stays clear of the box by more than the pair's margin
          * along one of the box's axes, so does every vertex and the scan would end with "apart" - the common case, a long link whose AABB merely overlaps
          * the table's (same outcome as the oracle's full scan; the 1e-5 keeps rounding at the threshold on the scanning side) */
@@ -549,7 +554,8 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
       asm volatile("" ::: "memory");                         /* (the transforms above are loaded again where they are needed: nothing of them stays in registers across the scan) */
       for (unsigned long long todo = __ballot(hq && s == 0); todo != 0ull; todo &= todo - 1ull) {
         const int src = __ffsll((long long)todo) - 1;        /* first lane of the group whose pair is scanned now (wave-uniform) */
-        const int ca = __builtin_amdgcn_readlane(a, src), cb = __builtin_amdgcn_readlane(b, src);
+        const int ca = __builtin_amdgcn_readlane(hc, src), cb = __builtin_amdgcn_readlane(bc, src);
+        const bool flip = __builtin_amdgcn_readlane((int)hswap, src) != 0;      /* the pair's normal points from b toward a: from the hull toward the box when the hull is b */
         const float mg = lane_read(margin0, src);
         const int body = m->col_body[ca];
         const M3 Rw = ldm3(&L.xR[9 * body]);
@@ -607,7 +613,7 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
               const V3 nb = pick3(k, b0, b1, b2);
               const V3 nrm = (bf & 1) ? -nb : nb;
               const V3 pB = w - nrm * best;                  /* on the box face under the vertex; the model's single application point lies halfway along the gap */
-              pt.p = pB + nrm * (0.5f * d); pt.n = nrm; pt.dist = d;
+              pt.p = pB + nrm * (0.5f * d); pt.n = flip ? -nrm : nrm; pt.dist = d;
             }
           }
         }

@@ -5,7 +5,7 @@
 detector's order - overlap only for every pair -, sphere_box) feeds the frozen reference step's manifold upkeep (`rpb_find_manifold`, `rpb_add_point`,
 `rpb_refresh`: points in the two bodies' frames, refreshed every substep, dropped beyond the breaking threshold, a new point within the threshold of a
 cached one replaces it).  Bit 1024 on top: manifolds keyed by OBJECT pair and the deepest point alone for a rotation-locked body against the static world -
-the fast model's own manifold rules, i.e. the same row counts as today's model.  Bit 512: rows in manifold order instead of the four-tier partition.
+the fast model's own manifold rules, i.e. the same row counts as today's model.  Bit 16384: rows in manifold order instead of the four-tier partition.
 
 Prints the 200-step arm divergence from the frozen reference step (default flags) per env and median / p90 / max, like tools/model_divergence.py.
     python tools/persist_experiment.py [--kinds R,U,P] [--envs 12]
@@ -41,8 +41,8 @@ def main():
     from oracle import OracleEnv
     import model_divergence as md
     base = 247
-    variants = [('stateless contacts (RP_CFG_STATELESS_CONTACTS)', base), ('shipped model: persistent manifolds (RPO_RULE_PERSIST)', base | 256), ('+ the reference step\'s own manifold upkeep', base | 2048), ('+ the same, the fast model\'s manifold rules', base | 2048 | 1024),
-                ('+ the same, manifold order', base | 2048 | 512)]
+    variants = [('stateless contacts (RP_CFG_STATELESS_CONTACTS)', base), ('persistent manifolds (RPO_RULE_PERSIST)', base | 256), ('+ the reference step\'s own manifold upkeep', base | 2048), ('+ the same, the fast model\'s manifold rules', base | 2048 | 1024),
+                ('+ the same, manifold order', base | 2048 | 16384), ('shipped model: + hull vertices against movable boxes (RPO_RULE_HULLMOV)', base | 256 | 512)]
     for kind in args.kinds.split(','):
         res = {v[0]: [] for v in variants}
         for e in range(args.envs):
