@@ -971,7 +971,6 @@ static void contact_response2(const rpo_env* e, int bodyA, int bodyB, const real
   }
 }
 
-static void contact_response(const rpo_env* e, int bodyA, int bodyB, const real* p, const real* n, const real* J, real* B) { contact_response2(e, bodyA, bodyB, p, p, n, 0, J, B); }
 /* the angular part of a body's Jacobian along n (torsional friction rows) */
 static void ang_jacobian(const rpo_env* e, int body, const real* n, real sign, real* J) {
   const rp_model* m = &e->m;
