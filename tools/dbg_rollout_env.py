@@ -53,9 +53,11 @@ for t in range(steps):
             e2 = VecPlayEnv(IDS[kind], 2, seed=9)
             for sub in range(12):
                 rec = record_from_oracle(o)
-                e2.set_state(torch.tensor(np.tile(rec, (2, 1))))
+                e2.set_state(torch.tensor(np.tile(rec, (2, 1))))      # (records only: no contact history on the device ...)
                 dbg = e2.debug_substep(0).numpy()
+                o.set_state(o.get_state())                               # (... nor in the oracle)
                 con = o.contacts()
+                o.set_state(o.get_state())
                 o.substep()
                 s1 = o.get_state()
                 vg = (dbg[480:480 + 27] + dbg[544:544 + 27])[:na]

@@ -2,6 +2,7 @@
 """Lock-step comparison (GPU box) like gpu_bisect2.py, but it does not stop at the first difference: before every substep the device gets the fp32
 oracle's state, runs ONE fused substep (rp_debug_substep), and the resulting velocities are compared.  Prints the distribution of the per-substep
 velocity differences and every substep whose difference exceeds 1e-4 with both row counts (a limit row present on one side only shows there).
+Both sides take every substep WITHOUT contact history (the oracle's cache is emptied too): this compares one substep's arithmetic, not the cache.
     python tools/gpu_bisect3.py [id] [steps]"""
 import os, sys
 import numpy as np, torch
@@ -38,8 +39,9 @@ for e in range(n):
         o.perform_action(act)
         for sub in range(12):
             rec = record_from_oracle(o)
-            env.set_state(torch.tensor(np.tile(rec, (2, 1))))
+            env.set_state(torch.tensor(np.tile(rec, (2, 1))))      # records only: the device takes this substep without contact history ...
             dbg = env.debug_substep(0).numpy()
+            o.set_state(o.get_state())                               # ... and so does the oracle (set_state empties its contact cache; the motors stay)
             o.substep()
             s1 = o.get_state()
             vg = (dbg[480:480 + 27] + dbg[544:544 + 27])[:na]
