@@ -526,6 +526,9 @@ static int hull_face(const rpo_env* e, int a, int b, real margin, cpoint* out) {
 static void pm_to_local(const rpo_env* e, int body, const real* pw, real* pl) { real t[3]; v3sub(t, pw, e->xb[body].p); m3tmulv(pl, e->xb[body].R, t); }
 static void pm_to_world(const rpo_env* e, int body, const real* pl, real* pw) { m3mulv(pw, e->xb[body].R, pl); v3add(pw, pw, e->xb[body].p); }
 static void solver_order(rpo_env* e);
+#ifdef RPO_ABX
+static int abx_gjk_epa(rpo_env* e, int a, int b, real margin, cpoint* out, int* tried, int distance_only);
+#endif
 static void collide_persistent(rpo_env* e) {
   const rp_model* m = &e->m;
   contact cand[MAX_CANDIDATES]; int ncand = 0, nactive = 0;
@@ -548,6 +551,13 @@ static void collide_persistent(rpo_env* e) {
       hf = hull_face(e, b, a, margin, pts);      /* a movable box (collider a) against an arm link's hull (collider b): the pair's normal points from b toward a */
       if (hf == 1) v3scale(pts[0].n, pts[0].n, -1);
     }
+#ifdef RPO_ABX
+    if (hf == -1 && (e->rule & 4096)) {      /* EXPERIMENT: where the vertex lies beside the face, the reference step's own GJK / EPA on the same shapes instead of the OBB path */
+      int tried = 0;
+      hf = abx_gjk_epa(e, a, b, margin, pts, &tried, (e->rule & 8192) != 0);
+      if (!tried) hf = -1;
+    }
+#endif
     if (hf >= 0) np = hf;
     else if (m->col_type[a] == 0 && m->col_type[b] == 0) np = box_box(e->xc[a].p, e->xc[a].R, ha, e->xc[b].p, e->xc[b].R, hb, 0, (e->rule & RPO_RULE_ODEORDER) != 0, pts);
     else if (m->col_type[a] == 0 && m->col_type[b] == 1) np = sphere_box(e->xc[b].p, hb[0], e->xc[a].p, e->xc[a].R, ha, margin, 1, pts);
@@ -1292,6 +1302,38 @@ static void substep_integrate(rpo_env* e, const real* vstar, real* dv) {
 #define RPO_BULLET_REF
 #include "rp_bullet_ref.c"
 #undef RPO_BULLET_REF
+static int abx_gjk_epa(rpo_env* e, int a, int b, real margin, cpoint* out, int* tried, int distance_only) {
+  rpb_state* st = rpb_get(e);
+  st->flags = RPB_DEFAULT;
+  const rp_model* m = &e->m;
+  /* only pairs with an arm hull on one side and a box on the other */
+  const int hull_a = st->shape[a] && st->shape[a]->shape == 2, hull_b = st->shape[b] && st->shape[b]->shape == 2;
+  if (!(hull_a ^ hull_b)) { *tried = 0; return -1; }
+  if (m->col_type[hull_a ? b : a] != 0) { *tried = 0; return -1; }
+  *tried = 1;
+  rpb_cvx A, Bs; real pa[3], pb[3], dist = 0, nB[3];
+  rpb_convex_of(e, st, a, &A); rpb_convex_of(e, st, b, &Bs);
+  rpb_sv simplex[4]; int ns = 0;
+  if (rpb_gjk(&A, &Bs, pa, pb, &dist, simplex, &ns)) {
+    if (dist > 1e-12) {
+      real v[3]; v3sub(v, pa, pb); v3scale(nB, v, 1 / dist);
+      real d = dist - A.margin - Bs.margin;
+      if (d > margin) return 0;
+      real pB[3]; v3cpy(pB, pb); v3axpy(pB, Bs.margin, nB);
+      v3cpy(out->n, nB); out->dist = d; v3cpy(out->p, pB); v3axpy(out->p, (real)0.5 * d, nB);
+      return 1;
+    }
+    return 0;
+  }
+  if (distance_only) { *tried = 0; return -1; }     /* cores overlap: leave it to the OBB path */
+  real nf[3], depth, wa[3], wb[3];
+  if (rpb_epa(&A, &Bs, nf, &depth, wa, wb)) {
+    v3scale(nB, nf, -1);
+    v3cpy(out->n, nB); out->dist = -depth; v3cpy(out->p, wb); v3axpy(out->p, (real)-0.5 * depth, nB);
+    return 1;
+  }
+  return 0;
+}
 static int collide_persist(rpo_env* e) {
   const rp_model* m = &e->m;
   rpb_state* st = rpb_get(e);
