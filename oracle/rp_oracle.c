@@ -49,6 +49,7 @@
 #define RPO_RULE_SPIN 128           /* spinning_friction of the gripper links: one torsional friction row per collider pair in contact */
 #define RPO_RULE_PERSIST 256        /* persistent contact manifolds (collide_persistent) */
 #define RPO_RULE_HULLMOV 512        /* ... and movable boxes (the block, the drawer, the door: collider a of the pair) with them too */
+#define RPO_RULE_GJK 1024           /* ... and where the deepest vertex lies BESIDE the face (box edges and corners): GJK's distance phase on hull and box (hull_box_gjk) */
 #define RPO_RULE_HULLFACE 4         /* arm links touch static boxes with the vertices of their collision meshes' convex hulls (hull_face) instead of their OBBs */
 #define HULL_MARGIN ((real)RP_HULL_MARGIN)
 #define FREE_LIN_DAMP ((real)0.04)
@@ -511,6 +512,139 @@ static int hull_face(const rpo_env* e, int a, int b, real margin, cpoint* out) {
   return 1;
 }
 
+/* ------------------------------------------------------------------ RPO_RULE_GJK: GJK distance between an arm link's hull and a box (btGjkPairDetector /
+ * btVoronoiSimplexSolver restated; the HIP library runs the same iteration, its support queries as whole-wave vertex scans).  Both shapes as the reference
+ * step sees them: cores - the hull's vertices; the box's half extents less the 0.001 margin, never below 0 - with that margin around each.  A simplex of
+ * Minkowski-difference points w = a - b (support points kept for the witnesses) is grown towards the origin; closest-point sub-cases after Ericson. */
+#if defined(RP_FLOAT)
+#define GJK_DUP ((real)1e-12)
+#define GJK_REL ((real)1e-6)
+#define GJK_ZERO ((real)1e-12)
+#define GJK_STALL ((real)(1 - 1e-6))
+#else
+#define GJK_DUP ((real)1e-24)
+#define GJK_REL ((real)1e-12)
+#define GJK_ZERO ((real)1e-20)
+#define GJK_STALL ((real)(1 - 1e-14))
+#endif
+typedef struct { real w[3], a[3], b[3]; } gjk_sv;
+static void gjk_closest(gjk_sv* s, int* n, real* lam) {      /* closest point of the simplex to the origin; the simplex shrinks to the supporting sub-simplex */
+  if (*n == 1) { lam[0] = 1; return; }
+  if (*n == 2) {
+    real ab[3]; v3sub(ab, s[1].w, s[0].w);
+    const real t = -v3dot(s[0].w, ab), den = v3dot(ab, ab);
+    if (t <= 0 || den <= 0) { *n = 1; lam[0] = 1; return; }
+    if (t >= den) { s[0] = s[1]; *n = 1; lam[0] = 1; return; }
+    lam[1] = t / den; lam[0] = 1 - lam[1];
+    return;
+  }
+  if (*n == 3) {
+    const real *a = s[0].w, *b = s[1].w, *c = s[2].w;
+    real ab[3], ac[3];
+    v3sub(ab, b, a); v3sub(ac, c, a);
+    const real d1 = -v3dot(ab, a), d2 = -v3dot(ac, a);
+    if (d1 <= 0 && d2 <= 0) { *n = 1; lam[0] = 1; return; }
+    const real d3 = -v3dot(ab, b), d4 = -v3dot(ac, b);
+    if (d3 >= 0 && d4 <= d3) { s[0] = s[1]; *n = 1; lam[0] = 1; return; }
+    const real vc = d1 * d4 - d3 * d2;
+    if (vc <= 0 && d1 >= 0 && d3 <= 0) { const real v = d1 / (d1 - d3); *n = 2; lam[0] = 1 - v; lam[1] = v; return; }
+    const real d5 = -v3dot(ab, c), d6 = -v3dot(ac, c);
+    if (d6 >= 0 && d5 <= d6) { s[0] = s[2]; *n = 1; lam[0] = 1; return; }
+    const real vb = d5 * d2 - d1 * d6;
+    if (vb <= 0 && d2 >= 0 && d6 <= 0) { const real w = d2 / (d2 - d6); s[1] = s[2]; *n = 2; lam[0] = 1 - w; lam[1] = w; return; }
+    const real va = d3 * d6 - d5 * d4;
+    if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) { const real w = (d4 - d3) / ((d4 - d3) + (d5 - d6)); s[0] = s[1]; s[1] = s[2]; *n = 2; lam[0] = 1 - w; lam[1] = w; return; }
+    const real den = 1 / (va + vb + vc);
+    lam[1] = vb * den; lam[2] = vc * den; lam[0] = 1 - lam[1] - lam[2];
+    return;
+  }
+  /* tetrahedron: the closest of the faces the origin lies outside of; inside all of them: the cores overlap */
+  static const int F[4][3] = {{0, 1, 2}, {0, 2, 3}, {0, 3, 1}, {1, 3, 2}};
+  static const int OPP[4] = {3, 1, 2, 0};
+  real best = (real)1e30; int bn = 0; gjk_sv bs[3]; real bl[3] = {0, 0, 0};
+  for (int f = 0; f < 4; f++) {
+    const real *a = s[F[f][0]].w, *b = s[F[f][1]].w, *c = s[F[f][2]].w, *d = s[OPP[f]].w;
+    real ab[3], ac[3], nrm[3], ad[3];
+    v3sub(ab, b, a); v3sub(ac, c, a); v3cross(nrm, ab, ac); v3sub(ad, d, a);
+    const real so = -v3dot(a, nrm), sd = v3dot(ad, nrm);
+    if (so * sd > 0) continue;
+    if (sd == 0 && so == 0) continue;
+    gjk_sv t[3] = {s[F[f][0]], s[F[f][1]], s[F[f][2]]}; int tn = 3; real tl[3];
+    gjk_closest(t, &tn, tl);
+    real q[3] = {0, 0, 0};
+    for (int i = 0; i < tn; i++) v3axpy(q, tl[i], t[i].w);
+    const real dd = v3dot(q, q);
+    if (dd < best) { best = dd; bn = tn; for (int i = 0; i < tn; i++) { bs[i] = t[i]; bl[i] = tl[i]; } }
+  }
+  if (bn == 0) { *n = 4; return; }
+  for (int i = 0; i < bn; i++) { s[i] = bs[i]; lam[i] = bl[i]; }
+  *n = bn;
+}
+/* returns 1 and the contact (normal from the box toward the hull, point = midpoint, like hull_face), 0 = farther apart than margin, -1 = the cores touch or
+ * overlap (deeper than the two margins: the OBB path keeps that case) */
+static int hull_box_gjk(const rpo_env* e, int hc, int bc, real margin, cpoint* out) {
+  const rp_model* m = &e->m;
+  const float (*hv)[4]; const int *hoff, *hcnt;
+  rp_hull_tables(m->kind, &hv, &hoff, &hcnt);
+  const int nvert = hcnt ? hcnt[hc] : 0;
+  if (nvert == 0) return -1;
+  hv += hoff[hc];
+  const xform* xa = &e->xb[m->col_body[hc]];
+  const xform* xb = &e->xc[bc];
+  real hb[3];
+  for (int k = 0; k < 3; k++) { const real h = (real)m->col_he[bc][k]; hb[k] = h - (HULL_MARGIN < h ? HULL_MARGIN : h); }
+  gjk_sv s[4]; int n = 0; real lam[4] = {0, 0, 0, 0};
+  real v[3]; v3sub(v, xa->p, xb->p);
+  if (v3dot(v, v) < GJK_ZERO) v3set(v, 1, 0, 0);
+  real dd = (real)1e30;
+  for (int it = 0; it < 32; it++) {
+    gjk_sv sv;
+    {                                                        /* hull: the vertex of largest projection on -v (first of equals) */
+      real dl[3], nv[3] = {-v[0], -v[1], -v[2]};
+      m3tmulv(dl, xa->R, nv);
+      int bi = 0; real bd = (real)-1e30;
+      for (int i = 0; i < nvert; i++) {
+        const real d = (real)hv[i][0] * dl[0] + (real)hv[i][1] * dl[1] + (real)hv[i][2] * dl[2];
+        if (d > bd) { bd = d; bi = i; }
+      }
+      const real l[3] = {(real)hv[bi][0], (real)hv[bi][1], (real)hv[bi][2]};
+      m3mulv(sv.a, xa->R, l); v3add(sv.a, sv.a, xa->p);
+    }
+    {                                                        /* box core: the corner of largest projection on v */
+      real dl[3], l[3];
+      m3tmulv(dl, xb->R, v);
+      for (int k = 0; k < 3; k++) l[k] = dl[k] >= 0 ? hb[k] : -hb[k];
+      m3mulv(sv.b, xb->R, l); v3add(sv.b, sv.b, xb->p);
+    }
+    v3sub(sv.w, sv.a, sv.b);
+    const real vv = v3dot(v, v), vw = v3dot(v, sv.w);
+    int dup = 0;
+    for (int i = 0; i < n; i++) { real d[3]; v3sub(d, s[i].w, sv.w); if (v3dot(d, d) < GJK_DUP) dup = 1; }
+    if (dup || (n > 0 && vv - vw <= GJK_REL * vv)) break;
+    s[n++] = sv;
+    gjk_closest(s, &n, lam);
+    if (n == 4) return -1;
+    real q[3] = {0, 0, 0};
+    for (int i = 0; i < n; i++) v3axpy(q, lam[i], s[i].w);
+    const real nd = v3dot(q, q);
+    v3cpy(v, q);
+    if (nd < GJK_ZERO) return -1;
+    if (nd >= dd * GJK_STALL && it > 0) { dd = nd; break; }
+    dd = nd;
+  }
+  real pb[3] = {0, 0, 0};
+  for (int i = 0; i < n; i++) v3axpy(pb, lam[i], s[i].b);
+  const real dist = R_SQRT(v3dot(v, v));
+  if (!(dist > GJK_ZERO)) return -1;
+  real nB[3]; v3scale(nB, v, 1 / dist);
+  const real d = dist - 2 * HULL_MARGIN;                     /* both margins */
+  if (d > margin) return 0;
+  real pB[3]; v3cpy(pB, pb); v3axpy(pB, HULL_MARGIN, nB);    /* on the box's surface */
+  v3cpy(out->n, nB); out->dist = d;
+  v3cpy(out->p, pB); v3axpy(out->p, (real)0.5 * d, nB);
+  return 1;
+}
+
 /* ------------------------------------------------------------------ RPO_RULE_PERSIST: persistent manifolds (btPersistentManifold's life cycle on the fast
  * model's own manifolds: one per OBJECT pair, <= 4 points).  Per substep:
  *   1. candidates as in collide() - same broadphase, caps and narrowphase, but a box pair makes points only while the boxes overlap (the cache keeps them
@@ -550,6 +684,14 @@ static void collide_persistent(rpo_env* e) {
     else if ((e->rule & RPO_RULE_HULLMOV) && (e->rule & RPO_RULE_HULLFACE) && m->col_type[a] == 0 && m->col_type[b] == 0 && body_is_arm(e, m->col_body[b]) && !body_is_arm(e, m->col_body[a]) && m->col_body[a] != 0) {
       hf = hull_face(e, b, a, margin, pts);      /* a movable box (collider a) against an arm link's hull (collider b): the pair's normal points from b toward a */
       if (hf == 1) v3scale(pts[0].n, pts[0].n, -1);
+    }
+    if (hf == -1 && (e->rule & RPO_RULE_GJK) && (e->rule & RPO_RULE_HULLFACE)) {
+      /* the vertex lies beside the face: GJK's distance phase (hull = the arm link's collider, whichever of the two it is) */
+      if (m->col_type[b] == 0 && m->col_body[b] == 0 && body_is_arm(e, m->col_body[a])) hf = hull_box_gjk(e, a, b, margin, pts);
+      else if ((e->rule & RPO_RULE_HULLMOV) && m->col_type[a] == 0 && m->col_type[b] == 0 && body_is_arm(e, m->col_body[b]) && !body_is_arm(e, m->col_body[a]) && m->col_body[a] != 0) {
+        hf = hull_box_gjk(e, b, a, margin, pts);
+        if (hf == 1) v3scale(pts[0].n, pts[0].n, -1);
+      }
     }
 #ifdef RPO_ABX
     if (hf == -1 && (e->rule & 4096)) {      /* EXPERIMENT: where the vertex lies beside the face, the reference step's own GJK / EPA on the same shapes instead of the OBB path */
@@ -758,6 +900,13 @@ static void collide(rpo_env* e) {
     else if ((e->rule & RPO_RULE_HULLMOV) && (e->rule & RPO_RULE_HULLFACE) && m->col_type[a] == 0 && m->col_type[b] == 0 && body_is_arm(e, m->col_body[b]) && !body_is_arm(e, m->col_body[a]) && m->col_body[a] != 0) {
       hf = hull_face(e, b, a, margin, pts);      /* a movable box (collider a) against an arm link's hull (collider b): the pair's normal points from b toward a */
       if (hf == 1) v3scale(pts[0].n, pts[0].n, -1);
+    }
+    if (hf == -1 && (e->rule & RPO_RULE_GJK) && (e->rule & RPO_RULE_HULLFACE)) {
+      if (m->col_type[b] == 0 && m->col_body[b] == 0 && body_is_arm(e, m->col_body[a])) hf = hull_box_gjk(e, a, b, margin, pts);
+      else if ((e->rule & RPO_RULE_HULLMOV) && m->col_type[a] == 0 && m->col_type[b] == 0 && body_is_arm(e, m->col_body[b]) && !body_is_arm(e, m->col_body[a]) && m->col_body[a] != 0) {
+        hf = hull_box_gjk(e, b, a, margin, pts);
+        if (hf == 1) v3scale(pts[0].n, pts[0].n, -1);
+      }
     }
     if (hf >= 0) np = hf;
     else if (m->col_type[a] == 0 && m->col_type[b] == 0)
