@@ -82,6 +82,11 @@ enum rp_config_flags {
                                    * threshold; a box pair makes new points only while the boxes overlap.  The cache is part of the state (rp_get_state /
                                    * rp_set_state rows carry it behind the record).  With the flag: round 3's first model - points
                                    * exist out to the pair's margin, nothing is remembered (13 % faster, further from Bullet: DESIGN.md section 2) */
+  ,
+  RP_CFG_HULL_GJK = 256           /* (no field) an arm link whose deepest hull vertex lies BESIDE the box face it approaches (box edges and corners) gets its contact
+                                   * from GJK's distance phase on hull and box instead of from the link's OBB (oracle RPO_RULE_GJK; closer to Bullet on those
+                                   * contacts - DESIGN.md section 2 - at 23 % of the throughput: a serial algorithm on one wave, it is the tail of every launch
+                                   * it occurs in).  Default: off */
 };
 
 typedef struct rp_config {

@@ -458,7 +458,7 @@ static int manifold_replace_index(const contact* c4, const contact* pt) {
  * normals on the hull's VERTICES; the contact is the hull vertex deepest along the face of least penetration, if it lies over that face.  This is
  * what GJK / EPA return for a vertex-on-face contact (the generic case of a link touching the ground plate or the table top); anything else
  * (vertex beside the face: edges, corners) is left to the OBB path.  Returns 1 and the point, 0 = no contact within margin, -1 = use the OBB path. */
-static int hull_face(const rpo_env* e, int a, int b, real margin, cpoint* out) {
+static int hull_face(const rpo_env* e, int a, int b, real margin, cpoint* out, real* lv) {
   const rp_model* m = &e->m;
   const float (*hv)[4]; const int *hoff, *hcnt;
   rp_hull_tables(m->kind, &hv, &hoff, &hcnt);
@@ -499,10 +499,13 @@ static int hull_face(const rpo_env* e, int a, int b, real margin, cpoint* out) {
   const real v[3] = {(real)hv[iv][0], (real)hv[iv][1], (real)hv[iv][2]};
   real w[3];
   m3mulv(w, xa->R, v); v3add(w, w, xa->p);
+  int beside = 0;
   for (int j = 0; j < 3; j++) {
     const real l = (u[j][0] * v[0] + u[j][1] * v[1] + u[j][2] * v[2]) - c[j];
-    if (j != k && R_FABS(l) > (real)m->col_he[b][j]) return -1;      /* beside the face: edges and corners stay with the OBB path */
+    lv[j] = l;                                               /* (the vertex in box coordinates: where hull_box_gjk starts from) */
+    if (j != k && R_FABS(l) > (real)m->col_he[b][j]) beside = 1;
   }
+  if (beside) return -1;                                     /* beside the face: edges and corners stay with the OBB path */
   real nl[3] = {0, 0, 0}; nl[k] = (bf & 1) ? -1 : 1;
   real n[3]; m3mulv(n, xb->R, nl);
   /* point on the box face under the vertex, then mode A's single application point: halfway along the gap */
@@ -582,7 +585,7 @@ static void gjk_closest(gjk_sv* s, int* n, real* lam) {      /* closest point of
 }
 /* returns 1 and the contact (normal from the box toward the hull, point = midpoint, like hull_face), 0 = farther apart than margin, -1 = the cores touch or
  * overlap (deeper than the two margins: the OBB path keeps that case) */
-static int hull_box_gjk(const rpo_env* e, int hc, int bc, real margin, cpoint* out) {
+static int hull_box_gjk(const rpo_env* e, int hc, int bc, real margin, const real* lv, cpoint* out) {
   const rp_model* m = &e->m;
   const float (*hv)[4]; const int *hoff, *hcnt;
   rp_hull_tables(m->kind, &hv, &hoff, &hcnt);
@@ -594,7 +597,11 @@ static int hull_box_gjk(const rpo_env* e, int hc, int bc, real margin, cpoint* o
   real hb[3];
   for (int k = 0; k < 3; k++) { const real h = (real)m->col_he[bc][k]; hb[k] = h - (HULL_MARGIN < h ? HULL_MARGIN : h); }
   gjk_sv s[4]; int n = 0; real lam[4] = {0, 0, 0, 0};
-  real v[3]; v3sub(v, xa->p, xb->p);
+  /* first direction: from the box core's nearest point to the vertex hull_face stopped at (lv: that vertex in box coordinates) - two or three rounds from
+   * there instead of the half dozen from the line of centres */
+  real v[3];
+  { real dl[3]; for (int k = 0; k < 3; k++) dl[k] = lv[k] - (lv[k] > hb[k] ? hb[k] : (lv[k] < -hb[k] ? -hb[k] : lv[k])); m3mulv(v, xb->R, dl); }
+  if (v3dot(v, v) < GJK_ZERO) v3sub(v, xa->p, xb->p);
   if (v3dot(v, v) < GJK_ZERO) v3set(v, 1, 0, 0);
   real dd = (real)1e30;
   for (int it = 0; it < 32; it++) {
@@ -679,17 +686,17 @@ static void collide_persistent(rpo_env* e) {
     cpoint pts[4]; int np = 0;
     real ha[3], hb[3];
     for (int k = 0; k < 3; k++) { ha[k] = (real)m->col_he[a][k]; hb[k] = (real)m->col_he[b][k]; }
-    int hf = -1;
-    if ((e->rule & RPO_RULE_HULLFACE) && m->col_type[b] == 0 && m->col_body[b] == 0 && body_is_arm(e, m->col_body[a])) hf = hull_face(e, a, b, margin, pts);
+    int hf = -1; real hlv[3] = {0, 0, 0};
+    if ((e->rule & RPO_RULE_HULLFACE) && m->col_type[b] == 0 && m->col_body[b] == 0 && body_is_arm(e, m->col_body[a])) hf = hull_face(e, a, b, margin, pts, hlv);
     else if ((e->rule & RPO_RULE_HULLMOV) && (e->rule & RPO_RULE_HULLFACE) && m->col_type[a] == 0 && m->col_type[b] == 0 && body_is_arm(e, m->col_body[b]) && !body_is_arm(e, m->col_body[a]) && m->col_body[a] != 0) {
-      hf = hull_face(e, b, a, margin, pts);      /* a movable box (collider a) against an arm link's hull (collider b): the pair's normal points from b toward a */
+      hf = hull_face(e, b, a, margin, pts, hlv);      /* a movable box (collider a) against an arm link's hull (collider b): the pair's normal points from b toward a */
       if (hf == 1) v3scale(pts[0].n, pts[0].n, -1);
     }
     if (hf == -1 && (e->rule & RPO_RULE_GJK) && (e->rule & RPO_RULE_HULLFACE)) {
       /* the vertex lies beside the face: GJK's distance phase (hull = the arm link's collider, whichever of the two it is) */
-      if (m->col_type[b] == 0 && m->col_body[b] == 0 && body_is_arm(e, m->col_body[a])) hf = hull_box_gjk(e, a, b, margin, pts);
+      if (m->col_type[b] == 0 && m->col_body[b] == 0 && body_is_arm(e, m->col_body[a])) hf = hull_box_gjk(e, a, b, margin, hlv, pts);
       else if ((e->rule & RPO_RULE_HULLMOV) && m->col_type[a] == 0 && m->col_type[b] == 0 && body_is_arm(e, m->col_body[b]) && !body_is_arm(e, m->col_body[a]) && m->col_body[a] != 0) {
-        hf = hull_box_gjk(e, b, a, margin, pts);
+        hf = hull_box_gjk(e, b, a, margin, hlv, pts);
         if (hf == 1) v3scale(pts[0].n, pts[0].n, -1);
       }
     }
@@ -894,17 +901,17 @@ static void collide(rpo_env* e) {
     cpoint pts[4]; int np = 0;
     real ha[3], hb[3];
     for (int k = 0; k < 3; k++) { ha[k] = (real)m->col_he[a][k]; hb[k] = (real)m->col_he[b][k]; }
-    int hf = -1;
+    int hf = -1; real hlv[3] = {0, 0, 0};
     if ((e->rule & RPO_RULE_HULLFACE) && m->col_type[b] == 0 && m->col_body[b] == 0 && body_is_arm(e, m->col_body[a]))
-      hf = hull_face(e, a, b, margin, pts);
+      hf = hull_face(e, a, b, margin, pts, hlv);
     else if ((e->rule & RPO_RULE_HULLMOV) && (e->rule & RPO_RULE_HULLFACE) && m->col_type[a] == 0 && m->col_type[b] == 0 && body_is_arm(e, m->col_body[b]) && !body_is_arm(e, m->col_body[a]) && m->col_body[a] != 0) {
-      hf = hull_face(e, b, a, margin, pts);      /* a movable box (collider a) against an arm link's hull (collider b): the pair's normal points from b toward a */
+      hf = hull_face(e, b, a, margin, pts, hlv);      /* a movable box (collider a) against an arm link's hull (collider b): the pair's normal points from b toward a */
       if (hf == 1) v3scale(pts[0].n, pts[0].n, -1);
     }
     if (hf == -1 && (e->rule & RPO_RULE_GJK) && (e->rule & RPO_RULE_HULLFACE)) {
-      if (m->col_type[b] == 0 && m->col_body[b] == 0 && body_is_arm(e, m->col_body[a])) hf = hull_box_gjk(e, a, b, margin, pts);
+      if (m->col_type[b] == 0 && m->col_body[b] == 0 && body_is_arm(e, m->col_body[a])) hf = hull_box_gjk(e, a, b, margin, hlv, pts);
       else if ((e->rule & RPO_RULE_HULLMOV) && m->col_type[a] == 0 && m->col_type[b] == 0 && body_is_arm(e, m->col_body[b]) && !body_is_arm(e, m->col_body[a]) && m->col_body[a] != 0) {
-        hf = hull_box_gjk(e, b, a, margin, pts);
+        hf = hull_box_gjk(e, b, a, margin, hlv, pts);
         if (hf == 1) v3scale(pts[0].n, pts[0].n, -1);
       }
     }
@@ -1510,8 +1517,8 @@ static int collide_persist(rpo_env* e) {
     real ha[3], hb[3];
     for (int k = 0; k < 3; k++) { ha[k] = (real)m->col_he[a][k]; hb[k] = (real)m->col_he[b][k]; }
     const real margin = (real)mf->thr;
-    int hf = -1;
-    if ((e->rule & RPO_RULE_HULLFACE) && m->col_type[b] == 0 && m->col_body[b] == 0 && body_is_arm(e, m->col_body[a])) hf = hull_face(e, a, b, margin, pts);
+    int hf = -1; real hlv[3] = {0, 0, 0};
+    if ((e->rule & RPO_RULE_HULLFACE) && m->col_type[b] == 0 && m->col_body[b] == 0 && body_is_arm(e, m->col_body[a])) hf = hull_face(e, a, b, margin, pts, hlv);
     if (hf >= 0) np = hf;
     else if (m->col_type[a] == 0 && m->col_type[b] == 0) np = box_box(e->xc[a].p, e->xc[a].R, ha, e->xc[b].p, e->xc[b].R, hb, 0, 1, pts);      /* overlap only: the manifold keeps the points */
     else if (m->col_type[a] == 0 && m->col_type[b] == 1) np = sphere_box(e->xc[b].p, hb[0], e->xc[a].p, e->xc[a].R, ha, margin, 1, pts);
@@ -2288,7 +2295,7 @@ rpo_env* rpo_create(int kind, unsigned long long seed, int env_index) {
   e->nv = m->n_arm + 6 * m->n_free + m->n_joint1;
   e->nbody = 1 + m->n_arm + m->n_free + m->n_joint1;
   e->seed = seed; e->env_index = (uint32_t)env_index;
-  e->rule = RPO_RULE_ORDER | RPO_RULE_LIMIT | RPO_RULE_HULLFACE | RPO_RULE_BOXOVERLAP | RPO_RULE_ODEORDER | RPO_RULE_LEVER | RPO_RULE_SPIN | RPO_RULE_PERSIST | RPO_RULE_HULLMOV;       /* the shipped model (the HIP kernels implement exactly this); rpo_set_rule(0) = round 2's rule */
+  e->rule = RPO_RULE_ORDER | RPO_RULE_LIMIT | RPO_RULE_HULLFACE | RPO_RULE_BOXOVERLAP | RPO_RULE_ODEORDER | RPO_RULE_LEVER | RPO_RULE_SPIN | RPO_RULE_PERSIST | RPO_RULE_HULLMOV;       /* the shipped model (the HIP kernels implement exactly this; RPO_RULE_GJK on top = the library's RP_CFG_HULL_GJK); rpo_set_rule(0) = round 2's rule */
   e->margin = -1; e->rew_thresh = (real)0.05; e->dense_reward = 0;
   /* envList.py:8-10, 18-22, 73-99: the env's flags and ranges go with its scene (play ids: complex_scene; reach ids:
    * default_scene; pick / push: push_scene); other ids on the same model override the ranges (rpo_set_ranges) */

@@ -190,15 +190,21 @@ __device__ unsigned long long g_clk[32 * 4096];
 #define CLK_MARK(i) if (lane == 0) { g_clk[8 * wb + (i)] = __builtin_readcyclecounter(); }      /* (k_solve2: wb = the wave's number in the launch) */
 #if RP_CLOCKS == 2
 #define PCLK(i) if (lane == 0) { g_clk[32 * (blockIdx.x & 4095) + (i)] = (i) >= 6 && (i) < 8 ? wall_clock64() : __builtin_readcyclecounter(); }
+#define PCLK_ZERO(i) if (lane == 0) { g_clk[32 * (blockIdx.x & 4095) + (i)] = 0ull; }
+#define PCLK_ADD(i, v) if (lane == 0) { g_clk[32 * (blockIdx.x & 4095) + (i)] += (unsigned long long)(v); }
 #define CLK_MARK2(i)
 #else
 #define PCLK(i)
+#define PCLK_ZERO(i)
+#define PCLK_ADD(i, v)
 #define CLK_MARK2(i) CLK_MARK(i)
 #endif
 #else
 #define CLK_MARK(i)
 #define CLK_MARK2(i)
 #define PCLK(i)
+#define PCLK_ZERO(i)
+#define PCLK_ADD(i, v)
 #endif
 
 /* The phases of a substep each run inside ONE wave (k_prep2 runs two of them side by side in the two waves of its block), so what they need
@@ -485,6 +491,88 @@ __device__ __forceinline__ float pick1(int i, float a, float b, float c) { retur
  * needed, so that the second scan finds the extreme of the first by equality */
 __device__ __forceinline__ float hull_coord(V3 u, float4 v, float c) { return __fmaf_rn(u.z, v.z, __fmaf_rn(u.y, v.y, u.x * v.x)) - c; }
 
+/* ---- GJK distance between an arm link's hull and a box (oracle hull_box_gjk, RPO_RULE_GJK): the simplex lives in the pair's narrowphase scratch
+ * (point k: w, a, b = 9 floats at S + 9 k), every lane runs the same closest-point arithmetic on it (LDS broadcasts; all lanes store the same values), the
+ * support queries are the whole-wave vertex scans of the hull contact above. */
+#define GJK_DUP 1e-12f
+#define GJK_REL 1e-6f
+#define GJK_ZERO 1e-12f
+#define GJK_STALL (1.f - 1e-6f)
+/* One pass of the wave over a link's hull vertices (lane, lane + 64, ...; per lane in rising order), HULL_UNROLL loads in flight at a time.  Measured with
+ * 2 / 4 / 8: nothing (the table sits in L2, the links near the scene have some two hundred vertices - three rounds) and the registers do not exist: 1 */
+template <int HULL_UNROLL, class F>
+__device__ __forceinline__ void hull_scan(const float4* __restrict__ tv, int nn, int lane, F&& f) {
+  for (int base = lane; base < nn; base += 64 * HULL_UNROLL) {
+    float4 q[HULL_UNROLL];
+#pragma unroll
+    for (int u = 0; u < HULL_UNROLL; u++) { const int i = base + 64 * u; q[u] = tv[i < nn ? i : base]; }
+#pragma unroll
+    for (int u = 0; u < HULL_UNROLL; u++) { const int i = base + 64 * u; if (i < nn) f(q[u], i); }
+  }
+}
+__device__ __forceinline__ void gjk_cp(float* dst, const float* src) { for (int t = 0; t < 9; t++) dst[t] = src[t]; }
+/* closest point of the simplex S[0 .. n) (n <= 3) to the origin; the simplex shrinks to the supporting sub-simplex (Ericson's sub-cases) */
+__device__ __forceinline__ void gjk_closest3(float* S, int& n, float* lam) {
+  if (n == 1) { lam[0] = 1.f; return; }
+  if (n == 2) {
+    const V3 a = ld3(S), b = ld3(S + 9), ab = b - a;
+    const float t = -dot(a, ab), den = dot(ab, ab);
+    if (t <= 0.f || den <= 0.f) { n = 1; lam[0] = 1.f; return; }
+    if (t >= den) { gjk_cp(S, S + 9); n = 1; lam[0] = 1.f; return; }
+    lam[1] = t / den; lam[0] = 1.f - lam[1];
+    return;
+  }
+  const V3 a = ld3(S), b = ld3(S + 9), c = ld3(S + 18), ab = b - a, ac = c - a;
+  const float d1 = -dot(ab, a), d2 = -dot(ac, a);
+  if (d1 <= 0.f && d2 <= 0.f) { n = 1; lam[0] = 1.f; return; }
+  const float d3 = -dot(ab, b), d4 = -dot(ac, b);
+  if (d3 >= 0.f && d4 <= d3) { gjk_cp(S, S + 9); n = 1; lam[0] = 1.f; return; }
+  const float vc = d1 * d4 - d3 * d2;
+  if (vc <= 0.f && d1 >= 0.f && d3 <= 0.f) { const float v = d1 / (d1 - d3); n = 2; lam[0] = 1.f - v; lam[1] = v; return; }
+  const float d5 = -dot(ab, c), d6 = -dot(ac, c);
+  if (d6 >= 0.f && d5 <= d6) { gjk_cp(S, S + 18); n = 1; lam[0] = 1.f; return; }
+  const float vb = d5 * d2 - d1 * d6;
+  if (vb <= 0.f && d2 >= 0.f && d6 <= 0.f) { const float w = d2 / (d2 - d6); gjk_cp(S + 9, S + 18); n = 2; lam[0] = 1.f - w; lam[1] = w; return; }
+  const float va = d3 * d6 - d5 * d4;
+  if (va <= 0.f && (d4 - d3) >= 0.f && (d5 - d6) >= 0.f) { const float w = (d4 - d3) / ((d4 - d3) + (d5 - d6)); gjk_cp(S, S + 9); gjk_cp(S + 9, S + 18); n = 2; lam[0] = 1.f - w; lam[1] = w; return; }
+  const float den = 1.f / (va + vb + vc);
+  lam[1] = vb * den; lam[2] = vc * den; lam[0] = 1.f - lam[1] - lam[2];
+}
+/* ... of a tetrahedron S[0 .. 4): the closest of the faces the origin lies outside of (T: 27 floats of scratch; the winning face is solved a second time
+ * instead of being kept: registers are what this kernel is short of); n stays 4 when the origin is inside */
+__device__ __forceinline__ void gjk_face(const float* S, float* T, int f) {
+  const int i0 = f == 3 ? 1 : 0, i1 = f == 0 ? 1 : (f == 1 ? 2 : 3), i2 = f == 0 ? 2 : (f == 1 ? 3 : (f == 2 ? 1 : 2));
+  gjk_cp(T, S + 9 * i0); gjk_cp(T + 9, S + 9 * i1); gjk_cp(T + 18, S + 9 * i2);
+}
+__device__ __forceinline__ void gjk_closest4(float* S, float* T, int& n, float* lam) {
+  float best = 1e30f; int bf = -1;
+#pragma unroll 1
+  for (int f = 0; f < 4; f++) {
+    const int i0 = f == 3 ? 1 : 0, i1 = f == 0 ? 1 : (f == 1 ? 2 : 3), i2 = f == 0 ? 2 : (f == 1 ? 3 : (f == 2 ? 1 : 2)), io = f == 0 ? 3 : (f == 1 ? 1 : (f == 2 ? 2 : 0));
+    float so, sd;
+    {
+      const V3 a = ld3(S + 9 * i0), nrm = cross(ld3(S + 9 * i1) - a, ld3(S + 9 * i2) - a);
+      so = -dot(a, nrm); sd = dot(ld3(S + 9 * io) - a, nrm);
+    }
+    if (so * sd > 0.f) continue;
+    if (sd == 0.f && so == 0.f) continue;
+    gjk_face(S, T, f);
+    int tn = 3; float tl[3] = {0.f, 0.f, 0.f};
+    gjk_closest3(T, tn, tl);
+    V3 q = ld3(T) * tl[0];
+    if (tn > 1) q = q + ld3(T + 9) * tl[1];
+    if (tn > 2) q = q + ld3(T + 18) * tl[2];
+    const float dd = dot(q, q);
+    if (dd < best) { best = dd; bf = f; }
+  }
+  if (bf < 0) { n = 4; return; }
+  gjk_face(S, T, bf);
+  int tn = 3;
+  gjk_closest3(T, tn, lam);
+  for (int t = 0; t < 9 * tn; t++) S[t] = T[t];
+  n = tn;
+}
+
 template <class LDS>
 __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int lane, int nact) {
   const int g = lane >> 3, s = lane & 7;
@@ -546,7 +634,12 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
         const float r1 = ha.x * fabsf(dot(B1, A0)) + ha.y * fabsf(dot(B1, A1)) + ha.z * fabsf(dot(B1, A2));
         const float r2 = ha.x * fabsf(dot(B2, A0)) + ha.y * fabsf(dot(B2, A1)) + ha.z * fabsf(dot(B2, A2));
         const float og = fmaxf(fmaxf(fabsf(dot(B0, tt)) - r0 - hb.x, fabsf(dot(B1, tt)) - r1 - hb.y), fabsf(dot(B2, tt)) - r2 - hb.z);
-        if (og > margin0 + RP_HULL_MARGIN + 1e-5f) { hq = false; hf = 0; }
+        /* ... and along the link OBB's own three axes (a lower bound of the hull's distance all the same: fewer pairs reach the scan and the GJK behind it) */
+        const float q0 = hb.x * fabsf(dot(A0, B0)) + hb.y * fabsf(dot(A0, B1)) + hb.z * fabsf(dot(A0, B2));
+        const float q1 = hb.x * fabsf(dot(A1, B0)) + hb.y * fabsf(dot(A1, B1)) + hb.z * fabsf(dot(A1, B2));
+        const float q2 = hb.x * fabsf(dot(A2, B0)) + hb.y * fabsf(dot(A2, B1)) + hb.z * fabsf(dot(A2, B2));
+        const float og2 = fmaxf(fmaxf(fabsf(dot(A0, tt)) - q0 - ha.x, fabsf(dot(A1, tt)) - q1 - ha.y), fabsf(dot(A2, tt)) - q2 - ha.z);
+        if (fmaxf(og, og2) > margin0 + RP_HULL_MARGIN + 1e-5f) { hq = false; hf = 0; }
       }
       /* The pairs that are left - rare - are done by the WHOLE WAVE, one at a time (a link of a thousand vertices in sixteen rounds instead of 125: its block
        * would otherwise end long after the rest of the launch): the pair's two collider indices go to all lanes, everything below is the same in every
@@ -570,11 +663,10 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
         const int nn = m->hull_cnt[ca];
         const float4* tv = (const float4*)m->hullv + m->hull_off[ca];
         float lo0 = 1e30f, lo1 = 1e30f, lo2 = 1e30f, hi0 = -1e30f, hi1 = -1e30f, hi2 = -1e30f;
-        for (int i = lane; i < nn; i += 64) {
-          const float4 v = tv[i];
+        hull_scan<1>(tv, nn, lane, [&](const float4& v, int) {
           const float l0 = hull_coord(u0, v, c0), l1 = hull_coord(u1, v, c1), l2 = hull_coord(u2, v, c2);
           lo0 = fminf(lo0, l0); hi0 = fmaxf(hi0, l0); lo1 = fminf(lo1, l1); hi1 = fmaxf(hi1, l1); lo2 = fminf(lo2, l2); hi2 = fmaxf(hi2, l2);
-        }
+        });
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
           lo0 = fminf(lo0, __shfl_xor(lo0, off)); lo1 = fminf(lo1, __shfl_xor(lo1, off)); lo2 = fminf(lo2, __shfl_xor(lo2, off));
@@ -598,8 +690,7 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
           const float ck = pick1(k, c0, c1, c2);
           const float ext = (bf & 1) ? pick1(k, hi0, hi1, hi2) : pick1(k, lo0, lo1, lo2);
           int iv = 0x7fffffff;
-          for (int i = lane; i < nn; i += 64)
-            if (hull_coord(uk, tv[i], ck) == ext) { iv = i; break; }
+          hull_scan<1>(tv, nn, lane, [&](const float4& v, int i) { if (hull_coord(uk, v, ck) == ext) iv = min(iv, i); });
 #pragma unroll
           for (int off = 1; off < 64; off <<= 1) iv = min(iv, __shfl_xor(iv, off));
           out = -1;
@@ -607,6 +698,7 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
             const float4 v = tv[iv];
             const float l0 = hull_coord(u0, v, c0), l1 = hull_coord(u1, v, c1), l2 = hull_coord(u2, v, c2);
             const bool beside = (k != 0 && fabsf(l0) > hc0.x) || (k != 1 && fabsf(l1) > hc0.y) || (k != 2 && fabsf(l2) > hc0.z);
+            st3(&L.npscr[NPG_SCRATCH * (src >> 3) + 87], mk3(l0, l1, l2));      /* (the vertex in box coordinates: where the GJK below starts from) */
             if (!beside) {
               out = 1;
               const V3 w = mulv(Rw, mk3(v.x, v.y, v.z)) + pw;
@@ -616,6 +708,87 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
               pt.p = pB + nrm * (0.5f * d); pt.n = flip ? -nrm : nrm; pt.dist = d;
             }
           }
+        }
+        if (out == -1 && m->gjk) {
+          /* the deepest vertex lies BESIDE the face (box edges and corners): GJK's distance phase, cores with the 0.001 margin around each (oracle hull_box_gjk;
+           * -1 again = the cores touch or overlap: the OBB path keeps that case).  The two transforms move to the scratch and are read where they are needed */
+          float* S = &L.npscr[NPG_SCRATCH * (src >> 3)];
+          float* X = S + 63;
+          PCLK_ADD(27, 1) PCLK_ADD(28, -(long long)__builtin_readcyclecounter()) PCLK_ADD(29, nn)
+          for (int t = 0; t < 9; t++) { X[t] = Rw.m[t]; X[12 + t] = xc.R.m[t]; }
+          st3(X + 9, pw); st3(X + 21, xc.p);
+          const V3 hbc = mk3(hc0.x - fminf(RP_HULL_MARGIN, hc0.x), hc0.y - fminf(RP_HULL_MARGIN, hc0.y), hc0.z - fminf(RP_HULL_MARGIN, hc0.z));
+          /* first direction: from the box core's nearest point to the vertex the scan stopped at - two or three rounds from there */
+          const V3 lv = ld3(X + 24);
+          V3 v = mulv(xc.R, mk3(lv.x - fminf(fmaxf(lv.x, -hbc.x), hbc.x), lv.y - fminf(fmaxf(lv.y, -hbc.y), hbc.y), lv.z - fminf(fmaxf(lv.z, -hbc.z), hbc.z)));
+          if (dot(v, v) < GJK_ZERO) v = pw - xc.p;
+          asm volatile("" ::: "memory");
+          WSYNC();
+          if (dot(v, v) < GJK_ZERO) v = mk3(1, 0, 0);
+          int n = 0; float lam[3] = {0.f, 0.f, 0.f};
+          float dd = 1e30f;
+          bool fail = false;
+#pragma unroll 1
+          for (int it = 0; it < 32; it++) {
+            V3 w, sa, sb;
+            PCLK_ADD(26, 1)
+            {                                                /* hull: the vertex of largest projection on -v (lowest index among equals) */
+              const V3 dl = tmulv(ldm3(X), -v);
+              float bd = -1e30f; int bi = 0x7fffffff;
+              hull_scan<1>(tv, nn, lane, [&](const float4& q, int i) {
+                const float dq = __fmaf_rn(dl.z, q.z, __fmaf_rn(dl.y, q.y, dl.x * q.x));
+                if (dq > bd) { bd = dq; bi = i; }
+              });
+#pragma unroll
+              for (int off = 1; off < 64; off <<= 1) {
+                const float od = __shfl_xor(bd, off); const int oi = __shfl_xor(bi, off);
+                if (od > bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
+              }
+              const float4 qv = tv[bi < nn ? bi : 0];
+              sa = mulv(ldm3(X), mk3(qv.x, qv.y, qv.z)) + ld3(X + 9);
+            }
+            {                                                /* box core: the corner of largest projection on v */
+              const M3 Rb = ldm3(X + 12);
+              const V3 dlb = tmulv(Rb, v);
+              sb = mulv(Rb, mk3(dlb.x >= 0.f ? hbc.x : -hbc.x, dlb.y >= 0.f ? hbc.y : -hbc.y, dlb.z >= 0.f ? hbc.z : -hbc.z)) + ld3(X + 21);
+            }
+            w = sa - sb;
+            const float vv = dot(v, v), vw = dot(v, w);
+            bool dup = false;
+            for (int i = 0; i < n; i++) { const V3 dw = ld3(S + 9 * i) - w; dup |= dot(dw, dw) < GJK_DUP; }
+            if (dup || (n > 0 && vv - vw <= GJK_REL * vv)) break;
+            st3(S + 9 * n, w); st3(S + 9 * n + 3, sa); st3(S + 9 * n + 6, sb);
+            n++;
+            WSYNC();
+            if (n == 4) gjk_closest4(S, S + 36, n, lam); else gjk_closest3(S, n, lam);
+            WSYNC();
+            if (n == 4) { fail = true; break; }
+            V3 q = ld3(S) * lam[0];
+            if (n > 1) q = q + ld3(S + 9) * lam[1];
+            if (n > 2) q = q + ld3(S + 18) * lam[2];
+            const float nd = dot(q, q);
+            v = q;
+            if (nd < GJK_ZERO) { fail = true; break; }
+            if (nd >= dd * GJK_STALL && it > 0) { dd = nd; break; }
+            dd = nd;
+          }
+          PCLK_ADD(28, __builtin_readcyclecounter())
+          const float dist = sqrtf(dot(v, v));
+          if (!fail && dist > GJK_ZERO) {
+            V3 pbw = ld3(S + 6) * lam[0];
+            if (n > 1) pbw = pbw + ld3(S + 15) * lam[1];
+            if (n > 2) pbw = pbw + ld3(S + 24) * lam[2];
+            const V3 nB = v * (1.f / dist);
+            const float dg = dist - 2.f * RP_HULL_MARGIN;
+            if (dg > mg) out = 0;
+            else {
+              out = 1;
+              const V3 pB = pbw + nB * RP_HULL_MARGIN;
+              pt.p = pB + nB * (0.5f * dg); pt.n = flip ? -nB : nB; pt.dist = dg;
+            }
+          }
+          WSYNC();
+          asm volatile("" ::: "memory");
         }
         if ((lane >> 3) == (src >> 3)) {
           hf = out;
@@ -2679,7 +2852,7 @@ __device__ __forceinline__ void prep2_body(const DevModel* __restrict__ m, const
 #pragma unroll
     for (int t = 0; t < 8; t++) cnt8[t] = sort_cnt[8 * lane + t];
   }
-  PCLK(6) PCLK(0)
+  PCLK(6) PCLK(0) PCLK_ZERO(26) PCLK_ZERO(27) PCLK_ZERO(28) PCLK_ZERO(29)
   static_assert(RP_REC_FLOATS == PREP_THREADS, "one float of the record per thread");
   L.st[tid] = state[(size_t)env * RP_REC_FLOATS + tid];
   __syncthreads();

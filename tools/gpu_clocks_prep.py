@@ -47,3 +47,8 @@ npd = (a[:, 9] - a[:, 8]).astype(float)
 print('narrowphase cycles vs active pairs: corr %.2f' % np.corrcoef(na, npd)[0, 1])
 late = w0 > np.percentile(w0, 50)
 print('first-round waves: total p50 %d; second-round waves: total p50 %d' % (np.median(tot[~late]), np.median(tot[late])))
+g = a[:, 27] > 0
+if g.any():
+    print('GJK: waves with a call %d of %d; calls per such wave p50 %d max %d; rounds per call p50 %.1f max %.1f; cycles per call p50 %d max %d; vertices p50 %d max %d' % (
+        g.sum(), n, np.median(a[g, 27]), a[g, 27].max(), np.median(a[g, 26] / a[g, 27]), (a[g, 26] / a[g, 27]).max(), np.median(a[g, 28] / a[g, 27]), (a[g, 28] / a[g, 27]).max(),
+        np.median(a[g, 29] / a[g, 27]), (a[g, 29] / a[g, 27]).max()))

@@ -13,11 +13,12 @@ from roboticsplayroompybullet_amd import VecPlayEnv
 kind = sys.argv[1] if len(sys.argv) > 1 else 'U'
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 n = 16
-RULE = None      # the oracle's default rule = the shipped model
+RULE = int(os.environ['RP_ORACLE_RULE']) if 'RP_ORACLE_RULE' in os.environ else (1015 | 1024 if 'RP_GJK' in os.environ else None)      # default: the oracle's default rule = the shipped model; RP_GJK=1: RP_CFG_HULL_GJK against RPO_RULE_GJK
 env = VecPlayEnv(IDS[kind], n, seed=9, persistent_manifolds=True); env.reset()
 fus = VecPlayEnv(IDS[kind], n, seed=9, persistent_manifolds=True); fus.set_fused(1); fus.reset()
-o64 = [OracleEnv(kind, seed=9, env_index=e) for e in range(n)]
-o32 = [OracleEnv(kind, seed=9, env_index=e, f32=True) for e in range(n)]
+KW = {} if RULE is None else dict(rule=RULE)
+o64 = [OracleEnv(kind, seed=9, env_index=e, **KW) for e in range(n)]
+o32 = [OracleEnv(kind, seed=9, env_index=e, f32=True, **KW) for e in range(n)]
 for a, b in zip(o64, o32):
     a.reset(); b.reset(); s = a.get_state(); a.set_state(s); b.set_state(s)       # (set_state empties the caches: all four start without contact history)
 rec = torch.tensor(np.stack([record_from_oracle(o) for o in o64]))

@@ -85,10 +85,10 @@ def main():
     args = ap.parse_args()
     D = oracle.REF_DEFAULT
     # the shipped model's rule bits (rp_oracle.c RPO_RULE_*): 1 Bullet's row order, 2 violated-only limits, 4 hull vertices against static boxes, 16 arm boxes overlap-only,
-    # 32 box-box points in the detector's order, 64 per-body lever arms, 128 torsional friction rows, 256 persistent manifolds, 512 hull vertices against movable boxes too
+    # 32 box-box points in the detector's order, 64 per-body lever arms, 128 torsional friction rows, 256 persistent manifolds, 512 hull vertices against movable boxes too, 1024 GJK's distance phase beside the face
     ALL = 503 | 512
     variants = [('A default (shipped)', dict()), ('A round 2 (rule 0)', dict(rule=0)), ('A -order -limit', dict(rule=ALL & ~3)), ('A -hull', dict(rule=ALL & ~4)),
-                ('A -boxorder', dict(rule=ALL & ~32)), ('A -lever', dict(rule=ALL & ~64)), ('A -spin', dict(rule=ALL & ~128)), ('A -persist', dict(rule=ALL & ~256)), ('A -hullmov', dict(rule=ALL & ~512)),
+                ('A -boxorder', dict(rule=ALL & ~32)), ('A -lever', dict(rule=ALL & ~64)), ('A -spin', dict(rule=ALL & ~128)), ('A -persist', dict(rule=ALL & ~256)), ('A -hullmov', dict(rule=ALL & ~512)), ('A +gjk', dict(rule=ALL | 1024)),
                 ('A -persist -hullmov -boxorder -lever -spin', dict(rule=23)), ('A -persist -boxoverlap', dict(rule=ALL & ~256 & ~16)),
                 ('A m=0', dict(margin=0.0)), ('A m=5mm', dict(margin=0.005)), ('A m=20mm', dict(margin=0.02))]
     for name, bit in oracle.REF_FLAGS.items():

@@ -42,8 +42,8 @@ def main():
     import model_divergence as md
     base = 247
     variants = [('stateless contacts (RP_CFG_STATELESS_CONTACTS)', base), ('persistent manifolds (RPO_RULE_PERSIST)', base | 256), ('+ the reference step\'s own manifold upkeep', base | 2048), ('+ the same, the fast model\'s manifold rules', base | 2048 | 1024),
-                ('+ the same, manifold order', base | 2048 | 16384), ('shipped model: + hull vertices against movable boxes (RPO_RULE_HULLMOV)', base | 256 | 512),
-                ('shipped + native GJK distance phase (RPO_RULE_GJK)', base | 256 | 512 | 1024), ('shipped + GJK / EPA where the vertex lies beside the face (experiment)', base | 256 | 512 | 4096), ('shipped + GJK distance only there, OBB when the cores overlap (experiment)', base | 256 | 512 | 4096 | 8192)]
+                ('+ the same, manifold order', base | 2048 | 16384), ('+ hull vertices against movable boxes (RPO_RULE_HULLMOV)', base | 256 | 512),
+                ('shipped model: + GJK distance phase beside the face (RPO_RULE_GJK)', base | 256 | 512 | 1024), ('shipped + GJK / EPA where the vertex lies beside the face (experiment)', base | 256 | 512 | 4096), ('shipped + GJK distance only there, OBB when the cores overlap (experiment)', base | 256 | 512 | 4096 | 8192)]
     for kind in args.kinds.split(','):
         res = {v[0]: [] for v in variants}
         for e in range(args.envs):
