@@ -714,7 +714,7 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
            * -1 again = the cores touch or overlap: the OBB path keeps that case).  The two transforms move to the scratch and are read where they are needed */
           float* S = &L.npscr[NPG_SCRATCH * (src >> 3)];
           float* X = S + 63;
-          PCLK_ADD(27, 1) PCLK_ADD(28, -(long long)__builtin_readcyclecounter()) PCLK_ADD(29, nn)
+          PCLK_ADD(27, 1) PCLK_ADD(28, -(long long)__builtin_readcyclecounter())
           for (int t = 0; t < 9; t++) { X[t] = Rw.m[t]; X[12 + t] = xc.R.m[t]; }
           st3(X + 9, pw); st3(X + 21, xc.p);
           const V3 hbc = mk3(hc0.x - fminf(RP_HULL_MARGIN, hc0.x), hc0.y - fminf(RP_HULL_MARGIN, hc0.y), hc0.z - fminf(RP_HULL_MARGIN, hc0.z));
@@ -731,7 +731,7 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
 #pragma unroll 1
           for (int it = 0; it < 32; it++) {
             V3 w, sa, sb;
-            PCLK_ADD(26, 1)
+            PCLK_ADD(26, 1) PCLK_ADD(29, -(long long)__builtin_readcyclecounter())
             {                                                /* hull: the vertex of largest projection on -v (lowest index among equals) */
               const V3 dl = tmulv(ldm3(X), -v);
               float bd = -1e30f; int bi = 0x7fffffff;
@@ -744,6 +744,7 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
                 const float od = __shfl_xor(bd, off); const int oi = __shfl_xor(bi, off);
                 if (od > bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
               }
+              PCLK_ADD(29, __builtin_readcyclecounter()) PCLK_ADD(30, -(long long)__builtin_readcyclecounter())
               const float4 qv = tv[bi < nn ? bi : 0];
               sa = mulv(ldm3(X), mk3(qv.x, qv.y, qv.z)) + ld3(X + 9);
             }
@@ -756,12 +757,14 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
             const float vv = dot(v, v), vw = dot(v, w);
             bool dup = false;
             for (int i = 0; i < n; i++) { const V3 dw = ld3(S + 9 * i) - w; dup |= dot(dw, dw) < GJK_DUP; }
-            if (dup || (n > 0 && vv - vw <= GJK_REL * vv)) break;
+            if (dup || (n > 0 && vv - vw <= GJK_REL * vv)) { PCLK_ADD(30, __builtin_readcyclecounter()) break; }
             st3(S + 9 * n, w); st3(S + 9 * n + 3, sa); st3(S + 9 * n + 6, sb);
             n++;
             WSYNC();
+            PCLK_ADD(30, __builtin_readcyclecounter()) PCLK_ADD(31, -(long long)__builtin_readcyclecounter())
             if (n == 4) gjk_closest4(S, S + 36, n, lam); else gjk_closest3(S, n, lam);
             WSYNC();
+            PCLK_ADD(31, __builtin_readcyclecounter())
             if (n == 4) { fail = true; break; }
             V3 q = ld3(S) * lam[0];
             if (n > 1) q = q + ld3(S + 9) * lam[1];
@@ -2852,7 +2855,7 @@ __device__ __forceinline__ void prep2_body(const DevModel* __restrict__ m, const
 #pragma unroll
     for (int t = 0; t < 8; t++) cnt8[t] = sort_cnt[8 * lane + t];
   }
-  PCLK(6) PCLK(0) PCLK_ZERO(26) PCLK_ZERO(27) PCLK_ZERO(28) PCLK_ZERO(29)
+  PCLK(6) PCLK(0) PCLK_ZERO(26) PCLK_ZERO(27) PCLK_ZERO(28) PCLK_ZERO(29) PCLK_ZERO(30) PCLK_ZERO(31)
   static_assert(RP_REC_FLOATS == PREP_THREADS, "one float of the record per thread");
   L.st[tid] = state[(size_t)env * RP_REC_FLOATS + tid];
   __syncthreads();

@@ -49,6 +49,7 @@ late = w0 > np.percentile(w0, 50)
 print('first-round waves: total p50 %d; second-round waves: total p50 %d' % (np.median(tot[~late]), np.median(tot[late])))
 g = a[:, 27] > 0
 if g.any():
-    print('GJK: waves with a call %d of %d; calls per such wave p50 %d max %d; rounds per call p50 %.1f max %.1f; cycles per call p50 %d max %d; vertices p50 %d max %d' % (
-        g.sum(), n, np.median(a[g, 27]), a[g, 27].max(), np.median(a[g, 26] / a[g, 27]), (a[g, 26] / a[g, 27]).max(), np.median(a[g, 28] / a[g, 27]), (a[g, 28] / a[g, 27]).max(),
-        np.median(a[g, 29] / a[g, 27]), (a[g, 29] / a[g, 27]).max()))
+    r = a[g, 26].astype(float)
+    print('GJK per round: scan + reduce p50 %d, support + tests + simplex store p50 %d, closest point p50 %d cycles' % (np.median(a[g, 29] / r), np.median(a[g, 30] / r), np.median(a[g, 31] / r)))
+    print('GJK: waves with a call %d of %d; calls per such wave p50 %d max %d; rounds per call p50 %.1f max %.1f; cycles per call p50 %d max %d' % (
+        g.sum(), n, np.median(a[g, 27]), a[g, 27].max(), np.median(a[g, 26] / a[g, 27]), (a[g, 26] / a[g, 27]).max(), np.median(a[g, 28] / a[g, 27]), (a[g, 28] / a[g, 27]).max()))
