@@ -1,6 +1,7 @@
 """Known-answer and property tests of the CPU oracle's physics pieces (no GPU).  These do not pin parity with PyBullet
 (unpinned); they pin the oracle against analytic answers so that it is a trustworthy checker."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -142,6 +143,59 @@ def test_hull_vertex_contacts_against_the_reference_steps_gjk_epa():
                 np.testing.assert_allclose(pB, pb, atol=5e-5)      # (a face-parallel edge or face has no unique closest point: those poses fail the two tests above and are skipped)
                 seen['inside' if c[8] < 0 else 'apart'] += 1
     assert seen['apart'] >= 5 and seen['inside'] >= 5, seen
+
+
+def test_hull_gjk_contacts_against_the_reference_steps_gjk():
+    """RPO_RULE_GJK (the library's RP_CFG_HULL_GJK; off by default): where an arm link's deepest hull vertex lies beside the box face, the fast model's
+    contact comes from its own GJK distance phase (hull_box_gjk) - checked here against the frozen reference step's GJK on the SAME hull and box
+    (rpo_ref_collider_distance) in the poses random playroom rollouts pass through: every point the rule makes that the model without it does not
+    (same pair, another distance) has the reference's distance, normal and witness point.  Stateless contacts on both oracles, so that contacts() is
+    the narrowphase of the pose and nothing else."""
+    import ctypes as C
+    import re
+    import oracle
+    from oracle import OracleEnv
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    import model_divergence as md
+    DP = C.POINTER(C.c_double)
+    lib = oracle.load(bullet_ref=True)
+    lib.rpo_ref_collider_distance.argtypes = [C.c_void_p, C.c_int, C.c_int, DP, DP, DP, DP]
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'roboticsplayroompybullet_amd', 'csrc', 'generated', 'rp_hullverts_gen.h')).read()
+    cnt = [int(x) for x in re.search(r'rp_hull_cnt_U\[64\] = \{([^}]*)\}', src).group(1).split(',')]
+    seen, steps = 0, 200
+    for e in range(24):
+        a = OracleEnv('U', seed=77, env_index=e, rule=(1015 | 1024) & ~256)
+        a0 = OracleEnv('U', seed=77, env_index=e, rule=1015 & ~256)
+        b = OracleEnv('U', seed=77, env_index=e, bullet_ref=True)
+        a.reset()
+        b.reset()
+        cols = a.collider_list()
+        acts = md.random_actions('U', steps, np.random.default_rng(1000 + e))
+        for t in range(steps):
+            a.step(acts[t])
+            st = a.get_state()
+            a0.set_state(st)
+            c1, c0 = a.contacts(), a0.contacts()
+            for c in c1:
+                ia, ib = int(c[0]), int(c[1])
+                if cnt[ia] > 0 and cols[ib]['type'] == 0 and cnt[ib] == 0:
+                    hull, box, sgn = ia, ib, 1.0
+                elif cnt[ib] > 0 and cols[ia]['type'] == 0 and cnt[ia] == 0:
+                    hull, box, sgn = ib, ia, -1.0      # a movable box against a link's hull: the pair's normal points from the hull toward the box
+                else:
+                    continue
+                if any(int(d[0]) == ia and int(d[1]) == ib and abs(d[8] - c[8]) < 1e-12 for d in c0):
+                    continue                           # the face path's (or the OBB path's) point, not GJK's
+                b.set_state(st)
+                dist, pa, pb, n = np.zeros(1), np.zeros(3), np.zeros(3), np.zeros(3)
+                r = lib.rpo_ref_collider_distance(b.h, hull, box, dist.ctypes.data_as(DP), pa.ctypes.data_as(DP), pb.ctypes.data_as(DP), n.ctypes.data_as(DP))
+                assert r != 0
+                assert abs(dist[0] - c[8]) < 1e-7, (e, t, hull, box, dist[0], c[8])
+                np.testing.assert_allclose(n, sgn * c[5:8], atol=2e-5)
+                on_b = c[2:5] - 0.5 * c[8] * c[5:8]     # the model's point p lies halfway along the gap: p - d/2 n is on the pair's collider b
+                np.testing.assert_allclose(on_b, pb if sgn > 0 else pa, atol=1e-6)
+                seen += 1
+    assert seen >= 6, seen
 
 
 def oracle_has_hull(col):
