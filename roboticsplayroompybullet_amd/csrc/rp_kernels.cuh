@@ -1038,7 +1038,7 @@ __device__ __forceinline__ int manifold_replace_index(const float* c4, const flo
 
 /* broadphase + narrowphase + manifolds -> L.con*, returns ncon (wave-uniform) */
 template <class LDS>
-__device__ __forceinline__ int collide(const DevModel* m, LDS& L, int lane, int env) {
+__device__ __forceinline__ int collide(const DevModel* m, LDS& L, int lane, int env, const int* npm_early = nullptr) {
   /* 1. AABB sweep over the baked candidate pairs, 64 per pass; keep the first MAXACT overlapping, in order */
   int nact = 0;
   const int npair = m->n_pair;
@@ -1098,7 +1098,12 @@ __device__ __forceinline__ int collide(const DevModel* m, LDS& L, int lane, int 
     float* C = L.npscr + 8 * MANPTS;
     static_assert(8 * MANPTS + PMC_FLOATS <= NPSCR_FLOATS, "the staged contact cache lies behind L.man in the narrowphase scratch");
     float* g = m->pmcache + (size_t)env * PMC_FLOATS;
-    for (int i = lane * 4; i < PMC_FLOATS; i += 256) *(float4*)&C[i] = *(const float4*)&g[i];
+    /* only the manifolds in use - typically four of eleven - are loaded and stored: their count is the row's first word (k_prep2 has it fetched with the state
+     * record by its other wave: npm_early; the one-kernel path reads it here) */
+    const int npm_pre = min(max(uni(npm_early ? *npm_early : __float_as_int(g[0])), 0), PM_MAX);
+    const int used_in = PMC_HDR + PMC_MAN * npm_pre;         /* (a multiple of four floats) */
+    for (int i = lane * 4; i < used_in; i += 256) *(float4*)&C[i] = *(const float4*)&g[i];
+    if (lane == 0) C[0] = __int_as_float(npm_pre);
     WSYNC();
     PCLK(21)
     int npm = uni(__float_as_int(C[0]));
@@ -1132,6 +1137,7 @@ __device__ __forceinline__ int collide(const DevModel* m, LDS& L, int lane, int 
         M[0] = __int_as_float(objk); M[1] = __int_as_float(0);
         M[2] = fminf(m->col_margin[m->pair[pi][0]], m->col_margin[m->pair[pi][1]]);
         M[3] = __int_as_float(L.key[lane] >> 16);
+        for (int t = 4; t < PMC_MAN; t++) M[t] = 0.f;        /* (the slot was not loaded: what lies there is narrowphase scratch, and the cache is part of the state rows) */
       }
       npm = min(PM_MAX, npm + (int)__popcll(mnew));
       WSYNC();
@@ -1301,7 +1307,7 @@ __device__ __forceinline__ int collide(const DevModel* m, LDS& L, int lane, int 
     PCLK(24)
     if (lane == 0) C[0] = __int_as_float(npm);
     WSYNC();
-    for (int i = lane * 4; i < PMC_FLOATS; i += 256) *(float4*)&g[i] = *(const float4*)&C[i];
+    for (int i = lane * 4; i < PMC_HDR + PMC_MAN * npm; i += 256) *(float4*)&g[i] = *(const float4*)&C[i];      /* (what lies behind the last manifold in memory is never read) */
     PCLK(25)
   } else {
   int mycnt = 0, run_end = lane;
@@ -2858,6 +2864,8 @@ __device__ __forceinline__ void prep2_body(const DevModel* __restrict__ m, const
   PCLK(6) PCLK(0) PCLK_ZERO(26) PCLK_ZERO(27) PCLK_ZERO(28) PCLK_ZERO(29) PCLK_ZERO(30) PCLK_ZERO(31)
   static_assert(RP_REC_FLOATS == PREP_THREADS, "one float of the record per thread");
   L.st[tid] = state[(size_t)env * RP_REC_FLOATS + tid];
+  const int cenv = cache_env ? cache_env[env] : env;         /* (rp_reset settles in a dense scratch range: the contact cache stays the env's own) */
+  if (tid == 64 && m->persist) L.hdr[2] = __float_as_int(m->pmcache[(size_t)cenv * PMC_FLOATS]);      /* the cache's manifold count, for collide() */
   __syncthreads();
   PCLK(16)
   if (wid == 0) fk_bodies(m, L, lane);
@@ -2869,7 +2877,7 @@ __device__ __forceinline__ void prep2_body(const DevModel* __restrict__ m, const
     collider_aabbs(m, L, lane);
     WSYNC();
     PCLK(1)
-    int ncon = collide(m, L, lane, cache_env ? cache_env[env] : env);      /* (rp_reset settles in a dense scratch range: the contact cache stays the env's own) */
+    int ncon = collide(m, L, lane, cenv, &L.hdr[2]);
     ncon = uni(ncon);
 #ifdef RP_ABL_MAXCON    /* timing ablation: drop contacts beyond RP_ABL_MAXCON to expose the tail effect in k_solve2 */
     if (ncon > RP_ABL_MAXCON) ncon = RP_ABL_MAXCON;
