@@ -680,6 +680,7 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
         if (g4 > best + K_TIE_EPS) { best = g4; bf = 4; }
         if (g5 > best + K_TIE_EPS) { best = g5; bf = 5; }
         const float d = best - RP_HULL_MARGIN;
+        PCLK_ADD(15, 1 + (d > mg ? 65536 : 0))               /* (profiling build: hull pairs scanned | of them apart << 16) */
         int out = 0;                                         /* this pair's hf */
         CPt pt; pt.p = mk3(0, 0, 0); pt.n = mk3(0, 0, 0); pt.dist = 0.f;
         if (!(d > mg)) {                                     /* (wave-uniform) */
@@ -2861,7 +2862,7 @@ __device__ __forceinline__ void prep2_body(const DevModel* __restrict__ m, const
 #pragma unroll
     for (int t = 0; t < 8; t++) cnt8[t] = sort_cnt[8 * lane + t];
   }
-  PCLK(6) PCLK(0) PCLK_ZERO(26) PCLK_ZERO(27) PCLK_ZERO(28) PCLK_ZERO(29) PCLK_ZERO(30) PCLK_ZERO(31)
+  PCLK(6) PCLK(0) PCLK_ZERO(15) PCLK_ZERO(26) PCLK_ZERO(27) PCLK_ZERO(28) PCLK_ZERO(29) PCLK_ZERO(30) PCLK_ZERO(31)
   static_assert(RP_REC_FLOATS == PREP_THREADS, "one float of the record per thread");
   L.st[tid] = state[(size_t)env * RP_REC_FLOATS + tid];
   const int cenv = cache_env ? cache_env[env] : env;         /* (rp_reset settles in a dense scratch range: the contact cache stays the env's own) */

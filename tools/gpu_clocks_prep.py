@@ -49,6 +49,8 @@ npd = (a[:, 9] - a[:, 8]).astype(float)
 print('narrowphase cycles vs active pairs: corr %.2f' % np.corrcoef(na, npd)[0, 1])
 late = w0 > np.percentile(w0, 50)
 print('first-round waves: total p50 %d; second-round waves: total p50 %d' % (np.median(tot[~late]), np.median(tot[late])))
+hp, ha = a[:, 15] & 0xFFFF, a[:, 15] >> 16
+print('hull pairs scanned per env: mean %.2f p90 %d max %d; of them apart (two scans for nothing): mean %.2f' % (hp.mean(), np.percentile(hp, 90), hp.max(), ha.mean()))
 g = a[:, 27] > 0
 if g.any():
     r = a[g, 26].astype(float)
