@@ -47,12 +47,13 @@ class playEnv:
                  goal_range_low=(-0.18, -0.18, -0.05), goal_range_high=(0.18, 0.18, 0.05), obj_lower_bound=(-0.18, -0.18, -0.05),
                  obj_upper_bound=(-0.18, -0.18, -0.05), sparse=True, use_orientation=False, sparse_rew_thresh=0.05,
                  fixed_gripper=False, return_velocity=True, max_episode_steps=250, play=False, action_type='absolute_rpy',
-                 show_goal=True, arm_type='Panda', device=0, seed=None, contact_margin=None):
+                 show_goal=True, arm_type='Panda', device=0, seed=None, contact_margin=None, persistent_manifolds=True, hull_gjk=False):
         # seed=None: like the reference, which draws from the global np.random (environments.py:496, 530, 579), every new env gets
         # its own episode stream and np.random.seed(k) makes it repeatable
         if seed is None:
             seed = int(np.random.randint(0, 2 ** 31 - 1))
         self.sparse, self._contact_margin = bool(sparse), contact_margin
+        self._model_opts = dict(persistent_manifolds=bool(persistent_manifolds), hull_gjk=bool(hull_gjk))      # the library's contact-model switches (rp_config.flags)
         self.timeStep = 1.0 / 300
         self.render_scene = False
         self.physics_client_active = 0
@@ -113,7 +114,7 @@ class playEnv:
                                goal_range_low=self.goal_lower_bound, goal_range_high=self.goal_upper_bound,
                                obj_lower_bound=self.obj_lower_bound, obj_upper_bound=self.obj_upper_bound,
                                env_range_high=self.env_upper_bound, sparse_rew_thresh=self.sparse_rew_thresh, sparse=self.sparse,
-                               contact_margin=self._contact_margin)
+                               contact_margin=self._contact_margin, **self._model_opts)
         # kwargs that define the layout belong to the registered id: refuse silently different envs
         d = self._vec.dims
         per_obj = 3 + (4 if self.use_orientation else 0) + (3 if self.return_velocity else 0)
