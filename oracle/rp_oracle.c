@@ -584,7 +584,14 @@ static void gjk_closest(gjk_sv* s, int* n, real* lam) {      /* closest point of
   *n = bn;
 }
 /* returns 1 and the contact (normal from the box toward the hull, point = midpoint, like hull_face), 0 = farther apart than margin, -1 = the cores touch or
- * overlap (deeper than the two margins: the OBB path keeps that case) */
+ * overlap (deeper than the two margins: the OBB path keeps that case).
+ * Everything happens in the BOX's frame (the box core is axis-aligned at the origin; a hull vertex q has the coordinates l_k = u_k . q - c_k of hull_face, so
+ * neither rotation is needed before the result goes back to the world), and the simplex starts from what hull_face already knows: the vertex it stopped at
+ * (lv) against the corner(s) of the box-core feature nearest to it - one corner, or the two ends of the nearest edge.  If that vertex IS the hull's closest
+ * point (a link's corner against a box edge: the usual case) the first support query ends the iteration; the HIP library runs the same iteration, its support
+ * queries as whole-wave vertex scans (narrowphase_coop). */
+static long g_gjk_stats[8];      /* calls, rounds, seeds with two points, results 1 / 0 / -1, tetrahedra solved */
+void rpo_gjk_stats(long* out, int reset) { for (int i = 0; i < 8; i++) { out[i] = g_gjk_stats[i]; if (reset) g_gjk_stats[i] = 0; } }
 static int hull_box_gjk(const rpo_env* e, int hc, int bc, real margin, const real* lv, cpoint* out) {
   const rp_model* m = &e->m;
   const float (*hv)[4]; const int *hoff, *hcnt;
@@ -594,59 +601,82 @@ static int hull_box_gjk(const rpo_env* e, int hc, int bc, real margin, const rea
   hv += hoff[hc];
   const xform* xa = &e->xb[m->col_body[hc]];
   const xform* xb = &e->xc[bc];
-  real hb[3];
-  for (int k = 0; k < 3; k++) { const real h = (real)m->col_he[bc][k]; hb[k] = h - (HULL_MARGIN < h ? HULL_MARGIN : h); }
+  real hb[3], u[3][3], c[3];
+  for (int k = 0; k < 3; k++) {
+    const real h = (real)m->col_he[bc][k]; hb[k] = h - (HULL_MARGIN < h ? HULL_MARGIN : h);
+    real bk[3] = {xb->R[k], xb->R[3 + k], xb->R[6 + k]}, t[3];
+    m3tmulv(u[k], xa->R, bk);
+    v3sub(t, xb->p, xa->p);
+    c[k] = v3dot(bk, t);
+  }
+  g_gjk_stats[0]++;
   gjk_sv s[4]; int n = 0; real lam[4] = {0, 0, 0, 0};
-  /* first direction: from the box core's nearest point to the vertex hull_face stopped at (lv: that vertex in box coordinates) - two or three rounds from
-   * there instead of the half dozen from the line of centres */
-  real v[3];
-  { real dl[3]; for (int k = 0; k < 3; k++) dl[k] = lv[k] - (lv[k] > hb[k] ? hb[k] : (lv[k] < -hb[k] ? -hb[k] : lv[k])); m3mulv(v, xb->R, dl); }
-  if (v3dot(v, v) < GJK_ZERO) v3sub(v, xa->p, xb->p);
-  if (v3dot(v, v) < GJK_ZERO) v3set(v, 1, 0, 0);
-  real dd = (real)1e30;
+  memset(s, 0, sizeof(s));
+  /* the seed: lv against the nearest feature of the box core */
+  int nout = 0, fk = -1;
+  for (int k = 0; k < 3; k++) { if (R_FABS(lv[k]) > hb[k]) nout++; else fk = k; }
+  if (nout == 0) { g_gjk_stats[5]++; return -1; }            /* the vertex lies inside the box core */
+  for (int i = 0; i < (nout == 2 ? 2 : 1); i++) {
+    for (int k = 0; k < 3; k++) {
+      s[i].b[k] = lv[k] >= 0 ? hb[k] : -hb[k];
+      if (nout == 2 && k == fk) s[i].b[k] = i == 0 ? -hb[k] : hb[k];
+      s[i].a[k] = lv[k];
+      s[i].w[k] = s[i].a[k] - s[i].b[k];
+    }
+    n++;
+  }
+  if (n == 2) g_gjk_stats[2]++;
+  real v[3] = {0, 0, 0};
+  gjk_closest(s, &n, lam);
+  for (int i = 0; i < n; i++) v3axpy(v, lam[i], s[i].w);
+  real dd = v3dot(v, v);
+  if (dd < GJK_ZERO) { g_gjk_stats[5]++; return -1; }
   for (int it = 0; it < 32; it++) {
     gjk_sv sv;
-    {                                                        /* hull: the vertex of largest projection on -v (first of equals) */
-      real dl[3], nv[3] = {-v[0], -v[1], -v[2]};
-      m3tmulv(dl, xa->R, nv);
+    g_gjk_stats[1]++;
+    {                                                        /* hull: the vertex of largest projection on -v (first of equals), v and the result in box coordinates */
+      real dl[3];
+      for (int j = 0; j < 3; j++) dl[j] = -(v[0] * u[0][j] + v[1] * u[1][j] + v[2] * u[2][j]);
       int bi = 0; real bd = (real)-1e30;
       for (int i = 0; i < nvert; i++) {
         const real d = (real)hv[i][0] * dl[0] + (real)hv[i][1] * dl[1] + (real)hv[i][2] * dl[2];
         if (d > bd) { bd = d; bi = i; }
       }
-      const real l[3] = {(real)hv[bi][0], (real)hv[bi][1], (real)hv[bi][2]};
-      m3mulv(sv.a, xa->R, l); v3add(sv.a, sv.a, xa->p);
+      const real q[3] = {(real)hv[bi][0], (real)hv[bi][1], (real)hv[bi][2]};
+      for (int k = 0; k < 3; k++) sv.a[k] = (u[k][0] * q[0] + u[k][1] * q[1] + u[k][2] * q[2]) - c[k];
     }
-    {                                                        /* box core: the corner of largest projection on v */
-      real dl[3], l[3];
-      m3tmulv(dl, xb->R, v);
-      for (int k = 0; k < 3; k++) l[k] = dl[k] >= 0 ? hb[k] : -hb[k];
-      m3mulv(sv.b, xb->R, l); v3add(sv.b, sv.b, xb->p);
-    }
+    for (int k = 0; k < 3; k++) sv.b[k] = v[k] >= 0 ? hb[k] : -hb[k];      /* box core: the corner of largest projection on v */
     v3sub(sv.w, sv.a, sv.b);
     const real vv = v3dot(v, v), vw = v3dot(v, sv.w);
     int dup = 0;
     for (int i = 0; i < n; i++) { real d[3]; v3sub(d, s[i].w, sv.w); if (v3dot(d, d) < GJK_DUP) dup = 1; }
-    if (dup || (n > 0 && vv - vw <= GJK_REL * vv)) break;
+    /* v . w / |v| is a lower bound of the distance between the cores: beyond the pair's margin (and the two shape margins) the answer is "apart" whatever the
+     * iteration would still find */
+    { const real far = margin + 2 * HULL_MARGIN; if (vw > 0 && vw * vw > far * far * vv) { g_gjk_stats[4]++; g_gjk_stats[7] += it + 1; return 0; } }
+    if (dup || vv - vw <= GJK_REL * vv) break;
     s[n++] = sv;
+    if (n == 4) g_gjk_stats[6]++;
     gjk_closest(s, &n, lam);
-    if (n == 4) return -1;
+    if (n == 4) { g_gjk_stats[5]++; return -1; }
     real q[3] = {0, 0, 0};
     for (int i = 0; i < n; i++) v3axpy(q, lam[i], s[i].w);
     const real nd = v3dot(q, q);
     v3cpy(v, q);
-    if (nd < GJK_ZERO) return -1;
-    if (nd >= dd * GJK_STALL && it > 0) { dd = nd; break; }
+    if (nd < GJK_ZERO) { g_gjk_stats[5]++; return -1; }
+    if (nd >= dd * GJK_STALL) { dd = nd; break; }
     dd = nd;
   }
-  real pb[3] = {0, 0, 0};
-  for (int i = 0; i < n; i++) v3axpy(pb, lam[i], s[i].b);
+  real pl[3] = {0, 0, 0};
+  for (int i = 0; i < n; i++) v3axpy(pl, lam[i], s[i].b);
   const real dist = R_SQRT(v3dot(v, v));
-  if (!(dist > GJK_ZERO)) return -1;
-  real nB[3]; v3scale(nB, v, 1 / dist);
+  if (!(dist > GJK_ZERO)) { g_gjk_stats[5]++; return -1; }
+  real nl[3]; v3scale(nl, v, 1 / dist);
   const real d = dist - 2 * HULL_MARGIN;                     /* both margins */
-  if (d > margin) return 0;
-  real pB[3]; v3cpy(pB, pb); v3axpy(pB, HULL_MARGIN, nB);    /* on the box's surface */
+  if (d > margin) { g_gjk_stats[4]++; return 0; }
+  g_gjk_stats[3]++;
+  v3axpy(pl, HULL_MARGIN, nl);                               /* on the box's surface */
+  real nB[3], pB[3];
+  m3mulv(nB, xb->R, nl); m3mulv(pB, xb->R, pl); v3add(pB, pB, xb->p);
   v3cpy(out->n, nB); out->dist = d;
   v3cpy(out->p, pB); v3axpy(out->p, (real)0.5 * d, nB);
   return 1;
@@ -2295,7 +2325,7 @@ rpo_env* rpo_create(int kind, unsigned long long seed, int env_index) {
   e->nv = m->n_arm + 6 * m->n_free + m->n_joint1;
   e->nbody = 1 + m->n_arm + m->n_free + m->n_joint1;
   e->seed = seed; e->env_index = (uint32_t)env_index;
-  e->rule = RPO_RULE_ORDER | RPO_RULE_LIMIT | RPO_RULE_HULLFACE | RPO_RULE_BOXOVERLAP | RPO_RULE_ODEORDER | RPO_RULE_LEVER | RPO_RULE_SPIN | RPO_RULE_PERSIST | RPO_RULE_HULLMOV;       /* the shipped model (the HIP kernels implement exactly this; RPO_RULE_GJK on top = the library's RP_CFG_HULL_GJK); rpo_set_rule(0) = round 2's rule */
+  e->rule = RPO_RULE_ORDER | RPO_RULE_LIMIT | RPO_RULE_HULLFACE | RPO_RULE_BOXOVERLAP | RPO_RULE_ODEORDER | RPO_RULE_LEVER | RPO_RULE_SPIN | RPO_RULE_PERSIST | RPO_RULE_HULLMOV | RPO_RULE_GJK;       /* = 2039: the shipped model (the HIP kernels implement exactly this; without RPO_RULE_GJK = the library's RP_CFG_OBB_EDGES, round 3's default); rpo_set_rule(0) = round 2's rule */
   e->margin = -1; e->rew_thresh = (real)0.05; e->dense_reward = 0;
   /* envList.py:8-10, 18-22, 73-99: the env's flags and ranges go with its scene (play ids: complex_scene; reach ids:
    * default_scene; pick / push: push_scene); other ids on the same model override the ranges (rpo_set_ranges) */

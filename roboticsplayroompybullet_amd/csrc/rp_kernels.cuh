@@ -510,67 +510,103 @@ __device__ __forceinline__ void hull_scan(const float4* __restrict__ tv, int nn,
     for (int u = 0; u < HULL_UNROLL; u++) { const int i = base + 64 * u; if (i < nn) f(q[u], i); }
   }
 }
-__device__ __forceinline__ void gjk_cp(float* dst, const float* src) { for (int t = 0; t < 9; t++) dst[t] = src[t]; }
-/* closest point of the simplex S[0 .. n) (n <= 3) to the origin; the simplex shrinks to the supporting sub-simplex (Ericson's sub-cases) */
-__device__ __forceinline__ void gjk_closest3(float* S, int& n, float* lam) {
-  if (n == 1) { lam[0] = 1.f; return; }
-  if (n == 2) {
-    const V3 a = ld3(S), b = ld3(S + 9), ab = b - a;
-    const float t = -dot(a, ab), den = dot(ab, ab);
-    if (t <= 0.f || den <= 0.f) { n = 1; lam[0] = 1.f; return; }
-    if (t >= den) { gjk_cp(S, S + 9); n = 1; lam[0] = 1.f; return; }
-    lam[1] = t / den; lam[0] = 1.f - lam[1];
-    return;
+/* wave-wide reductions through DPP (no LDS round trip: six butterflies through ds_bpermute cost ~900 cycles of latency per scan): every lane ends with the result */
+__device__ __forceinline__ float wave_max_f(float v) {
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true)));
+  return fmaxf(fmaxf(lane_read(v, 0), lane_read(v, 16)), fmaxf(lane_read(v, 32), lane_read(v, 48)));
+}
+__device__ __forceinline__ float wave_min_f(float v) { return -wave_max_f(-v); }
+__device__ __forceinline__ int wave_min_i(int v) {
+  v = min(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true));
+  v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true));
+  v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true));
+  v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true));
+  return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+/* closest point of the triangle a b c to the origin (Ericson's sub-cases in the oracle's order, gjk_closest), without branches: which vertices support it
+ * (bit k = vertex k stays) and their weights */
+struct GjkTri { int keep; float l0, l1, l2; };
+__device__ __forceinline__ GjkTri gjk_tri(V3 a, V3 b, V3 c) {
+  const V3 ab = b - a, ac = c - a;
+  const float d1 = -dot(ab, a), d2 = -dot(ac, a), d3 = -dot(ab, b), d4 = -dot(ac, b), d5 = -dot(ab, c), d6 = -dot(ac, c);
+  const float vc = d1 * d4 - d3 * d2, vb = d5 * d2 - d1 * d6, va = d3 * d6 - d5 * d4;
+  /* (v_rcp_f32, 1 ulp: four IEEE divisions are fifty instructions of this serial code, and the weights feed a distance that is compared at 1e-6 relative) */
+  const float tab = d1 * __builtin_amdgcn_rcpf(d1 - d3), tac = d2 * __builtin_amdgcn_rcpf(d2 - d6), tbc = (d4 - d3) * __builtin_amdgcn_rcpf((d4 - d3) + (d5 - d6)), den = __builtin_amdgcn_rcpf(va + vb + vc);
+  GjkTri r;
+  r.keep = 7; r.l1 = vb * den; r.l2 = vc * den; r.l0 = 1.f - r.l1 - r.l2;
+  if (va <= 0.f && (d4 - d3) >= 0.f && (d5 - d6) >= 0.f) { r.keep = 6; r.l0 = 0.f; r.l1 = 1.f - tbc; r.l2 = tbc; }
+  if (vb <= 0.f && d2 >= 0.f && d6 <= 0.f) { r.keep = 5; r.l0 = 1.f - tac; r.l1 = 0.f; r.l2 = tac; }
+  if (d6 >= 0.f && d5 <= d6) { r.keep = 4; r.l0 = 0.f; r.l1 = 0.f; r.l2 = 1.f; }
+  if (vc <= 0.f && d1 >= 0.f && d3 <= 0.f) { r.keep = 3; r.l0 = 1.f - tab; r.l1 = tab; r.l2 = 0.f; }
+  if (d3 >= 0.f && d4 <= d3) { r.keep = 2; r.l0 = 0.f; r.l1 = 1.f; r.l2 = 0.f; }
+  if (d1 <= 0.f && d2 <= 0.f) { r.keep = 1; r.l0 = 1.f; r.l1 = 0.f; r.l2 = 0.f; }      /* (the first test of the sequence wins: applied last) */
+  return r;
+}
+__device__ __forceinline__ GjkTri gjk_seg(V3 a, V3 b) {
+  const V3 ab = b - a;
+  const float t = -dot(a, ab), den = dot(ab, ab);
+  GjkTri r; r.l2 = 0.f;
+  r.keep = 3; r.l1 = t * __builtin_amdgcn_rcpf(den); r.l0 = 1.f - r.l1;
+  if (t >= den) { r.keep = 2; r.l0 = 0.f; r.l1 = 1.f; }
+  if (t <= 0.f || den <= 0.f) { r.keep = 1; r.l0 = 1.f; r.l1 = 0.f; }
+  return r;
+}
+__device__ __forceinline__ V3 sel3(bool c, V3 a, V3 b) { return mk3(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }
+/* The simplex of the GJK below: Minkowski-difference points w = (hull vertex) - (box-core corner) with the corner kept as the witness, all in the BOX's frame,
+ * in registers (wave-uniform values).  reduce(): keeps the vertices of `keep` (a subsequence of p0 p1 p2, in that order) with their weights */
+struct GjkSimplex {
+  V3 w0, w1, w2, w3; int b0, b1, b2, b3;       /* b: the box-core corner of the point, one sign bit per axis (bit k set = +hbc_k) */
+  int n; float l0, l1, l2;
+  /* (scalars by value: handed a GjkTri by reference, the compiler keeps it in private memory and turns the selects below into indexed loads) */
+  __device__ __forceinline__ void reduce(V3 p0, V3 p1, V3 p2, int q0, int q1, int q2, int keep, float r0, float r1, float r2) {
+    const bool k0 = keep & 1, k1 = keep & 2;
+    const float t12 = k1 ? r1 : r2;
+    w0 = sel3(k0, p0, sel3(k1, p1, p2)); b0 = k0 ? q0 : (k1 ? q1 : q2); l0 = k0 ? r0 : t12;
+    w1 = sel3(k0 && k1, p1, p2); b1 = (k0 && k1) ? q1 : q2; l1 = (k0 && k1) ? r1 : r2;
+    w2 = p2; b2 = q2; l2 = r2;
+    n = __popc(keep);
   }
-  const V3 a = ld3(S), b = ld3(S + 9), c = ld3(S + 18), ab = b - a, ac = c - a;
-  const float d1 = -dot(ab, a), d2 = -dot(ac, a);
-  if (d1 <= 0.f && d2 <= 0.f) { n = 1; lam[0] = 1.f; return; }
-  const float d3 = -dot(ab, b), d4 = -dot(ac, b);
-  if (d3 >= 0.f && d4 <= d3) { gjk_cp(S, S + 9); n = 1; lam[0] = 1.f; return; }
-  const float vc = d1 * d4 - d3 * d2;
-  if (vc <= 0.f && d1 >= 0.f && d3 <= 0.f) { const float v = d1 / (d1 - d3); n = 2; lam[0] = 1.f - v; lam[1] = v; return; }
-  const float d5 = -dot(ab, c), d6 = -dot(ac, c);
-  if (d6 >= 0.f && d5 <= d6) { gjk_cp(S, S + 18); n = 1; lam[0] = 1.f; return; }
-  const float vb = d5 * d2 - d1 * d6;
-  if (vb <= 0.f && d2 >= 0.f && d6 <= 0.f) { const float w = d2 / (d2 - d6); gjk_cp(S + 9, S + 18); n = 2; lam[0] = 1.f - w; lam[1] = w; return; }
-  const float va = d3 * d6 - d5 * d4;
-  if (va <= 0.f && (d4 - d3) >= 0.f && (d5 - d6) >= 0.f) { const float w = (d4 - d3) / ((d4 - d3) + (d5 - d6)); gjk_cp(S, S + 9); gjk_cp(S + 9, S + 18); n = 2; lam[0] = 1.f - w; lam[1] = w; return; }
-  const float den = 1.f / (va + vb + vc);
-  lam[1] = vb * den; lam[2] = vc * den; lam[0] = 1.f - lam[1] - lam[2];
+  __device__ __forceinline__ V3 closest() const { V3 q = w0 * l0; if (n > 1) q = q + w1 * l1; if (n > 2) q = q + w2 * l2; return q; }
+  static __device__ __forceinline__ V3 corner(int code, V3 h) { return mk3((code & 1) ? h.x : -h.x, (code & 2) ? h.y : -h.y, (code & 4) ? h.z : -h.z); }
+  __device__ __forceinline__ V3 witness(V3 h) const { V3 q = corner(b0, h) * l0; if (n > 1) q = q + corner(b1, h) * l1; if (n > 2) q = q + corner(b2, h) * l2; return q; }
+};
+__device__ __forceinline__ int gjk_fi(int f, int k, int p0, int p1, int p2, int p3) {
+  const int idx = k == 0 ? (f == 3 ? 1 : 0) : (k == 1 ? (f == 0 ? 1 : (f == 1 ? 2 : 3)) : (f == 0 ? 2 : (f == 1 ? 3 : (f == 2 ? 1 : 2))));
+  return idx == 0 ? p0 : (idx == 1 ? p1 : (idx == 2 ? p2 : p3));
 }
-/* ... of a tetrahedron S[0 .. 4): the closest of the faces the origin lies outside of (T: 27 floats of scratch; the winning face is solved a second time
- * instead of being kept: registers are what this kernel is short of); n stays 4 when the origin is inside */
-__device__ __forceinline__ void gjk_face(const float* S, float* T, int f) {
-  const int i0 = f == 3 ? 1 : 0, i1 = f == 0 ? 1 : (f == 1 ? 2 : 3), i2 = f == 0 ? 2 : (f == 1 ? 3 : (f == 2 ? 1 : 2));
-  gjk_cp(T, S + 9 * i0); gjk_cp(T + 9, S + 9 * i1); gjk_cp(T + 18, S + 9 * i2);
+/* face f of the tetrahedron (the oracle's F / OPP tables): vertex k of the face, k = 3: the vertex opposite */
+__device__ __forceinline__ V3 gjk_fv(int f, int k, V3 p0, V3 p1, V3 p2, V3 p3) {
+  /* F = {0,1,2},{0,2,3},{0,3,1},{1,3,2}; OPP = {3,1,2,0} */
+  const int idx = k == 0 ? (f == 3 ? 1 : 0) : (k == 1 ? (f == 0 ? 1 : (f == 1 ? 2 : 3)) : (k == 2 ? (f == 0 ? 2 : (f == 1 ? 3 : (f == 2 ? 1 : 2))) : (f == 0 ? 3 : (f == 1 ? 1 : (f == 2 ? 2 : 0)))));
+  return idx == 0 ? p0 : (idx == 1 ? p1 : (idx == 2 ? p2 : p3));
 }
-__device__ __forceinline__ void gjk_closest4(float* S, float* T, int& n, float* lam) {
+/* closest point of the simplex to the origin; the simplex shrinks to the supporting sub-simplex.  n = 4 afterwards: the origin lies inside the tetrahedron */
+__device__ __forceinline__ void gjk_closest(GjkSimplex& S, int lane) {
+  if (S.n == 1) { S.l0 = 1.f; return; }
+  if (S.n == 2) { const GjkTri r = gjk_seg(S.w0, S.w1); S.reduce(S.w0, S.w1, S.w1, S.b0, S.b1, S.b1, r.keep, r.l0, r.l1, r.l2); return; }
+  if (S.n == 3) { const GjkTri r = gjk_tri(S.w0, S.w1, S.w2); S.reduce(S.w0, S.w1, S.w2, S.b0, S.b1, S.b2, r.keep, r.l0, r.l1, r.l2); return; }
+  /* tetrahedron: the closest of the faces the origin lies outside of (one after the other: side by side in four lanes they cost the registers of four triangles
+   * at once, and this kernel has none to spare), then the winner once more */
   float best = 1e30f; int bf = -1;
 #pragma unroll 1
   for (int f = 0; f < 4; f++) {
-    const int i0 = f == 3 ? 1 : 0, i1 = f == 0 ? 1 : (f == 1 ? 2 : 3), i2 = f == 0 ? 2 : (f == 1 ? 3 : (f == 2 ? 1 : 2)), io = f == 0 ? 3 : (f == 1 ? 1 : (f == 2 ? 2 : 0));
+    const V3 a = gjk_fv(f, 0, S.w0, S.w1, S.w2, S.w3), b = gjk_fv(f, 1, S.w0, S.w1, S.w2, S.w3), c = gjk_fv(f, 2, S.w0, S.w1, S.w2, S.w3);
     float so, sd;
-    {
-      const V3 a = ld3(S + 9 * i0), nrm = cross(ld3(S + 9 * i1) - a, ld3(S + 9 * i2) - a);
-      so = -dot(a, nrm); sd = dot(ld3(S + 9 * io) - a, nrm);
-    }
-    if (so * sd > 0.f) continue;
-    if (sd == 0.f && so == 0.f) continue;
-    gjk_face(S, T, f);
-    int tn = 3; float tl[3] = {0.f, 0.f, 0.f};
-    gjk_closest3(T, tn, tl);
-    V3 q = ld3(T) * tl[0];
-    if (tn > 1) q = q + ld3(T + 9) * tl[1];
-    if (tn > 2) q = q + ld3(T + 18) * tl[2];
+    { const V3 d = gjk_fv(f, 3, S.w0, S.w1, S.w2, S.w3), nrm = cross(b - a, c - a); so = -dot(a, nrm); sd = dot(d - a, nrm); }
+    if (so * sd > 0.f || (sd == 0.f && so == 0.f)) continue;
+    const GjkTri r = gjk_tri(a, b, c);
+    const V3 q = a * r.l0 + b * r.l1 + c * r.l2;
     const float dd = dot(q, q);
     if (dd < best) { best = dd; bf = f; }
   }
-  if (bf < 0) { n = 4; return; }
-  gjk_face(S, T, bf);
-  int tn = 3;
-  gjk_closest3(T, tn, lam);
-  for (int t = 0; t < 9 * tn; t++) S[t] = T[t];
-  n = tn;
+  if (bf < 0) return;
+  const V3 a = gjk_fv(bf, 0, S.w0, S.w1, S.w2, S.w3), b = gjk_fv(bf, 1, S.w0, S.w1, S.w2, S.w3), c = gjk_fv(bf, 2, S.w0, S.w1, S.w2, S.w3);
+  const int qa = gjk_fi(bf, 0, S.b0, S.b1, S.b2, S.b3), qb = gjk_fi(bf, 1, S.b0, S.b1, S.b2, S.b3), qc = gjk_fi(bf, 2, S.b0, S.b1, S.b2, S.b3);
+  const GjkTri r = gjk_tri(a, b, c);
+  S.reduce(a, b, c, qa, qb, qc, r.keep, r.l0, r.l1, r.l2);
 }
 
 template <class LDS>
@@ -606,8 +642,6 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
       L.key[ai] = m->col_obj[a] * 256 + m->col_obj[b] + (single ? 65536 : 0) + ((r0 ? (r1 ? 2 : 1) : 0) << 20) + ((arm && movable) ? (1 << 22) : 0);
       L.pmu[ai] = m->col_friction[a] * m->col_friction[b];
     }
-    int np = 0;
-    CPt mine; mine.p = mk3(0, 0, 0); mine.n = mk3(0, 0, 0); mine.dist = 0.f;      /* the point this lane contributes (lane s < np of its group) */
     /* ---- arm link against a static box: the VERTICES of the convex hull of the link's collision mesh (Bullet: btConvexHullShape, margin 0.001) against the
      * box's six faces - the same decisions and arithmetic as the oracle's hull_face.  The vertex deepest along the face of least penetration is the contact
      * if it lies over that face (what GJK / EPA return for a vertex-on-face contact: a link on the ground plate, on the table top); beside the face the
@@ -624,7 +658,8 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
       bool hq = hn > 0 && (hswap || (tb == 0 && body_b0 == 0));
       if (hq) {
         const Xf xa = collider_xf(m, L, hc), xb = collider_xf(m, L, bc);
-        const V3 ha = ld3(m->col_he[hc]), hb = ld3(m->col_he[bc]);
+        const V3 ha = ld3(m->col_he[hc]), hb0 = ld3(m->col_he[bc]);
+        const V3 hb = mk3(fmaxf(hb0.x, RP_HULL_MARGIN), fmaxf(hb0.y, RP_HULL_MARGIN), fmaxf(hb0.z, RP_HULL_MARGIN));      /* (the box as the scan sees it: a plate thinner than the margin counts 0.001 thick) */
         /* the link's OBB (it contains the hull) against the same six faces first: if even the OBB stays clear of the box by more than the pair's margin
          * along one of the box's axes, so does every vertex and the scan would end with "apart" - the common case, a long link whose AABB merely overlaps
          * the table's (same outcome as the oracle's full scan; the 1e-5 keeps rounding at the threshold on the scanning side) */
@@ -650,29 +685,70 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
         const int ca = __builtin_amdgcn_readlane(hc, src), cb = __builtin_amdgcn_readlane(bc, src);
         const bool flip = __builtin_amdgcn_readlane((int)hswap, src) != 0;      /* the pair's normal points from b toward a: from the hull toward the box when the hull is b */
         const float mg = lane_read(margin0, src);
-        const int body = m->col_body[ca];
-        const M3 Rw = ldm3(&L.xR[9 * body]);
-        const V3 pw = ld3(&L.xp[3 * body]);
-        const Xf xc = collider_xf(m, L, cb);
         const V3 hc0 = ld3(m->col_he[cb]);
-        const V3 hc = mk3(fmaxf(hc0.x, RP_HULL_MARGIN), fmaxf(hc0.y, RP_HULL_MARGIN), fmaxf(hc0.z, RP_HULL_MARGIN));      /* the box as the reference step's GJK sees it: core + margin, a box thinner than the margin comes out 0.001 thick (oracle hull_face) */
-        const V3 tc = xc.p - pw;
-        const V3 b0 = col(xc.R, 0), b1 = col(xc.R, 1), b2 = col(xc.R, 2);
-        const V3 u0 = tmulv(Rw, b0), u1 = tmulv(Rw, b1), u2 = tmulv(Rw, b2);      /* box axes in the body frame: a vertex v has box coordinate u_k . v - c_k */
-        const float c0 = dot(b0, tc), c1 = dot(b1, tc), c2 = dot(b2, tc);
+        const V3 hcm = mk3(fmaxf(hc0.x, RP_HULL_MARGIN), fmaxf(hc0.y, RP_HULL_MARGIN), fmaxf(hc0.z, RP_HULL_MARGIN));      /* the box as the reference step's GJK sees it: core + margin, a box thinner than the margin comes out 0.001 thick (oracle hull_face) */
+        /* the box in the hull's body frame: a vertex v has the box coordinate u_k . v - c_k.  And one more direction, up / cp: of the fifteen directions of the box-box
+         * SAT on the link's OBB (one per lane) the one along which the OBB stays clearest of the box.  If even the OBB is clear by more than the margin there, the pair
+         * is apart (the diagonal arrangements - a link passing a table edge - that the six face directions let through); else the scan measures the HULL's own
+         * clearance along it on the way: three quarters of the pairs that the box's three axes cannot separate and GJK would find apart end there, in the one pass
+         * over the vertices that the face scan makes anyway */
+        V3 u0, u1, u2, up; float c0, c1, c2, cp; bool obb_apart;
+        {
+          const int body = m->col_body[ca];
+          const M3 Rw = ldm3(&L.xR[9 * body]);
+          const V3 pw = ld3(&L.xp[3 * body]);
+          const Xf xc = collider_xf(m, L, cb);
+          const V3 tc = xc.p - pw;
+          const V3 b0 = col(xc.R, 0), b1 = col(xc.R, 1), b2 = col(xc.R, 2);
+          u0 = tmulv(Rw, b0); u1 = tmulv(Rw, b1); u2 = tmulv(Rw, b2);
+          c0 = dot(b0, tc); c1 = dot(b1, tc); c2 = dot(b2, tc);
+          const Xf xh = collider_xf(m, L, ca);
+          const V3 hh = ld3(m->col_he[ca]);
+          const V3 a0 = col(xh.R, 0), a1 = col(xh.R, 1), a2 = col(xh.R, 2);
+          const int t = lane & 15;
+          V3 ax; bool okax = t < 15;
+          if (t < 3) ax = pick3(t, a0, a1, a2);
+          else if (t < 6) ax = pick3(t - 3, b0, b1, b2);
+          else {
+            const int e = t - 6, i = e / 3, j = e - 3 * i;
+            const V3 cr = cross(pick3(i, a0, a1, a2), pick3(j, b0, b1, b2));
+            const float l = norm(cr);
+            okax = okax && l > 1e-2f;
+            ax = cr * (1.f / fmaxf(l, 1e-2f));
+          }
+          const float ra = hh.x * fabsf(dot(ax, a0)) + hh.y * fabsf(dot(ax, a1)) + hh.z * fabsf(dot(ax, a2));
+          const float rb = hcm.x * fabsf(dot(ax, b0)) + hcm.y * fabsf(dot(ax, b1)) + hcm.z * fabsf(dot(ax, b2));
+          const float tl = dot(xh.p - xc.p, ax);
+          float gap = okax ? fabsf(tl) - ra - rb : -1e30f;
+          float gm = gap;
+          gm = fmaxf(gm, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(gm), 0xB1, 0xF, 0xF, true)));
+          gm = fmaxf(gm, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(gm), 0x4E, 0xF, 0xF, true)));
+          gm = fmaxf(gm, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(gm), 0x141, 0xF, 0xF, true)));
+          gm = fmaxf(gm, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(gm), 0x140, 0xF, 0xF, true)));
+          gm = lane_read(gm, 0);
+          const int wl = __ffsll((long long)(__ballot(gap == gm) & 0xFFFFull)) - 1;      /* (first of equals; at least one lane of the first row holds the maximum) */
+          const float sg = lane_read(tl, wl) < 0.f ? -1.f : 1.f;                         /* from the box toward the hull */
+          const V3 Ls = mk3(lane_read(ax.x, wl) * sg, lane_read(ax.y, wl) * sg, lane_read(ax.z, wl) * sg);
+          obb_apart = gm > mg + RP_HULL_MARGIN + 1e-5f;
+          up = tmulv(Rw, Ls);
+          const V3 hbc0 = mk3(hc0.x - fminf(RP_HULL_MARGIN, hc0.x), hc0.y - fminf(RP_HULL_MARGIN, hc0.y), hc0.z - fminf(RP_HULL_MARGIN, hc0.z));
+          cp = dot(Ls, tc) + hbc0.x * fabsf(dot(Ls, b0)) + hbc0.y * fabsf(dot(Ls, b1)) + hbc0.z * fabsf(dot(Ls, b2));      /* the box core's far end along it, seen from the body's origin */
+        }
+        if (obb_apart) {                                     /* (wave-uniform) */
+          if ((lane >> 3) == (src >> 3)) hf = 0;
+          continue;
+        }
         const int nn = m->hull_cnt[ca];
         const float4* tv = (const float4*)m->hullv + m->hull_off[ca];
-        float lo0 = 1e30f, lo1 = 1e30f, lo2 = 1e30f, hi0 = -1e30f, hi1 = -1e30f, hi2 = -1e30f;
-        hull_scan<1>(tv, nn, lane, [&](const float4& v, int) {
+        float lo0 = 1e30f, lo1 = 1e30f, lo2 = 1e30f, hi0 = -1e30f, hi1 = -1e30f, hi2 = -1e30f, pmin = 1e30f;
+        hull_scan<2>(tv, nn, lane, [&](const float4& v, int) {
           const float l0 = hull_coord(u0, v, c0), l1 = hull_coord(u1, v, c1), l2 = hull_coord(u2, v, c2);
           lo0 = fminf(lo0, l0); hi0 = fmaxf(hi0, l0); lo1 = fminf(lo1, l1); hi1 = fmaxf(hi1, l1); lo2 = fminf(lo2, l2); hi2 = fmaxf(hi2, l2);
+          pmin = fminf(pmin, hull_coord(up, v, cp));
         });
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-          lo0 = fminf(lo0, __shfl_xor(lo0, off)); lo1 = fminf(lo1, __shfl_xor(lo1, off)); lo2 = fminf(lo2, __shfl_xor(lo2, off));
-          hi0 = fmaxf(hi0, __shfl_xor(hi0, off)); hi1 = fmaxf(hi1, __shfl_xor(hi1, off)); hi2 = fmaxf(hi2, __shfl_xor(hi2, off));
-        }
-        const float g0 = lo0 - hc.x, g1 = -hi0 - hc.x, g2 = lo1 - hc.y, g3 = -hi1 - hc.y, g4 = lo2 - hc.z, g5 = -hi2 - hc.z;      /* face +k: lowest vertex above it; face -k: highest vertex below it */
+        lo0 = wave_min_f(lo0); lo1 = wave_min_f(lo1); lo2 = wave_min_f(lo2); hi0 = wave_max_f(hi0); hi1 = wave_max_f(hi1); hi2 = wave_max_f(hi2);
+        pmin = wave_min_f(pmin);
+        const float g0 = lo0 - hcm.x, g1 = -hi0 - hcm.x, g2 = lo1 - hcm.y, g3 = -hi1 - hcm.y, g4 = lo2 - hcm.z, g5 = -hi2 - hcm.z;      /* face +k: lowest vertex above it; face -k: highest vertex below it */
         float best = g0; int bf = 0;
         if (g1 > best + K_TIE_EPS) { best = g1; bf = 1; }
         if (g2 > best + K_TIE_EPS) { best = g2; bf = 2; }
@@ -680,10 +756,13 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
         if (g4 > best + K_TIE_EPS) { best = g4; bf = 4; }
         if (g5 > best + K_TIE_EPS) { best = g5; bf = 5; }
         const float d = best - RP_HULL_MARGIN;
-        PCLK_ADD(15, 1 + (d > mg ? 65536 : 0))               /* (profiling build: hull pairs scanned | of them apart << 16) */
+        /* the probe direction: cores farther apart than the margin and the two shape margins along it - what GJK's distance phase would end with (oracle
+         * hull_box_gjk: "apart").  Only with GJK on: without it such a pair goes to the OBB path, which finds the OBBs apart all the same */
+        const bool probe_apart = m->gjk && pmin > mg + 2.f * RP_HULL_MARGIN + 1e-6f;
+        PCLK_ADD(15, 1 + ((d > mg || probe_apart) ? 65536 : 0))               /* (profiling build: hull pairs scanned | of them apart << 16) */
         int out = 0;                                         /* this pair's hf */
-        CPt pt; pt.p = mk3(0, 0, 0); pt.n = mk3(0, 0, 0); pt.dist = 0.f;
-        if (!(d > mg)) {                                     /* (wave-uniform) */
+        V3 nloc = mk3(0, 0, 0), ploc = mk3(0, 0, 0); float dcon = 0.f;      /* the contact in the BOX's frame: normal (box toward hull), point on the box's surface, distance */
+        if (!(d > mg) && !probe_apart) {                     /* (wave-uniform) */
           /* the first vertex (lowest index: the oracle's sequential scan keeps the first strict extreme) whose coordinate along that axis IS the extreme -
            * the same instruction sequence gives the same bits */
           const int k = bf >> 1;
@@ -691,115 +770,124 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
           const float ck = pick1(k, c0, c1, c2);
           const float ext = (bf & 1) ? pick1(k, hi0, hi1, hi2) : pick1(k, lo0, lo1, lo2);
           int iv = 0x7fffffff;
-          hull_scan<1>(tv, nn, lane, [&](const float4& v, int i) { if (hull_coord(uk, v, ck) == ext) iv = min(iv, i); });
-#pragma unroll
-          for (int off = 1; off < 64; off <<= 1) iv = min(iv, __shfl_xor(iv, off));
+          hull_scan<4>(tv, nn, lane, [&](const float4& v, int i) { if (hull_coord(uk, v, ck) == ext) iv = min(iv, i); });
+          iv = wave_min_i(iv);
           out = -1;
           if (iv != 0x7fffffff) {
             const float4 v = tv[iv];
-            const float l0 = hull_coord(u0, v, c0), l1 = hull_coord(u1, v, c1), l2 = hull_coord(u2, v, c2);
-            const bool beside = (k != 0 && fabsf(l0) > hc0.x) || (k != 1 && fabsf(l1) > hc0.y) || (k != 2 && fabsf(l2) > hc0.z);
-            st3(&L.npscr[NPG_SCRATCH * (src >> 3) + 87], mk3(l0, l1, l2));      /* (the vertex in box coordinates: where the GJK below starts from) */
+            const V3 lv = mk3(hull_coord(u0, v, c0), hull_coord(u1, v, c1), hull_coord(u2, v, c2));      /* the vertex in box coordinates */
+            const bool beside = (k != 0 && fabsf(lv.x) > hc0.x) || (k != 1 && fabsf(lv.y) > hc0.y) || (k != 2 && fabsf(lv.z) > hc0.z);
             if (!beside) {
               out = 1;
-              const V3 w = mulv(Rw, mk3(v.x, v.y, v.z)) + pw;
-              const V3 nb = pick3(k, b0, b1, b2);
-              const V3 nrm = (bf & 1) ? -nb : nb;
-              const V3 pB = w - nrm * best;                  /* on the box face under the vertex; the model's single application point lies halfway along the gap */
-              pt.p = pB + nrm * (0.5f * d); pt.n = flip ? -nrm : nrm; pt.dist = d;
-            }
-          }
-        }
-        if (out == -1 && m->gjk) {
-          /* the deepest vertex lies BESIDE the face (box edges and corners): GJK's distance phase, cores with the 0.001 margin around each (oracle hull_box_gjk;
-           * -1 again = the cores touch or overlap: the OBB path keeps that case).  The two transforms move to the scratch and are read where they are needed */
-          float* S = &L.npscr[NPG_SCRATCH * (src >> 3)];
-          float* X = S + 63;
-          PCLK_ADD(27, 1) PCLK_ADD(28, -(long long)__builtin_readcyclecounter())
-          for (int t = 0; t < 9; t++) { X[t] = Rw.m[t]; X[12 + t] = xc.R.m[t]; }
-          st3(X + 9, pw); st3(X + 21, xc.p);
-          const V3 hbc = mk3(hc0.x - fminf(RP_HULL_MARGIN, hc0.x), hc0.y - fminf(RP_HULL_MARGIN, hc0.y), hc0.z - fminf(RP_HULL_MARGIN, hc0.z));
-          /* first direction: from the box core's nearest point to the vertex the scan stopped at - two or three rounds from there */
-          const V3 lv = ld3(X + 24);
-          V3 v = mulv(xc.R, mk3(lv.x - fminf(fmaxf(lv.x, -hbc.x), hbc.x), lv.y - fminf(fmaxf(lv.y, -hbc.y), hbc.y), lv.z - fminf(fmaxf(lv.z, -hbc.z), hbc.z)));
-          if (dot(v, v) < GJK_ZERO) v = pw - xc.p;
-          asm volatile("" ::: "memory");
-          WSYNC();
-          if (dot(v, v) < GJK_ZERO) v = mk3(1, 0, 0);
-          int n = 0; float lam[3] = {0.f, 0.f, 0.f};
-          float dd = 1e30f;
-          bool fail = false;
-#pragma unroll 1
-          for (int it = 0; it < 32; it++) {
-            V3 w, sa, sb;
-            PCLK_ADD(26, 1) PCLK_ADD(29, -(long long)__builtin_readcyclecounter())
-            {                                                /* hull: the vertex of largest projection on -v (lowest index among equals) */
-              const V3 dl = tmulv(ldm3(X), -v);
-              float bd = -1e30f; int bi = 0x7fffffff;
-              hull_scan<1>(tv, nn, lane, [&](const float4& q, int i) {
-                const float dq = __fmaf_rn(dl.z, q.z, __fmaf_rn(dl.y, q.y, dl.x * q.x));
-                if (dq > bd) { bd = dq; bi = i; }
-              });
-#pragma unroll
-              for (int off = 1; off < 64; off <<= 1) {
-                const float od = __shfl_xor(bd, off); const int oi = __shfl_xor(bi, off);
-                if (od > bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
+              const float sg = (bf & 1) ? -1.f : 1.f;
+              nloc = mk3(k == 0 ? sg : 0.f, k == 1 ? sg : 0.f, k == 2 ? sg : 0.f);
+              ploc = lv - nloc * best;                       /* on the box face under the vertex */
+              dcon = d;
+            } else if (m->gjk) {
+              /* the deepest vertex lies BESIDE the face (box edges and corners): GJK's distance phase, cores with the 0.001 margin around each (oracle hull_box_gjk;
+               * -1 again = the cores touch or overlap: the OBB path keeps that case).  Box frame, the simplex in registers, seeded with lv against the corner(s)
+               * of the box core's nearest feature; support queries = whole-wave vertex scans */
+              PCLK_ADD(27, 1) PCLK_ADD(28, -(long long)__builtin_readcyclecounter())
+              const V3 hbc = mk3(hc0.x - fminf(RP_HULL_MARGIN, hc0.x), hc0.y - fminf(RP_HULL_MARGIN, hc0.y), hc0.z - fminf(RP_HULL_MARGIN, hc0.z));
+              const bool ox = fabsf(lv.x) > hbc.x, oy = fabsf(lv.y) > hbc.y, oz = fabsf(lv.z) > hbc.z;
+              const int nout = (ox ? 1 : 0) + (oy ? 1 : 0) + (oz ? 1 : 0);
+              GjkSimplex S;
+              S.w1 = S.w2 = S.w3 = mk3(0, 0, 0); S.b1 = S.b2 = S.b3 = 0; S.l0 = 1.f; S.l1 = S.l2 = 0.f;
+              const int near = (lv.x >= 0.f ? 1 : 0) | (lv.y >= 0.f ? 2 : 0) | (lv.z >= 0.f ? 4 : 0);
+              S.b0 = near; S.n = 1;
+              if (nout == 2) {                               /* the two ends of the nearest edge: along the one axis lv lies inside of */
+                const int fb = !ox ? 1 : (!oy ? 2 : 4);
+                S.b0 = near & ~fb; S.b1 = near | fb;
+                S.w1 = lv - GjkSimplex::corner(S.b1, hbc); S.n = 2;
               }
-              PCLK_ADD(29, __builtin_readcyclecounter()) PCLK_ADD(30, -(long long)__builtin_readcyclecounter())
-              const float4 qv = tv[bi < nn ? bi : 0];
-              sa = mulv(ldm3(X), mk3(qv.x, qv.y, qv.z)) + ld3(X + 9);
+              S.w0 = lv - GjkSimplex::corner(S.b0, hbc);
+              bool fail = nout == 0;
+              bool apart = false;
+              V3 v = mk3(0, 0, 0); float dd = 0.f;
+              if (!fail) {
+                gjk_closest(S, lane);
+                v = S.closest(); dd = dot(v, v);
+                fail = dd < GJK_ZERO;
+              }
+              const float far = mg + 2.f * RP_HULL_MARGIN;
+#pragma unroll 1
+              for (int it = 0; it < 32 && !fail; it++) {
+                PCLK_ADD(26, 1) PCLK_ADD(29, -(long long)__builtin_readcyclecounter())
+                V3 wa;
+                /* (the simplex waits in the pair's scratch while the scan runs: the kernel has no registers for both) */
+                float* Z = &L.npscr[NPG_SCRATCH * (src >> 3) + 8];
+                st3(Z, S.w0); st3(Z + 3, S.w1); st3(Z + 6, S.w2); st3(Z + 9, mk3(S.l0, S.l1, S.l2));
+                asm volatile("" ::: "memory");
+                {                                            /* hull: the vertex of largest projection on -v (lowest index among equals) */
+                  const V3 dl = -(u0 * v.x + u1 * v.y + u2 * v.z);
+                  float bd = -1e30f; int bi = 0x7fffffff; V3 bq = mk3(0, 0, 0);
+                  hull_scan<4>(tv, nn, lane, [&](const float4& q, int i) {      /* (four loads in flight: the simplex is parked, the registers are there) */
+                    const float dq = __fmaf_rn(dl.z, q.z, __fmaf_rn(dl.y, q.y, dl.x * q.x));
+                    if (dq > bd) { bd = dq; bi = i; bq = mk3(q.x, q.y, q.z); }
+                  });
+                  const float top = wave_max_f(bd);
+                  const int win = wave_min_i(bd == top ? bi : 0x7fffffff) & 63;      /* (vertex i was scanned by lane i & 63) */
+                  const V3 q = mk3(lane_read(bq.x, win), lane_read(bq.y, win), lane_read(bq.z, win));
+                  wa = mk3(hull_coord(u0, make_float4(q.x, q.y, q.z, 0.f), c0), hull_coord(u1, make_float4(q.x, q.y, q.z, 0.f), c1), hull_coord(u2, make_float4(q.x, q.y, q.z, 0.f), c2));
+                }
+                asm volatile("" ::: "memory");
+                S.w0 = ld3(Z); S.w1 = ld3(Z + 3); S.w2 = ld3(Z + 6); { const V3 t = ld3(Z + 9); S.l0 = t.x; S.l1 = t.y; S.l2 = t.z; }
+                PCLK_ADD(29, __builtin_readcyclecounter()) PCLK_ADD(30, -(long long)__builtin_readcyclecounter())
+                const int wb = (v.x >= 0.f ? 1 : 0) | (v.y >= 0.f ? 2 : 0) | (v.z >= 0.f ? 4 : 0);      /* box core: the corner of largest projection on v */
+                const V3 w = wa - GjkSimplex::corner(wb, hbc);
+                const float vv = dot(v, v), vw = dot(v, w);
+                /* v . w / |v| is a lower bound of the distance: beyond the pair's margin and the two shape margins the pair is apart whatever the iteration would still find */
+                if (vw > 0.f && vw * vw > far * far * vv) { apart = true; PCLK_ADD(30, __builtin_readcyclecounter()) break; }
+                bool dup = false;
+                { V3 dw = S.w0 - w; dup |= dot(dw, dw) < GJK_DUP;
+                  dw = S.w1 - w; dup |= S.n > 1 && dot(dw, dw) < GJK_DUP;
+                  dw = S.w2 - w; dup |= S.n > 2 && dot(dw, dw) < GJK_DUP; }
+                if (dup || vv - vw <= GJK_REL * vv) { PCLK_ADD(30, __builtin_readcyclecounter()) break; }
+                if (S.n == 1) { S.w1 = w; S.b1 = wb; } else if (S.n == 2) { S.w2 = w; S.b2 = wb; } else { S.w3 = w; S.b3 = wb; }
+                S.n++;
+                PCLK_ADD(30, __builtin_readcyclecounter()) PCLK_ADD(31, -(long long)__builtin_readcyclecounter())
+                gjk_closest(S, lane);
+                PCLK_ADD(31, __builtin_readcyclecounter())
+                if (S.n == 4) { fail = true; break; }
+                v = S.closest();
+                const float nd = dot(v, v);
+                if (nd < GJK_ZERO) { fail = true; break; }
+                if (nd >= dd * GJK_STALL) { dd = nd; break; }
+                dd = nd;
+              }
+              PCLK_ADD(28, __builtin_readcyclecounter())
+              const float dist = sqrtf(dot(v, v));
+              if (apart) out = 0;
+              else if (!fail && dist > GJK_ZERO) {
+                const float dg = dist - 2.f * RP_HULL_MARGIN;
+                if (dg > mg) out = 0;
+                else {
+                  out = 1;
+                  nloc = v * (1.f / dist);
+                  ploc = S.witness(hbc) + nloc * RP_HULL_MARGIN;
+                  dcon = dg;
+                }
+              }
             }
-            {                                                /* box core: the corner of largest projection on v */
-              const M3 Rb = ldm3(X + 12);
-              const V3 dlb = tmulv(Rb, v);
-              sb = mulv(Rb, mk3(dlb.x >= 0.f ? hbc.x : -hbc.x, dlb.y >= 0.f ? hbc.y : -hbc.y, dlb.z >= 0.f ? hbc.z : -hbc.z)) + ld3(X + 21);
-            }
-            w = sa - sb;
-            const float vv = dot(v, v), vw = dot(v, w);
-            bool dup = false;
-            for (int i = 0; i < n; i++) { const V3 dw = ld3(S + 9 * i) - w; dup |= dot(dw, dw) < GJK_DUP; }
-            if (dup || (n > 0 && vv - vw <= GJK_REL * vv)) { PCLK_ADD(30, __builtin_readcyclecounter()) break; }
-            st3(S + 9 * n, w); st3(S + 9 * n + 3, sa); st3(S + 9 * n + 6, sb);
-            n++;
-            WSYNC();
-            PCLK_ADD(30, __builtin_readcyclecounter()) PCLK_ADD(31, -(long long)__builtin_readcyclecounter())
-            if (n == 4) gjk_closest4(S, S + 36, n, lam); else gjk_closest3(S, n, lam);
-            WSYNC();
-            PCLK_ADD(31, __builtin_readcyclecounter())
-            if (n == 4) { fail = true; break; }
-            V3 q = ld3(S) * lam[0];
-            if (n > 1) q = q + ld3(S + 9) * lam[1];
-            if (n > 2) q = q + ld3(S + 18) * lam[2];
-            const float nd = dot(q, q);
-            v = q;
-            if (nd < GJK_ZERO) { fail = true; break; }
-            if (nd >= dd * GJK_STALL && it > 0) { dd = nd; break; }
-            dd = nd;
           }
-          PCLK_ADD(28, __builtin_readcyclecounter())
-          const float dist = sqrtf(dot(v, v));
-          if (!fail && dist > GJK_ZERO) {
-            V3 pbw = ld3(S + 6) * lam[0];
-            if (n > 1) pbw = pbw + ld3(S + 15) * lam[1];
-            if (n > 2) pbw = pbw + ld3(S + 24) * lam[2];
-            const V3 nB = v * (1.f / dist);
-            const float dg = dist - 2.f * RP_HULL_MARGIN;
-            if (dg > mg) out = 0;
-            else {
-              out = 1;
-              const V3 pB = pbw + nB * RP_HULL_MARGIN;
-              pt.p = pB + nB * (0.5f * dg); pt.n = flip ? -nB : nB; pt.dist = dg;
-            }
-          }
-          WSYNC();
-          asm volatile("" ::: "memory");
         }
-        if ((lane >> 3) == (src >> 3)) {
-          hf = out;
-          if (out == 1 && s == 0) { mine = pt; np = 1; }
+        CPt pt; pt.p = mk3(0, 0, 0); pt.n = mk3(0, 0, 0); pt.dist = 0.f;
+        if (out == 1) {                                      /* back to the world; the model's single application point lies halfway along the gap */
+          const Xf xc = collider_xf(m, L, cb);
+          const V3 nrm = mulv(xc.R, nloc);
+          const V3 pB = mulv(xc.R, ploc) + xc.p;
+          pt.p = pB + nrm * (0.5f * dcon); pt.n = flip ? -nrm : nrm; pt.dist = dcon;
+        }
+        if ((lane >> 3) == (src >> 3)) hf = out;
+        if (lane == src && out == 1) {                       /* the point waits in its group's scratch (free until the SAT below): nothing of it stays in registers across the next pair's scan */
+          float* q = &L.npscr[NPG_SCRATCH * (src >> 3)];
+          st3(q, pt.p); st3(q + 3, pt.n); q[6] = pt.dist;
         }
       }
     }
+    int np = 0;
+    CPt mine; mine.p = mk3(0, 0, 0); mine.n = mk3(0, 0, 0); mine.dist = 0.f;      /* the point this lane contributes (lane s < np of its group) */
+    if (hf == 1 && s == 0) { mine.p = ld3(scr); mine.n = ld3(scr + 3); mine.dist = scr[6]; np = 1; }
     asm volatile("" ::: "memory");
     const Xf xa = collider_xf(m, L, a), xb = collider_xf(m, L, b);
     const V3 ha = ld3(m->col_he[a]), hb = ld3(m->col_he[b]);
@@ -2856,11 +2944,20 @@ __device__ __forceinline__ void prep2_body(const DevModel* __restrict__ m, const
   /* pairing table for the k_solve2 after this launch: this env's place among the envs of its group sorted by load class,
    * heaviest first = envs in heavier (class, replica) bins + its rank inside its bin (both from the previous k_solve2).
    * The loads are issued here (wave 1); the sum and the store sit at the end of the kernel */
-  int my_slot = 0, cnt8[8];
-  if (wid == 1) {
-    my_slot = sort_slot[env];
+  int pair_place = 0;
+  if (wid == 1) {      /* (summed right away: this wave has ~10 k cycles of slack against the collision wave, and eight more registers live across the whole kernel - they are
+                        * allocated in the collision wave's code too - are what pushed the narrowphase into scratch memory) */
+    const int my_slot = sort_slot[env];
+    int cnt8[8];
 #pragma unroll
     for (int t = 0; t < 8; t++) cnt8[t] = sort_cnt[8 * lane + t];
+    const int mybin = my_slot >> SORT_RANK_BITS;
+    int above = 0;
+#pragma unroll
+    for (int t = 0; t < 8; t++) above += (8 * lane + t > mybin) ? cnt8[t] : 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) above += __shfl_xor(above, d);
+    pair_place = above + (my_slot & SORT_RANK_MASK);
   }
   PCLK(6) PCLK(0) PCLK_ZERO(15) PCLK_ZERO(26) PCLK_ZERO(27) PCLK_ZERO(28) PCLK_ZERO(29) PCLK_ZERO(30) PCLK_ZERO(31)
   static_assert(RP_REC_FLOATS == PREP_THREADS, "one float of the record per thread");
@@ -2985,13 +3082,7 @@ __device__ __forceinline__ void prep2_body(const DevModel* __restrict__ m, const
     copy_out(w + W3_ROFF, (const float*)L.roff, 64, lane);
     copy_out(w + W3_SLOT, (const float*)L.slot, 64, lane);
   } else {
-    const int mybin = my_slot >> SORT_RANK_BITS;
-    int above = 0;
-#pragma unroll
-    for (int t = 0; t < 8; t++) above += (8 * lane + t > mybin) ? cnt8[t] : 0;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) above += __shfl_xor(above, d);
-    if (lane == 0) pair_env[env0 + above + (my_slot & SORT_RANK_MASK)] = env | (ncon << 24);     /* + its contact count: k_solve2 sizes its row copy without waiting for the header */
+    if (lane == 0) pair_env[env0 + pair_place] = env | (ncon << 24);     /* + its contact count: k_solve2 sizes its row copy without waiting for the header */
   }
   PCLK(5) PCLK(7)
 }

@@ -203,7 +203,7 @@ int rp_create(const rp_config* cfg, rp_handle* out) {
       CREATE_CHK(hipMemset(h->pmcache, 0, (size_t)N * PMC_FLOATS * sizeof(float)));
       d->persist = 1; d->pmcache = h->pmcache;
     }
-    d->gjk = ((cfg->flags & RP_CFG_HULL_GJK) || getenv("RP_GJK") != nullptr) ? 1 : 0;      /* (oracle RPO_RULE_GJK; RP_GJK=1: the tools' switch) */
+    d->gjk = ((cfg->flags & RP_CFG_OBB_EDGES) || getenv("RP_NO_GJK") != nullptr) ? 0 : 1;      /* (oracle RPO_RULE_GJK: the default; RP_NO_GJK=1: the tools' switch to round 3's OBB edges) */
     if (getenv("RP_NO_SPIN") != nullptr)                     /* timing / model studies only: no torsional friction rows */
       for (int c = 0; c < RP_MAX_COL; c++) d->col_spin[c] = 0.f;
   }

@@ -47,7 +47,7 @@ class playEnv:
                  goal_range_low=(-0.18, -0.18, -0.05), goal_range_high=(0.18, 0.18, 0.05), obj_lower_bound=(-0.18, -0.18, -0.05),
                  obj_upper_bound=(-0.18, -0.18, -0.05), sparse=True, use_orientation=False, sparse_rew_thresh=0.05,
                  fixed_gripper=False, return_velocity=True, max_episode_steps=250, play=False, action_type='absolute_rpy',
-                 show_goal=True, arm_type='Panda', device=0, seed=None, contact_margin=None, persistent_manifolds=True, hull_gjk=False):
+                 show_goal=True, arm_type='Panda', device=0, seed=None, contact_margin=None, persistent_manifolds=True, hull_gjk=True):
         # seed=None: like the reference, which draws from the global np.random (environments.py:496, 530, 579), every new env gets
         # its own episode stream and np.random.seed(k) makes it repeatable
         if seed is None:

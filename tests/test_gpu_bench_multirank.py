@@ -1,0 +1,61 @@
+"""bench.py's N > 1 branch, run for real: two FRESH child processes (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* from the environment, exactly what
+torch.distributed.run hands a rank), both on device 0, RP_BENCH_BACKEND=gloo - the documented control-flow path of bench.py for a box with fewer GPUs
+than ranks.  Never a measurement (two ranks share one GPU and the gather goes through the host): what is checked is that the branch runs and that its
+JSON line says what the driver reads off it.  The 1 -> 8 GPU curve itself stays unmeasured (no 8-GPU node was available to the builder).
+
+The children are started before this process touches the GPU (a GPU-initialised parent must never be replaced by another program, and need not be:
+subprocess.Popen forks a child, which execs; the parent goes on)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_bench_two_ranks_gloo_on_one_device():
+    port = free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE='2', LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   RP_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '5', '--warmup', '1', '--no-extras',
+                                       '--no-cpu-baseline', '--repeats', '1', '--envs-per-gpu', '512'],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=REPO))
+    outs = []
+    for p in procs:
+        try:
+            out, err = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append((p.returncode, out, err))
+    for rc, out, err in outs:
+        assert rc == 0, err[-2000:]
+    lines = [l for l in outs[0][1].splitlines() if l.startswith('{')]
+    assert len(lines) == 1 and not [l for l in outs[1][1].splitlines() if l.startswith('{')], 'rank 0 alone prints the line'
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['config']['ranks_seen'] == 2 and d['scaling'] == 'weak'
+    assert d['config']['collective'].startswith('all_gather(') and d['config']['collective_backend'] == 'gloo'
+    ranges = sorted(tuple(r['envs']) for r in d['config']['ranks'])
+    assert ranges == [(0, 512), (512, 1024)], ranges
+    assert sorted(r['rank'] for r in d['config']['ranks']) == [0, 1]
+    assert d['config']['global_envs'] == 1024 and d['steps'] == 5 and d['warmup'] == 1
+    v = d['value']
+    assert v == v and 0 < v < 1e9 and abs(v - 1024 * 5 / (d['ms_per_step'] * 5e-3)) < 1e-6 * v
+    assert d['non_finite_envs'] == 0
+    assert 'cpu_baseline' not in d and d['roofline']['traffic'] is None      # (not the headline batch size: no PMC profile quoted)

@@ -139,19 +139,20 @@ def test_rollout_200_steps_vs_fp64_oracle(kind):
           % (100.0 * capped.sum() / (n * steps), int((capped > 0).sum()), n, capped[~strict].mean() if (~strict).any() else 0.0, capped[strict].mean()))
 
 
-@pytest.mark.parametrize('kind', ['U', 'P'])
-def test_hull_gjk_option_vs_fp64_oracle(kind):
-    """RP_CFG_HULL_GJK (off by default: a fifth of the throughput) against the oracle's RPO_RULE_GJK: an arm link whose deepest hull vertex lies beside the
-    box face gets its contact from GJK's distance phase.  100 steps, 16 envs, the arm's own joints; same bound and envelope as the headline rollout:
-    1e-3 relative, three times the fp32 followers' own largest divergence where that is larger, and the median an order of magnitude inside."""
+@pytest.mark.parametrize('kind,gjk', [('U', True), ('P', True), ('U', False), ('P', False)])
+def test_hull_gjk_option_vs_fp64_oracle(kind, gjk):
+    """The two models of an arm link whose deepest hull vertex lies beside the box face (box edges and corners): GJK's distance phase on hull and box (the default
+    since round 4; oracle rule 2039 = 1015 | RPO_RULE_GJK) and, under RP_CFG_OBB_EDGES (hull_gjk=False), the link's OBB (round 3's default, oracle rule 1015).
+    100 steps, 16 envs, the arm's own joints; same bound and envelope as the headline rollout: 1e-3 relative, three times the fp32 followers' own largest
+    divergence where that is larger, and the median an order of magnitude inside."""
     from roboticsplayroompybullet_amd import VecPlayEnv
     import sys, os
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
     from gpu_debug import record_from_oracle
     n, steps = 16, 100
-    env = VecPlayEnv(IDS[kind], n, seed=9, hull_gjk=True)
+    env = VecPlayEnv(IDS[kind], n, seed=9, hull_gjk=gjk)
     env.reset()
-    fol = [Followers(kind, 9, e, extra=4, rule=1015 | 1024) for e in range(n)]
+    fol = [Followers(kind, 9, e, extra=4, rule=1015 | (1024 if gjk else 0)) for e in range(n)]
     for f in fol:
         f.o64.reset()
         f.start_from(f.o64)
@@ -168,7 +169,7 @@ def test_hull_gjk_option_vs_fp64_oracle(kind):
             qo = f.o64.get_state()[:n_arm]
             d_hip[e] = max(d_hip[e], float((np.abs(q[e] - qo) / np.maximum(1.0, np.abs(qo)))[:nm].max()))
             d_o32[e] = max(d_o32[e], float((f.gap(lambda o: o.get_state()[:nm]) / np.maximum(1.0, np.abs(qo[:nm]))).max()))
-    print('hull GJK option (%s, %d envs, %d steps): device max %.3e median %.3e; fp32 CPU followers max %.3e' % (kind, n, steps, d_hip.max(), np.median(d_hip), d_o32.max()))
+    print('hull GJK %s (%s, %d envs, %d steps): device max %.3e median %.3e; fp32 CPU followers max %.3e' % ('on' if gjk else 'off', kind, n, steps, d_hip.max(), np.median(d_hip), d_o32.max()))
     assert (d_hip <= np.maximum(1e-3, 3 * d_o32)).sum() >= n - 1, (d_hip, d_o32)
     assert np.median(d_hip) <= 1e-4
 
