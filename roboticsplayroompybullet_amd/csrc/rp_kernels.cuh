@@ -735,6 +735,7 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
           cp = dot(Ls, tc) + hbc0.x * fabsf(dot(Ls, b0)) + hbc0.y * fabsf(dot(Ls, b1)) + hbc0.z * fabsf(dot(Ls, b2));      /* the box core's far end along it, seen from the body's origin */
         }
         if (obb_apart) {                                     /* (wave-uniform) */
+          PCLK_ADD(15, 1ull << 48)
           if ((lane >> 3) == (src >> 3)) hf = 0;
           continue;
         }
@@ -759,7 +760,7 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
         /* the probe direction: cores farther apart than the margin and the two shape margins along it - what GJK's distance phase would end with (oracle
          * hull_box_gjk: "apart").  Only with GJK on: without it such a pair goes to the OBB path, which finds the OBBs apart all the same */
         const bool probe_apart = m->gjk && pmin > mg + 2.f * RP_HULL_MARGIN + 1e-6f;
-        PCLK_ADD(15, 1 + ((d > mg || probe_apart) ? 65536 : 0))               /* (profiling build: hull pairs scanned | of them apart << 16) */
+        PCLK_ADD(15, 1 + ((d > mg || probe_apart) ? 65536 : 0) + ((probe_apart && !(d > mg)) ? (1ull << 32) : 0ull))               /* (profiling build: hull pairs scanned | of them apart << 16) */
         int out = 0;                                         /* this pair's hf */
         V3 nloc = mk3(0, 0, 0), ploc = mk3(0, 0, 0); float dcon = 0.f;      /* the contact in the BOX's frame: normal (box toward hull), point on the box's surface, distance */
         if (!(d > mg) && !probe_apart) {                     /* (wave-uniform) */
@@ -857,12 +858,14 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
               }
               PCLK_ADD(28, __builtin_readcyclecounter())
               const float dist = sqrtf(dot(v, v));
+              PCLK_ADD(27, apart ? (1ull << 16) : (fail ? (1ull << 48) : 0ull))
               if (apart) out = 0;
               else if (!fail && dist > GJK_ZERO) {
                 const float dg = dist - 2.f * RP_HULL_MARGIN;
-                if (dg > mg) out = 0;
+                if (dg > mg) { out = 0; PCLK_ADD(27, 1ull << 16) }
                 else {
                   out = 1;
+                  PCLK_ADD(27, 1ull << 32)
                   nloc = v * (1.f / dist);
                   ploc = S.witness(hbc) + nloc * RP_HULL_MARGIN;
                   dcon = dg;

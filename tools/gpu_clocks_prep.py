@@ -49,7 +49,10 @@ npd = (a[:, 9] - a[:, 8]).astype(float)
 print('narrowphase cycles vs active pairs: corr %.2f' % np.corrcoef(na, npd)[0, 1])
 late = w0 > np.percentile(w0, 50)
 print('first-round waves: total p50 %d; second-round waves: total p50 %d' % (np.median(tot[~late]), np.median(tot[late])))
-hp, ha = a[:, 15] & 0xFFFF, a[:, 15] >> 16
+hp, ha, hpr, hob = a[:, 15] & 0xFFFF, (a[:, 15] >> 16) & 0xFFFF, (a[:, 15] >> 32) & 0xFFFF, (a[:, 15] >> 48) & 0xFFFF
+print('hull pairs per env: stopped by the 15-axis OBB test %.2f, scanned %.2f, of those apart along a box axis or the probe direction %.2f (by the probe alone %.2f); GJK calls %.2f, GJK rounds %.2f' % (hob.mean(), hp.mean(), ha.mean(), hpr.mean(), (a[:, 27] & 0xFFFF).mean(), a[:, 26].mean()))
+print('GJK outcomes per env: apart %.3f, contact %.3f, cores overlap (OBB path) %.3f' % (((a[:, 27] >> 16) & 0xFFFF).mean(), ((a[:, 27] >> 32) & 0xFFFF).mean(), ((a[:, 27] >> 48) & 0xFFFF).mean()))
+a[:, 27] &= 0xFFFF
 print('hull pairs scanned per env: mean %.2f p90 %d max %d; of them apart (two scans for nothing): mean %.2f' % (hp.mean(), np.percentile(hp, 90), hp.max(), ha.mean()))
 g = a[:, 27] > 0
 if g.any():
