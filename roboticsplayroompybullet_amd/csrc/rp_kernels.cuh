@@ -2934,38 +2934,15 @@ __device__ __forceinline__ void copy_out(float* __restrict__ dst, const float* s
 static_assert(W3_A % 4 == 0 && W3_ROWS % 4 == 0 && W3_ROFF % 4 == 0 && AOUT_FLOATS % 4 == 0, "16-byte copies");
 
 #define PREP_THREADS 128
-__device__ __forceinline__ void prep2_body(const DevModel* __restrict__ m, const float* __restrict__ state, float* __restrict__ ws, int env0, int N,
-                                           const int* __restrict__ sort_cnt, int* __restrict__ sort_cnt_next, const int* __restrict__ sort_slot, int* __restrict__ pair_env,
-                                           const int* __restrict__ member, const int bid, const int* __restrict__ cache_env = nullptr) {
-  __shared__ PrepLds L;
+/* one env's preparation by the two waves of a block: L = the block's PrepLds, env = the env, cenv = the env whose contact cache it uses (rp_reset settles in a dense
+ * scratch range: the cache stays the env's own), pair_out = where this env's entry of the pairing table goes (env | contact count << 24; stored by wave 1, lane 0).
+ * Ends without a barrier: the caller synchronises before L is used again. */
+__device__ __forceinline__ void prep2_core(PrepLds& L, const DevModel* __restrict__ m, const float* __restrict__ state, float* __restrict__ ws, const int env, const int cenv,
+                                           int* __restrict__ pair_out) {
   const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
-  int env = env0 + bid;
-  if (env >= N) return;
-  if (member) env = member[env];     /* this block's place in its group -> env (groups are cut by load, see k_member) */
-  if (bid == 0)               /* the histogram that the k_solve2 after this launch fills (for the substep after it) starts at zero */
-    for (int i = tid; i < SORT_BINS; i += PREP_THREADS) sort_cnt_next[i] = 0;
-  /* pairing table for the k_solve2 after this launch: this env's place among the envs of its group sorted by load class,
-   * heaviest first = envs in heavier (class, replica) bins + its rank inside its bin (both from the previous k_solve2).
-   * The loads are issued here (wave 1); the sum and the store sit at the end of the kernel */
-  int pair_place = 0;
-  if (wid == 1) {      /* (summed right away: this wave has ~10 k cycles of slack against the collision wave, and eight more registers live across the whole kernel - they are
-                        * allocated in the collision wave's code too - are what pushed the narrowphase into scratch memory) */
-    const int my_slot = sort_slot[env];
-    int cnt8[8];
-#pragma unroll
-    for (int t = 0; t < 8; t++) cnt8[t] = sort_cnt[8 * lane + t];
-    const int mybin = my_slot >> SORT_RANK_BITS;
-    int above = 0;
-#pragma unroll
-    for (int t = 0; t < 8; t++) above += (8 * lane + t > mybin) ? cnt8[t] : 0;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) above += __shfl_xor(above, d);
-    pair_place = above + (my_slot & SORT_RANK_MASK);
-  }
   PCLK(6) PCLK(0) PCLK_ZERO(15) PCLK_ZERO(26) PCLK_ZERO(27) PCLK_ZERO(28) PCLK_ZERO(29) PCLK_ZERO(30) PCLK_ZERO(31)
   static_assert(RP_REC_FLOATS == PREP_THREADS, "one float of the record per thread");
   L.st[tid] = state[(size_t)env * RP_REC_FLOATS + tid];
-  const int cenv = cache_env ? cache_env[env] : env;         /* (rp_reset settles in a dense scratch range: the contact cache stays the env's own) */
   if (tid == 64 && m->persist) L.hdr[2] = __float_as_int(m->pmcache[(size_t)cenv * PMC_FLOATS]);      /* the cache's manifold count, for collide() */
   __syncthreads();
   PCLK(16)
@@ -3085,9 +3062,39 @@ __device__ __forceinline__ void prep2_body(const DevModel* __restrict__ m, const
     copy_out(w + W3_ROFF, (const float*)L.roff, 64, lane);
     copy_out(w + W3_SLOT, (const float*)L.slot, 64, lane);
   } else {
-    if (lane == 0) pair_env[env0 + pair_place] = env | (ncon << 24);     /* + its contact count: k_solve2 sizes its row copy without waiting for the header */
+    if (lane == 0) *pair_out = env | (ncon << 24);     /* + its contact count: k_solve2 sizes its row copy without waiting for the header */
   }
   PCLK(5) PCLK(7)
+}
+/* k_prep2's block: its env from its place in the group, its place in the pairing table of the k_solve2 after this launch */
+__device__ __forceinline__ void prep2_body(const DevModel* __restrict__ m, const float* __restrict__ state, float* __restrict__ ws, int env0, int N,
+                                           const int* __restrict__ sort_cnt, int* __restrict__ sort_cnt_next, const int* __restrict__ sort_slot, int* __restrict__ pair_env,
+                                           const int* __restrict__ member, const int bid, const int* __restrict__ cache_env = nullptr) {
+  __shared__ PrepLds L;
+  const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+  int env = env0 + bid;
+  if (env >= N) return;
+  if (member) env = member[env];     /* this block's place in its group -> env (groups are cut by load, see k_member) */
+  if (bid == 0)               /* the histogram that the k_solve2 after this launch fills (for the substep after it) starts at zero */
+    for (int i = tid; i < SORT_BINS; i += PREP_THREADS) sort_cnt_next[i] = 0;
+  /* pairing table for the k_solve2 after this launch: this env's place among the envs of its group sorted by load class,
+   * heaviest first = envs in heavier (class, replica) bins + its rank inside its bin (both from the previous k_solve2) */
+  int pair_place = 0;
+  if (wid == 1) {      /* (summed right away: this wave has ~10 k cycles of slack against the collision wave, and eight more registers live across the whole kernel - they are
+                        * allocated in the collision wave's code too - are what pushed the narrowphase into scratch memory) */
+    const int my_slot = sort_slot[env];
+    int cnt8[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) cnt8[t] = sort_cnt[8 * lane + t];
+    const int mybin = my_slot >> SORT_RANK_BITS;
+    int above = 0;
+#pragma unroll
+    for (int t = 0; t < 8; t++) above += (8 * lane + t > mybin) ? cnt8[t] : 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) above += __shfl_xor(above, d);
+    pair_place = above + (my_slot & SORT_RANK_MASK);
+  }
+  prep2_core(L, m, state, ws, env, cache_env ? cache_env[env] : env, pair_env + env0 + pair_place);
 }
 /* two entry points on the same body: rp_step's substeps, and the settle substeps of rp_reset under their own name so that
  * profiles keep the two apart */
@@ -3239,11 +3246,11 @@ __device__ __forceinline__ int pair_env_id(int pe) {
   return e;
 }
 __device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, float* __restrict__ state, const float* __restrict__ ws, int env0, int N,
-                                                  const int* __restrict__ pair_env, int* __restrict__ sort_cnt_next, int* __restrict__ sort_slot, int debug_flags, Solve2Lds* Ls) {
+                                                  const int* __restrict__ pair_env, int* __restrict__ sort_cnt_next, int* __restrict__ sort_slot, int debug_flags, Solve2Lds* Ls, const int bq) {
   /* the waves of a block work independently, each on its own pair of envs and its own LDS block Ls[wid].  Few blocks come here (the ones with a coupled env:
    * 1 - 2 % of the envs) and they last twice as long as the four-env blocks: they are the launch's critical path (raising their wave priority changes nothing:
    * they already run alone for the second half of the launch) */
-  const int wid = threadIdx.x >> 6, wb = blockIdx.x * SOLVE_WAVES + wid;      /* wb: this wave's number in the launch */
+  const int wid = threadIdx.x >> 6, wb = bq * SOLVE_WAVES + wid;      /* wb: this wave's number in the launch (bq: the block's) */
   Solve2Lds& L = Ls[wid];
   const int lane = threadIdx.x & 63, half = lane >> 5, l = lane & 31, grp = l >> 4, l16 = lane & 15;
 #if defined(RP_CLOCKS) && RP_CLOCKS != 2
@@ -3439,7 +3446,7 @@ __device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, floa
    * heaviest wave runs).  The atomic is issued here, after the last wait on a load (vmcnt is in order), and its result is used in
    * the last lines of the kernel: its round trip under contention, several microseconds, hides behind the sweeps. */
   int sort_pos = 0, sort_bin = 0;
-  if (l == 0 && valid) {
+  if (l == 0 && valid && !(debug_flags & 4)) {      /* (flag 4: k_chain's substeps before the last - nobody reads their classes) */
     int key = 8 * (my_nC < 7 ? my_nC : 7) + (my_nS < 1 ? 0 : (my_nS > 14 ? 7 : (my_nS - 1) >> 1));      /* side-by-side slots in steps of two: a resting scene has 2..6 */
     sort_bin = key * SORT_REPS + ((wb * 2 + half) & (SORT_REPS - 1));
     sort_pos = atomicAdd(&sort_cnt_next[sort_bin], 1);
@@ -3575,7 +3582,7 @@ __device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, floa
   if (valid) {
     float* r = state + (size_t)env * RP_REC_FLOATS;
     for (int k = l; k < RP_REC_FLOATS; k += 32) r[k] = st[k];
-    if (l == 0) {
+    if (l == 0 && !(debug_flags & 4)) {
       int sp = sort_pos;
       asm volatile("" : "+v"(sp));           /* first use of the atomic's result: keeps its s_waitcnt down here */
       sort_slot[env] = (sort_bin << SORT_RANK_BITS) | sp;
@@ -3606,10 +3613,10 @@ __device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, floa
 #define S4_SLOTS1 16     /* row-1 contact slots (wave 1): one plane register */
 template <int T>
 __device__ __forceinline__ void solve4_body(const DevModel* __restrict__ m, float* __restrict__ state, const float* __restrict__ ws, int env0, int N,
-                                            const int* __restrict__ pair_env, int* __restrict__ sort_cnt_next, int* __restrict__ sort_slot, int debug_flags, float* __restrict__ stl) {
+                                            const int* __restrict__ pair_env, int* __restrict__ sort_cnt_next, int* __restrict__ sort_slot, int debug_flags, float* __restrict__ stl, const int bq) {
   constexpr int NSL = T == 0 ? S4_SLOTS0 : S4_SLOTS1;
   const int lane = threadIdx.x & 63, g = lane >> 4, l16 = lane & 15;
-  const int place = blockIdx.x * 4 + g;
+  const int place = bq * 4 + g;
   const int pe = place < N - env0 ? pair_env[env0 + place] : -1;
   const int env = pe < 0 ? -1 : pair_env_id(pe);
   const bool valid = env >= 0;
@@ -3735,7 +3742,7 @@ __device__ __forceinline__ void solve4_body(const DevModel* __restrict__ m, floa
   __builtin_amdgcn_s_waitcnt(0x0F70);    /* vmcnt(0): all row registers have landed before the sweep loop */
   /* counting sort by load class for the next substep's pairing: one atomic per env, from the row-1 wave */
   int sort_pos = 0, sort_bin = 0;
-  if (T == 1 && l16 == 0 && valid) {
+  if (T == 1 && l16 == 0 && valid && !(debug_flags & 4)) {
     const int my_nS = max(my_nA, my_nB);
     const int key = my_nS < 1 ? 0 : (my_nS > 14 ? 7 : (my_nS - 1) >> 1);
     sort_bin = key * SORT_REPS + (place & (SORT_REPS - 1));
@@ -3846,7 +3853,7 @@ __device__ __forceinline__ void solve4_body(const DevModel* __restrict__ m, floa
       if (l16 < n) { r[ST_Q + l16] = st[ST_Q + l16]; r[ST_QD + l16] = st[ST_QD + l16]; }
     } else {
       if (l16 < m->n_j1) { r[ST_JQ + l16] = st[ST_JQ + l16]; r[ST_JQD + l16] = st[ST_JQD + l16]; }
-      if (l16 == 0) {
+      if (l16 == 0 && !(debug_flags & 4)) {
         int sp = sort_pos;
         asm volatile("" : "+v"(sp));
         sort_slot[env] = (sort_bin << SORT_RANK_BITS) | sp;
@@ -3858,9 +3865,9 @@ __device__ __forceinline__ void solve4_body(const DevModel* __restrict__ m, floa
 }
 
 /* does this block take the four-env path?  Decided from the same headers by both waves alike. */
-__device__ __forceinline__ bool solve4_eligible(const float* __restrict__ ws, int env0, int N, const int* __restrict__ pair_env, int debug_flags) {
+__device__ __forceinline__ bool solve4_eligible(const float* __restrict__ ws, int env0, int N, const int* __restrict__ pair_env, int debug_flags, const int bq) {
   const int lane = threadIdx.x & 63, g = lane >> 4;
-  const int place = blockIdx.x * 4 + g;
+  const int place = bq * 4 + g;
   const int pe = place < N - env0 ? pair_env[env0 + place] : -1;
   const int envm = pair_env_id(pe);
   const bool valid = pe >= 0;
@@ -3880,17 +3887,80 @@ __device__ __forceinline__ bool solve4_eligible(const float* __restrict__ ws, in
 #else
 #define S4_CLK(i)
 #endif
+/* one block's solve: bq = its number among the blocks of the launch (its four envs: places 4 bq .. 4 bq + 3 of the pairing table), Ls = its LDS */
+__device__ __forceinline__ void solve_block(const DevModel* __restrict__ m, float* __restrict__ state, const float* __restrict__ ws, int env0, int N,
+                                            const int* __restrict__ pair_env, int* __restrict__ sort_cnt_next, int* __restrict__ sort_slot, int debug_flags, Solve2Lds* Ls, const int bq) {
+  static_assert(sizeof(Solve2Lds) >= 4 * RP_REC_FLOATS * sizeof(float), "the four-env path keeps four state records where the two-env path stages its rows");
+  if (solve4_eligible(ws, env0, N, pair_env, debug_flags, bq)) {
+    S4_CLK(4)
+    if ((threadIdx.x >> 6) == 0) solve4_body<0>(m, state, ws, env0, N, pair_env, sort_cnt_next, sort_slot, debug_flags, (float*)&Ls[0], bq);
+    else solve4_body<1>(m, state, ws, env0, N, pair_env, sort_cnt_next, sort_slot, debug_flags, (float*)&Ls[1], bq);
+    S4_CLK(5)
+  } else solve2_body(m, state, ws, env0, N, pair_env, sort_cnt_next, sort_slot, debug_flags, Ls, bq);
+}
 #define SOLVE_DISPATCH \
   __shared__ Solve2Lds Ls[SOLVE_WAVES]; \
-  static_assert(sizeof(Solve2Lds) >= 4 * RP_REC_FLOATS * sizeof(float), "the four-env path keeps four state records where the two-env path stages its rows"); \
-  if (solve4_eligible(ws, env0, N, pair_env, debug_flags)) { \
-    S4_CLK(4) \
-    if ((threadIdx.x >> 6) == 0) solve4_body<0>(m, state, ws, env0, N, pair_env, sort_cnt_next, sort_slot, debug_flags, (float*)&Ls[0]); \
-    else solve4_body<1>(m, state, ws, env0, N, pair_env, sort_cnt_next, sort_slot, debug_flags, (float*)&Ls[1]); \
-    S4_CLK(5) \
-  } else solve2_body(m, state, ws, env0, N, pair_env, sort_cnt_next, sort_slot, debug_flags, Ls);
+  solve_block(m, state, ws, env0, N, pair_env, sort_cnt_next, sort_slot, debug_flags, Ls, blockIdx.x);
 __global__ void __launch_bounds__(64 * SOLVE_WAVES, 2) k_solve2(SOLVE2_ARGS) { SOLVE_DISPATCH }
 __global__ void __launch_bounds__(64 * SOLVE_WAVES, 2) k_settle_solve(SOLVE2_ARGS) { SOLVE_DISPATCH }
+
+/* ------------------------------------------------------------------ k_chain: all substeps of a step in ONE launch (round 4's experiment, rp_set_pipeline(h, 2)).
+ * A block of two waves owns the same four envs (places 4 q .. 4 q + 3 of the load ranking `member`) for all nsub substeps and alternates inside itself between their
+ * preparation - prep2_core, one env after the other: both waves work on one env as in k_prep2 - and their solve - solve_block, the four-env path or the two-env path as
+ * their contacts demand.  The rows go through the same workspace as in the split pipeline (written and read by the same CU: L2 / L1 resident) and the pairing table is
+ * the identity on the ranking.  No launch boundary between substeps, so no launch-wide barrier: a block's heavy substeps add to its own chain and to nobody else's.
+ * What it costs: one register / LDS footprint for both phases - the solve's (217 VGPRs, 40 KB: two waves per SIMD) - where k_prep2 runs at four waves per SIMD.
+ * Same row bodies on the same rows in the same order: the same bits as the split pipeline (tests). */
+struct __align__(16) ChainLds { union { PrepLds P; Solve2Lds S[SOLVE_WAVES]; }; };
+#ifdef RP_CHAIN_CLOCKS
+__device__ long long g_chain_clk[4 * 4096];
+#endif
+/* the two phases as REAL calls: inlined into one loop body, everything they derive from the thread index and the model - hundreds of values - is hoisted in front of the
+ * substep loop and spilled (256 VGPRs + 580 bytes of scratch); a call keeps each phase's registers its own */
+/* (a called function gets its arguments in VGPRs; they are wave-uniform, and the bodies keep their guards in SGPRs: made scalar again here) */
+template <class T> __device__ __forceinline__ T* uniform_ptr(T* p) {
+  const unsigned long long v = (unsigned long long)p;
+  return (T*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v));
+}
+__device__ __attribute__((noinline)) void chain_prep(PrepLds* L, const DevModel* m, const float* state, float* ws, int env, int* pair_out) {
+  prep2_core(*uniform_ptr(L), uniform_ptr(m), uniform_ptr(state), uniform_ptr(ws), uni(env), uni(env), uniform_ptr(pair_out));
+}
+__device__ __attribute__((noinline)) void chain_solve(const DevModel* m, float* state, const float* ws, int N, const int* pair_tab, int* sort_cnt_next, int* sort_slot, int flags, Solve2Lds* Ls, int q) {
+  solve_block(uniform_ptr(m), uniform_ptr(state), uniform_ptr(ws), 0, uni(N), uniform_ptr(pair_tab), uniform_ptr(sort_cnt_next), uniform_ptr(sort_slot), uni(flags), uniform_ptr(Ls), uni(q));
+}
+__global__ void __launch_bounds__(64 * SOLVE_WAVES, 2) k_chain(const DevModel* __restrict__ m, float* state, float* ws, int N, const int* __restrict__ member,
+                                                              int* pair_tab, int* __restrict__ sort_cnt_next, int* __restrict__ sort_slot, int nsub, int debug_flags) {
+  __shared__ ChainLds L;
+  static_assert(PREP_THREADS == 64 * SOLVE_WAVES, "one block shape for both phases");
+  const int nq = (N + 3) >> 2;
+#ifdef RP_CHAIN_CLOCKS      /* profiling build: wall clock (100 MHz) spent in the two phases, per block: g_chain_clk[4 b] = prep, [4 b + 1] = solve, [4 b + 2] = start, [4 b + 3] = end */
+#define CHCLK(i, sign) if (threadIdx.x == 0) g_chain_clk[4 * blockIdx.x + (i)] += (sign) * (long long)wall_clock64();
+  if (threadIdx.x == 0) { g_chain_clk[4 * blockIdx.x] = 0; g_chain_clk[4 * blockIdx.x + 1] = 0; g_chain_clk[4 * blockIdx.x + 2] = (long long)wall_clock64(); }
+#else
+#define CHCLK(i, sign)
+#endif
+  for (int sub = 0; sub < nsub; sub++) {
+    const int flags = debug_flags | (sub + 1 < nsub ? 4 : 0);      /* load classes for the next step's ranking: from the last substep only */
+    for (int q = blockIdx.x; q < nq; q += gridDim.x) {
+      CHCLK(0, -1)
+      for (int k = 0; k < 4; k++) {
+        const int place = 4 * q + k;
+        if (place < N) {                                           /* (block-uniform) */
+          const int env = member ? member[place] : place;
+          chain_prep(&L.P, m, state, ws, env, pair_tab + place);
+        }
+        __syncthreads();                                           /* the next env's preparation (or the solve) takes the LDS over; this env's rows and its table entry are visible to the block */
+      }
+      CHCLK(0, 1) CHCLK(1, -1)
+      chain_solve(m, state, ws, N, pair_tab, sort_cnt_next, sort_slot, flags, L.S, q);
+      __syncthreads();                                             /* the records are written: the next substep's preparation may read them */
+      CHCLK(1, 1)
+    }
+  }
+#ifdef RP_CHAIN_CLOCKS
+  if (threadIdx.x == 0) g_chain_clk[4 * blockIdx.x + 3] = (long long)wall_clock64();
+#endif
+}
 
 
 /* first pairing of a group's envs (before any load class is known): everything in the lightest class, in index order */

@@ -361,6 +361,29 @@ int rp_step(rp_handle h, const float* action, const rp_out* out, void* stream) {
   if (h->timers_on && h->fused == 1) hipEventRecord(h->ev0, s);
   if (h->fused == 1) {
     hipLaunchKernelGGL(k_step, dim3(N), dim3(64), 0, s, h->dev_model, h->state, action, to_ptrs(out), N);
+  } else if (h->fused == 2) {
+    /* round 4's experiment (rp_set_fused(h, 2)): the twelve substeps in ONE launch, k_chain - blocks of two waves own four envs each (in the load ranking's order) for
+     * the whole step.  Ranking, action kernel, the chain, observations: four launches on the caller's stream */
+    OutPtrs op = to_ptrs(out);
+    GroupBounds gb;
+    gb.b[0] = 0;
+    for (int g = 1; g <= RP_MAX_GROUPS; g++) gb.b[g] = N;
+    if (h->sort_G == 0) hipLaunchKernelGGL(k_member_identity, dim3((N + 255) / 256), dim3(256), 0, s, h->member[h->member_cur], N);
+    else {
+      hipLaunchKernelGGL(k_member, dim3(1), dim3(1024), 0, s, h->member[h->member_cur], h->member[h->member_cur ^ 1], h->sort_cnt + (size_t)h->sort_par * RP_MAX_GROUPS * SORT_BINS,
+                         h->sort_slot, N, h->sort_G, h->gb, 1, gb);
+      h->member_cur ^= 1;
+    }
+    const int* member = h->member[h->member_cur];
+    int* cnt_next = h->sort_cnt + (size_t)(h->sort_par ^ 1) * RP_MAX_GROUPS * SORT_BINS;      /* the last substep's load classes: the next step's ranking */
+    HIPCHK(h, hipMemsetAsync(cnt_next, 0, SORT_BINS * sizeof(int), s));
+    hipLaunchKernelGGL(k_action, dim3((N + 3) / 4), dim3(64), 0, s, h->dev_model, h->state, action, op.target_poses, 0, N, member);
+    const int nq = (N + 3) / 4;
+    const char* cb = getenv("RP_CHAIN_BLOCKS");
+    const int blocks = min(nq, cb ? max(1, atoi(cb)) : 1024);          /* 256 CUs x 4 blocks of 40 KB LDS and 2 x 217 VGPRs: everything resident at once */
+    hipLaunchKernelGGL(k_chain, dim3(blocks), dim3(64 * SOLVE_WAVES), 0, s, h->dev_model, h->state, h->ws, N, member, h->pair_env, cnt_next, h->sort_slot, K_NSUB, h->debug_flags);
+    hipLaunchKernelGGL(k_calc_state, dim3(N), dim3(64), 0, s, h->dev_model, h->state, op, 0, N, member);
+    h->sort_par ^= 1; h->sort_G = 1; h->gb = gb;
   } else {
     OutPtrs op = to_ptrs(out);
     hipEvent_t* ev = h->pool ? h->pool + (size_t)h->pool_next * EV_PER_STEP : nullptr;
@@ -520,7 +543,8 @@ int rp_set_state(rp_handle h, const void* src, int32_t src_env_count, void* stre
 int rp_set_debug_flags(rp_handle h, int32_t flags) { if (!h) return RP_ERR_ARG; h->debug_flags = flags & 1; return RP_OK; }   /* bit 1 is internal (k_action_prep) */
 int rp_set_groups(rp_handle h, int32_t groups) { if (!h || groups < 1 || groups > RP_MAX_GROUPS) return RP_ERR_ARG; h->groups = groups; return RP_OK; }
 int rp_set_fused(rp_handle h, int32_t fused) {
-  if (!h || (fused != 0 && fused != 1)) return RP_ERR_ARG;
+  if (!h || fused < 0 || fused > 2) return RP_ERR_ARG;
+  if (fused != h->fused) h->sort_G = 0;          /* the load tables of one pipeline mean nothing to the other: start from the identity ranking */
   h->fused = fused;
   return RP_OK;
 }
@@ -669,6 +693,14 @@ int rp_debug_row_counts(rp_handle h, int32_t* host_buf) {
   return RP_OK;
 }
 
+#ifdef RP_CHAIN_CLOCKS
+int rp_debug_chain_clocks(rp_handle h, int64_t* host_buf, int32_t nblocks) {
+  if (!h || !host_buf || nblocks > 4096) return RP_ERR_ARG;
+  HIPCHK(h, hipDeviceSynchronize());
+  HIPCHK(h, hipMemcpyFromSymbol(host_buf, HIP_SYMBOL(g_chain_clk), (size_t)nblocks * 4 * sizeof(int64_t)));
+  return RP_OK;
+}
+#endif
 #ifdef RP_CLOCKS
 #if RP_CLOCKS == 2
 #define RP_CLK_STRIDE 32
