@@ -123,6 +123,8 @@ def load(f32=False, bullet_ref=False):
     lib.rpo_box_box.argtypes = [dp, dp, dp, dp, dp, dp, C.c_double, dp]
     lib.rpo_collider_poses.argtypes = [vp, dp]
     lib.rpo_collider_table.argtypes = [vp, dp]
+    lib.rpo_pair_table.argtypes = [vp, C.POINTER(C.c_int)]
+    lib.rpo_pair_table.restype = C.c_int
     lib.rpo_bench_rollout.argtypes = [C.c_int, C.c_ulonglong, C.c_int, C.c_int, C.c_int, dp, C.c_int, C.c_double]
     lib.rpo_bench_rollout.restype = C.c_double
     lib.rpo_rng_uniform.argtypes = [C.c_ulonglong, C.c_uint, C.c_uint]
@@ -386,6 +388,12 @@ class OracleEnv:
         t = np.zeros((self.n_arm, 6))
         self.lib.rpo_arm_table(self.h, t.ctypes.data_as(C.POINTER(C.c_double)))
         return t
+
+    def pair_list(self):
+        """the baked candidate pairs (collider a, collider b) the broadphase sweeps"""
+        buf = (C.c_int * 4096)()
+        n = self.lib.rpo_pair_table(self.h, buf)
+        return [(buf[2 * i], buf[2 * i + 1]) for i in range(n)]
 
     def collider_list(self):
         """every collider at the current state: dict(type, he [3], R [3, 3], p [3], body, friction, mass, stiffness, damping, threshold, link)"""

@@ -2496,6 +2496,11 @@ int rpo_collider_table(const rpo_env* e, double* out) {
 }
 
 /* the baked tables as the oracle holds them (tests/test_bake_independent.py walks them against an independent reading of the reference's files) */
+/* the baked candidate pairs (what the broadphase sweeps): out[2 i], out[2 i + 1] = the two collider indices of pair i; returns their number */
+int rpo_pair_table(const rpo_env* e, int* out) {
+  for (int i = 0; i < e->m.n_pair; i++) { out[2 * i] = e->m.pair[i][0]; out[2 * i + 1] = e->m.pair[i][1]; }
+  return e->m.n_pair;
+}
 int rpo_arm_table(const rpo_env* e, double* out) {       /* per dof: jtype, lower, upper, body mass, Bullet joint index, parent dof */
   const rp_model* m = &e->m;
   for (int i = 0; i < m->n_arm; i++) {

@@ -42,6 +42,7 @@ void rpo_set_action_type(rpo_env* e, int action_type);
  * 128: torsional friction rows of links with spinning_friction */
 void rpo_set_rule(rpo_env* e, int rule);
 int rpo_get_rule(const rpo_env* e);
+int rpo_pair_table(const rpo_env* e, int* out);      /* the baked candidate pairs: (a, b) collider indices; returns their number */
 void rpo_set_margin(rpo_env* e, double margin);                     /* one contact margin for all pairs, metres (default: per pair, rp_model.col_thr) */
 void rpo_set_reward_cfg(rpo_env* e, double sparse_rew_thresh, int dense);   /* environments.py:66, 169-170 */
 int rpo_action_dim(const rpo_env* e);

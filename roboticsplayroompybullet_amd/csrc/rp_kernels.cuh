@@ -569,9 +569,11 @@ struct GjkSimplex {
     w2 = p2; b2 = q2; l2 = r2;
     n = __popc(keep);
   }
-  __device__ __forceinline__ V3 closest() const { V3 q = w0 * l0; if (n > 1) q = q + w1 * l1; if (n > 2) q = q + w2 * l2; return q; }
+  __device__ __forceinline__ V3 closest() const {
+    V3 q = w0 * l0; if (n > 1) q = q + w1 * l1; if (n > 2) q = q + w2 * l2; return q; }
   static __device__ __forceinline__ V3 corner(int code, V3 h) { return mk3((code & 1) ? h.x : -h.x, (code & 2) ? h.y : -h.y, (code & 4) ? h.z : -h.z); }
-  __device__ __forceinline__ V3 witness(V3 h) const { V3 q = corner(b0, h) * l0; if (n > 1) q = q + corner(b1, h) * l1; if (n > 2) q = q + corner(b2, h) * l2; return q; }
+  __device__ __forceinline__ V3 witness(V3 h) const {
+    V3 q = corner(b0, h) * l0; if (n > 1) q = q + corner(b1, h) * l1; if (n > 2) q = q + corner(b2, h) * l2; return q; }
 };
 __device__ __forceinline__ int gjk_fi(int f, int k, int p0, int p1, int p2, int p3) {
   const int idx = k == 0 ? (f == 3 ? 1 : 0) : (k == 1 ? (f == 0 ? 1 : (f == 1 ? 2 : 3)) : (f == 0 ? 2 : (f == 1 ? 3 : (f == 2 ? 1 : 2))));
@@ -760,10 +762,10 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
         /* the probe direction: cores farther apart than the margin and the two shape margins along it - what GJK's distance phase would end with (oracle
          * hull_box_gjk: "apart").  Only with GJK on: without it such a pair goes to the OBB path, which finds the OBBs apart all the same */
         const bool probe_apart = m->gjk && pmin > mg + 2.f * RP_HULL_MARGIN + 1e-6f;
-        PCLK_ADD(15, 1 + ((d > mg || probe_apart) ? 65536 : 0) + ((probe_apart && !(d > mg)) ? (1ull << 32) : 0ull))               /* (profiling build: hull pairs scanned | of them apart << 16) */
+        PCLK_ADD(15, 1 + ((d > mg) ? 65536 : 0) + ((probe_apart && !(d > mg)) ? (1ull << 32) : 0ull))               /* (profiling build: hull pairs scanned | of them apart << 16) */
         int out = 0;                                         /* this pair's hf */
         V3 nloc = mk3(0, 0, 0), ploc = mk3(0, 0, 0); float dcon = 0.f;      /* the contact in the BOX's frame: normal (box toward hull), point on the box's surface, distance */
-        if (!(d > mg) && !probe_apart) {                     /* (wave-uniform) */
+        if (!(d > mg)) {                                     /* (wave-uniform) */
           /* the first vertex (lowest index: the oracle's sequential scan keeps the first strict extreme) whose coordinate along that axis IS the extreme -
            * the same instruction sequence gives the same bits */
           const int k = bf >> 1;
@@ -784,6 +786,9 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
               nloc = mk3(k == 0 ? sg : 0.f, k == 1 ? sg : 0.f, k == 2 ? sg : 0.f);
               ploc = lv - nloc * best;                       /* on the box face under the vertex */
               dcon = d;
+            } else if (probe_apart) {
+              out = 0;                                       /* (only here: a vertex OVER the face within the margin is a contact whatever the probe says - it can be a
+                                                              * millimetre beside the box CORE's face and read 'apart' by a fraction of the shape margin) */
             } else if (m->gjk) {
               /* the deepest vertex lies BESIDE the face (box edges and corners): GJK's distance phase, cores with the 0.001 margin around each (oracle hull_box_gjk;
                * -1 again = the cores touch or overlap: the OBB path keeps that case).  Box frame, the simplex in registers, seeded with lv against the corner(s)

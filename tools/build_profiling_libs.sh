@@ -3,7 +3,7 @@
 # RP_PLAYROOM_LIB.  Built here (hipcc cross-compiles), they travel to the GPU box with the snapshot.
 set -e
 cd "$(dirname "$0")/../roboticsplayroompybullet_amd/csrc"
-FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-fast-math -ffp-contract=on -fno-slp-vectorize"
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-fast-math -ffp-contract=off -fno-slp-vectorize"
 /opt/rocm/bin/hipcc $FLAGS -DRP_BUILD_ID=\"clocks1\" -DRP_CLOCKS=1 -shared -o ../../tools/clocks1.so rp_playroom.hip 2>/dev/null &
 /opt/rocm/bin/hipcc $FLAGS -DRP_BUILD_ID=\"clocks2\" -DRP_CLOCKS=2 -shared -o ../../tools/clocks2.so rp_playroom.hip 2>/dev/null &
 wait
