@@ -519,64 +519,63 @@ static int hull_face(const rpo_env* e, int a, int b, real margin, cpoint* out, r
  * btVoronoiSimplexSolver restated; the HIP library runs the same iteration, its support queries as whole-wave vertex scans).  Both shapes as the reference
  * step sees them: cores - the hull's vertices; the box's half extents less the 0.001 margin, never below 0 - with that margin around each.  A simplex of
  * Minkowski-difference points w = a - b (support points kept for the witnesses) is grown towards the origin; closest-point sub-cases after Ericson. */
-#if defined(RP_FLOAT)
-#define GJK_DUP ((real)1e-12)
-#define GJK_REL ((real)1e-6)
-#define GJK_ZERO ((real)1e-12)
-#define GJK_STALL ((real)(1 - 1e-6))
-#else
-#define GJK_DUP ((real)1e-24)
-#define GJK_REL ((real)1e-12)
-#define GJK_ZERO ((real)1e-20)
-#define GJK_STALL ((real)(1 - 1e-14))
-#endif
-typedef struct { real w[3], a[3], b[3]; } gjk_sv;
-static void gjk_closest(gjk_sv* s, int* n, real* lam) {      /* closest point of the simplex to the origin; the simplex shrinks to the supporting sub-simplex */
+#define GJK_DUP 1e-24
+#define GJK_REL 1e-12
+#define GJK_ZERO 1e-20
+#define GJK_STALL (1 - 1e-14)
+/* The simplex arithmetic runs in DOUBLE in every build (the fp32 build and the HIP library too): the sub-case determinants of a sliver simplex - three vertices of a finely
+ * tessellated link a few millimetres from the origin - cancel to 1e-3 relative in fp32, and the witness points of nearly parallel features move by centimetres with them. */
+typedef double greal;
+typedef struct { greal w[3], a[3], b[3]; } gjk_sv;
+static greal g3dot(const greal* a, const greal* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static void g3sub(greal* o, const greal* a, const greal* b) { o[0] = a[0] - b[0]; o[1] = a[1] - b[1]; o[2] = a[2] - b[2]; }
+static void g3cross(greal* o, const greal* a, const greal* b) { o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0]; }
+static void gjk_closest(gjk_sv* s, int* n, greal* lam) {      /* closest point of the simplex to the origin; the simplex shrinks to the supporting sub-simplex */
   if (*n == 1) { lam[0] = 1; return; }
   if (*n == 2) {
-    real ab[3]; v3sub(ab, s[1].w, s[0].w);
-    const real t = -v3dot(s[0].w, ab), den = v3dot(ab, ab);
+    greal ab[3]; g3sub(ab, s[1].w, s[0].w);
+    const greal t = -g3dot(s[0].w, ab), den = g3dot(ab, ab);
     if (t <= 0 || den <= 0) { *n = 1; lam[0] = 1; return; }
     if (t >= den) { s[0] = s[1]; *n = 1; lam[0] = 1; return; }
     lam[1] = t / den; lam[0] = 1 - lam[1];
     return;
   }
   if (*n == 3) {
-    const real *a = s[0].w, *b = s[1].w, *c = s[2].w;
-    real ab[3], ac[3];
-    v3sub(ab, b, a); v3sub(ac, c, a);
-    const real d1 = -v3dot(ab, a), d2 = -v3dot(ac, a);
+    const greal *a = s[0].w, *b = s[1].w, *c = s[2].w;
+    greal ab[3], ac[3];
+    g3sub(ab, b, a); g3sub(ac, c, a);
+    const greal d1 = -g3dot(ab, a), d2 = -g3dot(ac, a);
     if (d1 <= 0 && d2 <= 0) { *n = 1; lam[0] = 1; return; }
-    const real d3 = -v3dot(ab, b), d4 = -v3dot(ac, b);
+    const greal d3 = -g3dot(ab, b), d4 = -g3dot(ac, b);
     if (d3 >= 0 && d4 <= d3) { s[0] = s[1]; *n = 1; lam[0] = 1; return; }
-    const real vc = d1 * d4 - d3 * d2;
-    if (vc <= 0 && d1 >= 0 && d3 <= 0) { const real v = d1 / (d1 - d3); *n = 2; lam[0] = 1 - v; lam[1] = v; return; }
-    const real d5 = -v3dot(ab, c), d6 = -v3dot(ac, c);
+    const greal vc = d1 * d4 - d3 * d2;
+    if (vc <= 0 && d1 >= 0 && d3 <= 0) { const greal v = d1 / (d1 - d3); *n = 2; lam[0] = 1 - v; lam[1] = v; return; }
+    const greal d5 = -g3dot(ab, c), d6 = -g3dot(ac, c);
     if (d6 >= 0 && d5 <= d6) { s[0] = s[2]; *n = 1; lam[0] = 1; return; }
-    const real vb = d5 * d2 - d1 * d6;
-    if (vb <= 0 && d2 >= 0 && d6 <= 0) { const real w = d2 / (d2 - d6); s[1] = s[2]; *n = 2; lam[0] = 1 - w; lam[1] = w; return; }
-    const real va = d3 * d6 - d5 * d4;
-    if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) { const real w = (d4 - d3) / ((d4 - d3) + (d5 - d6)); s[0] = s[1]; s[1] = s[2]; *n = 2; lam[0] = 1 - w; lam[1] = w; return; }
-    const real den = 1 / (va + vb + vc);
+    const greal vb = d5 * d2 - d1 * d6;
+    if (vb <= 0 && d2 >= 0 && d6 <= 0) { const greal w = d2 / (d2 - d6); s[1] = s[2]; *n = 2; lam[0] = 1 - w; lam[1] = w; return; }
+    const greal va = d3 * d6 - d5 * d4;
+    if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) { const greal w = (d4 - d3) / ((d4 - d3) + (d5 - d6)); s[0] = s[1]; s[1] = s[2]; *n = 2; lam[0] = 1 - w; lam[1] = w; return; }
+    const greal den = 1 / (va + vb + vc);
     lam[1] = vb * den; lam[2] = vc * den; lam[0] = 1 - lam[1] - lam[2];
     return;
   }
   /* tetrahedron: the closest of the faces the origin lies outside of; inside all of them: the cores overlap */
   static const int F[4][3] = {{0, 1, 2}, {0, 2, 3}, {0, 3, 1}, {1, 3, 2}};
   static const int OPP[4] = {3, 1, 2, 0};
-  real best = (real)1e30; int bn = 0; gjk_sv bs[3]; real bl[3] = {0, 0, 0};
+  greal best = 1e30; int bn = 0; gjk_sv bs[3]; greal bl[3] = {0, 0, 0};
   for (int f = 0; f < 4; f++) {
-    const real *a = s[F[f][0]].w, *b = s[F[f][1]].w, *c = s[F[f][2]].w, *d = s[OPP[f]].w;
-    real ab[3], ac[3], nrm[3], ad[3];
-    v3sub(ab, b, a); v3sub(ac, c, a); v3cross(nrm, ab, ac); v3sub(ad, d, a);
-    const real so = -v3dot(a, nrm), sd = v3dot(ad, nrm);
+    const greal *a = s[F[f][0]].w, *b = s[F[f][1]].w, *c = s[F[f][2]].w, *d = s[OPP[f]].w;
+    greal ab[3], ac[3], nrm[3], ad[3];
+    g3sub(ab, b, a); g3sub(ac, c, a); g3cross(nrm, ab, ac); g3sub(ad, d, a);
+    const greal so = -g3dot(a, nrm), sd = g3dot(ad, nrm);
     if (so * sd > 0) continue;
     if (sd == 0 && so == 0) continue;
-    gjk_sv t[3] = {s[F[f][0]], s[F[f][1]], s[F[f][2]]}; int tn = 3; real tl[3];
+    gjk_sv t[3] = {s[F[f][0]], s[F[f][1]], s[F[f][2]]}; int tn = 3; greal tl[3];
     gjk_closest(t, &tn, tl);
-    real q[3] = {0, 0, 0};
-    for (int i = 0; i < tn; i++) v3axpy(q, tl[i], t[i].w);
-    const real dd = v3dot(q, q);
+    greal q[3] = {0, 0, 0};
+    for (int i = 0; i < tn; i++) for (int k = 0; k < 3; k++) q[k] += tl[i] * t[i].w[k];
+    const greal dd = g3dot(q, q);
     if (dd < best) { best = dd; bn = tn; for (int i = 0; i < tn; i++) { bs[i] = t[i]; bl[i] = tl[i]; } }
   }
   if (bn == 0) { *n = 4; return; }
@@ -610,7 +609,7 @@ static int hull_box_gjk(const rpo_env* e, int hc, int bc, real margin, const rea
     c[k] = v3dot(bk, t);
   }
   g_gjk_stats[0]++;
-  gjk_sv s[4]; int n = 0; real lam[4] = {0, 0, 0, 0};
+  gjk_sv s[4]; int n = 0; greal lam[4] = {0, 0, 0, 0};
   memset(s, 0, sizeof(s));
   /* the seed: lv against the nearest feature of the box core */
   int nout = 0, fk = -1;
@@ -626,17 +625,17 @@ static int hull_box_gjk(const rpo_env* e, int hc, int bc, real margin, const rea
     n++;
   }
   if (n == 2) g_gjk_stats[2]++;
-  real v[3] = {0, 0, 0};
+  greal v[3] = {0, 0, 0};
   gjk_closest(s, &n, lam);
-  for (int i = 0; i < n; i++) v3axpy(v, lam[i], s[i].w);
-  real dd = v3dot(v, v);
+  for (int i = 0; i < n; i++) for (int k = 0; k < 3; k++) v[k] += lam[i] * s[i].w[k];
+  greal dd = g3dot(v, v);
   if (dd < GJK_ZERO) { g_gjk_stats[5]++; return -1; }
   for (int it = 0; it < 32; it++) {
     gjk_sv sv;
     g_gjk_stats[1]++;
     {                                                        /* hull: the vertex of largest projection on -v (first of equals), v and the result in box coordinates */
       real dl[3];
-      for (int j = 0; j < 3; j++) dl[j] = -(v[0] * u[0][j] + v[1] * u[1][j] + v[2] * u[2][j]);
+      for (int j = 0; j < 3; j++) dl[j] = -((real)v[0] * u[0][j] + (real)v[1] * u[1][j] + (real)v[2] * u[2][j]);
       int bi = 0; real bd = (real)-1e30;
       for (int i = 0; i < nvert; i++) {
         const real d = (real)hv[i][0] * dl[0] + (real)hv[i][1] * dl[1] + (real)hv[i][2] * dl[2];
@@ -646,31 +645,32 @@ static int hull_box_gjk(const rpo_env* e, int hc, int bc, real margin, const rea
       for (int k = 0; k < 3; k++) sv.a[k] = (u[k][0] * q[0] + u[k][1] * q[1] + u[k][2] * q[2]) - c[k];
     }
     for (int k = 0; k < 3; k++) sv.b[k] = v[k] >= 0 ? hb[k] : -hb[k];      /* box core: the corner of largest projection on v */
-    v3sub(sv.w, sv.a, sv.b);
-    const real vv = v3dot(v, v), vw = v3dot(v, sv.w);
+    g3sub(sv.w, sv.a, sv.b);
+    const greal vv = g3dot(v, v), vw = g3dot(v, sv.w);
     int dup = 0;
-    for (int i = 0; i < n; i++) { real d[3]; v3sub(d, s[i].w, sv.w); if (v3dot(d, d) < GJK_DUP) dup = 1; }
+    for (int i = 0; i < n; i++) { greal d[3]; g3sub(d, s[i].w, sv.w); if (g3dot(d, d) < GJK_DUP) dup = 1; }
     /* v . w / |v| is a lower bound of the distance between the cores: beyond the pair's margin (and the two shape margins) the answer is "apart" whatever the
      * iteration would still find */
-    { const real far = margin + 2 * HULL_MARGIN; if (vw > 0 && vw * vw > far * far * vv) { g_gjk_stats[4]++; g_gjk_stats[7] += it + 1; return 0; } }
+    { const greal far = margin + 2 * HULL_MARGIN; if (vw > 0 && vw * vw > far * far * vv) { g_gjk_stats[4]++; g_gjk_stats[7] += it + 1; return 0; } }
     if (dup || vv - vw <= GJK_REL * vv) break;
     s[n++] = sv;
     if (n == 4) g_gjk_stats[6]++;
     gjk_closest(s, &n, lam);
     if (n == 4) { g_gjk_stats[5]++; return -1; }
-    real q[3] = {0, 0, 0};
-    for (int i = 0; i < n; i++) v3axpy(q, lam[i], s[i].w);
-    const real nd = v3dot(q, q);
-    v3cpy(v, q);
+    greal q[3] = {0, 0, 0};
+    for (int i = 0; i < n; i++) for (int k = 0; k < 3; k++) q[k] += lam[i] * s[i].w[k];
+    const greal nd = g3dot(q, q);
+    for (int k = 0; k < 3; k++) v[k] = q[k];
     if (nd < GJK_ZERO) { g_gjk_stats[5]++; return -1; }
     if (nd >= dd * GJK_STALL) { dd = nd; break; }
     dd = nd;
   }
-  real pl[3] = {0, 0, 0};
-  for (int i = 0; i < n; i++) v3axpy(pl, lam[i], s[i].b);
-  const real dist = R_SQRT(v3dot(v, v));
-  if (!(dist > GJK_ZERO)) { g_gjk_stats[5]++; return -1; }
-  real nl[3]; v3scale(nl, v, 1 / dist);
+  greal pg[3] = {0, 0, 0};
+  for (int i = 0; i < n; i++) for (int k = 0; k < 3; k++) pg[k] += lam[i] * s[i].b[k];
+  const greal distg = sqrt(g3dot(v, v));
+  if (!(distg > GJK_ZERO)) { g_gjk_stats[5]++; return -1; }
+  const real dist = (real)distg;
+  real nl[3] = {(real)(v[0] / distg), (real)(v[1] / distg), (real)(v[2] / distg)}, pl[3] = {(real)pg[0], (real)pg[1], (real)pg[2]};
   const real d = dist - 2 * HULL_MARGIN;                     /* both margins */
   if (d > margin) { g_gjk_stats[4]++; return 0; }
   g_gjk_stats[3]++;

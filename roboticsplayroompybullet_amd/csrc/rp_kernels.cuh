@@ -494,10 +494,10 @@ __device__ __forceinline__ float hull_coord(V3 u, float4 v, float c) { return __
 /* ---- GJK distance between an arm link's hull and a box (oracle hull_box_gjk, RPO_RULE_GJK): the simplex lives in the pair's narrowphase scratch
  * (point k: w, a, b = 9 floats at S + 9 k), every lane runs the same closest-point arithmetic on it (LDS broadcasts; all lanes store the same values), the
  * support queries are the whole-wave vertex scans of the hull contact above. */
-#define GJK_DUP 1e-12f
-#define GJK_REL 1e-6f
-#define GJK_ZERO 1e-12f
-#define GJK_STALL (1.f - 1e-6f)
+#define GJK_DUP 1e-24
+#define GJK_REL 1e-12
+#define GJK_ZERO 1e-20
+#define GJK_STALL (1.0 - 1e-14)
 /* One pass of the wave over a link's hull vertices (lane, lane + 64, ...; per lane in rising order), HULL_UNROLL loads in flight at a time.  Measured with
  * 2 / 4 / 8: nothing (the table sits in L2, the links near the scene have some two hundred vertices - three rounds) and the registers do not exist: 1 */
 template <int HULL_UNROLL, class F>
@@ -526,89 +526,113 @@ __device__ __forceinline__ int wave_min_i(int v) {
   v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true));
   return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
-/* closest point of the triangle a b c to the origin (Ericson's sub-cases in the oracle's order, gjk_closest), without branches: which vertices support it
- * (bit k = vertex k stays) and their weights */
-struct GjkTri { int keep; float l0, l1, l2; };
-__device__ __forceinline__ GjkTri gjk_tri(V3 a, V3 b, V3 c) {
-  const V3 ab = b - a, ac = c - a;
-  const float d1 = -dot(ab, a), d2 = -dot(ac, a), d3 = -dot(ab, b), d4 = -dot(ac, b), d5 = -dot(ab, c), d6 = -dot(ac, c);
-  const float vc = d1 * d4 - d3 * d2, vb = d5 * d2 - d1 * d6, va = d3 * d6 - d5 * d4;
-  /* (v_rcp_f32, 1 ulp: four IEEE divisions are fifty instructions of this serial code, and the weights feed a distance that is compared at 1e-6 relative) */
-  const float tab = d1 * __builtin_amdgcn_rcpf(d1 - d3), tac = d2 * __builtin_amdgcn_rcpf(d2 - d6), tbc = (d4 - d3) * __builtin_amdgcn_rcpf((d4 - d3) + (d5 - d6)), den = __builtin_amdgcn_rcpf(va + vb + vc);
-  GjkTri r;
-  r.keep = 7; r.l1 = vb * den; r.l2 = vc * den; r.l0 = 1.f - r.l1 - r.l2;
-  if (va <= 0.f && (d4 - d3) >= 0.f && (d5 - d6) >= 0.f) { r.keep = 6; r.l0 = 0.f; r.l1 = 1.f - tbc; r.l2 = tbc; }
-  if (vb <= 0.f && d2 >= 0.f && d6 <= 0.f) { r.keep = 5; r.l0 = 1.f - tac; r.l1 = 0.f; r.l2 = tac; }
-  if (d6 >= 0.f && d5 <= d6) { r.keep = 4; r.l0 = 0.f; r.l1 = 0.f; r.l2 = 1.f; }
-  if (vc <= 0.f && d1 >= 0.f && d3 <= 0.f) { r.keep = 3; r.l0 = 1.f - tab; r.l1 = tab; r.l2 = 0.f; }
-  if (d3 >= 0.f && d4 <= d3) { r.keep = 2; r.l0 = 0.f; r.l1 = 1.f; r.l2 = 0.f; }
-  if (d1 <= 0.f && d2 <= 0.f) { r.keep = 1; r.l0 = 1.f; r.l1 = 0.f; r.l2 = 0.f; }      /* (the first test of the sequence wins: applied last) */
+/* ---- the simplex arithmetic of the GJK below, in DOUBLE (as in every build of the oracle): the sub-case determinants of a sliver simplex - three vertices of a finely
+ * tessellated link, a few millimetres from the origin - cancel to 1e-3 relative in fp32, and the witness points of nearly parallel features then move by centimetres
+ * (measured on the CPU: fp32 against fp64 oracle, 15 of 360 poses with another contact; with this arithmetic in double: 1). */
+struct D3 { double x, y, z; };
+__device__ __forceinline__ D3 mkd(double x, double y, double z) { D3 r = {x, y, z}; return r; }
+__device__ __forceinline__ D3 operator-(D3 a, D3 b) { return mkd(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ double ddot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ D3 dcross(D3 a, D3 b) { return mkd(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+__device__ __forceinline__ D3 dsel(bool c, D3 a, D3 b) { return mkd(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }
+/* 1 / x: v_rcp_f64 and two Newton steps (full double precision; an IEEE division is a twenty-instruction sequence, four of them per triangle) */
+__device__ __forceinline__ double drcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
   return r;
 }
-__device__ __forceinline__ GjkTri gjk_seg(V3 a, V3 b) {
-  const V3 ab = b - a;
-  const float t = -dot(a, ab), den = dot(ab, ab);
-  GjkTri r; r.l2 = 0.f;
-  r.keep = 3; r.l1 = t * __builtin_amdgcn_rcpf(den); r.l0 = 1.f - r.l1;
-  if (t >= den) { r.keep = 2; r.l0 = 0.f; r.l1 = 1.f; }
-  if (t <= 0.f || den <= 0.f) { r.keep = 1; r.l0 = 1.f; r.l1 = 0.f; }
+/* closest point of the triangle a b c to the origin (Ericson's sub-cases in the oracle's order, gjk_closest), without branches: which vertices support it
+ * (bit k = vertex k stays) and their weights */
+struct GjkTri { int keep; double l0, l1, l2; };
+__device__ __forceinline__ GjkTri gjk_tri(D3 a, D3 b, D3 c) {
+  const D3 ab = b - a, ac = c - a;
+  const double d1 = -ddot(ab, a), d2 = -ddot(ac, a), d3 = -ddot(ab, b), d4 = -ddot(ac, b), d5 = -ddot(ab, c), d6 = -ddot(ac, c);
+  const double vc = d1 * d4 - d3 * d2, vb = d5 * d2 - d1 * d6, va = d3 * d6 - d5 * d4;
+  const double tab = d1 * drcp(d1 - d3), tac = d2 * drcp(d2 - d6), tbc = (d4 - d3) * drcp((d4 - d3) + (d5 - d6)), den = drcp(va + vb + vc);
+  GjkTri r;
+  r.keep = 7; r.l1 = vb * den; r.l2 = vc * den; r.l0 = 1.0 - r.l1 - r.l2;
+  if (va <= 0.0 && (d4 - d3) >= 0.0 && (d5 - d6) >= 0.0) { r.keep = 6; r.l0 = 0.0; r.l1 = 1.0 - tbc; r.l2 = tbc; }
+  if (vb <= 0.0 && d2 >= 0.0 && d6 <= 0.0) { r.keep = 5; r.l0 = 1.0 - tac; r.l1 = 0.0; r.l2 = tac; }
+  if (d6 >= 0.0 && d5 <= d6) { r.keep = 4; r.l0 = 0.0; r.l1 = 0.0; r.l2 = 1.0; }
+  if (vc <= 0.0 && d1 >= 0.0 && d3 <= 0.0) { r.keep = 3; r.l0 = 1.0 - tab; r.l1 = tab; r.l2 = 0.0; }
+  if (d3 >= 0.0 && d4 <= d3) { r.keep = 2; r.l0 = 0.0; r.l1 = 1.0; r.l2 = 0.0; }
+  if (d1 <= 0.0 && d2 <= 0.0) { r.keep = 1; r.l0 = 1.0; r.l1 = 0.0; r.l2 = 0.0; }      /* (the first test of the sequence wins: applied last) */
+  return r;
+}
+__device__ __forceinline__ GjkTri gjk_seg(D3 a, D3 b) {
+  const D3 ab = b - a;
+  const double t = -ddot(a, ab), den = ddot(ab, ab);
+  GjkTri r; r.l2 = 0.0;
+  r.keep = 3; r.l1 = t * drcp(den); r.l0 = 1.0 - r.l1;
+  if (t >= den) { r.keep = 2; r.l0 = 0.0; r.l1 = 1.0; }
+  if (t <= 0.0 || den <= 0.0) { r.keep = 1; r.l0 = 1.0; r.l1 = 0.0; }
   return r;
 }
 __device__ __forceinline__ V3 sel3(bool c, V3 a, V3 b) { return mk3(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }
-/* The simplex of the GJK below: Minkowski-difference points w = (hull vertex) - (box-core corner) with the corner kept as the witness, all in the BOX's frame,
- * in registers (wave-uniform values).  reduce(): keeps the vertices of `keep` (a subsequence of p0 p1 p2, in that order) with their weights */
+/* The simplex of the GJK below: Minkowski-difference points w = (hull vertex) - (box-core corner) with the corner kept as the witness, all in the BOX's frame.  The
+ * points live in LDS (W: four points of three doubles in the pair's narrowphase scratch; every lane holds the same values and stores the same values), the corners
+ * (one sign bit per axis: bit k set = +hbc_k), the count and the weights in registers.  reduce(): keeps the vertices of `keep` (a subsequence of p0 p1 p2, in that
+ * order) with their weights */
 struct GjkSimplex {
-  V3 w0, w1, w2, w3; int b0, b1, b2, b3;       /* b: the box-core corner of the point, one sign bit per axis (bit k set = +hbc_k) */
-  int n; float l0, l1, l2;
+  double* W; int b0, b1, b2, b3; int n; double l0, l1, l2;
+  __device__ __forceinline__ D3 pt(int i) const { return mkd(W[3 * i], W[3 * i + 1], W[3 * i + 2]); }
+  __device__ __forceinline__ void put(int i, D3 p) { W[3 * i] = p.x; W[3 * i + 1] = p.y; W[3 * i + 2] = p.z; }
   /* (scalars by value: handed a GjkTri by reference, the compiler keeps it in private memory and turns the selects below into indexed loads) */
-  __device__ __forceinline__ void reduce(V3 p0, V3 p1, V3 p2, int q0, int q1, int q2, int keep, float r0, float r1, float r2) {
+  __device__ __forceinline__ void reduce(D3 p0, D3 p1, D3 p2, int q0, int q1, int q2, int keep, double r0, double r1, double r2) {
     const bool k0 = keep & 1, k1 = keep & 2;
-    const float t12 = k1 ? r1 : r2;
-    w0 = sel3(k0, p0, sel3(k1, p1, p2)); b0 = k0 ? q0 : (k1 ? q1 : q2); l0 = k0 ? r0 : t12;
-    w1 = sel3(k0 && k1, p1, p2); b1 = (k0 && k1) ? q1 : q2; l1 = (k0 && k1) ? r1 : r2;
-    w2 = p2; b2 = q2; l2 = r2;
+    const double t12 = k1 ? r1 : r2;
+    put(0, dsel(k0, p0, dsel(k1, p1, p2))); b0 = k0 ? q0 : (k1 ? q1 : q2); l0 = k0 ? r0 : t12;
+    put(1, dsel(k0 && k1, p1, p2)); b1 = (k0 && k1) ? q1 : q2; l1 = (k0 && k1) ? r1 : r2;
+    put(2, p2); b2 = q2; l2 = r2;
     n = __popc(keep);
   }
-  __device__ __forceinline__ V3 closest() const {
-    V3 q = w0 * l0; if (n > 1) q = q + w1 * l1; if (n > 2) q = q + w2 * l2; return q; }
+  __device__ __forceinline__ D3 closest() const {
+    D3 p = pt(0);
+    D3 q = mkd(p.x * l0, p.y * l0, p.z * l0);
+    if (n > 1) { p = pt(1); q = mkd(q.x + p.x * l1, q.y + p.y * l1, q.z + p.z * l1); }
+    if (n > 2) { p = pt(2); q = mkd(q.x + p.x * l2, q.y + p.y * l2, q.z + p.z * l2); }
+    return q;
+  }
   static __device__ __forceinline__ V3 corner(int code, V3 h) { return mk3((code & 1) ? h.x : -h.x, (code & 2) ? h.y : -h.y, (code & 4) ? h.z : -h.z); }
-  __device__ __forceinline__ V3 witness(V3 h) const {
-    V3 q = corner(b0, h) * l0; if (n > 1) q = q + corner(b1, h) * l1; if (n > 2) q = q + corner(b2, h) * l2; return q; }
+  __device__ __forceinline__ D3 witness(V3 h) const {
+    V3 c = corner(b0, h);
+    D3 q = mkd(c.x * l0, c.y * l0, c.z * l0);
+    if (n > 1) { c = corner(b1, h); q = mkd(q.x + c.x * l1, q.y + c.y * l1, q.z + c.z * l1); }
+    if (n > 2) { c = corner(b2, h); q = mkd(q.x + c.x * l2, q.y + c.y * l2, q.z + c.z * l2); }
+    return q;
+  }
 };
-__device__ __forceinline__ int gjk_fi(int f, int k, int p0, int p1, int p2, int p3) {
-  const int idx = k == 0 ? (f == 3 ? 1 : 0) : (k == 1 ? (f == 0 ? 1 : (f == 1 ? 2 : 3)) : (f == 0 ? 2 : (f == 1 ? 3 : (f == 2 ? 1 : 2))));
-  return idx == 0 ? p0 : (idx == 1 ? p1 : (idx == 2 ? p2 : p3));
-}
-/* face f of the tetrahedron (the oracle's F / OPP tables): vertex k of the face, k = 3: the vertex opposite */
-__device__ __forceinline__ V3 gjk_fv(int f, int k, V3 p0, V3 p1, V3 p2, V3 p3) {
-  /* F = {0,1,2},{0,2,3},{0,3,1},{1,3,2}; OPP = {3,1,2,0} */
-  const int idx = k == 0 ? (f == 3 ? 1 : 0) : (k == 1 ? (f == 0 ? 1 : (f == 1 ? 2 : 3)) : (k == 2 ? (f == 0 ? 2 : (f == 1 ? 3 : (f == 2 ? 1 : 2))) : (f == 0 ? 3 : (f == 1 ? 1 : (f == 2 ? 2 : 0)))));
-  return idx == 0 ? p0 : (idx == 1 ? p1 : (idx == 2 ? p2 : p3));
-}
 /* closest point of the simplex to the origin; the simplex shrinks to the supporting sub-simplex.  n = 4 afterwards: the origin lies inside the tetrahedron */
 __device__ __forceinline__ void gjk_closest(GjkSimplex& S, int lane) {
-  if (S.n == 1) { S.l0 = 1.f; return; }
-  if (S.n == 2) { const GjkTri r = gjk_seg(S.w0, S.w1); S.reduce(S.w0, S.w1, S.w1, S.b0, S.b1, S.b1, r.keep, r.l0, r.l1, r.l2); return; }
-  if (S.n == 3) { const GjkTri r = gjk_tri(S.w0, S.w1, S.w2); S.reduce(S.w0, S.w1, S.w2, S.b0, S.b1, S.b2, r.keep, r.l0, r.l1, r.l2); return; }
-  /* tetrahedron: the closest of the faces the origin lies outside of (one after the other: side by side in four lanes they cost the registers of four triangles
-   * at once, and this kernel has none to spare), then the winner once more */
-  float best = 1e30f; int bf = -1;
+  (void)lane;
+  if (S.n == 1) { S.l0 = 1.0; return; }
+  if (S.n == 2) { const D3 a = S.pt(0), b = S.pt(1); const GjkTri r = gjk_seg(a, b); WSYNC(); S.reduce(a, b, b, S.b0, S.b1, S.b1, r.keep, r.l0, r.l1, r.l2); WSYNC(); return; }
+  if (S.n == 3) { const D3 a = S.pt(0), b = S.pt(1), c = S.pt(2); const GjkTri r = gjk_tri(a, b, c); WSYNC(); S.reduce(a, b, c, S.b0, S.b1, S.b2, r.keep, r.l0, r.l1, r.l2); WSYNC(); return; }
+  /* tetrahedron: the closest of the faces the origin lies outside of (the oracle's F / OPP tables; one face after the other: side by side in four lanes they cost
+   * the registers of four triangles at once, and this kernel has none to spare), then the winner once more */
+  double best = 1e30; int bf = -1;
 #pragma unroll 1
   for (int f = 0; f < 4; f++) {
-    const V3 a = gjk_fv(f, 0, S.w0, S.w1, S.w2, S.w3), b = gjk_fv(f, 1, S.w0, S.w1, S.w2, S.w3), c = gjk_fv(f, 2, S.w0, S.w1, S.w2, S.w3);
-    float so, sd;
-    { const V3 d = gjk_fv(f, 3, S.w0, S.w1, S.w2, S.w3), nrm = cross(b - a, c - a); so = -dot(a, nrm); sd = dot(d - a, nrm); }
-    if (so * sd > 0.f || (sd == 0.f && so == 0.f)) continue;
+    const int i0 = f == 3 ? 1 : 0, i1 = f == 0 ? 1 : (f == 1 ? 2 : 3), i2 = f == 0 ? 2 : (f == 1 ? 3 : (f == 2 ? 1 : 2)), io = f == 0 ? 3 : (f == 1 ? 1 : (f == 2 ? 2 : 0));
+    const D3 a = S.pt(i0), b = S.pt(i1), c = S.pt(i2);
+    double so, sd;
+    { const D3 d = S.pt(io), nrm = dcross(b - a, c - a); so = -ddot(a, nrm); sd = ddot(d - a, nrm); }
+    if (so * sd > 0.0 || (sd == 0.0 && so == 0.0)) continue;
     const GjkTri r = gjk_tri(a, b, c);
-    const V3 q = a * r.l0 + b * r.l1 + c * r.l2;
-    const float dd = dot(q, q);
+    const D3 q = mkd(a.x * r.l0 + b.x * r.l1 + c.x * r.l2, a.y * r.l0 + b.y * r.l1 + c.y * r.l2, a.z * r.l0 + b.z * r.l1 + c.z * r.l2);
+    const double dd = ddot(q, q);
     if (dd < best) { best = dd; bf = f; }
   }
   if (bf < 0) return;
-  const V3 a = gjk_fv(bf, 0, S.w0, S.w1, S.w2, S.w3), b = gjk_fv(bf, 1, S.w0, S.w1, S.w2, S.w3), c = gjk_fv(bf, 2, S.w0, S.w1, S.w2, S.w3);
-  const int qa = gjk_fi(bf, 0, S.b0, S.b1, S.b2, S.b3), qb = gjk_fi(bf, 1, S.b0, S.b1, S.b2, S.b3), qc = gjk_fi(bf, 2, S.b0, S.b1, S.b2, S.b3);
+  const int i0 = bf == 3 ? 1 : 0, i1 = bf == 0 ? 1 : (bf == 1 ? 2 : 3), i2 = bf == 0 ? 2 : (bf == 1 ? 3 : (bf == 2 ? 1 : 2));
+  const D3 a = S.pt(i0), b = S.pt(i1), c = S.pt(i2);
+  auto code = [&](int i) { return i == 0 ? S.b0 : (i == 1 ? S.b1 : (i == 2 ? S.b2 : S.b3)); };
+  const int qa = code(i0), qb = code(i1), qc = code(i2);
   const GjkTri r = gjk_tri(a, b, c);
+  WSYNC();
   S.reduce(a, b, c, qa, qb, qc, r.keep, r.l0, r.l1, r.l2);
+  WSYNC();
 }
 
 template <class LDS>
@@ -794,40 +818,49 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
                * -1 again = the cores touch or overlap: the OBB path keeps that case).  Box frame, the simplex in registers, seeded with lv against the corner(s)
                * of the box core's nearest feature; support queries = whole-wave vertex scans */
               PCLK_ADD(27, 1) PCLK_ADD(28, -(long long)__builtin_readcyclecounter())
-              const V3 hbc = mk3(hc0.x - fminf(RP_HULL_MARGIN, hc0.x), hc0.y - fminf(RP_HULL_MARGIN, hc0.y), hc0.z - fminf(RP_HULL_MARGIN, hc0.z));
+              V3 hbc = mk3(hc0.x - fminf(RP_HULL_MARGIN, hc0.x), hc0.y - fminf(RP_HULL_MARGIN, hc0.y), hc0.z - fminf(RP_HULL_MARGIN, hc0.z));
               const bool ox = fabsf(lv.x) > hbc.x, oy = fabsf(lv.y) > hbc.y, oz = fabsf(lv.z) > hbc.z;
               const int nout = (ox ? 1 : 0) + (oy ? 1 : 0) + (oz ? 1 : 0);
+              /* (the simplex lives in the pair's scratch, and so does v while a scan runs and the scan's directions while the simplex is solved: the kernel has no registers for them) */
+              double* Z = (double*)&L.npscr[NPG_SCRATCH * (src >> 3) + 8];
+              float* Y = &L.npscr[NPG_SCRATCH * (src >> 3) + 8 + 2 * 15];
+              static_assert((NPG_SCRATCH * 4) % 8 == 0 && NPG_SCRATCH >= 8 + 2 * 15 + 15, "the simplex: twelve doubles and v behind the staged point, 8-byte aligned; fifteen floats behind them");
+#define GJK_PARK_DIRS() do { st3(Y, u0); st3(Y + 3, u1); st3(Y + 6, u2); st3(Y + 9, mk3(c0, c1, c2)); st3(Y + 12, hbc); asm volatile("" ::: "memory"); } while (0)
+#define GJK_FETCH_DIRS() do { asm volatile("" ::: "memory"); u0 = ld3(Y); u1 = ld3(Y + 3); u2 = ld3(Y + 6); { const V3 t_ = ld3(Y + 9); c0 = t_.x; c1 = t_.y; c2 = t_.z; } hbc = ld3(Y + 12); } while (0)
               GjkSimplex S;
-              S.w1 = S.w2 = S.w3 = mk3(0, 0, 0); S.b1 = S.b2 = S.b3 = 0; S.l0 = 1.f; S.l1 = S.l2 = 0.f;
+              S.W = Z; S.b1 = S.b2 = S.b3 = 0; S.l0 = 1.0; S.l1 = S.l2 = 0.0;
               const int near = (lv.x >= 0.f ? 1 : 0) | (lv.y >= 0.f ? 2 : 0) | (lv.z >= 0.f ? 4 : 0);
               S.b0 = near; S.n = 1;
+              auto diffd = [](V3 a, V3 b) { return mkd((double)a.x - (double)b.x, (double)a.y - (double)b.y, (double)a.z - (double)b.z); };      /* w = a - b, in double from the fp32 points */
               if (nout == 2) {                               /* the two ends of the nearest edge: along the one axis lv lies inside of */
                 const int fb = !ox ? 1 : (!oy ? 2 : 4);
                 S.b0 = near & ~fb; S.b1 = near | fb;
-                S.w1 = lv - GjkSimplex::corner(S.b1, hbc); S.n = 2;
+                S.put(1, diffd(lv, GjkSimplex::corner(S.b1, hbc))); S.n = 2;
               }
-              S.w0 = lv - GjkSimplex::corner(S.b0, hbc);
+              S.put(0, diffd(lv, GjkSimplex::corner(S.b0, hbc)));
+              WSYNC();
               bool fail = nout == 0;
               bool apart = false;
-              V3 v = mk3(0, 0, 0); float dd = 0.f;
+              D3 v = mkd(0, 0, 0); double dd = 0.0;
               if (!fail) {
+                GJK_PARK_DIRS();
                 gjk_closest(S, lane);
-                v = S.closest(); dd = dot(v, v);
+                GJK_FETCH_DIRS();
+                v = S.closest(); dd = ddot(v, v);
                 fail = dd < GJK_ZERO;
               }
-              const float far = mg + 2.f * RP_HULL_MARGIN;
+              const double far = (double)mg + 2.0 * (double)RP_HULL_MARGIN;
 #pragma unroll 1
               for (int it = 0; it < 32 && !fail; it++) {
                 PCLK_ADD(26, 1) PCLK_ADD(29, -(long long)__builtin_readcyclecounter())
                 V3 wa;
-                /* (the simplex waits in the pair's scratch while the scan runs: the kernel has no registers for both) */
-                float* Z = &L.npscr[NPG_SCRATCH * (src >> 3) + 8];
-                st3(Z, S.w0); st3(Z + 3, S.w1); st3(Z + 6, S.w2); st3(Z + 9, mk3(S.l0, S.l1, S.l2));
+                const V3 vf = mk3((float)v.x, (float)v.y, (float)v.z);
+                Z[12] = v.x; Z[13] = v.y; Z[14] = v.z;
                 asm volatile("" ::: "memory");
                 {                                            /* hull: the vertex of largest projection on -v (lowest index among equals) */
-                  const V3 dl = -(u0 * v.x + u1 * v.y + u2 * v.z);
+                  const V3 dl = -(u0 * vf.x + u1 * vf.y + u2 * vf.z);
                   float bd = -1e30f; int bi = 0x7fffffff; V3 bq = mk3(0, 0, 0);
-                  hull_scan<4>(tv, nn, lane, [&](const float4& q, int i) {      /* (four loads in flight: the simplex is parked, the registers are there) */
+                  hull_scan<4>(tv, nn, lane, [&](const float4& q, int i) {      /* (four loads in flight) */
                     const float dq = __fmaf_rn(dl.z, q.z, __fmaf_rn(dl.y, q.y, dl.x * q.x));
                     if (dq > bd) { bd = dq; bi = i; bq = mk3(q.x, q.y, q.z); }
                   });
@@ -837,42 +870,51 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
                   wa = mk3(hull_coord(u0, make_float4(q.x, q.y, q.z, 0.f), c0), hull_coord(u1, make_float4(q.x, q.y, q.z, 0.f), c1), hull_coord(u2, make_float4(q.x, q.y, q.z, 0.f), c2));
                 }
                 asm volatile("" ::: "memory");
-                S.w0 = ld3(Z); S.w1 = ld3(Z + 3); S.w2 = ld3(Z + 6); { const V3 t = ld3(Z + 9); S.l0 = t.x; S.l1 = t.y; S.l2 = t.z; }
+                v = mkd(Z[12], Z[13], Z[14]);
                 PCLK_ADD(29, __builtin_readcyclecounter()) PCLK_ADD(30, -(long long)__builtin_readcyclecounter())
-                const int wb = (v.x >= 0.f ? 1 : 0) | (v.y >= 0.f ? 2 : 0) | (v.z >= 0.f ? 4 : 0);      /* box core: the corner of largest projection on v */
-                const V3 w = wa - GjkSimplex::corner(wb, hbc);
-                const float vv = dot(v, v), vw = dot(v, w);
+                const int wb = (vf.x >= 0.f ? 1 : 0) | (vf.y >= 0.f ? 2 : 0) | (vf.z >= 0.f ? 4 : 0);      /* box core: the corner of largest projection on v */
+                const D3 w = diffd(wa, GjkSimplex::corner(wb, hbc));
+                const double vv = ddot(v, v), vw = ddot(v, w);
                 /* v . w / |v| is a lower bound of the distance: beyond the pair's margin and the two shape margins the pair is apart whatever the iteration would still find */
-                if (vw > 0.f && vw * vw > far * far * vv) { apart = true; PCLK_ADD(30, __builtin_readcyclecounter()) break; }
+                if (vw > 0.0 && vw * vw > far * far * vv) { apart = true; PCLK_ADD(30, __builtin_readcyclecounter()) break; }
                 bool dup = false;
-                { V3 dw = S.w0 - w; dup |= dot(dw, dw) < GJK_DUP;
-                  dw = S.w1 - w; dup |= S.n > 1 && dot(dw, dw) < GJK_DUP;
-                  dw = S.w2 - w; dup |= S.n > 2 && dot(dw, dw) < GJK_DUP; }
+                { D3 dw = S.pt(0) - w; dup |= ddot(dw, dw) < GJK_DUP;
+                  dw = S.pt(1) - w; dup |= S.n > 1 && ddot(dw, dw) < GJK_DUP;
+                  dw = S.pt(2) - w; dup |= S.n > 2 && ddot(dw, dw) < GJK_DUP; }
                 if (dup || vv - vw <= GJK_REL * vv) { PCLK_ADD(30, __builtin_readcyclecounter()) break; }
-                if (S.n == 1) { S.w1 = w; S.b1 = wb; } else if (S.n == 2) { S.w2 = w; S.b2 = wb; } else { S.w3 = w; S.b3 = wb; }
+                S.put(S.n, w);
+                if (S.n == 1) S.b1 = wb; else if (S.n == 2) S.b2 = wb; else S.b3 = wb;
                 S.n++;
+                WSYNC();
                 PCLK_ADD(30, __builtin_readcyclecounter()) PCLK_ADD(31, -(long long)__builtin_readcyclecounter())
+                GJK_PARK_DIRS();
                 gjk_closest(S, lane);
+                GJK_FETCH_DIRS();
                 PCLK_ADD(31, __builtin_readcyclecounter())
                 if (S.n == 4) { fail = true; break; }
                 v = S.closest();
-                const float nd = dot(v, v);
+                const double nd = ddot(v, v);
                 if (nd < GJK_ZERO) { fail = true; break; }
                 if (nd >= dd * GJK_STALL) { dd = nd; break; }
                 dd = nd;
               }
+#undef GJK_PARK_DIRS
+#undef GJK_FETCH_DIRS
               PCLK_ADD(28, __builtin_readcyclecounter())
-              const float dist = sqrtf(dot(v, v));
+              const double distd = sqrt(ddot(v, v));
               PCLK_ADD(27, apart ? (1ull << 16) : (fail ? (1ull << 48) : 0ull))
               if (apart) out = 0;
-              else if (!fail && dist > GJK_ZERO) {
+              else if (!fail && distd > GJK_ZERO) {
+                const float dist = (float)distd;
                 const float dg = dist - 2.f * RP_HULL_MARGIN;
                 if (dg > mg) { out = 0; PCLK_ADD(27, 1ull << 16) }
                 else {
                   out = 1;
                   PCLK_ADD(27, 1ull << 32)
-                  nloc = v * (1.f / dist);
-                  ploc = S.witness(hbc) + nloc * RP_HULL_MARGIN;
+                  const double inv = drcp(distd);
+                  nloc = mk3((float)(v.x * inv), (float)(v.y * inv), (float)(v.z * inv));
+                  const D3 wit = S.witness(hbc);
+                  ploc = mk3((float)wit.x, (float)wit.y, (float)wit.z) + nloc * RP_HULL_MARGIN;
                   dcon = dg;
                 }
               }

@@ -250,17 +250,20 @@ def test_split_pipeline_equals_fused_kernel_bitwise():
         a = VecPlayEnv(IDS[kind], n, seed=5)
         b = VecPlayEnv(IDS[kind], n, seed=5)
         b.set_fused(1)                          # one fused kernel per env step
+        c = VecPlayEnv(IDS[kind], n, seed=5)
+        c.set_fused(2)                          # round 4's experiment: the twelve substeps in one launch (k_chain), blocks own four envs
         a.set_groups(3)                         # env groups on separate streams must not change any result
-        a.reset(); b.reset()
+        a.reset(); b.reset(); c.reset()
         acts = torch.tensor(actions(kind, 6, n, 8), dtype=torch.float32)
         for t in range(6):
             oa, ra, _, ia = a.step(acts[t])
             ob, rb, _, ib = b.step(acts[t])
+            oc, rc, _, ic = c.step(acts[t])
         torch.cuda.synchronize()
-        assert torch.equal(a.get_state(), b.get_state())
+        assert torch.equal(a.get_state(), b.get_state()) and torch.equal(a.get_state(), c.get_state())
         for k in ('obs_quat', 'achieved_goal', 'observation', 'velocity'):
-            assert torch.equal(oa[k], ob[k]), k
-        assert torch.equal(ia['target_poses'], ib['target_poses'])
+            assert torch.equal(oa[k], ob[k]) and torch.equal(oa[k], oc[k]), k
+        assert torch.equal(ia['target_poses'], ib['target_poses']) and torch.equal(ia['target_poses'], ic['target_poses'])
 
 
 def test_reset_through_split_pipeline_equals_fused_reset_bitwise():
@@ -988,7 +991,7 @@ def test_error_codes_of_the_c_abi():
     assert env.lib.rp_reset_to(env.h, C.c_void_p(short.data_ptr()), 10, None, C.byref(env.out), env._stream()) == -1
     assert b'18' in env.lib.rp_last_error(env.h)
     with pytest.raises(RuntimeError):
-        env.set_fused(2)
+        env.set_fused(3)
 
 
 def test_create_destroy_does_not_leak():
