@@ -86,6 +86,12 @@ enum rp_config_flags {
   RP_CFG_HULL_GJK = 256,          /* (no field; the DEFAULT since 0.3, accepted for callers written against 0.2) an arm link whose deepest hull vertex lies BESIDE the
                                    * box face it approaches (box edges and corners) gets its contact from GJK's distance phase on hull and box (oracle
                                    * RPO_RULE_GJK): the reference loads mesh colliders (environments.py:397, 409-411) and Bullet runs GJK on their hulls */
+  RP_CFG_SPECULATIVE_LIMITS = 1024, /* (no field) round 2's joint-limit rows: a row exists from 0.1 rad (m) BEFORE the limit on and lets the joint close the gap within the
+                                   * substep (a contact-like speculative row, erp of the contacts).  Default (flag clear): Bullet's rule as recalled - a row only
+                                   * while the limit is violated, erp 0.2 (btMultiBodyJointLimitConstraint::createConstraintRows) - under which a gripper joint whose
+                                   * position motor is commanded past its limit (every "open" action, environments.py:1037-1073) chatters at the limit: 1.1 mm for a
+                                   * Robotiq pad = 0.026 in obs_quat's gripper entry.  The flag trades that sawtooth for 1e-2 of free-motion divergence from the
+                                   * reference step: an A / B switch for learners that see the gripper observation */
   RP_CFG_OBB_EDGES = 512          /* (no field) round 3's contacts for that case: the link's OBB against the box (SAT + face clipping) instead of GJK on the hull -
                                    * a few per cent faster, further from Bullet (the headline id's block position: 8 cm instead of 2 mm median divergence from the
                                    * reference step over 200 steps) */

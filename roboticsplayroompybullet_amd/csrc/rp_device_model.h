@@ -101,6 +101,7 @@ typedef struct DevModel {
   float ll[7], ul[7], inc[7];
   /* convex-hull vertices of the arm links' collision meshes (generated/rp_hullverts_gen.h): device pointer to the arm's table (x, y, z, 0 in the owning
    * body's frame), per collider the first vertex and the count (0 = no hull).  rp_create uploads the table and sets the pointer. */
+  int spec_limits;                /* RP_CFG_SPECULATIVE_LIMITS: round 2's joint-limit rows (oracle rule without RPO_RULE_LIMIT) */
   int gjk;                        /* GJK's distance phase where a hull's deepest vertex lies beside the box face (collide(); oracle RPO_RULE_GJK) */
   int persist;                    /* unless RP_CFG_STATELESS_CONTACTS: collide() keeps its manifolds in pmcache (rp_kernels.cuh PMC_*) */
   float* pmcache;                 /* [N][PMC_FLOATS], device memory owned by the handle */
@@ -209,7 +210,7 @@ static inline void rp_build_dev_model(const rp_model* m, DevModel* d) {
     d->n_obs = 13; d->n_ag = 3; d->n_fps = 7; d->n_observation = 12; d->n_target = 7;
   }
   d->n_target = isP ? 7 : 6;            /* numDofs (environments.py:361, 371) */
-  d->rew_thresh = 0.05f; d->dense_reward = 0; d->boxbox_margin = 0.f; d->persist = 0; d->pmcache = nullptr; d->gjk = 0;
+  d->rew_thresh = 0.05f; d->dense_reward = 0; d->boxbox_margin = 0.f; d->persist = 0; d->pmcache = nullptr; d->gjk = 0; d->spec_limits = 0;
   for (int c = 0; c < m->n_col; c++) { d->col_margin[c] = (float)m->col_thr[c]; d->col_stiff[c] = (float)m->col_stiffness[c]; d->col_damp[c] = (float)m->col_damping[c]; d->col_spin[c] = (float)m->col_spin[c];
     d->col_toggle[c] = m->col_toggle[c]; for (int k = 0; k < 3; k++) d->col_rgb[c][k] = (float)m->col_rgb[c][k]; }
   d->floor_z = 1e30f;

@@ -70,6 +70,7 @@ static_assert(MAXACT <= 64 && NB_MAX <= 32, "a candidate record packs its pair i
 #define K_DEFMOTOR 1.0f
 #define K_LIMIT_MAXIMP 100.0f
 #define K_ERP_LIMIT 0.2f      /* btContactSolverInfo::m_erp: what a violated joint limit pushes back with */
+#define K_LIMIT_ACTIVATION 0.1f   /* RP_CFG_SPECULATIVE_LIMITS (round 2's rule): a limit row exists from this distance before the limit on */
 #define K_LIN_DAMP 0.04f
 #define K_ANG_DAMP 0.04f
 #define K_IK_DAMP 0.1f
@@ -1724,14 +1725,15 @@ __device__ __forceinline__ int build_small_rows(const DevModel* m, LDS& L, int l
     if (lane < 2 * n && m->arm_limited[i]) {
       float q = L.st[ST_Q + i];
       pen = side == 0 ? q - m->arm_lower[i] : m->arm_upper[i] - q;
-      on = !(pen > 0.f);
+      on = m->spec_limits ? !(pen > K_LIMIT_ACTIVATION) : !(pen > 0.f);      /* default: only while the limit is violated (btMultiBodyJointLimitConstraint); RP_CFG_SPECULATIVE_LIMITS: round 2's speculative rows */
     }
     unsigned long long mask = __ballot(on);
     if (on) {
       int r = nr + __popcll(mask & ((1ull << lane) - 1ull));
       float sgn = side == 0 ? 1.f : -1.f;
       float dinv = 1.f / L.Minv[i * 12 + i];
-      float relv = sgn * L.vstar[i], pos_err = -pen * K_ERP_LIMIT / K_DT, vel_err = -relv;
+      float relv = sgn * L.vstar[i], pos_err = 0.f, vel_err = -relv;
+      if (pen > 0.f) vel_err -= pen / K_DT; else pos_err = -pen * (m->spec_limits ? K_ERP : K_ERP_LIMIT) / K_DT;      /* (pen > 0 only under the speculative rule: the row lets the joint close the gap within the substep) */
       put_srow(L, r, SR_LIMIT, i, sgn, (pos_err + vel_err) * dinv, dinv, 0.f, K_LIMIT_MAXIMP, 0);
     }
     nr += __popcll(mask);
@@ -3435,6 +3437,7 @@ __device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, floa
   {
 #pragma unroll
     for (int s = 0; s < MAXC; s++) {
+      if (s >= nS && MAXC - 1 - s >= nC) { JN[s] = BN[s] = JF[0][s] = BF[0][s] = JF[1][s] = BF[1][s] = 0.f; continue; }      /* (wave-uniform) neither env of the wave has a contact in this slot: no LDS gathers, no index arithmetic - a coupled env fills 8 - 10 of the 21 */
       const int c = contact_of(s);
       const bool used = c >= 0;
       /* this lane's entry in the contact's compact rows: the normal and both friction rows share the two body slots */
@@ -3787,6 +3790,9 @@ __device__ __forceinline__ void solve4_body(const DevModel* __restrict__ m, floa
     }
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);    /* vmcnt(0): all row registers have landed before the sweep loop */
+#if defined(RP_CLOCKS) && RP_CLOCKS != 2
+  if (lane == 0) g_clk[8 * (bq * SOLVE_WAVES + T) + 1] = wall_clock64();      /* (profiling build: the four-env wave's rows are loaded) */
+#endif
   /* counting sort by load class for the next substep's pairing: one atomic per env, from the row-1 wave */
   int sort_pos = 0, sort_bin = 0;
   if (T == 1 && l16 == 0 && valid && !(debug_flags & 4)) {

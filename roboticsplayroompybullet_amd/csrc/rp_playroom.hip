@@ -204,6 +204,7 @@ int rp_create(const rp_config* cfg, rp_handle* out) {
       d->persist = 1; d->pmcache = h->pmcache;
     }
     d->gjk = ((cfg->flags & RP_CFG_OBB_EDGES) || getenv("RP_NO_GJK") != nullptr) ? 0 : 1;      /* (oracle RPO_RULE_GJK: the default; RP_NO_GJK=1: the tools' switch to round 3's OBB edges) */
+    d->spec_limits = (cfg->flags & RP_CFG_SPECULATIVE_LIMITS) ? 1 : 0;
     if (getenv("RP_NO_SPIN") != nullptr)                     /* timing / model studies only: no torsional friction rows */
       for (int c = 0; c < RP_MAX_COL; c++) d->col_spin[c] = 0.f;
   }

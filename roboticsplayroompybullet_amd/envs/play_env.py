@@ -47,13 +47,13 @@ class playEnv:
                  goal_range_low=(-0.18, -0.18, -0.05), goal_range_high=(0.18, 0.18, 0.05), obj_lower_bound=(-0.18, -0.18, -0.05),
                  obj_upper_bound=(-0.18, -0.18, -0.05), sparse=True, use_orientation=False, sparse_rew_thresh=0.05,
                  fixed_gripper=False, return_velocity=True, max_episode_steps=250, play=False, action_type='absolute_rpy',
-                 show_goal=True, arm_type='Panda', device=0, seed=None, contact_margin=None, persistent_manifolds=True, hull_gjk=True):
+                 show_goal=True, arm_type='Panda', device=0, seed=None, contact_margin=None, persistent_manifolds=True, hull_gjk=True, speculative_limits=False):
         # seed=None: like the reference, which draws from the global np.random (environments.py:496, 530, 579), every new env gets
         # its own episode stream and np.random.seed(k) makes it repeatable
         if seed is None:
             seed = int(np.random.randint(0, 2 ** 31 - 1))
         self.sparse, self._contact_margin = bool(sparse), contact_margin
-        self._model_opts = dict(persistent_manifolds=bool(persistent_manifolds), hull_gjk=bool(hull_gjk))      # the library's contact-model switches (rp_config.flags)
+        self._model_opts = dict(persistent_manifolds=bool(persistent_manifolds), hull_gjk=bool(hull_gjk), speculative_limits=bool(speculative_limits))      # the library's contact-model switches (rp_config.flags)
         self.timeStep = 1.0 / 300
         self.render_scene = False
         self.physics_client_active = 0

@@ -28,7 +28,7 @@ WIDE_STATE_LAYOUT = {'q': (0, 9), 'qd': (9, 18), 'free0': (18, 31), 'free1': (31
 class VecPlayEnv:
     def __init__(self, env_id, num_envs, device=0, seed=0, env_offset=0, action_type=None, goal_range_low=None, goal_range_high=None,
                  obj_lower_bound=None, obj_upper_bound=None, env_range_high=None, sparse_rew_thresh=None, sparse=True,
-                 contact_margin=None, persistent_manifolds=True, hull_gjk=True):
+                 contact_margin=None, persistent_manifolds=True, hull_gjk=True, speculative_limits=False):
         """The keyword arguments after env_offset are the constructor kwargs of the reference's env classes that reach the
         simulation (envList.py -> environments.py:64-67); None keeps what the id registers.  contact_margin: rp_config."""
         if env_id not in _lib.ENV_KINDS:
@@ -70,6 +70,8 @@ class VecPlayEnv:
             cfg.contact_margin = float(contact_margin)
         if not persistent_manifolds:
             flags |= _lib.CFG_STATELESS_CONTACTS      # rp_config_flags: no contact cache, points rebuilt every substep (round 3's first model)
+        if speculative_limits:
+            flags |= _lib.CFG_SPECULATIVE_LIMITS      # round 2's joint-limit rows (oracle rule without bit 2): no gripper chatter, further from Bullet's limit rule
         if not hull_gjk:
             flags |= _lib.CFG_OBB_EDGES               # round 3's contacts where a link's deepest hull vertex lies beside the box face: its OBB instead of GJK on the hull (oracle rule 1015)
         cfg.flags = flags

@@ -174,6 +174,44 @@ def test_hull_gjk_option_vs_fp64_oracle(kind, gjk):
     assert np.median(d_hip) <= 1e-4
 
 
+@pytest.mark.parametrize('kind', ['U', 'P'])
+def test_speculative_limits_option_vs_fp64_oracle(kind):
+    """RP_CFG_SPECULATIVE_LIMITS (speculative_limits=True): round 2's joint-limit rows - a row from 0.1 before the limit on, contact erp - against the oracle without
+    RPO_RULE_LIMIT (rule 2039 & ~2).  The switch exists so that a learner can be trained with and without the gripper's limit chatter (tests/tolerances.py): under
+    this rule the gripper's joints rest AT their limits, so they are held to the arm's own tolerance here - no sawtooth allowance (environments.py:1037-1073: the
+    "open" commands that push them there)."""
+    from roboticsplayroompybullet_amd import VecPlayEnv
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    from gpu_debug import record_from_oracle
+    n, steps = 8, 60
+    env = VecPlayEnv(IDS[kind], n, seed=9, speculative_limits=True)
+    env.reset()
+    fol = [Followers(kind, 9, e, extra=2, rule=2039 & ~2) for e in range(n)]
+    for f in fol:
+        f.o64.reset()
+        f.start_from(f.o64)
+    env.set_state(torch.tensor(np.stack([record_from_oracle(f.o64) for f in fol])))
+    acts = actions(kind, steps, n, 5)
+    acts[..., -1] = -1.0                                      # "open": every gripper joint is commanded past its limit
+    n_arm, nm = fol[0].o64.n_arm, N_MAIN[kind]
+    d_arm, d_grip, g32 = np.zeros(n), np.zeros(n), np.zeros(n)
+    for t in range(steps):
+        obs, r, done, info = env.step(torch.tensor(acts[t], dtype=torch.float32))
+        assert int((info['status'] & 1).sum()) == 0
+        q = arm_q(env, kind)
+        for e, f in enumerate(fol):
+            f.step(acts[t, e].astype(np.float32).astype(np.float64))
+            qo = f.o64.get_state()[:n_arm]
+            rel = np.abs(q[e] - qo) / np.maximum(1.0, np.abs(qo))
+            d_arm[e] = max(d_arm[e], float(rel[:nm].max()))
+            d_grip[e] = max(d_grip[e], float(rel[nm:].max()))
+            g32[e] = max(g32[e], float((f.gap(lambda o: o.get_state()[:n_arm]) / np.maximum(1.0, np.abs(qo))).max()))
+    print('speculative limits (%s, %d envs, %d steps of "open"): device arm max %.3e, gripper joints max %.3e; fp32 CPU followers max %.3e' % (kind, n, steps, d_arm.max(), d_grip.max(), g32.max()))
+    assert (d_arm <= np.maximum(1e-3, 3 * g32)).all(), (d_arm, g32)
+    assert (d_grip <= np.maximum(2e-3, 3 * g32)).all(), (d_grip, g32)      # no chatter: two orders of magnitude inside GRIP_JOINT_TOL
+
+
 def test_rollout_sampled_envs_of_4096_vs_fp64_oracle():
     """the same measure at BASELINE's batch size: 4096 headline envs stepped together (three env groups on three streams, pairs and groups
     re-sorted by load every substep), 16 of them - spread over the index range - followed by fp64 and fp32 CPU oracles (tolerances.Followers) with the

@@ -75,6 +75,8 @@ u2, cnt2 = np.unique(key2, return_counts=True)
 print('distinct SIMDs used', len(u2), 'waves per SIMD: min %d p50 %d max %d' % (cnt2.min(), np.median(cnt2), cnt2.max()))
 four = (a[:, 6] >> 30) & 1
 if four.any():
+    ld4 = (a[four == 1, 1] - a[four == 1, 4]) / 100.0
+    print('four-env waves: rows loaded after p10 %.1f p50 %.1f p90 %.1f max %.1f us of their p50 %.1f us' % (tuple(np.percentile(ld4, [10, 50, 90, 100])) + (np.median((a[four == 1, 5] - a[four == 1, 4]) / 100.0),)))
     d4 = (a[four == 1, 5] - a[four == 1, 4]) / 100.0
     d2 = (a[four == 0, 5] - a[four == 0, 4]) / 100.0
     print('waves on the four-env path: %d of %d; their duration us: p50 %.1f p90 %.1f max %.1f; two-env path waves: %d, duration us p50 %.1f max %.1f' % (
