@@ -49,6 +49,8 @@
 #define RPO_RULE_SPIN 128           /* spinning_friction of the gripper links: one torsional friction row per collider pair in contact */
 #define RPO_RULE_PERSIST 256        /* persistent contact manifolds (collide_persistent) */
 #define RPO_RULE_HULLMOV 512        /* ... and movable boxes (the block, the drawer, the door: collider a of the pair) with them too */
+#define RPO_RULE_XGRAN 32768        /* EXPERIMENT (tools/granularity_experiment.py; no HIP counterpart): the reference step's manifold granularity - one manifold per COLLIDER pair
+                                     * and every point of a rotation-locked body - on the shipped model's own contact cache */
 #define RPO_RULE_GJK 1024           /* ... and where the deepest vertex lies BESIDE the face (box edges and corners): GJK's distance phase on hull and box (hull_box_gjk) */
 #define RPO_RULE_HULLFACE 4         /* arm links touch static boxes with the vertices of their collision meshes' convex hulls (hull_face) instead of their OBBs */
 #define HULL_MARGIN ((real)RP_HULL_MARGIN)
@@ -60,9 +62,14 @@
 #define IK_MAX_STEP ((real)(45.0 * 3.14159265358979323846 / 180.0))
 #define TIE_EPS ((real)1e-6)            /* discrete narrowphase choices need a margin that fp32 and fp64 agree on */
 #ifndef MAX_CONTACTS
+#ifndef MAX_CONTACTS
 #define MAX_CONTACTS 21
 #endif
-#define PM_MAX 11                 /* cached manifolds per env under RPO_RULE_PERSIST (those with at least one point), shared with the HIP library */
+#endif
+#ifndef PM_MAX
+#define PM_MAX 11
+#endif
+                                  /* cached manifolds per env under RPO_RULE_PERSIST (those with at least one point), shared with the HIP library */
 #define MAX_TORS 4                /* torsional friction rows per substep (RPO_RULE_SPIN), shared with the HIP library (MAXT) */
 #define MAX_ACTIVE_PAIRS 64
 #define MAX_CANDIDATES 64    /* candidate points that enter the manifolds per substep (CANDMAX of the HIP library) */
@@ -712,7 +719,7 @@ static void collide_persistent(rpo_env* e) {
       if (e->aabb_lo[a][k] > e->aabb_hi[b][k] + margin || e->aabb_lo[b][k] > e->aabb_hi[a][k] + margin) sep = 1;
     if (sep) continue;
     if (nactive >= MAX_ACTIVE_PAIRS) continue;
-    act_oa[nactive] = m->col_obj[a]; act_ob[nactive] = m->col_obj[b]; act_thr[nactive] = (real)(m->col_thr[a] < m->col_thr[b] ? m->col_thr[a] : m->col_thr[b]); nactive++;
+    act_oa[nactive] = (e->rule & RPO_RULE_XGRAN) ? 1000 + a : m->col_obj[a]; act_ob[nactive] = (e->rule & RPO_RULE_XGRAN) ? 1000 + b : m->col_obj[b]; act_thr[nactive] = (real)(m->col_thr[a] < m->col_thr[b] ? m->col_thr[a] : m->col_thr[b]); nactive++;
     cpoint pts[4]; int np = 0;
     real ha[3], hb[3];
     for (int k = 0; k < 3; k++) { ha[k] = (real)m->col_he[a][k]; hb[k] = (real)m->col_he[b][k]; }
@@ -778,7 +785,7 @@ static void collide_persistent(rpo_env* e) {
     real clA[MAX_CANDIDATES][3], clB[MAX_CANDIDATES][3];
     for (int ci = 0; ci < ncand; ci++) {
       const contact* c = &cand[ci];
-      const int oa = m->col_obj[c->ca], ob = m->col_obj[c->cb];
+      const int oa = (e->rule & RPO_RULE_XGRAN) ? 1000 + c->ca : m->col_obj[c->ca], ob = (e->rule & RPO_RULE_XGRAN) ? 1000 + c->cb : m->col_obj[c->cb];
       cmi[ci] = -1; csl[ci] = -1;
       for (int i = 0; i < e->npm; i++) if (e->pm[i].oa == oa && e->pm[i].ob == ob) cmi[ci] = i;
       if (cmi[ci] < 0) continue;                           /* no room for its manifold (PM_MAX) */
@@ -863,7 +870,7 @@ static void collide_persistent(rpo_env* e) {
     int only = -1;
     if (e->pm[mi].n > 0) {
       const int kf = body_free_index(e, m->col_body[e->pm[mi].pt[0].ca]);
-      if (kf >= 0 && m->free_rot_locked[kf] && m->col_body[e->pm[mi].pt[0].cb] == 0) {
+      if (!(e->rule & RPO_RULE_XGRAN) && kf >= 0 && m->free_rot_locked[kf] && m->col_body[e->pm[mi].pt[0].cb] == 0) {
         only = 0;
         for (int i = 1; i < e->pm[mi].n; i++) if (e->pm[mi].pt[i].dist < e->pm[mi].pt[only].dist - TIE_EPS) only = i;
       }
