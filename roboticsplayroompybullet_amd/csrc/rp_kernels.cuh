@@ -2799,7 +2799,9 @@ __global__ void __launch_bounds__(64, RP_WAVES_PER_EU) k_reset_finish(const DevM
     const Q4 torn = {0.f, 0.f, 0.f, 1.f};
     reset_sample_arm_target(m, L, lane, seed, genv, tx);
     const float r = reset_arm_goal_obs(m, L, lane, seed, genv, tx, torn);
-    if (r > -1.f && mt.y + 1 < 64) { mt.y++; mt.z = 0; }      /* already solved: the whole reset again */
+    /* already solved: the whole reset again.  (sparse=False: the reward is -distance, never <= -1 inside the scene - the reference's `while r > -1` would not end,
+     * environments.py:176-186 with 169-170; there is no behaviour to match, and a dense env keeps its first draw like the oracle) */
+    if (!m->dense_reward && r > -1.f && mt.y + 1 < 64) { mt.y++; mt.z = 0; }
     else { mt.x = 0; write_outputs(m, L, lane, env, out); }
   }
   if (lane == 0) meta[env] = mt;

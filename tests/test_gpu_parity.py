@@ -129,9 +129,9 @@ def test_rollout_200_steps_vs_fp64_oracle(kind):
     # which the device - one more evaluation order - draws an outcome none of the seven CPU runs drew (tools/dbg_rollout_env.py U 42: split pipeline and
     # fused kernel agree bit for bit there, the arm returns to the oracle's trajectory to 3e-7 forty steps later)
     assert len(unexplained) <= n // 50, 'envs %s: device %s, fp32 CPU oracle %s' % (unexplained, d_hip[unexplained], d_o32[unexplained])
-    assert bad.size <= max(1, n // 20) and (d_hip[bad] <= 2e-2).all(), (bad, d_hip[bad])
+    assert bad.size <= (2 if kind == 'U' else 1) and (d_hip[bad] <= 2e-2).all(), (bad, d_hip[bad])      # measured (round 4): U one env (a marginal IK stop), the others none
     assert (g_hip <= GRIP_JOINT_TOL).all(), g_hip
-    assert strict.mean() >= 0.9
+    assert strict.sum() >= (59 if kind == 'U' else n - 1), strict.sum()      # measured (round 4): U 60 of 64 (the fp32 CPU oracle itself: 51), R / P / Q / V 8 of 8 - asserted: the measured count less one
     # status bit 8 (the IK ran out of its 4 x 20 / 200 iterations in that step; the joint targets then hang on the measured joints): how common it is, and
     # whether the envs that leave 1e-3 are the ones where it happens most - reported, not asserted: with a new random target every step it happens in
     # every env sooner or later, so it cannot single envs out
@@ -249,7 +249,7 @@ def test_rollout_sampled_envs_of_4096_vs_fp64_oracle():
     print('sampled envs of 4096, %d steps: device max %.3e median %.3e, %d of %d within 1e-3; fp32 CPU oracle max %.3e' % (
         steps, d_hip.max(), np.median(d_hip), int(strict.sum()), len(sample), d_o32.max()))      # (fp32 CPU oracles: seven runs per env)
     assert (d_hip <= np.maximum(1e-3, 3 * d_o32)).all(), (d_hip, d_o32)
-    assert strict.mean() >= 0.85
+    assert strict.sum() >= 14, strict.sum()      # measured (round 4): 15 of 16
 
 
 def oracle_goal_ptr(o):
@@ -775,7 +775,7 @@ def test_config_cem_mpc_broadcast_rollouts():
     n = n_start * n_cand
     src = VecPlayEnv(IDS['U'], n_start, seed=4)
     src.reset()
-    starts = src.get_state().clone()                                   # [32, 128]
+    starts = src.get_state().clone()                                   # [32, state floats per env]: record + contact cache (rp_state_bytes / 4)
     env = VecPlayEnv(IDS['U'], n, seed=4)
     env.set_state(starts.repeat_interleave(n_cand, dim=0))
     g = torch.Generator(device='cuda').manual_seed(9)

@@ -4,7 +4,7 @@
 # --runtime-trace), and the profiled program sits directly after `--`.
 #   gpurun --timeout 900 -- 'bash tools/collect_profiles.sh r01'
 set -u
-TAG=${1:-r02}
+TAG=${1:-r04}
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"

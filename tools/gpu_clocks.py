@@ -45,7 +45,8 @@ steps_seq = na + nj + 3 * nc
 stp = np.where(par == 1, steps_par, steps_seq)
 clk_per_wall = (a[:, 3] - a[:, 0]).astype(np.float64) / np.maximum(a[:, 5] - a[:, 4], 1)
 print('shader clocks per 100MHz tick: median %.2f' % np.median(clk_per_wall))
-print('load   cycles: p50 %d p90 %d max %d' % tuple(np.percentile(t_load, [50, 90, 100])))
+two = ((a[:, 6] >> 30) & 1) == 0
+print('load   cycles (two-env path waves): p50 %d p90 %d max %d' % tuple(np.percentile(t_load[two], [50, 90, 100])) if two.any() else 'no two-env waves')
 print('sweeps cycles: p50 %d p90 %d max %d' % tuple(np.percentile(t_sweep, [50, 90, 100])))
 print('tail   cycles: p50 %d p90 %d max %d' % tuple(np.percentile(t_tail, [50, 90, 100])))
 for name, sel in (('PAR', par == 1), ('SEQ', par == 0)):
