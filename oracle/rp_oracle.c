@@ -69,6 +69,7 @@
 #ifndef PM_MAX
 #define PM_MAX 11
 #endif
+#define GJK_AX 16                 /* cached GJK results per env (hull_box_gjk), shared with the HIP library (PMC_AXN) */
                                   /* cached manifolds per env under RPO_RULE_PERSIST (those with at least one point), shared with the HIP library */
 #define MAX_TORS 4                /* torsional friction rows per substep (RPO_RULE_SPIN), shared with the HIP library (MAXT) */
 #define MAX_ACTIVE_PAIRS 64
@@ -122,6 +123,9 @@ struct rpo_env {
   /* RPO_RULE_PERSIST: the contact cache - one manifold per object pair in creation order, <= 4 points each, kept in the two bodies' frames */
   struct { int oa, ob, n; real thr; struct { int ca, cb; real lA[3], lB[3], n[3], pA[3], pB[3], dist; } pt[4]; } pm[PM_MAX];
   int npm;
+  /* ... and, beside the manifolds, the direction GJK's distance phase last ended with for a (hull, box) collider pair, in the box's frame: the next call's first
+   * direction (btGjkPairDetector::m_cachedSeparatingAxis).  GJK_AX slots, direct-mapped by the baked pair index; tag = pair index + 1, 0 = empty */
+  struct { int tag, n, vi[3], code[3]; real v[3]; } gax[GJK_AX];
   void* ref;                        /* librp_oracle_bullet.so only: persistent state of the frozen Bullet-like step (rp_bullet_ref.c) */
 };
 
@@ -510,6 +514,7 @@ static int hull_face(const rpo_env* e, int a, int b, real margin, cpoint* out, r
   for (int j = 0; j < 3; j++) {
     const real l = (u[j][0] * v[0] + u[j][1] * v[1] + u[j][2] * v[2]) - c[j];
     lv[j] = l;                                               /* (the vertex in box coordinates: where hull_box_gjk starts from) */
+    lv[3] = (real)iv;
     if (j != k && R_FABS(l) > (real)m->col_he[b][j]) beside = 1;
   }
   if (beside) return -1;                                     /* beside the face: edges and corners stay with the OBB path */
@@ -533,7 +538,7 @@ static int hull_face(const rpo_env* e, int a, int b, real margin, cpoint* out, r
 /* The simplex arithmetic runs in DOUBLE in every build (the fp32 build and the HIP library too): the sub-case determinants of a sliver simplex - three vertices of a finely
  * tessellated link a few millimetres from the origin - cancel to 1e-3 relative in fp32, and the witness points of nearly parallel features move by centimetres with them. */
 typedef double greal;
-typedef struct { greal w[3], a[3], b[3]; } gjk_sv;
+typedef struct { greal w[3], a[3], b[3]; int vi, code; } gjk_sv;      /* vi: the hull vertex of a; code: the box-core corner b, one sign bit per axis */
 static greal g3dot(const greal* a, const greal* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 static void g3sub(greal* o, const greal* a, const greal* b) { o[0] = a[0] - b[0]; o[1] = a[1] - b[1]; o[2] = a[2] - b[2]; }
 static void g3cross(greal* o, const greal* a, const greal* b) { o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0]; }
@@ -596,9 +601,39 @@ static void gjk_closest(gjk_sv* s, int* n, greal* lam) {      /* closest point o
  * (lv) against the corner(s) of the box-core feature nearest to it - one corner, or the two ends of the nearest edge.  If that vertex IS the hull's closest
  * point (a link's corner against a box edge: the usual case) the first support query ends the iteration; the HIP library runs the same iteration, its support
  * queries as whole-wave vertex scans (narrowphase_coop). */
+/* The link's OBB (it contains the hull) against the box over the fifteen directions of the box-box SAT: clear of the box by more than the pair's margin (and the hull's
+ * shape margin) along one of them = the hull is too, whatever the vertex scan and GJK would find - the HIP library stops such a pair there, and so does the oracle, so that
+ * both run (and cache the direction of) the same GJK calls.  The box as the scans see it: a plate thinner than the margin counts 0.001 thick. */
+static int hull_has_vertices(const rpo_env* e, int c) { const float (*hv)[4]; const int *hoff, *hcnt; rp_hull_tables(e->m.kind, &hv, &hoff, &hcnt); return hcnt && hcnt[c] > 0; }
+static int obb_apart(const rpo_env* e, int hc, int bc, real margin) {
+  const rp_model* m = &e->m;
+  const xform *xa = &e->xc[hc], *xb = &e->xc[bc];
+  real A[3][3], B[3][3], ha[3], hb[3], t[3];
+  for (int k = 0; k < 3; k++) {
+    for (int r = 0; r < 3; r++) { A[k][r] = xa->R[3 * r + k]; B[k][r] = xb->R[3 * r + k]; }
+    ha[k] = (real)m->col_he[hc][k]; hb[k] = (real)m->col_he[bc][k] > HULL_MARGIN ? (real)m->col_he[bc][k] : HULL_MARGIN;
+  }
+  v3sub(t, xa->p, xb->p);
+  const real thr = margin + HULL_MARGIN + (real)1e-5;
+  for (int ax = 0; ax < 15; ax++) {
+    real L[3];
+    if (ax < 3) v3cpy(L, A[ax]);
+    else if (ax < 6) v3cpy(L, B[ax - 3]);
+    else {
+      v3cross(L, A[(ax - 6) / 3], B[(ax - 6) % 3]);
+      const real l = R_SQRT(v3dot(L, L));
+      if (!(l > (real)1e-2)) continue;
+      v3scale(L, L, 1 / l);
+    }
+    real ra = 0, rb = 0;
+    for (int k = 0; k < 3; k++) { ra += ha[k] * R_FABS(v3dot(L, A[k])); rb += hb[k] * R_FABS(v3dot(L, B[k])); }
+    if (R_FABS(v3dot(t, L)) - ra - rb > thr) return 1;
+  }
+  return 0;
+}
 static long g_gjk_stats[8];      /* calls, rounds, seeds with two points, results 1 / 0 / -1, tetrahedra solved */
 void rpo_gjk_stats(long* out, int reset) { for (int i = 0; i < 8; i++) { out[i] = g_gjk_stats[i]; if (reset) g_gjk_stats[i] = 0; } }
-static int hull_box_gjk(const rpo_env* e, int hc, int bc, real margin, const real* lv, cpoint* out) {
+static int hull_box_gjk(rpo_env* e, int hc, int bc, real margin, const real* lv, int lvi, cpoint* out, int pi) {
   const rp_model* m = &e->m;
   const float (*hv)[4]; const int *hoff, *hcnt;
   rp_hull_tables(m->kind, &hv, &hoff, &hcnt);
@@ -615,28 +650,70 @@ static int hull_box_gjk(const rpo_env* e, int hc, int bc, real margin, const rea
     v3sub(t, xb->p, xa->p);
     c[k] = v3dot(bk, t);
   }
+#define HULL_L(out3, vi_) do { const real q_[3] = {(real)hv[vi_][0], (real)hv[vi_][1], (real)hv[vi_][2]}; for (int k_ = 0; k_ < 3; k_++) (out3)[k_] = (u[k_][0] * q_[0] + u[k_][1] * q_[1] + u[k_][2] * q_[2]) - c[k_]; } while (0)
   g_gjk_stats[0]++;
   gjk_sv s[4]; int n = 0; greal lam[4] = {0, 0, 0, 0};
   memset(s, 0, sizeof(s));
-  /* the seed: lv against the nearest feature of the box core */
-  int nout = 0, fk = -1;
-  for (int k = 0; k < 3; k++) { if (R_FABS(lv[k]) > hb[k]) nout++; else fk = k; }
-  if (nout == 0) { g_gjk_stats[5]++; return -1; }            /* the vertex lies inside the box core */
-  for (int i = 0; i < (nout == 2 ? 2 : 1); i++) {
-    for (int k = 0; k < 3; k++) {
-      s[i].b[k] = lv[k] >= 0 ? hb[k] : -hb[k];
-      if (nout == 2 && k == fk) s[i].b[k] = i == 0 ? -hb[k] : hb[k];
-      s[i].a[k] = lv[k];
-      s[i].w[k] = s[i].a[k] - s[i].b[k];
-    }
-    n++;
-  }
-  if (n == 2) g_gjk_stats[2]++;
+  /* What this pair's last call ended with - the simplex (hull vertex numbers and box-core corners) and the direction v - waits in the contact cache (only with
+   * persistent manifolds): Bullet keeps the separating axis of a pair between calls (btGjkPairDetector::m_cachedSeparatingAxis); the simplex beside it turns a contact
+   * that is still there into one confirming round.  GJK_AX slots, direct-mapped by the baked pair index. */
+  const int cached = (e->rule & RPO_RULE_PERSIST) && e->margin < 0 && pi >= 0;
+  const int slot = pi & (GJK_AX - 1);
+  const int warm = cached && e->gax[slot].tag == pi + 1;
+#define GAX_STORE() do { if (cached) { e->gax[slot].tag = pi + 1; e->gax[slot].n = n; for (int i_ = 0; i_ < 3; i_++) { e->gax[slot].vi[i_] = i_ < n ? s[i_].vi : 0; e->gax[slot].code[i_] = i_ < n ? s[i_].code : 0; } \
+                                      for (int k_ = 0; k_ < 3; k_++) e->gax[slot].v[k_] = (real)(float)v[k_]; } } while (0)      /* (v in fp32: the HIP library's cache rows are fp32) */
+#define GAX_CLEAR() do { if (cached && e->gax[slot].tag == pi + 1) e->gax[slot].tag = 0; } while (0)
+#define CORNER(out3, code_) do { for (int k_ = 0; k_ < 3; k_++) (out3)[k_] = ((code_) >> k_) & 1 ? hb[k_] : -hb[k_]; } while (0)
   greal v[3] = {0, 0, 0};
+  greal dd = 1e30;
+  const greal far = margin + 2 * HULL_MARGIN;
+  if (warm) {
+    /* the cached direction first: the hull's clearance from the box core along it (a lower bound of their distance) beyond the margin and the two shape margins =
+     * apart, and nothing changes (the HIP library measures this in the one pass over the vertices that hull_face's scan makes anyway) */
+    real vn[3] = {e->gax[slot].v[0], e->gax[slot].v[1], e->gax[slot].v[2]};
+    const real l = R_SQRT(v3dot(vn, vn));
+    if (l > 0) {
+      v3scale(vn, vn, 1 / l);
+      real dl[3], lo = (real)1e30;
+      for (int j = 0; j < 3; j++) dl[j] = vn[0] * u[0][j] + vn[1] * u[1][j] + vn[2] * u[2][j];
+      const real cp = vn[0] * c[0] + vn[1] * c[1] + vn[2] * c[2] + hb[0] * R_FABS(vn[0]) + hb[1] * R_FABS(vn[1]) + hb[2] * R_FABS(vn[2]);
+      for (int i = 0; i < nvert; i++) {
+        const real pr = ((real)hv[i][0] * dl[0] + (real)hv[i][1] * dl[1] + (real)hv[i][2] * dl[2]) - cp;
+        if (pr < lo) lo = pr;
+      }
+      if (lo > (real)far + (real)1e-6) { g_gjk_stats[4]++; return 0; }
+    }
+    /* ... else the cached simplex at today's poses */
+    n = e->gax[slot].n;
+    for (int i = 0; i < n; i++) {
+      s[i].vi = e->gax[slot].vi[i] < nvert ? e->gax[slot].vi[i] : 0; s[i].code = e->gax[slot].code[i];
+      real a3[3], b3[3];
+      HULL_L(a3, s[i].vi); CORNER(b3, s[i].code);
+      for (int k = 0; k < 3; k++) { s[i].a[k] = a3[k]; s[i].b[k] = b3[k]; s[i].w[k] = (greal)a3[k] - (greal)b3[k]; }
+    }
+  } else {
+    /* the seed: lv (hull vertex lvi, where hull_face's scan stopped) against the nearest feature of the box core */
+    int nout = 0, fk = -1;
+    for (int k = 0; k < 3; k++) { if (R_FABS(lv[k]) > hb[k]) nout++; else fk = k; }
+    if (nout == 0) { g_gjk_stats[5]++; GAX_CLEAR(); return -1; }            /* the vertex lies inside the box core */
+    for (int i = 0; i < (nout == 2 ? 2 : 1); i++) {
+      s[i].vi = lvi; s[i].code = 0;
+      for (int k = 0; k < 3; k++) {
+        int plus = lv[k] >= 0;
+        if (nout == 2 && k == fk) plus = i == 1;
+        s[i].code |= plus << k;
+        s[i].b[k] = plus ? hb[k] : -hb[k];
+        s[i].a[k] = lv[k];
+        s[i].w[k] = (greal)s[i].a[k] - (greal)s[i].b[k];
+      }
+      n++;
+    }
+    if (n == 2) g_gjk_stats[2]++;
+  }
   gjk_closest(s, &n, lam);
   for (int i = 0; i < n; i++) for (int k = 0; k < 3; k++) v[k] += lam[i] * s[i].w[k];
-  greal dd = g3dot(v, v);
-  if (dd < GJK_ZERO) { g_gjk_stats[5]++; return -1; }
+  dd = g3dot(v, v);
+  if (dd < GJK_ZERO) { g_gjk_stats[5]++; GAX_CLEAR(); return -1; }
   for (int it = 0; it < 32; it++) {
     gjk_sv sv;
     g_gjk_stats[1]++;
@@ -648,34 +725,42 @@ static int hull_box_gjk(const rpo_env* e, int hc, int bc, real margin, const rea
         const real d = (real)hv[i][0] * dl[0] + (real)hv[i][1] * dl[1] + (real)hv[i][2] * dl[2];
         if (d > bd) { bd = d; bi = i; }
       }
-      const real q[3] = {(real)hv[bi][0], (real)hv[bi][1], (real)hv[bi][2]};
-      for (int k = 0; k < 3; k++) sv.a[k] = (u[k][0] * q[0] + u[k][1] * q[1] + u[k][2] * q[2]) - c[k];
+      real a3[3];
+      HULL_L(a3, bi);
+      sv.vi = bi;
+      for (int k = 0; k < 3; k++) sv.a[k] = a3[k];
     }
-    for (int k = 0; k < 3; k++) sv.b[k] = v[k] >= 0 ? hb[k] : -hb[k];      /* box core: the corner of largest projection on v */
+    sv.code = 0;
+    for (int k = 0; k < 3; k++) { const int plus = v[k] >= 0; sv.code |= plus << k; sv.b[k] = plus ? hb[k] : -hb[k]; }      /* box core: the corner of largest projection on v */
     g3sub(sv.w, sv.a, sv.b);
     const greal vv = g3dot(v, v), vw = g3dot(v, sv.w);
     int dup = 0;
     for (int i = 0; i < n; i++) { greal d[3]; g3sub(d, s[i].w, sv.w); if (g3dot(d, d) < GJK_DUP) dup = 1; }
     /* v . w / |v| is a lower bound of the distance between the cores: beyond the pair's margin (and the two shape margins) the answer is "apart" whatever the
      * iteration would still find */
-    { const greal far = margin + 2 * HULL_MARGIN; if (vw > 0 && vw * vw > far * far * vv) { g_gjk_stats[4]++; g_gjk_stats[7] += it + 1; return 0; } }
+    if (vw > 0 && vw * vw > far * far * vv) { g_gjk_stats[4]++; g_gjk_stats[7] += it + 1; GAX_STORE(); return 0; }
     if (dup || vv - vw <= GJK_REL * vv) break;
     s[n++] = sv;
     if (n == 4) g_gjk_stats[6]++;
     gjk_closest(s, &n, lam);
-    if (n == 4) { g_gjk_stats[5]++; return -1; }
+    if (n == 4) { g_gjk_stats[5]++; GAX_CLEAR(); return -1; }
     greal q[3] = {0, 0, 0};
     for (int i = 0; i < n; i++) for (int k = 0; k < 3; k++) q[k] += lam[i] * s[i].w[k];
     const greal nd = g3dot(q, q);
     for (int k = 0; k < 3; k++) v[k] = q[k];
-    if (nd < GJK_ZERO) { g_gjk_stats[5]++; return -1; }
+    if (nd < GJK_ZERO) { g_gjk_stats[5]++; GAX_CLEAR(); return -1; }
     if (nd >= dd * GJK_STALL) { dd = nd; break; }
     dd = nd;
   }
   greal pg[3] = {0, 0, 0};
   for (int i = 0; i < n; i++) for (int k = 0; k < 3; k++) pg[k] += lam[i] * s[i].b[k];
   const greal distg = sqrt(g3dot(v, v));
-  if (!(distg > GJK_ZERO)) { g_gjk_stats[5]++; return -1; }
+  if (!(distg > GJK_ZERO)) { g_gjk_stats[5]++; GAX_CLEAR(); return -1; }
+  GAX_STORE();
+#undef GAX_STORE
+#undef GAX_CLEAR
+#undef CORNER
+#undef HULL_L
   const real dist = (real)distg;
   real nl[3] = {(real)(v[0] / distg), (real)(v[1] / distg), (real)(v[2] / distg)}, pl[3] = {(real)pg[0], (real)pg[1], (real)pg[2]};
   const real d = dist - 2 * HULL_MARGIN;                     /* both margins */
@@ -723,17 +808,18 @@ static void collide_persistent(rpo_env* e) {
     cpoint pts[4]; int np = 0;
     real ha[3], hb[3];
     for (int k = 0; k < 3; k++) { ha[k] = (real)m->col_he[a][k]; hb[k] = (real)m->col_he[b][k]; }
-    int hf = -1; real hlv[3] = {0, 0, 0};
-    if ((e->rule & RPO_RULE_HULLFACE) && m->col_type[b] == 0 && m->col_body[b] == 0 && body_is_arm(e, m->col_body[a])) hf = hull_face(e, a, b, margin, pts, hlv);
+    int hf = -1; real hlv[4] = {0, 0, 0, 0};
+    const int gjk_on = (e->rule & RPO_RULE_GJK) && (e->rule & RPO_RULE_HULLFACE);
+    if ((e->rule & RPO_RULE_HULLFACE) && m->col_type[b] == 0 && m->col_body[b] == 0 && body_is_arm(e, m->col_body[a])) hf = (gjk_on && hull_has_vertices(e, a) && obb_apart(e, a, b, margin)) ? 0 : hull_face(e, a, b, margin, pts, hlv);
     else if ((e->rule & RPO_RULE_HULLMOV) && (e->rule & RPO_RULE_HULLFACE) && m->col_type[a] == 0 && m->col_type[b] == 0 && body_is_arm(e, m->col_body[b]) && !body_is_arm(e, m->col_body[a]) && m->col_body[a] != 0) {
-      hf = hull_face(e, b, a, margin, pts, hlv);      /* a movable box (collider a) against an arm link's hull (collider b): the pair's normal points from b toward a */
+      hf = (gjk_on && hull_has_vertices(e, b) && obb_apart(e, b, a, margin)) ? 0 : hull_face(e, b, a, margin, pts, hlv);      /* a movable box (collider a) against an arm link's hull (collider b): the pair's normal points from b toward a */
       if (hf == 1) v3scale(pts[0].n, pts[0].n, -1);
     }
     if (hf == -1 && (e->rule & RPO_RULE_GJK) && (e->rule & RPO_RULE_HULLFACE)) {
       /* the vertex lies beside the face: GJK's distance phase (hull = the arm link's collider, whichever of the two it is) */
-      if (m->col_type[b] == 0 && m->col_body[b] == 0 && body_is_arm(e, m->col_body[a])) hf = hull_box_gjk(e, a, b, margin, hlv, pts);
+      if (m->col_type[b] == 0 && m->col_body[b] == 0 && body_is_arm(e, m->col_body[a])) hf = hull_box_gjk(e, a, b, margin, hlv, (int)hlv[3], pts, pi);
       else if ((e->rule & RPO_RULE_HULLMOV) && m->col_type[a] == 0 && m->col_type[b] == 0 && body_is_arm(e, m->col_body[b]) && !body_is_arm(e, m->col_body[a]) && m->col_body[a] != 0) {
-        hf = hull_box_gjk(e, b, a, margin, hlv, pts);
+        hf = hull_box_gjk(e, b, a, margin, hlv, (int)hlv[3], pts, pi);
         if (hf == 1) v3scale(pts[0].n, pts[0].n, -1);
       }
     }
@@ -938,7 +1024,7 @@ static void collide(rpo_env* e) {
     cpoint pts[4]; int np = 0;
     real ha[3], hb[3];
     for (int k = 0; k < 3; k++) { ha[k] = (real)m->col_he[a][k]; hb[k] = (real)m->col_he[b][k]; }
-    int hf = -1; real hlv[3] = {0, 0, 0};
+    int hf = -1; real hlv[4] = {0, 0, 0, 0};
     if ((e->rule & RPO_RULE_HULLFACE) && m->col_type[b] == 0 && m->col_body[b] == 0 && body_is_arm(e, m->col_body[a]))
       hf = hull_face(e, a, b, margin, pts, hlv);
     else if ((e->rule & RPO_RULE_HULLMOV) && (e->rule & RPO_RULE_HULLFACE) && m->col_type[a] == 0 && m->col_type[b] == 0 && body_is_arm(e, m->col_body[b]) && !body_is_arm(e, m->col_body[a]) && m->col_body[a] != 0) {
@@ -946,9 +1032,9 @@ static void collide(rpo_env* e) {
       if (hf == 1) v3scale(pts[0].n, pts[0].n, -1);
     }
     if (hf == -1 && (e->rule & RPO_RULE_GJK) && (e->rule & RPO_RULE_HULLFACE)) {
-      if (m->col_type[b] == 0 && m->col_body[b] == 0 && body_is_arm(e, m->col_body[a])) hf = hull_box_gjk(e, a, b, margin, hlv, pts);
+      if (m->col_type[b] == 0 && m->col_body[b] == 0 && body_is_arm(e, m->col_body[a])) hf = hull_box_gjk(e, a, b, margin, hlv, (int)hlv[3], pts, pi);
       else if ((e->rule & RPO_RULE_HULLMOV) && m->col_type[a] == 0 && m->col_type[b] == 0 && body_is_arm(e, m->col_body[b]) && !body_is_arm(e, m->col_body[a]) && m->col_body[a] != 0) {
-        hf = hull_box_gjk(e, b, a, margin, hlv, pts);
+        hf = hull_box_gjk(e, b, a, margin, hlv, (int)hlv[3], pts, pi);
         if (hf == 1) v3scale(pts[0].n, pts[0].n, -1);
       }
     }
@@ -1554,7 +1640,7 @@ static int collide_persist(rpo_env* e) {
     real ha[3], hb[3];
     for (int k = 0; k < 3; k++) { ha[k] = (real)m->col_he[a][k]; hb[k] = (real)m->col_he[b][k]; }
     const real margin = (real)mf->thr;
-    int hf = -1; real hlv[3] = {0, 0, 0};
+    int hf = -1; real hlv[4] = {0, 0, 0, 0};
     if ((e->rule & RPO_RULE_HULLFACE) && m->col_type[b] == 0 && m->col_body[b] == 0 && body_is_arm(e, m->col_body[a])) hf = hull_face(e, a, b, margin, pts, hlv);
     if (hf >= 0) np = hf;
     else if (m->col_type[a] == 0 && m->col_type[b] == 0) np = box_box(e->xc[a].p, e->xc[a].R, ha, e->xc[b].p, e->xc[b].R, hb, 0, 1, pts);      /* overlap only: the manifold keeps the points */
@@ -2417,6 +2503,7 @@ void rpo_set_state(rpo_env* e, const double* s) {
   for (int k = 0; k < e->m.n_joint1; k++) e->jq[k] = (real)s[n++];
   for (int k = 0; k < e->m.n_joint1; k++) e->jqd[k] = (real)s[n++];
   e->npm = 0;                     /* a state set from outside starts with an empty contact cache (RPO_RULE_PERSIST) */
+  memset(e->gax, 0, sizeof(e->gax));
   update_transforms(e);
 }
 /* test hook: shift free body k, keeping its velocity and - unlike rpo_set_state - the contact cache (tests of the cache's life cycle) */

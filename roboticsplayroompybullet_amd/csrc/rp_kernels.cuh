@@ -36,7 +36,13 @@ static_assert(MAXACT <= 64 && NB_MAX <= 32, "a candidate record packs its pair i
 #define PMC_HDR 4
 #define PMC_PT 11
 #define PMC_MAN (8 + 4 * PMC_PT)
-#define PMC_FLOATS (PMC_HDR + PM_MAX * PMC_MAN)      /* 576 */
+#define PMC_MANIFOLDS (PMC_HDR + PM_MAX * PMC_MAN)   /* 576: the manifolds (staged in LDS by collide()) */
+/* ... and behind them what GJK's distance phase last ended with for a (hull, box) collider pair (oracle hull_box_gjk, rpo_env.gax): PMC_AXN slots, direct-mapped by the
+ * baked pair index, 8 words each: tag (pair index + 1, 0 = empty) | n + corner codes << 4 (three bits per simplex point, four bits apart) | three hull vertex numbers |
+ * the direction v in the box's frame.  Read and written in place (global memory), one slot per GJK call */
+#define PMC_AX PMC_MANIFOLDS
+#define PMC_AXN 16
+#define PMC_FLOATS (PMC_MANIFOLDS + 8 * PMC_AXN)      /* 704: a row of the contact cache (part of the state rows) */
 #define RP_MAX_GROUPS 16      /* env groups (streams) rp_step can cut the envs into */
 #define SORT_KEYS 64          /* load classes for pairing envs in k_solve2: 8 * min(folded slots, 7) + min((side-by-side slots - 1) / 2, 7) */
 #define SORT_REPS 8           /* histogram replicas (env & 7): one hot word would serialise ~4096 atomics at ~90 per us */
@@ -576,40 +582,42 @@ __device__ __forceinline__ V3 sel3(bool c, V3 a, V3 b) { return mk3(c ? a.x : b.
  * (one sign bit per axis: bit k set = +hbc_k), the count and the weights in registers.  reduce(): keeps the vertices of `keep` (a subsequence of p0 p1 p2, in that
  * order) with their weights */
 struct GjkSimplex {
-  double* W; int b0, b1, b2, b3; int n; double l0, l1, l2;
+  double* W; int b0, b1, b2, b3; int i0, i1, i2, i3; int n;      /* W: four points of three doubles, then the three weights (W[12 .. 15)); b: the points' box-core corners; i: their hull vertices (what the contact cache keeps of a call) */
   __device__ __forceinline__ D3 pt(int i) const { return mkd(W[3 * i], W[3 * i + 1], W[3 * i + 2]); }
   __device__ __forceinline__ void put(int i, D3 p) { W[3 * i] = p.x; W[3 * i + 1] = p.y; W[3 * i + 2] = p.z; }
+  __device__ __forceinline__ void weights(double a, double b, double c) { W[12] = a; W[13] = b; W[14] = c; }
   /* (scalars by value: handed a GjkTri by reference, the compiler keeps it in private memory and turns the selects below into indexed loads) */
-  __device__ __forceinline__ void reduce(D3 p0, D3 p1, D3 p2, int q0, int q1, int q2, int keep, double r0, double r1, double r2) {
+  __device__ __forceinline__ void reduce(D3 p0, D3 p1, D3 p2, int q0, int q1, int q2, int j0, int j1, int j2, int keep, double r0, double r1, double r2) {
     const bool k0 = keep & 1, k1 = keep & 2;
     const double t12 = k1 ? r1 : r2;
-    put(0, dsel(k0, p0, dsel(k1, p1, p2))); b0 = k0 ? q0 : (k1 ? q1 : q2); l0 = k0 ? r0 : t12;
-    put(1, dsel(k0 && k1, p1, p2)); b1 = (k0 && k1) ? q1 : q2; l1 = (k0 && k1) ? r1 : r2;
-    put(2, p2); b2 = q2; l2 = r2;
+    put(0, dsel(k0, p0, dsel(k1, p1, p2))); b0 = k0 ? q0 : (k1 ? q1 : q2); i0 = k0 ? j0 : (k1 ? j1 : j2);
+    put(1, dsel(k0 && k1, p1, p2)); b1 = (k0 && k1) ? q1 : q2; i1 = (k0 && k1) ? j1 : j2;
+    put(2, p2); b2 = q2; i2 = j2;
+    weights(k0 ? r0 : t12, (k0 && k1) ? r1 : r2, r2);
     n = __popc(keep);
   }
   __device__ __forceinline__ D3 closest() const {
     D3 p = pt(0);
-    D3 q = mkd(p.x * l0, p.y * l0, p.z * l0);
-    if (n > 1) { p = pt(1); q = mkd(q.x + p.x * l1, q.y + p.y * l1, q.z + p.z * l1); }
-    if (n > 2) { p = pt(2); q = mkd(q.x + p.x * l2, q.y + p.y * l2, q.z + p.z * l2); }
+    D3 q = mkd(p.x * W[12], p.y * W[12], p.z * W[12]);
+    if (n > 1) { p = pt(1); q = mkd(q.x + p.x * W[13], q.y + p.y * W[13], q.z + p.z * W[13]); }
+    if (n > 2) { p = pt(2); q = mkd(q.x + p.x * W[14], q.y + p.y * W[14], q.z + p.z * W[14]); }
     return q;
   }
   static __device__ __forceinline__ V3 corner(int code, V3 h) { return mk3((code & 1) ? h.x : -h.x, (code & 2) ? h.y : -h.y, (code & 4) ? h.z : -h.z); }
   __device__ __forceinline__ D3 witness(V3 h) const {
     V3 c = corner(b0, h);
-    D3 q = mkd(c.x * l0, c.y * l0, c.z * l0);
-    if (n > 1) { c = corner(b1, h); q = mkd(q.x + c.x * l1, q.y + c.y * l1, q.z + c.z * l1); }
-    if (n > 2) { c = corner(b2, h); q = mkd(q.x + c.x * l2, q.y + c.y * l2, q.z + c.z * l2); }
+    D3 q = mkd(c.x * W[12], c.y * W[12], c.z * W[12]);
+    if (n > 1) { c = corner(b1, h); q = mkd(q.x + c.x * W[13], q.y + c.y * W[13], q.z + c.z * W[13]); }
+    if (n > 2) { c = corner(b2, h); q = mkd(q.x + c.x * W[14], q.y + c.y * W[14], q.z + c.z * W[14]); }
     return q;
   }
 };
 /* closest point of the simplex to the origin; the simplex shrinks to the supporting sub-simplex.  n = 4 afterwards: the origin lies inside the tetrahedron */
 __device__ __forceinline__ void gjk_closest(GjkSimplex& S, int lane) {
   (void)lane;
-  if (S.n == 1) { S.l0 = 1.0; return; }
-  if (S.n == 2) { const D3 a = S.pt(0), b = S.pt(1); const GjkTri r = gjk_seg(a, b); WSYNC(); S.reduce(a, b, b, S.b0, S.b1, S.b1, r.keep, r.l0, r.l1, r.l2); WSYNC(); return; }
-  if (S.n == 3) { const D3 a = S.pt(0), b = S.pt(1), c = S.pt(2); const GjkTri r = gjk_tri(a, b, c); WSYNC(); S.reduce(a, b, c, S.b0, S.b1, S.b2, r.keep, r.l0, r.l1, r.l2); WSYNC(); return; }
+  if (S.n == 1) { S.weights(1.0, 0.0, 0.0); WSYNC(); return; }
+  if (S.n == 2) { const D3 a = S.pt(0), b = S.pt(1); const GjkTri r = gjk_seg(a, b); WSYNC(); S.reduce(a, b, b, S.b0, S.b1, S.b1, S.i0, S.i1, S.i1, r.keep, r.l0, r.l1, r.l2); WSYNC(); return; }
+  if (S.n == 3) { const D3 a = S.pt(0), b = S.pt(1), c = S.pt(2); const GjkTri r = gjk_tri(a, b, c); WSYNC(); S.reduce(a, b, c, S.b0, S.b1, S.b2, S.i0, S.i1, S.i2, r.keep, r.l0, r.l1, r.l2); WSYNC(); return; }
   /* tetrahedron: the closest of the faces the origin lies outside of (the oracle's F / OPP tables; one face after the other: side by side in four lanes they cost
    * the registers of four triangles at once, and this kernel has none to spare), then the winner once more */
   double best = 1e30; int bf = -1;
@@ -629,15 +637,16 @@ __device__ __forceinline__ void gjk_closest(GjkSimplex& S, int lane) {
   const int i0 = bf == 3 ? 1 : 0, i1 = bf == 0 ? 1 : (bf == 1 ? 2 : 3), i2 = bf == 0 ? 2 : (bf == 1 ? 3 : (bf == 2 ? 1 : 2));
   const D3 a = S.pt(i0), b = S.pt(i1), c = S.pt(i2);
   auto code = [&](int i) { return i == 0 ? S.b0 : (i == 1 ? S.b1 : (i == 2 ? S.b2 : S.b3)); };
-  const int qa = code(i0), qb = code(i1), qc = code(i2);
+  auto vert = [&](int i) { return i == 0 ? S.i0 : (i == 1 ? S.i1 : (i == 2 ? S.i2 : S.i3)); };
+  const int qa = code(i0), qb = code(i1), qc = code(i2), ja = vert(i0), jb = vert(i1), jc = vert(i2);
   const GjkTri r = gjk_tri(a, b, c);
   WSYNC();
-  S.reduce(a, b, c, qa, qb, qc, r.keep, r.l0, r.l1, r.l2);
+  S.reduce(a, b, c, qa, qb, qc, ja, jb, jc, r.keep, r.l0, r.l1, r.l2);
   WSYNC();
 }
 
 template <class LDS>
-__device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int lane, int nact) {
+__device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int lane, int nact, float* __restrict__ gax) {      /* gax: the env's cached GJK results (contact cache row + PMC_AX), nullptr without the cache */
   const int g = lane >> 3, s = lane & 7;
   float* scr = &L.npscr[NPG_SCRATCH * g];
   float* sv = scr;
@@ -712,13 +721,19 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
         const int ca = __builtin_amdgcn_readlane(hc, src), cb = __builtin_amdgcn_readlane(bc, src);
         const bool flip = __builtin_amdgcn_readlane((int)hswap, src) != 0;      /* the pair's normal points from b toward a: from the hull toward the box when the hull is b */
         const float mg = lane_read(margin0, src);
+        /* what this pair's last GJK call left in the contact cache (issued now, used after the scan) */
+        const int pi_u = __builtin_amdgcn_readlane(pi, src);
+        float* gslot = gax ? gax + 8 * (pi_u & (PMC_AXN - 1)) : nullptr;
+        float4 gs1 = make_float4(0.f, 0.f, 0.f, 0.f); int gtag = 0;
+        if (gslot && m->gjk) { gtag = __float_as_int(gslot[0]); gs1 = *(const float4*)(gslot + 4); }      /* (the direction for the scan; the simplex is fetched when GJK is reached) */
+        const bool warm = gtag == pi_u + 1;
         const V3 hc0 = ld3(m->col_he[cb]);
         const V3 hcm = mk3(fmaxf(hc0.x, RP_HULL_MARGIN), fmaxf(hc0.y, RP_HULL_MARGIN), fmaxf(hc0.z, RP_HULL_MARGIN));      /* the box as the reference step's GJK sees it: core + margin, a box thinner than the margin comes out 0.001 thick (oracle hull_face) */
-        /* the box in the hull's body frame: a vertex v has the box coordinate u_k . v - c_k.  And one more direction, up / cp: of the fifteen directions of the box-box
-         * SAT on the link's OBB (one per lane) the one along which the OBB stays clearest of the box.  If even the OBB is clear by more than the margin there, the pair
-         * is apart (the diagonal arrangements - a link passing a table edge - that the six face directions let through); else the scan measures the HULL's own
-         * clearance along it on the way: three quarters of the pairs that the box's three axes cannot separate and GJK would find apart end there, in the one pass
-         * over the vertices that the face scan makes anyway */
+        /* the box in the hull's body frame: a vertex v has the box coordinate u_k . v - c_k.  First the link's OBB against the box over the fifteen directions of the box-box
+         * SAT (one per lane; oracle obb_apart): clear by more than the margin along one of them = apart - the diagonal arrangements, a link passing a table edge, that
+         * the six face directions let through.  And one more direction for the scan, up / cp: the direction this pair's last GJK call ended with (if the cache has
+         * one): the scan measures the hull's clearance from the box core along it on the way, and beyond the margin and the two shape margins the pair is apart
+         * without GJK (oracle hull_box_gjk, the cached direction's test) */
         V3 u0, u1, u2, up; float c0, c1, c2, cp; bool obb_apart;
         {
           const int body = m->col_body[ca];
@@ -753,13 +768,18 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
           gm = fmaxf(gm, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(gm), 0x141, 0xF, 0xF, true)));
           gm = fmaxf(gm, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(gm), 0x140, 0xF, 0xF, true)));
           gm = lane_read(gm, 0);
-          const int wl = __ffsll((long long)(__ballot(gap == gm) & 0xFFFFull)) - 1;      /* (first of equals; at least one lane of the first row holds the maximum) */
-          const float sg = lane_read(tl, wl) < 0.f ? -1.f : 1.f;                         /* from the box toward the hull */
-          const V3 Ls = mk3(lane_read(ax.x, wl) * sg, lane_read(ax.y, wl) * sg, lane_read(ax.z, wl) * sg);
           obb_apart = gm > mg + RP_HULL_MARGIN + 1e-5f;
-          up = tmulv(Rw, Ls);
-          const V3 hbc0 = mk3(hc0.x - fminf(RP_HULL_MARGIN, hc0.x), hc0.y - fminf(RP_HULL_MARGIN, hc0.y), hc0.z - fminf(RP_HULL_MARGIN, hc0.z));
-          cp = dot(Ls, tc) + hbc0.x * fabsf(dot(Ls, b0)) + hbc0.y * fabsf(dot(Ls, b1)) + hbc0.z * fabsf(dot(Ls, b2));      /* the box core's far end along it, seen from the body's origin */
+          up = mk3(0, 0, 0); cp = 0.f;
+          if (warm) {
+            const V3 vc = mk3(gs1.y, gs1.z, gs1.w);
+            const float l = norm(vc);
+            if (l > 0.f) {
+              const V3 vn = vc * (1.f / l);                 /* (box frame) */
+              const V3 hbc0 = mk3(hc0.x - fminf(RP_HULL_MARGIN, hc0.x), hc0.y - fminf(RP_HULL_MARGIN, hc0.y), hc0.z - fminf(RP_HULL_MARGIN, hc0.z));
+              up = u0 * vn.x + u1 * vn.y + u2 * vn.z;
+              cp = vn.x * c0 + vn.y * c1 + vn.z * c2 + hbc0.x * fabsf(vn.x) + hbc0.y * fabsf(vn.y) + hbc0.z * fabsf(vn.z);      /* the box core's far end along it */
+            }
+          }
         }
         if (obb_apart) {                                     /* (wave-uniform) */
           PCLK_ADD(15, 1ull << 48)
@@ -769,11 +789,17 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
         const int nn = m->hull_cnt[ca];
         const float4* tv = (const float4*)m->hullv + m->hull_off[ca];
         float lo0 = 1e30f, lo1 = 1e30f, lo2 = 1e30f, hi0 = -1e30f, hi1 = -1e30f, hi2 = -1e30f, pmin = 1e30f;
-        hull_scan<2>(tv, nn, lane, [&](const float4& v, int) {
-          const float l0 = hull_coord(u0, v, c0), l1 = hull_coord(u1, v, c1), l2 = hull_coord(u2, v, c2);
-          lo0 = fminf(lo0, l0); hi0 = fmaxf(hi0, l0); lo1 = fminf(lo1, l1); hi1 = fmaxf(hi1, l1); lo2 = fminf(lo2, l2); hi2 = fmaxf(hi2, l2);
-          pmin = fminf(pmin, hull_coord(up, v, cp));
-        });
+        bool in_core = false;                                /* a vertex strictly inside the box core: the cores overlap, GJK would only find that out the long way */
+        {
+          const V3 hin = mk3(hc0.x - fminf(RP_HULL_MARGIN, hc0.x) - 1e-6f, hc0.y - fminf(RP_HULL_MARGIN, hc0.y) - 1e-6f, hc0.z - fminf(RP_HULL_MARGIN, hc0.z) - 1e-6f);
+          hull_scan<2>(tv, nn, lane, [&](const float4& v, int) {
+            const float l0 = hull_coord(u0, v, c0), l1 = hull_coord(u1, v, c1), l2 = hull_coord(u2, v, c2);
+            lo0 = fminf(lo0, l0); hi0 = fmaxf(hi0, l0); lo1 = fminf(lo1, l1); hi1 = fmaxf(hi1, l1); lo2 = fminf(lo2, l2); hi2 = fmaxf(hi2, l2);
+            pmin = fminf(pmin, hull_coord(up, v, cp));
+            in_core |= fabsf(l0) < hin.x && fabsf(l1) < hin.y && fabsf(l2) < hin.z;
+          });
+        }
+        const bool core_hit = __ballot(in_core) != 0ull;
         lo0 = wave_min_f(lo0); lo1 = wave_min_f(lo1); lo2 = wave_min_f(lo2); hi0 = wave_max_f(hi0); hi1 = wave_max_f(hi1); hi2 = wave_max_f(hi2);
         pmin = wave_min_f(pmin);
         const float g0 = lo0 - hcm.x, g1 = -hi0 - hcm.x, g2 = lo1 - hcm.y, g3 = -hi1 - hcm.y, g4 = lo2 - hcm.z, g5 = -hi2 - hcm.z;      /* face +k: lowest vertex above it; face -k: highest vertex below it */
@@ -786,7 +812,7 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
         const float d = best - RP_HULL_MARGIN;
         /* the probe direction: cores farther apart than the margin and the two shape margins along it - what GJK's distance phase would end with (oracle
          * hull_box_gjk: "apart").  Only with GJK on: without it such a pair goes to the OBB path, which finds the OBBs apart all the same */
-        const bool probe_apart = m->gjk && pmin > mg + 2.f * RP_HULL_MARGIN + 1e-6f;
+        const bool probe_apart = m->gjk && warm && pmin > mg + 2.f * RP_HULL_MARGIN + 1e-6f;
         PCLK_ADD(15, 1 + ((d > mg) ? 65536 : 0) + ((probe_apart && !(d > mg)) ? (1ull << 32) : 0ull))               /* (profiling build: hull pairs scanned | of them apart << 16) */
         int out = 0;                                         /* this pair's hf */
         V3 nloc = mk3(0, 0, 0), ploc = mk3(0, 0, 0); float dcon = 0.f;      /* the contact in the BOX's frame: normal (box toward hull), point on the box's surface, distance */
@@ -813,7 +839,9 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
               dcon = d;
             } else if (probe_apart) {
               out = 0;                                       /* (only here: a vertex OVER the face within the margin is a contact whatever the probe says - it can be a
-                                                              * millimetre beside the box CORE's face and read 'apart' by a fraction of the shape margin) */
+                                                              * millimetre beside the box CORE's face and read 'apart' by a fraction of the shape margin.  The cache stays) */
+            } else if (m->gjk && core_hit) {
+              if (warm && lane == 0) gslot[0] = __int_as_float(0);      /* cores overlap: the OBB path (out = -1), and the pair's cached simplex goes (the oracle's GJK ends the same way) */
             } else if (m->gjk) {
               /* the deepest vertex lies BESIDE the face (box edges and corners): GJK's distance phase, cores with the 0.001 margin around each (oracle hull_box_gjk;
                * -1 again = the cores touch or overlap: the OBB path keeps that case).  Box frame, the simplex in registers, seeded with lv against the corner(s)
@@ -824,23 +852,38 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
               const int nout = (ox ? 1 : 0) + (oy ? 1 : 0) + (oz ? 1 : 0);
               /* (the simplex lives in the pair's scratch, and so does v while a scan runs and the scan's directions while the simplex is solved: the kernel has no registers for them) */
               double* Z = (double*)&L.npscr[NPG_SCRATCH * (src >> 3) + 8];
-              float* Y = &L.npscr[NPG_SCRATCH * (src >> 3) + 8 + 2 * 15];
-              static_assert((NPG_SCRATCH * 4) % 8 == 0 && NPG_SCRATCH >= 8 + 2 * 15 + 15, "the simplex: twelve doubles and v behind the staged point, 8-byte aligned; fifteen floats behind them");
+              float* Y = &L.npscr[NPG_SCRATCH * (src >> 3) + 8 + 2 * 18];
+              static_assert((NPG_SCRATCH * 4) % 8 == 0 && NPG_SCRATCH >= 8 + 2 * 18 + 15, "the simplex: twelve doubles and v behind the staged point, 8-byte aligned; fifteen floats behind them");
 #define GJK_PARK_DIRS() do { st3(Y, u0); st3(Y + 3, u1); st3(Y + 6, u2); st3(Y + 9, mk3(c0, c1, c2)); st3(Y + 12, hbc); asm volatile("" ::: "memory"); } while (0)
 #define GJK_FETCH_DIRS() do { asm volatile("" ::: "memory"); u0 = ld3(Y); u1 = ld3(Y + 3); u2 = ld3(Y + 6); { const V3 t_ = ld3(Y + 9); c0 = t_.x; c1 = t_.y; c2 = t_.z; } hbc = ld3(Y + 12); } while (0)
               GjkSimplex S;
-              S.W = Z; S.b1 = S.b2 = S.b3 = 0; S.l0 = 1.0; S.l1 = S.l2 = 0.0;
-              const int near = (lv.x >= 0.f ? 1 : 0) | (lv.y >= 0.f ? 2 : 0) | (lv.z >= 0.f ? 4 : 0);
-              S.b0 = near; S.n = 1;
+              S.W = Z; S.b1 = S.b2 = S.b3 = 0; S.i1 = S.i2 = S.i3 = 0;
               auto diffd = [](V3 a, V3 b) { return mkd((double)a.x - (double)b.x, (double)a.y - (double)b.y, (double)a.z - (double)b.z); };      /* w = a - b, in double from the fp32 points */
-              if (nout == 2) {                               /* the two ends of the nearest edge: along the one axis lv lies inside of */
-                const int fb = !ox ? 1 : (!oy ? 2 : 4);
-                S.b0 = near & ~fb; S.b1 = near | fb;
-                S.put(1, diffd(lv, GjkSimplex::corner(S.b1, hbc))); S.n = 2;
+              bool fail = false;
+              if (warm) {
+                /* the simplex this pair's last call ended with, at today's poses: its hull vertices (by number) against its box-core corners */
+                const float4 gs0 = *(const float4*)gslot;
+                const int nc = __float_as_int(gs0.y);
+                S.n = nc & 15; S.b0 = (nc >> 4) & 7; S.b1 = (nc >> 8) & 7; S.b2 = (nc >> 12) & 7;
+                S.i0 = __float_as_int(gs0.z); S.i1 = __float_as_int(gs0.w); S.i2 = __float_as_int(gslot[4]);
+                S.i0 = (unsigned)S.i0 < (unsigned)nn ? S.i0 : 0; S.i1 = (unsigned)S.i1 < (unsigned)nn ? S.i1 : 0; S.i2 = (unsigned)S.i2 < (unsigned)nn ? S.i2 : 0;
+                S.n = S.n < 1 ? 1 : (S.n > 3 ? 3 : S.n);
+                const float4 q0 = tv[S.i0], q1 = tv[S.i1], q2 = tv[S.i2];
+                S.put(0, diffd(mk3(hull_coord(u0, q0, c0), hull_coord(u1, q0, c1), hull_coord(u2, q0, c2)), GjkSimplex::corner(S.b0, hbc)));
+                S.put(1, diffd(mk3(hull_coord(u0, q1, c0), hull_coord(u1, q1, c1), hull_coord(u2, q1, c2)), GjkSimplex::corner(S.b1, hbc)));
+                S.put(2, diffd(mk3(hull_coord(u0, q2, c0), hull_coord(u1, q2, c1), hull_coord(u2, q2, c2)), GjkSimplex::corner(S.b2, hbc)));
+              } else {
+                const int near = (lv.x >= 0.f ? 1 : 0) | (lv.y >= 0.f ? 2 : 0) | (lv.z >= 0.f ? 4 : 0);
+                S.b0 = near; S.n = 1; S.i0 = S.i1 = iv;
+                if (nout == 2) {                             /* the two ends of the nearest edge: along the one axis lv lies inside of */
+                  const int fb = !ox ? 1 : (!oy ? 2 : 4);
+                  S.b0 = near & ~fb; S.b1 = near | fb;
+                  S.put(1, diffd(lv, GjkSimplex::corner(S.b1, hbc))); S.n = 2;
+                }
+                S.put(0, diffd(lv, GjkSimplex::corner(S.b0, hbc)));
+                fail = nout == 0;
               }
-              S.put(0, diffd(lv, GjkSimplex::corner(S.b0, hbc)));
               WSYNC();
-              bool fail = nout == 0;
               bool apart = false;
               D3 v = mkd(0, 0, 0); double dd = 0.0;
               if (!fail) {
@@ -854,9 +897,9 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
 #pragma unroll 1
               for (int it = 0; it < 32 && !fail; it++) {
                 PCLK_ADD(26, 1) PCLK_ADD(29, -(long long)__builtin_readcyclecounter())
-                V3 wa;
+                V3 wa; int wi;
                 const V3 vf = mk3((float)v.x, (float)v.y, (float)v.z);
-                Z[12] = v.x; Z[13] = v.y; Z[14] = v.z;
+                Z[15] = v.x; Z[16] = v.y; Z[17] = v.z;
                 asm volatile("" ::: "memory");
                 {                                            /* hull: the vertex of largest projection on -v (lowest index among equals) */
                   const V3 dl = -(u0 * vf.x + u1 * vf.y + u2 * vf.z);
@@ -866,12 +909,13 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
                     if (dq > bd) { bd = dq; bi = i; bq = mk3(q.x, q.y, q.z); }
                   });
                   const float top = wave_max_f(bd);
-                  const int win = wave_min_i(bd == top ? bi : 0x7fffffff) & 63;      /* (vertex i was scanned by lane i & 63) */
+                  wi = wave_min_i(bd == top ? bi : 0x7fffffff);
+                  const int win = wi & 63;                   /* (vertex i was scanned by lane i & 63) */
                   const V3 q = mk3(lane_read(bq.x, win), lane_read(bq.y, win), lane_read(bq.z, win));
                   wa = mk3(hull_coord(u0, make_float4(q.x, q.y, q.z, 0.f), c0), hull_coord(u1, make_float4(q.x, q.y, q.z, 0.f), c1), hull_coord(u2, make_float4(q.x, q.y, q.z, 0.f), c2));
                 }
                 asm volatile("" ::: "memory");
-                v = mkd(Z[12], Z[13], Z[14]);
+                v = mkd(Z[15], Z[16], Z[17]);
                 PCLK_ADD(29, __builtin_readcyclecounter()) PCLK_ADD(30, -(long long)__builtin_readcyclecounter())
                 const int wb = (vf.x >= 0.f ? 1 : 0) | (vf.y >= 0.f ? 2 : 0) | (vf.z >= 0.f ? 4 : 0);      /* box core: the corner of largest projection on v */
                 const D3 w = diffd(wa, GjkSimplex::corner(wb, hbc));
@@ -884,7 +928,7 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
                   dw = S.pt(2) - w; dup |= S.n > 2 && ddot(dw, dw) < GJK_DUP; }
                 if (dup || vv - vw <= GJK_REL * vv) { PCLK_ADD(30, __builtin_readcyclecounter()) break; }
                 S.put(S.n, w);
-                if (S.n == 1) S.b1 = wb; else if (S.n == 2) S.b2 = wb; else S.b3 = wb;
+                if (S.n == 1) { S.b1 = wb; S.i1 = wi; } else if (S.n == 2) { S.b2 = wb; S.i2 = wi; } else { S.b3 = wb; S.i3 = wi; }
                 S.n++;
                 WSYNC();
                 PCLK_ADD(30, __builtin_readcyclecounter()) PCLK_ADD(31, -(long long)__builtin_readcyclecounter())
@@ -904,6 +948,12 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
               PCLK_ADD(28, __builtin_readcyclecounter())
               const double distd = sqrt(ddot(v, v));
               PCLK_ADD(27, apart ? (1ull << 16) : (fail ? (1ull << 48) : 0ull))
+              if (gslot && lane == 0) {                      /* what the next call of this pair starts from (oracle GAX_STORE / GAX_CLEAR) */
+                if (!fail && (apart || distd > GJK_ZERO)) {
+                  *(float4*)gslot = make_float4(__int_as_float(pi_u + 1), __int_as_float(S.n | (S.b0 << 4) | ((S.n > 1 ? S.b1 : 0) << 8) | ((S.n > 2 ? S.b2 : 0) << 12)), __int_as_float(S.i0), __int_as_float(S.n > 1 ? S.i1 : 0));
+                  *(float4*)(gslot + 4) = make_float4(__int_as_float(S.n > 2 ? S.i2 : 0), (float)v.x, (float)v.y, (float)v.z);
+                } else if (warm) gslot[0] = __int_as_float(0);
+              }
               if (apart) out = 0;
               else if (!fail && distd > GJK_ZERO) {
                 const float dist = (float)distd;
@@ -1217,7 +1267,7 @@ __device__ __forceinline__ int collide(const DevModel* m, LDS& L, int lane, int 
   if (lane == 0) g_clk[32 * (blockIdx.x & 4095) + 12] = nact;
 #endif
   /* 2. narrowphase: eight lanes per active pair */
-  narrowphase_coop(m, L, lane, nact);
+  narrowphase_coop(m, L, lane, nact, m->persist ? m->pmcache + (size_t)env * PMC_FLOATS + PMC_AX : nullptr);
   WSYNC();
   PCLK(9)
   /* 3. manifolds: one per run of equal object pairs, <= 4 points (1 for a rotation-locked body against the world).  A manifold's size
@@ -1236,7 +1286,7 @@ __device__ __forceinline__ int collide(const DevModel* m, LDS& L, int lane, int 
      * drift; the last point takes the slot); (e) the surviving points - the deepest alone for a rotation-locked body against the static world - go to
      * L.man as this substep's records, the cache goes back to memory. */
     float* C = L.npscr + 8 * MANPTS;
-    static_assert(8 * MANPTS + PMC_FLOATS <= NPSCR_FLOATS, "the staged contact cache lies behind L.man in the narrowphase scratch");
+    static_assert(8 * MANPTS + PMC_MANIFOLDS <= NPSCR_FLOATS, "the staged contact cache lies behind L.man in the narrowphase scratch");
     float* g = m->pmcache + (size_t)env * PMC_FLOATS;
     /* only the manifolds in use - typically four of eleven - are loaded and stored: their count is the row's first word (k_prep2 has it fetched with the state
      * record by its other wave: npm_early; the one-kernel path reads it here) */
@@ -2986,10 +3036,10 @@ static_assert(W3_A % 4 == 0 && W3_ROWS % 4 == 0 && W3_ROFF % 4 == 0 && AOUT_FLOA
 
 #define PREP_THREADS 128
 /* one env's preparation by the two waves of a block: L = the block's PrepLds, env = the env, cenv = the env whose contact cache it uses (rp_reset settles in a dense
- * scratch range: the cache stays the env's own), pair_out = where this env's entry of the pairing table goes (env | contact count << 24; stored by wave 1, lane 0).
+ * scratch range: the cache stays the env's own), pair_tab[pair_idx] = this env's entry of the pairing table (env | contact count << 24; stored by wave 1, lane 0).
  * Ends without a barrier: the caller synchronises before L is used again. */
 __device__ __forceinline__ void prep2_core(PrepLds& L, const DevModel* __restrict__ m, const float* __restrict__ state, float* __restrict__ ws, const int env, const int cenv,
-                                           int* __restrict__ pair_out) {
+                                           int* __restrict__ pair_tab, const int pair_idx) {      /* (table and index apart: a per-thread pointer held across the whole kernel costs two registers, and this kernel spills for less) */
   const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
   PCLK(6) PCLK(0) PCLK_ZERO(15) PCLK_ZERO(26) PCLK_ZERO(27) PCLK_ZERO(28) PCLK_ZERO(29) PCLK_ZERO(30) PCLK_ZERO(31)
   static_assert(RP_REC_FLOATS == PREP_THREADS, "one float of the record per thread");
@@ -3113,7 +3163,7 @@ __device__ __forceinline__ void prep2_core(PrepLds& L, const DevModel* __restric
     copy_out(w + W3_ROFF, (const float*)L.roff, 64, lane);
     copy_out(w + W3_SLOT, (const float*)L.slot, 64, lane);
   } else {
-    if (lane == 0) *pair_out = env | (ncon << 24);     /* + its contact count: k_solve2 sizes its row copy without waiting for the header */
+    if (lane == 0) pair_tab[pair_idx] = env | (ncon << 24);     /* + its contact count: k_solve2 sizes its row copy without waiting for the header */
   }
   PCLK(5) PCLK(7)
 }
@@ -3145,7 +3195,7 @@ __device__ __forceinline__ void prep2_body(const DevModel* __restrict__ m, const
     for (int d = 32; d >= 1; d >>= 1) above += __shfl_xor(above, d);
     pair_place = above + (my_slot & SORT_RANK_MASK);
   }
-  prep2_core(L, m, state, ws, env, cache_env ? cache_env[env] : env, pair_env + env0 + pair_place);
+  prep2_core(L, m, state, ws, env, cache_env ? cache_env[env] : env, pair_env, env0 + pair_place);
 }
 /* two entry points on the same body: rp_step's substeps, and the settle substeps of rp_reset under their own name so that
  * profiles keep the two apart */
@@ -3977,8 +4027,8 @@ template <class T> __device__ __forceinline__ T* uniform_ptr(T* p) {
   const unsigned long long v = (unsigned long long)p;
   return (T*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v));
 }
-__device__ __attribute__((noinline)) void chain_prep(PrepLds* L, const DevModel* m, const float* state, float* ws, int env, int* pair_out) {
-  prep2_core(*uniform_ptr(L), uniform_ptr(m), uniform_ptr(state), uniform_ptr(ws), uni(env), uni(env), uniform_ptr(pair_out));
+__device__ __attribute__((noinline)) void chain_prep(PrepLds* L, const DevModel* m, const float* state, float* ws, int env, int* pair_tab, int place) {
+  prep2_core(*uniform_ptr(L), uniform_ptr(m), uniform_ptr(state), uniform_ptr(ws), uni(env), uni(env), uniform_ptr(pair_tab), uni(place));
 }
 __device__ __attribute__((noinline)) void chain_solve(const DevModel* m, float* state, const float* ws, int N, const int* pair_tab, int* sort_cnt_next, int* sort_slot, int flags, Solve2Lds* Ls, int q) {
   solve_block(uniform_ptr(m), uniform_ptr(state), uniform_ptr(ws), 0, uni(N), uniform_ptr(pair_tab), uniform_ptr(sort_cnt_next), uniform_ptr(sort_slot), uni(flags), uniform_ptr(Ls), uni(q));
@@ -4002,7 +4052,7 @@ __global__ void __launch_bounds__(64 * SOLVE_WAVES, 2) k_chain(const DevModel* _
         const int place = 4 * q + k;
         if (place < N) {                                           /* (block-uniform) */
           const int env = member ? member[place] : place;
-          chain_prep(&L.P, m, state, ws, env, pair_tab + place);
+          chain_prep(&L.P, m, state, ws, env, pair_tab, place);
         }
         __syncthreads();                                           /* the next env's preparation (or the solve) takes the LDS over; this env's rows and its table entry are visible to the block */
       }
