@@ -192,6 +192,16 @@ static_assert(sizeof(PrepLds) <= 16384, "k_prep2: ten blocks (twenty waves) per 
 static_assert(offsetof(PrepLds, roff) % 16 == 0 && offsetof(PrepLds, slot) % 16 == 0 && offsetof(PrepLds, Minv) % 16 == 0 && offsetof(PrepLds, aout) % 16 == 0 &&
               offsetof(PrepLds, Md) % 8 == 0 && offsetof(PrepLds, cand) % 16 == 0 && offsetof(PrepLds, man) % 16 == 0, "16-byte copies out of LDS");
 
+/* ObsLds: k_calc_state alone - the record, the body transforms (and fk_bodies' scratch), the joint subspaces, the output block: 2.8 KB instead of EnvLds' 17, so that
+ * every env of a 4096-env step is resident at once (EnvLds: six blocks per CU, three rounds - 0.048 ms for a kernel that assembles an observation) */
+struct __align__(16) ObsLds {
+  float st[RP_REC_FLOATS];
+  float xR[NB_MAX * 9], xp[NB_MAX * 3];
+  float O[4];
+  float S[RP_MAX_ARM * 6];
+  alignas(16) float cand[2 * 12 * RP_MAX_ARM + 2 * RP_MAX_ARM + 4];      /* (fk_bodies' scratch) */
+  alignas(16) float out[O_FLOATS];
+};
 #ifdef RP_CLOCKS      /* profiling build only: per-wave phase timestamps of the last k_solve2 (1) / k_prep2 (2) launch */
 __device__ unsigned long long g_clk[32 * 4096];
 #define CLK_MARK(i) if (lane == 0) { g_clk[8 * wb + (i)] = __builtin_readcyclecounter(); }      /* (k_solve2: wb = the wave's number in the launch) */
@@ -352,7 +362,7 @@ __device__ __forceinline__ Xf joint_compose(const DevModel* m, const Xf& P, int 
 template <class LDS>
 __device__ __forceinline__ void fk_bodies(const DevModel* m, LDS& L, int lane) {
   float* T = L.cand;                     /* two buffers of 12 links x (R row-major, p), then 2 x 12 ancestor indices; dead space until collide() */
-  static_assert(2 * 12 * RP_MAX_ARM + 2 * RP_MAX_ARM <= CANDMAX * 8, "fk scratch fits the candidate list");
+  static_assert(2 * 12 * RP_MAX_ARM + 2 * RP_MAX_ARM <= CANDMAX * 8 && 2 * 12 * RP_MAX_ARM + 2 * RP_MAX_ARM <= (int)(sizeof(L.cand) / sizeof(float)), "fk scratch fits the candidate list");
   int* P = (int*)(T + 2 * 12 * RP_MAX_ARM);
   const int n = m->n_arm;
   Xf x; x.R = ident3(); x.p = mk3(0, 0, 0);
@@ -2364,7 +2374,8 @@ __device__ ChainQ perform_action(const DevModel* m, EnvLds& L, int lane, const f
 /* ------------------------------------------------------------------ observation / reward */
 __device__ __forceinline__ float dial01(float x) { float mod = x - 2.f * floorf(x * 0.5f); return (mod * RP_PI_F) / (2.2f * RP_PI_F); }
 
-__device__ __forceinline__ V3 site_pos_world(const DevModel* m, const EnvLds& L, int s) {
+template <class LDS>
+__device__ __forceinline__ V3 site_pos_world(const DevModel* m, const LDS& L, int s) {
   int b = m->site_body[s];
   return ld3(&L.xp[3 * b]) + mulv(ldm3(&L.xR[9 * b]), ld3(m->site_pos[s]));
 }
@@ -2438,7 +2449,8 @@ __device__ __forceinline__ void flip_quat(float* v, const float* last) {
 #endif
 
 /* calc_state (environments.py:799-864): transforms must be current (fk_bodies). Stateful in play mode. */
-__device__ void calc_state(const DevModel* m, EnvLds& L, int lane) {
+template <class LDS>
+__device__ void calc_state(const DevModel* m, LDS& L, int lane) {
   fk_bodies(m, L, lane);
   __syncthreads();
   joint_subspaces(m, L, lane);
@@ -2569,7 +2581,8 @@ struct OutPtrs {
   float* pack;            /* [N, n_obs + n_ag + 2]: obs_quat | achieved_goal | reward | is_success (rp_out.pack) */
 };
 
-__device__ void write_outputs(const DevModel* m, const EnvLds& L, int lane, int env, const OutPtrs& o) {
+template <class LDS>
+__device__ void write_outputs(const DevModel* m, const LDS& L, int lane, int env, const OutPtrs& o) {
   const float* s = L.out;
   if (o.obs_quat && lane < m->n_obs) o.obs_quat[(size_t)env * m->n_obs + lane] = s[O_OBS + lane];
   if (o.achieved_goal && lane < m->n_ag) o.achieved_goal[(size_t)env * m->n_ag + lane] = s[O_AG + lane];
@@ -2602,7 +2615,8 @@ __device__ __forceinline__ void load_state(LDS& L, const float* state, int env, 
   L.st[lane + 64] = r[lane + 64];
   __syncthreads();
 }
-__device__ __forceinline__ void store_state(const EnvLds& L, float* state, int env, int lane) {
+template <class LDS>
+__device__ __forceinline__ void store_state(const LDS& L, float* state, int env, int lane) {
   __syncthreads();
   float* r = state + (size_t)env * RP_REC_FLOATS;
   r[lane] = L.st[lane];
@@ -2630,7 +2644,7 @@ __global__ void __launch_bounds__(64, RP_WAVES_PER_EU) k_step(const DevModel* __
 
 __global__ void __launch_bounds__(64) k_calc_state(const DevModel* __restrict__ m, float* __restrict__ state, OutPtrs out, int env0, int N,
                                                    const int* __restrict__ member) {
-  __shared__ EnvLds L;
+  __shared__ ObsLds L;
   int env = env0 + blockIdx.x, lane = threadIdx.x;
   if (env >= N) return;
   if (member) env = member[env];          /* place in the group -> env (groups are cut by load, see k_member) */
