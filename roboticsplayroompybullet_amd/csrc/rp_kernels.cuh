@@ -663,7 +663,6 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
   float (*poly)[8][3] = (float (*)[8][3])(scr + 16);
   float (*kept)[4] = (float (*)[4])(scr + 64);
   const unsigned below = (1u << s) - 1u;
-  const unsigned long long lower_groups = (1ull << (8 * g)) - 1ull;      /* lanes of the groups before this one */
   int cbase = 0;                                    /* candidate points stored so far (wave-uniform) */
   for (int base = 0; base < nact; base += 64 / NPG) {      /* wave-uniform trip count; every lane reaches every barrier */
     const int ai = base + g;
@@ -1201,6 +1200,9 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
       np = outn;
     }
     /* the pair's points go to the compact candidate list, pairs in order; the list ends at CANDMAX points (the oracle's rule) */
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));                     /* (recomputed here, opaque: a 64-bit mask held across the hull scans is a register pair they spill for) */
+    const unsigned long long lower_groups = (1ull << (lane_o & ~7)) - 1ull;      /* lanes of the groups before this one */
     const int npl = (act && s == 0) ? np : 0;                /* the group's count, at its first lane */
     int off = cbase, tot = 0;
 #pragma unroll
@@ -3058,6 +3060,7 @@ __device__ __forceinline__ void prep2_core(PrepLds& L, const DevModel* __restric
   PCLK(6) PCLK(0) PCLK_ZERO(15) PCLK_ZERO(26) PCLK_ZERO(27) PCLK_ZERO(28) PCLK_ZERO(29) PCLK_ZERO(30) PCLK_ZERO(31)
   static_assert(RP_REC_FLOATS == PREP_THREADS, "one float of the record per thread");
   L.st[tid] = state[(size_t)env * RP_REC_FLOATS + tid];
+  if (tid == 64) L.hdr[3] = pair_idx;                        /* (waits in LDS for the end of the kernel: a register held across both phases is one the narrowphase spills for) */
   if (tid == 64 && m->persist) L.hdr[2] = __float_as_int(m->pmcache[(size_t)cenv * PMC_FLOATS]);      /* the cache's manifold count, for collide() */
   __syncthreads();
   PCLK(16)
@@ -3118,7 +3121,12 @@ __device__ __forceinline__ void prep2_core(PrepLds& L, const DevModel* __restric
   }
   __syncthreads();            /* the join: contacts (wave 0) and M^-1, v*, joint subspaces (wave 1) are there; aout and the dynamics scratch are dead */
   const int ncon = L.hdr[0];
-  if (wid == 0) {
+  int tid_j = threadIdx.x;
+  asm volatile("" : "+v"(tid_j));      /* (the thread's numbers once more, opaque to the compiler: what the phases above derived from them need not survive those phases) */
+  const int wid_j = tid_j >> 6;
+  if (wid_j == 0) {
+    const int lane = tid_j & 63;
+    float* w = ws + (size_t)env * W3_FLOATS;
     /* contact classes (collide() ordered them): rank inside the class -> slot tables for k_solve2 */
     const int cls = lane < ncon ? L.conk[lane] : 3;
     const unsigned long long mB = __ballot(cls == 0), mA = __ballot(cls == 1), mC = __ballot(cls == 2);
@@ -3177,7 +3185,7 @@ __device__ __forceinline__ void prep2_core(PrepLds& L, const DevModel* __restric
     copy_out(w + W3_ROFF, (const float*)L.roff, 64, lane);
     copy_out(w + W3_SLOT, (const float*)L.slot, 64, lane);
   } else {
-    if (lane == 0) pair_tab[pair_idx] = env | (ncon << 24);     /* + its contact count: k_solve2 sizes its row copy without waiting for the header */
+    if ((tid_j & 63) == 0) pair_tab[L.hdr[3]] = env | (ncon << 24);     /* + its contact count: k_solve2 sizes its row copy without waiting for the header */
   }
   PCLK(5) PCLK(7)
 }
