@@ -3236,7 +3236,12 @@ __global__ void __launch_bounds__(PREP_THREADS, RP_PREP_WAVES) k_action_prep(con
                                                                    const int* __restrict__ sort_cnt, int* __restrict__ sort_cnt_next, const int* __restrict__ sort_slot,
                                                                    int* __restrict__ pair_env, const int* __restrict__ member, const float* __restrict__ action,
                                                                    float* __restrict__ target_poses, int nab) {
-  if ((int)blockIdx.x < nab) action_body(m, state, action, target_poses, env0, N, member, blockIdx.x);
+  if ((int)blockIdx.x < nab) {
+    /* the IK is the launch's long pole (80 dependent iterations, one wave per SIMD) and the preparation blocks beside it have 150 us of slack: its waves go first
+     * wherever both want the same issue slot */
+    __builtin_amdgcn_s_setprio(3);
+    action_body(m, state, action, target_poses, env0, N, member, blockIdx.x);
+  }
   else prep2_body(m, state, ws, env0, N, sort_cnt, sort_cnt_next, sort_slot, pair_env, member, blockIdx.x - nab);
 }
 
