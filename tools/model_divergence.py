@@ -9,8 +9,8 @@ onto the block, close, lift: the contact-rich case) - N envs are reset once by m
     joints  the same over all dofs, the gripper's auxiliary joints included (north_star's "relative joint-state divergence")
     block   max over steps of |block position A - B| in metres
 as median / 90th percentile / max over the envs.  Rows:
-    A default      the shipped model: Bullet's row order and limit rule, hull vertices against static boxes, arm boxes overlap-only, box-box points in the
-                   detector's order, per-body lever arms, torsional friction rows, persistent manifolds (a uniform margin `A m=...` switches those off: it is a study
+    A default      the shipped model: Bullet's row order and limit rule, hull vertices against static and movable boxes, GJK's distance phase where the deepest vertex lies
+                   beside the face (since round 4), arm boxes overlap-only, box-box points in the detector's order, per-body lever arms, torsional friction rows, persistent manifolds (a uniform margin `A m=...` switches those off: it is a study
                    of the stateless contacts)
     A round 2      last round's model (rule 0); A -x: the shipped model with one of its round-3 features off
     A m=...        the same model with one uniform contact margin (0, 5 mm = round 1's choice, 20 mm = gContactBreakingThreshold taken absolute)
@@ -86,10 +86,10 @@ def main():
     D = oracle.REF_DEFAULT
     # the shipped model's rule bits (rp_oracle.c RPO_RULE_*): 1 Bullet's row order, 2 violated-only limits, 4 hull vertices against static boxes, 16 arm boxes overlap-only,
     # 32 box-box points in the detector's order, 64 per-body lever arms, 128 torsional friction rows, 256 persistent manifolds, 512 hull vertices against movable boxes too, 1024 GJK's distance phase beside the face
-    ALL = 503 | 512
+    ALL = 503 | 512 | 1024
     variants = [('A default (shipped)', dict()), ('A round 2 (rule 0)', dict(rule=0)), ('A -order -limit', dict(rule=ALL & ~3)), ('A -hull', dict(rule=ALL & ~4)),
-                ('A -boxorder', dict(rule=ALL & ~32)), ('A -lever', dict(rule=ALL & ~64)), ('A -spin', dict(rule=ALL & ~128)), ('A -persist', dict(rule=ALL & ~256)), ('A -hullmov', dict(rule=ALL & ~512)), ('A +gjk', dict(rule=ALL | 1024)),
-                ('A -persist -hullmov -boxorder -lever -spin', dict(rule=23)), ('A -persist -boxoverlap', dict(rule=ALL & ~256 & ~16)),
+                ('A -boxorder', dict(rule=ALL & ~32)), ('A -lever', dict(rule=ALL & ~64)), ('A -spin', dict(rule=ALL & ~128)), ('A -persist', dict(rule=ALL & ~256)), ('A -hullmov', dict(rule=ALL & ~512)), ('A -gjk (= RP_CFG_OBB_EDGES, round 3\'s default)', dict(rule=ALL & ~1024)), ('A -limit (= RP_CFG_SPECULATIVE_LIMITS)', dict(rule=ALL & ~2)),
+                ('A -persist -hullmov -boxorder -lever -spin -gjk (round 3\'s first model)', dict(rule=23)), ('A -persist -boxoverlap', dict(rule=ALL & ~256 & ~16)),
                 ('A m=0', dict(margin=0.0)), ('A m=5mm', dict(margin=0.005)), ('A m=20mm', dict(margin=0.02))]
     for name, bit in oracle.REF_FLAGS.items():
         if name == 'warm':
