@@ -3256,6 +3256,20 @@ struct __align__(16) Solve2Lds {
 #endif
 };
 
+/* The two-env path's contact-row registers: six values per slot (J and B of the normal and of both friction rows), 21 slots.  They are FILLED by a rolled loop through a
+ * wave-uniform index (VGPR indexing mode: s_set_gpr_idx_on / v_mov / off) and USED by the sweeps with constant indices.  Slots 0..15 of value a: element s of lo[a];
+ * slots 16..20: element 5 (a mod 3) + s - 16 of hi[a / 3] - 16-wide vectors throughout, which is what the backend indexes in place (an 8-wide one it expands into
+ * a chain of selects), 128 registers for 126 values. */
+typedef float f16v __attribute__((ext_vector_type(16)));
+struct RowRegs {
+  f16v lo[6], hi[2];
+  __device__ __forceinline__ float get(int a, int s) const { return s < 16 ? lo[a][s] : hi[a / 3][5 * (a % 3) + s - 16]; }
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int a = 0; a < 6; a++) lo[a] = (f16v)(0.f);
+    hi[0] = (f16v)(0.f); hi[1] = (f16v)(0.f);
+  }
+};
 /* DPP butterfly inside each 16-lane row: every lane ends with the sum over its row */
 __device__ __forceinline__ float row16_sum(float v) {
   int x = __float_as_int(v);
@@ -3365,6 +3379,12 @@ __device__ __forceinline__ void generic_row(float Jr, float Br, float& dv, Plane
 }
 
 #define SOLVE_WAVES 2                 /* k_solve2 waves per block */
+#ifdef RP_PROLOGUE_CLOCKS      /* profiling build: where the two-env path's prologue spends its time (tools/gpu_prologue_clocks.py) */
+__device__ unsigned long long g_pclk[8 * 4096];
+#define PRO_MARK(i) if (lane == 0) g_pclk[8 * (wb & 4095) + (i)] = __builtin_readcyclecounter();
+#else
+#define PRO_MARK(i)
+#endif
 /* a pair_env entry carries its env's contact count in the top byte.  The mask is inline asm on purpose: written in C, hipcc (ROCm 7.2) can drop it - in
  * solve4_eligible it turned (pe & 0xFFFFFF) * W3_FLOATS into a 24-bit multiply and then widened that to v_mad_u64_u32 on the unmasked register: wild
  * address, aperture violation */
@@ -3388,6 +3408,7 @@ __device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, floa
 #ifdef RP_SOLVE_PAD_KB
   if (N < 0) L.pad[lane] = 0.f;
 #endif
+  PRO_MARK(0)
   /* this wave's two envs: places 2b and 2b + 1 among the group's envs sorted by load class, heaviest first (table built
    * by the k_prep2 before this launch) */
   const int place = wb * 2 + half;
@@ -3416,6 +3437,7 @@ __device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, floa
   const bool par = nS_w + nC_w <= MAXC && !(debug_flags & 1);      /* debug flag 1 (tests): always take the fallback */
 #endif
   const int nS = par ? nS_w : 0, nC = par ? nC_w : nc_w;
+  PRO_MARK(1)      /* header there */
   const int dd = lane_dof(m, l);            /* velocity component owned by this lane, -1 if none */
   /* contact rows first: 16-byte coalesced copies of the slot tables and the compact rows into LDS (a per-lane gather
    * straight from memory costs one 16-cycle vector-memory instruction per row and array) */
@@ -3484,7 +3506,9 @@ __device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, floa
    * both rows (folded).  Two fixed ends keep the sweep's control flow two plain early-exit chains (a jump into the
    * middle of a chain makes the compiler build a flag-driven state machine).  contact_of(s) is this lane's contact
    * index in slot s, -1 if none. */
+  PRO_MARK(2)      /* plane / unit-row loads issued */
   WSYNC();
+  PRO_MARK(3)      /* staging copy landed */
   const float* S = L.stage[half];
   auto contact_of = [&](int s) {
     int c;
@@ -3511,12 +3535,22 @@ __device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, floa
 #pragma unroll
     for (int d = 0; d < 2; d++) { PF[d][r].rhs = ldz(&w[W3_ROWS + 4 * ((on ? my_nc : 0) + 2 * cc + d)], on); PF[d][r].lo = 0.f; PF[d][r].hi = 0.f; }
   }
+  PRO_MARK(4)      /* normal / friction plane loads issued */
   /* contact rows: compact (two body slots) -> lane-dense registers, from the LDS copy */
-  float JN[MAXC], BN[MAXC], JF[2][MAXC], BF[2][MAXC];
+  /* A ROLLED loop over the slots in use.  The waves of this path are few - a dozen per launch, on as many CUs - and whatever they execute once they fetch cold: unrolled
+   * (1 700 instructions) this gather ran at 15 cycles per instruction, 27 k of the prologue's 40 k cycles, against 6.6 k when the same code ran a second time
+   * (tools/gpu_prologue_clocks.py: instruction fetch, not the LDS, was the bound).  One iteration of ~100 instructions is fetched once. */
+  RowRegs RR;
+  RR.zero();
+#define JN_(s) RR.get(0, s)
+#define BN_(s) RR.get(1, s)
+#define JF_(r, s) RR.get(2 + 2 * (r), s)
+#define BF_(r, s) RR.get(3 + 2 * (r), s)
   {
-#pragma unroll
-    for (int s = 0; s < MAXC; s++) {
-      if (s >= nS && MAXC - 1 - s >= nC) { JN[s] = BN[s] = JF[0][s] = BF[0][s] = JF[1][s] = BF[1][s] = 0.f; continue; }      /* (wave-uniform) neither env of the wave has a contact in this slot: no LDS gathers, no index arithmetic - a coupled env fills 8 - 10 of the 21 */
+#pragma unroll 1
+    for (int s0 = 0; s0 < MAXC; s0++) {
+      int s = __builtin_amdgcn_readfirstlane(s0);
+      if (s >= nS && MAXC - 1 - s >= nC) { s0 = MAXC - 1 - nC; if (s0 < s) s0 = s; continue; }      /* (wave-uniform) the empty slots between the side-by-side ones and the folded ones */
       const int c = contact_of(s);
       const bool used = c >= 0;
       /* this lane's entry in the contact's compact rows: the normal and both friction rows share the two body slots */
@@ -3525,12 +3559,10 @@ __device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, floa
       const int idx = (unsigned)i1 < 6u ? 12 + i1 : ((unsigned)i0 < 12u ? i0 : -1);
       const bool ok = used && dd >= 0 && idx >= 0;
       const int rn = ROWW * c + idx, rf = ROWW * (my_nc + 2 * c) + idx;
-      JN[s] = S[ok ? 128 + rn : 63];                                    /* no select after the read: absent entries read a stored 0 */
-      BN[s] = S[ok ? 128 + ROWREG + rn : 63];
-      JF[0][s] = S[ok ? 128 + rf : 63];
-      BF[0][s] = S[ok ? 128 + ROWREG + rf : 63];
-      JF[1][s] = S[ok ? 128 + rf + ROWW : 63];
-      BF[1][s] = S[ok ? 128 + ROWREG + rf + ROWW : 63];
+      const float v0 = S[ok ? 128 + rn : 63], v1 = S[ok ? 128 + ROWREG + rn : 63], v2 = S[ok ? 128 + rf : 63], v3 = S[ok ? 128 + ROWREG + rf : 63],
+                  v4 = S[ok ? 128 + rf + ROWW : 63], v5 = S[ok ? 128 + ROWREG + rf + ROWW : 63];      /* no select after the read: absent entries read a stored 0 */
+      if (s < 16) { RR.lo[0][s] = v0; RR.lo[1][s] = v1; RR.lo[2][s] = v2; RR.lo[3][s] = v3; RR.lo[4][s] = v4; RR.lo[5][s] = v5; }
+      else { const int k = s - 16; RR.hi[0][k] = v0; RR.hi[0][5 + k] = v1; RR.hi[0][10 + k] = v2; RR.hi[1][k] = v3; RR.hi[1][5 + k] = v4; RR.hi[1][10 + k] = v5; }
     }
   }
 #pragma unroll
@@ -3562,6 +3594,7 @@ __device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, floa
       JT[t] = ldz(&w[W3_J + ROWW * r + (ok ? idx : 0)], ok); BT[t] = ldz(&w[W3_B + ROWW * r + (ok ? idx : 0)], ok);
     }
   }
+  PRO_MARK(5)      /* gathers done */
   WSYNC();                          /* rows are in registers: the staging area becomes the state records */
   {
     float* st = L.st[half];
@@ -3569,6 +3602,7 @@ __device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, floa
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);    /* vmcnt(0): all row registers have landed before the sweep loop */
   WSYNC();
+  PRO_MARK(6)
   CLK_MARK2(1)
   /* counting sort by load class for the NEXT substep's pairing (the classes of this substep stand in for the next one's:
    * which two envs share a wave never changes any result - absent rows are exact no-ops - it only decides how long the
@@ -3631,11 +3665,11 @@ __device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, floa
     plane_end(X0); plane_end(PL); plane_end(PU);
     /* contact normals: side-by-side slots while they last, then the folded slots.  Contacts are prefixes of both
      * ranges, so the guards are early exits: nothing is spent on absent slots */
-#define NRM_P(s) if (nS_it <= (s)) goto nrm_pdone; generic_row<(s), false>(JN[s], BN[s], dv, PN[(s) >> 4], l16, PN[(s) >> 4].rhsE);
+#define NRM_P(s) if (nS_it <= (s)) goto nrm_pdone; generic_row<(s), false>(JN_(s), BN_(s), dv, PN[(s) >> 4], l16, PN[(s) >> 4].rhsE);
     REP21(NRM_P)
 #undef NRM_P
   nrm_pdone:
-#define NRM_C(j) if (nC_it <= (j)) goto nrm_done; generic_row<MAXC - 1 - (j), true>(JN[MAXC - 1 - (j)], BN[MAXC - 1 - (j)], dv, PN[(MAXC - 1 - (j)) >> 4], l16, PN[(MAXC - 1 - (j)) >> 4].rhsE);
+#define NRM_C(j) if (nC_it <= (j)) goto nrm_done; generic_row<MAXC - 1 - (j), true>(JN_(MAXC - 1 - (j)), BN_(MAXC - 1 - (j)), dv, PN[(MAXC - 1 - (j)) >> 4], l16, PN[(MAXC - 1 - (j)) >> 4].rhsE);
     REP21(NRM_C)
 #undef NRM_C
   nrm_done:
@@ -3655,13 +3689,13 @@ __device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, floa
       fplane_begin(PF[0][0], muN[0] * PN[0].lam, PN[0].lam); fplane_begin(PF[1][0], muN[0] * PN[0].lam, PN[0].lam);
       fplane_begin(PF[0][1], muN[1] * PN[1].lam, PN[1].lam); fplane_begin(PF[1][1], muN[1] * PN[1].lam, PN[1].lam);
       PLANE_FENCE4(PF[0][0], PF[1][0], PF[0][1], PF[1][1]);
-#define FRC_P(s) if (nS_it <= (s)) goto frc_pdone; generic_row<(s), false>(JF[0][s], BF[0][s], dv, PF[0][(s) >> 4], l16, PF[0][(s) >> 4].rhs); \
-                 generic_row<(s), false>(JF[1][s], BF[1][s], dv, PF[1][(s) >> 4], l16, PF[1][(s) >> 4].rhs);
+#define FRC_P(s) if (nS_it <= (s)) goto frc_pdone; generic_row<(s), false>(JF_(0, s), BF_(0, s), dv, PF[0][(s) >> 4], l16, PF[0][(s) >> 4].rhs); \
+                 generic_row<(s), false>(JF_(1, s), BF_(1, s), dv, PF[1][(s) >> 4], l16, PF[1][(s) >> 4].rhs);
       REP21(FRC_P)
 #undef FRC_P
     frc_pdone:
-#define FRC_C(j) if (nC_it <= (j)) goto frc_done; generic_row<MAXC - 1 - (j), true>(JF[0][MAXC - 1 - (j)], BF[0][MAXC - 1 - (j)], dv, PF[0][(MAXC - 1 - (j)) >> 4], l16, PF[0][(MAXC - 1 - (j)) >> 4].rhs); \
-                 generic_row<MAXC - 1 - (j), true>(JF[1][MAXC - 1 - (j)], BF[1][MAXC - 1 - (j)], dv, PF[1][(MAXC - 1 - (j)) >> 4], l16, PF[1][(MAXC - 1 - (j)) >> 4].rhs);
+#define FRC_C(j) if (nC_it <= (j)) goto frc_done; generic_row<MAXC - 1 - (j), true>(JF_(0, MAXC - 1 - (j)), BF_(0, MAXC - 1 - (j)), dv, PF[0][(MAXC - 1 - (j)) >> 4], l16, PF[0][(MAXC - 1 - (j)) >> 4].rhs); \
+                 generic_row<MAXC - 1 - (j), true>(JF_(1, MAXC - 1 - (j)), BF_(1, MAXC - 1 - (j)), dv, PF[1][(MAXC - 1 - (j)) >> 4], l16, PF[1][(MAXC - 1 - (j)) >> 4].rhs);
       REP21(FRC_C)
 #undef FRC_C
     frc_done:

@@ -694,6 +694,14 @@ int rp_debug_row_counts(rp_handle h, int32_t* host_buf) {
   return RP_OK;
 }
 
+#ifdef RP_PROLOGUE_CLOCKS
+int rp_debug_prologue_clocks(rp_handle h, uint64_t* host_buf, int32_t nwaves) {
+  if (!h || !host_buf || nwaves > 4096) return RP_ERR_ARG;
+  HIPCHK(h, hipDeviceSynchronize());
+  HIPCHK(h, hipMemcpyFromSymbol(host_buf, HIP_SYMBOL(g_pclk), (size_t)nwaves * 8 * sizeof(uint64_t)));
+  return RP_OK;
+}
+#endif
 #ifdef RP_CHAIN_CLOCKS
 int rp_debug_chain_clocks(rp_handle h, int64_t* host_buf, int32_t nblocks) {
   if (!h || !host_buf || nblocks > 4096) return RP_ERR_ARG;
