@@ -122,6 +122,7 @@ struct __align__(16) EnvLds {
       alignas(16) float cand[CANDMAX * 8];     /* candidate points, compact, in pair order (fk_bodies' scratch before that) */
       alignas(16) float man[MANPTS * 8];                 /* merged manifolds, in solver-bound order */
       float npscr[NPSCR_FLOATS];
+      int hinfo[8][4], hout[8], hsync[4];      /* hull pairs of the narrowphase's current batch (hull_item; hsync: k_prep2's two waves only) */
     };
     struct {                                   /* arm_dynamics() */
       float inert[RP_MAX_ARM * 10], compI[RP_MAX_ARM * 10];
@@ -182,6 +183,7 @@ struct __align__(16) PrepLds {
       };
     };
   };
+  int hinfo[8][4], hout[8], hsync[4];         /* hull pairs of the narrowphase's current batch (hull_item), and the two waves' hand-over: unclaimed classes | classes done | - | narrowphase over */
 #ifdef RP_LDS_PAD                 /* occupancy experiments only: fewer k_prep2 blocks per CU */
   float pad[RP_LDS_PAD];
 #endif
@@ -209,11 +211,20 @@ __device__ unsigned long long g_clk[32 * 4096];
 #define PCLK(i) if (lane == 0) { g_clk[32 * (blockIdx.x & 4095) + (i)] = (i) >= 6 && (i) < 8 ? wall_clock64() : __builtin_readcyclecounter(); }
 #define PCLK_ZERO(i) if (lane == 0) { g_clk[32 * (blockIdx.x & 4095) + (i)] = 0ull; }
 #define PCLK_ADD(i, v) if (lane == 0) { g_clk[32 * (blockIdx.x & 4095) + (i)] += (unsigned long long)(v); }
+#ifdef RP_HPROF      /* experiment: slots 29-31 = cycles inside hull_item | in the narrowphase's hull section | waiting for the other wave (first wave only) */
+#define PCLK_G(i, v)
+#define PCLK_H(i, v) PCLK_ADD(i, v)
+#else
+#define PCLK_G(i, v) PCLK_ADD(i, v)
+#define PCLK_H(i, v)
+#endif
 #define CLK_MARK2(i)
 #else
 #define PCLK(i)
 #define PCLK_ZERO(i)
 #define PCLK_ADD(i, v)
+#define PCLK_G(i, v)
+#define PCLK_H(i, v)
 #define CLK_MARK2(i) CLK_MARK(i)
 #endif
 #else
@@ -222,6 +233,8 @@ __device__ unsigned long long g_clk[32 * 4096];
 #define PCLK(i)
 #define PCLK_ZERO(i)
 #define PCLK_ADD(i, v)
+#define PCLK_G(i, v)
+#define PCLK_H(i, v)
 #endif
 
 /* The phases of a substep each run inside ONE wave (k_prep2 runs two of them side by side in the two waves of its block), so what they need
@@ -655,83 +668,19 @@ __device__ __forceinline__ void gjk_closest(GjkSimplex& S, int lane) {
   WSYNC();
 }
 
+/* One hull pair, by a WHOLE WAVE (a link of a thousand vertices in sixteen rounds instead of 125): everything below is the same in every lane except the vertices it scans
+ * (lane, lane + 64, ...).  The pair is the one lane group gi of the narrowphase's current batch published in L.hinfo[gi] (hull collider | box collider << 8 | hull is
+ * collider b << 16, margin, baked pair index); the outcome goes to L.hout[gi] (1: hull contact, staged at the head of the group's scratch; 0: apart; -1: the OBB path) -
+ * through LDS both ways, because in k_prep2 the wave that runs this may be the OTHER wave of the block (hull_helper) */
 template <class LDS>
-__device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int lane, int nact, float* __restrict__ gax) {      /* gax: the env's cached GJK results (contact cache row + PMC_AX), nullptr without the cache */
-  const int g = lane >> 3, s = lane & 7;
-  float* scr = &L.npscr[NPG_SCRATCH * g];
-  float* sv = scr;
-  float (*poly)[8][3] = (float (*)[8][3])(scr + 16);
-  float (*kept)[4] = (float (*)[4])(scr + 64);
-  const unsigned below = (1u << s) - 1u;
-  int cbase = 0;                                    /* candidate points stored so far (wave-uniform) */
-  for (int base = 0; base < nact; base += 64 / NPG) {      /* wave-uniform trip count; every lane reaches every barrier */
-    const int ai = base + g;
-    const bool act = ai < nact;
-    const int pi = act ? L.act[ai] : 0;
-    const int a = m->pair[pi][0], b = m->pair[pi][1];
-    const int ta = m->col_type[a], tb = m->col_type[b];
-    const float margin0 = fminf(m->col_margin[a], m->col_margin[b]);     /* Bullet: a manifold's breaking threshold is the smaller of its two objects' */
-    const bool bbox = act && ta == 0 && tb == 0;
-    if (act && s == 0) {
-      /* what the pair's contacts will need later, looked up here (the table loads hide behind the axis tests): friction, and the manifold key =
-       * object pair, bit 16 "rotation-locked free body against the static world" (the drawer: that manifold keeps only its deepest point),
-       * bits 20-21 which halves of the velocity layout the two bodies touch (0 second only, 1 first only, 2 both: DPP row 0 = the arm and the
-       * free bodies of free_row0, DPP row 1 = the other free bodies and the scene joints), bit 22 arm link against a movable body - all
-       * properties of the two objects, so the same for the whole run of pairs that makes a manifold */
-      const int n = m->n_arm, ba = m->col_body[a], bdy = m->col_body[b];
-      const int kf = ba - 1 - n;
-      const bool single = kf >= 0 && kf < m->n_free && m->free_rot_locked[kf] && bdy == 0;
-      auto half0 = [&](int q) { int f = q - 1 - n; return q >= 1 && (q <= n || (f < m->n_free && ((m->free_row0 >> f) & 1))); };
-      const bool r0 = half0(ba) || half0(bdy), r1 = (ba >= 1 && !half0(ba)) || (bdy >= 1 && !half0(bdy));
-      const bool arm = (ba >= 1 && ba <= n) || (bdy >= 1 && bdy <= n), movable = ba > n || bdy > n;
-      L.key[ai] = m->col_obj[a] * 256 + m->col_obj[b] + (single ? 65536 : 0) + ((r0 ? (r1 ? 2 : 1) : 0) << 20) + ((arm && movable) ? (1 << 22) : 0);
-      L.pmu[ai] = m->col_friction[a] * m->col_friction[b];
-    }
-    /* ---- arm link against a static box: the VERTICES of the convex hull of the link's collision mesh (Bullet: btConvexHullShape, margin 0.001) against the
-     * box's six faces - the same decisions and arithmetic as the oracle's hull_face.  The vertex deepest along the face of least penetration is the contact
-     * if it lies over that face (what GJK / EPA return for a vertex-on-face contact: a link on the ground plate, on the table top); beside the face the
-     * pair stays with the OBB path below.  The eight lanes of the group scan the vertices in strides of eight and reduce (min / max per box axis, lowest
-     * vertex index among equals: the oracle's sequential scan). */
-    int hf = -1;                                             /* 1: hull contact (lane 0 of the group holds it), 0: hull says apart, -1: OBB path */
-    {
-      /* the hull is collider a against a STATIC box b - or collider b against a MOVABLE box a (pairs list the collider of the higher body first, and the
-       * movable bodies come after the arm's links: the block, the drawer, the door, ... against an arm link; oracle RPO_RULE_HULLMOV): hc / bc = hull / box */
-      const int body_b0 = m->col_body[b], body_a0 = m->col_body[a];
-      const bool hswap = act && m->hull_cnt[b] > 0 && ta == 0 && tb == 0 && body_a0 > m->n_arm;
-      const int hc = hswap ? b : a, bc = hswap ? a : b;
-      const int hn = act ? m->hull_cnt[hc] : 0;
-      bool hq = hn > 0 && (hswap || (tb == 0 && body_b0 == 0));
-      if (hq) {
-        const Xf xa = collider_xf(m, L, hc), xb = collider_xf(m, L, bc);
-        const V3 ha = ld3(m->col_he[hc]), hb0 = ld3(m->col_he[bc]);
-        const V3 hb = mk3(fmaxf(hb0.x, RP_HULL_MARGIN), fmaxf(hb0.y, RP_HULL_MARGIN), fmaxf(hb0.z, RP_HULL_MARGIN));      /* (the box as the scan sees it: a plate thinner than the margin counts 0.001 thick) */
-        /* the link's OBB (it contains the hull) against the same six faces first: if even the OBB stays clear of the box by more than the pair's margin
-         * along one of the box's axes, so does every vertex and the scan would end with "apart" - the common case, a long link whose AABB merely overlaps
-         * the table's (same outcome as the oracle's full scan; the 1e-5 keeps rounding at the threshold on the scanning side) */
-        const V3 tt = xa.p - xb.p;
-        const V3 A0 = col(xa.R, 0), A1 = col(xa.R, 1), A2 = col(xa.R, 2), B0 = col(xb.R, 0), B1 = col(xb.R, 1), B2 = col(xb.R, 2);
-        const float r0 = ha.x * fabsf(dot(B0, A0)) + ha.y * fabsf(dot(B0, A1)) + ha.z * fabsf(dot(B0, A2));
-        const float r1 = ha.x * fabsf(dot(B1, A0)) + ha.y * fabsf(dot(B1, A1)) + ha.z * fabsf(dot(B1, A2));
-        const float r2 = ha.x * fabsf(dot(B2, A0)) + ha.y * fabsf(dot(B2, A1)) + ha.z * fabsf(dot(B2, A2));
-        const float og = fmaxf(fmaxf(fabsf(dot(B0, tt)) - r0 - hb.x, fabsf(dot(B1, tt)) - r1 - hb.y), fabsf(dot(B2, tt)) - r2 - hb.z);
-        /* ... and along the link OBB's own three axes (a lower bound of the hull's distance all the same: fewer pairs reach the scan and the GJK behind it) */
-        const float q0 = hb.x * fabsf(dot(A0, B0)) + hb.y * fabsf(dot(A0, B1)) + hb.z * fabsf(dot(A0, B2));
-        const float q1 = hb.x * fabsf(dot(A1, B0)) + hb.y * fabsf(dot(A1, B1)) + hb.z * fabsf(dot(A1, B2));
-        const float q2 = hb.x * fabsf(dot(A2, B0)) + hb.y * fabsf(dot(A2, B1)) + hb.z * fabsf(dot(A2, B2));
-        const float og2 = fmaxf(fmaxf(fabsf(dot(A0, tt)) - q0 - ha.x, fabsf(dot(A1, tt)) - q1 - ha.y), fabsf(dot(A2, tt)) - q2 - ha.z);
-        if (fmaxf(og, og2) > margin0 + RP_HULL_MARGIN + 1e-5f) { hq = false; hf = 0; }
-      }
-      /* The pairs that are left - rare - are done by the WHOLE WAVE, one at a time (a link of a thousand vertices in sixteen rounds instead of 125: its block
-       * would otherwise end long after the rest of the launch): the pair's two collider indices go to all lanes, everything below is the same in every
-       * lane except the vertices it scans (lane, lane + 64, ...), and the pair's own group keeps the outcome. */
-      asm volatile("" ::: "memory");                         /* (the transforms above are loaded again where they are needed: nothing of them stays in registers across the scan) */
-      for (unsigned long long todo = __ballot(hq && s == 0); todo != 0ull; todo &= todo - 1ull) {
-        const int src = __ffsll((long long)todo) - 1;        /* first lane of the group whose pair is scanned now (wave-uniform) */
-        const int ca = __builtin_amdgcn_readlane(hc, src), cb = __builtin_amdgcn_readlane(bc, src);
-        const bool flip = __builtin_amdgcn_readlane((int)hswap, src) != 0;      /* the pair's normal points from b toward a: from the hull toward the box when the hull is b */
-        const float mg = lane_read(margin0, src);
+__device__ __forceinline__ void hull_item(const DevModel* m, LDS& L, const int lane, const int gi, float* gax) {
+        const int src = 8 * gi;
+        const int hinf = __builtin_amdgcn_readfirstlane(L.hinfo[gi][0]);
+        const int ca = hinf & 255, cb = (hinf >> 8) & 255;
+        const bool flip = ((hinf >> 16) & 1) != 0;                  /* the pair's normal points from b toward a: from the hull toward the box when the hull is b */
+        const float mg = __int_as_float(__builtin_amdgcn_readfirstlane(L.hinfo[gi][1]));
         /* what this pair's last GJK call left in the contact cache (issued now, used after the scan) */
-        const int pi_u = __builtin_amdgcn_readlane(pi, src);
+        const int pi_u = __builtin_amdgcn_readfirstlane(L.hinfo[gi][2]);
         float* gslot = gax ? gax + 8 * (pi_u & (PMC_AXN - 1)) : nullptr;
         float4 gs1 = make_float4(0.f, 0.f, 0.f, 0.f); int gtag = 0;
         if (gslot && m->gjk) { gtag = __float_as_int(gslot[0]); gs1 = *(const float4*)(gslot + 4); }      /* (the direction for the scan; the simplex is fetched when GJK is reached) */
@@ -792,8 +741,8 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
         }
         if (obb_apart) {                                     /* (wave-uniform) */
           PCLK_ADD(15, 1ull << 48)
-          if ((lane >> 3) == (src >> 3)) hf = 0;
-          continue;
+          if (lane == 0) L.hout[gi] = 0;
+          return;
         }
         const int nn = m->hull_cnt[ca];
         const float4* tv = (const float4*)m->hullv + m->hull_off[ca];
@@ -905,7 +854,7 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
               const double far = (double)mg + 2.0 * (double)RP_HULL_MARGIN;
 #pragma unroll 1
               for (int it = 0; it < 32 && !fail; it++) {
-                PCLK_ADD(26, 1) PCLK_ADD(29, -(long long)__builtin_readcyclecounter())
+                PCLK_ADD(26, 1) PCLK_G(29, -(long long)__builtin_readcyclecounter())
                 V3 wa; int wi;
                 const V3 vf = mk3((float)v.x, (float)v.y, (float)v.z);
                 Z[15] = v.x; Z[16] = v.y; Z[17] = v.z;
@@ -925,26 +874,26 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
                 }
                 asm volatile("" ::: "memory");
                 v = mkd(Z[15], Z[16], Z[17]);
-                PCLK_ADD(29, __builtin_readcyclecounter()) PCLK_ADD(30, -(long long)__builtin_readcyclecounter())
+                PCLK_G(29, __builtin_readcyclecounter()) PCLK_G(30, -(long long)__builtin_readcyclecounter())
                 const int wb = (vf.x >= 0.f ? 1 : 0) | (vf.y >= 0.f ? 2 : 0) | (vf.z >= 0.f ? 4 : 0);      /* box core: the corner of largest projection on v */
                 const D3 w = diffd(wa, GjkSimplex::corner(wb, hbc));
                 const double vv = ddot(v, v), vw = ddot(v, w);
                 /* v . w / |v| is a lower bound of the distance: beyond the pair's margin and the two shape margins the pair is apart whatever the iteration would still find */
-                if (vw > 0.0 && vw * vw > far * far * vv) { apart = true; PCLK_ADD(30, __builtin_readcyclecounter()) break; }
+                if (vw > 0.0 && vw * vw > far * far * vv) { apart = true; PCLK_G(30, __builtin_readcyclecounter()) break; }
                 bool dup = false;
                 { D3 dw = S.pt(0) - w; dup |= ddot(dw, dw) < GJK_DUP;
                   dw = S.pt(1) - w; dup |= S.n > 1 && ddot(dw, dw) < GJK_DUP;
                   dw = S.pt(2) - w; dup |= S.n > 2 && ddot(dw, dw) < GJK_DUP; }
-                if (dup || vv - vw <= GJK_REL * vv) { PCLK_ADD(30, __builtin_readcyclecounter()) break; }
+                if (dup || vv - vw <= GJK_REL * vv) { PCLK_G(30, __builtin_readcyclecounter()) break; }
                 S.put(S.n, w);
                 if (S.n == 1) { S.b1 = wb; S.i1 = wi; } else if (S.n == 2) { S.b2 = wb; S.i2 = wi; } else { S.b3 = wb; S.i3 = wi; }
                 S.n++;
                 WSYNC();
-                PCLK_ADD(30, __builtin_readcyclecounter()) PCLK_ADD(31, -(long long)__builtin_readcyclecounter())
+                PCLK_G(30, __builtin_readcyclecounter()) PCLK_G(31, -(long long)__builtin_readcyclecounter())
                 GJK_PARK_DIRS();
                 gjk_closest(S, lane);
                 GJK_FETCH_DIRS();
-                PCLK_ADD(31, __builtin_readcyclecounter())
+                PCLK_G(31, __builtin_readcyclecounter())
                 if (S.n == 4) { fail = true; break; }
                 v = S.closest();
                 const double nd = ddot(v, v);
@@ -988,11 +937,170 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
           const V3 pB = mulv(xc.R, ploc) + xc.p;
           pt.p = pB + nrm * (0.5f * dcon); pt.n = flip ? -nrm : nrm; pt.dist = dcon;
         }
-        if ((lane >> 3) == (src >> 3)) hf = out;
-        if (lane == src && out == 1) {                       /* the point waits in its group's scratch (free until the SAT below): nothing of it stays in registers across the next pair's scan */
-          float* q = &L.npscr[NPG_SCRATCH * (src >> 3)];
-          st3(q, pt.p); st3(q + 3, pt.n); q[6] = pt.dist;
+        if (lane == 0) {
+          L.hout[gi] = out;
+          if (out == 1) {                                    /* the point waits in its group's scratch (free until the SAT of this batch) */
+            float* q = &L.npscr[NPG_SCRATCH * gi];
+            st3(q, pt.p); st3(q + 3, pt.n); q[6] = pt.dist;
+          }
         }
+}
+/* the published batch's hull pairs, class by class.  A class = the pairs of the batch that share a slot of the GJK cache (PMC_AXN slots per env, pair index mod PMC_AXN):
+ * they run in pair order inside ONE wave, as the oracle's sequential loop has them - whichever of them stores last owns the slot afterwards; classes are independent of
+ * one another, and a wave takes the lowest unclaimed one (bit k of L.hsync[0] = the class led by group k) */
+template <class LDS>
+__device__ __forceinline__ void hull_claims(const DevModel* m, LDS& L, const int lane, float* gax, const int who = 0) {
+  for (;;) {
+    /* the lowest class nobody has taken.  The loop is wave-uniform and only the atomic itself sits under `if (lane == 0)`: with the whole take inside a divergent region
+     * (`if (lane == 0) { while ... break ... }`, then readfirstlane) the builds of this function gave results that changed with unrelated edits of the source, each
+     * build deterministic (tools/det_check.py); this form gives the sequential loop's bits */
+    int c = -1;
+    unsigned mk = (unsigned)__builtin_amdgcn_readfirstlane((int)*(volatile unsigned*)&L.hsync[0]);
+    while (mk != 0u) {
+      const int k = __ffs(mk) - 1;
+      const unsigned bit = 1u << k;
+      unsigned old1 = 0u;
+      if (lane == 0) old1 = atomicAnd((unsigned*)&L.hsync[0], ~bit);      /* (one lane: executed by all of them the compiler's wave-wide combining of the operands costs 2 500 cycles a take) */
+      const unsigned old = (unsigned)__builtin_amdgcn_readfirstlane((int)old1);
+      if (old & bit) { c = k; break; }
+      mk = old & ~bit;
+    }
+    if (c < 0) break;
+    WSYNC();
+    PCLK_ADD(19, who ? 65536 : 1)                           /* (profiling build: classes taken by the narrowphase's wave | by the other wave << 16) */
+    unsigned cls = (unsigned)__builtin_amdgcn_readfirstlane(L.hinfo[c][3]);
+    if (!who) { PCLK_H(29, -(long long)__builtin_readcyclecounter()) }
+#pragma unroll 1
+    for (; cls != 0u; cls &= cls - 1u) hull_item(m, L, lane, __ffs(cls) - 1, gax);
+    if (!who) { PCLK_H(29, __builtin_readcyclecounter()) }
+    WSYNC();
+    if (lane == 0) atomicAdd(&L.hsync[1], 1);               /* one more class done (the narrowphase's wave waits for the count) */
+  }
+}
+/* k_prep2's second wave, once its own work is done: takes classes of hull pairs off the first wave's hands until that wave has left the narrowphase (L.hsync[3]).
+ * The literal random-action rollout has envs with ten and more hull pairs in reach (an arm slewing across the table's furniture): their first wave alone was the
+ * launch's tail, 180 us of whole-wave vertex scans one pair after the other */
+template <class LDS>
+__device__ __forceinline__ void hull_helper(const DevModel* m, LDS& L, const int lane, float* gax) {
+#ifdef RP_NO_HELPER      /* experiment: the narrowphase's wave alone */
+  return;
+#endif
+  PCLK(20)
+  for (;;) {
+    unsigned lead, fin;
+    for (;;) {
+      lead = *(volatile unsigned*)&L.hsync[0]; fin = *(volatile unsigned*)&L.hsync[3];
+      if ((lead | fin) != 0u) break;
+      __builtin_amdgcn_s_sleep(4);
+    }
+    if (__builtin_amdgcn_readfirstlane(lead) == 0u) break;   /* nothing published and the narrowphase is over */
+    WSYNC();
+    hull_claims(m, L, lane, gax, 1);
+  }
+}
+
+template <class LDS, bool HELP = false>
+__device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int lane, int nact, float* __restrict__ gax) {      /* gax: the env's cached GJK results (contact cache row + PMC_AX), nullptr without the cache */
+  const int g = lane >> 3, s = lane & 7;
+  float* scr = &L.npscr[NPG_SCRATCH * g];
+  float* sv = scr;
+  float (*poly)[8][3] = (float (*)[8][3])(scr + 16);
+  float (*kept)[4] = (float (*)[4])(scr + 64);
+  const unsigned below = (1u << s) - 1u;
+  int cbase = 0;                                    /* candidate points stored so far (wave-uniform) */
+  for (int base = 0; base < nact; base += 64 / NPG) {      /* wave-uniform trip count; every lane reaches every barrier */
+    const int ai = base + g;
+    const bool act = ai < nact;
+    const int pi = act ? L.act[ai] : 0;
+    const int a = m->pair[pi][0], b = m->pair[pi][1];
+    const int ta = m->col_type[a], tb = m->col_type[b];
+    const float margin0 = fminf(m->col_margin[a], m->col_margin[b]);     /* Bullet: a manifold's breaking threshold is the smaller of its two objects' */
+    const bool bbox = act && ta == 0 && tb == 0;
+    if (act && s == 0) {
+      /* what the pair's contacts will need later, looked up here (the table loads hide behind the axis tests): friction, and the manifold key =
+       * object pair, bit 16 "rotation-locked free body against the static world" (the drawer: that manifold keeps only its deepest point),
+       * bits 20-21 which halves of the velocity layout the two bodies touch (0 second only, 1 first only, 2 both: DPP row 0 = the arm and the
+       * free bodies of free_row0, DPP row 1 = the other free bodies and the scene joints), bit 22 arm link against a movable body - all
+       * properties of the two objects, so the same for the whole run of pairs that makes a manifold */
+      const int n = m->n_arm, ba = m->col_body[a], bdy = m->col_body[b];
+      const int kf = ba - 1 - n;
+      const bool single = kf >= 0 && kf < m->n_free && m->free_rot_locked[kf] && bdy == 0;
+      auto half0 = [&](int q) { int f = q - 1 - n; return q >= 1 && (q <= n || (f < m->n_free && ((m->free_row0 >> f) & 1))); };
+      const bool r0 = half0(ba) || half0(bdy), r1 = (ba >= 1 && !half0(ba)) || (bdy >= 1 && !half0(bdy));
+      const bool arm = (ba >= 1 && ba <= n) || (bdy >= 1 && bdy <= n), movable = ba > n || bdy > n;
+      L.key[ai] = m->col_obj[a] * 256 + m->col_obj[b] + (single ? 65536 : 0) + ((r0 ? (r1 ? 2 : 1) : 0) << 20) + ((arm && movable) ? (1 << 22) : 0);
+      L.pmu[ai] = m->col_friction[a] * m->col_friction[b];
+    }
+    /* ---- arm link against a static box: the VERTICES of the convex hull of the link's collision mesh (Bullet: btConvexHullShape, margin 0.001) against the
+     * box's six faces - the same decisions and arithmetic as the oracle's hull_face.  The vertex deepest along the face of least penetration is the contact
+     * if it lies over that face (what GJK / EPA return for a vertex-on-face contact: a link on the ground plate, on the table top); beside the face the
+     * pair stays with the OBB path below.  The eight lanes of the group scan the vertices in strides of eight and reduce (min / max per box axis, lowest
+     * vertex index among equals: the oracle's sequential scan). */
+    int hf = -1;                                             /* 1: hull contact (lane 0 of the group holds it), 0: hull says apart, -1: OBB path */
+    {
+      /* the hull is collider a against a STATIC box b - or collider b against a MOVABLE box a (pairs list the collider of the higher body first, and the
+       * movable bodies come after the arm's links: the block, the drawer, the door, ... against an arm link; oracle RPO_RULE_HULLMOV): hc / bc = hull / box */
+      const int body_b0 = m->col_body[b], body_a0 = m->col_body[a];
+      const bool hswap = act && m->hull_cnt[b] > 0 && ta == 0 && tb == 0 && body_a0 > m->n_arm;
+      const int hc = hswap ? b : a, bc = hswap ? a : b;
+      const int hn = act ? m->hull_cnt[hc] : 0;
+      bool hq = hn > 0 && (hswap || (tb == 0 && body_b0 == 0));
+      if (hq) {
+        const Xf xa = collider_xf(m, L, hc), xb = collider_xf(m, L, bc);
+        const V3 ha = ld3(m->col_he[hc]), hb0 = ld3(m->col_he[bc]);
+        const V3 hb = mk3(fmaxf(hb0.x, RP_HULL_MARGIN), fmaxf(hb0.y, RP_HULL_MARGIN), fmaxf(hb0.z, RP_HULL_MARGIN));      /* (the box as the scan sees it: a plate thinner than the margin counts 0.001 thick) */
+        /* the link's OBB (it contains the hull) against the same six faces first: if even the OBB stays clear of the box by more than the pair's margin
+         * along one of the box's axes, so does every vertex and the scan would end with "apart" - the common case, a long link whose AABB merely overlaps
+         * the table's (same outcome as the oracle's full scan; the 1e-5 keeps rounding at the threshold on the scanning side) */
+        const V3 tt = xa.p - xb.p;
+        const V3 A0 = col(xa.R, 0), A1 = col(xa.R, 1), A2 = col(xa.R, 2), B0 = col(xb.R, 0), B1 = col(xb.R, 1), B2 = col(xb.R, 2);
+        const float r0 = ha.x * fabsf(dot(B0, A0)) + ha.y * fabsf(dot(B0, A1)) + ha.z * fabsf(dot(B0, A2));
+        const float r1 = ha.x * fabsf(dot(B1, A0)) + ha.y * fabsf(dot(B1, A1)) + ha.z * fabsf(dot(B1, A2));
+        const float r2 = ha.x * fabsf(dot(B2, A0)) + ha.y * fabsf(dot(B2, A1)) + ha.z * fabsf(dot(B2, A2));
+        const float og = fmaxf(fmaxf(fabsf(dot(B0, tt)) - r0 - hb.x, fabsf(dot(B1, tt)) - r1 - hb.y), fabsf(dot(B2, tt)) - r2 - hb.z);
+        /* ... and along the link OBB's own three axes (a lower bound of the hull's distance all the same: fewer pairs reach the scan and the GJK behind it) */
+        const float q0 = hb.x * fabsf(dot(A0, B0)) + hb.y * fabsf(dot(A0, B1)) + hb.z * fabsf(dot(A0, B2));
+        const float q1 = hb.x * fabsf(dot(A1, B0)) + hb.y * fabsf(dot(A1, B1)) + hb.z * fabsf(dot(A1, B2));
+        const float q2 = hb.x * fabsf(dot(A2, B0)) + hb.y * fabsf(dot(A2, B1)) + hb.z * fabsf(dot(A2, B2));
+        const float og2 = fmaxf(fmaxf(fabsf(dot(A0, tt)) - q0 - ha.x, fabsf(dot(A1, tt)) - q1 - ha.y), fabsf(dot(A2, tt)) - q2 - ha.z);
+        if (fmaxf(og, og2) > margin0 + RP_HULL_MARGIN + 1e-5f) { hq = false; hf = 0; }
+      }
+      /* The pairs that are left - rare - are done by the WHOLE WAVE, one at a time (a link of a thousand vertices in sixteen rounds instead of 125: its block
+       * would otherwise end long after the rest of the launch): the pair's two collider indices go to all lanes, everything below is the same in every
+       * lane except the vertices it scans (lane, lane + 64, ...), and the pair's own group keeps the outcome. */
+      asm volatile("" ::: "memory");                         /* (the transforms above are loaded again where they are needed: nothing of them stays in registers across the scan) */
+      const unsigned long long todo0 = __ballot(hq && s == 0);
+      if (todo0 != 0ull) { PCLK_H(30, -(long long)__builtin_readcyclecounter())                                  /* (wave-uniform, rare) the pairs that are left are done by a WHOLE WAVE each (hull_item), through LDS */
+        if (hq && s == 0) { L.hinfo[g][0] = hc | (bc << 8) | (hswap ? 65536 : 0); L.hinfo[g][1] = __float_as_int(margin0); L.hinfo[g][2] = pi; }
+        if (HELP) {
+          /* both waves of the block work the batch off (hull_claims): classes of pairs that share a GJK cache slot, led by their first group */
+          const int slot = (gax && m->gjk) ? (pi & (PMC_AXN - 1)) : 64 + g;
+          unsigned cls = 0u;
+#pragma unroll
+          for (int k = 0; k < 8; k++) {
+            const int sk = __builtin_amdgcn_readlane(slot, 8 * k);
+            if (((todo0 >> (8 * k)) & 1ull) && sk == slot) cls |= 1u << k;
+          }
+          const unsigned long long lm = __ballot(hq && s == 0 && (__ffs(cls) - 1) == g);
+          unsigned leaders = 0u;
+#pragma unroll
+          for (int k = 0; k < 8; k++) leaders |= (unsigned)((lm >> (8 * k)) & 1ull) << k;
+          if (hq && s == 0) L.hinfo[g][3] = (int)cls;
+          if (lane == 0) L.hsync[1] = 0;
+          WSYNC();
+          if (lane == 0) L.hsync[0] = (int)leaders;          /* published: from here on the other wave may take classes too */
+          hull_claims(m, L, lane, gax);
+          const int nlead = __popc(leaders);
+          PCLK_H(31, -(long long)__builtin_readcyclecounter())
+          while (*(volatile int*)&L.hsync[1] < nlead) __builtin_amdgcn_s_sleep(1);
+          PCLK_H(31, __builtin_readcyclecounter())      /* (a class the other wave still works on) */
+        } else {
+          WSYNC();
+          for (unsigned long long todo = todo0; todo != 0ull; todo &= todo - 1ull) hull_item(m, L, lane, (__ffsll((long long)todo) - 1) >> 3, gax);
+        }
+        WSYNC();
+        if (hq) hf = L.hout[g];
+        PCLK_H(30, __builtin_readcyclecounter())
       }
     }
     int np = 0;
@@ -1239,7 +1347,7 @@ __device__ __forceinline__ int manifold_replace_index(const float* c4, const flo
 }
 
 /* broadphase + narrowphase + manifolds -> L.con*, returns ncon (wave-uniform) */
-template <class LDS>
+template <class LDS, bool HELP = false>
 __device__ __forceinline__ int collide(const DevModel* m, LDS& L, int lane, int env, const int* npm_early = nullptr) {
   /* 1. AABB sweep over the baked candidate pairs, 64 per pass; keep the first MAXACT overlapping, in order */
   int nact = 0;
@@ -1279,8 +1387,9 @@ __device__ __forceinline__ int collide(const DevModel* m, LDS& L, int lane, int 
   if (lane == 0) g_clk[32 * (blockIdx.x & 4095) + 12] = nact;
 #endif
   /* 2. narrowphase: eight lanes per active pair */
-  narrowphase_coop(m, L, lane, nact, m->persist ? m->pmcache + (size_t)env * PMC_FLOATS + PMC_AX : nullptr);
+  narrowphase_coop<LDS, HELP>(m, L, lane, nact, m->persist ? m->pmcache + (size_t)env * PMC_FLOATS + PMC_AX : nullptr);
   WSYNC();
+  if (HELP && lane == 0) L.hsync[3] = 1;                   /* (k_prep2: the other wave need not wait for hull pairs any more) */
   PCLK(9)
   /* 3. manifolds: one per run of equal object pairs, <= 4 points (1 for a rotation-locked body against the world).  A manifold's size
    * follows from its candidate counts alone, so every manifold knows its place in the contact list before anything is merged; the
@@ -3057,9 +3166,10 @@ static_assert(W3_A % 4 == 0 && W3_ROWS % 4 == 0 && W3_ROFF % 4 == 0 && AOUT_FLOA
 __device__ __forceinline__ void prep2_core(PrepLds& L, const DevModel* __restrict__ m, const float* __restrict__ state, float* __restrict__ ws, const int env, const int cenv,
                                            int* __restrict__ pair_tab, const int pair_idx) {      /* (table and index apart: a per-thread pointer held across the whole kernel costs two registers, and this kernel spills for less) */
   const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
-  PCLK(6) PCLK(0) PCLK_ZERO(15) PCLK_ZERO(26) PCLK_ZERO(27) PCLK_ZERO(28) PCLK_ZERO(29) PCLK_ZERO(30) PCLK_ZERO(31)
+  PCLK(6) PCLK(0) PCLK_ZERO(15) PCLK_ZERO(19) PCLK_ZERO(26) PCLK_ZERO(27) PCLK_ZERO(28) PCLK_ZERO(29) PCLK_ZERO(30) PCLK_ZERO(31)
   static_assert(RP_REC_FLOATS == PREP_THREADS, "one float of the record per thread");
   L.st[tid] = state[(size_t)env * RP_REC_FLOATS + tid];
+  if (tid == 64) { L.hsync[0] = 0; L.hsync[1] = 0; L.hsync[3] = 0; }      /* the waves' hand-over of hull pairs (narrowphase_coop / hull_helper): nothing published yet */
   if (tid == 64) L.hdr[3] = pair_idx;                        /* (waits in LDS for the end of the kernel: a register held across both phases is one the narrowphase spills for) */
   if (tid == 64 && m->persist) L.hdr[2] = __float_as_int(m->pmcache[(size_t)cenv * PMC_FLOATS]);      /* the cache's manifold count, for collide() */
   __syncthreads();
@@ -3073,7 +3183,7 @@ __device__ __forceinline__ void prep2_core(PrepLds& L, const DevModel* __restric
     collider_aabbs(m, L, lane);
     WSYNC();
     PCLK(1)
-    int ncon = collide(m, L, lane, cenv, &L.hdr[2]);
+    int ncon = collide<PrepLds, true>(m, L, lane, cenv, &L.hdr[2]);
     ncon = uni(ncon);
 #ifdef RP_ABL_MAXCON    /* timing ablation: drop contacts beyond RP_ABL_MAXCON to expose the tail effect in k_solve2 */
     if (ncon > RP_ABL_MAXCON) ncon = RP_ABL_MAXCON;
@@ -3118,6 +3228,8 @@ __device__ __forceinline__ void prep2_core(PrepLds& L, const DevModel* __restric
     if (lane < 32) w[W3_VSTAR + lane] = L.vstar[lane];
     copy_out(w + W3_MINV, L.Minv, 144, lane);
     copy_out(w + W3_A, L.aout, AOUT_FLOATS, lane);
+    /* ... and then this wave lends itself to the other one's hull pairs, while there are any */
+    hull_helper(m, L, lane, m->persist ? m->pmcache + (size_t)cenv * PMC_FLOATS + PMC_AX : nullptr);
   }
   __syncthreads();            /* the join: contacts (wave 0) and M^-1, v*, joint subspaces (wave 1) are there; aout and the dynamics scratch are dead */
   const int ncon = L.hdr[0];

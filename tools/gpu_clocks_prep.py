@@ -60,3 +60,13 @@ if g.any():
     print('GJK per round: scan + reduce p50 %d, support + tests + simplex store p50 %d, closest point p50 %d cycles' % (np.median(a[g, 29] / r), np.median(a[g, 30] / r), np.median(a[g, 31] / r)))
     print('GJK: waves with a call %d of %d; calls per such wave p50 %d max %d; rounds per call p50 %.1f max %.1f; cycles per call p50 %d max %d' % (
         g.sum(), n, np.median(a[g, 27]), a[g, 27].max(), np.median(a[g, 26] / a[g, 27]), (a[g, 26] / a[g, 27]).max(), np.median(a[g, 28] / a[g, 27]), (a[g, 28] / a[g, 27]).max()))
+
+hc = a[:, 19]
+own, oth = hc & 0xffff, (hc >> 16) & 0xffff
+arr = a[:, 20] - a[:, 0]
+print('hull classes per env: taken by the narrowphase\'s wave %.2f, by the other wave %.2f (envs with any: %d); the other wave arrives p50 %d cycles after the start, the narrowphase starts p50 %d and ends p50 %d' % (
+    own.mean(), oth.mean(), int((hc > 0).sum()), np.median(arr[a[:, 20] > 0]), np.median(a[:, 8] - a[:, 0]), np.median(a[:, 9] - a[:, 0])))
+if os.environ.get('HPROF'):      # build with -DRP_HPROF: slots 29-31 re-used
+    sel = hc > 0
+    print('envs with hull pairs: the narrowphase\'s hull section p50 %d cycles (mean %d), of that inside hull_item (first wave) p50 %d (mean %d), waiting for the other wave p50 %d (mean %d); classes per such env %.2f + %.2f' % (
+        np.median(a[sel, 30]), a[sel, 30].mean(), np.median(a[sel, 29]), a[sel, 29].mean(), np.median(a[sel, 31]), a[sel, 31].mean(), own[sel].mean(), oth[sel].mean()))
