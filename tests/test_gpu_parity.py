@@ -304,6 +304,32 @@ def test_split_pipeline_equals_fused_kernel_bitwise():
         assert torch.equal(ia['target_poses'], ib['target_poses']) and torch.equal(ia['target_poses'], ic['target_poses'])
 
 
+def test_hull_pairs_shared_by_two_waves_equal_the_sequential_loop_bitwise():
+    """Under the literal random-action rollout (distribution A) the arm's links are inside the scene's AABBs most of the time: 1.5 hull pairs per env-substep reach
+    the whole-wave vertex scans and GJK.  k_prep2 hands them out to BOTH waves of the env's block (hull_claims / hull_helper: classes of pairs by GJK cache slot,
+    taken off an LDS word with atomics); the fused kernel k_step does them one after the other in one wave.  Same bits - records AND contact caches (the cached GJK
+    simplices included) - and the same bits again on a second run (no timing enters the result)."""
+    from roboticsplayroompybullet_amd import VecPlayEnv
+    n, steps = 192, 30
+    runs = []
+    for fused in (0, 1, 0):
+        env = VecPlayEnv(IDS['U'], n, seed=77)
+        env.set_fused(fused)
+        env.reset()
+        g = torch.Generator(device=env.device).manual_seed(99)
+        acts = (2 * torch.rand((steps, n, 7), generator=g, device=env.device) - 1) * env.action_high
+        states = []
+        for t in range(steps):
+            env.step(acts[t])
+            states.append(env.get_state().clone())
+        runs.append(torch.stack(states))
+        env.close()
+    torch.cuda.synchronize()
+    assert torch.equal(runs[0].view(torch.int32), runs[2].view(torch.int32)), 'two runs of the split pipeline differ'
+    same = (runs[0].view(torch.int32) == runs[1].view(torch.int32)).all(dim=2)
+    assert bool(same.all()), 'split pipeline != fused kernel: first differing (step, env) %s' % (torch.nonzero(~same)[0].tolist(),)
+
+
 def test_reset_through_split_pipeline_equals_fused_reset_bitwise():
     """rp_reset's default path (rounds of 100 x (k_prep2, k_solve2) over the gathered pending envs, host-driven) == the one-kernel
     k_reset (fused substeps), bit for bit: full resets, then a masked reset after some steps (other envs untouched)."""
