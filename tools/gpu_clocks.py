@@ -23,6 +23,8 @@ env = VecPlayEnv(bench.ENV_ID, n, seed=1234)
 env.set_groups(int(os.environ.get('GROUPS', '1')))
 env.reset()
 acts = bench.make_actions(n, steps, env.device, 1234)
+if os.environ.get('DIST') == 'A':      # the literal random-action rollout: a ~ U(action_space)
+    acts = (2 * torch.rand((steps, n, 7), generator=torch.Generator(device=env.device).manual_seed(4321), device=env.device) - 1) * env.action_high
 for k in range(steps):
     env.step(acts[k])
 torch.cuda.synchronize()
