@@ -1390,6 +1390,7 @@ __device__ __forceinline__ int collide(const DevModel* m, LDS& L, int lane, int 
   narrowphase_coop<LDS, HELP>(m, L, lane, nact, m->persist ? m->pmcache + (size_t)env * PMC_FLOATS + PMC_AX : nullptr);
   WSYNC();
   if (HELP && lane == 0) L.hsync[3] = 1;                   /* (k_prep2: the other wave need not wait for hull pairs any more) */
+  asm volatile("" : "+v"(lane));                          /* (the lane number once more, opaque: addresses the manifold stage derives from it are computed there, not held across the narrowphase) */
   PCLK(9)
   /* 3. manifolds: one per run of equal object pairs, <= 4 points (1 for a rotation-locked body against the world).  A manifold's size
    * follows from its candidate counts alone, so every manifold knows its place in the contact list before anything is merged; the

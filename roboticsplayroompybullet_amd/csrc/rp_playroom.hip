@@ -88,9 +88,9 @@ extern "C" {
 #define RP_BUILD_ID "unversioned"
 #endif
 #ifdef RP_WIDE
-const char* rp_version(void) { return "rp_playroom 0.2 (gfx950, wide build: two-object play ids) build " RP_BUILD_ID; }
+const char* rp_version(void) { return "rp_playroom 0.3 (gfx950, wide build: two-object play ids) build " RP_BUILD_ID; }
 #else
-const char* rp_version(void) { return "rp_playroom 0.2 (gfx950) build " RP_BUILD_ID; }
+const char* rp_version(void) { return "rp_playroom 0.3 (gfx950) build " RP_BUILD_ID; }
 #endif
 
 static void destroy_handle(rp_sim* h) {        /* frees whatever a (possibly partial) handle owns; hipFree(nullptr) etc. are no-ops */
