@@ -747,17 +747,21 @@ __device__ __forceinline__ void hull_item(const DevModel* m, LDS& L, const int l
         const int nn = m->hull_cnt[ca];
         const float4* tv = (const float4*)m->hullv + m->hull_off[ca];
         float lo0 = 1e30f, lo1 = 1e30f, lo2 = 1e30f, hi0 = -1e30f, hi1 = -1e30f, hi2 = -1e30f, pmin = 1e30f;
+        int il0 = 0x7fffffff, il1 = 0x7fffffff, il2 = 0x7fffffff, ih0 = 0x7fffffff, ih1 = 0x7fffffff, ih2 = 0x7fffffff;      /* the vertex that gave this lane each of its extremes (the first one: a lane meets its vertices in rising order) */
         bool in_core = false;                                /* a vertex strictly inside the box core: the cores overlap, GJK would only find that out the long way */
         {
           const V3 hin = mk3(hc0.x - fminf(RP_HULL_MARGIN, hc0.x) - 1e-6f, hc0.y - fminf(RP_HULL_MARGIN, hc0.y) - 1e-6f, hc0.z - fminf(RP_HULL_MARGIN, hc0.z) - 1e-6f);
-          hull_scan<2>(tv, nn, lane, [&](const float4& v, int) {
+          hull_scan<2>(tv, nn, lane, [&](const float4& v, int i) {
             const float l0 = hull_coord(u0, v, c0), l1 = hull_coord(u1, v, c1), l2 = hull_coord(u2, v, c2);
-            lo0 = fminf(lo0, l0); hi0 = fmaxf(hi0, l0); lo1 = fminf(lo1, l1); hi1 = fmaxf(hi1, l1); lo2 = fminf(lo2, l2); hi2 = fmaxf(hi2, l2);
+            if (l0 < lo0) { lo0 = l0; il0 = i; } if (l0 > hi0) { hi0 = l0; ih0 = i; }
+            if (l1 < lo1) { lo1 = l1; il1 = i; } if (l1 > hi1) { hi1 = l1; ih1 = i; }
+            if (l2 < lo2) { lo2 = l2; il2 = i; } if (l2 > hi2) { hi2 = l2; ih2 = i; }
             pmin = fminf(pmin, hull_coord(up, v, cp));
             in_core |= fabsf(l0) < hin.x && fabsf(l1) < hin.y && fabsf(l2) < hin.z;
           });
         }
         const bool core_hit = __ballot(in_core) != 0ull;
+        const float my_lo0 = lo0, my_lo1 = lo1, my_lo2 = lo2, my_hi0 = hi0, my_hi1 = hi1, my_hi2 = hi2;      /* (this lane's own extremes: which lane holds the wave's is asked below) */
         lo0 = wave_min_f(lo0); lo1 = wave_min_f(lo1); lo2 = wave_min_f(lo2); hi0 = wave_max_f(hi0); hi1 = wave_max_f(hi1); hi2 = wave_max_f(hi2);
         pmin = wave_min_f(pmin);
         const float g0 = lo0 - hcm.x, g1 = -hi0 - hcm.x, g2 = lo1 - hcm.y, g3 = -hi1 - hcm.y, g4 = lo2 - hcm.z, g5 = -hi2 - hcm.z;      /* face +k: lowest vertex above it; face -k: highest vertex below it */
@@ -775,15 +779,17 @@ __device__ __forceinline__ void hull_item(const DevModel* m, LDS& L, const int l
         int out = 0;                                         /* this pair's hf */
         V3 nloc = mk3(0, 0, 0), ploc = mk3(0, 0, 0); float dcon = 0.f;      /* the contact in the BOX's frame: normal (box toward hull), point on the box's surface, distance */
         if (!(d > mg)) {                                     /* (wave-uniform) */
-          /* the first vertex (lowest index: the oracle's sequential scan keeps the first strict extreme) whose coordinate along that axis IS the extreme -
-           * the same instruction sequence gives the same bits */
+          /* the first vertex (lowest index: the oracle's sequential scan keeps the first strict extreme) whose coordinate along that axis IS the extreme: every lane
+           * kept the first vertex of its own extreme during the scan above (no second pass over the hull: 3 k cycles a pair), the lanes whose extreme is the wave's
+           * offer theirs, the lowest index wins */
           const int k = bf >> 1;
           const V3 uk = pick3(k, u0, u1, u2);
           const float ck = pick1(k, c0, c1, c2);
           const float ext = (bf & 1) ? pick1(k, hi0, hi1, hi2) : pick1(k, lo0, lo1, lo2);
-          int iv = 0x7fffffff;
-          hull_scan<4>(tv, nn, lane, [&](const float4& v, int i) { if (hull_coord(uk, v, ck) == ext) iv = min(iv, i); });
-          iv = wave_min_i(iv);
+          const float myv = (bf & 1) ? pick1(k, my_hi0, my_hi1, my_hi2) : pick1(k, my_lo0, my_lo1, my_lo2);
+          const int myi = (bf & 1) ? (k == 0 ? ih0 : (k == 1 ? ih1 : ih2)) : (k == 0 ? il0 : (k == 1 ? il1 : il2));
+          int iv = wave_min_i(myv == ext ? myi : 0x7fffffff);
+          (void)uk; (void)ck;
           out = -1;
           if (iv != 0x7fffffff) {
             const float4 v = tv[iv];
