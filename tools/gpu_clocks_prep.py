@@ -70,3 +70,10 @@ if os.environ.get('HPROF'):      # build with -DRP_HPROF: slots 29-31 re-used
     sel = hc > 0
     print('envs with hull pairs: the narrowphase\'s hull section p50 %d cycles (mean %d), of that inside hull_item (first wave) p50 %d (mean %d), waiting for the other wave p50 %d (mean %d); classes per such env %.2f + %.2f' % (
         np.median(a[sel, 30]), a[sel, 30].mean(), np.median(a[sel, 29]), a[sel, 29].mean(), np.median(a[sel, 31]), a[sel, 31].mean(), own[sel].mean(), oth[sel].mean()))
+# the launch lasts as long as its slowest blocks: what are they made of?
+order = np.argsort(-tot)[:12]
+print('the 12 slowest blocks: total | load+FK+AABB, broadphase, narrowphase, manifolds, wait for the other wave, rows after the join [k cycles] | active pairs')
+for i in order:
+    join = max(a[i, 2], a[i, 3])
+    print('  %6.1f | %5.1f %5.1f %6.1f %5.1f %5.1f %5.1f | %d' % (tot[i] / 1e3, (a[i, 1] - a[i, 0]) / 1e3, (a[i, 8] - a[i, 1]) / 1e3, (a[i, 9] - a[i, 8]) / 1e3, (a[i, 2] - a[i, 9]) / 1e3,
+                                                               (join - a[i, 2]) / 1e3, (a[i, 4] - join) / 1e3, a[i, 12]))
