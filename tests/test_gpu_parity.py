@@ -311,23 +311,24 @@ def test_hull_pairs_shared_by_two_waves_equal_the_sequential_loop_bitwise():
     simplices included) - and the same bits again on a second run (no timing enters the result)."""
     from roboticsplayroompybullet_amd import VecPlayEnv
     n, steps = 192, 30
-    runs = []
-    for fused in (0, 1, 0):
-        env = VecPlayEnv(IDS['U'], n, seed=77)
-        env.set_fused(fused)
-        env.reset()
-        g = torch.Generator(device=env.device).manual_seed(99)
-        acts = (2 * torch.rand((steps, n, 7), generator=g, device=env.device) - 1) * env.action_high
-        states = []
-        for t in range(steps):
-            env.step(acts[t])
-            states.append(env.get_state().clone())
-        runs.append(torch.stack(states))
-        env.close()
-    torch.cuda.synchronize()
-    assert torch.equal(runs[0].view(torch.int32), runs[2].view(torch.int32)), 'two runs of the split pipeline differ'
-    same = (runs[0].view(torch.int32) == runs[1].view(torch.int32)).all(dim=2)
-    assert bool(same.all()), 'split pipeline != fused kernel: first differing (step, env) %s' % (torch.nonzero(~same)[0].tolist(),)
+    for kind in ('U', 'P', 'V'):
+        runs = []
+        for fused in (0, 1, 0):
+            env = VecPlayEnv(IDS[kind], n, seed=77)
+            env.set_fused(fused)
+            env.reset()
+            g = torch.Generator(device=env.device).manual_seed(99)
+            acts = (2 * torch.rand((steps, n, env.action_high.numel()), generator=g, device=env.device) - 1) * env.action_high
+            states = []
+            for t in range(steps):
+                env.step(acts[t])
+                states.append(env.get_state().clone())
+            runs.append(torch.stack(states))
+            env.close()
+        torch.cuda.synchronize()
+        assert torch.equal(runs[0].view(torch.int32), runs[2].view(torch.int32)), '%s: two runs of the split pipeline differ' % kind
+        same = (runs[0].view(torch.int32) == runs[1].view(torch.int32)).all(dim=2)
+        assert bool(same.all()), '%s: split pipeline != fused kernel: first differing (step, env) %s' % (kind, torch.nonzero(~same)[0].tolist())
 
 
 def test_reset_through_split_pipeline_equals_fused_reset_bitwise():
