@@ -100,6 +100,10 @@ static_assert(MAXACT <= 64 && NB_MAX <= 32, "a candidate record packs its pair i
 
 /* The phases of a substep are templates over the LDS block; both blocks below carry the same member names.
  * EnvLds: the one-kernel path (k_step, resets, calc_state): everything of a substep at once, the solver sweeps read all rows from LDS. */
+/* The hull pairs of a substep, pooled over all active pairs (narrowphase_coop's first phase; hull_item): per active pair its colliders | margin | baked pair index,
+ * its outcome (-1 no hull pair / the OBB path, 0 apart, 1 contact) and the staged contact; the pairs of each GJK cache slot as a 64-bit mask (a CLASS: worked off in
+ * pair order by one wave); a GJK scratch per wave; and k_prep2's hand-over between its two waves: unclaimed classes | classes done | - | narrowphase over */
+#define HULL_POOL_FIELDS int hinfo[MAXACT][4]; int hout[MAXACT]; float hpt[MAXACT][7]; unsigned long long hcls[PMC_AXN]; alignas(8) float gjkscr[2][56]; int hsync[4];
 struct __align__(16) EnvLds {
   float st[RP_REC_FLOATS];
   float xR[NB_MAX * 9], xp[NB_MAX * 3];
@@ -122,7 +126,7 @@ struct __align__(16) EnvLds {
       alignas(16) float cand[CANDMAX * 8];     /* candidate points, compact, in pair order (fk_bodies' scratch before that) */
       alignas(16) float man[MANPTS * 8];                 /* merged manifolds, in solver-bound order */
       float npscr[NPSCR_FLOATS];
-      int hinfo[8][4], hout[8], hsync[4];      /* hull pairs of the narrowphase's current batch (hull_item; hsync: k_prep2's two waves only) */
+      HULL_POOL_FIELDS
     };
     struct {                                   /* arm_dynamics() */
       float inert[RP_MAX_ARM * 10], compI[RP_MAX_ARM * 10];
@@ -183,14 +187,14 @@ struct __align__(16) PrepLds {
       };
     };
   };
-  int hinfo[8][4], hout[8], hsync[4];         /* hull pairs of the narrowphase's current batch (hull_item), and the two waves' hand-over: unclaimed classes | classes done | - | narrowphase over */
+  HULL_POOL_FIELDS
 #ifdef RP_LDS_PAD                 /* occupancy experiments only: fewer k_prep2 blocks per CU */
   float pad[RP_LDS_PAD];
 #endif
 };
 static_assert(offsetof(EnvLds, aabb) % 16 == 0 && offsetof(PrepLds, aabb) % 16 == 0 && offsetof(EnvLds, cand) % 16 == 0 && offsetof(EnvLds, man) % 16 == 0 && offsetof(EnvLds, srow) % 16 == 0 && offsetof(EnvLds, rowS) % 16 == 0 &&
               offsetof(EnvLds, rowT) % 16 == 0 && offsetof(EnvLds, J) % 16 == 0 && offsetof(EnvLds, B) % 16 == 0, "16-byte LDS accesses");
-static_assert(sizeof(PrepLds) <= 16384, "k_prep2: ten blocks (twenty waves) per CU");
+static_assert(sizeof(PrepLds) <= 20480 - 512, "k_prep2: eight blocks (sixteen waves: what its 128 VGPRs allow) per CU");
 static_assert(offsetof(PrepLds, roff) % 16 == 0 && offsetof(PrepLds, slot) % 16 == 0 && offsetof(PrepLds, Minv) % 16 == 0 && offsetof(PrepLds, aout) % 16 == 0 &&
               offsetof(PrepLds, Md) % 8 == 0 && offsetof(PrepLds, cand) % 16 == 0 && offsetof(PrepLds, man) % 16 == 0, "16-byte copies out of LDS");
 
@@ -673,8 +677,7 @@ __device__ __forceinline__ void gjk_closest(GjkSimplex& S, int lane) {
  * collider b << 16, margin, baked pair index); the outcome goes to L.hout[gi] (1: hull contact, staged at the head of the group's scratch; 0: apart; -1: the OBB path) -
  * through LDS both ways, because in k_prep2 the wave that runs this may be the OTHER wave of the block (hull_helper) */
 template <class LDS>
-__device__ __forceinline__ void hull_item(const DevModel* m, LDS& L, const int lane, const int gi, float* gax) {
-        const int src = 8 * gi;
+__device__ __forceinline__ void hull_item(const DevModel* m, LDS& L, const int lane, const int gi, float* gax, const int wsel) {      /* gi: the active pair's number; wsel: which wave's GJK scratch */
         const int hinf = __builtin_amdgcn_readfirstlane(L.hinfo[gi][0]);
         const int ca = hinf & 255, cb = (hinf >> 8) & 255;
         const bool flip = ((hinf >> 16) & 1) != 0;                  /* the pair's normal points from b toward a: from the hull toward the box when the hull is b */
@@ -815,9 +818,9 @@ __device__ __forceinline__ void hull_item(const DevModel* m, LDS& L, const int l
               const bool ox = fabsf(lv.x) > hbc.x, oy = fabsf(lv.y) > hbc.y, oz = fabsf(lv.z) > hbc.z;
               const int nout = (ox ? 1 : 0) + (oy ? 1 : 0) + (oz ? 1 : 0);
               /* (the simplex lives in the pair's scratch, and so does v while a scan runs and the scan's directions while the simplex is solved: the kernel has no registers for them) */
-              double* Z = (double*)&L.npscr[NPG_SCRATCH * (src >> 3) + 8];
-              float* Y = &L.npscr[NPG_SCRATCH * (src >> 3) + 8 + 2 * 18];
-              static_assert((NPG_SCRATCH * 4) % 8 == 0 && NPG_SCRATCH >= 8 + 2 * 18 + 15, "the simplex: twelve doubles and v behind the staged point, 8-byte aligned; fifteen floats behind them");
+              double* Z = (double*)&L.gjkscr[wsel][0];
+              float* Y = &L.gjkscr[wsel][2 * 18];
+              static_assert(sizeof(L.gjkscr[0]) >= (2 * 18 + 15) * sizeof(float), "the simplex: twelve doubles, the weights and v, 8-byte aligned; fifteen floats behind them");
 #define GJK_PARK_DIRS() do { st3(Y, u0); st3(Y + 3, u1); st3(Y + 6, u2); st3(Y + 9, mk3(c0, c1, c2)); st3(Y + 12, hbc); asm volatile("" ::: "memory"); } while (0)
 #define GJK_FETCH_DIRS() do { asm volatile("" ::: "memory"); u0 = ld3(Y); u1 = ld3(Y + 3); u2 = ld3(Y + 6); { const V3 t_ = ld3(Y + 9); c0 = t_.x; c1 = t_.y; c2 = t_.z; } hbc = ld3(Y + 12); } while (0)
               GjkSimplex S;
@@ -946,14 +949,14 @@ __device__ __forceinline__ void hull_item(const DevModel* m, LDS& L, const int l
         if (lane == 0) {
           L.hout[gi] = out;
           if (out == 1) {                                    /* the point waits in its group's scratch (free until the SAT of this batch) */
-            float* q = &L.npscr[NPG_SCRATCH * gi];
+            float* q = &L.hpt[gi][0];
             st3(q, pt.p); st3(q + 3, pt.n); q[6] = pt.dist;
           }
         }
 }
-/* the published batch's hull pairs, class by class.  A class = the pairs of the batch that share a slot of the GJK cache (PMC_AXN slots per env, pair index mod PMC_AXN):
- * they run in pair order inside ONE wave, as the oracle's sequential loop has them - whichever of them stores last owns the slot afterwards; classes are independent of
- * one another, and a wave takes the lowest unclaimed one (bit k of L.hsync[0] = the class led by group k) */
+/* the substep's hull pairs, class by class.  A class = the pairs that share a slot of the GJK cache (PMC_AXN slots per env, pair index mod PMC_AXN): they run in pair
+ * order inside ONE wave, as the oracle's sequential loop has them - whichever of them stores last owns the slot afterwards; classes are independent of one another, and
+ * a wave takes the lowest unclaimed one (bit c of L.hsync[0] = class c, its pairs the bits of L.hcls[c]) */
 template <class LDS>
 __device__ __forceinline__ void hull_claims(const DevModel* m, LDS& L, const int lane, float* gax, const int who = 0) {
   for (;;) {
@@ -974,16 +977,20 @@ __device__ __forceinline__ void hull_claims(const DevModel* m, LDS& L, const int
     if (c < 0) break;
     WSYNC();
     PCLK_ADD(19, who ? 65536 : 1)                           /* (profiling build: classes taken by the narrowphase's wave | by the other wave << 16) */
-    unsigned cls = (unsigned)__builtin_amdgcn_readfirstlane(L.hinfo[c][3]);
+    const unsigned long long cm = L.hcls[c];
+    unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)cm), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(cm >> 32));
     if (!who) { PCLK_H(29, -(long long)__builtin_readcyclecounter()) }
 #pragma unroll 1
-    for (; cls != 0u; cls &= cls - 1u) hull_item(m, L, lane, __ffs(cls) - 1, gax);
+    for (int half = 0; half < 2; half++) {
+#pragma unroll 1
+      for (unsigned w = half ? hi : lo; w != 0u; w &= w - 1u) hull_item(m, L, lane, 32 * half + __ffs(w) - 1, gax, who);
+    }
     if (!who) { PCLK_H(29, __builtin_readcyclecounter()) }
     WSYNC();
-    if (lane == 0) atomicAdd(&L.hsync[1], 1);               /* one more class done (the narrowphase's wave waits for the count) */
+    if (lane == 0) atomicAdd(&L.hsync[1], 1);                /* one more class done (the narrowphase's wave waits for the count) */
   }
 }
-/* k_prep2's second wave, once its own work is done: takes classes of hull pairs off the first wave's hands until that wave has left the narrowphase (L.hsync[3]).
+/* k_prep2's second wave, once its own work is done: takes classes of hull pairs off the first wave's hands until that wave has left the hull phase (L.hsync[3]).
  * The literal random-action rollout has envs with ten and more hull pairs in reach (an arm slewing across the table's furniture): their first wave alone was the
  * launch's tail, 180 us of whole-wave vertex scans one pair after the other */
 template <class LDS>
@@ -999,7 +1006,7 @@ __device__ __forceinline__ void hull_helper(const DevModel* m, LDS& L, const int
       if ((lead | fin) != 0u) break;
       __builtin_amdgcn_s_sleep(4);
     }
-    if (__builtin_amdgcn_readfirstlane(lead) == 0u) break;   /* nothing published and the narrowphase is over */
+    if (__builtin_amdgcn_readfirstlane(lead) == 0u) break;   /* nothing published and the hull phase is over */
     WSYNC();
     hull_claims(m, L, lane, gax, 1);
   }
@@ -1013,39 +1020,23 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
   float (*poly)[8][3] = (float (*)[8][3])(scr + 16);
   float (*kept)[4] = (float (*)[4])(scr + 64);
   const unsigned below = (1u << s) - 1u;
-  int cbase = 0;                                    /* candidate points stored so far (wave-uniform) */
-  for (int base = 0; base < nact; base += 64 / NPG) {      /* wave-uniform trip count; every lane reaches every barrier */
-    const int ai = base + g;
+  /* ---- 1. the HULL PAIRS of the substep, pooled over all active pairs (one lane per active pair decides whether its pair is one), before the eight-lanes-per-pair
+   * batches below look at anything.
+   * Arm link against a box: the VERTICES of the convex hull of the link's collision mesh (Bullet: btConvexHullShape, margin 0.001) against the
+   * box's six faces - the same decisions and arithmetic as the oracle's hull_face.  The vertex deepest along the face of least penetration is the contact
+   * if it lies over that face (what GJK / EPA return for a vertex-on-face contact: a link on the ground plate, on the table top); beside the face the
+   * pair goes to GJK's distance phase (hull_item), and to the OBB path below when the cores overlap.
+   * The pairs that pass the OBB tests are done by a WHOLE WAVE each (hull_item: a link of a thousand vertices in sixteen rounds), class by class (hull_claims) - in k_prep2 by
+   * BOTH waves of the block: the pool of a whole substep shares better than the hull pairs of one batch of eight did (an env of the literal random-action
+   * rollout has 1.5 of them on average and up to 16). */
+  {
+    const int ai = lane;
     const bool act = ai < nact;
     const int pi = act ? L.act[ai] : 0;
     const int a = m->pair[pi][0], b = m->pair[pi][1];
     const int ta = m->col_type[a], tb = m->col_type[b];
-    const float margin0 = fminf(m->col_margin[a], m->col_margin[b]);     /* Bullet: a manifold's breaking threshold is the smaller of its two objects' */
-    const bool bbox = act && ta == 0 && tb == 0;
-    if (act && s == 0) {
-      /* what the pair's contacts will need later, looked up here (the table loads hide behind the axis tests): friction, and the manifold key =
-       * object pair, bit 16 "rotation-locked free body against the static world" (the drawer: that manifold keeps only its deepest point),
-       * bits 20-21 which halves of the velocity layout the two bodies touch (0 second only, 1 first only, 2 both: DPP row 0 = the arm and the
-       * free bodies of free_row0, DPP row 1 = the other free bodies and the scene joints), bit 22 arm link against a movable body - all
-       * properties of the two objects, so the same for the whole run of pairs that makes a manifold */
-      const int n = m->n_arm, ba = m->col_body[a], bdy = m->col_body[b];
-      const int kf = ba - 1 - n;
-      const bool single = kf >= 0 && kf < m->n_free && m->free_rot_locked[kf] && bdy == 0;
-      auto half0 = [&](int q) { int f = q - 1 - n; return q >= 1 && (q <= n || (f < m->n_free && ((m->free_row0 >> f) & 1))); };
-      const bool r0 = half0(ba) || half0(bdy), r1 = (ba >= 1 && !half0(ba)) || (bdy >= 1 && !half0(bdy));
-      const bool arm = (ba >= 1 && ba <= n) || (bdy >= 1 && bdy <= n), movable = ba > n || bdy > n;
-      L.key[ai] = m->col_obj[a] * 256 + m->col_obj[b] + (single ? 65536 : 0) + ((r0 ? (r1 ? 2 : 1) : 0) << 20) + ((arm && movable) ? (1 << 22) : 0);
-      L.pmu[ai] = m->col_friction[a] * m->col_friction[b];
-    }
-    /* ---- arm link against a static box: the VERTICES of the convex hull of the link's collision mesh (Bullet: btConvexHullShape, margin 0.001) against the
-     * box's six faces - the same decisions and arithmetic as the oracle's hull_face.  The vertex deepest along the face of least penetration is the contact
-     * if it lies over that face (what GJK / EPA return for a vertex-on-face contact: a link on the ground plate, on the table top); beside the face the
-     * pair stays with the OBB path below.  The eight lanes of the group scan the vertices in strides of eight and reduce (min / max per box axis, lowest
-     * vertex index among equals: the oracle's sequential scan). */
-    int hf = -1;                                             /* 1: hull contact (lane 0 of the group holds it), 0: hull says apart, -1: OBB path */
-    {
-      /* the hull is collider a against a STATIC box b - or collider b against a MOVABLE box a (pairs list the collider of the higher body first, and the
-       * movable bodies come after the arm's links: the block, the drawer, the door, ... against an arm link; oracle RPO_RULE_HULLMOV): hc / bc = hull / box */
+    const float margin0 = fminf(m->col_margin[a], m->col_margin[b]);
+    int hf = -1;                                               /* 1: hull contact, 0: hull says apart, -1: no hull pair, or the OBB path */
       const int body_b0 = m->col_body[b], body_a0 = m->col_body[a];
       const bool hswap = act && m->hull_cnt[b] > 0 && ta == 0 && tb == 0 && body_a0 > m->n_arm;
       const int hc = hswap ? b : a, bc = hswap ? a : b;
@@ -1071,47 +1062,77 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
         const float og2 = fmaxf(fmaxf(fabsf(dot(A0, tt)) - q0 - ha.x, fabsf(dot(A1, tt)) - q1 - ha.y), fabsf(dot(A2, tt)) - q2 - ha.z);
         if (fmaxf(og, og2) > margin0 + RP_HULL_MARGIN + 1e-5f) { hq = false; hf = 0; }
       }
-      /* The pairs that are left - rare - are done by the WHOLE WAVE, one at a time (a link of a thousand vertices in sixteen rounds instead of 125: its block
-       * would otherwise end long after the rest of the launch): the pair's two collider indices go to all lanes, everything below is the same in every
-       * lane except the vertices it scans (lane, lane + 64, ...), and the pair's own group keeps the outcome. */
-      asm volatile("" ::: "memory");                         /* (the transforms above are loaded again where they are needed: nothing of them stays in registers across the scan) */
-      const unsigned long long todo0 = __ballot(hq && s == 0);
-      if (todo0 != 0ull) { PCLK_H(30, -(long long)__builtin_readcyclecounter())                                  /* (wave-uniform, rare) the pairs that are left are done by a WHOLE WAVE each (hull_item), through LDS */
-        if (hq && s == 0) { L.hinfo[g][0] = hc | (bc << 8) | (hswap ? 65536 : 0); L.hinfo[g][1] = __float_as_int(margin0); L.hinfo[g][2] = pi; }
+      if (act) L.hout[ai] = hf;
+      if (hq) { L.hinfo[ai][0] = hc | (bc << 8) | (hswap ? 65536 : 0); L.hinfo[ai][1] = __float_as_int(margin0); L.hinfo[ai][2] = pi; }
+      const unsigned long long any = __ballot(hq);
+      if (any != 0ull) {                                       /* (wave-uniform, rare in the bench workload: 2 % of the env-substeps) */
+        PCLK_H(30, -(long long)__builtin_readcyclecounter())
+        const int slot = (gax && m->gjk) ? (pi & (PMC_AXN - 1)) : (ai & (PMC_AXN - 1));      /* (without the cache nothing is shared: any grouping will do) */
+        unsigned leaders = 0u;
+        unsigned long long mycls = 0ull;
+#pragma unroll 1
+        for (int c = 0; c < PMC_AXN; c++) {
+          const unsigned long long mk = __ballot(hq && slot == c);
+          if (mk != 0ull) leaders |= 1u << c;
+          if (lane == c) mycls = mk;
+        }
+        if (lane < PMC_AXN) L.hcls[lane] = mycls;
         if (HELP) {
-          /* both waves of the block work the batch off (hull_claims): classes of pairs that share a GJK cache slot, led by their first group */
-          const int slot = (gax && m->gjk) ? (pi & (PMC_AXN - 1)) : 64 + g;
-          unsigned cls = 0u;
-#pragma unroll
-          for (int k = 0; k < 8; k++) {
-            const int sk = __builtin_amdgcn_readlane(slot, 8 * k);
-            if (((todo0 >> (8 * k)) & 1ull) && sk == slot) cls |= 1u << k;
-          }
-          const unsigned long long lm = __ballot(hq && s == 0 && (__ffs(cls) - 1) == g);
-          unsigned leaders = 0u;
-#pragma unroll
-          for (int k = 0; k < 8; k++) leaders |= (unsigned)((lm >> (8 * k)) & 1ull) << k;
-          if (hq && s == 0) L.hinfo[g][3] = (int)cls;
           if (lane == 0) L.hsync[1] = 0;
           WSYNC();
-          if (lane == 0) L.hsync[0] = (int)leaders;          /* published: from here on the other wave may take classes too */
-          hull_claims(m, L, lane, gax);
+          if (lane == 0) L.hsync[0] = (int)leaders;            /* published: from here on the other wave may take classes too */
+          hull_claims(m, L, lane, gax, 0);
           const int nlead = __popc(leaders);
           PCLK_H(31, -(long long)__builtin_readcyclecounter())
-          while (*(volatile int*)&L.hsync[1] < nlead) __builtin_amdgcn_s_sleep(1);
-          PCLK_H(31, __builtin_readcyclecounter())      /* (a class the other wave still works on) */
+          while (*(volatile int*)&L.hsync[1] < nlead) __builtin_amdgcn_s_sleep(1);      /* (a class the other wave still works on) */
+          PCLK_H(31, __builtin_readcyclecounter())
         } else {
           WSYNC();
-          for (unsigned long long todo = todo0; todo != 0ull; todo &= todo - 1ull) hull_item(m, L, lane, (__ffsll((long long)todo) - 1) >> 3, gax);
+#pragma unroll 1
+          for (unsigned lc = leaders; lc != 0u; lc &= lc - 1u) {
+            const unsigned long long cm = L.hcls[__ffs(lc) - 1];
+            unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)cm), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(cm >> 32));
+#pragma unroll 1
+            for (int half = 0; half < 2; half++) {
+#pragma unroll 1
+              for (unsigned w = half ? hi : lo; w != 0u; w &= w - 1u) hull_item(m, L, lane, 32 * half + __ffs(w) - 1, gax, 0);
+            }
+          }
         }
-        WSYNC();
-        if (hq) hf = L.hout[g];
         PCLK_H(30, __builtin_readcyclecounter())
       }
+    WSYNC();
+    if (HELP && lane == 0) L.hsync[3] = 1;                     /* (k_prep2: the other wave need not wait for hull pairs any more) */
+  }
+  /* ---- 2. everything else, eight lanes per active pair */
+  int cbase = 0;                                    /* candidate points stored so far (wave-uniform) */
+  for (int base = 0; base < nact; base += 64 / NPG) {      /* wave-uniform trip count; every lane reaches every barrier */
+    const int ai = base + g;
+    const bool act = ai < nact;
+    const int pi = act ? L.act[ai] : 0;
+    const int a = m->pair[pi][0], b = m->pair[pi][1];
+    const int ta = m->col_type[a], tb = m->col_type[b];
+    const float margin0 = fminf(m->col_margin[a], m->col_margin[b]);     /* Bullet: a manifold's breaking threshold is the smaller of its two objects' */
+    const bool bbox = act && ta == 0 && tb == 0;
+    if (act && s == 0) {
+      /* what the pair's contacts will need later, looked up here (the table loads hide behind the axis tests): friction, and the manifold key =
+       * object pair, bit 16 "rotation-locked free body against the static world" (the drawer: that manifold keeps only its deepest point),
+       * bits 20-21 which halves of the velocity layout the two bodies touch (0 second only, 1 first only, 2 both: DPP row 0 = the arm and the
+       * free bodies of free_row0, DPP row 1 = the other free bodies and the scene joints), bit 22 arm link against a movable body - all
+       * properties of the two objects, so the same for the whole run of pairs that makes a manifold */
+      const int n = m->n_arm, ba = m->col_body[a], bdy = m->col_body[b];
+      const int kf = ba - 1 - n;
+      const bool single = kf >= 0 && kf < m->n_free && m->free_rot_locked[kf] && bdy == 0;
+      auto half0 = [&](int q) { int f = q - 1 - n; return q >= 1 && (q <= n || (f < m->n_free && ((m->free_row0 >> f) & 1))); };
+      const bool r0 = half0(ba) || half0(bdy), r1 = (ba >= 1 && !half0(ba)) || (bdy >= 1 && !half0(bdy));
+      const bool arm = (ba >= 1 && ba <= n) || (bdy >= 1 && bdy <= n), movable = ba > n || bdy > n;
+      L.key[ai] = m->col_obj[a] * 256 + m->col_obj[b] + (single ? 65536 : 0) + ((r0 ? (r1 ? 2 : 1) : 0) << 20) + ((arm && movable) ? (1 << 22) : 0);
+      L.pmu[ai] = m->col_friction[a] * m->col_friction[b];
     }
+    const int hf = act ? L.hout[ai] : -1;                    /* the hull phase's outcome for this pair: 1 hull contact (staged in L.hpt), 0 the hull says apart, -1 no hull pair / the OBB path */
     int np = 0;
     CPt mine; mine.p = mk3(0, 0, 0); mine.n = mk3(0, 0, 0); mine.dist = 0.f;      /* the point this lane contributes (lane s < np of its group) */
-    if (hf == 1 && s == 0) { mine.p = ld3(scr); mine.n = ld3(scr + 3); mine.dist = scr[6]; np = 1; }
+    if (hf == 1 && s == 0) { const float* hp = &L.hpt[ai][0]; mine.p = ld3(hp); mine.n = ld3(hp + 3); mine.dist = hp[6]; np = 1; }
     asm volatile("" ::: "memory");
     const Xf xa = collider_xf(m, L, a), xb = collider_xf(m, L, b);
     const V3 ha = ld3(m->col_he[a]), hb = ld3(m->col_he[b]);
