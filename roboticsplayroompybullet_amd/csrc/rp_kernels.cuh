@@ -141,11 +141,12 @@ struct __align__(16) EnvLds {
 /* PrepLds: k_prep2 / k_settle_prep / the prep blocks of k_action_prep: one env per block of TWO waves.  A substep's preparation is a chain
  * of latency-bound phases; collision detection (AABBs, broadphase, narrowphase, manifolds: 26 k cycles) and the arm's dynamics (joint
  * subspaces, CRBA, Cholesky, bias forces, v*, the unit rows: 24 k) need nothing from each other, so wave 0 runs the first and wave 1 the
- * second, and only the contact rows wait for both.  What the kernel needs beyond that is resident waves, and LDS limits them: under 16 KB
- * per block ten blocks (twenty waves) fit a CU.  Lifetimes:
+ * second, and only the contact rows wait for both - and, since round 4, wave 1 lends itself to wave 0's hull pairs when its own work is done
+ * (hull_helper).  What the kernel needs beyond that is resident waves: its registers (108 - 128 VGPRs) allow sixteen per CU = eight blocks, so
+ * the block may take 160 KB / 8 = 20 KB of LDS and no more.  Lifetimes:
  *   whole kernel   st, body transforms, joint subspaces, the contact list, slot tables, M^-1, tau, v*, free-body inverse inertias
  *   wave 0         AABBs (dead after the broadphase: the narrowphase scratch and then the merged manifolds take their place), active-pair
- *                  tables, candidate points
+ *                  tables, candidate points; the hull pool (both waves: HULL_POOL_FIELDS)
  *   wave 1         the dynamics scratch, then over it the small rows; after the join ONE CHUNK of contact rows (PREP_CH contacts: built,
  *                  copied to the workspace, next chunk); aout (the unit rows in solver form) has left by then */
 struct __align__(16) PrepLds {
@@ -673,9 +674,9 @@ __device__ __forceinline__ void gjk_closest(GjkSimplex& S, int lane) {
 }
 
 /* One hull pair, by a WHOLE WAVE (a link of a thousand vertices in sixteen rounds instead of 125): everything below is the same in every lane except the vertices it scans
- * (lane, lane + 64, ...).  The pair is the one lane group gi of the narrowphase's current batch published in L.hinfo[gi] (hull collider | box collider << 8 | hull is
- * collider b << 16, margin, baked pair index); the outcome goes to L.hout[gi] (1: hull contact, staged at the head of the group's scratch; 0: apart; -1: the OBB path) -
- * through LDS both ways, because in k_prep2 the wave that runs this may be the OTHER wave of the block (hull_helper) */
+ * (lane, lane + 64, ...).  The pair is active pair gi of the substep, described in L.hinfo[gi] by narrowphase_coop's first phase (hull collider | box collider << 8 | hull is
+ * collider b << 16, margin, baked pair index); the outcome goes to L.hout[gi] (1: hull contact, staged in L.hpt[gi]; 0: apart; -1: the OBB path) - through LDS both
+ * ways, because in k_prep2 the wave that runs this may be the OTHER wave of the block (hull_helper) */
 template <class LDS>
 __device__ __forceinline__ void hull_item(const DevModel* m, LDS& L, const int lane, const int gi, float* gax, const int wsel) {      /* gi: the active pair's number; wsel: which wave's GJK scratch */
         const int hinf = __builtin_amdgcn_readfirstlane(L.hinfo[gi][0]);
