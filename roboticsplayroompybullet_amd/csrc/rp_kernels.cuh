@@ -3224,6 +3224,10 @@ __device__ __forceinline__ void prep2_core(PrepLds& L, const DevModel* __restric
     joint_subspaces(m, L, lane);
     PCLK(18)
     arm_dynamics(m, L, lane);
+    /* here - M^-1 is there, 28 k cycles into the kernel, about when the other wave has published its hull pairs - this wave lends itself to them while there are any
+     * (in the bench workload the hull phase is over by now and the call returns at once); v*, the unit rows and the copies to the workspace follow: nobody needs
+     * them before the join, and the other wave still has its batches and manifolds to do */
+    hull_helper(m, L, lane, m->persist ? m->pmcache + (size_t)cenv * PMC_FLOATS + PMC_AX : nullptr);
     unconstrained_velocities(m, L, lane);
     PCLK(3)
     int nsmall = build_small_rows(m, L, lane);
@@ -3257,8 +3261,6 @@ __device__ __forceinline__ void prep2_core(PrepLds& L, const DevModel* __restric
     if (lane < 32) w[W3_VSTAR + lane] = L.vstar[lane];
     copy_out(w + W3_MINV, L.Minv, 144, lane);
     copy_out(w + W3_A, L.aout, AOUT_FLOATS, lane);
-    /* ... and then this wave lends itself to the other one's hull pairs, while there are any */
-    hull_helper(m, L, lane, m->persist ? m->pmcache + (size_t)cenv * PMC_FLOATS + PMC_AX : nullptr);
   }
   __syncthreads();            /* the join: contacts (wave 0) and M^-1, v*, joint subspaces (wave 1) are there; aout and the dynamics scratch are dead */
   const int ncon = L.hdr[0];
