@@ -20,4 +20,4 @@ for rep in range(2):
 same = (outs[0].view(torch.int32) == outs[1].view(torch.int32)).all(dim=2)      # [steps, n]
 first_bad = [int(torch.nonzero(~same[:, e])[0]) for e in range(n) if not bool(same[:, e].all())]
 print('library %s: %d of %d envs identical over %d steps across two runs; first differing steps %s; checksum of run 0: %s' % (
-    os.environ.get('RP_PLAYROOM_LIB', 'default'), int(same.all(dim=0).sum()), n, steps, sorted(first_bad)[:8], hashlib.md5(outs[0].cpu().numpy().tobytes()).hexdigest()[:12]))
+    os.environ.get('RP_PLAYROOM_LIB', 'default'), int(same.all(dim=0).sum()), n, steps, sorted(first_bad)[:8], hashlib.md5(outs[0].cpu().numpy().tobytes()).hexdigest()[:12]) + '; of the 128-float records alone: %s' % hashlib.md5(outs[0][:, :, :128].contiguous().cpu().numpy().tobytes()).hexdigest()[:12])
