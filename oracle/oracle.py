@@ -95,6 +95,10 @@ def load(f32=False, bullet_ref=False):
     lib.rpo_last_num_tors.argtypes = [vp]
     lib.rpo_cache_size.argtypes = [vp, ip]
     lib.rpo_shift_free_body.argtypes = [vp, C.c_int, C.c_double, C.c_double, C.c_double]
+    fp = C.POINTER(C.c_float)
+    lib.rpo_get_cache_row.argtypes = [vp, fp]
+    lib.rpo_set_cache_row.argtypes = [vp, fp]
+    lib.rpo_gjk_stats.argtypes = [C.POINTER(C.c_long), C.c_int]
     lib.rpo_get_rule.argtypes = [vp]
     lib.rpo_set_reward_cfg.argtypes = [vp, C.c_double, C.c_int]
     lib.rpo_action_dim.argtypes = [vp]
@@ -344,6 +348,27 @@ class OracleEnv:
 
     def set_state(self, s):
         self.lib.rpo_set_state(self.h, _d(s)[1])
+
+    def get_cache_row(self):
+        """the contact cache in the HIP library's row layout (float32 [704], integers as bit patterns: rp_kernels.cuh PMC_*) - what rp_get_state rows carry
+        behind the 128-float record"""
+        row = np.zeros(self.lib.rpo_cache_row_words(), dtype=np.float32)
+        n = self.lib.rpo_get_cache_row(self.h, row.ctypes.data_as(C.POINTER(C.c_float)))
+        assert n == len(row), n
+        return row
+
+    def set_cache_row(self, row):
+        """takes a cache row (e.g. the device's own, rp_get_state[:, 128:]) as this env's contact history; call after set_state, which clears it"""
+        row = np.ascontiguousarray(row, dtype=np.float32)
+        assert len(row) == self.lib.rpo_cache_row_words(), len(row)
+        if self.lib.rpo_set_cache_row(self.h, row.ctypes.data_as(C.POINTER(C.c_float))) != 0:
+            raise ValueError('malformed cache row')
+
+    def gjk_stats(self, reset=False):
+        """GJK counters of the calling thread: calls, rounds, two-point seeds, contacts, apart, overlap, tetrahedra, rounds of the apart exits"""
+        st = (C.c_long * 8)()
+        self.lib.rpo_gjk_stats(st, int(bool(reset)))
+        return list(st)
 
     def get_motor(self):
         mode = np.zeros(self.n_arm, dtype=np.int32)

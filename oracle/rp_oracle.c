@@ -631,7 +631,8 @@ static int obb_apart(const rpo_env* e, int hc, int bc, real margin) {
   }
   return 0;
 }
-static long g_gjk_stats[8];      /* calls, rounds, seeds with two points, results 1 / 0 / -1, tetrahedra solved */
+static _Thread_local long g_gjk_stats[8];      /* calls, rounds, seeds with two points, results 1 / 0 / -1, tetrahedra solved.  Per THREAD: rpo_bench_rollout steps envs on many
+                                                * threads (one shared line of counters would be a data race and a contended cache line inside the timed baseline); rpo_gjk_stats reads the calling thread's */
 void rpo_gjk_stats(long* out, int reset) { for (int i = 0; i < 8; i++) { out[i] = g_gjk_stats[i]; if (reset) g_gjk_stats[i] = 0; } }
 static int hull_box_gjk(rpo_env* e, int hc, int bc, real margin, const real* lv, int lvi, cpoint* out, int pi) {
   const rp_model* m = &e->m;
@@ -2569,6 +2570,78 @@ int rpo_last_num_tors(const rpo_env* e) { return e->n_tors; }
 /* RPO_RULE_PERSIST: cached manifolds (empty ones included) and, in *points, their points */
 int rpo_cache_size(const rpo_env* e, int* points) { int n = 0; for (int i = 0; i < e->npm; i++) n += e->pm[i].n; if (points) *points = n; return e->npm; }      /* torsional rows of the latest substep (mode A) */
 int rpo_contact_substeps(const rpo_env* e) { return e->contact_substeps; }
+/* The contact cache in the HIP library's row layout (rp_kernels.cuh PMC_*: 704 words; integers as bit patterns) - what rp_get_state rows carry behind the 128-float record.
+ * Header: manifolds, 3 pad.  Manifold (52 words): object-pair key (objA * 256 + objB) | points | breaking threshold | pair flags (rebuilt every substep: 0 here) | 4 words of
+ * scratch | 4 points x 11: point in A's body frame, in B's, normal, distance, colliders and bodies (a | b << 8 | body a << 22 | body b << 27).  Behind the manifolds the GJK_AX
+ * cached GJK results, 8 words each: tag | n + corner codes << 4, 8, 12 | three hull vertex numbers | direction.  Tests: the device's cache against the oracle's, field by
+ * field, and a device row handed to the oracle (lock-step comparisons with contact history). */
+#define RPO_ROW_HDR 4
+#define RPO_ROW_PT 11
+#define RPO_ROW_MAN (8 + 4 * RPO_ROW_PT)
+#define RPO_ROW_AX (RPO_ROW_HDR + 11 * RPO_ROW_MAN)
+#define RPO_ROW_WORDS (RPO_ROW_AX + 8 * GJK_AX)
+static float i2f(int v) { float f; memcpy(&f, &v, 4); return f; }
+static int f2i(float f) { int v; memcpy(&v, &f, 4); return v; }
+int rpo_cache_row_words(void) { return PM_MAX == 11 ? RPO_ROW_WORDS : -1; }
+int rpo_get_cache_row(const rpo_env* e, float* row) {
+  if (PM_MAX != 11) return -1;
+  const rp_model* m = &e->m;
+  memset(row, 0, sizeof(float) * RPO_ROW_WORDS);
+  row[0] = i2f(e->npm);
+  for (int i = 0; i < e->npm; i++) {
+    float* M = row + RPO_ROW_HDR + RPO_ROW_MAN * i;
+    M[0] = i2f(e->pm[i].oa * 256 + e->pm[i].ob); M[1] = i2f(e->pm[i].n); M[2] = (float)e->pm[i].thr;
+    for (int q = 0; q < e->pm[i].n; q++) {
+      float* P = M + 8 + RPO_ROW_PT * q;
+      for (int k = 0; k < 3; k++) { P[k] = (float)e->pm[i].pt[q].lA[k]; P[3 + k] = (float)e->pm[i].pt[q].lB[k]; P[6 + k] = (float)e->pm[i].pt[q].n[k]; }
+      P[9] = (float)e->pm[i].pt[q].dist;
+      P[10] = i2f(e->pm[i].pt[q].ca | (e->pm[i].pt[q].cb << 8) | (m->col_body[e->pm[i].pt[q].ca] << 22) | (int)((unsigned)m->col_body[e->pm[i].pt[q].cb] << 27));
+    }
+  }
+  for (int s = 0; s < GJK_AX; s++) {
+    float* G = row + RPO_ROW_AX + 8 * s;
+    G[0] = i2f(e->gax[s].tag);
+    if (e->gax[s].tag == 0) continue;
+    const int n = e->gax[s].n;
+    G[1] = i2f(n | (e->gax[s].code[0] << 4) | ((n > 1 ? e->gax[s].code[1] : 0) << 8) | ((n > 2 ? e->gax[s].code[2] : 0) << 12));
+    G[2] = i2f(e->gax[s].vi[0]); G[3] = i2f(n > 1 ? e->gax[s].vi[1] : 0); G[4] = i2f(n > 2 ? e->gax[s].vi[2] : 0);
+    for (int k = 0; k < 3; k++) G[5 + k] = (float)e->gax[s].v[k];
+  }
+  return RPO_ROW_WORDS;
+}
+int rpo_set_cache_row(rpo_env* e, const float* row) {
+  if (PM_MAX != 11) return -1;
+  int npm = f2i(row[0]);
+  if (npm < 0 || npm > PM_MAX) return -1;
+  e->npm = npm;
+  for (int i = 0; i < npm; i++) {
+    const float* M = row + RPO_ROW_HDR + RPO_ROW_MAN * i;
+    const int key = f2i(M[0]);
+    e->pm[i].oa = key >> 8; e->pm[i].ob = key & 255; e->pm[i].n = f2i(M[1]); e->pm[i].thr = (real)M[2];
+    if (e->pm[i].n < 0 || e->pm[i].n > 4) return -1;
+    for (int q = 0; q < e->pm[i].n; q++) {
+      const float* P = M + 8 + RPO_ROW_PT * q;
+      for (int k = 0; k < 3; k++) { e->pm[i].pt[q].lA[k] = (real)P[k]; e->pm[i].pt[q].lB[k] = (real)P[3 + k]; e->pm[i].pt[q].n[k] = (real)P[6 + k]; }
+      e->pm[i].pt[q].dist = (real)P[9];
+      const int ab = f2i(P[10]);
+      e->pm[i].pt[q].ca = ab & 255; e->pm[i].pt[q].cb = (ab >> 8) & 255;
+    }
+  }
+  for (int s = 0; s < GJK_AX; s++) {
+    const float* G = row + RPO_ROW_AX + 8 * s;
+    memset(&e->gax[s], 0, sizeof(e->gax[s]));
+    e->gax[s].tag = f2i(G[0]);
+    if (e->gax[s].tag == 0) continue;
+    const int nc = f2i(G[1]);
+    e->gax[s].n = nc & 15;
+    if (e->gax[s].n < 1) e->gax[s].n = 1;                   /* (the HIP library clamps what it reads the same way: hull_item) */
+    if (e->gax[s].n > 3) e->gax[s].n = 3;
+    e->gax[s].code[0] = (nc >> 4) & 7; e->gax[s].code[1] = (nc >> 8) & 7; e->gax[s].code[2] = (nc >> 12) & 7;
+    e->gax[s].vi[0] = f2i(G[2]); e->gax[s].vi[1] = f2i(G[3]); e->gax[s].vi[2] = f2i(G[4]);
+    for (int k = 0; k < 3; k++) e->gax[s].v[k] = (real)G[5 + k];
+  }
+  return 0;
+}
 /* world pose of every collider in the current state: out[12 c] = R (row-major), p; returns the collider count (render / ray tests) */
 int rpo_collider_poses(rpo_env* e, double* out) {
   update_transforms(e);

@@ -95,6 +95,11 @@ void rpo_forward_dynamics(rpo_env*, double* qdd /* n_arm */);
 int rpo_contacts(rpo_env*, double* out /* per contact: colA colB px py pz nx ny nz dist */, int max);
 int rpo_last_num_tors(const rpo_env* e);        /* torsional friction rows of the latest substep */
 int rpo_cache_size(const rpo_env* e, int* points);     /* RPO_RULE_PERSIST: cached manifolds (empty ones included), their points */
+/* the contact cache in the HIP library's row layout (704 words, rp_kernels.cuh PMC_*): export, and import of a row (e.g. the device's own) - tests only */
+int rpo_cache_row_words(void);
+int rpo_get_cache_row(const rpo_env* e, float* row);
+int rpo_set_cache_row(rpo_env* e, const float* row);
+void rpo_gjk_stats(long* out8, int reset);       /* GJK counters of the calling thread: calls, rounds, two-point seeds, results 1 / 0 / -1, tetrahedra, rounds of the "apart" exits */
 void rpo_shift_free_body(rpo_env* e, int k, double dx, double dy, double dz);      /* test hook: moves a free body, keeps the contact cache */
 int rpo_last_num_rows(const rpo_env*);
 int rpo_arm_table(const rpo_env* e, double* out);                      /* [n_arm][6]: jtype, lower, upper, body mass, Bullet joint index, parent dof */
