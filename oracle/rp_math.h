@@ -18,6 +18,7 @@ typedef float real;
 #define R_FABS fabsf
 #define R_FMOD fmodf
 #define R_FLOOR floorf
+#define R_FMA fmaf
 #else
 typedef double real;
 #define R_SQRT sqrt
@@ -30,9 +31,13 @@ typedef double real;
 #define R_FABS fabs
 #define R_FMOD fmod
 #define R_FLOOR floor
+#define R_FMA fma
 #endif
 
 #define RP_PI ((real)3.14159265358979323846)
+/* a . b as the HIP library's hull scans form it (rp_kernels.cuh hull_coord, the GJK support scan): z, y, x folded in by fused multiply-adds - one rounding per step,
+ * the same vertex wins a near-tie on both sides */
+#define R_DOT3_FMA(a0, a1, a2, b0, b1, b2) R_FMA((a2), (b2), R_FMA((a1), (b1), (a0) * (b0)))
 
 static inline void v3set(real* o, real x, real y, real z) { o[0] = x; o[1] = y; o[2] = z; }
 static inline void v3cpy(real* o, const real* a) { o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; }

@@ -491,7 +491,7 @@ static int hull_face(const rpo_env* e, int a, int b, real margin, cpoint* out, r
   for (int i = 0; i < nvert; i++) {
     const real v[3] = {(real)hv[i][0], (real)hv[i][1], (real)hv[i][2]};
     for (int k = 0; k < 3; k++) {
-      const real l = (u[k][0] * v[0] + u[k][1] * v[1] + u[k][2] * v[2]) - c[k];
+      const real l = R_DOT3_FMA(u[k][0], u[k][1], u[k][2], v[0], v[1], v[2]) - c[k];      /* (rp_kernels.cuh hull_coord: the same fused sequence) */
       if (l < lo[k]) { lo[k] = l; ilo[k] = i; }
       if (l > hi[k]) { hi[k] = l; ihi[k] = i; }
     }
@@ -512,7 +512,7 @@ static int hull_face(const rpo_env* e, int a, int b, real margin, cpoint* out, r
   m3mulv(w, xa->R, v); v3add(w, w, xa->p);
   int beside = 0;
   for (int j = 0; j < 3; j++) {
-    const real l = (u[j][0] * v[0] + u[j][1] * v[1] + u[j][2] * v[2]) - c[j];
+    const real l = R_DOT3_FMA(u[j][0], u[j][1], u[j][2], v[0], v[1], v[2]) - c[j];
     lv[j] = l;                                               /* (the vertex in box coordinates: where hull_box_gjk starts from) */
     lv[3] = (real)iv;
     if (j != k && R_FABS(l) > (real)m->col_he[b][j]) beside = 1;
@@ -651,7 +651,7 @@ static int hull_box_gjk(rpo_env* e, int hc, int bc, real margin, const real* lv,
     v3sub(t, xb->p, xa->p);
     c[k] = v3dot(bk, t);
   }
-#define HULL_L(out3, vi_) do { const real q_[3] = {(real)hv[vi_][0], (real)hv[vi_][1], (real)hv[vi_][2]}; for (int k_ = 0; k_ < 3; k_++) (out3)[k_] = (u[k_][0] * q_[0] + u[k_][1] * q_[1] + u[k_][2] * q_[2]) - c[k_]; } while (0)
+#define HULL_L(out3, vi_) do { const real q_[3] = {(real)hv[vi_][0], (real)hv[vi_][1], (real)hv[vi_][2]}; for (int k_ = 0; k_ < 3; k_++) (out3)[k_] = R_DOT3_FMA(u[k_][0], u[k_][1], u[k_][2], q_[0], q_[1], q_[2]) - c[k_]; } while (0)
   g_gjk_stats[0]++;
   gjk_sv s[4]; int n = 0; greal lam[4] = {0, 0, 0, 0};
   memset(s, 0, sizeof(s));
@@ -679,7 +679,7 @@ static int hull_box_gjk(rpo_env* e, int hc, int bc, real margin, const real* lv,
       for (int j = 0; j < 3; j++) dl[j] = vn[0] * u[0][j] + vn[1] * u[1][j] + vn[2] * u[2][j];
       const real cp = vn[0] * c[0] + vn[1] * c[1] + vn[2] * c[2] + hb[0] * R_FABS(vn[0]) + hb[1] * R_FABS(vn[1]) + hb[2] * R_FABS(vn[2]);
       for (int i = 0; i < nvert; i++) {
-        const real pr = ((real)hv[i][0] * dl[0] + (real)hv[i][1] * dl[1] + (real)hv[i][2] * dl[2]) - cp;
+        const real pr = R_DOT3_FMA(dl[0], dl[1], dl[2], (real)hv[i][0], (real)hv[i][1], (real)hv[i][2]) - cp;      /* (hull_coord(up, v, cp)) */
         if (pr < lo) lo = pr;
       }
       if (lo > (real)far + (real)1e-6) { g_gjk_stats[4]++; return 0; }
@@ -723,7 +723,7 @@ static int hull_box_gjk(rpo_env* e, int hc, int bc, real margin, const real* lv,
       for (int j = 0; j < 3; j++) dl[j] = -((real)v[0] * u[0][j] + (real)v[1] * u[1][j] + (real)v[2] * u[2][j]);
       int bi = 0; real bd = (real)-1e30;
       for (int i = 0; i < nvert; i++) {
-        const real d = (real)hv[i][0] * dl[0] + (real)hv[i][1] * dl[1] + (real)hv[i][2] * dl[2];
+        const real d = R_DOT3_FMA(dl[0], dl[1], dl[2], (real)hv[i][0], (real)hv[i][1], (real)hv[i][2]);      /* (the support scan's fused sequence) */
         if (d > bd) { bd = d; bi = i; }
       }
       real a3[3];
@@ -1724,7 +1724,63 @@ static void site_world(const rpo_env* e, const xform* xb, int site, real* pos, r
   m3mul(R, x->R, sr);
 }
 
-static void solve_spd(real* A, real* b, int n) {   /* Gaussian elimination with partial pivoting, in place; b <- x */
+/* The IK's arithmetic uses FUSED multiply-adds in a fixed order, the same as the HIP library's ik_coop / chain_fk_coop (rp_kernels.cuh dotF, crossF, mulvF, mulvaddF, mulF,
+ * axis_angleF, qmulF): the library is compiled with -ffp-contract=off and writes these fma out, the oracle mirrors them so that both round alike (round 5). */
+static inline real ik_dot(const real* a, const real* b) { return R_FMA(a[2], b[2], R_FMA(a[1], b[1], a[0] * b[0])); }
+static inline void ik_cross(real* o, const real* a, const real* b) {
+  const real x = R_FMA(a[1], b[2], -(a[2] * b[1])), y = R_FMA(a[2], b[0], -(a[0] * b[2])), z = R_FMA(a[0], b[1], -(a[1] * b[0]));
+  o[0] = x; o[1] = y; o[2] = z;
+}
+static inline void ik_mulv(real* o, const real* M, const real* v) {
+  const real x = R_FMA(M[2], v[2], R_FMA(M[1], v[1], M[0] * v[0])), y = R_FMA(M[5], v[2], R_FMA(M[4], v[1], M[3] * v[0])), z = R_FMA(M[8], v[2], R_FMA(M[7], v[1], M[6] * v[0]));
+  o[0] = x; o[1] = y; o[2] = z;
+}
+static inline void ik_mulvadd(real* o, const real* M, const real* v, const real* p) {      /* p + M v */
+  const real x = R_FMA(M[2], v[2], R_FMA(M[1], v[1], R_FMA(M[0], v[0], p[0]))), y = R_FMA(M[5], v[2], R_FMA(M[4], v[1], R_FMA(M[3], v[0], p[1]))),
+             z = R_FMA(M[8], v[2], R_FMA(M[7], v[1], R_FMA(M[6], v[0], p[2])));
+  o[0] = x; o[1] = y; o[2] = z;
+}
+static inline void ik_mul(real* o, const real* A, const real* B) {
+  real t[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) t[3 * i + j] = R_FMA(A[3 * i + 2], B[6 + j], R_FMA(A[3 * i + 1], B[3 + j], A[3 * i] * B[j]));
+  for (int i = 0; i < 9; i++) o[i] = t[i];
+}
+static inline void ik_axis_angle(real* M, const real* a, real q) {
+  const real c = R_COS(q), s = R_SIN(q), t = 1 - c, tx = t * a[0], ty = t * a[1], tz = t * a[2], sx = s * a[0], sy = s * a[1], sz = s * a[2];
+  M[0] = R_FMA(tx, a[0], c);   M[1] = R_FMA(tx, a[1], -sz); M[2] = R_FMA(tx, a[2], sy);
+  M[3] = R_FMA(tx, a[1], sz);  M[4] = R_FMA(ty, a[1], c);   M[5] = R_FMA(ty, a[2], -sx);
+  M[6] = R_FMA(tx, a[2], -sy); M[7] = R_FMA(ty, a[2], sx);  M[8] = R_FMA(tz, a[2], c);
+}
+static inline void ik_quat_mul(real* o, const real* a, const real* b) {
+  const real x = R_FMA(-a[2], b[1], R_FMA(a[1], b[2], R_FMA(a[0], b[3], a[3] * b[0]))), y = R_FMA(a[2], b[0], R_FMA(a[1], b[3], R_FMA(-a[0], b[2], a[3] * b[1]))),
+             z = R_FMA(a[2], b[3], R_FMA(-a[1], b[0], R_FMA(a[0], b[1], a[3] * b[2]))), w = R_FMA(-a[2], b[2], R_FMA(-a[1], b[1], R_FMA(-a[0], b[0], a[3] * b[3])));
+  o[0] = x; o[1] = y; o[2] = z; o[3] = w;
+}
+static void ik_arm_fk(const rpo_env* e, const real* q, xform* xb) {      /* arm_fk in the IK's arithmetic */
+  const rp_model* m = &e->m;
+  for (int k = 0; k < 9; k++) xb[0].R[k] = (real)m->base_rot[k];
+  for (int k = 0; k < 3; k++) xb[0].p[k] = (real)m->base_pos[k];
+  for (int i = 0; i < m->n_arm; i++) {
+    const xform* P = &xb[1 + m->arm_parent[i]];
+    real jr[9], jp[3], ax[3], Rq[9], Rl[9];
+    for (int k = 0; k < 9; k++) jr[k] = (real)m->arm_jrot[i][k];
+    for (int k = 0; k < 3; k++) { jp[k] = (real)m->arm_jpos[i][k]; ax[k] = (real)m->arm_axis[i][k]; }
+    /* the joint's local transform first (rotation jr Rq at jp, or jr at jp + q jr ax), then the parent's composed with it: the HIP library's order */
+    if (m->arm_jtype[i] == 0) {
+      ik_axis_angle(Rq, ax, q[i]);
+      ik_mul(Rl, jr, Rq);
+    } else {
+      real d[3];
+      memcpy(Rl, jr, sizeof(jr));
+      ik_mulv(d, jr, ax);
+      for (int k = 0; k < 3; k++) jp[k] = R_FMA(d[k], q[i], jp[k]);
+    }
+    ik_mul(xb[1 + i].R, P->R, Rl);
+    ik_mulvadd(xb[1 + i].p, P->R, jp, P->p);
+  }
+}
+static void solve_spd(real* A, real* b, int n) {   /* Gaussian elimination with partial pivoting, in place; b <- x (row updates fused like the HIP library's) */
   for (int c = 0; c < n; c++) {
     int piv = c;
     for (int r = c + 1; r < n; r++) if (R_FABS(A[r * n + c]) > R_FABS(A[piv * n + c])) piv = r;
@@ -1734,13 +1790,13 @@ static void solve_spd(real* A, real* b, int n) {   /* Gaussian elimination with 
     }
     for (int r = c + 1; r < n; r++) {
       real f = A[r * n + c] / A[c * n + c];
-      for (int k = c; k < n; k++) A[r * n + k] -= f * A[c * n + k];
-      b[r] -= f * b[c];
+      for (int k = c; k < n; k++) A[r * n + k] = R_FMA(-f, A[c * n + k], A[r * n + k]);
+      b[r] = R_FMA(-f, b[c], b[r]);
     }
   }
   for (int r = n - 1; r >= 0; r--) {
     real s = b[r];
-    for (int k = r + 1; k < n; k++) s -= A[r * n + k] * b[k];
+    for (int k = r + 1; k < n; k++) s = R_FMA(-A[r * n + k], b[k], s);
     b[r] = s / A[r * n + r];
   }
 }
@@ -1754,21 +1810,28 @@ static void ik_solve(const rpo_env* e, const real* pos, const real* quat, const 
   for (int i = 0; i < n; i++) q[i] = q_seed[i];
   for (int it = 0; it < max_iter; it++) {
     xform xb[1 + RP_MAX_ARM];
-    arm_fk(e, q, xb);
+    ik_arm_fk(e, q, xb);
     real p[3], R[9], qc[4];
-    site_world(e, xb, RP_SITE_EE, p, R);
+    {
+      const xform* x = &xb[m->site_body[RP_SITE_EE]];
+      real sp[3], sr[9];
+      for (int i = 0; i < 3; i++) sp[i] = (real)m->site_pos[RP_SITE_EE][i];
+      for (int i = 0; i < 9; i++) sr[i] = (real)m->site_rot[RP_SITE_EE][i];
+      ik_mulvadd(p, x->R, sp, x->p);
+      ik_mul(R, x->R, sr);
+    }
     m3_to_quat(qc, R);
     real err[6];
     v3sub(err, pos, p);
-    if (it > 0 && v3norm(err) < IK_RESIDUAL) break;
+    if (it > 0 && R_SQRT(ik_dot(err, err)) < IK_RESIDUAL) break;
     real qinv[4] = {-qc[0], -qc[1], -qc[2], qc[3]}, dq[4];
-    quat_mul(dq, quat, qinv);
+    ik_quat_mul(dq, quat, qinv);
     /* btQuaternion::getAngle()/getAxis() = 2 acos(w), v / sqrt(1 - w^2), written in the equivalent
      * atan2 / |v| form, which stays accurate in fp32 for small rotations (the HIP path computes in fp32) */
-    real vn = R_SQRT(dq[0] * dq[0] + dq[1] * dq[1] + dq[2] * dq[2]);
+    real vn = R_SQRT(ik_dot(dq, dq));
     real angle = 2 * R_ATAN2(vn, dq[3]);
     real axis[3] = {1, 0, 0};
-    if (vn >= (real)1e-12) for (int k = 0; k < 3; k++) axis[k] = dq[k] / vn;
+    if (vn >= (real)1e-12) { const real sc = 1 / vn; for (int k = 0; k < 3; k++) axis[k] = dq[k] * sc; }
     if (angle > RP_PI) angle -= 2 * RP_PI;
     for (int k = 0; k < 3; k++) err[3 + k] = angle * axis[k];
     /* Jacobian columns of the chain to the site */
@@ -1777,10 +1840,10 @@ static void ik_solve(const rpo_env* e, const real* pos, const real* quat, const 
     for (int i = m->site_body[RP_SITE_EE] - 1; i >= 0; i = m->arm_parent[i]) {
       real ax[3], a[3];
       for (int k = 0; k < 3; k++) ax[k] = (real)m->arm_axis[i][k];
-      m3mulv(a, xb[1 + i].R, ax);
+      ik_mulv(a, xb[1 + i].R, ax);
       if (m->arm_jtype[i] == 0) {
         real r[3], c[3];
-        v3sub(r, p, xb[1 + i].p); v3cross(c, a, r);
+        v3sub(r, p, xb[1 + i].p); ik_cross(c, a, r);
         for (int k = 0; k < 3; k++) { J[k][i] = c[k]; J[3 + k][i] = a[k]; }
       } else {
         for (int k = 0; k < 3; k++) J[k][i] = a[k];
@@ -1789,19 +1852,19 @@ static void ik_solve(const rpo_env* e, const real* pos, const real* quat, const 
     real A[RP_MAX_ARM * RP_MAX_ARM], b[RP_MAX_ARM];
     for (int r = 0; r < n; r++) {
       for (int c = 0; c < n; c++) {
-        real s = 0;
-        for (int k = 0; k < 6; k++) s += J[k][r] * J[k][c];
+        real s = J[0][r] * J[0][c];
+        for (int k = 1; k < 6; k++) s = R_FMA(J[k][r], J[k][c], s);
         A[r * n + c] = s + (r == c ? IK_DAMP : 0);
       }
-      real s = 0;
-      for (int k = 0; k < 6; k++) s += J[k][r] * err[k];
+      real s = J[0][r] * err[0];
+      for (int k = 1; k < 6; k++) s = R_FMA(J[k][r], err[k], s);
       b[r] = s;
     }
     solve_spd(A, b, n);
     real mx = 0;
     for (int i = 0; i < n; i++) if (R_FABS(b[i]) > mx) mx = R_FABS(b[i]);
     real sc = mx > IK_MAX_STEP ? IK_MAX_STEP / mx : 1;
-    for (int i = 0; i < n; i++) q[i] += sc * b[i];
+    for (int i = 0; i < n; i++) q[i] = R_FMA(sc, b[i], q[i]);
   }
 }
 
@@ -2744,4 +2807,103 @@ double rpo_bench_rollout(int kind, unsigned long long seed, int n_envs, int n_st
   for (int t = 0; t < n_threads; t++) { pthread_join(th[t], 0); if (args[t].t0 < t0) t0 = args[t].t0; if (args[t].t1 > t1) t1 = args[t].t1; }
   pthread_barrier_destroy(&bar);
   return t1 - t0;
+}
+
+/* ------------------------------------------------------------------ exactness check of the support-vertex candidate tables (generated/rp_hullcells_gen.h; tools/bake_hull_cells.py)
+ * The HIP library answers every hull support query from the cube-map cell of the query's direction; the oracle keeps scanning all vertices.  These functions restate the
+ * LIBRARY's lookup in fp32 (rp_kernels.cuh hcell_of, hull_coord) so that tests/test_hull_cells.py can hold it against the full scan: same winner - the largest (smallest)
+ * computed coordinate, the lowest vertex number among equals - for every direction. */
+#include "../roboticsplayroompybullet_amd/csrc/generated/rp_hullcells_gen.h"
+int rpo_hullcell_of(const float* d) {
+  const float ax = fabsf(d[0]), ay = fabsf(d[1]), az = fabsf(d[2]);
+  int m = 0; float dm = d[0], dp = d[1], dq = d[2], am = ax;
+  if (ay > am) { m = 1; dm = d[1]; dp = d[2]; dq = d[0]; am = ay; }
+  if (az > am) { m = 2; dm = d[2]; dp = d[0]; dq = d[1]; am = az; }
+  const float inv = 1.0f / am;
+  const float a = dp * inv, b = dq * inv;
+  int i = (int)floorf((a + 1.0f) * (0.5f * RP_HCELL_G)), j = (int)floorf((b + 1.0f) * (0.5f * RP_HCELL_G));
+  i = i < 0 ? 0 : (i > RP_HCELL_G - 1 ? RP_HCELL_G - 1 : i); j = j < 0 ? 0 : (j > RP_HCELL_G - 1 ? RP_HCELL_G - 1 : j);
+  return ((2 * m + (dm < 0.0f ? 1 : 0)) * RP_HCELL_G + i) * RP_HCELL_G + j;
+}
+static inline float hullcell_coord(const float* u, const float* v, float c) { return fmaf(u[2], v[2], fmaf(u[1], v[1], u[0] * v[0])) - c; }
+/* the vertex of collider `col` with the largest (want_min: smallest) hull_coord(u, v, c), lowest number among equals: by the full scan (table = 0) or from the cell of
+ * +u (-u) (table = 1); *val = its coordinate, *cands = vertices looked at.  -1 = the collider has no hull */
+int rpo_hull_support(int kind, int col, const float* u, float c, int want_min, int table, float* val, int* cands) {
+  const float (*hv)[4]; const int *hoff, *hcnt;
+  rp_hull_tables(kind, &hv, &hoff, &hcnt);
+  const unsigned short* idx; const int *off, *first; int total;
+  if (!rp_hcell_tables(kind, &idx, &off, &first, &total)) return -1;
+  if (col < 0 || col >= 64 || hcnt[col] == 0 || first[col] < 0) return -1;
+  hv += hoff[col];
+  int best = -1; float bv = 0;
+  if (!table) {
+    for (int i = 0; i < hcnt[col]; i++) {
+      const float l = hullcell_coord(u, hv[i], c);
+      if (best < 0 || (want_min ? l < bv : l > bv)) { bv = l; best = i; }
+    }
+    if (cands) *cands = hcnt[col];
+  } else {
+    const float nu[3] = {-u[0], -u[1], -u[2]};
+    const int cell = rpo_hullcell_of(want_min ? nu : u);
+    const int o0 = off[first[col] + cell], o1 = off[first[col] + cell + 1];
+    for (int k = o0; k < o1; k++) {
+      const int i = idx[k];
+      if (i >= hcnt[col]) return -2;
+      const float l = hullcell_coord(u, hv[i], c);
+      if (best < 0 || (want_min ? l < bv : l > bv)) { bv = l; best = i; }      /* (rising vertex numbers: the first of equals is the lowest) */
+    }
+    if (cands) *cands = o1 - o0;
+  }
+  if (val) *val = bv;
+  return best;
+}
+/* n directions per hull of `kind` (mode 0: random directions of random length 1e-5 .. 1 and random box-centre coordinates; 1: the coordinate axes and small steps off them;
+ * 2: on and next to the borders of the cube map's cells and faces), each as a max and as a min query: returns the number of queries in which table and full scan part,
+ * *queries = how many were made, *mean_cands = the mean number of candidates a table query looked at */
+long rpo_hullcell_selftest(int kind, long n, int mode, unsigned long long seed, long* queries, double* mean_cands) {
+  const float (*hv)[4]; const int *hoff, *hcnt;
+  rp_hull_tables(kind, &hv, &hoff, &hcnt);
+  long bad = 0, nq = 0; double sum = 0;
+  uint64_t st = seed;
+#define RU() ((double)(splitmix64(st += 0x9E3779B97F4A7C15ULL) >> 11) * (1.0 / 9007199254740992.0))
+  for (int col = 0; col < 64; col++) {
+    if (hcnt[col] == 0) continue;
+    for (long t = 0; t < n; t++) {
+      float u[3]; float c = (float)(4 * RU() - 2);
+      if (mode == 0) {
+        double g[3], l2 = 0;
+        for (int k = 0; k < 3; k++) { const double u1 = RU() + 1e-12, u2 = RU(); g[k] = sqrt(-2 * log(u1)) * cos(6.283185307179586 * u2); l2 += g[k] * g[k]; }
+        const double len = (t & 1) ? 1.0 : pow(10.0, -5 * RU());
+        for (int k = 0; k < 3; k++) u[k] = (float)(g[k] / sqrt(l2) * len);
+        if (!(t & 1)) c = 0;                                /* (the library subtracts a box-centre coordinate only from UNIT directions' coordinates - the face scan, the probe -; GJK's directions, of any length, go without) */
+      } else if (mode == 1) {
+        const int ax = (int)(t % 3), sg = (t / 3) & 1;
+        const double tilt = ((t / 6) % 4 == 0) ? 0 : pow(10.0, -8 * RU());
+        for (int k = 0; k < 3; k++) u[k] = (float)(k == ax ? (sg ? -1.0 : 1.0) : tilt * (2 * RU() - 1));
+        { double l2 = 0; for (int k = 0; k < 3; k++) l2 += (double)u[k] * u[k]; for (int k = 0; k < 3; k++) u[k] = (float)(u[k] / sqrt(l2)); }
+      } else {
+        const int m = (int)(t % 3), sg = (t / 3) & 1;
+        const int gi = (int)(RU() * (RP_HCELL_G + 1));
+        double a = -1 + 2.0 * gi / RP_HCELL_G, b = 2 * RU() - 1;
+        const int w = (int)((t / 6) % 5);
+        a += (w == 1 ? 1e-7 : w == 2 ? -1e-7 : w == 3 ? 3e-6 : w == 4 ? -3e-6 : 0);
+        if ((t / 30) & 1) { b = -1 + 2.0 * (int)(RU() * (RP_HCELL_G + 1)) / RP_HCELL_G; }
+        const double len = (t & 64) ? 1.0 : pow(10.0, -4 * RU());
+        double d3[3]; d3[m] = sg ? -1 : 1; d3[(m + 1) % 3] = a; d3[(m + 2) % 3] = b;
+        if ((t / 60) & 1) { const double tmp = d3[(m + 1) % 3]; d3[(m + 1) % 3] = d3[(m + 2) % 3]; d3[(m + 2) % 3] = tmp; }
+        for (int k = 0; k < 3; k++) u[k] = (float)(d3[k] * len);
+        if (!(t & 64)) c = 0;
+      }
+      for (int want_min = 0; want_min < 2; want_min++) {
+        float v0, v1; int nc = 0;
+        const int i0 = rpo_hull_support(kind, col, u, c, want_min, 0, &v0, 0), i1 = rpo_hull_support(kind, col, u, c, want_min, 1, &v1, &nc);
+        nq++; sum += nc;
+        if (i0 != i1 || v0 != v1) bad++;
+      }
+    }
+  }
+#undef RU
+  if (queries) *queries = nq;
+  if (mean_cands) *mean_cands = nq ? sum / (double)nq : 0;
+  return bad;
 }

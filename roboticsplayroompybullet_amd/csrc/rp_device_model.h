@@ -107,6 +107,11 @@ typedef struct DevModel {
   float* pmcache;                 /* [N][PMC_FLOATS], device memory owned by the handle */
   const float* hullv;
   int hull_off[RP_MAX_COL], hull_cnt[RP_MAX_COL];
+  /* support-vertex candidate tables of those hulls (generated/rp_hullcells_gen.h; rp_kernels.cuh hcell_of): hcv = every cell's candidates as (x, y, z, vertex number) -
+   * device memory, expanded from the baked vertex numbers by rp_create -, hco = per hull RP_HCELL_N + 1 offsets into it, hcell_first[collider] = the hull's place in hco (-1: no hull) */
+  const float* hcv;
+  const int* hco;
+  int hcell_first[RP_MAX_COL];
 } DevModel;
 
 static inline int rp_dm_dof_of_joint(const rp_model* m, int j) {

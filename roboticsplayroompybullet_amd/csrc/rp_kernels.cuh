@@ -533,17 +533,20 @@ __device__ __forceinline__ float hull_coord(V3 u, float4 v, float c) { return __
 #define GJK_REL 1e-12
 #define GJK_ZERO 1e-20
 #define GJK_STALL (1.0 - 1e-14)
-/* One pass of the wave over a link's hull vertices (lane, lane + 64, ...; per lane in rising order), HULL_UNROLL loads in flight at a time.  Measured with
- * 2 / 4 / 8: nothing (the table sits in L2, the links near the scene have some two hundred vertices - three rounds) and the registers do not exist: 1 */
-template <int HULL_UNROLL, class F>
-__device__ __forceinline__ void hull_scan(const float4* __restrict__ tv, int nn, int lane, F&& f) {
-  for (int base = lane; base < nn; base += 64 * HULL_UNROLL) {
-    float4 q[HULL_UNROLL];
-#pragma unroll
-    for (int u = 0; u < HULL_UNROLL; u++) { const int i = base + 64 * u; q[u] = tv[i < nn ? i : base]; }
-#pragma unroll
-    for (int u = 0; u < HULL_UNROLL; u++) { const int i = base + 64 * u; if (i < nn) f(q[u], i); }
-  }
+/* Support-vertex candidate tables (generated/rp_hullcells_gen.h, tools/bake_hull_cells.py): the cube-map cell of a direction holds every vertex of the link's hull that can
+ * have the largest coordinate along some direction of the cell - a superset wide enough for fp32 rounding, so that scanning the cell returns the very vertex a scan of the
+ * whole hull returns (the largest computed coordinate, the lowest vertex number among equals; tests/test_hull_cells.py: 10^6 directions per arm against the oracle's full
+ * scan).  A cell has 3 - 8 candidates at the median where a link has 200 - 1000 vertices.  DevModel.hcv: the lists as (x, y, z, vertex number), hull after hull; DevModel.hco:
+ * per hull RP_HCELL_N + 1 offsets; DevModel.hcell_first[collider]: the hull's place in hco.  (The oracle keeps scanning whole hulls: the tables are the library's alone.) */
+__device__ __forceinline__ int hcell_of(V3 d) {
+  const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+  int m = 0; float dm = d.x, dp = d.y, dq = d.z, am = ax;
+  if (ay > am) { m = 1; dm = d.y; dp = d.z; dq = d.x; am = ay; }
+  if (az > am) { m = 2; dm = d.z; dp = d.x; dq = d.y; am = az; }
+  const float inv = __builtin_amdgcn_rcpf(fmaxf(am, 1e-30f));      /* (1 ulp: the cells are baked 1e-4 wider than they are; a zero vector - an unused probe - lands in some cell) */
+  int i = (int)floorf((dp * inv + 1.f) * (0.5f * RP_HCELL_G)), j = (int)floorf((dq * inv + 1.f) * (0.5f * RP_HCELL_G));
+  i = min(max(i, 0), RP_HCELL_G - 1); j = min(max(j, 0), RP_HCELL_G - 1);
+  return ((2 * m + (dm < 0.f ? 1 : 0)) * RP_HCELL_G + i) * RP_HCELL_G + j;
 }
 /* wave-wide reductions through DPP (no LDS round trip: six butterflies through ds_bpermute cost ~900 cycles of latency per scan): every lane ends with the result */
 __device__ __forceinline__ float wave_max_f(float v) {
@@ -750,24 +753,42 @@ __device__ __forceinline__ void hull_item(const DevModel* m, LDS& L, const int l
         }
         const int nn = m->hull_cnt[ca];
         const float4* tv = (const float4*)m->hullv + m->hull_off[ca];
-        float lo0 = 1e30f, lo1 = 1e30f, lo2 = 1e30f, hi0 = -1e30f, hi1 = -1e30f, hi2 = -1e30f, pmin = 1e30f;
-        int il0 = 0x7fffffff, il1 = 0x7fffffff, il2 = 0x7fffffff, ih0 = 0x7fffffff, ih1 = 0x7fffffff, ih2 = 0x7fffffff;      /* the vertex that gave this lane each of its extremes (the first one: a lane meets its vertices in rising order) */
-        bool in_core = false;                                /* a vertex strictly inside the box core: the cores overlap, GJK would only find that out the long way */
+        const float4* __restrict__ cv = (const float4*)m->hcv;
+        const int* __restrict__ co = m->hco + m->hcell_first[ca];
+        /* the hull's extent along the box's three axes - six support queries - and its clearance along the probe direction, a seventh: one group of eight lanes per query
+         * (groups 0 / 1: the lowest / highest l_0, 2 / 3: l_1, 4 / 5: l_2, 6: the lowest coordinate along the probe), each scanning the cell of its direction, eight
+         * candidates a round (rising vertex numbers in every lane's sequence: a lane's first strict extreme is its lowest-numbered one), then the groups' reductions side by
+         * side in three DPP steps.  (Until round 5 the wave scanned the whole hull, 4 - 16 rounds of 64 vertices with six running extremes and their vertex numbers per lane.) */
+        float lo0, lo1, lo2, hi0, hi1, hi2, pmin;
+        int il0, il1, il2, ih0, ih1, ih2;
         {
-          const V3 hin = mk3(hc0.x - fminf(RP_HULL_MARGIN, hc0.x) - 1e-6f, hc0.y - fminf(RP_HULL_MARGIN, hc0.y) - 1e-6f, hc0.z - fminf(RP_HULL_MARGIN, hc0.z) - 1e-6f);
-          hull_scan<2>(tv, nn, lane, [&](const float4& v, int i) {
-            const float l0 = hull_coord(u0, v, c0), l1 = hull_coord(u1, v, c1), l2 = hull_coord(u2, v, c2);
-            if (l0 < lo0) { lo0 = l0; il0 = i; } if (l0 > hi0) { hi0 = l0; ih0 = i; }
-            if (l1 < lo1) { lo1 = l1; il1 = i; } if (l1 > hi1) { hi1 = l1; ih1 = i; }
-            if (l2 < lo2) { lo2 = l2; il2 = i; } if (l2 > hi2) { hi2 = l2; ih2 = i; }
-            pmin = fminf(pmin, hull_coord(up, v, cp));
-            in_core |= fabsf(l0) < hin.x && fabsf(l1) < hin.y && fabsf(l2) < hin.z;
-          });
+          const int g8 = lane >> 3, s8 = lane & 7;
+          const V3 um = g8 < 2 ? u0 : (g8 < 4 ? u1 : (g8 < 6 ? u2 : up));
+          const float cm = g8 < 2 ? c0 : (g8 < 4 ? c1 : (g8 < 6 ? c2 : cp));
+          const bool wmax = (g8 & 1) != 0;
+          const bool act = g8 < 6 || (g8 == 6 && (up.x != 0.f || up.y != 0.f || up.z != 0.f));
+          const int cell = hcell_of(wmax ? um : -um);
+          const int o0 = co[cell], o1 = act ? co[cell + 1] : o0;
+          float bestv = -1e30f; int besti = 0x7fffffff;
+          for (int base = o0 + s8; __any(base < o1); base += 8) {
+            const float4 q = cv[base < o1 ? base : o0];
+            const float l = hull_coord(um, q, cm);
+            const float val = wmax ? l : -l;
+            if (base < o1 && val > bestv) { bestv = val; besti = __float_as_int(q.w); }
+          }
+          float gm = bestv;
+          gm = fmaxf(gm, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(gm), 0xB1, 0xF, 0xF, true)));
+          gm = fmaxf(gm, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(gm), 0x4E, 0xF, 0xF, true)));
+          gm = fmaxf(gm, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(gm), 0x141, 0xF, 0xF, true)));      /* (row_half_mirror: the other quad of the eight) */
+          int gi = bestv == gm ? besti : 0x7fffffff;
+          gi = min(gi, __builtin_amdgcn_update_dpp(0, gi, 0xB1, 0xF, 0xF, true));
+          gi = min(gi, __builtin_amdgcn_update_dpp(0, gi, 0x4E, 0xF, 0xF, true));
+          gi = min(gi, __builtin_amdgcn_update_dpp(0, gi, 0x141, 0xF, 0xF, true));
+          lo0 = -lane_read(gm, 0); hi0 = lane_read(gm, 8); lo1 = -lane_read(gm, 16); hi1 = lane_read(gm, 24); lo2 = -lane_read(gm, 32); hi2 = lane_read(gm, 40);
+          pmin = -lane_read(gm, 48);
+          il0 = __builtin_amdgcn_readlane(gi, 0); ih0 = __builtin_amdgcn_readlane(gi, 8); il1 = __builtin_amdgcn_readlane(gi, 16); ih1 = __builtin_amdgcn_readlane(gi, 24);
+          il2 = __builtin_amdgcn_readlane(gi, 32); ih2 = __builtin_amdgcn_readlane(gi, 40);
         }
-        const bool core_hit = __ballot(in_core) != 0ull;
-        const float my_lo0 = lo0, my_lo1 = lo1, my_lo2 = lo2, my_hi0 = hi0, my_hi1 = hi1, my_hi2 = hi2;      /* (this lane's own extremes: which lane holds the wave's is asked below) */
-        lo0 = wave_min_f(lo0); lo1 = wave_min_f(lo1); lo2 = wave_min_f(lo2); hi0 = wave_max_f(hi0); hi1 = wave_max_f(hi1); hi2 = wave_max_f(hi2);
-        pmin = wave_min_f(pmin);
         const float g0 = lo0 - hcm.x, g1 = -hi0 - hcm.x, g2 = lo1 - hcm.y, g3 = -hi1 - hcm.y, g4 = lo2 - hcm.z, g5 = -hi2 - hcm.z;      /* face +k: lowest vertex above it; face -k: highest vertex below it */
         float best = g0; int bf = 0;
         if (g1 > best + K_TIE_EPS) { best = g1; bf = 1; }
@@ -783,17 +804,9 @@ __device__ __forceinline__ void hull_item(const DevModel* m, LDS& L, const int l
         int out = 0;                                         /* this pair's hf */
         V3 nloc = mk3(0, 0, 0), ploc = mk3(0, 0, 0); float dcon = 0.f;      /* the contact in the BOX's frame: normal (box toward hull), point on the box's surface, distance */
         if (!(d > mg)) {                                     /* (wave-uniform) */
-          /* the first vertex (lowest index: the oracle's sequential scan keeps the first strict extreme) whose coordinate along that axis IS the extreme: every lane
-           * kept the first vertex of its own extreme during the scan above (no second pass over the hull: 3 k cycles a pair), the lanes whose extreme is the wave's
-           * offer theirs, the lowest index wins */
+          /* the first vertex (lowest number: the oracle's sequential scan keeps the first strict extreme) whose coordinate along that axis IS the extreme: its group kept it */
           const int k = bf >> 1;
-          const V3 uk = pick3(k, u0, u1, u2);
-          const float ck = pick1(k, c0, c1, c2);
-          const float ext = (bf & 1) ? pick1(k, hi0, hi1, hi2) : pick1(k, lo0, lo1, lo2);
-          const float myv = (bf & 1) ? pick1(k, my_hi0, my_hi1, my_hi2) : pick1(k, my_lo0, my_lo1, my_lo2);
-          const int myi = (bf & 1) ? (k == 0 ? ih0 : (k == 1 ? ih1 : ih2)) : (k == 0 ? il0 : (k == 1 ? il1 : il2));
-          int iv = wave_min_i(myv == ext ? myi : 0x7fffffff);
-          (void)uk; (void)ck;
+          const int iv = (bf & 1) ? (k == 0 ? ih0 : (k == 1 ? ih1 : ih2)) : (k == 0 ? il0 : (k == 1 ? il1 : il2));
           out = -1;
           if (iv != 0x7fffffff) {
             const float4 v = tv[iv];
@@ -808,8 +821,6 @@ __device__ __forceinline__ void hull_item(const DevModel* m, LDS& L, const int l
             } else if (probe_apart) {
               out = 0;                                       /* (only here: a vertex OVER the face within the margin is a contact whatever the probe says - it can be a
                                                               * millimetre beside the box CORE's face and read 'apart' by a fraction of the shape margin.  The cache stays) */
-            } else if (m->gjk && core_hit) {
-              if (warm && lane == 0) gslot[0] = __int_as_float(0);      /* cores overlap: the OBB path (out = -1), and the pair's cached simplex goes (the oracle's GJK ends the same way) */
             } else if (m->gjk) {
               /* the deepest vertex lies BESIDE the face (box edges and corners): GJK's distance phase, cores with the 0.001 margin around each (oracle hull_box_gjk;
                * -1 again = the cores touch or overlap: the OBB path keeps that case).  Box frame, the simplex in registers, seeded with lv against the corner(s)
@@ -872,13 +883,17 @@ __device__ __forceinline__ void hull_item(const DevModel* m, LDS& L, const int l
                 {                                            /* hull: the vertex of largest projection on -v (lowest index among equals) */
                   const V3 dl = -(u0 * vf.x + u1 * vf.y + u2 * vf.z);
                   float bd = -1e30f; int bi = 0x7fffffff; V3 bq = mk3(0, 0, 0);
-                  hull_scan<4>(tv, nn, lane, [&](const float4& q, int i) {      /* (four loads in flight) */
+                  const int cell = __builtin_amdgcn_readfirstlane(hcell_of(dl));
+                  const int o0 = co[cell], o1 = co[cell + 1];      /* (the cell of the direction: a few vertices, one round of the wave - three for a rim circle seen along its axis) */
+                  for (int base = o0 + lane; base - lane < o1; base += 64) {
+                    const float4 q = cv[base < o1 ? base : o0];
                     const float dq = __fmaf_rn(dl.z, q.z, __fmaf_rn(dl.y, q.y, dl.x * q.x));
-                    if (dq > bd) { bd = dq; bi = i; bq = mk3(q.x, q.y, q.z); }
-                  });
+                    if (base < o1 && dq > bd) { bd = dq; bi = __float_as_int(q.w); bq = mk3(q.x, q.y, q.z); }
+                  }
                   const float top = wave_max_f(bd);
-                  wi = wave_min_i(bd == top ? bi : 0x7fffffff);
-                  const int win = wi & 63;                   /* (vertex i was scanned by lane i & 63) */
+                  const int key = wave_min_i(bd == top ? ((bi << 6) | lane) : 0x7fffffff);      /* (the lowest vertex number among equals; the lane that holds it rides along) */
+                  wi = key >> 6;
+                  const int win = key & 63;
                   const V3 q = mk3(lane_read(bq.x, win), lane_read(bq.y, win), lane_read(bq.z, win));
                   wa = mk3(hull_coord(u0, make_float4(q.x, q.y, q.z, 0.f), c0), hull_coord(u1, make_float4(q.x, q.y, q.z, 0.f), c1), hull_coord(u2, make_float4(q.x, q.y, q.z, 0.f), c2));
                 }
@@ -1487,7 +1502,7 @@ __device__ __forceinline__ int collide(const DevModel* m, LDS& L, int lane, int 
      * - among the points as they are now, before any candidate of this substep goes in (the oracle's rule: that is what makes this parallel).  A matched
      * candidate replaces that point - of several on one slot the last in pair order (LDS max over the lane numbers) stays; the unmatched ones (a contact
      * in its first substep: rare) go in afterwards, one after the other, in the lane of their manifold */
-    unsigned long long unmatched;
+    unsigned long long unmatched, mine = 0ull;      /* candidates that matched no cached point: all of them | those of manifold `lane` */
     {
       int ncand = 0;
       if (lane < nact) { const int cn = L.candn[lane]; ncand = (cn >> 8) + (cn & 255); }
@@ -1526,18 +1541,21 @@ __device__ __forceinline__ int collide(const DevModel* m, LDS& L, int lane, int 
         st3(P, lA); st3(P + 3, lB); st3(P + 6, nr); P[9] = dist; P[10] = __int_as_float(abw & (int)0xFFC0FFFF);      /* colliders and bodies (the pair index is of this substep only) */
       }
       unmatched = __ballot(mi >= 0 && sl < 0);
+      if (unmatched != 0ull)                                 /* (wave-uniform) every manifold's own list: sequential inside a manifold, the manifolds side by side */
+        for (int jm = 0; jm < npm; jm++) { const unsigned long long b = __ballot(mi == jm && sl < 0); if (lane == jm) mine = b; }
       WSYNC();
     }
-    if (unmatched != 0ull && lane < npm) {                   /* (rare) lane i adds the unmatched candidates of manifold i, one after the other */
-      float* M = &C[PMC_HDR + PMC_MAN * lane];
-      const int key = __float_as_int(M[0]);
+    if (unmatched != 0ull) {                                 /* (a contact in its first substep) lane i adds the unmatched candidates of manifold i, one after the other in pair
+                                                              * order - round r takes every manifold's r-th at once (until round 5 the lanes walked ALL unmatched candidates and
+                                                              * skipped the other manifolds': 64 first contacts of an arm falling onto the furniture cost 80 k cycles) */
+      float* M = &C[PMC_HDR + PMC_MAN * (lane < npm ? lane : 0)];
       int n = __float_as_int(M[1]);
       const float thr = M[2];
-      for (unsigned long long todo = unmatched; todo != 0ull; todo &= todo - 1ull) {
+      for (unsigned long long todo = lane < npm ? mine : 0ull; __any(todo != 0ull); todo &= todo - 1ull) {
+        if (todo == 0ull) continue;
         const int ci = __ffsll((long long)todo) - 1;
         const float* c = &L.cand[8 * ci];
         const int abw = __float_as_int(c[7]);
-        if ((L.key[(abw >> 16) & 63] & 0xFFFF) != key) continue;
         const V3 p = ld3(c), nr = mk3(c[3], c[4], c[5]);
         const float dist = c[6];
         const int ba = (abw >> 22) & 31, bb = (abw >> 27) & 31;
@@ -1565,7 +1583,7 @@ __device__ __forceinline__ int collide(const DevModel* m, LDS& L, int lane, int 
         float* P = &M[8 + PMC_PT * sl];
         st3(P, lA); st3(P + 3, lB); st3(P + 6, nr); P[9] = dist; P[10] = __int_as_float(abw & (int)0xFFC0FFFF);
       }
-      M[1] = __int_as_float(n);
+      if (lane < npm) M[1] = __int_as_float(n);
     }
     WSYNC();
     PCLK(23)
@@ -2274,7 +2292,40 @@ struct ChainQ { float q[7]; };
  * broadcast), the back-substitution walks the pivots once.  ~700 instructions per iteration instead of ~2 700 for one
  * lane per env, and four times as many waves.  NC = chain length (6 UR5, 7 Panda).  All lanes of a row must call it
  * with the same target; qj = this lane's joint value; returns the new one.  `live` = this row has an env at all. */
-__device__ __forceinline__ Xf xf_compose(const Xf& a, const Xf& b) { Xf r; r.R = mul(a.R, b.R); r.p = a.p + mulv(a.R, b.p); return r; }
+/* The IK's arithmetic is written with FUSED multiply-adds in a fixed order (the library is compiled with -ffp-contract=off: nothing fuses by itself), and the oracle's
+ * ik_solve has the same fma in the same places (rp_oracle.c ik_* helpers): 1 139 instead of 1 346 VALU instructions per iteration, on a phase every chain of a step starts
+ * with (round 4 measured the fused IK against the UNFUSED oracle and had to reject it; mirrored, the two round alike). */
+__device__ __forceinline__ float dotF(V3 a, V3 b) { return __fmaf_rn(a.z, b.z, __fmaf_rn(a.y, b.y, a.x * b.x)); }
+__device__ __forceinline__ V3 crossF(V3 a, V3 b) { return mk3(__fmaf_rn(a.y, b.z, -(a.z * b.y)), __fmaf_rn(a.z, b.x, -(a.x * b.z)), __fmaf_rn(a.x, b.y, -(a.y * b.x))); }
+__device__ __forceinline__ V3 mulvF(const M3& a, V3 v) {
+  return mk3(__fmaf_rn(a.m[2], v.z, __fmaf_rn(a.m[1], v.y, a.m[0] * v.x)), __fmaf_rn(a.m[5], v.z, __fmaf_rn(a.m[4], v.y, a.m[3] * v.x)), __fmaf_rn(a.m[8], v.z, __fmaf_rn(a.m[7], v.y, a.m[6] * v.x)));
+}
+__device__ __forceinline__ V3 mulvaddF(const M3& a, V3 v, V3 p) {      /* p + a v */
+  return mk3(__fmaf_rn(a.m[2], v.z, __fmaf_rn(a.m[1], v.y, __fmaf_rn(a.m[0], v.x, p.x))), __fmaf_rn(a.m[5], v.z, __fmaf_rn(a.m[4], v.y, __fmaf_rn(a.m[3], v.x, p.y))),
+             __fmaf_rn(a.m[8], v.z, __fmaf_rn(a.m[7], v.y, __fmaf_rn(a.m[6], v.x, p.z))));
+}
+__device__ __forceinline__ M3 mulF(const M3& a, const M3& b) {
+  M3 r;
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) r.m[3 * i + j] = __fmaf_rn(a.m[3 * i + 2], b.m[6 + j], __fmaf_rn(a.m[3 * i + 1], b.m[3 + j], a.m[3 * i] * b.m[j]));
+  return r;
+}
+__device__ __forceinline__ M3 axis_angleF(V3 a, float q) {
+  float s, c;
+  sincosf(q, &s, &c);
+  const float t = 1.f - c, tx = t * a.x, ty = t * a.y, tz = t * a.z, sx = s * a.x, sy = s * a.y, sz = s * a.z;
+  M3 r = {{__fmaf_rn(tx, a.x, c), __fmaf_rn(tx, a.y, -sz), __fmaf_rn(tx, a.z, sy), __fmaf_rn(tx, a.y, sz), __fmaf_rn(ty, a.y, c), __fmaf_rn(ty, a.z, -sx), __fmaf_rn(tx, a.z, -sy),
+           __fmaf_rn(ty, a.z, sx), __fmaf_rn(tz, a.z, c)}};
+  return r;
+}
+__device__ __forceinline__ Q4 qmulF(Q4 a, Q4 b) {
+  Q4 r = {__fmaf_rn(-a.z, b.y, __fmaf_rn(a.y, b.z, __fmaf_rn(a.x, b.w, a.w * b.x))), __fmaf_rn(a.z, b.x, __fmaf_rn(a.y, b.w, __fmaf_rn(-a.x, b.z, a.w * b.y))),
+          __fmaf_rn(a.z, b.w, __fmaf_rn(-a.y, b.x, __fmaf_rn(a.x, b.y, a.w * b.z))), __fmaf_rn(-a.z, b.z, __fmaf_rn(-a.y, b.y, __fmaf_rn(-a.x, b.x, a.w * b.w)))};
+  return r;
+}
+__device__ __forceinline__ Xf xf_compose(const Xf& a, const Xf& b) { Xf r; r.R = mulF(a.R, b.R); r.p = mulvaddF(a.R, b.p, a.p); return r; }
 template <int D>
 __device__ __forceinline__ Xf xf_shr(const Xf& x) {
   Xf r;
@@ -2293,15 +2344,15 @@ __device__ __forceinline__ void chain_fk_coop(const M3& R0, V3 p0, V3 ax, bool r
   Xf x; x.R = ident3(); x.p = mk3(0, 0, 0);
   if (isj) {
     x.R = R0; x.p = p0;
-    if (rev) x.R = mul(R0, axis_angle(ax, qj)); else x.p = p0 + mulv(R0, ax) * qj;
+    if (rev) x.R = mulF(R0, axis_angleF(ax, qj)); else { const V3 d = mulvF(R0, ax); x.p = mk3(__fmaf_rn(d.x, qj, p0.x), __fmaf_rn(d.y, qj, p0.y), __fmaf_rn(d.z, qj, p0.z)); }
   }
   if (l16 == 0) x = xf_compose(base, x);
   { Xf y = xf_shr<1>(x); Xf z = xf_compose(y, x); if (l16 >= 1) x = z; }
   { Xf y = xf_shr<2>(x); Xf z = xf_compose(y, x); if (l16 >= 2) x = z; }
   { Xf y = xf_shr<4>(x); Xf z = xf_compose(y, x); if (l16 >= 4) x = z; }
-  org = x.p; axw = mulv(x.R, ax);
-  const V3 posl = x.p + mulv(x.R, sp);
-  const M3 Rsl = mul(x.R, sr);
+  org = x.p; axw = mulvF(x.R, ax);
+  const V3 posl = mulvaddF(x.R, sp, x.p);
+  const M3 Rsl = mulF(x.R, sr);
   pos = mk3(bcast16<NC - 1>(posl.x), bcast16<NC - 1>(posl.y), bcast16<NC - 1>(posl.z));
 #pragma unroll
   for (int k = 0; k < 9; k++) Rs.m[k] = bcast16<NC - 1>(Rsl.m[k]);
@@ -2369,7 +2420,7 @@ __device__ float ik_coop(const DevModel* m, V3 tpos, Q4 tq, float qj, int max_it
     V3 org, axw, pos; M3 Rs;
     chain_fk_coop<NC>(R0, p0, ax, rev, base, sp, sr, qj, l16, org, axw, pos, Rs);
     const V3 ep = tpos - pos;
-    const float res = norm(ep);
+    const float res = sqrtf(dotF(ep, ep));
     /* a stopping test decided within 0.5 % of the threshold (fp32 rounding of a residual of 1e-4 on positions of order 1: ~0.1 %): another evaluation order
      * of the same arithmetic (the CPU oracle's) may stop an iteration earlier or later and end ~5e-5 rad elsewhere (status bit 16 of the step; the parity
      * tests read it) */
@@ -2379,8 +2430,8 @@ __device__ float ik_coop(const DevModel* m, V3 tpos, Q4 tq, float qj, int max_it
     /* pose error, by every lane alike */
     Q4 qc = m3_to_quat(Rs);
     Q4 qi = {-qc.x, -qc.y, -qc.z, qc.w};
-    Q4 dq = qmul(tq, qi);
-    float vn = sqrtf(dq.x * dq.x + dq.y * dq.y + dq.z * dq.z);     /* 2 acos(w) in its fp32-safe atan2 form */
+    Q4 dq = qmulF(tq, qi);
+    float vn = sqrtf(__fmaf_rn(dq.z, dq.z, __fmaf_rn(dq.y, dq.y, dq.x * dq.x)));     /* 2 acos(w) in its fp32-safe atan2 form */
     float angle = 2.f * atan2f(vn, dq.w);
     V3 axis = mk3(1, 0, 0);
     if (vn >= 1e-12f) { float sc = 1.f / vn; axis = mk3(dq.x * sc, dq.y * sc, dq.z * sc); }
@@ -2390,18 +2441,18 @@ __device__ float ik_coop(const DevModel* m, V3 tpos, Q4 tq, float qj, int max_it
     float Jc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (isj) {
       V3 lin, ang = mk3(0, 0, 0);
-      if (rev) { lin = cross(axw, pos - org); ang = axw; } else lin = axw;
+      if (rev) { lin = crossF(axw, pos - org); ang = axw; } else lin = axw;
       Jc[0] = lin.x; Jc[1] = lin.y; Jc[2] = lin.z; Jc[3] = ang.x; Jc[4] = ang.y; Jc[5] = ang.z;
     }
     /* row l16 of A = J^T J + damp I and of b = J^T err */
-    float A[NC], b = 0.f;
+    float A[NC], b = Jc[0] * err[0];
 #pragma unroll
-    for (int k = 0; k < 6; k++) b += Jc[k] * err[k];
+    for (int k = 1; k < 6; k++) b = __fmaf_rn(Jc[k], err[k], b);
     static_for<0, NC>([&](auto cc) {
       constexpr int c = decltype(cc)::v;
-      float sacc = 0.f;
+      float sacc = Jc[0] * bcast16<c>(Jc[0]);
 #pragma unroll
-      for (int k = 0; k < 6; k++) sacc += Jc[k] * bcast16<c>(Jc[k]);
+      for (int k = 1; k < 6; k++) sacc = __fmaf_rn(Jc[k], bcast16<c>(Jc[k]), sacc);
       A[c] = sacc + (l16 == c ? K_IK_DAMP : 0.f);
     });
     /* SPD solve without pivoting: lane r eliminates its row against the broadcast pivot row; the pivots' reciprocals
@@ -2418,8 +2469,8 @@ __device__ float ik_coop(const DevModel* m, V3 tpos, Q4 tq, float qj, int max_it
       if (l16 > c) {
         float f = A[c] * inv;
 #pragma unroll
-        for (int k = c; k < NC; k++) A[k] -= f * pc[k];
-        b -= f * pbv;
+        for (int k = c; k < NC; k++) A[k] = __fmaf_rn(-f, pc[k], A[k]);
+        b = __fmaf_rn(-f, pbv, b);
       }
     });
     float xs[NC];
@@ -2427,14 +2478,14 @@ __device__ float ik_coop(const DevModel* m, V3 tpos, Q4 tq, float qj, int max_it
       constexpr int r = NC - 1 - decltype(rr)::v;
       float sacc = b;
 #pragma unroll
-      for (int k = r + 1; k < NC; k++) sacc -= A[k] * xs[k];
+      for (int k = r + 1; k < NC; k++) sacc = __fmaf_rn(-A[k], xs[k], sacc);
       xs[r] = bcast16<r>(sacc * ipiv[r]);
     });
     float mx = 0.f, mine = 0.f;
 #pragma unroll
     for (int j = 0; j < NC; j++) { mx = fmaxf(mx, fabsf(xs[j])); mine = l16 == j ? xs[j] : mine; }
     const float sc = mx > K_IK_MAXSTEP ? K_IK_MAXSTEP / mx : 1.f;
-    if (!done && isj) qj += sc * mine;
+    if (!done && isj) qj = __fmaf_rn(sc, mine, qj);
   }
   if (capped) *capped = !done;      /* the residual test never passed: this call ran out of iterations (status bit 8 of the step) */
   return qj;
@@ -2649,7 +2700,7 @@ __device__ void calc_state(const DevModel* m, LDS& L, int lane) {
     V3 lin = v.l + cross(v.a, pos - ld3(L.O)), ang = v.a;
     float grip = L.st[ST_Q + m->d_grip_obs] * (m->arm_type == RP_ARM_PANDA ? 1.f : 23.f);
     float* o = L.out;
-    float st[OBS_MAX], ag[AG_MAX];
+    float *st = &o[O_OBS], *ag = &o[O_AG];      /* assembled in place, in LDS: as private arrays their running indices (ns++, nag++) sent them to scratch memory (80 B a lane) */
     int ns = 0, nag = 0, nf = 0;
     st[ns++] = pos.x; st[ns++] = pos.y; st[ns++] = pos.z;
     if (m->return_velocity) { st[ns++] = lin.x; st[ns++] = lin.y; st[ns++] = lin.z; }
@@ -2687,8 +2738,6 @@ __device__ void calc_state(const DevModel* m, LDS& L, int lane) {
 #endif
       L.st[ST_HAVE_LAST] = 1.f;
     }
-    for (int k = 0; k < ns; k++) o[O_OBS + k] = st[k];
-    for (int k = 0; k < nag; k++) o[O_AG + k] = ag[k];
     int ng = __float_as_int(L.st[ST_NGOAL]);
     for (int k = 0; k < ng; k++) o[O_DG + k] = L.st[ST_GOAL + k];
     o[O_CAG] = pos.x; o[O_CAG + 1] = pos.y; o[O_CAG + 2] = pos.z; o[O_CAG + 3] = grip;
@@ -3641,8 +3690,11 @@ __device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, floa
   float Bm[12];                             /* B column of unit row t: M^-1[:, t] on the arm lanes, 1/m of scene joint t at its lane */
   {
     const float colJ = ldz(&bj[16 + kj], jl);
+    /* row ia of M^-1 as three 16-byte loads (twelve strided ones with an address select each until round 5); lanes without an arm dof and columns beyond n read zeros */
+    const float4 m0 = *(const float4*)&w[W3_MINV + ia * 12], m1 = *(const float4*)&w[W3_MINV + ia * 12 + 4], m2 = *(const float4*)&w[W3_MINV + ia * 12 + 8];
+    const float mr[12] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w, m2.x, m2.y, m2.z, m2.w};
 #pragma unroll
-    for (int t = 0; t < 12; t++) Bm[t] = row0 ? ldz(&w[W3_MINV + ia * 12 + t], arm_lane && t < n) : ((t < LBL_N && l16 == t) ? colJ : 0.f);
+    for (int t = 0; t < 12; t++) Bm[t] = row0 ? ((arm_lane && t < n) ? mr[t] : 0.f) : ((t < LBL_N && l16 == t) ? colJ : 0.f);
   }
   /* contact slots.  Slot s < nS holds, in DPP row 0, this env's s-th arm-only contact and, in DPP row 1, its s-th
    * non-arm contact (they commute: solved side by side, no fold); slot 20 - j holds its j-th spanning contact in
@@ -3987,8 +4039,10 @@ __device__ __forceinline__ void solve4_body(const DevModel* __restrict__ m, floa
       bool gl = valid && l16 == GEAR_LANE && my_gr != 0;
       PU.rhs = gl ? g4 : PU.rhs; PU.lo = gl ? g5 : PU.lo; PU.hi = gl ? g6 : PU.hi;
     }
+    const float4 m0 = *(const float4*)&w[W3_MINV + ia * 12], m1 = *(const float4*)&w[W3_MINV + ia * 12 + 4], m2 = *(const float4*)&w[W3_MINV + ia * 12 + 8];      /* (as in solve2_body) */
+    const float mr[12] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w, m2.x, m2.y, m2.z, m2.w};
 #pragma unroll
-    for (int t = 0; t < 12; t++) Bm[t] = ldz(&w[W3_MINV + ia * 12 + t], arm_lane && t < n);
+    for (int t = 0; t < 12; t++) Bm[t] = (arm_lane && t < n) ? mr[t] : 0.f;
   } else {
     const float colJ = ldz(&bj[16 + kj], jl);
 #pragma unroll

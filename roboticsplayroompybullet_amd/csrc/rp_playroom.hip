@@ -4,10 +4,13 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <vector>
+
 #include "../../include/rp_playroom.h"
 #include "../../include/rp_playroom_debug.h"
 #include "generated/rp_models_gen.h"
 #include "generated/rp_hullverts_gen.h"
+#include "generated/rp_hullcells_gen.h"
 #include "rp_device_model.h"
 #include "rp_kernels.cuh"
 #include "rp_render.cuh"
@@ -21,6 +24,7 @@ struct rp_sim {
   float* ws;               /* [N][W3_FLOATS] constraint-row workspace of the split step pipeline */
   float* dbg;
   float* hullv;            /* convex-hull vertices of the arm's collision meshes (DevModel.hullv points here) */
+  float* hcv; int* hco;    /* their support-vertex candidate tables (DevModel.hcv / hco) */
   float* pmcache;          /* the contact caches, [N][PMC_FLOATS] (DevModel.pmcache points here); nullptr under RP_CFG_STATELESS_CONTACTS */
   int* sort_cnt;           /* [2][RP_MAX_GROUPS][SORT_BINS] load-class histograms for pairing envs in k_solve2 (double-buffered) */
   int* sort_slot;          /* [N] per env: (bin << 16) | rank inside the bin, from the latest k_solve2 */
@@ -95,7 +99,7 @@ const char* rp_version(void) { return "rp_playroom 0.3 (gfx950) build " RP_BUILD
 
 static void destroy_handle(rp_sim* h) {        /* frees whatever a (possibly partial) handle owns; hipFree(nullptr) etc. are no-ops */
   if (!h) return;
-  hipFree(h->hullv); hipFree(h->pmcache); hipFree(h->dev_model); hipFree(h->state); hipFree(h->ws); hipFree(h->dbg); hipFree(h->sort_cnt); hipFree(h->sort_slot); hipFree(h->pair_env); hipFree(h->member[0]); hipFree(h->member[1]);
+  hipFree(h->hullv); hipFree(h->hcv); hipFree(h->hco); hipFree(h->pmcache); hipFree(h->dev_model); hipFree(h->state); hipFree(h->ws); hipFree(h->dbg); hipFree(h->sort_cnt); hipFree(h->sort_slot); hipFree(h->pair_env); hipFree(h->member[0]); hipFree(h->member[1]);
   hipFree(h->rc_tab); hipFree(h->rc_cnt); hipFree(h->rc_ee);
   hipFree(h->rs_state); hipFree(h->rs_idx); hipFree(h->rs_meta); hipFree(h->rs_count); hipFree(h->rs_sort_cnt); hipFree(h->rs_sort_slot); hipFree(h->rs_pair);
   if (h->rs_count_host) hipHostFree(h->rs_count_host);
@@ -196,8 +200,30 @@ int rp_create(const rp_config* cfg, rp_handle* out) {
       CREATE_CHK(hipMemcpy(h->hullv, hv, (size_t)nhv * 4 * sizeof(float), hipMemcpyHostToDevice));
       const bool off = getenv("RP_NO_HULL") != nullptr;      /* timing / model studies only: arm links as their OBBs everywhere (round 2's contacts) */
       for (int c = 0; c < RP_MAX_COL; c++) { d->hull_off[c] = hoff[c]; d->hull_cnt[c] = off ? 0 : hcnt[c]; }
+      /* the candidate tables: the baked lists hold vertex numbers; the kernels read (x, y, z, number) in one 16-byte load */
+      const unsigned short* cidx; const int *coff, *cfirst; int ctotal = 0;
+      const int ncoff = rp_hcell_tables(d->kind, &cidx, &coff, &cfirst, &ctotal);
+      if (ncoff > 0) {
+        std::vector<float> cv((size_t)ctotal * 4, 0.f);
+        std::vector<char> done((size_t)ncoff, 0);
+        for (int c = 0; c < RP_MAX_COL; c++) {
+          d->hcell_first[c] = hcnt[c] > 0 ? cfirst[c] : -1;
+          if (hcnt[c] <= 0 || cfirst[c] < 0 || done[cfirst[c]]) continue;
+          done[cfirst[c]] = 1;
+          for (int k = coff[cfirst[c]]; k < coff[cfirst[c] + RP_HCELL_N]; k++) {
+            const int vi = cidx[k];
+            if (vi >= hcnt[c]) { snprintf(g_err, 256, "rp_create: the candidate table refers to vertex %d of a %d-vertex hull", vi, hcnt[c]); e = hipErrorInvalidValue; goto fail; }
+            const float* v = hv[hoff[c] + vi];
+            cv[4 * (size_t)k] = v[0]; cv[4 * (size_t)k + 1] = v[1]; cv[4 * (size_t)k + 2] = v[2]; memcpy(&cv[4 * (size_t)k + 3], &vi, 4);
+          }
+        }
+        CREATE_CHK(hipMalloc((void**)&h->hcv, cv.size() * sizeof(float)));
+        CREATE_CHK(hipMemcpy(h->hcv, cv.data(), cv.size() * sizeof(float), hipMemcpyHostToDevice));
+        CREATE_CHK(hipMalloc((void**)&h->hco, (size_t)ncoff * sizeof(int)));
+        CREATE_CHK(hipMemcpy(h->hco, coff, (size_t)ncoff * sizeof(int), hipMemcpyHostToDevice));
+      }
     }
-    d->hullv = h->hullv;
+    d->hullv = h->hullv; d->hcv = h->hcv; d->hco = h->hco;
     if (!(cfg->flags & RP_CFG_STATELESS_CONTACTS) && !(cfg->flags & RP_CFG_CONTACT_MARGIN) && getenv("RP_STATELESS") == nullptr) {      /* (a uniform contact margin is a stateless-model study: it keeps the stateless contacts) */
       CREATE_CHK(hipMalloc((void**)&h->pmcache, (size_t)N * PMC_FLOATS * sizeof(float)));
       CREATE_CHK(hipMemset(h->pmcache, 0, (size_t)N * PMC_FLOATS * sizeof(float)));

@@ -9,10 +9,15 @@ import torch
 import torch.distributed as dist
 
 
-def shard_range(rank, world_size, envs_per_rank):
-    """global env indices owned by `rank`; env_offset for rp_create is the first one"""
-    lo = rank * envs_per_rank
-    return lo, lo + envs_per_rank
+def shard_range(rank, world_size, envs, total=False):
+    """global env indices [lo, hi) owned by `rank`; env_offset for rp_create is the first one.  Weak scaling (default): `envs` per rank.  total=True (strong
+    scaling: `envs` in all): contiguous shards of envs // world_size, the first envs % world_size ranks one env larger."""
+    if not total:
+        lo = rank * envs
+        return lo, lo + envs
+    base, rem = divmod(envs, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
 
 
 def pack_observations(obs, reward, is_success):
@@ -23,6 +28,21 @@ def pack_observations(obs, reward, is_success):
 def unpack_observations(pack, d_obs, d_ag):
     return {'obs_quat': pack[:, :d_obs], 'achieved_goal': pack[:, d_obs:d_obs + d_ag], 'reward': pack[:, d_obs + d_ag],
             'is_success': pack[:, d_obs + d_ag + 1].to(torch.int32)}
+
+
+def pad_rows(pack, rows):
+    """strong scaling with a remainder: a rank's pack padded with zero rows to the longest shard (collectives want equal contributions)"""
+    if pack.shape[0] == rows:
+        return pack
+    return torch.cat([pack, pack.new_zeros((rows - pack.shape[0], pack.shape[1]))], 0)
+
+
+def strip_padding(gathered, sizes):
+    """the valid rows of a gather of padded packs, in global env order: [sum(sizes), W]"""
+    rows = gathered.shape[0] // len(sizes)
+    if all(s == rows for s in sizes):
+        return gathered
+    return torch.cat([gathered[r * rows:r * rows + s] for r, s in enumerate(sizes)], 0)
 
 
 def gather_observations(pack, out=None, group=None, async_op=False):

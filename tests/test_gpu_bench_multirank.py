@@ -59,3 +59,54 @@ def test_bench_two_ranks_gloo_on_one_device():
     assert v == v and 0 < v < 1e9 and abs(v - 1024 * 5 / (d['ms_per_step'] * 5e-3)) < 1e-6 * v
     assert d['non_finite_envs'] == 0
     assert 'cpu_baseline' not in d and d['roofline']['traffic'] is None      # (not the headline batch size: no PMC profile quoted)
+
+
+def run_bench(extra, ranks=1, timeout=900):
+    port = free_port()
+    procs = []
+    for rank in range(ranks):
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+        if ranks > 1:
+            env.update(RANK=str(rank), WORLD_SIZE=str(ranks), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RP_BENCH_BACKEND='gloo')
+        procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', str(ranks)] + extra, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                      text=True, cwd=REPO))
+    outs = []
+    for p in procs:
+        try:
+            out, err = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, err[-2000:]
+        outs.append(out)
+    lines = [l for l in outs[0].splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+def test_bench_strong_scaling_two_ranks_gloo_on_one_device():
+    """--scaling strong: the config's envs IN TOTAL, split over the ranks in contiguous shards ("4096 total for strong scaling"); 1025 envs over two ranks
+    = shards of 513 and 512, the short one padded for the collective.  A control-flow test like the weak-scaling one above."""
+    d = run_bench(['--steps', '4', '--warmup', '1', '--no-extras', '--no-cpu-baseline', '--repeats', '1', '--scaling', 'strong', '--envs-per-gpu', '1025'], ranks=2)
+    assert d['n_gpus'] == 2 and d['scaling'] == 'strong' and d['config']['global_envs'] == 1025
+    assert sorted(tuple(r['envs']) for r in d['config']['ranks']) == [(0, 513), (513, 1025)]
+    assert abs(d['value'] - 1025 * 4 / (d['ms_per_step'] * 4e-3)) < 1e-6 * d['value'] and d['non_finite_envs'] == 0
+
+
+@pytest.mark.parametrize('config,env_id,envs', [('C2', 'UR5PlayAbsRPY1Obj-v0', 1024), ('C3', 'pandaPick-v0', 4096), ('C5', 'UR5PlayAbsRPY1Obj-v0', 16384)])
+def test_bench_prints_the_same_line_for_every_baseline_config(config, env_id, envs):
+    """bench.py --config {C2, C3, C5}: BASELINE.json's other configs through the same protocol, the same JSON shape (roofline with that config's algorithmic bytes,
+    per-launch times, the dominant kernel); C5 adds the CEM-MPC block.  Short regions: a shape test, the numbers are taken by tools/collect_profiles.sh."""
+    d = run_bench(['--config', config, '--steps', '50' if config == 'C5' else '6', '--warmup', '2', '--no-cpu-baseline', '--repeats', '1', '--no-extras'])
+    assert d['config']['name'] == config and env_id in d['config']['workload'] and d['config']['envs_per_gpu'] == envs and d['n_gpus'] == 1
+    assert d['unit'] == 'env-steps/s' and d['value'] > 0 and d['non_finite_envs'] == 0 and d['roofline']['traffic'] is None
+    alg = 552 if config == 'C3' else 1036
+    assert d['roofline']['algorithmic_bytes_per_step'] == alg * envs
+    assert abs(d['roofline']['achieved'] / d['roofline']['peak'] - d['roofline']['frac']) < 1e-12 and 0 < d['roofline']['frac'] < 1
+    assert d['roofline']['dominant_kernel']['kernel'] == 'k_solve2' and d['roofline']['per_launch_ms']['k_solve2'] > 0
+    if config == 'C5':
+        c = d['cem_mpc']
+        assert (c['start_states'], c['candidates'], c['horizon'], c['iterations']) == (32, 512, 50, 1) and d['steps'] == 50 and c['plans_per_s'] > 0
+    else:
+        assert 'cem_mpc' not in d and d['steps'] == 6

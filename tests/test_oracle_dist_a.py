@@ -31,32 +31,32 @@ def actions_a(kind, steps, n, seed):
 
 @pytest.mark.parametrize('kind', ['U', 'P', 'V'])
 def test_cache_row_carries_the_whole_contact_history(kind):
-    """30 steps of A, then a second fp32 oracle takes state + cache row (+ the goal; motors are re-commanded by every action) and both run on: same bits, caches included.
-    Without the row (set_state alone clears the history) they part - the test would be vacuous otherwise (asserted for the headline id; pandaPick's
-    block on its tray regenerates the same four points from nothing: not asserted there)."""
-    acts = actions_a(kind, 45, 1, 3)[:, 0]
-    a = OracleEnv(kind, seed=5, env_index=2, f32=True)
-    a.reset()
-    for t in range(30):
-        a.step(acts[t])
-    row = a.get_cache_row()
-    d = cache_rows.decode(row)
-    assert sum(m['n'] for m in d['manifolds']) > 0, 'the rollout has no contact history to carry'
-    b = OracleEnv(kind, seed=5, env_index=2, f32=True)
-    c = OracleEnv(kind, seed=5, env_index=2, f32=True)
-    for o in (b, c):
-        o.reset()
-        o.step(acts[0])                    # (motor modes: every action re-commands every motor, environments.py:1010-1073)
-        o.set_state(a.get_state())
-    b.set_cache_row(row)
-    assert np.array_equal(b.get_cache_row().view(np.int32), row.view(np.int32))
+    """30 steps of A, then a second fp32 oracle takes state + cache row (motors are re-commanded by every action) and both run on: same bits, caches included.
+    Without the row (set_state alone clears the history) a copy parts from the original in at least one of the envs tried - the test would be vacuous otherwise
+    (asserted for the headline id; a Panda's block on its tray regenerates the same four points from nothing)."""
     parted = False
-    for t in range(30, 45):
-        a.step(acts[t]); b.step(acts[t]); c.step(acts[t])
-        assert np.array_equal(a.get_state(), b.get_state()), 'step %d: the copy with the cache row left the original' % t
-        assert np.array_equal(a.get_cache_row().view(np.int32), b.get_cache_row().view(np.int32)), 'step %d: caches differ' % t
-        parted |= not np.array_equal(a.get_state(), c.get_state())
-    assert parted or kind != 'U', 'a copy WITHOUT the contact history follows the original bit for bit: the scenario does not exercise the cache'
+    for ei in (2, 5, 11, 14):
+        acts = actions_a(kind, 45, 1, 3 + ei)[:, 0]
+        a = OracleEnv(kind, seed=5, env_index=ei, f32=True)
+        a.reset()
+        for t in range(30):
+            a.step(acts[t])
+        row = a.get_cache_row()
+        assert sum(m['n'] for m in cache_rows.decode(row)['manifolds']) > 0, 'the rollout has no contact history to carry'
+        b = OracleEnv(kind, seed=5, env_index=ei, f32=True)
+        c = OracleEnv(kind, seed=5, env_index=ei, f32=True)
+        for o in (b, c):
+            o.reset()
+            o.step(acts[0])                    # (motor modes: every action re-commands every motor, environments.py:1010-1073)
+            o.set_state(a.get_state())
+        b.set_cache_row(row)
+        assert np.array_equal(b.get_cache_row().view(np.int32), row.view(np.int32))
+        for t in range(30, 45):
+            a.step(acts[t]); b.step(acts[t]); c.step(acts[t])
+            assert np.array_equal(a.get_state(), b.get_state()), 'env %d step %d: the copy with the cache row left the original' % (ei, t)
+            assert np.array_equal(a.get_cache_row().view(np.int32), b.get_cache_row().view(np.int32)), 'env %d step %d: caches differ' % (ei, t)
+            parted |= not np.array_equal(a.get_state(), c.get_state())
+    assert parted or kind != 'U', 'copies WITHOUT the contact history follow the originals bit for bit: the scenario does not exercise the cache'
 
 
 def positions(o, s):

@@ -52,6 +52,38 @@ def test_two_rank_gather_is_rank_ordered_concatenation():
     assert torch.equal(u['is_success'], (g.to(torch.int32) % 2))
 
 
+def _strong_worker(rank, world, port, total, w, ret):
+    """strong scaling (bench.py --scaling strong): `total` envs in all, shards of unequal size when world does not divide it; the gather is an all_gather into views of
+    one buffer, rank order = global env order"""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    lo, hi = sharding.shard_range(rank, world, total, total=True)
+    pack = torch.arange(lo, hi, dtype=torch.float32)[:, None] + 0.001 * torch.arange(w)[None]
+    sizes = [b - a for a, b in (sharding.shard_range(r, world, total, total=True) for r in range(world))]
+    out, work = sharding.gather_observations(sharding.pad_rows(pack, max(sizes)), async_op=True)      # (collectives want equal shards: the short ones are padded)
+    work.wait()
+    full = sharding.strip_padding(out, sizes)
+    dist.barrier()
+    if rank == 0:
+        ret['full'] = full.numpy().copy()
+        ret['sizes'] = sizes
+    dist.destroy_process_group()
+
+
+def test_strong_scaling_shards_cover_the_env_range_in_order():
+    for world, total in ((2, 7), (2, 8)):
+        ranges = [sharding.shard_range(r, world, total, total=True) for r in range(world)]
+        assert ranges[0][0] == 0 and ranges[-1][1] == total and all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1)), ranges
+        assert max(b - a for a, b in ranges) - min(b - a for a, b in ranges) <= 1
+    assert [sharding.shard_range(r, 8, 4096, total=True) for r in (0, 7)] == [(0, 512), (3584, 4096)]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_strong_worker, args=(2, _free_port(), 7, 5, ret), nprocs=2, join=True)
+    assert list(ret['sizes']) == [4, 3]
+    np.testing.assert_allclose(ret['full'][:, 0], np.arange(7))
+
+
 def test_global_env_index_keys_the_rng_so_shards_equal_one_run():
     """oracle-side statement of the shard-equivalence property (the GPU version is tests/test_gpu_parity.py)."""
     from oracle import OracleEnv
