@@ -57,6 +57,21 @@ def make_actions(n, steps, device, seed, env_id=ENV_ID):
     return lo + (hi - lo) * u
 
 
+def cpu_quota():
+    """CPUs' worth of time the cgroup of this process may use (cgroup v2 cpu.max, v1 cfs quota), None = unlimited / unknown"""
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        return None if q == 'max' else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+        per = float(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(seed, margin=None, env_id=ENV_ID):
     """The CPU oracle (a port of the same semantics, NOT PyBullet) on the box's host cores: a bounded sample of the workload on one thread and on all of them (envs over
     threads, static partition - SURVEY.md 8d).  Sized so that every thread steps for seconds, not a start-up transient: 32 envs x 100 steps per thread (round 4's 8 x 50 was
@@ -70,18 +85,25 @@ def cpu_baseline(seed, margin=None, env_id=ENV_ID):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
+    quota = cpu_quota()
+    if quota is not None:                              # a container may see 256 logical CPUs and be allowed the time of eight (round 4's "7.2 x on 256 threads")
+        cores = max(1, min(cores, int(quota + 0.999)))
     n_steps, per_thread = 100, 32
     a1 = lo + (hi - lo) * rng.random((per_thread, n_steps, 7))
     one = oracle.bench_rollout(env_id, seed, a1, 1, margin=margin)
     threads = min(cores, 1024)
-    aN = lo + (hi - lo) * rng.random((per_thread * threads, n_steps, 7))
+    # a short all-thread probe first: the sample is then sized for ~12 s of wall time whatever the box's real parallelism is (32 envs per thread at most, 2 at least)
+    probe = oracle.bench_rollout(env_id, seed, lo + (hi - lo) * rng.random((2 * threads, 20, 7)), threads, margin=margin)
+    per_thread_all = int(min(32, max(2, round(probe * 12.0 / (threads * n_steps)))))
+    aN = lo + (hi - lo) * rng.random((per_thread_all * threads, n_steps, 7))
     allc = oracle.bench_rollout(env_id, seed, aN, threads, margin=margin)
+    per_thread_one, per_thread = per_thread, per_thread_all
     return {'value': allc, 'unit': 'env-steps/s', 'cores': threads, 'kind': 'port',
-            'one_core': {'value': one, 'cores': 1, 'sample': '%d envs x %d steps' % (per_thread, n_steps)},
-            'parallel_efficiency': allc / (one * threads),
-            'sample': '%d envs x %d steps of %s (distribution B) on the fp64 CPU oracle, %d threads (= the logical CPUs this process may run on; os.cpu_count() = %s) with the '
-                      'envs statically partitioned (%d per thread), resets excluded; the one_core leg runs %d envs x %d steps on one thread; PyBullet is not installed '
-                      'on this box' % (per_thread * threads, n_steps, env_id, threads, os.cpu_count(), per_thread, per_thread, n_steps),
+            'one_core': {'value': one, 'cores': 1, 'sample': '%d envs x %d steps' % (per_thread_one, n_steps)},
+            'parallel_efficiency': allc / (one * threads), 'cpu_quota': quota,
+            'sample': '%d envs x %d steps of %s (distribution B) on the fp64 CPU oracle, %d threads (= the logical CPUs this process may run on, capped by its cgroup\'s CPU quota; os.cpu_count() = %s) with the '
+                      'envs statically partitioned (%d per thread, sized by a short probe for ~12 s of wall time), resets excluded; the one_core leg runs %d envs x %d steps on one thread; PyBullet is not installed '
+                      'on this box' % (per_thread * threads, n_steps, env_id, threads, os.cpu_count(), per_thread, per_thread_one, n_steps),
             'host_cpus': os.cpu_count()}
 
 

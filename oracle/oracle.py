@@ -55,13 +55,16 @@ REF_FLAGS = {'hull': 1, 'persist': 2, 'order': 4, 'lever': 8, 'soft': 16, 'ancho
 REF_DEFAULT = 255 + 512          # everything but warm starting (rp_bullet_ref.c RPB_DEFAULT)
 
 
-def load(f32=False, bullet_ref=False):
-    name = 'librp_oracle_bullet.so' if bullet_ref else ('librp_oracle_f32.so' if f32 else 'librp_oracle.so')
+def load(f32=False, bullet_ref=False, abx=False):
+    name = 'librp_oracle_abx.so' if abx else ('librp_oracle_bullet.so' if bullet_ref else ('librp_oracle_f32.so' if f32 else 'librp_oracle.so'))
     if name in _LIBS:
         return _LIBS[name]
     path = os.path.join(HERE, name)
     if not os.path.exists(path):
-        build()
+        if abx:
+            subprocess.run(['make', '-C', HERE, '-s', name], check=True)      # (the experiment build is not part of `make all`)
+        else:
+            build()
     lib = C.CDLL(path)
     dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
     vp = C.c_void_p
@@ -172,11 +175,11 @@ class OracleEnv:
     """One reference env (instance + playEnv) on the CPU oracle."""
 
     def __init__(self, kind, seed=0, env_index=0, f32=False, action_type=None, margin=None, ranges=None, sparse_rew_thresh=None,
-                 dense_reward=False, bullet_ref=False, ref_flags=None, rule=None):
+                 dense_reward=False, bullet_ref=False, ref_flags=None, rule=None, abx=False):
         """ranges = (goal_lo, goal_hi, obj_lo, obj_hi, env_hi): the env class's range kwargs (envList.py); margin: contact margin
         in metres for every pair (default, like the library: per pair the smaller of the two objects' Bullet breaking thresholds, rp_model.col_thr)"""
         self.bullet_ref = bullet_ref
-        self.lib = load(f32, bullet_ref)      # bullet_ref: the frozen Bullet-like step (rp_bullet_ref.c) under the same harness
+        self.lib = load(f32, bullet_ref, abx)      # bullet_ref: the frozen Bullet-like step (rp_bullet_ref.c) under the same harness; abx: the experiment build (Makefile)
         user_ranges = ranges
         ranges = None
         if kind in RANGES:

@@ -45,27 +45,29 @@ static inline void v3add(real* o, const real* a, const real* b) { o[0] = a[0] + 
 static inline void v3sub(real* o, const real* a, const real* b) { o[0] = a[0] - b[0]; o[1] = a[1] - b[1]; o[2] = a[2] - b[2]; }
 static inline void v3scale(real* o, const real* a, real s) { o[0] = a[0] * s; o[1] = a[1] * s; o[2] = a[2] * s; }
 static inline void v3axpy(real* o, real s, const real* a) { o[0] += s * a[0]; o[1] += s * a[1]; o[2] += s * a[2]; }
-static inline real v3dot(const real* a, const real* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+/* products of 3-vectors and 3 x 3 matrices accumulate through fused multiply-adds in the HIP library's order (rp_math.cuh dot / cross / mulv / tmulv / mul: x first,
+ * then y, then z folded in): one rounding convention on both sides (round 5) */
+static inline real v3dot(const real* a, const real* b) { return R_FMA(a[2], b[2], R_FMA(a[1], b[1], a[0] * b[0])); }
 static inline real v3norm(const real* a) { return R_SQRT(v3dot(a, a)); }
 static inline void v3cross(real* o, const real* a, const real* b) {
-  real x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  real x = R_FMA(a[1], b[2], -(a[2] * b[1])), y = R_FMA(a[2], b[0], -(a[0] * b[2])), z = R_FMA(a[0], b[1], -(a[1] * b[0]));
   o[0] = x; o[1] = y; o[2] = z;
 }
 /* 3x3 row-major */
 static inline void m3mulv(real* o, const real* M, const real* v) {
-  real x = M[0] * v[0] + M[1] * v[1] + M[2] * v[2], y = M[3] * v[0] + M[4] * v[1] + M[5] * v[2],
-       z = M[6] * v[0] + M[7] * v[1] + M[8] * v[2];
+  real x = R_FMA(M[2], v[2], R_FMA(M[1], v[1], M[0] * v[0])), y = R_FMA(M[5], v[2], R_FMA(M[4], v[1], M[3] * v[0])),
+       z = R_FMA(M[8], v[2], R_FMA(M[7], v[1], M[6] * v[0]));
   o[0] = x; o[1] = y; o[2] = z;
 }
 static inline void m3tmulv(real* o, const real* M, const real* v) {
-  real x = M[0] * v[0] + M[3] * v[1] + M[6] * v[2], y = M[1] * v[0] + M[4] * v[1] + M[7] * v[2],
-       z = M[2] * v[0] + M[5] * v[1] + M[8] * v[2];
+  real x = R_FMA(M[6], v[2], R_FMA(M[3], v[1], M[0] * v[0])), y = R_FMA(M[7], v[2], R_FMA(M[4], v[1], M[1] * v[0])),
+       z = R_FMA(M[8], v[2], R_FMA(M[5], v[1], M[2] * v[0]));
   o[0] = x; o[1] = y; o[2] = z;
 }
 static inline void m3mul(real* o, const real* A, const real* B) {
   real t[9];
   for (int i = 0; i < 3; i++)
-    for (int j = 0; j < 3; j++) t[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+    for (int j = 0; j < 3; j++) t[3 * i + j] = R_FMA(A[3 * i + 2], B[6 + j], R_FMA(A[3 * i + 1], B[3 + j], A[3 * i] * B[j]));
   for (int i = 0; i < 9; i++) o[i] = t[i];
 }
 static inline void m3ident(real* M) { for (int i = 0; i < 9; i++) M[i] = (i % 4 == 0) ? (real)1 : (real)0; }

@@ -51,6 +51,8 @@
 #define RPO_RULE_HULLMOV 512        /* ... and movable boxes (the block, the drawer, the door: collider a of the pair) with them too */
 #define RPO_RULE_XGRAN 32768        /* EXPERIMENT (tools/granularity_experiment.py; no HIP counterpart): the reference step's manifold granularity - one manifold per COLLIDER pair
                                      * and every point of a rotation-locked body - on the shipped model's own contact cache */
+#define RPO_RULE_CREATION_ORDER 65536      /* EXPERIMENT (tools/fidelity_r05.py row `A +creation-order`; no HIP counterpart): contacts are solved in the manifolds' creation order - Bullet's - instead
+                                            * of the four-tier partition the HIP library's two-stream solver needs (solver_order) */
 #define RPO_RULE_GJK 1024           /* ... and where the deepest vertex lies BESIDE the face (box edges and corners): GJK's distance phase on hull and box (hull_box_gjk) */
 #define RPO_RULE_HULLFACE 4         /* arm links touch static boxes with the vertices of their collision meshes' convex hulls (hull_face) instead of their OBBs */
 #define HULL_MARGIN ((real)RP_HULL_MARGIN)
@@ -971,7 +973,7 @@ static void collide_persistent(rpo_env* e) {
       c->mu = (real)(m->col_friction[c->ca] * m->col_friction[c->cb]);
     }
   }
-  solver_order(e);
+  if (!(e->rule & RPO_RULE_CREATION_ORDER)) solver_order(e);
 }
 
 static void solver_order(rpo_env* e) {

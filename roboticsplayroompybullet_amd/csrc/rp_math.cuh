@@ -15,8 +15,11 @@ __device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk3(a.x + b.x, a.y 
 __device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
 __device__ __forceinline__ V3 operator*(V3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
 __device__ __forceinline__ V3 operator-(V3 a) { return mk3(-a.x, -a.y, -a.z); }
-__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-__device__ __forceinline__ V3 cross(V3 a, V3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+/* Products of 3-vectors and 3 x 3 matrices accumulate through FUSED multiply-adds in a fixed order (x first, then y, then z folded in): the library is compiled with
+ * -ffp-contract=off, so these are the only fusions there are, and oracle/rp_math.h has the same ones in v3dot / v3cross / m3mulv / m3tmulv / m3mul (round 5: the
+ * rounding convention is shared, not left to either compiler). */
+__device__ __forceinline__ float dot(V3 a, V3 b) { return __fmaf_rn(a.z, b.z, __fmaf_rn(a.y, b.y, a.x * b.x)); }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) { return mk3(__fmaf_rn(a.y, b.z, -(a.z * b.y)), __fmaf_rn(a.z, b.x, -(a.x * b.z)), __fmaf_rn(a.x, b.y, -(a.y * b.x))); }
 __device__ __forceinline__ float norm(V3 a) { return sqrtf(dot(a, a)); }
 __device__ __forceinline__ float comp(V3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 
@@ -24,19 +27,19 @@ __device__ __forceinline__ M3 ldm3(const float* p) { M3 r; for (int i = 0; i < 9
 __device__ __forceinline__ void stm3(float* p, const M3& a) { for (int i = 0; i < 9; i++) p[i] = a.m[i]; }
 __device__ __forceinline__ M3 ident3() { M3 r = {{1, 0, 0, 0, 1, 0, 0, 0, 1}}; return r; }
 __device__ __forceinline__ V3 mulv(const M3& a, V3 v) {
-  return mk3(a.m[0] * v.x + a.m[1] * v.y + a.m[2] * v.z, a.m[3] * v.x + a.m[4] * v.y + a.m[5] * v.z,
-             a.m[6] * v.x + a.m[7] * v.y + a.m[8] * v.z);
+  return mk3(__fmaf_rn(a.m[2], v.z, __fmaf_rn(a.m[1], v.y, a.m[0] * v.x)), __fmaf_rn(a.m[5], v.z, __fmaf_rn(a.m[4], v.y, a.m[3] * v.x)),
+             __fmaf_rn(a.m[8], v.z, __fmaf_rn(a.m[7], v.y, a.m[6] * v.x)));
 }
 __device__ __forceinline__ V3 tmulv(const M3& a, V3 v) {
-  return mk3(a.m[0] * v.x + a.m[3] * v.y + a.m[6] * v.z, a.m[1] * v.x + a.m[4] * v.y + a.m[7] * v.z,
-             a.m[2] * v.x + a.m[5] * v.y + a.m[8] * v.z);
+  return mk3(__fmaf_rn(a.m[6], v.z, __fmaf_rn(a.m[3], v.y, a.m[0] * v.x)), __fmaf_rn(a.m[7], v.z, __fmaf_rn(a.m[4], v.y, a.m[1] * v.x)),
+             __fmaf_rn(a.m[8], v.z, __fmaf_rn(a.m[5], v.y, a.m[2] * v.x)));
 }
 __device__ __forceinline__ M3 mul(const M3& a, const M3& b) {
   M3 r;
 #pragma unroll
   for (int i = 0; i < 3; i++)
 #pragma unroll
-    for (int j = 0; j < 3; j++) r.m[3 * i + j] = a.m[3 * i] * b.m[j] + a.m[3 * i + 1] * b.m[3 + j] + a.m[3 * i + 2] * b.m[6 + j];
+    for (int j = 0; j < 3; j++) r.m[3 * i + j] = __fmaf_rn(a.m[3 * i + 2], b.m[6 + j], __fmaf_rn(a.m[3 * i + 1], b.m[3 + j], a.m[3 * i] * b.m[j]));
   return r;
 }
 __device__ __forceinline__ V3 col(const M3& a, int i) { return mk3(a.m[i], a.m[3 + i], a.m[6 + i]); }

@@ -231,7 +231,8 @@ def test_contact_margin_is_a_parameter_shared_with_the_oracle(margin):
         obs, r, _, info = env.step(a[t])
         for e, o in enumerate(oracles):
             oo, _, _, _ = o.step(a[t, e].numpy().astype(np.float64))
-            np.testing.assert_allclose(obs['obs_quat'][e].cpu().numpy(), oo['obs_quat'], atol=1e-3, rtol=0, err_msg='step %d env %d' % (t, e))
+            err = np.abs(obs['obs_quat'][e].cpu().numpy() - oo['obs_quat'])      # (the gripper entry: the phase of its limit sawtooth is decided at rounding level, tests/tolerances.py)
+            assert (err <= obs_atol('U', len(err), 1e-3)).all(), 'step %d env %d: %s' % (t, e, err)
     with pytest.raises(RuntimeError, match='contact_margin'):
         VecPlayEnv(U, 2, contact_margin=0.5)
 

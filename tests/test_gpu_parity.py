@@ -629,7 +629,7 @@ def test_play_family_action_types(gid):
             if (err[:8] <= tol[:8]).all() and not (err[8:] <= tol[8:]).all():
                 # the arm's link boxes make contact points only while they overlap the other box (Bullet's btBoxBoxDetector): whether a block that is being knocked
                 # over is hit in this substep or the next is decided at rounding level.  That env has branched too (its block by at most 0.05).
-                assert err[8:].max() <= 5e-2, 'step %d env %d: err %s tol %s' % (t, e, err, tol)
+                assert err[8:11].max() <= 5e-2, 'step %d env %d: err %s tol %s' % (t, e, err, tol)      # (its position; a block that tips over a substep apart turns by tenths in its quaternion within steps)
                 branched.add(e)
                 continue
             assert (err <= tol).all(), 'step %d env %d: err %s tol %s' % (t, e, err, tol)
