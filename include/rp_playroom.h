@@ -228,6 +228,11 @@ int rp_camera_from_yaw_pitch_roll(const float target[3], float distance, float y
  * drawer / door / button / dial drawn a second time, half transparent, at the poses the vectors name. */
 int rp_render(rp_handle h, const rp_camera* cam, int32_t width, int32_t height, int32_t first_env, int32_t num_envs, uint8_t* rgb,
               const float* sub_goal, void* stream);
+/* ... with the ghost ARM of visualise_sub_goal(sub_goal, 'controllable_achieved_goal' / 'full_positional_state') (ENV:623-637, 671-674): ghost_arm (may be NULL)
+ * [num_envs, 8] = EE position 3, orientation quaternion 4 (xyzw), gripper 1 (unused, as in the reference's reset_arm) - a second arm, half transparent, at the joints one
+ * default IK call from the rest pose finds for that pose (ENV:575-590).  Panda models only: RP_ERR_UNSUPPORTED for a UR5 (the reference raises NotImplementedError). */
+int rp_render_ex(rp_handle h, const rp_camera* cam, int32_t width, int32_t height, int32_t first_env, int32_t num_envs, uint8_t* rgb,
+                 const float* sub_goal, const float* ghost_arm, void* stream);
 /* bullet_client.rayTest(from, to) (ENV:738-741) for k rays per env: from / to [N, k, 3] world coordinates.  Outputs (each may be NULL):
  * hit_fraction [N, k] (1 on a miss), collider [N, k] (index into the model's collider table, -1 on a miss), link [N, k] (Bullet link
  * index of an arm collider, -1 otherwise), hit_position [N, k, 3], hit_normal [N, k, 3].  A ray that starts inside a shape does not hit it. */

@@ -130,6 +130,7 @@ def load(f32=False, bullet_ref=False, abx=False):
     lib.rpo_box_box.argtypes = [dp, dp, dp, dp, dp, dp, C.c_double, dp]
     lib.rpo_collider_poses.argtypes = [vp, dp]
     lib.rpo_collider_table.argtypes = [vp, dp]
+    lib.rpo_hull_vertices_world.argtypes = [vp, C.c_int, dp, C.c_int]
     lib.rpo_pair_table.argtypes = [vp, C.POINTER(C.c_int)]
     lib.rpo_pair_table.restype = C.c_int
     lib.rpo_bench_rollout.argtypes = [C.c_int, C.c_ulonglong, C.c_int, C.c_int, C.c_int, dp, C.c_int, C.c_double]
@@ -312,6 +313,12 @@ class OracleEnv:
         self.lib.rpo_collider_table(self.h, tab.ctypes.data_as(C.POINTER(C.c_double)))
         b = buf[:12 * n].reshape(n, 12)
         return b[:, :9].reshape(n, 3, 3), b[:, 9:], tab[:9 * n].reshape(n, 9)
+
+    def hull_vertices(self, c):
+        """world-frame vertices [n, 3] of the convex hull collider c collides as (arm links), None for boxes / spheres"""
+        buf = np.zeros(3 * 1024)
+        n = self.lib.rpo_hull_vertices_world(self.h, int(c), buf.ctypes.data_as(C.POINTER(C.c_double)), 1024)
+        return buf[:3 * n].reshape(n, 3).copy() if n > 0 else None
 
     def compute_reward(self, ag, dg):
         return self.lib.rpo_compute_reward(self.h, _d(ag)[1], _d(dg)[1])

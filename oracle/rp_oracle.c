@@ -2716,6 +2716,22 @@ int rpo_collider_poses(rpo_env* e, double* out) {
   }
   return e->m.n_col;
 }
+/* the convex-hull vertices of collider c's collision mesh in the WORLD frame at the current state (render / ray tests: an arm link is drawn as what it collides as); returns
+ * their number, 0 = the collider has no hull */
+int rpo_hull_vertices_world(rpo_env* e, int c, double* out, int max) {
+  const float (*hv)[4]; const int *hoff, *hcnt;
+  rp_hull_tables(e->m.kind, &hv, &hoff, &hcnt);
+  if (!hcnt || c < 0 || c >= e->m.n_col || hcnt[c] == 0) return 0;
+  update_transforms(e);
+  const xform* xb = &e->xb[e->m.col_body[c]];
+  const int n = hcnt[c] < max ? hcnt[c] : max;
+  for (int i = 0; i < n; i++) {
+    const real v[3] = {(real)hv[hoff[c] + i][0], (real)hv[hoff[c] + i][1], (real)hv[hoff[c] + i][2]};
+    real w[3]; m3mulv(w, xb->R, v); v3add(w, w, xb->p);
+    for (int k = 0; k < 3; k++) out[3 * i + k] = w[k];
+  }
+  return hcnt[c];
+}
 /* static tables a renderer needs: per collider [type, he3, rgb3, toggle, link] (9 doubles) */
 int rpo_collider_table(const rpo_env* e, double* out) {
   const rp_model* m = &e->m;

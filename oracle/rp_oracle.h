@@ -113,6 +113,7 @@ double rpo_rng_uniform(unsigned long long seed, unsigned env_index, unsigned cou
 #ifdef __cplusplus
 }
 #endif
+int rpo_hull_vertices_world(rpo_env* e, int c, double* out, int max);      /* world-frame hull vertices of an arm collider (0: none) */
 int rpo_collider_poses(rpo_env* e, double* out12_per_collider);      /* world R (row-major) and p of every collider, returns the count */
 int rpo_collider_table(const rpo_env* e, double* out9_per_collider); /* type, he3, rgb3, toggle, link */
 

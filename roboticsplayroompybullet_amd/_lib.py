@@ -73,7 +73,7 @@ class RpTimers(C.Structure):
 
 EXPORTS = ['rp_create', 'rp_destroy', 'rp_get_dims', 'rp_reset', 'rp_reset_to', 'rp_reset_goal', 'rp_step', 'rp_calc_state',
            'rp_compute_reward', 'rp_compute_reward_sparse', 'rp_state_bytes', 'rp_get_state', 'rp_set_state', 'rp_get_timers', 'rp_enable_timers',
-           'rp_last_error', 'rp_version', 'rp_default_camera', 'rp_camera_from_yaw_pitch_roll', 'rp_render', 'rp_ray_test']
+           'rp_last_error', 'rp_version', 'rp_default_camera', 'rp_camera_from_yaw_pitch_roll', 'rp_render', 'rp_render_ex', 'rp_ray_test']
 # include/rp_playroom_debug.h: test / tuning hooks
 DEBUG_EXPORTS = ['rp_set_fused', 'rp_set_groups', 'rp_set_debug_flags', 'rp_debug_substep', 'rp_debug_row_counts', 'rp_debug_reset_rounds']
 
@@ -121,6 +121,7 @@ def load(wide=False):
     lib.rp_default_camera.argtypes = [C.POINTER(RpCamera)]
     lib.rp_camera_from_yaw_pitch_roll.argtypes = [C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(RpCamera)]
     lib.rp_render.argtypes = [vp, C.POINTER(RpCamera), C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp]
+    lib.rp_render_ex.argtypes = [vp, C.POINTER(RpCamera), C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp]
     lib.rp_ray_test.argtypes = [vp, vp, vp, C.c_int32, vp, vp, vp, vp, vp, vp]
     lib.rp_debug_substep.argtypes = [vp, C.c_int32, C.POINTER(C.c_float)]
     lib.rp_set_fused.argtypes = [vp, C.c_int32]

@@ -112,6 +112,10 @@ typedef struct DevModel {
   const float* hcv;
   const int* hco;
   int hcell_first[RP_MAX_COL];
+  /* face planes of the hulls for the ray caster (generated/rp_hullplanes_gen.h; rp_render.cuh rc_ray_hull): (nx, ny, nz, w), n . x + w <= 0 inside, in the COLLIDER's frame
+   * (rp_create takes them there from the body frame they are baked in); per collider the first plane and the count (0: the collider is drawn as its box / sphere) */
+  const float* hpl;
+  int hpl_off[RP_MAX_COL], hpl_cnt[RP_MAX_COL];
 } DevModel;
 
 static inline int rp_dm_dof_of_joint(const rp_model* m, int j) {

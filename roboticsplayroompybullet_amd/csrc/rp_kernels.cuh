@@ -103,7 +103,7 @@ static_assert(MAXACT <= 64 && NB_MAX <= 32, "a candidate record packs its pair i
 /* The hull pairs of a substep, pooled over all active pairs (narrowphase_coop's first phase; hull_item): per active pair its colliders | margin | baked pair index,
  * its outcome (-1 no hull pair / the OBB path, 0 apart, 1 contact) and the staged contact; the pairs of each GJK cache slot as a 64-bit mask (a CLASS: worked off in
  * pair order by one wave); a GJK scratch per wave; and k_prep2's hand-over between its two waves: unclaimed classes | classes done | - | narrowphase over */
-#define HULL_POOL_FIELDS int hinfo[MAXACT][4]; int hout[MAXACT]; float hpt[MAXACT][7]; unsigned long long hcls[PMC_AXN]; alignas(8) float gjkscr[2][56]; int hsync[4];
+#define HULL_POOL_FIELDS int hinfo[MAXACT][4]; int hout[MAXACT]; float hpt[MAXACT][7]; unsigned long long hcls[PMC_AXN];
 struct __align__(16) EnvLds {
   float st[RP_REC_FLOATS];
   float xR[NB_MAX * 9], xp[NB_MAX * 3];
@@ -141,12 +141,11 @@ struct __align__(16) EnvLds {
 /* PrepLds: k_prep2 / k_settle_prep / the prep blocks of k_action_prep: one env per block of TWO waves.  A substep's preparation is a chain
  * of latency-bound phases; collision detection (AABBs, broadphase, narrowphase, manifolds: 26 k cycles) and the arm's dynamics (joint
  * subspaces, CRBA, Cholesky, bias forces, v*, the unit rows: 24 k) need nothing from each other, so wave 0 runs the first and wave 1 the
- * second, and only the contact rows wait for both - and, since round 4, wave 1 lends itself to wave 0's hull pairs when its own work is done
- * (hull_helper).  What the kernel needs beyond that is resident waves: its registers (108 - 128 VGPRs) allow sixteen per CU = eight blocks, so
+ * second, and only the contact rows wait for both.  What the kernel needs beyond that is resident waves: its registers (108 - 128 VGPRs) allow sixteen per CU = eight blocks, so
  * the block may take 160 KB / 8 = 20 KB of LDS and no more.  Lifetimes:
  *   whole kernel   st, body transforms, joint subspaces, the contact list, slot tables, M^-1, tau, v*, free-body inverse inertias
  *   wave 0         AABBs (dead after the broadphase: the narrowphase scratch and then the merged manifolds take their place), active-pair
- *                  tables, candidate points; the hull pool (both waves: HULL_POOL_FIELDS)
+ *                  tables, candidate points; the hull pool (HULL_POOL_FIELDS)
  *   wave 1         the dynamics scratch, then over it the small rows; after the join ONE CHUNK of contact rows (PREP_CH contacts: built,
  *                  copied to the workspace, next chunk); aout (the unit rows in solver form) has left by then */
 struct __align__(16) PrepLds {
@@ -216,6 +215,7 @@ __device__ unsigned long long g_clk[32 * 4096];
 #define PCLK(i) if (lane == 0) { g_clk[32 * (blockIdx.x & 4095) + (i)] = (i) >= 6 && (i) < 8 ? wall_clock64() : __builtin_readcyclecounter(); }
 #define PCLK_ZERO(i) if (lane == 0) { g_clk[32 * (blockIdx.x & 4095) + (i)] = 0ull; }
 #define PCLK_ADD(i, v) if (lane == 0) { g_clk[32 * (blockIdx.x & 4095) + (i)] += (unsigned long long)(v); }
+#define HCLK_ADD(i, v) if (l16 == 0) { atomicAdd(&g_clk[32 * (blockIdx.x & 4095) + (i)], (unsigned long long)(v)); }      /* (hull_item16: the four rows of a wave count side by side) */
 #ifdef RP_HPROF      /* experiment: slots 29-31 = cycles inside hull_item | in the narrowphase's hull section | waiting for the other wave (first wave only) */
 #define PCLK_G(i, v)
 #define PCLK_H(i, v) PCLK_ADD(i, v)
@@ -228,6 +228,7 @@ __device__ unsigned long long g_clk[32 * 4096];
 #define PCLK(i)
 #define PCLK_ZERO(i)
 #define PCLK_ADD(i, v)
+#define HCLK_ADD(i, v)
 #define PCLK_G(i, v)
 #define PCLK_H(i, v)
 #define CLK_MARK2(i) CLK_MARK(i)
@@ -238,6 +239,7 @@ __device__ unsigned long long g_clk[32 * 4096];
 #define PCLK(i)
 #define PCLK_ZERO(i)
 #define PCLK_ADD(i, v)
+#define HCLK_ADD(i, v)
 #define PCLK_G(i, v)
 #define PCLK_H(i, v)
 #endif
@@ -649,45 +651,76 @@ __device__ __forceinline__ void gjk_closest(GjkSimplex& S, int lane) {
   if (S.n == 1) { S.weights(1.0, 0.0, 0.0); WSYNC(); return; }
   if (S.n == 2) { const D3 a = S.pt(0), b = S.pt(1); const GjkTri r = gjk_seg(a, b); WSYNC(); S.reduce(a, b, b, S.b0, S.b1, S.b1, S.i0, S.i1, S.i1, r.keep, r.l0, r.l1, r.l2); WSYNC(); return; }
   if (S.n == 3) { const D3 a = S.pt(0), b = S.pt(1), c = S.pt(2); const GjkTri r = gjk_tri(a, b, c); WSYNC(); S.reduce(a, b, c, S.b0, S.b1, S.b2, S.i0, S.i1, S.i2, r.keep, r.l0, r.l1, r.l2); WSYNC(); return; }
-  /* tetrahedron: the closest of the faces the origin lies outside of (the oracle's F / OPP tables; one face after the other: side by side in four lanes they cost
-   * the registers of four triangles at once, and this kernel has none to spare), then the winner once more */
-  double best = 1e30; int bf = -1;
-#pragma unroll 1
-  for (int f = 0; f < 4; f++) {
+  /* tetrahedron: the closest of the faces the origin lies outside of (the oracle's F / OPP tables).  The four faces side by side in the four lanes of a quad - every lane
+   * of the row runs this code anyway, and one after the other the faces were four fifths of a deep GJK round's ~14 k cycles (an arm pressed into the furniture under the
+   * literal random-action rollout: a dozen such rounds per substep) -, then the quad's minimum, the lowest face among equals as the oracle's `dd < best` keeps it */
+  const int f = lane & 3;
+  double dd;
+  GjkTri r;
+  {
     const int i0 = f == 3 ? 1 : 0, i1 = f == 0 ? 1 : (f == 1 ? 2 : 3), i2 = f == 0 ? 2 : (f == 1 ? 3 : (f == 2 ? 1 : 2)), io = f == 0 ? 3 : (f == 1 ? 1 : (f == 2 ? 2 : 0));
     const D3 a = S.pt(i0), b = S.pt(i1), c = S.pt(i2);
     double so, sd;
     { const D3 d = S.pt(io), nrm = dcross(b - a, c - a); so = -ddot(a, nrm); sd = ddot(d - a, nrm); }
-    if (so * sd > 0.0 || (sd == 0.0 && so == 0.0)) continue;
-    const GjkTri r = gjk_tri(a, b, c);
+    const bool skip = so * sd > 0.0 || (sd == 0.0 && so == 0.0);
+    r = gjk_tri(a, b, c);
     const D3 q = mkd(a.x * r.l0 + b.x * r.l1 + c.x * r.l2, a.y * r.l0 + b.y * r.l1 + c.y * r.l2, a.z * r.l0 + b.z * r.l1 + c.z * r.l2);
-    const double dd = ddot(q, q);
-    if (dd < best) { best = dd; bf = f; }
+    dd = ddot(q, q);
+    if (skip || !(dd < 1e30)) dd = 1e30;
   }
-  if (bf < 0) return;
+  double mn = fmin(dd, __shfl_xor(dd, 1));
+  mn = fmin(mn, __shfl_xor(mn, 2));
+  int bf = (dd == mn && dd < 1e30) ? f : 4;
+  bf = min(bf, __shfl_xor(bf, 1));
+  bf = min(bf, __shfl_xor(bf, 2));
+  if (bf > 3) return;                                        /* the origin lies inside all four: the cores overlap (S.n stays 4) */
+  const int src = (lane & ~3) | bf;                          /* the lane of this quad that solved the winning face */
+  const int keep = __shfl(r.keep, src);
+  const double l0 = __shfl(r.l0, src), l1 = __shfl(r.l1, src), l2 = __shfl(r.l2, src);
   const int i0 = bf == 3 ? 1 : 0, i1 = bf == 0 ? 1 : (bf == 1 ? 2 : 3), i2 = bf == 0 ? 2 : (bf == 1 ? 3 : (bf == 2 ? 1 : 2));
   const D3 a = S.pt(i0), b = S.pt(i1), c = S.pt(i2);
   auto code = [&](int i) { return i == 0 ? S.b0 : (i == 1 ? S.b1 : (i == 2 ? S.b2 : S.b3)); };
   auto vert = [&](int i) { return i == 0 ? S.i0 : (i == 1 ? S.i1 : (i == 2 ? S.i2 : S.i3)); };
   const int qa = code(i0), qb = code(i1), qc = code(i2), ja = vert(i0), jb = vert(i1), jc = vert(i2);
-  const GjkTri r = gjk_tri(a, b, c);
   WSYNC();
-  S.reduce(a, b, c, qa, qb, qc, ja, jb, jc, r.keep, r.l0, r.l1, r.l2);
+  S.reduce(a, b, c, qa, qb, qc, ja, jb, jc, keep, l0, l1, l2);
   WSYNC();
 }
 
-/* One hull pair, by a WHOLE WAVE (a link of a thousand vertices in sixteen rounds instead of 125): everything below is the same in every lane except the vertices it scans
- * (lane, lane + 64, ...).  The pair is active pair gi of the substep, described in L.hinfo[gi] by narrowphase_coop's first phase (hull collider | box collider << 8 | hull is
- * collider b << 16, margin, baked pair index); the outcome goes to L.hout[gi] (1: hull contact, staged in L.hpt[gi]; 0: apart; -1: the OBB path) - through LDS both
- * ways, because in k_prep2 the wave that runs this may be the OTHER wave of the block (hull_helper) */
+/* One hull pair by the SIXTEEN LANES OF A DPP ROW, the four rows of a wave on four pairs at once (round 5; until then a whole wave did one pair after the other: since the
+ * support-vertex tables a query looks at a handful of vertices, and under the literal random-action rollout an arm lying on the furniture has ten such pairs per substep).
+ * Everything below is the same in the sixteen lanes of a row except the candidates a lane scans; nothing in it is wave-uniform - no readfirstlane, no ballot, the cross-lane
+ * steps are row DPP - and the rows diverge freely (a row whose pair needs no GJK idles while another iterates).  gi = the row's active pair of the substep, -1: none; the
+ * pair is described in L.hinfo[gi] by narrowphase_coop's first phase (hull collider | box collider << 8 | hull is collider b << 16, margin, baked pair index); the outcome
+ * goes to L.hout[gi] (1: hull contact, staged in L.hpt[gi]; 0: apart; -1: the OBB path).  The GJK simplex of a row lives in its 64 floats of the narrowphase scratch
+ * (free until the batches start). */
+template <int K>
+__device__ __forceinline__ int bcast16i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x150 + (K & 15), 0xF, 0xF, true); }
+__device__ __forceinline__ float row_max_f(float v) {      /* max over the 16 lanes of a DPP row, in every lane */
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true)));
+  return v;
+}
+__device__ __forceinline__ int row_min_i(int v) {
+  v = min(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true));
+  v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true));
+  v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true));
+  v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true));
+  return v;
+}
 template <class LDS>
-__device__ __forceinline__ void hull_item(const DevModel* m, LDS& L, const int lane, const int gi, float* gax, const int wsel) {      /* gi: the active pair's number; wsel: which wave's GJK scratch */
-        const int hinf = __builtin_amdgcn_readfirstlane(L.hinfo[gi][0]);
+__device__ __forceinline__ void hull_item16(const DevModel* m, LDS& L, const int lane, const int gi, float* gax) {
+  const int l16 = lane & 15, row = lane >> 4;
+  if (gi >= 0) {
+        PCLK_ADD(29, -(long long)__builtin_readcyclecounter())      /* (profiling build, row 0's items: cycles in the set-up and the 15-axis test | 30: the face scan | 31: GJK) */
+        const int hinf = L.hinfo[gi][0];
         const int ca = hinf & 255, cb = (hinf >> 8) & 255;
         const bool flip = ((hinf >> 16) & 1) != 0;                  /* the pair's normal points from b toward a: from the hull toward the box when the hull is b */
-        const float mg = __int_as_float(__builtin_amdgcn_readfirstlane(L.hinfo[gi][1]));
+        const float mg = __int_as_float(L.hinfo[gi][1]);
         /* what this pair's last GJK call left in the contact cache (issued now, used after the scan) */
-        const int pi_u = __builtin_amdgcn_readfirstlane(L.hinfo[gi][2]);
+        const int pi_u = L.hinfo[gi][2];
         float* gslot = gax ? gax + 8 * (pi_u & (PMC_AXN - 1)) : nullptr;
         float4 gs1 = make_float4(0.f, 0.f, 0.f, 0.f); int gtag = 0;
         if (gslot && m->gjk) { gtag = __float_as_int(gslot[0]); gs1 = *(const float4*)(gslot + 4); }      /* (the direction for the scan; the simplex is fetched when GJK is reached) */
@@ -712,7 +745,7 @@ __device__ __forceinline__ void hull_item(const DevModel* m, LDS& L, const int l
           const Xf xh = collider_xf(m, L, ca);
           const V3 hh = ld3(m->col_he[ca]);
           const V3 a0 = col(xh.R, 0), a1 = col(xh.R, 1), a2 = col(xh.R, 2);
-          const int t = lane & 15;
+          const int t = l16;
           V3 ax; bool okax = t < 15;
           if (t < 3) ax = pick3(t, a0, a1, a2);
           else if (t < 6) ax = pick3(t - 3, b0, b1, b2);
@@ -726,14 +759,8 @@ __device__ __forceinline__ void hull_item(const DevModel* m, LDS& L, const int l
           const float ra = hh.x * fabsf(dot(ax, a0)) + hh.y * fabsf(dot(ax, a1)) + hh.z * fabsf(dot(ax, a2));
           const float rb = hcm.x * fabsf(dot(ax, b0)) + hcm.y * fabsf(dot(ax, b1)) + hcm.z * fabsf(dot(ax, b2));
           const float tl = dot(xh.p - xc.p, ax);
-          float gap = okax ? fabsf(tl) - ra - rb : -1e30f;
-          float gm = gap;
-          gm = fmaxf(gm, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(gm), 0xB1, 0xF, 0xF, true)));
-          gm = fmaxf(gm, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(gm), 0x4E, 0xF, 0xF, true)));
-          gm = fmaxf(gm, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(gm), 0x141, 0xF, 0xF, true)));
-          gm = fmaxf(gm, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(gm), 0x140, 0xF, 0xF, true)));
-          gm = lane_read(gm, 0);
-          obb_apart = gm > mg + RP_HULL_MARGIN + 1e-5f;
+          const float gap = okax ? fabsf(tl) - ra - rb : -1e30f;
+          obb_apart = row_max_f(gap) > mg + RP_HULL_MARGIN + 1e-5f;
           up = mk3(0, 0, 0); cp = 0.f;
           if (warm) {
             const V3 vc = mk3(gs1.y, gs1.z, gs1.w);
@@ -746,49 +773,44 @@ __device__ __forceinline__ void hull_item(const DevModel* m, LDS& L, const int l
             }
           }
         }
-        if (obb_apart) {                                     /* (wave-uniform) */
-          PCLK_ADD(15, 1ull << 48)
-          if (lane == 0) L.hout[gi] = 0;
-          return;
-        }
+        int out = 0;                                         /* this pair's hf */
+        V3 nloc = mk3(0, 0, 0), ploc = mk3(0, 0, 0); float dcon = 0.f;      /* the contact in the BOX's frame: normal (box toward hull), point on the box's surface, distance */
+        HCLK_ADD(15, obb_apart ? (1ull << 48) : 0ull)
+        PCLK_ADD(29, __builtin_readcyclecounter())
+        if (!obb_apart) {
+        PCLK_ADD(30, -(long long)__builtin_readcyclecounter())
         const int nn = m->hull_cnt[ca];
         const float4* tv = (const float4*)m->hullv + m->hull_off[ca];
         const float4* __restrict__ cv = (const float4*)m->hcv;
         const int* __restrict__ co = m->hco + m->hcell_first[ca];
-        /* the hull's extent along the box's three axes - six support queries - and its clearance along the probe direction, a seventh: one group of eight lanes per query
-         * (groups 0 / 1: the lowest / highest l_0, 2 / 3: l_1, 4 / 5: l_2, 6: the lowest coordinate along the probe), each scanning the cell of its direction, eight
-         * candidates a round (rising vertex numbers in every lane's sequence: a lane's first strict extreme is its lowest-numbered one), then the groups' reductions side by
-         * side in three DPP steps.  (Until round 5 the wave scanned the whole hull, 4 - 16 rounds of 64 vertices with six running extremes and their vertex numbers per lane.) */
+        /* the hull's extent along the box's three axes - six support queries - and its clearance along the probe direction, a seventh: two lanes per query (lanes 2 q, 2 q + 1:
+         * q = 0 / 1 the lowest / highest l_0, 2 / 3: l_1, 4 / 5: l_2, 6: the lowest coordinate along the probe), each pair of lanes scanning the cell of its direction, two
+         * candidates a round (rising vertex numbers in every lane's sequence: a lane's first strict extreme is its lowest-numbered one), one DPP step joins the two lanes */
         float lo0, lo1, lo2, hi0, hi1, hi2, pmin;
         int il0, il1, il2, ih0, ih1, ih2;
         {
-          const int g8 = lane >> 3, s8 = lane & 7;
-          const V3 um = g8 < 2 ? u0 : (g8 < 4 ? u1 : (g8 < 6 ? u2 : up));
-          const float cm = g8 < 2 ? c0 : (g8 < 4 ? c1 : (g8 < 6 ? c2 : cp));
-          const bool wmax = (g8 & 1) != 0;
-          const bool act = g8 < 6 || (g8 == 6 && (up.x != 0.f || up.y != 0.f || up.z != 0.f));
+          const int q7 = l16 >> 1, h2 = l16 & 1;
+          const V3 um = q7 < 2 ? u0 : (q7 < 4 ? u1 : (q7 < 6 ? u2 : up));
+          const float cm = q7 < 2 ? c0 : (q7 < 4 ? c1 : (q7 < 6 ? c2 : cp));
+          const bool wmax = (q7 & 1) != 0;
+          const bool act = q7 < 6 || (q7 == 6 && (up.x != 0.f || up.y != 0.f || up.z != 0.f));
           const int cell = hcell_of(wmax ? um : -um);
           const int o0 = co[cell], o1 = act ? co[cell + 1] : o0;
           float bestv = -1e30f; int besti = 0x7fffffff;
-          for (int base = o0 + s8; __any(base < o1); base += 8) {
+          for (int base = o0 + h2; __any(base < o1); base += 2) {
             const float4 q = cv[base < o1 ? base : o0];
             const float l = hull_coord(um, q, cm);
             const float val = wmax ? l : -l;
             if (base < o1 && val > bestv) { bestv = val; besti = __float_as_int(q.w); }
           }
-          float gm = bestv;
-          gm = fmaxf(gm, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(gm), 0xB1, 0xF, 0xF, true)));
-          gm = fmaxf(gm, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(gm), 0x4E, 0xF, 0xF, true)));
-          gm = fmaxf(gm, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(gm), 0x141, 0xF, 0xF, true)));      /* (row_half_mirror: the other quad of the eight) */
-          int gi = bestv == gm ? besti : 0x7fffffff;
-          gi = min(gi, __builtin_amdgcn_update_dpp(0, gi, 0xB1, 0xF, 0xF, true));
-          gi = min(gi, __builtin_amdgcn_update_dpp(0, gi, 0x4E, 0xF, 0xF, true));
-          gi = min(gi, __builtin_amdgcn_update_dpp(0, gi, 0x141, 0xF, 0xF, true));
-          lo0 = -lane_read(gm, 0); hi0 = lane_read(gm, 8); lo1 = -lane_read(gm, 16); hi1 = lane_read(gm, 24); lo2 = -lane_read(gm, 32); hi2 = lane_read(gm, 40);
-          pmin = -lane_read(gm, 48);
-          il0 = __builtin_amdgcn_readlane(gi, 0); ih0 = __builtin_amdgcn_readlane(gi, 8); il1 = __builtin_amdgcn_readlane(gi, 16); ih1 = __builtin_amdgcn_readlane(gi, 24);
-          il2 = __builtin_amdgcn_readlane(gi, 32); ih2 = __builtin_amdgcn_readlane(gi, 40);
+          const float gm = fmaxf(bestv, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(bestv), 0xB1, 0xF, 0xF, true)));      /* (quad_perm [1, 0, 3, 2]: the other lane of the pair) */
+          int gi2 = bestv == gm ? besti : 0x7fffffff;
+          gi2 = min(gi2, __builtin_amdgcn_update_dpp(0, gi2, 0xB1, 0xF, 0xF, true));
+          lo0 = -bcast16<0>(gm); hi0 = bcast16<2>(gm); lo1 = -bcast16<4>(gm); hi1 = bcast16<6>(gm); lo2 = -bcast16<8>(gm); hi2 = bcast16<10>(gm);
+          pmin = -bcast16<12>(gm);
+          il0 = bcast16i<0>(gi2); ih0 = bcast16i<2>(gi2); il1 = bcast16i<4>(gi2); ih1 = bcast16i<6>(gi2); il2 = bcast16i<8>(gi2); ih2 = bcast16i<10>(gi2);
         }
+        PCLK_ADD(30, __builtin_readcyclecounter())
         const float g0 = lo0 - hcm.x, g1 = -hi0 - hcm.x, g2 = lo1 - hcm.y, g3 = -hi1 - hcm.y, g4 = lo2 - hcm.z, g5 = -hi2 - hcm.z;      /* face +k: lowest vertex above it; face -k: highest vertex below it */
         float best = g0; int bf = 0;
         if (g1 > best + K_TIE_EPS) { best = g1; bf = 1; }
@@ -800,11 +822,9 @@ __device__ __forceinline__ void hull_item(const DevModel* m, LDS& L, const int l
         /* the probe direction: cores farther apart than the margin and the two shape margins along it - what GJK's distance phase would end with (oracle
          * hull_box_gjk: "apart").  Only with GJK on: without it such a pair goes to the OBB path, which finds the OBBs apart all the same */
         const bool probe_apart = m->gjk && warm && pmin > mg + 2.f * RP_HULL_MARGIN + 1e-6f;
-        PCLK_ADD(15, 1 + ((d > mg) ? 65536 : 0) + ((probe_apart && !(d > mg)) ? (1ull << 32) : 0ull))               /* (profiling build: hull pairs scanned | of them apart << 16) */
-        int out = 0;                                         /* this pair's hf */
-        V3 nloc = mk3(0, 0, 0), ploc = mk3(0, 0, 0); float dcon = 0.f;      /* the contact in the BOX's frame: normal (box toward hull), point on the box's surface, distance */
-        if (!(d > mg)) {                                     /* (wave-uniform) */
-          /* the first vertex (lowest number: the oracle's sequential scan keeps the first strict extreme) whose coordinate along that axis IS the extreme: its group kept it */
+        HCLK_ADD(15, 1 + ((d > mg) ? 65536 : 0) + ((probe_apart && !(d > mg)) ? (1ull << 32) : 0ull))               /* (profiling build: hull pairs scanned | of them apart << 16) */
+        if (!(d > mg)) {
+          /* the first vertex (lowest number: the oracle's sequential scan keeps the first strict extreme) whose coordinate along that axis IS the extreme: its lanes kept it */
           const int k = bf >> 1;
           const int iv = (bf & 1) ? (k == 0 ? ih0 : (k == 1 ? ih1 : ih2)) : (k == 0 ? il0 : (k == 1 ? il1 : il2));
           out = -1;
@@ -823,16 +843,16 @@ __device__ __forceinline__ void hull_item(const DevModel* m, LDS& L, const int l
                                                               * millimetre beside the box CORE's face and read 'apart' by a fraction of the shape margin.  The cache stays) */
             } else if (m->gjk) {
               /* the deepest vertex lies BESIDE the face (box edges and corners): GJK's distance phase, cores with the 0.001 margin around each (oracle hull_box_gjk;
-               * -1 again = the cores touch or overlap: the OBB path keeps that case).  Box frame, the simplex in registers, seeded with lv against the corner(s)
-               * of the box core's nearest feature; support queries = whole-wave vertex scans */
-              PCLK_ADD(27, 1) PCLK_ADD(28, -(long long)__builtin_readcyclecounter())
+               * -1 again = the cores touch or overlap: the OBB path keeps that case).  Box frame, seeded with lv against the corner(s) of the box core's nearest feature;
+               * support queries = scans of the direction's cell by the row's sixteen lanes */
+              HCLK_ADD(27, 1) HCLK_ADD(28, -(long long)__builtin_readcyclecounter()) PCLK_ADD(31, -(long long)__builtin_readcyclecounter())
               V3 hbc = mk3(hc0.x - fminf(RP_HULL_MARGIN, hc0.x), hc0.y - fminf(RP_HULL_MARGIN, hc0.y), hc0.z - fminf(RP_HULL_MARGIN, hc0.z));
               const bool ox = fabsf(lv.x) > hbc.x, oy = fabsf(lv.y) > hbc.y, oz = fabsf(lv.z) > hbc.z;
               const int nout = (ox ? 1 : 0) + (oy ? 1 : 0) + (oz ? 1 : 0);
-              /* (the simplex lives in the pair's scratch, and so does v while a scan runs and the scan's directions while the simplex is solved: the kernel has no registers for them) */
-              double* Z = (double*)&L.gjkscr[wsel][0];
-              float* Y = &L.gjkscr[wsel][2 * 18];
-              static_assert(sizeof(L.gjkscr[0]) >= (2 * 18 + 15) * sizeof(float), "the simplex: twelve doubles, the weights and v, 8-byte aligned; fifteen floats behind them");
+              /* (the simplex lives in the row's scratch, and so does v while a scan runs and the scan's directions while the simplex is solved: the kernel has no registers for them) */
+              double* Z = (double*)&L.npscr[64 * row];
+              float* Y = &L.npscr[64 * row + 2 * 18];
+              static_assert(NPSCR_FLOATS >= 4 * 64 && 64 >= 2 * 18 + 15, "a row's GJK scratch: the simplex (twelve doubles), the weights and v, 8-byte aligned; fifteen floats behind them");
 #define GJK_PARK_DIRS() do { st3(Y, u0); st3(Y + 3, u1); st3(Y + 6, u2); st3(Y + 9, mk3(c0, c1, c2)); st3(Y + 12, hbc); asm volatile("" ::: "memory"); } while (0)
 #define GJK_FETCH_DIRS() do { asm volatile("" ::: "memory"); u0 = ld3(Y); u1 = ld3(Y + 3); u2 = ld3(Y + 6); { const V3 t_ = ld3(Y + 9); c0 = t_.x; c1 = t_.y; c2 = t_.z; } hbc = ld3(Y + 12); } while (0)
               GjkSimplex S;
@@ -875,50 +895,47 @@ __device__ __forceinline__ void hull_item(const DevModel* m, LDS& L, const int l
               const double far = (double)mg + 2.0 * (double)RP_HULL_MARGIN;
 #pragma unroll 1
               for (int it = 0; it < 32 && !fail; it++) {
-                PCLK_ADD(26, 1) PCLK_G(29, -(long long)__builtin_readcyclecounter())
+                HCLK_ADD(26, 1)
                 V3 wa; int wi;
                 const V3 vf = mk3((float)v.x, (float)v.y, (float)v.z);
                 Z[15] = v.x; Z[16] = v.y; Z[17] = v.z;
                 asm volatile("" ::: "memory");
-                {                                            /* hull: the vertex of largest projection on -v (lowest index among equals) */
+                {                                            /* hull: the vertex of largest projection on -v (lowest number among equals) */
                   const V3 dl = -(u0 * vf.x + u1 * vf.y + u2 * vf.z);
                   float bd = -1e30f; int bi = 0x7fffffff; V3 bq = mk3(0, 0, 0);
-                  const int cell = __builtin_amdgcn_readfirstlane(hcell_of(dl));
-                  const int o0 = co[cell], o1 = co[cell + 1];      /* (the cell of the direction: a few vertices, one round of the wave - three for a rim circle seen along its axis) */
-                  for (int base = o0 + lane; base - lane < o1; base += 64) {
+                  const int cell = hcell_of(dl);
+                  const int o0 = co[cell], o1 = co[cell + 1];      /* (the cell of the direction: a few vertices, one round of the row - five for a rim circle seen along its axis) */
+                  for (int base = o0 + l16; __any(base - l16 < o1); base += 16) {
                     const float4 q = cv[base < o1 ? base : o0];
                     const float dq = __fmaf_rn(dl.z, q.z, __fmaf_rn(dl.y, q.y, dl.x * q.x));
                     if (base < o1 && dq > bd) { bd = dq; bi = __float_as_int(q.w); bq = mk3(q.x, q.y, q.z); }
                   }
-                  const float top = wave_max_f(bd);
-                  const int key = wave_min_i(bd == top ? ((bi << 6) | lane) : 0x7fffffff);      /* (the lowest vertex number among equals; the lane that holds it rides along) */
-                  wi = key >> 6;
-                  const int win = key & 63;
-                  const V3 q = mk3(lane_read(bq.x, win), lane_read(bq.y, win), lane_read(bq.z, win));
+                  const float top = row_max_f(bd);
+                  const int key = row_min_i(bd == top ? ((bi << 4) | l16) : 0x7fffffff);      /* (the lowest vertex number among equals; the lane that holds it rides along) */
+                  wi = key >> 4;
+                  const int win = (lane & 48) | (key & 15);
+                  const V3 q = mk3(__shfl(bq.x, win), __shfl(bq.y, win), __shfl(bq.z, win));
                   wa = mk3(hull_coord(u0, make_float4(q.x, q.y, q.z, 0.f), c0), hull_coord(u1, make_float4(q.x, q.y, q.z, 0.f), c1), hull_coord(u2, make_float4(q.x, q.y, q.z, 0.f), c2));
                 }
                 asm volatile("" ::: "memory");
                 v = mkd(Z[15], Z[16], Z[17]);
-                PCLK_G(29, __builtin_readcyclecounter()) PCLK_G(30, -(long long)__builtin_readcyclecounter())
                 const int wb = (vf.x >= 0.f ? 1 : 0) | (vf.y >= 0.f ? 2 : 0) | (vf.z >= 0.f ? 4 : 0);      /* box core: the corner of largest projection on v */
                 const D3 w = diffd(wa, GjkSimplex::corner(wb, hbc));
                 const double vv = ddot(v, v), vw = ddot(v, w);
                 /* v . w / |v| is a lower bound of the distance: beyond the pair's margin and the two shape margins the pair is apart whatever the iteration would still find */
-                if (vw > 0.0 && vw * vw > far * far * vv) { apart = true; PCLK_G(30, __builtin_readcyclecounter()) break; }
+                if (vw > 0.0 && vw * vw > far * far * vv) { apart = true; break; }
                 bool dup = false;
                 { D3 dw = S.pt(0) - w; dup |= ddot(dw, dw) < GJK_DUP;
                   dw = S.pt(1) - w; dup |= S.n > 1 && ddot(dw, dw) < GJK_DUP;
                   dw = S.pt(2) - w; dup |= S.n > 2 && ddot(dw, dw) < GJK_DUP; }
-                if (dup || vv - vw <= GJK_REL * vv) { PCLK_G(30, __builtin_readcyclecounter()) break; }
+                if (dup || vv - vw <= GJK_REL * vv) break;
                 S.put(S.n, w);
                 if (S.n == 1) { S.b1 = wb; S.i1 = wi; } else if (S.n == 2) { S.b2 = wb; S.i2 = wi; } else { S.b3 = wb; S.i3 = wi; }
                 S.n++;
                 WSYNC();
-                PCLK_G(30, __builtin_readcyclecounter()) PCLK_G(31, -(long long)__builtin_readcyclecounter())
                 GJK_PARK_DIRS();
                 gjk_closest(S, lane);
                 GJK_FETCH_DIRS();
-                PCLK_G(31, __builtin_readcyclecounter())
                 if (S.n == 4) { fail = true; break; }
                 v = S.closest();
                 const double nd = ddot(v, v);
@@ -928,10 +945,10 @@ __device__ __forceinline__ void hull_item(const DevModel* m, LDS& L, const int l
               }
 #undef GJK_PARK_DIRS
 #undef GJK_FETCH_DIRS
-              PCLK_ADD(28, __builtin_readcyclecounter())
+              HCLK_ADD(28, __builtin_readcyclecounter()) PCLK_ADD(31, __builtin_readcyclecounter())
               const double distd = sqrt(ddot(v, v));
-              PCLK_ADD(27, apart ? (1ull << 16) : (fail ? (1ull << 48) : 0ull))
-              if (gslot && lane == 0) {                      /* what the next call of this pair starts from (oracle GAX_STORE / GAX_CLEAR) */
+              HCLK_ADD(27, apart ? (1ull << 16) : (fail ? (1ull << 48) : 0ull))
+              if (gslot && l16 == 0) {                       /* what the next call of this pair starts from (oracle GAX_STORE / GAX_CLEAR) */
                 if (!fail && (apart || distd > GJK_ZERO)) {
                   *(float4*)gslot = make_float4(__int_as_float(pi_u + 1), __int_as_float(S.n | (S.b0 << 4) | ((S.n > 1 ? S.b1 : 0) << 8) | ((S.n > 2 ? S.b2 : 0) << 12)), __int_as_float(S.i0), __int_as_float(S.n > 1 ? S.i1 : 0));
                   *(float4*)(gslot + 4) = make_float4(__int_as_float(S.n > 2 ? S.i2 : 0), (float)v.x, (float)v.y, (float)v.z);
@@ -941,10 +958,10 @@ __device__ __forceinline__ void hull_item(const DevModel* m, LDS& L, const int l
               else if (!fail && distd > GJK_ZERO) {
                 const float dist = (float)distd;
                 const float dg = dist - 2.f * RP_HULL_MARGIN;
-                if (dg > mg) { out = 0; PCLK_ADD(27, 1ull << 16) }
+                if (dg > mg) { out = 0; HCLK_ADD(27, 1ull << 16) }
                 else {
                   out = 1;
-                  PCLK_ADD(27, 1ull << 32)
+                  HCLK_ADD(27, 1ull << 32)
                   const double inv = drcp(distd);
                   nloc = mk3((float)(v.x * inv), (float)(v.y * inv), (float)(v.z * inv));
                   const D3 wit = S.witness(hbc);
@@ -955,6 +972,7 @@ __device__ __forceinline__ void hull_item(const DevModel* m, LDS& L, const int l
             }
           }
         }
+        }
         CPt pt; pt.p = mk3(0, 0, 0); pt.n = mk3(0, 0, 0); pt.dist = 0.f;
         if (out == 1) {                                      /* back to the world; the model's single application point lies halfway along the gap */
           const Xf xc = collider_xf(m, L, cb);
@@ -962,73 +980,17 @@ __device__ __forceinline__ void hull_item(const DevModel* m, LDS& L, const int l
           const V3 pB = mulv(xc.R, ploc) + xc.p;
           pt.p = pB + nrm * (0.5f * dcon); pt.n = flip ? -nrm : nrm; pt.dist = dcon;
         }
-        if (lane == 0) {
+        if (l16 == 0) {
           L.hout[gi] = out;
-          if (out == 1) {                                    /* the point waits in its group's scratch (free until the SAT of this batch) */
+          if (out == 1) {                                    /* the point waits for its pair's batch */
             float* q = &L.hpt[gi][0];
             st3(q, pt.p); st3(q + 3, pt.n); q[6] = pt.dist;
           }
         }
-}
-/* the substep's hull pairs, class by class.  A class = the pairs that share a slot of the GJK cache (PMC_AXN slots per env, pair index mod PMC_AXN): they run in pair
- * order inside ONE wave, as the oracle's sequential loop has them - whichever of them stores last owns the slot afterwards; classes are independent of one another, and
- * a wave takes the lowest unclaimed one (bit c of L.hsync[0] = class c, its pairs the bits of L.hcls[c]) */
-template <class LDS>
-__device__ __forceinline__ void hull_claims(const DevModel* m, LDS& L, const int lane, float* gax, const int who = 0) {
-  for (;;) {
-    /* the lowest class nobody has taken.  The loop is wave-uniform and only the atomic itself sits under `if (lane == 0)`: with the whole take inside a divergent region
-     * (`if (lane == 0) { while ... break ... }`, then readfirstlane) the builds of this function gave results that changed with unrelated edits of the source, each
-     * build deterministic (tools/det_check.py); this form gives the sequential loop's bits */
-    int c = -1;
-    unsigned mk = (unsigned)__builtin_amdgcn_readfirstlane((int)*(volatile unsigned*)&L.hsync[0]);
-    while (mk != 0u) {
-      const int k = __ffs(mk) - 1;
-      const unsigned bit = 1u << k;
-      unsigned old1 = 0u;
-      if (lane == 0) old1 = atomicAnd((unsigned*)&L.hsync[0], ~bit);      /* (one lane: executed by all of them the compiler's wave-wide combining of the operands costs 2 500 cycles a take) */
-      const unsigned old = (unsigned)__builtin_amdgcn_readfirstlane((int)old1);
-      if (old & bit) { c = k; break; }
-      mk = old & ~bit;
-    }
-    if (c < 0) break;
-    WSYNC();
-    PCLK_ADD(19, who ? 65536 : 1)                           /* (profiling build: classes taken by the narrowphase's wave | by the other wave << 16) */
-    const unsigned long long cm = L.hcls[c];
-    unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)cm), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(cm >> 32));
-    if (!who) { PCLK_H(29, -(long long)__builtin_readcyclecounter()) }
-#pragma unroll 1
-    for (int half = 0; half < 2; half++) {
-#pragma unroll 1
-      for (unsigned w = half ? hi : lo; w != 0u; w &= w - 1u) hull_item(m, L, lane, 32 * half + __ffs(w) - 1, gax, who);
-    }
-    if (!who) { PCLK_H(29, __builtin_readcyclecounter()) }
-    WSYNC();
-    if (lane == 0) atomicAdd(&L.hsync[1], 1);                /* one more class done (the narrowphase's wave waits for the count) */
-  }
-}
-/* k_prep2's second wave, once its own work is done: takes classes of hull pairs off the first wave's hands until that wave has left the hull phase (L.hsync[3]).
- * The literal random-action rollout has envs with ten and more hull pairs in reach (an arm slewing across the table's furniture): their first wave alone was the
- * launch's tail, 180 us of whole-wave vertex scans one pair after the other */
-template <class LDS>
-__device__ __forceinline__ void hull_helper(const DevModel* m, LDS& L, const int lane, float* gax) {
-#ifdef RP_NO_HELPER      /* experiment: the narrowphase's wave alone */
-  return;
-#endif
-  PCLK(20)
-  for (;;) {
-    unsigned lead, fin;
-    for (;;) {
-      lead = *(volatile unsigned*)&L.hsync[0]; fin = *(volatile unsigned*)&L.hsync[3];
-      if ((lead | fin) != 0u) break;
-      __builtin_amdgcn_s_sleep(4);
-    }
-    if (__builtin_amdgcn_readfirstlane(lead) == 0u) break;   /* nothing published and the hull phase is over */
-    WSYNC();
-    hull_claims(m, L, lane, gax, 1);
   }
 }
 
-template <class LDS, bool HELP = false>
+template <class LDS>
 __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int lane, int nact, float* __restrict__ gax) {      /* gax: the env's cached GJK results (contact cache row + PMC_AX), nullptr without the cache */
   const int g = lane >> 3, s = lane & 7;
   float* scr = &L.npscr[NPG_SCRATCH * g];
@@ -1042,9 +1004,9 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
    * box's six faces - the same decisions and arithmetic as the oracle's hull_face.  The vertex deepest along the face of least penetration is the contact
    * if it lies over that face (what GJK / EPA return for a vertex-on-face contact: a link on the ground plate, on the table top); beside the face the
    * pair goes to GJK's distance phase (hull_item), and to the OBB path below when the cores overlap.
-   * The pairs that pass the OBB tests are done by a WHOLE WAVE each (hull_item: a link of a thousand vertices in sixteen rounds), class by class (hull_claims) - in k_prep2 by
-   * BOTH waves of the block: the pool of a whole substep shares better than the hull pairs of one batch of eight did (an env of the literal random-action
-   * rollout has 1.5 of them on average and up to 16). */
+   * The pairs that pass the OBB tests are done sixteen lanes each, four at a time (hull_item16), class by class: a CLASS = the pairs that share a slot of the GJK cache
+   * (PMC_AXN slots per env, pair index mod PMC_AXN) runs in pair order in one DPP row, as the oracle's sequential loop has them - whichever of its pairs stores last
+   * owns the slot afterwards; classes are independent of one another (an env of the literal random-action rollout has 1.5 hull pairs on average and up to 16). */
   {
     const int ai = lane;
     const bool act = ai < nact;
@@ -1093,32 +1055,30 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
           if (lane == c) mycls = mk;
         }
         if (lane < PMC_AXN) L.hcls[lane] = mycls;
-        if (HELP) {
-          if (lane == 0) L.hsync[1] = 0;
-          WSYNC();
-          if (lane == 0) L.hsync[0] = (int)leaders;            /* published: from here on the other wave may take classes too */
-          hull_claims(m, L, lane, gax, 0);
-          const int nlead = __popc(leaders);
-          PCLK_H(31, -(long long)__builtin_readcyclecounter())
-          while (*(volatile int*)&L.hsync[1] < nlead) __builtin_amdgcn_s_sleep(1);      /* (a class the other wave still works on) */
-          PCLK_H(31, __builtin_readcyclecounter())
-        } else {
-          WSYNC();
+        WSYNC();
+        /* the classes four at a time, one per DPP row (rising class numbers; a row works through its class in pair order, the rows side by side: hull_item16) */
+        {
+          const int row = lane >> 4;
 #pragma unroll 1
-          for (unsigned lc = leaders; lc != 0u; lc &= lc - 1u) {
-            const unsigned long long cm = L.hcls[__ffs(lc) - 1];
-            unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)cm), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(cm >> 32));
+          for (unsigned rest = leaders; rest != 0u;) {       /* (wave-uniform) */
+            unsigned t = rest;
+            if (row >= 1) t &= t - 1u;
+            if (row >= 2) t &= t - 1u;
+            if (row >= 3) t &= t - 1u;
+            unsigned long long cm = t != 0u ? L.hcls[__ffs(t) - 1] : 0ull;
+            rest &= rest - 1u; rest &= rest - 1u; rest &= rest - 1u; rest &= rest - 1u;
 #pragma unroll 1
-            for (int half = 0; half < 2; half++) {
-#pragma unroll 1
-              for (unsigned w = half ? hi : lo; w != 0u; w &= w - 1u) hull_item(m, L, lane, 32 * half + __ffs(w) - 1, gax, 0);
+            while (__any(cm != 0ull)) {
+              const int gi = cm != 0ull ? __ffsll((long long)cm) - 1 : -1;
+              cm &= cm - 1ull;
+              hull_item16(m, L, lane, gi, gax);
             }
           }
         }
         PCLK_H(30, __builtin_readcyclecounter())
       }
     WSYNC();
-    if (HELP && lane == 0) L.hsync[3] = 1;                     /* (k_prep2: the other wave need not wait for hull pairs any more) */
+    PCLK(19)
   }
   /* ---- 2. everything else, eight lanes per active pair */
   int cbase = 0;                                    /* candidate points stored so far (wave-uniform) */
@@ -1390,7 +1350,7 @@ __device__ __forceinline__ int manifold_replace_index(const float* c4, const flo
 }
 
 /* broadphase + narrowphase + manifolds -> L.con*, returns ncon (wave-uniform) */
-template <class LDS, bool HELP = false>
+template <class LDS>
 __device__ __forceinline__ int collide(const DevModel* m, LDS& L, int lane, int env, const int* npm_early = nullptr) {
   /* 1. AABB sweep over the baked candidate pairs, 64 per pass; keep the first MAXACT overlapping, in order */
   int nact = 0;
@@ -1430,9 +1390,8 @@ __device__ __forceinline__ int collide(const DevModel* m, LDS& L, int lane, int 
   if (lane == 0) g_clk[32 * (blockIdx.x & 4095) + 12] = nact;
 #endif
   /* 2. narrowphase: eight lanes per active pair */
-  narrowphase_coop<LDS, HELP>(m, L, lane, nact, m->persist ? m->pmcache + (size_t)env * PMC_FLOATS + PMC_AX : nullptr);
+  narrowphase_coop<LDS>(m, L, lane, nact, m->persist ? m->pmcache + (size_t)env * PMC_FLOATS + PMC_AX : nullptr);
   WSYNC();
-  if (HELP && lane == 0) L.hsync[3] = 1;                   /* (k_prep2: the other wave need not wait for hull pairs any more) */
   asm volatile("" : "+v"(lane));                          /* (the lane number once more, opaque: addresses the manifold stage derives from it are computed there, not held across the narrowphase) */
   PCLK(9)
   /* 3. manifolds: one per run of equal object pairs, <= 4 points (1 for a rotation-locked body against the world).  A manifold's size
@@ -3247,7 +3206,6 @@ __device__ __forceinline__ void prep2_core(PrepLds& L, const DevModel* __restric
   PCLK(6) PCLK(0) PCLK_ZERO(15) PCLK_ZERO(19) PCLK_ZERO(26) PCLK_ZERO(27) PCLK_ZERO(28) PCLK_ZERO(29) PCLK_ZERO(30) PCLK_ZERO(31)
   static_assert(RP_REC_FLOATS == PREP_THREADS, "one float of the record per thread");
   L.st[tid] = state[(size_t)env * RP_REC_FLOATS + tid];
-  if (tid == 64) { L.hsync[0] = 0; L.hsync[1] = 0; L.hsync[3] = 0; }      /* the waves' hand-over of hull pairs (narrowphase_coop / hull_helper): nothing published yet */
   if (tid == 64) L.hdr[3] = pair_idx;                        /* (waits in LDS for the end of the kernel: a register held across both phases is one the narrowphase spills for) */
   if (tid == 64 && m->persist) L.hdr[2] = __float_as_int(m->pmcache[(size_t)cenv * PMC_FLOATS]);      /* the cache's manifold count, for collide() */
   __syncthreads();
@@ -3261,7 +3219,7 @@ __device__ __forceinline__ void prep2_core(PrepLds& L, const DevModel* __restric
     collider_aabbs(m, L, lane);
     WSYNC();
     PCLK(1)
-    int ncon = collide<PrepLds, true>(m, L, lane, cenv, &L.hdr[2]);
+    int ncon = collide<PrepLds>(m, L, lane, cenv, &L.hdr[2]);
     ncon = uni(ncon);
 #ifdef RP_ABL_MAXCON    /* timing ablation: drop contacts beyond RP_ABL_MAXCON to expose the tail effect in k_solve2 */
     if (ncon > RP_ABL_MAXCON) ncon = RP_ABL_MAXCON;
@@ -3273,10 +3231,6 @@ __device__ __forceinline__ void prep2_core(PrepLds& L, const DevModel* __restric
     joint_subspaces(m, L, lane);
     PCLK(18)
     arm_dynamics(m, L, lane);
-    /* here - M^-1 is there, 28 k cycles into the kernel, about when the other wave has published its hull pairs - this wave lends itself to them while there are any
-     * (in the bench workload the hull phase is over by now and the call returns at once); v*, the unit rows and the copies to the workspace follow: nobody needs
-     * them before the join, and the other wave still has its batches and manifolds to do */
-    hull_helper(m, L, lane, m->persist ? m->pmcache + (size_t)cenv * PMC_FLOATS + PMC_AX : nullptr);
     unconstrained_velocities(m, L, lane);
     PCLK(3)
     int nsmall = build_small_rows(m, L, lane);

@@ -11,6 +11,7 @@
 #include "generated/rp_models_gen.h"
 #include "generated/rp_hullverts_gen.h"
 #include "generated/rp_hullcells_gen.h"
+#include "generated/rp_hullplanes_gen.h"
 #include "rp_device_model.h"
 #include "rp_kernels.cuh"
 #include "rp_render.cuh"
@@ -25,6 +26,7 @@ struct rp_sim {
   float* dbg;
   float* hullv;            /* convex-hull vertices of the arm's collision meshes (DevModel.hullv points here) */
   float* hcv; int* hco;    /* their support-vertex candidate tables (DevModel.hcv / hco) */
+  float* hpl;              /* their face planes, collider frame (DevModel.hpl: the ray caster) */
   float* pmcache;          /* the contact caches, [N][PMC_FLOATS] (DevModel.pmcache points here); nullptr under RP_CFG_STATELESS_CONTACTS */
   int* sort_cnt;           /* [2][RP_MAX_GROUPS][SORT_BINS] load-class histograms for pairing envs in k_solve2 (double-buffered) */
   int* sort_slot;          /* [N] per env: (bin << 16) | rank inside the bin, from the latest k_solve2 */
@@ -99,7 +101,7 @@ const char* rp_version(void) { return "rp_playroom 0.3 (gfx950) build " RP_BUILD
 
 static void destroy_handle(rp_sim* h) {        /* frees whatever a (possibly partial) handle owns; hipFree(nullptr) etc. are no-ops */
   if (!h) return;
-  hipFree(h->hullv); hipFree(h->hcv); hipFree(h->hco); hipFree(h->pmcache); hipFree(h->dev_model); hipFree(h->state); hipFree(h->ws); hipFree(h->dbg); hipFree(h->sort_cnt); hipFree(h->sort_slot); hipFree(h->pair_env); hipFree(h->member[0]); hipFree(h->member[1]);
+  hipFree(h->hullv); hipFree(h->hcv); hipFree(h->hco); hipFree(h->hpl); hipFree(h->pmcache); hipFree(h->dev_model); hipFree(h->state); hipFree(h->ws); hipFree(h->dbg); hipFree(h->sort_cnt); hipFree(h->sort_slot); hipFree(h->pair_env); hipFree(h->member[0]); hipFree(h->member[1]);
   hipFree(h->rc_tab); hipFree(h->rc_cnt); hipFree(h->rc_ee);
   hipFree(h->rs_state); hipFree(h->rs_idx); hipFree(h->rs_meta); hipFree(h->rs_count); hipFree(h->rs_sort_cnt); hipFree(h->rs_sort_slot); hipFree(h->rs_pair);
   if (h->rs_count_host) hipHostFree(h->rs_count_host);
@@ -223,7 +225,31 @@ int rp_create(const rp_config* cfg, rp_handle* out) {
         CREATE_CHK(hipMemcpy(h->hco, coff, (size_t)ncoff * sizeof(int), hipMemcpyHostToDevice));
       }
     }
-    d->hullv = h->hullv; d->hcv = h->hcv; d->hco = h->hco;
+    {      /* the hulls' face planes for the ray caster: baked in the body frame, used in the collider's (x_body = Rc x_col + pc: n_col = Rc^T n, w_col = w + n . pc) */
+      const float (*pl)[4]; const int *poff, *pcnt;
+      const int npl = rp_hplane_tables(d->kind, &pl, &poff, &pcnt);
+      if (npl > 0 && nhv > 0 && getenv("RP_NO_HULL") == nullptr) {
+        std::vector<float> hp((size_t)npl * 4, 0.f);
+        std::vector<char> done((size_t)npl, 0);
+        for (int c = 0; c < RP_MAX_COL; c++) {
+          d->hpl_off[c] = poff[c]; d->hpl_cnt[c] = hcnt[c] > 0 ? pcnt[c] : 0;
+          if (d->hpl_cnt[c] <= 0) continue;
+          if (done[poff[c]]) { d->hpl_cnt[c] = 0; continue; }      /* (a plane list serves ONE collider frame; no model shares one between two) */
+          done[poff[c]] = 1;
+          const float* Rc = d->col_rot[c]; const float* pc = d->col_pos[c];
+          for (int k = poff[c]; k < poff[c] + pcnt[c]; k++) {
+            const float* n = pl[k];
+            hp[4 * (size_t)k] = Rc[0] * n[0] + Rc[3] * n[1] + Rc[6] * n[2];
+            hp[4 * (size_t)k + 1] = Rc[1] * n[0] + Rc[4] * n[1] + Rc[7] * n[2];
+            hp[4 * (size_t)k + 2] = Rc[2] * n[0] + Rc[5] * n[1] + Rc[8] * n[2];
+            hp[4 * (size_t)k + 3] = n[3] + n[0] * pc[0] + n[1] * pc[1] + n[2] * pc[2];
+          }
+        }
+        CREATE_CHK(hipMalloc((void**)&h->hpl, hp.size() * sizeof(float)));
+        CREATE_CHK(hipMemcpy(h->hpl, hp.data(), hp.size() * sizeof(float), hipMemcpyHostToDevice));
+      }
+    }
+    d->hullv = h->hullv; d->hcv = h->hcv; d->hco = h->hco; d->hpl = h->hpl;
     if (!(cfg->flags & RP_CFG_STATELESS_CONTACTS) && !(cfg->flags & RP_CFG_CONTACT_MARGIN) && getenv("RP_STATELESS") == nullptr) {      /* (a uniform contact margin is a stateless-model study: it keeps the stateless contacts) */
       CREATE_CHK(hipMalloc((void**)&h->pmcache, (size_t)N * PMC_FLOATS * sizeof(float)));
       CREATE_CHK(hipMemset(h->pmcache, 0, (size_t)N * PMC_FLOATS * sizeof(float)));
@@ -617,10 +643,13 @@ static RpCamera device_camera(const rp_camera* c) {
   return d;
 }
 
-int rp_render(rp_handle h, const rp_camera* cam, int32_t width, int32_t height, int32_t first_env, int32_t num_envs, uint8_t* rgb,
-              const float* sub_goal, void* stream) {
+int rp_render_ex(rp_handle h, const rp_camera* cam, int32_t width, int32_t height, int32_t first_env, int32_t num_envs, uint8_t* rgb,
+                 const float* sub_goal, const float* ghost_arm, void* stream) {
   if (!h || !rgb || width <= 0 || height <= 0 || width > 4096 || height > 4096 || first_env < 0 || num_envs <= 0 || first_env + num_envs > h->cfg.num_envs) {
     if (h) snprintf(h->err, 256, "rp_render: bad argument"); return RP_ERR_ARG;
+  }
+  if (ghost_arm && h->host_model.arm_type != RP_ARM_PANDA) {      /* environments.py:629-630: the reference has a ghost arm for the Panda only and raises for the UR5 */
+    snprintf(h->err, 256, "rp_render_ex: the ghost arm exists for the Panda only (environments.py:623-630)"); return RP_ERR_UNSUPPORTED;
   }
   DevGuard guard(h->cfg.device);
   rp_camera def;
@@ -629,11 +658,16 @@ int rp_render(rp_handle h, const rp_camera* cam, int32_t width, int32_t height, 
   int rc = rc_reserve(h, num_envs);
   if (rc != RP_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_collider_poses, dim3(num_envs), dim3(64), 0, s, h->dev_model, h->state, first_env, num_envs, h->rc_tab, h->rc_cnt, sub_goal, h->rc_ee);
+  hipLaunchKernelGGL(k_collider_poses, dim3(num_envs), dim3(64), 0, s, h->dev_model, h->state, first_env, num_envs, h->rc_tab, h->rc_cnt, sub_goal, h->rc_ee, ghost_arm);
   const int tiles = (width * height + 255) / 256;
-  hipLaunchKernelGGL(k_render, dim3((unsigned)num_envs * tiles), dim3(256), 0, s, h->rc_tab, h->rc_cnt, num_envs, device_camera(cam), h->rc_ee, width, height, rgb);
+  hipLaunchKernelGGL(k_render, dim3((unsigned)num_envs * tiles), dim3(256), 0, s, h->dev_model, h->rc_tab, h->rc_cnt, num_envs, device_camera(cam), h->rc_ee, width, height, rgb);
   HIPCHK(h, hipGetLastError());
   return RP_OK;
+}
+
+int rp_render(rp_handle h, const rp_camera* cam, int32_t width, int32_t height, int32_t first_env, int32_t num_envs, uint8_t* rgb,
+              const float* sub_goal, void* stream) {
+  return rp_render_ex(h, cam, width, height, first_env, num_envs, rgb, sub_goal, nullptr, stream);
 }
 
 int rp_ray_test(rp_handle h, const float* from, const float* to, int32_t k, float* hit_fraction, int32_t* collider, int32_t* link,
@@ -644,8 +678,8 @@ int rp_ray_test(rp_handle h, const float* from, const float* to, int32_t k, floa
   int rc = rc_reserve(h, N);
   if (rc != RP_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_collider_poses, dim3(N), dim3(64), 0, s, h->dev_model, h->state, 0, N, h->rc_tab, h->rc_cnt, (const float*)nullptr, (float*)nullptr);
-  hipLaunchKernelGGL(k_ray_test, dim3(N), dim3(64), 0, s, h->rc_tab, h->rc_cnt, N, k, from, to, hit_fraction, collider, link, hit_position, hit_normal);
+  hipLaunchKernelGGL(k_collider_poses, dim3(N), dim3(64), 0, s, h->dev_model, h->state, 0, N, h->rc_tab, h->rc_cnt, (const float*)nullptr, (float*)nullptr, (const float*)nullptr);
+  hipLaunchKernelGGL(k_ray_test, dim3(N), dim3(64), 0, s, h->dev_model, h->rc_tab, h->rc_cnt, N, k, from, to, hit_fraction, collider, link, hit_position, hit_normal);
   HIPCHK(h, hipGetLastError());
   return RP_OK;
 }

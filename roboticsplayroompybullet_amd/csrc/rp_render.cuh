@@ -2,8 +2,8 @@
  *
  * The reference renders obs['img'] with PyBullet's OpenGL rasteriser (environments.py:21-30, 841-845: getCameraImage(200, 200,
  * viewMatrix, projectionMatrix), fixed camera; gripper camera environments.py:33-49) and queries one ray per step for
- * gripper_proprioception (environments.py:720-743, rayTest).  Here both are ray casts against the SAME boxes and spheres the contact
- * model uses - the only geometry the library holds - with the colours of the reference's visual shapes (scenes.py rgbaColor, URDF
+ * gripper_proprioception (environments.py:720-743, rayTest).  Here both are ray casts against the SAME shapes the contact model uses - boxes, spheres and, for the arm's
+ * links, the convex hulls of their collision meshes (round 5: until then their boxes) - the only geometry the library holds - with the colours of the reference's visual shapes (scenes.py rgbaColor, URDF
  * materials; the button's globe and the dial's grill recoloured as updateToggles does, environments.py:469-483), flat Lambert shading,
  * no textures, no shadows (the reference passes shadow=0).  Sub-goal visualisation (environments.py:606-690) = the same bodies drawn a
  * second time, half transparent, at the poses a sub-goal vector names.
@@ -16,24 +16,46 @@
 #define RC_STRIDE 20          /* floats per collider record: R9 p3 he3 rgb3 type|flags link */
 #define RC_MAX (2 * RP_MAX_COL)
 #define RC_GHOST 0x100        /* flag in the type word: drawn half transparent, ignored by rp_ray_test */
+#define RC_HULL 0x200         /* flag in the type word: an arm link - the record's box is the box AROUND its collision hull, the shape is the hull (DevModel.hpl: its face planes) */
 
 struct RpCamera { float eye[3], fwd[3], right[3], up[3]; float tan_half_fov, aspect; int mode; };   /* mode 1: at the EE link (gripper camera) */
 
 /* world pose of every collider of env `first + blockIdx.x` into tab[blockIdx.x][RC_MAX][RC_STRIDE]; cnt[blockIdx.x] = records written.
- * sub_goal (may be null): [num][n_ag] achieved-goal vectors to visualise as ghosts (objects, drawer, door, button, dial). */
+ * sub_goal (may be null): [num][n_ag] achieved-goal vectors to visualise as ghosts (objects, drawer, door, button, dial).
+ * ghost_arm (may be null): [num][8] = EE position, orientation quaternion, gripper: the ghost ARM of visualise_sub_goal's 'controllable_achieved_goal' /
+ * 'full_positional_state' (environments.py:623-637, 671-674: reset_arm(ghost_arm, sub_goal, from_init=False) = the arm at its rest pose, one default IK call of 20
+ * iterations towards the pose, joints [0:6] taken - reset_arm_goal_obs' arithmetic), drawn half transparent like the other ghosts. */
 __global__ void __launch_bounds__(64) k_collider_poses(const DevModel* __restrict__ m, const float* __restrict__ state, int first, int num,
                                                        float* __restrict__ tab, int* __restrict__ cnt, const float* __restrict__ sub_goal,
-                                                       float* __restrict__ ee_pose) {
+                                                       float* __restrict__ ee_pose, const float* __restrict__ ghost_arm) {
   __shared__ EnvLds L;
   const int slot = blockIdx.x, lane = threadIdx.x;
   if (slot >= num) return;
   const int env = first + slot;
   load_state(L, state, env, lane);
   float* out = tab + (size_t)slot * RC_MAX * RC_STRIDE;
-  const int passes = (sub_goal && m->num_objects > 0) ? 2 : 1;
+  const bool obj_ghosts = sub_goal && m->num_objects > 0;
+  const int passes = (obj_ghosts || ghost_arm) ? 2 : 1;
   int nrec = 0;
   for (int pass = 0; pass < passes; pass++) {
-    if (pass == 1) {           /* the sub-goal's poses: objects [pos3 (quat4)] ..., then drawer y, door, button, dial (play ids) */
+    if (pass == 1 && ghost_arm) {      /* the ghost arm's joints: rest pose, one IK call, the first six joints (environments.py:575-590 with from_init's pose) */
+      const float* ga = ghost_arm + 8 * (size_t)slot;
+      __syncthreads();
+      if (lane == 0) {
+        const int nrest = m->arm_type == RP_ARM_PANDA ? 8 : 6;
+        for (int i = 0; i < nrest; i++) L.st[ST_Q + i] = m->rest[i];
+      }
+      __syncthreads();
+      ChainQ cur;
+#pragma unroll
+      for (int j = 0; j < 7; j++) cur.q[j] = j < m->ee_chain ? L.st[ST_Q + j] : 0.f;
+      Q4 gq; gq.x = ga[3]; gq.y = ga[4]; gq.z = ga[5]; gq.w = ga[6];
+      const ChainQ sol = ik_solve(m, mk3(ga[0], ga[1], ga[2]), gq, cur, 20, lane & 15);
+      __syncthreads();
+      if (lane == 0) for (int i = 0; i < 6; i++) L.st[ST_Q + i] = sol.q[i];
+      __syncthreads();
+    }
+    if (pass == 1 && obj_ghosts) {           /* the sub-goal's poses: objects [pos3 (quat4)] ..., then drawer y, door, button, dial (play ids) */
       __syncthreads();
       if (lane == 0) {
         const float* g = sub_goal + (size_t)slot * m->n_ag;
@@ -62,7 +84,8 @@ __global__ void __launch_bounds__(64) k_collider_poses(const DevModel* __restric
       st3(e, pos);
       for (int k = 0; k < 9; k++) e[3 + k] = Rs.m[k];
     }
-    const bool mine = lane < m->n_col && (pass == 0 || m->col_body[lane] > m->n_arm);    /* ghosts: free bodies and scene joints only */
+    const int cbody = lane < m->n_col ? m->col_body[lane] : 0;
+    const bool mine = lane < m->n_col && (pass == 0 || (obj_ghosts && cbody > m->n_arm) || (ghost_arm && cbody >= 1 && cbody <= m->n_arm));    /* ghosts: free bodies and scene joints of a sub-goal, the arm's links of a ghost arm */
     const unsigned long long bal = __ballot(mine);
     if (mine) {
       const int r = nrec + __popcll(bal & ((1ull << lane) - 1ull));
@@ -76,7 +99,7 @@ __global__ void __launch_bounds__(64) k_collider_poses(const DevModel* __restric
       if (tog == 1 && m->n_j1 > 1) { const bool on = L.st[ST_JQ + 1] < 0.025f; cr = 1.f; cg = on ? 0.f : 1.f; cb = on ? 0.f : 1.f; }
       if (tog == 2 && m->n_j1 > 2) { const bool on = dial01(L.st[ST_JQ + 2]) < 0.5f; cr = 1.f; cg = on ? 0.f : 1.f; cb = on ? 0.f : 1.f; }
       o[15] = cr; o[16] = cg; o[17] = cb;
-      o[18] = __int_as_float(m->col_type[lane] | (pass == 1 ? RC_GHOST : 0));
+      o[18] = __int_as_float(m->col_type[lane] | (pass == 1 ? RC_GHOST : 0) | ((m->hpl && m->hpl_cnt[lane] > 0) ? RC_HULL : 0));
       o[19] = __int_as_float((m->col_link[lane] << 8) | lane);
     }
     nrec += __popcll(bal);
@@ -105,6 +128,29 @@ __device__ __forceinline__ bool rc_ray_box(const float* rec, V3 o, V3 d, float t
   n_hit = col(R, axis) * sgn;
   return true;
 }
+/* ... against an arm link: the convex hull of its collision mesh - what the link collides as (rp_kernels.cuh hull_item16) - by clipping the ray against the hull's face
+ * planes (collider frame, n . x + w <= 0 inside), after the box around the hull, which most rays miss.  The reference draws the links' visual meshes; rounds 3 and 4 drew the
+ * boxes.  A ray that starts inside reports no hit, like the box's. */
+__device__ __forceinline__ bool rc_ray_hull(const float* rec, const float4* __restrict__ pl, int npl, V3 o, V3 d, float tmax, float& t_hit, V3& n_hit) {
+  float tb; V3 nb;
+  if (!rc_ray_box(rec, o, d, tmax, tb, nb)) return false;
+  const M3 R = ldm3(rec);
+  const V3 ol = tmulv(R, o - ld3(rec + 9)), dl = tmulv(R, d);
+  float t_in = 0.f, t_out = tmax; V3 nl = mk3(0, 0, 0); bool entered = false;
+  for (int k = 0; k < npl; k++) {
+    const float4 p = pl[k];
+    const float den = p.x * dl.x + p.y * dl.y + p.z * dl.z, num = -(p.x * ol.x + p.y * ol.y + p.z * ol.z + p.w);
+    if (fabsf(den) < 1e-12f) { if (num < 0.f) return false; continue; }      /* parallel to the plane: outside it = a miss */
+    const float t = num / den;
+    if (den < 0.f) { if (t > t_in) { t_in = t; nl = mk3(p.x, p.y, p.z); entered = true; } }
+    else t_out = fminf(t_out, t);
+    if (t_in > t_out) return false;
+  }
+  if (!entered) return false;
+  t_hit = t_in;
+  n_hit = mulv(R, nl);
+  return true;
+}
 __device__ __forceinline__ bool rc_ray_sphere(const float* rec, V3 o, V3 d, float tmax, float& t_hit, V3& n_hit) {
   const V3 c = ld3(rec + 9), oc = o - c;
   const float r = rec[12], a = dot(d, d), b = 2.f * dot(oc, d), cc = dot(oc, oc) - r * r;
@@ -119,7 +165,7 @@ __device__ __forceinline__ bool rc_ray_sphere(const float* rec, V3 o, V3 d, floa
 }
 
 /* obs['img'] (environments.py:841-845): one thread per pixel, row 0 = top of the image, uint8 rgb */
-__global__ void __launch_bounds__(256) k_render(const float* __restrict__ tab, const int* __restrict__ cnt, int num, RpCamera cam, const float* __restrict__ ee_pose,
+__global__ void __launch_bounds__(256) k_render(const DevModel* __restrict__ m, const float* __restrict__ tab, const int* __restrict__ cnt, int num, RpCamera cam, const float* __restrict__ ee_pose,
                                                 int width, int height, unsigned char* __restrict__ rgb) {
   __shared__ float T[RC_MAX * RC_STRIDE];
   const int tiles = (width * height + 255) / 256;
@@ -148,7 +194,9 @@ __global__ void __launch_bounds__(256) k_render(const float* __restrict__ tab, c
     const float* rec = &T[c * RC_STRIDE];
     const int tw = __float_as_int(rec[18]);
     float t; V3 nn;
-    const bool hit = (tw & 0xFF) == 0 ? rc_ray_box(rec, eye, d, far, t, nn) : rc_ray_sphere(rec, eye, d, far, t, nn);
+    const int ci = __float_as_int(rec[19]) & 0xFF;
+    const bool hit = (tw & RC_HULL) ? rc_ray_hull(rec, (const float4*)m->hpl + m->hpl_off[ci], m->hpl_cnt[ci], eye, d, far, t, nn)
+                                    : ((tw & 0xFF) == 0 ? rc_ray_box(rec, eye, d, far, t, nn) : rc_ray_sphere(rec, eye, d, far, t, nn));
     if (!hit) continue;
     if (tw & RC_GHOST) { if (t < gbest) { gbest = t; gn = nn; gi = c; } }
     else if (t < best) { best = t; bn = nn; bi = c; }
@@ -169,7 +217,7 @@ __global__ void __launch_bounds__(256) k_render(const float* __restrict__ tab, c
 }
 
 /* rayTest (environments.py:738-741) for K rays per env: from / to [num][K][3]; fraction 1 and collider -1 on a miss */
-__global__ void __launch_bounds__(64) k_ray_test(const float* __restrict__ tab, const int* __restrict__ cnt, int num, int K, const float* __restrict__ from,
+__global__ void __launch_bounds__(64) k_ray_test(const DevModel* __restrict__ m, const float* __restrict__ tab, const int* __restrict__ cnt, int num, int K, const float* __restrict__ from,
                                                  const float* __restrict__ to, float* __restrict__ frac, int* __restrict__ collider, int* __restrict__ link,
                                                  float* __restrict__ hit_pos, float* __restrict__ hit_nrm) {
   __shared__ float T[RC_MAX * RC_STRIDE];
@@ -187,7 +235,9 @@ __global__ void __launch_bounds__(64) k_ray_test(const float* __restrict__ tab, 
       const int tw = __float_as_int(rec[18]);
       if (tw & RC_GHOST) continue;
       float t; V3 nn;
-      const bool hit = (tw & 0xFF) == 0 ? rc_ray_box(rec, o, d, 1.f, t, nn) : rc_ray_sphere(rec, o, d, 1.f, t, nn);
+      const int ci = __float_as_int(rec[19]) & 0xFF;
+      const bool hit = (tw & RC_HULL) ? rc_ray_hull(rec, (const float4*)m->hpl + m->hpl_off[ci], m->hpl_cnt[ci], o, d, 1.f, t, nn)
+                                      : ((tw & 0xFF) == 0 ? rc_ray_box(rec, o, d, 1.f, t, nn) : rc_ray_sphere(rec, o, d, 1.f, t, nn));
       if (hit && t < best) { best = t; bn = nn; bi = c; }            /* the lowest collider index wins ties, as in calc_state's ray */
     }
     const bool hit = bi >= 0 && best <= 1.f;

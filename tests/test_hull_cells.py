@@ -40,3 +40,34 @@ def test_committed_header_is_what_the_bake_writes(tmp_path):
     fresh = str(tmp_path / 'rp_hullcells_gen.h')
     subprocess.run([sys.executable, os.path.join(REPO, 'tools', 'bake_hull_cells.py'), '--out', fresh], check=True, capture_output=True)
     assert open(fresh).read() == open(header).read(), 'csrc/generated/rp_hullcells_gen.h is stale: run tools/bake_hull_cells.py'
+
+
+def test_committed_plane_header_is_what_the_bake_writes(tmp_path):
+    """csrc/generated/rp_hullplanes_gen.h (the hulls' face planes for the ray caster: rp_render / rp_ray_test draw an arm link as the hull it collides as) against a
+    fresh run of tools/bake_hull_planes.py; and every plane keeps every vertex of its hull on its inner side"""
+    import re
+    import numpy as np
+    header = os.path.join(REPO, 'roboticsplayroompybullet_amd', 'csrc', 'generated', 'rp_hullplanes_gen.h')
+    fresh = str(tmp_path / 'rp_hullplanes_gen.h')
+    subprocess.run([sys.executable, os.path.join(REPO, 'tools', 'bake_hull_planes.py'), '--out', fresh], check=True, capture_output=True)
+    assert open(fresh).read() == open(header).read(), 'csrc/generated/rp_hullplanes_gen.h is stale: run tools/bake_hull_planes.py'
+    sys.path.insert(0, os.path.join(REPO, 'tools'))
+    import bake_hull_cells as bc
+    table, ints = bc.parse(open(bc.SRC).read())
+    src = open(header).read()
+    for arm, kind in (('UR5', 'U'), ('PANDA', 'P')):
+        m = re.search(r'static const float rp_hplane_%s\[(\d+)\]\[4\] = \{(.*?)\};' % arm, src, re.S)
+        pl = np.array([[float(x.rstrip('f')) for x in v.split(',')] for v in re.findall(r'\{([^{}]*)\}', m.group(2))])
+        poff = [int(x) for x in re.search(r'rp_hplane_off_%s\[64\] = \{([^}]*)\}' % kind, src).group(1).split(',')]
+        pcnt = [int(x) for x in re.search(r'rp_hplane_cnt_%s\[64\] = \{([^}]*)\}' % kind, src).group(1).split(',')]
+        V, off, cnt = table('rp_hullv_%s' % arm), ints('rp_hull_off_%s' % kind), ints('rp_hull_cnt_%s' % kind)
+        for c in range(64):
+            if cnt[c] == 0:
+                assert pcnt[c] == 0
+                continue
+            P = V[off[c]:off[c] + cnt[c]].astype(np.float64)
+            q = pl[poff[c]:poff[c] + pcnt[c]]
+            assert pcnt[c] >= 4 and np.abs(np.linalg.norm(q[:, :3], axis=1) - 1).max() < 1e-5
+            side = P @ q[:, :3].T + q[:, 3]                      # [vertex, plane]
+            assert side.max() < 2e-6, (arm, c, side.max())       # inside or on every plane
+            assert (np.abs(side) < 2e-6).sum(axis=0).min() >= 3  # every plane passes through at least three vertices

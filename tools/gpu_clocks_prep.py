@@ -57,23 +57,20 @@ print('hull pairs scanned per env: mean %.2f p90 %d max %d; of them apart (two s
 g = a[:, 27] > 0
 if g.any():
     r = a[g, 26].astype(float)
-    print('GJK per round: scan + reduce p50 %d, support + tests + simplex store p50 %d, closest point p50 %d cycles' % (np.median(a[g, 29] / r), np.median(a[g, 30] / r), np.median(a[g, 31] / r)))
+    pass
     print('GJK: waves with a call %d of %d; calls per such wave p50 %d max %d; rounds per call p50 %.1f max %.1f; cycles per call p50 %d max %d' % (
         g.sum(), n, np.median(a[g, 27]), a[g, 27].max(), np.median(a[g, 26] / a[g, 27]), (a[g, 26] / a[g, 27]).max(), np.median(a[g, 28] / a[g, 27]), (a[g, 28] / a[g, 27]).max()))
 
-hc = a[:, 19]
-own, oth = hc & 0xffff, (hc >> 16) & 0xffff
-arr = a[:, 20] - a[:, 0]
-print('hull classes per env: taken by the narrowphase\'s wave %.2f, by the other wave %.2f (envs with any: %d); the other wave arrives p50 %d cycles after the start, the narrowphase starts p50 %d and ends p50 %d' % (
-    own.mean(), oth.mean(), int((hc > 0).sum()), np.median(arr[a[:, 20] > 0]), np.median(a[:, 8] - a[:, 0]), np.median(a[:, 9] - a[:, 0])))
-if os.environ.get('HPROF'):      # build with -DRP_HPROF: slots 29-31 re-used
-    sel = hc > 0
-    print('envs with hull pairs: the narrowphase\'s hull section p50 %d cycles (mean %d), of that inside hull_item (first wave) p50 %d (mean %d), waiting for the other wave p50 %d (mean %d); classes per such env %.2f + %.2f' % (
-        np.median(a[sel, 30]), a[sel, 30].mean(), np.median(a[sel, 29]), a[sel, 29].mean(), np.median(a[sel, 31]), a[sel, 31].mean(), own[sel].mean(), oth[sel].mean()))
+hull = a[:, 19] - a[:, 8]
+batches = a[:, 9] - a[:, 19]
+print('narrowphase = hull phase (decisions, classes, hull_item16: four pairs at a time) p50 %d p90 %d max %d + the eight-lanes-per-pair batches p50 %d p90 %d max %d cycles' % (
+    np.median(hull), np.percentile(hull, 90), hull.max(), np.median(batches), np.percentile(batches, 90), batches.max()))
+print('hull_item16, row 0\'s items, cycles per env with any: set-up + 15-axis test p50 %d p90 %d max %d | face scan p50 %d p90 %d max %d | GJK p50 %d p90 %d max %d' % (
+    tuple(np.percentile(a[hp > 0, 29], [50, 90, 100])) + tuple(np.percentile(a[hp > 0, 30], [50, 90, 100])) + tuple(np.percentile(a[hp > 0, 31], [50, 90, 100]))))
 # the launch lasts as long as its slowest blocks: what are they made of?
 order = np.argsort(-tot)[:12]
-print('the 12 slowest blocks: total | load+FK+AABB, broadphase, narrowphase, manifolds, wait for the other wave, rows after the join [k cycles] | active pairs')
+print('the 12 slowest blocks: total | load+FK+AABB, broadphase, hull phase, batches, manifolds, wait for the other wave, rows after the join [k cycles] | active pairs, hull pairs scanned, GJK calls, GJK rounds | row 0: set-up, face scan, GJK [k cycles]')
 for i in order:
     join = max(a[i, 2], a[i, 3])
-    print('  %6.1f | %5.1f %5.1f %6.1f %5.1f %5.1f %5.1f | %d' % (tot[i] / 1e3, (a[i, 1] - a[i, 0]) / 1e3, (a[i, 8] - a[i, 1]) / 1e3, (a[i, 9] - a[i, 8]) / 1e3, (a[i, 2] - a[i, 9]) / 1e3,
-                                                               (join - a[i, 2]) / 1e3, (a[i, 4] - join) / 1e3, a[i, 12]))
+    print('  %6.1f | %5.1f %5.1f %6.1f %6.1f %5.1f %5.1f %5.1f | %d %d %d %d' % (tot[i] / 1e3, (a[i, 1] - a[i, 0]) / 1e3, (a[i, 8] - a[i, 1]) / 1e3, (a[i, 19] - a[i, 8]) / 1e3, (a[i, 9] - a[i, 19]) / 1e3,
+                                                                          (a[i, 2] - a[i, 9]) / 1e3, (join - a[i, 2]) / 1e3, (a[i, 4] - join) / 1e3, a[i, 12], hp[i], a[i, 27], a[i, 26]) + ' | %.1f %.1f %.1f' % (a[i, 29] / 1e3, a[i, 30] / 1e3, a[i, 31] / 1e3))
