@@ -92,9 +92,14 @@ enum rp_config_flags {
                                    * position motor is commanded past its limit (every "open" action, environments.py:1037-1073) chatters at the limit: 1.1 mm for a
                                    * Robotiq pad = 0.026 in obs_quat's gripper entry.  The flag trades that sawtooth for 1e-2 of free-motion divergence from the
                                    * reference step: an A / B switch for learners that see the gripper observation */
-  RP_CFG_OBB_EDGES = 512          /* (no field) round 3's contacts for that case: the link's OBB against the box (SAT + face clipping) instead of GJK on the hull -
+  RP_CFG_OBB_EDGES = 512,         /* (no field) round 3's contacts for that case: the link's OBB against the box (SAT + face clipping) instead of GJK on the hull -
                                    * a few per cent faster, further from Bullet (the headline id's block position: 8 cm instead of 2 mm median divergence from the
                                    * reference step over 200 steps) */
+  RP_CFG_HULL_EPA = 2048,         /* (no field) where GJK finds the CORES of a link's hull and a box overlapping, depth, normal and witness come from the expanding polytope
+                                   * on the two cores (Bullet's btGjkEpaSolver2; oracle RPO_RULE_EPA) instead of the OBB path.  The DEFAULT of the Panda ids (pandaPick: the
+                                   * worst arm divergence from the reference step over 200 steps 1.2e-3 -> 5.6e-5 rad), not of the UR5 ids (nothing moves in their table rows;
+                                   * 4 % of the headline, 19 % under the literal random-action rollout): this flag turns it on for those too ... */
+  RP_CFG_NO_HULL_EPA = 4096       /* ... and this one off for the Panda ids.  Both set: RP_ERR_ARG.  Ignored under RP_CFG_OBB_EDGES (no GJK, no polytope). */
 };
 
 typedef struct rp_config {

@@ -53,6 +53,8 @@
                                      * and every point of a rotation-locked body - on the shipped model's own contact cache */
 #define RPO_RULE_CREATION_ORDER 65536      /* EXPERIMENT (tools/fidelity_r05.py row `A +creation-order`; no HIP counterpart): contacts are solved in the manifolds' creation order - Bullet's - instead
                                             * of the four-tier partition the HIP library's two-stream solver needs (solver_order) */
+#define RPO_RULE_EPA 131072         /* ... and where GJK finds the CORES overlapping (its simplex a tetrahedron around the origin): the expanding-polytope algorithm on the two cores - exact for polytopes -
+                                     * gives depth, normal and witness points; the margins add 2 x 0.001 along the same normal (hull_box_epa).  Without the bit: the OBB path, as in round 4 */
 #define RPO_RULE_GJK 1024           /* ... and where the deepest vertex lies BESIDE the face (box edges and corners): GJK's distance phase on hull and box (hull_box_gjk) */
 #define RPO_RULE_HULLFACE 4         /* arm links touch static boxes with the vertices of their collision meshes' convex hulls (hull_face) instead of their OBBs */
 #define HULL_MARGIN ((real)RP_HULL_MARGIN)
@@ -633,6 +635,119 @@ static int obb_apart(const rpo_env* e, int hc, int bc, real margin) {
   }
   return 0;
 }
+/* ------------------------------------------------------------------ RPO_RULE_EPA: penetration of an arm link's hull core into a box core (btGjkEpaSolver2's expanding polytope, restated
+ * for two POLYTOPES: the Minkowski difference W = hull - box core is one, so the loop ends exactly when the closest face of the growing polytope is a face of W).  Starts from
+ * the tetrahedron GJK ended with; per round: the face nearest the origin (lowest number among equals), the support point of W along its normal, done if that does not lie
+ * beyond the face (1e-9) - else the faces that see the new point go, the horizon's edges get faces to it (dead slots first, in rising order).  Caps shared with the HIP
+ * library: EPA_MAXV vertices, EPA_MAXF faces, EPA_ITERS rounds (a cap reached = the current nearest face is the answer).  Face normals and distances are recomputed from the
+ * vertices whenever they are needed (the library keeps three vertex numbers per face and nothing else).  Box frame, double arithmetic like GJK's simplex. */
+#define EPA_MAXV 12
+#define EPA_MAXF 20
+#define EPA_MAXE 24               /* horizon edges while the visible faces are walked (a pair of opposite edges cancels) */
+#define EPA_ITERS 8
+typedef struct { const float (*hv)[4]; int nvert; real u[3][3], c[3], hb[3]; } hull_ctx;
+static void epa_support(const hull_ctx* h, const greal* d, gjk_sv* sv) {      /* the point of W farthest along d: hull vertex (the fp32 scan of hull_box_gjk: lowest number among equals) - box-core corner */
+  real dl[3];
+  for (int j = 0; j < 3; j++) dl[j] = (real)d[0] * h->u[0][j] + (real)d[1] * h->u[1][j] + (real)d[2] * h->u[2][j];
+  int bi = 0; real bd = (real)-1e30;
+  for (int i = 0; i < h->nvert; i++) {
+    const real q = R_DOT3_FMA(dl[0], dl[1], dl[2], (real)h->hv[i][0], (real)h->hv[i][1], (real)h->hv[i][2]);
+    if (q > bd) { bd = q; bi = i; }
+  }
+  sv->vi = bi; sv->code = 0;
+  for (int k = 0; k < 3; k++) {
+    const real qk[3] = {(real)h->hv[bi][0], (real)h->hv[bi][1], (real)h->hv[bi][2]};
+    sv->a[k] = R_DOT3_FMA(h->u[k][0], h->u[k][1], h->u[k][2], qk[0], qk[1], qk[2]) - h->c[k];
+    const int plus = -(real)d[k] >= 0;
+    sv->code |= plus << k; sv->b[k] = plus ? h->hb[k] : -h->hb[k];
+  }
+  g3sub(sv->w, sv->a, sv->b);
+}
+static int epa_face(const gjk_sv* V, int* f, greal* n, greal* dist) {      /* unit normal pointing away from the origin and the plane's distance; may swap f[1], f[2]; 0 = no area */
+  greal ab[3], ac[3];
+  g3sub(ab, V[f[1]].w, V[f[0]].w); g3sub(ac, V[f[2]].w, V[f[0]].w); g3cross(n, ab, ac);
+  const greal l2 = g3dot(n, n);
+  if (!(l2 > 1e-36)) return 0;
+  const greal inv = 1 / sqrt(l2);
+  for (int k = 0; k < 3; k++) n[k] *= inv;
+  *dist = g3dot(n, V[f[0]].w);
+  if (*dist < 0) { const int t = f[1]; f[1] = f[2]; f[2] = t; for (int k = 0; k < 3; k++) n[k] = -n[k]; *dist = -*dist; }
+  return 1;
+}
+static _Thread_local long g_epa_stats[4];      /* calls, rounds, converged, gave up */
+void rpo_epa_stats(long* out, int reset) { for (int i = 0; i < 4; i++) { out[i] = g_epa_stats[i]; if (reset) g_epa_stats[i] = 0; } }
+static int hull_box_epa(const hull_ctx* h, const gjk_sv* s4, greal* nrm, greal* depth, greal* wit_b) {
+  gjk_sv V[EPA_MAXV]; int nv = 4;
+  int F[EPA_MAXF][3], alive[EPA_MAXF], nf = 4;
+  static const int T[4][3] = {{0, 1, 2}, {0, 2, 3}, {0, 3, 1}, {1, 3, 2}};
+  for (int i = 0; i < 4; i++) { V[i] = s4[i]; alive[i] = 1; for (int k = 0; k < 3; k++) F[i][k] = T[i][k]; }
+  g_epa_stats[0]++;
+  for (int i = 0; i < 4; i++) { greal n[3], d; if (!epa_face(V, F[i], n, &d)) { g_epa_stats[3]++; return 0; } }
+  for (int it = 0; it < EPA_ITERS; it++) {
+    g_epa_stats[1]++;
+    int bf = -1; greal bd = 1e300, bn[3] = {0, 0, 0};
+    for (int i = 0; i < nf; i++) {
+      if (!alive[i]) continue;
+      greal n[3], d;
+      if (!epa_face(V, F[i], n, &d)) { g_epa_stats[3]++; return 0; }
+      if (d < bd) { bd = d; bf = i; for (int k = 0; k < 3; k++) bn[k] = n[k]; }
+    }
+    if (bf < 0) { g_epa_stats[3]++; return 0; }
+    gjk_sv sv;
+    epa_support(h, bn, &sv);
+    const greal ext = g3dot(sv.w, bn);
+    int nalive = 0;
+    for (int i = 0; i < nf; i++) nalive += alive[i];
+    int done = ext - bd < 1e-9 || nv >= EPA_MAXV || it == EPA_ITERS - 1;
+    int E[EPA_MAXE][2], ne = 0, kill[EPA_MAXF];
+    if (!done) {
+      int nkill = 0;
+      for (int i = 0; i < nf; i++) {
+        kill[i] = 0;
+        if (!alive[i]) continue;
+        greal n[3], d, t[3];
+        epa_face(V, F[i], n, &d);
+        g3sub(t, sv.w, V[F[i][0]].w);
+        if (!(g3dot(n, t) > 1e-12)) continue;
+        kill[i] = 1; nkill++;
+        for (int e2 = 0; e2 < 3; e2++) {
+          const int x = F[i][e2], y = F[i][(e2 + 1) % 3];
+          int found = -1;
+          for (int k = 0; k < ne; k++) if (E[k][0] == y && E[k][1] == x) found = k;
+          if (found >= 0) { E[found][0] = E[ne - 1][0]; E[found][1] = E[ne - 1][1]; ne--; }
+          else { if (ne >= EPA_MAXE) { g_epa_stats[3]++; return 0; } E[ne][0] = x; E[ne][1] = y; ne++; }
+        }
+      }
+      if (ne == 0) { g_epa_stats[3]++; return 0; }
+      if (nalive - nkill + ne > EPA_MAXF) done = 1;          /* no room for the new faces: the nearest face as it is */
+    }
+    if (done) {
+      /* the origin's projection on the nearest face in barycentric coordinates: the witness on the box core */
+      const gjk_sv *a = &V[F[bf][0]], *b = &V[F[bf][1]], *c = &V[F[bf][2]];
+      greal p[3], v0[3], v1[3], v2[3];
+      for (int k = 0; k < 3; k++) p[k] = bn[k] * bd;
+      g3sub(v0, b->w, a->w); g3sub(v1, c->w, a->w); g3sub(v2, p, a->w);
+      const greal d00 = g3dot(v0, v0), d01 = g3dot(v0, v1), d11 = g3dot(v1, v1), d20 = g3dot(v2, v0), d21 = g3dot(v2, v1);
+      const greal den = d00 * d11 - d01 * d01;
+      const greal bv = den != 0 ? (d11 * d20 - d01 * d21) / den : 0, bw = den != 0 ? (d00 * d21 - d01 * d20) / den : 0, bu = 1 - bv - bw;
+      for (int k = 0; k < 3; k++) { wit_b[k] = bu * a->b[k] + bv * b->b[k] + bw * c->b[k]; nrm[k] = bn[k]; }
+      *depth = bd;
+      g_epa_stats[2]++;
+      return 1;
+    }
+    for (int i = 0; i < nf; i++) if (kill[i]) alive[i] = 0;
+    V[nv] = sv;
+    for (int k = 0; k < ne; k++) {
+      int slot = -1;
+      for (int i = 0; i < nf; i++) if (!alive[i]) { slot = i; break; }
+      if (slot < 0) slot = nf++;
+      F[slot][0] = E[k][0]; F[slot][1] = E[k][1]; F[slot][2] = nv; alive[slot] = 1;
+    }
+    nv++;
+  }
+  g_epa_stats[3]++;
+  return 0;
+}
 static _Thread_local long g_gjk_stats[8];      /* calls, rounds, seeds with two points, results 1 / 0 / -1, tetrahedra solved.  Per THREAD: rpo_bench_rollout steps envs on many
                                                 * threads (one shared line of counters would be a data race and a contended cache line inside the timed baseline); rpo_gjk_stats reads the calling thread's */
 void rpo_gjk_stats(long* out, int reset) { for (int i = 0; i < 8; i++) { out[i] = g_gjk_stats[i]; if (reset) g_gjk_stats[i] = 0; } }
@@ -746,7 +861,25 @@ static int hull_box_gjk(rpo_env* e, int hc, int bc, real margin, const real* lv,
     s[n++] = sv;
     if (n == 4) g_gjk_stats[6]++;
     gjk_closest(s, &n, lam);
-    if (n == 4) { g_gjk_stats[5]++; GAX_CLEAR(); return -1; }
+    if (n == 4) {
+      g_gjk_stats[5]++; GAX_CLEAR();
+      if (e->rule & RPO_RULE_EPA) {                        /* the cores overlap: depth, normal and witness by the expanding polytope on the cores; the two margins add along the normal */
+        hull_ctx hx; hx.hv = hv; hx.nvert = nvert;
+        for (int k = 0; k < 3; k++) { hx.c[k] = c[k]; hx.hb[k] = hb[k]; for (int j = 0; j < 3; j++) hx.u[k][j] = u[k][j]; }
+        greal en[3], edepth, ewb[3];
+        if (hull_box_epa(&hx, s, en, &edepth, ewb)) {
+          real nl[3] = {(real)-en[0], (real)-en[1], (real)-en[2]}, pl[3] = {(real)ewb[0], (real)ewb[1], (real)ewb[2]};      /* from the box toward the hull */
+          const real d = -(real)edepth - 2 * HULL_MARGIN;
+          v3axpy(pl, HULL_MARGIN, nl);
+          real nB[3], pB[3];
+          m3mulv(nB, xb->R, nl); m3mulv(pB, xb->R, pl); v3add(pB, pB, xb->p);
+          v3cpy(out->n, nB); out->dist = d;
+          v3cpy(out->p, pB); v3axpy(out->p, (real)0.5 * d, nB);
+          return 1;
+        }
+      }
+      return -1;
+    }
     greal q[3] = {0, 0, 0};
     for (int i = 0; i < n; i++) for (int k = 0; k < 3; k++) q[k] += lam[i] * s[i].w[k];
     const greal nd = g3dot(q, q);
@@ -2484,7 +2617,13 @@ rpo_env* rpo_create(int kind, unsigned long long seed, int env_index) {
   e->nv = m->n_arm + 6 * m->n_free + m->n_joint1;
   e->nbody = 1 + m->n_arm + m->n_free + m->n_joint1;
   e->seed = seed; e->env_index = (uint32_t)env_index;
-  e->rule = RPO_RULE_ORDER | RPO_RULE_LIMIT | RPO_RULE_HULLFACE | RPO_RULE_BOXOVERLAP | RPO_RULE_ODEORDER | RPO_RULE_LEVER | RPO_RULE_SPIN | RPO_RULE_PERSIST | RPO_RULE_HULLMOV | RPO_RULE_GJK;       /* = 2039: the shipped model (the HIP kernels implement exactly this; without RPO_RULE_GJK = the library's RP_CFG_OBB_EDGES, round 3's default); rpo_set_rule(0) = round 2's rule */
+  e->rule = RPO_RULE_ORDER | RPO_RULE_LIMIT | RPO_RULE_HULLFACE | RPO_RULE_BOXOVERLAP | RPO_RULE_ODEORDER | RPO_RULE_LEVER | RPO_RULE_SPIN | RPO_RULE_PERSIST | RPO_RULE_HULLMOV | RPO_RULE_GJK |
+            (kind >= RP_KIND_P ? RPO_RULE_EPA : 0);
+  /* = 2039 for the UR5 kinds (U, R) and 133111 = 2039 | RPO_RULE_EPA for the Panda kinds (P, Q, V, W): the shipped model, the HIP kernels implement exactly this.  The expanding
+   * polytope is in the Panda ids' default because that is where it moves the fidelity table (profiles/r05_model_divergence.md: pandaPick 11 -> 12 of 12 envs, worst arm gap
+   * 1.2e-3 -> 5.6e-5; the Panda playroom 8 -> 10 of 12) and not in the UR5 ids' because there it moves nothing (7 of 12 either way) and costs 4 % of the headline (19 % under the
+   * literal random-action rollout); RP_CFG_HULL_EPA / RP_CFG_NO_HULL_EPA (rpo_set_rule) force it either way.  Without RPO_RULE_GJK and RPO_RULE_EPA = the library's
+   * RP_CFG_OBB_EDGES, round 3's default; rpo_set_rule(0) = round 2's rule */
   e->margin = -1; e->rew_thresh = (real)0.05; e->dense_reward = 0;
   /* envList.py:8-10, 18-22, 73-99: the env's flags and ranges go with its scene (play ids: complex_scene; reach ids:
    * default_scene; pick / push: push_scene); other ids on the same model override the ranges (rpo_set_ranges) */

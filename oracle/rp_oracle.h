@@ -99,7 +99,8 @@ int rpo_cache_size(const rpo_env* e, int* points);     /* RPO_RULE_PERSIST: cach
 int rpo_cache_row_words(void);
 int rpo_get_cache_row(const rpo_env* e, float* row);
 int rpo_set_cache_row(rpo_env* e, const float* row);
-void rpo_gjk_stats(long* out8, int reset);       /* GJK counters of the calling thread: calls, rounds, two-point seeds, results 1 / 0 / -1, tetrahedra, rounds of the "apart" exits */
+void rpo_gjk_stats(long* out8, int reset);
+void rpo_epa_stats(long* out4, int reset);       /* RPO_RULE_EPA counters of the calling thread: calls, rounds, converged, gave up */       /* GJK counters of the calling thread: calls, rounds, two-point seeds, results 1 / 0 / -1, tetrahedra, rounds of the "apart" exits */
 void rpo_shift_free_body(rpo_env* e, int k, double dx, double dy, double dz);      /* test hook: moves a free body, keeps the contact cache */
 int rpo_last_num_rows(const rpo_env*);
 int rpo_arm_table(const rpo_env* e, double* out);                      /* [n_arm][6]: jtype, lower, upper, body mass, Bullet joint index, parent dof */

@@ -43,7 +43,7 @@ class RpConfig(C.Structure):
 
 
 # rp_config_flags / rp_action_type (include/rp_playroom.h)
-CFG_GOAL_RANGE, CFG_OBJ_RANGE, CFG_ENV_RANGE, CFG_REW_THRESH, CFG_DENSE_REWARD, CFG_ACTION_TYPE, CFG_CONTACT_MARGIN, CFG_STATELESS_CONTACTS, CFG_HULL_GJK, CFG_OBB_EDGES, CFG_SPECULATIVE_LIMITS = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024
+CFG_GOAL_RANGE, CFG_OBJ_RANGE, CFG_ENV_RANGE, CFG_REW_THRESH, CFG_DENSE_REWARD, CFG_ACTION_TYPE, CFG_CONTACT_MARGIN, CFG_STATELESS_CONTACTS, CFG_HULL_GJK, CFG_OBB_EDGES, CFG_SPECULATIVE_LIMITS, CFG_HULL_EPA, CFG_NO_HULL_EPA = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096
 ACTION_TYPE_CODES = {'absolute_rpy': 0, 'relative_rpy': 1, 'absolute_quat': 2, 'relative_quat': 3, 'absolute_joints': 4, 'relative_joints': 5}
 
 

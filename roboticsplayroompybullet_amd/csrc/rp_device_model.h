@@ -103,6 +103,7 @@ typedef struct DevModel {
    * body's frame), per collider the first vertex and the count (0 = no hull).  rp_create uploads the table and sets the pointer. */
   int spec_limits;                /* RP_CFG_SPECULATIVE_LIMITS: round 2's joint-limit rows (oracle rule without RPO_RULE_LIMIT) */
   int gjk;                        /* GJK's distance phase where a hull's deepest vertex lies beside the box face (collide(); oracle RPO_RULE_GJK) */
+  int epa;                        /* ... and the expanding polytope where it finds the cores overlapping (hull_epa16; oracle RPO_RULE_EPA) */
   int persist;                    /* unless RP_CFG_STATELESS_CONTACTS: collide() keeps its manifolds in pmcache (rp_kernels.cuh PMC_*) */
   float* pmcache;                 /* [N][PMC_FLOATS], device memory owned by the handle */
   const float* hullv;

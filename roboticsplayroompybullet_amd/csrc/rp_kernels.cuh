@@ -687,13 +687,6 @@ __device__ __forceinline__ void gjk_closest(GjkSimplex& S, int lane) {
   WSYNC();
 }
 
-/* One hull pair by the SIXTEEN LANES OF A DPP ROW, the four rows of a wave on four pairs at once (round 5; until then a whole wave did one pair after the other: since the
- * support-vertex tables a query looks at a handful of vertices, and under the literal random-action rollout an arm lying on the furniture has ten such pairs per substep).
- * Everything below is the same in the sixteen lanes of a row except the candidates a lane scans; nothing in it is wave-uniform - no readfirstlane, no ballot, the cross-lane
- * steps are row DPP - and the rows diverge freely (a row whose pair needs no GJK idles while another iterates).  gi = the row's active pair of the substep, -1: none; the
- * pair is described in L.hinfo[gi] by narrowphase_coop's first phase (hull collider | box collider << 8 | hull is collider b << 16, margin, baked pair index); the outcome
- * goes to L.hout[gi] (1: hull contact, staged in L.hpt[gi]; 0: apart; -1: the OBB path).  The GJK simplex of a row lives in its 64 floats of the narrowphase scratch
- * (free until the batches start). */
 template <int K>
 __device__ __forceinline__ int bcast16i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x150 + (K & 15), 0xF, 0xF, true); }
 __device__ __forceinline__ float row_max_f(float v) {      /* max over the 16 lanes of a DPP row, in every lane */
@@ -710,6 +703,206 @@ __device__ __forceinline__ int row_min_i(int v) {
   v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true));
   return v;
 }
+__device__ __forceinline__ int row_max_i(int v) {
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true));
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true));
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true));
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true));
+  return v;
+}
+__device__ __forceinline__ unsigned row_or_u(unsigned v) {
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);
+  return v;
+}
+#define RP_DPP_D(v, ctrl) __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, 0xF, 0xF, true), __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, 0xF, 0xF, true))
+__device__ __forceinline__ double row_min_d(double v) {      /* (no NaNs here) */
+  v = fmin(v, RP_DPP_D(v, 0xB1));
+  v = fmin(v, RP_DPP_D(v, 0x4E));
+  v = fmin(v, RP_DPP_D(v, 0x141));
+  v = fmin(v, RP_DPP_D(v, 0x140));
+  return v;
+}
+/* ---- penetration of a hull core into a box core: the expanding polytope (oracle hull_box_epa, RPO_RULE_EPA; btGjkEpaSolver2 restated for two polytopes).  GJK's distance
+ * phase ended with a tetrahedron around the origin - the cores overlap; until round 5 that pair went to the OBB path.  The Minkowski difference of two polytopes is one, so
+ * the loop ends exactly: per round the face nearest the origin (lowest number among equals), the support point of hull - box along its normal (the same cell scan as
+ * GJK's), done if that is not beyond the face (1e-9) - else the faces that see it go and the horizon's edges get faces to it (dead slots first, rising).
+ * The sixteen lanes of the row share the polytope: its vertices (difference points in double, box-core corner codes) lie in the row's scratch; FACE f LIVES IN LANE f & 15
+ * (faces 16 - 19: a second set of registers in lanes 0 - 3) as its vertex word, unit normal and distance, computed ONCE when the face is made - a face never changes, and
+ * the oracle's re-evaluations return the same bits (its cross and dot products are unfused, so the turned normal of a swapped word is the exact negative).  Per round: a
+ * row minimum over the lanes' distances, the support scan, every lane's visibility test, the horizon's edge list (entry k in lane k & 15, the oracle's order of
+ * insertions and swap-removals kept: it fixes which slot a new face gets, and the lowest-number rule reads slots) and the new faces' planes in parallel.  The first
+ * version (every lane recomputing every face's plane from scratch twice a round, the edge list in LDS) cost 100 - 300 k cycles a call: the literal random-action
+ * rollout, whose arms lie IN the furniture, lost 40 %.  Caps shared with the oracle. */
+#define EPA_MAXV 12
+#define EPA_MAXF 20
+#define EPA_MAXE 24
+#define EPA_ITERS 8
+#define HROW_FLOATS 192      /* a row's scratch in L.npscr: [0, 64) GJK (hull_item16), [64, 136) the polytope's vertices, [136, 148) their corner codes */
+struct EpaFace { D3 n; double d; int word; bool ok; };
+__device__ __forceinline__ EpaFace epa_face(const double* Vw, int f) {      /* unit normal away from the origin, distance, the word with its last two vertices swapped if the normal had to turn */
+  const int ia = f & 31, ib = (f >> 5) & 31, ic = (f >> 10) & 31;
+  const D3 a = mkd(Vw[3 * ia], Vw[3 * ia + 1], Vw[3 * ia + 2]), b = mkd(Vw[3 * ib], Vw[3 * ib + 1], Vw[3 * ib + 2]), c = mkd(Vw[3 * ic], Vw[3 * ic + 1], Vw[3 * ic + 2]);
+  D3 n = dcross(b - a, c - a);
+  const double l2 = ddot(n, n);
+  EpaFace r; r.ok = l2 > 1e-36; r.word = f;
+  const double inv = drcp(sqrt(r.ok ? l2 : 1.0));
+  n = mkd(n.x * inv, n.y * inv, n.z * inv);
+  double d = ddot(n, a);
+  if (d < 0.0) { r.word = ia | (ic << 5) | (ib << 10); n = mkd(-n.x, -n.y, -n.z); d = -d; }
+  r.n = n; r.d = d;
+  return r;
+}
+template <class LDS>
+__device__ __forceinline__ bool hull_epa16(LDS& L, const int lane, const GjkSimplex& S, const float4* __restrict__ cv, const int* __restrict__ co, D3& nrm, double& depth, D3& witb) {      /* (the box axes in the hull's frame, the centre and the core's half extents wait in the row's GJK scratch: fetched around each support query) */
+  const int l16 = lane & 15, row = lane >> 4, rbase = lane & 48;
+  double* Vw = (double*)&L.npscr[HROW_FLOATS * row + 64];
+  int* Vm = (int*)&L.npscr[HROW_FLOATS * row + 136];
+  const float* Y = &L.npscr[HROW_FLOATS * row + 2 * 18];
+  static_assert(64 + 6 * EPA_MAXV == 136 && 136 + EPA_MAXV <= HROW_FLOATS && EPA_MAXF <= 32 && EPA_MAXE <= 32, "the row's scratch; two faces and two edges a lane");
+  for (int i = 0; i < 4; i++) { const D3 p = S.pt(i); Vw[3 * i] = p.x; Vw[3 * i + 1] = p.y; Vw[3 * i + 2] = p.z; }
+  Vm[0] = S.b0; Vm[1] = S.b1; Vm[2] = S.b2; Vm[3] = S.b3;
+  WSYNC();
+  int fw[2] = {0, 0}; D3 fn[2] = {mkd(0, 0, 0), mkd(0, 0, 0)}; double fd[2] = {1e300, 1e300}; int E[2] = {0, 0};
+  int nv = 4, nf = 4; unsigned alive = 0xFu;
+  {
+    const int w4 = l16 == 1 ? (0 | (2 << 5) | (3 << 10)) : l16 == 2 ? (0 | (3 << 5) | (1 << 10)) : l16 == 3 ? (1 | (3 << 5) | (2 << 10)) : (0 | (1 << 5) | (2 << 10));
+    const EpaFace r = epa_face(Vw, w4);
+    fw[0] = r.word; fn[0] = r.n; fd[0] = r.d;
+    if (row_or_u(l16 < 4 && !r.ok ? 1u : 0u) != 0u) return false;
+  }
+#pragma unroll 1
+  for (int it = 0; it < EPA_ITERS; it++) {
+    /* the face nearest the origin */
+    const bool a0 = (alive >> l16) & 1u, a1 = (alive >> (l16 + 16)) & 1u;
+    const double c0 = a0 ? fd[0] : 1e300, c1 = a1 ? fd[1] : 1e300;
+    const double bd = row_min_d(fmin(c0, c1));
+    const int bf = row_min_i(a0 && c0 == bd ? l16 : (a1 && c1 == bd ? l16 + 16 : 99));
+    if (bf >= 99) return false;
+    const int bsrc = rbase | (bf & 15);
+    const bool bhi = bf >= 16;
+    const D3 bn = mkd(__shfl(bhi ? fn[1].x : fn[0].x, bsrc), __shfl(bhi ? fn[1].y : fn[0].y, bsrc), __shfl(bhi ? fn[1].z : fn[0].z, bsrc));
+    /* the point of hull - box core farthest along bn: the hull's vertex by the scan of the direction's cell (lowest number among equals), the corner by signs */
+    const V3 bnf = mk3((float)bn.x, (float)bn.y, (float)bn.z);
+    V3 wa; int wb; V3 hbc;
+    {
+      const V3 u0 = ld3(Y), u1 = ld3(Y + 3), u2 = ld3(Y + 6);
+      const float c0 = Y[9], c1 = Y[10], c2 = Y[11];
+      hbc = ld3(Y + 12);
+      const V3 dl = u0 * bnf.x + u1 * bnf.y + u2 * bnf.z;
+      float sd = -1e30f; int bi = 0x7fffffff; V3 bq = mk3(0, 0, 0);
+      const int cell = hcell_of(dl);
+      const int o0 = co[cell], o1 = co[cell + 1];
+      for (int base = o0 + l16; __any(base - l16 < o1); base += 16) {
+        const float4 q = cv[base < o1 ? base : o0];
+        const float dq = __fmaf_rn(dl.z, q.z, __fmaf_rn(dl.y, q.y, dl.x * q.x));
+        if (base < o1 && dq > sd) { sd = dq; bi = __float_as_int(q.w); bq = mk3(q.x, q.y, q.z); }
+      }
+      const float top = row_max_f(sd);
+      const int key = row_min_i(sd == top ? ((bi << 4) | l16) : 0x7fffffff);
+      const int win = rbase | (key & 15);
+      const V3 q = mk3(__shfl(bq.x, win), __shfl(bq.y, win), __shfl(bq.z, win));
+      wa = mk3(hull_coord(u0, make_float4(q.x, q.y, q.z, 0.f), c0), hull_coord(u1, make_float4(q.x, q.y, q.z, 0.f), c1), hull_coord(u2, make_float4(q.x, q.y, q.z, 0.f), c2));
+      wb = (-bnf.x >= 0.f ? 1 : 0) | (-bnf.y >= 0.f ? 2 : 0) | (-bnf.z >= 0.f ? 4 : 0);
+    }
+    const V3 cb = GjkSimplex::corner(wb, hbc);
+    const D3 w = mkd((double)wa.x - (double)cb.x, (double)wa.y - (double)cb.y, (double)wa.z - (double)cb.z);
+    const double ext = ddot(w, bn);
+    bool done = ext - bd < 1e-9 || nv >= EPA_MAXV || it == EPA_ITERS - 1;
+    int ne = 0; unsigned kill = 0u;
+    if (!done) {
+      /* every lane: does its face see w */
+      {
+        const int i0 = fw[0] & 31, i1 = fw[1] & 31;
+        const bool v0 = a0 && ddot(fn[0], w - mkd(Vw[3 * i0], Vw[3 * i0 + 1], Vw[3 * i0 + 2])) > 1e-12;
+        bool v1 = false;
+        if ((alive >> 16) != 0u) v1 = a1 && ddot(fn[1], w - mkd(Vw[3 * i1], Vw[3 * i1 + 1], Vw[3 * i1 + 2])) > 1e-12;
+        kill = row_or_u((v0 ? 1u << l16 : 0u) | (v1 ? 1u << (l16 + 16) : 0u));
+      }
+      /* the horizon: the edges of the faces that go, face after face (rising), an edge whose reverse is in the list cancels it (the list's last entry takes the place) */
+      bool over = false;
+      unsigned rest = kill;
+#pragma unroll 1
+      while (rest != 0u) {
+        const int i = __ffs(rest) - 1; rest &= rest - 1u;
+        const int f = __shfl(i >= 16 ? fw[1] : fw[0], rbase | (i & 15));
+#pragma unroll 1
+        for (int e2 = 0; e2 < 3; e2++) {
+          const int x = (f >> (5 * e2)) & 31, y = (f >> (e2 == 2 ? 0 : 5 * e2 + 5)) & 31;
+          const int rev = y | (x << 8);
+          const int found = row_max_i(l16 + 16 < ne && E[1] == rev ? l16 + 16 : (l16 < ne && E[0] == rev ? l16 : -1));
+          if (found >= 0) {
+            const int last = ne - 1;
+            const int lv = __shfl(last >= 16 ? E[1] : E[0], rbase | (last & 15));
+            if (found == l16) E[0] = lv;
+            if (found == l16 + 16) E[1] = lv;
+            ne--;
+          } else if (ne >= EPA_MAXE) over = true;
+          else {
+            if (ne == l16) E[0] = x | (y << 8);
+            if (ne == l16 + 16) E[1] = x | (y << 8);
+            ne++;
+          }
+        }
+      }
+      if (over || ne == 0) return false;
+      if (__popc(alive) - __popc(kill) + ne > EPA_MAXF) done = true;      /* no room for the new faces: the nearest face as it is */
+    }
+    if (done) {
+      /* the origin's projection on the nearest face in barycentric coordinates: the witness on the box core */
+      const int f = __shfl(bhi ? fw[1] : fw[0], bsrc);
+      const int ia = f & 31, ib = (f >> 5) & 31, ic = (f >> 10) & 31;
+      const D3 a = mkd(Vw[3 * ia], Vw[3 * ia + 1], Vw[3 * ia + 2]), b = mkd(Vw[3 * ib], Vw[3 * ib + 1], Vw[3 * ib + 2]), c = mkd(Vw[3 * ic], Vw[3 * ic + 1], Vw[3 * ic + 2]);
+      const D3 p = mkd(bn.x * bd, bn.y * bd, bn.z * bd);
+      const D3 v0 = b - a, v1 = c - a, v2 = p - a;
+      const double d00 = ddot(v0, v0), d01 = ddot(v0, v1), d11 = ddot(v1, v1), d20 = ddot(v2, v0), d21 = ddot(v2, v1);
+      const double den = d00 * d11 - d01 * d01;
+      const double iden = den != 0.0 ? drcp(den) : 0.0;
+      const double bv = (d11 * d20 - d01 * d21) * iden, bw = (d00 * d21 - d01 * d20) * iden, bu = 1.0 - bv - bw;
+      const V3 hb2 = ld3(Y + 12);
+      const V3 ca = GjkSimplex::corner(Vm[ia], hb2), cbb = GjkSimplex::corner(Vm[ib], hb2), cc = GjkSimplex::corner(Vm[ic], hb2);
+      witb = mkd(bu * ca.x + bv * cbb.x + bw * cc.x, bu * ca.y + bv * cbb.y + bw * cc.y, bu * ca.z + bv * cbb.z + bw * cc.z);
+      nrm = bn; depth = bd;
+      return true;
+    }
+    alive &= ~kill;
+    Vw[3 * nv] = w.x; Vw[3 * nv + 1] = w.y; Vw[3 * nv + 2] = w.z; Vm[nv] = wb;
+    WSYNC();
+    /* edge k of the list makes a face with w in the k-th free slot (the dead ones rising, then new ones): each lane finds its slots' ranks and so their edges */
+    {
+      const unsigned dead = ~alive & ((1u << nf) - 1u);
+      const int nd = __popc(dead);
+      unsigned made = 0u; bool bad = false;
+#pragma unroll
+      for (int s = 0; s < 2; s++) {
+        const int j = l16 + 16 * s;
+        const int rank = ((dead >> j) & 1u) ? __popc(dead & ((1u << j) - 1u)) : (j >= nf ? nd + (j - nf) : 1000);
+        const bool mk = rank < ne;
+        made |= mk ? 1u << j : 0u;
+        if (s == 1 && max(nf, nf + ne - nd) <= 16) continue;      /* (row-uniform: there is no slot beyond the sixteenth) */
+        const int e0 = __shfl(E[0], rbase | (rank & 15)), e1 = __shfl(E[1], rbase | (rank & 15));
+        const int e = rank >= 16 ? e1 : e0;
+        const EpaFace r = epa_face(Vw, mk ? ((e & 255) | ((e >> 8) << 5) | (nv << 10)) : (0 | (1 << 5) | (2 << 10)));
+        if (mk) { fw[s] = r.word; fn[s] = r.n; fd[s] = r.d; bad |= !r.ok; }
+      }
+      alive |= row_or_u(made);
+      nf = max(nf, nf + ne - nd);
+      nv++;
+      if (row_or_u(bad ? 1u : 0u) != 0u) return false;
+    }
+  }
+  return false;
+}
+
+/* One hull pair by the SIXTEEN LANES OF A DPP ROW, the four rows of a wave on four pairs at once (round 5; until then a whole wave did one pair after the other: since the
+ * support-vertex tables a query looks at a handful of vertices, and under the literal random-action rollout an arm lying on the furniture has ten such pairs per substep).
+ * Everything below is the same in the sixteen lanes of a row except the candidates a lane scans; nothing in it is wave-uniform - no readfirstlane, no ballot, the cross-lane
+ * steps are row DPP - and the rows diverge freely (a row whose pair needs no GJK idles while another iterates).  gi = the row's active pair of the substep, -1: none; the
+ * pair is described in L.hinfo[gi] by narrowphase_coop's first phase (hull collider | box collider << 8 | hull is collider b << 16, margin, baked pair index); the outcome
+ * goes to L.hout[gi] (1: hull contact, staged in L.hpt[gi]; 0: apart; -1: the OBB path).  The GJK simplex of a row lives in its 64 floats of the narrowphase scratch
+ * (free until the batches start). */
 template <class LDS>
 __device__ __forceinline__ void hull_item16(const DevModel* m, LDS& L, const int lane, const int gi, float* gax) {
   const int l16 = lane & 15, row = lane >> 4;
@@ -797,11 +990,16 @@ __device__ __forceinline__ void hull_item16(const DevModel* m, LDS& L, const int
           const int cell = hcell_of(wmax ? um : -um);
           const int o0 = co[cell], o1 = act ? co[cell + 1] : o0;
           float bestv = -1e30f; int besti = 0x7fffffff;
-          for (int base = o0 + h2; __any(base < o1); base += 2) {
-            const float4 q = cv[base < o1 ? base : o0];
-            const float l = hull_coord(um, q, cm);
-            const float val = wmax ? l : -l;
-            if (base < o1 && val > bestv) { bestv = val; besti = __float_as_int(q.w); }
+          for (int base = o0 + h2; __any(base < o1); base += 8) {      /* (four loads in flight per lane: a rim circle seen along its axis has sixty candidates, and one load per round was thirty memory latencies in a row) */
+            float4 q[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) q[u] = cv[base + 2 * u < o1 ? base + 2 * u : o0];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              const float l = hull_coord(um, q[u], cm);
+              const float val = wmax ? l : -l;
+              if (base + 2 * u < o1 && val > bestv) { bestv = val; besti = __float_as_int(q[u].w); }
+            }
           }
           const float gm = fmaxf(bestv, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(bestv), 0xB1, 0xF, 0xF, true)));      /* (quad_perm [1, 0, 3, 2]: the other lane of the pair) */
           int gi2 = bestv == gm ? besti : 0x7fffffff;
@@ -850,9 +1048,9 @@ __device__ __forceinline__ void hull_item16(const DevModel* m, LDS& L, const int
               const bool ox = fabsf(lv.x) > hbc.x, oy = fabsf(lv.y) > hbc.y, oz = fabsf(lv.z) > hbc.z;
               const int nout = (ox ? 1 : 0) + (oy ? 1 : 0) + (oz ? 1 : 0);
               /* (the simplex lives in the row's scratch, and so does v while a scan runs and the scan's directions while the simplex is solved: the kernel has no registers for them) */
-              double* Z = (double*)&L.npscr[64 * row];
-              float* Y = &L.npscr[64 * row + 2 * 18];
-              static_assert(NPSCR_FLOATS >= 4 * 64 && 64 >= 2 * 18 + 15, "a row's GJK scratch: the simplex (twelve doubles), the weights and v, 8-byte aligned; fifteen floats behind them");
+              double* Z = (double*)&L.npscr[HROW_FLOATS * row];
+              float* Y = &L.npscr[HROW_FLOATS * row + 2 * 18];
+              static_assert(NPSCR_FLOATS >= 4 * HROW_FLOATS && 64 >= 2 * 18 + 15, "a row's scratch: GJK's simplex (twelve doubles), the weights and v, 8-byte aligned, fifteen floats behind them; the polytope of hull_epa16 from float 64 on");
 #define GJK_PARK_DIRS() do { st3(Y, u0); st3(Y + 3, u1); st3(Y + 6, u2); st3(Y + 9, mk3(c0, c1, c2)); st3(Y + 12, hbc); asm volatile("" ::: "memory"); } while (0)
 #define GJK_FETCH_DIRS() do { asm volatile("" ::: "memory"); u0 = ld3(Y); u1 = ld3(Y + 3); u2 = ld3(Y + 6); { const V3 t_ = ld3(Y + 9); c0 = t_.x; c1 = t_.y; c2 = t_.z; } hbc = ld3(Y + 12); } while (0)
               GjkSimplex S;
@@ -883,7 +1081,8 @@ __device__ __forceinline__ void hull_item16(const DevModel* m, LDS& L, const int
                 fail = nout == 0;
               }
               WSYNC();
-              bool apart = false;
+              bool apart = false, epa_ok = false, tetra = false;
+              D3 epa_n = mkd(0, 0, 0), epa_b = mkd(0, 0, 0); double epa_depth = 0.0;
               D3 v = mkd(0, 0, 0); double dd = 0.0;
               if (!fail) {
                 GJK_PARK_DIRS();
@@ -905,10 +1104,11 @@ __device__ __forceinline__ void hull_item16(const DevModel* m, LDS& L, const int
                   float bd = -1e30f; int bi = 0x7fffffff; V3 bq = mk3(0, 0, 0);
                   const int cell = hcell_of(dl);
                   const int o0 = co[cell], o1 = co[cell + 1];      /* (the cell of the direction: a few vertices, one round of the row - five for a rim circle seen along its axis) */
-                  for (int base = o0 + l16; __any(base - l16 < o1); base += 16) {
-                    const float4 q = cv[base < o1 ? base : o0];
-                    const float dq = __fmaf_rn(dl.z, q.z, __fmaf_rn(dl.y, q.y, dl.x * q.x));
-                    if (base < o1 && dq > bd) { bd = dq; bi = __float_as_int(q.w); bq = mk3(q.x, q.y, q.z); }
+                  for (int base = o0 + l16; __any(base - l16 < o1); base += 32) {
+                    const float4 qa = cv[base < o1 ? base : o0], qb = cv[base + 16 < o1 ? base + 16 : o0];      /* (two loads in flight) */
+                    const float da = __fmaf_rn(dl.z, qa.z, __fmaf_rn(dl.y, qa.y, dl.x * qa.x)), db = __fmaf_rn(dl.z, qb.z, __fmaf_rn(dl.y, qb.y, dl.x * qb.x));
+                    if (base < o1 && da > bd) { bd = da; bi = __float_as_int(qa.w); bq = mk3(qa.x, qa.y, qa.z); }
+                    if (base + 16 < o1 && db > bd) { bd = db; bi = __float_as_int(qb.w); bq = mk3(qb.x, qb.y, qb.z); }
                   }
                   const float top = row_max_f(bd);
                   const int key = row_min_i(bd == top ? ((bi << 4) | l16) : 0x7fffffff);      /* (the lowest vertex number among equals; the lane that holds it rides along) */
@@ -936,13 +1136,17 @@ __device__ __forceinline__ void hull_item16(const DevModel* m, LDS& L, const int
                 GJK_PARK_DIRS();
                 gjk_closest(S, lane);
                 GJK_FETCH_DIRS();
-                if (S.n == 4) { fail = true; break; }
+                if (S.n == 4) {                                  /* the origin lies inside the tetrahedron: the cores overlap */
+                  fail = true; tetra = true;
+                  break;
+                }
                 v = S.closest();
                 const double nd = ddot(v, v);
                 if (nd < GJK_ZERO) { fail = true; break; }
                 if (nd >= dd * GJK_STALL) { dd = nd; break; }
                 dd = nd;
               }
+              if (tetra && m->epa) { GJK_PARK_DIRS(); epa_ok = hull_epa16(L, lane, S, cv, co, epa_n, epa_depth, epa_b); }      /* (after the loop: fewer values live across it) */
 #undef GJK_PARK_DIRS
 #undef GJK_FETCH_DIRS
               HCLK_ADD(28, __builtin_readcyclecounter()) PCLK_ADD(31, __builtin_readcyclecounter())
@@ -954,7 +1158,12 @@ __device__ __forceinline__ void hull_item16(const DevModel* m, LDS& L, const int
                   *(float4*)(gslot + 4) = make_float4(__int_as_float(S.n > 2 ? S.i2 : 0), (float)v.x, (float)v.y, (float)v.z);
                 } else if (warm) gslot[0] = __int_as_float(0);
               }
-              if (apart) out = 0;
+              if (epa_ok) {                                  /* penetrating cores: the two margins add along the polytope's normal (oracle hull_box_gjk, RPO_RULE_EPA) */
+                out = 1;
+                nloc = mk3((float)-epa_n.x, (float)-epa_n.y, (float)-epa_n.z);      /* from the box toward the hull */
+                ploc = mk3((float)epa_b.x, (float)epa_b.y, (float)epa_b.z) + nloc * RP_HULL_MARGIN;
+                dcon = -(float)epa_depth - 2.f * RP_HULL_MARGIN;
+              } else if (apart) out = 0;
               else if (!fail && distd > GJK_ZERO) {
                 const float dist = (float)distd;
                 const float dg = dist - 2.f * RP_HULL_MARGIN;

@@ -118,6 +118,7 @@ int rp_create(const rp_config* cfg, rp_handle* out) {
   if (cfg->num_envs > RP_MAX_ENVS) { snprintf(g_err, 256, "rp_create: num_envs %d exceeds %d (rank field of the env pairing tables)", cfg->num_envs, RP_MAX_ENVS); return RP_ERR_ARG; }
   if (cfg->env_kind < 0 || cfg->env_kind >= RP_ENV_COUNT) { snprintf(g_err, 256, "rp_create: unsupported env kind %d", cfg->env_kind); return RP_ERR_UNSUPPORTED; }
   if ((cfg->flags & RP_CFG_ACTION_TYPE) && (cfg->action_type < 0 || cfg->action_type > RP_ACTION_RELATIVE_JOINTS)) { snprintf(g_err, 256, "rp_create: action_type %d", cfg->action_type); return RP_ERR_ARG; }
+  if ((cfg->flags & RP_CFG_HULL_EPA) && (cfg->flags & RP_CFG_NO_HULL_EPA)) { snprintf(g_err, 256, "rp_create: RP_CFG_HULL_EPA and RP_CFG_NO_HULL_EPA"); return RP_ERR_ARG; }
   if ((cfg->flags & RP_CFG_CONTACT_MARGIN) && !(cfg->contact_margin >= 0.f && cfg->contact_margin <= 0.05f)) { snprintf(g_err, 256, "rp_create: contact_margin %g outside [0, 0.05]", (double)cfg->contact_margin); return RP_ERR_ARG; }
   /* registered id -> baked model (arm + scene) and action type.  The ids of a play family share scene, arm and configuration
    * (envList.py:43-140); only perform_action differs. */
@@ -256,6 +257,12 @@ int rp_create(const rp_config* cfg, rp_handle* out) {
       d->persist = 1; d->pmcache = h->pmcache;
     }
     d->gjk = ((cfg->flags & RP_CFG_OBB_EDGES) || getenv("RP_NO_GJK") != nullptr) ? 0 : 1;      /* (oracle RPO_RULE_GJK: the default; RP_NO_GJK=1: the tools' switch to round 3's OBB edges) */
+    {      /* oracle RPO_RULE_EPA: the Panda kinds' default (rpo_create); RP_CFG_HULL_EPA / RP_CFG_NO_HULL_EPA or the tools' RP_EPA=1 / RP_NO_EPA=1 force it */
+      int epa = (SPEC[cfg->env_kind].model == 'U' || SPEC[cfg->env_kind].model == 'R') ? 0 : 1;
+      if ((cfg->flags & RP_CFG_HULL_EPA) || getenv("RP_EPA") != nullptr) epa = 1;
+      if ((cfg->flags & RP_CFG_NO_HULL_EPA) || getenv("RP_NO_EPA") != nullptr) epa = 0;
+      d->epa = d->gjk ? epa : 0;
+    }
     d->spec_limits = (cfg->flags & RP_CFG_SPECULATIVE_LIMITS) ? 1 : 0;
     if (getenv("RP_NO_SPIN") != nullptr)                     /* timing / model studies only: no torsional friction rows */
       for (int c = 0; c < RP_MAX_COL; c++) d->col_spin[c] = 0.f;

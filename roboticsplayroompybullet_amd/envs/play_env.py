@@ -47,13 +47,13 @@ class playEnv:
                  goal_range_low=(-0.18, -0.18, -0.05), goal_range_high=(0.18, 0.18, 0.05), obj_lower_bound=(-0.18, -0.18, -0.05),
                  obj_upper_bound=(-0.18, -0.18, -0.05), sparse=True, use_orientation=False, sparse_rew_thresh=0.05,
                  fixed_gripper=False, return_velocity=True, max_episode_steps=250, play=False, action_type='absolute_rpy',
-                 show_goal=True, arm_type='Panda', device=0, seed=None, contact_margin=None, persistent_manifolds=True, hull_gjk=True, speculative_limits=False):
+                 show_goal=True, arm_type='Panda', device=0, seed=None, contact_margin=None, persistent_manifolds=True, hull_gjk=True, speculative_limits=False, hull_epa=None):
         # seed=None: like the reference, which draws from the global np.random (environments.py:496, 530, 579), every new env gets
         # its own episode stream and np.random.seed(k) makes it repeatable
         if seed is None:
             seed = int(np.random.randint(0, 2 ** 31 - 1))
         self.sparse, self._contact_margin = bool(sparse), contact_margin
-        self._model_opts = dict(persistent_manifolds=bool(persistent_manifolds), hull_gjk=bool(hull_gjk), speculative_limits=bool(speculative_limits))      # the library's contact-model switches (rp_config.flags)
+        self._model_opts = dict(persistent_manifolds=bool(persistent_manifolds), hull_gjk=bool(hull_gjk), speculative_limits=bool(speculative_limits), hull_epa=hull_epa)      # the library's contact-model switches (rp_config.flags)
         self.timeStep = 1.0 / 300
         self.render_scene = False
         self.physics_client_active = 0
@@ -183,27 +183,36 @@ class playEnv:
         return float(np.linalg.norm(np.asarray(achieved_goal) - np.asarray(desired_goal)))
 
     def visualise_sub_goal(self, sub_goal, sub_goal_state='full_positional_state'):
-        """environments.py:606-690: draw a sub-goal into the images as half-transparent ghosts.  'achieved_goal' and the object part of
-        'full_positional_state' (objects, and for the play ids drawer / door / button / dial) are drawn; the ghost ARM of
-        'full_positional_state' / 'controllable_achieved_goal' is not (the reference has one for the Panda only and raises for the UR5)."""
+        """environments.py:606-690: draw a sub-goal into the images as half-transparent ghosts: the objects (and for the play ids drawer / door / button / dial) of
+        'achieved_goal' / 'full_positional_state', and the ghost ARM of 'full_positional_state' / 'controllable_achieved_goal' - for the Panda; like the reference
+        (environments.py:629-630) the UR5 raises NotImplementedError.  (The reference's Panda branch refers to an attribute that is never set, `self.ghost_panda`,
+        and cannot run as written; what it evidently means is implemented: reset_arm(ghost_arm, sub_goal, from_init=False) - rest pose, one default IK call towards
+        the sub-goal's EE pose, joints [0:6] - environments.py:575-590.)"""
         import torch
         if self._vec is None:
             raise RuntimeError('visualise_sub_goal before the first reset(): the physics client is not active yet')
         g = np.asarray(sub_goal, dtype=np.float32)
-        if sub_goal_state == 'controllable_achieved_goal':
-            raise NotImplementedError('the ghost arm is not drawn; only the object / fixture part of a sub-goal is visualised')
+        if sub_goal_state not in ('achieved_goal', 'full_positional_state', 'controllable_achieved_goal'):
+            raise ValueError(sub_goal_state)
+        arm = None
+        if sub_goal_state in ('full_positional_state', 'controllable_achieved_goal'):
+            if self.arm_type != 'Panda':
+                raise NotImplementedError      # environments.py:629-630
+            orn = g[3:7] if (sub_goal_state == 'full_positional_state' and self.use_orientation) else np.array([0.0, 0.0, 0.0, 1.0], dtype=np.float32)      # default_arm_orn = quaternion of RPY (0, 0, 0): environments.py:357-366
+            arm = np.concatenate([g[0:3], orn, [0.0]]).astype(np.float32)
         if sub_goal_state == 'full_positional_state':
             g = g[(8 if self.use_orientation else 4):]
-        elif sub_goal_state != 'achieved_goal':
-            raise ValueError(sub_goal_state)
-        if self.num_objects == 0:
-            raise NotImplementedError('this id has no objects: its sub-goal is the arm itself, which is not drawn')
+        self._vec.ghost_arm = torch.as_tensor(arm)[None] if arm is not None else None
+        if sub_goal_state == 'controllable_achieved_goal' or self.num_objects == 0:
+            self._vec.sub_goal = None
+            return
         assert g.shape == (self._vec.dims['achieved_goal'],), g.shape
         self._vec.sub_goal = torch.as_tensor(g)[None]
 
     def delete_sub_goal(self):
         if self._vec is not None:
             self._vec.sub_goal = None
+            self._vec.ghost_arm = None
 
     def close(self):
         if self._vec is not None:

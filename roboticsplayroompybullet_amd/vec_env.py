@@ -28,7 +28,7 @@ WIDE_STATE_LAYOUT = {'q': (0, 9), 'qd': (9, 18), 'free0': (18, 31), 'free1': (31
 class VecPlayEnv:
     def __init__(self, env_id, num_envs, device=0, seed=0, env_offset=0, action_type=None, goal_range_low=None, goal_range_high=None,
                  obj_lower_bound=None, obj_upper_bound=None, env_range_high=None, sparse_rew_thresh=None, sparse=True,
-                 contact_margin=None, persistent_manifolds=True, hull_gjk=True, speculative_limits=False):
+                 contact_margin=None, persistent_manifolds=True, hull_gjk=True, speculative_limits=False, hull_epa=None):
         """The keyword arguments after env_offset are the constructor kwargs of the reference's env classes that reach the
         simulation (envList.py -> environments.py:64-67); None keeps what the id registers.  contact_margin: rp_config."""
         if env_id not in _lib.ENV_KINDS:
@@ -74,6 +74,8 @@ class VecPlayEnv:
             flags |= _lib.CFG_SPECULATIVE_LIMITS      # round 2's joint-limit rows (oracle rule without bit 2): no gripper chatter, further from Bullet's limit rule
         if not hull_gjk:
             flags |= _lib.CFG_OBB_EDGES               # round 3's contacts where a link's deepest hull vertex lies beside the box face: its OBB instead of GJK on the hull (oracle rule 1015)
+        if hull_epa is not None:                      # None: the arm's default (Panda ids: on, UR5 ids: off - include/rp_playroom.h RP_CFG_HULL_EPA)
+            flags |= _lib.CFG_HULL_EPA if hull_epa else _lib.CFG_NO_HULL_EPA
         cfg.flags = flags
         self.h = C.c_void_p()
         self._done = None
@@ -107,6 +109,7 @@ class VecPlayEnv:
         self.image_envs = None              # (lo, hi): the envs whose img is rendered while record_images is set (default: all - 120 KB per env and call)
         self._img = None                    # reused image buffer: obs['img'] is overwritten by the next step / reset / calc_state (clone() to keep one)
         self.sub_goal = None                # [N, dims.achieved_goal] ghosts drawn into img (visualise_sub_goal)
+        self.ghost_arm = None               # [N, 8] ghost arm poses drawn into img (visualise_sub_goal's arm part, Panda ids)
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -120,7 +123,8 @@ class VecPlayEnv:
             if self._img is None or self._img.shape[0] != hi - lo:
                 self._img = torch.empty((hi - lo, 200, 200, 3), dtype=torch.uint8, device=self.device)
             sg = self.sub_goal[lo:hi] if (self.sub_goal is not None and self.sub_goal.shape[0] == self.num_envs) else self.sub_goal
-            o['img'] = self.render('rgb_array', envs=(lo, hi), sub_goal=sg, out=self._img)
+            ga = self.ghost_arm[lo:hi] if (self.ghost_arm is not None and self.ghost_arm.shape[0] == self.num_envs) else self.ghost_arm
+            o['img'] = self.render('rgb_array', envs=(lo, hi), sub_goal=sg, out=self._img, ghost_arm=ga)
         o['gripper_proprioception'] = self.buf['gripper_proprioception']
         return o
 
@@ -218,10 +222,12 @@ class VecPlayEnv:
         cam.fov_deg, cam.aspect, cam.mode = float(fov), float(aspect), 1 if gripper else 0
         return cam
 
-    def render(self, mode='rgb_array', width=200, height=200, envs=None, camera=None, sub_goal=None, out=None):
+    def render(self, mode='rgb_array', width=200, height=200, envs=None, camera=None, sub_goal=None, out=None, ghost_arm=None):
         """obs['img'] of the reference (environments.py:841-845: getCameraImage(200, 200, ...)[2][:, :, :3]) for envs [lo, hi) (default: all):
         uint8 [n, height, width, 3] on the device.  sub_goal [n, dims.achieved_goal]: draw the sub-goal's ghosts
-        (visualise_sub_goal, environments.py:606-690).  mode 'human' (a GUI window) does not exist here and returns None."""
+        (visualise_sub_goal, environments.py:606-690).  ghost_arm [n, 8] = EE position, orientation quaternion (xyzw), gripper: the ghost ARM of
+        visualise_sub_goal's 'controllable_achieved_goal' / 'full_positional_state' (environments.py:623-637, 671-674; Panda ids only - the reference raises for the
+        UR5).  mode 'human' (a GUI window) does not exist here and returns None."""
         if mode == 'human':
             return None
         lo, hi = (0, self.num_envs) if envs is None else (int(envs[0]), int(envs[1]))
@@ -233,6 +239,12 @@ class VecPlayEnv:
             sub_goal = sub_goal.to(device=self.device, dtype=torch.float32).contiguous()
             assert sub_goal.shape == (n, self.dims['achieved_goal']), sub_goal.shape
             sg = C.c_void_p(sub_goal.data_ptr())
+        if ghost_arm is not None:
+            ghost_arm = ghost_arm.to(device=self.device, dtype=torch.float32).contiguous()
+            assert ghost_arm.shape == (n, 8), ghost_arm.shape
+            _lib.check(self.lib, self.h, self.lib.rp_render_ex(self.h, C.byref(camera) if camera is not None else None, int(width), int(height), lo, n,
+                                                               C.c_void_p(img.data_ptr()), sg, C.c_void_p(ghost_arm.data_ptr()), self._stream()), 'rp_render_ex')
+            return img
         _lib.check(self.lib, self.h, self.lib.rp_render(self.h, C.byref(camera) if camera is not None else None, int(width), int(height), lo, n,
                                                         C.c_void_p(img.data_ptr()), sg, self._stream()), 'rp_render')
         return img

@@ -25,7 +25,10 @@ def test_contact_lists_pose_by_pose(kind):
     from roboticsplayroompybullet_amd import VecPlayEnv
     lib = oracle.load(f32=True)
     lib.rpo_gjk_stats.argtypes = [C.c_void_p, C.c_int]
+    lib.rpo_epa_stats.argtypes = [C.c_void_p, C.c_int]
     st = (C.c_long * 8)()
+    se = (C.c_long * 4)()
+    epa_contacts = 0
     env = VecPlayEnv(IDS[kind], 2, seed=7)
     rng = np.random.default_rng(11)
     poses = gjk_contacts = mismatched = 0
@@ -44,8 +47,11 @@ def test_contact_lists_pose_by_pose(kind):
             dbg = env.debug_substep(0).numpy()
             o.set_state(o.get_state())                       # (empties the oracle's contact cache: both sides start this substep without history)
             lib.rpo_gjk_stats(st, 1)
+            lib.rpo_epa_stats(se, 1)
             oc = o.contacts()
             lib.rpo_gjk_stats(st, 0)
+            lib.rpo_epa_stats(se, 0)
+            epa_contacts += se[2]
             o.set_state(o.get_state())
             poses += 1
             gjk_contacts += st[3]
@@ -61,6 +67,6 @@ def test_contact_lists_pose_by_pose(kind):
                 if mismatched <= 3:
                     print('pose %d of env %d: device %d contacts, oracle %d' % (t, e, ncon, len(oc)))
                     print(np.round(gc, 5)); print(np.round(oc, 5))
-    print('%s: %d poses, %d GJK contacts in the oracle, %d poses with another list on the device, worst point / distance error of the rest %.1e' % (kind, poses, gjk_contacts, mismatched, worst))
-    assert gjk_contacts >= 5, 'the rollouts no longer pass through GJK contacts'
+    print('%s: %d poses, %d GJK contacts and %d EPA contacts (overlapping cores, round 5) in the oracle, %d poses with another list on the device, worst point / distance error of the rest %.1e' % (kind, poses, gjk_contacts, epa_contacts, mismatched, worst))
+    assert gjk_contacts + epa_contacts >= 5, 'the rollouts no longer pass through GJK / EPA contacts'
     assert mismatched == 0

@@ -139,10 +139,11 @@ def test_rollout_200_steps_vs_fp64_oracle(kind):
           % (100.0 * capped.sum() / (n * steps), int((capped > 0).sum()), n, capped[~strict].mean() if (~strict).any() else 0.0, capped[strict].mean()))
 
 
-@pytest.mark.parametrize('kind,gjk', [('U', True), ('P', True), ('U', False), ('P', False)])
-def test_hull_gjk_option_vs_fp64_oracle(kind, gjk):
+@pytest.mark.parametrize('kind,gjk,epa', [('U', True, None), ('P', True, None), ('U', True, True), ('P', True, False), ('U', False, None), ('P', False, None)])
+def test_hull_gjk_option_vs_fp64_oracle(kind, gjk, epa):
     """The two models of an arm link whose deepest hull vertex lies beside the box face (box edges and corners): GJK's distance phase on hull and box (the default
-    since round 4; oracle rule 2039 = 1015 | RPO_RULE_GJK) and, under RP_CFG_OBB_EDGES (hull_gjk=False), the link's OBB (round 3's default, oracle rule 1015).
+    since round 4; oracle rule 2039 = 1015 | RPO_RULE_GJK), with the expanding polytope for overlapping cores (round 5; | RPO_RULE_EPA = 133111: the Panda ids' default, hull_epa=True /
+    False = RP_CFG_HULL_EPA / RP_CFG_NO_HULL_EPA force it) and, under RP_CFG_OBB_EDGES (hull_gjk=False), the link's OBB (round 3's default, oracle rule 1015).
     100 steps, 16 envs, the arm's own joints; same bound and envelope as the headline rollout: 1e-3 relative, three times the fp32 followers' own largest
     divergence where that is larger, and the median an order of magnitude inside."""
     from roboticsplayroompybullet_amd import VecPlayEnv
@@ -150,9 +151,10 @@ def test_hull_gjk_option_vs_fp64_oracle(kind, gjk):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
     from gpu_debug import record_from_oracle
     n, steps = 16, 100
-    env = VecPlayEnv(IDS[kind], n, seed=9, hull_gjk=gjk)
+    env = VecPlayEnv(IDS[kind], n, seed=9, hull_gjk=gjk, hull_epa=epa)
     env.reset()
-    fol = [Followers(kind, 9, e, extra=4, rule=1015 | (1024 if gjk else 0)) for e in range(n)]
+    with_epa = gjk and (epa if epa is not None else kind != 'U')
+    fol = [Followers(kind, 9, e, extra=4, rule=1015 | (1024 if gjk else 0) | (131072 if with_epa else 0)) for e in range(n)]
     for f in fol:
         f.o64.reset()
         f.start_from(f.o64)
@@ -169,7 +171,7 @@ def test_hull_gjk_option_vs_fp64_oracle(kind, gjk):
             qo = f.o64.get_state()[:n_arm]
             d_hip[e] = max(d_hip[e], float((np.abs(q[e] - qo) / np.maximum(1.0, np.abs(qo)))[:nm].max()))
             d_o32[e] = max(d_o32[e], float((f.gap(lambda o: o.get_state()[:nm]) / np.maximum(1.0, np.abs(qo[:nm]))).max()))
-    print('hull GJK %s (%s, %d envs, %d steps): device max %.3e median %.3e; fp32 CPU followers max %.3e' % ('on' if gjk else 'off', kind, n, steps, d_hip.max(), np.median(d_hip), d_o32.max()))
+    print('hull GJK %s, EPA %s (%s, %d envs, %d steps): device max %.3e median %.3e; fp32 CPU followers max %.3e' % ('on' if gjk else 'off', 'on' if with_epa else 'off', kind, n, steps, d_hip.max(), np.median(d_hip), d_o32.max()))
     assert (d_hip <= np.maximum(1e-3, 3 * d_o32)).sum() >= n - 1, (d_hip, d_o32)
     assert np.median(d_hip) <= 1e-4
 
@@ -177,7 +179,7 @@ def test_hull_gjk_option_vs_fp64_oracle(kind, gjk):
 @pytest.mark.parametrize('kind', ['U', 'P'])
 def test_speculative_limits_option_vs_fp64_oracle(kind):
     """RP_CFG_SPECULATIVE_LIMITS (speculative_limits=True): round 2's joint-limit rows - a row from 0.1 before the limit on, contact erp - against the oracle without
-    RPO_RULE_LIMIT (rule 2039 & ~2).  The switch exists so that a learner can be trained with and without the gripper's limit chatter (tests/tolerances.py): under
+    RPO_RULE_LIMIT (the kind's default rule & ~2).  The switch exists so that a learner can be trained with and without the gripper's limit chatter (tests/tolerances.py): under
     this rule the gripper's joints rest AT their limits, so they are held to the arm's own tolerance here - no sawtooth allowance (environments.py:1037-1073: the
     "open" commands that push them there)."""
     from roboticsplayroompybullet_amd import VecPlayEnv
@@ -187,7 +189,7 @@ def test_speculative_limits_option_vs_fp64_oracle(kind):
     n, steps = 8, 60
     env = VecPlayEnv(IDS[kind], n, seed=9, speculative_limits=True)
     env.reset()
-    fol = [Followers(kind, 9, e, extra=2, rule=2039 & ~2) for e in range(n)]
+    fol = [Followers(kind, 9, e, extra=2, rule=(2039 if kind == 'U' else 133111) & ~2) for e in range(n)]
     for f in fol:
         f.o64.reset()
         f.start_from(f.o64)

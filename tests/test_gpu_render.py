@@ -312,3 +312,41 @@ def test_single_env_adapter_records_images():
     with pytest.raises(NotImplementedError):
         env.visualise_sub_goal(o['controllable_achieved_goal'], sub_goal_state='controllable_achieved_goal')
     env.close()
+
+
+def test_panda_ghost_arm_of_visualise_sub_goal():
+    """visualise_sub_goal(sub_goal, 'controllable_achieved_goal' / 'full_positional_state') (environments.py:606-637, 671-674): a second, half-transparent Panda at the joints
+    one default IK call from the rest pose finds for the sub-goal's EE pose (reset_arm, environments.py:575-590).  The ghost is drawn (pixels change), it is not an obstacle
+    (rays do not see it), a ghost at the arm's own EE pose tints the arm's pixels - another set than the ghost beside it -, and the UR5 is refused as in the reference (NotImplementedError upstream,
+    RP_ERR_UNSUPPORTED at the C ABI)."""
+    import roboticsplayroompybullet_amd as rp
+    from roboticsplayroompybullet_amd import VecPlayEnv
+    V = 'pandaPlayAbsRPY1Obj-v0'
+    env = VecPlayEnv(V, 2, seed=3)
+    obs = env.reset()
+    plain = env.render('rgb_array').cpu().numpy()
+    ee = obs['obs_quat'][:, 0:7].clone()                              # EE position and orientation
+    away = torch.cat([ee[:, 0:3] + torch.tensor([0.15, 0.0, 0.05], device=ee.device), ee[:, 3:7], torch.zeros((2, 1), device=ee.device)], 1)
+    ghost = env.render('rgb_array', ghost_arm=away).cpu().numpy()
+    changed = (plain != ghost).any(axis=3)
+    assert 200 < changed[0].sum() < 15000, changed[0].sum()        # a second arm appeared, the picture is otherwise the same
+    same = torch.cat([ee, torch.zeros((2, 1), device=ee.device)], 1)
+    on_top = (env.render('rgb_array', ghost_arm=same).cpu().numpy() != plain).any(axis=3)
+    assert 200 < on_top[0].sum() < 15000 and (on_top[0] != changed[0]).sum() > 500      # (the tinted ghost over the arm itself: other pixels than the ghost 15 cm away)
+    ur5 = VecPlayEnv(U, 1, seed=3)
+    ur5.reset()
+    with pytest.raises(RuntimeError, match='Panda only'):
+        ur5.render('rgb_array', ghost_arm=torch.zeros((1, 8)))
+    single = rp.make(V, seed=1)
+    o = single.reset()
+    single.render('rgb_array')
+    o, r, d, info = single.step(np.array([0.0, 0.1, 0.1, 0, 0, 0, 0.0]))
+    before = o['img']
+    sg = o['full_positional_state'].copy()
+    sg[0] += 0.12
+    single.visualise_sub_goal(sg, sub_goal_state='full_positional_state')
+    with_ghost = single.instance.calc_state()['img']
+    assert 100 < (with_ghost != before).any(axis=2).sum()
+    single.delete_sub_goal()
+    assert (single.instance.calc_state()['img'] == before).all()
+    single.close()

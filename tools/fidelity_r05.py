@@ -24,7 +24,11 @@ import oracle  # noqa: E402
 from oracle import OracleEnv  # noqa: E402
 import model_divergence as md  # noqa: E402
 
-SHIPPED = 2039
+EPA = 131072
+
+
+def shipped(kind):      # rp_oracle.c rpo_create: the expanding polytope is in the Panda kinds' default, not in the UR5 kinds'
+    return 2039 | (0 if kind in 'UR' else EPA)
 
 
 def actions(kind, dist, steps, rng):
@@ -41,10 +45,11 @@ def main():
     ap.add_argument('--tag', default='r05')
     args = ap.parse_args()
     D = oracle.REF_DEFAULT
-    variants = [('A default (shipped, rule 2039)', dict(rule=SHIPPED)), ('A -gjk (= RP_CFG_OBB_EDGES)', dict(rule=SHIPPED & ~1024)),
-                ('A +epa (experiment)', dict(rule=SHIPPED | 4096, abx=True)), ('A +creation-order (experiment)', dict(rule=SHIPPED | 65536)),
-                ('A +epa +creation-order (experiment)', dict(rule=SHIPPED | 4096 | 65536, abx=True)),
+    variants = [('A -epa (rule 2039: overlapping cores on the OBB path)', dict(rule=2039)), ('A +epa (rule 133111: the expanding polytope for overlapping cores)', dict(rule=2039 | EPA)),
+                ('A -epa -gjk (= RP_CFG_OBB_EDGES, rule 1015)', dict(rule=1015)),
+                ('A -epa + the reference step\'s own GJK / EPA (experiment build)', dict(rule=2039 | 4096, abx=True)), ('A +epa +creation-order (experiment)', dict(rule=2039 | EPA | 65536)),
                 ('B -anchor (the reference step against itself)', dict(bullet_ref=True, ref_flags=D & ~oracle.REF_FLAGS['anchor']))]
+    ship_name = {k: [n for n, kw in variants if kw.get('rule') == shipped(k) and not kw.get('abx')][0] for k in 'URPQVW'}
     cases = [('R', 'random'), ('Q', 'random'), ('U', 'random'), ('U', 'A-dist'), ('P', 'random'), ('P', 'A-dist'), ('V', 'random'), ('V', 'A-dist')]
     results = {}
 
@@ -74,14 +79,15 @@ def main():
             a = np.array(v)
             js.setdefault(key, {})[name] = {'arm': a[:, 0].tolist(), 'joints': a[:, 1].tolist(), 'block': a[:, 2].tolist()}
             blk = '-' if key[0] in 'RQ' else '%.1e / %.1e / %.1e' % (np.median(a[:, 2]), np.percentile(a[:, 2], 90), a[:, 2].max())
-            lines.append('| %s | %s | %.1e / %.1e / %.1e / %.1e | %d of %d | %s |' % (key, name, np.median(a[:, 0]), np.percentile(a[:, 0], 75), np.percentile(a[:, 0], 90), a[:, 0].max(),
+            lines.append('| %s | %s | %.1e / %.1e / %.1e / %.1e | %d of %d | %s |' % (key, name + (' **<- shipped for this id**' if name == ship_name[key[0]] else ''), np.median(a[:, 0]), np.percentile(a[:, 0], 75), np.percentile(a[:, 0], 90), a[:, 0].max(),
                                                                                    int((a[:, 0] <= 1e-3).sum()), len(a), blk))
     os.makedirs(os.path.join(REPO, 'profiles'), exist_ok=True)
     json.dump({'envs': args.envs, 'steps': args.steps, 'reference': 'oracle/rp_bullet_ref.c, default flags %d' % D, 'results': js},
               open(os.path.join(REPO, 'profiles', '%s_model_divergence.json' % args.tag), 'w'), indent=1)
     head = ('# Fast model vs the frozen reference step, round 5 (tools/fidelity_r05.py: %d envs x %d steps, fp64, from the reference step\'s post-reset state)\n\n'
             '`random` = bench.py\'s distribution B (workspace-uniform targets); `A-dist` = the literal U(action_space) rollout.  Under A-dist every pair of runs parts within tens\n'
-            'of steps - the `B -anchor` row is the reference step against ITSELF with a 1e-14-level change - so its columns measure chaos, not models.\n\n' % (args.envs, args.steps))
+            'of steps - the `B -anchor` row is the reference step against ITSELF with a 1e-14-level change - so its columns measure chaos, not models.\n'
+            'The expanding polytope (`+epa`) is in the default of the Panda ids (P, Q, V, W), whose rows it moves, and not of the UR5 ids (U, R), whose rows it does not (DESIGN.md).\n\n' % (args.envs, args.steps))
     open(os.path.join(REPO, 'profiles', '%s_model_divergence.md' % args.tag), 'w').write(head + '\n'.join(lines) + '\n')
     print('\n'.join(lines))
 

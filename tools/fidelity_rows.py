@@ -35,7 +35,7 @@ def rows(kind, rule, envs=12, steps=200, scenario='random', **kw):
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
-    ap.add_argument('--rules', default='1015,2039')
+    ap.add_argument('--rules', default='1015,2039,133111')
     ap.add_argument('--kinds', default='U,P')
     ap.add_argument('--envs', type=int, default=12)
     args = ap.parse_args()
