@@ -309,8 +309,11 @@ def main():
     # repeats of the same region (same actions; the state keeps evolving) for a median, then the extras: distribution A (the literal
     # random-action distribution of SURVEY.md 8d: U(action_space.low, high)) and the other contact margin
     rep_values = [global_envs * args.steps / elapsed]
-    for _ in range(max(0, args.repeats - 1) if cem is None else 0):
-        t_rep, _ = timed_region(env, actions, args.warmup, args.steps)
+    n_rep = max(0, args.repeats - 1) if cem is None else 0
+    if n_rep:      # FRESH actions per repeat (round 5: replaying the first region's twenty actions let the arms settle near the same targets - each repeat 1 - 2 % faster than the one before)
+        more = make_actions(n, n_rep * args.steps, device, 9000 + rank, env_id)
+    for i in range(n_rep):
+        t_rep, _ = timed_region(env, more, i * args.steps, args.steps)
         rep_values.append(global_envs * args.steps / t_rep)
     extras = {}
     if not args.no_extras and world == 1 and cem is None:
@@ -392,7 +395,7 @@ def main():
                                            'how': 'hipEvent pair around every launch on the launch stream (rp_enable_timers), separate '
                                                   'region right after the timed one with the env-group streams switched off'}},
             'repeats': {'values': rep_values, 'median': sorted(rep_values)[len(rep_values) // 2],
-                        'what': '%d timed regions of %d steps each; `value` is the first' % (len(rep_values), args.steps)},
+                        'what': '%d timed regions of %d steps each, every region on actions of its own; `value` is the first' % (len(rep_values), args.steps)},
             'non_finite_envs': bad, 'fallen_objects': fell, 'success_rate_last_step': success,
         }
         if cem:

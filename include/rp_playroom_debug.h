@@ -12,8 +12,10 @@
 extern "C" {
 #endif
 
-/* step pipeline: 0 = split kernels (default), 1 = one fused kernel per env step (k_step; the in-library cross-check).
- * With fused = 1 and timers enabled rp_step synchronises on its own kernel to read the timer. */
+/* step pipeline: 0 = split kernels (default), 1 = one fused kernel per env step (k_step; the in-library cross-check), 2 = the twelve substeps of a step in one launch
+ * (k_chain, round 4's experiment: blocks of two waves own four envs for the whole step; grid = RP_CHAIN_BLOCKS read at rp_create, default 1024).  All three produce the
+ * same bits (tests/).  With fused = 1 and timers enabled rp_step synchronises on its own kernel to read the timer; fused = 2 has no per-launch timers: rp_set_fused(h, 2)
+ * with timers on, and rp_enable_timers(h, n > 0) under fused = 2, return RP_ERR_ARG. */
 int rp_set_fused(rp_handle h, int32_t fused);
 /* number of env groups (streams) of the split pipeline, 1 .. 16 */
 int rp_set_groups(rp_handle h, int32_t groups);
@@ -27,6 +29,17 @@ int rp_debug_substep(rp_handle h, int32_t env, float* host_buf);
 int rp_debug_row_counts(rp_handle h, int32_t* host_buf);
 /* rounds the most recent rp_reset took */
 int rp_debug_reset_rounds(rp_handle h);
+/* PROFILING BUILDS ONLY (tools/build_profiling_libs.sh, -DRP_CLOCKS / -DRP_PROLOGUE_CLOCKS / -DRP_CHAIN_CLOCKS; the shipped library does not export them and tests/test_abi.py
+ * does not expect them): the s_memtime marks the kernels of such a build leave per wave / block, copied to the host after a device synchronise. */
+#if defined(RP_CLOCKS)
+int rp_debug_clocks(rp_handle h, uint64_t* host_buf, int32_t nwaves);
+#endif
+#if defined(RP_PROLOGUE_CLOCKS)
+int rp_debug_prologue_clocks(rp_handle h, uint64_t* host_buf, int32_t nwaves);
+#endif
+#if defined(RP_CHAIN_CLOCKS)
+int rp_debug_chain_clocks(rp_handle h, int64_t* host_buf, int32_t nblocks);
+#endif
 
 #ifdef __cplusplus
 }

@@ -99,13 +99,13 @@ typedef struct DevModel {
   float floor_z;                  /* bottom of the lowest static collider: an object below it has left the scene (status bit 2) */
   /* joint clamps of goto_joint_poses (environments.py:1015-1021) */
   float ll[7], ul[7], inc[7];
-  /* convex-hull vertices of the arm links' collision meshes (generated/rp_hullverts_gen.h): device pointer to the arm's table (x, y, z, 0 in the owning
-   * body's frame), per collider the first vertex and the count (0 = no hull).  rp_create uploads the table and sets the pointer. */
   int spec_limits;                /* RP_CFG_SPECULATIVE_LIMITS: round 2's joint-limit rows (oracle rule without RPO_RULE_LIMIT) */
   int gjk;                        /* GJK's distance phase where a hull's deepest vertex lies beside the box face (collide(); oracle RPO_RULE_GJK) */
   int epa;                        /* ... and the expanding polytope where it finds the cores overlapping (hull_epa16; oracle RPO_RULE_EPA) */
   int persist;                    /* unless RP_CFG_STATELESS_CONTACTS: collide() keeps its manifolds in pmcache (rp_kernels.cuh PMC_*) */
   float* pmcache;                 /* [N][PMC_FLOATS], device memory owned by the handle */
+  /* convex-hull vertices of the arm links' collision meshes (generated/rp_hullverts_gen.h): device pointer to the arm's table (x, y, z, 0 in the owning
+   * body's frame), per collider the first vertex and the count (0 = no hull).  rp_create uploads the table and sets the pointer. */
   const float* hullv;
   int hull_off[RP_MAX_COL], hull_cnt[RP_MAX_COL];
   /* support-vertex candidate tables of those hulls (generated/rp_hullcells_gen.h; rp_kernels.cuh hcell_of): hcv = every cell's candidates as (x, y, z, vertex number) -

@@ -4430,7 +4430,7 @@ __device__ __forceinline__ void solve_block(const DevModel* __restrict__ m, floa
 __global__ void __launch_bounds__(64 * SOLVE_WAVES, 2) k_solve2(SOLVE2_ARGS) { SOLVE_DISPATCH }
 __global__ void __launch_bounds__(64 * SOLVE_WAVES, 2) k_settle_solve(SOLVE2_ARGS) { SOLVE_DISPATCH }
 
-/* ------------------------------------------------------------------ k_chain: all substeps of a step in ONE launch (round 4's experiment, rp_set_pipeline(h, 2)).
+/* ------------------------------------------------------------------ k_chain: all substeps of a step in ONE launch (round 4's experiment, rp_set_fused(h, 2)).
  * A block of two waves owns the same four envs (places 4 q .. 4 q + 3 of the load ranking `member`) for all nsub substeps and alternates inside itself between their
  * preparation - prep2_core, one env after the other: both waves work on one env as in k_prep2 - and their solve - solve_block, the four-env path or the two-env path as
  * their contacts demand.  The rows go through the same workspace as in the split pipeline (written and read by the same CU: L2 / L1 resident) and the pairing table is

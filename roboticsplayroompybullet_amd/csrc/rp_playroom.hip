@@ -44,7 +44,8 @@ struct rp_sim {
   int groups;              /* env groups of the default pipeline, each on its own stream (tail overlap) */
   hipStream_t gstream[RP_MAX_GROUPS];
   hipEvent_t gfork, gjoin[RP_MAX_GROUPS];
-  int fused;               /* 0: split pipeline (default), 1: single fused k_step kernel (in-library reference path) */
+  int fused;               /* 0: split pipeline (default), 1: single fused k_step kernel (in-library reference path), 2: k_chain - one launch for the twelve substeps (round 4's experiment) */
+  int chain_blocks;        /* k_chain's grid (RP_CHAIN_BLOCKS at rp_create, default 1024) */
   /* rp_reset through the split pipeline (allocated at the first reset): dense scratch records of the envs that are settling,
    * their env ids, per-env progress {pending, attempt, depth}, pairing tables of the scratch range */
   float* rs_state; int* rs_idx; int4* rs_meta; int* rs_count; int* rs_sort_cnt; int* rs_sort_slot; int* rs_pair; int* rs_count_host;
@@ -94,9 +95,9 @@ extern "C" {
 #define RP_BUILD_ID "unversioned"
 #endif
 #ifdef RP_WIDE
-const char* rp_version(void) { return "rp_playroom 0.3 (gfx950, wide build: two-object play ids) build " RP_BUILD_ID; }
+const char* rp_version(void) { return "rp_playroom 0.4 (gfx950, wide build: two-object play ids) build " RP_BUILD_ID; }
 #else
-const char* rp_version(void) { return "rp_playroom 0.3 (gfx950) build " RP_BUILD_ID; }
+const char* rp_version(void) { return "rp_playroom 0.4 (gfx950) build " RP_BUILD_ID; }
 #endif
 
 static void destroy_handle(rp_sim* h) {        /* frees whatever a (possibly partial) handle owns; hipFree(nullptr) etc. are no-ops */
@@ -275,6 +276,7 @@ int rp_create(const rp_config* cfg, rp_handle* out) {
     h->groups = g ? atoi(g) : 3;      /* 3 group streams + nothing else stays within the 4 hardware queues ROCm multiplexes onto */
     if (h->groups < 1) h->groups = 1;
     if (h->groups > RP_MAX_GROUPS) h->groups = RP_MAX_GROUPS;
+    { const char* cb = getenv("RP_CHAIN_BLOCKS"); h->chain_blocks = cb ? (atoi(cb) > 0 ? atoi(cb) : 1) : 1024; }      /* k_chain's grid: 256 CUs x 4 blocks of 40 KB LDS and 2 x 217 VGPRs - everything resident at once */
     CREATE_CHK(hipEventCreateWithFlags(&h->gfork, hipEventDisableTiming));
     /* RP_GROUP_SPLIT="30,30,40": relative group sizes, heaviest group first (default: 25,35,40 for 3 groups, equal otherwise).  Stream priorities for the heavy
      * group were tried and lose (2.69 vs 2.61 ms per step). */
@@ -439,8 +441,7 @@ int rp_step(rp_handle h, const float* action, const rp_out* out, void* stream) {
     HIPCHK(h, hipMemsetAsync(cnt_next, 0, SORT_BINS * sizeof(int), s));
     hipLaunchKernelGGL(k_action, dim3((N + 3) / 4), dim3(64), 0, s, h->dev_model, h->state, action, op.target_poses, 0, N, member);
     const int nq = (N + 3) / 4;
-    const char* cb = getenv("RP_CHAIN_BLOCKS");
-    const int blocks = min(nq, cb ? max(1, atoi(cb)) : 1024);          /* 256 CUs x 4 blocks of 40 KB LDS and 2 x 217 VGPRs: everything resident at once */
+    const int blocks = min(nq, h->chain_blocks);          /* 256 CUs x 4 blocks of 40 KB LDS and 2 x 217 VGPRs: everything resident at once */
     hipLaunchKernelGGL(k_chain, dim3(blocks), dim3(64 * SOLVE_WAVES), 0, s, h->dev_model, h->state, h->ws, N, member, h->pair_env, cnt_next, h->sort_slot, K_NSUB, h->debug_flags);
     hipLaunchKernelGGL(k_calc_state, dim3(N), dim3(64), 0, s, h->dev_model, h->state, op, 0, N, member);
     h->sort_par ^= 1; h->sort_G = 1; h->gb = gb;
@@ -604,6 +605,7 @@ int rp_set_debug_flags(rp_handle h, int32_t flags) { if (!h) return RP_ERR_ARG; 
 int rp_set_groups(rp_handle h, int32_t groups) { if (!h || groups < 1 || groups > RP_MAX_GROUPS) return RP_ERR_ARG; h->groups = groups; return RP_OK; }
 int rp_set_fused(rp_handle h, int32_t fused) {
   if (!h || fused < 0 || fused > 2) return RP_ERR_ARG;
+  if (fused == 2 && h->timers_on) { snprintf(h->err, 256, "rp_set_fused: the k_chain pipeline has no per-launch timers (rp_enable_timers(h, 0) first)"); return RP_ERR_ARG; }
   if (fused != h->fused) h->sort_G = 0;          /* the load tables of one pipeline mean nothing to the other: start from the identity ranking */
   h->fused = fused;
   return RP_OK;
@@ -721,6 +723,7 @@ int rp_get_timers(rp_handle h, rp_timers* t) {
 }
 int rp_enable_timers(rp_handle h, int32_t on) {
   if (!h || on < 0) return RP_ERR_ARG;
+  if (on > 0 && h->fused == 2) { snprintf(h->err, 256, "rp_enable_timers: the k_chain pipeline (rp_set_fused(h, 2)) is one launch for twelve substeps - no per-launch timers"); return RP_ERR_ARG; }
   DevGuard guard(h->cfg.device);
   if (h->pool) { for (int i = 0; i < h->pool_steps * EV_PER_STEP; i++) hipEventDestroy(h->pool[i]); free(h->pool); h->pool = nullptr; }
   h->timers_on = on; h->pool_steps = on; h->pool_next = 0; h->pool_count = 0;

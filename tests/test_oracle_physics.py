@@ -146,7 +146,7 @@ def test_hull_vertex_contacts_against_the_reference_steps_gjk_epa():
 
 
 def test_hull_gjk_contacts_against_the_reference_steps_gjk():
-    """RPO_RULE_GJK (the library's RP_CFG_HULL_GJK; off by default): where an arm link's deepest hull vertex lies beside the box face, the fast model's
+    """RPO_RULE_GJK (the library's default since round 4; RP_CFG_OBB_EDGES / hull_gjk=False opts out): where an arm link's deepest hull vertex lies beside the box face, the fast model's
     contact comes from its own GJK distance phase (hull_box_gjk) - checked here against the frozen reference step's GJK on the SAME hull and box
     (rpo_ref_collider_distance) in the poses random playroom rollouts pass through: every point the rule makes that the model without it does not
     (same pair, another distance) has the reference's distance, normal and witness point.  Stateless contacts on both oracles, so that contacts() is

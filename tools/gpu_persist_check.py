@@ -13,7 +13,7 @@ from roboticsplayroompybullet_amd import VecPlayEnv
 kind = sys.argv[1] if len(sys.argv) > 1 else 'U'
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 n = 16
-RULE = int(os.environ['RP_ORACLE_RULE']) if 'RP_ORACLE_RULE' in os.environ else (1015 if 'RP_NO_GJK' in os.environ else None)      # default: the oracle's default rule = the shipped model; RP_GJK=1: RP_CFG_HULL_GJK against RPO_RULE_GJK
+RULE = int(os.environ['RP_ORACLE_RULE']) if 'RP_ORACLE_RULE' in os.environ else (1015 if 'RP_NO_GJK' in os.environ else None)      # default: the oracle's default rule = the shipped model; RP_NO_GJK=1: the library's RP_NO_GJK switch (= RP_CFG_OBB_EDGES) against rule 1015
 env = VecPlayEnv(IDS[kind], n, seed=9, persistent_manifolds=True); env.reset()
 fus = VecPlayEnv(IDS[kind], n, seed=9, persistent_manifolds=True); fus.set_fused(1); fus.reset()
 KW = {} if RULE is None else dict(rule=RULE)
