@@ -29,17 +29,12 @@ int rp_debug_substep(rp_handle h, int32_t env, float* host_buf);
 int rp_debug_row_counts(rp_handle h, int32_t* host_buf);
 /* rounds the most recent rp_reset took */
 int rp_debug_reset_rounds(rp_handle h);
-/* PROFILING BUILDS ONLY (tools/build_profiling_libs.sh, -DRP_CLOCKS / -DRP_PROLOGUE_CLOCKS / -DRP_CHAIN_CLOCKS; the shipped library does not export them and tests/test_abi.py
- * does not expect them): the s_memtime marks the kernels of such a build leave per wave / block, copied to the host after a device synchronise. */
-#if defined(RP_CLOCKS)
-int rp_debug_clocks(rp_handle h, uint64_t* host_buf, int32_t nwaves);
-#endif
-#if defined(RP_PROLOGUE_CLOCKS)
-int rp_debug_prologue_clocks(rp_handle h, uint64_t* host_buf, int32_t nwaves);
-#endif
-#if defined(RP_CHAIN_CLOCKS)
-int rp_debug_chain_clocks(rp_handle h, int64_t* host_buf, int32_t nblocks);
-#endif
+/* PROFILING BUILDS ONLY (tools/build_profiling_libs.sh: -DRP_CLOCKS=1|2, -DRP_PROLOGUE_CLOCKS, -DRP_CHAIN_CLOCKS).  The shipped library exports none of these and
+ * tests/test_abi.py does not expect them; such a build also exports, for the tools that load it through RP_PLAYROOM_LIB:
+ *     rp_debug_clocks(rp_handle, uint64_t* host_buf, int32_t nwaves)              s_memtime marks per wave of k_solve2 (RP_CLOCKS=1) / per block of k_prep2 (=2)
+ *     rp_debug_prologue_clocks(rp_handle, uint64_t* host_buf, int32_t nwaves)     marks of k_solve2's prologue
+ *     rp_debug_chain_clocks(rp_handle, int64_t* host_buf, int32_t nblocks)        per block of k_chain: prepare / solve totals
+ * each copies the marks of the most recent launch to the host after a device synchronise. */
 
 #ifdef __cplusplus
 }
