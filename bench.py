@@ -319,15 +319,14 @@ def main():
     if not args.no_extras and world == 1 and cem is None:
         g = torch.Generator(device=device).manual_seed(4321 + rank)
         hi = env.action_high
-        acts_a = (2 * torch.rand((args.steps + args.warmup, n, 7), generator=g, device=device) - 1) * hi
-        for k in range(args.warmup):
+        acts_a = (2 * torch.rand((pre + args.warmup + args.steps, n, 7), generator=g, device=device) - 1) * hi
+        for k in range(pre + args.warmup):          # the same floor of untimed steps for this distribution (other actions, other contact sets), every step on actions of its own
             env.step(acts_a[k])
-        for k in range(pre):                        # the same floor for this distribution (other actions, other contact sets)
-            env.step(acts_a[args.warmup + k % args.steps])
-        t_a, info_a = timed_region(env, acts_a, args.warmup, args.steps)
+        t_a, info_a = timed_region(env, acts_a, pre + args.warmup, args.steps)
         extras['distribution_A'] = {'value': n * args.steps / t_a, 'ms_per_step': 1e3 * t_a / args.steps,
                                     'what': 'a ~ U(action_space.low, action_space.high) = U(-6, 6)^6 x U(-1, 1), resampled every step (the '
-                                            'literal random-action rollout: targets mostly unreachable, the arm slews at the per-step clip)',
+                                            'literal random-action rollout: targets mostly unreachable, the arm slews at the per-step clip); continues from the headline rollout, %d untimed steps of this '
+                                            'distribution first' % (pre + args.warmup),
                                     'non_finite_envs': int((info_a['status'] & 1).sum().item())}
         env.close()
         for other in ((0.005, 0.02) if args.config == 'headline' else ()):      # uniform margins beside the default (per pair: Bullet's relative breaking thresholds)
