@@ -15,5 +15,7 @@ timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$REPO/bench.py" --steps 5 --warmup 1 --groups 1 --no-cpu-baseline --no-extras --repeats 1 > /dev/null 2> "$OUT/pmc_write.log"
 cd "$REPO"
 python3 tools/summarize_profiles.py "$OUT" "$TAG"
+cp "$OUT/summary/${TAG}_pmc_summary.json" profiles/ 2>/dev/null      # (on the box: so that the bench lines below quote this build's traffic; the copy in gpurun_out/ is what travels back)
 timeout 300 python3 bench.py > "$OUT/bench_line.json" 2> "$OUT/bench_line.log"
+timeout 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_driver_flags.json" 2>> "$OUT/bench_line.log"
 tail -c 600 "$OUT/bench_line.json"
