@@ -131,7 +131,9 @@ def test_rollout_200_steps_vs_fp64_oracle(kind):
     assert len(unexplained) <= n // 50, 'envs %s: device %s, fp32 CPU oracle %s' % (unexplained, d_hip[unexplained], d_o32[unexplained])
     assert bad.size <= (2 if kind == 'U' else 1) and (d_hip[bad] <= 2e-2).all(), (bad, d_hip[bad])      # measured (round 4): U one env (a marginal IK stop), the others none
     assert (g_hip <= GRIP_JOINT_TOL).all(), g_hip
-    assert strict.sum() >= (59 if kind == 'U' else n - 1), strict.sum()      # measured (round 4): U 60 of 64 (the fp32 CPU oracle itself: 51), R / P / Q / V 8 of 8 - asserted: the measured count less one
+    # measured (round 4): U 60 of 64 (the fp32 CPU oracles, the worst of their runs per env: 51), R / P / Q / V 8 of 8.  Held against the CPU runs' own count (a
+    # compiler bump that moves one marginal env moves both sides) and, more loosely than before, against the measured one
+    assert strict.sum() >= int((d_o32 <= 1e-3).sum()) and strict.sum() >= (56 if kind == 'U' else n - 1), (strict.sum(), int((d_o32 <= 1e-3).sum()))
     # status bit 8 (the IK ran out of its 4 x 20 / 200 iterations in that step; the joint targets then hang on the measured joints): how common it is, and
     # whether the envs that leave 1e-3 are the ones where it happens most - reported, not asserted: with a new random target every step it happens in
     # every env sooner or later, so it cannot single envs out

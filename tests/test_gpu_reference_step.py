@@ -82,6 +82,8 @@ def test_hip_vs_frozen_reference_step(kind):
             qo = o.get_state()[:n_main]
             d = float((np.abs(q[e] - qo) / np.maximum(1.0, np.abs(qo))).max())
             d_all[e] = max(d_all[e], d)
+            twins[e].step(acts[t, e].astype(np.float32).astype(np.float64))
+            d_twin[e] = max(d_twin[e], float((np.abs(twins[e].get_state()[:n_main] - qo) / np.maximum(1.0, np.abs(qo))).max()))
             if not touched[e]:
                 d_free[e] = max(d_free[e], d)
                 g_free[e] = max(g_free[e], max(float((np.abs(x.get_state()[:n_main] - qo) / np.maximum(1.0, np.abs(qo))).max()) for x in nudged[e]))
@@ -100,7 +102,7 @@ def test_hip_vs_frozen_reference_step(kind):
 # by 5 mm in the reference step's state.
 IDS_CONTACT = {'U': 'UR5PlayAbsRPY1Obj-v0', 'P': 'pandaPick-v0'}
 # bounds one notch above the measured values (round 4, GJK on: printed by the test)
-BOUNDS_CONTACT = {'U': dict(median=6e-4, within=8), 'P': dict(median=3e-5, within=14)}      # measured: U median 4.2e-4, 9 of 16; P median 1.2e-5, 15 of 16
+BOUNDS_CONTACT = {'U': dict(median=6e-4, within=8), 'P': dict(median=3e-5, within=15)}      # measured: U median 4.2e-4, 9 of 16; P median 5.4e-6, 16 of 16, max 5.6e-5 (round 5, the expanding polytope; round 4: 1.2e-5, 15 of 16)
 
 
 def arm_clear(o, pairs=None, gap=0.005):
@@ -141,8 +143,13 @@ def test_hip_vs_frozen_reference_step_with_arm_contacts(kind):
     for o in refs:
         o.reset()
     env.set_state(torch.tensor(np.stack([record_from_oracle(o) for o in refs])))
+    # the fast model's own fp32 CPU oracle on the same rollout: what the MODEL parts from the reference step by, in one more evaluation order - the device's counts are held
+    # against its counts (thresholds relative to the CPU runs, not to measured constants alone)
+    twins = [OracleEnv(kind, seed=77, env_index=e, f32=True) for e in range(n)]
+    for o, r in zip(twins, refs):
+        o.set_state(r.get_state())
     acts = np.stack([md.random_actions(kind, steps, np.random.default_rng(1000 + e)) for e in range(n)], axis=1)
-    d_free, d_all = np.zeros(n), np.zeros(n)
+    d_free, d_all, d_twin = np.zeros(n), np.zeros(n), np.zeros(n)
     pairs = refs[0].pair_list()
     clear = np.array([arm_clear(o, pairs) for o in refs])
     first = np.where(clear, steps, 0)
@@ -157,6 +164,8 @@ def test_hip_vs_frozen_reference_step_with_arm_contacts(kind):
             qo = o.get_state()[:n_main]
             d = float((np.abs(q[e] - qo) / np.maximum(1.0, np.abs(qo))).max())
             d_all[e] = max(d_all[e], d)
+            twins[e].step(acts[t, e].astype(np.float32).astype(np.float64))
+            d_twin[e] = max(d_twin[e], float((np.abs(twins[e].get_state()[:n_main] - qo) / np.maximum(1.0, np.abs(qo))).max()))
             if clear[e]:
                 d_free[e] = max(d_free[e], d)
         assert int((info['status'] & 1).sum()) == 0
@@ -165,4 +174,7 @@ def test_hip_vs_frozen_reference_step_with_arm_contacts(kind):
           'median %.2e p75 %.2e max %.2e, %d envs within 1e-3' % (kind, n, steps, int(np.median(first)), int(first.min()), d_free.max(), np.median(d_all), np.percentile(d_all, 75), d_all.max(), within))
     assert (d_free <= TOL).all(), d_free
     b = BOUNDS_CONTACT[kind]
+    within_twin = int((d_twin <= TOL).sum())
+    print('    the fast model\'s fp32 CPU oracle on the same rollout: median %.2e, %d envs within 1e-3' % (np.median(d_twin), within_twin))
     assert np.median(d_all) <= b['median'] and within >= b['within'], (np.median(d_all), within, d_all)
+    assert within >= within_twin - 2 and np.median(d_all) <= max(3 * np.median(d_twin), 1e-5), (within, within_twin, np.median(d_all), np.median(d_twin))
