@@ -1200,7 +1200,7 @@ __device__ __forceinline__ void hull_item16(const DevModel* m, LDS& L, const int
 }
 
 template <class LDS>
-__device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int lane, int nact, float* __restrict__ gax) {      /* gax: the env's cached GJK results (contact cache row + PMC_AX), nullptr without the cache */
+__device__ __forceinline__ int narrowphase_coop(const DevModel* m, LDS& L, int lane, int nact, float* __restrict__ gax) {      /* returns the number of candidate points stored (wave-uniform) */      /* gax: the env's cached GJK results (contact cache row + PMC_AX), nullptr without the cache */
   const int g = lane >> 3, s = lane & 7;
   float* scr = &L.npscr[NPG_SCRATCH * g];
   float* sv = scr;
@@ -1541,6 +1541,7 @@ __device__ __forceinline__ void narrowphase_coop(const DevModel* m, LDS& L, int 
     if (act && s == 0) L.candn[ai] = nst | (min(off, CANDMAX) << 8);
     WSYNC();       /* the scratch is reused by the next pass */
   }
+  return min(cbase, CANDMAX);
 }
 
 /* btPersistentManifold::sortCachedPoints on points stored as 8-float records (p3 n3 dist pad) */
@@ -1599,7 +1600,7 @@ __device__ __forceinline__ int collide(const DevModel* m, LDS& L, int lane, int 
   if (lane == 0) g_clk[32 * (blockIdx.x & 4095) + 12] = nact;
 #endif
   /* 2. narrowphase: eight lanes per active pair */
-  narrowphase_coop<LDS>(m, L, lane, nact, m->persist ? m->pmcache + (size_t)env * PMC_FLOATS + PMC_AX : nullptr);
+  const int ncand_all = uni(narrowphase_coop<LDS>(m, L, lane, nact, m->persist ? m->pmcache + (size_t)env * PMC_FLOATS + PMC_AX : nullptr));
   WSYNC();
   asm volatile("" : "+v"(lane));                          /* (the lane number once more, opaque: addresses the manifold stage derives from it are computed there, not held across the narrowphase) */
   PCLK(9)
@@ -1632,8 +1633,9 @@ __device__ __forceinline__ int collide(const DevModel* m, LDS& L, int lane, int 
     int npm = uni(__float_as_int(C[0]));
     {                                                        /* (a) */
       const int mykey = lane < npm ? __float_as_int(C[PMC_HDR + PMC_MAN * lane]) : -1;
+      const int akey = L.key[lane < nact ? lane : 0];      /* pair k's key waits in lane k: the loops below read lanes, not LDS (a dependent LDS round trip per iteration until round 5) */
       bool touched = false; int fl = 0;
-      for (int k = 0; k < nact; k++) { const int kk = L.key[k]; if ((kk & 0xFFFF) == mykey) { touched = true; fl = kk >> 16; } }
+      for (int k = 0; k < nact; k++) { const int kk = __builtin_amdgcn_readlane(akey, k); if ((kk & 0xFFFF) == mykey) { touched = true; fl = kk >> 16; } }
       if (touched) C[PMC_HDR + PMC_MAN * lane + 3] = __int_as_float(fl);
       const unsigned long long keep = __ballot(touched);
       WSYNC();
@@ -1649,8 +1651,9 @@ __device__ __forceinline__ int collide(const DevModel* m, LDS& L, int lane, int 
     {                                                        /* (b) the collider pairs of one object pair are neighbours in the pair list */
       const int objk = lane < nact ? (L.key[lane] & 0xFFFF) : -1;
       const bool first = lane < nact && (lane == 0 || (L.key[lane - 1] & 0xFFFF) != objk);
+      const int mkey = __float_as_int(C[PMC_HDR + PMC_MAN * (lane < npm ? lane : 0)]);      /* (after the ranks closed) manifold j's key in lane j */
       bool present = false;
-      for (int j = 0; j < npm; j++) present |= __float_as_int(C[PMC_HDR + PMC_MAN * j]) == objk;
+      for (int j = 0; j < npm; j++) present |= __builtin_amdgcn_readlane(mkey, j) == objk;
       const bool isnew = first && !present;
       const unsigned long long mnew = __ballot(isnew);
       const int slot = npm + __popcll(mnew & lower);
@@ -1672,18 +1675,16 @@ __device__ __forceinline__ int collide(const DevModel* m, LDS& L, int lane, int 
      * in its first substep: rare) go in afterwards, one after the other, in the lane of their manifold */
     unsigned long long unmatched, mine = 0ull;      /* candidates that matched no cached point: all of them | those of manifold `lane` */
     {
-      int ncand = 0;
-      if (lane < nact) { const int cn = L.candn[lane]; ncand = (cn >> 8) + (cn & 255); }
-#pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) ncand = max(ncand, __shfl_xor(ncand, d));
+      const int ncand = ncand_all;                          /* (the narrowphase's own count: six dependent cross-lane maxima over the pairs' counts until round 5) */
       const bool isc = lane < ncand;
       const float* c = &L.cand[8 * (isc ? lane : 0)];
       const V3 p = ld3(c), nr = mk3(c[3], c[4], c[5]);
       const float dist = c[6];
       const int abw = __float_as_int(c[7]);
       const int objk = L.key[(abw >> 16) & 63] & 0xFFFF;
+      const int mkey = __float_as_int(C[PMC_HDR + PMC_MAN * (lane < npm ? lane : 0)]);      /* manifold j's key in lane j (the new ones included) */
       int mi = -1;
-      for (int jm = 0; jm < npm; jm++) if (__float_as_int(C[PMC_HDR + PMC_MAN * jm]) == objk) mi = jm;
+      for (int jm = 0; jm < npm; jm++) if (__builtin_amdgcn_readlane(mkey, jm) == objk) mi = jm;
       if (!isc) mi = -1;
       const float* M = &C[PMC_HDR + PMC_MAN * (mi >= 0 ? mi : 0)];
       const float thr = M[2];
