@@ -2215,6 +2215,12 @@ __device__ __forceinline__ void contact_rows(const DevModel* m, LDS& L, int lane
     int bodyA = m->col_body[L.cona[ci]], bodyB = m->col_body[L.conb[ci]];
     bool any_arm = (bodyA >= 1 && bodyA <= n) || (bodyB >= 1 && bodyB <= n);
     int nother = 0;
+    /* (round 5) the arm's entries accumulate in registers and every loop over the arm's dofs in this function is unrolled to RP_MAX_ARM with its loads unconditional: as rolled
+     * loops with a run-time bound each iteration was a dependent LDS round trip - a read-modify-write of J[k] here, two or three loads per term in passes B and C - and the
+     * rows after the join are the tail of every k_prep2 block (10 k cycles at the median, 18 - 33 k in the heavy ones).  Same terms, same order. */
+    float Jr[RP_MAX_ARM];
+#pragma unroll
+    for (int k = 0; k < RP_MAX_ARM; k++) Jr[k] = 0.f;
     for (int side = 0; side < 2; side++) {
       int body = side == 0 ? bodyA : bodyB;
       float sign = side == 0 ? 1.f : -1.f;
@@ -2223,9 +2229,11 @@ __device__ __forceinline__ void contact_rows(const DevModel* m, LDS& L, int lane
       if (body <= n) {
         V6 f; f.a = tors ? d : cross(p - O, d); f.l = tors ? mk3(0, 0, 0) : d;
         uint32_t anc = m->arm_anc[body - 1];
-#pragma unroll 1
-        for (int k = 0; k < n; k++)
-          if ((anc >> k) & 1u) J[k] += sign * dot6(ld6(&L.S[6 * k]), f);
+#pragma unroll
+        for (int k = 0; k < RP_MAX_ARM; k++) {
+          const float v = sign * dot6(ld6(&L.S[6 * k]), f);
+          Jr[k] = (k < n && ((anc >> k) & 1u)) ? Jr[k] + v : Jr[k];
+        }
         has_arm = true;
         continue;
       }
@@ -2259,7 +2267,11 @@ __device__ __forceinline__ void contact_rows(const DevModel* m, LDS& L, int lane
         if (base == 0) off0 = dd; else off1 = dd;
       }
     }
-    if (has_arm) off0 = 0;
+    if (has_arm) {
+      off0 = 0;
+#pragma unroll
+      for (int k = 0; k < RP_MAX_ARM; k++) if (k < n) J[k] = Jr[k];
+    }
     float* s = &L.rowS[4 * r];
     s[0] = diag; s[1] = relv; s[2] = dir == 0 ? 0.f : (tors ? L.tors[r - nc] : L.conmu[ci]); s[3] = __int_as_float(dir == 0 ? 0 : ci);
     float* t = &L.rowT[4 * r];
@@ -2272,7 +2284,8 @@ __device__ __forceinline__ void contact_rows(const DevModel* m, LDS& L, int lane
       const float* J = &L.J[r * ROWW];
       const float* Mi = &L.Minv[i * 12];
       float b = 0.f;
-      for (int k = 0; k < n; k++) b += Mi[k] * J[k];
+#pragma unroll
+      for (int k = 0; k < RP_MAX_ARM; k++) { const float t = Mi[k] * J[k]; b = k < n ? b + t : b; }
       L.B[r * ROWW + i] = b;
     }
   }
@@ -2284,7 +2297,8 @@ __device__ __forceinline__ void contact_rows(const DevModel* m, LDS& L, int lane
     if (__float_as_int(t[0]) != 0) {
       const float* J = &L.J[r * ROWW];
       const float* B = &L.B[r * ROWW];
-      for (int i = 0; i < n; i++) { diag += J[i] * B[i]; relv += J[i] * L.vstar[i]; }
+#pragma unroll
+      for (int i = 0; i < RP_MAX_ARM; i++) { const float jb = J[i] * B[i], jv = J[i] * L.vstar[i]; diag = i < n ? diag + jb : diag; relv = i < n ? relv + jv : relv; }
     }
     float dinv, rhs, cfmr = 0.f;
     if (r < nc) {
