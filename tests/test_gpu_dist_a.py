@@ -49,7 +49,7 @@ def leave_step(trace, bound):
     return int(over[0]) if over.size else len(trace)
 
 
-@pytest.mark.parametrize('kind,n,steps,scenario', [('U', 64, 200, 'A'), ('P', 16, 100, 'A'), ('V', 16, 100, 'A'), ('P', 12, 110, 'grasp')])
+@pytest.mark.parametrize('kind,n,steps,scenario', [('U', 64, 200, 'A'), ('P', 16, 100, 'A'), ('V', 16, 100, 'A'), ('P', 12, 110, 'grasp'), ('U', 32, 100, 'A+epa')])
 def test_distribution_a_lockstep_with_contact_history(kind, n, steps, scenario):
     """The device runs `steps` steps of distribution A free.  Before every step each env's fp32 oracle takes the device's record and cache row; after it the two are
     compared, in two parts:
@@ -62,15 +62,23 @@ def test_distribution_a_lockstep_with_contact_history(kind, n, steps, scenario):
     cached GJK pairs in all but a per cent of the env-steps.  scenario 'grasp' (pandaPick): the same comparison along the grasp-and-lift script of
     tests/test_gpu_fixtures.py::test_panda_pick_grasp_and_lift instead of random actions - the fingers' soft pads on the block, the finger gear, arm-against-block rows; that
     test judges the chaotic lift by its outcome, this one holds every step of it to the oracle.  RP_LOCKSTEP_DUMP=<dir> saves the first cases in which the caches differ although the arm agrees to 1e-6
-    (pre-step row, action, the device's targets, both post-step rows) for replay on the CPU (tools/lockstep_replay.py)."""
+    (pre-step row, action, the device's targets, both post-step rows) for replay on the CPU (tools/lockstep_replay.py).  scenario 'A+epa': the UR5 id with the expanding polytope
+    forced on (hull_epa=True / RP_CFG_HULL_EPA, oracle rule | 131072: the Panda ids have it by default) - arms lying IN the furniture under A are where the polytope runs most
+    (0.11 calls per env-substep), on the UR5's hulls of up to 1 000 vertices."""
     from gpu_debug import oracle_state_from_record
     from oracle import OracleEnv
     from roboticsplayroompybullet_amd import VecPlayEnv
-    env = VecPlayEnv(IDS[kind], n, seed=31)
+    epa = scenario == 'A+epa'
+    if epa:
+        scenario = 'A'
+    env = VecPlayEnv(IDS[kind], n, seed=31, hull_epa=True if epa else None)
     env.reset()
     obs = env.calc_state()
     acts = actions_a(env, steps, 7)
     ora = [OracleEnv(kind, seed=31, env_index=e, f32=True) for e in range(n)]
+    if epa:
+        for o in ora:
+            o.lib.rpo_set_rule(o.h, o.lib.rpo_get_rule(o.h) | 131072)
     for e, o in enumerate(ora):
         o.reset()
         o.step(acts[0, e].astype(np.float64))          # (motor modes; every action re-commands every motor, environments.py:1010-1073)
@@ -160,7 +168,7 @@ def test_distribution_a_lockstep_with_contact_history(kind, n, steps, scenario):
     assert np.median(d_arm[ok]) <= 1e-5
     assert (d_arm[ok] > 1e-3).mean() <= 0.01, (d_arm[ok] > 1e-3).mean()
     assert same[ok].mean() >= (0.95 if scenario == 'grasp' else 0.97), same[ok].mean()      # (grasp: the block between the soft pads makes and breaks points every substep: 96.6 - 99.9 % measured)
-    assert np.nanquantile(gap, 0.99) <= (1e-3 if scenario == "grasp" else 1e-4), np.nanquantile(gap, 0.99)      # (the block between the soft pads: 1.7e-4 .. 5.8e-4 measured)
+    assert np.nanquantile(gap, 0.99) <= (1e-3 if scenario == "grasp" else (2e-4 if epa else 1e-4)), np.nanquantile(gap, 0.99)      # (the block between the soft pads: 1.7e-4 .. 5.8e-4 measured; U with the polytope: 1.1e-4, without: 8.5e-5)
     assert np.median(d_ik[ok]) <= 1e-3, np.median(d_ik[ok])
 
 
