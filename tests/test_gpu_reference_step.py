@@ -82,8 +82,6 @@ def test_hip_vs_frozen_reference_step(kind):
             qo = o.get_state()[:n_main]
             d = float((np.abs(q[e] - qo) / np.maximum(1.0, np.abs(qo))).max())
             d_all[e] = max(d_all[e], d)
-            twins[e].step(acts[t, e].astype(np.float32).astype(np.float64))
-            d_twin[e] = max(d_twin[e], float((np.abs(twins[e].get_state()[:n_main] - qo) / np.maximum(1.0, np.abs(qo))).max()))
             if not touched[e]:
                 d_free[e] = max(d_free[e], d)
                 g_free[e] = max(g_free[e], max(float((np.abs(x.get_state()[:n_main] - qo) / np.maximum(1.0, np.abs(qo))).max()) for x in nudged[e]))
