@@ -124,6 +124,7 @@ def load(f32=False, bullet_ref=False, abx=False):
     lib.rpo_contacts.argtypes = [vp, dp, C.c_int]
     lib.rpo_last_num_rows.argtypes = [vp]
     lib.rpo_contact_substeps.argtypes = [vp]
+    lib.rpo_residual_substeps.argtypes = [vp]
     lib.rpo_arm_table.argtypes = [vp, dp]
     lib.rpo_collider_dynamics.argtypes = [vp, dp]
     lib.rpo_set_arm_q.argtypes = [vp, dp]

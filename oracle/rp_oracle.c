@@ -55,6 +55,9 @@
                                             * of the four-tier partition the HIP library's two-stream solver needs (solver_order) */
 #define RPO_RULE_EPA 131072         /* ... and where GJK finds the CORES overlapping (its simplex a tetrahedron around the origin): the expanding-polytope algorithm on the two cores - exact for polytopes -
                                      * gives depth, normal and witness points; the margins add 2 x 0.001 along the same normal (hull_box_epa).  Without the bit: the OBB path, as in round 4 */
+#define RPO_RULE_RESIDUAL 262144    /* the RESIDUAL (Delassus) form of the sequential-impulse sweeps for the envs the HIP library solves on its one-env-per-wave path: coupled envs (a contact
+                                     * that spans the two halves of the velocity layout) or envs with more contacts of one half than the four-env path has slots, with at most RES_MAX_CON
+                                     * contacts (solve_rows_residual).  Same rows, same order, same clamps; J . dv is carried along row by row instead of being summed anew: other rounding */
 #define RPO_RULE_GJK 1024           /* ... and where the deepest vertex lies BESIDE the face (box edges and corners): GJK's distance phase on hull and box (hull_box_gjk) */
 #define RPO_RULE_HULLFACE 4         /* arm links touch static boxes with the vertices of their collision meshes' convex hulls (hull_face) instead of their OBBs */
 #define HULL_MARGIN ((real)RP_HULL_MARGIN)
@@ -94,6 +97,7 @@ typedef struct {
   real cfm;            /* contact softness (cfm * dinv): the row's step also subtracts lambda * cfm */
   int fric_parent;     /* >=0: friction row, limits = -+mu*lambda[parent] */
   real mu;
+  int utype;           /* 1: the motor row of a dof (arm motor, scene-joint motor); 2: a joint-limit row; 0: everything else */
 } row;
 
 struct rpo_env {
@@ -123,6 +127,7 @@ struct rpo_env {
   xform xc[RP_MAX_COL]; real aabb_lo[RP_MAX_COL][3], aabb_hi[RP_MAX_COL][3];
   contact con[MAX_CONTACTS]; int ncon;
   row rows[MAX_ROWS]; int nrows, n_noncontact, n_tors;
+  int residual_substeps;            /* substeps so far solved in the residual form (RPO_RULE_RESIDUAL) */
   int contact_substeps;             /* substeps so far whose solve had at least one contact row (tests: where does a rollout stop being free motion) */
   /* RPO_RULE_PERSIST: the contact cache - one manifold per object pair in creation order, <= 4 points each, kept in the two bodies' frames */
   struct { int oa, ob, n; real thr; struct { int ca, cb; real lA[3], lB[3], n[3], pA[3], pB[3], dist; } pt[4]; } pm[PM_MAX];
@@ -1109,20 +1114,26 @@ static void collide_persistent(rpo_env* e) {
   if (!(e->rule & RPO_RULE_CREATION_ORDER)) solver_order(e);
 }
 
-static void solver_order(rpo_env* e) {
+/* which halves of the HIP library's velocity layout a contact touches (half 0: the arm and the free bodies of rp_model.free_row0 - the rotation-locked drawer; half 1:
+ * the other free bodies and the scene joints), and whether it joins the arm with a movable body */
+static void contact_halves(const rpo_env* e, const contact* c, int* half0, int* half1, int* arm, int* movable) {
   const rp_model* m = &e->m;
+  *half0 = *half1 = *arm = *movable = 0;
+  for (int side = 0; side < 2; side++) {
+    int b = m->col_body[side == 0 ? c->ca : c->cb];
+    if (b == 0) continue;
+    int f = b - 1 - m->n_arm;
+    if (b <= m->n_arm) *arm = 1; else *movable = 1;
+    if (b <= m->n_arm || (f < m->n_free && ((m->free_row0 >> f) & 1))) *half0 = 1; else *half1 = 1;
+  }
+}
+static void solver_order(rpo_env* e) {
   {
     contact tmp[MAX_CONTACTS]; int k = 0;
     for (int pass = 0; pass < 4; pass++)
       for (int i = 0; i < e->ncon; i++) {
-        int half0 = 0, half1 = 0, arm = 0, movable = 0;
-        for (int side = 0; side < 2; side++) {
-          int b = m->col_body[side == 0 ? e->con[i].ca : e->con[i].cb];
-          if (b == 0) continue;
-          int f = b - 1 - m->n_arm;
-          if (b <= m->n_arm) arm = 1; else movable = 1;
-          if (b <= m->n_arm || (f < m->n_free && ((m->free_row0 >> f) & 1))) half0 = 1; else half1 = 1;
-        }
+        int half0, half1, arm, movable;
+        contact_halves(e, &e->con[i], &half0, &half1, &arm, &movable);
         if (2 * (half0 && half1) + (arm && movable) == pass) tmp[k++] = e->con[i];
       }
     for (int i = 0; i < e->ncon; i++) e->con[i] = tmp[i];
@@ -1459,6 +1470,7 @@ static void build_rows(rpo_env* e, const real* vstar) {
       for (int i = 0; i < m->n_arm; i++) {
         row* r = new_row(e);
         real tau[RP_MAX_ARM] = {0};
+        r->utype = 1;
         tau[i] = 1;
         r->J[i] = 1;
         arm_impulse_response(e, -1, 0, tau, r->B);
@@ -1470,6 +1482,7 @@ static void build_rows(rpo_env* e, const real* vstar) {
     } else if (what == 1) { /* scene joint motors: button position motor (scenes.py:238), default velocity motors on door and dial */
       for (int k = 0; k < m->n_joint1; k++) {
         row* r = new_row(e);
+        r->utype = 1;
         int d = dof_j1(e, k);
         real minv = m->j1_type[k] == 1 ? 1 / (real)m->j1_mass[k] : 1 / (real)m->j1_inertia_axis[k];
         r->J[d] = 1; r->B[d] = minv; r->dinv = 1 / minv;
@@ -1489,6 +1502,7 @@ static void build_rows(rpo_env* e, const real* vstar) {
           if (blimit ? pen > 0 : pen > LIMIT_ACTIVATION) continue;
           real sgn = side == 0 ? (real)1 : (real)-1;
           row* r = new_row(e);
+          r->utype = 2;
           real tau[RP_MAX_ARM] = {0};
           tau[i] = sgn;
           r->J[i] = sgn;
@@ -1608,12 +1622,123 @@ static void solve_one(rpo_env* e, row* r, real lo, real hi, real* dv) {
   r->lambda += d;
   for (int i = 0; i < nv; i++) dv[i] += r->B[i] * d;
 }
+/* RPO_RULE_RESIDUAL.  Which envs: the ones the HIP library's k_solve2 cannot put on its four-env path (rp_kernels.cuh solve4_eligible: no contact that spans the two halves
+ * of the velocity layout, at most S4_SLOTS0 = 8 contacts of half 0 and S4_SLOTS1 = 16 of half 1) and whose rows fit the 64 lanes of one wave (RES_MAX_CON contacts: 14
+ * normals, 14 + 14 friction rows, 4 torsional rows, the gear, 12 + 3 dofs with unit rows).  A property of the env's own contact list: never of who shares a wave with whom. */
+#define RES_MAX_CON 14
+#define RES_SLOTS0 8
+#define RES_SLOTS1 16
+static int residual_form(const rpo_env* e) {
+  if (!(e->rule & RPO_RULE_RESIDUAL)) return 0;
+  int n0 = 0, n1 = 0, nspan = 0;
+  for (int i = 0; i < e->ncon; i++) {
+    int half0, half1, arm, movable;
+    contact_halves(e, &e->con[i], &half0, &half1, &arm, &movable);
+    if (half0 && half1) nspan++; else if (half0) n0++; else n1++;
+  }
+  return (nspan > 0 || n0 > RES_SLOTS0 || n1 > RES_SLOTS1) && e->ncon <= RES_MAX_CON;
+}
+/* The sweeps in residual form (the HIP library's heavy_solve, one env per wave).  A "lane" carries one number through the sweeps, the row's UNCLAMPED STEP
+ *   r = rhs - lambda cfm - Jd . dv        (Bullet's deltaImpulse before its clamp, resolveSingleConstraintRowGeneric)
+ * kept up to date instead of being summed anew:
+ *   - row lane g (the gear, every contact normal, torsional and friction row): r_g;
+ *   - dof lane d (arm dofs and scene-joint dofs - the dofs that have unit rows): r_d of the dof's MOTOR row; the limit rows of the dof read it plus the difference of
+ *     the right-hand sides (same Jd: the sign of a limit row is folded into its rhs and bounds, which is exact).
+ * Row step of row r: t = its lane's number; d = clamp(t, lo - lambda, hi - lambda); lambda += d; then EVERY lane l takes r_l = fma(-C[l][r], d, r_l) with
+ *   C[g][r] = Jd_g . B_r (summed over the dofs in ascending order with fused multiply-adds from zero), plus the row's own softness cfm_g when r = g;
+ *   C[d][r] = Jd_d B_r[d] for a dof lane (Jd_d = the motor row's folded entry).
+ * No velocity is carried: after the sweeps dv = sum over ALL rows of B_r lambda_r, in the order motors, lower limits, upper limits (dof by dof each), scene-joint
+ * motors, gear, then the contact rows in the HIP workspace's order (normals, friction pairs, torsional rows), with fused multiply-adds from zero.  Same rows, same
+ * order, same clamps as solve_rows below: in exact arithmetic its dv form line by line. */
+static void solve_rows_residual(rpo_env* e, real* dv) {
+  const rp_model* m = &e->m;
+  const int nv = e->nv, nnc = e->n_noncontact, nr = e->nrows;
+  int unit_dof[MAX_ROWS];             /* >= 0: a unit row (one entry of J) on that dof; -1: a row with a lane of its own */
+  int motor_of[RP_MAX_NV];            /* dof lane -> its motor row */
+  static _Thread_local real C[MAX_ROWS][MAX_ROWS];      /* row lanes: C[g][k] */
+  real rr[MAX_ROWS], rd[RP_MAX_NV], off[MAX_ROWS], sgn[MAX_ROWS];
+  for (int d = 0; d < nv; d++) { motor_of[d] = -1; rd[d] = 0; }
+  for (int ri = 0; ri < nr; ri++) {
+    const row* r = &e->rows[ri];
+    int nz = 0, last = -1;
+    for (int d = 0; d < nv; d++) if (r->J[d] != 0) { nz++; last = d; }
+    unit_dof[ri] = (ri < nnc && r->utype != 0 && nz == 1) ? last : -1;
+    rr[ri] = r->rhs; off[ri] = 0; sgn[ri] = 1;
+  }
+  for (int ri = 0; ri < nnc; ri++) if (unit_dof[ri] >= 0 && e->rows[ri].utype == 1) { motor_of[unit_dof[ri]] = ri; rd[unit_dof[ri]] = e->rows[ri].rhs; }
+  for (int ri = 0; ri < nnc; ri++) {
+    const int d = unit_dof[ri];
+    if (d < 0 || motor_of[d] == ri) continue;
+    /* a limit row: J = sgn Jd_motor; in the motor row's sign convention its rhs is sgn rhs, its step sgn d, its bounds sgn [lo, hi] */
+    sgn[ri] = e->rows[ri].J[d] * e->rows[motor_of[d]].J[d] < 0 ? (real)-1 : (real)1;
+    off[ri] = sgn[ri] * e->rows[ri].rhs - e->rows[motor_of[d]].rhs;
+  }
+  for (int g = 0; g < nr; g++) {
+    if (unit_dof[g] >= 0) continue;
+    for (int k = 0; k < nr; k++) {
+      real acc = 0;
+      for (int d = 0; d < nv; d++) acc = R_FMA(e->rows[g].J[d], e->rows[k].B[d], acc);
+      C[g][k] = k == g ? acc + e->rows[g].cfm : acc;
+    }
+  }
+#define RES_STEP(ri_, lo_, hi_) do { \
+    row* r_ = &e->rows[ri_]; \
+    const int ud_ = unit_dof[ri_]; \
+    const real s_ = sgn[ri_]; \
+    /* (in the motor row's sign convention: t, the bounds and the step times sgn; lambda itself stays the row's own) */ \
+    const real t_ = ud_ >= 0 ? rd[ud_] + off[ri_] : rr[ri_]; \
+    const real lam_ = s_ * r_->lambda; \
+    real lo2_ = s_ * (lo_) - lam_, hi2_ = s_ * (hi_) - lam_; \
+    if (lo2_ > hi2_) { const real x_ = lo2_; lo2_ = hi2_; hi2_ = x_; } \
+    const real d_ = t_ < lo2_ ? lo2_ : (t_ > hi2_ ? hi2_ : t_); \
+    r_->lambda = s_ * (lam_ + d_); \
+    for (int dd_ = 0; dd_ < nv; dd_++) if (motor_of[dd_] >= 0) rd[dd_] = R_FMA(-(e->rows[motor_of[dd_]].J[dd_] * (s_ * r_->B[dd_])), d_, rd[dd_]); \
+    for (int g_ = 0; g_ < nr; g_++) if (unit_dof[g_] < 0) rr[g_] = R_FMA(-(s_ * C[g_][ri_]), d_, rr[g_]); \
+  } while (0)
+  for (int it = 0; it < N_ITER; it++) {
+    for (int j = 0; j < nnc; j++) {
+      const int ri = ((e->rule & RPO_RULE_ORDER) && !(it & 1)) ? nnc - 1 - j : j;
+      RES_STEP(ri, e->rows[ri].lo, e->rows[ri].hi);
+    }
+    for (int ri = nnc; ri < nr; ri++) {
+      row* r = &e->rows[ri];
+      if (r->fric_parent >= 0) {
+        real tot = e->rows[r->fric_parent].lambda;
+        if (!(tot > 0)) continue;
+        real lim = r->mu * tot;
+        RES_STEP(ri, -lim, lim);
+      } else RES_STEP(ri, r->lo, r->hi);
+    }
+  }
+#undef RES_STEP
+  /* dv = sum of B_r lambda_r: motors, lower limits, upper limits (dof by dof), scene-joint motors, gear, normals, friction pairs, torsional rows */
+  const int n0 = nnc, nc = e->ncon, nt = e->n_tors;
+  int order[MAX_ROWS], no = 0;
+  for (int pass = 0; pass < 3; pass++)
+    for (int d = 0; d < m->n_arm; d++)
+      for (int ri = 0; ri < nnc; ri++) {
+        if (unit_dof[ri] != d) continue;
+        const int is_motor = motor_of[d] == ri;
+        if (pass == 0 ? is_motor : (!is_motor && (pass == 1) == (sgn[ri] > 0))) order[no++] = ri;
+      }
+  for (int ri = 0; ri < nnc; ri++) if (unit_dof[ri] >= m->n_arm) order[no++] = ri;
+  for (int ri = 0; ri < nnc; ri++) if (unit_dof[ri] < 0) order[no++] = ri;
+  for (int c = 0; c < nc; c++) order[no++] = n0 + c;
+  for (int f = 0; f < 2 * nc; f++) order[no++] = n0 + nc + nt + f;
+  for (int t = 0; t < nt; t++) order[no++] = n0 + nc + t;
+  for (int d = 0; d < nv; d++) {
+    real acc = 0;
+    for (int k = 0; k < no; k++) acc = R_FMA(e->rows[order[k]].B[d], e->rows[order[k]].lambda, acc);
+    dv[d] = acc;
+  }
+}
 static void solve_rows(rpo_env* e, real* dv) {
   int nv = e->nv, nnc = e->n_noncontact;
   for (int ri = 0; ri < e->nrows; ri++) {
     row* r = &e->rows[ri];
     for (int i = 0; i < nv; i++) r->J[i] *= r->dinv;
   }
+  if (residual_form(e)) { e->residual_substeps++; solve_rows_residual(e, dv); return; }
   for (int it = 0; it < N_ITER; it++) {
     for (int j = 0; j < nnc; j++) {      /* RPO_RULE_ORDER: backwards in the even sweeps (the first one), forwards in the odd ones */
       row* r = &e->rows[((e->rule & RPO_RULE_ORDER) && !(it & 1)) ? nnc - 1 - j : j];
@@ -2618,7 +2743,7 @@ rpo_env* rpo_create(int kind, unsigned long long seed, int env_index) {
   e->nbody = 1 + m->n_arm + m->n_free + m->n_joint1;
   e->seed = seed; e->env_index = (uint32_t)env_index;
   e->rule = RPO_RULE_ORDER | RPO_RULE_LIMIT | RPO_RULE_HULLFACE | RPO_RULE_BOXOVERLAP | RPO_RULE_ODEORDER | RPO_RULE_LEVER | RPO_RULE_SPIN | RPO_RULE_PERSIST | RPO_RULE_HULLMOV | RPO_RULE_GJK |
-            (kind >= RP_KIND_P ? RPO_RULE_EPA : 0);
+            RPO_RULE_RESIDUAL | (kind >= RP_KIND_P ? RPO_RULE_EPA : 0);
   /* = 2039 for the UR5 kinds (U, R) and 133111 = 2039 | RPO_RULE_EPA for the Panda kinds (P, Q, V, W): the shipped model, the HIP kernels implement exactly this.  The expanding
    * polytope is in the Panda ids' default because that is where it moves the fidelity table (profiles/r05_model_divergence.md: pandaPick 11 -> 12 of 12 envs, worst arm gap
    * 1.2e-3 -> 5.6e-5; the Panda playroom 8 -> 10 of 12) and not in the UR5 ids' because there it moves nothing (7 of 12 either way) and costs 4 % of the headline (19 % under the
@@ -2774,6 +2899,7 @@ int rpo_last_num_tors(const rpo_env* e) { return e->n_tors; }
 /* RPO_RULE_PERSIST: cached manifolds (empty ones included) and, in *points, their points */
 int rpo_cache_size(const rpo_env* e, int* points) { int n = 0; for (int i = 0; i < e->npm; i++) n += e->pm[i].n; if (points) *points = n; return e->npm; }      /* torsional rows of the latest substep (mode A) */
 int rpo_contact_substeps(const rpo_env* e) { return e->contact_substeps; }
+int rpo_residual_substeps(const rpo_env* e) { return e->residual_substeps; }
 /* The contact cache in the HIP library's row layout (rp_kernels.cuh PMC_*: 704 words; integers as bit patterns) - what rp_get_state rows carry behind the 128-float record.
  * Header: manifolds, 3 pad.  Manifold (52 words): object-pair key (objA * 256 + objB) | points | breaking threshold | pair flags (rebuilt every substep: 0 here) | 4 words of
  * scratch | 4 points x 11: point in A's body frame, in B's, normal, distance, colliders and bodies (a | b << 8 | body a << 22 | body b << 27).  Behind the manifolds the GJK_AX

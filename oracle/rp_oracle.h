@@ -106,6 +106,7 @@ int rpo_last_num_rows(const rpo_env*);
 int rpo_arm_table(const rpo_env* e, double* out);                      /* [n_arm][6]: jtype, lower, upper, body mass, Bullet joint index, parent dof */
 int rpo_collider_dynamics(const rpo_env* e, double* out);              /* [n_col][6]: body, friction, body mass, contact stiffness, damping, breaking threshold */
 void rpo_set_arm_q(rpo_env* e, const double* q);                      /* arm joints to q, at rest */
+int rpo_residual_substeps(const rpo_env* e);                          /* substeps since creation solved in the residual form (rule bit 262144) */
 int rpo_contact_substeps(const rpo_env* e);                           /* substeps since creation whose solve had a contact row */
 int rpo_box_box(const double* ca, const double* Ra, const double* ha, const double* cb, const double* Rb, const double* hb,
                 double margin, double* out /* per point: p3 n3 dist */);

@@ -2415,6 +2415,8 @@ __device__ float solve_rows(const DevModel* m, LDS& L, int lane, int nsmall_, in
 }
 
 /* ------------------------------------------------------------------ one stepSimulation() */
+/* (defined behind heavy_solve) a heavy env's solve + integration in the residual form, the very code k_solve2 runs: true if this env is one */
+__device__ bool substep_heavy(const DevModel* m, EnvLds& L, int lane, int nsmall, int ncon, int nt);
 __device__ void substep(const DevModel* m, EnvLds& L, int lane, int env) {
   int n = m->n_arm;
   fk_bodies(m, L, lane);
@@ -2430,6 +2432,7 @@ __device__ void substep(const DevModel* m, EnvLds& L, int lane, int env) {
   WSYNC();
   contact_rows(m, L, lane, 0, ncon, nt);
   __syncthreads();
+  if (substep_heavy(m, L, lane, nsmall, ncon, nt)) { __syncthreads(); return; }      /* (block-uniform: one wave per block) */
   float dv = solve_rows<EnvLds>(m, L, lane, nsmall, ncon, nt);
   __syncthreads();
   /* apply and integrate (semi-implicit Euler) */
@@ -3420,12 +3423,19 @@ __device__ __forceinline__ void copy_out(float* __restrict__ dst, const float* s
 #define AOUT_FLOATS (160 + 8 + 20)
 static_assert(W3_A % 4 == 0 && W3_ROWS % 4 == 0 && W3_ROFF % 4 == 0 && AOUT_FLOATS % 4 == 0, "16-byte copies");
 
+#define HV_MAXC 14                    /* contacts of an env on k_solve2's heavy path (heavy_solve; oracle: RES_MAX_CON) */
+/* which path of k_solve2 solves an env with nc contacts - nA of them touch the first half of the velocity layout only, nB the second half only, nC both.  0: the four-env
+ * path (dv form); 1: the heavy path (one env per wave, residual form); 2: more than HV_MAXC contacts - solve2_body (dv form) */
+__device__ __forceinline__ int hv_class(int nc, int nA, int nB, int nC) {
+  const bool heavy = nC != 0 || nA > 8 || nB > 16;      /* (S4_SLOTS0, S4_SLOTS1: static_assert at block_classes) */
+  return !heavy ? 0 : (nc <= HV_MAXC ? 1 : 2);
+}
 #define PREP_THREADS 128
 /* one env's preparation by the two waves of a block: L = the block's PrepLds, env = the env, cenv = the env whose contact cache it uses (rp_reset settles in a dense
  * scratch range: the cache stays the env's own), pair_tab[pair_idx] = this env's entry of the pairing table (env | contact count << 24; stored by wave 1, lane 0).
  * Ends without a barrier: the caller synchronises before L is used again. */
 __device__ __forceinline__ void prep2_core(PrepLds& L, const DevModel* __restrict__ m, const float* __restrict__ state, float* __restrict__ ws, const int env, const int cenv,
-                                           int* __restrict__ pair_tab, const int pair_idx) {      /* (table and index apart: a per-thread pointer held across the whole kernel costs two registers, and this kernel spills for less) */
+                                           int* __restrict__ pair_tab, const int pair_idx, int* __restrict__ hv_cnt = nullptr, int* __restrict__ hv_list = nullptr) {      /* hv_cnt, hv_list: k_solve2's list of heavy envs (its worker blocks), nullptr = none */      /* (table and index apart: a per-thread pointer held across the whole kernel costs two registers, and this kernel spills for less) */
   const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
   PCLK(6) PCLK(0) PCLK_ZERO(15) PCLK_ZERO(19) PCLK_ZERO(26) PCLK_ZERO(27) PCLK_ZERO(28) PCLK_ZERO(29) PCLK_ZERO(30) PCLK_ZERO(31)
   static_assert(RP_REC_FLOATS == PREP_THREADS, "one float of the record per thread");
@@ -3550,6 +3560,7 @@ __device__ __forceinline__ void prep2_core(PrepLds& L, const DevModel* __restric
       w[W3_HDR + 2] = __int_as_float(nj); w[W3_HDR + 3] = __int_as_float(ncon);
       w[W3_HDR + 4] = __int_as_float(__popcll(mA)); w[W3_HDR + 5] = __int_as_float(__popcll(mB));
       w[W3_HDR + 6] = __int_as_float(L.hdr[1] | (nt << 8)); w[W3_HDR + 7] = __int_as_float(__popcll(mC));      /* gear present | torsional rows << 8 */
+      if (hv_list != nullptr && hv_class(ncon, __popcll(mA), __popcll(mB), __popcll(mC)) == 1) hv_list[atomicAdd(hv_cnt, 1)] = env | (ncon << 24);      /* a heavy env: one wave of k_solve2's worker blocks to itself */
     }
     if (lane < 32) w[W3_MU + lane] = lane < ncon ? L.conmu[lane] : 0.f;
     copy_out(w + W3_ROFF, (const float*)L.roff, 64, lane);
@@ -3562,14 +3573,17 @@ __device__ __forceinline__ void prep2_core(PrepLds& L, const DevModel* __restric
 /* k_prep2's block: its env from its place in the group, its place in the pairing table of the k_solve2 after this launch */
 __device__ __forceinline__ void prep2_body(const DevModel* __restrict__ m, const float* __restrict__ state, float* __restrict__ ws, int env0, int N,
                                            const int* __restrict__ sort_cnt, int* __restrict__ sort_cnt_next, const int* __restrict__ sort_slot, int* __restrict__ pair_env,
-                                           const int* __restrict__ member, const int bid, const int* __restrict__ cache_env = nullptr) {
+                                           const int* __restrict__ member, const int bid, const int* __restrict__ cache_env = nullptr, int* __restrict__ hv_cnt = nullptr, int* __restrict__ hv_cnt_next = nullptr,
+                                           int* __restrict__ hv_list = nullptr) {
   __shared__ PrepLds L;
   const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
   int env = env0 + bid;
   if (env >= N) return;
   if (member) env = member[env];     /* this block's place in its group -> env (groups are cut by load, see k_member) */
-  if (bid == 0)               /* the histogram that the k_solve2 after this launch fills (for the substep after it) starts at zero */
+  if (bid == 0) {             /* the histogram that the k_solve2 after this launch fills (for the substep after it) starts at zero */
     for (int i = tid; i < SORT_BINS; i += PREP_THREADS) sort_cnt_next[i] = 0;
+    if (tid == 0 && hv_cnt_next) *hv_cnt_next = 0;      /* ... and so does the list of heavy envs that the NEXT preparation fills (this launch's own counter: zeroed by the launch before it / by k_member) */
+  }
   /* pairing table for the k_solve2 after this launch: this env's place among the envs of its group sorted by load class,
    * heaviest first = envs in heavier (class, replica) bins + its rank inside its bin (both from the previous k_solve2) */
   int pair_place = 0;
@@ -3587,14 +3601,15 @@ __device__ __forceinline__ void prep2_body(const DevModel* __restrict__ m, const
     for (int d = 32; d >= 1; d >>= 1) above += __shfl_xor(above, d);
     pair_place = above + (my_slot & SORT_RANK_MASK);
   }
-  prep2_core(L, m, state, ws, env, cache_env ? cache_env[env] : env, pair_env, env0 + pair_place);
+  prep2_core(L, m, state, ws, env, cache_env ? cache_env[env] : env, pair_env, env0 + pair_place, hv_cnt, hv_list ? hv_list + env0 : nullptr);
 }
 /* two entry points on the same body: rp_step's substeps, and the settle substeps of rp_reset under their own name so that
  * profiles keep the two apart */
 #define PREP2_ARGS const DevModel* __restrict__ m, const float* __restrict__ state, float* __restrict__ ws, int env0, int N, \
                    const int* __restrict__ sort_cnt, int* __restrict__ sort_cnt_next, const int* __restrict__ sort_slot, int* __restrict__ pair_env, \
                    const int* __restrict__ member
-__global__ void __launch_bounds__(PREP_THREADS, RP_PREP_WAVES) k_prep2(PREP2_ARGS) { prep2_body(m, state, ws, env0, N, sort_cnt, sort_cnt_next, sort_slot, pair_env, member, blockIdx.x); }
+#define HV_ARGS int* __restrict__ hv_cnt, int* __restrict__ hv_cnt_next, int* __restrict__ hv_list      /* the heavy envs of this substep (k_solve2's worker blocks): counter, the next substep's counter, list */
+__global__ void __launch_bounds__(PREP_THREADS, RP_PREP_WAVES) k_prep2(PREP2_ARGS, HV_ARGS) { prep2_body(m, state, ws, env0, N, sort_cnt, sort_cnt_next, sort_slot, pair_env, member, blockIdx.x, nullptr, hv_cnt, hv_cnt_next, hv_list); }
 __global__ void __launch_bounds__(PREP_THREADS, RP_PREP_WAVES) k_settle_prep(PREP2_ARGS, const int* __restrict__ cache_env) { prep2_body(m, state, ws, env0, N, sort_cnt, sort_cnt_next, sort_slot, pair_env, member, blockIdx.x, cache_env); }
 /* First substep of a step: the action kernel and the first k_prep2 in ONE launch.  Nothing k_prep2 builds depends on the new motor
  * targets except the motor rows themselves (v*, M^-1, contacts and limit rows see q and qd only), so the nab action blocks (first in
@@ -3605,14 +3620,14 @@ __global__ void __launch_bounds__(PREP_THREADS, RP_PREP_WAVES) k_settle_prep(PRE
 __global__ void __launch_bounds__(PREP_THREADS, RP_PREP_WAVES) k_action_prep(const DevModel* __restrict__ m, float* __restrict__ state, float* __restrict__ ws, int env0, int N,
                                                                    const int* __restrict__ sort_cnt, int* __restrict__ sort_cnt_next, const int* __restrict__ sort_slot,
                                                                    int* __restrict__ pair_env, const int* __restrict__ member, const float* __restrict__ action,
-                                                                   float* __restrict__ target_poses, int nab) {
+                                                                   float* __restrict__ target_poses, int nab, HV_ARGS) {
   if ((int)blockIdx.x < nab) {
     /* the IK is the launch's long pole (80 dependent iterations, one wave per SIMD) and the preparation blocks beside it have 150 us of slack: its waves go first
      * wherever both want the same issue slot */
     __builtin_amdgcn_s_setprio(3);
     action_body(m, state, action, target_poses, env0, N, member, blockIdx.x);
   }
-  else prep2_body(m, state, ws, env0, N, sort_cnt, sort_cnt_next, sort_slot, pair_env, member, blockIdx.x - nab);
+  else prep2_body(m, state, ws, env0, N, sort_cnt, sort_cnt_next, sort_slot, pair_env, member, blockIdx.x - nab, nullptr, hv_cnt, hv_cnt_next, hv_list);
 }
 
 
@@ -3764,7 +3779,8 @@ __device__ __forceinline__ int pair_env_id(int pe) {
   return e;
 }
 __device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, float* __restrict__ state, const float* __restrict__ ws, int env0, int N,
-                                                  const int* __restrict__ pair_env, int* __restrict__ sort_cnt_next, int* __restrict__ sort_slot, int debug_flags, Solve2Lds* Ls, const int bq) {
+                                                  const int* __restrict__ pair_env, int* __restrict__ sort_cnt_next, int* __restrict__ sort_slot, int debug_flags, Solve2Lds* Ls, const int bq,
+                                                  const unsigned gmask = 15u) {      /* gmask: bit k = the env at place 4 bq + k is this path's (solve_block) */
   /* the waves of a block work independently, each on its own pair of envs and its own LDS block Ls[wid].  Few blocks come here (the ones with a coupled env:
    * 1 - 2 % of the envs) and they last twice as long as the four-env blocks: they are the launch's critical path (raising their wave priority changes nothing:
    * they already run alone for the second half of the launch) */
@@ -3782,7 +3798,7 @@ __device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, floa
   /* this wave's two envs: places 2b and 2b + 1 among the group's envs sorted by load class, heaviest first (table built
    * by the k_prep2 before this launch) */
   const int place = wb * 2 + half;
-  const int pe = place < N - env0 ? pair_env[env0 + place] : -1;
+  const int pe = (place < N - env0 && ((gmask >> (2 * wid + half)) & 1u)) ? pair_env[env0 + place] : -1;
   const int env = pe < 0 ? -1 : pair_env_id(pe), pe_nc = pe < 0 ? 0 : (pe >> 24);
   const bool valid = env >= 0;
   const float* w = ws + (size_t)(valid ? env : 0) * W3_FLOATS;
@@ -4149,11 +4165,12 @@ __device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, floa
 #define S4_SLOTS1 16     /* row-1 contact slots (wave 1): one plane register */
 template <int T>
 __device__ __forceinline__ void solve4_body(const DevModel* __restrict__ m, float* __restrict__ state, const float* __restrict__ ws, int env0, int N,
-                                            const int* __restrict__ pair_env, int* __restrict__ sort_cnt_next, int* __restrict__ sort_slot, int debug_flags, float* __restrict__ stl, const int bq) {
+                                            const int* __restrict__ pair_env, int* __restrict__ sort_cnt_next, int* __restrict__ sort_slot, int debug_flags, float* __restrict__ stl, const int bq,
+                                            const unsigned gmask) {
   constexpr int NSL = T == 0 ? S4_SLOTS0 : S4_SLOTS1;
   const int lane = threadIdx.x & 63, g = lane >> 4, l16 = lane & 15;
   const int place = bq * 4 + g;
-  const int pe = place < N - env0 ? pair_env[env0 + place] : -1;
+  const int pe = (place < N - env0 && ((gmask >> g) & 1u)) ? pair_env[env0 + place] : -1;
   const int env = pe < 0 ? -1 : pair_env_id(pe);
   const bool valid = env >= 0;
   const float* w = ws + (size_t)(valid ? env : 0) * W3_FLOATS;
@@ -4279,7 +4296,8 @@ __device__ __forceinline__ void solve4_body(const DevModel* __restrict__ m, floa
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);    /* vmcnt(0): all row registers have landed before the sweep loop */
 #if defined(RP_CLOCKS) && RP_CLOCKS != 2
-  if (lane == 0) g_clk[8 * (bq * SOLVE_WAVES + T) + 1] = wall_clock64();      /* (profiling build: the four-env wave's rows are loaded) */
+  if (lane == 0) { g_clk[8 * (blockIdx.x * SOLVE_WAVES + T) + 1] = wall_clock64();      /* (profiling build: the four-env wave's rows are loaded; its stream, slots in use, limit rows) */
+    g_clk[8 * (blockIdx.x * SOLVE_WAVES + T) + 6] = (1ull << 30) | (unsigned long long)T | ((unsigned long long)nS << 8) | ((unsigned long long)(__popc(maskL) + __popc(maskU)) << 16) | ((unsigned long long)nT << 24); }
 #endif
   /* counting sort by load class for the next substep's pairing: one atomic per env, from the row-1 wave */
   int sort_pos = 0, sort_bin = 0;
@@ -4405,26 +4423,526 @@ __device__ __forceinline__ void solve4_body(const DevModel* __restrict__ m, floa
   }
 }
 
-/* does this block take the four-env path?  Decided from the same headers by both waves alike. */
-__device__ __forceinline__ bool solve4_eligible(const float* __restrict__ ws, int env0, int N, const int* __restrict__ pair_env, int debug_flags, const int bq) {
+/* ------------------------------------------------------------------ k_solve2, HEAVY envs: ONE env per wave, the sweeps in RESIDUAL (Delassus) form (round 6).
+ * Which envs: the ones the four-env path cannot take - a contact that spans the two halves of the velocity layout (arm or drawer against the block or a scene-joint body:
+ * a grasp, a push, a drawer pulled by the gripper) or more contacts of one half than that path has slots - with at most HV_MAXC contacts (hv_class; the oracle's
+ * residual_form, rule bit RPO_RULE_RESIDUAL).  Until round 5 they took solve2_body, two envs per wave, where every contact row is a 16- or 32-lane dot product inside the
+ * dependent chain (13 - 17 instructions and six wait states per row step, 185 cycles for a lone wave): 1 - 2 % of the envs, and their waves WERE every launch's second half
+ * (75 us at the median, 125 at the most, while 98 % of the waves had finished after 43).  Here a lane carries ONE NUMBER through the sweeps:
+ *   lanes  0 .. 11   dv of arm dof i              (motor, lower and upper limit of dof i read the same lane)
+ *   lanes 12 .. 14   dv of scene joint k
+ *   lane  15         w = Jd . dv of the Panda finger gear
+ *   lanes 16 .. 29   w of the normal of contact c;      30, 31, 46, 47: the torsional rows
+ *   lanes 32 .. 45 / 48 .. 61   w of its two friction rows
+ * and a row step is  t = fma(-jd, w, rhs) in every lane at once (jd = 1 outside the dof lanes), med3 against the lane's own bounds, ONE v_readlane of the row's lane, and
+ * w = fma(A[:, row], d, w): five instructions, none of them a reduction.  A[l][r] = X_l . B_r (X_l = e_d for a dof lane - so its column entry is B_r[d], the dv form's own
+ * update - and Jd_l for a row lane), summed over the dofs in ascending order with fused multiply-adds from zero, is built once per launch: the two dense tables X, B
+ * (64 labels x 32 dofs) in LDS, lane l keeps X_l in registers and reads B_r by broadcast, 64 column registers.  The free bodies' velocities have no lane: they are formed
+ * once after the sweeps, B_r[d] lambda_r over the contact rows in the workspace's row order.  Same rows, same order, same clamps as everywhere else (build_small_rows'
+ * order walked in alternating direction, normals, torsional rows, friction pairs): in exact arithmetic the dv form line by line, in fp32 another rounding - which is why
+ * the form is a property of the ENV'S OWN contact list (never of who shares a wave with whom) and why the oracle has it too. */
+#define RP_DBG_SEQ 1          /* debug flag 1 (tests): the dv-form envs take solve2_body's fallback (one contact per folded slot) instead of the four-env / side-by-side paths */
+#define RP_DBG_MOTOR 2        /* first substep after k_action_prep: the motor rows are rebuilt from the record */
+#define RP_DBG_NOSORT 4       /* k_chain's substeps before the last: nobody reads their load classes */
+#define RP_DBG_WORKERS 8      /* the heavy envs (residual form) of this launch are solved by the worker blocks at the head of the grid (k_solve2), not inside their own blocks */
+#define HV_ND 32                      /* dofs the dense tables hold (nv <= 30) */
+#define HV_STRIDE 36                  /* ... and their row stride in LDS (16-byte rows whose lanes do not all share a bank) */
+#define HV_L_J1 12
+#define HV_L_GEAR 15
+#define HV_L_N 16
+#define HV_L_F0 32
+#define HV_L_F1 48
+#define HV_LDS_FLOATS (2 * 64 * HV_STRIDE + RP_REC_FLOATS)
+__device__ __forceinline__ int hv_label_tors(int t) { return t < 2 ? 30 + t : 44 + t; }      /* 30, 31, 46, 47 */
+/* label of workspace row gr of an env with nc contacts: normals [0, nc), friction pairs nc + 2 c + d, torsional rows 3 nc + t */
+__device__ __forceinline__ int hv_label_row(int gr, int nc) {
+  if (gr < nc) return HV_L_N + gr;
+  if (gr < 3 * nc) { const int f = gr - nc; return ((f & 1) ? HV_L_F1 : HV_L_F0) + (f >> 1); }
+  return hv_label_tors(gr - 3 * nc);
+}
+/* Row steps, inline asm like the other row bodies (the compiler pads no hazards inside): r = the lanes' numbers, na = MINUS this lane's entry of the row's column.
+ * Wait states (gfx940 family): a v_readlane needs one after the VALU write of its source, a VALU read of the SGPR it wrote needs two.  Rows come in pairs where they
+ * can: the first row's v_writelane (the step into the impulse register) is the second row's wait state. */
+template <int K>
+__device__ __forceinline__ void hv_row1(float& r, float& dacc, const float loP, const float hiP, const float na) {
+  float t; int s;
+  asm volatile(
+      "v_med3_f32 %[t], %[r], %[lo], %[hi]\n"
+      "s_nop 0\n"
+      "v_readlane_b32 %[s], %[t], %[k]\n"
+      "s_nop 1\n"
+      "v_fmac_f32 %[r], %[s], %[a]\n"
+      "v_writelane_b32 %[dacc], %[s], %[k]\n"
+      : [r] "+v"(r), [dacc] "+v"(dacc), [t] "=&v"(t), [s] "=&s"(s)
+      : [lo] "v"(loP), [hi] "v"(hiP), [a] "v"(na), [k] "n"(K));
+}
+template <int K1, int K2>
+__device__ __forceinline__ void hv_row2(float& r, float& dacc, const float loP, const float hiP, const float na1, const float na2) {
+  float t; int s1, s2;
+  asm volatile(
+      "v_med3_f32 %[t], %[r], %[lo], %[hi]\n"
+      "s_nop 0\n"
+      "v_readlane_b32 %[s1], %[t], %[k1]\n"
+      "s_nop 1\n"
+      "v_fmac_f32 %[r], %[s1], %[a1]\n"
+      "v_med3_f32 %[t], %[r], %[lo], %[hi]\n"
+      "v_writelane_b32 %[dacc], %[s1], %[k1]\n"
+      "v_readlane_b32 %[s2], %[t], %[k2]\n"
+      "s_nop 1\n"
+      "v_fmac_f32 %[r], %[s2], %[a2]\n"
+      "v_writelane_b32 %[dacc], %[s2], %[k2]\n"
+      : [r] "+v"(r), [dacc] "+v"(dacc), [t] "=&v"(t), [s1] "=&s"(s1), [s2] "=&s"(s2)
+      : [lo] "v"(loP), [hi] "v"(hiP), [a1] "v"(na1), [a2] "v"(na2), [k1] "n"(K1), [k2] "n"(K2));
+}
+/* the two limit rows of arm dof K (its lane holds the MOTOR row's number: theirs is that plus the difference of the right-hand sides); A first, then B */
+template <int K>
+__device__ __forceinline__ void hv_rowLU(float& r, float& daccA, const float offA, const float loA, const float hiA, float& daccB, const float offB, const float loB, const float hiB, const float na) {
+  float t; int s1, s2;
+  asm volatile(
+      "v_add_f32 %[t], %[r], %[oa]\n"
+      "v_med3_f32 %[t], %[t], %[loa], %[hia]\n"
+      "s_nop 0\n"
+      "v_readlane_b32 %[s1], %[t], %[k]\n"
+      "s_nop 1\n"
+      "v_fmac_f32 %[r], %[s1], %[a]\n"
+      "v_add_f32 %[t], %[r], %[ob]\n"
+      "v_med3_f32 %[t], %[t], %[lob], %[hib]\n"
+      "v_writelane_b32 %[da], %[s1], %[k]\n"
+      "v_readlane_b32 %[s2], %[t], %[k]\n"
+      "s_nop 1\n"
+      "v_fmac_f32 %[r], %[s2], %[a]\n"
+      "v_writelane_b32 %[db], %[s2], %[k]\n"
+      : [r] "+v"(r), [da] "+v"(daccA), [db] "+v"(daccB), [t] "=&v"(t), [s1] "=&s"(s1), [s2] "=&s"(s2)
+      : [oa] "v"(offA), [loa] "v"(loA), [hia] "v"(hiA), [ob] "v"(offB), [lob] "v"(loB), [hib] "v"(hiB), [a] "v"(na), [k] "n"(K));
+}
+template <int K>
+__device__ __forceinline__ void hv_rowL(float& r, float& dacc, const float off, const float loP, const float hiP, const float na) {
+  float t; int s;
+  asm volatile(
+      "v_add_f32 %[t], %[r], %[o]\n"
+      "v_med3_f32 %[t], %[t], %[lo], %[hi]\n"
+      "s_nop 0\n"
+      "v_readlane_b32 %[s], %[t], %[k]\n"
+      "s_nop 1\n"
+      "v_fmac_f32 %[r], %[s], %[a]\n"
+      "v_writelane_b32 %[dacc], %[s], %[k]\n"
+      : [r] "+v"(r), [dacc] "+v"(dacc), [t] "=&v"(t), [s] "=&s"(s)
+      : [o] "v"(off), [lo] "v"(loP), [hi] "v"(hiP), [a] "v"(na), [k] "n"(K));
+}
+struct HvPlane { float lo, hi, lam, dacc, loP, hiP; };
+#ifdef RP_WIDE
+#define HV_NQ 8                       /* groups of four dofs in the dot products: nv = 30 (wide), <= 27 */
+#else
+#define HV_NQ 7
+#endif
+/* st_lds: the env's state record in LDS if the caller keeps it there (the one-kernel twins), else nullptr: the record is read from and written to `state`.
+ * w: the env's workspace row (W3_*).  lds: HV_LDS_FLOATS floats of this wave's own. */
+__device__ __forceinline__ void heavy_solve(const DevModel* __restrict__ m, float* __restrict__ state, const float* __restrict__ w, const int env, int* __restrict__ sort_cnt_next,
+                                            int* __restrict__ sort_slot, const int debug_flags, float* __restrict__ lds, float* st_lds, const int sort_salt, const int clk_wave = -1) {
+  const int lane = threadIdx.x & 63;
+  const int n = m->n_arm;
+#if defined(RP_CLOCKS) && RP_CLOCKS == 1      /* profiling build (tools/gpu_clocks6.py): 0 start, 1 tables and columns built, 2 sweeps done, 3 end (shader clock), 4 / 5 start / end (100 MHz wall clock), 6 rows, 7 where */
+#define HV_CLK(i) if (lane == 0 && clk_wave >= 0) g_clk[8 * clk_wave + (i)] = __builtin_readcyclecounter();
+  if (lane == 0 && clk_wave >= 0) g_clk[8 * clk_wave + 4] = wall_clock64();
+#else
+#define HV_CLK(i)
+#endif
+  HV_CLK(0)
+  float* Xd = lds; float* Yd = lds + 64 * HV_STRIDE; float* stl = st_lds ? st_lds : lds + 2 * 64 * HV_STRIDE;
+  static_assert(HV_STRIDE > 4 * HV_NQ + 0 && HV_STRIDE >= 33, "flag word");
+  int* hvfl0 = (int*)(Yd + 32);                             /* per label: bit 0 = its B row has an entry below dof 12, bit 1 = from 12 on.  Kept in the tables' padding: word 32 of B row `label` (HV_STRIDE 36 > 4 HV_NQ) */
+  const float4 h0 = *(const float4*)&w[W3_HDR], h1 = *(const float4*)&w[W3_HDR + 4];
+  const int maskL = uni(__float_as_int(h0.x)), maskU = uni(__float_as_int(h0.y)), nj = uni(__float_as_int(h0.z)), nc = uni(__float_as_int(h0.w));
+  const int nA = uni(__float_as_int(h1.x)), nB = uni(__float_as_int(h1.y)), gear = uni(__float_as_int(h1.z)) & 255, nt = uni(__float_as_int(h1.z)) >> 8, nC = uni(__float_as_int(h1.w));
+  const int nrc = 3 * nc + nt;
+  /* the state record: into registers now, into LDS when the tables are built */
+  float st_v0 = 0.f, st_v1 = 0.f;
+  if (!st_lds) { const float* r = state + (size_t)env * RP_REC_FLOATS; st_v0 = r[lane]; st_v1 = r[lane + 64]; }
+  /* ---- the planes: this lane's row(s) */
+  const float* wzero = w + W3_ZERO;
+  auto ldz = [&](const float* q, bool c) { return *(c ? q : wzero); };
+  const bool arm_lane = lane < n;
+  const int ia = arm_lane ? lane : 0;
+  const float* wa = w + W3_A;
+  const float* bj = w + W3_BJ;
+  const bool jl = lane >= HV_L_J1 && lane < HV_L_J1 + nj;
+  const int kj = jl ? lane - HV_L_J1 : 0;
+  int gr = -1, kind = 0, cpar = 0;                         /* this lane's workspace row; 1 friction, 2 torsional; the contact whose normal impulse bounds it */
+  if (lane >= HV_L_N && lane < HV_L_N + HV_MAXC) { if (lane - HV_L_N < nc) gr = lane - HV_L_N; }
+  else if (lane >= HV_L_F0 && lane < HV_L_F0 + HV_MAXC) { if (lane - HV_L_F0 < nc) { gr = nc + 2 * (lane - HV_L_F0); kind = 1; cpar = lane - HV_L_F0; } }
+  else if (lane >= HV_L_F1 && lane < HV_L_F1 + HV_MAXC) { if (lane - HV_L_F1 < nc) { gr = nc + 2 * (lane - HV_L_F1) + 1; kind = 1; cpar = lane - HV_L_F1; } }
+  else {
+    const int t = lane == 30 ? 0 : (lane == 31 ? 1 : (lane == 46 ? 2 : (lane == 47 ? 3 : -1)));
+    if (t >= 0 && t < nt) { gr = 3 * nc + t; kind = 2; }
+  }
+  const bool rl = gr >= 0;
+  const int grc = rl ? gr : 0;
+  const bool gl = lane == HV_L_GEAR && gear != 0;
+  HvPlane P0, PL, PU;
+  float cfm = 0.f, mu = 0.f;
+  float rhs0 = ldz(&w[W3_ROWS + 4 * grc], rl);
+  if (kind == 0) { cfm = ldz(&w[W3_ROWS + 4 * grc + 1], rl); P0.lo = 0.f; P0.hi = ldz(&w[W3_ROWT + 4 * grc + 1], rl); }
+  else { P0.lo = 0.f; P0.hi = 0.f; }
+  if (kind == 1) mu = w[W3_MU + cpar];
+  int tsrc = lane;
+  if (kind == 2) { mu = w[W3_ROWS + 4 * grc + 2]; tsrc = HV_L_N + (__float_as_int(w[W3_ROWS + 4 * grc + 3]) & 255); }
+  const float vstar_a = ldz(&w[W3_VSTAR + ia], arm_lane);
+  const float jd = arm_lane ? wa[ia] : (jl ? bj[kj] : 0.f);      /* the folded entry of a dof lane's unit rows */
+  if (arm_lane || jl) { rhs0 = arm_lane ? wa[16 + ia] : bj[4 + kj]; P0.lo = arm_lane ? wa[32 + ia] : bj[8 + kj]; P0.hi = arm_lane ? wa[48 + ia] : bj[12 + kj]; }
+  if (gl) { const float* g = w + W3_GEAR; rhs0 = g[4]; P0.lo = g[5]; P0.hi = g[6]; }
+  const float rhsL = ldz(&wa[64 + ia], arm_lane), rhsU = ldz(&wa[112 + ia], arm_lane);
+  PL.lo = ldz(&wa[80 + ia], arm_lane); PL.hi = ldz(&wa[96 + ia], arm_lane);
+  PU.lo = ldz(&wa[128 + ia], arm_lane); PU.hi = ldz(&wa[144 + ia], arm_lane);
+  if (debug_flags & RP_DBG_MOTOR) {      /* first substep after k_action_prep: the motor rows from the record's fresh targets (build_small_rows' formula; as in solve2_body) */
+    const float* r = st_lds ? st_lds : state + (size_t)env * RP_REC_FLOATS;
+    const float mode = r[ST_MMODE + ia], tgt = r[ST_MTARGET + ia], mx = r[ST_MMAXIMP + ia], qi = r[ST_Q + ia];
+    const float des = mode != 0.f ? K_KP * (tgt - qi) / K_DT : 0.f;
+    const float rhs = (des - vstar_a) * jd;
+    if (arm_lane) { rhs0 = rhs; P0.lo = -mx; P0.hi = mx; }
+  }
+  /* ---- the dense tables */
+#pragma unroll
+  for (int i = 0; i < 2 * 64 * HV_STRIDE / 256; i++) *(float4*)&lds[4 * lane + 256 * i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  WSYNC();
+  for (int e = lane; e < 144; e += 64) {                  /* arm dof t: X = jd e_t (the motor row's folded entry), B = M^-1[:, t] */
+    const int d = e / 12, t = e - 12 * d;
+    if (d < n && t < n) Yd[t * HV_STRIDE + d] = w[W3_MINV + e];
+  }
+  if (arm_lane) { Xd[lane * HV_STRIDE + lane] = jd; hvfl0[lane * HV_STRIDE] = 1; }
+  if (jl) { const int d = dof_j1(m, kj); Xd[lane * HV_STRIDE + d] = jd; Yd[lane * HV_STRIDE + d] = bj[16 + kj]; hvfl0[lane * HV_STRIDE] = d < 12 ? 1 : 2; }
+  if (gl) hvfl0[lane * HV_STRIDE] = 1;
+  if (gear != 0 && lane < n) {                             /* the gear: Jd = gd (e_a + ratio e_b), B = M^-1[:, a] + ratio M^-1[:, b] */
+    const float* g = w + W3_GEAR;
+    const int a = __float_as_int(g[0]) & 15, b = __float_as_int(g[1]) & 15;
+    const float ratio = g[2], gd = g[3];
+    Yd[HV_L_GEAR * HV_STRIDE + lane] = w[W3_MINV + lane * 12 + (a < 12 ? a : 0)] + ratio * w[W3_MINV + lane * 12 + (b < 12 ? b : 0)];
+    if (lane == a) Xd[HV_L_GEAR * HV_STRIDE + lane] = gd;
+    if (lane == b) Xd[HV_L_GEAR * HV_STRIDE + lane] = ratio * gd;
+  }
+  {                                                        /* contact, friction and torsional rows: compact (two body slots) -> dense.  All loads first: one latency, not one per pass */
+    constexpr int NIT = ((3 * HV_MAXC + MAXT) * ROWW + 63) / 64;
+    float jv[NIT], bv[NIT]; int of[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; i++) {
+      const int e = lane + 64 * i;
+      const bool ok = e < nrc * ROWW;
+      const int ec = ok ? e : 0, g2 = ec / ROWW, k = ec - g2 * ROWW;
+      jv[i] = w[W3_J + ec]; bv[i] = w[W3_B + ec];
+      of[i] = __float_as_int(w[W3_ROWT + 4 * g2 + (k < 12 ? 2 : 3)]);
+    }
+#pragma unroll
+    for (int i = 0; i < NIT; i++) {
+      const int e = lane + 64 * i;
+      const bool ok = e < nrc * ROWW;
+      const int ec = ok ? e : 0, g2 = ec / ROWW, k = ec - g2 * ROWW;
+      const int d = of[i] + (k < 12 ? k : k - 12);
+      const int lab = hv_label_row(g2, nc);
+      if (ok && d < 4 * HV_NQ) {                           /* (an empty slot has offset 64; entries past a body's dofs are zeros and must not overwrite a neighbour's) */
+        if (jv[i] != 0.f) Xd[lab * HV_STRIDE + d] = jv[i];
+        if (bv[i] != 0.f) { Yd[lab * HV_STRIDE + d] = bv[i]; atomicOr(&hvfl0[lab * HV_STRIDE], d < 12 ? 1 : 2); }
+      }
+    }
+  }
+  /* ---- the columns: -C[lane][s] for every label s in use */
+  WSYNC();
+  float X[4 * HV_NQ];
+#pragma unroll
+  for (int q = 0; q < HV_NQ; q++) { const float4 v = *(const float4*)&Xd[lane * HV_STRIDE + 4 * q]; X[4 * q] = v.x; X[4 * q + 1] = v.y; X[4 * q + 2] = v.z; X[4 * q + 3] = v.w; }
+  /* (a column leaves its loop through LDS - slot s of this half, one float per lane - and the registers are filled with constant indices afterwards: a dynamically
+   * indexed write into four 16-wide register vectors costs a copy of all of them per column) */
+  f16v AC[4];
+  {
+    const unsigned long long mc = nc >= 16 ? 0xFFFFull : ((1ull << nc) - 1ull);
+    const unsigned long long mt = (1ull << nt) - 1ull;
+    const unsigned long long use = ((1ull << n) - 1ull) | (((1ull << nj) - 1ull) << HV_L_J1) | (gear != 0 ? 1ull << HV_L_GEAR : 0ull)
+                                   | (mc << HV_L_N) | ((mt & 3ull) << 30) | (mc << HV_L_F0) | (((mt >> 2) & 3ull) << 46) | (mc << HV_L_F1);
+    float* Cst = Xd;                                       /* 32 x 64 floats: the X table's place (its rows are in registers now) */
+    static_assert(64 * HV_STRIDE >= 32 * 64, "column staging");
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      WSYNC();
+      int u = __builtin_amdgcn_readfirstlane((int)(unsigned)(use >> (32 * half)));
+#pragma unroll 1
+      while (u != 0) {
+        const int s5 = __builtin_ctz((unsigned)u);
+        u &= u - 1;
+        const int s = 32 * half + s5;
+        const float* Y = &Yd[s * HV_STRIDE];
+        float4 y[HV_NQ];
+#pragma unroll
+        for (int q = 0; q < HV_NQ; q++) y[q] = *(const float4*)&Y[4 * q];      /* the same address in every lane: broadcast reads */
+        float acc = 0.f;
+        /* a column's source touches the dofs below 12 (the arm), the ones from 12 on, or both (hvfl, filed with the tables): the terms of a part it does not touch are
+         * exact zeros and are left out */
+        const int fls = __builtin_amdgcn_readfirstlane(hvfl0[s * HV_STRIDE]);
+        if (fls & 1) {
+#pragma unroll
+          for (int q = 0; q < 3; q++) {
+            acc = __fmaf_rn(X[4 * q], y[q].x, acc); acc = __fmaf_rn(X[4 * q + 1], y[q].y, acc); acc = __fmaf_rn(X[4 * q + 2], y[q].z, acc); acc = __fmaf_rn(X[4 * q + 3], y[q].w, acc);
+          }
+        }
+        if (fls & 2) {
+#pragma unroll
+          for (int q = 3; q < HV_NQ; q++) {
+            acc = __fmaf_rn(X[4 * q], y[q].x, acc); acc = __fmaf_rn(X[4 * q + 1], y[q].y, acc); acc = __fmaf_rn(X[4 * q + 2], y[q].z, acc); acc = __fmaf_rn(X[4 * q + 3], y[q].w, acc);
+          }
+        }
+        Cst[s5 * 64 + lane] = -(lane == s ? acc + cfm : acc);      /* a soft normal row's own column carries its softness */
+      }
+      WSYNC();
+      const unsigned uh = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(use >> (32 * half)));
+#pragma unroll
+      for (int j = 0; j < 32; j++) {
+        const float v = ((uh >> j) & 1u) ? Cst[j * 64 + lane] : 0.f;      /* (wave-uniform select: unused labels read nothing that was written) */
+        AC[2 * half + (j >> 4)][j & 15] = v;
+      }
+    }
+  }
+  if (!st_lds) { stl[lane] = st_v0; stl[lane + 64] = st_v1; }
+  __builtin_amdgcn_s_waitcnt(0x0F70);    /* vmcnt(0): every plane value has landed before the sweep loop */
+  WSYNC();
+  /* counting sort by load class for the next substep's pairing (solve2_body explains it): the key of the two-env path */
+  int sort_pos = 0, sort_bin = 0;
+  if (lane == 0 && !(debug_flags & RP_DBG_NOSORT)) {
+    const int my_nS = max(nA, nB);
+    const int key = 8 * (nC < 7 ? nC : 7) + (my_nS < 1 ? 0 : (my_nS > 14 ? 7 : (my_nS - 1) >> 1));
+    sort_bin = key * SORT_REPS + (sort_salt & (SORT_REPS - 1));
+    sort_pos = atomicAdd(&sort_cnt_next[sort_bin], 1);
+  }
+  HV_CLK(1)
+  /* ---- the sweeps */
+  float rr = rhs0;
+  const float offL = rhsL - rhs0, offU = rhsU - rhs0;
+  P0.lam = 0.f; PL.lam = 0.f; PU.lam = 0.f;
+#pragma unroll 1
+  for (int it = 0; it < K_NITER; it++) {
+    int nc_it = uni(nc), nt_it = uni(nt), nj_it = uni(nj), mL_it = uni(maskL), mU_it = uni(maskU), gr_it = uni(gear), n_it = uni(n);
+    asm volatile("" : "+s"(nc_it), "+s"(nt_it), "+s"(nj_it), "+s"(mL_it), "+s"(mU_it), "+s"(gr_it), "+s"(n_it));
+    P0.loP = P0.lo - P0.lam; P0.hiP = P0.hi - P0.lam; P0.dacc = 0.f;
+    PL.loP = PL.lo - PL.lam; PL.hiP = PL.hi - PL.lam; PL.dacc = 0.f;
+    PU.loP = PU.lo - PU.lam; PU.hiP = PU.hi - PU.lam; PU.dacc = 0.f;
+#define HV_M2(i, j) hv_row2<(i), (j)>(rr, P0.dacc, P0.loP, P0.hiP, AC[0][i], AC[0][j]);
+#define HV_M1(i) hv_row1<(i)>(rr, P0.dacc, P0.loP, P0.hiP, AC[0][i]);
+#define HV_LO(i) hv_rowL<(i)>(rr, PL.dacc, offL, PL.loP, PL.hiP, AC[0][i]);
+#define HV_L(i) hv_rowLU<(i)>(rr, PL.dacc, offL, PL.loP, PL.hiP, PU.dacc, offU, PU.loP, PU.hiP, AC[0][i]);
+#define HV_LR(i) hv_rowLU<(i)>(rr, PU.dacc, offU, PU.loP, PU.hiP, PL.dacc, offL, PL.loP, PL.hiP, AC[0][i]);
+    /* the non-contact rows in build_small_rows' order - scene-joint motors, limits (dof-major, lower before upper; only while violated), arm motors, gear - forwards in
+     * the odd sweeps, backwards in the even ones (the first).  A row that is absent inside a pair or a group (a limit that holds, a motor beyond n_arm) is all zeros:
+     * its step is an exact zero */
+    if (it & 1) {
+      if (nj_it > 0) { HV_M2(12, 13) if (nj_it > 2) { HV_M1(14) } }
+      if ((mL_it | mU_it) & 0x03F) { if (mU_it & 0x03F) { HV_L(0) HV_L(1) HV_L(2) HV_L(3) HV_L(4) HV_L(5) } else { HV_LO(0) HV_LO(1) HV_LO(2) HV_LO(3) HV_LO(4) HV_LO(5) } }
+      if ((mL_it | mU_it) & 0xFC0) { if (mU_it & 0xFC0) { HV_L(6) HV_L(7) HV_L(8) HV_L(9) HV_L(10) HV_L(11) } else { HV_LO(6) HV_LO(7) HV_LO(8) HV_LO(9) HV_LO(10) HV_LO(11) } }
+      HV_M2(0, 1) HV_M2(2, 3) HV_M2(4, 5) HV_M2(6, 7)
+      if (n_it > 8) { HV_M2(8, 9) if (n_it > 10) { HV_M2(10, 11) } }
+      if (gr_it) { HV_M1(15) }
+    } else {
+      if (gr_it) { HV_M1(15) }
+      if (n_it > 8) { if (n_it > 10) { HV_M2(11, 10) } HV_M2(9, 8) }
+      HV_M2(7, 6) HV_M2(5, 4) HV_M2(3, 2) HV_M2(1, 0)
+      if ((mL_it | mU_it) & 0xFC0) { if (mU_it & 0xFC0) { HV_LR(11) HV_LR(10) HV_LR(9) HV_LR(8) HV_LR(7) HV_LR(6) } else { HV_LO(11) HV_LO(10) HV_LO(9) HV_LO(8) HV_LO(7) HV_LO(6) } }
+      if ((mL_it | mU_it) & 0x03F) { if (mU_it & 0x03F) { HV_LR(5) HV_LR(4) HV_LR(3) HV_LR(2) HV_LR(1) HV_LR(0) } else { HV_LO(5) HV_LO(4) HV_LO(3) HV_LO(2) HV_LO(1) HV_LO(0) } }
+      if (nj_it > 0) { if (nj_it > 2) { HV_M1(14) } HV_M2(13, 12) }
+    }
+#undef HV_L
+#undef HV_LR
+#undef HV_LO
+#undef HV_M2
+    /* contact normals, in contact order, two at a time (an absent second one: an exact zero step) */
+#define HV_N2(c) if (nc_it <= (c)) goto hv_ndone; hv_row2<HV_L_N + (c), HV_L_N + (c) + 1>(rr, P0.dacc, P0.loP, P0.hiP, AC[1][c], AC[1][(c) + 1]);
+    HV_N2(0) HV_N2(2) HV_N2(4) HV_N2(6) HV_N2(8) HV_N2(10) HV_N2(12)
+#undef HV_N2
+  hv_ndone:
+    P0.lam += P0.dacc; P0.dacc = 0.f;
+    PL.lam += PL.dacc; PU.lam += PU.dacc;
+    if (nc_it > 0) {
+      /* bounds of the friction and torsional rows: -+ mu * (normal impulse of their contact) - the normals' DPP row (lanes 16 .. 31) copied into every DPP row, the
+       * torsional rows' parents by a lane permute; while that impulse is not positive the row is skipped (step bounds [0, 0], Bullet's `if (totalImpulse > 0)`) */
+      const unsigned lu = __float_as_uint(P0.lam);
+      const auto s32 = __builtin_amdgcn_permlane32_swap(lu, lu, false, false);        /* [r0 r1 r0 r1] */
+      const auto s16 = __builtin_amdgcn_permlane16_swap(s32[0], s32[0], false, false);  /* ..., [r1 r1 r1 r1] */
+      float src = __uint_as_float(s16[1]);
+      if (nt_it > 0) { const float lp = __shfl(P0.lam, tsrc); src = kind == 2 ? lp : src; }
+      const float lim = mu * src;
+      const bool on = src > 0.f;
+      if (kind != 0) { P0.loP = on ? (0.f - lim) - P0.lam : 0.f; P0.hiP = on ? (0.f + lim) - P0.lam : 0.f; }
+      if (nt_it > 0) {
+        hv_row1<30>(rr, P0.dacc, P0.loP, P0.hiP, AC[1][14]);
+        if (nt_it > 1) hv_row1<31>(rr, P0.dacc, P0.loP, P0.hiP, AC[1][15]);
+        if (nt_it > 2) hv_row1<46>(rr, P0.dacc, P0.loP, P0.hiP, AC[2][14]);
+        if (nt_it > 3) hv_row1<47>(rr, P0.dacc, P0.loP, P0.hiP, AC[2][15]);
+      }
+#define HV_F(c) if (nc_it <= (c)) goto hv_fdone; hv_row2<HV_L_F0 + (c), HV_L_F1 + (c)>(rr, P0.dacc, P0.loP, P0.hiP, AC[2][c], AC[3][c]);
+      HV_F(0) HV_F(1) HV_F(2) HV_F(3) HV_F(4) HV_F(5) HV_F(6) HV_F(7) HV_F(8) HV_F(9) HV_F(10) HV_F(11) HV_F(12) HV_F(13)
+#undef HV_F
+    hv_fdone:
+      P0.lam += P0.dacc;
+    }
+#undef HV_M1
+  }
+  HV_CLK(2)
+  /* ---- the velocity change: dv = sum of B_r lambda_r over all rows - motors, lower limits, upper limits (dof by dof each), scene-joint motors, gear, then the contact
+   * rows in the workspace's order -, lane l < 32 <-> component lane_dof(l) as on the two-env path */
+  const int l = lane & 31;
+  const int dd = lane < 32 ? lane_dof(m, l) : -1;
+  float dv = 0.f;
+  {
+    /* the terms in their order, through LDS (the column staging's place): every lane files the impulses of its rows at their positions, then lane <-> dof sums them */
+    float* lamseq = Xd; int* offseq = (int*)(Xd + 128);
+    const int nlim = (maskL | maskU) != 0 ? 2 * n : 0;
+    const int base_j = n + nlim, base_g = base_j + nj, base_r = base_g + (gear != 0 ? 1 : 0), nterm = base_r + nrc;
+    WSYNC();
+    if (arm_lane) {
+      lamseq[lane] = P0.lam; offseq[lane] = lane * HV_STRIDE;
+      if (nlim) { lamseq[n + lane] = PL.lam; offseq[n + lane] = lane * HV_STRIDE; lamseq[2 * n + lane] = PU.lam; offseq[2 * n + lane] = lane * HV_STRIDE; }
+    }
+    if (jl) { lamseq[base_j + kj] = P0.lam; offseq[base_j + kj] = lane * HV_STRIDE; }
+    if (gl) { lamseq[base_g] = P0.lam; offseq[base_g] = lane * HV_STRIDE; }
+    if (rl) { lamseq[base_r + gr] = P0.lam; offseq[base_r + gr] = lane * HV_STRIDE; }
+    WSYNC();
+    const int ddc = (dd >= 0 && dd < 4 * HV_NQ) ? dd : 0;
+    const float* Yc = Yd + ddc;
+#pragma unroll 4
+    for (int k = 0; k < nterm; k++) dv = __fmaf_rn(Yc[offseq[k]], lamseq[k], dv);
+    if (dd < 0) dv = 0.f;
+  }
+  const float vstar = ldz(&w[W3_VSTAR + (dd >= 0 ? dd : 0)], dd >= 0);
+  const float vnew = clampf(vstar + dv, -K_MAXVEL, K_MAXVEL);
+  float* st = stl;
+  WSYNC();
+  if (dd >= 0) {
+    if (dd < n) { st[ST_QD + dd] = vnew; st[ST_Q + dd] += K_DT * vnew; }
+    else if (dd < n + 6 * m->n_free) { const int k = (dd - n) / 6, c = (dd - n) % 6; st[ST_FREE + 13 * k + 7 + c] = vnew; }
+    else { const int k = dd - n - 6 * m->n_free; st[ST_JQD + k] = vnew; st[ST_JQ + k] += K_DT * vnew; }
+  }
+  WSYNC();
+  if (lane < m->n_free) {
+    float* f = &st[ST_FREE + 13 * lane];
+    V3 v = ld3(f + 7), wv = ld3(f + 10);
+    st3(f, ld3(f) + v * K_DT);
+    float wn = norm(wv);
+    if (wn > 0.7853981633974483f / K_DT) wn = 0.7853981633974483f / K_DT;
+    V3 ax;
+    if (wn < 0.001f) ax = wv * (0.5f * K_DT - K_DT * K_DT * K_DT * 0.020833333333f * wn * wn);
+    else ax = wv * (sinf(0.5f * wn * K_DT) / wn);
+    Q4 dq = {ax.x, ax.y, ax.z, cosf(0.5f * wn * K_DT)};
+    Q4 q0 = {f[3], f[4], f[5], f[6]};
+    Q4 qn = qmul(dq, q0);
+    float nr = 1.f / sqrtf(qn.x * qn.x + qn.y * qn.y + qn.z * qn.z + qn.w * qn.w);
+    f[3] = qn.x * nr; f[4] = qn.y * nr; f[5] = qn.z * nr; f[6] = qn.w * nr;
+  }
+  WSYNC();
+  if (!st_lds) {
+    float* r = state + (size_t)env * RP_REC_FLOATS;
+    r[lane] = st[lane]; r[lane + 64] = st[lane + 64];
+  }
+  if (lane == 0 && !(debug_flags & RP_DBG_NOSORT)) {
+    int sp = sort_pos;
+    asm volatile("" : "+v"(sp));
+    sort_slot[env] = (sort_bin << SORT_RANK_BITS) | sp;
+  }
+  WSYNC();
+#if defined(RP_CLOCKS) && RP_CLOCKS == 1
+  HV_CLK(3)
+  if (lane == 0 && clk_wave >= 0) {
+    g_clk[8 * clk_wave + 5] = wall_clock64();
+    const int nlim = __popc(maskL) + __popc(maskU);
+    g_clk[8 * clk_wave + 6] = (unsigned long long)(n + nj + nlim + (gear ? 1 : 0)) | ((unsigned long long)nc << 8) | ((unsigned long long)nt << 16) | (1ull << 29);      /* bit 29: the heavy path */
+    unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    g_clk[8 * clk_wave + 7] = ((unsigned long long)xcc << 32) | hw;
+  }
+#endif
+#undef HV_CLK
+}
+
+/* The one-kernel twins (k_step, k_reset: substep()) on a heavy env: the rows they built in LDS are laid out as a workspace row - what k_prep2 hands to k_solve2 - and
+ * heavy_solve runs on it, integrating the record in L.st.  One implementation of the residual form on the device: the twins check the split pipeline's plumbing around
+ * it, the oracle checks the form. */
+__device__ bool substep_heavy(const DevModel* m, EnvLds& L, int lane, int nsmall, int ncon, int nt) {
+  const int cls = lane < ncon ? L.conk[lane] : 3;
+  const int nB = __popcll(__ballot(cls == 0)), nA = __popcll(__ballot(cls == 1)), nC = __popcll(__ballot(cls == 2));
+  if (hv_class(ncon, nA, nB, nC) != 1) return false;
+  __shared__ __align__(16) float w3[W3_FLOATS];
+  __shared__ __align__(16) float hv[2 * 64 * HV_STRIDE];
+  nsmall = uni(nsmall);
+  float* aout = w3 + W3_A;
+  for (int i = lane; i < AOUT_FLOATS; i += 64) aout[i] = 0.f;
+  WSYNC();
+  bool gear = false, lim_lo = false, lim_up = false; int dAl = 0;
+  if (lane < nsmall) {      /* the unit rows in the solver's dof-indexed form (prep2_core's wave 1, line for line: signs folded into rhs and bounds) */
+    const float* sr = &L.srow[8 * lane];
+    const int type = __float_as_int(sr[0]), dA = __float_as_int(sr[1]);
+    const float sg = sr[2], rhs = sr[3], dinv = sr[4], lo = sr[5], hi = sr[6];
+    dAl = dA;
+    if (type == SR_UNIT) { aout[dA] = dinv; aout[16 + dA] = rhs; aout[32 + dA] = lo; aout[48 + dA] = hi; }
+    else if (type == SR_LIMIT) {
+      const int pl = sg > 0.f ? 64 : 112;
+      aout[pl + dA] = sg * rhs; aout[pl + 16 + dA] = sg * lo; aout[pl + 32 + dA] = sg * hi;
+      lim_lo = sg > 0.f; lim_up = !(sg > 0.f);
+    } else if (type == SR_J1) {
+      const int k = lane;
+      if (k < NBJ) { float* bq = &aout[168]; bq[k] = dinv; bq[4 + k] = rhs; bq[8 + k] = lo; bq[12 + k] = hi; bq[16 + k] = sg; }
+    } else {
+      float* g = &aout[160];
+      g[0] = sr[1]; g[1] = sr[7]; g[2] = sg; g[3] = dinv; g[4] = rhs; g[5] = lo; g[6] = hi;
+      gear = true;
+    }
+  }
+  unsigned mL = 0u, mU = 0u;
+  for (int i = 0; i < RP_MAX_ARM; i++) { if (__ballot(lim_lo && dAl == i) != 0ull) mL |= 1u << i; if (__ballot(lim_up && dAl == i) != 0ull) mU |= 1u << i; }
+  const bool anygear = __ballot(gear) != 0ull;
+  if (lane == 0) {
+    const int nj = m->n_j1 < NBJ ? m->n_j1 : NBJ;
+    w3[W3_HDR] = __int_as_float((int)mL); w3[W3_HDR + 1] = __int_as_float((int)mU); w3[W3_HDR + 2] = __int_as_float(nj); w3[W3_HDR + 3] = __int_as_float(ncon);
+    w3[W3_HDR + 4] = __int_as_float(nA); w3[W3_HDR + 5] = __int_as_float(nB); w3[W3_HDR + 6] = __int_as_float((anygear ? 1 : 0) | (nt << 8)); w3[W3_HDR + 7] = __int_as_float(nC);
+  }
+  if (lane < 32) { w3[W3_VSTAR + lane] = L.vstar[lane]; w3[W3_MU + lane] = lane < ncon ? L.conmu[lane] : 0.f; }
+  for (int i = lane; i < 144; i += 64) w3[W3_MINV + i] = L.Minv[i];
+  /* contact rows: built normals, torsional rows, friction pairs (contact_rows); the workspace keeps normals, friction pairs, torsional rows */
+  const int nrc = 3 * ncon + nt;
+  auto global_row = [&](int lr) { return lr < ncon ? lr : (lr < ncon + nt ? 3 * ncon + (lr - ncon) : ncon + (lr - ncon - nt)); };
+  for (int e = lane; e < nrc * ROWW; e += 64) {
+    const int lr = e / ROWW, k = e - lr * ROWW, gr = global_row(lr);
+    w3[W3_J + gr * ROWW + k] = L.J[e]; w3[W3_B + gr * ROWW + k] = L.B[e];
+  }
+  for (int e = lane; e < nrc * 4; e += 64) {
+    const int lr = e >> 2, k = e & 3, gr = global_row(lr);
+    float v = L.rowS[e];
+    if (k == 3 && lr >= ncon && lr < ncon + nt) v = __int_as_float(L.torc[lr - ncon]);      /* a torsional row's parent contact (heavy_solve reads the low byte) */
+    w3[W3_ROWS + gr * 4 + k] = v; w3[W3_ROWT + gr * 4 + k] = L.rowT[e];
+  }
+  WSYNC();
+  heavy_solve(m, nullptr, w3, 0, nullptr, nullptr, RP_DBG_NOSORT, hv, L.st, 0);
+  return true;
+}
+
+/* The classes of a block's four envs (hv_class), decided from the same headers by both waves alike: masks of the places 4 bq + k whose env the four-env path takes,
+ * the heavy path (residual form), solve2_body (more than HV_MAXC contacts: dv form, like the four-env path) */
+static_assert(S4_SLOTS0 == 8 && S4_SLOTS1 == 16, "hv_class");
+__device__ __forceinline__ void block_classes(const float* __restrict__ ws, int env0, int N, const int* __restrict__ pair_env, const int bq, unsigned& light, unsigned& res, unsigned& super, int& env_g) {
   const int lane = threadIdx.x & 63, g = lane >> 4;
   const int place = bq * 4 + g;
   const int pe = place < N - env0 ? pair_env[env0 + place] : -1;
   const int envm = pair_env_id(pe);
   const bool valid = pe >= 0;
   const float* w = ws + (size_t)(valid ? envm : 0) * W3_FLOATS;
-  const float4 h1 = *(const float4*)&w[W3_HDR + 4];
-  const bool bad = valid && (__float_as_int(h1.w) != 0 || __float_as_int(h1.x) > S4_SLOTS0 || __float_as_int(h1.y) > S4_SLOTS1);
-#ifdef RP_S4_OFF            /* timing ablation: every block takes the two-env path */
-  return false;
+  const float4 h0 = *(const float4*)&w[W3_HDR], h1 = *(const float4*)&w[W3_HDR + 4];
+  const int cls = valid ? hv_class(__float_as_int(h0.w), __float_as_int(h1.x), __float_as_int(h1.y), __float_as_int(h1.w)) : -1;
+  auto pack = [](unsigned long long b) { return (unsigned)((b & 1ull) | ((b >> 15) & 2ull) | ((b >> 30) & 4ull) | ((b >> 45) & 8ull)); };
+#ifdef RP_S4_OFF            /* timing ablation: no block takes the four-env path */
+  light = 0u; super = pack(__ballot(cls == 0 || cls == 2));
+#else
+  light = pack(__ballot(cls == 0)); super = pack(__ballot(cls == 2));
 #endif
-  return __ballot(bad) == 0ull && !(debug_flags & 1);
+  res = pack(__ballot(cls == 1));
+  env_g = valid ? envm : -1;
 }
 
 #define SOLVE2_ARGS const DevModel* __restrict__ m, float* __restrict__ state, const float* __restrict__ ws, int env0, int N, \
                     const int* __restrict__ pair_env, int* __restrict__ sort_cnt_next, int* __restrict__ sort_slot, int debug_flags
 #if defined(RP_CLOCKS) && RP_CLOCKS != 2      /* profiling build: wall clock at both ends of a four-env wave, bit 30 of word 6 = "took the four-env path" */
-#define S4_CLK(i) if ((threadIdx.x & 63) == 0) { const int wb_ = blockIdx.x * SOLVE_WAVES + (threadIdx.x >> 6); g_clk[8 * wb_ + (i)] = wall_clock64(); g_clk[8 * wb_ + 6] = 1ull << 30; }
+#define S4_CLK(i) if ((threadIdx.x & 63) == 0) { const int wb_ = blockIdx.x * SOLVE_WAVES + (threadIdx.x >> 6); g_clk[8 * wb_ + (i)] = wall_clock64(); g_clk[8 * wb_ + 6] |= 1ull << 30; }
 #else
 #define S4_CLK(i)
 #endif
@@ -4432,18 +4950,59 @@ __device__ __forceinline__ bool solve4_eligible(const float* __restrict__ ws, in
 __device__ __forceinline__ void solve_block(const DevModel* __restrict__ m, float* __restrict__ state, const float* __restrict__ ws, int env0, int N,
                                             const int* __restrict__ pair_env, int* __restrict__ sort_cnt_next, int* __restrict__ sort_slot, int debug_flags, Solve2Lds* Ls, const int bq) {
   static_assert(sizeof(Solve2Lds) >= 4 * RP_REC_FLOATS * sizeof(float), "the four-env path keeps four state records where the two-env path stages its rows");
-  if (solve4_eligible(ws, env0, N, pair_env, debug_flags, bq)) {
+  static_assert(sizeof(Solve2Lds) >= HV_LDS_FLOATS * sizeof(float), "the heavy path's tables");
+  unsigned light, res, super; int env_g;
+  block_classes(ws, env0, N, pair_env, bq, light, res, super, env_g);
+  const int wid = threadIdx.x >> 6;
+  if (debug_flags & RP_DBG_SEQ) { super |= light; light = 0u; }
+  if (light != 0u) {
     S4_CLK(4)
-    if ((threadIdx.x >> 6) == 0) solve4_body<0>(m, state, ws, env0, N, pair_env, sort_cnt_next, sort_slot, debug_flags, (float*)&Ls[0], bq);
-    else solve4_body<1>(m, state, ws, env0, N, pair_env, sort_cnt_next, sort_slot, debug_flags, (float*)&Ls[1], bq);
+    if (wid == 0) solve4_body<0>(m, state, ws, env0, N, pair_env, sort_cnt_next, sort_slot, debug_flags, (float*)&Ls[0], bq, light);
+    else solve4_body<1>(m, state, ws, env0, N, pair_env, sort_cnt_next, sort_slot, debug_flags, (float*)&Ls[1], bq, light);
     S4_CLK(5)
-  } else solve2_body(m, state, ws, env0, N, pair_env, sort_cnt_next, sort_slot, debug_flags, Ls, bq);
+  }
+  if (super != 0u) {
+    if (light != 0u) WSYNC();
+    solve2_body(m, state, ws, env0, N, pair_env, sort_cnt_next, sort_slot, debug_flags, Ls, bq, super);
+  }
+  if (res != 0u && !(debug_flags & RP_DBG_WORKERS)) {      /* (k_chain, the settle substeps of rp_reset: no worker blocks) this block's heavy envs, one per wave at a time */
+    int k = 0;
+#pragma unroll 1
+    for (int g = 0; g < 4; g++) {
+      if (!((res >> g) & 1u)) continue;
+      if ((k & 1) == wid) {
+        WSYNC();
+        const int env = __builtin_amdgcn_readlane(env_g, 16 * g);
+        heavy_solve(m, state, ws + (size_t)env * W3_FLOATS, env, sort_cnt_next, sort_slot, debug_flags, (float*)&Ls[wid], nullptr, 4 * bq + g);
+      }
+      k++;
+    }
+  }
 }
-#define SOLVE_DISPATCH \
-  __shared__ Solve2Lds Ls[SOLVE_WAVES]; \
+/* k_solve2's grid: HB worker blocks in front - their waves take the heavy envs of the launch off the list the k_prep2 before it appended them to (hv_list: env | contact
+ * count << 24 at places env0 .. of its group, *hv_cnt of them), ONE ENV PER WAVE, wave i the entries i, i + 2 HB, ... - and behind them the blocks of four places each.
+ * The heavy waves are the launch's long poles: they start first, and nobody waits in line behind a partner. */
+__global__ void __launch_bounds__(64 * SOLVE_WAVES, 2) k_solve2(SOLVE2_ARGS, const int* __restrict__ hv_cnt, const int* __restrict__ hv_list, int HB) {
+  __shared__ Solve2Lds Ls[SOLVE_WAVES];
+  if ((int)blockIdx.x < HB) {
+    const int wid = threadIdx.x >> 6;
+    const int nH = __builtin_amdgcn_readfirstlane(*hv_cnt);
+#if defined(RP_CLOCKS) && RP_CLOCKS == 1
+    if ((threadIdx.x & 63) == 0) { const int wb_ = blockIdx.x * SOLVE_WAVES + wid; for (int q = 0; q < 8; q++) g_clk[8 * wb_ + q] = 0ull; g_clk[8 * wb_ + 6] = (1ull << 28) | (unsigned long long)nH; }      /* bit 28: a worker wave (without bit 29: it found no env) */
+#endif
+#pragma unroll 1
+    for (int i = blockIdx.x * SOLVE_WAVES + wid; i < nH; i += HB * SOLVE_WAVES) {
+      const int env = __builtin_amdgcn_readfirstlane(pair_env_id(hv_list[env0 + i]));
+      heavy_solve(m, state, ws + (size_t)env * W3_FLOATS, env, sort_cnt_next, sort_slot, debug_flags, (float*)&Ls[wid], nullptr, i, blockIdx.x * SOLVE_WAVES + wid);
+    }
+    return;
+  }
+  solve_block(m, state, ws, env0, N, pair_env, sort_cnt_next, sort_slot, debug_flags, Ls, blockIdx.x - HB);
+}
+__global__ void __launch_bounds__(64 * SOLVE_WAVES, 2) k_settle_solve(SOLVE2_ARGS) {
+  __shared__ Solve2Lds Ls[SOLVE_WAVES];
   solve_block(m, state, ws, env0, N, pair_env, sort_cnt_next, sort_slot, debug_flags, Ls, blockIdx.x);
-__global__ void __launch_bounds__(64 * SOLVE_WAVES, 2) k_solve2(SOLVE2_ARGS) { SOLVE_DISPATCH }
-__global__ void __launch_bounds__(64 * SOLVE_WAVES, 2) k_settle_solve(SOLVE2_ARGS) { SOLVE_DISPATCH }
+}
 
 /* ------------------------------------------------------------------ k_chain: all substeps of a step in ONE launch (round 4's experiment, rp_set_fused(h, 2)).
  * A block of two waves owns the same four envs (places 4 q .. 4 q + 3 of the load ranking `member`) for all nsub substeps and alternates inside itself between their
@@ -4520,9 +5079,10 @@ __global__ void k_sort_init(int* __restrict__ cnt, int* __restrict__ slot, int e
  * on membership or pairing. */
 struct GroupBounds { int b[RP_MAX_GROUPS + 1]; };     /* group g owns places [b[g], b[g + 1]) */
 __global__ void __launch_bounds__(1024) k_member(const int* __restrict__ member_old, int* __restrict__ member_new, int* __restrict__ cnt,
-                                                 int* __restrict__ sort_slot, int N, int G_old, GroupBounds bo, int G_new, GroupBounds bn) {
+                                                 int* __restrict__ sort_slot, int N, int G_old, GroupBounds bo, int G_new, GroupBounds bn, int* __restrict__ hv_cnt_all) {
   __shared__ int tot[SORT_BINS], above[SORT_BINS], gpre[RP_MAX_GROUPS * SORT_BINS];
   const int t = threadIdx.x;
+  if (t < 2 * RP_MAX_GROUPS) hv_cnt_all[t] = 0;      /* every group's two heavy-env counters start the step at zero */
   for (int b = t; b < SORT_BINS; b += 1024) {
     int sum = 0;
     for (int g = 0; g < G_old; g++) { gpre[g * SORT_BINS + b] = sum; sum += cnt[g * SORT_BINS + b]; }
@@ -4561,8 +5121,9 @@ __global__ void __launch_bounds__(1024) k_member(const int* __restrict__ member_
     sort_slot[member_new[p]] = ((SORT_REPS - 1 - (i & (SORT_REPS - 1))) << SORT_RANK_BITS) | (i >> 3);
   }
 }
-__global__ void k_member_identity(int* __restrict__ member, int N) {
+__global__ void k_member_identity(int* __restrict__ member, int N, int* __restrict__ hv_cnt_all) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 2 * RP_MAX_GROUPS) hv_cnt_all[i] = 0;
   if (i < N) member[i] = i;
 }
 

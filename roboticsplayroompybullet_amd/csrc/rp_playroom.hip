@@ -31,6 +31,9 @@ struct rp_sim {
   int* sort_cnt;           /* [2][RP_MAX_GROUPS][SORT_BINS] load-class histograms for pairing envs in k_solve2 (double-buffered) */
   int* sort_slot;          /* [N] per env: (bin << 16) | rank inside the bin, from the latest k_solve2 */
   int* pair_env;           /* [N] per group range: env ids sorted by load class, heaviest first (k_solve2 pairs neighbours) */
+  int* hv_list;            /* [N] per group range: the heavy envs of the current substep (k_prep2 appends, k_solve2's worker blocks take them: one env per wave) */
+  int hv_waves;            /* worker waves per group (0: an eighth of the group's envs, 16 .. 512; RP_HV_WAVES overrides) */
+  int* hv_cnt;             /* [2][RP_MAX_GROUPS] their number, double-buffered by substep parity (zeroed by k_member and by the k_prep2 before) */
   GroupBounds gb;          /* place ranges of the groups the tables were built for */
   int gsplit[RP_MAX_GROUPS]; /* RP_GROUP_SPLIT: relative sizes of the groups, heaviest first (0 = equal) */
   int* member[2];          /* [N] place -> env, all envs ranked by load class (k_member); group g owns places [N g / G, N (g + 1) / G) */
@@ -102,7 +105,7 @@ const char* rp_version(void) { return "rp_playroom 0.4 (gfx950) build " RP_BUILD
 
 static void destroy_handle(rp_sim* h) {        /* frees whatever a (possibly partial) handle owns; hipFree(nullptr) etc. are no-ops */
   if (!h) return;
-  hipFree(h->hullv); hipFree(h->hcv); hipFree(h->hco); hipFree(h->hpl); hipFree(h->pmcache); hipFree(h->dev_model); hipFree(h->state); hipFree(h->ws); hipFree(h->dbg); hipFree(h->sort_cnt); hipFree(h->sort_slot); hipFree(h->pair_env); hipFree(h->member[0]); hipFree(h->member[1]);
+  hipFree(h->hullv); hipFree(h->hcv); hipFree(h->hco); hipFree(h->hpl); hipFree(h->pmcache); hipFree(h->dev_model); hipFree(h->state); hipFree(h->ws); hipFree(h->dbg); hipFree(h->sort_cnt); hipFree(h->sort_slot); hipFree(h->pair_env); hipFree(h->hv_list); hipFree(h->hv_cnt); hipFree(h->member[0]); hipFree(h->member[1]);
   hipFree(h->rc_tab); hipFree(h->rc_cnt); hipFree(h->rc_ee);
   hipFree(h->rs_state); hipFree(h->rs_idx); hipFree(h->rs_meta); hipFree(h->rs_count); hipFree(h->rs_sort_cnt); hipFree(h->rs_sort_slot); hipFree(h->rs_pair);
   if (h->rs_count_host) hipHostFree(h->rs_count_host);
@@ -194,6 +197,10 @@ int rp_create(const rp_config* cfg, rp_handle* out) {
   CREATE_CHK(hipMalloc((void**)&h->sort_cnt, (size_t)2 * RP_MAX_GROUPS * SORT_BINS * sizeof(int)));
   CREATE_CHK(hipMalloc((void**)&h->sort_slot, (size_t)N * sizeof(int)));
   CREATE_CHK(hipMalloc((void**)&h->pair_env, (size_t)N * sizeof(int)));
+  { const char* e = getenv("RP_HV_WAVES"); h->hv_waves = e ? atoi(e) : 0; }
+  CREATE_CHK(hipMalloc((void**)&h->hv_list, (size_t)N * sizeof(int)));
+  CREATE_CHK(hipMalloc((void**)&h->hv_cnt, 2 * RP_MAX_GROUPS * sizeof(int)));
+  CREATE_CHK(hipMemset(h->hv_cnt, 0, 2 * RP_MAX_GROUPS * sizeof(int)));
   CREATE_CHK(hipMalloc((void**)&h->member[0], (size_t)N * sizeof(int)));
   CREATE_CHK(hipMalloc((void**)&h->member[1], (size_t)N * sizeof(int)));
   {
@@ -430,10 +437,10 @@ int rp_step(rp_handle h, const float* action, const rp_out* out, void* stream) {
     GroupBounds gb;
     gb.b[0] = 0;
     for (int g = 1; g <= RP_MAX_GROUPS; g++) gb.b[g] = N;
-    if (h->sort_G == 0) hipLaunchKernelGGL(k_member_identity, dim3((N + 255) / 256), dim3(256), 0, s, h->member[h->member_cur], N);
+    if (h->sort_G == 0) hipLaunchKernelGGL(k_member_identity, dim3((N + 255) / 256), dim3(256), 0, s, h->member[h->member_cur], N, h->hv_cnt);
     else {
       hipLaunchKernelGGL(k_member, dim3(1), dim3(1024), 0, s, h->member[h->member_cur], h->member[h->member_cur ^ 1], h->sort_cnt + (size_t)h->sort_par * RP_MAX_GROUPS * SORT_BINS,
-                         h->sort_slot, N, h->sort_G, h->gb, 1, gb);
+                         h->sort_slot, N, h->sort_G, h->gb, 1, gb, h->hv_cnt);
       h->member_cur ^= 1;
     }
     const int* member = h->member[h->member_cur];
@@ -479,10 +486,10 @@ int rp_step(rp_handle h, const float* action, const rp_out* out, void* stream) {
     }
     const int* member = h->member[h->member_cur];
     if (h->sort_G == 0) {
-      hipLaunchKernelGGL(k_member_identity, dim3((N + 255) / 256), dim3(256), 0, s, h->member[h->member_cur], N);
+      hipLaunchKernelGGL(k_member_identity, dim3((N + 255) / 256), dim3(256), 0, s, h->member[h->member_cur], N, h->hv_cnt);
     } else {
       hipLaunchKernelGGL(k_member, dim3(1), dim3(1024), 0, s, member, h->member[h->member_cur ^ 1], h->sort_cnt + (size_t)h->sort_par * RP_MAX_GROUPS * SORT_BINS,
-                         h->sort_slot, N, h->sort_G, h->gb, G, gb);
+                         h->sort_slot, N, h->sort_G, h->gb, G, gb, h->hv_cnt);
       h->member_cur ^= 1;
       member = h->member[h->member_cur];
     }
@@ -491,7 +498,7 @@ int rp_step(rp_handle h, const float* action, const rp_out* out, void* stream) {
      * machine's width) sets the step time at N = 4096, so all chains have to start at once - enqueued group by group, the last group's chain
      * started a whole group's worth of host launch time late (2.38 -> 2.1x ms per step).  Same kernels, same arguments, same order inside
      * every stream. */
-    struct GroupCtx { hipStream_t gs; int e0, e1, ng, nab; int* gcnt[2]; } gc[RP_MAX_GROUPS];
+    struct GroupCtx { hipStream_t gs; int e0, e1, ng, nab, hb; int* gcnt[2]; int* hvc[2]; } gc[RP_MAX_GROUPS];
     const int par0 = h->sort_par;
     for (int g = 0; g < G; g++) {
       GroupCtx& c = gc[g];
@@ -503,6 +510,10 @@ int rp_step(rp_handle h, const float* action, const rp_out* out, void* stream) {
       /* env pairing of this group: k_solve2 ranks its envs by load class (histogram, double-buffered), the next k_prep2
        * turns the ranks into the table the next k_solve2 reads */
       c.gcnt[0] = h->sort_cnt + (size_t)g * SORT_BINS; c.gcnt[1] = h->sort_cnt + (size_t)(RP_MAX_GROUPS + g) * SORT_BINS;
+      /* the heavy envs of a substep (1 - 2 % of the envs: a grasp, a push, a crowded drawer) are listed by its k_prep2 and solved one per wave by worker blocks at the head
+       * of k_solve2's grid: an eighth of the group's envs' worth of waves (a longer list is walked in strides) */
+      c.hvc[0] = h->hv_cnt + g; c.hvc[1] = h->hv_cnt + RP_MAX_GROUPS + g;
+      { const int wv = h->hv_waves > 0 ? h->hv_waves : min(max(c.ng / 8, 16), 512); c.hb = (wv + SOLVE_WAVES - 1) / SOLVE_WAVES; }
       if (c.gs != s) hipStreamWaitEvent(c.gs, h->gfork, 0);
       if (ev) hipEventRecord(ev[0], c.gs);
       if (h->sort_G == 0) hipLaunchKernelGGL(k_sort_init, dim3((max(c.ng, SORT_BINS) + 255) / 256), dim3(256), 0, c.gs, c.gcnt[par0], h->sort_slot, c.e0, c.ng);
@@ -521,18 +532,19 @@ int rp_step(rp_handle h, const float* action, const rp_out* out, void* stream) {
           fprintf(stderr, "[rp sync] before k_action_prep: %d\n", (int)hipDeviceSynchronize()); fflush(stderr);
 #endif
           hipLaunchKernelGGL(k_action_prep, dim3((c.ng + 7) / 8 + c.ng), dim3(PREP_THREADS), 0, gs, h->dev_model, h->state, h->ws, c.e0, c.e1, c.gcnt[par], c.gcnt[par ^ 1], h->sort_slot,
-                             h->pair_env, member, action, op.target_poses, (c.ng + 7) / 8);
+                             h->pair_env, member, action, op.target_poses, (c.ng + 7) / 8, c.hvc[sub & 1], c.hvc[(sub & 1) ^ 1], h->hv_list);
 #ifdef RP_SYNC_DEBUG
           fprintf(stderr, "[rp sync] after k_action_prep: %d\n", (int)hipDeviceSynchronize()); fflush(stderr);
 #endif
         } else
-          TIMED(hipLaunchKernelGGL(k_prep2, dim3(c.ng), dim3(PREP_THREADS), 0, gs, h->dev_model, h->state, h->ws, c.e0, c.e1, c.gcnt[par], c.gcnt[par ^ 1], h->sort_slot, h->pair_env, member));
+          TIMED(hipLaunchKernelGGL(k_prep2, dim3(c.ng), dim3(PREP_THREADS), 0, gs, h->dev_model, h->state, h->ws, c.e0, c.e1, c.gcnt[par], c.gcnt[par ^ 1], h->sort_slot, h->pair_env, member,
+                                   c.hvc[sub & 1], c.hvc[(sub & 1) ^ 1], h->hv_list));
       }
       for (int g = 0; g < G; g++) {
         const GroupCtx& c = gc[g];
         hipStream_t gs = c.gs;
-        TIMED(hipLaunchKernelGGL(k_solve2, dim3((c.ng + 2 * SOLVE_WAVES - 1) / (2 * SOLVE_WAVES)), dim3(64 * SOLVE_WAVES), 0, gs, h->dev_model, h->state, h->ws, c.e0, c.e1, h->pair_env, c.gcnt[par ^ 1], h->sort_slot,
-                                 h->debug_flags | (merged ? 2 : 0)));
+        TIMED(hipLaunchKernelGGL(k_solve2, dim3(c.hb + (c.ng + 2 * SOLVE_WAVES - 1) / (2 * SOLVE_WAVES)), dim3(64 * SOLVE_WAVES), 0, gs, h->dev_model, h->state, h->ws, c.e0, c.e1, h->pair_env, c.gcnt[par ^ 1], h->sort_slot,
+                                 h->debug_flags | (merged ? RP_DBG_MOTOR : 0) | RP_DBG_WORKERS, (const int*)c.hvc[sub & 1], (const int*)h->hv_list, c.hb));
       }
       par ^= 1;
     }

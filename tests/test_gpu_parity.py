@@ -156,7 +156,7 @@ def test_hull_gjk_option_vs_fp64_oracle(kind, gjk, epa):
     env = VecPlayEnv(IDS[kind], n, seed=9, hull_gjk=gjk, hull_epa=epa)
     env.reset()
     with_epa = gjk and (epa if epa is not None else kind != 'U')
-    fol = [Followers(kind, 9, e, extra=4, rule=1015 | (1024 if gjk else 0) | (131072 if with_epa else 0)) for e in range(n)]
+    fol = [Followers(kind, 9, e, extra=4, rule=1015 | 262144 | (1024 if gjk else 0) | (131072 if with_epa else 0)) for e in range(n)]
     for f in fol:
         f.o64.reset()
         f.start_from(f.o64)
@@ -191,7 +191,7 @@ def test_speculative_limits_option_vs_fp64_oracle(kind):
     n, steps = 8, 60
     env = VecPlayEnv(IDS[kind], n, seed=9, speculative_limits=True)
     env.reset()
-    fol = [Followers(kind, 9, e, extra=2, rule=(2039 if kind == 'U' else 133111) & ~2) for e in range(n)]
+    fol = [Followers(kind, 9, e, extra=2, rule=((2039 if kind == 'U' else 133111) | 262144) & ~2) for e in range(n)]
     for f in fol:
         f.o64.reset()
         f.start_from(f.o64)
