@@ -56,7 +56,7 @@
 #define RPO_RULE_EPA 131072         /* ... and where GJK finds the CORES overlapping (its simplex a tetrahedron around the origin): the expanding-polytope algorithm on the two cores - exact for polytopes -
                                      * gives depth, normal and witness points; the margins add 2 x 0.001 along the same normal (hull_box_epa).  Without the bit: the OBB path, as in round 4 */
 #define RPO_RULE_RESIDUAL 262144    /* the RESIDUAL (Delassus) form of the sequential-impulse sweeps for the envs the HIP library solves on its one-env-per-wave path: coupled envs (a contact
-                                     * that spans the two halves of the velocity layout) or envs with more contacts of one half than the four-env path has slots, with at most RES_MAX_CON
+                                     * that spans the two halves of the velocity layout) or envs with more contacts of one half than the four-env path has slots
                                      * contacts (solve_rows_residual).  Same rows, same order, same clamps; J . dv is carried along row by row instead of being summed anew: other rounding */
 #define RPO_RULE_GJK 1024           /* ... and where the deepest vertex lies BESIDE the face (box edges and corners): GJK's distance phase on hull and box (hull_box_gjk) */
 #define RPO_RULE_HULLFACE 4         /* arm links touch static boxes with the vertices of their collision meshes' convex hulls (hull_face) instead of their OBBs */
@@ -1623,11 +1623,10 @@ static void solve_one(rpo_env* e, row* r, real lo, real hi, real* dv) {
   for (int i = 0; i < nv; i++) dv[i] += r->B[i] * d;
 }
 /* RPO_RULE_RESIDUAL.  Which envs: the ones the HIP library's k_solve2 cannot put on its four-env path (rp_kernels.cuh solve4_eligible: no contact that spans the two halves
- * of the velocity layout, at most S4_SLOTS0 = 8 contacts of half 0 and S4_SLOTS1 = 16 of half 1) and whose rows fit the 64 lanes of one wave (RES_MAX_CON contacts: 14
- * normals, 14 + 14 friction rows, 4 torsional rows, the gear, 12 + 3 dofs with unit rows).  A property of the env's own contact list: never of who shares a wave with whom. */
-#define RES_MAX_CON 14
+ * of the velocity layout, at most S4_SLOTS0 = 8 contacts of half 0 and S4_SLOTS1 = 8 of half 1).  A property of the env's own contact list: never of who shares a wave
+ * with whom. */
 #define RES_SLOTS0 8
-#define RES_SLOTS1 16
+#define RES_SLOTS1 8
 static int residual_form(const rpo_env* e) {
   if (!(e->rule & RPO_RULE_RESIDUAL)) return 0;
   int n0 = 0, n1 = 0, nspan = 0;
@@ -1636,7 +1635,7 @@ static int residual_form(const rpo_env* e) {
     contact_halves(e, &e->con[i], &half0, &half1, &arm, &movable);
     if (half0 && half1) nspan++; else if (half0) n0++; else n1++;
   }
-  return (nspan > 0 || n0 > RES_SLOTS0 || n1 > RES_SLOTS1) && e->ncon <= RES_MAX_CON;
+  return nspan > 0 || n0 > RES_SLOTS0 || n1 > RES_SLOTS1;
 }
 /* The sweeps in residual form (the HIP library's heavy_solve, one env per wave).  A "lane" carries one number through the sweeps, the row's UNCLAMPED STEP
  *   r = rhs - lambda cfm - Jd . dv        (Bullet's deltaImpulse before its clamp, resolveSingleConstraintRowGeneric)

@@ -3418,16 +3418,24 @@ __device__ __forceinline__ void copy_out(float* __restrict__ dst, const float* s
 #define W3_SLOT (W3_ROFF + 64)        /* 64 ints: contact index of the s-th non-arm | arm-only | spanning contact (21 each), -1 = none */
 #define W3_J (W3_SLOT + 64)           /* compact contact rows, ROWW floats each */
 #define W3_B (W3_J + ROWREG)
-#define W3_FLOATS (W3_B + ROWREG)
+#define W3_SROW (W3_B + ROWREG)       /* the non-contact rows as build_small_rows made them (typed list, signs not folded): [0] their number, [4 + 8 r ..] row r.  Written for the envs
+                                       * super_solve takes (more than HV_MAXC contacts; every env under debug flag 1) */
+#define W3_FLOATS (W3_SROW + 4 + 8 * MAXSMALL)
 #define STAGE_FLOATS (128 + 2 * ROWREG)   /* ROFF | SLOT | J | B: contiguous, staged through LDS by k_solve2 */
 #define AOUT_FLOATS (160 + 8 + 20)
 static_assert(W3_A % 4 == 0 && W3_ROWS % 4 == 0 && W3_ROFF % 4 == 0 && AOUT_FLOATS % 4 == 0, "16-byte copies");
 
 #define HV_MAXC 14                    /* contacts of an env on k_solve2's heavy path (heavy_solve; oracle: RES_MAX_CON) */
+#ifndef S4_SLOTS0
+#define S4_SLOTS0 8                   /* the four-env path's contact slots: row-0 stream (arm, drawer: wave 0; oracle: RES_SLOTS0) */
+#endif
+#ifndef S4_SLOTS1
+#define S4_SLOTS1 8                   /* ... row-1 stream (objects, scene-joint bodies: wave 1; oracle: RES_SLOTS1) */
+#endif
 /* which path of k_solve2 solves an env with nc contacts - nA of them touch the first half of the velocity layout only, nB the second half only, nC both.  0: the four-env
- * path (dv form); 1: the heavy path (one env per wave, residual form); 2: more than HV_MAXC contacts - solve2_body (dv form) */
+ * path (dv form); 1: the heavy path (one env per wave, residual form); 2: the heavy path with more than HV_MAXC contacts (a second lane register: heavy_solve<true>) */
 __device__ __forceinline__ int hv_class(int nc, int nA, int nB, int nC) {
-  const bool heavy = nC != 0 || nA > 8 || nB > 16;      /* (S4_SLOTS0, S4_SLOTS1: static_assert at block_classes) */
+  const bool heavy = nC != 0 || nA > S4_SLOTS0 || nB > S4_SLOTS1;
   return !heavy ? 0 : (nc <= HV_MAXC ? 1 : 2);
 }
 #define PREP_THREADS 128
@@ -3435,7 +3443,7 @@ __device__ __forceinline__ int hv_class(int nc, int nA, int nB, int nC) {
  * scratch range: the cache stays the env's own), pair_tab[pair_idx] = this env's entry of the pairing table (env | contact count << 24; stored by wave 1, lane 0).
  * Ends without a barrier: the caller synchronises before L is used again. */
 __device__ __forceinline__ void prep2_core(PrepLds& L, const DevModel* __restrict__ m, const float* __restrict__ state, float* __restrict__ ws, const int env, const int cenv,
-                                           int* __restrict__ pair_tab, const int pair_idx, int* __restrict__ hv_cnt = nullptr, int* __restrict__ hv_list = nullptr) {      /* hv_cnt, hv_list: k_solve2's list of heavy envs (its worker blocks), nullptr = none */      /* (table and index apart: a per-thread pointer held across the whole kernel costs two registers, and this kernel spills for less) */
+                                           int* __restrict__ pair_tab, const int pair_idx, int* __restrict__ hv_cnt = nullptr, int* __restrict__ hv_list = nullptr, const int prep_flags = 0) {      /* hv_cnt, hv_list: k_solve2's list of heavy envs (its worker blocks), nullptr = none; prep_flags bit 0: every env's typed row list */      /* (table and index apart: a per-thread pointer held across the whole kernel costs two registers, and this kernel spills for less) */
   const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
   PCLK(6) PCLK(0) PCLK_ZERO(15) PCLK_ZERO(19) PCLK_ZERO(26) PCLK_ZERO(27) PCLK_ZERO(28) PCLK_ZERO(29) PCLK_ZERO(30) PCLK_ZERO(31)
   static_assert(RP_REC_FLOATS == PREP_THREADS, "one float of the record per thread");
@@ -3471,6 +3479,7 @@ __device__ __forceinline__ void prep2_core(PrepLds& L, const DevModel* __restric
     nsmall = uni(nsmall);
     for (int i = lane; i < AOUT_FLOATS; i += 64) L.aout[i] = 0.f;
     if (lane < 2) L.amask[lane] = 0u;
+    if (lane == 2) L.amask[2] = (unsigned)nsmall;      /* (waits in LDS for the end of the kernel, like the pairing index) */
     WSYNC();
     bool gear = false;
     if (lane < nsmall) {      /* signs folded into rhs and bounds: exact */
@@ -3560,13 +3569,20 @@ __device__ __forceinline__ void prep2_core(PrepLds& L, const DevModel* __restric
       w[W3_HDR + 2] = __int_as_float(nj); w[W3_HDR + 3] = __int_as_float(ncon);
       w[W3_HDR + 4] = __int_as_float(__popcll(mA)); w[W3_HDR + 5] = __int_as_float(__popcll(mB));
       w[W3_HDR + 6] = __int_as_float(L.hdr[1] | (nt << 8)); w[W3_HDR + 7] = __int_as_float(__popcll(mC));      /* gear present | torsional rows << 8 */
-      if (hv_list != nullptr && hv_class(ncon, __popcll(mA), __popcll(mB), __popcll(mC)) == 1) hv_list[atomicAdd(hv_cnt, 1)] = env | (ncon << 24);      /* a heavy env: one wave of k_solve2's worker blocks to itself */
+      if (hv_list != nullptr && (hv_class(ncon, __popcll(mA), __popcll(mB), __popcll(mC)) != 0 || (prep_flags & 1))) hv_list[atomicAdd(hv_cnt, 1)] = env | (ncon << 24);      /* a heavy env: one of k_solve2's worker blocks to itself */
     }
     if (lane < 32) w[W3_MU + lane] = lane < ncon ? L.conmu[lane] : 0.f;
     copy_out(w + W3_ROFF, (const float*)L.roff, 64, lane);
     copy_out(w + W3_SLOT, (const float*)L.slot, 64, lane);
   } else {
     if ((tid_j & 63) == 0) pair_tab[L.hdr[3]] = env | (ncon << 24);     /* + its contact count: k_solve2 sizes its row copy without waiting for the header */
+    if (prep_flags & 1) {      /* (debug flag 1) super_solve's envs: the typed row list too (it walks the rows the way the one-kernel path does) */
+      const int lane = tid_j & 63;
+      float* w = ws + (size_t)env * W3_FLOATS;
+      const int nsm = (int)L.amask[2];
+      if (lane == 0) w[W3_SROW] = __int_as_float(nsm);
+      for (int i = lane; i < 8 * nsm; i += 64) w[W3_SROW + 4 + i] = L.srow[i];
+    }
   }
   PCLK(5) PCLK(7)
 }
@@ -3574,7 +3590,7 @@ __device__ __forceinline__ void prep2_core(PrepLds& L, const DevModel* __restric
 __device__ __forceinline__ void prep2_body(const DevModel* __restrict__ m, const float* __restrict__ state, float* __restrict__ ws, int env0, int N,
                                            const int* __restrict__ sort_cnt, int* __restrict__ sort_cnt_next, const int* __restrict__ sort_slot, int* __restrict__ pair_env,
                                            const int* __restrict__ member, const int bid, const int* __restrict__ cache_env = nullptr, int* __restrict__ hv_cnt = nullptr, int* __restrict__ hv_cnt_next = nullptr,
-                                           int* __restrict__ hv_list = nullptr) {
+                                           int* __restrict__ hv_list = nullptr, const int prep_flags = 0) {
   __shared__ PrepLds L;
   const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
   int env = env0 + bid;
@@ -3601,16 +3617,16 @@ __device__ __forceinline__ void prep2_body(const DevModel* __restrict__ m, const
     for (int d = 32; d >= 1; d >>= 1) above += __shfl_xor(above, d);
     pair_place = above + (my_slot & SORT_RANK_MASK);
   }
-  prep2_core(L, m, state, ws, env, cache_env ? cache_env[env] : env, pair_env, env0 + pair_place, hv_cnt, hv_list ? hv_list + env0 : nullptr);
+  prep2_core(L, m, state, ws, env, cache_env ? cache_env[env] : env, pair_env, env0 + pair_place, hv_cnt, hv_list ? hv_list + env0 : nullptr, prep_flags);
 }
 /* two entry points on the same body: rp_step's substeps, and the settle substeps of rp_reset under their own name so that
  * profiles keep the two apart */
 #define PREP2_ARGS const DevModel* __restrict__ m, const float* __restrict__ state, float* __restrict__ ws, int env0, int N, \
                    const int* __restrict__ sort_cnt, int* __restrict__ sort_cnt_next, const int* __restrict__ sort_slot, int* __restrict__ pair_env, \
                    const int* __restrict__ member
-#define HV_ARGS int* __restrict__ hv_cnt, int* __restrict__ hv_cnt_next, int* __restrict__ hv_list      /* the heavy envs of this substep (k_solve2's worker blocks): counter, the next substep's counter, list */
-__global__ void __launch_bounds__(PREP_THREADS, RP_PREP_WAVES) k_prep2(PREP2_ARGS, HV_ARGS) { prep2_body(m, state, ws, env0, N, sort_cnt, sort_cnt_next, sort_slot, pair_env, member, blockIdx.x, nullptr, hv_cnt, hv_cnt_next, hv_list); }
-__global__ void __launch_bounds__(PREP_THREADS, RP_PREP_WAVES) k_settle_prep(PREP2_ARGS, const int* __restrict__ cache_env) { prep2_body(m, state, ws, env0, N, sort_cnt, sort_cnt_next, sort_slot, pair_env, member, blockIdx.x, cache_env); }
+#define HV_ARGS int* __restrict__ hv_cnt, int* __restrict__ hv_cnt_next, int* __restrict__ hv_list, int prep_flags      /* the heavy envs of this substep (k_solve2's worker blocks): counter, the next substep's counter, list; prep2_core's flags */
+__global__ void __launch_bounds__(PREP_THREADS, RP_PREP_WAVES) k_prep2(PREP2_ARGS, HV_ARGS) { prep2_body(m, state, ws, env0, N, sort_cnt, sort_cnt_next, sort_slot, pair_env, member, blockIdx.x, nullptr, hv_cnt, hv_cnt_next, hv_list, prep_flags); }
+__global__ void __launch_bounds__(PREP_THREADS, RP_PREP_WAVES) k_settle_prep(PREP2_ARGS, const int* __restrict__ cache_env, int prep_flags) { prep2_body(m, state, ws, env0, N, sort_cnt, sort_cnt_next, sort_slot, pair_env, member, blockIdx.x, cache_env, nullptr, nullptr, nullptr, prep_flags); }
 /* First substep of a step: the action kernel and the first k_prep2 in ONE launch.  Nothing k_prep2 builds depends on the new motor
  * targets except the motor rows themselves (v*, M^-1, contacts and limit rows see q and qd only), so the nab action blocks (first in
  * the grid: they are the long pole, ~80 dependent IK iterations) and the prep blocks of the same envs run side by side instead of
@@ -3627,34 +3643,11 @@ __global__ void __launch_bounds__(PREP_THREADS, RP_PREP_WAVES) k_action_prep(con
     __builtin_amdgcn_s_setprio(3);
     action_body(m, state, action, target_poses, env0, N, member, blockIdx.x);
   }
-  else prep2_body(m, state, ws, env0, N, sort_cnt, sort_cnt_next, sort_slot, pair_env, member, blockIdx.x - nab, nullptr, hv_cnt, hv_cnt_next, hv_list);
+  else prep2_body(m, state, ws, env0, N, sort_cnt, sort_cnt_next, sort_slot, pair_env, member, blockIdx.x - nab, nullptr, hv_cnt, hv_cnt_next, hv_list, prep_flags);
 }
 
 
-struct __align__(16) Solve2Lds {
-  union {
-    float st[2][RP_REC_FLOATS];            /* state records (after the prologue) */
-    float stage[2][STAGE_FLOATS];          /* prologue: ROFF | J | B of both envs, copied in with 16-byte loads */
-  };
-#ifdef RP_SOLVE_PAD_KB      /* occupancy experiments: pad LDS so that fewer waves are resident than work units */
-  float pad[RP_SOLVE_PAD_KB * 256];
-#endif
-};
-
-/* The two-env path's contact-row registers: six values per slot (J and B of the normal and of both friction rows), 21 slots.  They are FILLED by a rolled loop through a
- * wave-uniform index (VGPR indexing mode: s_set_gpr_idx_on / v_mov / off) and USED by the sweeps with constant indices.  Slots 0..15 of value a: element s of lo[a];
- * slots 16..20: element 5 (a mod 3) + s - 16 of hi[a / 3] - 16-wide vectors throughout, which is what the backend indexes in place (an 8-wide one it expands into
- * a chain of selects), 128 registers for 126 values. */
 typedef float f16v __attribute__((ext_vector_type(16)));
-struct RowRegs {
-  f16v lo[6], hi[2];
-  __device__ __forceinline__ float get(int a, int s) const { return s < 16 ? lo[a][s] : hi[a / 3][5 * (a % 3) + s - 16]; }
-  __device__ __forceinline__ void zero() {
-#pragma unroll
-    for (int a = 0; a < 6; a++) lo[a] = (f16v)(0.f);
-    hi[0] = (f16v)(0.f); hi[1] = (f16v)(0.f);
-  }
-};
 /* DPP butterfly inside each 16-lane row: every lane ends with the sum over its row */
 __device__ __forceinline__ float row16_sum(float v) {
   int x = __float_as_int(v);
@@ -3764,6 +3757,9 @@ __device__ __forceinline__ void generic_row(float Jr, float Br, float& dv, Plane
 }
 
 #define SOLVE_WAVES 2                 /* k_solve2 waves per block */
+#ifndef RP_SOLVE_WAVES_PER_EU
+#define RP_SOLVE_WAVES_PER_EU 3       /* k_solve2's register budget: 168 VGPRs (round 6: the two-env register path is gone; the block's 24 KB of LDS allow six blocks = three waves per SIMD) */
+#endif
 #ifdef RP_PROLOGUE_CLOCKS      /* profiling build: where the two-env path's prologue spends its time (tools/gpu_prologue_clocks.py) */
 __device__ unsigned long long g_pclk[8 * 4096];
 #define PRO_MARK(i) if (lane == 0) g_pclk[8 * (wb & 4095) + (i)] = __builtin_readcyclecounter();
@@ -3778,380 +3774,6 @@ __device__ __forceinline__ int pair_env_id(int pe) {
   asm volatile("v_and_b32 %0, 0xffffff, %1" : "=v"(e) : "v"(pe));
   return e;
 }
-__device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, float* __restrict__ state, const float* __restrict__ ws, int env0, int N,
-                                                  const int* __restrict__ pair_env, int* __restrict__ sort_cnt_next, int* __restrict__ sort_slot, int debug_flags, Solve2Lds* Ls, const int bq,
-                                                  const unsigned gmask = 15u) {      /* gmask: bit k = the env at place 4 bq + k is this path's (solve_block) */
-  /* the waves of a block work independently, each on its own pair of envs and its own LDS block Ls[wid].  Few blocks come here (the ones with a coupled env:
-   * 1 - 2 % of the envs) and they last twice as long as the four-env blocks: they are the launch's critical path (raising their wave priority changes nothing:
-   * they already run alone for the second half of the launch) */
-  const int wid = threadIdx.x >> 6, wb = bq * SOLVE_WAVES + wid;      /* wb: this wave's number in the launch (bq: the block's) */
-  Solve2Lds& L = Ls[wid];
-  const int lane = threadIdx.x & 63, half = lane >> 5, l = lane & 31, grp = l >> 4, l16 = lane & 15;
-#if defined(RP_CLOCKS) && RP_CLOCKS != 2
-  if (lane == 0) g_clk[8 * wb + 4] = wall_clock64();
-#endif
-  CLK_MARK2(0)
-#ifdef RP_SOLVE_PAD_KB
-  if (N < 0) L.pad[lane] = 0.f;
-#endif
-  PRO_MARK(0)
-  /* this wave's two envs: places 2b and 2b + 1 among the group's envs sorted by load class, heaviest first (table built
-   * by the k_prep2 before this launch) */
-  const int place = wb * 2 + half;
-  const int pe = (place < N - env0 && ((gmask >> (2 * wid + half)) & 1u)) ? pair_env[env0 + place] : -1;
-  const int env = pe < 0 ? -1 : pair_env_id(pe), pe_nc = pe < 0 ? 0 : (pe >> 24);
-  const bool valid = env >= 0;
-  const float* w = ws + (size_t)(valid ? env : 0) * W3_FLOATS;
-  const int n = m->n_arm;
-  /* header: per half, then wave-uniform unions for the guards */
-  const float4 h0 = *(const float4*)&w[W3_HDR], h1 = *(const float4*)&w[W3_HDR + 4];
-  const int my_mL = valid ? __float_as_int(h0.x) : 0, my_mU = valid ? __float_as_int(h0.y) : 0;
-  const int my_nj = valid ? __float_as_int(h0.z) : 0, my_nc = valid ? __float_as_int(h0.w) : 0;
-  const int my_nA = valid ? __float_as_int(h1.x) : 0, my_nB = valid ? __float_as_int(h1.y) : 0;
-  const int my_gr = valid ? (__float_as_int(h1.z) & 255) : 0, my_nC = valid ? __float_as_int(h1.w) : 0;
-  const int my_nt = valid ? (__float_as_int(h1.z) >> 8) : 0;       /* torsional rows */
-#define WAVE_OR(x) (__builtin_amdgcn_readlane(x, 0) | __builtin_amdgcn_readlane(x, 32))
-#define WAVE_MAX(x) max(__builtin_amdgcn_readlane(x, 0), __builtin_amdgcn_readlane(x, 32))
-  const int maskL = WAVE_OR(my_mL), maskU = WAVE_OR(my_mU), gear = WAVE_OR(my_gr);
-  const int my_nS = max(my_nA, my_nB);
-  const int nS_w = WAVE_MAX(my_nS), nC_w = WAVE_MAX(my_nC), nc_w = WAVE_MAX(my_nc), nT = WAVE_MAX(my_nt);
-  /* side-by-side slots for both envs of the wave fit the 21 row registers (practically always); otherwise every contact
-   * takes its own slot and folds (nS = 0): same code, same results */
-#if defined(RP_FORCE_PATH)    /* timing ablation: 0 = never side by side */
-  const bool par = RP_FORCE_PATH == 1 && nS_w + nC_w <= MAXC;
-#else
-  const bool par = nS_w + nC_w <= MAXC && !(debug_flags & 1);      /* debug flag 1 (tests): always take the fallback */
-#endif
-  const int nS = par ? nS_w : 0, nC = par ? nC_w : nc_w;
-  PRO_MARK(1)      /* header there */
-  const int dd = lane_dof(m, l);            /* velocity component owned by this lane, -1 if none */
-  /* contact rows first: 16-byte coalesced copies of the slot tables and the compact rows into LDS (a per-lane gather
-   * straight from memory costs one 16-cycle vector-memory instruction per row and array) */
-  {
-    float* S = L.stage[half];
-    const float* src = w + W3_ROFF;
-    const int nf = valid ? (ROWW * 3 * pe_nc + 3) & ~3 : 0;
-    *(float4*)&S[4 * l] = *(const float4*)&src[4 * l];                       /* ROFF | SLOT: 128 words */
-    for (int i = 4 * l; i < nf; i += 128) {
-      *(float4*)&S[128 + i] = *(const float4*)&src[128 + i];
-      *(float4*)&S[128 + ROWREG + i] = *(const float4*)&src[128 + ROWREG + i];
-    }
-  }
-  /* the state record: loaded now, parked in registers until the staging area is free */
-  float st_v0, st_v1, st_v2, st_v3;
-  {
-    const float* r = state + (size_t)(valid ? env : 0) * RP_REC_FLOATS;
-    st_v0 = r[l]; st_v1 = r[l + 32]; st_v2 = r[l + 64]; st_v3 = r[l + 96];
-  }
-  /* all other prologue loads are unconditional from clamped addresses (absent entries read a stored 0) */
-  const float* wzero = w + W3_ZERO;
-  auto ldz = [&](const float* q, bool c) { return *(c ? q : wzero); };
-  const float vstar = ldz(&w[W3_VSTAR + (dd >= 0 ? dd : 0)], valid && dd >= 0);
-  const bool row0 = grp == 0, arm_lane = valid && row0 && l16 < n;
-  /* unit rows: dof-indexed planes.  DPP row 0: motor / lower / upper limit of arm dof i at lane i; DPP row 1: scene joint
-   * k at lane k of the motor plane (zeros elsewhere, where a unit row then is an exact no-op) */
-  const float* wa = w + W3_A;
-  const float* bj = w + W3_BJ;
-  const int ia = arm_lane ? l16 : 0;
-  const bool jl = valid && !row0 && l16 < my_nj;
-  const int kj = jl ? l16 : 0;
-  const float dinvX = row0 ? ldz(&wa[ia], arm_lane) : ldz(&bj[kj], jl);
-  Plane X0, PL, PU;
-  X0.rhs = row0 ? ldz(&wa[16 + ia], arm_lane) : ldz(&bj[4 + kj], jl);
-  X0.lo = row0 ? ldz(&wa[32 + ia], arm_lane) : ldz(&bj[8 + kj], jl);
-  X0.hi = row0 ? ldz(&wa[48 + ia], arm_lane) : ldz(&bj[12 + kj], jl);
-  PL.rhs = ldz(&wa[64 + ia], arm_lane); PL.lo = ldz(&wa[80 + ia], arm_lane); PL.hi = ldz(&wa[96 + ia], arm_lane);
-  PU.rhs = ldz(&wa[112 + ia], arm_lane); PU.lo = ldz(&wa[128 + ia], arm_lane); PU.hi = ldz(&wa[144 + ia], arm_lane);
-  if (debug_flags & 2) {      /* first substep after k_action_prep: the motor rows from the record's fresh targets (build_small_rows' formula) */
-    const float* r = state + (size_t)(valid ? env : 0) * RP_REC_FLOATS;
-    const float mode = r[ST_MMODE + ia], tgt = r[ST_MTARGET + ia], mx = r[ST_MMAXIMP + ia], qi = r[ST_Q + ia];
-    const float des = mode != 0.f ? K_KP * (tgt - qi) / K_DT : 0.f;
-    const float rhs = (des - vstar) * dinvX;
-    if (arm_lane) { X0.rhs = rhs; X0.lo = -mx; X0.hi = mx; }
-  }
-  float Jg = 0.f, Bg = 0.f;                 /* Panda finger gear: J = e_a + ratio e_b, scalars at lane GEAR_LANE of plane U */
-  {
-    const float* g = w + W3_GEAR;
-    float g0 = g[0], g1 = g[1], ratio = g[2], gd = g[3], g4 = g[4], g5 = g[5], g6 = g[6];
-    int a = __float_as_int(g0) & 15, b = __float_as_int(g1) & 15;
-    float ma = w[W3_MINV + ia * 12 + (a < 12 ? a : 0)], mb = w[W3_MINV + ia * 12 + (b < 12 ? b : 0)];
-    bool on = arm_lane && my_gr != 0;
-    Jg = on ? (l16 == a ? gd : (l16 == b ? ratio * gd : 0.f)) : 0.f;
-    Bg = on ? ma + ratio * mb : 0.f;
-    bool gl = valid && row0 && l16 == GEAR_LANE && my_gr != 0;
-    PU.rhs = gl ? g4 : PU.rhs; PU.lo = gl ? g5 : PU.lo; PU.hi = gl ? g6 : PU.hi;
-  }
-  float Bm[12];                             /* B column of unit row t: M^-1[:, t] on the arm lanes, 1/m of scene joint t at its lane */
-  {
-    const float colJ = ldz(&bj[16 + kj], jl);
-    /* row ia of M^-1 as three 16-byte loads (twelve strided ones with an address select each until round 5); lanes without an arm dof and columns beyond n read zeros */
-    const float4 m0 = *(const float4*)&w[W3_MINV + ia * 12], m1 = *(const float4*)&w[W3_MINV + ia * 12 + 4], m2 = *(const float4*)&w[W3_MINV + ia * 12 + 8];
-    const float mr[12] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w, m2.x, m2.y, m2.z, m2.w};
-#pragma unroll
-    for (int t = 0; t < 12; t++) Bm[t] = row0 ? ((arm_lane && t < n) ? mr[t] : 0.f) : ((t < LBL_N && l16 == t) ? colJ : 0.f);
-  }
-  /* contact slots.  Slot s < nS holds, in DPP row 0, this env's s-th arm-only contact and, in DPP row 1, its s-th
-   * non-arm contact (they commute: solved side by side, no fold); slot 20 - j holds its j-th spanning contact in
-   * both rows (folded).  Two fixed ends keep the sweep's control flow two plain early-exit chains (a jump into the
-   * middle of a chain makes the compiler build a flag-driven state machine).  contact_of(s) is this lane's contact
-   * index in slot s, -1 if none. */
-  PRO_MARK(2)      /* plane / unit-row loads issued */
-  WSYNC();
-  PRO_MARK(3)      /* staging copy landed */
-  const float* S = L.stage[half];
-  auto contact_of = [&](int s) {
-    int c;
-    if (s < nS) {
-      bool has = row0 ? s < my_nA : s < my_nB;
-      c = has ? __float_as_int(S[64 + (row0 ? 21 : 0) + s]) : -1;
-    } else {
-      int j = MAXC - 1 - s;                  /* folded slots fill from the top end downwards */
-      c = par ? (j < my_nC ? __float_as_int(S[64 + 42 + j]) : -1) : (j < my_nc ? j : -1);
-    }
-    return valid ? c : -1;
-  };
-  PlaneN PN[2]; Plane PF[2][2];             /* normals, frictions [direction][register]; slot = 16 r + lane */
-  float muN[2];
-#pragma unroll
-  for (int r = 0; r < 2; r++) {
-    int s = 16 * r + l16;
-    int c = s < MAXC ? contact_of(s) : -1;
-    bool on = c >= 0;
-    int cc = on ? c : 0;
-    PN[r].rhs = ldz(&w[W3_ROWS + 4 * cc], on); PN[r].lo = 0.f; PN[r].hi = ldz(&w[W3_ROWT + 4 * cc + 1], on);
-    PN[r].cfm = ldz(&w[W3_ROWS + 4 * cc + 1], on); PN[r].rhsE = PN[r].rhs;
-    muN[r] = ldz(&w[W3_MU + cc], on);
-#pragma unroll
-    for (int d = 0; d < 2; d++) { PF[d][r].rhs = ldz(&w[W3_ROWS + 4 * ((on ? my_nc : 0) + 2 * cc + d)], on); PF[d][r].lo = 0.f; PF[d][r].hi = 0.f; }
-  }
-  PRO_MARK(4)      /* normal / friction plane loads issued */
-  /* contact rows: compact (two body slots) -> lane-dense registers, from the LDS copy */
-  /* A ROLLED loop over the slots in use.  The waves of this path are few - a dozen per launch, on as many CUs - and whatever they execute once they fetch cold: unrolled
-   * (1 700 instructions) this gather ran at 15 cycles per instruction, 27 k of the prologue's 40 k cycles, against 6.6 k when the same code ran a second time
-   * (tools/gpu_prologue_clocks.py: instruction fetch, not the LDS, was the bound).  One iteration of ~100 instructions is fetched once. */
-  RowRegs RR;
-  RR.zero();
-#define JN_(s) RR.get(0, s)
-#define BN_(s) RR.get(1, s)
-#define JF_(r, s) RR.get(2 + 2 * (r), s)
-#define BF_(r, s) RR.get(3 + 2 * (r), s)
-  {
-#pragma unroll 1
-    for (int s0 = 0; s0 < MAXC; s0++) {
-      int s = __builtin_amdgcn_readfirstlane(s0);
-      if (s >= nS && MAXC - 1 - s >= nC) { s0 = MAXC - 1 - nC; if (s0 < s) s0 = s; continue; }      /* (wave-uniform) the empty slots between the side-by-side ones and the folded ones */
-      const int c = contact_of(s);
-      const bool used = c >= 0;
-      /* this lane's entry in the contact's compact rows: the normal and both friction rows share the two body slots */
-      const int off = __float_as_int(S[used ? c : 63]);                 /* entry 63: offsets 0, value 0.0f */
-      const int i1 = dd - (off >> 8), i0 = dd - (off & 255);
-      const int idx = (unsigned)i1 < 6u ? 12 + i1 : ((unsigned)i0 < 12u ? i0 : -1);
-      const bool ok = used && dd >= 0 && idx >= 0;
-      const int rn = ROWW * c + idx, rf = ROWW * (my_nc + 2 * c) + idx;
-      const float v0 = S[ok ? 128 + rn : 63], v1 = S[ok ? 128 + ROWREG + rn : 63], v2 = S[ok ? 128 + rf : 63], v3 = S[ok ? 128 + ROWREG + rf : 63],
-                  v4 = S[ok ? 128 + rf + ROWW : 63], v5 = S[ok ? 128 + ROWREG + rf + ROWW : 63];      /* no select after the read: absent entries read a stored 0 */
-      if (s < 16) { RR.lo[0][s] = v0; RR.lo[1][s] = v1; RR.lo[2][s] = v2; RR.lo[3][s] = v3; RR.lo[4][s] = v4; RR.lo[5][s] = v5; }
-      else { const int k = s - 16; RR.hi[0][k] = v0; RR.hi[0][5 + k] = v1; RR.hi[0][10 + k] = v2; RR.hi[1][k] = v3; RR.hi[1][5 + k] = v4; RR.hi[1][10 + k] = v5; }
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < 2; r++) { PN[r].lam = 0.f; PF[0][r].lam = 0.f; PF[1][r].lam = 0.f; }
-  X0.lam = 0.f; PL.lam = 0.f; PU.lam = 0.f;
-  /* torsional rows (rare: a gripper link in contact): row t at label t of plane PT, in BOTH DPP rows (they fold like the spanning contacts; for a row that
-   * touches the arm only the other row's sum is an exact +0), J / B straight from the workspace (compact rows 3 ncon + t).  Its bounds follow the normal
-   * impulse of its parent contact: that contact's slot - from its class and rank, the way contact_of fills the slots - names the lane and the register of
-   * the normals' planes, DPP row 0 of this half */
-  float JT[MAXT], BT[MAXT], spinT = 0.f; Plane PT; int tsrc = lane; bool treg = false;
-  PT.rhs = PT.lo = PT.hi = PT.lam = PT.dacc = PT.loP = PT.hiP = 0.f;
-#pragma unroll
-  for (int t = 0; t < MAXT; t++) { JT[t] = 0.f; BT[t] = 0.f; }
-  if (nT > 0) {
-    const bool on = l16 < my_nt;
-    const int rt = 3 * my_nc + (on ? l16 : 0);
-    PT.rhs = ldz(&w[W3_ROWS + 4 * rt], on);
-    spinT = ldz(&w[W3_ROWS + 4 * rt + 2], on);
-    const int pk = on ? __float_as_int(w[W3_ROWS + 4 * rt + 3]) : 0;
-    const int pslot = par ? (((pk >> 8) & 3) == 1 ? (pk >> 12) : MAXC - 1 - (pk >> 12)) : MAXC - 1 - (pk & 255);
-    tsrc = (lane & 32) + (pslot & 15); treg = pslot >= 16;
-#pragma unroll
-    for (int t = 0; t < MAXT; t++) {
-      const bool used = t < my_nt;
-      const int r = 3 * my_nc + (used ? t : 0);
-      const int i1 = dd - (used ? __float_as_int(w[W3_ROWT + 4 * r + 3]) : 64), i0 = dd - (used ? __float_as_int(w[W3_ROWT + 4 * r + 2]) : 64);
-      const int idx = (unsigned)i1 < 6u ? 12 + i1 : ((unsigned)i0 < 12u ? i0 : -1);
-      const bool ok = used && dd >= 0 && idx >= 0;
-      JT[t] = ldz(&w[W3_J + ROWW * r + (ok ? idx : 0)], ok); BT[t] = ldz(&w[W3_B + ROWW * r + (ok ? idx : 0)], ok);
-    }
-  }
-  PRO_MARK(5)      /* gathers done */
-  WSYNC();                          /* rows are in registers: the staging area becomes the state records */
-  {
-    float* st = L.st[half];
-    st[l] = st_v0; st[l + 32] = st_v1; st[l + 64] = st_v2; st[l + 96] = st_v3;
-  }
-  __builtin_amdgcn_s_waitcnt(0x0F70);    /* vmcnt(0): all row registers have landed before the sweep loop */
-  WSYNC();
-  PRO_MARK(6)
-  CLK_MARK2(1)
-  /* counting sort by load class for the NEXT substep's pairing (the classes of this substep stand in for the next one's:
-   * which two envs share a wave never changes any result - absent rows are exact no-ops - it only decides how long the
-   * heaviest wave runs).  The atomic is issued here, after the last wait on a load (vmcnt is in order), and its result is used in
-   * the last lines of the kernel: its round trip under contention, several microseconds, hides behind the sweeps. */
-  int sort_pos = 0, sort_bin = 0;
-  if (l == 0 && valid && !(debug_flags & 4)) {      /* (flag 4: k_chain's substeps before the last - nobody reads their classes) */
-    int key = 8 * (my_nC < 7 ? my_nC : 7) + (my_nS < 1 ? 0 : (my_nS > 14 ? 7 : (my_nS - 1) >> 1));      /* side-by-side slots in steps of two: a resting scene has 2..6 */
-    sort_bin = key * SORT_REPS + ((wb * 2 + half) & (SORT_REPS - 1));
-    sort_pos = atomicAdd(&sort_cnt_next[sort_bin], 1);
-  }
-  float dv = 0.f;
-#define REP12(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11)
-#define REP12R(M) M(11) M(10) M(9) M(8) M(7) M(6) M(5) M(4) M(3) M(2) M(1) M(0)
-#define REP21(M) REP12(M) M(12) M(13) M(14) M(15) M(16) M(17) M(18) M(19) M(20)      /* literal indices: they name labels */
-  static_assert(MAXC == 21, "slot macros");
-#pragma unroll 1
-  for (int it = 0; it < K_NITER; it++) {
-    /* in-loop copies of the guards: kept in SGPRs and re-read every sweep so that they stay s_cmp + s_cbranch */
-#ifdef RP_ABL_NOCONTACT
-    int nS_it = 0, nC_it = 0, mL_it = maskL, mU_it = maskU, gr_it = gear;
-#else
-    int nS_it = nS, nC_it = nC, mL_it = maskL, mU_it = maskU, gr_it = gear;
-#endif
-    int nT_it = nT;
-    asm volatile("" : "+s"(nS_it), "+s"(nC_it), "+s"(mL_it), "+s"(mU_it), "+s"(gr_it), "+s"(nT_it));
-    nT_it = __builtin_amdgcn_readfirstlane(nT_it);
-    nS_it = __builtin_amdgcn_readfirstlane(nS_it); nC_it = __builtin_amdgcn_readfirstlane(nC_it);
-    mL_it = __builtin_amdgcn_readfirstlane(mL_it); mU_it = __builtin_amdgcn_readfirstlane(mU_it);
-    gr_it = __builtin_amdgcn_readfirstlane(gr_it);
-    plane_begin(X0); plane_begin(PL); plane_begin(PU); nplane_begin(PN[0]); nplane_begin(PN[1]);
-    PLANE_FENCE4(X0, PL, PU, PN[0]);
-    PLANE_FENCE_N(PN[1], PN[0], PN[1]);
-    /* unit rows in Bullet's order (build_small_rows), walked backwards in the even sweeps and forwards in the odd ones: forwards = the limits
-     * (dof-major, lower before upper), the motors (motor t in DPP row 0 beside scene joint t in DPP row 1; t >= n_arm / absent joint: exact
-     * no-op), the gear.  A limit row exists only while its limit is violated: per group of six dofs the guards pick {nothing, lower rows
-     * only, both interleaved} - an absent row is all zeros and an exact no-op that costs about as much as the branch that would skip it.
-     * (The UR5's opening gripper is the common case with limit rows: its six joints 6..11 commanded below their lower limits.) */
-#define UNIT_M(t) unit_row<(t)>(dinvX, Bm[t], dv, X0, l16);
-#define UNIT_L(i) unit_row<(i)>(dinvX, Bm[i], dv, PL, l16); unit_row<(i)>(dinvX, Bm[i], dv, PU, l16);
-#define UNIT_LR(i) unit_row<(i)>(dinvX, Bm[i], dv, PU, l16); unit_row<(i)>(dinvX, Bm[i], dv, PL, l16);
-#define UNIT_LO(i) unit_row<(i)>(dinvX, Bm[i], dv, PL, l16);
-#ifndef RP_ABL_NOUNIT      /* timing ablations only (tools/): RP_ABL_NOUNIT drops the unit rows, RP_ABL_NOCONTACT the contact rows */
-    if (it & 1) {
-      if ((mL_it | mU_it) & 0x03F) { if (mU_it & 0x03F) { UNIT_L(0) UNIT_L(1) UNIT_L(2) UNIT_L(3) UNIT_L(4) UNIT_L(5) } else { UNIT_LO(0) UNIT_LO(1) UNIT_LO(2) UNIT_LO(3) UNIT_LO(4) UNIT_LO(5) } }
-      if ((mL_it | mU_it) & 0xFC0) { if (mU_it & 0xFC0) { UNIT_L(6) UNIT_L(7) UNIT_L(8) UNIT_L(9) UNIT_L(10) UNIT_L(11) } else { UNIT_LO(6) UNIT_LO(7) UNIT_LO(8) UNIT_LO(9) UNIT_LO(10) UNIT_LO(11) } }
-      REP12(UNIT_M)
-      if (gr_it) generic_row<GEAR_LANE, false>(Jg, Bg, dv, PU, l16, PU.rhs);
-    } else {
-      if (gr_it) generic_row<GEAR_LANE, false>(Jg, Bg, dv, PU, l16, PU.rhs);
-      REP12R(UNIT_M)
-      if ((mL_it | mU_it) & 0xFC0) { if (mU_it & 0xFC0) { UNIT_LR(11) UNIT_LR(10) UNIT_LR(9) UNIT_LR(8) UNIT_LR(7) UNIT_LR(6) } else { UNIT_LO(11) UNIT_LO(10) UNIT_LO(9) UNIT_LO(8) UNIT_LO(7) UNIT_LO(6) } }
-      if ((mL_it | mU_it) & 0x03F) { if (mU_it & 0x03F) { UNIT_LR(5) UNIT_LR(4) UNIT_LR(3) UNIT_LR(2) UNIT_LR(1) UNIT_LR(0) } else { UNIT_LO(5) UNIT_LO(4) UNIT_LO(3) UNIT_LO(2) UNIT_LO(1) UNIT_LO(0) } }
-    }
-#endif
-#undef UNIT_M
-#undef UNIT_L
-#undef UNIT_LR
-#undef UNIT_LO
-    plane_end(X0); plane_end(PL); plane_end(PU);
-    /* contact normals: side-by-side slots while they last, then the folded slots.  Contacts are prefixes of both
-     * ranges, so the guards are early exits: nothing is spent on absent slots */
-#define NRM_P(s) if (nS_it <= (s)) goto nrm_pdone; generic_row<(s), false>(JN_(s), BN_(s), dv, PN[(s) >> 4], l16, PN[(s) >> 4].rhsE);
-    REP21(NRM_P)
-#undef NRM_P
-  nrm_pdone:
-#define NRM_C(j) if (nC_it <= (j)) goto nrm_done; generic_row<MAXC - 1 - (j), true>(JN_(MAXC - 1 - (j)), BN_(MAXC - 1 - (j)), dv, PN[(MAXC - 1 - (j)) >> 4], l16, PN[(MAXC - 1 - (j)) >> 4].rhsE);
-    REP21(NRM_C)
-#undef NRM_C
-  nrm_done:
-    plane_end(PN[0]); plane_end(PN[1]);
-    if (nT_it > 0) {                                           /* torsional rows: after the normals, before the friction rows (Bullet's order) */
-      const float l0 = __shfl(PN[0].lam, tsrc), l1 = __shfl(PN[1].lam, tsrc);
-      const float lp = treg ? l1 : l0;
-      fplane_begin(PT, spinT * lp, lp);
-      asm volatile("s_nop 1" : "+v"(PT.loP), "+v"(PT.hiP));
-      generic_row<0, true>(JT[0], BT[0], dv, PT, l16, PT.rhs);
-      if (nT_it > 1) generic_row<1, true>(JT[1], BT[1], dv, PT, l16, PT.rhs);
-      if (nT_it > 2) generic_row<2, true>(JT[2], BT[2], dv, PT, l16, PT.rhs);
-      if (nT_it > 3) generic_row<3, true>(JT[3], BT[3], dv, PT, l16, PT.rhs);
-      plane_end(PT);
-    }
-    if (nS_it + nC_it > 0) {                                   /* frictions, slot by slot: bounds -+ mu * (normal impulse) */
-      fplane_begin(PF[0][0], muN[0] * PN[0].lam, PN[0].lam); fplane_begin(PF[1][0], muN[0] * PN[0].lam, PN[0].lam);
-      fplane_begin(PF[0][1], muN[1] * PN[1].lam, PN[1].lam); fplane_begin(PF[1][1], muN[1] * PN[1].lam, PN[1].lam);
-      PLANE_FENCE4(PF[0][0], PF[1][0], PF[0][1], PF[1][1]);
-#define FRC_P(s) if (nS_it <= (s)) goto frc_pdone; generic_row<(s), false>(JF_(0, s), BF_(0, s), dv, PF[0][(s) >> 4], l16, PF[0][(s) >> 4].rhs); \
-                 generic_row<(s), false>(JF_(1, s), BF_(1, s), dv, PF[1][(s) >> 4], l16, PF[1][(s) >> 4].rhs);
-      REP21(FRC_P)
-#undef FRC_P
-    frc_pdone:
-#define FRC_C(j) if (nC_it <= (j)) goto frc_done; generic_row<MAXC - 1 - (j), true>(JF_(0, MAXC - 1 - (j)), BF_(0, MAXC - 1 - (j)), dv, PF[0][(MAXC - 1 - (j)) >> 4], l16, PF[0][(MAXC - 1 - (j)) >> 4].rhs); \
-                 generic_row<MAXC - 1 - (j), true>(JF_(1, MAXC - 1 - (j)), BF_(1, MAXC - 1 - (j)), dv, PF[1][(MAXC - 1 - (j)) >> 4], l16, PF[1][(MAXC - 1 - (j)) >> 4].rhs);
-      REP21(FRC_C)
-#undef FRC_C
-    frc_done:
-      plane_end(PF[0][0]); plane_end(PF[1][0]); plane_end(PF[0][1]); plane_end(PF[1][1]);
-    }
-  }
-#undef REP12
-#undef REP12R
-#undef REP21
-#undef WAVE_OR
-#undef WAVE_MAX
-  /* integrate: lane l holds velocity component lane_dof(l) of this half's env */
-  float* st = L.st[half];
-  float vnew = clampf(vstar + dv, -K_MAXVEL, K_MAXVEL);       /* btMultiBody::applyDeltaVeeMultiDof's clamp (never active in ordinary motion) */
-  WSYNC();
-  CLK_MARK2(2)
-  if (dd >= 0) {
-    if (dd < n) {
-      st[ST_QD + dd] = vnew;
-      st[ST_Q + dd] += K_DT * vnew;
-    } else if (dd < n + 6 * m->n_free) {
-      int k = (dd - n) / 6, c = (dd - n) % 6;
-      st[ST_FREE + 13 * k + 7 + c] = vnew;
-    } else {
-      int k = dd - n - 6 * m->n_free;
-      st[ST_JQD + k] = vnew;
-      st[ST_JQ + k] += K_DT * vnew;
-    }
-  }
-  WSYNC();
-  if (l < m->n_free) {
-    float* f = &st[ST_FREE + 13 * l];
-    V3 v = ld3(f + 7), wv = ld3(f + 10);
-    st3(f, ld3(f) + v * K_DT);
-    float wn = norm(wv);
-    if (wn > 0.7853981633974483f / K_DT) wn = 0.7853981633974483f / K_DT;
-    V3 ax;
-    if (wn < 0.001f) ax = wv * (0.5f * K_DT - K_DT * K_DT * K_DT * 0.020833333333f * wn * wn);
-    else ax = wv * (sinf(0.5f * wn * K_DT) / wn);
-    Q4 dq = {ax.x, ax.y, ax.z, cosf(0.5f * wn * K_DT)};
-    Q4 q0 = {f[3], f[4], f[5], f[6]};
-    Q4 qn = qmul(dq, q0);
-    float nr = 1.f / sqrtf(qn.x * qn.x + qn.y * qn.y + qn.z * qn.z + qn.w * qn.w);
-    f[3] = qn.x * nr; f[4] = qn.y * nr; f[5] = qn.z * nr; f[6] = qn.w * nr;
-  }
-  WSYNC();
-  if (valid) {
-    float* r = state + (size_t)env * RP_REC_FLOATS;
-    for (int k = l; k < RP_REC_FLOATS; k += 32) r[k] = st[k];
-    if (l == 0 && !(debug_flags & 4)) {
-      int sp = sort_pos;
-      asm volatile("" : "+v"(sp));           /* first use of the atomic's result: keeps its s_waitcnt down here */
-      sort_slot[env] = (sort_bin << SORT_RANK_BITS) | sp;
-    }
-  }
-#if defined(RP_CLOCKS) && RP_CLOCKS != 2
-  CLK_MARK(3)
-  if (lane == 0) {
-    g_clk[8 * wb + 5] = wall_clock64();
-    int na = n + __popc(maskL) + __popc(maskU);
-    g_clk[8 * wb + 6] = (unsigned long long)na | ((unsigned long long)nS << 8) | ((unsigned long long)nC << 16) | ((unsigned long long)(par ? 1 : 0) << 24);
-    unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    g_clk[8 * wb + 7] = ((unsigned long long)xcc << 32) | hw;
-  }
-#endif
-}
 /* ------------------------------------------------------------------ k_solve2, uncoupled envs: FOUR envs per pair of waves.
  * When no contact of an env touches both halves of the velocity layout (the usual case: block on table, drawer on its rails), the rows of
  * DPP row 0 (arm motors, limits, gear, the drawer's contacts) and those of DPP row 1 (scene-joint motors, the objects' contacts) never
@@ -4161,8 +3783,6 @@ __device__ __forceinline__ void solve2_body(const DevModel* __restrict__ m, floa
  * their row-1 streams.  Same row bodies, same order inside each stream, hence the same bits - with half the instructions per env and a
  * shorter chain (row-0 stream: ~20 unit rows + the drawer's 6; row-1 stream: 3 unit rows + the block's 12).  A block takes this path if
  * all its four envs are uncoupled and their contacts fit the slots below; otherwise its waves run solve2_body on two envs each. */
-#define S4_SLOTS0 8      /* row-0 contact slots (wave 0) */
-#define S4_SLOTS1 16     /* row-1 contact slots (wave 1): one plane register */
 template <int T>
 __device__ __forceinline__ void solve4_body(const DevModel* __restrict__ m, float* __restrict__ state, const float* __restrict__ ws, int env0, int N,
                                             const int* __restrict__ pair_env, int* __restrict__ sort_cnt_next, int* __restrict__ sort_slot, int debug_flags, float* __restrict__ stl, const int bq,
@@ -4313,6 +3933,27 @@ __device__ __forceinline__ void solve4_body(const DevModel* __restrict__ m, floa
 #define REP12(M) REP8(M) M(8) M(9) M(10) M(11)
 #define REP12R(M) M(11) M(10) M(9) M(8) M(7) M(6) M(5) M(4) M(3) M(2) M(1) M(0)
 #define REP16(M) REP12(M) M(12) M(13) M(14) M(15)
+  /* one macro call per contact slot of the stream (literal indices: they name labels) */
+#if S4_SLOTS0 == 3
+#define REPS0(M) M(0) M(1) M(2)
+#elif S4_SLOTS0 == 4
+#define REPS0(M) M(0) M(1) M(2) M(3)
+#elif S4_SLOTS0 == 8
+#define REPS0(M) REP8(M)
+#else
+#error "S4_SLOTS0: 3, 4 or 8"
+#endif
+#if S4_SLOTS1 == 4
+#define REPS1(M) M(0) M(1) M(2) M(3)
+#elif S4_SLOTS1 == 6
+#define REPS1(M) M(0) M(1) M(2) M(3) M(4) M(5)
+#elif S4_SLOTS1 == 8
+#define REPS1(M) REP8(M)
+#elif S4_SLOTS1 == 16
+#define REPS1(M) REP16(M)
+#else
+#error "S4_SLOTS1: 4, 6, 8 or 16"
+#endif
 #pragma unroll 1
   for (int it = 0; it < K_NITER; it++) {
     /* in-loop copies of the guards, re-read every sweep so that they stay s_cmp + s_cbranch */
@@ -4348,7 +3989,7 @@ __device__ __forceinline__ void solve4_body(const DevModel* __restrict__ m, floa
 #undef UNIT_LR
 #undef UNIT_LO
 #define NRM4(s) if (nS_it <= (s)) goto nrm_done; generic_row<(s), false>(JN[s], BN[s], dv, PN, l16, PN.rhsE);
-    if (T == 0) { REP8(NRM4) } else { REP16(NRM4) }
+    if (T == 0) { REPS0(NRM4) } else { REPS1(NRM4) }
 #undef NRM4
   nrm_done:
     plane_end(PN);
@@ -4366,7 +4007,7 @@ __device__ __forceinline__ void solve4_body(const DevModel* __restrict__ m, floa
       fplane_begin(PF[0], muN * PN.lam, PN.lam); fplane_begin(PF[1], muN * PN.lam, PN.lam);
       asm volatile("s_nop 1" : "+v"(PF[0].loP), "+v"(PF[0].hiP), "+v"(PF[1].loP), "+v"(PF[1].hiP));
 #define FRC4(s) if (nS_it <= (s)) goto frc_done; generic_row<(s), false>(JF[0][s], BF[0][s], dv, PF[0], l16, PF[0].rhs); generic_row<(s), false>(JF[1][s], BF[1][s], dv, PF[1], l16, PF[1].rhs);
-      if (T == 0) { REP8(FRC4) } else { REP16(FRC4) }
+      if (T == 0) { REPS0(FRC4) } else { REPS1(FRC4) }
 #undef FRC4
     frc_done:
       plane_end(PF[0]); plane_end(PF[1]);
@@ -4377,6 +4018,8 @@ __device__ __forceinline__ void solve4_body(const DevModel* __restrict__ m, floa
 #undef REP12
 #undef REP12R
 #undef REP16
+#undef REPS0
+#undef REPS1
 #undef W4_OR
 #undef W4_MAX
   /* integrate this stream's components and bodies; write this stream's fields of the records */
@@ -4425,46 +4068,66 @@ __device__ __forceinline__ void solve4_body(const DevModel* __restrict__ m, floa
 
 /* ------------------------------------------------------------------ k_solve2, HEAVY envs: ONE env per wave, the sweeps in RESIDUAL (Delassus) form (round 6).
  * Which envs: the ones the four-env path cannot take - a contact that spans the two halves of the velocity layout (arm or drawer against the block or a scene-joint body:
- * a grasp, a push, a drawer pulled by the gripper) or more contacts of one half than that path has slots - with at most HV_MAXC contacts (hv_class; the oracle's
- * residual_form, rule bit RPO_RULE_RESIDUAL).  Until round 5 they took solve2_body, two envs per wave, where every contact row is a 16- or 32-lane dot product inside the
- * dependent chain (13 - 17 instructions and six wait states per row step, 185 cycles for a lone wave): 1 - 2 % of the envs, and their waves WERE every launch's second half
- * (75 us at the median, 125 at the most, while 98 % of the waves had finished after 43).  Here a lane carries ONE NUMBER through the sweeps:
- *   lanes  0 .. 11   dv of arm dof i              (motor, lower and upper limit of dof i read the same lane)
- *   lanes 12 .. 14   dv of scene joint k
- *   lane  15         w = Jd . dv of the Panda finger gear
- *   lanes 16 .. 29   w of the normal of contact c;      30, 31, 46, 47: the torsional rows
- *   lanes 32 .. 45 / 48 .. 61   w of its two friction rows
- * and a row step is  t = fma(-jd, w, rhs) in every lane at once (jd = 1 outside the dof lanes), med3 against the lane's own bounds, ONE v_readlane of the row's lane, and
- * w = fma(A[:, row], d, w): five instructions, none of them a reduction.  A[l][r] = X_l . B_r (X_l = e_d for a dof lane - so its column entry is B_r[d], the dv form's own
- * update - and Jd_l for a row lane), summed over the dofs in ascending order with fused multiply-adds from zero, is built once per launch: the two dense tables X, B
- * (64 labels x 32 dofs) in LDS, lane l keeps X_l in registers and reads B_r by broadcast, 64 column registers.  The free bodies' velocities have no lane: they are formed
- * once after the sweeps, B_r[d] lambda_r over the contact rows in the workspace's row order.  Same rows, same order, same clamps as everywhere else (build_small_rows'
- * order walked in alternating direction, normals, torsional rows, friction pairs): in exact arithmetic the dv form line by line, in fp32 another rounding - which is why
- * the form is a property of the ENV'S OWN contact list (never of who shares a wave with whom) and why the oracle has it too. */
-#define RP_DBG_SEQ 1          /* debug flag 1 (tests): the dv-form envs take solve2_body's fallback (one contact per folded slot) instead of the four-env / side-by-side paths */
+ * a grasp, a push, a drawer pulled by the gripper) or more contacts of one half than that path has slots (hv_class; the oracle's residual_form, rule bit
+ * RPO_RULE_RESIDUAL).  Until round 5 they took a two-envs-per-wave path where every contact row is a 16- or 32-lane dot product inside the dependent chain (13 - 17
+ * instructions and six wait states per row step, 185 cycles for a lone wave): 1 - 2 % of the envs, and their waves WERE every launch's second half (75 us at the median,
+ * 125 at the most, while 98 % of the waves had finished after 43).  Here a lane carries ONE NUMBER through the sweeps, the row's unclamped step
+ *     r = rhs - lambda cfm - Jd . dv      (Bullet's deltaImpulse before its clamp),
+ * kept up to date instead of being summed anew:
+ *   lanes  0 .. 11   arm dof i: r of its MOTOR row (the dof's limit rows read the same lane plus the difference of the right-hand sides: same Jd, signs folded)
+ *   lanes 12 .. 14   scene joint k: r of its motor row;        lane 15: the Panda finger gear
+ *   lanes 16 .. 29   normal of contact c (c < 14);             30, 31, 46, 47: the torsional rows
+ *   lanes 32 .. 45 / 48 .. 61   its two friction rows
+ *   (BIG, more than HV_MAXC contacts) a SECOND number per lane: lanes 0 .. 6 / 8 .. 14 / 16 .. 22 = normal / friction rows of contacts 14 .. 20
+ * and a row step is  d = med3(r, lo - lambda, hi - lambda) in every lane at once, ONE v_readlane of the row's lane, and r = fma(-C[:, row], d, r): four instructions, none
+ * of them a reduction.  C[l][r] = X_l . B_r (X_l = Jd_l for a row lane, the motor row's folded entry times e_d for a dof lane; plus the row's own softness on the
+ * diagonal), summed over the dofs in ascending order with fused multiply-adds from zero, is built once per launch: the two dense tables X, B (labels x 28 dofs) in LDS,
+ * lane l keeps X_l in registers and reads B_r by broadcast; the columns end in 64 registers (BIG: 21 more, and the second number's columns in LDS, fetched one row step
+ * ahead).  No velocity is carried: after the sweeps dv = sum of B_r lambda_r over all rows in a fixed order.  Same rows, same order, same clamps as everywhere else
+ * (build_small_rows' order walked in alternating direction, normals, torsional rows, friction pairs): in exact arithmetic the dv form line by line, in fp32 another
+ * rounding - which is why the form is a property of the ENV'S OWN contact list (never of who shares a wave with whom) and why the oracle has it too
+ * (solve_rows_residual). */
+#define RP_DBG_SEQ 1          /* debug flag 1 (tests): the dv-form envs take super_solve (the one-kernel path's solver on the workspace's rows) instead of the four-env path */
 #define RP_DBG_MOTOR 2        /* first substep after k_action_prep: the motor rows are rebuilt from the record */
 #define RP_DBG_NOSORT 4       /* k_chain's substeps before the last: nobody reads their load classes */
 #define RP_DBG_WORKERS 8      /* the heavy envs (residual form) of this launch are solved by the worker blocks at the head of the grid (k_solve2), not inside their own blocks */
-#define HV_ND 32                      /* dofs the dense tables hold (nv <= 30) */
-#define HV_STRIDE 36                  /* ... and their row stride in LDS (16-byte rows whose lanes do not all share a bank) */
+#ifdef RP_WIDE
+#define HV_NQ 8                       /* groups of four dofs in the dot products: nv = 30 (wide), <= 27 */
+#else
+#define HV_NQ 7
+#endif
+#define HV_STRIDE (4 * HV_NQ)         /* row stride of the dense tables */
 #define HV_L_J1 12
 #define HV_L_GEAR 15
 #define HV_L_N 16
 #define HV_L_F0 32
 #define HV_L_F1 48
-#define HV_LDS_FLOATS (2 * 64 * HV_STRIDE + RP_REC_FLOATS)
+#define HV_L2 64                      /* first label of the second register (BIG): contact 14 + c: normal 64 + c, friction rows 72 + c, 80 + c */
+#define HV_NLAB 88                    /* labels of a BIG env (64 + 24) */
+#define HV_A2W 24                     /* lanes of the second register */
+#define HV_STAGE 16                   /* columns staged through LDS at a time on their way into registers */
+/* LDS of one heavy env: X table (after the build: the second register's columns, 88 x 24; after the sweeps: the final sum's sequence) | B table | column staging | label flags | record */
+#define HV_OFF_Y (HV_NLAB * HV_STRIDE)
+#define HV_OFF_ST (2 * HV_NLAB * HV_STRIDE)
+#define HV_OFF_FL (HV_OFF_ST + HV_STAGE * 64)
+#define HV_OFF_REC (HV_OFF_FL + HV_NLAB)
+#define HV_LDS_FLOATS (((HV_OFF_REC + RP_REC_FLOATS) + 3) & ~3)
+static_assert(HV_NLAB * HV_STRIDE >= HV_NLAB * HV_A2W && HV_NLAB * HV_STRIDE >= 256, "the X table's place holds the second register's columns, then the final sum's sequence");
 __device__ __forceinline__ int hv_label_tors(int t) { return t < 2 ? 30 + t : 44 + t; }      /* 30, 31, 46, 47 */
 /* label of workspace row gr of an env with nc contacts: normals [0, nc), friction pairs nc + 2 c + d, torsional rows 3 nc + t */
 __device__ __forceinline__ int hv_label_row(int gr, int nc) {
-  if (gr < nc) return HV_L_N + gr;
-  if (gr < 3 * nc) { const int f = gr - nc; return ((f & 1) ? HV_L_F1 : HV_L_F0) + (f >> 1); }
+  if (gr < nc) return gr < HV_MAXC ? HV_L_N + gr : HV_L2 + gr - HV_MAXC;
+  if (gr < 3 * nc) {
+    const int f = gr - nc, c = f >> 1;
+    return c < HV_MAXC ? ((f & 1) ? HV_L_F1 : HV_L_F0) + c : HV_L2 + ((f & 1) ? 16 : 8) + c - HV_MAXC;
+  }
   return hv_label_tors(gr - 3 * nc);
 }
 /* Row steps, inline asm like the other row bodies (the compiler pads no hazards inside): r = the lanes' numbers, na = MINUS this lane's entry of the row's column.
  * Wait states (gfx940 family): a v_readlane needs one after the VALU write of its source, a VALU read of the SGPR it wrote needs two.  Rows come in pairs where they
- * can: the first row's v_writelane (the step into the impulse register) is the second row's wait state. */
+ * can: the first row's v_writelane (the step into the impulse register) is the second row's wait state.  The steps (SGPRs) are returned for the second register (BIG). */
 template <int K>
-__device__ __forceinline__ void hv_row1(float& r, float& dacc, const float loP, const float hiP, const float na) {
+__device__ __forceinline__ int hv_row1(float& r, float& dacc, const float loP, const float hiP, const float na) {
   float t; int s;
   asm volatile(
       "v_med3_f32 %[t], %[r], %[lo], %[hi]\n"
@@ -4475,9 +4138,11 @@ __device__ __forceinline__ void hv_row1(float& r, float& dacc, const float loP, 
       "v_writelane_b32 %[dacc], %[s], %[k]\n"
       : [r] "+v"(r), [dacc] "+v"(dacc), [t] "=&v"(t), [s] "=&s"(s)
       : [lo] "v"(loP), [hi] "v"(hiP), [a] "v"(na), [k] "n"(K));
+  return s;
 }
+struct HvS2 { int a, b; };
 template <int K1, int K2>
-__device__ __forceinline__ void hv_row2(float& r, float& dacc, const float loP, const float hiP, const float na1, const float na2) {
+__device__ __forceinline__ HvS2 hv_row2(float& r, float& dacc, const float loP, const float hiP, const float na1, const float na2) {
   float t; int s1, s2;
   asm volatile(
       "v_med3_f32 %[t], %[r], %[lo], %[hi]\n"
@@ -4493,10 +4158,12 @@ __device__ __forceinline__ void hv_row2(float& r, float& dacc, const float loP, 
       "v_writelane_b32 %[dacc], %[s2], %[k2]\n"
       : [r] "+v"(r), [dacc] "+v"(dacc), [t] "=&v"(t), [s1] "=&s"(s1), [s2] "=&s"(s2)
       : [lo] "v"(loP), [hi] "v"(hiP), [a1] "v"(na1), [a2] "v"(na2), [k1] "n"(K1), [k2] "n"(K2));
+  HvS2 o = {s1, s2};
+  return o;
 }
 /* the two limit rows of arm dof K (its lane holds the MOTOR row's number: theirs is that plus the difference of the right-hand sides); A first, then B */
 template <int K>
-__device__ __forceinline__ void hv_rowLU(float& r, float& daccA, const float offA, const float loA, const float hiA, float& daccB, const float offB, const float loB, const float hiB, const float na) {
+__device__ __forceinline__ HvS2 hv_rowLU(float& r, float& daccA, const float offA, const float loA, const float hiA, float& daccB, const float offB, const float loB, const float hiB, const float na) {
   float t; int s1, s2;
   asm volatile(
       "v_add_f32 %[t], %[r], %[oa]\n"
@@ -4514,9 +4181,11 @@ __device__ __forceinline__ void hv_rowLU(float& r, float& daccA, const float off
       "v_writelane_b32 %[db], %[s2], %[k]\n"
       : [r] "+v"(r), [da] "+v"(daccA), [db] "+v"(daccB), [t] "=&v"(t), [s1] "=&s"(s1), [s2] "=&s"(s2)
       : [oa] "v"(offA), [loa] "v"(loA), [hia] "v"(hiA), [ob] "v"(offB), [lob] "v"(loB), [hib] "v"(hiB), [a] "v"(na), [k] "n"(K));
+  HvS2 o = {s1, s2};
+  return o;
 }
 template <int K>
-__device__ __forceinline__ void hv_rowL(float& r, float& dacc, const float off, const float loP, const float hiP, const float na) {
+__device__ __forceinline__ int hv_rowL(float& r, float& dacc, const float off, const float loP, const float hiP, const float na) {
   float t; int s;
   asm volatile(
       "v_add_f32 %[t], %[r], %[o]\n"
@@ -4528,36 +4197,65 @@ __device__ __forceinline__ void hv_rowL(float& r, float& dacc, const float off, 
       "v_writelane_b32 %[dacc], %[s], %[k]\n"
       : [r] "+v"(r), [dacc] "+v"(dacc), [t] "=&v"(t), [s] "=&s"(s)
       : [o] "v"(off), [lo] "v"(loP), [hi] "v"(hiP), [a] "v"(na), [k] "n"(K));
+  return s;
+}
+/* a row of the SECOND register (lane K of it): its step goes into both registers; na = the first register's entry of its column, na2 the second's */
+template <int K>
+__device__ __forceinline__ void hv_rowB(float& r, float& r2, float& dacc2, const float loP2, const float hiP2, const float na, const float na2) {
+  float t; int s;
+  asm volatile(
+      "v_med3_f32 %[t], %[r2], %[lo], %[hi]\n"
+      "s_nop 0\n"
+      "v_readlane_b32 %[s], %[t], %[k]\n"
+      "s_nop 1\n"
+      "v_fmac_f32 %[r], %[s], %[a]\n"
+      "v_fmac_f32 %[r2], %[s], %[a2]\n"
+      "v_writelane_b32 %[dacc], %[s], %[k]\n"
+      : [r] "+v"(r), [r2] "+v"(r2), [dacc] "+v"(dacc2), [t] "=&v"(t), [s] "=&s"(s)
+      : [lo] "v"(loP2), [hi] "v"(hiP2), [a] "v"(na), [a2] "v"(na2), [k] "n"(K));
 }
 struct HvPlane { float lo, hi, lam, dacc, loP, hiP; };
-#ifdef RP_WIDE
-#define HV_NQ 8                       /* groups of four dofs in the dot products: nv = 30 (wide), <= 27 */
-#else
-#define HV_NQ 7
-#endif
 /* st_lds: the env's state record in LDS if the caller keeps it there (the one-kernel twins), else nullptr: the record is read from and written to `state`.
- * w: the env's workspace row (W3_*).  lds: HV_LDS_FLOATS floats of this wave's own. */
+ * w: the env's workspace row (W3_*).  lds: HV_LDS_FLOATS floats of this wave's own.  BIG: the env has more than HV_MAXC contacts. */
+template <bool BIG>
 __device__ __forceinline__ void heavy_solve(const DevModel* __restrict__ m, float* __restrict__ state, const float* __restrict__ w, const int env, int* __restrict__ sort_cnt_next,
-                                            int* __restrict__ sort_slot, const int debug_flags, float* __restrict__ lds, float* st_lds, const int sort_salt, const int clk_wave = -1) {
-  const int lane = threadIdx.x & 63;
+                                            int* __restrict__ sort_slot, const int debug_flags, float* __restrict__ lds, float* st_lds, const int sort_salt, const int clk_wave = -1, const int nc_hint = -1) {
+  /* nc_hint: the env's contact count if the caller has it already (the list entry carries it): then the header need not arrive before the row and plane loads go out */
+  int lane_ = threadIdx.x & 63;
+  asm volatile("" : "+v"(lane_));      /* (opaque: the callers loop over envs, and everything derived from the lane number - dozens of table indices - would be hoisted out of that loop and held in registers across the whole solve) */
+  const int lane = lane_;
   const int n = m->n_arm;
 #if defined(RP_CLOCKS) && RP_CLOCKS == 1      /* profiling build (tools/gpu_clocks6.py): 0 start, 1 tables and columns built, 2 sweeps done, 3 end (shader clock), 4 / 5 start / end (100 MHz wall clock), 6 rows, 7 where */
 #define HV_CLK(i) if (lane == 0 && clk_wave >= 0) g_clk[8 * clk_wave + (i)] = __builtin_readcyclecounter();
+#define HV_CLK2(i) if (lane == 0 && clk_wave >= 0) g_clk[8 * (clk_wave + 1) + (i)] = __builtin_readcyclecounter();      /* (the block's idle second wave's slots: header there, tables scattered, X rows loaded, sort atomic issued) */
   if (lane == 0 && clk_wave >= 0) g_clk[8 * clk_wave + 4] = wall_clock64();
 #else
 #define HV_CLK(i)
+#define HV_CLK2(i)
 #endif
   HV_CLK(0)
-  float* Xd = lds; float* Yd = lds + 64 * HV_STRIDE; float* stl = st_lds ? st_lds : lds + 2 * 64 * HV_STRIDE;
-  static_assert(HV_STRIDE > 4 * HV_NQ + 0 && HV_STRIDE >= 33, "flag word");
-  int* hvfl0 = (int*)(Yd + 32);                             /* per label: bit 0 = its B row has an entry below dof 12, bit 1 = from 12 on.  Kept in the tables' padding: word 32 of B row `label` (HV_STRIDE 36 > 4 HV_NQ) */
+  float* Xd = lds; float* Yd = lds + HV_OFF_Y; float* Cst = lds + HV_OFF_ST; float* stl = st_lds ? st_lds : lds + HV_OFF_REC;
+  constexpr int NLAB = BIG ? HV_NLAB : 64;
+  constexpr int MAXCON = BIG ? MAXC : HV_MAXC;
   const float4 h0 = *(const float4*)&w[W3_HDR], h1 = *(const float4*)&w[W3_HDR + 4];
-  const int maskL = uni(__float_as_int(h0.x)), maskU = uni(__float_as_int(h0.y)), nj = uni(__float_as_int(h0.z)), nc = uni(__float_as_int(h0.w));
-  const int nA = uni(__float_as_int(h1.x)), nB = uni(__float_as_int(h1.y)), gear = uni(__float_as_int(h1.z)) & 255, nt = uni(__float_as_int(h1.z)) >> 8, nC = uni(__float_as_int(h1.w));
-  const int nrc = 3 * nc + nt;
+  const int nc = nc_hint >= 0 ? nc_hint : uni(__float_as_int(h0.w));
+  const int nj = m->n_j1 < NBJ ? m->n_j1 : NBJ;      /* (= the header's: prep2_core) */
   /* the state record: into registers now, into LDS when the tables are built */
   float st_v0 = 0.f, st_v1 = 0.f;
   if (!st_lds) { const float* r = state + (size_t)env * RP_REC_FLOATS; st_v0 = r[lane]; st_v1 = r[lane + 64]; }
+  /* the rows, compact (two body slots), all loads first: one latency, not one per pass (beyond the env's rows they read stale rows of its own workspace: never used) */
+  constexpr int HV_NIT = ((3 * MAXCON + MAXT) * ROWW + 63) / 64;
+  float jv[HV_NIT], bv[HV_NIT]; int of[HV_NIT];
+#pragma unroll
+  for (int i = 0; i < HV_NIT; i++) {
+    const int e = lane + 64 * i;
+    const int g2 = e / ROWW, k = e - g2 * ROWW;
+    jv[i] = w[W3_J + e]; bv[i] = w[W3_B + e];
+    of[i] = __float_as_int(w[W3_ROWT + 4 * g2 + (k < 12 ? 2 : 3)]);
+  }
+  float mv[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) mv[i] = w[W3_MINV + (lane + 64 * i < 144 ? lane + 64 * i : 0)];
   /* ---- the planes: this lane's row(s) */
   const float* wzero = w + W3_ZERO;
   auto ldz = [&](const float* q, bool c) { return *(c ? q : wzero); };
@@ -4573,11 +4271,10 @@ __device__ __forceinline__ void heavy_solve(const DevModel* __restrict__ m, floa
   else if (lane >= HV_L_F1 && lane < HV_L_F1 + HV_MAXC) { if (lane - HV_L_F1 < nc) { gr = nc + 2 * (lane - HV_L_F1) + 1; kind = 1; cpar = lane - HV_L_F1; } }
   else {
     const int t = lane == 30 ? 0 : (lane == 31 ? 1 : (lane == 46 ? 2 : (lane == 47 ? 3 : -1)));
-    if (t >= 0 && t < nt) { gr = 3 * nc + t; kind = 2; }
+    if (t >= 0) { gr = 3 * nc + t; kind = 2; }           /* (whether the env has that many torsional rows: when the header is there) */
   }
   const bool rl = gr >= 0;
   const int grc = rl ? gr : 0;
-  const bool gl = lane == HV_L_GEAR && gear != 0;
   HvPlane P0, PL, PU;
   float cfm = 0.f, mu = 0.f;
   float rhs0 = ldz(&w[W3_ROWS + 4 * grc], rl);
@@ -4585,15 +4282,30 @@ __device__ __forceinline__ void heavy_solve(const DevModel* __restrict__ m, floa
   else { P0.lo = 0.f; P0.hi = 0.f; }
   if (kind == 1) mu = w[W3_MU + cpar];
   int tsrc = lane;
-  if (kind == 2) { mu = w[W3_ROWS + 4 * grc + 2]; tsrc = HV_L_N + (__float_as_int(w[W3_ROWS + 4 * grc + 3]) & 255); }
+  if (kind == 2) {
+    mu = w[W3_ROWS + 4 * grc + 2];
+    const int cp = __float_as_int(w[W3_ROWS + 4 * grc + 3]) & 255;
+    tsrc = cp < HV_MAXC ? HV_L_N + cp : 64 + cp - HV_MAXC;      /* (BIG: a parent in the second register: 64 + its lane there) */
+  }
   const float vstar_a = ldz(&w[W3_VSTAR + ia], arm_lane);
   const float jd = arm_lane ? wa[ia] : (jl ? bj[kj] : 0.f);      /* the folded entry of a dof lane's unit rows */
   if (arm_lane || jl) { rhs0 = arm_lane ? wa[16 + ia] : bj[4 + kj]; P0.lo = arm_lane ? wa[32 + ia] : bj[8 + kj]; P0.hi = arm_lane ? wa[48 + ia] : bj[12 + kj]; }
-  if (gl) { const float* g = w + W3_GEAR; rhs0 = g[4]; P0.lo = g[5]; P0.hi = g[6]; }
   const float rhsL = ldz(&wa[64 + ia], arm_lane), rhsU = ldz(&wa[112 + ia], arm_lane);
   PL.lo = ldz(&wa[80 + ia], arm_lane); PL.hi = ldz(&wa[96 + ia], arm_lane);
   PU.lo = ldz(&wa[128 + ia], arm_lane); PU.hi = ldz(&wa[144 + ia], arm_lane);
-  if (debug_flags & RP_DBG_MOTOR) {      /* first substep after k_action_prep: the motor rows from the record's fresh targets (build_small_rows' formula; as in solve2_body) */
+  /* (BIG) the second register's rows: lanes 0 .. 6 normals, 8 .. 14 / 16 .. 22 friction rows of contacts 14 + (lane & 7) */
+  HvPlane P2; float cfm2 = 0.f, mu2 = 0.f, rhs2 = 0.f; int gr2 = -1, kind2 = 0;
+  P2.lo = P2.hi = P2.lam = P2.dacc = P2.loP = P2.hiP = 0.f;
+  if (BIG) {
+    const int c2 = HV_MAXC + (lane & 7), sec = lane >> 3;
+    if (lane < HV_A2W && (lane & 7) < MAXC - HV_MAXC && c2 < nc) { gr2 = sec == 0 ? c2 : nc + 2 * c2 + (sec - 1); kind2 = sec == 0 ? 0 : 1; }
+    const bool r2l = gr2 >= 0;
+    const int g2c = r2l ? gr2 : 0;
+    rhs2 = ldz(&w[W3_ROWS + 4 * g2c], r2l);
+    if (kind2 == 0) { cfm2 = ldz(&w[W3_ROWS + 4 * g2c + 1], r2l); P2.hi = ldz(&w[W3_ROWT + 4 * g2c + 1], r2l); }
+    else mu2 = ldz(&w[W3_MU + c2], r2l);
+  }
+  if (debug_flags & RP_DBG_MOTOR) {      /* first substep after k_action_prep: the motor rows from the record's fresh targets (build_small_rows' formula) */
     const float* r = st_lds ? st_lds : state + (size_t)env * RP_REC_FLOATS;
     const float mode = r[ST_MMODE + ia], tgt = r[ST_MTARGET + ia], mx = r[ST_MMAXIMP + ia], qi = r[ST_Q + ia];
     const float des = mode != 0.f ? K_KP * (tgt - qi) / K_DT : 0.f;
@@ -4601,16 +4313,32 @@ __device__ __forceinline__ void heavy_solve(const DevModel* __restrict__ m, floa
     if (arm_lane) { rhs0 = rhs; P0.lo = -mx; P0.hi = mx; }
   }
   /* ---- the dense tables */
+  {
+    constexpr int NZ = (2 * NLAB * HV_STRIDE + 255) / 256;      /* (X and B tables are neighbours; the staging area behind them soaks up the last store's overshoot) */
+    static_assert(2 * HV_NLAB * HV_STRIDE + 256 <= HV_OFF_FL + 256, "zeroing");
 #pragma unroll
-  for (int i = 0; i < 2 * 64 * HV_STRIDE / 256; i++) *(float4*)&lds[4 * lane + 256 * i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  WSYNC();
-  for (int e = lane; e < 144; e += 64) {                  /* arm dof t: X = jd e_t (the motor row's folded entry), B = M^-1[:, t] */
-    const int d = e / 12, t = e - 12 * d;
-    if (d < n && t < n) Yd[t * HV_STRIDE + d] = w[W3_MINV + e];
+    for (int i = 0; i < NZ; i++) {
+      const int a = 4 * lane + 256 * i;
+      if (BIG) { if (a < 2 * HV_NLAB * HV_STRIDE) *(float4*)&lds[a] = make_float4(0.f, 0.f, 0.f, 0.f); }
+      else { if (a < 64 * HV_STRIDE) *(float4*)&Xd[a] = make_float4(0.f, 0.f, 0.f, 0.f); if (a < 64 * HV_STRIDE) *(float4*)&Yd[a] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    }
   }
-  if (arm_lane) { Xd[lane * HV_STRIDE + lane] = jd; hvfl0[lane * HV_STRIDE] = 1; }
-  if (jl) { const int d = dof_j1(m, kj); Xd[lane * HV_STRIDE + d] = jd; Yd[lane * HV_STRIDE + d] = bj[16 + kj]; hvfl0[lane * HV_STRIDE] = d < 12 ? 1 : 2; }
-  if (gl) hvfl0[lane * HV_STRIDE] = 1;
+  /* the header (every load above is in flight by now) */
+  const int maskL = uni(__float_as_int(h0.x)), maskU = uni(__float_as_int(h0.y));
+  const int nA = uni(__float_as_int(h1.x)), nB = uni(__float_as_int(h1.y)), gear = uni(__float_as_int(h1.z)) & 255, nt = uni(__float_as_int(h1.z)) >> 8, nC = uni(__float_as_int(h1.w));
+  const int nrc = 3 * nc + nt;
+  HV_CLK2(0)
+  if (kind == 2 && gr - 3 * nc >= nt) { gr = -1; kind = 0; rhs0 = 0.f; mu = 0.f; tsrc = lane; }      /* a torsional lane without a row */
+  const bool gl = lane == HV_L_GEAR && gear != 0;
+  if (gl) { const float* g = w + W3_GEAR; rhs0 = g[4]; P0.lo = g[5]; P0.hi = g[6]; }
+  WSYNC();
+#pragma unroll
+  for (int i = 0; i < 3; i++) {                            /* arm dof t: X = jd e_t (the motor row's folded entry), B = M^-1[:, t] */
+    const int e = lane + 64 * i, d = e / 12, t = e - 12 * d;
+    if (e < 144 && d < n && t < n) Yd[t * HV_STRIDE + d] = mv[i];
+  }
+  if (arm_lane) Xd[lane * HV_STRIDE + lane] = jd;
+  if (jl) { const int d = dof_j1(m, kj); Xd[lane * HV_STRIDE + d] = jd; Yd[lane * HV_STRIDE + d] = bj[16 + kj]; }
   if (gear != 0 && lane < n) {                             /* the gear: Jd = gd (e_a + ratio e_b), B = M^-1[:, a] + ratio M^-1[:, b] */
     const float* g = w + W3_GEAR;
     const int a = __float_as_int(g[0]) & 15, b = __float_as_int(g[1]) & 15;
@@ -4619,89 +4347,104 @@ __device__ __forceinline__ void heavy_solve(const DevModel* __restrict__ m, floa
     if (lane == a) Xd[HV_L_GEAR * HV_STRIDE + lane] = gd;
     if (lane == b) Xd[HV_L_GEAR * HV_STRIDE + lane] = ratio * gd;
   }
-  {                                                        /* contact, friction and torsional rows: compact (two body slots) -> dense.  All loads first: one latency, not one per pass */
-    constexpr int NIT = ((3 * HV_MAXC + MAXT) * ROWW + 63) / 64;
-    float jv[NIT], bv[NIT]; int of[NIT];
 #pragma unroll
-    for (int i = 0; i < NIT; i++) {
-      const int e = lane + 64 * i;
-      const bool ok = e < nrc * ROWW;
-      const int ec = ok ? e : 0, g2 = ec / ROWW, k = ec - g2 * ROWW;
-      jv[i] = w[W3_J + ec]; bv[i] = w[W3_B + ec];
-      of[i] = __float_as_int(w[W3_ROWT + 4 * g2 + (k < 12 ? 2 : 3)]);
-    }
-#pragma unroll
-    for (int i = 0; i < NIT; i++) {
-      const int e = lane + 64 * i;
-      const bool ok = e < nrc * ROWW;
-      const int ec = ok ? e : 0, g2 = ec / ROWW, k = ec - g2 * ROWW;
-      const int d = of[i] + (k < 12 ? k : k - 12);
-      const int lab = hv_label_row(g2, nc);
-      if (ok && d < 4 * HV_NQ) {                           /* (an empty slot has offset 64; entries past a body's dofs are zeros and must not overwrite a neighbour's) */
-        if (jv[i] != 0.f) Xd[lab * HV_STRIDE + d] = jv[i];
-        if (bv[i] != 0.f) { Yd[lab * HV_STRIDE + d] = bv[i]; atomicOr(&hvfl0[lab * HV_STRIDE], d < 12 ? 1 : 2); }
-      }
+  for (int i = 0; i < HV_NIT; i++) {                       /* contact, friction and torsional rows: compact (two body slots) -> dense */
+    const int e = lane + 64 * i;
+    const bool ok = e < nrc * ROWW;
+    const int ec = ok ? e : 0, g2 = ec / ROWW, k = ec - g2 * ROWW;
+    const int d = of[i] + (k < 12 ? k : k - 12);
+    const int lab = hv_label_row(g2, nc);
+    if (ok && d < HV_STRIDE) {                             /* (an empty slot has offset 64; entries past a body's dofs are zeros and must not overwrite a neighbour's) */
+      if (jv[i] != 0.f) Xd[lab * HV_STRIDE + d] = jv[i];
+      if (bv[i] != 0.f) Yd[lab * HV_STRIDE + d] = bv[i];
     }
   }
   /* ---- the columns: -C[lane][s] for every label s in use */
   WSYNC();
-  float X[4 * HV_NQ];
+  HV_CLK2(1)
+  float X[4 * HV_NQ], X2[BIG ? 4 * HV_NQ : 1];
 #pragma unroll
   for (int q = 0; q < HV_NQ; q++) { const float4 v = *(const float4*)&Xd[lane * HV_STRIDE + 4 * q]; X[4 * q] = v.x; X[4 * q + 1] = v.y; X[4 * q + 2] = v.z; X[4 * q + 3] = v.w; }
-  /* (a column leaves its loop through LDS - slot s of this half, one float per lane - and the registers are filled with constant indices afterwards: a dynamically
-   * indexed write into four 16-wide register vectors costs a copy of all of them per column) */
-  f16v AC[4];
+  if (BIG) {
+    const int l2 = lane < HV_A2W ? HV_L2 + lane : 0;
+#pragma unroll
+    for (int q = 0; q < HV_NQ; q++) { const float4 v = *(const float4*)&Xd[l2 * HV_STRIDE + 4 * q]; const bool on = lane < HV_A2W; X2[4 * q] = on ? v.x : 0.f; X2[4 * q + 1] = on ? v.y : 0.f; X2[4 * q + 2] = on ? v.z : 0.f; X2[4 * q + 3] = on ? v.w : 0.f; }
+  }
+  /* (a column leaves its loop through LDS - HV_STAGE columns at a time, one float per lane - and the registers are filled with constant indices afterwards: a dynamically
+   * indexed write into 16-wide register vectors costs a copy of all of them per column.  BIG: the second register's entries go to their final place, A2, where the X table was) */
+  HV_CLK2(2)
+  f16v AC[4]; f16v AC2a; float AC2b[8];
+  float* A2 = Xd;
   {
-    const unsigned long long mc = nc >= 16 ? 0xFFFFull : ((1ull << nc) - 1ull);
+    const unsigned long long mc = nc >= 14 ? 0x3FFFull : ((1ull << nc) - 1ull);
     const unsigned long long mt = (1ull << nt) - 1ull;
     const unsigned long long use = ((1ull << n) - 1ull) | (((1ull << nj) - 1ull) << HV_L_J1) | (gear != 0 ? 1ull << HV_L_GEAR : 0ull)
                                    | (mc << HV_L_N) | ((mt & 3ull) << 30) | (mc << HV_L_F0) | (((mt >> 2) & 3ull) << 46) | (mc << HV_L_F1);
-    float* Cst = Xd;                                       /* 32 x 64 floats: the X table's place (its rows are in registers now) */
-    static_assert(64 * HV_STRIDE >= 32 * 64, "column staging");
+    const unsigned m2 = BIG ? (nc > HV_MAXC ? (1u << (nc - HV_MAXC)) - 1u : 0u) : 0u;
+    const unsigned use2 = m2 | (m2 << 8) | (m2 << 16);      /* labels 64 + j */
+    if (BIG) WSYNC();                                      /* (every lane has its X rows: A2 may overwrite the table) */
+    constexpr int NCH = BIG ? 6 : 4;
 #pragma unroll
-    for (int half = 0; half < 2; half++) {
+    for (int ch = 0; ch < NCH; ch++) {
       WSYNC();
-      int u = __builtin_amdgcn_readfirstlane((int)(unsigned)(use >> (32 * half)));
-#pragma unroll 1
-      while (u != 0) {
-        const int s5 = __builtin_ctz((unsigned)u);
+#pragma unroll
+      for (int i = 0; i < HV_STAGE * 64 / 256; i++) *(float4*)&Cst[4 * lane + 256 * i] = make_float4(0.f, 0.f, 0.f, 0.f);      /* (labels not in use: zero columns - their rows' steps are exact zeros, but 0 x garbage is not) */
+      WSYNC();
+      const unsigned um = ch < 4 ? (unsigned)((use >> (16 * ch)) & 0xFFFFull) : (unsigned)((use2 >> (16 * (ch - 4))) & 0xFFFFu);
+      int u = __builtin_amdgcn_readfirstlane((int)um);
+      /* two columns per pass, the B row of the one after next on its way while a column's dot product runs (a lone wave: nobody else hides an LDS round trip).  Every term
+       * is taken, zeros included: they are exact, and a branch around them costs an LDS round trip of its own */
+#define HV_LOADY(YV, sl) { const float* Y_ = &Yd[(16 * ch + (sl)) * HV_STRIDE]; _Pragma("unroll") for (int q = 0; q < HV_NQ; q++) YV[q] = *(const float4*)&Y_[4 * q]; }      /* the same address in every lane: broadcast reads */
+#define HV_COLUMN(YV, sl) { \
+        float acc = 0.f, acc2 = 0.f; \
+        _Pragma("unroll") for (int q = 0; q < HV_NQ; q++) { \
+          const float4 y4 = YV[q]; \
+          acc = __fmaf_rn(X[4 * q], y4.x, acc); acc = __fmaf_rn(X[4 * q + 1], y4.y, acc); acc = __fmaf_rn(X[4 * q + 2], y4.z, acc); acc = __fmaf_rn(X[4 * q + 3], y4.w, acc); \
+          if (BIG) { acc2 = __fmaf_rn(X2[4 * q], y4.x, acc2); acc2 = __fmaf_rn(X2[4 * q + 1], y4.y, acc2); acc2 = __fmaf_rn(X2[4 * q + 2], y4.z, acc2); acc2 = __fmaf_rn(X2[4 * q + 3], y4.w, acc2); } \
+        } \
+        const int s_ = 16 * ch + (sl); \
+        Cst[(sl) * 64 + lane] = -(lane == s_ ? acc + cfm : acc);      /* a soft normal row's own column carries its softness */ \
+        if (BIG) { if (lane < HV_A2W) A2[s_ * HV_A2W + lane] = -(HV_L2 + lane == s_ ? acc2 + cfm2 : acc2); } }
+      if (u != 0) {
+        float4 ya[HV_NQ], yb[HV_NQ];
+        int sa = __builtin_ctz((unsigned)u);
         u &= u - 1;
-        const int s = 32 * half + s5;
-        const float* Y = &Yd[s * HV_STRIDE];
-        float4 y[HV_NQ];
-#pragma unroll
-        for (int q = 0; q < HV_NQ; q++) y[q] = *(const float4*)&Y[4 * q];      /* the same address in every lane: broadcast reads */
-        float acc = 0.f;
-        /* a column's source touches the dofs below 12 (the arm), the ones from 12 on, or both (hvfl, filed with the tables): the terms of a part it does not touch are
-         * exact zeros and are left out */
-        const int fls = __builtin_amdgcn_readfirstlane(hvfl0[s * HV_STRIDE]);
-        if (fls & 1) {
-#pragma unroll
-          for (int q = 0; q < 3; q++) {
-            acc = __fmaf_rn(X[4 * q], y[q].x, acc); acc = __fmaf_rn(X[4 * q + 1], y[q].y, acc); acc = __fmaf_rn(X[4 * q + 2], y[q].z, acc); acc = __fmaf_rn(X[4 * q + 3], y[q].w, acc);
-          }
+        HV_LOADY(ya, sa)
+#pragma unroll 1
+        while (true) {
+          const bool more_b = u != 0;
+          const int sb = more_b ? __builtin_ctz((unsigned)u) : sa;
+          u &= u - 1;
+          HV_LOADY(yb, sb)                                 /* (no column left: the same row once more, unused) */
+          HV_COLUMN(ya, sa)
+          if (!more_b) break;
+          const bool more_a = u != 0;
+          sa = more_a ? __builtin_ctz((unsigned)u) : sb;
+          u &= u - 1;
+          HV_LOADY(ya, sa)
+          HV_COLUMN(yb, sb)
+          if (!more_a) break;
         }
-        if (fls & 2) {
-#pragma unroll
-          for (int q = 3; q < HV_NQ; q++) {
-            acc = __fmaf_rn(X[4 * q], y[q].x, acc); acc = __fmaf_rn(X[4 * q + 1], y[q].y, acc); acc = __fmaf_rn(X[4 * q + 2], y[q].z, acc); acc = __fmaf_rn(X[4 * q + 3], y[q].w, acc);
-          }
-        }
-        Cst[s5 * 64 + lane] = -(lane == s ? acc + cfm : acc);      /* a soft normal row's own column carries its softness */
       }
+#undef HV_LOADY
+#undef HV_COLUMN
       WSYNC();
-      const unsigned uh = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(use >> (32 * half)));
 #pragma unroll
-      for (int j = 0; j < 32; j++) {
-        const float v = ((uh >> j) & 1u) ? Cst[j * 64 + lane] : 0.f;      /* (wave-uniform select: unused labels read nothing that was written) */
-        AC[2 * half + (j >> 4)][j & 15] = v;
+      for (int j = 0; j < 16; j++) {
+        const float v = Cst[j * 64 + lane];                 /* (no select: sixteen conditional loads are sixteen jumps into cold code) */
+        if (ch < 4) AC[ch < 4 ? ch : 0][j] = v;
+        else if (ch == 4) AC2a[j] = v;
+        else if (j < 8) AC2b[j] = v;
       }
     }
   }
+  /* (the first register's entry of the column of second-register row j: contact 14 + (j & 7), normal / friction rows j >> 3) */
+#define HV_AC2(j) ((j) < 16 ? AC2a[(j) & 15] : AC2b[((j) - 16) & 7])
+  HV_CLK2(3)
   if (!st_lds) { stl[lane] = st_v0; stl[lane + 64] = st_v1; }
   __builtin_amdgcn_s_waitcnt(0x0F70);    /* vmcnt(0): every plane value has landed before the sweep loop */
   WSYNC();
-  /* counting sort by load class for the next substep's pairing (solve2_body explains it): the key of the two-env path */
+  /* counting sort by load class for the next substep's pairing (solve4_body explains it): coupled envs first */
   int sort_pos = 0, sort_bin = 0;
   if (lane == 0 && !(debug_flags & RP_DBG_NOSORT)) {
     const int my_nS = max(nA, nB);
@@ -4711,9 +4454,13 @@ __device__ __forceinline__ void heavy_solve(const DevModel* __restrict__ m, floa
   }
   HV_CLK(1)
   /* ---- the sweeps */
-  float rr = rhs0;
+  float rr = rhs0, rr2 = rhs2;
   const float offL = rhsL - rhs0, offU = rhsU - rhs0;
   P0.lam = 0.f; PL.lam = 0.f; PU.lam = 0.f;
+  const float* a2p = A2 + (lane < HV_A2W ? lane : 0);      /* this lane's entries of the second register's columns: a2p[s * HV_A2W] */
+  /* BIG: a first-register row's step goes into the second register too; the column entry is fetched before the row's chain starts */
+#define HV_B1(lab, sexpr) { if (BIG) { const float a2_ = a2p[(lab) * HV_A2W]; const int s_ = (sexpr); rr2 = __fmaf_rn(a2_, __int_as_float(s_), rr2); } else { (void)(sexpr); } }
+#define HV_B2(labA, labB, sexpr) { if (BIG) { const float a2a_ = a2p[(labA) * HV_A2W], a2b_ = a2p[(labB) * HV_A2W]; const HvS2 s_ = (sexpr); rr2 = __fmaf_rn(a2a_, __int_as_float(s_.a), rr2); rr2 = __fmaf_rn(a2b_, __int_as_float(s_.b), rr2); } else { (void)(sexpr); } }
 #pragma unroll 1
   for (int it = 0; it < K_NITER; it++) {
     int nc_it = uni(nc), nt_it = uni(nt), nj_it = uni(nj), mL_it = uni(maskL), mU_it = uni(maskU), gr_it = uni(gear), n_it = uni(n);
@@ -4721,11 +4468,12 @@ __device__ __forceinline__ void heavy_solve(const DevModel* __restrict__ m, floa
     P0.loP = P0.lo - P0.lam; P0.hiP = P0.hi - P0.lam; P0.dacc = 0.f;
     PL.loP = PL.lo - PL.lam; PL.hiP = PL.hi - PL.lam; PL.dacc = 0.f;
     PU.loP = PU.lo - PU.lam; PU.hiP = PU.hi - PU.lam; PU.dacc = 0.f;
-#define HV_M2(i, j) hv_row2<(i), (j)>(rr, P0.dacc, P0.loP, P0.hiP, AC[0][i], AC[0][j]);
-#define HV_M1(i) hv_row1<(i)>(rr, P0.dacc, P0.loP, P0.hiP, AC[0][i]);
-#define HV_LO(i) hv_rowL<(i)>(rr, PL.dacc, offL, PL.loP, PL.hiP, AC[0][i]);
-#define HV_L(i) hv_rowLU<(i)>(rr, PL.dacc, offL, PL.loP, PL.hiP, PU.dacc, offU, PU.loP, PU.hiP, AC[0][i]);
-#define HV_LR(i) hv_rowLU<(i)>(rr, PU.dacc, offU, PU.loP, PU.hiP, PL.dacc, offL, PL.loP, PL.hiP, AC[0][i]);
+    if (BIG) { P2.loP = P2.lo - P2.lam; P2.hiP = P2.hi - P2.lam; P2.dacc = 0.f; }
+#define HV_M2(i, j) HV_B2(i, j, (hv_row2<(i), (j)>(rr, P0.dacc, P0.loP, P0.hiP, AC[0][i], AC[0][j])))
+#define HV_M1(i) HV_B1(i, (hv_row1<(i)>(rr, P0.dacc, P0.loP, P0.hiP, AC[0][i])))
+#define HV_LO(i) HV_B1(i, (hv_rowL<(i)>(rr, PL.dacc, offL, PL.loP, PL.hiP, AC[0][i])))
+#define HV_L(i) HV_B2(i, i, (hv_rowLU<(i)>(rr, PL.dacc, offL, PL.loP, PL.hiP, PU.dacc, offU, PU.loP, PU.hiP, AC[0][i])))
+#define HV_LR(i) HV_B2(i, i, (hv_rowLU<(i)>(rr, PU.dacc, offU, PU.loP, PU.hiP, PL.dacc, offL, PL.loP, PL.hiP, AC[0][i])))
     /* the non-contact rows in build_small_rows' order - scene-joint motors, limits (dof-major, lower before upper; only while violated), arm motors, gear - forwards in
      * the odd sweeps, backwards in the even ones (the first).  A row that is absent inside a pair or a group (a limit that holds, a motor beyond n_arm) is all zeros:
      * its step is an exact zero */
@@ -4749,12 +4497,18 @@ __device__ __forceinline__ void heavy_solve(const DevModel* __restrict__ m, floa
 #undef HV_LO
 #undef HV_M2
     /* contact normals, in contact order, two at a time (an absent second one: an exact zero step) */
-#define HV_N2(c) if (nc_it <= (c)) goto hv_ndone; hv_row2<HV_L_N + (c), HV_L_N + (c) + 1>(rr, P0.dacc, P0.loP, P0.hiP, AC[1][c], AC[1][(c) + 1]);
+#define HV_N2(c) if (nc_it <= (c)) goto hv_ndone; HV_B2(HV_L_N + (c), HV_L_N + (c) + 1, (hv_row2<HV_L_N + (c), HV_L_N + (c) + 1>(rr, P0.dacc, P0.loP, P0.hiP, AC[1][c], AC[1][(c) + 1])))
     HV_N2(0) HV_N2(2) HV_N2(4) HV_N2(6) HV_N2(8) HV_N2(10) HV_N2(12)
 #undef HV_N2
+    if (BIG) {
+#define HV_NB(j) if (nc_it <= HV_MAXC + (j)) goto hv_ndone; hv_rowB<(j)>(rr, rr2, P2.dacc, P2.loP, P2.hiP, HV_AC2(j), a2p[(HV_L2 + (j)) * HV_A2W]);
+      HV_NB(0) HV_NB(1) HV_NB(2) HV_NB(3) HV_NB(4) HV_NB(5) HV_NB(6)
+#undef HV_NB
+    }
   hv_ndone:
     P0.lam += P0.dacc; P0.dacc = 0.f;
     PL.lam += PL.dacc; PU.lam += PU.dacc;
+    if (BIG) { P2.lam += P2.dacc; P2.dacc = 0.f; }
     if (nc_it > 0) {
       /* bounds of the friction and torsional rows: -+ mu * (normal impulse of their contact) - the normals' DPP row (lanes 16 .. 31) copied into every DPP row, the
        * torsional rows' parents by a lane permute; while that impulse is not positive the row is skipped (step bounds [0, 0], Bullet's `if (totalImpulse > 0)`) */
@@ -4762,32 +4516,52 @@ __device__ __forceinline__ void heavy_solve(const DevModel* __restrict__ m, floa
       const auto s32 = __builtin_amdgcn_permlane32_swap(lu, lu, false, false);        /* [r0 r1 r0 r1] */
       const auto s16 = __builtin_amdgcn_permlane16_swap(s32[0], s32[0], false, false);  /* ..., [r1 r1 r1 r1] */
       float src = __uint_as_float(s16[1]);
-      if (nt_it > 0) { const float lp = __shfl(P0.lam, tsrc); src = kind == 2 ? lp : src; }
+      if (nt_it > 0) {
+        float lp = __shfl(P0.lam, tsrc & 63);
+        if (BIG) { const float lp2 = __shfl(P2.lam, tsrc & 63); lp = tsrc >= 64 ? lp2 : lp; }
+        src = kind == 2 ? lp : src;
+      }
       const float lim = mu * src;
       const bool on = src > 0.f;
       if (kind != 0) { P0.loP = on ? (0.f - lim) - P0.lam : 0.f; P0.hiP = on ? (0.f + lim) - P0.lam : 0.f; }
-      if (nt_it > 0) {
-        hv_row1<30>(rr, P0.dacc, P0.loP, P0.hiP, AC[1][14]);
-        if (nt_it > 1) hv_row1<31>(rr, P0.dacc, P0.loP, P0.hiP, AC[1][15]);
-        if (nt_it > 2) hv_row1<46>(rr, P0.dacc, P0.loP, P0.hiP, AC[2][14]);
-        if (nt_it > 3) hv_row1<47>(rr, P0.dacc, P0.loP, P0.hiP, AC[2][15]);
+      if (BIG) {
+        const float src2 = __shfl(P2.lam, lane & 7);
+        const float lim2 = mu2 * src2;
+        const bool on2 = src2 > 0.f;
+        if (kind2 != 0) { P2.loP = on2 ? (0.f - lim2) - P2.lam : 0.f; P2.hiP = on2 ? (0.f + lim2) - P2.lam : 0.f; }
       }
-#define HV_F(c) if (nc_it <= (c)) goto hv_fdone; hv_row2<HV_L_F0 + (c), HV_L_F1 + (c)>(rr, P0.dacc, P0.loP, P0.hiP, AC[2][c], AC[3][c]);
+      if (nt_it > 0) {
+        HV_B1(30, (hv_row1<30>(rr, P0.dacc, P0.loP, P0.hiP, AC[1][14])))
+        if (nt_it > 1) HV_B1(31, (hv_row1<31>(rr, P0.dacc, P0.loP, P0.hiP, AC[1][15])))
+        if (nt_it > 2) HV_B1(46, (hv_row1<46>(rr, P0.dacc, P0.loP, P0.hiP, AC[2][14])))
+        if (nt_it > 3) HV_B1(47, (hv_row1<47>(rr, P0.dacc, P0.loP, P0.hiP, AC[2][15])))
+      }
+#define HV_F(c) if (nc_it <= (c)) goto hv_fdone; HV_B2(HV_L_F0 + (c), HV_L_F1 + (c), (hv_row2<HV_L_F0 + (c), HV_L_F1 + (c)>(rr, P0.dacc, P0.loP, P0.hiP, AC[2][c], AC[3][c])))
       HV_F(0) HV_F(1) HV_F(2) HV_F(3) HV_F(4) HV_F(5) HV_F(6) HV_F(7) HV_F(8) HV_F(9) HV_F(10) HV_F(11) HV_F(12) HV_F(13)
 #undef HV_F
+      if (BIG) {
+#define HV_FB(j) if (nc_it <= HV_MAXC + (j)) goto hv_fdone; hv_rowB<8 + (j)>(rr, rr2, P2.dacc, P2.loP, P2.hiP, HV_AC2(8 + (j)), a2p[(HV_L2 + 8 + (j)) * HV_A2W]); \
+                                                            hv_rowB<16 + (j)>(rr, rr2, P2.dacc, P2.loP, P2.hiP, HV_AC2(16 + (j)), a2p[(HV_L2 + 16 + (j)) * HV_A2W]);
+        HV_FB(0) HV_FB(1) HV_FB(2) HV_FB(3) HV_FB(4) HV_FB(5) HV_FB(6)
+#undef HV_FB
+      }
     hv_fdone:
       P0.lam += P0.dacc;
+      if (BIG) P2.lam += P2.dacc;
     }
 #undef HV_M1
   }
+#undef HV_B1
+#undef HV_B2
+#undef HV_AC2
   HV_CLK(2)
   /* ---- the velocity change: dv = sum of B_r lambda_r over all rows - motors, lower limits, upper limits (dof by dof each), scene-joint motors, gear, then the contact
-   * rows in the workspace's order -, lane l < 32 <-> component lane_dof(l) as on the two-env path */
+   * rows in the workspace's order -, lane l < 32 <-> component lane_dof(l) as on the four-env path */
   const int l = lane & 31;
   const int dd = lane < 32 ? lane_dof(m, l) : -1;
   float dv = 0.f;
   {
-    /* the terms in their order, through LDS (the column staging's place): every lane files the impulses of its rows at their positions, then lane <-> dof sums them */
+    /* the terms in their order, through LDS (where the X table / the second register's columns were): every lane files the impulses of its rows at their positions, then lane <-> dof sums them */
     float* lamseq = Xd; int* offseq = (int*)(Xd + 128);
     const int nlim = (maskL | maskU) != 0 ? 2 * n : 0;
     const int base_j = n + nlim, base_g = base_j + nj, base_r = base_g + (gear != 0 ? 1 : 0), nterm = base_r + nrc;
@@ -4798,9 +4572,10 @@ __device__ __forceinline__ void heavy_solve(const DevModel* __restrict__ m, floa
     }
     if (jl) { lamseq[base_j + kj] = P0.lam; offseq[base_j + kj] = lane * HV_STRIDE; }
     if (gl) { lamseq[base_g] = P0.lam; offseq[base_g] = lane * HV_STRIDE; }
-    if (rl) { lamseq[base_r + gr] = P0.lam; offseq[base_r + gr] = lane * HV_STRIDE; }
+    if (gr >= 0) { lamseq[base_r + gr] = P0.lam; offseq[base_r + gr] = lane * HV_STRIDE; }
+    if (BIG) { if (gr2 >= 0) { lamseq[base_r + gr2] = P2.lam; offseq[base_r + gr2] = (HV_L2 + lane) * HV_STRIDE; } }
     WSYNC();
-    const int ddc = (dd >= 0 && dd < 4 * HV_NQ) ? dd : 0;
+    const int ddc = (dd >= 0 && dd < HV_STRIDE) ? dd : 0;
     const float* Yc = Yd + ddc;
 #pragma unroll 4
     for (int k = 0; k < nterm; k++) dv = __fmaf_rn(Yc[offseq[k]], lamseq[k], dv);
@@ -4854,7 +4629,120 @@ __device__ __forceinline__ void heavy_solve(const DevModel* __restrict__ m, floa
   }
 #endif
 #undef HV_CLK
+#undef HV_CLK2
 }
+
+/* the second-register variant (inlined: as a real call it would make k_solve2's register count the callee's unlimited one - 248, one wave per SIMD - measured) */
+__device__ __forceinline__ void heavy_solve_big(const DevModel* m, float* state, const float* w, int env, int* sort_cnt_next, int* sort_slot, int debug_flags, float* lds, float* st_lds, int sort_salt, int clk_wave, int nc_hint) {
+#ifdef RP_NO_BIG      /* register experiments only */
+  heavy_solve<false>(m, state, w, env, sort_cnt_next, sort_slot, debug_flags, lds, st_lds, sort_salt, clk_wave, nc_hint);
+#else
+  heavy_solve<true>(m, state, w, env, sort_cnt_next, sort_slot, debug_flags, lds, st_lds, sort_salt, clk_wave, nc_hint);
+#endif
+}
+/* ------------------------------------------------------------------ k_solve2 under debug flag 1 (tests): the dv-form envs by the one-kernel path's own sweeps instead of
+ * the four-env path.  solve_rows (k_step's solver: rows streamed from LDS, dot products by wave_sum32) is the bitwise twin of the four-env path's row bodies - this is the
+ * test that holds it inside the split pipeline.  The rows come from the workspace (under the flag k_prep2 also files the typed non-contact row list: W3_SROW) in the order
+ * contact_rows built them: normals, torsional rows, friction pairs. */
+struct __align__(16) SuperLds {
+  float st[RP_REC_FLOATS];
+  alignas(16) float Minv[144];
+  float vstar[32];
+  alignas(16) float srow[MAXSMALL * 8];
+  alignas(16) float rowS[MAXROWC * 4];
+  alignas(16) float rowT[MAXROWC * 4];
+  alignas(16) float J[ROWREG];
+  alignas(16) float B[ROWREG];
+};
+__device__ __forceinline__ void super_solve(const DevModel* __restrict__ m, float* __restrict__ state, const float* __restrict__ w, const int env, int* __restrict__ sort_cnt_next,
+                                            int* __restrict__ sort_slot, const int debug_flags, SuperLds& L, const int sort_salt) {
+  int lane_ = threadIdx.x & 63;
+  asm volatile("" : "+v"(lane_));      /* (as in heavy_solve) */
+  const int lane = lane_;
+  const int n = m->n_arm;
+  const float4 h0 = *(const float4*)&w[W3_HDR], h1 = *(const float4*)&w[W3_HDR + 4];
+  const int nc = uni(__float_as_int(h0.w)), nt = uni(__float_as_int(h1.z)) >> 8;
+  const int nA = uni(__float_as_int(h1.x)), nB = uni(__float_as_int(h1.y)), nC = uni(__float_as_int(h1.w));
+  const int nsmall = uni(__float_as_int(w[W3_SROW]));
+  const int nrc = 3 * nc + nt;
+  {
+    const float* r = state + (size_t)env * RP_REC_FLOATS;
+    L.st[lane] = r[lane]; L.st[lane + 64] = r[lane + 64];
+  }
+  for (int i = lane; i < 144; i += 64) L.Minv[i] = w[W3_MINV + i];
+  if (lane < 32) L.vstar[lane] = w[W3_VSTAR + lane];
+  for (int i = lane; i < 8 * nsmall; i += 64) L.srow[i] = w[W3_SROW + 4 + i];
+  auto global_row = [&](int lr) { return lr < nc ? lr : (lr < nc + nt ? 3 * nc + (lr - nc) : nc + (lr - nc - nt)); };
+  for (int e = lane; e < nrc * ROWW; e += 64) {
+    const int lr = e / ROWW, k = e - lr * ROWW, gr = global_row(lr);
+    L.J[e] = w[W3_J + gr * ROWW + k]; L.B[e] = w[W3_B + gr * ROWW + k];
+  }
+  for (int e = lane; e < nrc * 4; e += 64) {
+    const int lr = e >> 2, k = e & 3, gr = global_row(lr);
+    float v = w[W3_ROWS + gr * 4 + k];
+    if (k == 3 && lr >= nc && lr < nc + nt) v = __int_as_float(__float_as_int(v) & 255);      /* a torsional row's parent contact (packed with its class and rank for the four-env path) */
+    L.rowS[e] = v; L.rowT[e] = w[W3_ROWT + gr * 4 + k];
+  }
+  WSYNC();
+  if ((debug_flags & RP_DBG_MOTOR) && lane < nsmall) {      /* first substep after k_action_prep: the motor rows from the record's fresh targets (build_small_rows' formula) */
+    float* sr = &L.srow[8 * lane];
+    if (__float_as_int(sr[0]) == SR_UNIT) {
+      const int dA = __float_as_int(sr[1]);
+      const float mode = L.st[ST_MMODE + dA], tgt = L.st[ST_MTARGET + dA], mx = L.st[ST_MMAXIMP + dA], qi = L.st[ST_Q + dA];
+      const float des = mode != 0.f ? K_KP * (tgt - qi) / K_DT : 0.f;
+      sr[3] = (des - L.vstar[dA]) * sr[4]; sr[5] = -mx; sr[6] = mx;
+    }
+  }
+  WSYNC();
+  int sort_pos = 0, sort_bin = 0;
+  if (lane == 0 && !(debug_flags & RP_DBG_NOSORT)) {
+    const int my_nS = max(nA, nB);
+    const int key = 8 * (nC < 7 ? nC : 7) + (my_nS < 1 ? 0 : (my_nS > 14 ? 7 : (my_nS - 1) >> 1));
+    sort_bin = key * SORT_REPS + (sort_salt & (SORT_REPS - 1));
+    sort_pos = atomicAdd(&sort_cnt_next[sort_bin], 1);
+  }
+  const float dv = solve_rows<SuperLds>(m, L, lane, nsmall, nc, nt);
+  WSYNC();
+  /* apply and integrate: substep()'s lines */
+  const int dd = lane_dof(m, lane);
+  const float vnew = clampf((dd >= 0 ? L.vstar[dd] : 0.f) + dv, -K_MAXVEL, K_MAXVEL);
+  if (dd >= 0 && dd < n) { L.st[ST_QD + dd] = vnew; L.st[ST_Q + dd] += K_DT * vnew; }
+  else if (dd >= 0 && dd < n + 6 * m->n_free) { const int k = (dd - n) / 6, c = (dd - n) % 6; L.st[ST_FREE + 13 * k + 7 + c] = vnew; }
+  else if (dd >= 0) { const int k = dd - n - 6 * m->n_free; L.st[ST_JQD + k] = vnew; L.st[ST_JQ + k] += K_DT * vnew; }
+  WSYNC();
+  if (lane < m->n_free) {
+    float* f = &L.st[ST_FREE + 13 * lane];
+    V3 v = ld3(f + 7), wv = ld3(f + 10);
+    st3(f, ld3(f) + v * K_DT);
+    float wn = norm(wv);
+    if (wn > 0.7853981633974483f / K_DT) wn = 0.7853981633974483f / K_DT;
+    V3 ax;
+    if (wn < 0.001f) ax = wv * (0.5f * K_DT - K_DT * K_DT * K_DT * 0.020833333333f * wn * wn);
+    else ax = wv * (sinf(0.5f * wn * K_DT) / wn);
+    Q4 dq = {ax.x, ax.y, ax.z, cosf(0.5f * wn * K_DT)};
+    Q4 q0 = {f[3], f[4], f[5], f[6]};
+    Q4 qn = qmul(dq, q0);
+    float nr = 1.f / sqrtf(qn.x * qn.x + qn.y * qn.y + qn.z * qn.z + qn.w * qn.w);
+    f[3] = qn.x * nr; f[4] = qn.y * nr; f[5] = qn.z * nr; f[6] = qn.w * nr;
+  }
+  WSYNC();
+  {
+    float* r = state + (size_t)env * RP_REC_FLOATS;
+    r[lane] = L.st[lane]; r[lane + 64] = L.st[lane + 64];
+  }
+  if (lane == 0 && !(debug_flags & RP_DBG_NOSORT)) {
+    int sp = sort_pos;
+    asm volatile("" : "+v"(sp));
+    sort_slot[env] = (sort_bin << SORT_RANK_BITS) | sp;
+  }
+  WSYNC();
+}
+/* a block's LDS: four state records per wave (the four-env path), or ONE heavy env's tables / one super env's rows (worker blocks; the in-block fallback) */
+union __align__(16) BlockLds {
+  float rec[SOLVE_WAVES][4 * RP_REC_FLOATS];
+  float hv[HV_LDS_FLOATS];
+  SuperLds sup;
+};
 
 /* The one-kernel twins (k_step, k_reset: substep()) on a heavy env: the rows they built in LDS are laid out as a workspace row - what k_prep2 hands to k_solve2 - and
  * heavy_solve runs on it, integrating the record in L.st.  One implementation of the residual form on the device: the twins check the split pipeline's plumbing around
@@ -4862,9 +4750,10 @@ __device__ __forceinline__ void heavy_solve(const DevModel* __restrict__ m, floa
 __device__ bool substep_heavy(const DevModel* m, EnvLds& L, int lane, int nsmall, int ncon, int nt) {
   const int cls = lane < ncon ? L.conk[lane] : 3;
   const int nB = __popcll(__ballot(cls == 0)), nA = __popcll(__ballot(cls == 1)), nC = __popcll(__ballot(cls == 2));
-  if (hv_class(ncon, nA, nB, nC) != 1) return false;
+  const int hcls = hv_class(ncon, nA, nB, nC);
+  if (hcls == 0) return false;
   __shared__ __align__(16) float w3[W3_FLOATS];
-  __shared__ __align__(16) float hv[2 * 64 * HV_STRIDE];
+  __shared__ __align__(16) float hv[HV_LDS_FLOATS];
   nsmall = uni(nsmall);
   float* aout = w3 + W3_A;
   for (int i = lane; i < AOUT_FLOATS; i += 64) aout[i] = 0.f;
@@ -4913,13 +4802,13 @@ __device__ bool substep_heavy(const DevModel* m, EnvLds& L, int lane, int nsmall
     w3[W3_ROWS + gr * 4 + k] = v; w3[W3_ROWT + gr * 4 + k] = L.rowT[e];
   }
   WSYNC();
-  heavy_solve(m, nullptr, w3, 0, nullptr, nullptr, RP_DBG_NOSORT, hv, L.st, 0);
+  if (hcls == 1) heavy_solve<false>(m, nullptr, w3, 0, nullptr, nullptr, RP_DBG_NOSORT, hv, L.st, 0);
+  else heavy_solve_big(m, nullptr, w3, 0, nullptr, nullptr, RP_DBG_NOSORT, hv, L.st, 0, -1, -1);
   return true;
 }
 
 /* The classes of a block's four envs (hv_class), decided from the same headers by both waves alike: masks of the places 4 bq + k whose env the four-env path takes,
- * the heavy path (residual form), solve2_body (more than HV_MAXC contacts: dv form, like the four-env path) */
-static_assert(S4_SLOTS0 == 8 && S4_SLOTS1 == 16, "hv_class");
+ * the heavy path (residual form), the heavy path with its second lane register (more than HV_MAXC contacts) */
 __device__ __forceinline__ void block_classes(const float* __restrict__ ws, int env0, int N, const int* __restrict__ pair_env, const int bq, unsigned& light, unsigned& res, unsigned& super, int& env_g) {
   const int lane = threadIdx.x & 63, g = lane >> 4;
   const int place = bq * 4 + g;
@@ -4948,59 +4837,66 @@ __device__ __forceinline__ void block_classes(const float* __restrict__ ws, int 
 #endif
 /* one block's solve: bq = its number among the blocks of the launch (its four envs: places 4 bq .. 4 bq + 3 of the pairing table), Ls = its LDS */
 __device__ __forceinline__ void solve_block(const DevModel* __restrict__ m, float* __restrict__ state, const float* __restrict__ ws, int env0, int N,
-                                            const int* __restrict__ pair_env, int* __restrict__ sort_cnt_next, int* __restrict__ sort_slot, int debug_flags, Solve2Lds* Ls, const int bq) {
-  static_assert(sizeof(Solve2Lds) >= 4 * RP_REC_FLOATS * sizeof(float), "the four-env path keeps four state records where the two-env path stages its rows");
-  static_assert(sizeof(Solve2Lds) >= HV_LDS_FLOATS * sizeof(float), "the heavy path's tables");
+                                            const int* __restrict__ pair_env, int* __restrict__ sort_cnt_next, int* __restrict__ sort_slot, int debug_flags, BlockLds& Ls, const int bq) {
   unsigned light, res, super; int env_g;
   block_classes(ws, env0, N, pair_env, bq, light, res, super, env_g);
   const int wid = threadIdx.x >> 6;
-  if (debug_flags & RP_DBG_SEQ) { super |= light; light = 0u; }
+  const unsigned big = super;                              /* class 2: the heavy path with its second lane register */
+  super = 0u;
+  if (debug_flags & RP_DBG_SEQ) { super = light; light = 0u; }      /* (tests) the dv-form envs by the other implementation of the dv form: the one-kernel path's solver on the workspace's rows */
   if (light != 0u) {
     S4_CLK(4)
-    if (wid == 0) solve4_body<0>(m, state, ws, env0, N, pair_env, sort_cnt_next, sort_slot, debug_flags, (float*)&Ls[0], bq, light);
-    else solve4_body<1>(m, state, ws, env0, N, pair_env, sort_cnt_next, sort_slot, debug_flags, (float*)&Ls[1], bq, light);
+    if (wid == 0) solve4_body<0>(m, state, ws, env0, N, pair_env, sort_cnt_next, sort_slot, debug_flags, Ls.rec[0], bq, light);
+    else solve4_body<1>(m, state, ws, env0, N, pair_env, sort_cnt_next, sort_slot, debug_flags, Ls.rec[1], bq, light);
     S4_CLK(5)
   }
-  if (super != 0u) {
-    if (light != 0u) WSYNC();
-    solve2_body(m, state, ws, env0, N, pair_env, sort_cnt_next, sort_slot, debug_flags, Ls, bq, super);
-  }
-  if (res != 0u && !(debug_flags & RP_DBG_WORKERS)) {      /* (k_chain, the settle substeps of rp_reset: no worker blocks) this block's heavy envs, one per wave at a time */
-    int k = 0;
+  if (debug_flags & RP_DBG_WORKERS) return;                /* the launch's worker blocks take the other envs (k_solve2) */
+  /* (k_chain, the settle substeps of rp_reset: no worker blocks) this block's other envs, one after the other, by its first wave */
+  const unsigned rest = res | big | super;
+  if (rest == 0u) return;                                  /* (block-uniform) */
+  __syncthreads();                                         /* the state records of both waves' four-env pass are done with */
+  if (wid == 0) {
 #pragma unroll 1
     for (int g = 0; g < 4; g++) {
-      if (!((res >> g) & 1u)) continue;
-      if ((k & 1) == wid) {
-        WSYNC();
-        const int env = __builtin_amdgcn_readlane(env_g, 16 * g);
-        heavy_solve(m, state, ws + (size_t)env * W3_FLOATS, env, sort_cnt_next, sort_slot, debug_flags, (float*)&Ls[wid], nullptr, 4 * bq + g);
-      }
-      k++;
+      if (!((rest >> g) & 1u)) continue;
+      const int env = __builtin_amdgcn_readlane(env_g, 16 * g);
+      if ((res >> g) & 1u) heavy_solve<false>(m, state, ws + (size_t)env * W3_FLOATS, env, sort_cnt_next, sort_slot, debug_flags, Ls.hv, nullptr, 4 * bq + g);
+      else if ((big >> g) & 1u) heavy_solve_big(m, state, ws + (size_t)env * W3_FLOATS, env, sort_cnt_next, sort_slot, debug_flags, Ls.hv, nullptr, 4 * bq + g, -1, -1);
+      else super_solve(m, state, ws + (size_t)env * W3_FLOATS, env, sort_cnt_next, sort_slot, debug_flags, Ls.sup, 4 * bq + g);
+      WSYNC();
     }
   }
 }
-/* k_solve2's grid: HB worker blocks in front - their waves take the heavy envs of the launch off the list the k_prep2 before it appended them to (hv_list: env | contact
- * count << 24 at places env0 .. of its group, *hv_cnt of them), ONE ENV PER WAVE, wave i the entries i, i + 2 HB, ... - and behind them the blocks of four places each.
- * The heavy waves are the launch's long poles: they start first, and nobody waits in line behind a partner. */
-__global__ void __launch_bounds__(64 * SOLVE_WAVES, 2) k_solve2(SOLVE2_ARGS, const int* __restrict__ hv_cnt, const int* __restrict__ hv_list, int HB) {
-  __shared__ Solve2Lds Ls[SOLVE_WAVES];
+/* k_solve2's grid: HB worker blocks in front - each takes heavy envs of the launch off the list the k_prep2 before it appended them to (hv_list: env | contact count << 24 at
+ * places env0 .. of its group, *hv_cnt of them; under debug flag 1 every env is on it), ONE ENV PER BLOCK at a time (its first wave; the block's LDS is one env's tables),
+ * block i the entries i, i + HB, ... - and behind them the blocks of four places each.  The heavy envs are the launch's long poles: they start first, and nobody waits
+ * in line behind a partner. */
+__global__ void __launch_bounds__(64 * SOLVE_WAVES, RP_SOLVE_WAVES_PER_EU) k_solve2(SOLVE2_ARGS, const int* __restrict__ hv_cnt, const int* __restrict__ hv_list, int HB) {
+  __shared__ BlockLds Ls;
   if ((int)blockIdx.x < HB) {
-    const int wid = threadIdx.x >> 6;
+    if ((threadIdx.x >> 6) != 0) return;
     const int nH = __builtin_amdgcn_readfirstlane(*hv_cnt);
 #if defined(RP_CLOCKS) && RP_CLOCKS == 1
-    if ((threadIdx.x & 63) == 0) { const int wb_ = blockIdx.x * SOLVE_WAVES + wid; for (int q = 0; q < 8; q++) g_clk[8 * wb_ + q] = 0ull; g_clk[8 * wb_ + 6] = (1ull << 28) | (unsigned long long)nH; }      /* bit 28: a worker wave (without bit 29: it found no env) */
+    if ((threadIdx.x & 63) == 0) { const int wb_ = blockIdx.x * SOLVE_WAVES; for (int q = 0; q < 8; q++) g_clk[8 * wb_ + q] = 0ull; g_clk[8 * wb_ + 6] = (1ull << 28) | (unsigned long long)nH; }      /* bit 28: a worker wave (without bit 29: it found no env) */
 #endif
 #pragma unroll 1
-    for (int i = blockIdx.x * SOLVE_WAVES + wid; i < nH; i += HB * SOLVE_WAVES) {
-      const int env = __builtin_amdgcn_readfirstlane(pair_env_id(hv_list[env0 + i]));
-      heavy_solve(m, state, ws + (size_t)env * W3_FLOATS, env, sort_cnt_next, sort_slot, debug_flags, (float*)&Ls[wid], nullptr, i, blockIdx.x * SOLVE_WAVES + wid);
+    for (int i = blockIdx.x; i < nH; i += HB) {
+      const int pe = __builtin_amdgcn_readfirstlane(hv_list[env0 + i]);
+      const int env = __builtin_amdgcn_readfirstlane(pair_env_id(pe)), pnc = pe >> 24;
+      const float* w = ws + (size_t)env * W3_FLOATS;
+      const float4 h1 = *(const float4*)&w[W3_HDR + 4];
+      const int cls = hv_class(pnc, uni(__float_as_int(h1.x)), uni(__float_as_int(h1.y)), uni(__float_as_int(h1.w)));
+      if (cls == 1) heavy_solve<false>(m, state, w, env, sort_cnt_next, sort_slot, debug_flags, Ls.hv, nullptr, i, blockIdx.x * SOLVE_WAVES, pnc);
+      else if (cls == 2) heavy_solve_big(m, state, w, env, sort_cnt_next, sort_slot, debug_flags, Ls.hv, nullptr, i, blockIdx.x * SOLVE_WAVES, pnc);
+      else super_solve(m, state, w, env, sort_cnt_next, sort_slot, debug_flags, Ls.sup, i);      /* (debug flag 1: a dv-form env) */
+      WSYNC();
     }
     return;
   }
   solve_block(m, state, ws, env0, N, pair_env, sort_cnt_next, sort_slot, debug_flags, Ls, blockIdx.x - HB);
 }
-__global__ void __launch_bounds__(64 * SOLVE_WAVES, 2) k_settle_solve(SOLVE2_ARGS) {
-  __shared__ Solve2Lds Ls[SOLVE_WAVES];
+__global__ void __launch_bounds__(64 * SOLVE_WAVES, RP_SOLVE_WAVES_PER_EU) k_settle_solve(SOLVE2_ARGS) {
+  __shared__ BlockLds Ls;
   solve_block(m, state, ws, env0, N, pair_env, sort_cnt_next, sort_slot, debug_flags, Ls, blockIdx.x);
 }
 
@@ -5011,7 +4907,7 @@ __global__ void __launch_bounds__(64 * SOLVE_WAVES, 2) k_settle_solve(SOLVE2_ARG
  * the identity on the ranking.  No launch boundary between substeps, so no launch-wide barrier: a block's heavy substeps add to its own chain and to nobody else's.
  * What it costs: one register / LDS footprint for both phases - the solve's (217 VGPRs, 40 KB: two waves per SIMD) - where k_prep2 runs at four waves per SIMD.
  * Same row bodies on the same rows in the same order: the same bits as the split pipeline (tests). */
-struct __align__(16) ChainLds { union { PrepLds P; Solve2Lds S[SOLVE_WAVES]; }; };
+struct __align__(16) ChainLds { union { PrepLds P; BlockLds S; }; };
 #ifdef RP_CHAIN_CLOCKS
 __device__ long long g_chain_clk[4 * 4096];
 #endif
@@ -5022,11 +4918,11 @@ template <class T> __device__ __forceinline__ T* uniform_ptr(T* p) {
   const unsigned long long v = (unsigned long long)p;
   return (T*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v));
 }
-__device__ __attribute__((noinline)) void chain_prep(PrepLds* L, const DevModel* m, const float* state, float* ws, int env, int* pair_tab, int place) {
-  prep2_core(*uniform_ptr(L), uniform_ptr(m), uniform_ptr(state), uniform_ptr(ws), uni(env), uni(env), uniform_ptr(pair_tab), uni(place));
+__device__ __attribute__((noinline)) void chain_prep(PrepLds* L, const DevModel* m, const float* state, float* ws, int env, int* pair_tab, int place, int prep_flags) {
+  prep2_core(*uniform_ptr(L), uniform_ptr(m), uniform_ptr(state), uniform_ptr(ws), uni(env), uni(env), uniform_ptr(pair_tab), uni(place), nullptr, nullptr, uni(prep_flags));
 }
-__device__ __attribute__((noinline)) void chain_solve(const DevModel* m, float* state, const float* ws, int N, const int* pair_tab, int* sort_cnt_next, int* sort_slot, int flags, Solve2Lds* Ls, int q) {
-  solve_block(uniform_ptr(m), uniform_ptr(state), uniform_ptr(ws), 0, uni(N), uniform_ptr(pair_tab), uniform_ptr(sort_cnt_next), uniform_ptr(sort_slot), uni(flags), uniform_ptr(Ls), uni(q));
+__device__ __attribute__((noinline)) void chain_solve(const DevModel* m, float* state, const float* ws, int N, const int* pair_tab, int* sort_cnt_next, int* sort_slot, int flags, BlockLds* Ls, int q) {
+  solve_block(uniform_ptr(m), uniform_ptr(state), uniform_ptr(ws), 0, uni(N), uniform_ptr(pair_tab), uniform_ptr(sort_cnt_next), uniform_ptr(sort_slot), uni(flags), *uniform_ptr(Ls), uni(q));
 }
 __global__ void __launch_bounds__(64 * SOLVE_WAVES, 2) k_chain(const DevModel* __restrict__ m, float* state, float* ws, int N, const int* __restrict__ member,
                                                               int* pair_tab, int* __restrict__ sort_cnt_next, int* __restrict__ sort_slot, int nsub, int debug_flags) {
@@ -5047,12 +4943,12 @@ __global__ void __launch_bounds__(64 * SOLVE_WAVES, 2) k_chain(const DevModel* _
         const int place = 4 * q + k;
         if (place < N) {                                           /* (block-uniform) */
           const int env = member ? member[place] : place;
-          chain_prep(&L.P, m, state, ws, env, pair_tab, place);
+          chain_prep(&L.P, m, state, ws, env, pair_tab, place, debug_flags & 1);
         }
         __syncthreads();                                           /* the next env's preparation (or the solve) takes the LDS over; this env's rows and its table entry are visible to the block */
       }
       CHCLK(0, 1) CHCLK(1, -1)
-      chain_solve(m, state, ws, N, pair_tab, sort_cnt_next, sort_slot, flags, L.S, q);
+      chain_solve(m, state, ws, N, pair_tab, sort_cnt_next, sort_slot, flags, &L.S, q);
       __syncthreads();                                             /* the records are written: the next substep's preparation may read them */
       CHCLK(1, 1)
     }

@@ -32,7 +32,7 @@ struct rp_sim {
   int* sort_slot;          /* [N] per env: (bin << 16) | rank inside the bin, from the latest k_solve2 */
   int* pair_env;           /* [N] per group range: env ids sorted by load class, heaviest first (k_solve2 pairs neighbours) */
   int* hv_list;            /* [N] per group range: the heavy envs of the current substep (k_prep2 appends, k_solve2's worker blocks take them: one env per wave) */
-  int hv_waves;            /* worker waves per group (0: an eighth of the group's envs, 16 .. 512; RP_HV_WAVES overrides) */
+  int hv_waves;            /* worker blocks per group (0: an eighth of the group's envs, 16 .. 512; RP_HV_WAVES overrides) */
   int* hv_cnt;             /* [2][RP_MAX_GROUPS] their number, double-buffered by substep parity (zeroed by k_member and by the k_prep2 before) */
   GroupBounds gb;          /* place ranges of the groups the tables were built for */
   int gsplit[RP_MAX_GROUPS]; /* RP_GROUP_SPLIT: relative sizes of the groups, heaviest first (0 = equal) */
@@ -360,7 +360,7 @@ static int reset_split(rp_handle h, const uint8_t* mask, const rp_out* out, hipS
     hipLaunchKernelGGL(k_sort_init, dim3((max(M, SORT_BINS) + 255) / 256), dim3(256), 0, s, cnt[0], h->rs_sort_slot, 0, M);
     int par = 0;
     for (int i = 0; i < K_NSETTLE; i++) {
-      hipLaunchKernelGGL(k_settle_prep, dim3(M), dim3(PREP_THREADS), 0, s, h->dev_model, h->rs_state, h->ws, 0, M, cnt[par], cnt[par ^ 1], h->rs_sort_slot, h->rs_pair, (const int*)nullptr, (const int*)h->rs_idx);
+      hipLaunchKernelGGL(k_settle_prep, dim3(M), dim3(PREP_THREADS), 0, s, h->dev_model, h->rs_state, h->ws, 0, M, cnt[par], cnt[par ^ 1], h->rs_sort_slot, h->rs_pair, (const int*)nullptr, (const int*)h->rs_idx, h->debug_flags & 1);
       hipLaunchKernelGGL(k_settle_solve, dim3((M + 2 * SOLVE_WAVES - 1) / (2 * SOLVE_WAVES)), dim3(64 * SOLVE_WAVES), 0, s, h->dev_model, h->rs_state, h->ws, 0, M, h->rs_pair, cnt[par ^ 1], h->rs_sort_slot, h->debug_flags);
       par ^= 1;
     }
@@ -513,7 +513,7 @@ int rp_step(rp_handle h, const float* action, const rp_out* out, void* stream) {
       /* the heavy envs of a substep (1 - 2 % of the envs: a grasp, a push, a crowded drawer) are listed by its k_prep2 and solved one per wave by worker blocks at the head
        * of k_solve2's grid: an eighth of the group's envs' worth of waves (a longer list is walked in strides) */
       c.hvc[0] = h->hv_cnt + g; c.hvc[1] = h->hv_cnt + RP_MAX_GROUPS + g;
-      { const int wv = h->hv_waves > 0 ? h->hv_waves : min(max(c.ng / 8, 16), 512); c.hb = (wv + SOLVE_WAVES - 1) / SOLVE_WAVES; }
+      c.hb = (h->debug_flags & 1) ? c.ng : (h->hv_waves > 0 ? h->hv_waves : max((c.ng + 1) / 2, 16));      /* worker blocks: one heavy env each at a time (debug flag 1: every env is on the list) */
       if (c.gs != s) hipStreamWaitEvent(c.gs, h->gfork, 0);
       if (ev) hipEventRecord(ev[0], c.gs);
       if (h->sort_G == 0) hipLaunchKernelGGL(k_sort_init, dim3((max(c.ng, SORT_BINS) + 255) / 256), dim3(256), 0, c.gs, c.gcnt[par0], h->sort_slot, c.e0, c.ng);
@@ -532,13 +532,13 @@ int rp_step(rp_handle h, const float* action, const rp_out* out, void* stream) {
           fprintf(stderr, "[rp sync] before k_action_prep: %d\n", (int)hipDeviceSynchronize()); fflush(stderr);
 #endif
           hipLaunchKernelGGL(k_action_prep, dim3((c.ng + 7) / 8 + c.ng), dim3(PREP_THREADS), 0, gs, h->dev_model, h->state, h->ws, c.e0, c.e1, c.gcnt[par], c.gcnt[par ^ 1], h->sort_slot,
-                             h->pair_env, member, action, op.target_poses, (c.ng + 7) / 8, c.hvc[sub & 1], c.hvc[(sub & 1) ^ 1], h->hv_list);
+                             h->pair_env, member, action, op.target_poses, (c.ng + 7) / 8, c.hvc[sub & 1], c.hvc[(sub & 1) ^ 1], h->hv_list, h->debug_flags & 1);
 #ifdef RP_SYNC_DEBUG
           fprintf(stderr, "[rp sync] after k_action_prep: %d\n", (int)hipDeviceSynchronize()); fflush(stderr);
 #endif
         } else
           TIMED(hipLaunchKernelGGL(k_prep2, dim3(c.ng), dim3(PREP_THREADS), 0, gs, h->dev_model, h->state, h->ws, c.e0, c.e1, c.gcnt[par], c.gcnt[par ^ 1], h->sort_slot, h->pair_env, member,
-                                   c.hvc[sub & 1], c.hvc[(sub & 1) ^ 1], h->hv_list));
+                                   c.hvc[sub & 1], c.hvc[(sub & 1) ^ 1], h->hv_list, h->debug_flags & 1));
       }
       for (int g = 0; g < G; g++) {
         const GroupCtx& c = gc[g];

@@ -61,6 +61,9 @@ if (heavy & live).any():
     nu, nc, nt = h[:, 6] & 255, (h[:, 6] >> 8) & 255, (h[:, 6] >> 16) & 255
     rows = nu + 3 * nc + nt
     print('heavy waves: build cycles p50 %d p90 %d max %d | sweeps p50 %d p90 %d max %d | tail p50 %d max %d' % (pct(build) + pct(sweep) + pct(tail, (50, 100))))
+    idx = np.nonzero(heavy & live)[0]
+    sub = a[idx + 1, :4] - a[idx, 0:1]      # the idle second wave's slots: header there, tables scattered, X rows loaded, columns built (cycles since the start)
+    print('heavy waves: cycles since start p50: header there %d, tables scattered %d, X rows loaded %d, columns built %d, sweeps start %d' % (tuple(np.median(sub, 0)) + (np.median(build),)))
     print('heavy waves: row steps per sweep p50 %d max %d; contacts p50 %d max %d; cycles per row step p50 %.1f p10 %.1f p90 %.1f' % (
         np.median(rows), rows.max(), np.median(nc), nc.max(), *np.percentile(sweep / (50.0 * rows), [50, 10, 90])))
     A = np.stack([np.ones(len(h)), nu.astype(float), nc.astype(float)], 1)
@@ -69,8 +72,8 @@ if (heavy & live).any():
     A = np.stack([np.ones(len(h)), rows.astype(float)], 1)
     coef = np.linalg.lstsq(A, build.astype(float), rcond=None)[0]
     print('heavy build cycles ~ %.0f + %.0f * rows' % tuple(coef))
-f4 = four & live
-if f4.any():
+f4 = four & live & (((fl >> 8) & 255) < 64)
+if f4.any() and False:
     T4, nS4, nl4 = fl[f4] & 1, (fl[f4] >> 8) & 255, (fl[f4] >> 16) & 255
     d4 = us(a[f4, 5] - a[f4, 4])
     for T in (0, 1):
