@@ -44,6 +44,12 @@ def positions(o, s):
     return s[idx]
 
 
+def free_positions(o, s):
+    """poses of the free bodies and scene-joint positions only (the block IS achieved_goal): positions() without the arm's joints, whose gripper part chatters at its limits
+    by construction of Bullet's limit rule (tests/tolerances.py)"""
+    return positions(o, s)[o.n_arm:]
+
+
 def leave_step(trace, bound):
     over = np.nonzero(np.asarray(trace) > bound)[0]
     return int(over[0]) if over.size else len(trace)
@@ -76,15 +82,22 @@ def test_distribution_a_lockstep_with_contact_history(kind, n, steps, scenario):
     obs = env.calc_state()
     acts = actions_a(env, steps, 7)
     ora = [OracleEnv(kind, seed=31, env_index=e, f32=True) for e in range(n)]
+    twin = [OracleEnv(kind, seed=31, env_index=e, f32=True) for e in range(n)]      # the CPU twin (round 6): the same fp32 oracle from the same record with the arm joints ONE ULP off
+    twin5 = [OracleEnv(kind, seed=31, env_index=e, f32=True) for e in range(n)]     # ... and a second one 1e-5 (relative) off: tolerances.Followers' nudge, which stands in for another evaluation order
     if epa:
-        for o in ora:
+        for o in ora + twin + twin5:
             o.lib.rpo_set_rule(o.h, o.lib.rpo_get_rule(o.h) | 131072)
     for e, o in enumerate(ora):
         o.reset()
         o.step(acts[0, e].astype(np.float64))          # (motor modes; every action re-commands every motor, environments.py:1010-1073)
+        for w in (twin[e], twin5[e]):
+            w.reset()
+            w.step(acts[0, e].astype(np.float64))
     nm, na, nt = N_MAIN[kind], ora[0].n_arm, ora[0].n_target
     shape = (steps, n)
     d_arm = np.zeros(shape); d_pos = np.zeros(shape); d_ik = np.zeros(shape); gap = np.full(shape, np.nan)
+    t_pos = np.zeros(shape); t_gap = np.full(shape, np.nan); t_strict = np.zeros(shape, dtype=bool)      # the twin against the oracle: the same one-step measures
+    d_free = np.zeros(shape); t_free = np.zeros(shape); t5_free = np.zeros(shape)      # ... and the free bodies + scene joints alone
     same = np.zeros(shape, dtype=bool); feat = np.zeros(shape, dtype=bool); strict = np.zeros(shape, dtype=bool)
     capped = np.zeros(shape, dtype=bool); skipped = np.zeros(shape, dtype=bool)
     npts = np.zeros(shape, dtype=int); ngjk = np.zeros(shape, dtype=int)
@@ -115,10 +128,28 @@ def test_distribution_a_lockstep_with_contact_history(kind, n, steps, scenario):
             tp = o.perform_action(a)                   # the oracle's own IK from the same state (and every motor re-commanded) ...
             o.goto_joint_poses(tp_dev[e], gripper=float(a[-1]))      # ... then the device's joint targets for the 12 substeps
             o.run_simulation()
-            return tp, o.get_state(), o.get_cache_row()
+            outs = []
+            for w, rel in ((twin[e], 0.0), (twin5[e], 1e-5)):
+                sw = oracle_state_from_record(w, pre[e])
+                q = sw[:w.n_arm].astype(np.float32)
+                sw[:w.n_arm] = (np.nextafter(q, np.float32(np.inf)) if rel == 0.0 else (q * np.float32(1.0 + rel) + np.float32(rel))).astype(np.float64)
+                w.set_state(sw)
+                w.set_cache_row(pre[e, REC:])
+                w.perform_action(a)
+                w.goto_joint_poses(tp_dev[e], gripper=float(a[-1]))
+                w.run_simulation()
+                outs.append(w.get_state())
+            return tp, o.get_state(), o.get_cache_row(), outs[0], twin[e].get_cache_row(), outs[1]
         res = list(pool.map(one, range(n)))
-        for e, (tp, so, ro) in enumerate(res):
+        for e, (tp, so, ro, sw, rw, sw5) in enumerate(res):
             sd = oracle_state_from_record(ora[e], post[e])
+            t5_free[t, e] = float(np.abs(free_positions(ora[e], sw5) - free_positions(ora[e], so)).max()) if len(so) > 2 * na else 0.0
+            t_pos[t, e] = float(np.abs(positions(ora[e], sw) - positions(ora[e], so)).max())
+            t_free[t, e] = float(np.abs(free_positions(ora[e], sw) - free_positions(ora[e], so)).max()) if len(so) > 2 * na else 0.0
+            d_free[t, e] = float(np.abs(free_positions(ora[e], sd) - free_positions(ora[e], so)).max()) if len(so) > 2 * na else 0.0
+            t_strict[t, e] = cache_rows.integers(rw) == cache_rows.integers(ro)
+            if t_strict[t, e]:
+                t_gap[t, e] = cache_rows.float_gap(rw, ro)
             d_ik[t, e] = float(np.abs(tp[:nt] - tp_dev[e, :nt]).max())
             d_arm[t, e] = float((np.abs(sd[:na] - so[:na]) / np.maximum(1.0, np.abs(so[:na])))[:nm].max())
             d_pos[t, e] = float(np.abs(positions(ora[e], sd) - positions(ora[e], so)).max())
@@ -138,8 +169,8 @@ def test_distribution_a_lockstep_with_contact_history(kind, n, steps, scenario):
                     dumped.append(dict(kind=kind, step=t, env=e, pre=pre[e].copy(), action=acts[t, e].copy(), targets=tp_dev[e].copy(), post_device=post[e].copy(), oracle_cache=ro.copy(),
                                        oracle_state=so.copy()))
         if dump_dir:
-            for e, (tp, so, ro) in enumerate(res):
-                if same[t, e] and d_pos[t, e] > 1e-4 and d_arm[t, e] <= 1e-6 and len(moved) < 16 and not skipped[t, e]:
+            for e, (tp, so, ro, sw, rw, sw5) in enumerate(res):
+                if same[t, e] and d_free[t, e] > 1e-4 and d_arm[t, e] <= 1e-6 and len(moved) < 16 and not skipped[t, e]:
                     moved.append(dict(kind=kind, step=t, env=e, pre=pre[e].copy(), action=acts[t, e].copy(), targets=tp_dev[e].copy(), post_device=post[e].copy(), oracle_cache=ro.copy(),
                                       oracle_state=so.copy()))
         pre = post
@@ -159,6 +190,28 @@ def test_distribution_a_lockstep_with_contact_history(kind, n, steps, scenario):
           % (kind, 'distribution A' if scenario == 'A' else 'the grasp-and-lift script', n, steps, tot, npts[ok].mean(), ngjk[ok].mean(), 100.0 * capped[ok].mean(), np.median(d_ik[ok]), np.quantile(d_ik[ok], 0.9), 100.0 * (d_ik[ok] > 1e-3).mean(),
              np.median(d_arm[ok]), np.quantile(d_arm[ok], 0.99), int((d_arm[ok] > 1e-3).sum()), int((d_pos[ok] > 1e-4).sum()), 100.0 * same[ok].mean(), 100.0 * feat[ok].mean(),
              100.0 * strict[ok].mean(), np.nanquantile(gap, 0.99), np.nanmax(gap)))
+    # the free bodies (the block IS achieved_goal) and the cached points, held against the CPU twin: a one-ulp nudge of the arm joints moves the fp32 oracle's own
+    # block / drawer / scene joints by more than 1e-4 in one step in a few per cent of the env-steps of A (a contact made or lost a substep apart: 4 mm per substep of arm travel
+    # at the per-step clip) - the device is held to that rate and that tail, not to a constant
+    f_dev, f_tw = float((d_free[ok] > 1e-4).mean()), float((t_free[ok] > 1e-4).mean())
+    f3_dev, f3_tw = float((d_free[ok] > 1e-3).mean()), float((t_free[ok] > 1e-3).mean())
+    a_dev, a_tw = float((d_pos[ok] > 1e-4).mean()), float((t_pos[ok] > 1e-4).mean())
+    g_dev, g_tw = float(np.nanmax(gap)), float(np.nanmax(t_gap)) if np.isfinite(t_gap).any() else 0.0
+    print('    one step from identical inputs, free bodies + scene joints: device vs oracle beyond 1e-4 in %.2f %%, beyond 1e-3 in %.2f %% (p99 %.1e, max %.1e); the one-ulp CPU twin vs the oracle: %.2f %% / %.2f %% (p99 %.1e, max %.1e); '
+          'all positions, the gripper\'s joints included: %.2f %% / twin %.2f %% beyond 1e-4; body-frame points where the cache integers agree: device max %.1e, twin max %.1e (twin: same integers in %.2f %%)'
+          % (100 * f_dev, 100 * f3_dev, float(np.quantile(d_free[ok], 0.99)), float(d_free[ok].max()), 100 * f_tw, 100 * f3_tw, float(np.quantile(t_free[ok], 0.99)), float(t_free[ok].max()),
+             100 * a_dev, 100 * a_tw, g_dev, g_tw, 100.0 * t_strict[ok].mean()))
+    # What "positions beyond 1e-4" (round 5's printed count: 5.6 % of the env-steps of U / A) is made of: almost all of it the GRIPPER'S joints, which chatter at their limits by
+    # construction of Bullet's limit rule (tests/tolerances.py) - the one-ulp CPU twin shows the same rate (6.9 %).  The free bodies and scene joints - the block IS achieved_goal -
+    # are held here against the twin's rate and tail, not against a constant; tools/lockstep_moved.py replays the dumped cases beside eight nudged CPU runs.
+    f5_tw, f53_tw = float((t5_free[ok] > 1e-4).mean()), float((t5_free[ok] > 1e-3).mean())
+    print('    the 1e-5 CPU twin vs the oracle, free bodies + scene joints: beyond 1e-4 in %.2f %%, beyond 1e-3 in %.2f %% (max %.1e)' % (100 * f5_tw, 100 * f53_tw, float(t5_free[ok].max())))
+    # measured (round 6): U / A 0.00 % (max 7.6e-5; both twins 0.00 %) - with and without the polytope; P / A 0.00 %; V / A 0.25 % (one-ulp twin 0.19 %); the grasp script 1.7 % beyond 1e-4 and
+    # 1.4 % beyond 1e-3 (19 of 1 320 env-steps: the block between the soft pads) against 0.5 % / 0.2 % of the one-ulp twin
+    assert f_dev <= 3.0 * max(f_tw, f5_tw) + 0.005, (f_dev, f_tw, f5_tw)
+    assert f3_dev <= 3.0 * max(f3_tw, f53_tw) + 0.005, (f3_dev, f3_tw, f53_tw)
+    assert a_dev <= 2.0 * a_tw + 0.01, (a_dev, a_tw)
+    assert g_dev <= max(3.0 * g_tw, 1e-3), (g_dev, g_tw)
     assert tot >= 0.98 * n * steps
     assert npts[ok].mean() >= 4 and (kind == 'P' or ngjk[ok].mean() >= 0.5), 'the rollout no longer carries contact history'
     if scenario == 'grasp':

@@ -171,8 +171,9 @@ def test_panda_pick_grasp_and_lift():
     of every env against the fp32 oracle inside the running fp32 / fp64 sensitivity envelope.  The lift itself is chaotic (DESIGN.md
     section 2: the fp32 and the fp64 oracle part ways by centimetres too, and which envs end with the block in the air differs between any two
     runs), so it is judged by its outcome: the device holds the block in the air in as many of the envs as the eight CPU followers
-    (tolerances.Followers: fp64, fp32, six nudged fp32 runs) do, give or take two - the followers share the oracle's evaluation order and agree with one another
-    more than with any other order (round 5: all of them 3 - 4 of 6, the device 6 of 6).  The lift's physics is held to the oracle step by step in
+    (tolerances.Followers: fp64, fp32, six nudged fp32 runs) do, give or take ONE (round 5's final build and round 6: the followers 3 - 4 of 6, the device 4 of 6; the
+    "device 6 of 6" that once widened this bound to two was measured before the oracle and the device shared one fma convention).  The lift RATE on 64 envs is the next test's;
+    the lift's physics is held to the oracle step by step in
     tests/test_gpu_dist_a.py::test_distribution_a_lockstep_with_contact_history[P-12-110-grasp]: from the same state, cache and joint targets every step of it agrees."""
     from oracle import OracleEnv
     from roboticsplayroompybullet_amd import VecPlayEnv
@@ -224,8 +225,50 @@ def test_panda_pick_grasp_and_lift():
     assert folded > 0, 'the scenario must exercise arm-against-block rows'
     assert kicked.sum() <= n // 3, kicked
     assert lifted.max() >= 1, zs
-    assert lifted.min() - 2 <= n_dev <= lifted.max() + 2, (z_dev, zs)
+    assert lifted.min() - 1 <= n_dev <= lifted.max() + 1, (z_dev, zs)
     print('panda pick scenario: worst arm error / tolerance before the lift = %.2f, lifted %d of %d (the eight CPU followers: %s)' % (worst, n_dev, n, lifted))
+
+
+def test_panda_pick_lift_rate_64_envs():
+    """The grasp-and-lift script of the test above on 64 envs: the lift is a chaotic outcome per env, its RATE is not.  Device against the fp32 and the fp64 CPU oracle from
+    their own resets (same seeds), every env driven by its own observation as a learner would: the fraction of envs that hold the block above 5 cm at the end, printed for all
+    three and the device held between the CPU runs' rates widened by 0.15 (64 draws: a standard deviation of 0.06 at a rate of one half)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import OracleEnv
+    from roboticsplayroompybullet_amd import VecPlayEnv
+    n, seed, steps = 64, 5, 110
+
+    def script(blk, t):
+        a = np.zeros(7)
+        a[0:3] = blk
+        a[2] = blk[2] if t < 60 else 0.15
+        a[6] = -1.0 if t < 30 else 1.0
+        return a
+
+    env = VecPlayEnv('pandaPick-v0', n, seed=seed)
+    obs = env.reset()
+    for t in range(steps):
+        blk = obs['achieved_goal'][:, :3].cpu().numpy()
+        a = np.stack([script(blk[e], t) for e in range(n)])
+        obs, r, _, info = env.step(torch.tensor(a, dtype=torch.float32))
+    assert int((info['status'] & 1).sum()) == 0
+    z_dev = obs['achieved_goal'][:, 2].cpu().numpy()
+
+    def cpu(args):
+        e, f32 = args
+        o = OracleEnv('P', seed=seed, env_index=e, f32=f32)
+        ob = o.reset()
+        for t in range(steps):
+            ob = o.step(script(ob['achieved_goal'][:3], t))[0]
+        return ob['achieved_goal'][2]
+    with ThreadPoolExecutor(16) as pool:
+        z32 = np.array(list(pool.map(cpu, [(e, True) for e in range(n)])))
+        z64 = np.array(list(pool.map(cpu, [(e, False) for e in range(n)])))
+    rd, r32, r64 = float((z_dev > 0.05).mean()), float((z32 > 0.05).mean()), float((z64 > 0.05).mean())
+    print('pandaPick grasp-and-lift, 64 envs: block in the air at the end: device %.2f, fp32 CPU oracle %.2f, fp64 CPU oracle %.2f; the same outcome as the fp32 oracle in %d of 64 envs (fp64 vs fp32: %d)'
+          % (rd, r32, r64, int(((z_dev > 0.05) == (z32 > 0.05)).sum()), int(((z64 > 0.05) == (z32 > 0.05)).sum())))
+    assert min(r32, r64) > 0.1, 'the script no longer lifts anything'
+    assert min(r32, r64) - 0.15 <= rd <= max(r32, r64) + 0.15, (rd, r32, r64)
 
 
 def test_fixture_values_through_calc_state_and_reward(golden):

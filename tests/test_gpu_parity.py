@@ -132,8 +132,10 @@ def test_rollout_200_steps_vs_fp64_oracle(kind):
     assert bad.size <= (2 if kind == 'U' else 1) and (d_hip[bad] <= 2e-2).all(), (bad, d_hip[bad])      # measured (round 4): U one env (a marginal IK stop), the others none
     assert (g_hip <= GRIP_JOINT_TOL).all(), g_hip
     # measured (round 4): U 60 of 64 (the fp32 CPU oracles, the worst of their runs per env: 51), R / P / Q / V 8 of 8.  Held against the CPU runs' own count (a
-    # compiler bump that moves one marginal env moves both sides) and, more loosely than before, against the measured one
+    # compiler bump that moves one marginal env moves both sides) and against the measured one less one
+    # round 6: 57 of 64 (the fp32 CPU runs: 51) - the heavy envs' sweeps are in residual form now, one more rounding of the same fifty sweeps in 1.5 % of the env-substeps; round 5's build: 60
     assert strict.sum() >= int((d_o32 <= 1e-3).sum()) and strict.sum() >= (56 if kind == 'U' else n - 1), (strict.sum(), int((d_o32 <= 1e-3).sum()))
+    print('    within 1e-3 of the fp64 oracle after %d steps: device %d of %d, the fp32 CPU runs (worst per env) %d' % (steps, int(strict.sum()), n, int((d_o32 <= 1e-3).sum())))
     # status bit 8 (the IK ran out of its 4 x 20 / 200 iterations in that step; the joint targets then hang on the measured joints): how common it is, and
     # whether the envs that leave 1e-3 are the ones where it happens most - reported, not asserted: with a new random target every step it happens in
     # every env sooner or later, so it cannot single envs out
