@@ -27,6 +27,8 @@ int rp_debug_substep(rp_handle h, int32_t env, float* host_buf);
 /* per env of the most recent k_prep2: host_buf[2 e] = unit rows, host_buf[2 e + 1] = contacts + 1000 * (arm contact) + 100000 *
  * spanning contacts; synchronises the device */
 int rp_debug_row_counts(rp_handle h, int32_t* host_buf);
+/* the joints [num_envs][8] of the ghost arm(s) drawn by the latest rp_render_ex with a ghost_arm (environments.py:575-590: rest pose, one IK call, joints [0:6]) */
+int rp_debug_ghost_joints(rp_handle h, float* host_buf, int32_t num_envs);
 /* rounds the most recent rp_reset took */
 int rp_debug_reset_rounds(rp_handle h);
 /* PROFILING BUILDS ONLY (tools/build_profiling_libs.sh: -DRP_CLOCKS=1|2, -DRP_PROLOGUE_CLOCKS, -DRP_CHAIN_CLOCKS).  The shipped library exports none of these and

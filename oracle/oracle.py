@@ -125,6 +125,8 @@ def load(f32=False, bullet_ref=False, abx=False):
     lib.rpo_last_num_rows.argtypes = [vp]
     lib.rpo_contact_substeps.argtypes = [vp]
     lib.rpo_residual_substeps.argtypes = [vp]
+    lib.rpo_rest_pose.argtypes = [vp, dp]
+    lib.rpo_set_proprioception_boxes.argtypes = [C.c_int]
     lib.rpo_arm_table.argtypes = [vp, dp]
     lib.rpo_collider_dynamics.argtypes = [vp, dp]
     lib.rpo_set_arm_q.argtypes = [vp, dp]
@@ -334,6 +336,11 @@ class OracleEnv:
         self.lib.rpo_goto_joint_poses(self.h, _d(poses)[1], int(gripper is not None), float(gripper or 0.0),
                                       tp.ctypes.data_as(C.POINTER(C.c_double)))
         return tp[:self.n_target].copy()
+
+    def rest_pose(self):
+        out = np.zeros(self.n_arm)
+        self.lib.rpo_rest_pose(self.h, out.ctypes.data_as(C.POINTER(C.c_double)))
+        return out
 
     def ik(self, pos, quat, q_seed, max_iter=20):
         out = np.zeros(self.n_arm)

@@ -106,15 +106,14 @@ int rpo_last_num_rows(const rpo_env*);
 int rpo_arm_table(const rpo_env* e, double* out);                      /* [n_arm][6]: jtype, lower, upper, body mass, Bullet joint index, parent dof */
 int rpo_collider_dynamics(const rpo_env* e, double* out);              /* [n_col][6]: body, friction, body mass, contact stiffness, damping, breaking threshold */
 void rpo_set_arm_q(rpo_env* e, const double* q);                      /* arm joints to q, at rest */
+int rpo_rest_pose(const rpo_env* e, double* out);                     /* the arm's rest joints (environments.py:361, 371), n_arm values; returns how many the reference resets (6 UR5, 8 Panda) */
+void rpo_set_proprioception_boxes(int on);                            /* test hook, process-wide: gripper_proprioception's ray against the links' boxes (rounds 1 - 5) instead of their hulls */
 int rpo_residual_substeps(const rpo_env* e);                          /* substeps since creation solved in the residual form (rule bit 262144) */
 int rpo_contact_substeps(const rpo_env* e);                           /* substeps since creation whose solve had a contact row */
 int rpo_box_box(const double* ca, const double* Ra, const double* ha, const double* cb, const double* Rb, const double* hb,
                 double margin, double* out /* per point: p3 n3 dist */);
 double rpo_rng_uniform(unsigned long long seed, unsigned env_index, unsigned counter);
 
-#ifdef __cplusplus
-}
-#endif
 int rpo_hull_vertices_world(rpo_env* e, int c, double* out, int max);      /* world-frame hull vertices of an arm collider (0: none) */
 int rpo_collider_poses(rpo_env* e, double* out12_per_collider);      /* world R (row-major) and p of every collider, returns the count */
 int rpo_collider_table(const rpo_env* e, double* out9_per_collider); /* type, he3, rgb3, toggle, link */
@@ -122,5 +121,9 @@ int rpo_collider_table(const rpo_env* e, double* out9_per_collider); /* type, he
 /* bench.py's cpu_baseline: n_envs envs over n_threads threads (static partition), n_steps steps each of actions [n_envs][n_steps][action_dim];
  * returns wall seconds of the stepping phase (resets excluded).  margin < 0 keeps the default. */
 double rpo_bench_rollout(int kind, unsigned long long seed, int n_envs, int n_steps, int action_dim, const double* actions, int n_threads, double margin);
+
+#ifdef __cplusplus
+}
+#endif
 
 #endif

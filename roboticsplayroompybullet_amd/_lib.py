@@ -75,7 +75,7 @@ EXPORTS = ['rp_create', 'rp_destroy', 'rp_get_dims', 'rp_reset', 'rp_reset_to', 
            'rp_compute_reward', 'rp_compute_reward_sparse', 'rp_state_bytes', 'rp_get_state', 'rp_set_state', 'rp_get_timers', 'rp_enable_timers',
            'rp_last_error', 'rp_version', 'rp_default_camera', 'rp_camera_from_yaw_pitch_roll', 'rp_render', 'rp_render_ex', 'rp_ray_test']
 # include/rp_playroom_debug.h: test / tuning hooks
-DEBUG_EXPORTS = ['rp_set_fused', 'rp_set_groups', 'rp_set_debug_flags', 'rp_debug_substep', 'rp_debug_row_counts', 'rp_debug_reset_rounds']
+DEBUG_EXPORTS = ['rp_set_fused', 'rp_set_groups', 'rp_set_debug_flags', 'rp_debug_substep', 'rp_debug_row_counts', 'rp_debug_reset_rounds', 'rp_debug_ghost_joints']
 
 _lib = None
 _libs = {}
@@ -127,6 +127,7 @@ def load(wide=False):
     lib.rp_set_fused.argtypes = [vp, C.c_int32]
     lib.rp_set_groups.argtypes = [vp, C.c_int32]
     lib.rp_set_debug_flags.argtypes = [vp, C.c_int32]
+    lib.rp_debug_ghost_joints.argtypes = [vp, C.c_void_p, C.c_int32]
     lib.rp_debug_row_counts.argtypes = [vp, C.POINTER(C.c_int32)]
     lib.rp_debug_reset_rounds.argtypes = [vp]
     _libs[path] = lib

@@ -2839,14 +2839,16 @@ __device__ void calc_state(const DevModel* m, LDS& L, int lane) {
     V3 ee = site_pos_world(m, L, RP_SITE_EE), wr = site_pos_world(m, L, RP_SITE_WRIST);
     V3 p1 = ee - (ee - wr) * 0.5f, p2 = (g1 + g2) * 0.5f + (ee - wr) * 0.2f, d = p2 - p1;
     float t = 2.f; int link = -1;
+    bool hull_cand = false;      /* an arm link whose box the segment meets: its HULL is the collider (round 6; rounds 1 - 5: the box) - clipped against its face planes below */
     if (lane < m->n_col) {
       Xf x = collider_xf(m, L, lane);
       V3 he = ld3(m->col_he[lane]);
       if (m->col_type[lane] == 0) {
+        const bool is_hull = m->hpl != nullptr && m->hpl_cnt[lane] > 0;
         V3 ol = tmulv(x.R, p1 - x.p), dl = tmulv(x.R, d);
         float o3[3] = {ol.x, ol.y, ol.z}, d3[3] = {dl.x, dl.y, dl.z}, h3[3] = {he.x, he.y, he.z};
         bool inside = fabsf(o3[0]) <= h3[0] && fabsf(o3[1]) <= h3[1] && fabsf(o3[2]) <= h3[2];
-        bool hit = !inside;
+        bool hit = !inside || is_hull;      /* (the box around a hull is a cull only: a start inside it says nothing about the hull) */
         float tmin = 0.f, tmax = 1.f;
         for (int k = 0; k < 3 && hit; k++) {
           if (fabsf(d3[k]) < 1e-12f) { if (fabsf(o3[k]) > h3[k]) hit = false; continue; }
@@ -2855,7 +2857,8 @@ __device__ void calc_state(const DevModel* m, LDS& L, int lane) {
           tmin = fmaxf(tmin, t1); tmax = fminf(tmax, t2);
           if (tmin > tmax) hit = false;
         }
-        if (hit) { t = tmin; link = m->col_link[lane]; }
+        if (is_hull) hull_cand = hit;
+        else if (hit) { t = tmin; link = m->col_link[lane]; }
       } else {
         V3 oc = p1 - x.p;
         float a = dot(d, d), b = 2.f * dot(oc, d), cc = dot(oc, oc) - he.x * he.x;
@@ -2864,6 +2867,30 @@ __device__ void calc_state(const DevModel* m, LDS& L, int lane) {
           float tt = (-b - sqrtf(disc)) / (2.f * a);
           if (tt >= 0.f && tt <= 1.f) { t = tt; link = m->col_link[lane]; }
         }
+      }
+    }
+    /* the hull candidates, one after the other, by the whole wave: lane k clips against planes k, k + 64, ... (the oracle's ray_hull: enter = the latest plane crossed inwards at
+     * a positive parameter, exit = the earliest crossed outwards, a ray outside a plane it runs parallel to misses) */
+    {
+      unsigned long long cand = __ballot(hull_cand);
+      while (cand != 0ull) {
+        const int c = __builtin_ctzll(cand);
+        cand &= cand - 1ull;
+        const Xf x = collider_xf(m, L, c);
+        const V3 ol = tmulv(x.R, p1 - x.p), dl = tmulv(x.R, d);
+        const float4* pl = (const float4*)m->hpl + m->hpl_off[c];
+        const int npl = m->hpl_cnt[c];
+        float t_in = 0.f, t_lim = 1.f; bool miss = false;
+        for (int k = lane; k < npl; k += 64) {
+          const float4 p = pl[k];
+          const float den = p.x * dl.x + p.y * dl.y + p.z * dl.z, num = -(p.x * ol.x + p.y * ol.y + p.z * ol.z + p.w);
+          if (fabsf(den) < 1e-12f) { if (num < 0.f) miss = true; continue; }
+          const float tt = num / den;
+          if (den < 0.f) t_in = fmaxf(t_in, tt); else t_lim = fminf(t_lim, tt);
+        }
+        for (int off = 32; off > 0; off >>= 1) { t_in = fmaxf(t_in, __shfl_xor(t_in, off)); t_lim = fminf(t_lim, __shfl_xor(t_lim, off)); }
+        const bool hit = __ballot(miss) == 0ull && t_in > 0.f && t_in <= t_lim;
+        if (hit && lane == c) { t = t_in; link = m->col_link[c]; }
       }
     }
     /* min over lanes, lowest collider index wins ties (the oracle scans colliders in order with <) */

@@ -53,7 +53,7 @@ struct rp_sim {
    * their env ids, per-env progress {pending, attempt, depth}, pairing tables of the scratch range */
   float* rs_state; int* rs_idx; int4* rs_meta; int* rs_count; int* rs_sort_cnt; int* rs_sort_slot; int* rs_pair; int* rs_count_host;
   int reset_rounds;        /* rounds the latest rp_reset took (rp_debug) */
-  float* rc_tab; int* rc_cnt; float* rc_ee; int rc_cap;      /* rp_render / rp_ray_test: collider poses of rc_cap envs (allocated on first use) */
+  float* rc_tab; int* rc_cnt; float* rc_ee; int rc_cap; int rc_last_num;      /* rp_render / rp_ray_test: collider poses of rc_cap envs (allocated on first use) */
   rp_timers timers;
   char err[256];
 };
@@ -214,16 +214,24 @@ int rp_create(const rp_config* cfg, rp_handle* out) {
       /* the candidate tables: the baked lists hold vertex numbers; the kernels read (x, y, z, number) in one 16-byte load */
       const unsigned short* cidx; const int *coff, *cfirst; int ctotal = 0;
       const int ncoff = rp_hcell_tables(d->kind, &cidx, &coff, &cfirst, &ctotal);
+      for (int c = 0; c < RP_MAX_COL; c++) d->hcell_first[c] = -1;
+      if (ncoff <= 0) {      /*  hulls without candidate tables - a new kind, a bake that went wrong: the narrowphase would read through a null table */
+        for (int c = 0; c < RP_MAX_COL; c++)
+          if (d->hull_cnt[c] > 0) { snprintf(g_err, 256, "rp_create: collider %d collides as a hull of %d vertices but the model has no support-vertex candidate tables (rp_hullcells_gen.h)", c, d->hull_cnt[c]); e = hipErrorInvalidValue; goto fail; }
+      }
       if (ncoff > 0) {
         std::vector<float> cv((size_t)ctotal * 4, 0.f);
         std::vector<char> done((size_t)ncoff, 0);
         for (int c = 0; c < RP_MAX_COL; c++) {
           d->hcell_first[c] = hcnt[c] > 0 ? cfirst[c] : -1;
-          if (hcnt[c] <= 0 || cfirst[c] < 0 || done[cfirst[c]]) continue;
+          if (d->hull_cnt[c] > 0 && cfirst[c] < 0) { snprintf(g_err, 256, "rp_create: collider %d collides as a hull but has no candidate table", c); e = hipErrorInvalidValue; goto fail; }
+          if (hcnt[c] <= 0 || cfirst[c] < 0) continue;
+          const bool first_user = !done[cfirst[c]];
           done[cfirst[c]] = 1;
           for (int k = coff[cfirst[c]]; k < coff[cfirst[c] + RP_HCELL_N]; k++) {
             const int vi = cidx[k];
-            if (vi >= hcnt[c]) { snprintf(g_err, 256, "rp_create: the candidate table refers to vertex %d of a %d-vertex hull", vi, hcnt[c]); e = hipErrorInvalidValue; goto fail; }
+            if (vi >= hcnt[c]) {      /* (checked for EVERY collider that shares the table, not only the first) */ snprintf(g_err, 256, "rp_create: the candidate table refers to vertex %d of a %d-vertex hull", vi, hcnt[c]); e = hipErrorInvalidValue; goto fail; }
+            if (!first_user) continue;
             const float* v = hv[hoff[c] + vi];
             cv[4 * (size_t)k] = v[0]; cv[4 * (size_t)k + 1] = v[1]; cv[4 * (size_t)k + 2] = v[2]; memcpy(&cv[4 * (size_t)k + 3], &vi, 4);
           }
@@ -628,7 +636,7 @@ static int rc_reserve(rp_handle h, int num) {
   h->rc_tab = nullptr; h->rc_cnt = nullptr; h->rc_ee = nullptr; h->rc_cap = 0;
   HIPCHK(h, hipMalloc((void**)&h->rc_tab, (size_t)num * RC_MAX * RC_STRIDE * sizeof(float)));
   HIPCHK(h, hipMalloc((void**)&h->rc_cnt, (size_t)num * sizeof(int)));
-  HIPCHK(h, hipMalloc((void**)&h->rc_ee, (size_t)num * 12 * sizeof(float)));
+  HIPCHK(h, hipMalloc((void**)&h->rc_ee, (size_t)num * 20 * sizeof(float)));      /* [num][12] EE poses, then [num][8] the ghost arm's joints of the latest rp_render_ex (rp_debug_ghost_joints) */
   h->rc_cap = num;
   return RP_OK;
 }
@@ -679,6 +687,7 @@ int rp_render_ex(rp_handle h, const rp_camera* cam, int32_t width, int32_t heigh
   int rc = rc_reserve(h, num_envs);
   if (rc != RP_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
+  h->rc_last_num = num_envs;
   hipLaunchKernelGGL(k_collider_poses, dim3(num_envs), dim3(64), 0, s, h->dev_model, h->state, first_env, num_envs, h->rc_tab, h->rc_cnt, sub_goal, h->rc_ee, ghost_arm);
   const int tiles = (width * height + 255) / 256;
   hipLaunchKernelGGL(k_render, dim3((unsigned)num_envs * tiles), dim3(256), 0, s, h->dev_model, h->rc_tab, h->rc_cnt, num_envs, device_camera(cam), h->rc_ee, width, height, rgb);
@@ -758,6 +767,15 @@ int rp_debug_substep(rp_handle h, int32_t env, float* host_buf) {
   hipLaunchKernelGGL(k_debug_substep, dim3(N), dim3(64), 0, 0, h->dev_model, h->state, h->dbg, N, env);
   HIPCHK(h, hipDeviceSynchronize());
   HIPCHK(h, hipMemcpy(host_buf, h->dbg, 4096 * sizeof(float), hipMemcpyDeviceToHost));
+  return RP_OK;
+}
+
+/* test hook: the joints of the ghost arm(s) of the latest rp_render_ex with a ghost_arm, [num_envs of that call][8], into host_buf */
+int rp_debug_ghost_joints(rp_handle h, float* host_buf, int32_t num_envs) {
+  if (!h || !host_buf || num_envs < 1 || num_envs > h->rc_cap || !h->rc_ee) return RP_ERR_ARG;
+  DevGuard guard(h->cfg.device);
+  HIPCHK(h, hipDeviceSynchronize());
+  HIPCHK(h, hipMemcpy(host_buf, h->rc_ee + (size_t)12 * h->rc_last_num, (size_t)num_envs * 8 * sizeof(float), hipMemcpyDeviceToHost));
   return RP_OK;
 }
 

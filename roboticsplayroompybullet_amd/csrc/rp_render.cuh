@@ -54,6 +54,7 @@ __global__ void __launch_bounds__(64) k_collider_poses(const DevModel* __restric
       __syncthreads();
       if (lane == 0) for (int i = 0; i < 6; i++) L.st[ST_Q + i] = sol.q[i];
       __syncthreads();
+      if (ee_pose && lane < 8) ee_pose[12 * (size_t)num + 8 * (size_t)slot + lane] = L.st[ST_Q + lane];      /* (test hook rp_debug_ghost_joints: the ghost's joints behind the EE poses) */
     }
     if (pass == 1 && obj_ghosts) {           /* the sub-goal's poses: objects [pos3 (quat4)] ..., then drawer y, door, button, dial (play ids) */
       __syncthreads();
@@ -132,10 +133,21 @@ __device__ __forceinline__ bool rc_ray_box(const float* rec, V3 o, V3 d, float t
  * planes (collider frame, n . x + w <= 0 inside), after the box around the hull, which most rays miss.  The reference draws the links' visual meshes; rounds 3 and 4 drew the
  * boxes.  A ray that starts inside reports no hit, like the box's. */
 __device__ __forceinline__ bool rc_ray_hull(const float* rec, const float4* __restrict__ pl, int npl, V3 o, V3 d, float tmax, float& t_hit, V3& n_hit) {
-  float tb; V3 nb;
-  if (!rc_ray_box(rec, o, d, tmax, tb, nb)) return false;
   const M3 R = ldm3(rec);
   const V3 ol = tmulv(R, o - ld3(rec + 9)), dl = tmulv(R, d);
+  {      /* the box around the hull as a SLAB-OVERLAP cull only: a ray that starts inside the box but outside the hull (the gripper camera at the EE link, a ray cast from
+          * beside the arm: the links' boxes are much larger than their hulls) still meets the planes below - rc_ray_box's "starts inside = no hit" is about the hull */
+    const float o3[3] = {ol.x, ol.y, ol.z}, d3[3] = {dl.x, dl.y, dl.z}, h3[3] = {rec[12], rec[13], rec[14]};
+    float tmin = 0.f, tm = tmax;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      if (fabsf(d3[k]) < 1e-12f) { if (fabsf(o3[k]) > h3[k]) return false; continue; }
+      float t1 = (-h3[k] - o3[k]) / d3[k], t2 = (h3[k] - o3[k]) / d3[k];
+      if (t1 > t2) { const float w = t1; t1 = t2; t2 = w; }
+      tmin = fmaxf(tmin, t1); tm = fminf(tm, t2);
+      if (tmin > tm) return false;
+    }
+  }
   float t_in = 0.f, t_out = tmax; V3 nl = mk3(0, 0, 0); bool entered = false;
   for (int k = 0; k < npl; k++) {
     const float4 p = pl[k];

@@ -187,7 +187,15 @@ class playEnv:
         'achieved_goal' / 'full_positional_state', and the ghost ARM of 'full_positional_state' / 'controllable_achieved_goal' - for the Panda; like the reference
         (environments.py:629-630) the UR5 raises NotImplementedError.  (The reference's Panda branch refers to an attribute that is never set, `self.ghost_panda`,
         and cannot run as written; what it evidently means is implemented: reset_arm(ghost_arm, sub_goal, from_init=False) - rest pose, one default IK call towards
-        the sub-goal's EE pose, joints [0:6] - environments.py:575-590.)"""
+        the sub-goal's EE pose, joints [0:6] - environments.py:575-590.)
+
+        Deviations from the reference's lines, all on the ghost arm (INTEGRATION.md section 4 lists them too):
+          * UR5 ids with 'full_positional_state' / 'controllable_achieved_goal' raise NotImplementedError as upstream does (rounds 1 - 4 of this library drew the object and
+            fixture ghosts and no arm for them: callers that relied on that get the upstream behaviour now; 'achieved_goal' still draws the objects);
+          * the ghost's orientation is sub_goal[3:7] (the EE quaternion of a use_orientation state); the reference's reset_arm reads o[6:10] when return_velocity is set -
+            no registered Panda id has both flags, so the two agree on every id that can be made;
+          * the ghost's IK starts from the rest pose on EVERY call; the reference passes from_init=False, i.e. the second and later calls start from the previous ghost's
+            joints.  Stateless on purpose: the ghost of a sub-goal does not depend on which ghosts were drawn before it."""
         import torch
         if self._vec is None:
             raise RuntimeError('visualise_sub_goal before the first reset(): the physics client is not active yet')

@@ -143,6 +143,55 @@ def test_rollout_200_steps_vs_fp64_oracle(kind):
           % (100.0 * capped.sum() / (n * steps), int((capped > 0).sum()), n, capped[~strict].mean() if (~strict).any() else 0.0, capped[strict].mean()))
 
 
+def test_proprioception_ray_meets_the_links_hulls_not_their_boxes():
+    """gripper_proprioception (environments.py:720-743: rayTest from the wrist to between the pads, 1 if the first thing hit is not a pad) against what the links COLLIDE as - the
+    convex hulls of their meshes - since round 6, on the device (calc_state: the hull's face planes, whole wave per candidate link) and in the oracle (ray_hull); rounds 1 - 5
+    tested the boxes around them, and rp_ray_test / img had the hulls: the same ray could answer differently.  States with the gripper's joints anywhere in
+    and beyond their ranges and the block near the fingers, searched on the CPU for both kinds: flag by hulls != flag by boxes (the oracle's test hook switches), and equal.  The
+    device gives the hull answer in every one of them."""
+    from oracle import OracleEnv
+    from roboticsplayroompybullet_amd import VecPlayEnv
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    from gpu_debug import record_from_oracle
+    o = OracleEnv('U', seed=3, env_index=0, f32=True)
+    ob = o.reset()
+    st0, na = o.get_state(), o.n_arm
+    ee = np.array(ob['obs_quat'][:3])
+    rng = np.random.default_rng(0)
+    differ, same, flags = [], [], []
+    try:
+        for trial in range(6000):
+            s = st0.copy()
+            s[6:12] = rng.uniform(-0.1, 0.8, 6) * np.array([0.06, 0.06, 1.0, 1.0, 1.0, 1.0])      # the six gripper joints anywhere, beyond their ranges too: inside them the links' boxes
+            #                                                                                              and hulls give the same flag in every pose tried (6 000 of 6 000; rollouts: 720 of 720) - the difference
+            #                                                                                              needs a finger folded across the ray (4 % of these poses)
+            off = rng.uniform(-0.12, 0.12, 3); off[2] = rng.uniform(-0.15, 0.1)
+            s[2 * na:2 * na + 3] = ee + off
+            q = rng.normal(size=4); s[2 * na + 3:2 * na + 7] = q / np.linalg.norm(q)
+            o.set_state(s)
+            h = int(o.calc_state()['gripper_proprioception'])
+            o.lib.rpo_set_proprioception_boxes(1)
+            b = int(o.calc_state()['gripper_proprioception'])
+            o.lib.rpo_set_proprioception_boxes(0)
+            tgt = differ if h != b else same
+            if len(tgt) < 48:
+                tgt.append((record_from_oracle(o), h))
+            if len(differ) >= 48 and len(same) >= 48:
+                break
+    finally:
+        o.lib.rpo_set_proprioception_boxes(0)
+    assert len(differ) >= 16, 'the search no longer finds poses in which box and hull disagree'
+    cases = differ + same
+    env = VecPlayEnv(IDS['U'], len(cases), seed=3)
+    env.reset()
+    env.set_state(torch.tensor(np.stack([c[0] for c in cases])))
+    got = env.calc_state()['gripper_proprioception'].cpu().numpy().astype(int)
+    want = np.array([c[1] for c in cases])
+    assert (got == want).all(), (np.nonzero(got != want)[0], len(differ))
+    print('    proprioception ray: %d poses in which the links\' boxes and hulls answer differently, %d in which they agree: the device gives the hulls\' answer in all' % (len(differ), len(same)))
+
+
 @pytest.mark.parametrize('kind,gjk,epa', [('U', True, None), ('P', True, None), ('U', True, True), ('P', True, False), ('U', False, None), ('P', False, None)])
 def test_hull_gjk_option_vs_fp64_oracle(kind, gjk, epa):
     """The two models of an arm link whose deepest hull vertex lies beside the box face (box edges and corners): GJK's distance phase on hull and box (the default

@@ -228,6 +228,53 @@ def test_arm_links_are_drawn_as_the_hulls_they_collide_as():
     assert hull_hits > 200 and box_only > 30, (hull_hits, box_only)
 
 
+def test_rays_that_start_inside_a_links_box_but_outside_its_hull():
+    """the box around a hull is a cull, not the collider - a ray whose origin lies inside a link's box (much larger than the rounded link) but outside the hull
+    must still hit the hull straight ahead (the gripper camera at the EE link, rays cast from beside the arm).  Origins sampled in the links' boxes, kept where the numpy
+    planes say "outside this hull", aimed through the hull's middle: the device agrees with the numpy polytope cast (same collider, same parameter to 2e-5)."""
+    from oracle import OracleEnv
+    from roboticsplayroompybullet_amd import VecPlayEnv
+    n, k = 2, 256
+    env = VecPlayEnv(U, n, seed=12)
+    env.reset()
+    rng = np.random.default_rng(9)
+    f_all, t_all = np.zeros((n, k, 3)), np.zeros((n, k, 3))
+    keep = []
+    for e in range(n):
+        o = OracleEnv('U', seed=12, env_index=e, f32=True)
+        o.reset()
+        R, p, tab = o.colliders()
+        hulls = oracle_hulls(o)
+        links = sorted(hulls)
+        frm, to = [], []
+        while len(frm) < k:
+            c = links[int(rng.integers(len(links)))]
+            x = p[c] + R[c] @ (tab[c, 1:4] * rng.uniform(-0.98, 0.98, 3))      # inside the link's box
+            nn, w = hulls[c]
+            if (x @ nn.T + w).max() < 2e-3:                                     # ... and inside (or within 2 mm of) its hull: not a case
+                continue
+            ctr = o.hull_vertices(c).mean(axis=0)
+            frm.append(x); to.append(x + (ctr - x) * 3.0)
+        f_all[e], t_all[e] = np.array(frm), np.array(to)
+    out = env.ray_test(torch.tensor(f_all, dtype=torch.float32), torch.tensor(t_all, dtype=torch.float32))
+    torch.cuda.synchronize()
+    hits = 0
+    for e in range(n):
+        o = OracleEnv('U', seed=12, env_index=e, f32=True)
+        o.reset()
+        R, p, tab = o.colliders()
+        hulls = oracle_hulls(o)
+        f32, t32 = np.float32(f_all[e]).astype(np.float64), np.float32(t_all[e]).astype(np.float64)
+        t_h, who_h, _ = cast(R, p, tab, f32, t32 - f32, 1.0, hulls)
+        got_c, got_t = out['collider'][e].cpu().numpy(), out['hit_fraction'][e].cpu().numpy()
+        agree = got_c == who_h
+        assert agree.mean() > 0.97, (agree.mean(), got_c[~agree][:8], who_h[~agree][:8])
+        on_arm = agree & np.isin(who_h, list(hulls))
+        np.testing.assert_allclose(got_t[on_arm], t_h[on_arm], atol=2e-5)
+        hits += int(on_arm.sum())
+    assert hits > 0.8 * n * k, hits      # nearly every such ray hits a hull (before the fix: a miss whenever the origin was inside that link's box)
+
+
 def test_sub_goal_ghosts_and_other_cameras():
     from roboticsplayroompybullet_amd import VecPlayEnv
     env = VecPlayEnv(U, 2, seed=5)
@@ -330,6 +377,21 @@ def test_panda_ghost_arm_of_visualise_sub_goal():
     ghost = env.render('rgb_array', ghost_arm=away).cpu().numpy()
     changed = (plain != ghost).any(axis=3)
     assert 200 < changed[0].sum() < 15000, changed[0].sum()        # a second arm appeared, the picture is otherwise the same
+    # the ghost's joints against the oracle's reset_arm arithmetic (round 6: until now only pixels were counted): the rest pose, ONE inverse-kinematics call of 20 iterations
+    # towards the pose, joints [0:6] taken, the seventh keeps its rest value (environments.py:575-593)
+    import ctypes as C
+    from oracle import OracleEnv
+    gq = (C.c_float * 16)()
+    assert env.lib.rp_debug_ghost_joints(env.h, gq, 2) == 0
+    gq = np.frombuffer(gq, dtype=np.float32).reshape(2, 8)
+    for e in range(2):
+        o = OracleEnv('V', seed=3, env_index=e, f32=True)
+        o.reset()
+        rest = o.rest_pose()
+        a = away[e].cpu().numpy().astype(np.float64)
+        sol = o.ik(a[0:3], a[3:7], rest, max_iter=20)
+        want = np.concatenate([sol[:6], rest[6:7]])
+        np.testing.assert_allclose(gq[e, :7], want, atol=2e-4)
     same = torch.cat([ee, torch.zeros((2, 1), device=ee.device)], 1)
     on_top = (env.render('rgb_array', ghost_arm=same).cpu().numpy() != plain).any(axis=3)
     assert 200 < on_top[0].sum() < 15000 and (on_top[0] != changed[0]).sum() > 500      # (the tinted ghost over the arm itself: other pixels than the ghost 15 cm away)
