@@ -108,13 +108,13 @@ def cpu_baseline(seed, margin=None, env_id=ENV_ID):
 
 
 STEP_KERNELS = ('k_action_prep', 'k_prep2', 'k_solve2', 'k_calc_state')     # what one rp_step launches (default pipeline)
-PMC_SUMMARY = 'r05_pmc_summary.json'
+PMC_SUMMARY = 'r06_pmc_summary.json'      # (the round's profile; pmc_traffic refuses it for another build of the library)
 WARMUP_FLOOR = 200     # untimed steps before the first timed region whatever --warmup says: the rollout has reached its steady contact statistics by then (the first ~100 steps after a reset run ~3 % slower: arms still travelling from the rest pose), and clocks, caches and the load-sorted env pairing have settled
 
 
 def pmc_traffic(kernel=None):
     """HBM-side bytes per launch of `kernel` (None: per env step, all of STEP_KERNELS weighted by their launches per step) from the
-    committed rocprofv3 PMC passes (profiles/r05_pmc_summary.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same bench;
+    committed rocprofv3 PMC passes (profiles/r06_pmc_summary.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same bench;
     KB units; reads doubled per the gfx950 FETCH_SIZE correction in MI355X_MICROARCH.md).  PMC counters cannot be read from
     inside this process, so this is the profile's number, not a live one.  None if the file is absent, was taken with another
     library version, or lacks one of the kernels rp_step launches today (a stale profile is refused, not quoted)."""
