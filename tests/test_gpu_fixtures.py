@@ -128,7 +128,11 @@ def test_dial_turned_by_the_closed_gripper():
     q = env.get_state()[:, JQ + 2].cpu().numpy()
     q32 = np.array([o.get_state()[2 * o.n_arm + 26 + 2] for o in o32])
     assert (np.abs(q) > 0.1).all() and (np.abs(q) < 2.0).all(), q                # turned, not spun
-    np.testing.assert_allclose(q, q32, atol=max(2e-2, 3 * float(np.abs(q32 - np.array([o.get_state()[2 * o.n_arm + 26 + 2] for o in o64])).max())))
+    # where it comes to rest after the branch: TWO rest angles 0.10 rad apart, -1.411 and -1.307, and runs of one arithmetic land on either - measured in round 6: the fp32 oracle
+    # -1.411 / -1.411 / -1.307 and the fp64 oracle -1.411 (x3) with the motor row's number in the arm lanes of the residual form; both oracles -1.307 (x3) with s in
+    # those lanes (the same sweeps to 1e-14 per step until step 73, where ONE step of the spinning dial - 0.4 rad - parts them by 5e-2: tools/residual_check.py's kind of
+    # event); the device -1.411 / -1.307 / -1.410.  Until then this line held the device to the fp32 oracle's angle within 2e-2, which is a statement about that draw.
+    np.testing.assert_allclose(q, q32, atol=max(0.15, 3 * float(np.abs(q32 - np.array([o.get_state()[2 * o.n_arm + 26 + 2] for o in o64])).max())))
     want = (q - 2.0 * np.floor(q / 2.0)) / 2.2                                   # dial_to_0_1_range: (q mod 2) / 2.2 with Python's modulo
     np.testing.assert_allclose(after, want, atol=1e-5)
     print('dial scenario: q = %s, worst error / tolerance = %.2f' % (q, worst))
