@@ -147,7 +147,7 @@ def test_distribution_a_lockstep_with_contact_history(kind, n, steps, scenario):
             t_pos[t, e] = float(np.abs(positions(ora[e], sw) - positions(ora[e], so)).max())
             t_free[t, e] = float(np.abs(free_positions(ora[e], sw) - free_positions(ora[e], so)).max()) if len(so) > 2 * na else 0.0
             d_free[t, e] = float(np.abs(free_positions(ora[e], sd) - free_positions(ora[e], so)).max()) if len(so) > 2 * na else 0.0
-            if dump_dir and d_free[t, e] > 1e-2 and len(moved) < 16:      # (debugging: the big ones, whatever the caches say)
+            if dump_dir and os.environ.get('RP_LOCKSTEP_DUMP_BIG') and d_free[t, e] > 1e-2 and len(moved) < 16:      # (debugging: the big ones, whatever the caches say - round 6's robot-base finding came from these)
                 moved.append(dict(kind=kind, step=t, env=e, pre=pre[e].copy(), action=acts[t, e].copy(), targets=tp_dev[e].copy(), post_device=post[e].copy(), oracle_cache=ro.copy(), oracle_state=so.copy()))
             if os.environ.get('RP_LOCKSTEP_VERBOSE') and d_free[t, e] > 1e-3:
                 print('   [verbose] step %d env %d: free bodies off by %.2e; device block %s oracle block %s' % (t, e, d_free[t, e], np.round(sd[2 * na:2 * na + 13], 3).tolist(), np.round(so[2 * na:2 * na + 13], 3).tolist()))
