@@ -125,6 +125,8 @@ def load(f32=False, bullet_ref=False, abx=False):
     lib.rpo_last_num_rows.argtypes = [vp]
     lib.rpo_contact_substeps.argtypes = [vp]
     lib.rpo_residual_substeps.argtypes = [vp]
+    lib.rpo_ik_iterations.argtypes = [C.c_int]
+    lib.rpo_ik_iterations.restype = C.c_long
     lib.rpo_rest_pose.argtypes = [vp, dp]
     lib.rpo_set_proprioception_boxes.argtypes = [C.c_int]
     lib.rpo_arm_table.argtypes = [vp, dp]

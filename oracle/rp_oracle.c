@@ -2084,11 +2084,14 @@ static void solve_spd(real* A, real* b, int n) {   /* Gaussian elimination with 
 /* calculateInverseKinematics(body, ee, pos, orn) with IK2_VEL_DLS_WITH_ORIENTATION, as recalled in SURVEY.md App. E:
  * iterate { FK; e = [dpos; axis*angle(q_t * q_cur^-1)]; dq = (J^T J + damp I)^-1 J^T e; clamp max|dq| to 45 deg }
  * until |dpos| < 1e-4 or max_iter.  All movable dofs take part; non-ancestor columns are zero. */
+static _Thread_local long g_ik_iters = 0;      /* loop passes of ik_solve in the calling thread (tools/ik_histogram.py: what bounds k_action) */
+long rpo_ik_iterations(int reset) { long v = g_ik_iters; if (reset) g_ik_iters = 0; return v; }
 static void ik_solve(const rpo_env* e, const real* pos, const real* quat, const real* q_seed, int max_iter, real* q) {
   const rp_model* m = &e->m;
   int n = m->n_arm;
   for (int i = 0; i < n; i++) q[i] = q_seed[i];
   for (int it = 0; it < max_iter; it++) {
+    g_ik_iters++;
     xform xb[1 + RP_MAX_ARM];
     ik_arm_fk(e, q, xb);
     real p[3], R[9], qc[4];

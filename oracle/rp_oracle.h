@@ -109,6 +109,7 @@ void rpo_set_arm_q(rpo_env* e, const double* q);                      /* arm joi
 int rpo_rest_pose(const rpo_env* e, double* out);                     /* the arm's rest joints (environments.py:361, 371), n_arm values; returns how many the reference resets (6 UR5, 8 Panda) */
 void rpo_set_proprioception_boxes(int on);                            /* test hook, process-wide: gripper_proprioception's ray against the links' boxes (rounds 1 - 5) instead of their hulls */
 int rpo_residual_substeps(const rpo_env* e);                          /* substeps since creation solved in the residual form (rule bit 262144) */
+long rpo_ik_iterations(int reset);                                    /* loop passes of the IK in the calling thread since the last reset of the counter (a pass that ends at the residual test included) */
 int rpo_contact_substeps(const rpo_env* e);                           /* substeps since creation whose solve had a contact row */
 int rpo_box_box(const double* ca, const double* Ra, const double* ha, const double* cb, const double* Rb, const double* hb,
                 double margin, double* out /* per point: p3 n3 dist */);
