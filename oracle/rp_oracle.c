@@ -160,10 +160,11 @@ static real next_u(ustream* s) {
 /* ------------------------------------------------------------------ body bookkeeping */
 static inline int body_is_arm(const rpo_env* e, int b) { return b >= 1 && b <= e->m.n_arm; }
 /* debugging switches (environment, read once): 0 RPO_NO_SLANE - the residual form with the motor row's number in an arm dof's lane, as until the middle of round 6 (with the
- * HIP library built -DRP_NO_SLANE); 1 RPO_NO_HULLLINK - the robot's static links as boxes against movable boxes, as until then */
+ * HIP library built -DRP_NO_SLANE); 1 RPO_NO_HULLLINK - the robot's static links as boxes against movable boxes, as until then; 2 RPO_FORCE_RESIDUAL - every env in the
+ * residual form (CPU studies of the form on the whole population: tools/slane_check.py; the HIP library has no such switch) */
 static int dbg_switch(int k) {
-  static int v[2] = {-1, -1};
-  if (v[k] < 0) v[k] = getenv(k == 0 ? "RPO_NO_SLANE" : "RPO_NO_HULLLINK") != 0;
+  static int v[3] = {-1, -1, -1};
+  if (v[k] < 0) v[k] = getenv(k == 0 ? "RPO_NO_SLANE" : (k == 1 ? "RPO_NO_HULLLINK" : "RPO_FORCE_RESIDUAL")) != 0;
   return v[k];
 }
 static inline int body_free_index(const rpo_env* e, int b) { int k = b - 1 - e->m.n_arm; return (k >= 0 && k < e->m.n_free) ? k : -1; }
@@ -1642,6 +1643,7 @@ static void solve_one(rpo_env* e, row* r, real lo, real hi, real* dv) {
 #define RES_SLOTS1 8
 static int residual_form(const rpo_env* e) {
   if (!(e->rule & RPO_RULE_RESIDUAL)) return 0;
+  if (dbg_switch(2)) return 1;
   int n0 = 0, n1 = 0, nspan = 0;
   for (int i = 0; i < e->ncon; i++) {
     int half0, half1, arm, movable;
