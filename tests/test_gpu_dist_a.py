@@ -55,7 +55,7 @@ def leave_step(trace, bound):
     return int(over[0]) if over.size else len(trace)
 
 
-@pytest.mark.parametrize('kind,n,steps,scenario', [('U', 64, 200, 'A'), ('P', 16, 100, 'A'), ('V', 16, 100, 'A'), ('P', 12, 110, 'grasp'), ('U', 32, 100, 'A+epa')])
+@pytest.mark.parametrize('kind,n,steps,scenario', [('U', 64, 200, 'A'), ('P', 16, 100, 'A'), ('V', 16, 100, 'A'), ('P', 12, 110, 'grasp'), ('U', 32, 100, 'A+epa'), ('U', 24, 60, 'scatter'), ('V', 24, 60, 'scatter')])
 def test_distribution_a_lockstep_with_contact_history(kind, n, steps, scenario):
     """The device runs `steps` steps of distribution A free.  Before every step each env's fp32 oracle takes the device's record and cache row; after it the two are
     compared, in two parts:
@@ -70,7 +70,9 @@ def test_distribution_a_lockstep_with_contact_history(kind, n, steps, scenario):
     test judges the chaotic lift by its outcome, this one holds every step of it to the oracle.  RP_LOCKSTEP_DUMP=<dir> saves the first cases in which the caches differ although the arm agrees to 1e-6
     (pre-step row, action, the device's targets, both post-step rows) for replay on the CPU (tools/lockstep_replay.py).  scenario 'A+epa': the UR5 id with the expanding polytope
     forced on (hull_epa=True / RP_CFG_HULL_EPA, oracle rule | 131072: the Panda ids have it by default) - arms lying IN the furniture under A are where the polytope runs most
-    (0.11 calls per env-substep), on the UR5's hulls of up to 1 000 vertices."""
+    (0.11 calls per env-substep), on the UR5's hulls of up to 1 000 vertices.  scenario 'scatter' (round 6, after a block thrown at the robot's base showed oracle and device
+    colliding different shapes there): the block dropped from 6 cm onto a random collider of the scene in a random orientation, moderate actions - measured: free bodies beyond
+    1e-4 in 0.00 % of 1 387 (U) / 1 440 (V) env-steps, same manifolds and points in 100 %."""
     from gpu_debug import oracle_state_from_record
     from oracle import OracleEnv
     from roboticsplayroompybullet_amd import VecPlayEnv
@@ -79,8 +81,28 @@ def test_distribution_a_lockstep_with_contact_history(kind, n, steps, scenario):
         scenario = 'A'
     env = VecPlayEnv(IDS[kind], n, seed=31, hull_epa=True if epa else None)
     env.reset()
+    if scenario == 'scatter':
+        # (round 6, after the robot's-base finding) the block dropped from 6 cm onto a random collider of the scene - furniture, drawer, door, button, the robot's base, an arm
+        # link - in a random orientation, then moderate actions (distribution B's box): the places a block does not get to under random actions, held to the oracle step by step
+        probe = OracleEnv(kind, seed=31, env_index=0, f32=True)
+        probe.reset()
+        cols = probe.collider_list()
+        rng = np.random.default_rng(41)
+        st = env.get_state().cpu().numpy()
+        for e in range(n):
+            c = cols[rng.integers(len(cols))]
+            top = c['p'][2] + float(np.abs(c['R'][2]) @ c['he'])
+            q = rng.normal(size=4); q /= np.linalg.norm(q)
+            st[e, 24:27] = [c['p'][0] + rng.uniform(-1, 1) * min(c['he'][0], 0.1), c['p'][1] + rng.uniform(-1, 1) * min(c['he'][1], 0.1), top + 0.06 + 0.043]
+            st[e, 27:31] = q
+            st[e, 31:37] = 0.0
+        st[:, REC:] = 0.0                                # (no contact history for the moved block)
+        env.set_state(torch.tensor(st))
     obs = env.calc_state()
     acts = actions_a(env, steps, 7)
+    if scenario == 'scatter':
+        lo = np.array([-0.18, 0.0, 0.05, -0.5, -0.5, -0.5, -1.0]); hi = np.array([0.18, 0.3, 0.3, 0.5, 0.5, 0.5, 1.0])
+        acts = (lo + (hi - lo) * np.random.default_rng(43).random((steps, n, 7))).astype(np.float32)
     ora = [OracleEnv(kind, seed=31, env_index=e, f32=True) for e in range(n)]
     twin = [OracleEnv(kind, seed=31, env_index=e, f32=True) for e in range(n)]      # the CPU twin (round 6): the same fp32 oracle from the same record with the arm joints ONE ULP off
     twin5 = [OracleEnv(kind, seed=31, env_index=e, f32=True) for e in range(n)]     # ... and a second one 1e-5 (relative) off: tolerances.Followers' nudge, which stands in for another evaluation order
@@ -191,7 +213,7 @@ def test_distribution_a_lockstep_with_contact_history(kind, n, steps, scenario):
           'IK joint targets from the same state: median gap %.1e, p90 %.1e, beyond 1e-3 in %.2f %%; the 12 substeps from the same state + cache + targets, arm joints: median %.1e, p99 %.1e, '
           'beyond 1e-3 in %d env-steps; positions beyond 1e-4 in %d; caches: same manifolds / points / GJK pairs in %.2f %%, same simplex features in %.2f %%, the very same simplices in '
           '%.2f %%; body-frame points where the caches agree: p99 gap %.1e, max %.1e'
-          % (kind, 'distribution A' if scenario == 'A' else 'the grasp-and-lift script', n, steps, tot, npts[ok].mean(), ngjk[ok].mean(), 100.0 * capped[ok].mean(), np.median(d_ik[ok]), np.quantile(d_ik[ok], 0.9), 100.0 * (d_ik[ok] > 1e-3).mean(),
+          % (kind, {'A': 'distribution A', 'grasp': 'the grasp-and-lift script', 'scatter': 'the block dropped onto a random collider, distribution B'}[scenario], n, steps, tot, npts[ok].mean(), ngjk[ok].mean(), 100.0 * capped[ok].mean(), np.median(d_ik[ok]), np.quantile(d_ik[ok], 0.9), 100.0 * (d_ik[ok] > 1e-3).mean(),
              np.median(d_arm[ok]), np.quantile(d_arm[ok], 0.99), int((d_arm[ok] > 1e-3).sum()), int((d_pos[ok] > 1e-4).sum()), 100.0 * same[ok].mean(), 100.0 * feat[ok].mean(),
              100.0 * strict[ok].mean(), np.nanquantile(gap, 0.99), np.nanmax(gap)))
     # the free bodies (the block IS achieved_goal) and the cached points, held against the CPU twin: a one-ulp nudge of the arm joints moves the fp32 oracle's own
@@ -216,8 +238,8 @@ def test_distribution_a_lockstep_with_contact_history(kind, n, steps, scenario):
     assert f3_dev <= 3.0 * max(f3_tw, f53_tw) + 0.005, (f3_dev, f3_tw, f53_tw)
     assert a_dev <= 2.0 * a_tw + 0.01, (a_dev, a_tw)
     assert g_dev <= max(3.0 * g_tw, 1e-3), (g_dev, g_tw)
-    assert tot >= 0.98 * n * steps
-    assert npts[ok].mean() >= 4 and (kind == 'P' or ngjk[ok].mean() >= 0.5), 'the rollout no longer carries contact history'
+    assert tot >= (0.9 if scenario == 'scatter' else 0.98) * n * steps      # (scatter: a block dropped onto the cabinet's edge or the robot's base may roll out of the scene - status bit 2, nothing to compare: 53 of 1 440 env-steps)
+    assert npts[ok].mean() >= 4 and (kind == 'P' or scenario == 'scatter' or ngjk[ok].mean() >= 0.5), 'the rollout no longer carries contact history'      # (scatter: calm arms, the history is the block's manifolds: 11 cached points per env, 0.4 - 1.1 GJK pairs)
     if scenario == 'grasp':
         held = int((obs['achieved_goal'][:, 2] > 0.05).sum())
         print('    the device holds the block in the air in %d of %d envs at the end' % (held, n))
